@@ -1,0 +1,64 @@
+"""Builds the C-ABI HIP library (libgsdeblur_hip.so) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs on the CPU-only build box; the
+resulting .so is git-ignored but travels with the repo snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+LIB_PATH = PKG_DIR / "libgsdeblur_hip.so"
+
+# (source, extra flags).  project.hip must not contract a*b+c into fma: its integer
+# outputs (radii, tile bounds, depth key bits) are compared bit-for-bit with the oracle.
+SOURCES = [
+    ("project.hip", ["-ffp-contract=off"]),
+    ("binning.hip", []),
+    ("raster.hip", []),
+]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fvisibility=hidden"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    headers = sorted(CSRC.glob("*.h"))
+    objs = []
+    hipcc = _hipcc()
+    build_dir = PKG_DIR / "build"
+    build_dir.mkdir(exist_ok=True)
+    for src, extra in SOURCES:
+        s = CSRC / src
+        o = build_dir / (s.stem + ".o")
+        if force or _stale(o, [s, *headers]):
+            cmd = [hipcc, *COMMON, *extra, "-c", str(s), "-o", str(o)]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(LIB_PATH, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB_PATH)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

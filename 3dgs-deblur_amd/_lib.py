@@ -1,0 +1,91 @@
+"""ctypes binding of the C-ABI HIP library (include/gsdeblur.h).
+
+There is no CPU fallback: if the library cannot be loaded every op raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+from ._build import LIB_PATH, build_library
+
+_P, _I, _F, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
+
+# name -> argtypes (restype int unless noted); mirrors include/gsdeblur.h
+_SIGS = {
+    "gs_subpose_viewmats_fwd": [_I, _P, _P, _P, _P, _P, _P],
+    "gs_subpose_viewmats_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gs_project_fwd": [_I, _P, _P, _F, _P, _P, _F, _F, _F, _F, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gs_project_bwd": [_I, _P, _P, _F, _P, _P, _F, _F, _F, _F, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gs_sh_fwd": [_I, _I, _I, _P, _P, _P, _P],
+    "gs_sh_bwd": [_I, _I, _I, _P, _P, _P, _P],
+    "gs_project_fused_fwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I,
+                             _P, _P, _P, _P, _P],
+    "gs_project_fused_bwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I,
+                             _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gs_pack_records": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "gs_unpack_record_grads": [_I, _P, _P, _P, _P, _P, _P],
+    "gs_exclusive_scan_u32": [_L, _P, _P, _P, _P, _L, _P],
+    "gs_radix_sort_pairs_u32": [_L, _P, _P, _P, _P, _I, _I, _I, _P, _L, ctypes.POINTER(_I), _P],
+    "gs_radix_sort_pairs_u64": [_L, _P, _P, _P, _P, _I, _I, _I, _P, _L, ctypes.POINTER(_I), _P],
+    "gs_make_depth_keys64": [_L, _I, _P, _P, _P],
+    "gs_gather_counts": [_L, _P, _P, _P, _P],
+    "gs_emit_intersects": [_L, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P],
+    "gs_tile_bin_edges_u32": [_L, _P, _I, _P, _P],
+    "gs_tile_bin_edges_u64": [_L, _P, _I, _P, _P],
+    "gs_map_gaussian_to_intersects": [_I, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "gs_rasterize_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "gs_rasterize_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "gs_combine_fwd": [_I, _L, _P, _F, _F, _P, _P],
+    "gs_combine_bwd": [_I, _L, _P, _F, _F, _P, _P, _P, _P],
+}
+_SIGS_LL = {
+    "gs_scan_workspace_bytes": [_L],
+    "gs_radix_sort_workspace_bytes": [_L, _I, _I],
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load(build_if_missing: bool = True) -> ctypes.CDLL:
+    """Load libgsdeblur_hip.so (building it in-tree first if absent). Raises loudly on failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(LIB_PATH)
+    if not path.exists():
+        if not build_if_missing:
+            raise HipLibraryError(f"{path} is missing; run __graft_entry__.build()")
+        build_library()
+    try:
+        lib = ctypes.CDLL(str(path))
+    except OSError as e:  # pragma: no cover
+        raise HipLibraryError(f"cannot load HIP library {path}: {e}") from e
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _I
+    for name, args in _SIGS_LL.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _L
+    lib.gs_version.restype = ctypes.c_char_p
+    lib.gs_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def exported_names():
+    return sorted(list(_SIGS) + list(_SIGS_LL) + ["gs_version"])
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        kind = {1: "invalid argument", 3: "workspace too small"}.get(status, None)
+        if kind is None and status >= 1000:
+            kind = f"hipError_t {status - 1000}"
+        raise HipLibraryError(f"{what} failed: {kind or status}")

@@ -1,0 +1,482 @@
+// binning.hip — Gaussian -> tile binning, radix sort and tile bin edges (integer
+// work; results are bit-exact against the oracle).
+//
+// Restates (absent fork sources): gsplat map_gaussian_to_intersects,
+// the torch.sort on int64 isect ids, get_tile_bin_edges and the cumsum in
+// compute_cumulative_intersects (App. A "Keys").
+//
+// MI355X design.  Upstream sorts I (tile<<32 | depth_bits) int64 keys: 6-7 LSD
+// passes over 12-byte pairs.  Here the same total order is produced with far less
+// HBM traffic:
+//   1. sort the P*N (sub-pose, depth_bits) keys          (N-sized, cheap)
+//   2. emit the intersections in that depth order, key = p*T + tile (u32)
+//   3. ONE stable LSD sort over ceil(log2(P*T)) bits of the 8-byte pairs
+//      (2 passes at 1080p up to 10 sub-poses).
+// A stable bucket-by-tile of a depth-ordered stream is exactly the
+// (tile, depth, gaussian-id) order of the 64-bit sort; ties (same tile, same depth
+// bits) resolve to ascending Gaussian id on both routes, the deterministic
+// tiebreak SURVEY §7 asks for.  The 64-bit route is kept (gs_map_gaussian_to_intersects
+// + gs_radix_sort_pairs_u64) for API parity and as the cross-check in tests.
+//
+// The radix sort is a 3-kernel LSD pass (histogram / scan / scatter) with
+// wave64 match-any ranking (ballot per digit bit), one contiguous key run per wave
+// so stability needs no block-wide exchange.
+#include "gs_common.h"
+
+namespace gs {
+
+// ---------------------------------------------------------------------------
+// exclusive scan (u32)
+// ---------------------------------------------------------------------------
+constexpr int kScanItems = 8;                 // per thread
+constexpr int kScanBlock = 256 * kScanItems;  // per block
+
+// exclusive prefix of v over the 256 threads of the block; total returned to all.
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned& total, unsigned* lds /*[8]*/) {
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  unsigned inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  unsigned w0 = lds[0], w1 = lds[1], w2 = lds[2], w3 = lds[3];
+  unsigned woff = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+  total = w0 + w1 + w2 + w3;
+  __syncthreads();
+  return woff + inc - v;
+}
+
+__global__ __launch_bounds__(256) void scan_reduce_kernel(size_t n, const unsigned* __restrict__ in,
+                                                          unsigned* __restrict__ bsum) {
+  __shared__ unsigned lds[8];
+  size_t base = (size_t)blockIdx.x * kScanBlock;
+  unsigned s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    size_t i = base + (size_t)k * 256 + threadIdx.x;
+    s += i < n ? in[i] : 0u;
+  }
+  unsigned total;
+  block_excl_scan(s, total, lds);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of the block sums in place; writes the grand total
+__global__ __launch_bounds__(256) void scan_bsums_kernel(unsigned nb, unsigned* __restrict__ bsum,
+                                                         unsigned* __restrict__ total_out) {
+  __shared__ unsigned lds[8];
+  unsigned carry = 0;
+  for (unsigned base = 0; base < nb; base += 256) {
+    unsigned i = base + threadIdx.x;
+    unsigned v = i < nb ? bsum[i] : 0u;
+    unsigned total;
+    unsigned ex = block_excl_scan(v, total, lds);
+    if (i < nb) bsum[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(size_t n, const unsigned* __restrict__ in,
+                                                         const unsigned* __restrict__ bsum,
+                                                         unsigned* __restrict__ out) {
+  __shared__ unsigned lds[8];
+  // blocked arrangement: thread t owns items [t*8, t*8+8) of the block
+  size_t base = (size_t)blockIdx.x * kScanBlock + (size_t)threadIdx.x * kScanItems;
+  unsigned v[kScanItems];
+  unsigned s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    size_t i = base + k;
+    v[k] = i < n ? in[i] : 0u;
+    s += v[k];
+  }
+  unsigned total;
+  unsigned ex = block_excl_scan(s, total, lds) + bsum[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    size_t i = base + k;
+    if (i < n) out[i] = ex;
+    ex += v[k];
+  }
+}
+
+static inline size_t scan_ws_bytes(size_t n) {
+  size_t nb = (n + kScanBlock - 1) / kScanBlock;
+  return (nb + 1) * sizeof(unsigned);
+}
+
+static int run_scan(size_t n, const unsigned* in, unsigned* out, unsigned* total_out, void* ws, hipStream_t st) {
+  size_t nb = (n + kScanBlock - 1) / kScanBlock;
+  unsigned* bsum = reinterpret_cast<unsigned*>(ws);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum);
+  hipLaunchKernelGGL(scan_bsums_kernel, dim3(1), dim3(256), 0, st, (unsigned)nb, bsum, total_out);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, out);
+  return gs_launch_status();
+}
+
+// ---------------------------------------------------------------------------
+// radix sort (LSD, stable), KeyT in {u32,u64}, 32-bit payload
+// ---------------------------------------------------------------------------
+constexpr int kSortRounds = 16;                   // keys per thread
+constexpr int kSortBlock = 256 * kSortRounds;     // keys per block (4 waves x 16 x 64)
+
+template <typename KeyT, int BITS>
+__global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* __restrict__ keys, int shift,
+                                                         unsigned mask, unsigned nblk,
+                                                         unsigned* __restrict__ ghist) {
+  constexpr int NB = 1 << BITS;
+  __shared__ unsigned hist[NB];
+  for (int d = threadIdx.x; d < NB; d += 256) hist[d] = 0;
+  __syncthreads();
+  size_t base = (size_t)blockIdx.x * kSortBlock;
+#pragma unroll 4
+  for (int r = 0; r < kSortRounds; ++r) {
+    size_t i = base + (size_t)r * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&hist[(unsigned)(keys[i] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < NB; d += 256) ghist[(size_t)d * nblk + blockIdx.x] = hist[d];
+}
+
+template <typename KeyT, int BITS>
+__global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT* __restrict__ keys_in,
+                                                            const unsigned* __restrict__ vals_in,  // null => iota
+                                                            KeyT* __restrict__ keys_out,
+                                                            unsigned* __restrict__ vals_out, int shift, unsigned mask,
+                                                            unsigned nblk,
+                                                            const unsigned* __restrict__ ghist_scanned) {
+  constexpr int NB = 1 << BITS;
+  __shared__ unsigned cnt[4][NB];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  for (int d = threadIdx.x; d < 4 * NB; d += 256) (&cnt[0][0])[d] = 0;
+  __syncthreads();
+  const size_t wbase = (size_t)blockIdx.x * kSortBlock + (size_t)wave * (kSortRounds * 64);
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  KeyT key[kSortRounds];
+  unsigned pos[kSortRounds];
+#pragma unroll
+  for (int r = 0; r < kSortRounds; ++r) {
+    size_t i = wbase + (size_t)r * 64 + lane;
+    bool valid = i < n;
+    key[r] = valid ? keys_in[i] : (KeyT)0;
+    unsigned digit = (unsigned)(key[r] >> shift) & mask;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+      bool bit = (digit >> b) & 1u;
+      unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    unsigned prefix = __popcll(peers & lt_mask);
+    unsigned total = __popcll(peers);
+    unsigned base = 0;
+    if (valid) base = cnt[wave][digit];
+    __builtin_amdgcn_wave_barrier();
+    if (valid && prefix == 0) cnt[wave][digit] = base + total;
+    __builtin_amdgcn_wave_barrier();
+    pos[r] = base + prefix;
+  }
+  __syncthreads();
+  // per digit: exclusive prefix over the 4 waves + this block's global base
+  for (int d = threadIdx.x; d < NB; d += 256) {
+    unsigned run = ghist_scanned[(size_t)d * nblk + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned c = cnt[w][d];
+      cnt[w][d] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kSortRounds; ++r) {
+    size_t i = wbase + (size_t)r * 64 + lane;
+    if (i < n) {
+      unsigned digit = (unsigned)(key[r] >> shift) & mask;
+      size_t dst = (size_t)cnt[wave][digit] + pos[r];
+      keys_out[dst] = key[r];
+      vals_out[dst] = vals_in ? vals_in[i] : (unsigned)i;
+    }
+  }
+}
+
+static inline unsigned sort_nblk(size_t n) { return (unsigned)((n + kSortBlock - 1) / kSortBlock); }
+
+// digit plan for sorting `bits` key bits: fewest passes with digits <= 11 bits, equal widths
+static inline void radix_plan(int bits, int* passes, int* per, int* tmpl_bits) {
+  int ps = (bits + 10) / 11;
+  if (ps < 1) ps = 1;
+  int w = (bits + ps - 1) / ps;
+  *passes = ps; *per = w; *tmpl_bits = w < 8 ? 8 : w;
+}
+
+static inline size_t radix_hist_bytes(size_t n, int bits) {
+  int ps, per, tb;
+  radix_plan(bits, &ps, &per, &tb);
+  size_t b = ((size_t)1 << tb) * sort_nblk(n) * sizeof(unsigned);
+  return (b + 255) & ~(size_t)255;
+}
+
+static inline size_t radix_ws_bytes(size_t n, int bits) {
+  int ps, per, tb;
+  radix_plan(bits, &ps, &per, &tb);
+  return radix_hist_bytes(n, bits) + scan_ws_bytes(((size_t)1 << tb) * sort_nblk(n)) + 256;
+}
+
+template <typename KeyT, int BITS>
+static void radix_pass(size_t n, const KeyT* kin, const unsigned* vin, KeyT* kout, unsigned* vout, int shift,
+                       unsigned mask, void* ws, size_t hist_bytes, hipStream_t st) {
+  unsigned nblk = sort_nblk(n);
+  unsigned* ghist = reinterpret_cast<unsigned*>(ws);
+  size_t hn = ((size_t)1 << BITS) * nblk;
+  void* scan_ws = reinterpret_cast<char*>(ws) + hist_bytes;
+  hipLaunchKernelGGL((radix_hist_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, shift, mask, nblk, ghist);
+  run_scan(hn, ghist, ghist, nullptr, scan_ws, st);
+  hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, vin, kout, vout, shift,
+                     mask, nblk, ghist);
+}
+
+// Sort bits [begin_bit, end_bit).  Ping-pongs between (k0,v0) and (k1,v1); returns the index
+// (0/1) of the buffer pair that holds the result through *result_buf.
+template <typename KeyT>
+static int radix_sort(size_t n, KeyT* k0, unsigned* v0, KeyT* k1, unsigned* v1, int v0_is_iota, int begin_bit,
+                      int end_bit, void* ws, size_t ws_bytes, int* result_buf, hipStream_t st) {
+  int bits = end_bit - begin_bit;
+  if (bits <= 0) return GS_ERR_INVALID;
+  if (ws_bytes < radix_ws_bytes(n, bits)) return GS_ERR_WORKSPACE;
+  int passes, per, tb;
+  radix_plan(bits, &passes, &per, &tb);
+  const size_t hist_bytes = radix_hist_bytes(n, bits);
+  KeyT* kk[2] = {k0, k1};
+  unsigned* vv[2] = {v0, v1};
+  int cur = 0, shift = begin_bit;
+  for (int p = 0; p < passes; ++p) {
+    int w = per;
+    if (shift + w > end_bit) w = end_bit - shift;
+    const unsigned mask = (1u << w) - 1u;
+    const unsigned* vin = (p == 0 && v0_is_iota) ? nullptr : vv[cur];
+    switch (tb) {
+      case 8:  radix_pass<KeyT, 8>(n, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
+      case 9:  radix_pass<KeyT, 9>(n, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
+      case 10: radix_pass<KeyT, 10>(n, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
+      default: radix_pass<KeyT, 11>(n, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
+    }
+    shift += w;
+    cur ^= 1;
+  }
+  *result_buf = cur;
+  return gs_launch_status();
+}
+
+// ---------------------------------------------------------------------------
+// tile counts in depth order, intersection emission, bin edges
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_counts_kernel(size_t n, const unsigned* __restrict__ sorted_gi,
+                                                            const int* __restrict__ ntiles,
+                                                            unsigned* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (unsigned)ntiles[sorted_gi[i]];
+}
+
+// One block expands 256 consecutive depth-ranked Gaussians; output range of the block is
+// contiguous, every thread writes consecutive entries (coalesced), source Gaussian found
+// by binary search in the block's LDS scan.
+__global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T, int tiles_x,
+                                                   const unsigned* __restrict__ sorted_gi,
+                                                   const unsigned* __restrict__ cum,   // exclusive, in rank order
+                                                   const float* __restrict__ records, size_t n_isect,
+                                                   unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+  __shared__ unsigned s_cum[257];
+  __shared__ unsigned s_gi[256];
+  __shared__ unsigned s_lo[256], s_hi[256];
+  size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned gi = 0, lo = 0, hi = 0, c = 0;
+  if (r < n_ranked) {
+    gi = sorted_gi[r];
+    c = cum[r];
+    const float* rec = records + (size_t)gi * kRecFloats;
+    lo = (unsigned)__float_as_int(rec[10]);
+    hi = (unsigned)__float_as_int(rec[11]);
+  }
+  s_gi[threadIdx.x] = gi; s_lo[threadIdx.x] = lo; s_hi[threadIdx.x] = hi; s_cum[threadIdx.x] = c;
+  size_t r_last = (size_t)blockIdx.x * 256 + 256;
+  if (threadIdx.x == 0) s_cum[256] = r_last < n_ranked ? cum[r_last] : (unsigned)n_isect;
+  __syncthreads();
+  const unsigned first = s_cum[0];
+  // ranks past n_ranked hold cum = 0: make their slots empty by pointing them at the block end
+  const unsigned last = s_cum[256];
+  const int n_live = (int)min((size_t)256, n_ranked - (size_t)blockIdx.x * 256);
+  for (unsigned e = first + threadIdx.x; e < last; e += 256) {
+    // largest li in [0,n_live) with s_cum[li] <= e
+    int a = 0, b = n_live - 1;
+    while (a < b) {
+      int mid = (a + b + 1) >> 1;
+      if (s_cum[mid] <= e) a = mid; else b = mid - 1;
+    }
+    unsigned rem = e - s_cum[a];
+    unsigned l = s_lo[a], h = s_hi[a];
+    int x0 = l & 0xFFFF, y0 = l >> 16, x1 = h & 0xFFFF;
+    int w = x1 - x0;
+    int ty = y0 + (int)(rem / (unsigned)w), tx = x0 + (int)(rem % (unsigned)w);
+    unsigned g = s_gi[a];
+    unsigned p = g / (unsigned)N;
+    keys[e] = p * (unsigned)T + (unsigned)(ty * tiles_x + tx);
+    vals[e] = g;
+  }
+}
+
+template <typename KeyT, int SHIFT>
+__global__ __launch_bounds__(256) void bin_edges_kernel(size_t n, const KeyT* __restrict__ keys,
+                                                        int2* __restrict__ bins) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  unsigned t = (unsigned)(keys[i] >> SHIFT);
+  if (i == 0 || (unsigned)(keys[i - 1] >> SHIFT) != t) bins[t].x = (int)i;
+  if (i == n - 1 || (unsigned)(keys[i + 1] >> SHIFT) != t) bins[t].y = (int)(i + 1);
+}
+
+// upstream-compatible 64-bit intersection ids (one thread per Gaussian; API-parity path)
+__global__ __launch_bounds__(256) void map_isect_kernel(int N, const float* __restrict__ xys,
+                                                        const float* __restrict__ depths,
+                                                        const int* __restrict__ radii,
+                                                        const int* __restrict__ cum_tiles_hit,  // inclusive
+                                                        int tiles_x, int tiles_y, long long* __restrict__ isect_ids,
+                                                        int* __restrict__ gaussian_ids) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  int rad = radii[i];
+  if (rad <= 0) return;
+  const float inv_tile = 1.0f / (float)K::kTile;
+  float radf = (float)rad;
+  float tcx = xys[2 * i] * inv_tile, tcy = xys[2 * i + 1] * inv_tile, tr = radf * inv_tile;
+  int x0 = (int)(tcx - tr), x1 = (int)(tcx + tr + 1.0f);
+  int y0 = (int)(tcy - tr), y1 = (int)(tcy + tr + 1.0f);
+  x0 = x0 < 0 ? 0 : (x0 > tiles_x ? tiles_x : x0);
+  x1 = x1 < 0 ? 0 : (x1 > tiles_x ? tiles_x : x1);
+  y0 = y0 < 0 ? 0 : (y0 > tiles_y ? tiles_y : y0);
+  y1 = y1 < 0 ? 0 : (y1 > tiles_y ? tiles_y : y1);
+  long long depth_bits = (long long)(unsigned)__float_as_int(depths[i]);
+  int cur = i == 0 ? 0 : cum_tiles_hit[i - 1];
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      long long tile = (long long)(y * tiles_x + x);
+      isect_ids[cur] = (tile << 32) | depth_bits;
+      gaussian_ids[cur] = i;
+      ++cur;
+    }
+}
+
+__global__ __launch_bounds__(256) void depth_keys64_kernel(size_t n, int N, const unsigned* __restrict__ dk,
+                                                           unsigned long long* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = ((unsigned long long)(i / (size_t)N) << 32) | (unsigned long long)dk[i];
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+// C ABI -------------------------------------------------------------------------
+GS_EXPORT long long gs_scan_workspace_bytes(long long n) { return (long long)scan_ws_bytes((size_t)n) + 256; }
+GS_EXPORT long long gs_radix_sort_workspace_bytes(long long n, int begin_bit, int end_bit) {
+  if (n <= 0 || end_bit <= begin_bit) return 0;
+  return (long long)radix_ws_bytes((size_t)n, end_bit - begin_bit);
+}
+
+// out[i] = sum_{j<i} in[j]; *total_out (device u32, nullable) = sum of all.  in == out allowed.
+GS_EXPORT int gs_exclusive_scan_u32(long long n, const unsigned* in, unsigned* out, unsigned* total_out, void* ws,
+                                    long long ws_bytes, void* stream) {
+  if (n <= 0) return GS_ERR_INVALID;
+  if ((size_t)ws_bytes < scan_ws_bytes((size_t)n)) return GS_ERR_WORKSPACE;
+  return run_scan((size_t)n, in, out, total_out, ws, (hipStream_t)stream);
+}
+
+// Stable LSD radix sort of (key, u32 value) pairs over key bits [begin_bit, end_bit).
+// Buffers 0 are the input (clobbered), buffers 1 scratch of the same size; *result_buf (host int)
+// receives which pair holds the sorted output.  vals0_is_iota!=0: vals0 is not read, values = index.
+GS_EXPORT int gs_radix_sort_pairs_u32(long long n, unsigned* keys0, unsigned* vals0, unsigned* keys1,
+                                      unsigned* vals1, int vals0_is_iota, int begin_bit, int end_bit, void* ws,
+                                      long long ws_bytes, int* result_buf, void* stream) {
+  if (n <= 0 || begin_bit < 0 || end_bit > 32) return GS_ERR_INVALID;
+  return radix_sort<unsigned>((size_t)n, keys0, vals0, keys1, vals1, vals0_is_iota, begin_bit, end_bit, ws,
+                              (size_t)ws_bytes, result_buf, (hipStream_t)stream);
+}
+
+GS_EXPORT int gs_radix_sort_pairs_u64(long long n, unsigned long long* keys0, unsigned* vals0,
+                                      unsigned long long* keys1, unsigned* vals1, int vals0_is_iota, int begin_bit,
+                                      int end_bit, void* ws, long long ws_bytes, int* result_buf, void* stream) {
+  if (n <= 0 || begin_bit < 0 || end_bit > 64) return GS_ERR_INVALID;
+  return radix_sort<unsigned long long>((size_t)n, keys0, vals0, keys1, vals1, vals0_is_iota, begin_bit, end_bit, ws,
+                                        (size_t)ws_bytes, result_buf, (hipStream_t)stream);
+}
+
+// (sub-pose, depth) keys for the N-sized pre-sort: out[i] = (i / N) << 32 | depth_keys[i]
+GS_EXPORT int gs_make_depth_keys64(long long n, int N, const unsigned* depth_keys, unsigned long long* out,
+                                   void* stream) {
+  if (n <= 0 || N <= 0) return GS_ERR_INVALID;
+  hipLaunchKernelGGL(depth_keys64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (size_t)n, N, depth_keys, out);
+  return gs_launch_status();
+}
+
+// counts_out[r] = num_tiles_hit[sorted_gi[r]]
+GS_EXPORT int gs_gather_counts(long long n, const unsigned* sorted_gi, const int* num_tiles_hit, unsigned* counts_out,
+                               void* stream) {
+  if (n <= 0) return GS_ERR_INVALID;
+  hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (size_t)n, sorted_gi, num_tiles_hit, counts_out);
+  return gs_launch_status();
+}
+
+// Emit the tile intersections of the depth-ranked Gaussians: keys[e] = p*T + tile, vals[e] = p*N + g.
+GS_EXPORT int gs_emit_intersects(long long n_ranked, int N, int H, int W, const unsigned* sorted_gi,
+                                 const unsigned* cum_excl, const float* records, long long n_isect, unsigned* keys,
+                                 unsigned* vals, void* stream) {
+  if (n_ranked <= 0 || N <= 0) return GS_ERR_INVALID;
+  if (n_isect <= 0) return GS_OK;
+  int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
+  hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((n_ranked + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (size_t)n_ranked, N, tiles_x * tiles_y, tiles_x, sorted_gi, cum_excl, records, (size_t)n_isect,
+                     keys, vals);
+  return gs_launch_status();
+}
+
+// bins[t] = [start,end) of key t in the sorted u32 keys; bins are zeroed here first.
+GS_EXPORT int gs_tile_bin_edges_u32(long long n, const unsigned* sorted_keys, int num_bins, int* bins, void* stream) {
+  if (num_bins <= 0) return GS_ERR_INVALID;
+  hipError_t e = hipMemsetAsync(bins, 0, (size_t)num_bins * 2 * sizeof(int), (hipStream_t)stream);
+  if (e != hipSuccess) return 1000 + (int)e;
+  if (n <= 0) return GS_OK;
+  hipLaunchKernelGGL((bin_edges_kernel<unsigned, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (size_t)n, sorted_keys, reinterpret_cast<int2*>(bins));
+  return gs_launch_status();
+}
+
+// gsplat.get_tile_bin_edges: tile id = isect_id >> 32
+GS_EXPORT int gs_tile_bin_edges_u64(long long n, const unsigned long long* sorted_ids, int num_bins, int* bins,
+                                    void* stream) {
+  if (num_bins <= 0) return GS_ERR_INVALID;
+  hipError_t e = hipMemsetAsync(bins, 0, (size_t)num_bins * 2 * sizeof(int), (hipStream_t)stream);
+  if (e != hipSuccess) return 1000 + (int)e;
+  if (n <= 0) return GS_OK;
+  hipLaunchKernelGGL((bin_edges_kernel<unsigned long long, 32>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (size_t)n, sorted_ids, reinterpret_cast<int2*>(bins));
+  return gs_launch_status();
+}
+
+// gsplat.map_gaussian_to_intersects (device side): cum_tiles_hit is the INCLUSIVE cumsum like upstream.
+GS_EXPORT int gs_map_gaussian_to_intersects(int N, const float* xys, const float* depths, const int* radii,
+                                            const int* cum_tiles_hit, int H, int W, long long* isect_ids,
+                                            int* gaussian_ids, void* stream) {
+  if (N <= 0) return GS_ERR_INVALID;
+  int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
+  hipLaunchKernelGGL(map_isect_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, xys, depths,
+                     radii, cum_tiles_hit, tiles_x, tiles_y, isect_ids, gaussian_ids);
+  return gs_launch_status();
+}
+
+GS_EXPORT const char* gs_version(void) { return "gsdeblur-hip 0.1 (gfx950, wave64)"; }

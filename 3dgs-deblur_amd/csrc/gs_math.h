@@ -1,0 +1,413 @@
+// gs_math.h — per-Gaussian math of the hot path, shared by every HIP kernel.
+//
+// Everything here is `GS_HD` (host+device) plain C++ so that the very same
+// code can be (a) inlined into the gfx950 kernels and (b) compiled with g++
+// into tests/host_math (TEST INFRASTRUCTURE ONLY) and checked against the
+// float64 oracle on a box without a GPU.  Nothing in the product path calls
+// the host build.
+//
+// What it restates (the reference's fork sources are NOT in /root/reference —
+// see SURVEY.md §0; the spec is SURVEY.md App. A, recollected from upstream
+// gsplat 0.1.11, base commit named at /root/reference/README.md:199):
+//   project_gaussians fwd/bwd  (SURVEY §8 a1,a3)
+//   spherical_harmonics fwd/bwd
+//   SE(3) screw interpolation of sub-poses (north_star)
+// All recollected constants live in `gs::K` below so they can be corrected in
+// one place.
+//
+// Floating-point contract: the projection path is compiled with
+// -ffp-contract=off and written with an explicit left-to-right association so
+// the integer outputs (radii, tile bounds, depth key bits) are bit-identical
+// to the oracle's float32 restatement (oracle/gs_oracle.py::project_f32).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GS_HD __host__ __device__ __forceinline__
+#else
+#define GS_HD inline
+#endif
+
+namespace gs {
+
+// ---- recollected constants ------------------------------
+struct K {
+  static constexpr float kFovLimit   = 1.3f;    // clamp of x/z, y/z: 1.3 * tan(fov/2)
+  static constexpr float kDilation   = 0.3f;    // EWA low-pass added to cov2d diagonal
+  static constexpr float kMinEigDisc = 0.1f;    // max(0.1, mid^2 - det)
+  static constexpr float kRadiusSig  = 3.0f;    // radius = ceil(3 sqrt(lambda_max))
+  static constexpr float kAlphaMax   = 0.999f;  // alpha = min(0.999, o * exp(-sigma))
+  static constexpr float kAlphaMin   = 1.0f / 255.0f;  // skip below
+  static constexpr float kTMin       = 1e-4f;   // stop when T*(1-alpha) <= 1e-4
+  static constexpr int   kTile       = 16;      // block_width
+};
+
+// Per-Gaussian projected record consumed by the rasterizer: 12 floats = 48 B,
+// three 16-byte loads per gather.
+//   [0] x  [1] y  [2] conic.x  [3] conic.y | [4] conic.z [5] opacity [6] r [7] g |
+//   [8] b  [9] depth [10] radius(int bits) [11] tiles(int bits)
+constexpr int kRecFloats = 12;
+
+struct Proj {
+  float x, y, depth;
+  float conic_x, conic_y, conic_z;
+  float comp;
+  int   radius;
+  int   tmin_x, tmin_y, tmax_x, tmax_y;
+  int   ntiles;
+  float cov3d[6];
+};
+
+// normalised quaternion (w,x,y,z) -> rotation matrix, row-major R[9]
+GS_HD void quat_to_rotmat(const float q[4], float R[9], float qn[4], float* inv_norm) {
+  float n2 = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
+  float inv = 1.0f / sqrtf(n2);
+  float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+  qn[0] = w; qn[1] = x; qn[2] = y; qn[3] = z; *inv_norm = inv;
+  R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - w * z);       R[2] = 2.f * (x * z + w * y);
+  R[3] = 2.f * (x * y + w * z);       R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - w * x);
+  R[6] = 2.f * (x * z - w * y);       R[7] = 2.f * (y * z + w * x);       R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// cov3d (upper triangle, 6) = (R S)(R S)^T ; also returns M = R S (row-major 9)
+GS_HD void scale_rot_to_cov3d(const float s[3], float glob, const float R[9], float M[9], float c[6]) {
+  float s0 = glob * s[0], s1 = glob * s[1], s2 = glob * s[2];
+  M[0] = R[0] * s0; M[1] = R[1] * s1; M[2] = R[2] * s2;
+  M[3] = R[3] * s0; M[4] = R[4] * s1; M[5] = R[5] * s2;
+  M[6] = R[6] * s0; M[7] = R[7] * s1; M[8] = R[8] * s2;
+  c[0] = (M[0] * M[0] + M[1] * M[1]) + M[2] * M[2];
+  c[1] = (M[0] * M[3] + M[1] * M[4]) + M[2] * M[5];
+  c[2] = (M[0] * M[6] + M[1] * M[7]) + M[2] * M[8];
+  c[3] = (M[3] * M[3] + M[4] * M[4]) + M[5] * M[5];
+  c[4] = (M[3] * M[6] + M[4] * M[7]) + M[5] * M[8];
+  c[5] = (M[6] * M[6] + M[7] * M[7]) + M[8] * M[8];
+}
+
+// Intermediates of one projection that the backward pass re-derives.
+struct ProjCtx {
+  float pc[3];      // camera-space mean
+  float rz;         // 1/z
+  float tx, ty;     // fov-clamped x,y
+  int   clamp_x, clamp_y;  // -1/0/+1 which side the clamp hit
+  float J00, J02, J11, J12;
+  float T[6];       // J*W, 2x3
+  float a, b, c;    // cov2d after dilation
+  float a0, c0;     // before dilation
+  float det, det0;
+};
+
+// Project one Gaussian with covariance c3 (6) under viewmat V (row-major 4x4,
+// rows 0..2 used).  Returns false when culled (near plane / singular / no tile).
+GS_HD bool project_one(const float mean[3], const float c3[6], const float* V,
+                       float fx, float fy, float cx, float cy, int img_w, int img_h,
+                       int tiles_x, int tiles_y, float clip, Proj& o, ProjCtx& k) {
+  o.radius = 0; o.ntiles = 0; o.tmin_x = o.tmin_y = o.tmax_x = o.tmax_y = 0;
+  float px = ((V[0] * mean[0] + V[1] * mean[1]) + V[2] * mean[2]) + V[3];
+  float py = ((V[4] * mean[0] + V[5] * mean[1]) + V[6] * mean[2]) + V[7];
+  float pz = ((V[8] * mean[0] + V[9] * mean[1]) + V[10] * mean[2]) + V[11];
+  k.pc[0] = px; k.pc[1] = py; k.pc[2] = pz;
+  o.depth = pz;
+  if (!(pz > clip)) return false;
+  float rz = 1.0f / pz;
+  k.rz = rz;
+  float lim_x = K::kFovLimit * (0.5f * (float)img_w / fx);
+  float lim_y = K::kFovLimit * (0.5f * (float)img_h / fy);
+  float xz = px * rz, yz = py * rz;
+  k.clamp_x = xz > lim_x ? 1 : (xz < -lim_x ? -1 : 0);
+  k.clamp_y = yz > lim_y ? 1 : (yz < -lim_y ? -1 : 0);
+  float tx = pz * fminf(lim_x, fmaxf(-lim_x, xz));
+  float ty = pz * fminf(lim_y, fmaxf(-lim_y, yz));
+  k.tx = tx; k.ty = ty;
+  float rz2 = rz * rz;
+  float J00 = fx * rz, J02 = -(fx * tx) * rz2;
+  float J11 = fy * rz, J12 = -(fy * ty) * rz2;
+  k.J00 = J00; k.J02 = J02; k.J11 = J11; k.J12 = J12;
+  // T = J * W   (W = V[0:3,0:3])
+  float* T = k.T;
+  T[0] = J00 * V[0] + J02 * V[8];
+  T[1] = J00 * V[1] + J02 * V[9];
+  T[2] = J00 * V[2] + J02 * V[10];
+  T[3] = J11 * V[4] + J12 * V[8];
+  T[4] = J11 * V[5] + J12 * V[9];
+  T[5] = J11 * V[6] + J12 * V[10];
+  // U = T * Sigma (2x3)
+  float U0 = (T[0] * c3[0] + T[1] * c3[1]) + T[2] * c3[2];
+  float U1 = (T[0] * c3[1] + T[1] * c3[3]) + T[2] * c3[4];
+  float U2 = (T[0] * c3[2] + T[1] * c3[4]) + T[2] * c3[5];
+  float U3 = (T[3] * c3[0] + T[4] * c3[1]) + T[5] * c3[2];
+  float U4 = (T[3] * c3[1] + T[4] * c3[3]) + T[5] * c3[4];
+  float U5 = (T[3] * c3[2] + T[4] * c3[4]) + T[5] * c3[5];
+  float a0 = (U0 * T[0] + U1 * T[1]) + U2 * T[2];
+  float b  = (U0 * T[3] + U1 * T[4]) + U2 * T[5];
+  float c0 = (U3 * T[3] + U4 * T[4]) + U5 * T[5];
+  float det0 = a0 * c0 - b * b;
+  float a = a0 + K::kDilation, c = c0 + K::kDilation;
+  float det = a * c - b * b;
+  k.a = a; k.b = b; k.c = c; k.a0 = a0; k.c0 = c0; k.det = det; k.det0 = det0;
+  if (det == 0.0f) return false;
+  o.comp = sqrtf(fmaxf(0.0f, det0 / det));
+  float inv_det = 1.0f / det;
+  o.conic_x = c * inv_det; o.conic_y = -b * inv_det; o.conic_z = a * inv_det;
+  float mid = 0.5f * (a + c);
+  float lam = mid + sqrtf(fmaxf(K::kMinEigDisc, mid * mid - det));
+  float radf = ceilf(K::kRadiusSig * sqrtf(lam));
+  int radius = (int)radf;
+  o.x = (fx * px) * rz + cx;
+  o.y = (fy * py) * rz + cy;
+  // tile bounding box
+  const float inv_tile = 1.0f / (float)K::kTile;
+  float tcx = o.x * inv_tile, tcy = o.y * inv_tile, tr = radf * inv_tile;
+  int x0 = (int)(tcx - tr), x1 = (int)(tcx + tr + 1.0f);
+  int y0 = (int)(tcy - tr), y1 = (int)(tcy + tr + 1.0f);
+  x0 = x0 < 0 ? 0 : (x0 > tiles_x ? tiles_x : x0);
+  x1 = x1 < 0 ? 0 : (x1 > tiles_x ? tiles_x : x1);
+  y0 = y0 < 0 ? 0 : (y0 > tiles_y ? tiles_y : y0);
+  y1 = y1 < 0 ? 0 : (y1 > tiles_y ? tiles_y : y1);
+  int area = (x1 - x0) * (y1 - y0);
+  if (area <= 0) return false;
+  o.radius = radius; o.ntiles = area;
+  o.tmin_x = x0; o.tmin_y = y0; o.tmax_x = x1; o.tmax_y = y1;
+  return true;
+}
+
+// ---- projection backward -----------------------------------------------------
+// Gradients flowing in: v_xy[2], v_depth, v_conic[3], v_comp.
+// Out (accumulated with =, caller sums): v_mean[3], v_cov3d[6] (for upper-triangle
+// parametrisation: off-diagonals carry the sum of both symmetric entries),
+// v_V[12] (rows 0..2 of the viewmat).
+GS_HD void project_one_bwd(const float mean[3], const float c3[6], const float* V,
+                           float fx, float fy, const ProjCtx& k, float comp,
+                           const float v_xy[2], float v_depth, const float v_conic[3], float v_comp,
+                           float v_mean[3], float v_c3[6], float v_V[12]) {
+  const float a = k.a, b = k.b, c = k.c, det = k.det;
+  const float inv_det = 1.0f / det, inv_det2 = inv_det * inv_det;
+  // conic -> (a,b,c)
+  float v0 = v_conic[0], v1 = v_conic[1], v2 = v_conic[2];
+  float v_a = (-c * c * v0 + b * c * v1 - b * b * v2) * inv_det2;
+  float v_c = (-b * b * v0 + a * b * v1 - a * a * v2) * inv_det2;
+  float v_b = (2.f * b * c * v0 - (a * c + b * b) * v1 + 2.f * a * b * v2) * inv_det2;
+  // compensation = sqrt(max(0, det0/det))
+  if (comp > 0.0f && v_comp != 0.0f) {
+    float v_r = v_comp * 0.5f / comp;
+    float det0 = k.det0;
+    v_a += v_r * (k.c0 * inv_det - det0 * c * inv_det2);
+    v_c += v_r * (k.a0 * inv_det - det0 * a * inv_det2);
+    v_b += v_r * (-2.f * b * inv_det + det0 * 2.f * b * inv_det2);
+  }
+  // cov2d = T Sigma T^T ; Gc = [[v_a, v_b/2],[v_b/2, v_c]]
+  const float* T = k.T;
+  float g00 = v_a, g01 = 0.5f * v_b, g11 = v_c;
+  // v_Sigma = T^T Gc T  (3x3 symmetric) -> upper-triangle parametrisation
+  float GT0 = g00 * T[0] + g01 * T[3], GT1 = g00 * T[1] + g01 * T[4], GT2 = g00 * T[2] + g01 * T[5];
+  float GT3 = g01 * T[0] + g11 * T[3], GT4 = g01 * T[1] + g11 * T[4], GT5 = g01 * T[2] + g11 * T[5];
+  float vS00 = T[0] * GT0 + T[3] * GT3;
+  float vS01 = T[0] * GT1 + T[3] * GT4;
+  float vS02 = T[0] * GT2 + T[3] * GT5;
+  float vS11 = T[1] * GT1 + T[4] * GT4;
+  float vS12 = T[1] * GT2 + T[4] * GT5;
+  float vS22 = T[2] * GT2 + T[5] * GT5;
+  v_c3[0] = vS00; v_c3[1] = 2.f * vS01; v_c3[2] = 2.f * vS02;
+  v_c3[3] = vS11; v_c3[4] = 2.f * vS12; v_c3[5] = vS22;
+  // v_T = 2 Gc T Sigma   (2x3)
+  float S00 = c3[0], S01 = c3[1], S02 = c3[2], S11 = c3[3], S12 = c3[4], S22 = c3[5];
+  float vT0 = 2.f * (GT0 * S00 + GT1 * S01 + GT2 * S02);
+  float vT1 = 2.f * (GT0 * S01 + GT1 * S11 + GT2 * S12);
+  float vT2 = 2.f * (GT0 * S02 + GT1 * S12 + GT2 * S22);
+  float vT3 = 2.f * (GT3 * S00 + GT4 * S01 + GT5 * S02);
+  float vT4 = 2.f * (GT3 * S01 + GT4 * S11 + GT5 * S12);
+  float vT5 = 2.f * (GT3 * S02 + GT4 * S12 + GT5 * S22);
+  // T = J W : v_J = v_T W^T ; v_W = J^T v_T
+  float vJ00 = vT0 * V[0] + vT1 * V[1] + vT2 * V[2];
+  float vJ02 = vT0 * V[8] + vT1 * V[9] + vT2 * V[10];
+  float vJ11 = vT3 * V[4] + vT4 * V[5] + vT5 * V[6];
+  float vJ12 = vT3 * V[8] + vT4 * V[9] + vT5 * V[10];
+  float vW[9];
+  vW[0] = k.J00 * vT0; vW[1] = k.J00 * vT1; vW[2] = k.J00 * vT2;
+  vW[3] = k.J11 * vT3; vW[4] = k.J11 * vT4; vW[5] = k.J11 * vT5;
+  vW[6] = k.J02 * vT0 + k.J12 * vT3; vW[7] = k.J02 * vT1 + k.J12 * vT4; vW[8] = k.J02 * vT2 + k.J12 * vT5;
+  // J(pc)
+  const float px = k.pc[0], py = k.pc[1], pz = k.pc[2], rz = k.rz;
+  const float rz2 = rz * rz, rz3 = rz2 * rz;
+  float v_tx = -fx * rz2 * vJ02;
+  float v_ty = -fy * rz2 * vJ12;
+  float v_pz = -fx * rz2 * vJ00 - fy * rz2 * vJ11 + 2.f * fx * k.tx * rz3 * vJ02 + 2.f * fy * k.ty * rz3 * vJ12;
+  float v_px = 0.f, v_py = 0.f;
+  if (k.clamp_x == 0) v_px += v_tx; else v_pz += v_tx * (k.tx * rz);  // tx = (+-lim) * z
+  if (k.clamp_y == 0) v_py += v_ty; else v_pz += v_ty * (k.ty * rz);
+  // pixel centre + depth
+  v_px += fx * rz * v_xy[0];
+  v_py += fy * rz * v_xy[1];
+  v_pz += -(fx * px * rz2 * v_xy[0] + fy * py * rz2 * v_xy[1]) + v_depth;
+  // pc = W mean + t
+  v_mean[0] = V[0] * v_px + V[4] * v_py + V[8] * v_pz;
+  v_mean[1] = V[1] * v_px + V[5] * v_py + V[9] * v_pz;
+  v_mean[2] = V[2] * v_px + V[6] * v_py + V[10] * v_pz;
+  v_V[0] = vW[0] + v_px * mean[0]; v_V[1] = vW[1] + v_px * mean[1]; v_V[2]  = vW[2] + v_px * mean[2]; v_V[3]  = v_px;
+  v_V[4] = vW[3] + v_py * mean[0]; v_V[5] = vW[4] + v_py * mean[1]; v_V[6]  = vW[5] + v_py * mean[2]; v_V[7]  = v_py;
+  v_V[8] = vW[6] + v_pz * mean[0]; v_V[9] = vW[7] + v_pz * mean[1]; v_V[10] = vW[8] + v_pz * mean[2]; v_V[11] = v_pz;
+}
+
+// cov3d (upper-triangle grads as produced above) -> scale, quat grads.
+GS_HD void cov3d_bwd(const float s[3], float glob, const float q[4], const float v_c3[6],
+                     float v_s[3], float v_q[4]) {
+  float R[9], qn[4], inv;
+  quat_to_rotmat(q, R, qn, &inv);
+  float M[9], c3[6];
+  scale_rot_to_cov3d(s, glob, R, M, c3);
+  // symmetric v_Sigma from upper-triangle parametrisation
+  float S00 = v_c3[0], S01 = 0.5f * v_c3[1], S02 = 0.5f * v_c3[2];
+  float S11 = v_c3[3], S12 = 0.5f * v_c3[4], S22 = v_c3[5];
+  // v_M = 2 v_Sigma M
+  float vM[9];
+  vM[0] = 2.f * (S00 * M[0] + S01 * M[3] + S02 * M[6]);
+  vM[1] = 2.f * (S00 * M[1] + S01 * M[4] + S02 * M[7]);
+  vM[2] = 2.f * (S00 * M[2] + S01 * M[5] + S02 * M[8]);
+  vM[3] = 2.f * (S01 * M[0] + S11 * M[3] + S12 * M[6]);
+  vM[4] = 2.f * (S01 * M[1] + S11 * M[4] + S12 * M[7]);
+  vM[5] = 2.f * (S01 * M[2] + S11 * M[5] + S12 * M[8]);
+  vM[6] = 2.f * (S02 * M[0] + S12 * M[3] + S22 * M[6]);
+  vM[7] = 2.f * (S02 * M[1] + S12 * M[4] + S22 * M[7]);
+  vM[8] = 2.f * (S02 * M[2] + S12 * M[5] + S22 * M[8]);
+  v_s[0] = glob * (vM[0] * R[0] + vM[3] * R[3] + vM[6] * R[6]);
+  v_s[1] = glob * (vM[1] * R[1] + vM[4] * R[4] + vM[7] * R[7]);
+  v_s[2] = glob * (vM[2] * R[2] + vM[5] * R[5] + vM[8] * R[8]);
+  float s0 = glob * s[0], s1 = glob * s[1], s2 = glob * s[2];
+  float vR[9] = {vM[0] * s0, vM[1] * s1, vM[2] * s2, vM[3] * s0, vM[4] * s1, vM[5] * s2,
+                 vM[6] * s0, vM[7] * s1, vM[8] * s2};
+  float w = qn[0], x = qn[1], y = qn[2], z = qn[3];
+  float g[4];
+  g[0] = 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
+  g[1] = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[3] + vR[1]) + z * (vR[6] + vR[2]) + w * (vR[7] - vR[5]));
+  g[2] = 2.f * (x * (vR[3] + vR[1]) - 2.f * y * (vR[0] + vR[8]) + z * (vR[7] + vR[5]) + w * (vR[2] - vR[6]));
+  g[3] = 2.f * (x * (vR[6] + vR[2]) + y * (vR[7] + vR[5]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
+  // through the normalisation q/|q|
+  float dotp = g[0] * w + g[1] * x + g[2] * y + g[3] * z;
+  v_q[0] = (g[0] - w * dotp) * inv;
+  v_q[1] = (g[1] - x * dotp) * inv;
+  v_q[2] = (g[2] - y * dotp) * inv;
+  v_q[3] = (g[3] - z * dotp) * inv;
+}
+
+// ---- spherical harmonics (real, degree <= 4) ---------------------------------
+// basis values for unit direction (x,y,z); nb = (deg+1)^2.  Sloan-style
+// recurrences with the usual 3DGS sign convention.
+GS_HD void sh_basis(int deg, float x, float y, float z, float* B) {
+  B[0] = 0.2820947917738781f;
+  if (deg < 1) return;
+  B[1] = -0.48860251190292f * y;
+  B[2] = 0.48860251190292f * z;
+  B[3] = -0.48860251190292f * x;
+  if (deg < 2) return;
+  float z2 = z * z;
+  float fTmp0B = -1.092548430592079f * z;
+  float fC1 = x * x - y * y, fS1 = 2.f * x * y;
+  B[6] = 0.9461746957575601f * z2 - 0.3153915652525201f;
+  B[7] = fTmp0B * x;
+  B[5] = fTmp0B * y;
+  B[8] = 0.5462742152960395f * fC1;
+  B[4] = 0.5462742152960395f * fS1;
+  if (deg < 3) return;
+  float fTmp0C = -2.285228997322329f * z2 + 0.4570457994644658f;
+  float fTmp1B = 1.445305721320277f * z;
+  float fC2 = x * fC1 - y * fS1, fS2 = x * fS1 + y * fC1;
+  B[12] = z * (1.865881662950577f * z2 - 1.119528997770346f);
+  B[13] = fTmp0C * x;
+  B[11] = fTmp0C * y;
+  B[14] = fTmp1B * fC1;
+  B[10] = fTmp1B * fS1;
+  B[15] = -0.5900435899266435f * fC2;
+  B[9]  = -0.5900435899266435f * fS2;
+  if (deg < 4) return;
+  float fTmp0D = z * (-4.683325804901025f * z2 + 2.007139630671868f);
+  float fTmp1C = 3.31161143515146f * z2 - 0.47308734787878f;
+  float fTmp2B = -1.770130769779931f * z;
+  float fC3 = x * fC2 - y * fS2, fS3 = x * fS2 + y * fC2;
+  B[20] = 1.984313483298443f * z * B[12] - 1.006230589874905f * B[6];
+  B[21] = fTmp0D * x;
+  B[19] = fTmp0D * y;
+  B[22] = fTmp1C * fC1;
+  B[18] = fTmp1C * fS1;
+  B[23] = fTmp2B * fC2;
+  B[17] = fTmp2B * fS2;
+  B[24] = 0.6258357354491763f * fC3;
+  B[16] = 0.6258357354491763f * fS3;
+}
+
+// ---- SE(3) screw interpolation ------------------------------------------------
+// Camera-to-world at time t under constant body twist xi = (v, w), both in the
+// (OpenCV) camera frame:  C(t) = C0 * Exp(t * xi)  =>  viewmat(t) = Exp(-t*xi) * viewmat0.
+// Velocity frame convention: /root/reference/process_synthetic_inputs.py:157-165,
+// /root/reference/render_video.py:100-115 (R_w2c @ velocity_w).
+// Templated so that the backward kernel can push dual numbers through it.
+template <typename S>
+GS_HD void se3_exp(const S v[3], const S w[3], S E[12]) {
+  // E = [R | V v] with R = I + A K + B K^2, V = I + B K + C K^2, K = [w]x
+  S th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  S A, B, C;
+  if (th2 < S(1e-8f)) {   // series, keeps derivatives finite at w = 0
+    A = S(1.f) - th2 * S(1.f / 6.f);
+    B = S(0.5f) - th2 * S(1.f / 24.f);
+    C = S(1.f / 6.f) - th2 * S(1.f / 120.f);
+  } else {
+    S th = sqrt(th2);
+    A = sin(th) / th;
+    B = (S(1.f) - cos(th)) / th2;
+    C = (S(1.f) - A) / th2;
+  }
+  S K[9] = {S(0.f), -w[2], w[1], w[2], S(0.f), -w[0], -w[1], w[0], S(0.f)};
+  S K2[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      K2[i * 3 + j] = K[i * 3 + 0] * K[0 * 3 + j] + K[i * 3 + 1] * K[1 * 3 + j] + K[i * 3 + 2] * K[2 * 3 + j];
+  for (int i = 0; i < 3; ++i) {
+    S t = S(0.f);
+    for (int j = 0; j < 3; ++j) {
+      S I = S(i == j ? 1.f : 0.f);
+      E[i * 4 + j] = I + A * K[i * 3 + j] + B * K2[i * 3 + j];
+      S Vij = I + B * K[i * 3 + j] + C * K2[i * 3 + j];
+      t = t + Vij * v[j];
+    }
+    E[i * 4 + 3] = t;
+  }
+}
+
+// viewmat(t) rows 0..2 = Exp(-t xi) * viewmat0
+template <typename S>
+GS_HD void subpose_viewmat(const S V0[12], const S lin[3], const S ang[3], S t, S out[12]) {
+  S v[3] = {-t * lin[0], -t * lin[1], -t * lin[2]};
+  S w[3] = {-t * ang[0], -t * ang[1], -t * ang[2]};
+  S E[12];
+  se3_exp<S>(v, w, E);
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 4; ++j) {
+      S acc = E[i * 4 + 0] * V0[0 * 4 + j] + E[i * 4 + 1] * V0[1 * 4 + j] + E[i * 4 + 2] * V0[2 * 4 + j];
+      if (j == 3) acc = acc + E[i * 4 + 3];
+      out[i * 4 + j] = acc;
+    }
+  }
+}
+
+// minimal forward-mode dual number with N tangents (used only on P<=~100 sub-poses)
+template <int N>
+struct Dual {
+  float v;
+  float d[N];
+  GS_HD Dual() : v(0.f) { for (int i = 0; i < N; ++i) d[i] = 0.f; }
+  GS_HD explicit Dual(float x) : v(x) { for (int i = 0; i < N; ++i) d[i] = 0.f; }
+};
+template <int N> GS_HD Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int N> GS_HD Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int N> GS_HD Dual<N> operator-(const Dual<N>& a) { Dual<N> r; r.v = -a.v; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
+template <int N> GS_HD Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int N> GS_HD Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; float ib = 1.f / b.v; r.v = a.v * ib; for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
+template <int N> GS_HD bool operator<(const Dual<N>& a, const Dual<N>& b) { return a.v < b.v; }
+template <int N> GS_HD Dual<N> sqrt(const Dual<N>& a) { Dual<N> r; r.v = sqrtf(a.v); float h = 0.5f / r.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * h; return r; }
+template <int N> GS_HD Dual<N> sin(const Dual<N>& a) { Dual<N> r; r.v = sinf(a.v); float c = cosf(a.v); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * c; return r; }
+template <int N> GS_HD Dual<N> cos(const Dual<N>& a) { Dual<N> r; r.v = cosf(a.v); float s = -sinf(a.v); for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * s; return r; }
+
+GS_HD float sqrt(float a) { return sqrtf(a); }
+GS_HD float sin(float a) { return sinf(a); }
+GS_HD float cos(float a) { return cosf(a); }
+
+}  // namespace gs

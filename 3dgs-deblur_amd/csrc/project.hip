@@ -1,0 +1,537 @@
+// project.hip — per-Gaussian kernels: SE(3) sub-pose interpolation, EWA
+// projection (single pose, gsplat-compatible arrays) and the fused multi-sub-pose
+// projection + SH colour + antialiased opacity that writes rasterizer records.
+//
+// Compiled with -ffp-contract=off: radii / tile bounds / depth key bits must be
+// bit-identical to oracle/gs_oracle.py::project_gaussians in float32.
+//
+// Restates (absent fork sources): gsplat project_gaussians
+// forward/backward kernels, compute_sh_forward/backward (SURVEY.md §2.3, §8 a1,
+// a3, a9; App. A) and the model-level sub-pose loop (§8 a2, a10; north_star).
+#include "gs_common.h"
+
+namespace gs {
+
+// ---------------------------------------------------------------------------
+// SE(3) screw interpolation of sub-pose viewmats
+// ---------------------------------------------------------------------------
+__global__ void subpose_fwd_kernel(int P, const float* __restrict__ V0, const float* __restrict__ lin,
+                                   const float* __restrict__ ang, const float* __restrict__ times,
+                                   float* __restrict__ out) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float v0[12], l[3], a[3], o[12];
+  for (int j = 0; j < 12; ++j) v0[j] = V0[j];
+  for (int j = 0; j < 3; ++j) { l[j] = lin[j]; a[j] = ang[j]; }
+  subpose_viewmat<float>(v0, l, a, times[p], o);
+  for (int j = 0; j < 12; ++j) out[16 * p + j] = o[j];
+  out[16 * p + 12] = 0.f; out[16 * p + 13] = 0.f; out[16 * p + 14] = 0.f; out[16 * p + 15] = 1.f;
+}
+
+// one thread per sub-pose pushes 18 tangents (12 viewmat, 3 lin, 3 ang) through the
+// closed form; P is tiny (<= ~100) so the per-thread cost is irrelevant.
+__global__ void subpose_bwd_kernel(int P, const float* __restrict__ V0, const float* __restrict__ lin,
+                                   const float* __restrict__ ang, const float* __restrict__ times,
+                                   const float* __restrict__ v_out, float* __restrict__ v_V0,
+                                   float* __restrict__ v_lin, float* __restrict__ v_ang) {
+  typedef Dual<18> D;
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  D dV[12], dl[3], da[3], o[12];
+  for (int j = 0; j < 12; ++j) { dV[j] = D(V0[j]); dV[j].d[j] = 1.f; }
+  for (int j = 0; j < 3; ++j) {
+    dl[j] = D(lin[j]); dl[j].d[12 + j] = 1.f;
+    da[j] = D(ang[j]); da[j].d[15 + j] = 1.f;
+  }
+  subpose_viewmat<D>(dV, dl, da, D(times[p]), o);
+  float acc[18];
+  for (int t = 0; t < 18; ++t) acc[t] = 0.f;
+  for (int j = 0; j < 12; ++j) {
+    float g = v_out[16 * p + j];
+    for (int t = 0; t < 18; ++t) acc[t] += g * o[j].d[t];
+  }
+  for (int t = 0; t < 12; ++t) atomic_add_f32(v_V0 + t, acc[t]);
+  for (int t = 0; t < 3; ++t) { atomic_add_f32(v_lin + t, acc[12 + t]); atomic_add_f32(v_ang + t, acc[15 + t]); }
+}
+
+// ---------------------------------------------------------------------------
+// gsplat-compatible single-pose projection (separate output arrays)
+// ---------------------------------------------------------------------------
+struct Intrin { float fx, fy, cx, cy; int W, H, tiles_x, tiles_y; float clip; };
+
+__global__ __launch_bounds__(256) void project_fwd_kernel(int N, const float* __restrict__ means,
+    const float* __restrict__ scales, float glob, const float* __restrict__ quats, const float* __restrict__ V,
+    Intrin in, float* __restrict__ xys, float* __restrict__ depths, int* __restrict__ radii,
+    float* __restrict__ conics, float* __restrict__ comp, int* __restrict__ ntiles, float* __restrict__ cov3d,
+    int* __restrict__ tbounds) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float Vm[12];
+  for (int j = 0; j < 12; ++j) Vm[j] = V[j];
+  float m[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+  float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+  float q[4] = {quats[4 * i], quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3]};
+  float R[9], qn[4], inv, M[9], c3[6];
+  quat_to_rotmat(q, R, qn, &inv);
+  scale_rot_to_cov3d(s, glob, R, M, c3);
+  Proj o; ProjCtx k;
+  bool ok = project_one(m, c3, Vm, in.fx, in.fy, in.cx, in.cy, in.W, in.H, in.tiles_x, in.tiles_y, in.clip, o, k);
+  for (int j = 0; j < 6; ++j) cov3d[6 * i + j] = c3[j];
+  depths[i] = o.depth;
+  radii[i] = ok ? o.radius : 0;
+  ntiles[i] = ok ? o.ntiles : 0;
+  xys[2 * i] = ok ? o.x : 0.f; xys[2 * i + 1] = ok ? o.y : 0.f;
+  conics[3 * i] = ok ? o.conic_x : 0.f; conics[3 * i + 1] = ok ? o.conic_y : 0.f; conics[3 * i + 2] = ok ? o.conic_z : 0.f;
+  comp[i] = ok ? o.comp : 0.f;
+  if (tbounds) {
+    tbounds[4 * i] = o.tmin_x; tbounds[4 * i + 1] = o.tmin_y; tbounds[4 * i + 2] = o.tmax_x; tbounds[4 * i + 3] = o.tmax_y;
+  }
+}
+
+// block-reduce 12 viewmat-gradient components and add them to v_V (global, atomics)
+__device__ __forceinline__ void reduce_vV(const float vV[12], float* __restrict__ v_V, float* lds /*[4*12]*/) {
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    float t = wave_sum_to_lane63(vV[j]);
+    if (lane == 63) lds[wave * 12 + j] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    float t = lds[threadIdx.x] + lds[12 + threadIdx.x] + lds[24 + threadIdx.x] + lds[36 + threadIdx.x];
+    if (t != 0.f) atomic_add_f32(v_V + threadIdx.x, t);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void project_bwd_kernel(int N, const float* __restrict__ means,
+    const float* __restrict__ scales, float glob, const float* __restrict__ quats, const float* __restrict__ V,
+    Intrin in, const float* __restrict__ v_xys, const float* __restrict__ v_depths,
+    const float* __restrict__ v_conics, const float* __restrict__ v_comp, float* __restrict__ v_means,
+    float* __restrict__ v_scales, float* __restrict__ v_quats, float* __restrict__ v_V) {
+  __shared__ float lds[48];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float vV[12];
+  for (int j = 0; j < 12; ++j) vV[j] = 0.f;
+  if (i < N) {
+    float Vm[12];
+    for (int j = 0; j < 12; ++j) Vm[j] = V[j];
+    float m[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+    float q[4] = {quats[4 * i], quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3]};
+    float R[9], qn[4], inv, M[9], c3[6];
+    quat_to_rotmat(q, R, qn, &inv);
+    scale_rot_to_cov3d(s, glob, R, M, c3);
+    Proj o; ProjCtx k;
+    bool ok = project_one(m, c3, Vm, in.fx, in.fy, in.cx, in.cy, in.W, in.H, in.tiles_x, in.tiles_y, in.clip, o, k);
+    float vm[3] = {0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      float vxy[2] = {v_xys[2 * i], v_xys[2 * i + 1]};
+      float vc[3] = {v_conics[3 * i], v_conics[3 * i + 1], v_conics[3 * i + 2]};
+      float vc3[6];
+      project_one_bwd(m, c3, Vm, in.fx, in.fy, k, o.comp, vxy, v_depths ? v_depths[i] : 0.f, vc,
+                      v_comp ? v_comp[i] : 0.f, vm, vc3, vV);
+      cov3d_bwd(s, glob, q, vc3, vs, vq);
+    }
+    for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = vm[j]; v_scales[3 * i + j] = vs[j]; }
+    for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = vq[j];
+  }
+  if (v_V) reduce_vV(vV, v_V, lds);
+}
+
+// ---------------------------------------------------------------------------
+// spherical harmonics (gsplat.spherical_harmonics compat)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sh_fwd_kernel(int N, int K_stride, int deg, const float* __restrict__ dirs,
+                                                     const float* __restrict__ coeffs, float* __restrict__ colors) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float x = dirs[3 * i], y = dirs[3 * i + 1], z = dirs[3 * i + 2];
+  float inv = 1.0f / sqrtf(x * x + y * y + z * z);
+  float B[25];
+  sh_basis(deg, x * inv, y * inv, z * inv, B);
+  int nb = (deg + 1) * (deg + 1);
+  float r = 0.f, g = 0.f, b = 0.f;
+  const float* c = coeffs + (size_t)i * K_stride * 3;
+#pragma unroll
+  for (int k = 0; k < 25; ++k)
+    if (k < nb) { r += B[k] * c[3 * k]; g += B[k] * c[3 * k + 1]; b += B[k] * c[3 * k + 2]; }
+  colors[3 * i] = r; colors[3 * i + 1] = g; colors[3 * i + 2] = b;
+}
+
+__global__ __launch_bounds__(256) void sh_bwd_kernel(int N, int K_stride, int deg, const float* __restrict__ dirs,
+                                                     const float* __restrict__ v_colors, float* __restrict__ v_coeffs) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float x = dirs[3 * i], y = dirs[3 * i + 1], z = dirs[3 * i + 2];
+  float inv = 1.0f / sqrtf(x * x + y * y + z * z);
+  float B[25];
+  sh_basis(deg, x * inv, y * inv, z * inv, B);
+  int nb = (deg + 1) * (deg + 1);
+  float r = v_colors[3 * i], g = v_colors[3 * i + 1], b = v_colors[3 * i + 2];
+  float* c = v_coeffs + (size_t)i * K_stride * 3;
+#pragma unroll
+  for (int k = 0; k < 25; ++k) {
+    if (k < K_stride) {
+      float bk = k < nb ? B[k] : 0.f;
+      c[3 * k] = bk * r; c[3 * k + 1] = bk * g; c[3 * k + 2] = bk * b;
+    }
+  }
+  for (int k = 25; k < K_stride; ++k) { c[3 * k] = 0.f; c[3 * k + 1] = 0.f; c[3 * k + 2] = 0.f; }
+}
+
+// ---------------------------------------------------------------------------
+// pack gsplat-style arrays into rasterizer records (compat rasterize path) —
+// recomputes the tile bounds from (xy, radius) like upstream's get_tile_bbox.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void tile_bbox(float x, float y, int radius, int tiles_x, int tiles_y, int& x0, int& y0,
+                                          int& x1, int& y1) {
+  const float inv_tile = 1.0f / (float)K::kTile;
+  float radf = (float)radius;
+  float tcx = x * inv_tile, tcy = y * inv_tile, tr = radf * inv_tile;
+  x0 = (int)(tcx - tr); x1 = (int)(tcx + tr + 1.0f);
+  y0 = (int)(tcy - tr); y1 = (int)(tcy + tr + 1.0f);
+  x0 = x0 < 0 ? 0 : (x0 > tiles_x ? tiles_x : x0);
+  x1 = x1 < 0 ? 0 : (x1 > tiles_x ? tiles_x : x1);
+  y0 = y0 < 0 ? 0 : (y0 > tiles_y ? tiles_y : y0);
+  y1 = y1 < 0 ? 0 : (y1 > tiles_y ? tiles_y : y1);
+}
+
+__global__ __launch_bounds__(256) void pack_records_kernel(int N, const float* __restrict__ xys,
+    const float* __restrict__ depths, const int* __restrict__ radii, const float* __restrict__ conics,
+    const float* __restrict__ colors, const float* __restrict__ opacity, int tiles_x, int tiles_y,
+    float* __restrict__ records, unsigned* __restrict__ depth_keys, int* __restrict__ ntiles) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int rad = radii[i];
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  float x = xys[2 * i], y = xys[2 * i + 1];
+  if (rad > 0) tile_bbox(x, y, rad, tiles_x, tiles_y, x0, y0, x1, y1);
+  int area = (x1 - x0) * (y1 - y0);
+  bool ok = rad > 0 && area > 0;
+  float4* r = reinterpret_cast<float4*>(records + (size_t)i * kRecFloats);
+  float d = depths[i];
+  if (ok) {
+    r[0] = make_float4(x, y, conics[3 * i], conics[3 * i + 1]);
+    r[1] = make_float4(conics[3 * i + 2], opacity[i], colors[3 * i], colors[3 * i + 1]);
+    r[2] = make_float4(colors[3 * i + 2], d, __int_as_float(x0 | (y0 << 16)), __int_as_float(x1 | (y1 << 16)));
+  } else {
+    r[0] = make_float4(0.f, 0.f, 0.f, 0.f); r[1] = r[0]; r[2] = r[0];
+  }
+  depth_keys[i] = ok ? (unsigned)__float_as_int(d) : 0xFFFFFFFFu;
+  ntiles[i] = ok ? area : 0;
+}
+
+// unpack record gradients into gsplat-style gradient arrays
+__global__ __launch_bounds__(256) void unpack_grads_kernel(int N, const float* __restrict__ v_records,
+    float* __restrict__ v_xys, float* __restrict__ v_conics, float* __restrict__ v_colors,
+    float* __restrict__ v_opacity) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float4* r = reinterpret_cast<const float4*>(v_records + (size_t)i * kRecFloats);
+  float4 a = r[0], b = r[1], c = r[2];
+  v_xys[2 * i] = a.x; v_xys[2 * i + 1] = a.y;
+  v_conics[3 * i] = a.z; v_conics[3 * i + 1] = a.w; v_conics[3 * i + 2] = b.x;
+  v_opacity[i] = b.y;
+  v_colors[3 * i] = b.z; v_colors[3 * i + 1] = b.w; v_colors[3 * i + 2] = c.x;
+}
+
+// ---------------------------------------------------------------------------
+// fused multi-sub-pose projection: one thread per Gaussian reads its parameters
+// ONCE (means/scales/quats/opacity/SH = 59 floats at degree 3) and projects it
+// under all P sub-pose viewmats, evaluating SH colour per sub-pose view direction
+// and writing one 48-byte rasterizer record per (sub-pose, Gaussian).
+// ---------------------------------------------------------------------------
+struct FusedParams {
+  int N, P;
+  const float* means; const float* scales; const float* quats; const float* opacities;
+  const float* sh;       // [N, K_stride, 3]
+  const float* viewmats; // [P,16]
+  float glob;
+  int K_stride, deg, antialiased;
+  Intrin in;
+};
+
+template <int MAXB>
+__global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, float* __restrict__ records,
+    unsigned* __restrict__ depth_keys, int* __restrict__ ntiles, int* __restrict__ radii) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= fp.N) return;
+  float m[3] = {fp.means[3 * i], fp.means[3 * i + 1], fp.means[3 * i + 2]};
+  float s[3] = {fp.scales[3 * i], fp.scales[3 * i + 1], fp.scales[3 * i + 2]};
+  float q[4] = {fp.quats[4 * i], fp.quats[4 * i + 1], fp.quats[4 * i + 2], fp.quats[4 * i + 3]};
+  float opac = fp.opacities[i];
+  float R[9], qn[4], inv, M[9], c3[6];
+  quat_to_rotmat(q, R, qn, &inv);
+  scale_rot_to_cov3d(s, fp.glob, R, M, c3);
+  const int nb = (fp.deg + 1) * (fp.deg + 1);
+  float coef[MAXB * 3];
+  {
+    const float* c = fp.sh + (size_t)i * fp.K_stride * 3;
+#pragma unroll
+    for (int k = 0; k < MAXB * 3; ++k) coef[k] = (k < nb * 3) ? c[k] : 0.f;
+  }
+  for (int p = 0; p < fp.P; ++p) {
+    const float* V = fp.viewmats + 16 * p;
+    float Vm[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) Vm[j] = V[j];
+    Proj o; ProjCtx k;
+    bool ok = project_one(m, c3, Vm, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x,
+                          fp.in.tiles_y, fp.in.clip, o, k);
+    size_t idx = (size_t)p * fp.N + i;
+    float4* r = reinterpret_cast<float4*>(records + idx * kRecFloats);
+    if (ok) {
+      // camera centre = -R^T t ; view direction = mean - centre (no gradient, like splatfacto's detach)
+      float cxw = -(Vm[0] * Vm[3] + Vm[4] * Vm[7] + Vm[8] * Vm[11]);
+      float cyw = -(Vm[1] * Vm[3] + Vm[5] * Vm[7] + Vm[9] * Vm[11]);
+      float czw = -(Vm[2] * Vm[3] + Vm[6] * Vm[7] + Vm[10] * Vm[11]);
+      float dx = m[0] - cxw, dy = m[1] - cyw, dz = m[2] - czw;
+      float dinv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+      float B[MAXB];
+      sh_basis(fp.deg, dx * dinv, dy * dinv, dz * dinv, B);
+      float cr = 0.5f, cg = 0.5f, cb = 0.5f;
+#pragma unroll
+      for (int b = 0; b < MAXB; ++b) {
+        if (b < nb) { cr += B[b] * coef[3 * b]; cg += B[b] * coef[3 * b + 1]; cb += B[b] * coef[3 * b + 2]; }
+      }
+      cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
+      float op = fp.antialiased ? opac * o.comp : opac;
+      r[0] = make_float4(o.x, o.y, o.conic_x, o.conic_y);
+      r[1] = make_float4(o.conic_z, op, cr, cg);
+      r[2] = make_float4(cb, o.depth, __int_as_float(o.tmin_x | (o.tmin_y << 16)),
+                         __int_as_float(o.tmax_x | (o.tmax_y << 16)));
+    } else {
+      float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      r[0] = z; r[1] = z; r[2] = z;
+    }
+    depth_keys[idx] = ok ? (unsigned)__float_as_int(o.depth) : 0xFFFFFFFFu;
+    ntiles[idx] = ok ? o.ntiles : 0;
+    if (radii) radii[idx] = ok ? o.radius : 0;
+  }
+}
+
+template <int MAXB>
+__global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, const float* __restrict__ records,
+    const float* __restrict__ v_records, float* __restrict__ v_means, float* __restrict__ v_scales,
+    float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
+    float* __restrict__ v_viewmats /* [P,16] accumulated, may be null */) {
+  __shared__ float lds[48];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < fp.N;
+  const int ii = live ? i : 0;
+  float m[3] = {fp.means[3 * ii], fp.means[3 * ii + 1], fp.means[3 * ii + 2]};
+  float s[3] = {fp.scales[3 * ii], fp.scales[3 * ii + 1], fp.scales[3 * ii + 2]};
+  float q[4] = {fp.quats[4 * ii], fp.quats[4 * ii + 1], fp.quats[4 * ii + 2], fp.quats[4 * ii + 3]};
+  float opac = fp.opacities[ii];
+  float R[9], qn[4], inv, M[9], c3[6];
+  quat_to_rotmat(q, R, qn, &inv);
+  scale_rot_to_cov3d(s, fp.glob, R, M, c3);
+  const int nb = (fp.deg + 1) * (fp.deg + 1);
+  float vcoef[MAXB * 3];
+#pragma unroll
+  for (int k = 0; k < MAXB * 3; ++k) vcoef[k] = 0.f;
+  float vm[3] = {0.f, 0.f, 0.f}, vc3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vop = 0.f;
+  for (int p = 0; p < fp.P; ++p) {
+    const float* V = fp.viewmats + 16 * p;
+    float Vm[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) Vm[j] = V[j];
+    float vV[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) vV[j] = 0.f;
+    if (live) {
+      Proj o; ProjCtx k;
+      bool ok = project_one(m, c3, Vm, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x,
+                            fp.in.tiles_y, fp.in.clip, o, k);
+      if (ok) {
+        size_t idx = (size_t)p * fp.N + i;
+        const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kRecFloats);
+        float4 ga = g4[0], gb = g4[1], gc = g4[2];
+        const float4* r4 = reinterpret_cast<const float4*>(records + idx * kRecFloats);
+        float4 rb = r4[1], rc = r4[2];
+        // colour: rgb = max(SH + 0.5, 0)
+        float vr = rb.z > 0.f ? gb.z : 0.f, vg = rb.w > 0.f ? gb.w : 0.f, vb = rc.x > 0.f ? gc.x : 0.f;
+        if (vr != 0.f || vg != 0.f || vb != 0.f) {
+          float cxw = -(Vm[0] * Vm[3] + Vm[4] * Vm[7] + Vm[8] * Vm[11]);
+          float cyw = -(Vm[1] * Vm[3] + Vm[5] * Vm[7] + Vm[9] * Vm[11]);
+          float czw = -(Vm[2] * Vm[3] + Vm[6] * Vm[7] + Vm[10] * Vm[11]);
+          float dx = m[0] - cxw, dy = m[1] - cyw, dz = m[2] - czw;
+          float dinv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+          float B[MAXB];
+          sh_basis(fp.deg, dx * dinv, dy * dinv, dz * dinv, B);
+#pragma unroll
+          for (int b = 0; b < MAXB; ++b) {
+            if (b < nb) { vcoef[3 * b] += B[b] * vr; vcoef[3 * b + 1] += B[b] * vg; vcoef[3 * b + 2] += B[b] * vb; }
+          }
+        }
+        float v_comp = 0.f;
+        if (fp.antialiased) { vop += gb.y * o.comp; v_comp = gb.y * opac; } else { vop += gb.y; }
+        float vxy[2] = {ga.x, ga.y};
+        float vcon[3] = {ga.z, ga.w, gb.x};
+        float vm1[3], vc31[6];
+        project_one_bwd(m, c3, Vm, fp.in.fx, fp.in.fy, k, o.comp, vxy, 0.f, vcon, v_comp, vm1, vc31, vV);
+        for (int j = 0; j < 3; ++j) vm[j] += vm1[j];
+        for (int j = 0; j < 6; ++j) vc3[j] += vc31[j];
+      }
+    }
+    if (v_viewmats) reduce_vV(vV, v_viewmats + 16 * p, lds);
+  }
+  if (!live) return;
+  float vs[3], vq[4];
+  cov3d_bwd(s, fp.glob, q, vc3, vs, vq);
+  for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = vm[j]; v_scales[3 * i + j] = vs[j]; }
+  for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = vq[j];
+  v_opac[i] = vop;
+  float* c = v_sh + (size_t)i * fp.K_stride * 3;
+  const int kn = fp.K_stride * 3;
+#pragma unroll
+  for (int k = 0; k < MAXB * 3; ++k)   // static indices only: a runtime index would push vcoef to scratch
+    if (k < kn) c[k] = vcoef[k];
+  for (int k = MAXB * 3; k < kn; ++k) c[k] = 0.f;
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+static inline Intrin make_intrin(float fx, float fy, float cx, float cy, int H, int W, float clip) {
+  Intrin in;
+  in.fx = fx; in.fy = fy; in.cx = cx; in.cy = cy; in.W = W; in.H = H;
+  in.tiles_x = (W + K::kTile - 1) / K::kTile; in.tiles_y = (H + K::kTile - 1) / K::kTile; in.clip = clip;
+  return in;
+}
+
+// C ABI -------------------------------------------------------------------------
+GS_EXPORT int gs_subpose_viewmats_fwd(int P, const float* viewmat, const float* lin_vel, const float* ang_vel,
+                                      const float* times, float* out_viewmats, void* stream) {
+  if (P <= 0) return GS_ERR_INVALID;
+  hipLaunchKernelGGL(subpose_fwd_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, viewmat, lin_vel,
+                     ang_vel, times, out_viewmats);
+  return gs_launch_status();
+}
+
+// v_viewmat[16], v_lin[3], v_ang[3] are ACCUMULATED into (caller zeroes).
+GS_EXPORT int gs_subpose_viewmats_bwd(int P, const float* viewmat, const float* lin_vel, const float* ang_vel,
+                                      const float* times, const float* v_out, float* v_viewmat, float* v_lin,
+                                      float* v_ang, void* stream) {
+  if (P <= 0) return GS_ERR_INVALID;
+  hipLaunchKernelGGL(subpose_bwd_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, viewmat, lin_vel,
+                     ang_vel, times, v_out, v_viewmat, v_lin, v_ang);
+  return gs_launch_status();
+}
+
+// gsplat.project_gaussians forward (device side).  tile_bounds [N,4] may be null.
+GS_EXPORT int gs_project_fwd(int N, const float* means, const float* scales, float glob_scale, const float* quats,
+                             const float* viewmat, float fx, float fy, float cx, float cy, int H, int W, float clip,
+                             float* xys, float* depths, int* radii, float* conics, float* comp, int* num_tiles_hit,
+                             float* cov3d, int* tile_bounds, void* stream) {
+  if (N <= 0) return GS_ERR_INVALID;
+  Intrin in = make_intrin(fx, fy, cx, cy, H, W, clip);
+  hipLaunchKernelGGL(project_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, means, scales,
+                     glob_scale, quats, viewmat, in, xys, depths, radii, conics, comp, num_tiles_hit, cov3d,
+                     tile_bounds);
+  return gs_launch_status();
+}
+
+// gsplat.project_gaussians backward.  v_viewmat[16] (rows 0..2 used) is accumulated into; may be null.
+GS_EXPORT int gs_project_bwd(int N, const float* means, const float* scales, float glob_scale, const float* quats,
+                             const float* viewmat, float fx, float fy, float cx, float cy, int H, int W, float clip,
+                             const float* v_xys, const float* v_depths, const float* v_conics, const float* v_comp,
+                             float* v_means, float* v_scales, float* v_quats, float* v_viewmat, void* stream) {
+  if (N <= 0) return GS_ERR_INVALID;
+  Intrin in = make_intrin(fx, fy, cx, cy, H, W, clip);
+  hipLaunchKernelGGL(project_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, means, scales,
+                     glob_scale, quats, viewmat, in, v_xys, v_depths, v_conics, v_comp, v_means, v_scales, v_quats,
+                     v_viewmat);
+  return gs_launch_status();
+}
+
+GS_EXPORT int gs_sh_fwd(int N, int K_stride, int degrees_to_use, const float* dirs, const float* coeffs,
+                        float* colors, void* stream) {
+  if (N <= 0 || degrees_to_use < 0 || degrees_to_use > 4 || (degrees_to_use + 1) * (degrees_to_use + 1) > K_stride)
+    return GS_ERR_INVALID;
+  hipLaunchKernelGGL(sh_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, K_stride,
+                     degrees_to_use, dirs, coeffs, colors);
+  return gs_launch_status();
+}
+
+GS_EXPORT int gs_sh_bwd(int N, int K_stride, int degrees_to_use, const float* dirs, const float* v_colors,
+                        float* v_coeffs, void* stream) {
+  if (N <= 0 || degrees_to_use < 0 || degrees_to_use > 4 || (degrees_to_use + 1) * (degrees_to_use + 1) > K_stride)
+    return GS_ERR_INVALID;
+  hipLaunchKernelGGL(sh_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, K_stride,
+                     degrees_to_use, dirs, v_colors, v_coeffs);
+  return gs_launch_status();
+}
+
+GS_EXPORT int gs_pack_records(int N, const float* xys, const float* depths, const int* radii, const float* conics,
+                              const float* colors, const float* opacity, int H, int W, float* records,
+                              unsigned* depth_keys, int* ntiles, void* stream) {
+  if (N <= 0) return GS_ERR_INVALID;
+  int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
+  hipLaunchKernelGGL(pack_records_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, xys, depths,
+                     radii, conics, colors, opacity, tiles_x, tiles_y, records, depth_keys, ntiles);
+  return gs_launch_status();
+}
+
+GS_EXPORT int gs_unpack_record_grads(int N, const float* v_records, float* v_xys, float* v_conics, float* v_colors,
+                                     float* v_opacity, void* stream) {
+  if (N <= 0) return GS_ERR_INVALID;
+  hipLaunchKernelGGL(unpack_grads_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, v_records,
+                     v_xys, v_conics, v_colors, v_opacity);
+  return gs_launch_status();
+}
+
+static inline FusedParams make_fused(int N, int P, const float* means, const float* scales, float glob,
+                                     const float* quats, const float* opac, const float* sh, int K_stride, int deg,
+                                     const float* viewmats, float fx, float fy, float cx, float cy, int H, int W,
+                                     float clip, int antialiased) {
+  FusedParams fp;
+  fp.N = N; fp.P = P; fp.means = means; fp.scales = scales; fp.quats = quats; fp.opacities = opac; fp.sh = sh;
+  fp.viewmats = viewmats; fp.glob = glob; fp.K_stride = K_stride; fp.deg = deg; fp.antialiased = antialiased;
+  fp.in = make_intrin(fx, fy, cx, cy, H, W, clip);
+  return fp;
+}
+
+// Fused projection of N Gaussians under P sub-pose viewmats (+SH colour, antialiased opacity).
+//   records    [P*N*12] f32, depth_keys [P*N] u32, num_tiles_hit [P*N] i32, radii [P*N] i32 (nullable)
+GS_EXPORT int gs_project_fused_fwd(int N, int P, const float* means, const float* scales, float glob_scale,
+                                   const float* quats, const float* opacities, const float* sh, int K_stride,
+                                   int sh_degree, const float* viewmats, float fx, float fy, float cx, float cy,
+                                   int H, int W, float clip, int antialiased, float* records, unsigned* depth_keys,
+                                   int* num_tiles_hit, int* radii, void* stream) {
+  if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride)
+    return GS_ERR_INVALID;
+  FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmats,
+                              fx, fy, cx, cy, H, W, clip, antialiased);
+  dim3 grid((N + 255) / 256), block(256);
+  if (sh_degree <= 3)
+    hipLaunchKernelGGL(project_fused_fwd_kernel<16>, grid, block, 0, (hipStream_t)stream, fp, records, depth_keys,
+                       num_tiles_hit, radii);
+  else
+    hipLaunchKernelGGL(project_fused_fwd_kernel<25>, grid, block, 0, (hipStream_t)stream, fp, records, depth_keys,
+                       num_tiles_hit, radii);
+  return gs_launch_status();
+}
+
+// Backward of the fused projection.  v_viewmats [P,16] is accumulated into (caller zeroes; nullable).
+GS_EXPORT int gs_project_fused_bwd(int N, int P, const float* means, const float* scales, float glob_scale,
+                                   const float* quats, const float* opacities, const float* sh, int K_stride,
+                                   int sh_degree, const float* viewmats, float fx, float fy, float cx, float cy,
+                                   int H, int W, float clip, int antialiased, const float* records,
+                                   const float* v_records, float* v_means, float* v_scales, float* v_quats,
+                                   float* v_opacities, float* v_sh, float* v_viewmats, void* stream) {
+  if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride)
+    return GS_ERR_INVALID;
+  FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmats,
+                              fx, fy, cx, cy, H, W, clip, antialiased);
+  dim3 grid((N + 255) / 256), block(256);
+  if (sh_degree <= 3)
+    hipLaunchKernelGGL(project_fused_bwd_kernel<16>, grid, block, 0, (hipStream_t)stream, fp, records, v_records,
+                       v_means, v_scales, v_quats, v_opacities, v_sh, v_viewmats);
+  else
+    hipLaunchKernelGGL(project_fused_bwd_kernel<25>, grid, block, 0, (hipStream_t)stream, fp, records, v_records,
+                       v_means, v_scales, v_quats, v_opacities, v_sh, v_viewmats);
+  return gs_launch_status();
+}

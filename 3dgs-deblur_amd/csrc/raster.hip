@@ -1,0 +1,372 @@
+// raster.hip — per-pixel front-to-back alpha compositing (forward) and its
+// reverse-order backward, written for gfx950 / wave64.
+//
+// Restates (absent fork sources) gsplat's rasterize_forward /
+// rasterize_backward_kernel as recollected in SURVEY.md App. A "Blend" and
+// "Backward"; constants in gs::K (gs_math.h).
+//
+// MI355X design (not the CUDA 256-thread-block/shared-memory tiling):
+//   * one wave64 owns one 16x16 tile; each lane owns a 1x4 pixel column segment
+//     (x = lane&15, y = 4*(lane>>4)+k).  No LDS, no __syncthreads: the 64
+//     Gaussians of a batch live one-per-lane in VGPRs and are broadcast with
+//     v_readlane_b32 into SGPRs, so the per-pair math reads uniform operands
+//     from the scalar file.
+//   * dx is shared by a lane's 4 pixels.
+//   * early termination is a wave ballot.
+//   * backward: a lane pre-sums its 4 pixels, one 6-step DPP wave reduction per
+//     gradient component per (Gaussian, tile), the total is parked in the lane
+//     that owns the Gaussian, and every lane issues its own 9 fp32 atomics after
+//     the batch (64 distinct addresses per instruction, no same-address storms).
+#include "gs_common.h"
+
+namespace gs {
+
+struct RasterParams {
+  const float* records;      // [P*N, 12]
+  const int*   sorted_vals;  // [I]   p*N+g, sorted by (p*T+tile, depth)
+  const int2*  tile_bins;    // [P*T]
+  const int*   band_edges;   // [R+1] tile-row edges of the rolling-shutter bands
+  const float* background;   // [3]
+  int S, R, H, W, tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ int find_band(const int* __restrict__ edges, int R, int ty) {
+  int r = 0;
+  while (r + 1 < R && ty >= edges[r + 1]) ++r;
+  return r;
+}
+
+struct Rec9 { float x, y, cx, cy, cz, op, r, g, b; };
+
+__device__ __forceinline__ Rec9 load_rec(const float* __restrict__ records, int gid, bool valid) {
+  Rec9 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    const float4* p = reinterpret_cast<const float4*>(records + (size_t)gid * kRecFloats);
+    float4 a = p[0], b = p[1], c = p[2];
+    o.x = a.x; o.y = a.y; o.cx = a.z; o.cy = a.w;
+    o.cz = b.x; o.op = b.y; o.r = b.z; o.g = b.w;
+    o.b = c.x;
+  }
+  return o;
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void raster_fwd_kernel(RasterParams prm, float* __restrict__ out_img,
+                                                         float* __restrict__ out_T, int* __restrict__ final_idx,
+                                                         unsigned n_blocks) {
+  const int lane = lane_id();
+  const int T = prm.tiles_x * prm.tiles_y;
+  const unsigned work = xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6);
+  if (work >= (unsigned)(prm.S * T)) return;
+  const int s = work / T, t = work % T;
+  const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
+  const int p = s * prm.R + find_band(prm.band_edges, prm.R, ty);
+  const int2 range = prm.tile_bins[(size_t)p * T + t];
+
+  const int px = tx * K::kTile + (lane & 15);
+  const int py0 = ty * K::kTile + (lane >> 4) * 4;
+  const float pxf = (float)px + 0.5f;
+  float Tk[4], Cr[4], Cg[4], Cb[4];
+  int last[4];
+  bool done[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    Tk[k] = 1.f; Cr[k] = Cg[k] = Cb[k] = 0.f; last[k] = range.x;
+    done[k] = !(px < prm.W && (py0 + k) < prm.H);
+  }
+
+  const int* __restrict__ vals = prm.sorted_vals;
+  // software pipeline: ids two batches ahead, records one batch ahead
+  int id_next = 0;
+  {
+    int i0 = range.x + lane;
+    id_next = i0 < range.y ? vals[i0] : 0;
+  }
+  Rec9 rec_next = load_rec(prm.records, id_next, (range.x + lane) < range.y);
+  {
+    int i1 = range.x + 64 + lane;
+    id_next = i1 < range.y ? vals[i1] : 0;
+  }
+
+  for (int batch = range.x; batch < range.y; batch += 64) {
+    if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
+    Rec9 rec = rec_next;
+    // prefetch the following batch
+    rec_next = load_rec(prm.records, id_next, (batch + 64 + lane) < range.y);
+    {
+      int i2 = batch + 128 + lane;
+      id_next = i2 < range.y ? vals[i2] : 0;
+    }
+    const int n = min(64, range.y - batch);
+    for (int j = 0; j < n; ++j) {
+      if ((j & 7) == 0 && j && __ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
+      const float gx = readlane_f(rec.x, j), gy = readlane_f(rec.y, j);
+      const float cx = readlane_f(rec.cx, j), cy = readlane_f(rec.cy, j), cz = readlane_f(rec.cz, j);
+      const float op = readlane_f(rec.op, j);
+      const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
+      const float dx = gx - pxf;
+      const float hx = 0.5f * cx * dx * dx;   // shared by the lane's 4 pixels
+      const float bx = cy * dx;
+      const float hz = 0.5f * cz;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!done[k]) {
+          const float dy = gy - ((float)(py0 + k) + 0.5f);
+          const float sigma = hx + dy * (bx + hz * dy);
+          if (sigma >= 0.f) {
+            const float alpha = fminf(K::kAlphaMax, op * __expf(-sigma));
+            if (alpha >= K::kAlphaMin) {
+              const float nT = Tk[k] * (1.f - alpha);
+              if (nT <= K::kTMin) {
+                done[k] = true;
+              } else {
+                const float w = alpha * Tk[k];
+                Cr[k] += w * cr; Cg[k] += w * cg; Cb[k] += w * cb;
+                Tk[k] = nT;
+                last[k] = batch + j + 1;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  const float bgr = prm.background[0], bgg = prm.background[1], bgb = prm.background[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = py0 + k;
+    if (px < prm.W && y < prm.H) {
+      size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
+      out_img[pix * 3 + 0] = Cr[k] + Tk[k] * bgr;
+      out_img[pix * 3 + 1] = Cg[k] + Tk[k] * bgg;
+      out_img[pix * 3 + 2] = Cb[k] + Tk[k] * bgb;
+      out_T[pix] = Tk[k];
+      final_idx[pix] = last[k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void raster_bwd_kernel(RasterParams prm, const float* __restrict__ out_T,
+                                                         const int* __restrict__ final_idx,
+                                                         const float* __restrict__ v_img,
+                                                         const float* __restrict__ v_alpha,  // may be null
+                                                         float* __restrict__ v_records, unsigned n_blocks) {
+  const int lane = lane_id();
+  const int T = prm.tiles_x * prm.tiles_y;
+  const unsigned work = xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6);
+  if (work >= (unsigned)(prm.S * T)) return;
+  const int s = work / T, t = work % T;
+  const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
+  const int p = s * prm.R + find_band(prm.band_edges, prm.R, ty);
+  const int2 range = prm.tile_bins[(size_t)p * T + t];
+  if (range.y <= range.x) return;
+
+  const int px = tx * K::kTile + (lane & 15);
+  const int py0 = ty * K::kTile + (lane >> 4) * 4;
+  const float pxf = (float)px + 0.5f;
+  const float bgr = prm.background[0], bgg = prm.background[1], bgb = prm.background[2];
+
+  float Tk[4], Tfin[4], Br[4], Bg[4], Bb[4], vr[4], vg[4], vb[4], va[4];
+  int fin[4];
+  int my_end = range.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = py0 + k;
+    Br[k] = Bg[k] = Bb[k] = 0.f;
+    if (px < prm.W && y < prm.H) {
+      size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
+      Tfin[k] = out_T[pix];
+      fin[k] = final_idx[pix];
+      vr[k] = v_img[pix * 3 + 0]; vg[k] = v_img[pix * 3 + 1]; vb[k] = v_img[pix * 3 + 2];
+      float va_out = v_alpha ? v_alpha[pix] : 0.f;
+      // d(out)/d(alpha_i) carries T_final/(1-alpha_i) * (v_alpha_out - sum_c bg_c v_c)
+      va[k] = Tfin[k] * (va_out - (bgr * vr[k] + bgg * vg[k] + bgb * vb[k]));
+    } else {
+      Tfin[k] = 1.f; fin[k] = range.x; vr[k] = vg[k] = vb[k] = 0.f; va[k] = 0.f;
+    }
+    Tk[k] = Tfin[k];
+    my_end = max(my_end, fin[k]);
+  }
+  const int wave_end = wave_max_i(my_end);
+  const int* __restrict__ vals = prm.sorted_vals;
+
+  for (int batch_end = wave_end; batch_end > range.x; batch_end -= 64) {
+    const int idx = batch_end - 1 - lane;
+    const bool valid = idx >= range.x;
+    const int gid = valid ? vals[idx] : 0;
+    const Rec9 rec = load_rec(prm.records, gid, valid);
+    float a_x = 0.f, a_y = 0.f, a_cx = 0.f, a_cy = 0.f, a_cz = 0.f, a_op = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
+    const int n = min(64, batch_end - range.x);
+    for (int j = 0; j < n; ++j) {
+      const int idx_j = batch_end - 1 - j;
+      const float gx = readlane_f(rec.x, j), gy = readlane_f(rec.y, j);
+      const float cx = readlane_f(rec.cx, j), cy = readlane_f(rec.cy, j), cz = readlane_f(rec.cz, j);
+      const float op = readlane_f(rec.op, j);
+      const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
+      const float dx = gx - pxf;
+      const float hx = 0.5f * cx * dx * dx;
+      const float bx = cy * dx;
+      const float hz = 0.5f * cz;
+      float p_x = 0.f, p_y = 0.f, p_cx = 0.f, p_cy = 0.f, p_cz = 0.f, p_op = 0.f, p_r = 0.f, p_g = 0.f, p_b = 0.f;
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (idx_j < fin[k]) {
+          const float dy = gy - ((float)(py0 + k) + 0.5f);
+          const float sigma = hx + dy * (bx + hz * dy);
+          if (sigma >= 0.f) {
+            const float vis = __expf(-sigma);
+            const float ov = op * vis;
+            const float alpha = fminf(K::kAlphaMax, ov);
+            if (alpha >= K::kAlphaMin) {
+              any = true;
+              const float ra = 1.f / (1.f - alpha);
+              Tk[k] *= ra;                       // transmittance in front of this Gaussian
+              const float fac = alpha * Tk[k];
+              p_r += fac * vr[k]; p_g += fac * vg[k]; p_b += fac * vb[k];
+              float v_al = (cr * Tk[k] - Br[k] * ra) * vr[k] + (cg * Tk[k] - Bg[k] * ra) * vg[k] +
+                           (cb * Tk[k] - Bb[k] * ra) * vb[k] + va[k] * ra;
+              Br[k] += cr * fac; Bg[k] += cg * fac; Bb[k] += cb * fac;
+              if (ov <= K::kAlphaMax) {          // d min(0.999, o*vis) = 0 when clamped
+                const float v_sigma = -ov * v_al;
+                p_op += vis * v_al;
+                p_cx += 0.5f * v_sigma * dx * dx;
+                p_cy += v_sigma * dx * dy;
+                p_cz += 0.5f * v_sigma * dy * dy;
+                p_x += v_sigma * (cx * dx + cy * dy);
+                p_y += v_sigma * (cy * dx + cz * dy);
+              }
+            }
+          }
+        }
+      }
+      if (__ballot(any) == 0ull) continue;
+      const float t_x = wave_sum_uniform(p_x), t_y = wave_sum_uniform(p_y);
+      const float t_cx = wave_sum_uniform(p_cx), t_cy = wave_sum_uniform(p_cy), t_cz = wave_sum_uniform(p_cz);
+      const float t_op = wave_sum_uniform(p_op);
+      const float t_r = wave_sum_uniform(p_r), t_g = wave_sum_uniform(p_g), t_b = wave_sum_uniform(p_b);
+      if (lane == j) {
+        a_x = t_x; a_y = t_y; a_cx = t_cx; a_cy = t_cy; a_cz = t_cz; a_op = t_op; a_r = t_r; a_g = t_g; a_b = t_b;
+      }
+    }
+    if (valid) {
+      float* dst = v_records + (size_t)gid * kRecFloats;
+      if (a_x != 0.f) atomic_add_f32(dst + 0, a_x);
+      if (a_y != 0.f) atomic_add_f32(dst + 1, a_y);
+      if (a_cx != 0.f) atomic_add_f32(dst + 2, a_cx);
+      if (a_cy != 0.f) atomic_add_f32(dst + 3, a_cy);
+      if (a_cz != 0.f) atomic_add_f32(dst + 4, a_cz);
+      if (a_op != 0.f) atomic_add_f32(dst + 5, a_op);
+      if (a_r != 0.f) atomic_add_f32(dst + 6, a_r);
+      if (a_g != 0.f) atomic_add_f32(dst + 7, a_g);
+      if (a_b != 0.f) atomic_add_f32(dst + 8, a_b);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// sub-frame averaging in linearised colour:
+//   out = ( mean_k max(C_k, m)^gamma )^(1/gamma),  m = min_rgb_level/255
+// ---------------------------------------------------------------------------
+__global__ void combine_fwd_kernel(int S, size_t n, const float* __restrict__ samples, float gamma, float m,
+                                   float* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int k = 0; k < S; ++k) {
+    float c = samples[(size_t)k * n + i];
+    if (m > 0.f) c = fmaxf(c, m);
+    if (gamma != 1.f) c = __powf(fmaxf(c, 1e-12f), gamma);
+    acc += c;
+  }
+  acc *= 1.f / (float)S;
+  out[i] = gamma != 1.f ? __powf(acc, 1.f / gamma) : acc;
+}
+
+__global__ void combine_bwd_kernel(int S, size_t n, const float* __restrict__ samples, float gamma, float m,
+                                   const float* __restrict__ out, const float* __restrict__ v_out,
+                                   float* __restrict__ v_samples) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float vo = v_out[i];
+  const float invS = 1.f / (float)S;
+  // d out / d mean = (1/gamma) mean^(1/gamma - 1) = out^(1-gamma) / gamma
+  float d_mean = 1.f;
+  if (gamma != 1.f) d_mean = __powf(fmaxf(out[i], 1e-12f), 1.f - gamma) / gamma;
+  for (int k = 0; k < S; ++k) {
+    float c = samples[(size_t)k * n + i];
+    float g = vo * d_mean * invS;
+    if (m > 0.f && c < m) g = 0.f;
+    if (gamma != 1.f) {
+      float cc = fmaxf(m > 0.f ? fmaxf(c, m) : c, 1e-12f);
+      g *= gamma * __powf(cc, gamma - 1.f);
+      if (c < 1e-12f) g = 0.f;
+    }
+    v_samples[(size_t)k * n + i] = g;
+  }
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+// C ABI -----------------------------------------------------------------------
+// Replaces the device side of gsplat.rasterize_gaussians' forward
+// (_C.rasterize_forward in the absent fork; SURVEY.md §8 a7, boundary §8b).
+GS_EXPORT int gs_rasterize_fwd(const float* records, const int* sorted_vals, const int* tile_bins,
+                               const int* band_edges, const float* background, int S, int R, int H, int W,
+                               float* out_img, float* out_T, int* final_idx, void* stream) {
+  if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
+  RasterParams prm;
+  prm.records = records; prm.sorted_vals = sorted_vals; prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
+  prm.band_edges = band_edges; prm.background = background;
+  prm.S = S; prm.R = R; prm.H = H; prm.W = W;
+  prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
+  unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
+  unsigned blocks = (work + 3) / 4;
+  hipLaunchKernelGGL(raster_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_img, out_T,
+                     final_idx, blocks);
+  return gs_launch_status();
+}
+
+// Replaces _C.rasterize_backward.  v_records must be zeroed by the caller;
+// gradients are accumulated with fp32 atomics.
+GS_EXPORT int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* tile_bins,
+                               const int* band_edges, const float* background, int S, int R, int H, int W,
+                               const float* out_T, const int* final_idx, const float* v_img, const float* v_alpha,
+                               float* v_records, void* stream) {
+  if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
+  RasterParams prm;
+  prm.records = records; prm.sorted_vals = sorted_vals; prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
+  prm.band_edges = band_edges; prm.background = background;
+  prm.S = S; prm.R = R; prm.H = H; prm.W = W;
+  prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
+  unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
+  unsigned blocks = (work + 3) / 4;
+  hipLaunchKernelGGL(raster_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T, final_idx,
+                     v_img, v_alpha, v_records, blocks);
+  return gs_launch_status();
+}
+
+GS_EXPORT int gs_combine_fwd(int S, long long n, const float* samples, float gamma, float min_level,
+                             float* out, void* stream) {
+  if (S <= 0 || n <= 0) return GS_ERR_INVALID;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(combine_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, (size_t)n, samples,
+                     gamma, min_level, out);
+  return gs_launch_status();
+}
+
+GS_EXPORT int gs_combine_bwd(int S, long long n, const float* samples, float gamma, float min_level,
+                             const float* out, const float* v_out, float* v_samples, void* stream) {
+  if (S <= 0 || n <= 0) return GS_ERR_INVALID;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(combine_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, (size_t)n, samples,
+                     gamma, min_level, out, v_out, v_samples);
+  return gs_launch_status();
+}

@@ -1,0 +1,250 @@
+"""Splatfacto-style model surface over the HIP hot path.
+
+Mirrors what the reference needs from the nerfstudio fork's ``SplatfactoModel``
+(absent submodule, /root/reference/.gitmodules:1-3):
+  * config fields set by /root/reference/train.py:14-22,40,46-70,119-120
+    (rasterize_mode, blur_samples, rolling_shutter_compensation, gamma, min_rgb_level,
+    camera_optimizer.mode, camera_velocity_optimizer.*, background_color, ...)
+  * ``get_outputs_for_camera(camera=...)`` returning ``rgb`` and ``depth`` and honouring
+    ``camera.metadata['cam_idx']``                      (/root/reference/render_model.py:216-219)
+  * per-frame ``camera_linear_velocity`` / ``camera_angular_velocity`` in the (OpenGL) camera
+    frame plus scene-level ``exposure_time`` / ``rolling_shutter_time``
+    (/root/reference/process_synthetic_inputs.py:113-129,157-176).
+Only the forward/backward rendering surface is here; densification, the trainer, data
+managers and the viewer are out of scope.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+
+
+@dataclass
+class CameraOptimizerConfig:
+    mode: str = "off"  # "off" | "SO3xR3"   (train.py:40)
+
+
+@dataclass
+class CameraVelocityOptimizerConfig:
+    enabled: bool = False                 # train.py:66
+    zero_initial_velocities: bool = False  # train.py:70
+
+
+@dataclass
+class SplatfactoDeblurConfig:
+    sh_degree: int = 3
+    rasterize_mode: str = "antialiased"      # train.py:119 ("classic" disables the compensation factor)
+    use_scale_regularization: bool = False   # train.py:120 (loss-side; carried for CLI parity)
+    blur_samples: int = 5                    # train.py:46,51 ; 0 disables motion-blur sampling
+    rolling_shutter_compensation: bool = True  # train.py:56
+    rs_bands: int = 10                       # row bands per frame when rolling-shutter compensation is on
+    gamma: float = 2.2                       # train.py:62 (gamma=1 when gamma correction is off)
+    min_rgb_level: float = 0.0               # train.py:60 (10 with gamma correction)
+    background_color: str = "black"          # train.py:17 ("auto" = learnable)
+    num_downscales: int = 0                  # train.py:14 (resolution schedule lives in the trainer)
+    cull_scale_thresh: float = 0.5           # train.py:18 (densification; carried for CLI parity)
+    optimize_eval_velocities: bool = True    # train.py:20
+    output_depth_during_training: bool = False
+    camera_optimizer: CameraOptimizerConfig = field(default_factory=CameraOptimizerConfig)
+    camera_velocity_optimizer: CameraVelocityOptimizerConfig = field(default_factory=CameraVelocityOptimizerConfig)
+
+
+@dataclass
+class Camera:
+    """Minimal stand-in for nerfstudio's Cameras (one camera).  camera_to_world uses the dataset's
+    OpenGL convention (-z forward, +y up; process_synthetic_inputs.py:230-238)."""
+    camera_to_world: Tensor  # [3,4] or [4,4]
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    width: int
+    height: int
+    metadata: Dict = field(default_factory=dict)  # cam_idx, camera_linear_velocity, camera_angular_velocity,
+    #                                               exposure_time, rolling_shutter_time
+
+
+def _skew(w: Tensor) -> Tensor:
+    z = torch.zeros((), device=w.device, dtype=w.dtype)
+    return torch.stack([torch.stack([z, -w[2], w[1]]), torch.stack([w[2], z, -w[0]]), torch.stack([-w[1], w[0], z])])
+
+
+def _so3_exp(w: Tensor) -> Tensor:
+    th2 = (w * w).sum()
+    K = _skew(w)
+    eye = torch.eye(3, device=w.device, dtype=w.dtype)
+    small = th2 < 1e-10
+    th = torch.sqrt(torch.clamp(th2, min=1e-20))
+    A = torch.where(small, 1.0 - th2 / 6.0, torch.sin(th) / th)
+    B = torch.where(small, 0.5 - th2 / 24.0, (1.0 - torch.cos(th)) / torch.clamp(th2, min=1e-20))
+    return eye + A * K + B * (K @ K)
+
+
+class SplatfactoDeblurModel(nn.Module):
+    """Gaussian parameters + ``get_outputs`` through the fused HIP path."""
+
+    def __init__(self, config: SplatfactoDeblurConfig, means: Tensor, log_scales: Tensor, quats: Tensor,
+                 opacity_logits: Tensor, features_dc: Tensor, features_rest: Tensor, num_cameras: int = 1):
+        super().__init__()
+        self.config = config
+        # parameter names follow splatfacto's gauss_params
+        self.means = nn.Parameter(means.float())
+        self.scales = nn.Parameter(log_scales.float())
+        self.quats = nn.Parameter(quats.float())
+        self.opacities = nn.Parameter(opacity_logits.float().reshape(-1, 1))
+        self.features_dc = nn.Parameter(features_dc.float())
+        self.features_rest = nn.Parameter(features_rest.float())
+        if config.background_color == "auto":
+            self.background_param = nn.Parameter(torch.zeros(3))
+        else:
+            self.background_param = None
+        self.num_cameras = num_cameras
+        if config.camera_optimizer.mode == "SO3xR3":
+            self.pose_adjustment = nn.Parameter(torch.zeros(num_cameras, 6))
+        elif config.camera_optimizer.mode == "off":
+            self.pose_adjustment = None
+        else:
+            raise ValueError(f"unknown camera_optimizer.mode {config.camera_optimizer.mode!r}")
+        if config.camera_velocity_optimizer.enabled:
+            self.velocity_adjustment = nn.Parameter(torch.zeros(num_cameras, 6))
+        else:
+            self.velocity_adjustment = None
+        self.radii: Optional[Tensor] = None
+        self.last_samples: Optional[Tensor] = None
+
+    # -- splatfacto-style accessors ------------------------------------------------
+    @property
+    def num_points(self) -> int:
+        return self.means.shape[0]
+
+    def gauss_params(self) -> Dict[str, nn.Parameter]:
+        return {"means": self.means, "scales": self.scales, "quats": self.quats, "opacities": self.opacities,
+                "features_dc": self.features_dc, "features_rest": self.features_rest}
+
+    def _background(self, device) -> Tensor:
+        c = self.config.background_color
+        if c == "auto":
+            return torch.sigmoid(self.background_param).to(device)
+        if c == "random" and self.training:
+            return torch.rand(3, device=device)
+        if c == "white":
+            return torch.ones(3, device=device)
+        return torch.zeros(3, device=device)
+
+    # -- camera handling -------------------------------------------------------------
+    def _viewmat_and_velocity(self, camera: Camera):
+        dev = self.means.device
+        c2w = camera.camera_to_world.to(device=dev, dtype=torch.float32)
+        R_gl, t = c2w[:3, :3], c2w[:3, 3]
+        cam_idx = int(camera.metadata.get("cam_idx", 0))
+        if self.pose_adjustment is not None and 0 <= cam_idx < self.num_cameras:
+            adj = self.pose_adjustment[cam_idx]
+            R_gl = _so3_exp(adj[3:]) @ R_gl       # SO3xR3: rotate about the world axes, then translate
+            t = t + adj[:3]
+        flip = torch.tensor([1.0, -1.0, -1.0], device=dev)
+        R_cv = R_gl * flip[None, :]                # OpenGL -> OpenCV camera axes (x, -y, -z)
+        R_wc = R_cv.T
+        t_wc = -(R_wc @ t)
+        viewmat = torch.eye(4, device=dev)
+        viewmat = torch.cat([torch.cat([R_wc, t_wc[:, None]], dim=1), viewmat[3:4]], dim=0)
+        md = camera.metadata
+        zero3 = torch.zeros(3, device=dev)
+        use_data_vel = not self.config.camera_velocity_optimizer.zero_initial_velocities
+        lin = torch.as_tensor(md.get("camera_linear_velocity", zero3), dtype=torch.float32, device=dev)
+        ang = torch.as_tensor(md.get("camera_angular_velocity", zero3), dtype=torch.float32, device=dev)
+        if not use_data_vel:
+            lin, ang = zero3, zero3
+        # velocities are given in the OpenGL camera frame (process_synthetic_inputs.py:163-165)
+        lin, ang = lin * flip, ang * flip
+        if self.velocity_adjustment is not None and 0 <= cam_idx < self.num_cameras:
+            is_eval = bool(md.get("is_eval", False))
+            adj = self.velocity_adjustment[cam_idx]
+            if is_eval and not self.config.optimize_eval_velocities:
+                adj = adj.detach() * 0.0
+            lin, ang = lin + adj[:3], ang + adj[3:]
+        return viewmat, lin, ang
+
+    def _schedule(self, camera: Camera):
+        cfg = self.config
+        S = cfg.blur_samples if cfg.blur_samples > 0 else 1
+        R = cfg.rs_bands if cfg.rolling_shutter_compensation else 1
+        exposure = float(camera.metadata.get("exposure_time", 0.0))
+        readout = float(camera.metadata.get("rolling_shutter_time", 0.0))
+        if exposure == 0.0:
+            S = 1
+        if readout == 0.0:
+            R = 1
+        times, _, _ = ops.subpose_schedule(S, exposure, R, readout)
+        return S, R, times
+
+    # -- rendering ---------------------------------------------------------------------
+    def get_outputs(self, camera: Camera) -> Dict[str, Tensor]:
+        cfg = self.config
+        dev = self.means.device
+        viewmat, lin, ang = self._viewmat_and_velocity(camera)
+        S, R, times = self._schedule(camera)
+        times_t = torch.tensor(times, dtype=torch.float32, device=dev)
+        viewmats = ops.subpose_viewmats(viewmat, lin, ang, times_t)
+        sh = torch.cat([self.features_dc[:, None, :], self.features_rest], dim=1)
+        bg = self._background(dev)
+        use_gamma = cfg.blur_samples > 0
+        samples, alphas, radii = ops.render_subposes(
+            self.means, torch.exp(self.scales), self.quats, torch.sigmoid(self.opacities).reshape(-1), sh,
+            viewmats, bg, S, R, camera.fx, camera.fy, camera.cx, camera.cy, camera.height, camera.width,
+            sh_degree=cfg.sh_degree, antialiased=(cfg.rasterize_mode == "antialiased"))
+        self.radii = radii
+        self.last_samples = samples
+        gamma = cfg.gamma if use_gamma else 1.0
+        min_level = cfg.min_rgb_level if use_gamma else 0.0
+        rgb = ops.combine_samples(samples, gamma, min_level) if (S > 1 or gamma != 1.0 or min_level > 0) \
+            else samples[0]
+        accumulation = alphas.mean(dim=0)[..., None]
+        out = {"rgb": torch.clamp(rgb, max=1.0) if not self.training else rgb,
+               "accumulation": accumulation, "background": bg}
+        if cfg.output_depth_during_training or not self.training:
+            out["depth"] = self._render_depth(camera, viewmat, accumulation)
+        else:
+            out["depth"] = None
+        return out
+
+    @torch.no_grad()
+    def _render_depth(self, camera: Camera, viewmat: Tensor, accumulation: Tensor) -> Tensor:
+        """Expected depth at the mid-exposure pose: rasterize colour := depth, divide by alpha
+        (how splatfacto 1.1.0 produces outputs['depth'], render_model.py:219)."""
+        xys, depths, radii, conics, comp, ntiles, _ = ops.project_gaussians(
+            self.means, torch.exp(self.scales), 1.0, self.quats, viewmat, camera.fx, camera.fy, camera.cx,
+            camera.cy, camera.height, camera.width, ops.TILE)
+        op = torch.sigmoid(self.opacities).reshape(-1)
+        if self.config.rasterize_mode == "antialiased":
+            op = op * comp
+        d3 = depths[:, None].repeat(1, 3)
+        img, alpha = ops.rasterize_gaussians(xys, depths, radii, conics, ntiles, d3, op[:, None], camera.height,
+                                             camera.width, ops.TILE, background=torch.zeros(3, device=xys.device),
+                                             return_alpha=True)
+        depth = img[..., 0:1]
+        a = alpha[..., None]
+        return torch.where(a > 0, depth / torch.clamp(a, min=1e-10), depth.detach().max())
+
+    @torch.no_grad()
+    def get_outputs_for_camera(self, camera: Camera) -> Dict[str, Tensor]:
+        """Eval entry point used by /root/reference/render_model.py:217."""
+        was = self.training
+        self.eval()
+        try:
+            return self.get_outputs(camera)
+        finally:
+            self.train(was)
+
+    @staticmethod
+    def from_scene(config: SplatfactoDeblurConfig, scene: Dict, device, num_cameras: int = 1):
+        """Build from a dict with means/log_scales/quats/opacity_logits/sh (e.g. a synthetic scene)."""
+        sh = scene["sh"]
+        m = SplatfactoDeblurModel(config, scene["means"], scene["log_scales"], scene["quats"],
+                                  scene["opacity_logits"], sh[:, 0, :], sh[:, 1:, :], num_cameras)
+        return m.to(device)

@@ -1,0 +1,541 @@
+"""gsplat-compatible operator surface over the HIP C-ABI library.
+
+Mirrors the (absent) SpectacularAI gsplat fork's Python layer — upstream gsplat
+0.1.11 signatures, SURVEY.md §8b — so nerfstudio's splatfacto model can call
+``project_gaussians`` / ``rasterize_gaussians`` / ``spherical_harmonics`` unchanged
+(/root/reference/render_model.py:11-15,217; /root/reference/train.py:115-122), plus
+the fused multi-sub-pose path (``render_subposes``) used by :mod:`model`.
+
+Host code is Python on PyTorch-ROCm: torch owns device memory and streams, every
+kernel is hand-written HIP behind ``include/gsdeblur.h``.  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from . import _lib
+
+TILE = 16
+REC = 12  # floats per rasterizer record
+
+
+# --------------------------------------------------------------------------- #
+# helpers
+# --------------------------------------------------------------------------- #
+def _L():
+    return _lib.load()
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a CUDA(HIP) tensor: the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _tiles(h: int, w: int) -> Tuple[int, int]:
+    return (w + TILE - 1) // TILE, (h + TILE - 1) // TILE
+
+
+def _bits(n: int) -> int:
+    return max(1, int(math.ceil(math.log2(max(2, n)))))
+
+
+def _check(st: int, what: str):
+    _lib.check(st, what)
+
+
+def _viewmat16(viewmat: Tensor) -> Tensor:
+    v = _f32(viewmat, "viewmat")
+    if v.shape[-2:] == (3, 4):
+        pad = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=v.device, dtype=v.dtype)
+        v = torch.cat([v, pad.expand(v.shape[:-2] + (1, 4))], dim=-2).contiguous()
+    if v.shape[-2:] != (4, 4):
+        raise ValueError("viewmat must be [4,4] (or [3,4])")
+    return v
+
+
+# --------------------------------------------------------------------------- #
+# scan / sort primitives (device-side; thin wrappers used by the binning code and tests)
+# --------------------------------------------------------------------------- #
+def exclusive_scan_u32(x: Tensor) -> Tuple[Tensor, Tensor]:
+    """x int32 [n] (values >= 0) -> (exclusive prefix int32 [n], total int32 [1])"""
+    assert x.dtype == torch.int32 and x.is_cuda and x.is_contiguous()
+    n = x.numel()
+    out = torch.empty_like(x)
+    total = torch.zeros(1, dtype=torch.int32, device=x.device)
+    if n == 0:
+        return out, total
+    ws_bytes = _L().gs_scan_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    _check(_L().gs_exclusive_scan_u32(n, _ptr(x), _ptr(out), _ptr(total), _ptr(ws), ws_bytes, _stream()), "scan")
+    return out, total
+
+
+def radix_sort_pairs(keys: Tensor, vals: Optional[Tensor], begin_bit: int, end_bit: int) -> Tuple[Tensor, Tensor]:
+    """Stable ascending sort of (key, int32 value) pairs over key bits [begin_bit, end_bit).
+    keys int32 (treated as u32) or int64 (u64); vals None => iota.  Inputs are clobbered."""
+    assert keys.is_cuda and keys.is_contiguous() and keys.dtype in (torch.int32, torch.int64)
+    n = keys.numel()
+    dev = keys.device
+    if vals is None:
+        v0 = torch.empty(n, dtype=torch.int32, device=dev)
+        iota = 1
+    else:
+        assert vals.dtype == torch.int32 and vals.is_contiguous() and vals.numel() == n
+        v0, iota = vals, 0
+    if n == 0:
+        return keys, v0
+    k1 = torch.empty_like(keys)
+    v1 = torch.empty_like(v0)
+    L = _L()
+    ws_bytes = L.gs_radix_sort_workspace_bytes(n, begin_bit, end_bit)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    res = ctypes.c_int(0)
+    fn = L.gs_radix_sort_pairs_u32 if keys.dtype == torch.int32 else L.gs_radix_sort_pairs_u64
+    _check(fn(n, _ptr(keys), _ptr(v0), _ptr(k1), _ptr(v1), iota, begin_bit, end_bit, _ptr(ws), ws_bytes,
+              ctypes.byref(res), _stream()), "radix sort")
+    return (k1, v1) if res.value == 1 else (keys, v0)
+
+
+# --------------------------------------------------------------------------- #
+# binning of rasterizer records (fast path shared by compat + fused ops)
+# --------------------------------------------------------------------------- #
+def bin_and_sort_records(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int,
+                         img_height: int, img_width: int):
+    """-> (sorted_vals int32 [I], tile_bins int32 [P*T,2], n_isect, sorted_keys int32 [I]).
+
+    Depth pre-sort (P*N keys) -> emission in depth order -> stable tile sort: the same total order
+    as upstream's 64-bit (tile<<32|depth) sort at a fraction of the HBM traffic (see binning.hip)."""
+    L = _L()
+    dev = records.device
+    n = P * N
+    tx, ty = _tiles(img_height, img_width)
+    T = tx * ty
+    keys64 = torch.empty(n, dtype=torch.int64, device=dev)
+    _check(L.gs_make_depth_keys64(n, N, _ptr(depth_keys), _ptr(keys64), _stream()), "depth keys")
+    end_bit = 32 + (_bits(P) if P > 1 else 0)
+    _, sorted_gi = radix_sort_pairs(keys64, None, 0, end_bit)
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    _check(L.gs_gather_counts(n, _ptr(sorted_gi), _ptr(num_tiles_hit), _ptr(counts), _stream()), "gather counts")
+    cum, total = exclusive_scan_u32(counts)
+    n_isect = int(total.item())  # host sync, as upstream's cum_tiles_hit[-1].item()
+    bins = torch.empty(P * T, 2, dtype=torch.int32, device=dev)
+    if n_isect == 0:
+        bins.zero_()
+        z = torch.zeros(1, dtype=torch.int32, device=dev)
+        return z, bins, 0, z.clone()
+    if n_isect < 0:
+        raise OverflowError("more than 2^31-1 tile intersections; chunk the sub-poses")
+    keys = torch.empty(n_isect, dtype=torch.int32, device=dev)
+    vals = torch.empty(n_isect, dtype=torch.int32, device=dev)
+    _check(L.gs_emit_intersects(n, N, img_height, img_width, _ptr(sorted_gi), _ptr(cum), _ptr(records), n_isect,
+                                _ptr(keys), _ptr(vals), _stream()), "emit intersects")
+    skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T))
+    _check(L.gs_tile_bin_edges_u32(n_isect, _ptr(skeys), P * T, _ptr(bins), _stream()), "bin edges")
+    return svals, bins, n_isect, skeys
+
+
+def _band_edges(img_height: int, rs_bands: int, device) -> Tensor:
+    _, ty = _tiles(img_height, 1)
+    R = max(1, int(rs_bands))
+    edges = [(r * ty) // R for r in range(R + 1)]
+    return torch.tensor(edges, dtype=torch.int32, device=device)
+
+
+def _background(background: Optional[Tensor], device) -> Tensor:
+    if background is None:
+        return torch.zeros(3, dtype=torch.float32, device=device)
+    bg = background.detach().to(device=device, dtype=torch.float32).contiguous()
+    if bg.numel() != 3:
+        raise ValueError("background must have 3 channels")
+    return bg
+
+
+# --------------------------------------------------------------------------- #
+# gsplat.project_gaussians
+# --------------------------------------------------------------------------- #
+class _ProjectGaussians(Function):
+    @staticmethod
+    def forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
+                block_width, clip_thresh):
+        if block_width != TILE:
+            raise ValueError("only block_width=16 is supported")
+        means3d, scales, quats = _f32(means3d, "means3d"), _f32(scales, "scales"), _f32(quats, "quats")
+        V = _viewmat16(viewmat)
+        N = means3d.shape[0]
+        dev = means3d.device
+        xys = torch.empty(N, 2, device=dev)
+        depths = torch.empty(N, device=dev)
+        radii = torch.empty(N, dtype=torch.int32, device=dev)
+        conics = torch.empty(N, 3, device=dev)
+        comp = torch.empty(N, device=dev)
+        ntiles = torch.empty(N, dtype=torch.int32, device=dev)
+        cov3d = torch.empty(N, 6, device=dev)
+        _check(_L().gs_project_fwd(N, _ptr(means3d), _ptr(scales), float(glob_scale), _ptr(quats), _ptr(V),
+                                   float(fx), float(fy), float(cx), float(cy), int(img_height), int(img_width),
+                                   float(clip_thresh), _ptr(xys), _ptr(depths), _ptr(radii), _ptr(conics),
+                                   _ptr(comp), _ptr(ntiles), _ptr(cov3d), None, _stream()), "project_fwd")
+        ctx.save_for_backward(means3d, scales, quats, V)
+        ctx.args = (float(glob_scale), float(fx), float(fy), float(cx), float(cy), int(img_height),
+                    int(img_width), float(clip_thresh))
+        ctx.mark_non_differentiable(radii, ntiles)
+        return xys, depths, radii, conics, comp, ntiles, cov3d
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_comp, v_ntiles, v_cov3d):
+        means3d, scales, quats, V = ctx.saved_tensors
+        glob, fx, fy, cx, cy, H, W, clip = ctx.args
+        N = means3d.shape[0]
+        dev = means3d.device
+
+        def z(g, shape):
+            return torch.zeros(shape, device=dev) if g is None else g.contiguous().float()
+        v_xys, v_depths, v_conics, v_comp = z(v_xys, (N, 2)), z(v_depths, (N,)), z(v_conics, (N, 3)), z(v_comp, (N,))
+        v_means = torch.empty(N, 3, device=dev)
+        v_scales = torch.empty(N, 3, device=dev)
+        v_quats = torch.empty(N, 4, device=dev)
+        need_v = ctx.needs_input_grad[4]
+        v_V = torch.zeros(4, 4, device=dev) if need_v else None
+        _check(_L().gs_project_bwd(N, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(V), fx, fy, cx, cy, H, W,
+                                   clip, _ptr(v_xys), _ptr(v_depths), _ptr(v_conics), _ptr(v_comp), _ptr(v_means),
+                                   _ptr(v_scales), _ptr(v_quats), _ptr(v_V), _stream()), "project_bwd")
+        return (v_means, v_scales, None, v_quats, v_V, None, None, None, None, None, None, None, None)
+
+
+def project_gaussians(means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor, viewmat: Tensor,
+                      fx: float, fy: float, cx: float, cy: float, img_height: int, img_width: int,
+                      block_width: int = TILE, clip_thresh: float = 0.01):
+    """gsplat.project_gaussians (0.1.11 positional signature).
+    -> (xys, depths, radii, conics, compensation, num_tiles_hit, cov3d)"""
+    return _ProjectGaussians.apply(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height,
+                                   img_width, block_width, clip_thresh)
+
+
+# --------------------------------------------------------------------------- #
+# gsplat.spherical_harmonics
+# --------------------------------------------------------------------------- #
+class _SphericalHarmonics(Function):
+    @staticmethod
+    def forward(ctx, degrees_to_use, viewdirs, coeffs):
+        viewdirs, coeffs = _f32(viewdirs, "viewdirs"), _f32(coeffs, "coeffs")
+        N, K = coeffs.shape[0], coeffs.shape[1]
+        colors = torch.empty(N, 3, device=coeffs.device)
+        _check(_L().gs_sh_fwd(N, K, int(degrees_to_use), _ptr(viewdirs), _ptr(coeffs), _ptr(colors), _stream()),
+               "sh_fwd")
+        ctx.save_for_backward(viewdirs)
+        ctx.K, ctx.deg = K, int(degrees_to_use)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        (viewdirs,) = ctx.saved_tensors
+        N = viewdirs.shape[0]
+        v_coeffs = torch.empty(N, ctx.K, 3, device=viewdirs.device)
+        _check(_L().gs_sh_bwd(N, ctx.K, ctx.deg, _ptr(viewdirs), _ptr(v_colors.contiguous().float()),
+                              _ptr(v_coeffs), _stream()), "sh_bwd")
+        return None, None, v_coeffs
+
+
+def spherical_harmonics(degrees_to_use: int, viewdirs: Tensor, coeffs: Tensor) -> Tensor:
+    """gsplat.spherical_harmonics: coeffs [N,K,3], viewdirs [N,3] -> colors [N,3] (no grad to dirs)."""
+    return _SphericalHarmonics.apply(degrees_to_use, viewdirs, coeffs)
+
+
+# --------------------------------------------------------------------------- #
+# gsplat.rasterize_gaussians
+# --------------------------------------------------------------------------- #
+class _RasterizeGaussians(Function):
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
+                block_width, background, return_alpha):
+        if block_width != TILE:
+            raise ValueError("only block_width=16 is supported")
+        if colors.shape[-1] != 3:
+            raise ValueError("only 3-channel colours are supported (render depth as colour=depth.repeat(3))")
+        xys, depths, conics = _f32(xys, "xys"), _f32(depths, "depths"), _f32(conics, "conics")
+        colors, opacity = _f32(colors, "colors"), _f32(opacity, "opacity").reshape(-1)
+        radii = radii.to(torch.int32).contiguous()
+        N = xys.shape[0]
+        dev = xys.device
+        H, W = int(img_height), int(img_width)
+        L = _L()
+        records = torch.empty(N, REC, device=dev)
+        dkeys = torch.empty(N, dtype=torch.int32, device=dev)
+        ntiles = torch.empty(N, dtype=torch.int32, device=dev)
+        _check(L.gs_pack_records(N, _ptr(xys), _ptr(depths), _ptr(radii), _ptr(conics), _ptr(colors), _ptr(opacity),
+                                 H, W, _ptr(records), _ptr(dkeys), _ptr(ntiles), _stream()), "pack_records")
+        svals, bins, n_isect, _ = bin_and_sort_records(records, dkeys, ntiles, 1, N, H, W)
+        bg = _background(background, dev)
+        edges = _band_edges(H, 1, dev)
+        out_img = torch.empty(1, H, W, 3, device=dev)
+        out_T = torch.empty(1, H, W, device=dev)
+        fidx = torch.empty(1, H, W, dtype=torch.int32, device=dev)
+        _check(L.gs_rasterize_fwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), 1, 1, H, W,
+                                  _ptr(out_img), _ptr(out_T), _ptr(fidx), _stream()), "rasterize_fwd")
+        ctx.save_for_backward(records, svals, bins, edges, bg, out_T, fidx)
+        ctx.dims = (N, H, W)
+        ctx.bg_grad = background is not None and ctx.needs_input_grad[10]
+        out = out_img[0]
+        if return_alpha:
+            return out, 1.0 - out_T[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, v_img, v_alpha=None):
+        records, svals, bins, edges, bg, out_T, fidx = ctx.saved_tensors
+        N, H, W = ctx.dims
+        dev = records.device
+        L = _L()
+        v_img = v_img.contiguous().float()
+        v_al = None if v_alpha is None else v_alpha.contiguous().float()
+        v_records = torch.zeros(N, REC, device=dev)
+        _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), 1, 1, H, W,
+                                  _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records), _stream()),
+               "rasterize_bwd")
+        v_xys = torch.empty(N, 2, device=dev)
+        v_conics = torch.empty(N, 3, device=dev)
+        v_colors = torch.empty(N, 3, device=dev)
+        v_opacity = torch.empty(N, 1, device=dev)
+        _check(L.gs_unpack_record_grads(N, _ptr(v_records), _ptr(v_xys), _ptr(v_conics), _ptr(v_colors),
+                                        _ptr(v_opacity), _stream()), "unpack grads")
+        v_bg = (out_T[0][..., None] * v_img).sum(dim=(0, 1)) if ctx.bg_grad else None
+        return (v_xys, None, None, v_conics, None, v_colors, v_opacity, None, None, None, v_bg, None)
+
+
+def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor, num_tiles_hit: Tensor,
+                        colors: Tensor, opacity: Tensor, img_height: int, img_width: int, block_width: int = TILE,
+                        background: Optional[Tensor] = None, return_alpha: bool = False):
+    """gsplat.rasterize_gaussians (0.1.11 positional signature) -> out_img [H,W,3] (, out_alpha [H,W])."""
+    opacity_in = opacity
+    out = _RasterizeGaussians.apply(xys, depths, radii, conics, num_tiles_hit, colors, opacity_in.reshape(-1, 1),
+                                    img_height, img_width, block_width, background, return_alpha)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# gsplat utility ops (API parity; 64-bit intersection ids)
+# --------------------------------------------------------------------------- #
+def compute_cumulative_intersects(num_tiles_hit: Tensor) -> Tuple[int, Tensor]:
+    """gsplat.utils.compute_cumulative_intersects -> (num_intersects, INCLUSIVE cumsum int32)"""
+    nt = num_tiles_hit.to(torch.int32).contiguous()
+    ex, total = exclusive_scan_u32(nt)
+    return int(total.item()), ex + nt
+
+
+def map_gaussian_to_intersects(num_points: int, num_intersects: int, xys: Tensor, depths: Tensor, radii: Tensor,
+                               cum_tiles_hit: Tensor, tile_bounds, block_width: int = TILE):
+    """gsplat.utils.map_gaussian_to_intersects -> (isect_ids int64 [I], gaussian_ids int32 [I]).
+    tile_bounds = (tiles_x, tiles_y, 1) like upstream."""
+    dev = xys.device
+    isect = torch.zeros(max(1, num_intersects), dtype=torch.int64, device=dev)
+    gids = torch.zeros(max(1, num_intersects), dtype=torch.int32, device=dev)
+    W, H = int(tile_bounds[0]) * TILE, int(tile_bounds[1]) * TILE
+    _check(_L().gs_map_gaussian_to_intersects(int(num_points), _ptr(_f32(xys, "xys")), _ptr(_f32(depths, "depths")),
+                                              _ptr(radii.to(torch.int32).contiguous()),
+                                              _ptr(cum_tiles_hit.to(torch.int32).contiguous()), H, W, _ptr(isect),
+                                              _ptr(gids), _stream()), "map_gaussian_to_intersects")
+    return isect[:num_intersects], gids[:num_intersects]
+
+
+def get_tile_bin_edges(num_intersects: int, isect_ids_sorted: Tensor, tile_bounds) -> Tensor:
+    """gsplat.utils.get_tile_bin_edges -> int32 [T,2]"""
+    T = int(tile_bounds[0]) * int(tile_bounds[1])
+    bins = torch.empty(T, 2, dtype=torch.int32, device=isect_ids_sorted.device)
+    _check(_L().gs_tile_bin_edges_u64(int(num_intersects), _ptr(isect_ids_sorted.contiguous()), T, _ptr(bins),
+                                      _stream()), "tile_bin_edges")
+    return bins
+
+
+def bin_and_sort_gaussians(num_points: int, num_intersects: int, xys: Tensor, depths: Tensor, radii: Tensor,
+                           cum_tiles_hit: Tensor, tile_bounds, block_width: int = TILE):
+    """gsplat.utils.bin_and_sort_gaussians ->
+    (isect_ids_unsorted, gaussian_ids_unsorted, isect_ids_sorted, gaussian_ids_sorted, tile_bins)"""
+    isect, gids = map_gaussian_to_intersects(num_points, num_intersects, xys, depths, radii, cum_tiles_hit,
+                                             tile_bounds, block_width)
+    T = int(tile_bounds[0]) * int(tile_bounds[1])
+    if num_intersects == 0:
+        return isect, gids, isect, gids, torch.zeros(T, 2, dtype=torch.int32, device=xys.device)
+    ks, vs = radix_sort_pairs(isect.clone(), gids.clone(), 0, 32 + _bits(T))
+    bins = get_tile_bin_edges(num_intersects, ks, tile_bounds)
+    return isect, gids, ks, vs, bins
+
+
+# --------------------------------------------------------------------------- #
+# sub-pose viewmats (SE(3) screw interpolation)
+# --------------------------------------------------------------------------- #
+class _SubposeViewmats(Function):
+    @staticmethod
+    def forward(ctx, viewmat, lin_vel, ang_vel, times):
+        V = _viewmat16(viewmat)
+        lin, ang, times = _f32(lin_vel, "lin_vel"), _f32(ang_vel, "ang_vel"), _f32(times, "times")
+        P = times.numel()
+        out = torch.empty(P, 4, 4, device=V.device)
+        _check(_L().gs_subpose_viewmats_fwd(P, _ptr(V), _ptr(lin), _ptr(ang), _ptr(times), _ptr(out), _stream()),
+               "subpose_viewmats_fwd")
+        ctx.save_for_backward(V, lin, ang, times)
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out):
+        V, lin, ang, times = ctx.saved_tensors
+        P = times.numel()
+        dev = V.device
+        v_V = torch.zeros(4, 4, device=dev)
+        v_lin = torch.zeros(3, device=dev)
+        v_ang = torch.zeros(3, device=dev)
+        _check(_L().gs_subpose_viewmats_bwd(P, _ptr(V), _ptr(lin), _ptr(ang), _ptr(times),
+                                            _ptr(v_out.contiguous().float()), _ptr(v_V), _ptr(v_lin), _ptr(v_ang),
+                                            _stream()), "subpose_viewmats_bwd")
+        return v_V, v_lin, v_ang, None
+
+
+def subpose_viewmats(viewmat: Tensor, lin_vel: Tensor, ang_vel: Tensor, times: Tensor) -> Tensor:
+    """viewmat(t) = Exp(-t [lin_vel; ang_vel]) @ viewmat for every t in times -> [P,4,4] (differentiable)."""
+    return _SubposeViewmats.apply(viewmat, lin_vel, ang_vel, times)
+
+
+def subpose_schedule(blur_samples: int, exposure_time: float, rs_bands: int, rolling_shutter_time: float):
+    """Host-side schedule: (times [P], sample index [P], band index [P]); p = s*R + r.
+    t = ((s+.5)/S - .5) * exposure + ((r+.5)/R - .5) * readout."""
+    S, R = max(1, int(blur_samples)), max(1, int(rs_bands))
+    times, samp, band = [], [], []
+    for s in range(S):
+        ts = ((s + 0.5) / S - 0.5) * exposure_time if S > 1 else 0.0
+        for r in range(R):
+            tr = ((r + 0.5) / R - 0.5) * rolling_shutter_time if R > 1 else 0.0
+            times.append(ts + tr)
+            samp.append(s)
+            band.append(r)
+    return times, samp, band
+
+
+# --------------------------------------------------------------------------- #
+# fused multi-sub-pose render
+# --------------------------------------------------------------------------- #
+class _RenderSubposes(Function):
+    @staticmethod
+    def forward(ctx, means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
+                img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh):
+        means3d, scales, quats = _f32(means3d, "means3d"), _f32(scales, "scales"), _f32(quats, "quats")
+        opacities, sh = _f32(opacities, "opacities").reshape(-1), _f32(sh, "sh")
+        V = _f32(viewmats, "viewmats")
+        N, K = means3d.shape[0], sh.shape[1]
+        P = S * R
+        if V.shape != (P, 4, 4):
+            raise ValueError(f"viewmats must be [{P},4,4]")
+        H, W = int(img_height), int(img_width)
+        dev = means3d.device
+        L = _L()
+        records = torch.empty(P * N, REC, device=dev)
+        dkeys = torch.empty(P * N, dtype=torch.int32, device=dev)
+        ntiles = torch.empty(P * N, dtype=torch.int32, device=dev)
+        radii = torch.empty(P, N, dtype=torch.int32, device=dev)
+        args = (N, P, float(glob_scale), K, int(sh_degree), float(fx), float(fy), float(cx), float(cy), H, W,
+                float(clip_thresh), int(bool(antialiased)))
+        _check(L.gs_project_fused_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
+                                      _ptr(sh), K, args[4], _ptr(V), args[5], args[6], args[7], args[8], H, W,
+                                      args[11], args[12], _ptr(records), _ptr(dkeys), _ptr(ntiles), _ptr(radii),
+                                      _stream()), "project_fused_fwd")
+        svals, bins, n_isect, _ = bin_and_sort_records(records, dkeys, ntiles, P, N, H, W)
+        bg = _background(background, dev)
+        edges = _band_edges(H, R, dev)
+        out_img = torch.empty(S, H, W, 3, device=dev)
+        out_T = torch.empty(S, H, W, device=dev)
+        fidx = torch.empty(S, H, W, dtype=torch.int32, device=dev)
+        _check(L.gs_rasterize_fwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
+                                  _ptr(out_img), _ptr(out_T), _ptr(fidx), _stream()), "rasterize_fwd")
+        ctx.save_for_backward(means3d, scales, quats, opacities, sh, V, records, svals, bins, edges, bg, out_T, fidx)
+        ctx.args = args
+        ctx.SR = (S, R)
+        ctx.n_isect = n_isect
+        ctx.bg_grad = background is not None and ctx.needs_input_grad[6]
+        ctx.mark_non_differentiable(radii)
+        return out_img, 1.0 - out_T, radii
+
+    @staticmethod
+    def backward(ctx, v_img, v_alpha, _v_radii):
+        (means3d, scales, quats, opacities, sh, V, records, svals, bins, edges, bg, out_T, fidx) = ctx.saved_tensors
+        N, P, glob, K, deg, fx, fy, cx, cy, H, W, clip, aa = ctx.args
+        S, R = ctx.SR
+        dev = means3d.device
+        L = _L()
+        v_img = v_img.contiguous().float()
+        v_al = None if v_alpha is None else v_alpha.contiguous().float()
+        v_records = torch.zeros(P * N, REC, device=dev)
+        _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
+                                  _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records), _stream()),
+               "rasterize_bwd")
+        v_means = torch.empty(N, 3, device=dev)
+        v_scales = torch.empty(N, 3, device=dev)
+        v_quats = torch.empty(N, 4, device=dev)
+        v_opac = torch.empty(N, device=dev)
+        v_sh = torch.empty(N, K, 3, device=dev)
+        need_v = ctx.needs_input_grad[5]
+        v_V = torch.zeros(P, 4, 4, device=dev) if need_v else None
+        _check(L.gs_project_fused_bwd(N, P, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(opacities), _ptr(sh),
+                                      K, deg, _ptr(V), fx, fy, cx, cy, H, W, clip, aa, _ptr(records), _ptr(v_records),
+                                      _ptr(v_means), _ptr(v_scales), _ptr(v_quats), _ptr(v_opac), _ptr(v_sh),
+                                      _ptr(v_V), _stream()), "project_fused_bwd")
+        v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
+        return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 12
+
+
+def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, sh: Tensor,
+                    viewmats: Tensor, background: Optional[Tensor], blur_samples: int, rs_bands: int,
+                    fx: float, fy: float, cx: float, cy: float, img_height: int, img_width: int,
+                    sh_degree: int = 3, antialiased: bool = True, glob_scale: float = 1.0,
+                    clip_thresh: float = 0.01):
+    """Fused hot path: project N Gaussians under P=S*R sub-pose viewmats, bin, sort, composite.
+    -> (samples [S,H,W,3], alphas [S,H,W], radii int32 [P,N]).  scales/opacities are activated values."""
+    S, R = max(1, int(blur_samples)), max(1, int(rs_bands))
+    return _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
+                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh)
+
+
+# --------------------------------------------------------------------------- #
+# sub-frame averaging
+# --------------------------------------------------------------------------- #
+class _CombineSamples(Function):
+    @staticmethod
+    def forward(ctx, samples, gamma, min_rgb_level):
+        samples = _f32(samples, "samples")
+        S = samples.shape[0]
+        n = samples[0].numel()
+        out = torch.empty_like(samples[0])
+        m = float(min_rgb_level) / 255.0
+        _check(_L().gs_combine_fwd(S, n, _ptr(samples), float(gamma), m, _ptr(out), _stream()), "combine_fwd")
+        ctx.save_for_backward(samples, out)
+        ctx.gm = (float(gamma), m)
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out):
+        samples, out = ctx.saved_tensors
+        gamma, m = ctx.gm
+        S = samples.shape[0]
+        n = samples[0].numel()
+        v_samples = torch.empty_like(samples)
+        _check(_L().gs_combine_bwd(S, n, _ptr(samples), gamma, m, _ptr(out), _ptr(v_out.contiguous().float()),
+                                   _ptr(v_samples), _stream()), "combine_bwd")
+        return v_samples, None, None
+
+
+def combine_samples(samples: Tensor, gamma: float = 1.0, min_rgb_level: float = 0.0) -> Tensor:
+    """[S,...] per-sample composites -> ( mean_k max(C_k, min/255)^gamma )^(1/gamma)"""
+    return _CombineSamples.apply(samples, gamma, min_rgb_level)

@@ -1,0 +1,539 @@
+"""CPU oracle for the 3DGS-deblur hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module; the product package (``3dgs-deblur_amd/``) never
+does and fails loudly when its HIP library is missing.
+
+PARITY UNPINNED.  The code this restates — the SpectacularAI forks of gsplat
+(base nerfstudio-project/gsplat@409bcd3c, "based on 0.1.11") and nerfstudio
+(base v1.1.0) named at /root/reference/README.md:199 and /root/reference/.gitmodules:1-6
+— is NOT vendored under /root/reference (empty submodule directories) and is not
+installed, so there are no reference golden vectors, no reference tests and
+nothing to import.  This restatement follows SURVEY.md App. A (recollection of
+upstream gsplat 0.1.11's ``_torch_impl`` and CUDA kernels) and the in-tree data
+contracts:
+  * velocity frame / definition: /root/reference/process_synthetic_inputs.py:157-165,
+    /root/reference/render_video.py:85-115
+  * model config surface (blur_samples, rolling_shutter_compensation, gamma,
+    min_rgb_level, rasterize_mode=antialiased): /root/reference/train.py:17-22,46-70,119
+It is pinned instead by reference-independent known-answer tests
+(tests/test_oracle.py): finite differences, analytic single-Gaussian image,
+static == zero-velocity, SH orthonormality, SE(3) exp vs matrix_exp, ...
+
+Everything is written with torch on CPU, dtype-generic:
+  float32 -> bit-for-bit the op order of csrc/gs_math.h (integer outputs exact),
+  float64 -> differentiable high-precision reference (gradients by autograd,
+             an independent check of the hand-written HIP backward).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+# ---- recollected constants — mirror of gs::K in csrc/gs_math.h
+FOV_LIMIT = 1.3
+DILATION = 0.3
+MIN_EIG_DISC = 0.1
+RADIUS_SIGMA = 3.0
+ALPHA_MAX = 0.999
+ALPHA_MIN = 1.0 / 255.0
+T_MIN = 1e-4
+TILE = 16
+
+
+# --------------------------------------------------------------------------- #
+# projection  (App. A "Projection", "Tile bbox")
+# --------------------------------------------------------------------------- #
+def quat_to_rotmat(q: torch.Tensor) -> torch.Tensor:
+    """(w,x,y,z) -> R[...,3,3]; normalises like gs::quat_to_rotmat."""
+    n2 = ((q[..., 0] * q[..., 0] + q[..., 1] * q[..., 1]) + q[..., 2] * q[..., 2]) + q[..., 3] * q[..., 3]
+    inv = 1.0 / torch.sqrt(n2)
+    w, x, y, z = q[..., 0] * inv, q[..., 1] * inv, q[..., 2] * inv, q[..., 3] * inv
+    R = torch.stack(
+        [
+            1.0 - 2.0 * (y * y + z * z), 2.0 * (x * y - w * z), 2.0 * (x * z + w * y),
+            2.0 * (x * y + w * z), 1.0 - 2.0 * (x * x + z * z), 2.0 * (y * z - w * x),
+            2.0 * (x * z - w * y), 2.0 * (y * z + w * x), 1.0 - 2.0 * (x * x + y * y),
+        ],
+        dim=-1,
+    )
+    return R.reshape(q.shape[:-1] + (3, 3))
+
+
+def scale_rot_to_cov3d(scales: torch.Tensor, glob_scale: float, quats: torch.Tensor) -> torch.Tensor:
+    """cov3d upper triangle [N,6] = (R S)(R S)^T, same association as gs::scale_rot_to_cov3d."""
+    R = quat_to_rotmat(quats)
+    s = glob_scale * scales
+    M = R * s[..., None, :]
+    def dot(i, j):
+        return (M[..., i, 0] * M[..., j, 0] + M[..., i, 1] * M[..., j, 1]) + M[..., i, 2] * M[..., j, 2]
+    return torch.stack([dot(0, 0), dot(0, 1), dot(0, 2), dot(1, 1), dot(1, 2), dot(2, 2)], dim=-1)
+
+
+@dataclass
+class Projected:
+    xys: torch.Tensor          # [N,2]
+    depths: torch.Tensor       # [N]
+    radii: torch.Tensor        # [N] int32 (0 = culled)
+    conics: torch.Tensor       # [N,3]
+    compensation: torch.Tensor # [N]
+    num_tiles_hit: torch.Tensor  # [N] int32
+    cov3d: torch.Tensor        # [N,6]
+    tile_min: torch.Tensor     # [N,2] int32 (x,y)
+    tile_max: torch.Tensor     # [N,2] int32 (x,y), exclusive
+
+
+def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy,
+                      img_height, img_width, block_width=TILE, clip_thresh=0.01) -> Projected:
+    """Restates gsplat.project_gaussians (absent fork).  dtype follows inputs."""
+    assert block_width == TILE
+    dt = means3d.dtype
+    V = viewmat.to(dt)
+    c3 = scale_rot_to_cov3d(scales, glob_scale, quats)
+    mx, my, mz = means3d[:, 0], means3d[:, 1], means3d[:, 2]
+    px = ((V[0, 0] * mx + V[0, 1] * my) + V[0, 2] * mz) + V[0, 3]
+    py = ((V[1, 0] * mx + V[1, 1] * my) + V[1, 2] * mz) + V[1, 3]
+    pz = ((V[2, 0] * mx + V[2, 1] * my) + V[2, 2] * mz) + V[2, 3]
+    valid = pz > clip_thresh
+    pz_safe = torch.where(valid, pz, torch.ones_like(pz))
+    rz = 1.0 / pz_safe
+    one = torch.ones((), dtype=dt)
+    lim_x = (one * FOV_LIMIT) * ((one * 0.5) * float(img_width) / (one * fx))
+    lim_y = (one * FOV_LIMIT) * ((one * 0.5) * float(img_height) / (one * fy))
+    fx_t, fy_t, cx_t, cy_t = one * fx, one * fy, one * cx, one * cy
+    tx = pz_safe * torch.minimum(lim_x, torch.maximum(-lim_x, px * rz))
+    ty = pz_safe * torch.minimum(lim_y, torch.maximum(-lim_y, py * rz))
+    rz2 = rz * rz
+    J00 = fx_t * rz
+    J02 = -(fx_t * tx) * rz2
+    J11 = fy_t * rz
+    J12 = -(fy_t * ty) * rz2
+    T0 = J00 * V[0, 0] + J02 * V[2, 0]
+    T1 = J00 * V[0, 1] + J02 * V[2, 1]
+    T2 = J00 * V[0, 2] + J02 * V[2, 2]
+    T3 = J11 * V[1, 0] + J12 * V[2, 0]
+    T4 = J11 * V[1, 1] + J12 * V[2, 1]
+    T5 = J11 * V[1, 2] + J12 * V[2, 2]
+    S00, S01, S02, S11, S12, S22 = (c3[:, i] for i in range(6))
+    U0 = (T0 * S00 + T1 * S01) + T2 * S02
+    U1 = (T0 * S01 + T1 * S11) + T2 * S12
+    U2 = (T0 * S02 + T1 * S12) + T2 * S22
+    U3 = (T3 * S00 + T4 * S01) + T5 * S02
+    U4 = (T3 * S01 + T4 * S11) + T5 * S12
+    U5 = (T3 * S02 + T4 * S12) + T5 * S22
+    a0 = (U0 * T0 + U1 * T1) + U2 * T2
+    b = (U0 * T3 + U1 * T4) + U2 * T5
+    c0 = (U3 * T3 + U4 * T4) + U5 * T5
+    det0 = a0 * c0 - b * b
+    a = a0 + DILATION
+    c = c0 + DILATION
+    det = a * c - b * b
+    valid = valid & (det != 0)
+    det_safe = torch.where(valid, det, torch.ones_like(det))
+    comp = torch.sqrt(torch.clamp(det0 / det_safe, min=0.0))
+    inv_det = 1.0 / det_safe
+    conics = torch.stack([c * inv_det, -b * inv_det, a * inv_det], dim=-1)
+    mid = 0.5 * (a + c)
+    lam = mid + torch.sqrt(torch.clamp(mid * mid - det, min=MIN_EIG_DISC))
+    radf = torch.ceil(RADIUS_SIGMA * torch.sqrt(lam.detach()))
+    x = (fx_t * px) * rz + cx_t
+    y = (fy_t * py) * rz + cy_t
+    tiles_x = (img_width + TILE - 1) // TILE
+    tiles_y = (img_height + TILE - 1) // TILE
+    inv_tile = one / float(TILE)
+    xd, yd = x.detach(), y.detach()
+    tcx, tcy, tr = xd * inv_tile, yd * inv_tile, radf * inv_tile
+    # (int) casts truncate toward zero
+    x0 = torch.trunc(tcx - tr).clamp(0, tiles_x).to(torch.int32)
+    x1 = torch.trunc((tcx + tr) + 1.0).clamp(0, tiles_x).to(torch.int32)
+    y0 = torch.trunc(tcy - tr).clamp(0, tiles_y).to(torch.int32)
+    y1 = torch.trunc((tcy + tr) + 1.0).clamp(0, tiles_y).to(torch.int32)
+    area = (x1 - x0) * (y1 - y0)
+    valid = valid & (area > 0)
+    zi = torch.zeros_like(area)
+    radii = torch.where(valid, radf.to(torch.int32), zi)
+    ntiles = torch.where(valid, area, zi)
+    tmin = torch.stack([torch.where(valid, x0, zi), torch.where(valid, y0, zi)], dim=-1)
+    tmax = torch.stack([torch.where(valid, x1, zi), torch.where(valid, y1, zi)], dim=-1)
+    vf = valid.to(dt)
+    return Projected(
+        xys=torch.stack([x, y], dim=-1) * vf[:, None],
+        depths=pz,   # reported even for culled Gaussians (never used when radius == 0)
+        radii=radii,
+        conics=conics * vf[:, None],
+        compensation=comp * vf,
+        num_tiles_hit=ntiles,
+        cov3d=c3,
+        tile_min=tmin,
+        tile_max=tmax,
+    )
+
+
+# --------------------------------------------------------------------------- #
+# spherical harmonics — classical explicit 3DGS polynomials for
+# degree<=3 (an independent restatement of the recurrences in gs_math.h);
+# degree 4 uses the recurrence form.
+# --------------------------------------------------------------------------- #
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+SH_C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
+         -0.4570457994644658, 1.445305721320277, -0.5900435899266435]
+
+
+def sh_basis(deg: int, dirs: torch.Tensor) -> torch.Tensor:
+    """[N,3] unit dirs -> [N,(deg+1)^2] real SH basis."""
+    x, y, z = dirs[:, 0], dirs[:, 1], dirs[:, 2]
+    B = [torch.full_like(x, SH_C0)]
+    if deg >= 1:
+        B += [-SH_C1 * y, SH_C1 * z, -SH_C1 * x]
+    if deg >= 2:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        B += [SH_C2[0] * xy, SH_C2[1] * yz, SH_C2[2] * (2.0 * zz - xx - yy), SH_C2[3] * xz, SH_C2[4] * (xx - yy)]
+    if deg >= 3:
+        B += [SH_C3[0] * y * (3.0 * xx - yy), SH_C3[1] * xy * z, SH_C3[2] * y * (4.0 * zz - xx - yy),
+              SH_C3[3] * z * (2.0 * zz - 3.0 * xx - 3.0 * yy), SH_C3[4] * x * (4.0 * zz - xx - yy),
+              SH_C3[5] * z * (xx - yy), SH_C3[6] * x * (xx - 3.0 * yy)]
+    if deg >= 4:
+        z2 = z * z
+        fC1, fS1 = x * x - y * y, 2.0 * x * y
+        fC2, fS2 = x * fC1 - y * fS1, x * fS1 + y * fC1
+        fC3, fS3 = x * fC2 - y * fS2, x * fS2 + y * fC2
+        fTmp0D = z * (-4.683325804901025 * z2 + 2.007139630671868)
+        fTmp1C = 3.31161143515146 * z2 - 0.47308734787878
+        fTmp2B = -1.770130769779931 * z
+        p12 = z * (1.865881662950577 * z2 - 1.119528997770346)
+        p6 = 0.9461746957575601 * z2 - 0.3153915652525201
+        b = [None] * 9
+        b[4] = 1.984313483298443 * z * p12 - 1.006230589874905 * p6
+        b[5], b[3] = fTmp0D * x, fTmp0D * y
+        b[6], b[2] = fTmp1C * fC1, fTmp1C * fS1
+        b[7], b[1] = fTmp2B * fC2, fTmp2B * fS2
+        b[8], b[0] = 0.6258357354491763 * fC3, 0.6258357354491763 * fS3
+        B += b
+    return torch.stack(B, dim=-1)
+
+
+def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor) -> torch.Tensor:
+    """gsplat.spherical_harmonics: coeffs [N,K,3], viewdirs [N,3] (normalised inside, no grad to dirs)."""
+    d = viewdirs.detach()
+    d = d / torch.linalg.norm(d, dim=-1, keepdim=True)
+    nb = (degrees_to_use + 1) ** 2
+    B = sh_basis(degrees_to_use, d)
+    return (B[:, :, None] * coeffs[:, :nb, :]).sum(dim=1)
+
+
+# --------------------------------------------------------------------------- #
+# binning / sort (App. A "Keys") — integer, numpy
+# --------------------------------------------------------------------------- #
+def map_gaussian_to_intersects(proj: Projected, img_width: int, tile_offset: int = 0):
+    """-> (isect_ids int64 [I], gaussian_ids int32 [I]) in emission (gaussian-major, y then x) order."""
+    tiles_x = (img_width + TILE - 1) // TILE
+    tmin = proj.tile_min.numpy().astype(np.int64)
+    tmax = proj.tile_max.numpy().astype(np.int64)
+    depth_bits = proj.depths.detach().to(torch.float32).numpy().view(np.int32).astype(np.int64)
+    keys: List[np.ndarray] = []
+    gids: List[np.ndarray] = []
+    for g in np.nonzero(proj.num_tiles_hit.numpy() > 0)[0]:
+        ys = np.arange(tmin[g, 1], tmax[g, 1])
+        xs = np.arange(tmin[g, 0], tmax[g, 0])
+        tid = (ys[:, None] * tiles_x + xs[None, :]).reshape(-1) + tile_offset
+        keys.append((tid << 32) | depth_bits[g])
+        gids.append(np.full(tid.shape, g, dtype=np.int32))
+    if not keys:
+        return np.zeros(0, np.int64), np.zeros(0, np.int32)
+    return np.concatenate(keys), np.concatenate(gids)
+
+
+def sort_intersects(isect_ids: np.ndarray, gaussian_ids: np.ndarray):
+    """ascending key; ties broken by emission order (== gaussian id) — the deterministic
+    tiebreak SURVEY §7 'Hard parts' asks both sides to share."""
+    order = np.argsort(isect_ids, kind="stable")
+    return isect_ids[order], gaussian_ids[order]
+
+
+def get_tile_bin_edges(sorted_ids: np.ndarray, num_tiles: int) -> np.ndarray:
+    """-> int32 [T,2] [start,end) per tile id."""
+    tid = (sorted_ids >> 32).astype(np.int64)
+    bins = np.zeros((num_tiles, 2), dtype=np.int32)
+    if tid.size:
+        starts = np.searchsorted(tid, np.arange(num_tiles), side="left")
+        ends = np.searchsorted(tid, np.arange(num_tiles), side="right")
+        bins[:, 0], bins[:, 1] = starts, ends
+    return bins
+
+
+# --------------------------------------------------------------------------- #
+# rasterize (App. A "Blend") — vectorised per tile, autograd bwd
+# --------------------------------------------------------------------------- #
+@dataclass
+class Rasterized:
+    img: torch.Tensor        # [H,W,3]
+    alpha: torch.Tensor      # [H,W]  = 1 - final_T
+    final_T: torch.Tensor    # [H,W]
+    final_idx: torch.Tensor  # [H,W] int32: one past the last contributing sorted entry (tile start if none)
+    fragile: torch.Tensor    # [H,W] bool: a threshold decision was within rounding of flipping
+
+
+def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.ndarray, tile_bins: np.ndarray,
+                     img_height: int, img_width: int, background: Optional[torch.Tensor] = None,
+                     tile_rows: Optional[Tuple[int, int]] = None) -> Rasterized:
+    """Front-to-back alpha compositing of pre-sorted intersections, differentiable by autograd."""
+    dt = xys.dtype
+    H, W = img_height, img_width
+    tiles_x = (W + TILE - 1) // TILE
+    tiles_y = (H + TILE - 1) // TILE
+    ty0, ty1 = (0, tiles_y) if tile_rows is None else tile_rows
+    opac = opacities.reshape(-1)
+    bg = torch.zeros(3, dtype=dt) if background is None else background.to(dt)
+    out_idx = torch.zeros(H, W, dtype=torch.int32)
+    frag = torch.zeros(H, W, dtype=torch.bool)
+    row_imgs, row_Ts = [], []
+    for ty in range(tiles_y):
+        y_lo, y_hi = ty * TILE, min((ty + 1) * TILE, H)
+        hh = y_hi - y_lo
+        if ty < ty0 or ty >= ty1:
+            # rows outside the rendered band stay exactly zero / T=1 (they belong to other sub-poses)
+            row_imgs.append(torch.zeros(hh, W, 3, dtype=dt))
+            row_Ts.append(torch.ones(hh, W, dtype=dt))
+            continue
+        tile_imgs, tile_Ts = [], []
+        for tx in range(tiles_x):
+            t = ty * tiles_x + tx
+            s, e = int(tile_bins[t, 0]), int(tile_bins[t, 1])
+            x_lo, x_hi = tx * TILE, min((tx + 1) * TILE, W)
+            ww = x_hi - x_lo
+            out_idx[y_lo:y_hi, x_lo:x_hi] = s
+            if e <= s:
+                tile_imgs.append(bg.expand(hh, ww, 3))
+                tile_Ts.append(torch.ones(hh, ww, dtype=dt))
+                continue
+            ids = torch.from_numpy(gaussian_ids_sorted[s:e].astype(np.int64))
+            py = torch.arange(y_lo, y_hi, dtype=dt) + 0.5
+            px = torch.arange(x_lo, x_hi, dtype=dt) + 0.5
+            PX = px[None, :].expand(hh, ww).reshape(-1)
+            PY = py[:, None].expand(hh, ww).reshape(-1)
+            gx, gy = xys[ids, 0], xys[ids, 1]
+            cxx, cxy, cyy = conics[ids, 0], conics[ids, 1], conics[ids, 2]
+            dx = gx[:, None] - PX[None, :]
+            dy = gy[:, None] - PY[None, :]
+            sigma = 0.5 * (cxx[:, None] * dx * dx + cyy[:, None] * dy * dy) + cxy[:, None] * dx * dy
+            vis = torch.exp(-sigma)
+            alpha = torch.clamp(opac[ids][:, None] * vis, max=ALPHA_MAX)
+            valid = (sigma >= 0) & (alpha >= ALPHA_MIN)
+            a = torch.where(valid, alpha, torch.zeros_like(alpha))
+            Tincl = torch.cumprod(1.0 - a, dim=0)
+            Texcl = torch.cat([torch.ones_like(Tincl[:1]), Tincl[:-1]], dim=0)
+            live = Tincl > T_MIN           # entries blended before the stop
+            w = a * Texcl * live.to(dt)
+            C = (w[:, :, None] * colors[ids][:, None, :]).sum(dim=0)
+            n_live_T = torch.where(live, Tincl, torch.full_like(Tincl, 2.0))
+            Tfin = torch.clamp(n_live_T.min(dim=0).values, max=1.0)
+            C = C + Tfin[:, None] * bg[None, :]
+            contrib = valid & live
+            k = torch.arange(1, e - s + 1, dtype=torch.int32)[:, None]
+            last = torch.where(contrib, k, torch.zeros_like(k)).max(dim=0).values + s
+            # fragile decisions (used only to exclude pixels from strict comparisons)
+            with torch.no_grad():
+                reach = Texcl > T_MIN
+                f1 = (reach & ((alpha / ALPHA_MIN - 1.0).abs() < 2e-4)).any(dim=0)
+                f2 = (valid & reach & ((Tincl / T_MIN - 1.0).abs() < 2e-3)).any(dim=0)
+                f3 = (reach & (sigma.abs() < 1e-7) & (sigma != 0)).any(dim=0)
+            tile_imgs.append(C.reshape(hh, ww, 3))
+            tile_Ts.append(Tfin.reshape(hh, ww))
+            out_idx[y_lo:y_hi, x_lo:x_hi] = last.reshape(hh, ww).to(torch.int32)
+            frag[y_lo:y_hi, x_lo:x_hi] = (f1 | f2 | f3).reshape(hh, ww)
+        row_imgs.append(torch.cat(tile_imgs, dim=1))
+        row_Ts.append(torch.cat(tile_Ts, dim=1))
+    img = torch.cat(row_imgs, dim=0)
+    Tm = torch.cat(row_Ts, dim=0)
+    return Rasterized(img=img, alpha=1.0 - Tm, final_T=Tm, final_idx=out_idx, fragile=frag)
+
+
+def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
+                        block_width=TILE, background=None, return_alpha=False, proj: Optional[Projected] = None):
+    """gsplat.rasterize_gaussians restated (bin + sort + composite).  Needs tile bounds, which upstream
+    recomputes from xys/radii; here they are recomputed the same way when `proj` is not given."""
+    assert block_width == TILE
+    if proj is None:
+        proj = _bounds_from_xys_radii(xys, depths, radii, num_tiles_hit, img_height, img_width)
+    keys, gids = map_gaussian_to_intersects(proj, img_width)
+    keys, gids = sort_intersects(keys, gids)
+    tiles = ((img_width + TILE - 1) // TILE) * ((img_height + TILE - 1) // TILE)
+    bins = get_tile_bin_edges(keys, tiles)
+    r = rasterize_sorted(xys, conics, colors, opacity, gids, bins, img_height, img_width, background)
+    return (r.img, r.alpha, r) if return_alpha else (r.img, r)
+
+
+def _bounds_from_xys_radii(xys, depths, radii, num_tiles_hit, H, W) -> Projected:
+    tiles_x = (W + TILE - 1) // TILE
+    tiles_y = (H + TILE - 1) // TILE
+    x32 = xys.detach().to(torch.float32)
+    inv_tile = torch.ones((), dtype=torch.float32) / float(TILE)
+    radf = radii.to(torch.float32)
+    tcx, tcy, tr = x32[:, 0] * inv_tile, x32[:, 1] * inv_tile, radf * inv_tile
+    x0 = torch.trunc(tcx - tr).clamp(0, tiles_x).to(torch.int32)
+    x1 = torch.trunc((tcx + tr) + 1.0).clamp(0, tiles_x).to(torch.int32)
+    y0 = torch.trunc(tcy - tr).clamp(0, tiles_y).to(torch.int32)
+    y1 = torch.trunc((tcy + tr) + 1.0).clamp(0, tiles_y).to(torch.int32)
+    ok = radii > 0
+    zi = torch.zeros_like(x0)
+    tmin = torch.stack([torch.where(ok, x0, zi), torch.where(ok, y0, zi)], -1)
+    tmax = torch.stack([torch.where(ok, x1, zi), torch.where(ok, y1, zi)], -1)
+    nt = (tmax[:, 0] - tmin[:, 0]) * (tmax[:, 1] - tmin[:, 1])
+    return Projected(xys, depths, radii, None, None, nt.to(torch.int32), None, tmin, tmax)
+
+
+# --------------------------------------------------------------------------- #
+# sub-poses: SE(3) screw interpolation (north_star)
+# --------------------------------------------------------------------------- #
+def subpose_times(blur_samples: int, exposure_time: float, rs_bands: int, rolling_shutter_time: float):
+    """Sub-pose schedule: returns (times[P], sample_index[P], band_index[P]) with P = S*R.
+    Motion-blur sample k in [0,S): centred uniform grid over the exposure, t_k = ((k+0.5)/S - 0.5) * T_e
+    Rolling-shutter band r in [0,R): row-band centre time tau_r = ((r+0.5)/R - 0.5) * T_ro."""
+    S = max(1, int(blur_samples))
+    R = max(1, int(rs_bands))
+    times, samp, band = [], [], []
+    for k in range(S):
+        tk = ((k + 0.5) / S - 0.5) * exposure_time if S > 1 else 0.0
+        for r in range(R):
+            tr_ = ((r + 0.5) / R - 0.5) * rolling_shutter_time if R > 1 else 0.0
+            times.append(tk + tr_)
+            samp.append(k)
+            band.append(r)
+    return times, samp, band
+
+
+def band_tile_rows(img_height: int, rs_bands: int) -> List[Tuple[int, int]]:
+    """Tile-row range [ty0,ty1) rendered by each rolling-shutter band (bands are whole tile rows)."""
+    tiles_y = (img_height + TILE - 1) // TILE
+    R = max(1, int(rs_bands))
+    edges = [(r * tiles_y) // R for r in range(R + 1)]
+    return [(edges[r], edges[r + 1]) for r in range(R)]
+
+
+def subpose_viewmats(viewmat: torch.Tensor, lin_vel: torch.Tensor, ang_vel: torch.Tensor, times) -> torch.Tensor:
+    """viewmat(t) = Exp(-t*xi) @ viewmat with body twist xi=(v,w) in the OpenCV camera frame, through
+    torch.linalg.matrix_exp (an independent route from the closed form in gs_math.h::se3_exp)."""
+    dt = viewmat.dtype
+    out = []
+    for t in times:
+        xi = torch.zeros(4, 4, dtype=dt)
+        w = -float(t) * ang_vel.to(dt)
+        v = -float(t) * lin_vel.to(dt)
+        xi = torch.stack([
+            torch.stack([torch.zeros((), dtype=dt), -w[2], w[1], v[0]]),
+            torch.stack([w[2], torch.zeros((), dtype=dt), -w[0], v[1]]),
+            torch.stack([-w[1], w[0], torch.zeros((), dtype=dt), v[2]]),
+            torch.zeros(4, dtype=dt),
+        ])
+        out.append(torch.linalg.matrix_exp(xi) @ viewmat.to(dt))
+    return torch.stack(out)
+
+
+# --------------------------------------------------------------------------- #
+# the full path: S x R sub-poses -> gamma-space mean
+# --------------------------------------------------------------------------- #
+@dataclass
+class RenderConfig:
+    img_height: int
+    img_width: int
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    sh_degree: int = 3
+    blur_samples: int = 1            # S ; 0/1 = no motion-blur averaging   (train.py:46,51)
+    rs_bands: int = 1                # R ; 1 = no rolling-shutter compensation (train.py:56)
+    exposure_time: float = 0.0
+    rolling_shutter_time: float = 0.0
+    gamma: float = 1.0               # train.py:62
+    min_rgb_level: float = 0.0       # in 0..255 units, train.py:60
+    antialiased: bool = True         # train.py:119
+    glob_scale: float = 1.0
+    clip_thresh: float = 0.01
+
+
+def combine_samples(samples: torch.Tensor, gamma: float, min_rgb_level: float) -> torch.Tensor:
+    """[S,H,W,3] per-sample composites -> final image: mean in linearised colour.
+    out = ( mean_k max(C_k, m)^gamma )^(1/gamma), m = min_rgb_level/255."""
+    m = min_rgb_level / 255.0
+    x = torch.clamp(samples, min=m) if m > 0 else samples
+    if gamma == 1.0:
+        return x.mean(dim=0)
+    x = torch.clamp(x, min=1e-12)
+    return x.pow(gamma).mean(dim=0).pow(1.0 / gamma)
+
+
+def render(cfg: RenderConfig, means, scales, quats, opacities, sh_coeffs, viewmat, lin_vel, ang_vel,
+           background: Optional[torch.Tensor] = None, return_parts: bool = False):
+    """Full oracle path.  scales/opacities are ACTIVATED values (exp / sigmoid applied by the caller)."""
+    dt = means.dtype
+    times, samp, band = subpose_times(cfg.blur_samples, cfg.exposure_time, cfg.rs_bands, cfg.rolling_shutter_time)
+    vms = subpose_viewmats(viewmat, lin_vel, ang_vel, times)
+    rows = band_tile_rows(cfg.img_height, cfg.rs_bands)
+    S = max(1, cfg.blur_samples)
+    H, W = cfg.img_height, cfg.img_width
+    sample_imgs = [torch.zeros(H, W, 3, dtype=dt) for _ in range(S)]
+    sample_alpha = [torch.zeros(H, W, dtype=dt) for _ in range(S)]
+    parts = []
+    frag = torch.zeros(H, W, dtype=torch.bool)
+    for p, V in enumerate(vms):
+        pr = project_gaussians(means, scales, cfg.glob_scale, quats, V, cfg.fx, cfg.fy, cfg.cx, cfg.cy,
+                               H, W, TILE, cfg.clip_thresh)
+        Rwc, twc = V[:3, :3].detach(), V[:3, 3].detach()
+        cam_pos = -(Rwc.T @ twc)
+        dirs = means.detach() - cam_pos[None, :]
+        rgb = torch.clamp(spherical_harmonics(cfg.sh_degree, dirs, sh_coeffs) + 0.5, min=0.0)
+        op = opacities.reshape(-1) * (pr.compensation if cfg.antialiased else 1.0)
+        keys, gids = map_gaussian_to_intersects(pr, W)
+        keys, gids = sort_intersects(keys, gids)
+        tiles = ((W + TILE - 1) // TILE) * ((H + TILE - 1) // TILE)
+        bins = get_tile_bin_edges(keys, tiles)
+        r = rasterize_sorted(pr.xys, pr.conics, rgb, op, gids, bins, H, W, background, tile_rows=rows[band[p]])
+        sample_imgs[samp[p]] = sample_imgs[samp[p]] + r.img
+        sample_alpha[samp[p]] = sample_alpha[samp[p]] + r.alpha
+        frag |= r.fragile
+        parts.append((pr, keys, gids, bins, r, rgb, op))
+    samples = torch.stack(sample_imgs)
+    out = combine_samples(samples, cfg.gamma, cfg.min_rgb_level)
+    alpha = torch.stack(sample_alpha).mean(dim=0)
+    if return_parts:
+        return out, alpha, samples, frag, parts, vms
+    return out, alpha
+
+
+# --------------------------------------------------------------------------- #
+# seeded synthetic scenes
+# --------------------------------------------------------------------------- #
+def synthetic_scene(n: int, width: int, height: int, sh_degree: int = 3, seed: int = 1234, dtype=torch.float32,
+                    scale_mult: float = 1.0):
+    """Camera at origin, OpenCV axes, fx=fy=0.8*W.  Returns dict of raw (pre-activation) parameters.
+    scale_mult enlarges the Gaussians (tests at tiny resolutions use it to get dense overlap and early
+    termination; the benchmark scenes of SURVEY §8d use 1.0)."""
+    g = torch.Generator().manual_seed(seed)
+    fx = fy = 0.8 * width
+    cx, cy = width / 2.0, height / 2.0
+    z = 1.0 + 9.0 * torch.rand(n, generator=g)
+    u = (torch.rand(n, generator=g) * 2 - 1) * 1.2
+    v = (torch.rand(n, generator=g) * 2 - 1) * 1.2
+    x = u * z * (0.5 * width / fx)
+    y = v * z * (0.5 * height / fy)
+    means = torch.stack([x, y, z], -1)
+    zbar = 5.5
+    log_scales = math.log(0.004 * zbar * scale_mult) + 0.6 * torch.randn(n, 3, generator=g)
+    quats = torch.randn(n, 4, generator=g)
+    quats = quats / quats.norm(dim=-1, keepdim=True)
+    opacity_logits = 2.0 * torch.randn(n, generator=g)
+    K = (sh_degree + 1) ** 2
+    sh = torch.cat([0.5 * torch.randn(n, 1, 3, generator=g), 0.05 * torch.randn(n, K - 1, 3, generator=g)], 1)
+    lin_vel = 0.1 * (torch.rand(3, generator=g) * 2 - 1)
+    ang_vel = 0.2 * (torch.rand(3, generator=g) * 2 - 1)
+    d = dict(means=means, log_scales=log_scales, quats=quats, opacity_logits=opacity_logits, sh=sh,
+             viewmat=torch.eye(4), lin_vel=lin_vel, ang_vel=ang_vel, fx=fx, fy=fy, cx=cx, cy=cy,
+             exposure_time=1.0 / 60.0, rolling_shutter_time=1.0 / 30.0)
+    return {k: (t.to(dtype) if isinstance(t, torch.Tensor) else t) for k, t in d.items()}

@@ -1,0 +1,101 @@
+"""Host-side logic on CPU: sub-pose schedule, camera convention handling, DP sharding and the
+gradient all-reduce over a world_size-2 gloo group."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_schedule_matches_oracle(gs, oracle):
+    for S, R in [(1, 1), (5, 1), (1, 10), (3, 4), (0, 0)]:
+        a = gs.subpose_schedule(S, 1 / 60, R, 1 / 30)
+        b = oracle.subpose_times(S, 1 / 60, R, 1 / 30)
+        assert np.allclose(a[0], b[0]) and a[1] == b[1] and a[2] == b[2]
+    t, s, r = gs.subpose_schedule(5, 0.02, 1, 0.0)
+    assert abs(sum(t)) < 1e-12 and max(t) < 0.01 and min(t) > -0.01     # centred, inside the exposure
+    assert s == list(range(5)) and r == [0] * 5
+
+
+def test_band_edges_partition_tile_rows(gs, oracle):
+    from gsdeblur_amd.ops import _band_edges
+    for H in (16, 270, 1080, 2160):
+        for R in (1, 3, 10, 68):
+            e = _band_edges(H, R, "cpu").tolist()
+            ty = (H + 15) // 16
+            assert e[0] == 0 and e[-1] == ty and all(e[i] <= e[i + 1] for i in range(R))
+            assert [tuple(x) for x in zip(e[:-1], e[1:])] == oracle.band_tile_rows(H, R)
+
+
+def test_camera_convention_opengl_to_opencv(gs):
+    """A camera looking down -z (OpenGL) must see a point in front of it at +z in the OpenCV viewmat, and
+    velocities given in the OpenGL camera frame must be flipped consistently
+    (process_synthetic_inputs.py:163-165, render_video.py:110-115)."""
+    cfg = gs.SplatfactoDeblurConfig(background_color="black")
+    n = 4
+    model = gs.SplatfactoDeblurModel(cfg, torch.zeros(n, 3), torch.zeros(n, 3), torch.ones(n, 4), torch.zeros(n),
+                                     torch.zeros(n, 3), torch.zeros(n, 15, 3))
+    c2w = torch.eye(4)[:3]
+    c2w[:, 3] = torch.tensor([1.0, 2.0, 3.0])
+    cam = gs.Camera(c2w, 100, 100, 32, 32, 64, 64,
+                    metadata=dict(camera_linear_velocity=[0.1, 0.2, 0.3], camera_angular_velocity=[0.01, 0.02, 0.03],
+                                  exposure_time=0.01, rolling_shutter_time=0.02))
+    V, lin, ang = model._viewmat_and_velocity(cam)
+    p_world = torch.tensor([1.0, 2.0, 3.0 - 5.0, 1.0])             # 5 units along the GL viewing direction (-z)
+    pc = V @ p_world
+    assert torch.allclose(pc[:3], torch.tensor([0.0, 0.0, 5.0]), atol=1e-6)
+    assert torch.allclose(lin, torch.tensor([0.1, -0.2, -0.3])) and torch.allclose(ang, torch.tensor([0.01, -0.02, -0.03]))
+    S, R, times = model._schedule(cam)
+    assert (S, R) == (cfg.blur_samples, cfg.rs_bands) and len(times) == S * R
+    cam.metadata["exposure_time"] = 0.0
+    cam.metadata["rolling_shutter_time"] = 0.0
+    assert model._schedule(cam)[:2] == (1, 1)
+
+
+def test_shard_views_covers_every_view_once(gs):
+    for world in (1, 2, 3, 8):
+        got = sorted(i for r in range(world) for i in gs.dp.shard_views(8, r, world))
+        assert got == list(range(8))
+    with pytest.raises(ValueError):
+        gs.dp.shard_views(8, 8, 8)
+
+
+def _dp_worker(rank, world, port, mode, q):
+    sys.path.insert(0, str(ROOT))
+    import gsdeblur_amd as gs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    shapes = [(50, 3), (50, 3), (50, 4), (50, 1), (50, 3), (50, 15, 3)]      # the 6 Gaussian gradient tensors
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    params[3].grad = None if rank == 0 else params[3].grad                    # a rank without a grad contributes 0
+    gs.dp.allreduce_gradients(params, mode=mode)
+    ok = True
+    for i, p in enumerate(params):
+        want = sum(float(r + 1) * (i + 1) for r in range(world) if not (i == 3 and r == 0))
+        ok &= bool(torch.allclose(p.grad, torch.full_like(p, want)))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+def test_gradient_allreduce_world2_gloo(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + (0 if mode == "allreduce" else 1)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

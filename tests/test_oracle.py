@@ -1,0 +1,221 @@
+"""Reference-independent known-answer tests that pin the CPU oracle (parity is otherwise
+unpinned: the reference's implementation of this path is not vendored — SURVEY.md §8c)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def _cfg(O, sc, H, W, **kw):
+    return O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], **kw)
+
+
+def _render64(O, sc, cfg, **over):
+    g = lambda k: over.get(k, sc[k]).double()
+    return O.render(cfg, g("means"), g("log_scales").exp(), g("quats"), torch.sigmoid(g("opacity_logits")),
+                    g("sh"), g("viewmat"), g("lin_vel"), g("ang_vel"))
+
+
+def test_single_gaussian_analytic(oracle):
+    """One isotropic Gaussian on the optical axis: image = o * exp(-r^2 / (2 s^2)) * colour."""
+    O = oracle
+    H = W = 96
+    fx = fy = 40.0
+    z, s3d, o = 4.0, 0.3, 0.8
+    means = torch.tensor([[0.0, 0.0, z]], dtype=torch.float64)
+    scales = torch.full((1, 3), s3d, dtype=torch.float64)
+    quats = torch.tensor([[1.0, 0, 0, 0]], dtype=torch.float64)
+    pr = O.project_gaussians(means, scales, 1.0, quats, torch.eye(4, dtype=torch.float64), fx, fy, W / 2, H / 2, H, W)
+    var = (fx * s3d / z) ** 2 + O.DILATION
+    assert abs(pr.conics[0, 0].item() - 1 / var) < 1e-12 and abs(pr.conics[0, 1].item()) < 1e-12
+    assert pr.radii[0].item() == int(np.ceil(3 * np.sqrt(var)))
+    assert abs(pr.compensation[0].item() - ((fx * s3d / z) ** 2) / var) < 1e-12  # sqrt(det0/det) = s^2/(s^2+.3)
+    col = torch.tensor([[0.2, 0.5, 0.9]], dtype=torch.float64)
+    img, r = O.rasterize_gaussians(pr.xys, pr.depths, pr.radii, pr.conics, pr.num_tiles_hit, col,
+                                   torch.tensor([o], dtype=torch.float64), H, W, proj=pr)
+    yy, xx = np.meshgrid(np.arange(H) + 0.5, np.arange(W) + 0.5, indexing="ij")
+    r2 = (xx - W / 2) ** 2 + (yy - H / 2) ** 2
+    a = o * np.exp(-0.5 * r2 / var)
+    a[a < 1 / 255] = 0
+    # tiles the bbox does not reach stay empty
+    ref = a[..., None] * col.numpy()[0]
+    got = img.numpy()
+    covered = np.zeros((H, W), bool)
+    tmn, tmx = pr.tile_min[0].numpy(), pr.tile_max[0].numpy()
+    covered[tmn[1] * 16:tmx[1] * 16, tmn[0] * 16:tmx[0] * 16] = True
+    assert np.abs(got[covered] - ref[covered]).max() < 1e-12
+    assert np.abs(got[~covered]).max() == 0
+
+
+def test_opaque_front_gaussian_stops_the_rest(oracle):
+    """Front-to-back order + early stop: behind a stack that drives T below 1e-4 nothing contributes."""
+    O = oracle
+    H = W = 16
+    n_front = 8
+    means = torch.tensor([[0.0, 0.0, 2.0 + 0.01 * i] for i in range(n_front)] + [[0.0, 0.0, 5.0]], dtype=torch.float64)
+    scales = torch.full((n_front + 1, 3), 5.0, dtype=torch.float64)
+    quats = torch.tensor([[1.0, 0, 0, 0]] * (n_front + 1), dtype=torch.float64)
+    pr = O.project_gaussians(means, scales, 1.0, quats, torch.eye(4, dtype=torch.float64), 20, 20, 8, 8, H, W)
+    cols = torch.tensor([[1.0, 0, 0]] * n_front + [[0, 1.0, 0]], dtype=torch.float64)
+    op = torch.full((n_front + 1,), 0.99, dtype=torch.float64)
+    img, r = O.rasterize_gaussians(pr.xys, pr.depths, pr.radii, pr.conics, pr.num_tiles_hit, cols, op, H, W, proj=pr)
+    assert img[..., 1].abs().max().item() == 0.0          # the green one behind is never blended
+    assert (r.final_T > oracle.T_MIN).all()                 # stop happens BEFORE T would fall to <= 1e-4
+    assert (r.final_idx < n_front + 1).all()
+
+
+def test_static_equals_zero_velocity_and_S_average(oracle):
+    O = oracle
+    W, H = 64, 48
+    sc = O.synthetic_scene(300, W, H, seed=3, scale_mult=8.0)
+    zero = torch.zeros(3)
+    base, _ = _render64(O, sc, _cfg(O, sc, H, W))
+    blur0, _ = _render64(O, sc, _cfg(O, sc, H, W, blur_samples=4, rs_bands=3, exposure_time=0.02,
+                                     rolling_shutter_time=0.03), lin_vel=zero, ang_vel=zero)
+    assert torch.allclose(base, blur0, atol=1e-12)
+    # S-sample average == mean of S independent single-pose renders at the sub-pose viewmats
+    cfgS = _cfg(O, sc, H, W, blur_samples=3, exposure_time=0.05)
+    outS, _ = _render64(O, sc, cfgS)
+    times, _, _ = O.subpose_times(3, 0.05, 1, 0.0)
+    vms = O.subpose_viewmats(sc["viewmat"].double(), sc["lin_vel"].double(), sc["ang_vel"].double(), times)
+    acc = 0
+    for V in vms:
+        o, _ = _render64(O, sc, _cfg(O, sc, H, W), viewmat=V, lin_vel=zero, ang_vel=zero)
+        acc = acc + o
+    assert torch.allclose(outS, acc / 3, atol=1e-12)
+
+
+def test_gamma_mean_identities(oracle):
+    O = oracle
+    s = torch.rand(4, 5, 6, 3, dtype=torch.float64)
+    assert torch.allclose(O.combine_samples(s, 1.0, 0.0), s.mean(0))
+    same = s[:1].expand(4, -1, -1, -1)
+    assert torch.allclose(O.combine_samples(same, 2.2, 0.0), s[0], atol=1e-12)   # mean of equal samples is identity
+    m = 10.0
+    out = O.combine_samples(s * 0.01, 2.2, m)                                      # everything below the floor
+    assert torch.allclose(out, torch.full_like(out, m / 255.0), atol=1e-12)
+
+
+def test_permutation_invariance(oracle):
+    O = oracle
+    W, H = 48, 32
+    sc = O.synthetic_scene(200, W, H, seed=5, scale_mult=8.0)
+    cfg = _cfg(O, sc, H, W)
+    a, _ = _render64(O, sc, cfg)
+    perm = torch.randperm(200, generator=torch.Generator().manual_seed(0))
+    sc2 = {k: (v[perm] if isinstance(v, torch.Tensor) and v.shape[:1] == (200,) else v) for k, v in sc.items()}
+    b, _ = _render64(O, sc2, cfg)
+    assert torch.allclose(a, b, atol=1e-12)
+
+
+@pytest.mark.parametrize("sh_degree", [0, 3])
+def test_finite_difference_gradients(oracle, sh_degree):
+    """autograd through the float64 oracle vs central differences on a few coordinates.
+    View directions are detached (splatfacto semantics: no gradient through SH dirs), so with
+    sh_degree=3 only the parameters that do not move the view direction are differenced."""
+    O = oracle
+    W, H = 32, 32
+    sc = O.synthetic_scene(40, W, H, seed=9, scale_mult=10.0, sh_degree=sh_degree)
+    cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], sh_degree=sh_degree, blur_samples=2,
+                         rs_bands=2, exposure_time=0.02, rolling_shutter_time=0.02, gamma=2.2, min_rgb_level=5.0)
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel"]
+    fd_names = names if sh_degree == 0 else ["log_scales", "quats", "opacity_logits", "sh"]
+    ps = {k: sc[k].double().clone().requires_grad_(True) for k in names}
+    wt = torch.rand(H, W, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+
+    def loss(p):
+        out, _ = O.render(cfg, p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["opacity_logits"]),
+                          p["sh"], sc["viewmat"].double(), p["lin_vel"], p["ang_vel"])
+        return (out * wt).sum()
+
+    loss(ps).backward()
+    rng = np.random.default_rng(0)
+    eps = 1e-6
+    worst = {}
+    for k in fd_names:
+        flat = ps[k].detach().reshape(-1)
+        for idx in rng.choice(flat.numel(), size=min(5, flat.numel()), replace=False):
+            def at(delta):
+                q = {kk: vv.detach().clone() for kk, vv in ps.items()}
+                q[k].reshape(-1)[idx] += delta
+                return loss(q).item()
+            fd = (at(eps) - at(-eps)) / (2 * eps)
+            an = ps[k].grad.reshape(-1)[idx].item()
+            worst[k] = max(worst.get(k, 0.0), abs(fd - an) / (abs(an) + abs(fd) + 1e-5))
+    # thresholds (alpha>=1/255, T<=1e-4, bbox tiles) make the image piecewise smooth; with eps=1e-6 a
+    # flip is improbable on 40 Gaussians and would show up as an O(1) relative error
+    assert max(worst.values()) < 5e-4, worst
+
+
+def test_sh_orthonormal_and_independent_forms(oracle):
+    """All 25 real SH basis functions are orthonormal on the sphere (Gauss-Legendre x uniform-phi quadrature)."""
+    O = oracle
+    x, w = np.polynomial.legendre.leggauss(64)
+    ph = np.arange(128) * 2 * np.pi / 128
+    th = np.arccos(x)
+    T, Pm = np.meshgrid(th, ph, indexing="ij")
+    dirs = np.stack([np.sin(T) * np.cos(Pm), np.sin(T) * np.sin(Pm), np.cos(T)], -1).reshape(-1, 3)
+    ww = (w[:, None] * np.ones(128)[None, :] * 2 * np.pi / 128).reshape(-1)
+    B = O.sh_basis(4, torch.from_numpy(dirs)).numpy()
+    G = (B * ww[:, None]).T @ B
+    assert np.abs(G - np.eye(25)).max() < 1e-12
+
+
+def test_se3_screw_properties(oracle):
+    O = oracle
+    V0 = O.subpose_viewmats(torch.eye(4, dtype=torch.float64), torch.tensor([0.3, -0.2, 0.5], dtype=torch.float64),
+                            torch.tensor([0.2, 0.4, -0.1], dtype=torch.float64), [1.0])[0]
+    lin = torch.tensor([0.1, 0.2, -0.3], dtype=torch.float64)
+    ang = torch.tensor([-0.5, 0.25, 0.4], dtype=torch.float64)
+    Vs = O.subpose_viewmats(V0, lin, ang, [-0.2, 0.0, 0.2, 0.4])
+    assert torch.allclose(Vs[1], V0, atol=1e-14)                                  # t=0 is the identity
+    R = Vs[:, :3, :3]
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3, dtype=torch.float64).expand(4, 3, 3), atol=1e-13)
+    # one-parameter subgroup: V(t1+t2) = Exp(-t2 xi) V(t1)
+    V02 = O.subpose_viewmats(Vs[2], lin, ang, [0.2])[0]
+    assert torch.allclose(V02, Vs[3], atol=1e-13)
+    # pure translation: camera centre moves by +t*R_c2w*v
+    Vt = O.subpose_viewmats(V0, lin, torch.zeros(3, dtype=torch.float64), [0.5])[0]
+    c0 = -(V0[:3, :3].T @ V0[:3, 3])
+    c1 = -(Vt[:3, :3].T @ Vt[:3, 3])
+    assert torch.allclose(c1 - c0, 0.5 * (V0[:3, :3].T @ lin), atol=1e-13)
+
+
+def test_binning_consistency(oracle):
+    O = oracle
+    W, H = 80, 64
+    sc = O.synthetic_scene(400, W, H, seed=21, scale_mult=10.0)
+    pr = O.project_gaussians(sc["means"], sc["log_scales"].exp(), 1.0, sc["quats"], sc["viewmat"], sc["fx"], sc["fy"],
+                             sc["cx"], sc["cy"], H, W)
+    keys, gids = O.map_gaussian_to_intersects(pr, W)
+    assert len(keys) == int(pr.num_tiles_hit.sum())
+    sk, sg = O.sort_intersects(keys, gids)
+    assert (np.diff(sk) >= 0).all()
+    T = 5 * 4
+    bins = O.get_tile_bin_edges(sk, T)
+    assert bins[:, 1].max() == len(sk) and ((bins[:, 1] - bins[:, 0]).sum() == len(sk))
+    for t in range(T):
+        s, e = bins[t]
+        assert ((sk[s:e] >> 32) == t).all()
+        d = pr.depths.numpy()[sg[s:e]]
+        assert (np.diff(d) >= 0).all()
+
+
+@pytest.mark.parametrize("name", ["static_small", "blur_rs_small"])
+def test_oracle_matches_committed_golden(oracle, name):
+    """The oracle reproduces the committed fixtures (guards against silent drift of the checker)."""
+    O = oracle
+    d = np.load(GOLD / f"{name}.npz")
+    H, W, S, R, deg = (int(v) for v in d["cfg"])
+    et, rt, gamma, mlevel = (float(v) for v in d["cfg_f"])
+    cfg = O.RenderConfig(H, W, float(d["fx"]), float(d["fy"]), float(d["cx"]), float(d["cy"]), sh_degree=deg,
+                         blur_samples=S, rs_bands=R, exposure_time=et, rolling_shutter_time=rt, gamma=gamma,
+                         min_rgb_level=mlevel)
+    t = lambda k: torch.from_numpy(d[k]).double()
+    out, alpha = O.render(cfg, t("means"), t("log_scales").exp(), t("quats"), torch.sigmoid(t("opacity_logits")),
+                          t("sh"), t("viewmat"), t("lin_vel"), t("ang_vel"), background=t("background"))
+    assert np.abs(out.numpy() - d["out"]).max() < 1e-12
+    assert np.abs(alpha.numpy() - d["alpha"]).max() < 1e-12
