@@ -25,6 +25,53 @@ TILE = 16
 REC = 12  # floats per rasterizer record
 
 
+class StageProfiler:
+    """Optional per-stage timing with HIP events recorded on the stream the kernels are launched on
+    (torch's current stream).  Enabled by bench.py; `None` (default) costs nothing."""
+
+    def __init__(self):
+        self.events = {}
+
+    class _Ctx:
+        def __init__(self, prof, name):
+            self.prof, self.name = prof, name
+
+        def __enter__(self):
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+            return self
+
+        def __exit__(self, *exc):
+            self.b.record()
+            self.prof.events.setdefault(self.name, []).append((self.a, self.b))
+            return False
+
+    def stage(self, name):
+        return StageProfiler._Ctx(self, name)
+
+    def summary_ms(self):
+        torch.cuda.synchronize()
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in self.events.items()}
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+profiler: Optional[StageProfiler] = None
+last_num_intersects: int = 0
+_NULL = _Null()
+
+
+def _stage(name: str):
+    return _NULL if profiler is None else profiler.stage(name)
+
+
 # --------------------------------------------------------------------------- #
 # helpers
 # --------------------------------------------------------------------------- #
@@ -127,14 +174,18 @@ def bin_and_sort_records(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     n = P * N
     tx, ty = _tiles(img_height, img_width)
     T = tx * ty
-    keys64 = torch.empty(n, dtype=torch.int64, device=dev)
-    _check(L.gs_make_depth_keys64(n, N, _ptr(depth_keys), _ptr(keys64), _stream()), "depth keys")
-    end_bit = 32 + (_bits(P) if P > 1 else 0)
-    _, sorted_gi = radix_sort_pairs(keys64, None, 0, end_bit)
-    counts = torch.empty(n, dtype=torch.int32, device=dev)
-    _check(L.gs_gather_counts(n, _ptr(sorted_gi), _ptr(num_tiles_hit), _ptr(counts), _stream()), "gather counts")
-    cum, total = exclusive_scan_u32(counts)
+    global last_num_intersects
+    with _stage("depth_sort"):
+        keys64 = torch.empty(n, dtype=torch.int64, device=dev)
+        _check(L.gs_make_depth_keys64(n, N, _ptr(depth_keys), _ptr(keys64), _stream()), "depth keys")
+        end_bit = 32 + (_bits(P) if P > 1 else 0)
+        _, sorted_gi = radix_sort_pairs(keys64, None, 0, end_bit)
+    with _stage("count_scan"):
+        counts = torch.empty(n, dtype=torch.int32, device=dev)
+        _check(L.gs_gather_counts(n, _ptr(sorted_gi), _ptr(num_tiles_hit), _ptr(counts), _stream()), "gather counts")
+        cum, total = exclusive_scan_u32(counts)
     n_isect = int(total.item())  # host sync, as upstream's cum_tiles_hit[-1].item()
+    last_num_intersects = n_isect
     bins = torch.empty(P * T, 2, dtype=torch.int32, device=dev)
     if n_isect == 0:
         bins.zero_()
@@ -142,12 +193,15 @@ def bin_and_sort_records(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
         return z, bins, 0, z.clone()
     if n_isect < 0:
         raise OverflowError("more than 2^31-1 tile intersections; chunk the sub-poses")
-    keys = torch.empty(n_isect, dtype=torch.int32, device=dev)
-    vals = torch.empty(n_isect, dtype=torch.int32, device=dev)
-    _check(L.gs_emit_intersects(n, N, img_height, img_width, _ptr(sorted_gi), _ptr(cum), _ptr(records), n_isect,
-                                _ptr(keys), _ptr(vals), _stream()), "emit intersects")
-    skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T))
-    _check(L.gs_tile_bin_edges_u32(n_isect, _ptr(skeys), P * T, _ptr(bins), _stream()), "bin edges")
+    with _stage("emit"):
+        keys = torch.empty(n_isect, dtype=torch.int32, device=dev)
+        vals = torch.empty(n_isect, dtype=torch.int32, device=dev)
+        _check(L.gs_emit_intersects(n, N, img_height, img_width, _ptr(sorted_gi), _ptr(cum), _ptr(records), n_isect,
+                                    _ptr(keys), _ptr(vals), _stream()), "emit intersects")
+    with _stage("tile_sort"):
+        skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T))
+    with _stage("bin_edges"):
+        _check(L.gs_tile_bin_edges_u32(n_isect, _ptr(skeys), P * T, _ptr(bins), _stream()), "bin edges")
     return svals, bins, n_isect, skeys
 
 
@@ -448,18 +502,20 @@ class _RenderSubposes(Function):
         radii = torch.empty(P, N, dtype=torch.int32, device=dev)
         args = (N, P, float(glob_scale), K, int(sh_degree), float(fx), float(fy), float(cx), float(cy), H, W,
                 float(clip_thresh), int(bool(antialiased)))
-        _check(L.gs_project_fused_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
-                                      _ptr(sh), K, args[4], _ptr(V), args[5], args[6], args[7], args[8], H, W,
-                                      args[11], args[12], _ptr(records), _ptr(dkeys), _ptr(ntiles), _ptr(radii),
-                                      _stream()), "project_fused_fwd")
+        with _stage("project_fwd"):
+            _check(L.gs_project_fused_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
+                                          _ptr(sh), K, args[4], _ptr(V), args[5], args[6], args[7], args[8], H, W,
+                                          args[11], args[12], _ptr(records), _ptr(dkeys), _ptr(ntiles), _ptr(radii),
+                                          _stream()), "project_fused_fwd")
         svals, bins, n_isect, _ = bin_and_sort_records(records, dkeys, ntiles, P, N, H, W)
         bg = _background(background, dev)
         edges = _band_edges(H, R, dev)
         out_img = torch.empty(S, H, W, 3, device=dev)
         out_T = torch.empty(S, H, W, device=dev)
         fidx = torch.empty(S, H, W, dtype=torch.int32, device=dev)
-        _check(L.gs_rasterize_fwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
-                                  _ptr(out_img), _ptr(out_T), _ptr(fidx), _stream()), "rasterize_fwd")
+        with _stage("raster_fwd"):
+            _check(L.gs_rasterize_fwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
+                                      _ptr(out_img), _ptr(out_T), _ptr(fidx), _stream()), "rasterize_fwd")
         ctx.save_for_backward(means3d, scales, quats, opacities, sh, V, records, svals, bins, edges, bg, out_T, fidx)
         ctx.args = args
         ctx.SR = (S, R)
@@ -478,9 +534,10 @@ class _RenderSubposes(Function):
         v_img = v_img.contiguous().float()
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
         v_records = torch.zeros(P * N, REC, device=dev)
-        _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
-                                  _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records), _stream()),
-               "rasterize_bwd")
+        with _stage("raster_bwd"):
+            _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
+                                      _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records), _stream()),
+                   "rasterize_bwd")
         v_means = torch.empty(N, 3, device=dev)
         v_scales = torch.empty(N, 3, device=dev)
         v_quats = torch.empty(N, 4, device=dev)
@@ -488,10 +545,11 @@ class _RenderSubposes(Function):
         v_sh = torch.empty(N, K, 3, device=dev)
         need_v = ctx.needs_input_grad[5]
         v_V = torch.zeros(P, 4, 4, device=dev) if need_v else None
-        _check(L.gs_project_fused_bwd(N, P, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(opacities), _ptr(sh),
-                                      K, deg, _ptr(V), fx, fy, cx, cy, H, W, clip, aa, _ptr(records), _ptr(v_records),
-                                      _ptr(v_means), _ptr(v_scales), _ptr(v_quats), _ptr(v_opac), _ptr(v_sh),
-                                      _ptr(v_V), _stream()), "project_fused_bwd")
+        with _stage("project_bwd"):
+            _check(L.gs_project_fused_bwd(N, P, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(opacities),
+                                          _ptr(sh), K, deg, _ptr(V), fx, fy, cx, cy, H, W, clip, aa, _ptr(records),
+                                          _ptr(v_records), _ptr(v_means), _ptr(v_scales), _ptr(v_quats), _ptr(v_opac),
+                                          _ptr(v_sh), _ptr(v_V), _stream()), "project_fused_bwd")
         v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
         return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 12
 

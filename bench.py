@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py — fwd+bwd rasterize throughput of the hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
+torch.distributed.run with one rank per GPU (RCCL).  W untimed warm-up steps, then EXACTLY K timed
+steps bracketed by barrier + synchronize; MAX over ranks; rank 0 prints ONE JSON line.
+
+A "step" = one forward + backward of the full path for one camera view per rank:
+  SE(3) sub-pose viewmats -> fused projection of all Gaussians under S sub-poses (+SH, opacity)
+  -> depth pre-sort, tile emission, stable tile sort, bin edges -> per-pixel composite of the S
+  sample images -> gamma-space average -> dL/d(image) -> reverse-order rasterize backward ->
+  projection/SH backward to all Gaussian parameters, viewmat and velocity gradients
+  (+ for N>1: one all-reduce of the flattened Gaussian gradients).
+Workload = BASELINE.json's metric configuration: 1M Gaussians, 1920x1080, 5 motion-blur sub-poses,
+SH degree 3, seeded synthetic scene of SURVEY.md §8d; inputs resident in HBM before timing.
+Weak scaling: every rank renders its own view of the same (replicated) Gaussians.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def make_scene(n, W, H, seed=1234):
+    import gs_oracle as O   # only its seeded scene generator (data), never its renderer, on this leg
+    return O.synthetic_scene(n, W, H, sh_degree=3, seed=seed)
+
+
+def cpu_baseline():
+    """The CPU oracle (kind 'port': this repo's own restatement — gsplat's _torch_impl is not in the
+    reference tree) timed on BASELINE.json config 1: 5k Gaussians, 256x256, 1 sub-pose, fwd+bwd, fp32."""
+    import gs_oracle as O
+    W = H = 256
+    n = 5000
+    sc = O.synthetic_scene(n, W, H, seed=1234, scale_mult=4.0)
+    cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], blur_samples=1, rs_bands=1)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh"]
+
+    def one():
+        p = {k: sc[k].clone().requires_grad_(True) for k in names}
+        out, _ = O.render(cfg, p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["opacity_logits"]),
+                          p["sh"], sc["viewmat"], sc["lin_vel"], sc["ang_vel"])
+        out.mean().backward()
+
+    one()
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        one()
+        reps += 1
+        if time.perf_counter() - t0 > 10.0 or reps >= 20:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(W * H / 1e6 / dt, 5), "unit": "MPix/s", "cores": cores, "kind": "port",
+            "sample": f"own CPU oracle (torch fp32, vectorised per tile), 5k Gaussians 256x256 1 sub-pose, "
+                      f"fwd+bwd, mean of {reps} runs = {dt * 1e3:.0f} ms"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--subposes", type=int, default=5, help="motion-blur samples S")
+    ap.add_argument("--rs-bands", type=int, default=1, help="rolling-shutter row bands R")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allreduce", default="allreduce", choices=["allreduce", "rs_ag"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import gsdeblur_amd as gs
+    from gsdeblur_amd import ops
+
+    N, W, H, S, R = args.gaussians, args.width, args.height, args.subposes, args.rs_bands
+    sc = make_scene(N, W, H)
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh"]
+    params = {k: sc[k].to(dev).requires_grad_(True) for k in names}
+    # every rank renders its own view: rotate / shift the camera and vary the velocity per rank
+    g = torch.Generator().manual_seed(1000 + rank)
+    lin = (sc["lin_vel"] * (1.0 + 0.1 * rank)).to(dev).requires_grad_(True)
+    ang = (sc["ang_vel"] * (1.0 + 0.1 * rank)).to(dev).requires_grad_(True)
+    import gs_oracle as O
+    V0 = O.subpose_viewmats(torch.eye(4, dtype=torch.float64), torch.tensor([0.05 * rank, 0.0, 0.0], dtype=torch.float64),
+                            torch.tensor([0.0, 0.01 * rank, 0.0], dtype=torch.float64), [1.0])[0].float()
+    viewmat = V0.to(dev).requires_grad_(True)
+    times, _, _ = gs.subpose_schedule(S, sc["exposure_time"], R, sc["rolling_shutter_time"])
+    times_t = torch.tensor(times, device=dev)
+    wt = torch.rand(H, W, 3, generator=g).to(dev)        # dL/d(image): fixed random weights
+    bg = torch.zeros(3, device=dev)
+    all_params = list(params.values())
+
+    def step():
+        for p in all_params + [lin, ang, viewmat]:
+            p.grad = None
+        vms = gs.subpose_viewmats(viewmat, lin, ang, times_t)
+        samples, alphas, _ = gs.render_subposes(params["means"], params["log_scales"].exp(), params["quats"],
+                                                torch.sigmoid(params["opacity_logits"]), params["sh"], vms, bg, S, R,
+                                                sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, sh_degree=3,
+                                                antialiased=True)
+        out = gs.combine_samples(samples, 2.2, 10.0)
+        loss = (out * wt).sum()
+        loss.backward()
+        if world > 1:
+            gs.dp.allreduce_gradients(all_params, mode=args.allreduce)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.profiler = ops.StageProfiler()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    stages = ops.profiler.summary_ms()
+    ops.profiler = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    n_isect = ops.last_num_intersects
+
+    if rank == 0:
+        npix = H * W
+        value = world * npix / 1e6 / (ms_per_step / 1e3)
+        stage_ms = {k: round(sum(v) / len(v), 4) for k, v in stages.items()}
+        # dominant single kernel = the stage with the largest mean time among the single-launch stages
+        single = {k: stage_ms[k] for k in ("raster_bwd", "raster_fwd", "project_fwd", "project_bwd") if k in stage_ms}
+        dom = max(single, key=single.get)
+        P = S * R
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        # algorithmic bytes per launch, I = measured intersections of the step
+        alg = {
+            "raster_fwd": 40 * n_isect + S * 20 * npix,
+            "raster_bwd": 40 * n_isect + S * 32 * npix + 36 * P * N,
+            "project_fwd": 236 * N + 48 * P * N,
+            "project_bwd": 84 * P * N + 2 * 236 * N,
+        }
+        pipeline_bytes = (alg["project_fwd"] + n_isect * (12 + 24) + 8 * P * T + alg["raster_fwd"] + 12 * npix +
+                          alg["raster_bwd"] + alg["project_bwd"])
+        achieved = alg[dom] / (single[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": {"raster_bwd": "raster_bwd_kernel", "raster_fwd": "raster_fwd_kernel",
+                                               "project_fwd": "project_fused_fwd_kernel",
+                                               "project_bwd": "project_fused_bwd_kernel"}[dom],
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": single[dom],
+                    "pipeline_frac": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "pipeline_algorithmic_bytes": pipeline_bytes}
+        line = {
+            "metric": "fwd+bwd rasterize MPix/s at 1M Gaussians, 1080p, 5 sub-poses",
+            "value": round(value, 3), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic scene (SURVEY §8d, seed 1234): {N} Gaussians, {W}x{H}, "
+                                   f"S={S} motion-blur sub-poses x R={R} row bands, SH degree 3, gamma 2.2, "
+                                   f"fwd+bwd to all Gaussian params + viewmat + velocities",
+                       "gaussians": N, "width": W, "height": H, "subposes": S, "rs_bands": R,
+                       "tile_intersections_per_step": n_isect, "views_per_step": world,
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "subpose_MPix_per_s": round(value * S, 3)},
+            "stage_ms": stage_ms,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

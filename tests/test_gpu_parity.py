@@ -1,0 +1,434 @@
+"""GPU parity: the HIP path (through the C-ABI library) against the CPU oracle on the same seeded
+inputs and against the committed golden fixtures.
+
+Bars (north_star): tile counts / radii / sort keys / sorted order / bin edges BIT-EXACT; floats
+within the fp32 tolerances written at each assert (fp32 HIP with fast exp vs float64 oracle).
+Pixels whose threshold decisions (alpha >= 1/255, T <= 1e-4) sit within rounding of flipping are
+flagged by the oracle (`fragile`) and excluded from strict comparisons; everything else is compared.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+IMG_ATOL = 2e-4       # rendered colour, absolute (values in [0,1])
+GRAD_RTOL = 3e-3      # gradients, relative to the tensor's max |g| (sums of ~1e3-1e5 fp32 atomics)
+
+
+def rel_max(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def to_dev(sc, dev):
+    return {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
+
+
+# --------------------------------------------------------------------------- #
+# integer primitives
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("n", [1, 63, 2048, 2049, 100_003, 3_000_017])
+def test_exclusive_scan(gs, dev, n):
+    g = torch.Generator().manual_seed(n)
+    x = torch.randint(0, 300, (n,), generator=g, dtype=torch.int32)
+    ex, total = gs.exclusive_scan_u32(x.to(dev))
+    ref = torch.cumsum(x.long(), 0) - x.long()
+    assert torch.equal(ex.cpu().long(), ref)
+    assert int(total.item()) == int(x.long().sum())
+
+
+@pytest.mark.parametrize("n,bits,dtype", [(1, 8, torch.int32), (4097, 16, torch.int32), (300_001, 17, torch.int32),
+                                          (1_000_003, 32, torch.int32), (200_003, 45, torch.int64),
+                                          (50_001, 35, torch.int64), (70_000, 13, torch.int32)])
+def test_radix_sort_stable(gs, dev, n, bits, dtype):
+    """ascending, STABLE (ties keep input order), payload follows; keys limited to `bits` bits."""
+    g = torch.Generator().manual_seed(bits * 1000 + n % 997)
+    hi = 2 ** min(bits, 62)
+    keys = torch.randint(0, hi, (n,), generator=g, dtype=torch.int64)
+    if n > 100:
+        keys[: n // 3] = keys[n // 3: 2 * (n // 3)]        # plenty of ties
+    vals = torch.arange(n, dtype=torch.int32)
+    kd = keys.to(dtype).to(dev) if dtype == torch.int64 else keys.to(torch.int32).to(dev)   # u32 bit pattern
+    ks, vs = gs.radix_sort_pairs(kd.clone(), vals.to(dev).clone(), 0, bits)
+    order = torch.sort(keys, stable=True).indices
+    assert torch.equal(vs.cpu().long(), order)
+    got = ks.cpu().long()
+    if dtype == torch.int32:
+        got = got & 0xFFFFFFFF
+    assert torch.equal(got, keys[order])
+    # iota payload path
+    ks2, vs2 = gs.radix_sort_pairs(kd.clone(), None, 0, bits)
+    assert torch.equal(vs2.cpu().long(), order)
+
+
+# --------------------------------------------------------------------------- #
+# projection / SH / sub-poses
+# --------------------------------------------------------------------------- #
+def _scene(oracle, n, W, H, seed, scale_mult, dev):
+    sc = oracle.synthetic_scene(n, W, H, seed=seed, scale_mult=scale_mult)
+    means = sc["means"].clone()
+    k = max(1, n // 100)
+    means[:k, 2] = -1.0
+    means[k:2 * k, 0] *= 5.0
+    sc["means"] = means
+    return sc
+
+
+def test_subpose_viewmats_fwd_bwd(gs, oracle, dev):
+    V0 = oracle.subpose_viewmats(torch.eye(4, dtype=torch.float64), torch.tensor([0.3, -0.2, 0.5], dtype=torch.float64),
+                                 torch.tensor([0.2, 0.4, -0.1], dtype=torch.float64), [1.0])[0].float()
+    lin, ang = torch.tensor([0.1, 0.05, -0.2]), torch.tensor([0.05, -0.08, 0.03])
+    times = torch.tensor([-0.02, -0.01, 0.0, 0.01, 0.3])
+    for a in (ang, torch.zeros(3)):
+        Vd, ld, ad = (t.to(dev).requires_grad_(True) for t in (V0, lin, a))
+        out = gs.subpose_viewmats(Vd, ld, ad, times.to(dev))
+        V64, l64, a64 = (t.double().requires_grad_(True) for t in (V0, lin, a))
+        ref = oracle.subpose_viewmats(V64, l64, a64, times.tolist())
+        assert np.abs(out.detach().cpu().numpy() - ref.detach().numpy()).max() < 2e-6
+        go = torch.randn(5, 4, 4, generator=torch.Generator().manual_seed(1))
+        go[:, 3, :] = 0
+        (out * go.to(dev)).sum().backward()
+        (ref * go.double()).sum().backward()
+        assert rel_max(Vd.grad.cpu()[:3], V64.grad[:3]) < 1e-5
+        assert rel_max(ld.grad.cpu(), l64.grad) < 1e-5
+        assert rel_max(ad.grad.cpu(), a64.grad) < 1e-5
+
+
+@pytest.mark.parametrize("n,W,H,mult", [(5000, 256, 256, 4.0), (20000, 640, 360, 2.0), (7, 16, 16, 10.0)])
+def test_project_gaussians_parity(gs, oracle, dev, n, W, H, mult):
+    O = oracle
+    sc = _scene(O, n, W, H, 7, mult, dev)
+    V = O.subpose_viewmats(torch.eye(4, dtype=torch.float64), torch.tensor([0.1, 0.05, -0.2], dtype=torch.float64),
+                           torch.tensor([0.05, -0.08, 0.03], dtype=torch.float64), [1.0])[0].float()
+    scales, quats = sc["log_scales"].exp(), sc["quats"] * 1.7
+    pr = O.project_gaussians(sc["means"], scales, 1.0, quats, V, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W)
+    md, sd, qd, Vd = (t.to(dev).requires_grad_(True) for t in (sc["means"], scales, quats, V))
+    xys, depths, radii, conics, comp, ntiles, cov3d = gs.project_gaussians(
+        md, sd, 1.0, qd, Vd, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, 16)
+    # integers and depth key bits: exact
+    assert torch.equal(radii.cpu(), pr.radii)
+    assert torch.equal(ntiles.cpu(), pr.num_tiles_hit)
+    assert torch.equal(depths.cpu().view(torch.int32), pr.depths.view(torch.int32))
+    ok = pr.radii > 0
+    # floats: same op order without fma contraction -> expected bit-equal; tolerance 1e-6 relative
+    assert torch.allclose(xys.cpu()[ok], pr.xys[ok], rtol=1e-6, atol=1e-5)
+    assert torch.allclose(conics.cpu()[ok], pr.conics[ok], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(comp.cpu()[ok], pr.compensation[ok], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(cov3d.cpu(), pr.cov3d, rtol=1e-6, atol=1e-9)
+    assert (xys.cpu()[~ok] == 0).all()
+    # backward vs float64 autograd
+    g = torch.Generator().manual_seed(1)
+    vx, vd, vc, vcomp = (torch.randn(*s, generator=g) for s in ((n, 2), (n,), (n, 3), (n,)))
+    loss = (xys * vx.to(dev)).sum() + (depths * vd.to(dev) * (radii > 0)).sum() + (conics * vc.to(dev)).sum() + \
+        (comp * vcomp.to(dev)).sum()
+    loss.backward()
+    m64, s64, q64, V64 = (t.double().requires_grad_(True) for t in (sc["means"], scales, quats, V))
+    prd = O.project_gaussians(m64, s64, 1.0, q64, V64, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W)
+    l64 = (prd.xys * vx.double()).sum() + (prd.depths * vd.double() * (prd.radii > 0)).sum() + \
+        (prd.conics * vc.double()).sum() + (prd.compensation * vcomp.double()).sum()
+    l64.backward()
+    assert rel_max(md.grad.cpu(), m64.grad) < 3e-5
+    assert rel_max(sd.grad.cpu(), s64.grad) < 3e-5
+    assert rel_max(qd.grad.cpu(), q64.grad) < 3e-5
+    assert rel_max(Vd.grad.cpu()[:3], V64.grad[:3]) < 3e-4     # sum over N of fp32 terms (wave reduce + atomics)
+
+
+@pytest.mark.parametrize("deg,K", [(0, 1), (1, 4), (2, 9), (3, 16), (4, 25), (2, 16)])
+def test_spherical_harmonics_parity(gs, oracle, dev, deg, K):
+    g = torch.Generator().manual_seed(deg)
+    n = 3000
+    dirs = torch.randn(n, 3, generator=g) * 3.0                   # not normalised on purpose
+    coeffs = torch.randn(n, K, 3, generator=g)
+    cd = coeffs.to(dev).requires_grad_(True)
+    col = gs.spherical_harmonics(deg, dirs.to(dev), cd)
+    c64 = coeffs.double().requires_grad_(True)
+    ref = oracle.spherical_harmonics(deg, dirs.double(), c64)
+    assert np.abs(col.detach().cpu().numpy() - ref.detach().numpy()).max() < 2e-5
+    go = torch.randn(n, 3, generator=g)
+    (col * go.to(dev)).sum().backward()
+    (ref * go.double()).sum().backward()
+    assert rel_max(cd.grad.cpu(), c64.grad) < 1e-5
+    assert cd.grad.shape == (n, K, 3)
+
+
+# --------------------------------------------------------------------------- #
+# binning: 64-bit upstream-format route and the 2-stage route agree with the oracle exactly
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("n,W,H,mult", [(5000, 256, 256, 4.0), (30000, 640, 368, 2.0), (3, 16, 16, 10.0)])
+def test_binning_keys_and_order_bit_exact(gs, oracle, dev, n, W, H, mult):
+    O = oracle
+    sc = _scene(O, n, W, H, 13, mult, dev)
+    if n > 100:                       # force exact depth ties: identical Gaussians must order by id
+        sc["means"][200:260] = sc["means"][140:200]
+    scales = sc["log_scales"].exp()
+    pr = O.project_gaussians(sc["means"], scales, 1.0, sc["quats"], sc["viewmat"], sc["fx"], sc["fy"], sc["cx"],
+                             sc["cy"], H, W)
+    keys, gids = O.map_gaussian_to_intersects(pr, W)
+    skeys, sgids = O.sort_intersects(keys, gids)
+    tx, ty = (W + 15) // 16, (H + 15) // 16
+    bins_ref = O.get_tile_bin_edges(skeys, tx * ty)
+
+    xys, depths, radii, conics, comp, ntiles, _ = gs.project_gaussians(
+        sc["means"].to(dev), scales.to(dev), 1.0, sc["quats"].to(dev), sc["viewmat"].to(dev), sc["fx"], sc["fy"],
+        sc["cx"], sc["cy"], H, W, 16)
+    num_isect, cum = gs.compute_cumulative_intersects(ntiles)
+    assert num_isect == len(keys)
+    assert torch.equal(cum.cpu().long(), torch.cumsum(pr.num_tiles_hit.long(), 0))
+    iu, gu, isrt, gsrt, bins = gs.bin_and_sort_gaussians(n, num_isect, xys, depths, radii, cum, (tx, ty, 1), 16)
+    assert np.array_equal(iu.cpu().numpy(), keys) and np.array_equal(gu.cpu().numpy(), gids)
+    assert np.array_equal(isrt.cpu().numpy(), skeys)                      # sort keys bit-exact
+    assert np.array_equal(gsrt.cpu().numpy(), sgids)                      # incl. the tie-break order
+    assert np.array_equal(bins.cpu().numpy(), bins_ref)
+
+    # 2-stage route (depth pre-sort -> emit -> stable tile sort) yields the identical order
+    from gsdeblur_amd import ops
+    L = gs._lib.load()
+    rec = torch.empty(n, 12, device=dev)
+    dk = torch.empty(n, dtype=torch.int32, device=dev)
+    nt2 = torch.empty(n, dtype=torch.int32, device=dev)
+    col = torch.rand(n, 3, device=dev)
+    op = torch.rand(n, device=dev)
+    gs._lib.check(L.gs_pack_records(n, ops._ptr(xys), ops._ptr(depths), ops._ptr(radii), ops._ptr(conics),
+                                    ops._ptr(col), ops._ptr(op), H, W, ops._ptr(rec), ops._ptr(dk), ops._ptr(nt2),
+                                    ops._stream()), "pack")
+    assert torch.equal(nt2.cpu(), pr.num_tiles_hit)
+    svals, bins2, I2, skeys32 = gs.bin_and_sort_records(rec, dk, nt2, 1, n, H, W)
+    assert I2 == len(keys)
+    if I2:
+        assert np.array_equal(svals.cpu().numpy(), sgids)
+        assert np.array_equal(skeys32.cpu().numpy().astype(np.int64), skeys >> 32)
+    assert np.array_equal(bins2.cpu().numpy(), bins_ref)
+
+
+# --------------------------------------------------------------------------- #
+# rasterize_gaussians forward / backward
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("n,W,H,mult,bg", [(5000, 256, 256, 4.0, True), (3000, 100, 60, 12.0, False),
+                                           (2000, 48, 40, 3.0, True)])
+def test_rasterize_gaussians_parity(gs, oracle, dev, n, W, H, mult, bg):
+    """config 1 of BASELINE.json (5k Gaussians, 256x256, 1 sub-pose) plus ragged image sizes."""
+    O = oracle
+    sc = _scene(O, n, W, H, 17, mult, dev)
+    scales = sc["log_scales"].exp()
+    pr = O.project_gaussians(sc["means"], scales, 1.0, sc["quats"], sc["viewmat"], sc["fx"], sc["fy"], sc["cx"],
+                             sc["cy"], H, W)
+    g = torch.Generator().manual_seed(2)
+    colors = torch.rand(n, 3, generator=g)
+    opac = torch.sigmoid(sc["opacity_logits"]) * pr.compensation
+    background = torch.tensor([0.3, 0.6, 0.1]) if bg else None
+    # oracle in float64 on the float32-projected inputs
+    x64, c64, col64, o64 = (t.double().requires_grad_(True) for t in (pr.xys, pr.conics, colors, opac))
+    img_ref, alpha_ref, r = O.rasterize_gaussians(x64, pr.depths, pr.radii, c64, pr.num_tiles_hit, col64, o64, H, W,
+                                                  background=None if background is None else background.double(),
+                                                  return_alpha=True, proj=pr)
+    xd, cd, cold, od = (t.to(dev).requires_grad_(True) for t in (pr.xys, pr.conics, colors, opac))
+    bgd = None if background is None else background.to(dev).requires_grad_(True)
+    img, alpha = gs.rasterize_gaussians(xd, pr.depths.to(dev), pr.radii.to(dev), cd, pr.num_tiles_hit.to(dev), cold,
+                                        od[:, None], H, W, 16, bgd, return_alpha=True)
+    good = ~r.fragile
+    assert good.float().mean() > 0.9
+    d_img = (img.detach().cpu().double() - img_ref.detach()).abs()
+    assert d_img[good].max().item() < IMG_ATOL
+    assert (alpha.detach().cpu().double() - alpha_ref.detach()).abs()[good].max().item() < IMG_ATOL
+    # fragile pixels may flip one threshold decision but stay bounded
+    assert d_img.max().item() < 0.05
+    # backward on the non-fragile pixels
+    wt = torch.rand(H, W, 3, generator=g) * good[..., None]
+    wa = torch.rand(H, W, generator=g) * good
+    ((img * wt.to(dev)).sum() + (alpha * wa.to(dev)).sum()).backward()
+    ((img_ref * wt.double()).sum() + (alpha_ref * wa.double()).sum()).backward()
+    assert rel_max(xd.grad.cpu(), x64.grad) < GRAD_RTOL
+    assert rel_max(cd.grad.cpu(), c64.grad) < GRAD_RTOL
+    assert rel_max(cold.grad.cpu(), col64.grad) < GRAD_RTOL
+    assert rel_max(od.grad.cpu(), o64.grad) < GRAD_RTOL
+    if bg:
+        vbg_ref = (r.final_T[..., None] * wt.double()).sum(dim=(0, 1))
+        assert rel_max(bgd.grad.cpu(), vbg_ref) < 1e-4
+
+
+def test_rasterize_empty_scene(gs, dev):
+    """all Gaussians culled -> background image, zero alpha, zero gradients (edge case: I == 0)."""
+    n, H, W = 10, 40, 50
+    xys = torch.zeros(n, 2, device=dev, requires_grad=True)
+    col = torch.rand(n, 3, device=dev, requires_grad=True)
+    bg = torch.tensor([0.2, 0.4, 0.6], device=dev)
+    img, alpha = gs.rasterize_gaussians(xys, torch.ones(n, device=dev), torch.zeros(n, dtype=torch.int32, device=dev),
+                                        torch.ones(n, 3, device=dev), torch.zeros(n, dtype=torch.int32, device=dev),
+                                        col, torch.ones(n, 1, device=dev), H, W, 16, bg, return_alpha=True)
+    assert torch.allclose(img, bg.expand(H, W, 3)) and alpha.abs().max().item() == 0
+    img.sum().backward()
+    assert xys.grad.abs().max().item() == 0 and col.grad.abs().max().item() == 0
+
+
+# --------------------------------------------------------------------------- #
+# fused multi-sub-pose path vs the full oracle, and the committed golden fixtures
+# --------------------------------------------------------------------------- #
+def _run_full(gs, oracle, dev, sc, H, W, S, R, et, rt, gamma, mlevel, deg, background, weights):
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel", "viewmat"]
+    p = {k: sc[k].float().to(dev).requires_grad_(True) for k in names}
+    times, _, _ = gs.subpose_schedule(S, et, R, rt)
+    vms = gs.subpose_viewmats(p["viewmat"], p["lin_vel"], p["ang_vel"], torch.tensor(times, device=dev))
+    samples, alphas, radii = gs.render_subposes(p["means"], p["log_scales"].exp(), p["quats"],
+                                                torch.sigmoid(p["opacity_logits"]), p["sh"], vms,
+                                                background.float().to(dev), S, R, sc["fx"], sc["fy"], sc["cx"],
+                                                sc["cy"], H, W, sh_degree=deg, antialiased=True)
+    out = gs.combine_samples(samples, gamma, mlevel)
+    (out * weights.float().to(dev)).sum().backward()
+    return out, alphas.mean(0), samples, vms, p, radii
+
+
+@pytest.mark.parametrize("name", ["static_small", "blur_rs_small"])
+def test_fused_path_matches_golden(gs, dev, name):
+    d = np.load(GOLD / f"{name}.npz")
+    H, W, S, R, deg = (int(v) for v in d["cfg"])
+    et, rt, gamma, mlevel = (float(v) for v in d["cfg_f"])
+    sc = {k: torch.from_numpy(d[k]) for k in ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel",
+                                              "ang_vel", "viewmat"]}
+    sc.update(fx=float(d["fx"]), fy=float(d["fy"]), cx=float(d["cx"]), cy=float(d["cy"]))
+    out, alpha, samples, vms, p, radii = _run_full(gs, None, dev, sc, H, W, S, R, et, rt, gamma, mlevel, deg,
+                                                   torch.from_numpy(d["background"]), torch.from_numpy(d["weights"]))
+    assert np.abs(vms.detach().cpu().numpy() - d["viewmats"]).max() < 2e-6
+    good = ~d["fragile"]
+    # tolerance: IMG_ATOL on the per-sample composites; the gamma chain (x^2.2 -> mean -> ^(1/2.2)) with the
+    # fast pow amplifies it near the floor, hence 5e-4 on the combined image
+    assert np.abs(samples.detach().cpu().numpy() - d["samples"])[:, good].max() < IMG_ATOL
+    assert np.abs(out.detach().cpu().numpy() - d["out"])[good].max() < 5e-4
+    assert np.abs(alpha.detach().cpu().numpy() - d["alpha"])[good].max() < IMG_ATOL
+    if S * R == 1:      # t = 0: the sub-pose viewmat is the input viewmat exactly, so integers must match exactly
+        assert np.array_equal(radii[0].cpu().numpy(), d["p0_radii"])
+    else:               # HIP float32 closed-form SE(3) vs the fixture's float64 matrix_exp: a ceil() may move
+        assert (radii[0].cpu().numpy() != d["p0_radii"]).mean() < 2e-3
+    for k in ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel"]:
+        assert rel_max(p[k].grad.cpu(), d["g_" + k]) < GRAD_RTOL, k
+    assert rel_max(p["viewmat"].grad.cpu()[:3], d["g_viewmat"][:3]) < GRAD_RTOL
+
+
+@pytest.mark.parametrize("S,R,W,H,n", [(1, 1, 160, 96, 3000), (5, 1, 128, 128, 2000), (1, 6, 96, 200, 2000),
+                                       (2, 3, 112, 80, 1500)])
+def test_fused_path_vs_oracle_integers_and_image(gs, oracle, dev, S, R, W, H, n):
+    """Per sub-pose: radii / tile counts / sorted order bit-exact vs the float32 oracle fed the SAME
+    viewmats; image vs the float64 oracle."""
+    O = oracle
+    sc = O.synthetic_scene(n, W, H, seed=100 + S * 10 + R, scale_mult=6.0)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10     # visible motion at this size
+    et, rt, gamma, mlevel = 1 / 60, 1 / 30, 2.2, 10.0
+    bg = torch.tensor([0.05, 0.1, 0.15])
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5))
+    out, alpha, samples, vms, p, radii = _run_full(gs, O, dev, sc, H, W, S, R, et, rt, gamma, mlevel, 3, bg, wt)
+    vms_cpu = vms.detach().cpu()
+    from gsdeblur_amd import ops
+    # integer parity per sub-pose with identical viewmats
+    P = S * R
+    for pidx in range(P):
+        pr = O.project_gaussians(sc["means"], sc["log_scales"].exp(), 1.0, sc["quats"], vms_cpu[pidx], sc["fx"],
+                                 sc["fy"], sc["cx"], sc["cy"], H, W)
+        assert np.array_equal(radii[pidx].cpu().numpy(), pr.radii.numpy())
+    # full image vs float64 oracle driven by the same float32 viewmats (skip its own SE(3) exp)
+    cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], blur_samples=S, rs_bands=R, exposure_time=et,
+                         rolling_shutter_time=rt, gamma=gamma, min_rgb_level=mlevel)
+    ref, ref_alpha, ref_samples, frag, parts, _ = O.render(
+        cfg, sc["means"].double(), sc["log_scales"].double().exp(), sc["quats"].double(),
+        torch.sigmoid(sc["opacity_logits"].double()), sc["sh"].double(), sc["viewmat"].double(),
+        sc["lin_vel"].double(), sc["ang_vel"].double(), background=bg.double(), return_parts=True)
+    good = ~frag
+    assert good.float().mean() > 0.9
+    assert (samples.detach().cpu().double() - ref_samples)[:, good].abs().max().item() < IMG_ATOL
+    assert (out.detach().cpu().double() - ref)[good].abs().max().item() < 5e-4
+
+
+# --------------------------------------------------------------------------- #
+# size-independent properties at larger sizes (no oracle run needed)
+# --------------------------------------------------------------------------- #
+def test_properties_at_scale(gs, oracle, dev):
+    """300k Gaussians, 1080p (BASELINE.json config 2 shape): sortedness of the tile keys, bin edges
+    partition the list, depth order inside tiles, zero-velocity S-sample average == static render,
+    gradient linearity."""
+    O = oracle
+    n, W, H = 300_000, 1920, 1080
+    sc = to_dev(O.synthetic_scene(n, W, H, seed=1234), dev)
+    from gsdeblur_amd import ops
+    L = gs._lib.load()
+    S, R = 2, 1
+    sh = sc["sh"]
+    vm1 = sc["viewmat"][None].contiguous()
+    scales, opac = sc["log_scales"].exp(), torch.sigmoid(sc["opacity_logits"])
+    s1, a1, rad1 = gs.render_subposes(sc["means"], scales, sc["quats"], opac, sh, vm1, None, 1, 1, sc["fx"],
+                                      sc["fy"], sc["cx"], sc["cy"], H, W)
+    vm2 = sc["viewmat"][None].repeat(2, 1, 1).contiguous()
+    s2, a2, _ = gs.render_subposes(sc["means"], scales, sc["quats"], opac, sh, vm2, None, 2, 1, sc["fx"], sc["fy"],
+                                   sc["cx"], sc["cy"], H, W)
+    assert torch.equal(s2[0], s1[0]) and torch.equal(s2[1], s1[0])           # identical poses -> identical samples
+    assert torch.allclose(gs.combine_samples(s2, 2.2, 10.0), gs.combine_samples(s1, 2.2, 10.0), atol=2e-6)
+    assert torch.isfinite(s1).all() and s1.min() >= 0
+    # binning invariants
+    N = n
+    rec = torch.empty(N, 12, device=dev)
+    dk = torch.empty(N, dtype=torch.int32, device=dev)
+    nt = torch.empty(N, dtype=torch.int32, device=dev)
+    gs._lib.check(L.gs_project_fused_fwd(N, 1, ops._ptr(sc["means"]), ops._ptr(scales.contiguous()), 1.0,
+                                         ops._ptr(sc["quats"]), ops._ptr(opac.contiguous()), ops._ptr(sh), 16, 3,
+                                         ops._ptr(vm1), sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, 0.01, 1,
+                                         ops._ptr(rec), ops._ptr(dk), ops._ptr(nt), None, ops._stream()), "fused")
+    svals, bins, I, skeys = gs.bin_and_sort_records(rec, dk, nt, 1, N, H, W)
+    assert I == int(nt.long().sum().item())
+    sk = skeys.long()
+    assert bool((sk[1:] >= sk[:-1]).all())                                   # sortedness
+    T = 120 * 68
+    b = bins.long()
+    assert int((b[:, 1] - b[:, 0]).sum().item()) == I                       # bins partition the list
+    nonempty = b[:, 1] > b[:, 0]
+    assert bool((sk[b[nonempty, 0]] == torch.arange(T, device=dev)[nonempty]).all())
+    depth_sorted = rec[svals.long(), 9]
+    same_tile = sk[1:] == sk[:-1]
+    assert bool((depth_sorted[1:][same_tile] >= depth_sorted[:-1][same_tile]).all())   # front-to-back inside tiles
+    # gradient linearity: d(2*loss) == 2*d(loss)
+    m = sc["means"].clone().requires_grad_(True)
+    w = torch.rand(1, H, W, 3, device=dev)
+    g = []
+    for scale in (1.0, 2.0):
+        if m.grad is not None:
+            m.grad = None
+        s, _, _ = gs.render_subposes(m, scales, sc["quats"], opac, sh, vm1, None, 1, 1, sc["fx"], sc["fy"],
+                                     sc["cx"], sc["cy"], H, W)
+        (scale * (s * w).sum()).backward()
+        g.append(m.grad.clone())
+    assert torch.isfinite(g[0]).all()
+    assert rel_max(g[1].cpu(), (2 * g[0]).cpu()) < 2e-3      # atomics reorder fp32 sums run to run
+
+
+def test_model_get_outputs(gs, oracle, dev):
+    """Model surface: dict keys / shapes / ranges that render_model.py:217-219 relies on, and backward."""
+    O = oracle
+    W, H, n = 160, 120, 4000
+    sc = O.synthetic_scene(n, W, H, seed=31, scale_mult=6.0)
+    cfg = gs.SplatfactoDeblurConfig(blur_samples=3, rs_bands=4, gamma=2.2, min_rgb_level=10.0,
+                                    background_color="auto")
+    cfg.camera_optimizer.mode = "SO3xR3"
+    cfg.camera_velocity_optimizer.enabled = True
+    model = gs.SplatfactoDeblurModel.from_scene(cfg, sc, dev, num_cameras=3)
+    c2w = torch.eye(4)[:3].clone()
+    c2w[:, 1] *= -1
+    c2w[:, 2] *= -1                        # OpenGL camera looking down the oracle scene's +z
+    cam = gs.Camera(c2w, sc["fx"], sc["fy"], sc["cx"], sc["cy"], W, H,
+                    metadata=dict(cam_idx=1, camera_linear_velocity=[0.5, 0.1, 0.0],
+                                  camera_angular_velocity=[0.0, 0.3, 0.1], exposure_time=1 / 60,
+                                  rolling_shutter_time=1 / 30))
+    model.train()
+    out = model.get_outputs(cam)
+    assert out["rgb"].shape == (H, W, 3) and out["accumulation"].shape == (H, W, 1)
+    assert model.radii.shape == (12, n)
+    out["rgb"].mean().backward()
+    for name, prm in model.gauss_params().items():
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+    assert model.pose_adjustment.grad[1].abs().sum() > 0 and model.pose_adjustment.grad[0].abs().sum() == 0
+    assert model.velocity_adjustment.grad[1].abs().sum() > 0
+    assert model.background_param.grad is not None
+    ev = model.get_outputs_for_camera(cam)
+    assert ev["depth"].shape == (H, W, 1) and torch.isfinite(ev["depth"]).all()
+    assert 0.0 <= ev["rgb"].min().item() and ev["rgb"].max().item() <= 1.0
+    assert (ev["depth"][ev["accumulation"] > 0.5] > 0.9).all()
