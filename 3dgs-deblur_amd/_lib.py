@@ -34,7 +34,7 @@ _SIGS = {
     "gs_tile_bin_edges_u32": [_L, _P, _I, _P, _P],
     "gs_tile_bin_edges_u64": [_L, _P, _I, _P, _P],
     "gs_map_gaussian_to_intersects": [_I, _P, _P, _P, _P, _I, _I, _P, _P, _P],
-    "gs_rasterize_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "gs_rasterize_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
     "gs_rasterize_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "gs_combine_fwd": [_I, _L, _P, _F, _F, _P, _P],
     "gs_combine_bwd": [_I, _L, _P, _F, _F, _P, _P, _P, _P],

@@ -120,21 +120,31 @@ static int run_scan(size_t n, const unsigned* in, unsigned* out, unsigned* total
 
 // ---------------------------------------------------------------------------
 // radix sort (LSD, stable), KeyT in {u32,u64}, 32-bit payload
+//
+// One pass = histogram kernel (keys only) + scan + scatter kernel.  The scatter ranks keys
+// with wave64 match-any (one ballot per digit bit), each wave owning a contiguous key run so
+// stability needs no exchange, then REORDERS keys and payloads through LDS so that every
+// digit's keys leave the block as one contiguous, coalesced run (a direct per-lane scatter
+// wrote 64 different cache lines per instruction and ran at ~0.5 TB/s).
 // ---------------------------------------------------------------------------
-constexpr int kSortRounds = 16;                   // keys per thread
-constexpr int kSortBlock = 256 * kSortRounds;     // keys per block (4 waves x 16 x 64)
+template <typename KeyT> struct SortCfg;
+template <> struct SortCfg<unsigned> { static constexpr int kRounds = 32; };            // 8192 keys / block
+template <> struct SortCfg<unsigned long long> { static constexpr int kRounds = 16; };  // 4096 keys / block
+
+template <typename KeyT> constexpr int sort_block_keys() { return 256 * SortCfg<KeyT>::kRounds; }
 
 template <typename KeyT, int BITS>
 __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* __restrict__ keys, int shift,
                                                          unsigned mask, unsigned nblk,
                                                          unsigned* __restrict__ ghist) {
   constexpr int NB = 1 << BITS;
+  constexpr int R = SortCfg<KeyT>::kRounds;
   __shared__ unsigned hist[NB];
   for (int d = threadIdx.x; d < NB; d += 256) hist[d] = 0;
   __syncthreads();
-  size_t base = (size_t)blockIdx.x * kSortBlock;
-#pragma unroll 4
-  for (int r = 0; r < kSortRounds; ++r) {
+  size_t base = (size_t)blockIdx.x * (256 * R);
+#pragma unroll 8
+  for (int r = 0; r < R; ++r) {
     size_t i = base + (size_t)r * 256 + threadIdx.x;
     if (i < n) atomicAdd(&hist[(unsigned)(keys[i] >> shift) & mask], 1u);
   }
@@ -150,16 +160,25 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
                                                             unsigned nblk,
                                                             const unsigned* __restrict__ ghist_scanned) {
   constexpr int NB = 1 << BITS;
-  __shared__ unsigned cnt[4][NB];
+  constexpr int R = SortCfg<KeyT>::kRounds;
+  constexpr int BK = 256 * R;
+  constexpr int DPT = NB / 256;                 // digits per thread in the offset phase
+  __shared__ KeyT s_keys[BK];
+  __shared__ unsigned s_vals[BK];
+  __shared__ unsigned cnt[4][NB];               // per-wave digit counts -> per-wave LDS offsets
+  __shared__ unsigned s_dbase[NB];              // first LDS slot of each digit
+  __shared__ unsigned s_gbase[NB];              // first global slot of each digit for this block
+  __shared__ unsigned s_scan[8];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   for (int d = threadIdx.x; d < 4 * NB; d += 256) (&cnt[0][0])[d] = 0;
   __syncthreads();
-  const size_t wbase = (size_t)blockIdx.x * kSortBlock + (size_t)wave * (kSortRounds * 64);
+  const size_t bbase = (size_t)blockIdx.x * BK;
+  const size_t wbase = bbase + (size_t)wave * (R * 64);
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  KeyT key[kSortRounds];
-  unsigned pos[kSortRounds];
+  KeyT key[R];
+  unsigned short pos[R];
 #pragma unroll
-  for (int r = 0; r < kSortRounds; ++r) {
+  for (int r = 0; r < R; ++r) {
     size_t i = wbase + (size_t)r * 64 + lane;
     bool valid = i < n;
     key[r] = valid ? keys_in[i] : (KeyT)0;
@@ -178,33 +197,66 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
     __builtin_amdgcn_wave_barrier();
     if (valid && prefix == 0) cnt[wave][digit] = base + total;
     __builtin_amdgcn_wave_barrier();
-    pos[r] = base + prefix;
+    pos[r] = (unsigned short)(base + prefix);
   }
   __syncthreads();
-  // per digit: exclusive prefix over the 4 waves + this block's global base
-  for (int d = threadIdx.x; d < NB; d += 256) {
-    unsigned run = ghist_scanned[(size_t)d * nblk + blockIdx.x];
+  // per digit: block count -> LDS base (exclusive scan over digits), per-wave offsets, global base
+  {
+    unsigned c[DPT], sum = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      unsigned c = cnt[w][d];
-      cnt[w][d] = run;
-      run += c;
+    for (int j = 0; j < DPT; ++j) {
+      int d = threadIdx.x * DPT + j;
+      c[j] = cnt[0][d] + cnt[1][d] + cnt[2][d] + cnt[3][d];
+      sum += c[j];
+    }
+    unsigned tot;
+    unsigned ex = block_excl_scan(sum, tot, s_scan);
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+      int d = threadIdx.x * DPT + j;
+      s_dbase[d] = ex;
+      s_gbase[d] = ghist_scanned[(size_t)d * nblk + blockIdx.x];
+      unsigned run = ex;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        unsigned cw = cnt[w][d];
+        cnt[w][d] = run;
+        run += cw;
+      }
+      ex += c[j];
     }
   }
   __syncthreads();
+  // stage keys + payloads in LDS in sorted-by-digit order
 #pragma unroll
-  for (int r = 0; r < kSortRounds; ++r) {
+  for (int r = 0; r < R; ++r) {
     size_t i = wbase + (size_t)r * 64 + lane;
     if (i < n) {
       unsigned digit = (unsigned)(key[r] >> shift) & mask;
-      size_t dst = (size_t)cnt[wave][digit] + pos[r];
-      keys_out[dst] = key[r];
-      vals_out[dst] = vals_in ? vals_in[i] : (unsigned)i;
+      unsigned slot = cnt[wave][digit] + pos[r];
+      s_keys[slot] = key[r];
+      s_vals[slot] = vals_in ? vals_in[i] : (unsigned)i;
+    }
+  }
+  __syncthreads();
+  const unsigned nvalid = (unsigned)min((size_t)BK, n - bbase);
+#pragma unroll 4
+  for (int r = 0; r < R; ++r) {
+    unsigned slot = (unsigned)r * 256 + threadIdx.x;
+    if (slot < nvalid) {
+      KeyT k = s_keys[slot];
+      unsigned digit = (unsigned)(k >> shift) & mask;
+      size_t dst = (size_t)s_gbase[digit] + (slot - s_dbase[digit]);
+      keys_out[dst] = k;
+      vals_out[dst] = s_vals[slot];
     }
   }
 }
 
-static inline unsigned sort_nblk(size_t n) { return (unsigned)((n + kSortBlock - 1) / kSortBlock); }
+template <typename KeyT>
+static inline unsigned sort_nblk(size_t n) {
+  return (unsigned)((n + sort_block_keys<KeyT>() - 1) / sort_block_keys<KeyT>());
+}
 
 // digit plan for sorting `bits` key bits: fewest passes with digits <= 11 bits, equal widths
 static inline void radix_plan(int bits, int* passes, int* per, int* tmpl_bits) {
@@ -214,23 +266,25 @@ static inline void radix_plan(int bits, int* passes, int* per, int* tmpl_bits) {
   *passes = ps; *per = w; *tmpl_bits = w < 8 ? 8 : w;
 }
 
+template <typename KeyT>
 static inline size_t radix_hist_bytes(size_t n, int bits) {
   int ps, per, tb;
   radix_plan(bits, &ps, &per, &tb);
-  size_t b = ((size_t)1 << tb) * sort_nblk(n) * sizeof(unsigned);
+  size_t b = ((size_t)1 << tb) * sort_nblk<KeyT>(n) * sizeof(unsigned);
   return (b + 255) & ~(size_t)255;
 }
 
+template <typename KeyT>
 static inline size_t radix_ws_bytes(size_t n, int bits) {
   int ps, per, tb;
   radix_plan(bits, &ps, &per, &tb);
-  return radix_hist_bytes(n, bits) + scan_ws_bytes(((size_t)1 << tb) * sort_nblk(n)) + 256;
+  return radix_hist_bytes<KeyT>(n, bits) + scan_ws_bytes(((size_t)1 << tb) * sort_nblk<KeyT>(n)) + 256;
 }
 
 template <typename KeyT, int BITS>
 static void radix_pass(size_t n, const KeyT* kin, const unsigned* vin, KeyT* kout, unsigned* vout, int shift,
                        unsigned mask, void* ws, size_t hist_bytes, hipStream_t st) {
-  unsigned nblk = sort_nblk(n);
+  unsigned nblk = sort_nblk<KeyT>(n);
   unsigned* ghist = reinterpret_cast<unsigned*>(ws);
   size_t hn = ((size_t)1 << BITS) * nblk;
   void* scan_ws = reinterpret_cast<char*>(ws) + hist_bytes;
@@ -247,10 +301,10 @@ static int radix_sort(size_t n, KeyT* k0, unsigned* v0, KeyT* k1, unsigned* v1, 
                       int end_bit, void* ws, size_t ws_bytes, int* result_buf, hipStream_t st) {
   int bits = end_bit - begin_bit;
   if (bits <= 0) return GS_ERR_INVALID;
-  if (ws_bytes < radix_ws_bytes(n, bits)) return GS_ERR_WORKSPACE;
+  if (ws_bytes < radix_ws_bytes<KeyT>(n, bits)) return GS_ERR_WORKSPACE;
   int passes, per, tb;
   radix_plan(bits, &passes, &per, &tb);
-  const size_t hist_bytes = radix_hist_bytes(n, bits);
+  const size_t hist_bytes = radix_hist_bytes<KeyT>(n, bits);
   KeyT* kk[2] = {k0, k1};
   unsigned* vv[2] = {v0, v1};
   int cur = 0, shift = begin_bit;
@@ -282,9 +336,10 @@ __global__ __launch_bounds__(256) void gather_counts_kernel(size_t n, const unsi
   if (i < n) out[i] = (unsigned)ntiles[sorted_gi[i]];
 }
 
-// One block expands 256 consecutive depth-ranked Gaussians; output range of the block is
-// contiguous, every thread writes consecutive entries (coalesced), source Gaussian found
-// by binary search in the block's LDS scan.
+// One block expands 256 consecutive depth-ranked Gaussians; the block's output range is
+// contiguous and every thread writes consecutive entries (coalesced).  The source Gaussian of an
+// entry is found by a branch-free 8-step binary search in the block's LDS scan; tile coordinates
+// come from a float reciprocal (exact for rem < 2^16, w <= tiles_x) instead of integer division.
 __global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T, int tiles_x,
                                                    const unsigned* __restrict__ sorted_gi,
                                                    const unsigned* __restrict__ cum,   // exclusive, in rank order
@@ -292,51 +347,61 @@ __global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T
                                                    unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
   __shared__ unsigned s_cum[257];
   __shared__ unsigned s_gi[256];
-  __shared__ unsigned s_lo[256], s_hi[256];
+  __shared__ unsigned s_kbase[256];   // p*T + y0*tiles_x + x0
+  __shared__ unsigned s_w[256];
+  __shared__ float s_rw[256];
   size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-  unsigned gi = 0, lo = 0, hi = 0, c = 0;
+  unsigned gi = 0, c = 0, kbase = 0, w = 1;
   if (r < n_ranked) {
     gi = sorted_gi[r];
     c = cum[r];
     const float* rec = records + (size_t)gi * kRecFloats;
-    lo = (unsigned)__float_as_int(rec[10]);
-    hi = (unsigned)__float_as_int(rec[11]);
+    unsigned lo = (unsigned)__float_as_int(rec[10]);
+    unsigned hi = (unsigned)__float_as_int(rec[11]);
+    unsigned x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu;
+    w = x1 > x0 ? x1 - x0 : 1u;
+    kbase = (gi / (unsigned)N) * (unsigned)T + y0 * (unsigned)tiles_x + x0;
   }
-  s_gi[threadIdx.x] = gi; s_lo[threadIdx.x] = lo; s_hi[threadIdx.x] = hi; s_cum[threadIdx.x] = c;
+  s_gi[threadIdx.x] = gi; s_kbase[threadIdx.x] = kbase; s_w[threadIdx.x] = w; s_rw[threadIdx.x] = 1.0f / (float)w;
+  s_cum[threadIdx.x] = c;
   size_t r_last = (size_t)blockIdx.x * 256 + 256;
   if (threadIdx.x == 0) s_cum[256] = r_last < n_ranked ? cum[r_last] : (unsigned)n_isect;
   __syncthreads();
   const unsigned first = s_cum[0];
-  // ranks past n_ranked hold cum = 0: make their slots empty by pointing them at the block end
   const unsigned last = s_cum[256];
   const int n_live = (int)min((size_t)256, n_ranked - (size_t)blockIdx.x * 256);
   for (unsigned e = first + threadIdx.x; e < last; e += 256) {
-    // largest li in [0,n_live) with s_cum[li] <= e
-    int a = 0, b = n_live - 1;
-    while (a < b) {
-      int mid = (a + b + 1) >> 1;
-      if (s_cum[mid] <= e) a = mid; else b = mid - 1;
+    // largest a in [0,n_live) with s_cum[a] <= e  (zero-count Gaussians share a cum and are skipped)
+    int a = 0;
+#pragma unroll
+    for (int step = 128; step > 0; step >>= 1) {
+      int m = a + step;
+      if (m < n_live && s_cum[m] <= e) a = m;
     }
     unsigned rem = e - s_cum[a];
-    unsigned l = s_lo[a], h = s_hi[a];
-    int x0 = l & 0xFFFF, y0 = l >> 16, x1 = h & 0xFFFF;
-    int w = x1 - x0;
-    int ty = y0 + (int)(rem / (unsigned)w), tx = x0 + (int)(rem % (unsigned)w);
-    unsigned g = s_gi[a];
-    unsigned p = g / (unsigned)N;
-    keys[e] = p * (unsigned)T + (unsigned)(ty * tiles_x + tx);
-    vals[e] = g;
+    unsigned wa = s_w[a];
+    unsigned q = (unsigned)(((float)rem + 0.5f) * s_rw[a]);
+    unsigned x = rem - q * wa;
+    keys[e] = s_kbase[a] + q * (unsigned)tiles_x + x;
+    vals[e] = s_gi[a];
   }
 }
 
+// bins[t] = [start,end) of tile t in the sorted keys; one boundary test per element:
+// a key change between i-1 and i closes tile key[i-1] and opens tile key[i].
 template <typename KeyT, int SHIFT>
 __global__ __launch_bounds__(256) void bin_edges_kernel(size_t n, const KeyT* __restrict__ keys,
                                                         int2* __restrict__ bins) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   unsigned t = (unsigned)(keys[i] >> SHIFT);
-  if (i == 0 || (unsigned)(keys[i - 1] >> SHIFT) != t) bins[t].x = (int)i;
-  if (i == n - 1 || (unsigned)(keys[i + 1] >> SHIFT) != t) bins[t].y = (int)(i + 1);
+  if (i == 0) {
+    bins[t].x = 0;
+  } else {
+    unsigned tp = (unsigned)(keys[i - 1] >> SHIFT);
+    if (tp != t) { bins[t].x = (int)i; bins[tp].y = (int)i; }
+  }
+  if (i == n - 1) bins[t].y = (int)n;
 }
 
 // upstream-compatible 64-bit intersection ids (one thread per Gaussian; API-parity path)
@@ -384,7 +449,10 @@ using namespace gs;
 GS_EXPORT long long gs_scan_workspace_bytes(long long n) { return (long long)scan_ws_bytes((size_t)n) + 256; }
 GS_EXPORT long long gs_radix_sort_workspace_bytes(long long n, int begin_bit, int end_bit) {
   if (n <= 0 || end_bit <= begin_bit) return 0;
-  return (long long)radix_ws_bytes((size_t)n, end_bit - begin_bit);
+  // sized for the larger (u64) layout so one query serves both key widths
+  size_t a = radix_ws_bytes<unsigned>((size_t)n, end_bit - begin_bit);
+  size_t b = radix_ws_bytes<unsigned long long>((size_t)n, end_bit - begin_bit);
+  return (long long)(a > b ? a : b);
 }
 
 // out[i] = sum_{j<i} in[j]; *total_out (device u32, nullable) = sum of all.  in == out allowed.

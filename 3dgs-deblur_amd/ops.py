@@ -21,8 +21,12 @@ from torch.autograd import Function
 
 from . import _lib
 
+import os
+
 TILE = 16
 REC = 12  # floats per rasterizer record
+# kernel variant selector for A/B measurements (0 = default)
+RASTER_FWD_VARIANT = int(os.environ.get("GSD_RASTER_FWD_VARIANT", "0"))
 
 
 class StageProfiler:
@@ -341,7 +345,8 @@ class _RasterizeGaussians(Function):
         out_T = torch.empty(1, H, W, device=dev)
         fidx = torch.empty(1, H, W, dtype=torch.int32, device=dev)
         _check(L.gs_rasterize_fwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), 1, 1, H, W,
-                                  _ptr(out_img), _ptr(out_T), _ptr(fidx), _stream()), "rasterize_fwd")
+                                  _ptr(out_img), _ptr(out_T), _ptr(fidx), RASTER_FWD_VARIANT, _stream()),
+               "rasterize_fwd")
         ctx.save_for_backward(records, svals, bins, edges, bg, out_T, fidx)
         ctx.dims = (N, H, W)
         ctx.bg_grad = background is not None and ctx.needs_input_grad[10]
@@ -515,7 +520,8 @@ class _RenderSubposes(Function):
         fidx = torch.empty(S, H, W, dtype=torch.int32, device=dev)
         with _stage("raster_fwd"):
             _check(L.gs_rasterize_fwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
-                                      _ptr(out_img), _ptr(out_T), _ptr(fidx), _stream()), "rasterize_fwd")
+                                      _ptr(out_img), _ptr(out_T), _ptr(fidx), RASTER_FWD_VARIANT, _stream()),
+                   "rasterize_fwd")
         ctx.save_for_backward(means3d, scales, quats, opacities, sh, V, records, svals, bins, edges, bg, out_T, fidx)
         ctx.args = args
         ctx.SR = (S, R)

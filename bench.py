@@ -44,7 +44,13 @@ def cpu_baseline():
     n = 5000
     sc = O.synthetic_scene(n, W, H, seed=1234, scale_mult=4.0)
     cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], blur_samples=1, rs_bands=1)
-    cores = os.cpu_count() or 1
+    # threads: torch's default, capped by the CPU affinity mask and 16 (os.cpu_count() ignores cgroup
+    # limits; oversubscribing tiny per-tile tensor ops makes the baseline pathologically slow)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(torch.get_num_threads(), avail, 16))
     torch.set_num_threads(cores)
     names = ["means", "log_scales", "quats", "opacity_logits", "sh"]
 
@@ -66,6 +72,28 @@ def cpu_baseline():
     return {"value": round(W * H / 1e6 / dt, 5), "unit": "MPix/s", "cores": cores, "kind": "port",
             "sample": f"own CPU oracle (torch fp32, vectorised per tile), 5k Gaussians 256x256 1 sub-pose, "
                       f"fwd+bwd, mean of {reps} runs = {dt * 1e3:.0f} ms"}
+
+
+def guarded_cpu_baseline(limit_s: int = 150):
+    """Never let the (reported-only) CPU leg cost the GPU line: hard time limit via SIGALRM."""
+    import signal
+
+    class _Timeout(Exception):
+        pass
+
+    def _raise(*_):
+        raise _Timeout()
+
+    old = signal.signal(signal.SIGALRM, _raise)
+    signal.alarm(limit_s)
+    try:
+        return cpu_baseline()
+    except _Timeout:
+        return {"value": None, "unit": "MPix/s", "cores": None, "kind": "port",
+                "sample": f"own CPU oracle did not finish 5k Gaussians 256x256 fwd+bwd within {limit_s} s"}
+    finally:
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, old)
 
 
 def main():
@@ -194,7 +222,7 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = guarded_cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -135,7 +135,8 @@ int gs_map_gaussian_to_intersects(int N, const float* xys, const float* depths, 
 int gs_rasterize_fwd(const float* records, const int* sorted_vals, const int* tile_bins,
                      const int* band_edges /*R+1*/, const float* background /*3*/, int S, int R,
                      int img_height, int img_width, float* out_img /*S*H*W*3*/, float* out_T /*S*H*W*/,
-                     int* final_idx /*S*H*W*/, void* stream);
+                     int* final_idx /*S*H*W*/, int variant /*0 = default kernel; 1 = branchy reference kernel*/,
+                     void* stream);
 /* v_records [P*N*12] is accumulated into with fp32 atomics (caller zeroes); v_alpha may be NULL. */
 int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* tile_bins,
                      const int* band_edges, const float* background, int S, int R, int img_height,

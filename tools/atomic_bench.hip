@@ -15,6 +15,20 @@ __global__ void k_atomic(float* buf, const unsigned* idx, size_t n) {
 #pragma unroll
   for (int c = 0; c < 9; ++c) __hip_atomic_fetch_add(p + c, 1.0f + c, __ATOMIC_RELAXED, SCOPE);
 }
+// SoA: component c of record r lives at buf[c*nrec + r]
+__global__ void k_atomic_soa(float* buf, const unsigned* idx, size_t n, size_t nrec) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float* p = buf + idx[i];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) __hip_atomic_fetch_add(p + (size_t)c * nrec, 1.0f + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one atomic per lane
+__global__ void k_atomic_one(float* buf, const unsigned* idx, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  __hip_atomic_fetch_add(buf + (size_t)idx[i] * 12, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __global__ void k_store(float* buf, const unsigned* idx, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -39,7 +53,7 @@ int main() {
     }
     hipMemcpy(idx, h.data(), n * sizeof(unsigned), hipMemcpyHostToDevice);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int v = 0; v < 3; ++v) {
+    for (int v = 0; v < 5; ++v) {
       hipMemset(buf, 0, nrec * 12 * sizeof(float));
       float best = 1e30f;
       for (int rep = 0; rep < 3; ++rep) {
@@ -47,14 +61,16 @@ int main() {
         dim3 g((unsigned)((n + 255) / 256)), blk(256);
         if (v == 0) hipLaunchKernelGGL(k_atomic<__HIP_MEMORY_SCOPE_AGENT>, g, blk, 0, 0, buf, idx, n);
         else if (v == 1) hipLaunchKernelGGL(k_atomic<__HIP_MEMORY_SCOPE_WORKGROUP>, g, blk, 0, 0, buf, idx, n);
-        else hipLaunchKernelGGL(k_store, g, blk, 0, 0, buf, idx, n);
+        else if (v == 2) hipLaunchKernelGGL(k_store, g, blk, 0, 0, buf, idx, n);
+        else if (v == 3) hipLaunchKernelGGL(k_atomic_soa, g, blk, 0, 0, buf, idx, n, nrec);
+        else hipLaunchKernelGGL(k_atomic_one, g, blk, 0, 0, buf, idx, n);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         if (ms < best) best = ms;
       }
-      const char* nm[3] = {"atomic agent", "atomic workgroup", "plain store"};
+      const char* nm[5] = {"atomic agent", "atomic workgroup", "plain store", "atomic SoA", "atomic 1/lane"};
       printf("%s %-17s: %8.3f ms  %7.2f G ops/s\n", mode == 0 ? "random   " : "clustered", nm[v], best,
-             (double)n * 9 / best / 1e6);
+             (double)n * (v == 4 ? 1 : 9) / best / 1e6);
     }
   }
   return 0;
