@@ -1,32 +1,48 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, smoke, micro-benchmarks, bench, rocprof kernel trace.
-# Usage (from the repo root on the GPU box): bash tools/gpu_round.sh [quick|full]
+# One GPU-box visit: parity tests, smoke, micro-benchmarks, bench, rocprof kernel trace + PMC passes.
+# Usage (from the repo root on the GPU box): bash tools/gpu_round.sh [quick|full|pmc]
 set -u
 MODE=${1:-full}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
 echo "== build ==" | tee $OUT/summary.log
 timeout 300 python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -2 | tee -a $OUT/summary.log
+if [ "$MODE" != "pmc" ]; then
 echo "== pytest -m gpu ==" | tee -a $OUT/summary.log
-timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
-tail -40 $OUT/pytest_gpu.log | tee -a $OUT/summary.log
+timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s > $OUT/pytest_gpu.log 2>&1
+grep -E "ulp diffs|^FAILED|^ERROR|passed|failed" $OUT/pytest_gpu.log | tail -30 | tee -a $OUT/summary.log
 echo "== smoke ==" | tee -a $OUT/summary.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee -a $OUT/summary.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee -a $OUT/summary.log
+fi
 if [ "$MODE" = "full" ]; then
   echo "== atomic microbench ==" | tee -a $OUT/summary.log
-  (hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -Wno-unused-value tools/atomic_bench.hip -o /tmp/atomic_bench && timeout 120 /tmp/atomic_bench) 2>&1 | tail -8 | tee -a $OUT/summary.log
+  (hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -Wno-unused-value tools/atomic_bench.hip -o /tmp/atomic_bench && timeout 120 /tmp/atomic_bench) 2>&1 | tail -12 | tee -a $OUT/summary.log
 fi
-echo "== bench small (100k, 1 step) ==" | tee -a $OUT/summary.log
-timeout 300 python bench.py --gaussians 100000 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -3 | tee -a $OUT/summary.log
+echo "== bench A/B raster fwd variant 1 (branchy) vs 0 (default) ==" | tee -a $OUT/summary.log
+for v in 1 0 1 0; do
+  GSD_RASTER_FWD_VARIANT=$v timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('variant $v', d['value'], d['ms_per_step'], d['stage_ms'])" | tee -a $OUT/summary.log
+done
 echo "== bench default ==" | tee -a $OUT/summary.log
-timeout 900 python bench.py --steps 5 --warmup 2 > $OUT/bench.log 2>&1
-tail -3 $OUT/bench.log | tee -a $OUT/summary.log
-if [ "$MODE" = "full" ]; then
+timeout 600 python bench.py > $OUT/bench.log 2>&1
+tail -2 $OUT/bench.log | cut -c1-2500 | tee -a $OUT/summary.log
+if [ "$MODE" != "quick" ]; then
   echo "== rocprofv3 kernel trace ==" | tee -a $OUT/summary.log
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline) > $OUT/rocprof.log 2>&1
-  tail -3 $OUT/rocprof.log | tee -a $OUT/summary.log
-  find $OUT/prof -name "*stats*" | head | tee -a $OUT/summary.log
-  for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -25 $f | cut -c1-200 | tee -a $OUT/summary.log; done
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline) > $OUT/rocprof.log 2>&1
+  grep -o '{"metric.*' $OUT/rocprof.log | cut -c1-400 | tee -a $OUT/summary.log
+  for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -22 $f | cut -c1-220 | tee -a $OUT/summary.log; done
+  for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR"; do
+    tag=$(echo $pmc | cut -d' ' -f1)
+    echo "== rocprofv3 pmc $tag ==" | tee -a $OUT/summary.log
+    (cd /tmp && timeout 600 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $R/$OUT/pmc_$tag -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $OUT/pmc_$tag.log 2>&1
+    tail -2 $OUT/pmc_$tag.log | cut -c1-300 | tee -a $OUT/summary.log
+    find $OUT/pmc_$tag -name "*.csv" | head -5 | tee -a $OUT/summary.log
+  done
+  python tools/pmc_summary.py $OUT 2>&1 | tail -40 | tee -a $OUT/summary.log
 fi
 echo "== done ==" | tee -a $OUT/summary.log
