@@ -127,8 +127,11 @@ static int run_scan(size_t n, const unsigned* in, unsigned* out, unsigned* total
 // digit's keys leave the block as one contiguous, coalesced run (a direct per-lane scatter
 // wrote 64 different cache lines per instruction and ran at ~0.5 TB/s).
 // ---------------------------------------------------------------------------
+#ifndef GS_SORT_ROUNDS_U32
+#define GS_SORT_ROUNDS_U32 16   // 4096 keys per block: 36 KB LDS -> 4 blocks / CU
+#endif
 template <typename KeyT> struct SortCfg;
-template <> struct SortCfg<unsigned> { static constexpr int kRounds = 32; };            // 8192 keys / block
+template <> struct SortCfg<unsigned> { static constexpr int kRounds = GS_SORT_ROUNDS_U32; };  // keys / thread
 template <> struct SortCfg<unsigned long long> { static constexpr int kRounds = 16; };  // 4096 keys / block
 
 template <typename KeyT> constexpr int sort_block_keys() { return 256 * SortCfg<KeyT>::kRounds; }

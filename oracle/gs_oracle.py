@@ -48,10 +48,20 @@ TILE = 16
 # --------------------------------------------------------------------------- #
 # projection  (App. A "Projection", "Tile bbox")
 # --------------------------------------------------------------------------- #
+def _sqrt(x: torch.Tensor) -> torch.Tensor:
+    """Correctly rounded sqrt.  torch's vectorised float32 CPU sqrt (Sleef) is NOT correctly rounded
+    (~0.6 % of inputs are off by one ulp, machine dependent), whereas the HIP kernels' sqrtf is
+    (v_sqrt_f32 + fma residual fix-up) — so float32 goes through float64, whose rounding back to
+    float32 is exact for sqrt (53 >= 2*24+2)."""
+    if x.dtype == torch.float32:
+        return torch.sqrt(x.double()).float()
+    return torch.sqrt(x)
+
+
 def quat_to_rotmat(q: torch.Tensor) -> torch.Tensor:
     """(w,x,y,z) -> R[...,3,3]; normalises like gs::quat_to_rotmat."""
     n2 = ((q[..., 0] * q[..., 0] + q[..., 1] * q[..., 1]) + q[..., 2] * q[..., 2]) + q[..., 3] * q[..., 3]
-    inv = 1.0 / torch.sqrt(n2)
+    inv = 1.0 / _sqrt(n2)
     w, x, y, z = q[..., 0] * inv, q[..., 1] * inv, q[..., 2] * inv, q[..., 3] * inv
     R = torch.stack(
         [
@@ -134,12 +144,12 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
     det = a * c - b * b
     valid = valid & (det != 0)
     det_safe = torch.where(valid, det, torch.ones_like(det))
-    comp = torch.sqrt(torch.clamp(det0 / det_safe, min=0.0))
+    comp = _sqrt(torch.clamp(det0 / det_safe, min=0.0))
     inv_det = 1.0 / det_safe
     conics = torch.stack([c * inv_det, -b * inv_det, a * inv_det], dim=-1)
     mid = 0.5 * (a + c)
-    lam = mid + torch.sqrt(torch.clamp(mid * mid - det, min=MIN_EIG_DISC))
-    radf = torch.ceil(RADIUS_SIGMA * torch.sqrt(lam.detach()))
+    lam = mid + _sqrt(torch.clamp(mid * mid - det, min=MIN_EIG_DISC))
+    radf = torch.ceil(RADIUS_SIGMA * _sqrt(lam.detach()))
     x = (fx_t * px) * rz + cx_t
     y = (fy_t * py) * rz + cy_t
     tiles_x = (img_width + TILE - 1) // TILE
