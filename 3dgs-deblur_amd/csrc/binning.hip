@@ -407,6 +407,98 @@ __global__ __launch_bounds__(256) void bin_edges_kernel(size_t n, const KeyT* __
   if (i == n - 1) bins[t].y = (int)n;
 }
 
+// ---------------------------------------------------------------------------
+// depth-sliced binning (front-to-back slices; tiles whose pixels have all stopped are "done" and
+// receive no further intersections).  With early termination only a few percent of the
+// (Gaussian, tile) intersections are ever composited; slicing keeps the emit/sort/bin work
+// proportional to what the compositor can still use.  Results are identical to the unsliced path:
+// every pixel sees the same Gaussians in the same order.
+// ---------------------------------------------------------------------------
+struct SliceDesc {
+  const int* begin;    // [P]   first depth rank (absolute index into sorted_gi) of the slice in sub-pose p
+  const int* prefix;   // [P+1] prefix sums of the per-sub-pose slice lengths
+  int P;
+};
+
+__device__ __forceinline__ int slice_rank(const SliceDesc& sd, int j) {
+  int p = 0;
+  while (p + 1 < sd.P && j >= sd.prefix[p + 1]) ++p;
+  return sd.begin[p] + (j - sd.prefix[p]);
+}
+
+// summed-area table of NOT-done tiles per sub-pose: sat[p][(y)*(tx+1)+x] = #open tiles in [0,y)x[0,x)
+__global__ __launch_bounds__(256) void tile_sat_kernel(int tiles_x, int tiles_y, const unsigned char* __restrict__ done,
+                                                       int* __restrict__ sat) {
+  const int p = blockIdx.x;
+  const int T = tiles_x * tiles_y, SW = tiles_x + 1;
+  const unsigned char* d = done + (size_t)p * T;
+  int* s = sat + (size_t)p * SW * (tiles_y + 1);
+  // row prefix sums (one thread per row), then column sums (one thread per column)
+  for (int y = threadIdx.x; y <= tiles_y; y += 256) {
+    int run = 0;
+    s[y * SW] = 0;
+    for (int x = 0; x < tiles_x; ++x) {
+      if (y > 0) run += d[(y - 1) * tiles_x + x] ? 0 : 1;
+      s[y * SW + x + 1] = run;
+    }
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x <= tiles_x; x += 256) {
+    int run = 0;
+    for (int y = 0; y <= tiles_y; ++y) {
+      run += s[y * SW + x];
+      s[y * SW + x] = run;
+    }
+  }
+}
+
+// per slice Gaussian: gather its global index and count its still-open tiles (SAT query)
+__global__ __launch_bounds__(256) void slice_counts_kernel(int n_slice, SliceDesc sd, int N, int tiles_x, int tiles_y,
+                                                           const unsigned* __restrict__ sorted_gi,
+                                                           const float* __restrict__ records,
+                                                           const int* __restrict__ sat,   // null: nothing done yet
+                                                           unsigned* __restrict__ slice_gi,
+                                                           unsigned* __restrict__ counts) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_slice) return;
+  unsigned gi = sorted_gi[slice_rank(sd, j)];
+  const float* rec = records + (size_t)gi * kRecFloats;
+  unsigned lo = (unsigned)__float_as_int(rec[10]), hi = (unsigned)__float_as_int(rec[11]);
+  int x0 = lo & 0xFFFF, y0 = lo >> 16, x1 = hi & 0xFFFF, y1 = hi >> 16;
+  unsigned c = (unsigned)((x1 - x0) * (y1 - y0));
+  if (sat && c) {
+    const int SW = tiles_x + 1;
+    const int* s = sat + (size_t)(gi / (unsigned)N) * SW * (tiles_y + 1);
+    c = (unsigned)(s[y1 * SW + x1] - s[y0 * SW + x1] - s[y1 * SW + x0] + s[y0 * SW + x0]);
+  }
+  slice_gi[j] = gi;
+  counts[j] = c;
+}
+
+// emission with holes: one thread per slice Gaussian walks its tile box and writes the open tiles
+__global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int T, int tiles_x,
+                                                        const unsigned* __restrict__ slice_gi,
+                                                        const unsigned* __restrict__ counts,
+                                                        const unsigned* __restrict__ cum,
+                                                        const float* __restrict__ records,
+                                                        const unsigned char* __restrict__ done,
+                                                        unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+  int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_slice) return;
+  if (counts[j] == 0) return;
+  unsigned gi = slice_gi[j];
+  const float* rec = records + (size_t)gi * kRecFloats;
+  unsigned lo = (unsigned)__float_as_int(rec[10]), hi = (unsigned)__float_as_int(rec[11]);
+  int x0 = lo & 0xFFFF, y0 = lo >> 16, x1 = hi & 0xFFFF, y1 = hi >> 16;
+  unsigned pbase = (gi / (unsigned)N) * (unsigned)T;
+  unsigned e = cum[j];
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      unsigned k = pbase + (unsigned)(y * tiles_x + x);
+      if (!done[k]) { keys[e] = k; vals[e] = gi; ++e; }
+    }
+}
+
 // upstream-compatible 64-bit intersection ids (one thread per Gaussian; API-parity path)
 __global__ __launch_bounds__(256) void map_isect_kernel(int N, const float* __restrict__ xys,
                                                         const float* __restrict__ depths,
@@ -547,6 +639,40 @@ GS_EXPORT int gs_map_gaussian_to_intersects(int N, const float* xys, const float
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
   hipLaunchKernelGGL(map_isect_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, xys, depths,
                      radii, cum_tiles_hit, tiles_x, tiles_y, isect_ids, gaussian_ids);
+  return gs_launch_status();
+}
+
+// ---- depth-sliced binning -------------------------------------------------------------------
+// sat [P*(tiles_y+1)*(tiles_x+1)]: summed-area table of tiles that are NOT done.
+GS_EXPORT int gs_tile_open_sat(int P, int H, int W, const unsigned char* tile_done, int* sat, void* stream) {
+  if (P <= 0) return GS_ERR_INVALID;
+  int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
+  hipLaunchKernelGGL(tile_sat_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, tiles_x, tiles_y, tile_done, sat);
+  return gs_launch_status();
+}
+
+// For the n_slice = slice_prefix[P] Gaussians of a depth slice (sub-pose p contributes the depth ranks
+// slice_begin[p] .. of sorted_gi): slice_gi[j] = their global index, counts[j] = tiles still open
+// (sat == NULL: all tiles open).
+GS_EXPORT int gs_slice_counts(int n_slice, int P, int N, const int* slice_begin, const int* slice_prefix,
+                              const unsigned* sorted_gi, const float* records, const int* sat, int H, int W,
+                              unsigned* slice_gi, unsigned* counts, void* stream) {
+  if (n_slice <= 0 || P <= 0) return GS_ERR_INVALID;
+  int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
+  SliceDesc sd; sd.begin = slice_begin; sd.prefix = slice_prefix; sd.P = P;
+  hipLaunchKernelGGL(slice_counts_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice, sd,
+                     N, tiles_x, tiles_y, sorted_gi, records, sat, slice_gi, counts);
+  return gs_launch_status();
+}
+
+// Emit the intersections of a slice with the tiles that are still open (depth order preserved).
+GS_EXPORT int gs_emit_open_intersects(int n_slice, int N, int H, int W, const unsigned* slice_gi,
+                                      const unsigned* counts, const unsigned* cum_excl, const float* records,
+                                      const unsigned char* tile_done, unsigned* keys, unsigned* vals, void* stream) {
+  if (n_slice <= 0) return GS_ERR_INVALID;
+  int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
+  hipLaunchKernelGGL(emit_open_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice, N,
+                     tiles_x * tiles_y, tiles_x, slice_gi, counts, cum_excl, records, tile_done, keys, vals);
   return gs_launch_status();
 }
 

@@ -234,13 +234,121 @@ __global__ __launch_bounds__(256) void raster_fwd_kernel_v2(RasterParams prm, fl
 }
 
 // ---------------------------------------------------------------------------
+// forward, depth-sliced: same inner loop as variant 2, but the per-pixel state (colour without
+// background, final T, live T) persists in HBM between slices and a tile whose pixels have all
+// stopped is flagged `done` (it gets its background term then, is skipped by later slices and
+// receives no further intersections from the binning).  first && last reproduces the unsliced pass.
+// ---------------------------------------------------------------------------
+struct SliceState {
+  unsigned char* tile_done;   // [P*T]
+  float* live_T;              // [S,H,W]  0 once a pixel has stopped
+  int first, last;
+};
+
+__global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm, SliceState st,
+                                                               float* __restrict__ out_img,
+                                                               float* __restrict__ out_T,
+                                                               int* __restrict__ final_idx, unsigned n_blocks) {
+  const int lane = lane_id();
+  const int T = prm.tiles_x * prm.tiles_y;
+  const unsigned work = xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6);
+  if (work >= (unsigned)(prm.S * T)) return;
+  const int s = work / T, t = work % T;
+  const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
+  const int p = s * prm.R + find_band(prm.band_edges, prm.R, ty);
+  const size_t tkey = (size_t)p * T + t;
+  if (!st.first && st.tile_done[tkey]) return;
+  const int2 range = prm.tile_bins[tkey];
+  if (!st.first && !st.last && range.y <= range.x) return;   // nothing for this tile in this slice
+
+  const int px = tx * K::kTile + (lane & 15);
+  const int py0 = ty * K::kTile + (lane >> 4) * 4;
+  const float pxf = (float)px + 0.5f;
+  float Tk[4], Tf[4], Cr[4], Cg[4], Cb[4], pyf[4];
+  int last[4];
+  bool inside[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    inside[k] = px < prm.W && (py0 + k) < prm.H;
+    Tk[k] = inside[k] ? 1.f : 0.f; Tf[k] = 1.f; Cr[k] = Cg[k] = Cb[k] = 0.f; last[k] = range.x;
+    pyf[k] = (float)(py0 + k) + 0.5f;
+    if (!st.first && inside[k]) {
+      size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
+      Cr[k] = out_img[pix * 3 + 0]; Cg[k] = out_img[pix * 3 + 1]; Cb[k] = out_img[pix * 3 + 2];
+      Tf[k] = out_T[pix];
+      Tk[k] = st.live_T[pix];
+    }
+  }
+  const int* __restrict__ vals = prm.sorted_vals;
+  int id_next = (range.x + lane) < range.y ? vals[range.x + lane] : 0;
+  Rec9 rec_next = load_rec(prm.records, id_next, (range.x + lane) < range.y);
+  id_next = (range.x + 64 + lane) < range.y ? vals[range.x + 64 + lane] : 0;
+  const float kL2E = -1.4426950408889634f;
+
+  for (int batch = range.x; batch < range.y; batch += 64) {
+    if (__ballot(fmaxf(fmaxf(Tk[0], Tk[1]), fmaxf(Tk[2], Tk[3])) > 0.f) == 0ull) break;
+    Rec9 rec = rec_next;
+    rec_next = load_rec(prm.records, id_next, (batch + 64 + lane) < range.y);
+    id_next = (batch + 128 + lane) < range.y ? vals[batch + 128 + lane] : 0;
+    rec.cx *= 0.5f * kL2E; rec.cy *= kL2E; rec.cz *= 0.5f * kL2E;
+    const int n = min(64, range.y - batch);
+    for (int j = 0; j < n; ++j) {
+      if ((j & 15) == 15 && __ballot(fmaxf(fmaxf(Tk[0], Tk[1]), fmaxf(Tk[2], Tk[3])) > 0.f) == 0ull) break;
+      const float gx = readlane_f(rec.x, j), gy = readlane_f(rec.y, j);
+      const float cx = readlane_f(rec.cx, j), cy = readlane_f(rec.cy, j), cz = readlane_f(rec.cz, j);
+      const float op = readlane_f(rec.op, j);
+      const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
+      const float dx = gx - pxf;
+      const float hx = cx * dx * dx;
+      const float bx = cy * dx;
+      const int idx1 = batch + j + 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dy = gy - pyf[k];
+        const float s2 = hx + dy * (bx + cz * dy);
+        const float alpha = fminf(K::kAlphaMax, op * __builtin_amdgcn_exp2f(s2));
+        const bool valid = (s2 <= 0.f) && (alpha >= K::kAlphaMin);
+        const float nT = Tk[k] - Tk[k] * alpha;
+        const bool upd = valid && (nT > K::kTMin);
+        const float w = upd ? alpha * Tk[k] : 0.f;
+        Cr[k] += w * cr; Cg[k] += w * cg; Cb[k] += w * cb;
+        Tf[k] = upd ? nT : Tf[k];
+        Tk[k] = upd ? nT : (valid ? 0.f : Tk[k]);
+        last[k] = upd ? idx1 : last[k];
+      }
+    }
+  }
+  const bool all_stopped = __ballot(fmaxf(fmaxf(Tk[0], Tk[1]), fmaxf(Tk[2], Tk[3])) > 0.f) == 0ull;
+  const bool finalize = all_stopped || st.last;
+  const float bgr = finalize ? prm.background[0] : 0.f, bgg = finalize ? prm.background[1] : 0.f,
+              bgb = finalize ? prm.background[2] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (inside[k]) {
+      size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
+      out_img[pix * 3 + 0] = Cr[k] + Tf[k] * bgr;
+      out_img[pix * 3 + 1] = Cg[k] + Tf[k] * bgg;
+      out_img[pix * 3 + 2] = Cb[k] + Tf[k] * bgb;
+      out_T[pix] = Tf[k];
+      final_idx[pix] = last[k];
+      if (!st.last) st.live_T[pix] = Tk[k];
+    }
+  }
+  if (all_stopped && !st.last && lane == 0) st.tile_done[tkey] = 1;
+}
+
+// ---------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------
+// STATE = true: depth-sliced backward — the running transmittance and the colour accumulated from
+// behind persist in bwd_T / bwd_B between slice launches (slices are visited back to front).
+template <bool STATE>
 __global__ __launch_bounds__(256) void raster_bwd_kernel(RasterParams prm, const float* __restrict__ out_T,
                                                          const int* __restrict__ final_idx,
                                                          const float* __restrict__ v_img,
                                                          const float* __restrict__ v_alpha,  // may be null
-                                                         float* __restrict__ v_records, unsigned n_blocks) {
+                                                         float* __restrict__ v_records, unsigned n_blocks,
+                                                         float* __restrict__ bwd_T, float* __restrict__ bwd_B) {
   const int lane = lane_id();
   const int T = prm.tiles_x * prm.tiles_y;
   const unsigned work = xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6);
@@ -275,6 +383,11 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(RasterParams prm, const
       Tfin[k] = 1.f; fin[k] = range.x; vr[k] = vg[k] = vb[k] = 0.f; va[k] = 0.f;
     }
     Tk[k] = Tfin[k];
+    if (STATE && px < prm.W && y < prm.H) {
+      size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
+      Tk[k] = bwd_T[pix];
+      Br[k] = bwd_B[pix * 3 + 0]; Bg[k] = bwd_B[pix * 3 + 1]; Bb[k] = bwd_B[pix * 3 + 2];
+    }
     my_end = max(my_end, fin[k]);
   }
   const int wave_end = wave_max_i(my_end);
@@ -350,6 +463,17 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(RasterParams prm, const
       if (a_r != 0.f) atomic_add_f32(dst + 6, a_r);
       if (a_g != 0.f) atomic_add_f32(dst + 7, a_g);
       if (a_b != 0.f) atomic_add_f32(dst + 8, a_b);
+    }
+  }
+  if (STATE) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = py0 + k;
+      if (px < prm.W && y < prm.H) {
+        size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
+        bwd_T[pix] = Tk[k];
+        bwd_B[pix * 3 + 0] = Br[k]; bwd_B[pix * 3 + 1] = Bg[k]; bwd_B[pix * 3 + 2] = Bb[k];
+      }
     }
   }
 }
@@ -437,8 +561,51 @@ GS_EXPORT int gs_rasterize_bwd(const float* records, const int* sorted_vals, con
   prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
-  hipLaunchKernelGGL(raster_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T, final_idx,
-                     v_img, v_alpha, v_records, blocks);
+  hipLaunchKernelGGL(raster_bwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T, final_idx,
+                     v_img, v_alpha, v_records, blocks, (float*)nullptr, (float*)nullptr);
+  return gs_launch_status();
+}
+
+// ---- depth-sliced variants (see binning.hip "depth-sliced binning") ---------------------------------
+// One forward launch per slice, slices front to back.  out_img / out_T / live_T carry the per-pixel
+// state between launches; tile_done [S*R*T] (zeroed by the caller before the first slice) flags tiles
+// whose pixels have all stopped.  first/last mark the first and the final slice (first && last ==
+// the unsliced pass).  final_idx is per slice (the backward needs one per slice).
+GS_EXPORT int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
+                                     const int* band_edges, const float* background, int S, int R, int H, int W,
+                                     float* out_img, float* out_T, float* live_T, int* final_idx,
+                                     unsigned char* tile_done, int first, int last, void* stream) {
+  if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
+  RasterParams prm;
+  prm.records = records; prm.sorted_vals = sorted_vals; prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
+  prm.band_edges = band_edges; prm.background = background;
+  prm.S = S; prm.R = R; prm.H = H; prm.W = W;
+  prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
+  SliceState st; st.tile_done = tile_done; st.live_T = live_T; st.first = first; st.last = last;
+  unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
+  unsigned blocks = (work + 3) / 4;
+  hipLaunchKernelGGL(raster_fwd_slice_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, st, out_img,
+                     out_T, final_idx, blocks);
+  return gs_launch_status();
+}
+
+// One backward launch per slice, slices back to front.  bwd_T (initialised by the caller to out_T) and
+// bwd_B [S,H,W,3] (initialised to 0) carry the reverse-traversal state between launches.
+GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
+                                     const int* band_edges, const float* background, int S, int R, int H, int W,
+                                     const float* out_T, const int* final_idx, const float* v_img,
+                                     const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records,
+                                     void* stream) {
+  if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
+  RasterParams prm;
+  prm.records = records; prm.sorted_vals = sorted_vals; prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
+  prm.band_edges = band_edges; prm.background = background;
+  prm.S = S; prm.R = R; prm.H = H; prm.W = W;
+  prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
+  unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
+  unsigned blocks = (work + 3) / 4;
+  hipLaunchKernelGGL(raster_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T, final_idx,
+                     v_img, v_alpha, v_records, blocks, bwd_T, bwd_B);
   return gs_launch_status();
 }
 

@@ -27,6 +27,10 @@ TILE = 16
 REC = 12  # floats per rasterizer record
 # kernel variant selector for A/B measurements (0 = default)
 RASTER_FWD_VARIANT = int(os.environ.get("GSD_RASTER_FWD_VARIANT", "0"))
+# depth slicing of the fused path: average tile-list length budget of the first slice (doubling per
+# slice); 0 disables slicing (single pass over all intersections)
+SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "128"))
+last_slice_intersects = []
 
 
 class StageProfiler:
@@ -223,6 +227,133 @@ def _background(background: Optional[Tensor], device) -> Tensor:
     if bg.numel() != 3:
         raise ValueError("background must have 3 channels")
     return bg
+
+
+def _depth_rank(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int):
+    """(sub-pose, depth) pre-sort -> (sorted_gi [P*N], exclusive scan of tile counts in rank order, total)"""
+    L = _L()
+    n = P * N
+    dev = records.device
+    with _stage("depth_sort"):
+        keys64 = torch.empty(n, dtype=torch.int64, device=dev)
+        _check(L.gs_make_depth_keys64(n, N, _ptr(depth_keys), _ptr(keys64), _stream()), "depth keys")
+        end_bit = 32 + (_bits(P) if P > 1 else 0)
+        _, sorted_gi = radix_sort_pairs(keys64, None, 0, end_bit)
+    with _stage("count_scan"):
+        counts = torch.empty(n, dtype=torch.int32, device=dev)
+        _check(L.gs_gather_counts(n, _ptr(sorted_gi), _ptr(num_tiles_hit), _ptr(counts), _stream()), "gather counts")
+        cum, total = exclusive_scan_u32(counts)
+    return sorted_gi, cum, total
+
+
+def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
+                   img_height: int, img_width: int, bg: Tensor, edges: Tensor, slice_base: int):
+    """Front-to-back depth-sliced bin + sort + composite.
+    -> (out_img [S,H,W,3], out_T [S,H,W], slices) ; slices = list of (sorted_vals, tile_bins, final_idx, I_k)
+    that the backward walks in reverse."""
+    global last_num_intersects, last_slice_intersects
+    L = _L()
+    dev = records.device
+    H, W = img_height, img_width
+    tx, ty = _tiles(H, W)
+    T = tx * ty
+    sorted_gi, cum, total = _depth_rank(records, depth_keys, num_tiles_hit, P, N)
+    # slice boundaries in depth-rank space: cumulative intersections per sub-pose reach T*slice_base*2^k
+    KMAX = 16
+    with _stage("slice_plan"):
+        rel = cum.view(P, N).long()
+        rel = rel - rel[:, :1]
+        tgt = (T * slice_base) * (2 ** torch.arange(KMAX, device=dev, dtype=torch.int64))
+        bounds = torch.searchsorted(rel, tgt[None, :].expand(P, KMAX).contiguous())      # [P,KMAX] first rank >= tgt
+        plan = torch.cat([bounds.reshape(-1), total.long()]).cpu()                       # one host sync
+    n_total = int(plan[-1])
+    last_num_intersects = n_total
+    b = plan[:-1].view(P, KMAX).tolist()
+    # number of slices: up to the first k whose boundary reaches N in every sub-pose
+    K = KMAX
+    for k in range(KMAX):
+        if all(b[p][k] >= N for p in range(P)):
+            K = k + 1
+            break
+    begins, prefixes, n_slices = [], [], []
+    for k in range(K):
+        lo = [0 if k == 0 else min(b[p][k - 1], N) for p in range(P)]
+        hi = [N if k == K - 1 else min(b[p][k], N) for p in range(P)]
+        begins.append([p * N + lo[p] for p in range(P)])
+        pre = [0]
+        for p in range(P):
+            pre.append(pre[-1] + max(0, hi[p] - lo[p]))
+        prefixes.append(pre)
+        n_slices.append(pre[-1])
+    desc = torch.tensor([bb + pp for bb, pp in zip(begins, prefixes)], dtype=torch.int32).to(dev)   # [K, 2P+1]
+    out_img = torch.empty(S, H, W, 3, device=dev)
+    out_T = torch.empty(S, H, W, device=dev)
+    live_T = torch.empty(S, H, W, device=dev)
+    tile_done = torch.zeros(P * T, dtype=torch.uint8, device=dev)
+    sat = torch.empty(P * (ty + 1) * (tx + 1), dtype=torch.int32, device=dev)
+    slices = []
+    last_slice_intersects = []
+    for k in range(K):
+        first, last = k == 0, k == K - 1
+        n_k = n_slices[k]
+        I_k = 0
+        svals = bins = None
+        if n_k > 0:
+            with _stage("slice_count"):
+                slice_gi = torch.empty(n_k, dtype=torch.int32, device=dev)
+                counts = torch.empty(n_k, dtype=torch.int32, device=dev)
+                d = desc[k]
+                _check(L.gs_slice_counts(n_k, P, N, _ptr(d), ctypes.c_void_p(d.data_ptr() + 4 * P), _ptr(sorted_gi),
+                                         _ptr(records), None if first else _ptr(sat), H, W, _ptr(slice_gi),
+                                         _ptr(counts), _stream()), "slice_counts")
+                cum_k, total_k = exclusive_scan_u32(counts)
+            I_k = int(total_k.item())          # host sync (one per slice)
+        if I_k > 0:
+            with _stage("emit"):
+                keys = torch.empty(I_k, dtype=torch.int32, device=dev)
+                vals = torch.empty(I_k, dtype=torch.int32, device=dev)
+                if first:
+                    _check(L.gs_emit_intersects(n_k, N, H, W, _ptr(slice_gi), _ptr(cum_k), _ptr(records), I_k,
+                                                _ptr(keys), _ptr(vals), _stream()), "emit intersects")
+                else:
+                    _check(L.gs_emit_open_intersects(n_k, N, H, W, _ptr(slice_gi), _ptr(counts), _ptr(cum_k),
+                                                     _ptr(records), _ptr(tile_done), _ptr(keys), _ptr(vals),
+                                                     _stream()), "emit open intersects")
+            with _stage("tile_sort"):
+                skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T))
+            with _stage("bin_edges"):
+                bins = torch.empty(P * T, 2, dtype=torch.int32, device=dev)
+                _check(L.gs_tile_bin_edges_u32(I_k, _ptr(skeys), P * T, _ptr(bins), _stream()), "bin edges")
+        last_slice_intersects.append(I_k)
+        if I_k == 0 and not (first or last):
+            continue
+        if I_k == 0:
+            svals = torch.zeros(1, dtype=torch.int32, device=dev)
+            bins = torch.zeros(P * T, 2, dtype=torch.int32, device=dev)
+        fidx = torch.empty(S, H, W, dtype=torch.int32, device=dev)
+        with _stage("raster_fwd"):
+            _check(L.gs_rasterize_fwd_slice(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
+                                            _ptr(out_img), _ptr(out_T), _ptr(live_T), _ptr(fidx), _ptr(tile_done),
+                                            int(first), int(last), _stream()), "rasterize_fwd_slice")
+        if I_k > 0:
+            slices.append((svals, bins, fidx, I_k))
+        if not last:
+            with _stage("slice_sat"):
+                _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _stream()), "tile_open_sat")
+    return out_img, out_T, slices
+
+
+def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, img_width: int, bg: Tensor,
+                    edges: Tensor, out_T: Tensor, v_img: Tensor, v_alpha: Optional[Tensor], v_records: Tensor):
+    L = _L()
+    H, W = img_height, img_width
+    bwd_T = out_T.clone()
+    bwd_B = torch.zeros(S, H, W, 3, device=records.device)
+    with _stage("raster_bwd"):
+        for svals, bins, fidx, _ in reversed(slices):
+            _check(L.gs_rasterize_bwd_slice(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
+                                            _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_alpha), _ptr(bwd_T),
+                                            _ptr(bwd_B), _ptr(v_records), _stream()), "rasterize_bwd_slice")
 
 
 # --------------------------------------------------------------------------- #
@@ -512,16 +643,23 @@ class _RenderSubposes(Function):
                                           _ptr(sh), K, args[4], _ptr(V), args[5], args[6], args[7], args[8], H, W,
                                           args[11], args[12], _ptr(records), _ptr(dkeys), _ptr(ntiles), _ptr(radii),
                                           _stream()), "project_fused_fwd")
-        svals, bins, n_isect, _ = bin_and_sort_records(records, dkeys, ntiles, P, N, H, W)
         bg = _background(background, dev)
         edges = _band_edges(H, R, dev)
-        out_img = torch.empty(S, H, W, 3, device=dev)
-        out_T = torch.empty(S, H, W, device=dev)
-        fidx = torch.empty(S, H, W, dtype=torch.int32, device=dev)
-        with _stage("raster_fwd"):
-            _check(L.gs_rasterize_fwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
-                                      _ptr(out_img), _ptr(out_T), _ptr(fidx), RASTER_FWD_VARIANT, _stream()),
-                   "rasterize_fwd")
+        ctx.sliced = SLICE_BASE > 0
+        if ctx.sliced:
+            out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE)
+            ctx.slices = slices
+            svals = bins = fidx = torch.zeros(1, dtype=torch.int32, device=dev)
+            n_isect = last_num_intersects
+        else:
+            svals, bins, n_isect, _ = bin_and_sort_records(records, dkeys, ntiles, P, N, H, W)
+            out_img = torch.empty(S, H, W, 3, device=dev)
+            out_T = torch.empty(S, H, W, device=dev)
+            fidx = torch.empty(S, H, W, dtype=torch.int32, device=dev)
+            with _stage("raster_fwd"):
+                _check(L.gs_rasterize_fwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
+                                          _ptr(out_img), _ptr(out_T), _ptr(fidx), RASTER_FWD_VARIANT, _stream()),
+                       "rasterize_fwd")
         ctx.save_for_backward(means3d, scales, quats, opacities, sh, V, records, svals, bins, edges, bg, out_T, fidx)
         ctx.args = args
         ctx.SR = (S, R)
@@ -540,10 +678,13 @@ class _RenderSubposes(Function):
         v_img = v_img.contiguous().float()
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
         v_records = torch.zeros(P * N, REC, device=dev)
-        with _stage("raster_bwd"):
-            _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
-                                      _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records), _stream()),
-                   "rasterize_bwd")
+        if ctx.sliced:
+            sliced_backward(records, ctx.slices, S, R, H, W, bg, edges, out_T, v_img, v_al, v_records)
+        else:
+            with _stage("raster_bwd"):
+                _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
+                                          _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records),
+                                          _stream()), "rasterize_bwd")
         v_means = torch.empty(N, 3, device=dev)
         v_scales = torch.empty(N, 3, device=dev)
         v_quats = torch.empty(N, 4, device=dev)

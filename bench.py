@@ -182,7 +182,7 @@ def main():
     if rank == 0:
         npix = H * W
         value = world * npix / 1e6 / (ms_per_step / 1e3)
-        stage_ms = {k: round(sum(v) / len(v), 4) for k, v in stages.items()}
+        stage_ms = {k: round(sum(v) / args.steps, 4) for k, v in stages.items()}   # per step (sum over slices)
         # dominant single kernel = the stage with the largest mean time among the single-launch stages
         single = {k: stage_ms[k] for k in ("raster_bwd", "raster_fwd", "project_fwd", "project_bwd") if k in stage_ms}
         dom = max(single, key=single.get)
@@ -215,7 +215,10 @@ def main():
                                    f"S={S} motion-blur sub-poses x R={R} row bands, SH degree 3, gamma 2.2, "
                                    f"fwd+bwd to all Gaussian params + viewmat + velocities",
                        "gaussians": N, "width": W, "height": H, "subposes": S, "rs_bands": R,
-                       "tile_intersections_per_step": n_isect, "views_per_step": world,
+                       "tile_intersections_per_step": n_isect,
+                       "tile_intersections_emitted": int(sum(ops.last_slice_intersects)) if ops.SLICE_BASE > 0 else n_isect,
+                       "depth_slices": list(ops.last_slice_intersects) if ops.SLICE_BASE > 0 else None,
+                       "views_per_step": world,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "subpose_MPix_per_s": round(value * S, 3)},
             "stage_ms": stage_ms,

@@ -143,6 +143,34 @@ int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* ti
                      int img_width, const float* out_T, const int* final_idx, const float* v_img,
                      const float* v_alpha, float* v_records, void* stream);
 
+/* ---- depth-sliced variant of the same path (MI355X design, no upstream counterpart) ----------
+ * With early termination only a few percent of the (Gaussian, tile) intersections are ever
+ * composited.  The depth-ranked Gaussians are processed in front-to-back slices; a tile whose
+ * pixels have all stopped is flagged done and later slices emit no intersections for it.  Every
+ * pixel still sees the same Gaussians in the same order, so results equal the unsliced pass. */
+/* sat [P*(tiles_y+1)*(tiles_x+1)] = summed-area table of tiles NOT done (tile_done u8 [P*T]) */
+int gs_tile_open_sat(int P, int img_height, int img_width, const unsigned char* tile_done, int* sat,
+                     void* stream);
+/* slice = for each sub-pose p the depth ranks sorted_gi[slice_begin[p] + i], i < prefix[p+1]-prefix[p];
+ * writes slice_gi[j] (global index) and counts[j] (open tiles; sat == NULL: all tiles open) */
+int gs_slice_counts(int n_slice, int P, int N, const int* slice_begin /*P*/, const int* slice_prefix /*P+1*/,
+                    const unsigned* sorted_gi, const float* records, const int* sat, int img_height,
+                    int img_width, unsigned* slice_gi, unsigned* counts, void* stream);
+int gs_emit_open_intersects(int n_slice, int N, int img_height, int img_width, const unsigned* slice_gi,
+                            const unsigned* counts, const unsigned* cum_excl, const float* records,
+                            const unsigned char* tile_done, unsigned* keys, unsigned* vals, void* stream);
+/* one launch per slice, front to back; out_img/out_T/live_T carry per-pixel state, tile_done is zeroed
+ * by the caller before the first slice; first && last == the unsliced pass; final_idx is per slice */
+int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
+                           const int* band_edges, const float* background, int S, int R, int img_height,
+                           int img_width, float* out_img, float* out_T, float* live_T, int* final_idx,
+                           unsigned char* tile_done, int first, int last, void* stream);
+/* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B [S,H,W,3] (init = 0) carry state */
+int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
+                           const int* band_edges, const float* background, int S, int R, int img_height,
+                           int img_width, const float* out_T, const int* final_idx, const float* v_img,
+                           const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records, void* stream);
+
 /* ---- sub-frame averaging in linearised colour (flags train.py:60,62) ---------
  * out = ( mean_k max(C_k, min_level)^gamma )^(1/gamma); n = H*W*3 values per sample. */
 int gs_combine_fwd(int S, long long n, const float* samples /*S*n*/, float gamma, float min_level,
