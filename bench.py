@@ -183,7 +183,9 @@ def main():
         npix = H * W
         value = world * npix / 1e6 / (ms_per_step / 1e3)
         stage_ms = {k: round(sum(v) / args.steps, 4) for k, v in stages.items()}   # per step (sum over slices)
-        # dominant single kernel = the stage with the largest mean time among the single-launch stages
+        # dominant kernel = the single-kernel stage with the largest time per step (a depth-sliced step
+        # launches it once per slice: bytes and time are both summed over the step's launches)
+        launches = {k: len(v) / args.steps for k, v in stages.items()}
         single = {k: stage_ms[k] for k in ("raster_bwd", "raster_fwd", "project_fwd", "project_bwd") if k in stage_ms}
         dom = max(single, key=single.get)
         P = S * R
@@ -203,7 +205,9 @@ def main():
                                                "project_bwd": "project_fused_bwd_kernel"}[dom],
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": single[dom],
+                    "algorithmic_bytes_per_step": alg[dom], "kernel_ms_per_step": single[dom],
+                    "launches_per_step": launches.get(dom, 1.0),
+                    "avg_launch_ms": round(single[dom] / max(1.0, launches.get(dom, 1.0)), 4),
                     "pipeline_frac": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "pipeline_algorithmic_bytes": pipeline_bytes}
         line = {
