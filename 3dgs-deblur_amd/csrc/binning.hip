@@ -426,30 +426,31 @@ __device__ __forceinline__ int slice_rank(const SliceDesc& sd, int j) {
   return sd.begin[p] + (j - sd.prefix[p]);
 }
 
-// summed-area table of NOT-done tiles per sub-pose: sat[p][(y)*(tx+1)+x] = #open tiles in [0,y)x[0,x)
+// summed-area table of NOT-done tiles per sub-pose: sat[p][(y)*(tx+1)+x] = #open tiles in [0,y)x[0,x).
+// One block per sub-pose, table built in LDS (dynamic, (tx+1)*(ty+1) ints), written out coalesced.
 __global__ __launch_bounds__(256) void tile_sat_kernel(int tiles_x, int tiles_y, const unsigned char* __restrict__ done,
                                                        int* __restrict__ sat) {
+  extern __shared__ int s[];
   const int p = blockIdx.x;
-  const int T = tiles_x * tiles_y, SW = tiles_x + 1;
+  const int T = tiles_x * tiles_y, SW = tiles_x + 1, SH = tiles_y + 1;
   const unsigned char* d = done + (size_t)p * T;
-  int* s = sat + (size_t)p * SW * (tiles_y + 1);
-  // row prefix sums (one thread per row), then column sums (one thread per column)
-  for (int y = threadIdx.x; y <= tiles_y; y += 256) {
-    int run = 0;
-    s[y * SW] = 0;
-    for (int x = 0; x < tiles_x; ++x) {
-      if (y > 0) run += d[(y - 1) * tiles_x + x] ? 0 : 1;
-      s[y * SW + x + 1] = run;
-    }
+  for (int i = threadIdx.x; i < SW * SH; i += 256) {
+    int y = i / SW, x = i % SW;
+    s[i] = (y > 0 && x > 0) ? (d[(y - 1) * tiles_x + (x - 1)] ? 0 : 1) : 0;
   }
   __syncthreads();
-  for (int x = threadIdx.x; x <= tiles_x; x += 256) {
+  for (int y = threadIdx.x; y < SH; y += 256) {        // row prefix sums
     int run = 0;
-    for (int y = 0; y <= tiles_y; ++y) {
-      run += s[y * SW + x];
-      s[y * SW + x] = run;
-    }
+    for (int x = 0; x < SW; ++x) { run += s[y * SW + x]; s[y * SW + x] = run; }
   }
+  __syncthreads();
+  for (int x = threadIdx.x; x < SW; x += 256) {        // column prefix sums
+    int run = 0;
+    for (int y = 0; y < SH; ++y) { run += s[y * SW + x]; s[y * SW + x] = run; }
+  }
+  __syncthreads();
+  int* o = sat + (size_t)p * SW * SH;
+  for (int i = threadIdx.x; i < SW * SH; i += 256) o[i] = s[i];
 }
 
 // per slice Gaussian: gather its global index and count its still-open tiles (SAT query)
@@ -475,7 +476,9 @@ __global__ __launch_bounds__(256) void slice_counts_kernel(int n_slice, SliceDes
   counts[j] = c;
 }
 
-// emission with holes: one thread per slice Gaussian walks its tile box and writes the open tiles
+// emission with holes, wave-cooperative: a wave owns 64 slice Gaussians; every Gaussian that still has
+// open tiles is expanded by the whole wave (64 tiles of its box per step, ballot-compacted), so one
+// huge box does not serialise a lane while the other 63 idle.  Order inside a Gaussian = (y, x).
 __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int T, int tiles_x,
                                                         const unsigned* __restrict__ slice_gi,
                                                         const unsigned* __restrict__ counts,
@@ -483,20 +486,49 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
                                                         const float* __restrict__ records,
                                                         const unsigned char* __restrict__ done,
                                                         unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+  const int lane = lane_id();
   int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_slice) return;
-  if (counts[j] == 0) return;
-  unsigned gi = slice_gi[j];
-  const float* rec = records + (size_t)gi * kRecFloats;
-  unsigned lo = (unsigned)__float_as_int(rec[10]), hi = (unsigned)__float_as_int(rec[11]);
-  int x0 = lo & 0xFFFF, y0 = lo >> 16, x1 = hi & 0xFFFF, y1 = hi >> 16;
-  unsigned pbase = (gi / (unsigned)N) * (unsigned)T;
-  unsigned e = cum[j];
-  for (int y = y0; y < y1; ++y)
-    for (int x = x0; x < x1; ++x) {
-      unsigned k = pbase + (unsigned)(y * tiles_x + x);
-      if (!done[k]) { keys[e] = k; vals[e] = gi; ++e; }
+  unsigned cnt = 0, gi = 0, e0 = 0, lo = 0, hi = 0;
+  if (j < n_slice) {
+    cnt = counts[j];
+    if (cnt) {
+      gi = slice_gi[j];
+      e0 = cum[j];
+      const float* rec = records + (size_t)gi * kRecFloats;
+      lo = (unsigned)__float_as_int(rec[10]);
+      hi = (unsigned)__float_as_int(rec[11]);
     }
+  }
+  unsigned long long todo = __ballot(cnt != 0);
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const unsigned g = (unsigned)readlane_i((int)gi, src);
+    unsigned e = (unsigned)readlane_i((int)e0, src);
+    const unsigned l = (unsigned)readlane_i((int)lo, src), h = (unsigned)readlane_i((int)hi, src);
+    const int x0 = l & 0xFFFF, y0 = l >> 16, x1 = h & 0xFFFF, y1 = h >> 16;
+    const int w = x1 - x0, area = w * (y1 - y0);
+    const float rw = 1.0f / (float)w;
+    const unsigned pbase = (g / (unsigned)N) * (unsigned)T;
+    for (int base = 0; base < area; base += 64) {
+      const int t = base + lane;
+      bool open = false;
+      unsigned k = 0;
+      if (t < area) {
+        const int q = (int)(((float)t + 0.5f) * rw);
+        k = pbase + (unsigned)((y0 + q) * tiles_x + x0 + (t - q * w));
+        open = done[k] == 0;
+      }
+      const unsigned long long m = __ballot(open);
+      if (open) {
+        const unsigned dst = e + (unsigned)__popcll(m & lt_mask);
+        keys[dst] = k;
+        vals[dst] = g;
+      }
+      e += (unsigned)__popcll(m);
+    }
+  }
 }
 
 // upstream-compatible 64-bit intersection ids (one thread per Gaussian; API-parity path)
@@ -647,7 +679,12 @@ GS_EXPORT int gs_map_gaussian_to_intersects(int N, const float* xys, const float
 GS_EXPORT int gs_tile_open_sat(int P, int H, int W, const unsigned char* tile_done, int* sat, void* stream) {
   if (P <= 0) return GS_ERR_INVALID;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
-  hipLaunchKernelGGL(tile_sat_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, tiles_x, tiles_y, tile_done, sat);
+  size_t lds = (size_t)(tiles_x + 1) * (tiles_y + 1) * sizeof(int);
+  if (lds > 160 * 1024) return GS_ERR_INVALID;
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  hipLaunchKernelGGL(tile_sat_kernel, dim3(P), dim3(256), lds, (hipStream_t)stream, tiles_x, tiles_y, tile_done, sat);
   return gs_launch_status();
 }
 

@@ -479,6 +479,182 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(RasterParams prm, const
 }
 
 // ---------------------------------------------------------------------------
+// backward, variant 2 (default for the depth-sliced path).  Same math as raster_bwd_kernel, cheaper
+// instruction stream:
+//   * one predicate per pixel instead of three nested exec-mask regions, exp2 on a pre-scaled
+//     exponent, v_rcp_f32 for 1/(1-alpha) (the IEEE division expansion cost ~10 VALU per pixel);
+//   * the 9 per-Gaussian wave reductions (54 DPP adds + 18 lane moves) are replaced by a transposed
+//     reduction through wave-private LDS: every lane drops its 9 partials into row (g*9+c) of a
+//     [36][68] tile (conflict-free ds_write_b32), after 4 Gaussians lanes 0..35 each sum one row
+//     with 16 conflict-free ds_read_b128 and park the total in tot[j][c]; at the end of the batch
+//     lane j picks up its 9 totals.  ~20 issue slots per Gaussian instead of ~80.
+// ---------------------------------------------------------------------------
+constexpr int kRedG = 4;                    // Gaussians per transposed-reduction group
+constexpr int kRedStride = 68;              // floats per row (64 + 4: 16-byte aligned, b128 conflict-free)
+constexpr int kRedFloats = kRedG * 9 * kRedStride + 64 * 9;
+
+template <bool STATE>
+__global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, const float* __restrict__ out_T,
+                                                            const int* __restrict__ final_idx,
+                                                            const float* __restrict__ v_img,
+                                                            const float* __restrict__ v_alpha,  // may be null
+                                                            float* __restrict__ v_records, unsigned n_blocks,
+                                                            float* __restrict__ bwd_T, float* __restrict__ bwd_B) {
+  __shared__ __attribute__((aligned(16))) float lds_all[4 * kRedFloats];
+  const int lane = lane_id();
+  float* red = lds_all + (threadIdx.x >> 6) * kRedFloats;   // wave-private
+  float* tot = red + kRedG * 9 * kRedStride;
+  const int T = prm.tiles_x * prm.tiles_y;
+  const unsigned work = xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6);
+  if (work >= (unsigned)(prm.S * T)) return;
+  const int s = work / T, t = work % T;
+  const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
+  const int p = s * prm.R + find_band(prm.band_edges, prm.R, ty);
+  const int2 range = prm.tile_bins[(size_t)p * T + t];
+  if (range.y <= range.x) return;
+
+  const int px = tx * K::kTile + (lane & 15);
+  const int py0 = ty * K::kTile + (lane >> 4) * 4;
+  const float pxf = (float)px + 0.5f;
+  const float bgr = prm.background[0], bgg = prm.background[1], bgb = prm.background[2];
+
+  float Tk[4], Br[4], Bg[4], Bb[4], vr[4], vg[4], vb[4], va[4], pyf[4];
+  int fin[4];
+  int my_end = range.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = py0 + k;
+    pyf[k] = (float)y + 0.5f;
+    Br[k] = Bg[k] = Bb[k] = 0.f;
+    Tk[k] = 1.f; fin[k] = range.x; vr[k] = vg[k] = vb[k] = 0.f; va[k] = 0.f;
+    if (px < prm.W && y < prm.H) {
+      size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
+      const float Tfin = out_T[pix];
+      fin[k] = final_idx[pix];
+      vr[k] = v_img[pix * 3 + 0]; vg[k] = v_img[pix * 3 + 1]; vb[k] = v_img[pix * 3 + 2];
+      const float va_out = v_alpha ? v_alpha[pix] : 0.f;
+      va[k] = Tfin * (va_out - (bgr * vr[k] + bgg * vg[k] + bgb * vb[k]));
+      Tk[k] = Tfin;
+      if (STATE) {
+        Tk[k] = bwd_T[pix];
+        Br[k] = bwd_B[pix * 3 + 0]; Bg[k] = bwd_B[pix * 3 + 1]; Bb[k] = bwd_B[pix * 3 + 2];
+      }
+    }
+    my_end = max(my_end, fin[k]);
+  }
+  const int wave_end = wave_max_i(my_end);
+  const int* __restrict__ vals = prm.sorted_vals;
+  const float kL2E = -1.4426950408889634f;
+  const int row = lane;                        // row-sum role: lanes 0..35
+  const int row_g = row / 9, row_c = row - row_g * 9;
+
+  for (int batch_end = wave_end; batch_end > range.x; batch_end -= 64) {
+    const int idx = batch_end - 1 - lane;
+    const bool valid = idx >= range.x;
+    const int gid = valid ? vals[idx] : 0;
+    const Rec9 rec = load_rec(prm.records, gid, valid);
+    const float sx = rec.cx * (0.5f * kL2E), sy = rec.cy * kL2E, sz = rec.cz * (0.5f * kL2E);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) tot[lane * 9 + c] = 0.f;
+    const int n = min(64, batch_end - range.x);
+    unsigned filled = 0;                          // which slots of the current group hold data
+    for (int j = 0; j < n; ++j) {
+      const int idx_j = batch_end - 1 - j;
+      const int g = j & (kRedG - 1);
+      const float gx = readlane_f(rec.x, j), gy = readlane_f(rec.y, j);
+      const float cx = readlane_f(rec.cx, j), cy = readlane_f(rec.cy, j), cz = readlane_f(rec.cz, j);
+      const float qx = readlane_f(sx, j), qy = readlane_f(sy, j), qz = readlane_f(sz, j);
+      const float op = readlane_f(rec.op, j);
+      const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
+      const float dx = gx - pxf;
+      const float hx = qx * dx * dx;             // exponent terms, pre-scaled by -log2(e)
+      const float bx = qy * dx;
+      const float hdx2 = 0.5f * dx * dx;
+      const float cxdx = cx * dx, cydx = cy * dx;
+      float p_x = 0.f, p_y = 0.f, p_cx = 0.f, p_cy = 0.f, p_cz = 0.f, p_op = 0.f, p_r = 0.f, p_g = 0.f, p_b = 0.f;
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dy = gy - pyf[k];
+        const float s2 = hx + dy * (bx + qz * dy);
+        const float vis = __builtin_amdgcn_exp2f(s2);
+        const float ov = op * vis;
+        const float alpha = fminf(K::kAlphaMax, ov);
+        if ((idx_j < fin[k]) && (s2 <= 0.f) && (alpha >= K::kAlphaMin)) {
+          any = true;
+          const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+          Tk[k] *= ra;                       // transmittance in front of this Gaussian
+          const float fac = alpha * Tk[k];
+          p_r += fac * vr[k]; p_g += fac * vg[k]; p_b += fac * vb[k];
+          const float v_al = (cr * Tk[k] - Br[k] * ra) * vr[k] + (cg * Tk[k] - Bg[k] * ra) * vg[k] +
+                             (cb * Tk[k] - Bb[k] * ra) * vb[k] + va[k] * ra;
+          Br[k] += cr * fac; Bg[k] += cg * fac; Bb[k] += cb * fac;
+          const float v_sigma = (ov <= K::kAlphaMax) ? -ov * v_al : 0.f;   // d min(0.999, o*vis) = 0 when clamped
+          p_op += (ov <= K::kAlphaMax) ? vis * v_al : 0.f;
+          const float vsdy = v_sigma * dy;
+          p_cx += v_sigma * hdx2;
+          p_cy += vsdy * dx;
+          p_cz += vsdy * (0.5f * dy);
+          p_x += v_sigma * (cxdx + cy * dy);
+          p_y += v_sigma * (cydx + cz * dy);
+        }
+      }
+      if (__ballot(any) != 0ull) {
+        filled |= 1u << g;
+        float* r0 = red + g * (9 * kRedStride) + lane;
+        r0[0 * kRedStride] = p_x;  r0[1 * kRedStride] = p_y;  r0[2 * kRedStride] = p_cx;
+        r0[3 * kRedStride] = p_cy; r0[4 * kRedStride] = p_cz; r0[5 * kRedStride] = p_op;
+        r0[6 * kRedStride] = p_r;  r0[7 * kRedStride] = p_g;  r0[8 * kRedStride] = p_b;
+      }
+      if (g == kRedG - 1 || j == n - 1) {
+        if (filled) {
+          __builtin_amdgcn_wave_barrier();
+          if (row < kRedG * 9 && ((filled >> row_g) & 1u)) {
+            const float4* rp = reinterpret_cast<const float4*>(red + row * kRedStride);
+            float4 a0 = rp[0], a1 = rp[1], a2 = rp[2], a3 = rp[3];
+#pragma unroll
+            for (int q = 4; q < 16; q += 4) {
+              float4 b0 = rp[q], b1 = rp[q + 1], b2 = rp[q + 2], b3 = rp[q + 3];
+              a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+              a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+              a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
+              a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
+            }
+            const float sum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
+                              ((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w));
+            const int jj = (j & ~(kRedG - 1)) + row_g;      // batch position of this row's Gaussian
+            tot[jj * 9 + row_c] = sum;
+          }
+          __builtin_amdgcn_wave_barrier();
+          filled = 0;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      float* dst = v_records + (size_t)gid * kRecFloats;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const float a = tot[lane * 9 + c];
+        if (a != 0.f) atomic_add_f32(dst + c, a);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (STATE) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = py0 + k;
+      if (px < prm.W && y < prm.H) {
+        size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
+        bwd_T[pix] = Tk[k];
+        bwd_B[pix * 3 + 0] = Br[k]; bwd_B[pix * 3 + 1] = Bg[k]; bwd_B[pix * 3 + 2] = Bb[k];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // sub-frame averaging in linearised colour:
 //   out = ( mean_k max(C_k, m)^gamma )^(1/gamma),  m = min_rgb_level/255
 // ---------------------------------------------------------------------------
@@ -595,7 +771,7 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
                                      const int* band_edges, const float* background, int S, int R, int H, int W,
                                      const float* out_T, const int* final_idx, const float* v_img,
                                      const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records,
-                                     void* stream) {
+                                     int variant, void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm;
   prm.records = records; prm.sorted_vals = sorted_vals; prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
@@ -604,8 +780,12 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
   prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
-  hipLaunchKernelGGL(raster_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T, final_idx,
-                     v_img, v_alpha, v_records, blocks, bwd_T, bwd_B);
+  if (variant == 1)
+    hipLaunchKernelGGL(raster_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T,
+                       final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B);
+  else
+    hipLaunchKernelGGL(raster_bwd_kernel_v2<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T,
+                       final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B);
   return gs_launch_status();
 }
 

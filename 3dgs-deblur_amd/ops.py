@@ -27,9 +27,10 @@ TILE = 16
 REC = 12  # floats per rasterizer record
 # kernel variant selector for A/B measurements (0 = default)
 RASTER_FWD_VARIANT = int(os.environ.get("GSD_RASTER_FWD_VARIANT", "0"))
+RASTER_BWD_VARIANT = int(os.environ.get("GSD_RASTER_BWD_VARIANT", "0"))
 # depth slicing of the fused path: average tile-list length budget of the first slice (doubling per
 # slice); 0 disables slicing (single pass over all intersections)
-SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "128"))
+SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "256"))
 last_slice_intersects = []
 
 
@@ -307,7 +308,16 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                          _ptr(records), None if first else _ptr(sat), H, W, _ptr(slice_gi),
                                          _ptr(counts), _stream()), "slice_counts")
                 cum_k, total_k = exclusive_scan_u32(counts)
-            I_k = int(total_k.item())          # host sync (one per slice)
+            if first:
+                I_k = int(total_k.item())          # host sync (one per slice)
+            else:
+                # same sync also fetches how many tiles are still open after the previous slice
+                both = torch.cat([total_k, sat.view(P, -1)[:, -1].sum(dtype=torch.int32).reshape(1)]).tolist()
+                I_k = int(both[0])
+                if both[1] == 0:
+                    # every tile is done (each already received its background term): nothing left to do
+                    last_slice_intersects.append(0)
+                    break
         if I_k > 0:
             with _stage("emit"):
                 keys = torch.empty(I_k, dtype=torch.int32, device=dev)
@@ -353,7 +363,8 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
         for svals, bins, fidx, _ in reversed(slices):
             _check(L.gs_rasterize_bwd_slice(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
                                             _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_alpha), _ptr(bwd_T),
-                                            _ptr(bwd_B), _ptr(v_records), _stream()), "rasterize_bwd_slice")
+                                            _ptr(bwd_B), _ptr(v_records), RASTER_BWD_VARIANT, _stream()),
+                   "rasterize_bwd_slice")
 
 
 # --------------------------------------------------------------------------- #

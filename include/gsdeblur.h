@@ -169,7 +169,9 @@ int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const i
 int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                            const int* band_edges, const float* background, int S, int R, int img_height,
                            int img_width, const float* out_T, const int* final_idx, const float* v_img,
-                           const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records, void* stream);
+                           const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records,
+                           int variant /*0 = default (LDS-transposed reduction); 1 = DPP reference kernel*/,
+                           void* stream);
 
 /* ---- sub-frame averaging in linearised colour (flags train.py:60,62) ---------
  * out = ( mean_k max(C_k, min_level)^gamma )^(1/gamma); n = H*W*3 values per sample. */
