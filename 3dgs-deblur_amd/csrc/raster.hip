@@ -245,20 +245,26 @@ struct SliceState {
   int first, last;
 };
 
+template <bool SKIP_EMPTY>
 __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm, SliceState st,
                                                                float* __restrict__ out_img,
                                                                float* __restrict__ out_T,
                                                                int* __restrict__ final_idx, unsigned n_blocks) {
   const int lane = lane_id();
   const int T = prm.tiles_x * prm.tiles_y;
-  const unsigned work = xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6);
+  // wave-uniform tile index in an SGPR: the tile header loads become scalar loads and both loops
+  // run on the scalar unit
+  const unsigned work = (unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6)));
   if (work >= (unsigned)(prm.S * T)) return;
   const int s = work / T, t = work % T;
   const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
   const int p = s * prm.R + find_band(prm.band_edges, prm.R, ty);
   const size_t tkey = (size_t)p * T + t;
   if (!st.first && st.tile_done[tkey]) return;
-  const int2 range = prm.tile_bins[tkey];
+  int2 range = prm.tile_bins[tkey];
+  range.x = __builtin_amdgcn_readfirstlane(range.x);
+  range.y = __builtin_amdgcn_readfirstlane(range.y);
   if (!st.first && !st.last && range.y <= range.x) return;   // nothing for this tile in this slice
 
   const int px = tx * K::kTile + (lane & 15);
@@ -297,23 +303,30 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
       const float gx = readlane_f(rec.x, j), gy = readlane_f(rec.y, j);
       const float cx = readlane_f(rec.cx, j), cy = readlane_f(rec.cy, j), cz = readlane_f(rec.cz, j);
       const float op = readlane_f(rec.op, j);
-      const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
       const float dx = gx - pxf;
       const float hx = cx * dx * dx;
       const float bx = cy * dx;
-      const int idx1 = batch + j + 1;
+      float alpha[4];
+      bool valid[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float dy = gy - pyf[k];
         const float s2 = hx + dy * (bx + cz * dy);
-        const float alpha = fminf(K::kAlphaMax, op * __builtin_amdgcn_exp2f(s2));
-        const bool valid = (s2 <= 0.f) && (alpha >= K::kAlphaMin);
-        const float nT = Tk[k] - Tk[k] * alpha;
-        const bool upd = valid && (nT > K::kTMin);
-        const float w = upd ? alpha * Tk[k] : 0.f;
+        alpha[k] = fminf(K::kAlphaMax, op * __builtin_amdgcn_exp2f(s2));
+        valid[k] = (s2 <= 0.f) && (alpha[k] >= K::kAlphaMin);
+      }
+      // the tile list comes from a bounding BOX: many (Gaussian, tile) pairs touch no pixel at all
+      if (SKIP_EMPTY && __ballot(valid[0] || valid[1] || valid[2] || valid[3]) == 0ull) continue;
+      const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
+      const int idx1 = batch + j + 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float nT = Tk[k] - Tk[k] * alpha[k];
+        const bool upd = valid[k] && (nT > K::kTMin);
+        const float w = upd ? alpha[k] * Tk[k] : 0.f;
         Cr[k] += w * cr; Cg[k] += w * cg; Cb[k] += w * cb;
         Tf[k] = upd ? nT : Tf[k];
-        Tk[k] = upd ? nT : (valid ? 0.f : Tk[k]);
+        Tk[k] = upd ? nT : (valid[k] ? 0.f : Tk[k]);
         last[k] = upd ? idx1 : last[k];
       }
     }
@@ -493,7 +506,7 @@ constexpr int kRedG = 4;                    // Gaussians per transposed-reductio
 constexpr int kRedStride = 68;              // floats per row (64 + 4: 16-byte aligned, b128 conflict-free)
 constexpr int kRedFloats = kRedG * 9 * kRedStride + 64 * 9;
 
-template <bool STATE>
+template <bool STATE, bool ABLATE_ATOMICS>
 __global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, const float* __restrict__ out_T,
                                                             const int* __restrict__ final_idx,
                                                             const float* __restrict__ v_img,
@@ -505,12 +518,15 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, co
   float* red = lds_all + (threadIdx.x >> 6) * kRedFloats;   // wave-private
   float* tot = red + kRedG * 9 * kRedStride;
   const int T = prm.tiles_x * prm.tiles_y;
-  const unsigned work = xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6);
+  const unsigned work = (unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6)));
   if (work >= (unsigned)(prm.S * T)) return;
   const int s = work / T, t = work % T;
   const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
   const int p = s * prm.R + find_band(prm.band_edges, prm.R, ty);
-  const int2 range = prm.tile_bins[(size_t)p * T + t];
+  int2 range = prm.tile_bins[(size_t)p * T + t];
+  range.x = __builtin_amdgcn_readfirstlane(range.x);
+  range.y = __builtin_amdgcn_readfirstlane(range.y);
   if (range.y <= range.x) return;
 
   const int px = tx * K::kTile + (lane & 15);
@@ -542,7 +558,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, co
     }
     my_end = max(my_end, fin[k]);
   }
-  const int wave_end = wave_max_i(my_end);
+  const int wave_end = __builtin_amdgcn_readfirstlane(wave_max_i(my_end));
   const int* __restrict__ vals = prm.sorted_vals;
   const float kL2E = -1.4426950408889634f;
   const int row = lane;                        // row-sum role: lanes 0..35
@@ -636,7 +652,11 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, co
 #pragma unroll
       for (int c = 0; c < 9; ++c) {
         const float a = tot[lane * 9 + c];
-        if (a != 0.f) atomic_add_f32(dst + c, a);
+        if (ABLATE_ATOMICS) {            // timing experiment only (wrong gradients): plain stores
+          if (a != 0.f) dst[c] = a;
+        } else if (a != 0.f) {
+          atomic_add_f32(dst + c, a);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -750,7 +770,7 @@ GS_EXPORT int gs_rasterize_bwd(const float* records, const int* sorted_vals, con
 GS_EXPORT int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                                      const int* band_edges, const float* background, int S, int R, int H, int W,
                                      float* out_img, float* out_T, float* live_T, int* final_idx,
-                                     unsigned char* tile_done, int first, int last, void* stream) {
+                                     unsigned char* tile_done, int first, int last, int variant, void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm;
   prm.records = records; prm.sorted_vals = sorted_vals; prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
@@ -760,8 +780,12 @@ GS_EXPORT int gs_rasterize_fwd_slice(const float* records, const int* sorted_val
   SliceState st; st.tile_done = tile_done; st.live_T = live_T; st.first = first; st.last = last;
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
-  hipLaunchKernelGGL(raster_fwd_slice_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, st, out_img,
-                     out_T, final_idx, blocks);
+  if (variant == 1)
+    hipLaunchKernelGGL(raster_fwd_slice_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, st,
+                       out_img, out_T, final_idx, blocks);
+  else
+    hipLaunchKernelGGL(raster_fwd_slice_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, st,
+                       out_img, out_T, final_idx, blocks);
   return gs_launch_status();
 }
 
@@ -783,9 +807,12 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
   if (variant == 1)
     hipLaunchKernelGGL(raster_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T,
                        final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B);
+  else if (variant == 2)   // ablation: no atomics (timing experiments only)
+    hipLaunchKernelGGL((raster_bwd_kernel_v2<true, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm,
+                       out_T, final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B);
   else
-    hipLaunchKernelGGL(raster_bwd_kernel_v2<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T,
-                       final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B);
+    hipLaunchKernelGGL((raster_bwd_kernel_v2<true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm,
+                       out_T, final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B);
   return gs_launch_status();
 }
 

@@ -344,7 +344,8 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         with _stage("raster_fwd"):
             _check(L.gs_rasterize_fwd_slice(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
                                             _ptr(out_img), _ptr(out_T), _ptr(live_T), _ptr(fidx), _ptr(tile_done),
-                                            int(first), int(last), _stream()), "rasterize_fwd_slice")
+                                            int(first), int(last), RASTER_FWD_VARIANT, _stream()),
+                   "rasterize_fwd_slice")
         if I_k > 0:
             slices.append((svals, bins, fidx, I_k))
         if not last:

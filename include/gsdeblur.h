@@ -164,13 +164,14 @@ int gs_emit_open_intersects(int n_slice, int N, int img_height, int img_width, c
 int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                            const int* band_edges, const float* background, int S, int R, int img_height,
                            int img_width, float* out_img, float* out_T, float* live_T, int* final_idx,
-                           unsigned char* tile_done, int first, int last, void* stream);
+                           unsigned char* tile_done, int first, int last,
+                           int variant /*0 = default (skips pairs that touch no pixel); 1 = no skip*/, void* stream);
 /* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B [S,H,W,3] (init = 0) carry state */
 int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                            const int* band_edges, const float* background, int S, int R, int img_height,
                            int img_width, const float* out_T, const int* final_idx, const float* v_img,
                            const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records,
-                           int variant /*0 = default (LDS-transposed reduction); 1 = DPP reference kernel*/,
+                           int variant /*0 = default (LDS-transposed reduction); 1 = DPP reference kernel; 2 = timing ablation, no atomics (wrong gradients)*/,
                            void* stream);
 
 /* ---- sub-frame averaging in linearised colour (flags train.py:60,62) ---------
