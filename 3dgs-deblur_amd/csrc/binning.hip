@@ -339,6 +339,46 @@ __global__ __launch_bounds__(256) void gather_counts_kernel(size_t n, const unsi
   if (i < n) out[i] = (unsigned)ntiles[sorted_gi[i]];
 }
 
+// ---------------------------------------------------------------------------
+// Exact tile culling.  The tile list of a Gaussian comes from the bounding BOX of its 3-sigma
+// circle (upstream rule, kept for num_tiles_hit), but a pixel can only receive a contribution if
+// alpha = o*exp(-sigma) >= 1/255, i.e. sigma <= tau = ln(255*o).  A tile whose pixel-centre rectangle
+// lies entirely outside that ellipse is dead weight for the compositor (about half of all pairs for
+// anisotropic Gaussians).  sigma is convex, so its minimum over the rectangle is 0 if the centre is
+// inside, else the smallest of the four edge minima (1-D quadratics, clamped).  A relative+absolute
+// slack keeps the test conservative against the compositor's float32 rounding: culled pairs
+// contribute exactly nothing, so images are unchanged.
+// ---------------------------------------------------------------------------
+struct Ellipse { float gx, gy, a, b, c, tau; };
+
+__device__ __forceinline__ Ellipse make_ellipse(const float* __restrict__ rec) {
+  Ellipse e;
+  e.gx = rec[0]; e.gy = rec[1]; e.a = rec[2]; e.b = rec[3]; e.c = rec[4];
+  const float op = rec[5];
+  e.tau = op > 0.f ? __logf(255.0f * op) : -1.f;
+  return e;
+}
+
+__device__ __forceinline__ float edge_min(float fixed, float lo, float hi, float qf, float qb, float qv) {
+  // min over v in [lo,hi] of 0.5*qf*fixed^2 + qb*fixed*v + 0.5*qv*v^2
+  float v = fminf(hi, fmaxf(lo, -qb * fixed / qv));
+  return 0.5f * qf * fixed * fixed + qb * fixed * v + 0.5f * qv * v * v;
+}
+
+__device__ __forceinline__ bool tile_hit(const Ellipse& e, int tx, int ty, int W, int H) {
+  if (e.tau < 0.f) return false;
+  const float u0 = (float)(tx * K::kTile) + 0.5f - e.gx;
+  const float u1 = fminf((float)(tx * K::kTile + K::kTile) - 0.5f, (float)W - 0.5f) - e.gx;
+  const float v0 = (float)(ty * K::kTile) + 0.5f - e.gy;
+  const float v1 = fminf((float)(ty * K::kTile + K::kTile) - 0.5f, (float)H - 0.5f) - e.gy;
+  if (u0 <= 0.f && u1 >= 0.f && v0 <= 0.f && v1 >= 0.f) return true;
+  float m = edge_min(u0, v0, v1, e.a, e.b, e.c);
+  m = fminf(m, edge_min(u1, v0, v1, e.a, e.b, e.c));
+  m = fminf(m, edge_min(v0, u0, u1, e.c, e.b, e.a));
+  m = fminf(m, edge_min(v1, u0, u1, e.c, e.b, e.a));
+  return m <= e.tau * 1.001f + 1e-3f;
+}
+
 // One block expands 256 consecutive depth-ranked Gaussians; the block's output range is
 // contiguous and every thread writes consecutive entries (coalesced).  The source Gaussian of an
 // entry is found by a branch-free 8-step binary search in the block's LDS scan; tile coordinates
@@ -347,14 +387,18 @@ __global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T
                                                    const unsigned* __restrict__ sorted_gi,
                                                    const unsigned* __restrict__ cum,   // exclusive, in rank order
                                                    const float* __restrict__ records, size_t n_isect,
-                                                   unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+                                                   unsigned* __restrict__ keys, unsigned* __restrict__ vals,
+                                                   int W, int H, unsigned invalid_key /*0: no exact culling*/) {
   __shared__ unsigned s_cum[257];
   __shared__ unsigned s_gi[256];
   __shared__ unsigned s_kbase[256];   // p*T + y0*tiles_x + x0
   __shared__ unsigned s_w[256];
+  __shared__ unsigned s_xy0[256];
   __shared__ float s_rw[256];
+  __shared__ Ellipse s_el[256];
   size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-  unsigned gi = 0, c = 0, kbase = 0, w = 1;
+  unsigned gi = 0, c = 0, kbase = 0, w = 1, xy0 = 0;
+  Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f};
   if (r < n_ranked) {
     gi = sorted_gi[r];
     c = cum[r];
@@ -363,9 +407,12 @@ __global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T
     unsigned hi = (unsigned)__float_as_int(rec[11]);
     unsigned x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu;
     w = x1 > x0 ? x1 - x0 : 1u;
-    kbase = (gi / (unsigned)N) * (unsigned)T + y0 * (unsigned)tiles_x + x0;
+    xy0 = lo;
+    kbase = (gi / (unsigned)N) * (unsigned)T;
+    if (invalid_key) el = make_ellipse(rec);
   }
   s_gi[threadIdx.x] = gi; s_kbase[threadIdx.x] = kbase; s_w[threadIdx.x] = w; s_rw[threadIdx.x] = 1.0f / (float)w;
+  s_xy0[threadIdx.x] = xy0; s_el[threadIdx.x] = el;
   s_cum[threadIdx.x] = c;
   size_t r_last = (size_t)blockIdx.x * 256 + 256;
   if (threadIdx.x == 0) s_cum[256] = r_last < n_ranked ? cum[r_last] : (unsigned)n_isect;
@@ -385,7 +432,11 @@ __global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T
     unsigned wa = s_w[a];
     unsigned q = (unsigned)(((float)rem + 0.5f) * s_rw[a]);
     unsigned x = rem - q * wa;
-    keys[e] = s_kbase[a] + q * (unsigned)tiles_x + x;
+    const unsigned xy = s_xy0[a];
+    const int tx = (int)((xy & 0xFFFFu) + x), ty = (int)((xy >> 16) + q);
+    unsigned key = s_kbase[a] + (unsigned)(ty * tiles_x + tx);
+    if (invalid_key && !tile_hit(s_el[a], tx, ty, W, H)) key = invalid_key;
+    keys[e] = key;
     vals[e] = s_gi[a];
   }
 }
@@ -485,10 +536,12 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
                                                         const unsigned* __restrict__ cum,
                                                         const float* __restrict__ records,
                                                         const unsigned char* __restrict__ done,
-                                                        unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+                                                        unsigned* __restrict__ keys, unsigned* __restrict__ vals,
+                                                        int W, int H, unsigned invalid_key) {
   const int lane = lane_id();
   int j = blockIdx.x * 256 + threadIdx.x;
   unsigned cnt = 0, gi = 0, e0 = 0, lo = 0, hi = 0;
+  Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f};
   if (j < n_slice) {
     cnt = counts[j];
     if (cnt) {
@@ -497,6 +550,7 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
       const float* rec = records + (size_t)gi * kRecFloats;
       lo = (unsigned)__float_as_int(rec[10]);
       hi = (unsigned)__float_as_int(rec[11]);
+      if (invalid_key) el = make_ellipse(rec);
     }
   }
   unsigned long long todo = __ballot(cnt != 0);
@@ -507,6 +561,9 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
     const unsigned g = (unsigned)readlane_i((int)gi, src);
     unsigned e = (unsigned)readlane_i((int)e0, src);
     const unsigned l = (unsigned)readlane_i((int)lo, src), h = (unsigned)readlane_i((int)hi, src);
+    Ellipse eg;
+    eg.gx = readlane_f(el.gx, src); eg.gy = readlane_f(el.gy, src); eg.a = readlane_f(el.a, src);
+    eg.b = readlane_f(el.b, src); eg.c = readlane_f(el.c, src); eg.tau = readlane_f(el.tau, src);
     const int x0 = l & 0xFFFF, y0 = l >> 16, x1 = h & 0xFFFF, y1 = h >> 16;
     const int w = x1 - x0, area = w * (y1 - y0);
     const float rw = 1.0f / (float)w;
@@ -517,8 +574,10 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
       unsigned k = 0;
       if (t < area) {
         const int q = (int)(((float)t + 0.5f) * rw);
-        k = pbase + (unsigned)((y0 + q) * tiles_x + x0 + (t - q * w));
+        const int tx = x0 + (t - q * w), ty = y0 + q;
+        k = pbase + (unsigned)(ty * tiles_x + tx);
         open = done[k] == 0;
+        if (open && invalid_key && !tile_hit(eg, tx, ty, W, H)) k = invalid_key;
       }
       const unsigned long long m = __ballot(open);
       if (open) {
@@ -630,13 +689,13 @@ GS_EXPORT int gs_gather_counts(long long n, const unsigned* sorted_gi, const int
 // Emit the tile intersections of the depth-ranked Gaussians: keys[e] = p*T + tile, vals[e] = p*N + g.
 GS_EXPORT int gs_emit_intersects(long long n_ranked, int N, int H, int W, const unsigned* sorted_gi,
                                  const unsigned* cum_excl, const float* records, long long n_isect, unsigned* keys,
-                                 unsigned* vals, void* stream) {
+                                 unsigned* vals, unsigned invalid_key, void* stream) {
   if (n_ranked <= 0 || N <= 0) return GS_ERR_INVALID;
   if (n_isect <= 0) return GS_OK;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
   hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((n_ranked + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (size_t)n_ranked, N, tiles_x * tiles_y, tiles_x, sorted_gi, cum_excl, records, (size_t)n_isect,
-                     keys, vals);
+                     keys, vals, W, H, invalid_key);
   return gs_launch_status();
 }
 
@@ -705,11 +764,13 @@ GS_EXPORT int gs_slice_counts(int n_slice, int P, int N, const int* slice_begin,
 // Emit the intersections of a slice with the tiles that are still open (depth order preserved).
 GS_EXPORT int gs_emit_open_intersects(int n_slice, int N, int H, int W, const unsigned* slice_gi,
                                       const unsigned* counts, const unsigned* cum_excl, const float* records,
-                                      const unsigned char* tile_done, unsigned* keys, unsigned* vals, void* stream) {
+                                      const unsigned char* tile_done, unsigned* keys, unsigned* vals,
+                                      unsigned invalid_key, void* stream) {
   if (n_slice <= 0) return GS_ERR_INVALID;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
   hipLaunchKernelGGL(emit_open_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice, N,
-                     tiles_x * tiles_y, tiles_x, slice_gi, counts, cum_excl, records, tile_done, keys, vals);
+                     tiles_x * tiles_y, tiles_x, slice_gi, counts, cum_excl, records, tile_done, keys, vals, W, H,
+                     invalid_key);
   return gs_launch_status();
 }
 

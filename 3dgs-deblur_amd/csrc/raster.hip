@@ -534,26 +534,29 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, co
   const float pxf = (float)px + 0.5f;
   const float bgr = prm.background[0], bgg = prm.background[1], bgb = prm.background[2];
 
-  float Tk[4], Br[4], Bg[4], Bb[4], vr[4], vg[4], vb[4], va[4], pyf[4];
+  // per pixel: Tk = transmittance behind the current Gaussian, Dv = (colour accumulated from behind,
+  // dotted with v_out) - va, where va = T_final * (v_alpha_out - bg . v_out).  Only the DOT of the
+  // behind-colour with v_out is ever needed, so one float replaces the three colour channels.
+  float Tk[4], Dv[4], vr[4], vg[4], vb[4], pyf[4];
   int fin[4];
   int my_end = range.x;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int y = py0 + k;
     pyf[k] = (float)y + 0.5f;
-    Br[k] = Bg[k] = Bb[k] = 0.f;
-    Tk[k] = 1.f; fin[k] = range.x; vr[k] = vg[k] = vb[k] = 0.f; va[k] = 0.f;
+    Tk[k] = 1.f; Dv[k] = 0.f; fin[k] = range.x; vr[k] = vg[k] = vb[k] = 0.f;
     if (px < prm.W && y < prm.H) {
       size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
       const float Tfin = out_T[pix];
       fin[k] = final_idx[pix];
       vr[k] = v_img[pix * 3 + 0]; vg[k] = v_img[pix * 3 + 1]; vb[k] = v_img[pix * 3 + 2];
       const float va_out = v_alpha ? v_alpha[pix] : 0.f;
-      va[k] = Tfin * (va_out - (bgr * vr[k] + bgg * vg[k] + bgb * vb[k]));
+      const float va = Tfin * (va_out - (bgr * vr[k] + bgg * vg[k] + bgb * vb[k]));
       Tk[k] = Tfin;
+      Dv[k] = -va;
       if (STATE) {
         Tk[k] = bwd_T[pix];
-        Br[k] = bwd_B[pix * 3 + 0]; Bg[k] = bwd_B[pix * 3 + 1]; Bb[k] = bwd_B[pix * 3 + 2];
+        Dv[k] = bwd_B[pix] - va;
       }
     }
     my_end = max(my_end, fin[k]);
@@ -578,44 +581,50 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, co
       const int idx_j = batch_end - 1 - j;
       const int g = j & (kRedG - 1);
       const float gx = readlane_f(rec.x, j), gy = readlane_f(rec.y, j);
-      const float cx = readlane_f(rec.cx, j), cy = readlane_f(rec.cy, j), cz = readlane_f(rec.cz, j);
       const float qx = readlane_f(sx, j), qy = readlane_f(sy, j), qz = readlane_f(sz, j);
       const float op = readlane_f(rec.op, j);
-      const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
       const float dx = gx - pxf;
       const float hx = qx * dx * dx;             // exponent terms, pre-scaled by -log2(e)
       const float bx = qy * dx;
-      const float hdx2 = 0.5f * dx * dx;
-      const float cxdx = cx * dx, cydx = cy * dx;
-      float p_x = 0.f, p_y = 0.f, p_cx = 0.f, p_cy = 0.f, p_cz = 0.f, p_op = 0.f, p_r = 0.f, p_g = 0.f, p_b = 0.f;
-      bool any = false;
+      float vis[4], ov[4];
+      bool hit[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float dy = gy - pyf[k];
         const float s2 = hx + dy * (bx + qz * dy);
-        const float vis = __builtin_amdgcn_exp2f(s2);
-        const float ov = op * vis;
-        const float alpha = fminf(K::kAlphaMax, ov);
-        if ((idx_j < fin[k]) && (s2 <= 0.f) && (alpha >= K::kAlphaMin)) {
-          any = true;
-          const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
-          Tk[k] *= ra;                       // transmittance in front of this Gaussian
-          const float fac = alpha * Tk[k];
-          p_r += fac * vr[k]; p_g += fac * vg[k]; p_b += fac * vb[k];
-          const float v_al = (cr * Tk[k] - Br[k] * ra) * vr[k] + (cg * Tk[k] - Bg[k] * ra) * vg[k] +
-                             (cb * Tk[k] - Bb[k] * ra) * vb[k] + va[k] * ra;
-          Br[k] += cr * fac; Bg[k] += cg * fac; Bb[k] += cb * fac;
-          const float v_sigma = (ov <= K::kAlphaMax) ? -ov * v_al : 0.f;   // d min(0.999, o*vis) = 0 when clamped
-          p_op += (ov <= K::kAlphaMax) ? vis * v_al : 0.f;
-          const float vsdy = v_sigma * dy;
-          p_cx += v_sigma * hdx2;
-          p_cy += vsdy * dx;
-          p_cz += vsdy * (0.5f * dy);
-          p_x += v_sigma * (cxdx + cy * dy);
-          p_y += v_sigma * (cydx + cz * dy);
-        }
+        vis[k] = __builtin_amdgcn_exp2f(s2);
+        ov[k] = op * vis[k];
+        hit[k] = (idx_j < fin[k]) && (s2 <= 0.f) && (fminf(K::kAlphaMax, ov[k]) >= K::kAlphaMin);
       }
-      if (__ballot(any) != 0ull) {
+      if (__ballot(hit[0] || hit[1] || hit[2] || hit[3]) != 0ull) {
+        const float cx = readlane_f(rec.cx, j), cy = readlane_f(rec.cy, j), cz = readlane_f(rec.cz, j);
+        const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
+        const float hdx2 = 0.5f * dx * dx;
+        const float cxdx = cx * dx, cydx = cy * dx;
+        float p_x = 0.f, p_y = 0.f, p_cx = 0.f, p_cy = 0.f, p_cz = 0.f, p_op = 0.f, p_r = 0.f, p_g = 0.f, p_b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (hit[k]) {
+            const float dy = gy - pyf[k];
+            const float alpha = fminf(K::kAlphaMax, ov[k]);
+            const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+            Tk[k] *= ra;                       // transmittance in front of this Gaussian
+            const float fac = alpha * Tk[k];
+            p_r += fac * vr[k]; p_g += fac * vg[k]; p_b += fac * vb[k];
+            const float cv = cr * vr[k] + cg * vg[k] + cb * vb[k];
+            const float v_al = Tk[k] * cv - ra * Dv[k];
+            Dv[k] += fac * cv;
+            const bool free_ = ov[k] <= K::kAlphaMax;     // d min(0.999, o*vis) = 0 when clamped
+            const float v_sigma = free_ ? -ov[k] * v_al : 0.f;
+            p_op += free_ ? vis[k] * v_al : 0.f;
+            const float vsdy = v_sigma * dy;
+            p_cx += v_sigma * hdx2;
+            p_cy += vsdy * dx;
+            p_cz += vsdy * (0.5f * dy);
+            p_x += v_sigma * (cxdx + cy * dy);
+            p_y += v_sigma * (cydx + cz * dy);
+          }
+        }
         filled |= 1u << g;
         float* r0 = red + g * (9 * kRedStride) + lane;
         r0[0 * kRedStride] = p_x;  r0[1 * kRedStride] = p_y;  r0[2 * kRedStride] = p_cx;
@@ -667,8 +676,11 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, co
       const int y = py0 + k;
       if (px < prm.W && y < prm.H) {
         size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
+        const float Tfin = out_T[pix];
+        const float va_out = v_alpha ? v_alpha[pix] : 0.f;
+        const float va = Tfin * (va_out - (bgr * vr[k] + bgg * vg[k] + bgb * vb[k]));
         bwd_T[pix] = Tk[k];
-        bwd_B[pix * 3 + 0] = Br[k]; bwd_B[pix * 3 + 1] = Bg[k]; bwd_B[pix * 3 + 2] = Bb[k];
+        bwd_B[pix] = Dv[k] + va;       // behind-colour . v_out
       }
     }
   }

@@ -31,6 +31,8 @@ RASTER_BWD_VARIANT = int(os.environ.get("GSD_RASTER_BWD_VARIANT", "0"))
 # depth slicing of the fused path: average tile-list length budget of the first slice (doubling per
 # slice); 0 disables slicing (single pass over all intersections)
 SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "256"))
+# exact ellipse-vs-tile culling of (Gaussian, tile) pairs in the fused path (images unchanged)
+EXACT_TILE_CULL = int(os.environ.get("GSD_EXACT_TILE_CULL", "1"))
 last_slice_intersects = []
 
 
@@ -206,7 +208,7 @@ def bin_and_sort_records(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
         keys = torch.empty(n_isect, dtype=torch.int32, device=dev)
         vals = torch.empty(n_isect, dtype=torch.int32, device=dev)
         _check(L.gs_emit_intersects(n, N, img_height, img_width, _ptr(sorted_gi), _ptr(cum), _ptr(records), n_isect,
-                                    _ptr(keys), _ptr(vals), _stream()), "emit intersects")
+                                    _ptr(keys), _ptr(vals), 0, _stream()), "emit intersects")
     with _stage("tile_sort"):
         skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T))
     with _stage("bin_edges"):
@@ -261,21 +263,26 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     sorted_gi, cum, total = _depth_rank(records, depth_keys, num_tiles_hit, P, N)
     # slice boundaries in depth-rank space: cumulative intersections per sub-pose reach T*slice_base*2^k
     KMAX = 16
-    with _stage("slice_plan"):
-        rel = cum.view(P, N).long()
-        rel = rel - rel[:, :1]
-        tgt = (T * slice_base) * (2 ** torch.arange(KMAX, device=dev, dtype=torch.int64))
-        bounds = torch.searchsorted(rel, tgt[None, :].expand(P, KMAX).contiguous())      # [P,KMAX] first rank >= tgt
-        plan = torch.cat([bounds.reshape(-1), total.long()]).cpu()                       # one host sync
-    n_total = int(plan[-1])
+    if slice_base > 0:
+        with _stage("slice_plan"):
+            rel = cum.view(P, N).long()
+            rel = rel - rel[:, :1]
+            tgt = (T * slice_base) * (2 ** torch.arange(KMAX, device=dev, dtype=torch.int64))
+            bounds = torch.searchsorted(rel, tgt[None, :].expand(P, KMAX).contiguous())  # [P,KMAX] first rank >= tgt
+            plan = torch.cat([bounds.reshape(-1), total.long()]).cpu()                   # one host sync
+        n_total = int(plan[-1])
+        b = plan[:-1].view(P, KMAX).tolist()
+        # number of slices: up to the first k whose boundary reaches N in every sub-pose
+        K = KMAX
+        for k in range(KMAX):
+            if all(b[p][k] >= N for p in range(P)):
+                K = k + 1
+                break
+    else:
+        n_total = int(total.item())
+        b = [[N] for _ in range(P)]
+        K = 1
     last_num_intersects = n_total
-    b = plan[:-1].view(P, KMAX).tolist()
-    # number of slices: up to the first k whose boundary reaches N in every sub-pose
-    K = KMAX
-    for k in range(KMAX):
-        if all(b[p][k] >= N for p in range(P)):
-            K = k + 1
-            break
     begins, prefixes, n_slices = [], [], []
     for k in range(K):
         lo = [0 if k == 0 else min(b[p][k - 1], N) for p in range(P)]
@@ -294,6 +301,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     sat = torch.empty(P * (ty + 1) * (tx + 1), dtype=torch.int32, device=dev)
     slices = []
     last_slice_intersects = []
+    invalid_key = P * T if EXACT_TILE_CULL else 0
     for k in range(K):
         first, last = k == 0, k == K - 1
         n_k = n_slices[k]
@@ -324,16 +332,16 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                 vals = torch.empty(I_k, dtype=torch.int32, device=dev)
                 if first:
                     _check(L.gs_emit_intersects(n_k, N, H, W, _ptr(slice_gi), _ptr(cum_k), _ptr(records), I_k,
-                                                _ptr(keys), _ptr(vals), _stream()), "emit intersects")
+                                                _ptr(keys), _ptr(vals), invalid_key, _stream()), "emit intersects")
                 else:
                     _check(L.gs_emit_open_intersects(n_k, N, H, W, _ptr(slice_gi), _ptr(counts), _ptr(cum_k),
                                                      _ptr(records), _ptr(tile_done), _ptr(keys), _ptr(vals),
-                                                     _stream()), "emit open intersects")
+                                                     invalid_key, _stream()), "emit open intersects")
             with _stage("tile_sort"):
-                skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T))
+                skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T + 1))
             with _stage("bin_edges"):
-                bins = torch.empty(P * T, 2, dtype=torch.int32, device=dev)
-                _check(L.gs_tile_bin_edges_u32(I_k, _ptr(skeys), P * T, _ptr(bins), _stream()), "bin edges")
+                bins = torch.empty(P * T + 1, 2, dtype=torch.int32, device=dev)   # last row: culled pairs
+                _check(L.gs_tile_bin_edges_u32(I_k, _ptr(skeys), P * T + 1, _ptr(bins), _stream()), "bin edges")
         last_slice_intersects.append(I_k)
         if I_k == 0 and not (first or last):
             continue
@@ -359,7 +367,9 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
     L = _L()
     H, W = img_height, img_width
     bwd_T = out_T.clone()
-    bwd_B = torch.zeros(S, H, W, 3, device=records.device)
+    # reverse-traversal state: v2 keeps (behind-colour . v_out) as ONE float per pixel, the DPP
+    # reference kernel keeps the three channels
+    bwd_B = torch.zeros((S, H, W, 3) if RASTER_BWD_VARIANT == 1 else (S, H, W), device=records.device)
     with _stage("raster_bwd"):
         for svals, bins, fidx, _ in reversed(slices):
             _check(L.gs_rasterize_bwd_slice(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
@@ -657,21 +667,12 @@ class _RenderSubposes(Function):
                                           _stream()), "project_fused_fwd")
         bg = _background(background, dev)
         edges = _band_edges(H, R, dev)
-        ctx.sliced = SLICE_BASE > 0
-        if ctx.sliced:
-            out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE)
-            ctx.slices = slices
-            svals = bins = fidx = torch.zeros(1, dtype=torch.int32, device=dev)
-            n_isect = last_num_intersects
-        else:
-            svals, bins, n_isect, _ = bin_and_sort_records(records, dkeys, ntiles, P, N, H, W)
-            out_img = torch.empty(S, H, W, 3, device=dev)
-            out_T = torch.empty(S, H, W, device=dev)
-            fidx = torch.empty(S, H, W, dtype=torch.int32, device=dev)
-            with _stage("raster_fwd"):
-                _check(L.gs_rasterize_fwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
-                                          _ptr(out_img), _ptr(out_T), _ptr(fidx), RASTER_FWD_VARIANT, _stream()),
-                       "rasterize_fwd")
+        # SLICE_BASE == 0: one slice holding every intersection, through the very same kernels
+        ctx.sliced = True
+        out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE)
+        ctx.slices = slices
+        svals = bins = fidx = torch.zeros(1, dtype=torch.int32, device=dev)
+        n_isect = last_num_intersects
         ctx.save_for_backward(means3d, scales, quats, opacities, sh, V, records, svals, bins, edges, bg, out_T, fidx)
         ctx.args = args
         ctx.SR = (S, R)

@@ -116,10 +116,12 @@ int gs_make_depth_keys64(long long n, int N, const unsigned* depth_keys, unsigne
                          void* stream);
 int gs_gather_counts(long long n, const unsigned* sorted_gi, const int* num_tiles_hit,
                      unsigned* counts_out, void* stream);
-/* keys[e] = p*T + tile, vals[e] = p*N + g, emitted in depth-rank order */
+/* keys[e] = p*T + tile, vals[e] = p*N + g, emitted in depth-rank order.  invalid_key != 0 enables exact
+ * tile culling: a (Gaussian, tile) pair whose pixel-centre rectangle lies outside the alpha >= 1/255
+ * ellipse gets key = invalid_key (pass S*R*T: it sorts behind every real tile and is never composited) */
 int gs_emit_intersects(long long n_ranked, int N, int img_height, int img_width, const unsigned* sorted_gi,
                        const unsigned* cum_excl, const float* records, long long n_isect, unsigned* keys,
-                       unsigned* vals, void* stream);
+                       unsigned* vals, unsigned invalid_key, void* stream);
 int gs_tile_bin_edges_u32(long long n, const unsigned* sorted_keys, int num_bins, int* bins /*num_bins*2*/,
                           void* stream);
 int gs_tile_bin_edges_u64(long long n, const unsigned long long* sorted_isect_ids, int num_bins,
@@ -158,7 +160,8 @@ int gs_slice_counts(int n_slice, int P, int N, const int* slice_begin /*P*/, con
                     int img_width, unsigned* slice_gi, unsigned* counts, void* stream);
 int gs_emit_open_intersects(int n_slice, int N, int img_height, int img_width, const unsigned* slice_gi,
                             const unsigned* counts, const unsigned* cum_excl, const float* records,
-                            const unsigned char* tile_done, unsigned* keys, unsigned* vals, void* stream);
+                            const unsigned char* tile_done, unsigned* keys, unsigned* vals,
+                            unsigned invalid_key, void* stream);
 /* one launch per slice, front to back; out_img/out_T/live_T carry per-pixel state, tile_done is zeroed
  * by the caller before the first slice; first && last == the unsliced pass; final_idx is per slice */
 int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
@@ -166,7 +169,8 @@ int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const i
                            int img_width, float* out_img, float* out_T, float* live_T, int* final_idx,
                            unsigned char* tile_done, int first, int last,
                            int variant /*0 = default (skips pairs that touch no pixel); 1 = no skip*/, void* stream);
-/* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B [S,H,W,3] (init = 0) carry state */
+/* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B (init = 0) carry state:
+ * bwd_B is [S,H,W] for the default kernel (behind-colour . v_out), [S,H,W,3] for variant 1 */
 int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                            const int* band_edges, const float* background, int S, int R, int img_height,
                            int img_width, const float* out_T, const int* final_idx, const float* v_img,

@@ -378,6 +378,32 @@ def test_depth_sliced_equals_single_pass(gs, oracle, dev, S, R, base):
         assert rel_max(res["sliced"][2][k].cpu(), res["single"][2][k].cpu()) < 1e-4, k
 
 
+def test_exact_tile_culling_changes_nothing(gs, oracle, dev):
+    """Culling (Gaussian, tile) pairs whose pixel rectangle lies outside the alpha >= 1/255 ellipse must
+    leave the image BIT-IDENTICAL (the pairs contributed exactly nothing) and the gradients equal up to
+    atomic reordering."""
+    from gsdeblur_amd import ops
+    O = oracle
+    W, H, n = 240, 176, 8000
+    sc = O.synthetic_scene(n, W, H, seed=123, scale_mult=6.0)
+    sc["log_scales"] = sc["log_scales"] + torch.tensor([0.9, -0.9, 0.0])        # needle-like Gaussians
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(4))
+    res = {}
+    old = ops.EXACT_TILE_CULL
+    try:
+        for cull in (0, 1):
+            ops.EXACT_TILE_CULL = cull
+            out, alpha, samples, vms, p, radii = _run_full(gs, O, dev, sc, H, W, 2, 2, 1 / 60, 1 / 30, 2.2, 10.0, 3, bg, wt)
+            res[cull] = (samples.detach().clone(), alpha.detach().clone(),
+                         {k: v.grad.detach().clone() for k, v in p.items()})
+    finally:
+        ops.EXACT_TILE_CULL = old
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in res[0][2]:
+        assert rel_max(res[1][2][k].cpu(), res[0][2][k].cpu()) < 1e-4, k
+
+
 # --------------------------------------------------------------------------- #
 # size-independent properties at larger sizes (no oracle run needed)
 # --------------------------------------------------------------------------- #
