@@ -379,10 +379,26 @@ __device__ __forceinline__ bool tile_hit(const Ellipse& e, int tx, int ty, int W
   return m <= e.tau * 1.001f + 1e-3f;
 }
 
-// One block expands 256 consecutive depth-ranked Gaussians; the block's output range is
-// contiguous and every thread writes consecutive entries (coalesced).  The source Gaussian of an
-// entry is found by a branch-free 8-step binary search in the block's LDS scan; tile coordinates
-// come from a float reciprocal (exact for rem < 2^16, w <= tiles_x) instead of integer division.
+// Entry-parallel emission: a block owns kEmitChunk consecutive OUTPUT entries (so the grid scales with
+// the number of intersections, not the number of Gaussians: the nearest 50k Gaussians of a slice can own
+// 20M entries).  The block locates the Gaussians that cover its chunk with two binary searches in the
+// exclusive scan, stages up to 256 of them in LDS, and every thread then finds the source Gaussian of
+// its entries with a branch-free LDS search; tile coordinates come from a float reciprocal (exact for
+// rem < 2^16) instead of integer division.  Chunks spanning more than 256 Gaussians walk them in
+// windows.  Writes are perfectly coalesced.
+constexpr int kEmitItems = 16;
+constexpr int kEmitChunk = 256 * kEmitItems;
+
+// last rank r in [0,n) with cum[r] <= e
+__device__ __forceinline__ unsigned rank_of_entry(const unsigned* __restrict__ cum, unsigned n, unsigned e) {
+  unsigned lo = 0, hi = n - 1;
+  while (lo < hi) {
+    unsigned mid = (lo + hi + 1) >> 1;
+    if (cum[mid] <= e) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 __global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T, int tiles_x,
                                                    const unsigned* __restrict__ sorted_gi,
                                                    const unsigned* __restrict__ cum,   // exclusive, in rank order
@@ -391,53 +407,69 @@ __global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T
                                                    int W, int H, unsigned invalid_key /*0: no exact culling*/) {
   __shared__ unsigned s_cum[257];
   __shared__ unsigned s_gi[256];
-  __shared__ unsigned s_kbase[256];   // p*T + y0*tiles_x + x0
+  __shared__ unsigned s_kbase[256];   // p*T
   __shared__ unsigned s_w[256];
   __shared__ unsigned s_xy0[256];
   __shared__ float s_rw[256];
-  __shared__ Ellipse s_el[256];
-  size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-  unsigned gi = 0, c = 0, kbase = 0, w = 1, xy0 = 0;
-  Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f};
-  if (r < n_ranked) {
-    gi = sorted_gi[r];
-    c = cum[r];
-    const float* rec = records + (size_t)gi * kRecFloats;
-    unsigned lo = (unsigned)__float_as_int(rec[10]);
-    unsigned hi = (unsigned)__float_as_int(rec[11]);
-    unsigned x0 = lo & 0xFFFFu, y0 = lo >> 16, x1 = hi & 0xFFFFu;
-    w = x1 > x0 ? x1 - x0 : 1u;
-    xy0 = lo;
-    kbase = (gi / (unsigned)N) * (unsigned)T;
-    if (invalid_key) el = make_ellipse(rec);
-  }
-  s_gi[threadIdx.x] = gi; s_kbase[threadIdx.x] = kbase; s_w[threadIdx.x] = w; s_rw[threadIdx.x] = 1.0f / (float)w;
-  s_xy0[threadIdx.x] = xy0; s_el[threadIdx.x] = el;
-  s_cum[threadIdx.x] = c;
-  size_t r_last = (size_t)blockIdx.x * 256 + 256;
-  if (threadIdx.x == 0) s_cum[256] = r_last < n_ranked ? cum[r_last] : (unsigned)n_isect;
+  __shared__ float s_gx[256], s_gy[256], s_a[256], s_b[256], s_c[256], s_tau[256];
+  __shared__ unsigned s_rng[2];
+  const unsigned e_begin = blockIdx.x * (unsigned)kEmitChunk;
+  const unsigned e_end = (unsigned)min((size_t)e_begin + kEmitChunk, n_isect);
+  if (threadIdx.x < 2)
+    s_rng[threadIdx.x] = rank_of_entry(cum, (unsigned)n_ranked, threadIdx.x == 0 ? e_begin : e_end - 1);
   __syncthreads();
-  const unsigned first = s_cum[0];
-  const unsigned last = s_cum[256];
-  const int n_live = (int)min((size_t)256, n_ranked - (size_t)blockIdx.x * 256);
-  for (unsigned e = first + threadIdx.x; e < last; e += 256) {
-    // largest a in [0,n_live) with s_cum[a] <= e  (zero-count Gaussians share a cum and are skipped)
-    int a = 0;
-#pragma unroll
-    for (int step = 128; step > 0; step >>= 1) {
-      int m = a + step;
-      if (m < n_live && s_cum[m] <= e) a = m;
+  const unsigned g_lo = s_rng[0], g_hi = s_rng[1];
+  for (unsigned wbase = g_lo; wbase <= g_hi; wbase += 256) {
+    const unsigned r = wbase + threadIdx.x;
+    unsigned gi = 0, c = 0xFFFFFFFFu, kbase = 0, w = 1, xy0 = 0;
+    Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f};
+    if (r <= g_hi) {
+      gi = sorted_gi[r];
+      c = cum[r];
+      const float* rec = records + (size_t)gi * kRecFloats;
+      unsigned lo = (unsigned)__float_as_int(rec[10]);
+      unsigned hi = (unsigned)__float_as_int(rec[11]);
+      unsigned x0 = lo & 0xFFFFu, x1 = hi & 0xFFFFu;
+      w = x1 > x0 ? x1 - x0 : 1u;
+      xy0 = lo;
+      kbase = (gi / (unsigned)N) * (unsigned)T;
+      if (invalid_key) el = make_ellipse(rec);
     }
-    unsigned rem = e - s_cum[a];
-    unsigned wa = s_w[a];
-    unsigned q = (unsigned)(((float)rem + 0.5f) * s_rw[a]);
-    unsigned x = rem - q * wa;
-    const unsigned xy = s_xy0[a];
-    const int tx = (int)((xy & 0xFFFFu) + x), ty = (int)((xy >> 16) + q);
-    unsigned key = s_kbase[a] + (unsigned)(ty * tiles_x + tx);
-    if (invalid_key && !tile_hit(s_el[a], tx, ty, W, H)) key = invalid_key;
-    keys[e] = key;
-    vals[e] = s_gi[a];
+    __syncthreads();     // previous window fully consumed
+    s_gi[threadIdx.x] = gi; s_kbase[threadIdx.x] = kbase; s_w[threadIdx.x] = w; s_rw[threadIdx.x] = 1.0f / (float)w;
+    s_xy0[threadIdx.x] = xy0; s_cum[threadIdx.x] = c;
+    s_gx[threadIdx.x] = el.gx; s_gy[threadIdx.x] = el.gy; s_a[threadIdx.x] = el.a; s_b[threadIdx.x] = el.b;
+    s_c[threadIdx.x] = el.c; s_tau[threadIdx.x] = el.tau;
+    if (threadIdx.x == 0) {
+      unsigned nxt = wbase + 256;
+      s_cum[256] = nxt <= g_hi ? cum[nxt] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    // entries of this chunk that belong to the window: [max(e_begin, cum[wbase]), min(e_end, cum[wbase+256]))
+    const unsigned w_first = max(e_begin, s_cum[0]);
+    const unsigned w_last = min(e_end, s_cum[256]);
+    for (unsigned e = w_first + threadIdx.x; e < w_last; e += 256) {
+      int a = 0;
+#pragma unroll
+      for (int step = 128; step > 0; step >>= 1) {
+        int m = a + step;
+        if (s_cum[m] <= e) a = m;          // padded slots hold 0xFFFFFFFF and are never selected
+      }
+      unsigned rem = e - s_cum[a];
+      unsigned wa = s_w[a];
+      unsigned q = (unsigned)(((float)rem + 0.5f) * s_rw[a]);
+      unsigned x = rem - q * wa;
+      const unsigned xy = s_xy0[a];
+      const int tx = (int)((xy & 0xFFFFu) + x), ty = (int)((xy >> 16) + q);
+      unsigned key = s_kbase[a] + (unsigned)(ty * tiles_x + tx);
+      if (invalid_key) {
+        Ellipse el2;
+        el2.gx = s_gx[a]; el2.gy = s_gy[a]; el2.a = s_a[a]; el2.b = s_b[a]; el2.c = s_c[a]; el2.tau = s_tau[a];
+        if (!tile_hit(el2, tx, ty, W, H)) key = invalid_key;
+      }
+      keys[e] = key;
+      vals[e] = s_gi[a];
+    }
   }
 }
 
@@ -693,9 +725,9 @@ GS_EXPORT int gs_emit_intersects(long long n_ranked, int N, int H, int W, const 
   if (n_ranked <= 0 || N <= 0) return GS_ERR_INVALID;
   if (n_isect <= 0) return GS_OK;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
-  hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((n_ranked + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (size_t)n_ranked, N, tiles_x * tiles_y, tiles_x, sorted_gi, cum_excl, records, (size_t)n_isect,
-                     keys, vals, W, H, invalid_key);
+  hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((n_isect + kEmitChunk - 1) / kEmitChunk)), dim3(256), 0,
+                     (hipStream_t)stream, (size_t)n_ranked, N, tiles_x * tiles_y, tiles_x, sorted_gi, cum_excl, records,
+                     (size_t)n_isect, keys, vals, W, H, invalid_key);
   return gs_launch_status();
 }
 

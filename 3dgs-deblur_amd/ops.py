@@ -30,7 +30,7 @@ RASTER_FWD_VARIANT = int(os.environ.get("GSD_RASTER_FWD_VARIANT", "0"))
 RASTER_BWD_VARIANT = int(os.environ.get("GSD_RASTER_BWD_VARIANT", "0"))
 # depth slicing of the fused path: average tile-list length budget of the first slice (doubling per
 # slice); 0 disables slicing (single pass over all intersections)
-SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "256"))
+SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "512"))
 # exact ellipse-vs-tile culling of (Gaussian, tile) pairs in the fused path (images unchanged)
 EXACT_TILE_CULL = int(os.environ.get("GSD_EXACT_TILE_CULL", "1"))
 last_slice_intersects = []
