@@ -23,7 +23,9 @@ namespace gs {
 
 struct RasterParams {
   const float* records;      // [P*N, 12]
-  const int*   sorted_vals;  // [I]   p*N+g, sorted by (p*T+tile, depth)
+  const int*   sorted_vals;  // [I]   p*N+g sorted by (p*T+tile, depth) -- or, when gi_of_e != null, the
+                             //       EMISSION index e of each sorted entry (p*N+g = gi_of_e[e])
+  const int*   gi_of_e;      // [I]   nullable
   const int2*  tile_bins;    // [P*T]
   const int*   band_edges;   // [R+1] tile-row edges of the rolling-shutter bands
   const float* background;   // [3]
@@ -286,16 +288,23 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
     }
   }
   const int* __restrict__ vals = prm.sorted_vals;
-  int id_next = (range.x + lane) < range.y ? vals[range.x + lane] : 0;
-  Rec9 rec_next = load_rec(prm.records, id_next, (range.x + lane) < range.y);
-  id_next = (range.x + 64 + lane) < range.y ? vals[range.x + 64 + lane] : 0;
+  const int* __restrict__ gi_of_e = prm.gi_of_e;
+  // software pipeline over batches of 64 sorted entries: entry ids 3 batches ahead, Gaussian ids 2
+  // ahead (one more dependent gather when the list stores emission indices), records 1 ahead
+  auto load_id = [&](int i) -> int { return i < range.y ? vals[i] : 0; };
+  auto to_gi = [&](int id, int i) -> int { return (gi_of_e && i < range.y) ? gi_of_e[id] : id; };
+  int gi_next = to_gi(load_id(range.x + lane), range.x + lane);
+  Rec9 rec_next = load_rec(prm.records, gi_next, (range.x + lane) < range.y);
+  gi_next = to_gi(load_id(range.x + 64 + lane), range.x + 64 + lane);
+  int id_next = load_id(range.x + 128 + lane);
   const float kL2E = -1.4426950408889634f;
 
   for (int batch = range.x; batch < range.y; batch += 64) {
     if (__ballot(fmaxf(fmaxf(Tk[0], Tk[1]), fmaxf(Tk[2], Tk[3])) > 0.f) == 0ull) break;
     Rec9 rec = rec_next;
-    rec_next = load_rec(prm.records, id_next, (batch + 64 + lane) < range.y);
-    id_next = (batch + 128 + lane) < range.y ? vals[batch + 128 + lane] : 0;
+    rec_next = load_rec(prm.records, gi_next, (batch + 64 + lane) < range.y);
+    gi_next = to_gi(id_next, batch + 128 + lane);
+    id_next = load_id(batch + 192 + lane);
     rec.cx *= 0.5f * kL2E; rec.cy *= kL2E; rec.cz *= 0.5f * kL2E;
     const int n = min(64, range.y - batch);
     for (int j = 0; j < n; ++j) {
@@ -506,13 +515,19 @@ constexpr int kRedG = 4;                    // Gaussians per transposed-reductio
 constexpr int kRedStride = 68;              // floats per row (64 + 4: 16-byte aligned, b128 conflict-free)
 constexpr int kRedFloats = kRedG * 9 * kRedStride + 64 * 9;
 
-template <bool STATE, bool ABLATE_ATOMICS>
+// OUT = 0: 9 fp32 atomics per (Gaussian, tile) into v_records;  OUT = 2: timing ablation (plain stores);
+// OUT = 1: no atomics at all — the entry's 9 gradients go to tuples[e] (48 B, e = emission index of the
+// entry, so the tuples of one Gaussian are CONTIGUOUS) and flags[e] = 1; gs_reduce_grad_tuples then sums
+// each Gaussian's segment.  At ~20 G atomic ops/s the atomics were 40 % of this kernel.
+template <bool STATE, int OUT>
 __global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, const float* __restrict__ out_T,
                                                             const int* __restrict__ final_idx,
                                                             const float* __restrict__ v_img,
                                                             const float* __restrict__ v_alpha,  // may be null
                                                             float* __restrict__ v_records, unsigned n_blocks,
-                                                            float* __restrict__ bwd_T, float* __restrict__ bwd_B) {
+                                                            float* __restrict__ bwd_T, float* __restrict__ bwd_B,
+                                                            float* __restrict__ tuples,
+                                                            unsigned char* __restrict__ flags) {
   __shared__ __attribute__((aligned(16))) float lds_all[4 * kRedFloats];
   const int lane = lane_id();
   float* red = lds_all + (threadIdx.x >> 6) * kRedFloats;   // wave-private
@@ -570,7 +585,8 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, co
   for (int batch_end = wave_end; batch_end > range.x; batch_end -= 64) {
     const int idx = batch_end - 1 - lane;
     const bool valid = idx >= range.x;
-    const int gid = valid ? vals[idx] : 0;
+    const int eid = valid ? vals[idx] : 0;
+    const int gid = (valid && prm.gi_of_e) ? prm.gi_of_e[eid] : eid;
     const Rec9 rec = load_rec(prm.records, gid, valid);
     const float sx = rec.cx * (0.5f * kL2E), sy = rec.cy * kL2E, sz = rec.cz * (0.5f * kL2E);
 #pragma unroll
@@ -657,14 +673,27 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, co
     }
     __builtin_amdgcn_wave_barrier();
     if (valid) {
-      float* dst = v_records + (size_t)gid * kRecFloats;
+      float a[9];
+      bool nz = false;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        const float a = tot[lane * 9 + c];
-        if (ABLATE_ATOMICS) {            // timing experiment only (wrong gradients): plain stores
-          if (a != 0.f) dst[c] = a;
-        } else if (a != 0.f) {
-          atomic_add_f32(dst + c, a);
+      for (int c = 0; c < 9; ++c) { a[c] = tot[lane * 9 + c]; nz |= a[c] != 0.f; }
+      if (OUT == 1) {
+        if (nz) {
+          float4* dst = reinterpret_cast<float4*>(tuples + (size_t)eid * kRecFloats);
+          dst[0] = make_float4(a[0], a[1], a[2], a[3]);
+          dst[1] = make_float4(a[4], a[5], a[6], a[7]);
+          dst[2] = make_float4(a[8], 0.f, 0.f, 0.f);
+          flags[eid] = 1;
+        }
+      } else {
+        float* dst = v_records + (size_t)gid * kRecFloats;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+          if (OUT == 2) {                  // timing experiment only (wrong gradients): plain stores
+            if (a[c] != 0.f) dst[c] = a[c];
+          } else if (a[c] != 0.f) {
+            atomic_add_f32(dst + c, a[c]);
+          }
         }
       }
     }
@@ -683,6 +712,75 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, co
         bwd_B[pix] = Dv[k] + va;       // behind-colour . v_out
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Segmented sum of the gradient tuples of one depth slice.  The tuples of slice Gaussian j occupy
+// [cum[j], cum[j]+counts[j]) (emission order); flags mark the entries the backward actually touched.
+// A wave owns 64 Gaussians: short segments are summed by their own lane, long ones (near Gaussians
+// cover hundreds of tiles) by the whole wave with one DPP reduction per component.  Every Gaussian
+// belongs to exactly one slice, so the result is a plain store into v_records — no atomics anywhere.
+// ---------------------------------------------------------------------------
+constexpr unsigned kReduceSolo = 16;
+
+__global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const unsigned* __restrict__ slice_gi,
+                                                            const unsigned* __restrict__ counts,
+                                                            const unsigned* __restrict__ cum,
+                                                            const float* __restrict__ tuples,
+                                                            const unsigned char* __restrict__ flags,
+                                                            float* __restrict__ v_records) {
+  const int lane = lane_id();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  unsigned cnt = 0, e0 = 0, gi = 0;
+  if (j < n_slice) { cnt = counts[j]; e0 = cum[j]; gi = slice_gi[j]; }
+  float acc[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) acc[c] = 0.f;
+  bool any = false;
+  if (cnt && cnt <= kReduceSolo) {
+    for (unsigned i = 0; i < cnt; ++i) {
+      if (flags[e0 + i]) {
+        const float4* t = reinterpret_cast<const float4*>(tuples + (size_t)(e0 + i) * kRecFloats);
+        float4 a = t[0], b = t[1], c = t[2];
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w; acc[8] += c.x;
+        any = true;
+      }
+    }
+  }
+  unsigned long long big = __ballot(cnt > kReduceSolo);
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const unsigned c_n = (unsigned)readlane_i((int)cnt, src), c_e = (unsigned)readlane_i((int)e0, src);
+    float part[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) part[c] = 0.f;
+    bool hit = false;
+    for (unsigned i = lane; i < c_n; i += 64) {
+      if (flags[c_e + i]) {
+        const float4* t = reinterpret_cast<const float4*>(tuples + (size_t)(c_e + i) * kRecFloats);
+        float4 a = t[0], b = t[1], c = t[2];
+        part[0] += a.x; part[1] += a.y; part[2] += a.z; part[3] += a.w;
+        part[4] += b.x; part[5] += b.y; part[6] += b.z; part[7] += b.w; part[8] += c.x;
+        hit = true;
+      }
+    }
+    if (__ballot(hit) != 0ull) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const float tsum = wave_sum_uniform(part[c]);
+        if (lane == src) acc[c] = tsum;
+      }
+      if (lane == src) any = true;
+    }
+  }
+  if (any) {
+    float4* dst = reinterpret_cast<float4*>(v_records + (size_t)gi * kRecFloats);
+    dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    dst[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
   }
 }
 
@@ -775,7 +873,8 @@ GS_EXPORT int gs_rasterize_fwd(const float* records, const int* sorted_vals, con
                                float* out_img, float* out_T, int* final_idx, int variant, void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm;
-  prm.records = records; prm.sorted_vals = sorted_vals; prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
+  prm.records = records; prm.sorted_vals = sorted_vals; prm.gi_of_e = nullptr;
+  prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
   prm.band_edges = band_edges; prm.background = background;
   prm.S = S; prm.R = R; prm.H = H; prm.W = W;
   prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
@@ -798,7 +897,8 @@ GS_EXPORT int gs_rasterize_bwd(const float* records, const int* sorted_vals, con
                                float* v_records, void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm;
-  prm.records = records; prm.sorted_vals = sorted_vals; prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
+  prm.records = records; prm.sorted_vals = sorted_vals; prm.gi_of_e = nullptr;
+  prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
   prm.band_edges = band_edges; prm.background = background;
   prm.S = S; prm.R = R; prm.H = H; prm.W = W;
   prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
@@ -817,13 +917,16 @@ GS_EXPORT int gs_rasterize_bwd(const float* records, const int* sorted_vals, con
 GS_EXPORT int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                                      const int* band_edges, const float* background, int S, int R, int H, int W,
                                      float* out_img, float* out_T, float* live_T, int* final_idx,
-                                     unsigned char* tile_done, int first, int last, int variant, void* stream) {
+                                     unsigned char* tile_done, int first, int last, const int* gi_of_e, int variant,
+                                     void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm;
-  prm.records = records; prm.sorted_vals = sorted_vals; prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
+  prm.records = records; prm.sorted_vals = sorted_vals; prm.gi_of_e = nullptr;
+  prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
   prm.band_edges = band_edges; prm.background = background;
   prm.S = S; prm.R = R; prm.H = H; prm.W = W;
   prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
+  prm.gi_of_e = gi_of_e;
   SliceState st; st.tile_done = tile_done; st.live_T = live_T; st.first = first; st.last = last;
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
@@ -842,24 +945,44 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
                                      const int* band_edges, const float* background, int S, int R, int H, int W,
                                      const float* out_T, const int* final_idx, const float* v_img,
                                      const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records,
-                                     int variant, void* stream) {
+                                     const int* gi_of_e, float* tuples, unsigned char* flags, int variant,
+                                     void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm;
-  prm.records = records; prm.sorted_vals = sorted_vals; prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
+  prm.records = records; prm.sorted_vals = sorted_vals; prm.gi_of_e = nullptr;
+  prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
   prm.band_edges = band_edges; prm.background = background;
   prm.S = S; prm.R = R; prm.H = H; prm.W = W;
   prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
-  if (variant == 1)
-    hipLaunchKernelGGL(raster_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T,
-                       final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B);
-  else if (variant == 2)   // ablation: no atomics (timing experiments only)
-    hipLaunchKernelGGL((raster_bwd_kernel_v2<true, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm,
-                       out_T, final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B);
-  else
-    hipLaunchKernelGGL((raster_bwd_kernel_v2<true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm,
-                       out_T, final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B);
+  prm.gi_of_e = gi_of_e;
+  hipStream_t st = (hipStream_t)stream;
+  if (variant == 1) {          // DPP reference kernel (atomics); needs plain Gaussian ids in the list
+    if (gi_of_e) return GS_ERR_INVALID;
+    hipLaunchKernelGGL(raster_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx, v_img, v_alpha,
+                       v_records, blocks, bwd_T, bwd_B);
+  } else if (variant == 2) {   // ablation: no atomics (timing experiments only)
+    hipLaunchKernelGGL((raster_bwd_kernel_v2<true, 2>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx, v_img,
+                       v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);
+  } else if (tuples && flags && gi_of_e) {
+    hipLaunchKernelGGL((raster_bwd_kernel_v2<true, 1>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx, v_img,
+                       v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);
+  } else {
+    hipLaunchKernelGGL((raster_bwd_kernel_v2<true, 0>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx, v_img,
+                       v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);
+  }
+  return gs_launch_status();
+}
+
+// Sum each slice Gaussian's gradient tuples (written by gs_rasterize_bwd_slice with tuples != NULL) into
+// v_records[slice_gi[j]] (plain stores; Gaussians without a touched entry are left as they are).
+GS_EXPORT int gs_reduce_grad_tuples(int n_slice, const unsigned* slice_gi, const unsigned* counts,
+                                    const unsigned* cum_excl, const float* tuples, const unsigned char* flags,
+                                    float* v_records, void* stream) {
+  if (n_slice <= 0) return GS_ERR_INVALID;
+  hipLaunchKernelGGL(reduce_tuples_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice,
+                     slice_gi, counts, cum_excl, tuples, flags, v_records);
   return gs_launch_status();
 }
 

@@ -33,6 +33,8 @@ RASTER_BWD_VARIANT = int(os.environ.get("GSD_RASTER_BWD_VARIANT", "0"))
 SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "512"))
 # exact ellipse-vs-tile culling of (Gaussian, tile) pairs in the fused path (images unchanged)
 EXACT_TILE_CULL = int(os.environ.get("GSD_EXACT_TILE_CULL", "1"))
+# atomic-free backward: per-entry gradient tuples + segmented reduce (0 = fp32 atomics into v_records)
+GRAD_TUPLES = int(os.environ.get("GSD_GRAD_TUPLES", "1"))
 last_slice_intersects = []
 
 
@@ -302,6 +304,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     slices = []
     last_slice_intersects = []
     invalid_key = P * T if EXACT_TILE_CULL else 0
+    use_tuples = bool(GRAD_TUPLES) and RASTER_BWD_VARIANT != 1
     for k in range(K):
         first, last = k == 0, k == K - 1
         n_k = n_slices[k]
@@ -338,7 +341,11 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                                      _ptr(records), _ptr(tile_done), _ptr(keys), _ptr(vals),
                                                      invalid_key, _stream()), "emit open intersects")
             with _stage("tile_sort"):
-                skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T + 1))
+                if use_tuples:
+                    # payload = emission index e (iota); the Gaussian id of a sorted entry is vals[e]
+                    skeys, svals = radix_sort_pairs(keys, None, 0, _bits(P * T + 1))
+                else:
+                    skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T + 1))
             with _stage("bin_edges"):
                 bins = torch.empty(P * T + 1, 2, dtype=torch.int32, device=dev)   # last row: culled pairs
                 _check(L.gs_tile_bin_edges_u32(I_k, _ptr(skeys), P * T + 1, _ptr(bins), _stream()), "bin edges")
@@ -352,10 +359,11 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         with _stage("raster_fwd"):
             _check(L.gs_rasterize_fwd_slice(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
                                             _ptr(out_img), _ptr(out_T), _ptr(live_T), _ptr(fidx), _ptr(tile_done),
-                                            int(first), int(last), RASTER_FWD_VARIANT, _stream()),
-                   "rasterize_fwd_slice")
+                                            int(first), int(last), _ptr(vals) if (use_tuples and I_k > 0) else None,
+                                            RASTER_FWD_VARIANT, _stream()), "rasterize_fwd_slice")
         if I_k > 0:
-            slices.append((svals, bins, fidx, I_k))
+            slices.append(dict(svals=svals, bins=bins, fidx=fidx, I=I_k, gi_of_e=vals if use_tuples else None,
+                               slice_gi=slice_gi, counts=counts, cum=cum_k, n=n_k))
         if not last:
             with _stage("slice_sat"):
                 _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _stream()), "tile_open_sat")
@@ -370,12 +378,23 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
     # reverse-traversal state: v2 keeps (behind-colour . v_out) as ONE float per pixel, the DPP
     # reference kernel keeps the three channels
     bwd_B = torch.zeros((S, H, W, 3) if RASTER_BWD_VARIANT == 1 else (S, H, W), device=records.device)
-    with _stage("raster_bwd"):
-        for svals, bins, fidx, _ in reversed(slices):
-            _check(L.gs_rasterize_bwd_slice(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
-                                            _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_alpha), _ptr(bwd_T),
-                                            _ptr(bwd_B), _ptr(v_records), RASTER_BWD_VARIANT, _stream()),
+    dev = records.device
+    for sl in reversed(slices):
+        tuples = flags = None
+        if sl["gi_of_e"] is not None:
+            tuples = torch.empty(sl["I"] * REC, device=dev)
+            flags = torch.zeros(sl["I"], dtype=torch.uint8, device=dev)
+        with _stage("raster_bwd"):
+            _check(L.gs_rasterize_bwd_slice(_ptr(records), _ptr(sl["svals"]), _ptr(sl["bins"]), _ptr(edges), _ptr(bg),
+                                            S, R, H, W, _ptr(out_T), _ptr(sl["fidx"]), _ptr(v_img), _ptr(v_alpha),
+                                            _ptr(bwd_T), _ptr(bwd_B), _ptr(v_records), _ptr(sl["gi_of_e"]),
+                                            _ptr(tuples), _ptr(flags), RASTER_BWD_VARIANT, _stream()),
                    "rasterize_bwd_slice")
+        if tuples is not None:
+            with _stage("grad_reduce"):
+                _check(L.gs_reduce_grad_tuples(sl["n"], _ptr(sl["slice_gi"]), _ptr(sl["counts"]), _ptr(sl["cum"]),
+                                               _ptr(tuples), _ptr(flags), _ptr(v_records), _stream()),
+                       "reduce_grad_tuples")
 
 
 # --------------------------------------------------------------------------- #

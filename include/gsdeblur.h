@@ -168,6 +168,8 @@ int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const i
                            const int* band_edges, const float* background, int S, int R, int img_height,
                            int img_width, float* out_img, float* out_T, float* live_T, int* final_idx,
                            unsigned char* tile_done, int first, int last,
+                           const int* gi_of_e /*NULL: sorted_vals are Gaussian ids; else sorted_vals are emission
+                                                indices e and the Gaussian id is gi_of_e[e]*/,
                            int variant /*0 = default (skips pairs that touch no pixel); 1 = no skip*/, void* stream);
 /* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B (init = 0) carry state:
  * bwd_B is [S,H,W] for the default kernel (behind-colour . v_out), [S,H,W,3] for variant 1 */
@@ -175,8 +177,18 @@ int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const i
                            const int* band_edges, const float* background, int S, int R, int img_height,
                            int img_width, const float* out_T, const int* final_idx, const float* v_img,
                            const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records,
+                           const int* gi_of_e /*as in the forward*/,
+                           float* tuples /*[I*12] or NULL*/, unsigned char* flags /*[I], zeroed, or NULL*/,
                            int variant /*0 = default (LDS-transposed reduction); 1 = DPP reference kernel; 2 = timing ablation, no atomics (wrong gradients)*/,
                            void* stream);
+
+/* Atomic-free gradient accumulation: with gi_of_e, tuples and flags given, gs_rasterize_bwd_slice writes the 9
+ * gradients of sorted entry i to tuples[e*12..] (e = sorted_vals[i]) and sets flags[e]; the tuples of slice
+ * Gaussian j are the contiguous range [cum_excl[j], cum_excl[j]+counts[j]) and this call sums them into
+ * v_records[slice_gi[j]] with plain stores (each Gaussian belongs to exactly one slice). */
+int gs_reduce_grad_tuples(int n_slice, const unsigned* slice_gi, const unsigned* counts,
+                          const unsigned* cum_excl, const float* tuples, const unsigned char* flags,
+                          float* v_records, void* stream);
 
 /* ---- sub-frame averaging in linearised colour (flags train.py:60,62) ---------
  * out = ( mean_k max(C_k, min_level)^gamma )^(1/gamma); n = H*W*3 values per sample. */

@@ -378,6 +378,30 @@ def test_depth_sliced_equals_single_pass(gs, oracle, dev, S, R, base):
         assert rel_max(res["sliced"][2][k].cpu(), res["single"][2][k].cpu()) < 1e-4, k
 
 
+def test_tuple_backward_equals_atomic_backward(gs, oracle, dev):
+    """The atomic-free backward (per-entry gradient tuples + segmented reduce) and the fp32-atomics backward
+    compute the same sums; only the summation order differs."""
+    from gsdeblur_amd import ops
+    O = oracle
+    W, H, n = 200, 152, 7000
+    sc = O.synthetic_scene(n, W, H, seed=55, scale_mult=7.0)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10
+    bg = torch.tensor([0.1, 0.3, 0.2])
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(6))
+    res = {}
+    old = (ops.GRAD_TUPLES, ops.SLICE_BASE)
+    try:
+        for tup in (0, 1):
+            ops.GRAD_TUPLES, ops.SLICE_BASE = tup, 8          # several slices, some with holes
+            out, alpha, samples, vms, p, radii = _run_full(gs, O, dev, sc, H, W, 2, 2, 1 / 60, 1 / 30, 2.2, 10.0, 3, bg, wt)
+            res[tup] = (samples.detach().clone(), {k: v.grad.detach().clone() for k, v in p.items()})
+    finally:
+        ops.GRAD_TUPLES, ops.SLICE_BASE = old
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert rel_max(res[1][1][k].cpu(), res[0][1][k].cpu()) < 1e-4, k
+
+
 def test_exact_tile_culling_changes_nothing(gs, oracle, dev):
     """Culling (Gaussian, tile) pairs whose pixel rectangle lies outside the alpha >= 1/255 ellipse must
     leave the image BIT-IDENTICAL (the pairs contributed exactly nothing) and the gradients equal up to

@@ -20,14 +20,14 @@ if [ "$MODE" = "full" ]; then
   echo "== atomic microbench ==" | tee -a $OUT/summary.log
   (hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -Wno-unused-value tools/atomic_bench.hip -o /tmp/atomic_bench && timeout 120 /tmp/atomic_bench) 2>&1 | tail -12 | tee -a $OUT/summary.log
 fi
-echo "== bench A/B: GSD_SLICE_BASE / GSD_RASTER_BWD_VARIANT (2 = no-atomics ablation, 1 = DPP reference) ==" | tee -a $OUT/summary.log
-for cfg in "512 0" "512 2" "512 1" "768 0" "512 0" "512 2"; do
+echo "== bench A/B: GSD_SLICE_BASE / GSD_GRAD_TUPLES ==" | tee -a $OUT/summary.log
+for cfg in "512 0" "512 1" "384 1" "768 1" "512 0" "512 1"; do
   set -- $cfg
-  GSD_SLICE_BASE=$1 GSD_RASTER_BWD_VARIANT=$2 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+  GSD_SLICE_BASE=$1 GSD_GRAD_TUPLES=$2 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('slice $1 bwdv $2:', d['value'], d['ms_per_step'], d['stage_ms'], d['config'].get('depth_slices'))" | tee -a $OUT/summary.log
+        d=json.loads(l); print('slice $1 tuples $2:', d['value'], d['ms_per_step'], d['stage_ms'], d['config'].get('depth_slices'))" | tee -a $OUT/summary.log
 done
 echo "== bench default ==" | tee -a $OUT/summary.log
 timeout 600 python bench.py > $OUT/bench.log 2>&1
