@@ -784,6 +784,44 @@ __global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const u
   }
 }
 
+// wave-per-Gaussian form for slices of few, large Gaussians (the nearest slice: ~50k Gaussians owning
+// ~400 tiles each): the thread-per-Gaussian form would run 200 blocks with 64-deep serial ballot loops.
+__global__ __launch_bounds__(256) void reduce_tuples_wave_kernel(int n_slice, const unsigned* __restrict__ slice_gi,
+                                                                 const unsigned* __restrict__ counts,
+                                                                 const unsigned* __restrict__ cum,
+                                                                 const float* __restrict__ tuples,
+                                                                 const unsigned char* __restrict__ flags,
+                                                                 float* __restrict__ v_records) {
+  const int lane = lane_id();
+  const int j = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (j >= n_slice) return;
+  const unsigned c_n = counts[j], c_e = cum[j];
+  if (c_n == 0) return;
+  float part[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) part[c] = 0.f;
+  bool hit = false;
+  for (unsigned i = lane; i < c_n; i += 64) {
+    if (flags[c_e + i]) {
+      const float4* t = reinterpret_cast<const float4*>(tuples + (size_t)(c_e + i) * kRecFloats);
+      float4 a = t[0], b = t[1], c = t[2];
+      part[0] += a.x; part[1] += a.y; part[2] += a.z; part[3] += a.w;
+      part[4] += b.x; part[5] += b.y; part[6] += b.z; part[7] += b.w; part[8] += c.x;
+      hit = true;
+    }
+  }
+  if (__ballot(hit) == 0ull) return;
+  float tot[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) tot[c] = wave_sum_uniform(part[c]);
+  if (lane == 0) {
+    float4* dst = reinterpret_cast<float4*>(v_records + (size_t)slice_gi[j] * kRecFloats);
+    dst[0] = make_float4(tot[0], tot[1], tot[2], tot[3]);
+    dst[1] = make_float4(tot[4], tot[5], tot[6], tot[7]);
+    dst[2] = make_float4(tot[8], 0.f, 0.f, 0.f);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // sub-frame averaging in linearised colour:
 //   out = ( mean_k max(C_k, m)^gamma )^(1/gamma),  m = min_rgb_level/255
@@ -979,10 +1017,14 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
 // v_records[slice_gi[j]] (plain stores; Gaussians without a touched entry are left as they are).
 GS_EXPORT int gs_reduce_grad_tuples(int n_slice, const unsigned* slice_gi, const unsigned* counts,
                                     const unsigned* cum_excl, const float* tuples, const unsigned char* flags,
-                                    float* v_records, void* stream) {
+                                    float* v_records, long long n_isect, void* stream) {
   if (n_slice <= 0) return GS_ERR_INVALID;
-  hipLaunchKernelGGL(reduce_tuples_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice,
-                     slice_gi, counts, cum_excl, tuples, flags, v_records);
+  if (n_isect > 32ll * n_slice)    // few large Gaussians: one wave each
+    hipLaunchKernelGGL(reduce_tuples_wave_kernel, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream, n_slice,
+                       slice_gi, counts, cum_excl, tuples, flags, v_records);
+  else
+    hipLaunchKernelGGL(reduce_tuples_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice,
+                       slice_gi, counts, cum_excl, tuples, flags, v_records);
   return gs_launch_status();
 }
 

@@ -393,7 +393,7 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
         if tuples is not None:
             with _stage("grad_reduce"):
                 _check(L.gs_reduce_grad_tuples(sl["n"], _ptr(sl["slice_gi"]), _ptr(sl["counts"]), _ptr(sl["cum"]),
-                                               _ptr(tuples), _ptr(flags), _ptr(v_records), _stream()),
+                                               _ptr(tuples), _ptr(flags), _ptr(v_records), sl["I"], _stream()),
                        "reduce_grad_tuples")
 
 

@@ -188,7 +188,8 @@ int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const i
  * v_records[slice_gi[j]] with plain stores (each Gaussian belongs to exactly one slice). */
 int gs_reduce_grad_tuples(int n_slice, const unsigned* slice_gi, const unsigned* counts,
                           const unsigned* cum_excl, const float* tuples, const unsigned char* flags,
-                          float* v_records, void* stream);
+                          float* v_records, long long n_isect /*entries of the slice: picks the kernel form*/,
+                          void* stream);
 
 /* ---- sub-frame averaging in linearised colour (flags train.py:60,62) ---------
  * out = ( mean_k max(C_k, min_level)^gamma )^(1/gamma); n = H*W*3 values per sample. */
