@@ -301,8 +301,18 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     out_img = torch.empty(S, H, W, 3, device=dev)
     out_T = torch.empty(S, H, W, device=dev)
     live_T = torch.empty(S, H, W, device=dev)
-    tile_done = torch.zeros(P * T, dtype=torch.uint8, device=dev)
     sat = torch.empty(P * (ty + 1) * (tx + 1), dtype=torch.int32, device=dev)
+    if R > 1:
+        # rolling-shutter bands: sub-pose p = s*R + r only ever composites tile rows [edge[r], edge[r+1]);
+        # every other tile of p is "done" from the start so the binning never emits for it
+        e = [(r * ty) // R for r in range(R + 1)]       # same formula as _band_edges (no device sync)
+        rows = torch.arange(ty, device=dev)
+        band_open = torch.stack([(rows >= e[r]) & (rows < e[r + 1]) for r in range(R)])          # [R, ty]
+        tile_done = (~band_open).to(torch.uint8)[None, :, :, None].expand(S, R, ty, tx).reshape(-1).contiguous()
+        _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _stream()), "tile_open_sat")
+    else:
+        tile_done = torch.zeros(P * T, dtype=torch.uint8, device=dev)
+    holes0 = R > 1          # the very first slice already has closed tiles
     slices = []
     last_slice_intersects = []
     invalid_key = P * T if EXACT_TILE_CULL else 0
@@ -318,7 +328,8 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                 counts = torch.empty(n_k, dtype=torch.int32, device=dev)
                 d = desc[k]
                 _check(L.gs_slice_counts(n_k, P, N, _ptr(d), ctypes.c_void_p(d.data_ptr() + 4 * P), _ptr(sorted_gi),
-                                         _ptr(records), None if first else _ptr(sat), H, W, _ptr(slice_gi),
+                                         _ptr(records), None if (first and not holes0) else _ptr(sat), H, W,
+                                         _ptr(slice_gi),
                                          _ptr(counts), _stream()), "slice_counts")
                 cum_k, total_k = exclusive_scan_u32(counts)
             if first:
@@ -335,7 +346,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
             with _stage("emit"):
                 keys = torch.empty(I_k, dtype=torch.int32, device=dev)
                 vals = torch.empty(I_k, dtype=torch.int32, device=dev)
-                if first:
+                if first and not holes0:
                     _check(L.gs_emit_intersects(n_k, N, H, W, _ptr(slice_gi), _ptr(cum_k), _ptr(records), I_k,
                                                 _ptr(keys), _ptr(vals), invalid_key, _stream()), "emit intersects")
                 else:
