@@ -62,7 +62,8 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = Path(LIB_PATH)
+    import os
+    path = Path(os.environ.get("GSD_LIB_PATH", LIB_PATH))   # override: A/B builds of the same sources
     if not path.exists():
         if not build_if_missing:
             raise HipLibraryError(f"{path} is missing; run __graft_entry__.build()")

@@ -511,7 +511,10 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(RasterParams prm, const
 //     with 16 conflict-free ds_read_b128 and park the total in tot[j][c]; at the end of the batch
 //     lane j picks up its 9 totals.  ~20 issue slots per Gaussian instead of ~80.
 // ---------------------------------------------------------------------------
-constexpr int kRedG = 4;                    // Gaussians per transposed-reduction group
+#ifndef GS_RED_G
+#define GS_RED_G 4
+#endif
+constexpr int kRedG = GS_RED_G;             // Gaussians per transposed-reduction group
 constexpr int kRedStride = 68;              // floats per row (64 + 4: 16-byte aligned, b128 conflict-free)
 constexpr int kRedFloats = kRedG * 9 * kRedStride + 64 * 9;
 
@@ -519,8 +522,11 @@ constexpr int kRedFloats = kRedG * 9 * kRedStride + 64 * 9;
 // OUT = 1: no atomics at all — the entry's 9 gradients go to tuples[e] (48 B, e = emission index of the
 // entry, so the tuples of one Gaussian are CONTIGUOUS) and flags[e] = 1; gs_reduce_grad_tuples then sums
 // each Gaussian's segment.  At ~20 G atomic ops/s the atomics were 40 % of this kernel.
+#ifndef GS_BWD_WAVES
+#define GS_BWD_WAVES 1
+#endif
 template <bool STATE, int OUT>
-__global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, const float* __restrict__ out_T,
+__global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(RasterParams prm, const float* __restrict__ out_T,
                                                             const int* __restrict__ final_idx,
                                                             const float* __restrict__ v_img,
                                                             const float* __restrict__ v_alpha,  // may be null
@@ -593,9 +599,9 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, co
     for (int c = 0; c < 9; ++c) tot[lane * 9 + c] = 0.f;
     const int n = min(64, batch_end - range.x);
     unsigned filled = 0;                          // which slots of the current group hold data
-    for (int j = 0; j < n; ++j) {
+    int g = 0, gbase = 0;                         // slot inside the group, batch position of its first Gaussian
+    for (int j = 0; j < n; ++j, ++g) {
       const int idx_j = batch_end - 1 - j;
-      const int g = j & (kRedG - 1);
       const float gx = readlane_f(rec.x, j), gy = readlane_f(rec.y, j);
       const float qx = readlane_f(sx, j), qy = readlane_f(sy, j), qz = readlane_f(sz, j);
       const float op = readlane_f(rec.op, j);
@@ -663,12 +669,14 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel_v2(RasterParams prm, co
             }
             const float sum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
                               ((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w));
-            const int jj = (j & ~(kRedG - 1)) + row_g;      // batch position of this row's Gaussian
+            const int jj = gbase + row_g;                   // batch position of this row's Gaussian
             tot[jj * 9 + row_c] = sum;
           }
           __builtin_amdgcn_wave_barrier();
           filled = 0;
         }
+        g = -1;
+        gbase = j + 1;
       }
     }
     __builtin_amdgcn_wave_barrier();
