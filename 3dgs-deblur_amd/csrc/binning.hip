@@ -136,23 +136,31 @@ template <> struct SortCfg<unsigned long long> { static constexpr int kRounds = 
 
 template <typename KeyT> constexpr int sort_block_keys() { return 256 * SortCfg<KeyT>::kRounds; }
 
+// Segmented form: the input is `n / seg_len` independent segments of seg_len keys (seg_len == n: one
+// segment); blocks never straddle a segment and the histogram is laid out [segment][digit][block], so ONE
+// flat exclusive scan yields every block's global output offset (earlier segments contribute exactly
+// their length).
+struct SegInfo { size_t seg_len; unsigned nblk_seg; };
+
 template <typename KeyT, int BITS>
 __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* __restrict__ keys, int shift,
-                                                         unsigned mask, unsigned nblk,
+                                                         unsigned mask, SegInfo sg,
                                                          unsigned* __restrict__ ghist) {
   constexpr int NB = 1 << BITS;
   constexpr int R = SortCfg<KeyT>::kRounds;
   __shared__ unsigned hist[NB];
   for (int d = threadIdx.x; d < NB; d += 256) hist[d] = 0;
   __syncthreads();
-  size_t base = (size_t)blockIdx.x * (256 * R);
+  const unsigned seg = blockIdx.x / sg.nblk_seg, b = blockIdx.x % sg.nblk_seg;
+  const size_t base = (size_t)seg * sg.seg_len + (size_t)b * (256 * R);
+  const size_t limit = min(n, (size_t)(seg + 1) * sg.seg_len);
 #pragma unroll 8
   for (int r = 0; r < R; ++r) {
     size_t i = base + (size_t)r * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&hist[(unsigned)(keys[i] >> shift) & mask], 1u);
+    if (i < limit) atomicAdd(&hist[(unsigned)(keys[i] >> shift) & mask], 1u);
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < NB; d += 256) ghist[(size_t)d * nblk + blockIdx.x] = hist[d];
+  for (int d = threadIdx.x; d < NB; d += 256) ghist[((size_t)seg * NB + d) * sg.nblk_seg + b] = hist[d];
 }
 
 template <typename KeyT, int BITS>
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
                                                             const unsigned* __restrict__ vals_in,  // null => iota
                                                             KeyT* __restrict__ keys_out,
                                                             unsigned* __restrict__ vals_out, int shift, unsigned mask,
-                                                            unsigned nblk,
+                                                            SegInfo sg,
                                                             const unsigned* __restrict__ ghist_scanned) {
   constexpr int NB = 1 << BITS;
   constexpr int R = SortCfg<KeyT>::kRounds;
@@ -175,7 +183,9 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   for (int d = threadIdx.x; d < 4 * NB; d += 256) (&cnt[0][0])[d] = 0;
   __syncthreads();
-  const size_t bbase = (size_t)blockIdx.x * BK;
+  const unsigned seg = blockIdx.x / sg.nblk_seg, blk = blockIdx.x % sg.nblk_seg;
+  const size_t bbase = (size_t)seg * sg.seg_len + (size_t)blk * BK;
+  const size_t limit = min(n, (size_t)(seg + 1) * sg.seg_len);
   const size_t wbase = bbase + (size_t)wave * (R * 64);
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   KeyT key[R];
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     size_t i = wbase + (size_t)r * 64 + lane;
-    bool valid = i < n;
+    bool valid = i < limit;
     key[r] = valid ? keys_in[i] : (KeyT)0;
     unsigned digit = (unsigned)(key[r] >> shift) & mask;
     unsigned long long peers = __ballot(valid);
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
     for (int j = 0; j < DPT; ++j) {
       int d = threadIdx.x * DPT + j;
       s_dbase[d] = ex;
-      s_gbase[d] = ghist_scanned[(size_t)d * nblk + blockIdx.x];
+      s_gbase[d] = ghist_scanned[((size_t)seg * NB + d) * sg.nblk_seg + blk];
       unsigned run = ex;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     size_t i = wbase + (size_t)r * 64 + lane;
-    if (i < n) {
+    if (i < limit) {
       unsigned digit = (unsigned)(key[r] >> shift) & mask;
       unsigned slot = cnt[wave][digit] + pos[r];
       s_keys[slot] = key[r];
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
     }
   }
   __syncthreads();
-  const unsigned nvalid = (unsigned)min((size_t)BK, n - bbase);
+  const unsigned nvalid = bbase < limit ? (unsigned)min((size_t)BK, limit - bbase) : 0u;
 #pragma unroll 4
   for (int r = 0; r < R; ++r) {
     unsigned slot = (unsigned)r * 256 + threadIdx.x;
@@ -260,6 +270,13 @@ template <typename KeyT>
 static inline unsigned sort_nblk(size_t n) {
   return (unsigned)((n + sort_block_keys<KeyT>() - 1) / sort_block_keys<KeyT>());
 }
+// total blocks of a segmented sort (segments of seg_len keys; seg_len == 0 or >= n: one segment)
+template <typename KeyT>
+static inline unsigned sort_nblk_seg(size_t n, size_t seg_len, unsigned* nblk_seg) {
+  if (seg_len == 0 || seg_len >= n) { *nblk_seg = sort_nblk<KeyT>(n); return *nblk_seg; }
+  *nblk_seg = sort_nblk<KeyT>(seg_len);
+  return (unsigned)((n + seg_len - 1) / seg_len) * *nblk_seg;
+}
 
 // digit plan for sorting `bits` key bits: fewest passes with digits <= 11 bits, equal widths
 static inline void radix_plan(int bits, int* passes, int* per, int* tmpl_bits) {
@@ -270,44 +287,49 @@ static inline void radix_plan(int bits, int* passes, int* per, int* tmpl_bits) {
 }
 
 template <typename KeyT>
-static inline size_t radix_hist_bytes(size_t n, int bits) {
+static inline size_t radix_hist_bytes(size_t n, size_t seg_len, int bits) {
   int ps, per, tb;
   radix_plan(bits, &ps, &per, &tb);
-  size_t b = ((size_t)1 << tb) * sort_nblk<KeyT>(n) * sizeof(unsigned);
+  unsigned nbs;
+  size_t b = ((size_t)1 << tb) * sort_nblk_seg<KeyT>(n, seg_len, &nbs) * sizeof(unsigned);
   return (b + 255) & ~(size_t)255;
 }
 
 template <typename KeyT>
-static inline size_t radix_ws_bytes(size_t n, int bits) {
+static inline size_t radix_ws_bytes(size_t n, size_t seg_len, int bits) {
   int ps, per, tb;
   radix_plan(bits, &ps, &per, &tb);
-  return radix_hist_bytes<KeyT>(n, bits) + scan_ws_bytes(((size_t)1 << tb) * sort_nblk<KeyT>(n)) + 256;
+  unsigned nbs;
+  return radix_hist_bytes<KeyT>(n, seg_len, bits) +
+         scan_ws_bytes(((size_t)1 << tb) * sort_nblk_seg<KeyT>(n, seg_len, &nbs)) + 256;
 }
 
 template <typename KeyT, int BITS>
-static void radix_pass(size_t n, const KeyT* kin, const unsigned* vin, KeyT* kout, unsigned* vout, int shift,
-                       unsigned mask, void* ws, size_t hist_bytes, hipStream_t st) {
-  unsigned nblk = sort_nblk<KeyT>(n);
+static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned* vin, KeyT* kout, unsigned* vout,
+                       int shift, unsigned mask, void* ws, size_t hist_bytes, hipStream_t st) {
+  SegInfo sg;
+  unsigned nblk = sort_nblk_seg<KeyT>(n, seg_len, &sg.nblk_seg);
+  sg.seg_len = (seg_len == 0 || seg_len >= n) ? n : seg_len;
   unsigned* ghist = reinterpret_cast<unsigned*>(ws);
   size_t hn = ((size_t)1 << BITS) * nblk;
   void* scan_ws = reinterpret_cast<char*>(ws) + hist_bytes;
-  hipLaunchKernelGGL((radix_hist_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, shift, mask, nblk, ghist);
+  hipLaunchKernelGGL((radix_hist_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, shift, mask, sg, ghist);
   run_scan(hn, ghist, ghist, nullptr, scan_ws, st);
   hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, vin, kout, vout, shift,
-                     mask, nblk, ghist);
+                     mask, sg, ghist);
 }
 
 // Sort bits [begin_bit, end_bit).  Ping-pongs between (k0,v0) and (k1,v1); returns the index
 // (0/1) of the buffer pair that holds the result through *result_buf.
 template <typename KeyT>
-static int radix_sort(size_t n, KeyT* k0, unsigned* v0, KeyT* k1, unsigned* v1, int v0_is_iota, int begin_bit,
-                      int end_bit, void* ws, size_t ws_bytes, int* result_buf, hipStream_t st) {
+static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1, unsigned* v1, int v0_is_iota,
+                      int begin_bit, int end_bit, void* ws, size_t ws_bytes, int* result_buf, hipStream_t st) {
   int bits = end_bit - begin_bit;
   if (bits <= 0) return GS_ERR_INVALID;
-  if (ws_bytes < radix_ws_bytes<KeyT>(n, bits)) return GS_ERR_WORKSPACE;
+  if (ws_bytes < radix_ws_bytes<KeyT>(n, seg_len, bits)) return GS_ERR_WORKSPACE;
   int passes, per, tb;
   radix_plan(bits, &passes, &per, &tb);
-  const size_t hist_bytes = radix_hist_bytes<KeyT>(n, bits);
+  const size_t hist_bytes = radix_hist_bytes<KeyT>(n, seg_len, bits);
   KeyT* kk[2] = {k0, k1};
   unsigned* vv[2] = {v0, v1};
   int cur = 0, shift = begin_bit;
@@ -317,10 +339,10 @@ static int radix_sort(size_t n, KeyT* k0, unsigned* v0, KeyT* k1, unsigned* v1, 
     const unsigned mask = (1u << w) - 1u;
     const unsigned* vin = (p == 0 && v0_is_iota) ? nullptr : vv[cur];
     switch (tb) {
-      case 8:  radix_pass<KeyT, 8>(n, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
-      case 9:  radix_pass<KeyT, 9>(n, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
-      case 10: radix_pass<KeyT, 10>(n, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
-      default: radix_pass<KeyT, 11>(n, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
+      case 8:  radix_pass<KeyT, 8>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
+      case 9:  radix_pass<KeyT, 9>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
+      case 10: radix_pass<KeyT, 10>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
+      default: radix_pass<KeyT, 11>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
     }
     shift += w;
     cur ^= 1;
@@ -668,8 +690,8 @@ GS_EXPORT long long gs_scan_workspace_bytes(long long n) { return (long long)sca
 GS_EXPORT long long gs_radix_sort_workspace_bytes(long long n, int begin_bit, int end_bit) {
   if (n <= 0 || end_bit <= begin_bit) return 0;
   // sized for the larger (u64) layout so one query serves both key widths
-  size_t a = radix_ws_bytes<unsigned>((size_t)n, end_bit - begin_bit);
-  size_t b = radix_ws_bytes<unsigned long long>((size_t)n, end_bit - begin_bit);
+  size_t a = radix_ws_bytes<unsigned>((size_t)n, 0, end_bit - begin_bit);
+  size_t b = radix_ws_bytes<unsigned long long>((size_t)n, 0, end_bit - begin_bit);
   return (long long)(a > b ? a : b);
 }
 
@@ -688,7 +710,7 @@ GS_EXPORT int gs_radix_sort_pairs_u32(long long n, unsigned* keys0, unsigned* va
                                       unsigned* vals1, int vals0_is_iota, int begin_bit, int end_bit, void* ws,
                                       long long ws_bytes, int* result_buf, void* stream) {
   if (n <= 0 || begin_bit < 0 || end_bit > 32) return GS_ERR_INVALID;
-  return radix_sort<unsigned>((size_t)n, keys0, vals0, keys1, vals1, vals0_is_iota, begin_bit, end_bit, ws,
+  return radix_sort<unsigned>((size_t)n, 0, keys0, vals0, keys1, vals1, vals0_is_iota, begin_bit, end_bit, ws,
                               (size_t)ws_bytes, result_buf, (hipStream_t)stream);
 }
 
@@ -696,8 +718,24 @@ GS_EXPORT int gs_radix_sort_pairs_u64(long long n, unsigned long long* keys0, un
                                       unsigned long long* keys1, unsigned* vals1, int vals0_is_iota, int begin_bit,
                                       int end_bit, void* ws, long long ws_bytes, int* result_buf, void* stream) {
   if (n <= 0 || begin_bit < 0 || end_bit > 64) return GS_ERR_INVALID;
-  return radix_sort<unsigned long long>((size_t)n, keys0, vals0, keys1, vals1, vals0_is_iota, begin_bit, end_bit, ws,
-                                        (size_t)ws_bytes, result_buf, (hipStream_t)stream);
+  return radix_sort<unsigned long long>((size_t)n, 0, keys0, vals0, keys1, vals1, vals0_is_iota, begin_bit, end_bit,
+                                        ws, (size_t)ws_bytes, result_buf, (hipStream_t)stream);
+}
+
+// Segmented variant: n = num_segments * seg_len keys, every segment of seg_len keys sorted independently
+// (stable) in one set of launches.  Used for the per-sub-pose depth pre-sort: 32-bit depth keys, 3 passes,
+// instead of 35-bit (sub-pose, depth) keys in u64.
+GS_EXPORT long long gs_segmented_sort_workspace_bytes(long long n, long long seg_len, int begin_bit, int end_bit) {
+  if (n <= 0 || seg_len <= 0 || end_bit <= begin_bit) return 0;
+  return (long long)radix_ws_bytes<unsigned>((size_t)n, (size_t)seg_len, end_bit - begin_bit);
+}
+
+GS_EXPORT int gs_segmented_sort_pairs_u32(long long n, long long seg_len, unsigned* keys0, unsigned* vals0,
+                                          unsigned* keys1, unsigned* vals1, int vals0_is_iota, int begin_bit,
+                                          int end_bit, void* ws, long long ws_bytes, int* result_buf, void* stream) {
+  if (n <= 0 || seg_len <= 0 || n % seg_len != 0 || begin_bit < 0 || end_bit > 32) return GS_ERR_INVALID;
+  return radix_sort<unsigned>((size_t)n, (size_t)seg_len, keys0, vals0, keys1, vals1, vals0_is_iota, begin_bit,
+                              end_bit, ws, (size_t)ws_bytes, result_buf, (hipStream_t)stream);
 }
 
 // (sub-pose, depth) keys for the N-sized pre-sort: out[i] = (i / N) << 32 | depth_keys[i]

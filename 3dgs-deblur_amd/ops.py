@@ -234,16 +234,31 @@ def _background(background: Optional[Tensor], device) -> Tensor:
     return bg
 
 
+def segmented_sort_pairs_u32(keys: Tensor, seg_len: int) -> Tuple[Tensor, Tensor]:
+    """Stable ascending sort of every seg_len-long segment of int32 (u32) keys; payload = global index.
+    Input is clobbered."""
+    n = keys.numel()
+    dev = keys.device
+    L = _L()
+    v0 = torch.empty(n, dtype=torch.int32, device=dev)
+    k1 = torch.empty_like(keys)
+    v1 = torch.empty_like(v0)
+    ws_bytes = L.gs_segmented_sort_workspace_bytes(n, seg_len, 0, 32)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    res = ctypes.c_int(0)
+    _check(L.gs_segmented_sort_pairs_u32(n, seg_len, _ptr(keys), _ptr(v0), _ptr(k1), _ptr(v1), 1, 0, 32, _ptr(ws),
+                                         ws_bytes, ctypes.byref(res), _stream()), "segmented sort")
+    return (k1, v1) if res.value == 1 else (keys, v0)
+
+
 def _depth_rank(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int):
-    """(sub-pose, depth) pre-sort -> (sorted_gi [P*N], exclusive scan of tile counts in rank order, total)"""
+    """per-sub-pose depth pre-sort -> (sorted_gi [P*N], exclusive scan of tile counts in rank order, total)"""
     L = _L()
     n = P * N
     dev = records.device
     with _stage("depth_sort"):
-        keys64 = torch.empty(n, dtype=torch.int64, device=dev)
-        _check(L.gs_make_depth_keys64(n, N, _ptr(depth_keys), _ptr(keys64), _stream()), "depth keys")
-        end_bit = 32 + (_bits(P) if P > 1 else 0)
-        _, sorted_gi = radix_sort_pairs(keys64, None, 0, end_bit)
+        # P independent segments of 32-bit depth keys (culled = 0xFFFFFFFF sorts last), one set of launches
+        _, sorted_gi = segmented_sort_pairs_u32(depth_keys.clone(), N)
     with _stage("count_scan"):
         counts = torch.empty(n, dtype=torch.int32, device=dev)
         _check(L.gs_gather_counts(n, _ptr(sorted_gi), _ptr(num_tiles_hit), _ptr(counts), _stream()), "gather counts")

@@ -111,7 +111,13 @@ int gs_radix_sort_pairs_u64(long long n, unsigned long long* keys0, unsigned* va
                             unsigned long long* keys1, unsigned* vals1, int vals0_is_iota, int begin_bit,
                             int end_bit, void* ws, long long ws_bytes, int* result_buf /*host*/,
                             void* stream);
-/* out[i] = (i / N) << 32 | depth_keys[i] : the (sub-pose, depth) key of the N-sized pre-sort */
+/* segmented form: n = k*seg_len keys, each segment of seg_len keys sorted independently and stably by the
+ * same launches (per-sub-pose depth pre-sort on 32-bit keys) */
+long long gs_segmented_sort_workspace_bytes(long long n, long long seg_len, int begin_bit, int end_bit);
+int gs_segmented_sort_pairs_u32(long long n, long long seg_len, unsigned* keys0, unsigned* vals0,
+                                unsigned* keys1, unsigned* vals1, int vals0_is_iota, int begin_bit, int end_bit,
+                                void* ws, long long ws_bytes, int* result_buf /*host*/, void* stream);
+/* out[i] = (i / N) << 32 | depth_keys[i] : the (sub-pose, depth) key of the N-sized pre-sort (64-bit route) */
 int gs_make_depth_keys64(long long n, int N, const unsigned* depth_keys, unsigned long long* out,
                          void* stream);
 int gs_gather_counts(long long n, const unsigned* sorted_gi, const int* num_tiles_hit,

@@ -66,6 +66,22 @@ def test_radix_sort_stable(gs, dev, n, bits, dtype):
     assert torch.equal(vs2.cpu().long(), order)
 
 
+@pytest.mark.parametrize("P,N", [(1, 5000), (5, 4097), (3, 100_003), (10, 4096)])
+def test_segmented_sort_stable(gs, dev, P, N):
+    """every segment sorted independently, ascending, stable; payload = global index"""
+    from gsdeblur_amd import ops
+    g = torch.Generator().manual_seed(P * 7 + N)
+    keys = torch.randint(0, 2 ** 32, (P * N,), generator=g, dtype=torch.int64)
+    keys[: N // 2] = keys[N // 2: 2 * (N // 2)]                 # ties
+    keys[-3:] = 0xFFFFFFFF                                      # "culled" marker sorts last
+    ks, vs = ops.segmented_sort_pairs_u32(keys.to(torch.int32).to(dev), N)
+    for p in range(P):
+        seg = keys[p * N:(p + 1) * N]
+        order = torch.sort(seg, stable=True).indices + p * N
+        assert torch.equal(vs[p * N:(p + 1) * N].cpu().long(), order)
+        assert torch.equal(ks[p * N:(p + 1) * N].cpu().long() & 0xFFFFFFFF, keys[order])
+
+
 # --------------------------------------------------------------------------- #
 # projection / SH / sub-poses
 # --------------------------------------------------------------------------- #

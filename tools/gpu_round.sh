@@ -20,14 +20,13 @@ if [ "$MODE" = "full" ]; then
   echo "== atomic microbench ==" | tee -a $OUT/summary.log
   (hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -Wno-unused-value tools/atomic_bench.hip -o /tmp/atomic_bench && timeout 120 /tmp/atomic_bench) 2>&1 | tail -12 | tee -a $OUT/summary.log
 fi
-echo "== bench A/B: GSD_SLICE_BASE / GSD_GRAD_TUPLES ==" | tee -a $OUT/summary.log
-for cfg in "512 0" "512 1" "384 1" "768 1" "512 0" "512 1"; do
-  set -- $cfg
-  GSD_SLICE_BASE=$1 GSD_GRAD_TUPLES=$2 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+echo "== bench x2 (no cpu baseline) ==" | tee -a $OUT/summary.log
+for v in 1 2; do
+  timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('slice $1 tuples $2:', d['value'], d['ms_per_step'], d['stage_ms'], d['config'].get('depth_slices'))" | tee -a $OUT/summary.log
+        d=json.loads(l); print('run $v:', d['value'], d['ms_per_step'], d['stage_ms'], d['config'].get('depth_slices'))" | tee -a $OUT/summary.log
 done
 echo "== bench default ==" | tee -a $OUT/summary.log
 timeout 600 python bench.py > $OUT/bench.log 2>&1
