@@ -279,28 +279,30 @@ static inline unsigned sort_nblk_seg(size_t n, size_t seg_len, unsigned* nblk_se
 }
 
 // digit plan for sorting `bits` key bits: fewest passes with digits <= 11 bits, equal widths
-static inline void radix_plan(int bits, int* passes, int* per, int* tmpl_bits) {
-  int ps = (bits + 10) / 11;
+static inline void radix_plan(int bits, int* passes, int* per, int* tmpl_bits, int max_digit = 11) {
+  if (max_digit < 8) max_digit = 8;
+  if (max_digit > 11) max_digit = 11;
+  int ps = (bits + max_digit - 1) / max_digit;
   if (ps < 1) ps = 1;
   int w = (bits + ps - 1) / ps;
   *passes = ps; *per = w; *tmpl_bits = w < 8 ? 8 : w;
 }
 
 template <typename KeyT>
-static inline size_t radix_hist_bytes(size_t n, size_t seg_len, int bits) {
+static inline size_t radix_hist_bytes(size_t n, size_t seg_len, int bits, int max_digit = 11) {
   int ps, per, tb;
-  radix_plan(bits, &ps, &per, &tb);
+  radix_plan(bits, &ps, &per, &tb, max_digit);
   unsigned nbs;
   size_t b = ((size_t)1 << tb) * sort_nblk_seg<KeyT>(n, seg_len, &nbs) * sizeof(unsigned);
   return (b + 255) & ~(size_t)255;
 }
 
 template <typename KeyT>
-static inline size_t radix_ws_bytes(size_t n, size_t seg_len, int bits) {
+static inline size_t radix_ws_bytes(size_t n, size_t seg_len, int bits, int max_digit = 11) {
   int ps, per, tb;
-  radix_plan(bits, &ps, &per, &tb);
+  radix_plan(bits, &ps, &per, &tb, max_digit);
   unsigned nbs;
-  return radix_hist_bytes<KeyT>(n, seg_len, bits) +
+  return radix_hist_bytes<KeyT>(n, seg_len, bits, max_digit) +
          scan_ws_bytes(((size_t)1 << tb) * sort_nblk_seg<KeyT>(n, seg_len, &nbs)) + 256;
 }
 
@@ -323,13 +325,14 @@ static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned
 // (0/1) of the buffer pair that holds the result through *result_buf.
 template <typename KeyT>
 static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1, unsigned* v1, int v0_is_iota,
-                      int begin_bit, int end_bit, void* ws, size_t ws_bytes, int* result_buf, hipStream_t st) {
+                      int begin_bit, int end_bit, void* ws, size_t ws_bytes, int* result_buf, hipStream_t st,
+                      int max_digit = 11) {
   int bits = end_bit - begin_bit;
   if (bits <= 0) return GS_ERR_INVALID;
-  if (ws_bytes < radix_ws_bytes<KeyT>(n, seg_len, bits)) return GS_ERR_WORKSPACE;
+  if (ws_bytes < radix_ws_bytes<KeyT>(n, seg_len, bits, max_digit)) return GS_ERR_WORKSPACE;
   int passes, per, tb;
-  radix_plan(bits, &passes, &per, &tb);
-  const size_t hist_bytes = radix_hist_bytes<KeyT>(n, seg_len, bits);
+  radix_plan(bits, &passes, &per, &tb, max_digit);
+  const size_t hist_bytes = radix_hist_bytes<KeyT>(n, seg_len, bits, max_digit);
   KeyT* kk[2] = {k0, k1};
   unsigned* vv[2] = {v0, v1};
   int cur = 0, shift = begin_bit;
@@ -727,15 +730,17 @@ GS_EXPORT int gs_radix_sort_pairs_u64(long long n, unsigned long long* keys0, un
 // instead of 35-bit (sub-pose, depth) keys in u64.
 GS_EXPORT long long gs_segmented_sort_workspace_bytes(long long n, long long seg_len, int begin_bit, int end_bit) {
   if (n <= 0 || seg_len <= 0 || end_bit <= begin_bit) return 0;
-  return (long long)radix_ws_bytes<unsigned>((size_t)n, (size_t)seg_len, end_bit - begin_bit);
+  return (long long)radix_ws_bytes<unsigned>((size_t)n, (size_t)seg_len, end_bit - begin_bit, 8);
 }
 
 GS_EXPORT int gs_segmented_sort_pairs_u32(long long n, long long seg_len, unsigned* keys0, unsigned* vals0,
                                           unsigned* keys1, unsigned* vals1, int vals0_is_iota, int begin_bit,
                                           int end_bit, void* ws, long long ws_bytes, int* result_buf, void* stream) {
   if (n <= 0 || seg_len <= 0 || n % seg_len != 0 || begin_bit < 0 || end_bit > 32) return GS_ERR_INVALID;
+  // 8-bit digits: at a few million keys the light 4-wave-per-SIMD 8-bit passes beat three 11-bit passes
+  // (250 VGPRs, 80 KB LDS per block) — measured 0.51 ms vs 0.37 ms for the 64-bit route at 5M keys
   return radix_sort<unsigned>((size_t)n, (size_t)seg_len, keys0, vals0, keys1, vals1, vals0_is_iota, begin_bit,
-                              end_bit, ws, (size_t)ws_bytes, result_buf, (hipStream_t)stream);
+                              end_bit, ws, (size_t)ws_bytes, result_buf, (hipStream_t)stream, 8);
 }
 
 // (sub-pose, depth) keys for the N-sized pre-sort: out[i] = (i / N) << 32 | depth_keys[i]

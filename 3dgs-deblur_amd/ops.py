@@ -35,6 +35,8 @@ SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "512"))
 EXACT_TILE_CULL = int(os.environ.get("GSD_EXACT_TILE_CULL", "1"))
 # atomic-free backward: per-entry gradient tuples + segmented reduce (0 = fp32 atomics into v_records)
 GRAD_TUPLES = int(os.environ.get("GSD_GRAD_TUPLES", "1"))
+# depth pre-sort: 1 = per-sub-pose segments of 32-bit keys, 0 = one sort of 64-bit (sub-pose, depth) keys
+DEPTH_SORT_SEGMENTED = int(os.environ.get("GSD_DEPTH_SORT_SEGMENTED", "1"))
 last_slice_intersects = []
 
 
@@ -257,8 +259,13 @@ def _depth_rank(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: i
     n = P * N
     dev = records.device
     with _stage("depth_sort"):
-        # P independent segments of 32-bit depth keys (culled = 0xFFFFFFFF sorts last), one set of launches
-        _, sorted_gi = segmented_sort_pairs_u32(depth_keys.clone(), N)
+        if DEPTH_SORT_SEGMENTED:
+            # P independent segments of 32-bit depth keys (culled = 0xFFFFFFFF sorts last), one set of launches
+            _, sorted_gi = segmented_sort_pairs_u32(depth_keys.clone(), N)
+        else:
+            keys64 = torch.empty(n, dtype=torch.int64, device=dev)
+            _check(L.gs_make_depth_keys64(n, N, _ptr(depth_keys), _ptr(keys64), _stream()), "depth keys")
+            _, sorted_gi = radix_sort_pairs(keys64, None, 0, 32 + (_bits(P) if P > 1 else 0))
     with _stage("count_scan"):
         counts = torch.empty(n, dtype=torch.int32, device=dev)
         _check(L.gs_gather_counts(n, _ptr(sorted_gi), _ptr(num_tiles_hit), _ptr(counts), _stream()), "gather counts")
