@@ -534,6 +534,24 @@ __device__ __forceinline__ int slice_rank(const SliceDesc& sd, int j) {
   return sd.begin[p] + (j - sd.prefix[p]);
 }
 
+// slice boundaries: bounds[p*K + k] = first depth rank r of sub-pose p whose cumulative intersection count
+// (cum[p*N + r] - cum[p*N], modulo 2^32) reaches base << k.  One thread per (p, k), binary search.
+__global__ void slice_plan_kernel(int P, int N, int K, const unsigned* __restrict__ cum, unsigned long long base,
+                                  int* __restrict__ bounds) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * K) return;
+  const int p = i / K, k = i % K;
+  const unsigned* c = cum + (size_t)p * N;
+  const unsigned long long tgt = base << k;
+  const unsigned c0 = c[0];
+  int lo = 0, hi = N;                 // first r in [0,N] with rel(r) >= tgt  (N if none)
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if ((unsigned long long)(unsigned)(c[mid] - c0) >= tgt) hi = mid; else lo = mid + 1;
+  }
+  bounds[i] = lo;
+}
+
 // summed-area table of NOT-done tiles per sub-pose: sat[p][(y)*(tx+1)+x] = #open tiles in [0,y)x[0,x).
 // One block per sub-pose, table built in LDS (dynamic, (tx+1)*(ty+1) ints), written out coalesced.
 __global__ __launch_bounds__(256) void tile_sat_kernel(int tiles_x, int tiles_y, const unsigned char* __restrict__ done,
@@ -809,6 +827,14 @@ GS_EXPORT int gs_map_gaussian_to_intersects(int N, const float* xys, const float
 }
 
 // ---- depth-sliced binning -------------------------------------------------------------------
+// bounds [P*K]: first depth rank of each sub-pose at which the cumulative intersection count reaches base<<k
+GS_EXPORT int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl, long long base, int* bounds, void* stream) {
+  if (P <= 0 || N <= 0 || K <= 0 || K > 32 || base <= 0) return GS_ERR_INVALID;
+  hipLaunchKernelGGL(slice_plan_kernel, dim3((P * K + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, N, K, cum_excl,
+                     (unsigned long long)base, bounds);
+  return gs_launch_status();
+}
+
 // sat [P*(tiles_y+1)*(tiles_x+1)]: summed-area table of tiles that are NOT done.
 GS_EXPORT int gs_tile_open_sat(int P, int H, int W, const unsigned char* tile_done, int* sat, void* stream) {
   if (P <= 0) return GS_ERR_INVALID;

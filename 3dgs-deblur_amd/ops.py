@@ -291,11 +291,11 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         with _stage("slice_plan"):
             # the scan is u32 (wraps above 2^32 total intersections): differences inside one sub-pose are
             # still exact modulo 2^32 as long as a single sub-pose has fewer than 2^32 intersections
-            rel = cum.view(P, N).long() & 0xFFFFFFFF
-            rel = (rel - rel[:, :1]) & 0xFFFFFFFF
-            tgt = (T * slice_base) * (2 ** torch.arange(KMAX, device=dev, dtype=torch.int64))
-            bounds = torch.searchsorted(rel, tgt[None, :].expand(P, KMAX).contiguous())  # [P,KMAX] first rank >= tgt
-            plan = torch.cat([bounds.reshape(-1), total.long() & 0xFFFFFFFF]).cpu()      # one host sync
+            bounds = torch.empty(P * KMAX + 1, dtype=torch.int32, device=dev)
+            _check(L.gs_slice_plan(P, N, KMAX, _ptr(cum), T * slice_base, _ptr(bounds), _stream()), "slice_plan")
+            bounds[-1:] = total
+            plan = bounds.cpu().long()                                                   # one host sync
+            plan[-1] &= 0xFFFFFFFF
         n_total = int(plan[-1])
         b = plan[:-1].view(P, KMAX).tolist()
         # number of slices: up to the first k whose boundary reaches N in every sub-pose

@@ -156,6 +156,9 @@ int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* ti
  * composited.  The depth-ranked Gaussians are processed in front-to-back slices; a tile whose
  * pixels have all stopped is flagged done and later slices emit no intersections for it.  Every
  * pixel still sees the same Gaussians in the same order, so results equal the unsliced pass. */
+/* bounds[p*K+k] = first depth rank of sub-pose p whose cumulative intersection count reaches base<<k */
+int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl /*P*N, rank order*/, long long base,
+                  int* bounds /*P*K*/, void* stream);
 /* sat [P*(tiles_y+1)*(tiles_x+1)] = summed-area table of tiles NOT done (tile_done u8 [P*T]) */
 int gs_tile_open_sat(int P, int img_height, int img_width, const unsigned char* tile_done, int* sat,
                      void* stream);
