@@ -1,0 +1,128 @@
+"""`transforms.json` loader: the wire format between the reference's data preparation and the model
+(App. B).  Field contract, all from the reference tree:
+  top level   w h cx cy fl_x fl_y k1 k2 p1 p2 exposure_time rolling_shutter_time frames[]
+              (/root/reference/process_synthetic_inputs.py:113-129), optional ply_file_path (:298),
+              applied_transform, k3 (/root/reference/combine.py:118,127)
+  per frame   file_path transform_matrix[4][4] camera_linear_velocity[3] camera_angular_velocity[3]
+              (/root/reference/process_synthetic_inputs.py:171-176), optional motion_blur_score
+              (/root/reference/combine.py:79-81)
+  conventions camera-to-world in OpenGL axes; velocities in that camera frame
+              (/root/reference/process_synthetic_inputs.py:157-165)
+  eval split  "interval": sorted index i % 8 == 0 (/root/reference/train.py:174-177,
+              /root/reference/process_synthetic_inputs.py:287-293); "filename": eval_/train_ prefixes
+              (/root/reference/train_eval_split_by_blur_score.py:34-37, /root/reference/train.py:169-172);
+              "all" (/root/reference/train.py:164-167)
+Pure host code (json + torch tensors); no images are decoded here.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .model import Camera
+
+
+@dataclass
+class TransformsScene:
+    cameras: List[Camera]
+    image_paths: List[str]
+    train_indices: List[int]
+    eval_indices: List[int]
+    exposure_time: float
+    rolling_shutter_time: float
+    distortion: Dict[str, float] = field(default_factory=dict)
+    ply_file_path: Optional[str] = None
+    applied_transform: Optional[torch.Tensor] = None
+
+
+def split_indices(file_paths: List[str], eval_mode: str = "interval", eval_interval: int = 8) -> Tuple[List[int], List[int]]:
+    """(train, eval) indices into the path-sorted frame list."""
+    n = len(file_paths)
+    if eval_mode == "all":
+        return list(range(n)), list(range(n))
+    if eval_mode == "interval":
+        ev = [i for i in range(n) if i % eval_interval == 0]
+        return [i for i in range(n) if i % eval_interval != 0], ev
+    if eval_mode == "filename":
+        ev = [i for i, p in enumerate(file_paths) if os.path.basename(p).startswith("eval_")]
+        tr = [i for i, p in enumerate(file_paths) if os.path.basename(p).startswith("train_")]
+        if not ev and not tr:
+            raise ValueError("eval_mode='filename' needs eval_/train_ prefixed file names")
+        return tr, ev
+    raise ValueError(f"unknown eval_mode {eval_mode!r}")
+
+
+def load_transforms(path: str, eval_mode: str = "interval", eval_interval: int = 8,
+                    downscale: int = 1) -> TransformsScene:
+    """Parse a nerfstudio-style transforms.json written by the reference's converters."""
+    json_path = os.path.join(path, "transforms.json") if os.path.isdir(path) else path
+    root = os.path.dirname(json_path)
+    with open(json_path, "rt") as f:
+        meta = json.load(f)
+    for k in ("w", "h", "fl_x", "fl_y", "cx", "cy", "frames"):
+        if k not in meta:
+            raise KeyError(f"transforms.json misses '{k}'")
+    frames = sorted(meta["frames"], key=lambda fr: fr["file_path"])
+    exposure = float(meta.get("exposure_time", 0.0))
+    readout = float(meta.get("rolling_shutter_time", 0.0))
+    s = 1.0 / float(downscale)
+    W, H = int(round(meta["w"] * s)), int(round(meta["h"] * s))
+    cams, paths = [], []
+    is_eval_set = set()
+    tr, ev = split_indices([fr["file_path"] for fr in frames], eval_mode, eval_interval)
+    is_eval_set.update(ev)
+    for i, fr in enumerate(frames):
+        c2w = torch.tensor(fr["transform_matrix"], dtype=torch.float32)
+        if c2w.shape != (4, 4):
+            raise ValueError(f"frame {fr['file_path']}: transform_matrix must be 4x4")
+        md = {
+            "cam_idx": i,
+            "camera_linear_velocity": [float(v) for v in fr.get("camera_linear_velocity", (0.0, 0.0, 0.0))],
+            "camera_angular_velocity": [float(v) for v in fr.get("camera_angular_velocity", (0.0, 0.0, 0.0))],
+            "exposure_time": exposure,
+            "rolling_shutter_time": readout,
+            "is_eval": i in is_eval_set and eval_mode != "all",
+        }
+        if "motion_blur_score" in fr:
+            md["motion_blur_score"] = float(fr["motion_blur_score"])
+        cams.append(Camera(c2w[:3], float(fr.get("fl_x", meta["fl_x"])) * s, float(fr.get("fl_y", meta["fl_y"])) * s,
+                           float(fr.get("cx", meta["cx"])) * s, float(fr.get("cy", meta["cy"])) * s, W, H, md))
+        paths.append(os.path.normpath(os.path.join(root, fr["file_path"])))
+    at = meta.get("applied_transform")
+    return TransformsScene(
+        cameras=cams, image_paths=paths, train_indices=tr, eval_indices=ev, exposure_time=exposure,
+        rolling_shutter_time=readout,
+        distortion={k: float(meta[k]) for k in ("k1", "k2", "k3", "p1", "p2") if k in meta},
+        ply_file_path=(os.path.normpath(os.path.join(root, meta["ply_file_path"])) if "ply_file_path" in meta else None),
+        applied_transform=(torch.tensor(at, dtype=torch.float32) if at is not None else None),
+    )
+
+
+def load_seed_points_ply(path: str) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ASCII PLY seed cloud `x y z red green blue` (/root/reference/process_synthetic_inputs.py:203-219)
+    -> (xyz [N,3] float32, rgb [N,3] float32 in 0..1)."""
+    with open(path, "rt") as f:
+        lines = f.read().splitlines()
+    if not lines or lines[0].strip() != "ply":
+        raise ValueError("not a PLY file")
+    n, props, i = 0, [], 0
+    for i, ln in enumerate(lines):
+        t = ln.split()
+        if t[:2] == ["element", "vertex"]:
+            n = int(t[2])
+        elif t[:1] == ["property"]:
+            props.append(t[-1])
+        elif t[:1] == ["format"] and t[1] != "ascii":
+            raise ValueError("only ASCII PLY seed clouds are supported")
+        elif t[:1] == ["end_header"]:
+            break
+    rows = [[float(v) for v in ln.split()] for ln in lines[i + 1:i + 1 + n]]
+    data = torch.tensor(rows, dtype=torch.float32).reshape(n, len(props))
+    col = {p: j for j, p in enumerate(props)}
+    xyz = data[:, [col["x"], col["y"], col["z"]]]
+    rgb = data[:, [col["red"], col["green"], col["blue"]]] / 255.0 if "red" in col else torch.full((n, 3), 0.5)
+    return xyz, rgb

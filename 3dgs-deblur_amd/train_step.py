@@ -1,0 +1,89 @@
+"""Loss + optimizer step around the hot path: what the nerfstudio fork's trainer
+does right after `get_outputs` — splatfacto's `0.8*L1 + 0.2*(1-SSIM)` image loss, the scale
+regularisation switched on by /root/reference/train.py:120 (`use-scale-regularization`), and one Adam
+step per parameter group.  Plain torch on top of :mod:`model`; the render and its backward are the HIP path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from .model import Camera, SplatfactoDeblurModel
+
+
+def _gauss_window(size: int = 11, sigma: float = 1.5, device=None) -> Tensor:
+    x = torch.arange(size, dtype=torch.float32, device=device) - (size - 1) / 2.0
+    g = torch.exp(-(x * x) / (2 * sigma * sigma))
+    g = g / g.sum()
+    return (g[:, None] * g[None, :])[None, None]
+
+
+def ssim(img: Tensor, ref: Tensor, window: int = 11) -> Tensor:
+    """Mean SSIM of two [H,W,3] images in [0,1] (Gaussian 11x11 window, sigma 1.5, valid padding)."""
+    x = img.permute(2, 0, 1)[None]
+    y = ref.permute(2, 0, 1)[None]
+    w = _gauss_window(window, 1.5, img.device).expand(3, 1, window, window)
+    mu_x, mu_y = F.conv2d(x, w, groups=3), F.conv2d(y, w, groups=3)
+    sxx = F.conv2d(x * x, w, groups=3) - mu_x * mu_x
+    syy = F.conv2d(y * y, w, groups=3) - mu_y * mu_y
+    sxy = F.conv2d(x * y, w, groups=3) - mu_x * mu_y
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    s = ((2 * mu_x * mu_y + c1) * (2 * sxy + c2)) / ((mu_x * mu_x + mu_y * mu_y + c1) * (sxx + syy + c2))
+    return s.mean()
+
+
+def psnr(img: Tensor, ref: Tensor) -> float:
+    mse = torch.mean((img.clamp(0, 1) - ref.clamp(0, 1)) ** 2).item()
+    return float("inf") if mse == 0 else -10.0 * math.log10(mse)
+
+
+def image_loss(pred: Tensor, gt: Tensor, ssim_lambda: float = 0.2) -> Tensor:
+    l1 = torch.abs(gt - pred).mean()
+    if ssim_lambda <= 0:
+        return l1
+    return (1.0 - ssim_lambda) * l1 + ssim_lambda * (1.0 - ssim(pred, gt))
+
+
+def scale_regularization(log_scales: Tensor, max_gauss_ratio: float = 10.0) -> Tensor:
+    """Penalise needle-like Gaussians (PhysGaussian-style, as in splatfacto): mean(max(s_max/s_min, r) - r)."""
+    s = torch.exp(log_scales)
+    ratio = s.amax(dim=-1) / s.amin(dim=-1)
+    r = torch.tensor(max_gauss_ratio, device=s.device, dtype=s.dtype)
+    return 0.1 * (torch.maximum(ratio, r) - r).mean()
+
+
+def make_optimizers(model: SplatfactoDeblurModel, lr_scale: float = 1.0) -> Dict[str, torch.optim.Optimizer]:
+    """One Adam per parameter group with splatfacto's default learning rates."""
+    lrs = {"means": 1.6e-4, "scales": 5e-3, "quats": 1e-3, "opacities": 5e-2, "features_dc": 2.5e-3,
+           "features_rest": 2.5e-3 / 20}
+    opts = {k: torch.optim.Adam([p], lr=lrs[k] * lr_scale, eps=1e-15) for k, p in model.gauss_params().items()}
+    if model.pose_adjustment is not None:
+        opts["camera_opt"] = torch.optim.Adam([model.pose_adjustment], lr=1e-4 * lr_scale, eps=1e-15)
+    if model.velocity_adjustment is not None:
+        opts["camera_velocity_opt"] = torch.optim.Adam([model.velocity_adjustment], lr=1e-3 * lr_scale, eps=1e-15)
+    if model.background_param is not None:
+        opts["background"] = torch.optim.Adam([model.background_param], lr=1e-3 * lr_scale, eps=1e-15)
+    return opts
+
+
+def train_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.Optimizer], camera: Camera,
+               gt_image: Tensor, ssim_lambda: float = 0.2, allreduce: Optional[str] = None) -> Dict[str, float]:
+    """One training iteration: render (HIP) -> loss -> backward (HIP) -> [DP gradient all-reduce] -> Adam."""
+    model.train()
+    for o in optimizers.values():
+        o.zero_grad(set_to_none=True)
+    out = model.get_outputs(camera)
+    loss = image_loss(out["rgb"], gt_image, ssim_lambda)
+    if model.config.use_scale_regularization:
+        loss = loss + scale_regularization(model.scales)
+    loss.backward()
+    if allreduce is not None:
+        from . import dp
+        dp.allreduce_gradients(list(model.gauss_params().values()), mode=allreduce, average=True)
+    for o in optimizers.values():
+        o.step()
+    return {"loss": float(loss.item()), "psnr": psnr(out["rgb"].detach(), gt_image)}

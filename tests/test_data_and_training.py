@@ -1,0 +1,123 @@
+"""transforms.json loader (CPU) and loss / optimizer step (GPU)."""
+import json
+import math
+
+import numpy as np
+import pytest
+import torch
+
+
+def _write_scene(tmp_path, n_frames=17, prefix=False):
+    frames = []
+    for i in range(n_frames):
+        c2w = np.eye(4)
+        c2w[0, 3] = 0.1 * i
+        name = f"{i:03d}.png"
+        if prefix:
+            name = ("eval_" if i % 4 == 0 else "train_") + name
+        fr = {"file_path": f"./images/{name}", "transform_matrix": c2w.tolist(),
+              "camera_linear_velocity": [0.0, 0.0, 0.0] if i % 8 == 0 else [0.1 * i, 0.0, -0.2],
+              "camera_angular_velocity": [0.0, 0.0, 0.0] if i % 8 == 0 else [0.0, 0.01 * i, 0.0]}
+        if i % 3 == 0:
+            fr["motion_blur_score"] = float(i)
+        frames.append(fr)
+    rng = np.random.default_rng(0)
+    rng.shuffle(frames)                                   # the loader must sort by file_path
+    meta = {"aabb_scale": 16, "w": 400, "h": 300, "cx": 200.0, "cy": 150.0, "orientation_override": "none",
+            "exposure_time": 1 / 60, "rolling_shutter_time": 1 / 50, "fl_x": 320.0, "fl_y": 318.0, "k1": 0, "k2": 0,
+            "p1": 0, "p2": 0, "frames": frames, "ply_file_path": "./sparse_pc.ply"}
+    (tmp_path / "transforms.json").write_text(json.dumps(meta))
+    ply = ["ply", "format ascii 1.0", "element vertex 3", "property float x", "property float y", "property float z",
+           "property uint8 red", "property uint8 green", "property uint8 blue", "end_header",
+           "0.0 1.0 2.0 255 0 0", "1.5 -1.0 0.5 0 128 0", "-2.0 0.25 3.0 10 20 30"]
+    (tmp_path / "sparse_pc.ply").write_text("\n".join(ply) + "\n")
+    return meta
+
+
+def test_load_transforms_contract(gs, tmp_path):
+    _write_scene(tmp_path)
+    sc = gs.load_transforms(str(tmp_path))
+    assert len(sc.cameras) == 17 and sc.exposure_time == pytest.approx(1 / 60) and sc.rolling_shutter_time == pytest.approx(0.02)
+    assert [c.metadata["cam_idx"] for c in sc.cameras] == list(range(17))
+    assert [p.split("/")[-1] for p in sc.image_paths] == [f"{i:03d}.png" for i in range(17)]      # sorted by path
+    assert sc.eval_indices == [0, 8, 16] and len(sc.train_indices) == 14                            # i % 8 == 0
+    for i in sc.eval_indices:          # eval frames of the synthetic sets are static (process_synthetic_inputs.py:287-293)
+        assert sum(map(abs, sc.cameras[i].metadata["camera_linear_velocity"])) == 0
+        assert sc.cameras[i].metadata["is_eval"]
+    c5 = sc.cameras[5]
+    assert c5.metadata["camera_linear_velocity"] == pytest.approx([0.5, 0.0, -0.2])
+    assert c5.camera_to_world.shape == (3, 4) and c5.camera_to_world[0, 3].item() == pytest.approx(0.5)
+    assert (c5.fx, c5.fy, c5.cx, c5.cy, c5.width, c5.height) == (320.0, 318.0, 200.0, 150.0, 400, 300)
+    assert sc.cameras[3].metadata["motion_blur_score"] == 3.0 and "motion_blur_score" not in sc.cameras[4].metadata
+    xyz, rgb = gs.load_seed_points_ply(sc.ply_file_path)
+    assert xyz.shape == (3, 3) and torch.allclose(rgb[0], torch.tensor([1.0, 0.0, 0.0]))
+    half = gs.load_transforms(str(tmp_path / "transforms.json"), downscale=2)
+    assert (half.cameras[0].width, half.cameras[0].fx) == (200, 160.0)
+
+
+def test_eval_split_modes(gs, tmp_path):
+    _write_scene(tmp_path, prefix=True)
+    sc = gs.load_transforms(str(tmp_path), eval_mode="filename")
+    names = [p.split("/")[-1] for p in sc.image_paths]
+    assert all(names[i].startswith("eval_") for i in sc.eval_indices) and len(sc.eval_indices) == 5
+    assert all(names[i].startswith("train_") for i in sc.train_indices) and len(sc.train_indices) == 12
+    al = gs.load_transforms(str(tmp_path), eval_mode="all")
+    assert al.train_indices == list(range(17)) == al.eval_indices
+    with pytest.raises(ValueError):
+        gs.data.split_indices(["a.png", "b.png"], "filename")
+    with pytest.raises(KeyError):
+        (tmp_path / "bad.json").write_text(json.dumps({"w": 1, "frames": []}))
+        gs.load_transforms(str(tmp_path / "bad.json"))
+
+
+def test_ssim_and_loss_identities(gs):
+    T = gs.training
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(40, 48, 3, generator=g)
+    assert T.ssim(a, a).item() == pytest.approx(1.0, abs=1e-6)
+    assert T.image_loss(a, a).item() == pytest.approx(0.0, abs=1e-6)
+    b = (a + 0.2 * torch.randn(40, 48, 3, generator=g)).clamp(0, 1)
+    assert 0 < T.ssim(a, b).item() < 0.95 and T.psnr(a, a) == float("inf") and 5 < T.psnr(a, b) < 30
+    ls = torch.log(torch.tensor([[1.0, 1.0, 1.0], [1.0, 1.0, 30.0]]))
+    assert T.scale_regularization(ls).item() == pytest.approx(0.1 * (20.0 / 2), rel=1e-5)      # only the needle is penalised
+
+
+@pytest.mark.gpu
+def test_training_recovers_blurred_target(gs, oracle, dev):
+    """End-to-end: targets are motion-blurred renders of ground-truth Gaussians; a perturbed copy trained with
+    the reference's loss through the HIP forward/backward must raise PSNR by a wide margin."""
+    O = oracle
+    W, H, n = 128, 96, 1500
+    sc = O.synthetic_scene(n, W, H, seed=5, scale_mult=7.0)
+    cfg = gs.SplatfactoDeblurConfig(blur_samples=3, rs_bands=2, gamma=2.2, min_rgb_level=10.0, background_color="black",
+                                    use_scale_regularization=True)
+    c2w = torch.eye(4)[:3].clone()
+    c2w[:, 1] *= -1
+    c2w[:, 2] *= -1
+    cams = [gs.Camera(c2w.clone(), sc["fx"], sc["fy"], sc["cx"], sc["cy"], W, H,
+                      metadata=dict(cam_idx=i, camera_linear_velocity=[0.6 * (i - 1), 0.2, 0.0],
+                                    camera_angular_velocity=[0.0, 0.2 * (i - 1), 0.1], exposure_time=1 / 60,
+                                    rolling_shutter_time=1 / 30)) for i in range(3)]
+    gt_model = gs.SplatfactoDeblurModel.from_scene(cfg, sc, dev, num_cameras=3)
+    with torch.no_grad():
+        gt_model.train()
+        targets = [gt_model.get_outputs(c)["rgb"].clone() for c in cams]
+    g = torch.Generator().manual_seed(1)
+    pert = dict(sc)
+    pert["sh"] = sc["sh"] + 0.3 * torch.randn(sc["sh"].shape, generator=g)
+    pert["opacity_logits"] = sc["opacity_logits"] + 0.5 * torch.randn(n, generator=g)
+    pert["means"] = sc["means"] + 0.01 * torch.randn(n, 3, generator=g)
+    model = gs.SplatfactoDeblurModel.from_scene(cfg, pert, dev, num_cameras=3)
+    opts = gs.training.make_optimizers(model, lr_scale=4.0)
+    with torch.no_grad():
+        model.train()
+        psnr0 = np.mean([gs.training.psnr(model.get_outputs(c)["rgb"], t) for c, t in zip(cams, targets)])
+    hist = []
+    for it in range(150):
+        i = it % 3
+        hist.append(gs.training.train_step(model, opts, cams[i], targets[i]))
+    with torch.no_grad():
+        psnr1 = np.mean([gs.training.psnr(model.get_outputs(c)["rgb"], t) for c, t in zip(cams, targets)])
+    assert all(math.isfinite(h["loss"]) for h in hist)
+    assert np.mean([h["loss"] for h in hist[-9:]]) < 0.6 * np.mean([h["loss"] for h in hist[:9]])
+    assert psnr1 > psnr0 + 4.0, (psnr0, psnr1)
