@@ -22,7 +22,7 @@ _SIGS = {
     "gs_project_fused_fwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I,
                              _P, _P, _P, _P, _P],
     "gs_project_fused_bwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I,
-                             _P, _P, _P, _P, _P, _P, _P, _P, _P],
+                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gs_pack_records": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "gs_unpack_record_grads": [_I, _P, _P, _P, _P, _P, _P],
     "gs_exclusive_scan_u32": [_L, _P, _P, _P, _P, _L, _P],
@@ -43,7 +43,7 @@ _SIGS = {
     "gs_emit_open_intersects": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, ctypes.c_uint, _P],
     "gs_rasterize_fwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],
     "gs_rasterize_bwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    "gs_reduce_grad_tuples": [_I, _P, _P, _P, _P, _P, _P, _L, _P],
+    "gs_reduce_grad_tuples": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "gs_combine_fwd": [_I, _L, _P, _F, _F, _P, _P],
     "gs_combine_bwd": [_I, _L, _P, _F, _F, _P, _P, _P, _P],
 }

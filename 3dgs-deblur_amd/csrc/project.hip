@@ -315,7 +315,8 @@ template <int MAXB>
 __global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, const float* __restrict__ records,
     const float* __restrict__ v_records, float* __restrict__ v_means, float* __restrict__ v_scales,
     float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
-    float* __restrict__ v_viewmats /* [P,16] accumulated, may be null */) {
+    float* __restrict__ v_viewmats /* [P,16] accumulated, may be null */,
+    const unsigned char* __restrict__ touched /* [P*N] or null: 0 => v_records row is all-zero, not read */) {
   __shared__ float lds[48];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < fp.N;
@@ -340,7 +341,9 @@ __global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, 
     float vV[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) vV[j] = 0.f;
-    if (live) {
+    // early termination leaves most Gaussians without any gradient: their records are neither read nor
+    // re-projected (the compositor's tuple reduce marks the ones it touched)
+    if (live && (!touched || touched[(size_t)p * fp.N + i])) {
       Proj o; ProjCtx k;
       bool ok = project_one(m, c3, Vm, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x,
                             fp.in.tiles_y, fp.in.clip, o, k);
@@ -521,7 +524,8 @@ GS_EXPORT int gs_project_fused_bwd(int N, int P, const float* means, const float
                                    int sh_degree, const float* viewmats, float fx, float fy, float cx, float cy,
                                    int H, int W, float clip, int antialiased, const float* records,
                                    const float* v_records, float* v_means, float* v_scales, float* v_quats,
-                                   float* v_opacities, float* v_sh, float* v_viewmats, void* stream) {
+                                   float* v_opacities, float* v_sh, float* v_viewmats,
+                                   const unsigned char* touched, void* stream) {
   if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride)
     return GS_ERR_INVALID;
   FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmats,
@@ -529,9 +533,9 @@ GS_EXPORT int gs_project_fused_bwd(int N, int P, const float* means, const float
   dim3 grid((N + 255) / 256), block(256);
   if (sh_degree <= 3)
     hipLaunchKernelGGL(project_fused_bwd_kernel<16>, grid, block, 0, (hipStream_t)stream, fp, records, v_records,
-                       v_means, v_scales, v_quats, v_opacities, v_sh, v_viewmats);
+                       v_means, v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched);
   else
     hipLaunchKernelGGL(project_fused_bwd_kernel<25>, grid, block, 0, (hipStream_t)stream, fp, records, v_records,
-                       v_means, v_scales, v_quats, v_opacities, v_sh, v_viewmats);
+                       v_means, v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched);
   return gs_launch_status();
 }

@@ -737,7 +737,8 @@ __global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const u
                                                             const unsigned* __restrict__ cum,
                                                             const float* __restrict__ tuples,
                                                             const unsigned char* __restrict__ flags,
-                                                            float* __restrict__ v_records) {
+                                                            float* __restrict__ v_records,
+                                                            unsigned char* __restrict__ touched) {
   const int lane = lane_id();
   const int j = blockIdx.x * 256 + threadIdx.x;
   unsigned cnt = 0, e0 = 0, gi = 0;
@@ -789,6 +790,7 @@ __global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const u
     dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
     dst[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
+    if (touched) touched[gi] = 1;
   }
 }
 
@@ -799,7 +801,8 @@ __global__ __launch_bounds__(256) void reduce_tuples_wave_kernel(int n_slice, co
                                                                  const unsigned* __restrict__ cum,
                                                                  const float* __restrict__ tuples,
                                                                  const unsigned char* __restrict__ flags,
-                                                                 float* __restrict__ v_records) {
+                                                                 float* __restrict__ v_records,
+                                                                 unsigned char* __restrict__ touched) {
   const int lane = lane_id();
   const int j = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (j >= n_slice) return;
@@ -823,10 +826,12 @@ __global__ __launch_bounds__(256) void reduce_tuples_wave_kernel(int n_slice, co
 #pragma unroll
   for (int c = 0; c < 9; ++c) tot[c] = wave_sum_uniform(part[c]);
   if (lane == 0) {
-    float4* dst = reinterpret_cast<float4*>(v_records + (size_t)slice_gi[j] * kRecFloats);
+    const unsigned gi = slice_gi[j];
+    float4* dst = reinterpret_cast<float4*>(v_records + (size_t)gi * kRecFloats);
     dst[0] = make_float4(tot[0], tot[1], tot[2], tot[3]);
     dst[1] = make_float4(tot[4], tot[5], tot[6], tot[7]);
     dst[2] = make_float4(tot[8], 0.f, 0.f, 0.f);
+    if (touched) touched[gi] = 1;
   }
 }
 
@@ -1031,14 +1036,14 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
 // v_records[slice_gi[j]] (plain stores; Gaussians without a touched entry are left as they are).
 GS_EXPORT int gs_reduce_grad_tuples(int n_slice, const unsigned* slice_gi, const unsigned* counts,
                                     const unsigned* cum_excl, const float* tuples, const unsigned char* flags,
-                                    float* v_records, long long n_isect, void* stream) {
+                                    float* v_records, unsigned char* touched, long long n_isect, void* stream) {
   if (n_slice <= 0) return GS_ERR_INVALID;
   if (n_isect > 32ll * n_slice)    // few large Gaussians: one wave each
     hipLaunchKernelGGL(reduce_tuples_wave_kernel, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream, n_slice,
-                       slice_gi, counts, cum_excl, tuples, flags, v_records);
+                       slice_gi, counts, cum_excl, tuples, flags, v_records, touched);
   else
     hipLaunchKernelGGL(reduce_tuples_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice,
-                       slice_gi, counts, cum_excl, tuples, flags, v_records);
+                       slice_gi, counts, cum_excl, tuples, flags, v_records, touched);
   return gs_launch_status();
 }
 

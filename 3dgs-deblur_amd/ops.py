@@ -406,7 +406,8 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
 
 
 def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, img_width: int, bg: Tensor,
-                    edges: Tensor, out_T: Tensor, v_img: Tensor, v_alpha: Optional[Tensor], v_records: Tensor):
+                    edges: Tensor, out_T: Tensor, v_img: Tensor, v_alpha: Optional[Tensor], v_records: Tensor,
+                    touched: Optional[Tensor] = None):
     L = _L()
     H, W = img_height, img_width
     bwd_T = out_T.clone()
@@ -428,7 +429,8 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
         if tuples is not None:
             with _stage("grad_reduce"):
                 _check(L.gs_reduce_grad_tuples(sl["n"], _ptr(sl["slice_gi"]), _ptr(sl["counts"]), _ptr(sl["cum"]),
-                                               _ptr(tuples), _ptr(flags), _ptr(v_records), sl["I"], _stream()),
+                                               _ptr(tuples), _ptr(flags), _ptr(v_records), _ptr(touched), sl["I"],
+                                               _stream()),
                        "reduce_grad_tuples")
 
 
@@ -744,9 +746,17 @@ class _RenderSubposes(Function):
         L = _L()
         v_img = v_img.contiguous().float()
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
-        v_records = torch.zeros(P * N, REC, device=dev)
+        # atomic-free path: only Gaussians the compositor touched get a gradient record (plain stores) and a
+        # `touched` flag; the projection backward skips everything else, so v_records needs no 240 MB memset
+        all_tuples = all(sl["gi_of_e"] is not None for sl in ctx.slices)
+        if all_tuples:
+            v_records = torch.empty(P * N, REC, device=dev)
+            touched = torch.zeros(P * N, dtype=torch.uint8, device=dev)
+        else:
+            v_records = torch.zeros(P * N, REC, device=dev)
+            touched = None
         if ctx.sliced:
-            sliced_backward(records, ctx.slices, S, R, H, W, bg, edges, out_T, v_img, v_al, v_records)
+            sliced_backward(records, ctx.slices, S, R, H, W, bg, edges, out_T, v_img, v_al, v_records, touched)
         else:
             with _stage("raster_bwd"):
                 _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
@@ -763,7 +773,7 @@ class _RenderSubposes(Function):
             _check(L.gs_project_fused_bwd(N, P, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(opacities),
                                           _ptr(sh), K, deg, _ptr(V), fx, fy, cx, cy, H, W, clip, aa, _ptr(records),
                                           _ptr(v_records), _ptr(v_means), _ptr(v_scales), _ptr(v_quats), _ptr(v_opac),
-                                          _ptr(v_sh), _ptr(v_V), _stream()), "project_fused_bwd")
+                                          _ptr(v_sh), _ptr(v_V), _ptr(touched), _stream()), "project_fused_bwd")
         v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
         return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 12
 

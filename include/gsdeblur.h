@@ -85,7 +85,10 @@ int gs_project_fused_bwd(int N, int P, const float* means3d, const float* scales
                          int sh_degree, const float* viewmats, float fx, float fy, float cx, float cy,
                          int img_height, int img_width, float clip_thresh, int antialiased,
                          const float* records, const float* v_records, float* v_means3d, float* v_scales,
-                         float* v_quats, float* v_opacities, float* v_sh, float* v_viewmats, void* stream);
+                         float* v_quats, float* v_opacities, float* v_sh, float* v_viewmats,
+                         const unsigned char* touched /*[P*N] or NULL; 0 = that v_records row is zero and is
+                                                        not read (set by gs_reduce_grad_tuples)*/,
+                         void* stream);
 
 /* ---- gsplat-array <-> record glue for the rasterize_gaussians signature -------- */
 int gs_pack_records(int N, const float* xys, const float* depths, const int* radii, const float* conics,
@@ -197,7 +200,8 @@ int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const i
  * v_records[slice_gi[j]] with plain stores (each Gaussian belongs to exactly one slice). */
 int gs_reduce_grad_tuples(int n_slice, const unsigned* slice_gi, const unsigned* counts,
                           const unsigned* cum_excl, const float* tuples, const unsigned char* flags,
-                          float* v_records, long long n_isect /*entries of the slice: picks the kernel form*/,
+                          float* v_records, unsigned char* touched /*[P*N] or NULL: set to 1 where written*/,
+                          long long n_isect /*entries of the slice: picks the kernel form*/,
                           void* stream);
 
 /* ---- sub-frame averaging in linearised colour (flags train.py:60,62) ---------
