@@ -319,12 +319,22 @@ __global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, 
     const unsigned char* __restrict__ touched /* [P*N] or null: 0 => v_records row is all-zero, not read */) {
   __shared__ float lds[48];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < fp.N;
+  bool live = i < fp.N;
+  if (touched && live) {
+    // with touched flags the caller pre-zeroes every output: a Gaussian no sub-pose touched (the vast
+    // majority under early termination) neither reads its 59 parameters nor writes its 59 gradients
+    bool any = false;
+    for (int p = 0; p < fp.P; ++p) any |= touched[(size_t)p * fp.N + i] != 0;
+    live = any;
+  }
   const int ii = live ? i : 0;
-  float m[3] = {fp.means[3 * ii], fp.means[3 * ii + 1], fp.means[3 * ii + 2]};
-  float s[3] = {fp.scales[3 * ii], fp.scales[3 * ii + 1], fp.scales[3 * ii + 2]};
-  float q[4] = {fp.quats[4 * ii], fp.quats[4 * ii + 1], fp.quats[4 * ii + 2], fp.quats[4 * ii + 3]};
-  float opac = fp.opacities[ii];
+  float m[3] = {0.f, 0.f, 1.f}, s[3] = {1.f, 1.f, 1.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, opac = 0.f;
+  if (live) {
+    m[0] = fp.means[3 * ii]; m[1] = fp.means[3 * ii + 1]; m[2] = fp.means[3 * ii + 2];
+    s[0] = fp.scales[3 * ii]; s[1] = fp.scales[3 * ii + 1]; s[2] = fp.scales[3 * ii + 2];
+    q[0] = fp.quats[4 * ii]; q[1] = fp.quats[4 * ii + 1]; q[2] = fp.quats[4 * ii + 2]; q[3] = fp.quats[4 * ii + 3];
+    opac = fp.opacities[ii];
+  }
   float R[9], qn[4], inv, M[9], c3[6];
   quat_to_rotmat(q, R, qn, &inv);
   scale_rot_to_cov3d(s, fp.glob, R, M, c3);

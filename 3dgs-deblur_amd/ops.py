@@ -364,6 +364,8 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                     # every tile is done (each already received its background term): nothing left to do
                     last_slice_intersects.append(0)
                     break
+        if I_k >= 2 ** 31 or I_k < 0:
+            raise OverflowError(f"depth slice {k} holds {I_k} tile intersections (limit 2^31-1): lower GSD_SLICE_BASE")
         if I_k > 0:
             with _stage("emit"):
                 keys = torch.empty(I_k, dtype=torch.int32, device=dev)
@@ -762,11 +764,12 @@ class _RenderSubposes(Function):
                 _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
                                           _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records),
                                           _stream()), "rasterize_bwd")
-        v_means = torch.empty(N, 3, device=dev)
-        v_scales = torch.empty(N, 3, device=dev)
-        v_quats = torch.empty(N, 4, device=dev)
-        v_opac = torch.empty(N, device=dev)
-        v_sh = torch.empty(N, K, 3, device=dev)
+        alloc = torch.zeros if touched is not None else torch.empty     # untouched Gaussians are skipped
+        v_means = alloc(N, 3, device=dev)
+        v_scales = alloc(N, 3, device=dev)
+        v_quats = alloc(N, 4, device=dev)
+        v_opac = alloc(N, device=dev)
+        v_sh = alloc(N, K, 3, device=dev)
         need_v = ctx.needs_input_grad[5]
         v_V = torch.zeros(P, 4, 4, device=dev) if need_v else None
         with _stage("project_bwd"):

@@ -86,8 +86,10 @@ int gs_project_fused_bwd(int N, int P, const float* means3d, const float* scales
                          int img_height, int img_width, float clip_thresh, int antialiased,
                          const float* records, const float* v_records, float* v_means3d, float* v_scales,
                          float* v_quats, float* v_opacities, float* v_sh, float* v_viewmats,
-                         const unsigned char* touched /*[P*N] or NULL; 0 = that v_records row is zero and is
-                                                        not read (set by gs_reduce_grad_tuples)*/,
+                         const unsigned char* touched /*[P*N] or NULL; 0 = that v_records row is zero and is not
+                                                        read (set by gs_reduce_grad_tuples).  With touched given,
+                                                        the caller must ZERO the five gradient outputs: Gaussians
+                                                        untouched in every sub-pose are skipped entirely*/,
                          void* stream);
 
 /* ---- gsplat-array <-> record glue for the rasterize_gaussians signature -------- */
