@@ -388,7 +388,9 @@ __global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, 
         for (int j = 0; j < 6; ++j) vc3[j] += vc31[j];
       }
     }
-    if (v_viewmats) reduce_vV(vV, v_viewmats + 16 * p, lds);
+    // block-uniform skip: most 256-Gaussian blocks hold nothing the compositor touched
+    if (v_viewmats && __syncthreads_or(live && (!touched || touched[(size_t)p * fp.N + i])))
+      reduce_vV(vV, v_viewmats + 16 * p, lds);
   }
   if (!live) return;
   float vs[3], vq[4];
