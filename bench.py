@@ -107,7 +107,9 @@ def main():
     ap.add_argument("--subposes", type=int, default=5, help="motion-blur samples S")
     ap.add_argument("--rs-bands", type=int, default=1, help="rolling-shutter row bands R")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--allreduce", default="allreduce", choices=["allreduce", "rs_ag"])
+    ap.add_argument("--allreduce", default="sparse", choices=["sparse", "allreduce", "rs_ag"],
+                    help="DP gradient exchange: row-sparse all-gather (default; dense fallback built in), "
+                         "dense all-reduce, or reduce-scatter + all-gather")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -254,6 +256,7 @@ def main():
                        "depth_slices": list(ops.last_slice_intersects) if ops.SLICE_BASE > 0 else None,
                        "views_per_step": world,
                        "parallelism": f"dp{world}" if world > 1 else "single",
+                       "gradient_exchange": args.allreduce if world > 1 else None,
                        "subpose_MPix_per_s": round(value * S, 3)},
             "stage_ms": stage_ms,
             "roofline": roofline,

@@ -87,6 +87,49 @@ def _dp_worker(rank, world, port, mode, q):
     dist.destroy_process_group()
 
 
+def _dp_sparse_worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    import gsdeblur_amd as gs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N = 4000
+    shapes = [(N, 3), (N, 3), (N, 4), (N, 1), (N, 3), (N, 15, 3)]
+    ok = True
+    for density, expect_sparse in ((0.01, True), (0.6, False)):
+        gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]
+        all_grads = []
+        for r in range(world):
+            touched = torch.rand(N, generator=gens[r]) < density
+            all_grads.append([torch.randn(s, generator=gens[r]) * touched.view(-1, *([1] * (len(s) - 1))) for s in shapes])
+        params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+        for p, g in zip(params, all_grads[rank]):
+            p.grad = g.clone()
+        all_grads[1][4] = torch.zeros(shapes[4])                            # rank 1 has no grad for param 4
+        if rank == 1:
+            params[4].grad = None                                           # a missing grad counts as zero
+        gs.dp.allreduce_gradients(params, mode="sparse")
+        for i, p in enumerate(params):
+            want = sum(all_grads[r][i] for r in range(world))
+            ok &= bool(torch.allclose(p.grad, want, atol=1e-6))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_sparse_gradient_exchange_world2_gloo():
+    """row-sparse all-gather exchange == dense sum, for a sparse case and for the dense fallback"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_sparse_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
 @pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
 def test_gradient_allreduce_world2_gloo(mode):
     ctx = mp.get_context("spawn")
