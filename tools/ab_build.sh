@@ -6,12 +6,12 @@ mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 C="3dgs-deblur_amd/csrc"; B="3dgs-deblur_amd/build"
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fvisibility=hidden"
-declare -A V=( [g4w1]="-DGS_RED_G=4 -DGS_BWD_WAVES=1" [g3w4]="-DGS_RED_G=3 -DGS_BWD_WAVES=4" [g3w1]="-DGS_RED_G=3 -DGS_BWD_WAVES=1" [g2w4]="-DGS_RED_G=2 -DGS_BWD_WAVES=4" )
+declare -A V=( [base]="" [noslp]="-fno-slp-vectorize" [noslp_g4]="-fno-slp-vectorize -DGS_RED_G=4" )
 for t in "${!V[@]}"; do
   hipcc $FL ${V[$t]} -c $C/raster.hip -o /tmp/raster_$t.o && hipcc --offload-arch=gfx950 -shared -fPIC $B/project.o $B/binning.o /tmp/raster_$t.o -o /tmp/libgsd_$t.so
 done
 for rep in 1 2; do
-for t in g4w1 g3w4 g3w1 g2w4; do
+for t in base noslp noslp_g4; do
   GSD_LIB_PATH=/tmp/libgsd_$t.so timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
