@@ -1,17 +1,17 @@
 #!/bin/bash
-# A/B of compile-time variants of raster.hip: builds /tmp/libgsd_<tag>.so and benches each (interleaved).
+# A/B of compile-time variants of raster_bwd.hip: builds /tmp/libgsd_<tag>.so and benches each (interleaved).
 set -u
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 C="3dgs-deblur_amd/csrc"; B="3dgs-deblur_amd/build"
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fvisibility=hidden"
-declare -A V=( [base]="" [noslp]="-fno-slp-vectorize" [noslp_g4]="-fno-slp-vectorize -DGS_RED_G=4" )
+declare -A V=( [base]="-fno-slp-vectorize" [w5]="-fno-slp-vectorize -DGS_BWD_WAVES=5 -DGS_RED_G=2" [g2]="-fno-slp-vectorize -DGS_RED_G=2" )
 for t in "${!V[@]}"; do
-  hipcc $FL ${V[$t]} -c $C/raster.hip -o /tmp/raster_$t.o && hipcc --offload-arch=gfx950 -shared -fPIC $B/project.o $B/binning.o /tmp/raster_$t.o -o /tmp/libgsd_$t.so
+  hipcc $FL ${V[$t]} -c $C/raster_bwd.hip -o /tmp/raster_bwd_$t.o && hipcc --offload-arch=gfx950 -shared -fPIC $B/project.o $B/binning.o $B/raster.o /tmp/raster_bwd_$t.o -o /tmp/libgsd_$t.so
 done
 for rep in 1 2; do
-for t in base noslp noslp_g4; do
+for t in base w5 g2; do
   GSD_LIB_PATH=/tmp/libgsd_$t.so timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
