@@ -535,9 +535,12 @@ __device__ __forceinline__ int slice_rank(const SliceDesc& sd, int j) {
 }
 
 // slice boundaries: bounds[p*K + k] = first depth rank r of sub-pose p whose cumulative intersection count
-// (cum[p*N + r] - cum[p*N], modulo 2^32) reaches base << k.  One thread per (p, k), binary search.
-__global__ void slice_plan_kernel(int P, int N, int K, const unsigned* __restrict__ cum, unsigned long long base,
-                                  int* __restrict__ bounds) {
+// (cum[p*N + r] - cum[p*N], modulo 2^32) reaches base << k, and rels[p*K + k] = that cumulative count at the
+// boundary (the sub-pose total when the boundary is N).  One thread per (p, k), binary search.  With the
+// counts on the host the first slice needs no extra device->host sync for its size.
+__global__ void slice_plan_kernel(int P, int N, int K, const unsigned* __restrict__ cum,
+                                  const unsigned* __restrict__ total, unsigned long long base,
+                                  int* __restrict__ bounds, unsigned* __restrict__ rels) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P * K) return;
   const int p = i / K, k = i % K;
@@ -550,6 +553,8 @@ __global__ void slice_plan_kernel(int P, int N, int K, const unsigned* __restric
     if ((unsigned long long)(unsigned)(c[mid] - c0) >= tgt) hi = mid; else lo = mid + 1;
   }
   bounds[i] = lo;
+  const unsigned seg_end = (p + 1 < P) ? c[N] : *total;
+  rels[i] = (lo < N ? c[lo] : seg_end) - c0;
 }
 
 // summed-area table of NOT-done tiles per sub-pose: sat[p][(y)*(tx+1)+x] = #open tiles in [0,y)x[0,x).
@@ -828,10 +833,11 @@ GS_EXPORT int gs_map_gaussian_to_intersects(int N, const float* xys, const float
 
 // ---- depth-sliced binning -------------------------------------------------------------------
 // bounds [P*K]: first depth rank of each sub-pose at which the cumulative intersection count reaches base<<k
-GS_EXPORT int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl, long long base, int* bounds, void* stream) {
+GS_EXPORT int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl, const unsigned* total, long long base,
+                            int* bounds, unsigned* rels, void* stream) {
   if (P <= 0 || N <= 0 || K <= 0 || K > 32 || base <= 0) return GS_ERR_INVALID;
   hipLaunchKernelGGL(slice_plan_kernel, dim3((P * K + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, N, K, cum_excl,
-                     (unsigned long long)base, bounds);
+                     total, (unsigned long long)base, bounds, rels);
   return gs_launch_status();
 }
 

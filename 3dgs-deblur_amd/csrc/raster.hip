@@ -1,211 +1,25 @@
-// raster.hip — per-pixel front-to-back alpha compositing (forward) and its
-// reverse-order backward, written for gfx950 / wave64.
+// raster.hip — per-pixel front-to-back alpha compositing (forward) and the sub-frame averaging, written
+// for gfx950 / wave64.  The reverse-order backward lives in raster_bwd.hip.
 //
-// Restates (absent fork sources) gsplat's rasterize_forward /
-// rasterize_backward_kernel as recollected in SURVEY.md App. A "Blend" and
-// "Backward"; constants in gs::K (gs_math.h).
+// Restates (absent fork sources) gsplat's rasterize_forward as recollected in SURVEY.md
+// App. A "Blend"; constants in gs::K (gs_math.h).
 //
 // MI355X design (not the CUDA 256-thread-block/shared-memory tiling):
 //   * one wave64 owns one 16x16 tile; each lane owns a 1x4 pixel column segment
-//     (x = lane&15, y = 4*(lane>>4)+k).  No LDS, no __syncthreads: the 64
-//     Gaussians of a batch live one-per-lane in VGPRs and are broadcast with
-//     v_readlane_b32 into SGPRs, so the per-pair math reads uniform operands
-//     from the scalar file.
-//   * dx is shared by a lane's 4 pixels.
-//   * early termination is a wave ballot.
-//   * backward: a lane pre-sums its 4 pixels, one 6-step DPP wave reduction per
-//     gradient component per (Gaussian, tile), the total is parked in the lane
-//     that owns the Gaussian, and every lane issues its own 9 fp32 atomics after
-//     the batch (64 distinct addresses per instruction, no same-address storms).
+//     (x = lane&15, y = 4*(lane>>4)+k).  No LDS, no __syncthreads: the 64 Gaussians of a batch live
+//     one-per-lane in VGPRs and are broadcast with v_readlane_b32 into SGPRs, so the per-pair math reads
+//     uniform operands from the scalar file; dx is shared by a lane's 4 pixels.
+//   * tile header and both loops run on the scalar unit (readfirstlane); the inner loop is branch-free
+//     ("stopped" == T = 0, every update a select, exp2 on a pre-scaled exponent); early termination and the
+//     skip of (Gaussian, tile) pairs that touch no pixel are wave ballots.
+//   * entry ids / Gaussian ids / records are software-prefetched 3 / 2 / 1 batches ahead.
+//   * per-pixel state persists in HBM between depth slices (see binning.hip "depth-sliced binning").
 #include "raster_common.h"
 
 namespace gs {
 
 // ---------------------------------------------------------------------------
-// forward
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void raster_fwd_kernel(RasterParams prm, float* __restrict__ out_img,
-                                                         float* __restrict__ out_T, int* __restrict__ final_idx,
-                                                         unsigned n_blocks) {
-  const int lane = lane_id();
-  const int T = prm.tiles_x * prm.tiles_y;
-  const unsigned work = xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6);
-  if (work >= (unsigned)(prm.S * T)) return;
-  const int s = work / T, t = work % T;
-  const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
-  const int p = s * prm.R + find_band(prm.band_edges, prm.R, ty);
-  const int2 range = prm.tile_bins[(size_t)p * T + t];
-
-  const int px = tx * K::kTile + (lane & 15);
-  const int py0 = ty * K::kTile + (lane >> 4) * 4;
-  const float pxf = (float)px + 0.5f;
-  float Tk[4], Cr[4], Cg[4], Cb[4];
-  int last[4];
-  bool done[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    Tk[k] = 1.f; Cr[k] = Cg[k] = Cb[k] = 0.f; last[k] = range.x;
-    done[k] = !(px < prm.W && (py0 + k) < prm.H);
-  }
-
-  const int* __restrict__ vals = prm.sorted_vals;
-  // software pipeline: ids two batches ahead, records one batch ahead
-  int id_next = 0;
-  {
-    int i0 = range.x + lane;
-    id_next = i0 < range.y ? vals[i0] : 0;
-  }
-  Rec9 rec_next = load_rec(prm.records, id_next, (range.x + lane) < range.y);
-  {
-    int i1 = range.x + 64 + lane;
-    id_next = i1 < range.y ? vals[i1] : 0;
-  }
-
-  for (int batch = range.x; batch < range.y; batch += 64) {
-    if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
-    Rec9 rec = rec_next;
-    // prefetch the following batch
-    rec_next = load_rec(prm.records, id_next, (batch + 64 + lane) < range.y);
-    {
-      int i2 = batch + 128 + lane;
-      id_next = i2 < range.y ? vals[i2] : 0;
-    }
-    const int n = min(64, range.y - batch);
-    for (int j = 0; j < n; ++j) {
-      if ((j & 7) == 0 && j && __ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
-      const float gx = readlane_f(rec.x, j), gy = readlane_f(rec.y, j);
-      const float cx = readlane_f(rec.cx, j), cy = readlane_f(rec.cy, j), cz = readlane_f(rec.cz, j);
-      const float op = readlane_f(rec.op, j);
-      const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
-      const float dx = gx - pxf;
-      const float hx = 0.5f * cx * dx * dx;   // shared by the lane's 4 pixels
-      const float bx = cy * dx;
-      const float hz = 0.5f * cz;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (!done[k]) {
-          const float dy = gy - ((float)(py0 + k) + 0.5f);
-          const float sigma = hx + dy * (bx + hz * dy);
-          if (sigma >= 0.f) {
-            const float alpha = fminf(K::kAlphaMax, op * __expf(-sigma));
-            if (alpha >= K::kAlphaMin) {
-              const float nT = Tk[k] * (1.f - alpha);
-              if (nT <= K::kTMin) {
-                done[k] = true;
-              } else {
-                const float w = alpha * Tk[k];
-                Cr[k] += w * cr; Cg[k] += w * cg; Cb[k] += w * cb;
-                Tk[k] = nT;
-                last[k] = batch + j + 1;
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-  const float bgr = prm.background[0], bgg = prm.background[1], bgb = prm.background[2];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int y = py0 + k;
-    if (px < prm.W && y < prm.H) {
-      size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
-      out_img[pix * 3 + 0] = Cr[k] + Tk[k] * bgr;
-      out_img[pix * 3 + 1] = Cg[k] + Tk[k] * bgg;
-      out_img[pix * 3 + 2] = Cb[k] + Tk[k] * bgb;
-      out_T[pix] = Tk[k];
-      final_idx[pix] = last[k];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// forward, variant 2: branch-free inner loop.  "Stopped" is encoded as T = 0 (so a stopped
-// pixel can never pass nT > 1e-4 again), conics are pre-scaled by -log2(e) so the exponent feeds
-// v_exp_f32 directly, and every update is a select: ~20 VALU per (pixel, Gaussian) with no
-// exec-mask juggling.  Bit-for-bit the same decisions as variant 1 except for the exp argument
-// rounding (inside the stated fp32 tolerance).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void raster_fwd_kernel_v2(RasterParams prm, float* __restrict__ out_img,
-                                                            float* __restrict__ out_T, int* __restrict__ final_idx,
-                                                            unsigned n_blocks) {
-  const int lane = lane_id();
-  const int T = prm.tiles_x * prm.tiles_y;
-  const unsigned work = xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6);
-  if (work >= (unsigned)(prm.S * T)) return;
-  const int s = work / T, t = work % T;
-  const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
-  const int p = s * prm.R + find_band(prm.band_edges, prm.R, ty);
-  const int2 range = prm.tile_bins[(size_t)p * T + t];
-
-  const int px = tx * K::kTile + (lane & 15);
-  const int py0 = ty * K::kTile + (lane >> 4) * 4;
-  const float pxf = (float)px + 0.5f;
-  float Tk[4], Tf[4], Cr[4], Cg[4], Cb[4], pyf[4];
-  int last[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const bool inside = px < prm.W && (py0 + k) < prm.H;
-    Tk[k] = inside ? 1.f : 0.f; Tf[k] = 1.f; Cr[k] = Cg[k] = Cb[k] = 0.f; last[k] = range.x;
-    pyf[k] = (float)(py0 + k) + 0.5f;
-  }
-  const int* __restrict__ vals = prm.sorted_vals;
-  int id_next = (range.x + lane) < range.y ? vals[range.x + lane] : 0;
-  Rec9 rec_next = load_rec(prm.records, id_next, (range.x + lane) < range.y);
-  id_next = (range.x + 64 + lane) < range.y ? vals[range.x + 64 + lane] : 0;
-  const float kL2E = -1.4426950408889634f;
-
-  for (int batch = range.x; batch < range.y; batch += 64) {
-    if (__ballot(fmaxf(fmaxf(Tk[0], Tk[1]), fmaxf(Tk[2], Tk[3])) > 0.f) == 0ull) break;
-    Rec9 rec = rec_next;
-    rec_next = load_rec(prm.records, id_next, (batch + 64 + lane) < range.y);
-    id_next = (batch + 128 + lane) < range.y ? vals[batch + 128 + lane] : 0;
-    // pre-scale: sigma2 = -log2e * sigma = hx2 + dy*(bx2 + hz2*dy)
-    rec.cx *= 0.5f * kL2E; rec.cy *= kL2E; rec.cz *= 0.5f * kL2E;
-    const int n = min(64, range.y - batch);
-    for (int j = 0; j < n; ++j) {
-      if ((j & 15) == 15 && __ballot(fmaxf(fmaxf(Tk[0], Tk[1]), fmaxf(Tk[2], Tk[3])) > 0.f) == 0ull) break;
-      const float gx = readlane_f(rec.x, j), gy = readlane_f(rec.y, j);
-      const float cx = readlane_f(rec.cx, j), cy = readlane_f(rec.cy, j), cz = readlane_f(rec.cz, j);
-      const float op = readlane_f(rec.op, j);
-      const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
-      const float dx = gx - pxf;
-      const float hx = cx * dx * dx;
-      const float bx = cy * dx;
-      const int idx1 = batch + j + 1;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float dy = gy - pyf[k];
-        const float s2 = hx + dy * (bx + cz * dy);                // = -log2e * sigma
-        const float alpha = fminf(K::kAlphaMax, op * __builtin_amdgcn_exp2f(s2));
-        const bool valid = (s2 <= 0.f) && (alpha >= K::kAlphaMin);
-        const float nT = Tk[k] - Tk[k] * alpha;
-        const bool upd = valid && (nT > K::kTMin);
-        const float w = upd ? alpha * Tk[k] : 0.f;
-        Cr[k] += w * cr; Cg[k] += w * cg; Cb[k] += w * cb;
-        Tf[k] = upd ? nT : Tf[k];
-        Tk[k] = upd ? nT : (valid ? 0.f : Tk[k]);
-        last[k] = upd ? idx1 : last[k];
-      }
-    }
-  }
-  const float bgr = prm.background[0], bgg = prm.background[1], bgb = prm.background[2];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int y = py0 + k;
-    if (px < prm.W && y < prm.H) {
-      size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
-      out_img[pix * 3 + 0] = Cr[k] + Tf[k] * bgr;
-      out_img[pix * 3 + 1] = Cg[k] + Tf[k] * bgg;
-      out_img[pix * 3 + 2] = Cb[k] + Tf[k] * bgb;
-      out_T[pix] = Tf[k];
-      final_idx[pix] = last[k];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// forward, depth-sliced: same inner loop as variant 2, but the per-pixel state (colour without
+// forward compositor (single pass and depth-sliced): the per-pixel state (colour without
 // background, final T, live T) persists in HBM between slices and a tile whose pixels have all
 // stopped is flagged `done` (it gets its background term then, is skipped by later slices and
 // receives no further intersections from the binning).  first && last reproduces the unsliced pass.
@@ -422,20 +236,17 @@ GS_EXPORT int gs_rasterize_fwd(const float* records, const int* sorted_vals, con
                                const int* band_edges, const float* background, int S, int R, int H, int W,
                                float* out_img, float* out_T, int* final_idx, int variant, void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
-  RasterParams prm;
-  prm.records = records; prm.sorted_vals = sorted_vals; prm.gi_of_e = nullptr;
-  prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
-  prm.band_edges = band_edges; prm.background = background;
-  prm.S = S; prm.R = R; prm.H = H; prm.W = W;
-  prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
+  RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
+  // one pass over the complete tile lists = the sliced kernel with first == last (no persistent state)
+  SliceState st; st.tile_done = nullptr; st.live_T = nullptr; st.first = 1; st.last = 1;
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
   if (variant == 1)
-    hipLaunchKernelGGL(raster_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_img, out_T,
-                       final_idx, blocks);
+    hipLaunchKernelGGL(raster_fwd_slice_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, st,
+                       out_img, out_T, final_idx, blocks);
   else
-    hipLaunchKernelGGL(raster_fwd_kernel_v2, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_img, out_T,
-                       final_idx, blocks);
+    hipLaunchKernelGGL(raster_fwd_slice_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, st,
+                       out_img, out_T, final_idx, blocks);
   return gs_launch_status();
 }
 
@@ -450,16 +261,11 @@ GS_EXPORT int gs_rasterize_fwd_slice(const float* records, const int* sorted_val
                                      unsigned char* tile_done, int first, int last, const int* gi_of_e, int variant,
                                      void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
-  RasterParams prm;
-  prm.records = records; prm.sorted_vals = sorted_vals; prm.gi_of_e = nullptr;
-  prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
-  prm.band_edges = band_edges; prm.background = background;
-  prm.S = S; prm.R = R; prm.H = H; prm.W = W;
-  prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
-  prm.gi_of_e = gi_of_e;
-  SliceState st; st.tile_done = tile_done; st.live_T = live_T; st.first = first; st.last = last;
+  RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
+  prm.gi_of_e = gi_of_e;
+  SliceState st; st.tile_done = tile_done; st.live_T = live_T; st.first = first; st.last = last;
   if (variant == 1)
     hipLaunchKernelGGL(raster_fwd_slice_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, st,
                        out_img, out_T, final_idx, blocks);

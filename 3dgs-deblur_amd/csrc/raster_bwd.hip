@@ -8,149 +8,8 @@
 namespace gs {
 
 // ---------------------------------------------------------------------------
-// backward
-// ---------------------------------------------------------------------------
-// STATE = true: depth-sliced backward — the running transmittance and the colour accumulated from
-// behind persist in bwd_T / bwd_B between slice launches (slices are visited back to front).
-template <bool STATE>
-__global__ __launch_bounds__(256) void raster_bwd_kernel(RasterParams prm, const float* __restrict__ out_T,
-                                                         const int* __restrict__ final_idx,
-                                                         const float* __restrict__ v_img,
-                                                         const float* __restrict__ v_alpha,  // may be null
-                                                         float* __restrict__ v_records, unsigned n_blocks,
-                                                         float* __restrict__ bwd_T, float* __restrict__ bwd_B) {
-  const int lane = lane_id();
-  const int T = prm.tiles_x * prm.tiles_y;
-  const unsigned work = xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6);
-  if (work >= (unsigned)(prm.S * T)) return;
-  const int s = work / T, t = work % T;
-  const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
-  const int p = s * prm.R + find_band(prm.band_edges, prm.R, ty);
-  const int2 range = prm.tile_bins[(size_t)p * T + t];
-  if (range.y <= range.x) return;
-
-  const int px = tx * K::kTile + (lane & 15);
-  const int py0 = ty * K::kTile + (lane >> 4) * 4;
-  const float pxf = (float)px + 0.5f;
-  const float bgr = prm.background[0], bgg = prm.background[1], bgb = prm.background[2];
-
-  float Tk[4], Tfin[4], Br[4], Bg[4], Bb[4], vr[4], vg[4], vb[4], va[4];
-  int fin[4];
-  int my_end = range.x;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int y = py0 + k;
-    Br[k] = Bg[k] = Bb[k] = 0.f;
-    if (px < prm.W && y < prm.H) {
-      size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
-      Tfin[k] = out_T[pix];
-      fin[k] = final_idx[pix];
-      vr[k] = v_img[pix * 3 + 0]; vg[k] = v_img[pix * 3 + 1]; vb[k] = v_img[pix * 3 + 2];
-      float va_out = v_alpha ? v_alpha[pix] : 0.f;
-      // d(out)/d(alpha_i) carries T_final/(1-alpha_i) * (v_alpha_out - sum_c bg_c v_c)
-      va[k] = Tfin[k] * (va_out - (bgr * vr[k] + bgg * vg[k] + bgb * vb[k]));
-    } else {
-      Tfin[k] = 1.f; fin[k] = range.x; vr[k] = vg[k] = vb[k] = 0.f; va[k] = 0.f;
-    }
-    Tk[k] = Tfin[k];
-    if (STATE && px < prm.W && y < prm.H) {
-      size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
-      Tk[k] = bwd_T[pix];
-      Br[k] = bwd_B[pix * 3 + 0]; Bg[k] = bwd_B[pix * 3 + 1]; Bb[k] = bwd_B[pix * 3 + 2];
-    }
-    my_end = max(my_end, fin[k]);
-  }
-  const int wave_end = wave_max_i(my_end);
-  const int* __restrict__ vals = prm.sorted_vals;
-
-  for (int batch_end = wave_end; batch_end > range.x; batch_end -= 64) {
-    const int idx = batch_end - 1 - lane;
-    const bool valid = idx >= range.x;
-    const int gid = valid ? vals[idx] : 0;
-    const Rec9 rec = load_rec(prm.records, gid, valid);
-    float a_x = 0.f, a_y = 0.f, a_cx = 0.f, a_cy = 0.f, a_cz = 0.f, a_op = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
-    const int n = min(64, batch_end - range.x);
-    for (int j = 0; j < n; ++j) {
-      const int idx_j = batch_end - 1 - j;
-      const float gx = readlane_f(rec.x, j), gy = readlane_f(rec.y, j);
-      const float cx = readlane_f(rec.cx, j), cy = readlane_f(rec.cy, j), cz = readlane_f(rec.cz, j);
-      const float op = readlane_f(rec.op, j);
-      const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
-      const float dx = gx - pxf;
-      const float hx = 0.5f * cx * dx * dx;
-      const float bx = cy * dx;
-      const float hz = 0.5f * cz;
-      float p_x = 0.f, p_y = 0.f, p_cx = 0.f, p_cy = 0.f, p_cz = 0.f, p_op = 0.f, p_r = 0.f, p_g = 0.f, p_b = 0.f;
-      bool any = false;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (idx_j < fin[k]) {
-          const float dy = gy - ((float)(py0 + k) + 0.5f);
-          const float sigma = hx + dy * (bx + hz * dy);
-          if (sigma >= 0.f) {
-            const float vis = __expf(-sigma);
-            const float ov = op * vis;
-            const float alpha = fminf(K::kAlphaMax, ov);
-            if (alpha >= K::kAlphaMin) {
-              any = true;
-              const float ra = 1.f / (1.f - alpha);
-              Tk[k] *= ra;                       // transmittance in front of this Gaussian
-              const float fac = alpha * Tk[k];
-              p_r += fac * vr[k]; p_g += fac * vg[k]; p_b += fac * vb[k];
-              float v_al = (cr * Tk[k] - Br[k] * ra) * vr[k] + (cg * Tk[k] - Bg[k] * ra) * vg[k] +
-                           (cb * Tk[k] - Bb[k] * ra) * vb[k] + va[k] * ra;
-              Br[k] += cr * fac; Bg[k] += cg * fac; Bb[k] += cb * fac;
-              if (ov <= K::kAlphaMax) {          // d min(0.999, o*vis) = 0 when clamped
-                const float v_sigma = -ov * v_al;
-                p_op += vis * v_al;
-                p_cx += 0.5f * v_sigma * dx * dx;
-                p_cy += v_sigma * dx * dy;
-                p_cz += 0.5f * v_sigma * dy * dy;
-                p_x += v_sigma * (cx * dx + cy * dy);
-                p_y += v_sigma * (cy * dx + cz * dy);
-              }
-            }
-          }
-        }
-      }
-      if (__ballot(any) == 0ull) continue;
-      const float t_x = wave_sum_uniform(p_x), t_y = wave_sum_uniform(p_y);
-      const float t_cx = wave_sum_uniform(p_cx), t_cy = wave_sum_uniform(p_cy), t_cz = wave_sum_uniform(p_cz);
-      const float t_op = wave_sum_uniform(p_op);
-      const float t_r = wave_sum_uniform(p_r), t_g = wave_sum_uniform(p_g), t_b = wave_sum_uniform(p_b);
-      if (lane == j) {
-        a_x = t_x; a_y = t_y; a_cx = t_cx; a_cy = t_cy; a_cz = t_cz; a_op = t_op; a_r = t_r; a_g = t_g; a_b = t_b;
-      }
-    }
-    if (valid) {
-      float* dst = v_records + (size_t)gid * kRecFloats;
-      if (a_x != 0.f) atomic_add_f32(dst + 0, a_x);
-      if (a_y != 0.f) atomic_add_f32(dst + 1, a_y);
-      if (a_cx != 0.f) atomic_add_f32(dst + 2, a_cx);
-      if (a_cy != 0.f) atomic_add_f32(dst + 3, a_cy);
-      if (a_cz != 0.f) atomic_add_f32(dst + 4, a_cz);
-      if (a_op != 0.f) atomic_add_f32(dst + 5, a_op);
-      if (a_r != 0.f) atomic_add_f32(dst + 6, a_r);
-      if (a_g != 0.f) atomic_add_f32(dst + 7, a_g);
-      if (a_b != 0.f) atomic_add_f32(dst + 8, a_b);
-    }
-  }
-  if (STATE) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int y = py0 + k;
-      if (px < prm.W && y < prm.H) {
-        size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
-        bwd_T[pix] = Tk[k];
-        bwd_B[pix * 3 + 0] = Br[k]; bwd_B[pix * 3 + 1] = Bg[k]; bwd_B[pix * 3 + 2] = Bb[k];
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// backward, variant 2 (default for the depth-sliced path).  Same math as raster_bwd_kernel, cheaper
-// instruction stream:
+// backward compositor (single pass and depth-sliced): reverse-order traversal from each pixel's final
+// index, written for a cheap instruction stream:
 //   * one predicate per pixel instead of three nested exec-mask regions, exp2 on a pre-scaled
 //     exponent, v_rcp_f32 for 1/(1-alpha) (the IEEE division expansion cost ~10 VALU per pixel);
 //   * the 9 per-Gaussian wave reductions (54 DPP adds + 18 lane moves) are replaced by a transposed
@@ -487,28 +346,25 @@ __global__ __launch_bounds__(256) void reduce_tuples_wave_kernel(int n_slice, co
 
 using namespace gs;
 
-// Replaces _C.rasterize_backward.  v_records must be zeroed by the caller;
-// gradients are accumulated with fp32 atomics.
+// Replaces _C.rasterize_backward: one pass over complete tile lists.  v_records must be
+// zeroed by the caller; gradients are accumulated with fp32 atomics (the gsplat-compatible op has no
+// emission-order index to build tuples from).
 GS_EXPORT int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* tile_bins,
                                const int* band_edges, const float* background, int S, int R, int H, int W,
                                const float* out_T, const int* final_idx, const float* v_img, const float* v_alpha,
                                float* v_records, void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
-  RasterParams prm;
-  prm.records = records; prm.sorted_vals = sorted_vals; prm.gi_of_e = nullptr;
-  prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
-  prm.band_edges = band_edges; prm.background = background;
-  prm.S = S; prm.R = R; prm.H = H; prm.W = W;
-  prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
+  RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
-  hipLaunchKernelGGL(raster_bwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T, final_idx,
-                     v_img, v_alpha, v_records, blocks, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL((raster_bwd_kernel_v2<false, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T,
+                     final_idx, v_img, v_alpha, v_records, blocks, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                     (unsigned char*)nullptr);
   return gs_launch_status();
 }
 
 // One backward launch per slice, slices back to front.  bwd_T (initialised by the caller to out_T) and
-// bwd_B [S,H,W,3] (initialised to 0) carry the reverse-traversal state between launches.
+// bwd_B [S,H,W] (behind-colour . v_out, initialised to 0) carry the reverse-traversal state between launches.
 GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                                      const int* band_edges, const float* background, int S, int R, int H, int W,
                                      const float* out_T, const int* final_idx, const float* v_img,
@@ -516,21 +372,12 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
                                      const int* gi_of_e, float* tuples, unsigned char* flags, int variant,
                                      void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
-  RasterParams prm;
-  prm.records = records; prm.sorted_vals = sorted_vals; prm.gi_of_e = nullptr;
-  prm.tile_bins = reinterpret_cast<const int2*>(tile_bins);
-  prm.band_edges = band_edges; prm.background = background;
-  prm.S = S; prm.R = R; prm.H = H; prm.W = W;
-  prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
+  RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
+  prm.gi_of_e = gi_of_e;
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
-  prm.gi_of_e = gi_of_e;
   hipStream_t st = (hipStream_t)stream;
-  if (variant == 1) {          // DPP reference kernel (atomics); needs plain Gaussian ids in the list
-    if (gi_of_e) return GS_ERR_INVALID;
-    hipLaunchKernelGGL(raster_bwd_kernel<true>, dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx, v_img, v_alpha,
-                       v_records, blocks, bwd_T, bwd_B);
-  } else if (variant == 2) {   // ablation: no atomics (timing experiments only)
+  if (variant == 2) {          // ablation: plain stores instead of atomics (timing experiments only)
     hipLaunchKernelGGL((raster_bwd_kernel_v2<true, 2>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx, v_img,
                        v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);
   } else if (tuples && flags && gi_of_e) {

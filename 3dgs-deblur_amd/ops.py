@@ -291,13 +291,14 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         with _stage("slice_plan"):
             # the scan is u32 (wraps above 2^32 total intersections): differences inside one sub-pose are
             # still exact modulo 2^32 as long as a single sub-pose has fewer than 2^32 intersections
-            bounds = torch.empty(P * KMAX + 1, dtype=torch.int32, device=dev)
-            _check(L.gs_slice_plan(P, N, KMAX, _ptr(cum), T * slice_base, _ptr(bounds), _stream()), "slice_plan")
-            bounds[-1:] = total
-            plan = bounds.cpu().long()                                                   # one host sync
-            plan[-1] &= 0xFFFFFFFF
+            plan_dev = torch.empty(2 * P * KMAX + 1, dtype=torch.int32, device=dev)     # bounds | rels | total
+            _check(L.gs_slice_plan(P, N, KMAX, _ptr(cum), _ptr(total), T * slice_base, _ptr(plan_dev),
+                                   ctypes.c_void_p(plan_dev.data_ptr() + 4 * P * KMAX), _stream()), "slice_plan")
+            plan_dev[-1:] = total
+            plan = plan_dev.cpu().long() & 0xFFFFFFFF                                    # one host sync
+            rel_at = plan[P * KMAX:2 * P * KMAX].view(P, KMAX).tolist()
         n_total = int(plan[-1])
-        b = plan[:-1].view(P, KMAX).tolist()
+        b = plan[:P * KMAX].view(P, KMAX).tolist()
         # number of slices: up to the first k whose boundary reaches N in every sub-pose
         K = KMAX
         for k in range(KMAX):
@@ -305,8 +306,9 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                 K = k + 1
                 break
     else:
-        n_total = int(total.item())
+        n_total = int(total.item()) & 0xFFFFFFFF
         b = [[N] for _ in range(P)]
+        rel_at = None
         K = 1
     last_num_intersects = n_total
     begins, prefixes, n_slices = [], [], []
@@ -338,7 +340,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     slices = []
     last_slice_intersects = []
     invalid_key = P * T if EXACT_TILE_CULL else 0
-    use_tuples = bool(GRAD_TUPLES) and RASTER_BWD_VARIANT != 1
+    use_tuples = bool(GRAD_TUPLES)
     for k in range(K):
         first, last = k == 0, k == K - 1
         n_k = n_slices[k]
@@ -354,8 +356,15 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                          _ptr(slice_gi),
                                          _ptr(counts), _stream()), "slice_counts")
                 cum_k, total_k = exclusive_scan_u32(counts)
-            if first:
-                I_k = int(total_k.item())          # host sync (one per slice)
+            if first and not holes0:
+                # every tile is open: the slice holds exactly the bounding-box intersections of its ranks,
+                # already known on the host from the plan read-back -> no sync
+                if K == 1:
+                    I_k = n_total
+                else:
+                    I_k = sum(rel_at[p][0] for p in range(P))
+            elif first:
+                I_k = int(total_k.item())          # host sync
             else:
                 # same sync also fetches how many tiles are still open after the previous slice
                 both = torch.cat([total_k, sat.view(P, -1)[:, -1].sum(dtype=torch.int32).reshape(1)]).tolist()
@@ -413,9 +422,8 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
     L = _L()
     H, W = img_height, img_width
     bwd_T = out_T.clone()
-    # reverse-traversal state: v2 keeps (behind-colour . v_out) as ONE float per pixel, the DPP
-    # reference kernel keeps the three channels
-    bwd_B = torch.zeros((S, H, W, 3) if RASTER_BWD_VARIANT == 1 else (S, H, W), device=records.device)
+    # reverse-traversal state: (behind-colour . v_out), ONE float per pixel
+    bwd_B = torch.zeros((S, H, W), device=records.device)
     dev = records.device
     for sl in reversed(slices):
         tuples = flags = None

@@ -148,7 +148,7 @@ int gs_map_gaussian_to_intersects(int N, const float* xys, const float* depths, 
 int gs_rasterize_fwd(const float* records, const int* sorted_vals, const int* tile_bins,
                      const int* band_edges /*R+1*/, const float* background /*3*/, int S, int R,
                      int img_height, int img_width, float* out_img /*S*H*W*3*/, float* out_T /*S*H*W*/,
-                     int* final_idx /*S*H*W*/, int variant /*0 = default kernel; 1 = branchy reference kernel*/,
+                     int* final_idx /*S*H*W*/, int variant /*0 = default; 1 = without the empty-pair skip (A/B)*/,
                      void* stream);
 /* v_records [P*N*12] is accumulated into with fp32 atomics (caller zeroes); v_alpha may be NULL. */
 int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* tile_bins,
@@ -161,9 +161,11 @@ int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* ti
  * composited.  The depth-ranked Gaussians are processed in front-to-back slices; a tile whose
  * pixels have all stopped is flagged done and later slices emit no intersections for it.  Every
  * pixel still sees the same Gaussians in the same order, so results equal the unsliced pass. */
-/* bounds[p*K+k] = first depth rank of sub-pose p whose cumulative intersection count reaches base<<k */
-int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl /*P*N, rank order*/, long long base,
-                  int* bounds /*P*K*/, void* stream);
+/* bounds[p*K+k] = first depth rank of sub-pose p whose cumulative intersection count reaches base<<k;
+ * rels[p*K+k] = that cumulative count at the boundary (sub-pose total when the boundary is N) */
+int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl /*P*N, rank order*/,
+                  const unsigned* total /*device: grand total of the scan*/, long long base,
+                  int* bounds /*P*K*/, unsigned* rels /*P*K*/, void* stream);
 /* sat [P*(tiles_y+1)*(tiles_x+1)] = summed-area table of tiles NOT done (tile_done u8 [P*T]) */
 int gs_tile_open_sat(int P, int img_height, int img_width, const unsigned char* tile_done, int* sat,
                      void* stream);
@@ -185,15 +187,15 @@ int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const i
                            const int* gi_of_e /*NULL: sorted_vals are Gaussian ids; else sorted_vals are emission
                                                 indices e and the Gaussian id is gi_of_e[e]*/,
                            int variant /*0 = default (skips pairs that touch no pixel); 1 = no skip*/, void* stream);
-/* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B (init = 0) carry state:
- * bwd_B is [S,H,W] for the default kernel (behind-colour . v_out), [S,H,W,3] for variant 1 */
+/* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B [S,H,W] (behind-colour . v_out, init = 0)
+ * carry the reverse-traversal state */
 int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                            const int* band_edges, const float* background, int S, int R, int img_height,
                            int img_width, const float* out_T, const int* final_idx, const float* v_img,
                            const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records,
                            const int* gi_of_e /*as in the forward*/,
                            float* tuples /*[I*12] or NULL*/, unsigned char* flags /*[I], zeroed, or NULL*/,
-                           int variant /*0 = default (LDS-transposed reduction); 1 = DPP reference kernel; 2 = timing ablation, no atomics (wrong gradients)*/,
+                           int variant /*0 = default; 2 = timing ablation: plain stores instead of atomics (wrong gradients)*/,
                            void* stream);
 
 /* Atomic-free gradient accumulation: with gi_of_e, tuples and flags given, gs_rasterize_bwd_slice writes the 9
