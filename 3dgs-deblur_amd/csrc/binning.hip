@@ -607,6 +607,77 @@ __global__ __launch_bounds__(256) void slice_counts_kernel(int n_slice, SliceDes
   counts[j] = c;
 }
 
+// Exact per-Gaussian counts: tiles of the box that are still open AND intersect the alpha >= 1/255
+// ellipse (tile_hit).  With exact counts the emission is compact — no culled pairs reach the tile sort,
+// the bin edges, the gradient tuples or their flags.  A wave owns 64 slice Gaussians; the summed-area
+// table rejects Gaussians without open tiles with four loads, small boxes are walked by their own
+// lane, large boxes (the nearest Gaussians cover hundreds of tiles) by the whole wave, 64 tiles per step.
+constexpr int kCountSolo = 12;
+
+__global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, SliceDesc sd, int N, int tiles_x,
+                                                                 int tiles_y, const unsigned* __restrict__ sorted_gi,
+                                                                 const float* __restrict__ records,
+                                                                 const int* __restrict__ sat,            // nullable
+                                                                 const unsigned char* __restrict__ done, // nullable
+                                                                 int W, int H, unsigned* __restrict__ slice_gi,
+                                                                 unsigned* __restrict__ counts) {
+  const int lane = lane_id();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  unsigned gi = 0, lo = 0, hi = 0;
+  int area = 0;
+  Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f};
+  if (j < n_slice) {
+    gi = sorted_gi[slice_rank(sd, j)];
+    const float* rec = records + (size_t)gi * kRecFloats;
+    lo = (unsigned)__float_as_int(rec[10]); hi = (unsigned)__float_as_int(rec[11]);
+    const int x0 = lo & 0xFFFF, y0 = lo >> 16, x1 = hi & 0xFFFF, y1 = hi >> 16;
+    area = (x1 - x0) * (y1 - y0);
+    if (area > 0 && sat) {
+      const int SW = tiles_x + 1;
+      const int* s = sat + (size_t)(gi / (unsigned)N) * SW * (tiles_y + 1);
+      if (s[y1 * SW + x1] - s[y0 * SW + x1] - s[y1 * SW + x0] + s[y0 * SW + x0] == 0) area = 0;
+    }
+    if (area > 0) el = make_ellipse(rec);
+    if (el.tau < 0.f) area = 0;
+  }
+  const unsigned T = (unsigned)(tiles_x * tiles_y);
+  unsigned cnt = 0;
+  if (area > 0 && area <= kCountSolo) {
+    const int x0 = lo & 0xFFFF, y0 = lo >> 16, x1 = hi & 0xFFFF, y1 = hi >> 16;
+    const unsigned pbase = (gi / (unsigned)N) * T;
+    for (int y = y0; y < y1; ++y)
+      for (int x = x0; x < x1; ++x)
+        if ((!done || done[pbase + (unsigned)(y * tiles_x + x)] == 0) && tile_hit(el, x, y, W, H)) ++cnt;
+  }
+  unsigned long long big = __ballot(area > kCountSolo);
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const unsigned g = (unsigned)readlane_i((int)gi, src);
+    const unsigned l = (unsigned)readlane_i((int)lo, src), h = (unsigned)readlane_i((int)hi, src);
+    Ellipse eg;
+    eg.gx = readlane_f(el.gx, src); eg.gy = readlane_f(el.gy, src); eg.a = readlane_f(el.a, src);
+    eg.b = readlane_f(el.b, src); eg.c = readlane_f(el.c, src); eg.tau = readlane_f(el.tau, src);
+    const int x0 = l & 0xFFFF, y0 = l >> 16, x1 = h & 0xFFFF, y1 = h >> 16;
+    const int w = x1 - x0, a = w * (y1 - y0);
+    const float rw = 1.0f / (float)w;
+    const unsigned pbase = (g / (unsigned)N) * T;
+    unsigned c = 0;
+    for (int base = 0; base < a; base += 64) {
+      const int t = base + lane;
+      bool ok = false;
+      if (t < a) {
+        const int q = (int)(((float)t + 0.5f) * rw);
+        const int tx = x0 + (t - q * w), ty = y0 + q;
+        ok = (!done || done[pbase + (unsigned)(ty * tiles_x + tx)] == 0) && tile_hit(eg, tx, ty, W, H);
+      }
+      c += (unsigned)__popcll(__ballot(ok));
+    }
+    if (lane == src) cnt = c;
+  }
+  if (j < n_slice) { slice_gi[j] = gi; counts[j] = cnt; }
+}
+
 // emission with holes, wave-cooperative: a wave owns 64 slice Gaussians; every Gaussian that still has
 // open tiles is expanded by the whole wave (64 tiles of its box per step, ballot-compacted), so one
 // huge box does not serialise a lane while the other 63 idle.  Order inside a Gaussian = (y, x).
@@ -617,7 +688,7 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
                                                         const float* __restrict__ records,
                                                         const unsigned char* __restrict__ done,
                                                         unsigned* __restrict__ keys, unsigned* __restrict__ vals,
-                                                        int W, int H, unsigned invalid_key) {
+                                                        int W, int H, unsigned invalid_key, int compact) {
   const int lane = lane_id();
   int j = blockIdx.x * 256 + threadIdx.x;
   unsigned cnt = 0, gi = 0, e0 = 0, lo = 0, hi = 0;
@@ -656,8 +727,11 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
         const int q = (int)(((float)t + 0.5f) * rw);
         const int tx = x0 + (t - q * w), ty = y0 + q;
         k = pbase + (unsigned)(ty * tiles_x + tx);
-        open = done[k] == 0;
-        if (open && invalid_key && !tile_hit(eg, tx, ty, W, H)) k = invalid_key;
+        open = !done || done[k] == 0;
+        if (open && invalid_key && !tile_hit(eg, tx, ty, W, H)) {
+          if (compact) open = false;      // counts are exact: culled pairs take no slot
+          else k = invalid_key;           // counts are box counts: park the slot behind every tile
+        }
       }
       const unsigned long long m = __ballot(open);
       if (open) {
@@ -868,16 +942,29 @@ GS_EXPORT int gs_slice_counts(int n_slice, int P, int N, const int* slice_begin,
   return gs_launch_status();
 }
 
+// Exact counts: open tiles that also pass the ellipse test (sat / tile_done NULL: every tile open).
+GS_EXPORT int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_begin, const int* slice_prefix,
+                                    const unsigned* sorted_gi, const float* records, const int* sat,
+                                    const unsigned char* tile_done, int H, int W, unsigned* slice_gi,
+                                    unsigned* counts, void* stream) {
+  if (n_slice <= 0 || P <= 0) return GS_ERR_INVALID;
+  int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
+  SliceDesc sd; sd.begin = slice_begin; sd.prefix = slice_prefix; sd.P = P;
+  hipLaunchKernelGGL(slice_counts_exact_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W, H, slice_gi, counts);
+  return gs_launch_status();
+}
+
 // Emit the intersections of a slice with the tiles that are still open (depth order preserved).
 GS_EXPORT int gs_emit_open_intersects(int n_slice, int N, int H, int W, const unsigned* slice_gi,
                                       const unsigned* counts, const unsigned* cum_excl, const float* records,
                                       const unsigned char* tile_done, unsigned* keys, unsigned* vals,
-                                      unsigned invalid_key, void* stream) {
+                                      unsigned invalid_key, int compact, void* stream) {
   if (n_slice <= 0) return GS_ERR_INVALID;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
   hipLaunchKernelGGL(emit_open_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice, N,
                      tiles_x * tiles_y, tiles_x, slice_gi, counts, cum_excl, records, tile_done, keys, vals, W, H,
-                     invalid_key);
+                     invalid_key, compact);
   return gs_launch_status();
 }
 

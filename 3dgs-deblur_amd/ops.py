@@ -35,6 +35,8 @@ SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "512"))
 EXACT_TILE_CULL = int(os.environ.get("GSD_EXACT_TILE_CULL", "1"))
 # atomic-free backward: per-entry gradient tuples + segmented reduce (0 = fp32 atomics into v_records)
 GRAD_TUPLES = int(os.environ.get("GSD_GRAD_TUPLES", "1"))
+# exact per-Gaussian hit counts -> compact emission (no culled pairs in the sort); needs EXACT_TILE_CULL
+COMPACT_EMIT = int(os.environ.get("GSD_COMPACT_EMIT", "1"))
 # depth pre-sort: 1 = per-sub-pose segments of 32-bit keys, 0 = one sort of 64-bit (sub-pose, depth) keys
 DEPTH_SORT_SEGMENTED = int(os.environ.get("GSD_DEPTH_SORT_SEGMENTED", "1"))
 last_slice_intersects = []
@@ -341,6 +343,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     last_slice_intersects = []
     invalid_key = P * T if EXACT_TILE_CULL else 0
     use_tuples = bool(GRAD_TUPLES)
+    compact = bool(COMPACT_EMIT) and bool(EXACT_TILE_CULL)
     for k in range(K):
         first, last = k == 0, k == K - 1
         n_k = n_slices[k]
@@ -351,12 +354,18 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                 slice_gi = torch.empty(n_k, dtype=torch.int32, device=dev)
                 counts = torch.empty(n_k, dtype=torch.int32, device=dev)
                 d = desc[k]
-                _check(L.gs_slice_counts(n_k, P, N, _ptr(d), ctypes.c_void_p(d.data_ptr() + 4 * P), _ptr(sorted_gi),
-                                         _ptr(records), None if (first and not holes0) else _ptr(sat), H, W,
-                                         _ptr(slice_gi),
-                                         _ptr(counts), _stream()), "slice_counts")
+                have_holes = (not first) or holes0
+                if compact:
+                    _check(L.gs_slice_counts_exact(n_k, P, N, _ptr(d), ctypes.c_void_p(d.data_ptr() + 4 * P),
+                                                   _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None,
+                                                   _ptr(tile_done) if have_holes else None, H, W, _ptr(slice_gi),
+                                                   _ptr(counts), _stream()), "slice_counts_exact")
+                else:
+                    _check(L.gs_slice_counts(n_k, P, N, _ptr(d), ctypes.c_void_p(d.data_ptr() + 4 * P),
+                                             _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None, H, W,
+                                             _ptr(slice_gi), _ptr(counts), _stream()), "slice_counts")
                 cum_k, total_k = exclusive_scan_u32(counts)
-            if first and not holes0:
+            if first and not holes0 and not compact:
                 # every tile is open: the slice holds exactly the bounding-box intersections of its ranks,
                 # already known on the host from the plan read-back -> no sync
                 if K == 1:
@@ -379,13 +388,15 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
             with _stage("emit"):
                 keys = torch.empty(I_k, dtype=torch.int32, device=dev)
                 vals = torch.empty(I_k, dtype=torch.int32, device=dev)
-                if first and not holes0:
+                if first and not holes0 and not compact:
                     _check(L.gs_emit_intersects(n_k, N, H, W, _ptr(slice_gi), _ptr(cum_k), _ptr(records), I_k,
                                                 _ptr(keys), _ptr(vals), invalid_key, _stream()), "emit intersects")
                 else:
                     _check(L.gs_emit_open_intersects(n_k, N, H, W, _ptr(slice_gi), _ptr(counts), _ptr(cum_k),
-                                                     _ptr(records), _ptr(tile_done), _ptr(keys), _ptr(vals),
-                                                     invalid_key, _stream()), "emit open intersects")
+                                                     _ptr(records),
+                                                     _ptr(tile_done) if ((not first) or holes0) else None,
+                                                     _ptr(keys), _ptr(vals), invalid_key, int(compact), _stream()),
+                           "emit open intersects")
             with _stage("tile_sort"):
                 if use_tuples:
                     # payload = emission index e (iota); the Gaussian id of a sorted entry is vals[e]

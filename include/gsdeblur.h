@@ -174,10 +174,17 @@ int gs_tile_open_sat(int P, int img_height, int img_width, const unsigned char* 
 int gs_slice_counts(int n_slice, int P, int N, const int* slice_begin /*P*/, const int* slice_prefix /*P+1*/,
                     const unsigned* sorted_gi, const float* records, const int* sat, int img_height,
                     int img_width, unsigned* slice_gi, unsigned* counts, void* stream);
+/* exact counts: tiles of the box that are open AND pass the ellipse test of gs_emit_*; with these counts and
+ * compact != 0 the emission holds no culled pairs at all (sat / tile_done NULL: every tile is open) */
+int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_begin, const int* slice_prefix,
+                          const unsigned* sorted_gi, const float* records, const int* sat,
+                          const unsigned char* tile_done, int img_height, int img_width, unsigned* slice_gi,
+                          unsigned* counts, void* stream);
 int gs_emit_open_intersects(int n_slice, int N, int img_height, int img_width, const unsigned* slice_gi,
                             const unsigned* counts, const unsigned* cum_excl, const float* records,
-                            const unsigned char* tile_done, unsigned* keys, unsigned* vals,
-                            unsigned invalid_key, void* stream);
+                            const unsigned char* tile_done /*NULL: all open*/, unsigned* keys, unsigned* vals,
+                            unsigned invalid_key, int compact /*1: counts are exact, culled pairs take no slot*/,
+                            void* stream);
 /* one launch per slice, front to back; out_img/out_T/live_T carry per-pixel state, tile_done is zeroed
  * by the caller before the first slice; first && last == the unsliced pass; final_idx is per slice */
 int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
