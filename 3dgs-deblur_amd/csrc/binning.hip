@@ -614,6 +614,9 @@ __global__ __launch_bounds__(256) void slice_counts_kernel(int n_slice, SliceDes
 // lane, large boxes (the nearest Gaussians cover hundreds of tiles) by the whole wave, 64 tiles per step.
 constexpr int kCountSolo = 12;
 
+// WAVE_PER_G: one Gaussian per wave (lane 0 owns it) — for slices of few, large Gaussians, where 64 big
+// boxes per wave would serialise ~25k tile tests in each of only a few hundred waves.
+template <bool WAVE_PER_G>
 __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, SliceDesc sd, int N, int tiles_x,
                                                                  int tiles_y, const unsigned* __restrict__ sorted_gi,
                                                                  const float* __restrict__ records,
@@ -622,7 +625,8 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
                                                                  int W, int H, unsigned* __restrict__ slice_gi,
                                                                  unsigned* __restrict__ counts) {
   const int lane = lane_id();
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = WAVE_PER_G ? (lane == 0 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : n_slice)
+                           : (int)(blockIdx.x * 256 + threadIdx.x);
   unsigned gi = 0, lo = 0, hi = 0;
   int area = 0;
   Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f};
@@ -681,6 +685,7 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
 // emission with holes, wave-cooperative: a wave owns 64 slice Gaussians; every Gaussian that still has
 // open tiles is expanded by the whole wave (64 tiles of its box per step, ballot-compacted), so one
 // huge box does not serialise a lane while the other 63 idle.  Order inside a Gaussian = (y, x).
+template <bool WAVE_PER_G>
 __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int T, int tiles_x,
                                                         const unsigned* __restrict__ slice_gi,
                                                         const unsigned* __restrict__ counts,
@@ -690,7 +695,8 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
                                                         unsigned* __restrict__ keys, unsigned* __restrict__ vals,
                                                         int W, int H, unsigned invalid_key, int compact) {
   const int lane = lane_id();
-  int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = WAVE_PER_G ? (lane == 0 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : n_slice)
+                           : (int)(blockIdx.x * 256 + threadIdx.x);
   unsigned cnt = 0, gi = 0, e0 = 0, lo = 0, hi = 0;
   Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f};
   if (j < n_slice) {
@@ -946,12 +952,17 @@ GS_EXPORT int gs_slice_counts(int n_slice, int P, int N, const int* slice_begin,
 GS_EXPORT int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_begin, const int* slice_prefix,
                                     const unsigned* sorted_gi, const float* records, const int* sat,
                                     const unsigned char* tile_done, int H, int W, unsigned* slice_gi,
-                                    unsigned* counts, void* stream) {
+                                    unsigned* counts, int wave_per_gaussian, void* stream) {
   if (n_slice <= 0 || P <= 0) return GS_ERR_INVALID;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
   SliceDesc sd; sd.begin = slice_begin; sd.prefix = slice_prefix; sd.P = P;
-  hipLaunchKernelGGL(slice_counts_exact_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W, H, slice_gi, counts);
+  if (wave_per_gaussian)
+    hipLaunchKernelGGL(slice_counts_exact_kernel<true>, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W, H, slice_gi, counts);
+  else
+    hipLaunchKernelGGL(slice_counts_exact_kernel<false>, dim3((n_slice + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W,
+                       H, slice_gi, counts);
   return gs_launch_status();
 }
 
@@ -959,12 +970,17 @@ GS_EXPORT int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_
 GS_EXPORT int gs_emit_open_intersects(int n_slice, int N, int H, int W, const unsigned* slice_gi,
                                       const unsigned* counts, const unsigned* cum_excl, const float* records,
                                       const unsigned char* tile_done, unsigned* keys, unsigned* vals,
-                                      unsigned invalid_key, int compact, void* stream) {
+                                      unsigned invalid_key, int compact, int wave_per_gaussian, void* stream) {
   if (n_slice <= 0) return GS_ERR_INVALID;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
-  hipLaunchKernelGGL(emit_open_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice, N,
-                     tiles_x * tiles_y, tiles_x, slice_gi, counts, cum_excl, records, tile_done, keys, vals, W, H,
-                     invalid_key, compact);
+  if (wave_per_gaussian)
+    hipLaunchKernelGGL(emit_open_kernel<true>, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream, n_slice, N,
+                       tiles_x * tiles_y, tiles_x, slice_gi, counts, cum_excl, records, tile_done, keys, vals, W, H,
+                       invalid_key, compact);
+  else
+    hipLaunchKernelGGL(emit_open_kernel<false>, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice,
+                       N, tiles_x * tiles_y, tiles_x, slice_gi, counts, cum_excl, records, tile_done, keys, vals, W, H,
+                       invalid_key, compact);
   return gs_launch_status();
 }
 

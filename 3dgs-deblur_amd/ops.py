@@ -355,11 +355,14 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                 counts = torch.empty(n_k, dtype=torch.int32, device=dev)
                 d = desc[k]
                 have_holes = (not first) or holes0
+                # few Gaussians with large boxes (the nearest slice): one wave per Gaussian
+                box_total = (n_total if K == 1 else sum(rel_at[p][0] for p in range(P))) if first else 0
+                wave_per_g = int(first and box_total > 32 * n_k)
                 if compact:
                     _check(L.gs_slice_counts_exact(n_k, P, N, _ptr(d), ctypes.c_void_p(d.data_ptr() + 4 * P),
                                                    _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None,
                                                    _ptr(tile_done) if have_holes else None, H, W, _ptr(slice_gi),
-                                                   _ptr(counts), _stream()), "slice_counts_exact")
+                                                   _ptr(counts), wave_per_g, _stream()), "slice_counts_exact")
                 else:
                     _check(L.gs_slice_counts(n_k, P, N, _ptr(d), ctypes.c_void_p(d.data_ptr() + 4 * P),
                                              _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None, H, W,
@@ -395,7 +398,8 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                     _check(L.gs_emit_open_intersects(n_k, N, H, W, _ptr(slice_gi), _ptr(counts), _ptr(cum_k),
                                                      _ptr(records),
                                                      _ptr(tile_done) if ((not first) or holes0) else None,
-                                                     _ptr(keys), _ptr(vals), invalid_key, int(compact), _stream()),
+                                                     _ptr(keys), _ptr(vals), invalid_key, int(compact), wave_per_g,
+                                                     _stream()),
                            "emit open intersects")
             with _stage("tile_sort"):
                 if use_tuples:

@@ -179,12 +179,13 @@ int gs_slice_counts(int n_slice, int P, int N, const int* slice_begin /*P*/, con
 int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_begin, const int* slice_prefix,
                           const unsigned* sorted_gi, const float* records, const int* sat,
                           const unsigned char* tile_done, int img_height, int img_width, unsigned* slice_gi,
-                          unsigned* counts, void* stream);
+                          unsigned* counts, int wave_per_gaussian /*1: one Gaussian per wave (few, large boxes)*/,
+                          void* stream);
 int gs_emit_open_intersects(int n_slice, int N, int img_height, int img_width, const unsigned* slice_gi,
                             const unsigned* counts, const unsigned* cum_excl, const float* records,
                             const unsigned char* tile_done /*NULL: all open*/, unsigned* keys, unsigned* vals,
                             unsigned invalid_key, int compact /*1: counts are exact, culled pairs take no slot*/,
-                            void* stream);
+                            int wave_per_gaussian, void* stream);
 /* one launch per slice, front to back; out_img/out_T/live_T carry per-pixel state, tile_done is zeroed
  * by the caller before the first slice; first && last == the unsliced pass; final_idx is per slice */
 int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
