@@ -19,8 +19,9 @@ _SIGS = {
     "gs_project_bwd": [_I, _P, _P, _F, _P, _P, _F, _F, _F, _F, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gs_sh_fwd": [_I, _I, _I, _P, _P, _P, _P],
     "gs_sh_bwd": [_I, _I, _I, _P, _P, _P, _P],
-    "gs_project_fused_fwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I,
+    "gs_project_fused_fwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I, _I,
                              _P, _P, _P, _P, _P],
+    "gs_slice_colors": [_I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P],
     "gs_project_fused_bwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I,
                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gs_pack_records": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],

@@ -249,6 +249,7 @@ struct FusedParams {
   const float* viewmats; // [P,16]
   float glob;
   int K_stride, deg, antialiased;
+  int defer_color;   // 1: leave rgb = 0, gs_slice_colors fills it for the Gaussians a depth slice actually emits
   Intrin in;
 };
 
@@ -266,10 +267,13 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
   scale_rot_to_cov3d(s, fp.glob, R, M, c3);
   const int nb = (fp.deg + 1) * (fp.deg + 1);
   float coef[MAXB * 3];
-  {
+  if (!fp.defer_color) {
     const float* c = fp.sh + (size_t)i * fp.K_stride * 3;
 #pragma unroll
     for (int k = 0; k < MAXB * 3; ++k) coef[k] = (k < nb * 3) ? c[k] : 0.f;
+  } else {
+#pragma unroll
+    for (int k = 0; k < MAXB * 3; ++k) coef[k] = 0.f;
   }
   for (int p = 0; p < fp.P; ++p) {
     const float* V = fp.viewmats + 16 * p;
@@ -288,14 +292,17 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
       float czw = -(Vm[2] * Vm[3] + Vm[6] * Vm[7] + Vm[10] * Vm[11]);
       float dx = m[0] - cxw, dy = m[1] - cyw, dz = m[2] - czw;
       float dinv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-      float B[MAXB];
-      sh_basis(fp.deg, dx * dinv, dy * dinv, dz * dinv, B);
-      float cr = 0.5f, cg = 0.5f, cb = 0.5f;
+      float cr = 0.f, cg = 0.f, cb = 0.f;
+      if (!fp.defer_color) {
+        float B[MAXB];
+        sh_basis(fp.deg, dx * dinv, dy * dinv, dz * dinv, B);
+        cr = 0.5f; cg = 0.5f; cb = 0.5f;
 #pragma unroll
-      for (int b = 0; b < MAXB; ++b) {
-        if (b < nb) { cr += B[b] * coef[3 * b]; cg += B[b] * coef[3 * b + 1]; cb += B[b] * coef[3 * b + 2]; }
+        for (int b = 0; b < MAXB; ++b) {
+          if (b < nb) { cr += B[b] * coef[3 * b]; cg += B[b] * coef[3 * b + 1]; cb += B[b] * coef[3 * b + 2]; }
+        }
+        cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
       }
-      cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
       float op = fp.antialiased ? opac * o.comp : opac;
       r[0] = make_float4(o.x, o.y, o.conic_x, o.conic_y);
       r[1] = make_float4(o.conic_z, op, cr, cg);
@@ -406,6 +413,41 @@ __global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, 
   for (int k = MAXB * 3; k < kn; ++k) c[k] = 0.f;
 }
 
+// Deferred SH colour: with early termination only a few percent of the Gaussians are ever composited, so
+// the fused projection can skip the 192-byte SH read and the per-sub-pose evaluation for everyone and this
+// kernel colours just the Gaussians a depth slice emits (counts[j] > 0).  Same arithmetic as the fused
+// kernel (basis, +0.5, clamp >= 0).
+template <int MAXB>
+__global__ __launch_bounds__(256) void slice_colors_kernel(int n_slice, const unsigned* __restrict__ slice_gi,
+                                                           const unsigned* __restrict__ counts, int N,
+                                                           const float* __restrict__ means,
+                                                           const float* __restrict__ sh, int K_stride, int deg,
+                                                           const float* __restrict__ viewmats,
+                                                           float* __restrict__ records) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_slice || counts[j] == 0) return;
+  const unsigned gi = slice_gi[j];
+  const unsigned p = gi / (unsigned)N, g = gi - p * (unsigned)N;
+  const float* V = viewmats + 16 * p;
+  const float m0 = means[3 * g], m1 = means[3 * g + 1], m2 = means[3 * g + 2];
+  float cxw = -(V[0] * V[3] + V[4] * V[7] + V[8] * V[11]);
+  float cyw = -(V[1] * V[3] + V[5] * V[7] + V[9] * V[11]);
+  float czw = -(V[2] * V[3] + V[6] * V[7] + V[10] * V[11]);
+  float dx = m0 - cxw, dy = m1 - cyw, dz = m2 - czw;
+  float dinv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+  float B[MAXB];
+  sh_basis(deg, dx * dinv, dy * dinv, dz * dinv, B);
+  const int nb = (deg + 1) * (deg + 1);
+  const float* c = sh + (size_t)g * K_stride * 3;
+  float cr = 0.5f, cg = 0.5f, cb = 0.5f;
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    if (b < nb) { cr += B[b] * c[3 * b]; cg += B[b] * c[3 * b + 1]; cb += B[b] * c[3 * b + 2]; }
+  }
+  float* r = records + (size_t)gi * kRecFloats;
+  r[6] = fmaxf(cr, 0.f); r[7] = fmaxf(cg, 0.f); r[8] = fmaxf(cb, 0.f);
+}
+
 }  // namespace gs
 
 using namespace gs;
@@ -501,10 +543,11 @@ GS_EXPORT int gs_unpack_record_grads(int N, const float* v_records, float* v_xys
 static inline FusedParams make_fused(int N, int P, const float* means, const float* scales, float glob,
                                      const float* quats, const float* opac, const float* sh, int K_stride, int deg,
                                      const float* viewmats, float fx, float fy, float cx, float cy, int H, int W,
-                                     float clip, int antialiased) {
+                                     float clip, int antialiased, int defer_color = 0) {
   FusedParams fp;
   fp.N = N; fp.P = P; fp.means = means; fp.scales = scales; fp.quats = quats; fp.opacities = opac; fp.sh = sh;
   fp.viewmats = viewmats; fp.glob = glob; fp.K_stride = K_stride; fp.deg = deg; fp.antialiased = antialiased;
+  fp.defer_color = defer_color;
   fp.in = make_intrin(fx, fy, cx, cy, H, W, clip);
   return fp;
 }
@@ -514,12 +557,12 @@ static inline FusedParams make_fused(int N, int P, const float* means, const flo
 GS_EXPORT int gs_project_fused_fwd(int N, int P, const float* means, const float* scales, float glob_scale,
                                    const float* quats, const float* opacities, const float* sh, int K_stride,
                                    int sh_degree, const float* viewmats, float fx, float fy, float cx, float cy,
-                                   int H, int W, float clip, int antialiased, float* records, unsigned* depth_keys,
-                                   int* num_tiles_hit, int* radii, void* stream) {
+                                   int H, int W, float clip, int antialiased, int defer_color, float* records,
+                                   unsigned* depth_keys, int* num_tiles_hit, int* radii, void* stream) {
   if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride)
     return GS_ERR_INVALID;
   FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmats,
-                              fx, fy, cx, cy, H, W, clip, antialiased);
+                              fx, fy, cx, cy, H, W, clip, antialiased, defer_color);
   dim3 grid((N + 255) / 256), block(256);
   if (sh_degree <= 3)
     hipLaunchKernelGGL(project_fused_fwd_kernel<16>, grid, block, 0, (hipStream_t)stream, fp, records, depth_keys,
@@ -527,6 +570,23 @@ GS_EXPORT int gs_project_fused_fwd(int N, int P, const float* means, const float
   else
     hipLaunchKernelGGL(project_fused_fwd_kernel<25>, grid, block, 0, (hipStream_t)stream, fp, records, depth_keys,
                        num_tiles_hit, radii);
+  return gs_launch_status();
+}
+
+// Colours (rgb = max(SH + 0.5, 0)) of the slice Gaussians with counts[j] > 0, written into their records;
+// pairs with gs_project_fused_fwd(defer_color = 1).
+GS_EXPORT int gs_slice_colors(int n_slice, const unsigned* slice_gi, const unsigned* counts, int N,
+                              const float* means, const float* sh, int K_stride, int sh_degree,
+                              const float* viewmats, float* records, void* stream) {
+  if (n_slice <= 0 || N <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride)
+    return GS_ERR_INVALID;
+  dim3 grid((n_slice + 255) / 256), block(256);
+  if (sh_degree <= 3)
+    hipLaunchKernelGGL(slice_colors_kernel<16>, grid, block, 0, (hipStream_t)stream, n_slice, slice_gi, counts, N,
+                       means, sh, K_stride, sh_degree, viewmats, records);
+  else
+    hipLaunchKernelGGL(slice_colors_kernel<25>, grid, block, 0, (hipStream_t)stream, n_slice, slice_gi, counts, N,
+                       means, sh, K_stride, sh_degree, viewmats, records);
   return gs_launch_status();
 }
 

@@ -37,6 +37,8 @@ EXACT_TILE_CULL = int(os.environ.get("GSD_EXACT_TILE_CULL", "1"))
 GRAD_TUPLES = int(os.environ.get("GSD_GRAD_TUPLES", "1"))
 # exact per-Gaussian hit counts -> compact emission (no culled pairs in the sort); needs EXACT_TILE_CULL
 COMPACT_EMIT = int(os.environ.get("GSD_COMPACT_EMIT", "1"))
+# deferred SH colour: the fused projection skips SH, each depth slice colours only the Gaussians it emits
+DEFER_COLOR = int(os.environ.get("GSD_DEFER_COLOR", "1"))
 # depth pre-sort: 1 = per-sub-pose segments of 32-bit keys, 0 = one sort of 64-bit (sub-pose, depth) keys
 DEPTH_SORT_SEGMENTED = int(os.environ.get("GSD_DEPTH_SORT_SEGMENTED", "1"))
 last_slice_intersects = []
@@ -276,7 +278,7 @@ def _depth_rank(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: i
 
 
 def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
-                   img_height: int, img_width: int, bg: Tensor, edges: Tensor, slice_base: int):
+                   img_height: int, img_width: int, bg: Tensor, edges: Tensor, slice_base: int, color=None):
     """Front-to-back depth-sliced bin + sort + composite.
     -> (out_img [S,H,W,3], out_T [S,H,W], slices) ; slices = list of (sorted_vals, tile_bins, final_idx, I_k)
     that the backward walks in reverse."""
@@ -368,6 +370,11 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                              _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None, H, W,
                                              _ptr(slice_gi), _ptr(counts), _stream()), "slice_counts")
                 cum_k, total_k = exclusive_scan_u32(counts)
+                if color is not None:
+                    # deferred SH colour for exactly the Gaussians this slice emits
+                    c_means, c_sh, c_K, c_deg, c_V = color
+                    _check(L.gs_slice_colors(n_k, _ptr(slice_gi), _ptr(counts), N, _ptr(c_means), _ptr(c_sh), c_K,
+                                             c_deg, _ptr(c_V), _ptr(records), _stream()), "slice_colors")
             if first and not holes0 and not compact:
                 # every tile is open: the slice holds exactly the bounding-box intersections of its ranks,
                 # already known on the host from the plan read-back -> no sync
@@ -744,13 +751,14 @@ class _RenderSubposes(Function):
         with _stage("project_fwd"):
             _check(L.gs_project_fused_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
                                           _ptr(sh), K, args[4], _ptr(V), args[5], args[6], args[7], args[8], H, W,
-                                          args[11], args[12], _ptr(records), _ptr(dkeys), _ptr(ntiles), _ptr(radii),
-                                          _stream()), "project_fused_fwd")
+                                          args[11], args[12], int(bool(DEFER_COLOR)), _ptr(records), _ptr(dkeys),
+                                          _ptr(ntiles), _ptr(radii), _stream()), "project_fused_fwd")
         bg = _background(background, dev)
         edges = _band_edges(H, R, dev)
         # SLICE_BASE == 0: one slice holding every intersection, through the very same kernels
         ctx.sliced = True
-        out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE)
+        color = (means3d, sh, K, args[4], V) if DEFER_COLOR else None
+        out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE, color)
         ctx.slices = slices
         svals = bins = fidx = torch.zeros(1, dtype=torch.int32, device=dev)
         n_isect = last_num_intersects

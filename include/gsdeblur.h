@@ -77,8 +77,13 @@ int gs_project_fused_fwd(int N, int P, const float* means3d, const float* scales
                          const float* sh /*N*K_stride*3*/, int K_stride, int sh_degree,
                          const float* viewmats /*P*16*/, float fx, float fy, float cx, float cy,
                          int img_height, int img_width, float clip_thresh, int antialiased,
+                         int defer_color /*1: leave rgb = 0 and skip the SH read; gs_slice_colors fills it later*/,
                          float* records /*P*N*12*/, unsigned* depth_keys /*P*N*/,
                          int* num_tiles_hit /*P*N*/, int* radii /*P*N or NULL*/, void* stream);
+/* deferred SH colour of the slice Gaussians with counts[j] > 0 (global index slice_gi[j] = p*N + g) */
+int gs_slice_colors(int n_slice, const unsigned* slice_gi, const unsigned* counts, int N, const float* means3d,
+                    const float* sh, int K_stride, int sh_degree, const float* viewmats, float* records,
+                    void* stream);
 /* v_viewmats [P*16] accumulated into (caller zeroes; NULL to skip). */
 int gs_project_fused_bwd(int N, int P, const float* means3d, const float* scales, float glob_scale,
                          const float* quats, const float* opacities, const float* sh, int K_stride,

@@ -418,6 +418,32 @@ def test_tuple_backward_equals_atomic_backward(gs, oracle, dev):
         assert rel_max(res[1][1][k].cpu(), res[0][1][k].cpu()) < 1e-4, k
 
 
+def test_deferred_colour_and_compact_emission_change_nothing(gs, oracle, dev):
+    """Deferred SH colouring (only emitted Gaussians are coloured) and compact emission (exact hit counts) are
+    pure work-avoidance: images bit-identical, gradients equal up to summation order."""
+    from gsdeblur_amd import ops
+    O = oracle
+    W, H, n = 216, 168, 7000
+    sc = O.synthetic_scene(n, W, H, seed=321, scale_mult=6.5)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10
+    bg = torch.tensor([0.15, 0.25, 0.05])
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(8))
+    res = {}
+    old = (ops.DEFER_COLOR, ops.COMPACT_EMIT, ops.SLICE_BASE)
+    try:
+        for mode in ((0, 0), (1, 1), (1, 0), (0, 1)):
+            ops.DEFER_COLOR, ops.COMPACT_EMIT = mode
+            ops.SLICE_BASE = 16
+            out, alpha, samples, vms, p, radii = _run_full(gs, O, dev, sc, H, W, 2, 2, 1 / 60, 1 / 30, 2.2, 10.0, 3, bg, wt)
+            res[mode] = (samples.detach().clone(), {k: v.grad.detach().clone() for k, v in p.items()})
+    finally:
+        ops.DEFER_COLOR, ops.COMPACT_EMIT, ops.SLICE_BASE = old
+    for mode in ((1, 1), (1, 0), (0, 1)):
+        assert torch.equal(res[(0, 0)][0], res[mode][0]), mode
+        for k in res[mode][1]:
+            assert rel_max(res[mode][1][k].cpu(), res[(0, 0)][1][k].cpu()) < 1e-4, (mode, k)
+
+
 def test_exact_tile_culling_changes_nothing(gs, oracle, dev):
     """Culling (Gaussian, tile) pairs whose pixel rectangle lies outside the alpha >= 1/255 ellipse must
     leave the image BIT-IDENTICAL (the pairs contributed exactly nothing) and the gradients equal up to
@@ -475,7 +501,7 @@ def test_properties_at_scale(gs, oracle, dev):
     nt = torch.empty(N, dtype=torch.int32, device=dev)
     gs._lib.check(L.gs_project_fused_fwd(N, 1, ops._ptr(sc["means"]), ops._ptr(scales.contiguous()), 1.0,
                                          ops._ptr(sc["quats"]), ops._ptr(opac.contiguous()), ops._ptr(sh), 16, 3,
-                                         ops._ptr(vm1), sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, 0.01, 1,
+                                         ops._ptr(vm1), sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, 0.01, 1, 0,
                                          ops._ptr(rec), ops._ptr(dk), ops._ptr(nt), None, ops._stream()), "fused")
     svals, bins, I, skeys = gs.bin_and_sort_records(rec, dk, nt, 1, N, H, W)
     assert I == int(nt.long().sum().item())

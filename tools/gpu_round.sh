@@ -22,7 +22,7 @@ if [ "$MODE" = "full" ]; then
 fi
 echo "== bench x2 (no cpu baseline) ==" | tee -a $OUT/summary.log
 for v in 0 1 0 1; do
-  GSD_COMPACT_EMIT=$v timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+  GSD_DEFER_COLOR=$v timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
