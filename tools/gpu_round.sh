@@ -21,8 +21,8 @@ if [ "$MODE" = "full" ]; then
   (hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -Wno-unused-value tools/atomic_bench.hip -o /tmp/atomic_bench && timeout 120 /tmp/atomic_bench) 2>&1 | tail -12 | tee -a $OUT/summary.log
 fi
 echo "== bench x2 (no cpu baseline) ==" | tee -a $OUT/summary.log
-for v in 0 1 0 1; do
-  GSD_DEFER_COLOR=$v timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+for v in 1 2; do
+  timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
