@@ -28,30 +28,28 @@ __global__ void subpose_fwd_kernel(int P, const float* __restrict__ V0, const fl
   out[16 * p + 12] = 0.f; out[16 * p + 13] = 0.f; out[16 * p + 14] = 0.f; out[16 * p + 15] = 1.f;
 }
 
-// one thread per sub-pose pushes 18 tangents (12 viewmat, 3 lin, 3 ang) through the
-// closed form; P is tiny (<= ~100) so the per-thread cost is irrelevant.
+// one thread per (sub-pose, input tangent): thread (p, t) seeds input t of the 18 (12 viewmat, 3 lin, 3 ang)
+// with a unit dual part and pushes it through the closed form — a Dual<1> chain is short enough to stay in
+// registers, where the former one-thread-per-sub-pose Dual<18> version spilled (41 us for 5 sub-poses).
 __global__ void subpose_bwd_kernel(int P, const float* __restrict__ V0, const float* __restrict__ lin,
                                    const float* __restrict__ ang, const float* __restrict__ times,
                                    const float* __restrict__ v_out, float* __restrict__ v_V0,
                                    float* __restrict__ v_lin, float* __restrict__ v_ang) {
-  typedef Dual<18> D;
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
+  typedef Dual<1> D;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= P * 18) return;
+  const int p = gid / 18, t = gid - p * 18;
   D dV[12], dl[3], da[3], o[12];
-  for (int j = 0; j < 12; ++j) { dV[j] = D(V0[j]); dV[j].d[j] = 1.f; }
+  for (int j = 0; j < 12; ++j) { dV[j] = D(V0[j]); dV[j].d[0] = (j == t) ? 1.f : 0.f; }
   for (int j = 0; j < 3; ++j) {
-    dl[j] = D(lin[j]); dl[j].d[12 + j] = 1.f;
-    da[j] = D(ang[j]); da[j].d[15 + j] = 1.f;
+    dl[j] = D(lin[j]); dl[j].d[0] = (12 + j == t) ? 1.f : 0.f;
+    da[j] = D(ang[j]); da[j].d[0] = (15 + j == t) ? 1.f : 0.f;
   }
   subpose_viewmat<D>(dV, dl, da, D(times[p]), o);
-  float acc[18];
-  for (int t = 0; t < 18; ++t) acc[t] = 0.f;
-  for (int j = 0; j < 12; ++j) {
-    float g = v_out[16 * p + j];
-    for (int t = 0; t < 18; ++t) acc[t] += g * o[j].d[t];
-  }
-  for (int t = 0; t < 12; ++t) atomic_add_f32(v_V0 + t, acc[t]);
-  for (int t = 0; t < 3; ++t) { atomic_add_f32(v_lin + t, acc[12 + t]); atomic_add_f32(v_ang + t, acc[15 + t]); }
+  float acc = 0.f;
+  for (int j = 0; j < 12; ++j) acc += v_out[16 * p + j] * o[j].d[0];
+  float* dst = t < 12 ? v_V0 + t : (t < 15 ? v_lin + (t - 12) : v_ang + (t - 15));
+  atomic_add_f32(dst, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -318,22 +316,13 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
   }
 }
 
+// Body shared by the two launch shapes below: Gaussian `i` of this thread (`live` false = idle lane that only
+// takes part in the block reductions).  MUST be called block-uniformly (it contains barriers).
 template <int MAXB>
-__global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, const float* __restrict__ records,
+__device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const float* __restrict__ records,
     const float* __restrict__ v_records, float* __restrict__ v_means, float* __restrict__ v_scales,
     float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
-    float* __restrict__ v_viewmats /* [P,16] accumulated, may be null */,
-    const unsigned char* __restrict__ touched /* [P*N] or null: 0 => v_records row is all-zero, not read */) {
-  __shared__ float lds[48];
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool live = i < fp.N;
-  if (touched && live) {
-    // with touched flags the caller pre-zeroes every output: a Gaussian no sub-pose touched (the vast
-    // majority under early termination) neither reads its 59 parameters nor writes its 59 gradients
-    bool any = false;
-    for (int p = 0; p < fp.P; ++p) any |= touched[(size_t)p * fp.N + i] != 0;
-    live = any;
-  }
+    float* __restrict__ v_viewmats, const unsigned char* __restrict__ touched, int i, bool live, float* lds) {
   const int ii = live ? i : 0;
   float m[3] = {0.f, 0.f, 1.f}, s[3] = {1.f, 1.f, 1.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, opac = 0.f;
   if (live) {
@@ -360,12 +349,13 @@ __global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, 
     for (int j = 0; j < 12; ++j) vV[j] = 0.f;
     // early termination leaves most Gaussians without any gradient: their records are neither read nor
     // re-projected (the compositor's tuple reduce marks the ones it touched)
-    if (live && (!touched || touched[(size_t)p * fp.N + i])) {
+    const bool mine = live && (!touched || touched[(size_t)p * fp.N + ii]);
+    if (mine) {
       Proj o; ProjCtx k;
       bool ok = project_one(m, c3, Vm, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x,
                             fp.in.tiles_y, fp.in.clip, o, k);
       if (ok) {
-        size_t idx = (size_t)p * fp.N + i;
+        size_t idx = (size_t)p * fp.N + ii;
         const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kRecFloats);
         float4 ga = g4[0], gb = g4[1], gc = g4[2];
         const float4* r4 = reinterpret_cast<const float4*>(records + idx * kRecFloats);
@@ -395,9 +385,8 @@ __global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, 
         for (int j = 0; j < 6; ++j) vc3[j] += vc31[j];
       }
     }
-    // block-uniform skip: most 256-Gaussian blocks hold nothing the compositor touched
-    if (v_viewmats && __syncthreads_or(live && (!touched || touched[(size_t)p * fp.N + i])))
-      reduce_vV(vV, v_viewmats + 16 * p, lds);
+    // block-uniform skip: most blocks hold nothing the compositor touched in this sub-pose
+    if (v_viewmats && __syncthreads_or(mine)) reduce_vV(vV, v_viewmats + 16 * p, lds);
   }
   if (!live) return;
   float vs[3], vq[4];
@@ -411,6 +400,58 @@ __global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, 
   for (int k = 0; k < MAXB * 3; ++k)   // static indices only: a runtime index would push vcoef to scratch
     if (k < kn) c[k] = vcoef[k];
   for (int k = MAXB * 3; k < kn; ++k) c[k] = 0.f;
+}
+
+// dense launch: one thread per Gaussian (no touched flags: every Gaussian gets its gradient written)
+template <int MAXB>
+__global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, const float* __restrict__ records,
+    const float* __restrict__ v_records, float* __restrict__ v_means, float* __restrict__ v_scales,
+    float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
+    float* __restrict__ v_viewmats /* [P,16] accumulated, may be null */) {
+  __shared__ float lds[48];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  fused_bwd_body<MAXB>(fp, records, v_records, v_means, v_scales, v_quats, v_opac, v_sh, v_viewmats, nullptr, i,
+                       i < fp.N, lds);
+}
+
+// sparse launch (touched flags; the caller pre-zeroes every output): under early termination ~1 % of the
+// Gaussians carry a gradient and they are scattered, so with one thread per Gaussian nearly every wave ran
+// the whole body for one or two lanes.  A block owns kFusedChunk consecutive Gaussians, compacts the ids of
+// the touched ones into LDS (ballot + prefix, deterministic order) and runs the body on dense rounds of 256.
+constexpr int kFusedChunk = 2048;
+
+template <int MAXB>
+__global__ __launch_bounds__(256) void project_fused_bwd_sparse_kernel(FusedParams fp,
+    const float* __restrict__ records, const float* __restrict__ v_records, float* __restrict__ v_means,
+    float* __restrict__ v_scales, float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
+    float* __restrict__ v_viewmats, const unsigned char* __restrict__ touched /* [P*N] */) {
+  __shared__ float lds[48];
+  __shared__ int list[kFusedChunk];
+  __shared__ int wave_cnt[4];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int base = blockIdx.x * kFusedChunk;
+  int n_list = 0;
+  for (int r = 0; r < kFusedChunk / 256; ++r) {
+    const int g = base + r * 256 + (int)threadIdx.x;
+    bool any = false;
+    if (g < fp.N)
+      for (int p = 0; p < fp.P; ++p) any |= touched[(size_t)p * fp.N + g] != 0;
+    const unsigned long long bal = __ballot(any);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int off = n_list, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int c = wave_cnt[w]; if (w < wave) off += c; total += c; }
+    if (any) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = g;
+    n_list += total;
+    __syncthreads();
+  }
+  for (int k0 = 0; k0 < n_list; k0 += 256) {
+    const int k = k0 + (int)threadIdx.x;
+    const bool live = k < n_list;
+    fused_bwd_body<MAXB>(fp, records, v_records, v_means, v_scales, v_quats, v_opac, v_sh, v_viewmats, touched,
+                         live ? list[k] : 0, live, lds);
+  }
 }
 
 // Deferred SH colour: with early termination only a few percent of the Gaussians are ever composited, so
@@ -473,7 +514,7 @@ GS_EXPORT int gs_subpose_viewmats_bwd(int P, const float* viewmat, const float* 
                                       const float* times, const float* v_out, float* v_viewmat, float* v_lin,
                                       float* v_ang, void* stream) {
   if (P <= 0) return GS_ERR_INVALID;
-  hipLaunchKernelGGL(subpose_bwd_kernel, dim3((P + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, viewmat, lin_vel,
+  hipLaunchKernelGGL(subpose_bwd_kernel, dim3((P * 18 + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, viewmat, lin_vel,
                      ang_vel, times, v_out, v_viewmat, v_lin, v_ang);
   return gs_launch_status();
 }
@@ -602,12 +643,24 @@ GS_EXPORT int gs_project_fused_bwd(int N, int P, const float* means, const float
     return GS_ERR_INVALID;
   FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmats,
                               fx, fy, cx, cy, H, W, clip, antialiased);
-  dim3 grid((N + 255) / 256), block(256);
-  if (sh_degree <= 3)
-    hipLaunchKernelGGL(project_fused_bwd_kernel<16>, grid, block, 0, (hipStream_t)stream, fp, records, v_records,
-                       v_means, v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched);
-  else
-    hipLaunchKernelGGL(project_fused_bwd_kernel<25>, grid, block, 0, (hipStream_t)stream, fp, records, v_records,
-                       v_means, v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched);
+  dim3 block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (touched) {
+    dim3 grid((N + kFusedChunk - 1) / kFusedChunk);
+    if (sh_degree <= 3)
+      hipLaunchKernelGGL(project_fused_bwd_sparse_kernel<16>, grid, block, 0, st, fp, records, v_records, v_means,
+                         v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched);
+    else
+      hipLaunchKernelGGL(project_fused_bwd_sparse_kernel<25>, grid, block, 0, st, fp, records, v_records, v_means,
+                         v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched);
+  } else {
+    dim3 grid((N + 255) / 256);
+    if (sh_degree <= 3)
+      hipLaunchKernelGGL(project_fused_bwd_kernel<16>, grid, block, 0, st, fp, records, v_records, v_means, v_scales,
+                         v_quats, v_opacities, v_sh, v_viewmats);
+    else
+      hipLaunchKernelGGL(project_fused_bwd_kernel<25>, grid, block, 0, st, fp, records, v_records, v_means, v_scales,
+                         v_quats, v_opacities, v_sh, v_viewmats);
+  }
   return gs_launch_status();
 }

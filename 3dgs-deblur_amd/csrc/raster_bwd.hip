@@ -1,8 +1,9 @@
 // raster_bwd.hip — reverse-order backward of the compositor and the atomic-free gradient reduce.
-// Split from raster.hip because this translation unit is compiled with -fno-slp-vectorize: the SLP
-// vectoriser packs the four per-pixel chains into v_pk_*_f32 pairs, which on gfx950 issue at the scalar
-// rate but need v_mov shuffles to assemble (128 -> 99 VGPRs, -14 % kernel time measured); the forward
-// kernel is marginally faster WITH packing, so it keeps the default flags.
+// Split from raster.hip because this translation unit is compiled with -fno-slp-vectorize: left to itself the
+// SLP vectoriser packs the four per-pixel chains into v_pk_*_f32 pairs but needs v_mov shuffles to assemble
+// them (128 -> 99 VGPRs, -14 % kernel time with SLP off).  The packing that pays is done BY HAND instead
+// (GS_BWD_PK: the lane's four pixels are two float2 pairs from load to store, non-hit pixels neutralised by
+// selects instead of exec regions: ~160 -> ~126 VALU per hit entry, -5 % kernel time measured, run 29).
 #include "raster_common.h"
 
 namespace gs {
@@ -29,6 +30,11 @@ constexpr int kRedFloats = kRedG * 9 * kRedStride + 64 * 9;
 // OUT = 1: no atomics at all — the entry's 9 gradients go to tuples[e] (48 B, e = emission index of the
 // entry, so the tuples of one Gaussian are CONTIGUOUS) and flags[e] = 1; gs_reduce_grad_tuples then sums
 // each Gaussian's segment.  At ~20 G atomic ops/s the atomics were 40 % of this kernel.
+#ifndef GS_BWD_PK
+#define GS_BWD_PK 1     // 1: hand-packed float2 hit part + row sums (v_pk_*_f32); 0: scalar chains with per-pixel exec regions
+#endif
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef GS_BWD_WAVES
 #define GS_BWD_WAVES 4   // 128 VGPRs + 38 KB LDS per block -> 4 waves per SIMD (+3.5 % measured)
 #endif
@@ -67,6 +73,9 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
   // behind-colour with v_out is ever needed, so one float replaces the three colour channels.
   float Tk[4], Dv[4], vr[4], vg[4], vb[4], pyf[4];
   int fin[4];
+#if GS_BWD_PK
+  f2 Tk2[2], Dv2[2], vr2[2], vg2[2], vb2[2], pyf2[2];
+#endif
   int my_end = range.x;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -90,6 +99,14 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
     my_end = max(my_end, fin[k]);
   }
   const int wave_end = __builtin_amdgcn_readfirstlane(wave_max_i(my_end));
+#if GS_BWD_PK
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    Tk2[h] = f2{Tk[2 * h], Tk[2 * h + 1]}; Dv2[h] = f2{Dv[2 * h], Dv[2 * h + 1]};
+    vr2[h] = f2{vr[2 * h], vr[2 * h + 1]}; vg2[h] = f2{vg[2 * h], vg[2 * h + 1]}; vb2[h] = f2{vb[2 * h], vb[2 * h + 1]};
+    pyf2[h] = f2{pyf[2 * h], pyf[2 * h + 1]};
+  }
+#endif
   const int* __restrict__ vals = prm.sorted_vals;
   const float kL2E = -1.4426950408889634f;
   const int row = lane;                        // row-sum role: lanes 0..35
@@ -115,6 +132,62 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
       const float dx = gx - pxf;
       const float hx = qx * dx * dx;             // exponent terms, pre-scaled by -log2(e)
       const float bx = qy * dx;
+#if GS_BWD_PK
+      // hand-packed variant: the four pixels of a lane are two float2 pairs, every multiply-add of the hit
+      // part is one v_pk_*_f32 per pair; pixels that are not hit are neutralised by SELECTING alpha = 0
+      // (1/(1-0) = 1 exactly, every contribution is an exact zero) instead of per-pixel exec regions
+      f2 dy2[2], vis2[2], ov2[2];
+      bool hit[4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        dy2[h] = gy - pyf2[h];
+        const f2 s2 = hx + dy2[h] * (bx + qz * dy2[h]);
+        vis2[h] = f2{__builtin_amdgcn_exp2f(s2.x), __builtin_amdgcn_exp2f(s2.y)};
+        ov2[h] = op * vis2[h];
+        hit[2 * h] = (idx_j < fin[2 * h]) && (s2.x <= 0.f) && (fminf(K::kAlphaMax, ov2[h].x) >= K::kAlphaMin);
+        hit[2 * h + 1] = (idx_j < fin[2 * h + 1]) && (s2.y <= 0.f) && (fminf(K::kAlphaMax, ov2[h].y) >= K::kAlphaMin);
+      }
+      if (__ballot(hit[0] || hit[1] || hit[2] || hit[3]) != 0ull) {
+        const float cx = readlane_f(rec.cx, j), cy = readlane_f(rec.cy, j), cz = readlane_f(rec.cz, j);
+        const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
+        const float hdx2 = 0.5f * dx * dx;
+        const float cxdx = cx * dx, cydx = cy * dx;
+        f2 q_x = {0.f, 0.f}, q_y = q_x, q_cx = q_x, q_cy = q_x, q_cz = q_x, q_op = q_x, q_r = q_x, q_g = q_x, q_b = q_x;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool h0 = hit[2 * h], h1 = hit[2 * h + 1];
+          const f2 alpha = {h0 ? fminf(K::kAlphaMax, ov2[h].x) : 0.f, h1 ? fminf(K::kAlphaMax, ov2[h].y) : 0.f};
+          const f2 om = 1.f - alpha;
+          const f2 ra = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+          Tk2[h] *= ra;                          // transmittance in front of this Gaussian
+          const f2 fac = alpha * Tk2[h];
+          q_r += fac * vr2[h]; q_g += fac * vg2[h]; q_b += fac * vb2[h];
+          const f2 cv = cr * vr2[h] + cg * vg2[h] + cb * vb2[h];
+          const f2 v_al = Tk2[h] * cv - ra * Dv2[h];
+          Dv2[h] += fac * cv;
+          // d min(0.999, o*vis) = 0 when clamped
+          const bool f0 = h0 && ov2[h].x <= K::kAlphaMax, f1 = h1 && ov2[h].y <= K::kAlphaMax;
+          const f2 ovm = {f0 ? ov2[h].x : 0.f, f1 ? ov2[h].y : 0.f};
+          const f2 vism = {f0 ? vis2[h].x : 0.f, f1 ? vis2[h].y : 0.f};
+          const f2 v_sigma = -ovm * v_al;
+          q_op += vism * v_al;
+          const f2 vsdy = v_sigma * dy2[h];
+          q_cx += v_sigma * hdx2;
+          q_cy += vsdy * dx;
+          q_cz += vsdy * dy2[h];                 // * 0.5 below
+          q_x += v_sigma * (cxdx + cy * dy2[h]);
+          q_y += v_sigma * (cydx + cz * dy2[h]);
+        }
+        const float p_x = q_x.x + q_x.y, p_y = q_y.x + q_y.y, p_cx = q_cx.x + q_cx.y, p_cy = q_cy.x + q_cy.y,
+                    p_cz = 0.5f * (q_cz.x + q_cz.y), p_op = q_op.x + q_op.y, p_r = q_r.x + q_r.y,
+                    p_g = q_g.x + q_g.y, p_b = q_b.x + q_b.y;
+        filled |= 1u << g;
+        float* r0 = red + g * (9 * kRedStride) + lane;
+        r0[0 * kRedStride] = p_x;  r0[1 * kRedStride] = p_y;  r0[2 * kRedStride] = p_cx;
+        r0[3 * kRedStride] = p_cy; r0[4 * kRedStride] = p_cz; r0[5 * kRedStride] = p_op;
+        r0[6 * kRedStride] = p_r;  r0[7 * kRedStride] = p_g;  r0[8 * kRedStride] = p_b;
+      }
+#else
       float vis[4], ov[4];
       bool hit[4];
 #pragma unroll
@@ -160,10 +233,19 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
         r0[3 * kRedStride] = p_cy; r0[4 * kRedStride] = p_cz; r0[5 * kRedStride] = p_op;
         r0[6 * kRedStride] = p_r;  r0[7 * kRedStride] = p_g;  r0[8 * kRedStride] = p_b;
       }
+#endif
       if (g == kRedG - 1 || j == n - 1) {
         if (filled) {
           __builtin_amdgcn_wave_barrier();
           if (row < kRedG * 9 && ((filled >> row_g) & 1u)) {
+#if GS_BWD_PK
+            const f4* rp = reinterpret_cast<const f4*>(red + row * kRedStride);
+            f4 a0 = rp[0], a1 = rp[1], a2 = rp[2], a3 = rp[3];
+#pragma unroll
+            for (int q = 4; q < 16; q += 4) { a0 += rp[q]; a1 += rp[q + 1]; a2 += rp[q + 2]; a3 += rp[q + 3]; }
+            const f4 v = (a0 + a1) + (a2 + a3);
+            const float sum = (v.x + v.y) + (v.z + v.w);
+#else
             const float4* rp = reinterpret_cast<const float4*>(red + row * kRedStride);
             float4 a0 = rp[0], a1 = rp[1], a2 = rp[2], a3 = rp[3];
 #pragma unroll
@@ -176,6 +258,7 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
             }
             const float sum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
                               ((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w));
+#endif
             const int jj = gbase + row_g;                   // batch position of this row's Gaussian
             tot[jj * 9 + row_c] = sum;
           }
@@ -215,6 +298,12 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
     __builtin_amdgcn_wave_barrier();
   }
   if (STATE) {
+#if GS_BWD_PK
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      Tk[2 * h] = Tk2[h].x; Tk[2 * h + 1] = Tk2[h].y; Dv[2 * h] = Dv2[h].x; Dv[2 * h + 1] = Dv2[h].y;
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int y = py0 + k;
