@@ -322,7 +322,8 @@ template <int MAXB>
 __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const float* __restrict__ records,
     const float* __restrict__ v_records, float* __restrict__ v_means, float* __restrict__ v_scales,
     float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
-    float* __restrict__ v_viewmats, const unsigned char* __restrict__ touched, int i, bool live, float* lds) {
+    float* __restrict__ v_viewmats, const unsigned char* __restrict__ touched, float* __restrict__ v_xy_sum,
+    int i, bool live, float* lds) {
   const int ii = live ? i : 0;
   float m[3] = {0.f, 0.f, 1.f}, s[3] = {1.f, 1.f, 1.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, opac = 0.f;
   if (live) {
@@ -338,7 +339,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
   float vcoef[MAXB * 3];
 #pragma unroll
   for (int k = 0; k < MAXB * 3; ++k) vcoef[k] = 0.f;
-  float vm[3] = {0.f, 0.f, 0.f}, vc3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vop = 0.f;
+  float vm[3] = {0.f, 0.f, 0.f}, vc3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vop = 0.f, vxs = 0.f, vys = 0.f;
   for (int p = 0; p < fp.P; ++p) {
     const float* V = fp.viewmats + 16 * p;
     float Vm[12];
@@ -378,6 +379,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
         float v_comp = 0.f;
         if (fp.antialiased) { vop += gb.y * o.comp; v_comp = gb.y * opac; } else { vop += gb.y; }
         float vxy[2] = {ga.x, ga.y};
+        vxs += ga.x; vys += ga.y;
         float vcon[3] = {ga.z, ga.w, gb.x};
         float vm1[3], vc31[6];
         project_one_bwd(m, c3, Vm, fp.in.fx, fp.in.fy, k, o.comp, vxy, 0.f, vcon, v_comp, vm1, vc31, vV);
@@ -394,6 +396,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
   for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = vm[j]; v_scales[3 * i + j] = vs[j]; }
   for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = vq[j];
   v_opac[i] = vop;
+  if (v_xy_sum) { v_xy_sum[2 * i] = vxs; v_xy_sum[2 * i + 1] = vys; }
   float* c = v_sh + (size_t)i * fp.K_stride * 3;
   const int kn = fp.K_stride * 3;
 #pragma unroll
@@ -407,11 +410,11 @@ template <int MAXB>
 __global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, const float* __restrict__ records,
     const float* __restrict__ v_records, float* __restrict__ v_means, float* __restrict__ v_scales,
     float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
-    float* __restrict__ v_viewmats /* [P,16] accumulated, may be null */) {
+    float* __restrict__ v_viewmats /* [P,16] accumulated, may be null */, float* __restrict__ v_xy_sum) {
   __shared__ float lds[48];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  fused_bwd_body<MAXB>(fp, records, v_records, v_means, v_scales, v_quats, v_opac, v_sh, v_viewmats, nullptr, i,
-                       i < fp.N, lds);
+  fused_bwd_body<MAXB>(fp, records, v_records, v_means, v_scales, v_quats, v_opac, v_sh, v_viewmats, nullptr,
+                       v_xy_sum, i, i < fp.N, lds);
 }
 
 // sparse launch (touched flags; the caller pre-zeroes every output): under early termination ~1 % of the
@@ -424,7 +427,8 @@ template <int MAXB>
 __global__ __launch_bounds__(256) void project_fused_bwd_sparse_kernel(FusedParams fp,
     const float* __restrict__ records, const float* __restrict__ v_records, float* __restrict__ v_means,
     float* __restrict__ v_scales, float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
-    float* __restrict__ v_viewmats, const unsigned char* __restrict__ touched /* [P*N] */) {
+    float* __restrict__ v_viewmats, const unsigned char* __restrict__ touched /* [P*N] */,
+    float* __restrict__ v_xy_sum) {
   __shared__ float lds[48];
   __shared__ int list[kFusedChunk];
   __shared__ int wave_cnt[4];
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(256) void project_fused_bwd_sparse_kernel(FusedPara
     const int k = k0 + (int)threadIdx.x;
     const bool live = k < n_list;
     fused_bwd_body<MAXB>(fp, records, v_records, v_means, v_scales, v_quats, v_opac, v_sh, v_viewmats, touched,
-                         live ? list[k] : 0, live, lds);
+                         v_xy_sum, live ? list[k] : 0, live, lds);
   }
 }
 
@@ -638,7 +642,7 @@ GS_EXPORT int gs_project_fused_bwd(int N, int P, const float* means, const float
                                    int H, int W, float clip, int antialiased, const float* records,
                                    const float* v_records, float* v_means, float* v_scales, float* v_quats,
                                    float* v_opacities, float* v_sh, float* v_viewmats,
-                                   const unsigned char* touched, void* stream) {
+                                   const unsigned char* touched, float* v_xy_sum, void* stream) {
   if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride)
     return GS_ERR_INVALID;
   FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmats,
@@ -649,18 +653,18 @@ GS_EXPORT int gs_project_fused_bwd(int N, int P, const float* means, const float
     dim3 grid((N + kFusedChunk - 1) / kFusedChunk);
     if (sh_degree <= 3)
       hipLaunchKernelGGL(project_fused_bwd_sparse_kernel<16>, grid, block, 0, st, fp, records, v_records, v_means,
-                         v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched);
+                         v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched, v_xy_sum);
     else
       hipLaunchKernelGGL(project_fused_bwd_sparse_kernel<25>, grid, block, 0, st, fp, records, v_records, v_means,
-                         v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched);
+                         v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched, v_xy_sum);
   } else {
     dim3 grid((N + 255) / 256);
     if (sh_degree <= 3)
       hipLaunchKernelGGL(project_fused_bwd_kernel<16>, grid, block, 0, st, fp, records, v_records, v_means, v_scales,
-                         v_quats, v_opacities, v_sh, v_viewmats);
+                         v_quats, v_opacities, v_sh, v_viewmats, v_xy_sum);
     else
       hipLaunchKernelGGL(project_fused_bwd_kernel<25>, grid, block, 0, st, fp, records, v_records, v_means, v_scales,
-                         v_quats, v_opacities, v_sh, v_viewmats);
+                         v_quats, v_opacities, v_sh, v_viewmats, v_xy_sum);
   }
   return gs_launch_status();
 }

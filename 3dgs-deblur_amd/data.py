@@ -126,3 +126,31 @@ def load_seed_points_ply(path: str) -> Tuple[torch.Tensor, torch.Tensor]:
     xyz = data[:, [col["x"], col["y"], col["z"]]]
     rgb = data[:, [col["red"], col["green"], col["blue"]]] / 255.0 if "red" in col else torch.full((n, 3), 0.5)
     return xyz, rgb
+
+
+def synthetic_scene(n: int, width: int, height: int, sh_degree: int = 3, seed: int = 1234,
+                    scale_mult: float = 1.0) -> Dict:
+    """The seeded benchmark scene of SURVEY.md §8d (the inputs bench.py measures on): camera at the origin,
+    OpenCV axes, fx = fy = 0.8*W; Gaussians uniform in the frustum slab z in [1,10] reaching 1.2x the field
+    of view, log-scales ~ N(log(0.004 * 5.5 * scale_mult), 0.6^2), random unit quaternions, opacity logits
+    ~ N(0, 2^2), SH dc ~ N(0, 0.5^2), higher bands ~ N(0, 0.05^2); camera velocity 0.1*U[-1,1]^3 m/s and
+    0.2*U[-1,1]^3 rad/s, exposure 1/60 s, readout 1/30 s.  Raw (pre-activation) float32 parameters on the CPU.
+    The test oracle draws the same scene from the same generator sequence (tests/test_host_logic.py pins it)."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    fx = fy = 0.8 * width
+    z = 1.0 + 9.0 * torch.rand(n, generator=g)
+    u = (torch.rand(n, generator=g) * 2 - 1) * 1.2
+    v = (torch.rand(n, generator=g) * 2 - 1) * 1.2
+    means = torch.stack([u * z * (0.5 * width / fx), v * z * (0.5 * height / fy), z], -1)
+    log_scales = math.log(0.004 * 5.5 * scale_mult) + 0.6 * torch.randn(n, 3, generator=g)
+    quats = torch.randn(n, 4, generator=g)
+    quats = quats / quats.norm(dim=-1, keepdim=True)
+    opacity_logits = 2.0 * torch.randn(n, generator=g)
+    K = (sh_degree + 1) ** 2
+    sh = torch.cat([0.5 * torch.randn(n, 1, 3, generator=g), 0.05 * torch.randn(n, K - 1, 3, generator=g)], 1)
+    lin_vel = 0.1 * (torch.rand(3, generator=g) * 2 - 1)
+    ang_vel = 0.2 * (torch.rand(3, generator=g) * 2 - 1)
+    return dict(means=means, log_scales=log_scales, quats=quats, opacity_logits=opacity_logits, sh=sh,
+                viewmat=torch.eye(4), lin_vel=lin_vel, ang_vel=ang_vel, fx=fx, fy=fy, cx=width / 2.0,
+                cy=height / 2.0, exposure_time=1.0 / 60.0, rolling_shutter_time=1.0 / 30.0)

@@ -10,8 +10,8 @@ Mirrors what the reference needs from the nerfstudio fork's ``SplatfactoModel``
   * per-frame ``camera_linear_velocity`` / ``camera_angular_velocity`` in the (OpenGL) camera
     frame plus scene-level ``exposure_time`` / ``rolling_shutter_time``
     (/root/reference/process_synthetic_inputs.py:113-129,157-176).
-Only the forward/backward rendering surface is here; densification, the trainer, data
-managers and the viewer are out of scope.
+The forward/backward rendering surface; the densification step that follows it lives in densify.py
+(SURVEY §8 f3); the trainer, data managers and the viewer are out of scope.
 """
 from __future__ import annotations
 
@@ -117,6 +117,11 @@ class SplatfactoDeblurModel(nn.Module):
             self.velocity_adjustment = None
         self.radii: Optional[Tensor] = None
         self.last_samples: Optional[Tensor] = None
+        # densification statistics (densify.py): when enabled, every training render leaves the summed
+        # screen-space centre gradient of its backward pass in self.xy_grad [N,2] (pixels)
+        self.collect_densify_stats = False
+        self.xy_grad: Optional[Tensor] = None
+        self.last_size = (0, 0)
 
     # -- splatfacto-style accessors ------------------------------------------------
     @property
@@ -194,11 +199,15 @@ class SplatfactoDeblurModel(nn.Module):
         sh = torch.cat([self.features_dc[:, None, :], self.features_rest], dim=1)
         bg = self._background(dev)
         use_gamma = cfg.blur_samples > 0
+        self.xy_grad = None
+        if self.training and self.collect_densify_stats:
+            self.xy_grad = torch.zeros(self.num_points, 2, device=dev)
         samples, alphas, radii = ops.render_subposes(
             self.means, torch.exp(self.scales), self.quats, torch.sigmoid(self.opacities).reshape(-1), sh,
             viewmats, bg, S, R, camera.fx, camera.fy, camera.cx, camera.cy, camera.height, camera.width,
-            sh_degree=cfg.sh_degree, antialiased=(cfg.rasterize_mode == "antialiased"))
+            sh_degree=cfg.sh_degree, antialiased=(cfg.rasterize_mode == "antialiased"), xy_grad_out=self.xy_grad)
         self.radii = radii
+        self.last_size = (camera.width, camera.height)
         self.last_samples = samples
         gamma = cfg.gamma if use_gamma else 1.0
         min_level = cfg.min_rgb_level if use_gamma else 0.0

@@ -731,9 +731,14 @@ def subpose_schedule(blur_samples: int, exposure_time: float, rs_bands: int, rol
 class _RenderSubposes(Function):
     @staticmethod
     def forward(ctx, means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
-                img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh):
+                img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out):
         means3d, scales, quats = _f32(means3d, "means3d"), _f32(scales, "scales"), _f32(quats, "quats")
         opacities, sh = _f32(opacities, "opacities").reshape(-1), _f32(sh, "sh")
+        if xy_grad_out is not None:
+            if (xy_grad_out.shape != (means3d.shape[0], 2) or xy_grad_out.dtype != torch.float32
+                    or not xy_grad_out.is_contiguous() or xy_grad_out.device != means3d.device):
+                raise ValueError("xy_grad_out must be a contiguous float32 [N,2] tensor on the Gaussians' device")
+        ctx.xy_grad_out = xy_grad_out
         V = _f32(viewmats, "viewmats")
         N, K = means3d.shape[0], sh.shape[1]
         P = S * R
@@ -803,25 +808,31 @@ class _RenderSubposes(Function):
         v_sh = alloc(N, K, 3, device=dev)
         need_v = ctx.needs_input_grad[5]
         v_V = torch.zeros(P, 4, 4, device=dev) if need_v else None
+        xy_out = ctx.xy_grad_out
+        if xy_out is not None and touched is not None:
+            xy_out.zero_()
         with _stage("project_bwd"):
             _check(L.gs_project_fused_bwd(N, P, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(opacities),
                                           _ptr(sh), K, deg, _ptr(V), fx, fy, cx, cy, H, W, clip, aa, _ptr(records),
                                           _ptr(v_records), _ptr(v_means), _ptr(v_scales), _ptr(v_quats), _ptr(v_opac),
-                                          _ptr(v_sh), _ptr(v_V), _ptr(touched), _stream()), "project_fused_bwd")
+                                          _ptr(v_sh), _ptr(v_V), _ptr(touched), _ptr(xy_out), _stream()),
+                   "project_fused_bwd")
         v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
-        return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 12
+        return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 13
 
 
 def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, sh: Tensor,
                     viewmats: Tensor, background: Optional[Tensor], blur_samples: int, rs_bands: int,
                     fx: float, fy: float, cx: float, cy: float, img_height: int, img_width: int,
                     sh_degree: int = 3, antialiased: bool = True, glob_scale: float = 1.0,
-                    clip_thresh: float = 0.01):
+                    clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None):
     """Fused hot path: project N Gaussians under P=S*R sub-pose viewmats, bin, sort, composite.
-    -> (samples [S,H,W,3], alphas [S,H,W], radii int32 [P,N]).  scales/opacities are activated values."""
+    -> (samples [S,H,W,3], alphas [S,H,W], radii int32 [P,N]).  scales/opacities are activated values.
+    xy_grad_out (optional float32 [N,2]) is OVERWRITTEN during backward with the sum over the sub-poses of
+    the screen-space centre gradient in pixels — what splatfacto's densification reads from ``xys.grad``."""
     S, R = max(1, int(blur_samples)), max(1, int(rs_bands))
     return _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
-                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh)
+                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out)
 
 
 # --------------------------------------------------------------------------- #

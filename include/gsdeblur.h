@@ -95,6 +95,9 @@ int gs_project_fused_bwd(int N, int P, const float* means3d, const float* scales
                                                         read (set by gs_reduce_grad_tuples).  With touched given,
                                                         the caller must ZERO the five gradient outputs: Gaussians
                                                         untouched in every sub-pose are skipped entirely*/,
+                         float* v_xy_sum /*[N*2] or NULL: sum over the sub-poses of the screen-space centre
+                                           gradient (pixels) — the densification statistic splatfacto reads from
+                                           xys.grad; same zeroing rule as the other outputs*/,
                          void* stream);
 
 /* ---- gsplat-array <-> record glue for the rasterize_gaussians signature -------- */

@@ -1,0 +1,186 @@
+"""densify / cull after the hot path — host logic on CPU (torch tensor surgery and the
+world_size-2 statistics exchange); the GPU-side statistic (xy_grad from the HIP projection backward) is
+checked against the oracle in test_gpu_parity.py."""
+import math
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _model(gs, n, seed=0, device="cpu"):
+    g = torch.Generator().manual_seed(seed)
+    cfg = gs.SplatfactoDeblurConfig(sh_degree=1)
+    means = torch.randn(n, 3, generator=g)
+    log_scales = torch.full((n, 3), math.log(0.005))
+    quats = torch.randn(n, 4, generator=g)
+    opac = torch.full((n,), 2.0)
+    dc = torch.rand(n, 3, generator=g)
+    rest = torch.zeros(n, 3, 3)
+    return gs.SplatfactoDeblurModel(cfg, means, log_scales, quats, opac, dc, rest).to(device)
+
+
+def _prime_adam(gs, model):
+    opts = gs.training.make_optimizers(model)
+    for name, p in model.gauss_params().items():
+        p.grad = torch.full_like(p, 0.5)
+    for o in opts.values():
+        o.step()
+    return opts
+
+
+def test_state_accumulates_visible_only(gs):
+    st = gs.densify.DensifyState(4, "cpu")
+    radii = torch.tensor([[3, 0, 0, 8], [5, 0, 2, 0]], dtype=torch.int32)        # P=2 sub-poses
+    xy = torch.tensor([[3.0, 4.0], [10.0, 0.0], [0.0, 1.0], [0.0, 0.0]])
+    st.after_backward(radii, xy, 200, 100)
+    assert st.xys_grad_norm.tolist() == [5.0, 0.0, 1.0, 0.0]                     # Gaussian 1 is culled everywhere
+    assert st.vis_counts.tolist() == [1.0, 0.0, 1.0, 1.0]
+    assert st.max_2Dsize.tolist() == pytest.approx([5 / 200, 0.0, 2 / 200, 8 / 200])
+    st.after_backward(radii, xy, 200, 100)
+    assert st.vis_counts.tolist() == [2.0, 0.0, 2.0, 2.0] and st.xys_grad_norm[0].item() == 10.0
+
+
+def test_refine_split_duplicate_cull_and_adam_state(gs):
+    n = 10
+    model = _model(gs, n)
+    opts = _prime_adam(gs, model)
+    cfg = gs.densify.DensifyConfig(n_split_samples=2)
+    with torch.no_grad():
+        model.scales[0] = math.log(0.05)        # big + high gradient  -> split
+        model.scales[1] = math.log(0.05)        # big, low gradient    -> kept
+        model.opacities[4] = -5.0               # transparent          -> culled
+        model.opacities[2] = -5.0               # high gradient AND transparent: duplicated, original culled
+    st = gs.densify.DensifyState(n, "cpu")
+    st.size = (100, 100)
+    st.vis_counts += 2
+    st.xys_grad_norm[[0, 2, 3]] = 1.0           # avg = 0.5 * 0.5 * 100 = 25 > thresh
+    old = {k: v.detach().clone() for k, v in model.gauss_params().items()}
+    old_m = {k: opts[k].state[p]["exp_avg"].clone() for k, p in model.gauss_params().items()}
+    res = gs.densify.refine(model, opts, st, step=600, cfg=cfg)
+    assert res == {"split": 1, "duplicated": 2, "culled_low_opacity": 2, "culled_too_big": 0, "before": 10, "after": 11}
+    assert model.num_points == 11 and st.vis_counts.shape == (11,) and float(st.vis_counts.sum()) == 0
+    keep = [1, 3, 5, 6, 7, 8, 9]                # 0 split away, 2 and 4 culled
+    for k, p in model.gauss_params().items():
+        assert p.shape[0] == 11 and p.requires_grad
+        assert torch.equal(p[:7], old[k][keep])
+        assert opts[k].param_groups[0]["params"][0] is p
+        stt = opts[k].state[p]
+        assert stt["exp_avg"].shape == p.shape and stt["exp_avg_sq"].shape == p.shape
+        assert torch.equal(stt["exp_avg"][:7], old_m[k][keep])               # kept rows keep their moments
+        assert float(stt["exp_avg"][7:].abs().sum()) == 0                    # new rows start from zero
+    # children: 2 samples of Gaussian 0 (scales / 1.6, same quat/colour), then the duplicates of 2 and 3
+    assert torch.allclose(model.scales[7:9], old["scales"][0].expand(2, 3) - math.log(1.6))
+    assert torch.equal(model.quats[7:9], old["quats"][0].expand(2, 4))
+    assert not torch.equal(model.means[7], model.means[8])
+    assert (model.means[7:9] - old["means"][0]).norm(dim=-1).max() < 0.05 * 6    # inside ~6 sigma of the parent
+    assert torch.equal(model.means[9:11], old["means"][[2, 3]])
+    # the optimizers still step with the new shapes
+    for p in model.gauss_params().values():
+        p.grad = torch.ones_like(p)
+    for o in opts.values():
+        o.step()
+
+
+def test_refine_is_deterministic_in_step_and_seed(gs):
+    outs = []
+    for _ in range(2):
+        model = _model(gs, 50, seed=3)
+        opts = _prime_adam(gs, model)
+        with torch.no_grad():
+            model.scales[:25] = math.log(0.03)
+        st = gs.densify.DensifyState(50, "cpu")
+        st.size = (64, 64)
+        st.vis_counts += 1
+        st.xys_grad_norm += 0.01
+        gs.densify.refine(model, opts, st, step=700, cfg=gs.densify.DensifyConfig())
+        outs.append(model.means.detach().clone())
+    assert outs[0].shape == (25 * 2 + 25 * 2, 3) and torch.equal(outs[0], outs[1])
+
+
+def test_cull_scale_thresh_applies_after_first_opacity_reset(gs):
+    cfg = gs.densify.DensifyConfig(cull_scale_thresh=0.5)            # train.py:18 sets 2.0 for some datasets
+    for step, expect in ((600, 6), (cfg.refine_every * cfg.reset_alpha_every + 100, 5)):
+        model = _model(gs, 6)
+        opts = _prime_adam(gs, model)
+        with torch.no_grad():
+            model.scales[3] = math.log(0.8)
+        st = gs.densify.DensifyState(6, "cpu")
+        st.size = (64, 64)
+        gs.densify.refine(model, opts, st, step=step, cfg=cfg)
+        assert model.num_points == expect
+    # after stop_split_at only culling continues
+    model = _model(gs, 6)
+    opts = _prime_adam(gs, model)
+    with torch.no_grad():
+        model.opacities[0] = -6.0
+    st = gs.densify.DensifyState(6, "cpu")
+    st.xys_grad_norm += 100.0
+    st.vis_counts += 1
+    res = gs.densify.refine(model, opts, st, step=20000, cfg=cfg)
+    assert res["split"] == res["duplicated"] == 0 and model.num_points == 5
+
+
+def test_reset_opacities(gs):
+    model = _model(gs, 5)
+    opts = _prime_adam(gs, model)
+    cfg = gs.densify.DensifyConfig()
+    with torch.no_grad():
+        model.opacities[0] = -3.0
+    gs.densify.reset_opacities(model, opts, cfg)
+    cap = math.log(0.2 / 0.8)
+    assert model.opacities[0].item() == pytest.approx(-3.0) and model.opacities[1].item() == pytest.approx(cap)
+    assert float(opts["opacities"].state[model.opacities]["exp_avg"].abs().sum()) == 0
+
+
+def _densify_worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    import gsdeblur_amd as gs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 40
+    model = _model(gs, n, seed=7)                       # replicated Gaussians
+    opts = _prime_adam(gs, model)
+    with torch.no_grad():
+        model.scales[:10] = math.log(0.04)
+    st = gs.densify.DensifyState(n, "cpu")
+    model.collect_densify_stats = True
+    # every rank saw a different view: different visibility and gradients
+    g = torch.Generator().manual_seed(50 + rank)
+    model.radii = (torch.rand(2, n, generator=g) < 0.6).to(torch.int32) * 7
+    model.xy_grad = torch.rand(n, 2, generator=g) * 1e-4 * (1 + 30 * (torch.arange(n) % 3 == rank).float())[:, None]
+    model.last_size = (320, 240)
+    cfg = gs.densify.DensifyConfig(warmup_length=0, refine_every=1)
+    res = gs.densify.step_callback(model, opts, st, step=3, cfg=cfg)
+    flat = torch.cat([p.detach().reshape(-1) for p in model.gauss_params().values()])
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([flat.numel()]))
+    same = all(int(s) == flat.numel() for s in sizes)
+    if same:
+        other = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        same = all(torch.equal(o, flat) for o in other)
+    q.put((rank, same, res["after"], res["split"] + res["duplicated"]))
+    dist.destroy_process_group()
+
+
+def test_densify_world2_gloo_ranks_stay_identical():
+    """statistics are reduced over the ranks and the split noise is seeded by the step: replicas stay bit-identical"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_densify_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
+    assert res[0][2] == res[1][2] and res[0][3] > 0      # same N on both ranks, and something was densified

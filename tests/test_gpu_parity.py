@@ -6,6 +6,7 @@ within the fp32 tolerances written at each assert (fp32 HIP with fast exp vs flo
 Pixels whose threshold decisions (alpha >= 1/255, T <= 1e-4) sit within rounding of flipping are
 flagged by the oracle (`fragile`) and excluded from strict comparisons; everything else is compared.
 """
+import math
 from pathlib import Path
 
 import numpy as np
@@ -561,3 +562,86 @@ def test_model_get_outputs(gs, oracle, dev):
     assert ev["depth"].shape == (H, W, 1) and torch.isfinite(ev["depth"]).all()
     assert 0.0 <= ev["rgb"].min().item() and ev["rgb"].max().item() <= 1.0
     assert (ev["depth"][ev["accumulation"] > 0.5] > 0.9).all()
+
+
+# --------------------------------------------------------------------------- #
+# densification statistic out of the HIP projection backward, and the refine step in a loop
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("S,R", [(1, 1), (3, 2)])
+def test_xy_grad_statistic_matches_oracle(gs, oracle, dev, S, R):
+    """xy_grad_out == sum over the sub-poses of d loss / d xys (float64 oracle, autograd through its
+    per-sub-pose projections), and Gaussians culled everywhere report exactly zero."""
+    O = oracle
+    W, H, n = 128, 96, 1500
+    sc = O.synthetic_scene(n, W, H, seed=77, scale_mult=6.0)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10
+    et, rt, gamma, mlevel = 1 / 60, 1 / 30, 2.2, 10.0
+    bg = torch.tensor([0.05, 0.1, 0.15])
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(6))
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel", "viewmat"]
+    p = {k: sc[k].float().to(dev).requires_grad_(True) for k in names}
+    times, _, _ = gs.subpose_schedule(S, et, R, rt)
+    vms = gs.subpose_viewmats(p["viewmat"], p["lin_vel"], p["ang_vel"], torch.tensor(times, device=dev))
+    xy_grad = torch.full((n, 2), 123.0, device=dev)                   # must be overwritten, not accumulated
+    samples, alphas, radii = gs.render_subposes(p["means"], p["log_scales"].exp(), p["quats"],
+                                                torch.sigmoid(p["opacity_logits"]), p["sh"], vms, bg.to(dev), S, R,
+                                                sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, sh_degree=3,
+                                                xy_grad_out=xy_grad)
+    out = gs.combine_samples(samples, gamma, mlevel)
+    (out * wt.to(dev)).sum().backward()
+    cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], blur_samples=S, rs_bands=R, exposure_time=et,
+                         rolling_shutter_time=rt, gamma=gamma, min_rgb_level=mlevel)
+    q = {k: sc[k].double().requires_grad_(True) for k in names}
+    ref, _, _, frag, parts, _ = O.render(cfg, q["means"], q["log_scales"].exp(), q["quats"],
+                                         torch.sigmoid(q["opacity_logits"]), q["sh"], q["viewmat"], q["lin_vel"],
+                                         q["ang_vel"], background=bg.double(), return_parts=True)
+    for part in parts:
+        part[0].xys.retain_grad()
+    (ref * wt.double()).sum().backward()
+    want = sum(part[0].xys.grad for part in parts)
+    assert rel_max(xy_grad.cpu(), want) < GRAD_RTOL
+    invisible = (radii == 0).all(dim=0)
+    assert invisible.any() and float(xy_grad[invisible].abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        gs.render_subposes(p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["opacity_logits"]), p["sh"],
+                           vms, bg.to(dev), S, R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W,
+                           xy_grad_out=torch.zeros(n, 3, device=dev))
+
+
+def test_training_loop_with_densification(gs, oracle, dev):
+    """f2 + f3 end to end: fit a blurred target rendered from a reference scene, refining every few steps; N
+    changes, Adam follows, the loss goes down and stays finite."""
+    O = oracle
+    W, H = 128, 96
+    target_sc = O.synthetic_scene(1500, W, H, seed=5, scale_mult=6.0)
+    cfg = gs.SplatfactoDeblurConfig(blur_samples=3, rolling_shutter_compensation=False, gamma=2.2, min_rgb_level=10.0)
+    c2w = torch.eye(4)[:3].clone()
+    c2w[:, 1] *= -1
+    c2w[:, 2] *= -1
+    cam = gs.Camera(c2w, target_sc["fx"], target_sc["fy"], target_sc["cx"], target_sc["cy"], W, H,
+                    metadata=dict(cam_idx=0, camera_linear_velocity=[1.0, 0.2, 0.0],
+                                  camera_angular_velocity=[0.0, 0.5, 0.2], exposure_time=1 / 60,
+                                  rolling_shutter_time=0.0))
+    target_model = gs.SplatfactoDeblurModel.from_scene(cfg, target_sc, dev)
+    gt = target_model.get_outputs_for_camera(cam)["rgb"].detach()
+    start = O.synthetic_scene(400, W, H, seed=6, scale_mult=8.0)
+    model = gs.SplatfactoDeblurModel.from_scene(cfg, start, dev)
+    model.collect_densify_stats = True
+    opts = gs.training.make_optimizers(model, lr_scale=10.0)
+    dcfg = gs.densify.DensifyConfig(warmup_length=5, refine_every=5, densify_grad_thresh=2e-5)
+    state = gs.densify.DensifyState(model.num_points, dev)
+    losses, sizes, results = [], [model.num_points], []
+    for step in range(1, 31):
+        st = gs.training.train_step(model, opts, cam, gt)
+        assert math.isfinite(st["loss"])
+        losses.append(st["loss"])
+        assert model.xy_grad is not None and model.xy_grad.shape == (model.num_points, 2)
+        r = gs.densify.step_callback(model, opts, state, step, dcfg)
+        if r is not None:
+            results.append(r)
+            sizes.append(r["after"])
+            for name, prm in model.gauss_params().items():
+                assert prm.shape[0] == r["after"] and opts[name].param_groups[0]["params"][0] is prm
+    assert len(results) == 5 and sum(r["split"] + r["duplicated"] for r in results) > 0
+    assert sizes[-1] != sizes[0]
+    assert min(losses[-10:]) < losses[0]

@@ -142,3 +142,24 @@ def test_gradient_allreduce_world2_gloo(mode):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_benchmark_scene_generator_is_the_oracles(gs, oracle):
+    """bench.py draws its inputs from the package (the product never imports the oracle); the oracle's
+    generator must yield the very same scene so that parity cases and the benchmark share inputs."""
+    for n, W, H, deg, seed, mult in ((1000, 256, 256, 3, 1234, 1.0), (17, 64, 48, 2, 7, 4.0)):
+        a = gs.data.synthetic_scene(n, W, H, sh_degree=deg, seed=seed, scale_mult=mult)
+        b = oracle.synthetic_scene(n, W, H, sh_degree=deg, seed=seed, scale_mult=mult)
+        assert set(a) == set(b)
+        for k in a:
+            if isinstance(a[k], torch.Tensor):
+                assert a[k].dtype == torch.float32 and torch.equal(a[k], b[k]), k
+            else:
+                assert a[k] == b[k], k
+
+
+def test_bench_main_leg_does_not_touch_the_oracle():
+    src = (ROOT / "bench.py").read_text()
+    main = src[src.index("def main():"):]
+    assert "gs_oracle" not in main and "_import_oracle" not in main
+    assert src.count("= _import_oracle()") == 1          # the cpu_baseline leg only
