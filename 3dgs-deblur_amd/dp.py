@@ -111,15 +111,16 @@ def _allreduce_sparse_rows(params: Sequence[torch.Tensor], group, world: int, av
         mask |= (r != 0).any(dim=1)
     idx = mask.nonzero(as_tuple=False).reshape(-1)
     m_local = torch.tensor([idx.numel()], dtype=torch.int64, device=dev)
-    m_max = m_local.clone()
-    dist.all_reduce(m_max, op=dist.ReduceOp.MAX, group=group)
-    Mmax = int(m_max.item())
-    if Mmax * world > dense_threshold * N:        # identical on every rank: m_max is global
+    counts_t = [torch.empty_like(m_local) for _ in range(world)]
+    dist.all_gather(counts_t, m_local, group=group)
+    counts = [int(c.item()) for c in torch.stack(counts_t).reshape(-1).cpu()]
+    Mmax = max(counts)
+    if Mmax * world > dense_threshold * N:        # identical on every rank: the counts are global
         return False
     if Mmax == 0:
         return True
     M = idx.numel()
-    idx_pad = torch.full((Mmax,), -1, dtype=torch.int64, device=dev)
+    idx_pad = torch.zeros(Mmax, dtype=torch.int64, device=dev)
     idx_pad[:M] = idx
     pay = torch.zeros(Mmax, sum(widths), dtype=torch.float32, device=dev)
     if M:
@@ -128,16 +129,18 @@ def _allreduce_sparse_rows(params: Sequence[torch.Tensor], group, world: int, av
     pay_all = [torch.empty_like(pay) for _ in range(world)]
     dist.all_gather(idx_all, idx_pad, group=group)
     dist.all_gather(pay_all, pay, group=group)
-    idx_cat = torch.cat(idx_all)
-    pay_cat = torch.cat(pay_all)
-    keep = idx_cat >= 0
-    idx_cat, pay_cat = idx_cat[keep], pay_cat[keep]
-    if average:
-        pay_cat = pay_cat / world
+    # Replicas must stay BIT-identical, so the sum has one fixed order on every rank: rank 0's rows first,
+    # then rank 1's, ...  A rank's row indices are unique, so each index_add_ below has no colliding writes
+    # (a single index_add_ over the concatenation would add in atomic, i.e. arbitrary, order).
+    scale = 1.0 / world if average else 1.0
     off = 0
     for p, w in zip(params, widths):
         g = torch.zeros(N, w, dtype=torch.float32, device=dev)
-        g.index_add_(0, idx_cat, pay_cat[:, off:off + w])
+        for r in range(world):
+            if counts[r]:
+                g.index_add_(0, idx_all[r][:counts[r]], pay_all[r][:counts[r], off:off + w])
+        if average:
+            g.mul_(scale)
         off += w
         p.grad = g.view_as(p)          # replace (no extra 236 MB copy)
     return True
