@@ -104,6 +104,40 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(size_t n, const unsigne
   }
 }
 
+// scan_apply with the block-sum scan folded in: block b sums the RAW sums of the blocks before it (256 threads,
+// stride 256) instead of reading a pre-scanned array — one launch less per scan; the LSD sorts run one scan
+// per digit pass, so a frame saves ~9 single-block launches.  Used while that prologue stays short.
+constexpr size_t kScanFusedMaxBlocks = 8192;
+
+__global__ __launch_bounds__(256) void scan_apply_fused_kernel(size_t n, const unsigned* __restrict__ in,
+                                                               const unsigned* __restrict__ bsum_raw,
+                                                               unsigned* __restrict__ out,
+                                                               unsigned* __restrict__ total_out) {
+  __shared__ unsigned lds[8];
+  unsigned part = 0;
+  for (unsigned b = threadIdx.x; b < blockIdx.x; b += 256) part += bsum_raw[b];
+  unsigned prefix;
+  block_excl_scan(part, prefix, lds);              // total over the block = sum of the preceding block sums
+  size_t base = (size_t)blockIdx.x * kScanBlock + (size_t)threadIdx.x * kScanItems;
+  unsigned v[kScanItems];
+  unsigned s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    size_t i = base + k;
+    v[k] = i < n ? in[i] : 0u;
+    s += v[k];
+  }
+  unsigned total;
+  unsigned ex = block_excl_scan(s, total, lds) + prefix;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    size_t i = base + k;
+    if (i < n) out[i] = ex;
+    ex += v[k];
+  }
+  if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = prefix + total;
+}
+
 static inline size_t scan_ws_bytes(size_t n) {
   size_t nb = (n + kScanBlock - 1) / kScanBlock;
   return (nb + 1) * sizeof(unsigned);
@@ -113,8 +147,12 @@ static int run_scan(size_t n, const unsigned* in, unsigned* out, unsigned* total
   size_t nb = (n + kScanBlock - 1) / kScanBlock;
   unsigned* bsum = reinterpret_cast<unsigned*>(ws);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum);
-  hipLaunchKernelGGL(scan_bsums_kernel, dim3(1), dim3(256), 0, st, (unsigned)nb, bsum, total_out);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, out);
+  if (nb <= kScanFusedMaxBlocks) {
+    hipLaunchKernelGGL(scan_apply_fused_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, out, total_out);
+  } else {
+    hipLaunchKernelGGL(scan_bsums_kernel, dim3(1), dim3(256), 0, st, (unsigned)nb, bsum, total_out);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, out);
+  }
   return gs_launch_status();
 }
 

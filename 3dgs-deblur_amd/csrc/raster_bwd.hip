@@ -467,11 +467,18 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
   unsigned blocks = (work + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
   if (variant == 2) {          // ablation: plain stores instead of atomics (timing experiments only)
+    if (!bwd_T || !bwd_B) return GS_ERR_INVALID;
     hipLaunchKernelGGL((raster_bwd_kernel_v2<true, 2>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx, v_img,
                        v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);
   } else if (tuples && flags && gi_of_e) {
-    hipLaunchKernelGGL((raster_bwd_kernel_v2<true, 1>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx, v_img,
-                       v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);
+    if (bwd_T && bwd_B)
+      hipLaunchKernelGGL((raster_bwd_kernel_v2<true, 1>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx,
+                         v_img, v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);
+    else          // the only slice: no reverse-traversal state to load or store
+      hipLaunchKernelGGL((raster_bwd_kernel_v2<false, 1>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx,
+                         v_img, v_alpha, v_records, blocks, (float*)nullptr, (float*)nullptr, tuples, flags);
+  } else if (!bwd_T || !bwd_B) {
+    return GS_ERR_INVALID;
   } else {
     hipLaunchKernelGGL((raster_bwd_kernel_v2<true, 0>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx, v_img,
                        v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);

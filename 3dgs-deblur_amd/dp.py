@@ -120,15 +120,15 @@ def _allreduce_sparse_rows(params: Sequence[torch.Tensor], group, world: int, av
     if Mmax == 0:
         return True
     M = idx.numel()
-    idx_pad = torch.zeros(Mmax, dtype=torch.int64, device=dev)
-    idx_pad[:M] = idx
-    pay = torch.zeros(Mmax, sum(widths), dtype=torch.float32, device=dev)
+    # one collective: the row index travels as the bit pattern of an extra float32 column (N < 2^31)
+    wsum = sum(widths)
+    pay = torch.zeros(Mmax, wsum + 1, dtype=torch.float32, device=dev)
     if M:
-        pay[:M] = torch.cat([r[idx] for r in rows], dim=1)
-    idx_all = [torch.empty_like(idx_pad) for _ in range(world)]
+        pay[:M, :wsum] = torch.cat([r[idx] for r in rows], dim=1)
+        pay[:M, wsum] = idx.to(torch.int32).view(torch.float32)
     pay_all = [torch.empty_like(pay) for _ in range(world)]
-    dist.all_gather(idx_all, idx_pad, group=group)
     dist.all_gather(pay_all, pay, group=group)
+    idx_all = [pa[:, wsum].contiguous().view(torch.int32).to(torch.int64) for pa in pay_all]
     # Replicas must stay BIT-identical, so the sum has one fixed order on every rank: rank 0's rows first,
     # then rank 1's, ...  A rank's row indices are unique, so each index_add_ below has no colliding writes
     # (a single index_add_ over the concatenation would add in atomic, i.e. arbitrary, order).

@@ -443,10 +443,13 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
                     touched: Optional[Tensor] = None):
     L = _L()
     H, W = img_height, img_width
-    bwd_T = out_T.clone()
-    # reverse-traversal state: (behind-colour . v_out), ONE float per pixel
-    bwd_B = torch.zeros((S, H, W), device=records.device)
     dev = records.device
+    # reverse-traversal state between slices: running T and (behind-colour . v_out), ONE float per pixel each;
+    # a frame that needed a single slice (the common case) carries none
+    bwd_T = bwd_B = None
+    if len(slices) > 1 or any(sl["gi_of_e"] is None for sl in slices):
+        bwd_T = out_T.clone()
+        bwd_B = torch.zeros((S, H, W), device=dev)
     for sl in reversed(slices):
         tuples = flags = None
         if sl["gi_of_e"] is not None:

@@ -187,7 +187,7 @@ def main():
     for _ in range(args.warmup):
         step()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     ops.profiler = ops.StageProfiler()
     t0 = time.perf_counter()
@@ -195,7 +195,7 @@ def main():
         step()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     dt = time.perf_counter() - t0
     stages = ops.profiler.summary_ms()
     ops.profiler = None
@@ -240,7 +240,7 @@ def main():
 
         alg, alg_survey = alg_bytes(I_emit), alg_bytes(n_isect)
         kname = {"raster_bwd": "raster_bwd_kernel_v2", "raster_fwd": "raster_fwd_slice_kernel",
-                 "project_fwd": "project_fused_fwd_kernel", "project_bwd": "project_fused_bwd_kernel"}[dom]
+                 "project_fwd": "project_fused_fwd_kernel", "project_bwd": "project_fused_bwd_sparse_kernel"}[dom]
         achieved = alg[dom] / (single[dom] * 1e-3) / 1e9
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"

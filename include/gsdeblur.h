@@ -204,7 +204,7 @@ int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const i
                                                 indices e and the Gaussian id is gi_of_e[e]*/,
                            int variant /*0 = default (skips pairs that touch no pixel); 1 = no skip*/, void* stream);
 /* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B [S,H,W] (behind-colour . v_out, init = 0)
- * carry the reverse-traversal state */
+ * carry the reverse-traversal state; both may be NULL on the tuple path when the frame has a single slice */
 int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                            const int* band_edges, const float* background, int S, int R, int img_height,
                            int img_width, const float* out_T, const int* final_idx, const float* v_img,

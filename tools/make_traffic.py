@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 out, tag = sys.argv[1], sys.argv[2]
-KERNELS = ["raster_bwd_kernel_v2", "raster_fwd_slice_kernel", "project_fused_fwd_kernel", "project_fused_bwd_kernel",
+KERNELS = ["raster_bwd_kernel_v2", "raster_fwd_slice_kernel", "project_fused_fwd_kernel", "project_fused_bwd_sparse_kernel",
            "slice_counts_exact_kernel", "slice_colors_kernel", "emit_open_kernel", "reduce_tuples_wave_kernel"]
 
 
