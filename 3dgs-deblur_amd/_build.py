@@ -19,9 +19,11 @@ SOURCES = [
     ("project.hip", ["-ffp-contract=off"]),
     ("binning.hip", []),
     ("raster.hip", []),
-    # backward compositor: SLP packing into v_pk_*_f32 costs v_mov shuffles and 29 VGPRs on gfx950 (A/B:
-    # 1.27 -> 1.09 ms); the forward kernel is slightly faster with packing and keeps the default
+    # backward compositor: automatic SLP packing into v_pk_*_f32 costs v_mov shuffles and 29 VGPRs on gfx950
+    # (A/B: 1.27 -> 1.09 ms); the packing is done by hand in the source instead (GS_BWD_PK)
     ("raster_bwd.hip", ["-fno-slp-vectorize"]),
+    # x*scale + y must round twice, like the torch ops it replaces (tests compare bit for bit)
+    ("dp_exchange.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fvisibility=hidden"]
 

@@ -48,6 +48,10 @@ _SIGS = {
     "gs_reduce_grad_tuples": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "gs_combine_fwd": [_I, _L, _P, _F, _F, _P, _P],
     "gs_combine_bwd": [_I, _L, _P, _F, _F, _P, _P, _P, _P],
+    # host arrays (pointer table, widths) are passed as ctypes arrays -> plain pointers
+    "gs_dp_row_mask": [_I, _I, _P, _P, _P, _P],
+    "gs_dp_pack_rows": [_L, _P, _I, _P, _P, _P, _P],
+    "gs_dp_scatter_add_rows": [_L, _P, _I, _P, _P, _F, _P],
 }
 _SIGS_LL = {
     "gs_scan_workspace_bytes": [_L],

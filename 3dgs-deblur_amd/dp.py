@@ -96,51 +96,103 @@ def allreduce_gradients(params: Iterable[torch.Tensor], group: Optional[dist.Pro
     unflatten_grads(flat, params)
 
 
+class _RowOps:
+    """Row mask / pack / scatter-add over the gradient tensors.  CUDA tensors go through the HIP kernels of
+    dp_exchange.hip (one launch per step for all tensors; raises if the library is missing); CPU tensors —
+    the gloo tests of the exchange logic — through the equivalent torch ops."""
+
+    def __init__(self, grads: Sequence[torch.Tensor]):
+        self.grads = grads
+        self.N = grads[0].shape[0]
+        self.widths = [g[0].numel() if self.N else 1 for g in grads]
+        self.wtot = sum(self.widths)
+        self.dev = grads[0].device
+        self.hip = self.dev.type == "cuda"
+        if self.hip:
+            import ctypes
+            from . import _lib
+            self._L = _lib.load()
+            self._check = _lib.check
+            n = len(grads)
+            self._ptrs = (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads])
+            self._w = (ctypes.c_int * n)(*self.widths)
+            self._stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+            self._vp = ctypes.c_void_p
+
+    def row_mask(self) -> torch.Tensor:
+        if self.hip:
+            mask = torch.empty(self.N, dtype=torch.uint8, device=self.dev)
+            self._check(self._L.gs_dp_row_mask(self.N, len(self.grads), self._ptrs, self._w,
+                                               self._vp(mask.data_ptr()), self._stream), "dp_row_mask")
+            return mask.bool()
+        mask = torch.zeros(self.N, dtype=torch.bool, device=self.dev)
+        for g in self.grads:
+            mask |= (g.reshape(self.N, -1) != 0).any(dim=1)
+        return mask
+
+    def pack(self, idx: torch.Tensor, rows_padded: int) -> torch.Tensor:
+        """[rows_padded, wtot+1] payload: the rows idx (int64) and, in the last column, their indices as int32
+        bit patterns; rows beyond len(idx) are zero padding."""
+        M = idx.numel()
+        pay = torch.zeros(rows_padded, self.wtot + 1, dtype=torch.float32, device=self.dev)
+        if M == 0:
+            return pay
+        if self.hip:
+            self._check(self._L.gs_dp_pack_rows(M, self._vp(idx.data_ptr()), len(self.grads), self._ptrs, self._w,
+                                                self._vp(pay.data_ptr()), self._stream), "dp_pack_rows")
+        else:
+            pay[:M, :self.wtot] = torch.cat([g.reshape(self.N, -1)[idx] for g in self.grads], dim=1)
+            pay[:M, self.wtot] = idx.to(torch.int32).view(torch.float32)
+        return pay
+
+    def scatter_add(self, payload: torch.Tensor, M: int, scale: float) -> None:
+        """grads[row] += scale * payload[:M]; the M row indices of one payload are unique."""
+        if M == 0:
+            return
+        if self.hip:
+            self._check(self._L.gs_dp_scatter_add_rows(M, self._vp(payload.data_ptr()), len(self.grads), self._ptrs,
+                                                       self._w, float(scale), self._stream), "dp_scatter_add_rows")
+            return
+        rows = payload[:M, self.wtot].contiguous().view(torch.int32).to(torch.int64)
+        off = 0
+        for g, w in zip(self.grads, self.widths):
+            g.reshape(self.N, -1).index_add_(0, rows, payload[:M, off:off + w] * scale)
+            off += w
+
+
 def _allreduce_sparse_rows(params: Sequence[torch.Tensor], group, world: int, average: bool,
                            dense_threshold: float = 0.25) -> bool:
     """Row-sparse gradient exchange.  All params must share the leading (per-Gaussian) dimension.
     Returns False (nothing changed) when the caller should use the dense path instead."""
     N = params[0].shape[0]
-    if any(p.shape[0] != N for p in params):
+    if N == 0 or any(p.shape[0] != N for p in params):
         return False
-    dev = params[0].device
-    rows = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(N, -1) for p in params]
-    widths = [r.shape[1] for r in rows]
-    mask = torch.zeros(N, dtype=torch.bool, device=dev)
-    for r in rows:
-        mask |= (r != 0).any(dim=1)
-    idx = mask.nonzero(as_tuple=False).reshape(-1)
-    m_local = torch.tensor([idx.numel()], dtype=torch.int64, device=dev)
+    for p in params:            # a rank without a gradient for some tensor contributes zeros
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        elif not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
+            p.grad = p.grad.contiguous().float()
+    ops = _RowOps([p.grad for p in params])
+    idx = ops.row_mask().nonzero(as_tuple=False).reshape(-1)
+    m_local = torch.tensor([idx.numel()], dtype=torch.int64, device=ops.dev)
     counts_t = [torch.empty_like(m_local) for _ in range(world)]
     dist.all_gather(counts_t, m_local, group=group)
-    counts = [int(c.item()) for c in torch.stack(counts_t).reshape(-1).cpu()]
+    counts = [int(c) for c in torch.stack(counts_t).reshape(-1).cpu()]
     Mmax = max(counts)
     if Mmax * world > dense_threshold * N:        # identical on every rank: the counts are global
         return False
     if Mmax == 0:
         return True
-    M = idx.numel()
-    # one collective: the row index travels as the bit pattern of an extra float32 column (N < 2^31)
-    wsum = sum(widths)
-    pay = torch.zeros(Mmax, wsum + 1, dtype=torch.float32, device=dev)
-    if M:
-        pay[:M, :wsum] = torch.cat([r[idx] for r in rows], dim=1)
-        pay[:M, wsum] = idx.to(torch.int32).view(torch.float32)
+    # one collective: a payload row = the 59 gradient floats + the row index as a float32 bit pattern
+    pay = ops.pack(idx, Mmax)
     pay_all = [torch.empty_like(pay) for _ in range(world)]
     dist.all_gather(pay_all, pay, group=group)
-    idx_all = [pa[:, wsum].contiguous().view(torch.int32).to(torch.int64) for pa in pay_all]
-    # Replicas must stay BIT-identical, so the sum has one fixed order on every rank: rank 0's rows first,
-    # then rank 1's, ...  A rank's row indices are unique, so each index_add_ below has no colliding writes
-    # (a single index_add_ over the concatenation would add in atomic, i.e. arbitrary, order).
+    # Replicas must stay BIT-identical, so the sum has one fixed order on every rank: start from zero, add
+    # rank 0's rows, then rank 1's, ...  A rank's row indices are unique, so no add collides (a single
+    # scatter-add over the concatenation would add in atomic, i.e. arbitrary, order).
+    for p in params:
+        p.grad.zero_()
     scale = 1.0 / world if average else 1.0
-    off = 0
-    for p, w in zip(params, widths):
-        g = torch.zeros(N, w, dtype=torch.float32, device=dev)
-        for r in range(world):
-            if counts[r]:
-                g.index_add_(0, idx_all[r][:counts[r]], pay_all[r][:counts[r], off:off + w])
-        if average:
-            g.mul_(scale)
-        off += w
-        p.grad = g.view_as(p)          # replace (no extra 236 MB copy)
+    for r in range(world):
+        ops.scatter_add(pay_all[r], counts[r], scale)
     return True

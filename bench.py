@@ -205,6 +205,7 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     n_isect = ops.last_num_intersects
+    rows_with_grad = int((params["means"].grad != 0).any(dim=1).sum()) if params["means"].grad is not None else 0
 
     if rank == 0:
         npix = H * W
@@ -279,6 +280,7 @@ def main():
                        "tile_intersections_per_step": n_isect,
                        "tile_intersections_emitted": int(sum(ops.last_slice_intersects)) if ops.SLICE_BASE > 0 else n_isect,
                        "depth_slices": list(ops.last_slice_intersects) if ops.SLICE_BASE > 0 else None,
+                       "gaussians_with_gradient": rows_with_grad,
                        "views_per_step": world,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "gradient_exchange": args.allreduce if world > 1 else None,

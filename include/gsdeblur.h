@@ -231,6 +231,21 @@ int gs_combine_fwd(int S, long long n, const float* samples /*S*n*/, float gamma
 int gs_combine_bwd(int S, long long n, const float* samples, float gamma, float min_level,
                    const float* out, const float* v_out, float* v_samples /*S*n*/, void* stream);
 
+/* ---- data-parallel gradient exchange (no reference counterpart: the reference is single-GPU,
+ *      train.py:114-122 passes no device / world-size flags) -------------------------------------------------
+ * The Gaussian gradient tensors share the leading dimension N; tensor t has widths[t] floats per row
+ * (means 3, scales 3, quats 4, opacities 1, features_dc 3, features_rest 45 at SH degree 3).  `grads` and
+ * `widths` are HOST arrays of n_tensors (<= 16) entries; grads[t] are device pointers.
+ * A payload row is wtot = sum(widths) floats followed by the row index as an int32 bit pattern. */
+int gs_dp_row_mask(int N, int n_tensors, float* const* grads, const int* widths,
+                   unsigned char* mask /*N: 1 where any of the row's floats is non-zero*/, void* stream);
+int gs_dp_pack_rows(long long M, const long long* row_idx /*M, device, int64*/, int n_tensors,
+                    float* const* grads, const int* widths, float* payload /*M*(wtot+1)*/, void* stream);
+/* grads[t][row] += scale * payload row, for the M payload rows; the row indices of ONE payload must be unique
+ * (no atomics).  Apply the ranks' payloads in rank order for a bit-identical sum on every rank. */
+int gs_dp_scatter_add_rows(long long M, const float* payload, int n_tensors, float* const* grads,
+                           const int* widths, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -645,3 +645,42 @@ def test_training_loop_with_densification(gs, oracle, dev):
     assert len(results) == 5 and sum(r["split"] + r["duplicated"] for r in results) > 0
     assert sizes[-1] != sizes[0]
     assert min(losses[-10:]) < losses[0]
+
+
+# --------------------------------------------------------------------------- #
+# device side of the row-sparse gradient exchange (the collective itself is covered by the
+# world-2 gloo tests on CPU; here the HIP row kernels are held against the torch ops they replace)
+# --------------------------------------------------------------------------- #
+def test_dp_row_kernels_match_torch(gs, dev):
+    from gsdeblur_amd.dp import _RowOps
+    N = 20011
+    shapes = [(N, 3), (N, 3), (N, 4), (N, 1), (N, 3), (N, 15, 3)]
+    world = 3
+    gens = [torch.Generator().manual_seed(900 + r) for r in range(world)]
+    rank_grads = []
+    for r in range(world):
+        touched = torch.rand(N, generator=gens[r]) < 0.03
+        rank_grads.append([torch.randn(s, generator=gens[r]) * touched.view(-1, *([1] * (len(s) - 1))) for s in shapes])
+    rank_grads[1][3].zero_()                                   # a tensor that is zero on one rank
+    payloads, counts = [], []
+    for r in range(world):
+        cpu = _RowOps([g.clone() for g in rank_grads[r]])
+        hip = _RowOps([g.clone().to(dev) for g in rank_grads[r]])
+        m_cpu, m_hip = cpu.row_mask(), hip.row_mask()
+        assert torch.equal(m_cpu, m_hip.cpu())
+        idx = m_cpu.nonzero().reshape(-1)
+        Mpad = idx.numel() + 7
+        p_cpu, p_hip = cpu.pack(idx, Mpad), hip.pack(idx.to(dev), Mpad)
+        assert torch.equal(p_cpu.view(torch.int32), p_hip.cpu().view(torch.int32))       # bit-exact incl. the index column
+        payloads.append(p_cpu)
+        counts.append(idx.numel())
+    # every "rank" applies all payloads in rank order: HIP result == torch result, bit for bit
+    acc_cpu = _RowOps([torch.zeros(s) for s in shapes])
+    acc_hip = _RowOps([torch.zeros(s, device=dev) for s in shapes])
+    for r in range(world):
+        acc_cpu.scatter_add(payloads[r], counts[r], 1.0 / world)
+        acc_hip.scatter_add(payloads[r].to(dev), counts[r], 1.0 / world)
+    for a, b, i in zip(acc_cpu.grads, acc_hip.grads, range(len(shapes))):
+        assert torch.equal(a, b.cpu()), i
+        want = sum(rank_grads[r][i] for r in range(world)) / world
+        assert torch.allclose(a, want, atol=1e-6)
