@@ -51,7 +51,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     for src, extra in SOURCES:
         s = CSRC / src
         o = build_dir / (s.stem + ".o")
-        if force or _stale(o, [s, *headers]):
+        if force or _stale(o, [s, *headers, Path(__file__)]):     # the flags live in this file
             cmd = [hipcc, *COMMON, *extra, "-c", str(s), "-o", str(o)]
             if verbose:
                 print(" ".join(cmd))
