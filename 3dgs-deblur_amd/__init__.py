@@ -15,6 +15,7 @@ from .ops import (  # noqa: F401
     bin_and_sort_gaussians,
     bin_and_sort_records,
     render_subposes,
+    render_combined,
     subpose_viewmats,
     subpose_schedule,
     combine_samples,

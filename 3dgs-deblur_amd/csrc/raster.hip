@@ -146,18 +146,6 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
 // sub-frame averaging in linearised colour:
 //   out = ( mean_k max(C_k, m)^gamma )^(1/gamma),  m = min_rgb_level/255
 // ---------------------------------------------------------------------------
-// x^y for x > 0 as exp2(y*log2(x)) on the hardware transcendentals (HIP's __powf expands to the
-// full-precision ocml pow, ~100 instructions)
-__device__ __forceinline__ float fast_pow(float x, float y) {
-  return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
-}
-
-__device__ __forceinline__ float combine_lin(float c, float gamma, float m) {
-  if (m > 0.f) c = fmaxf(c, m);
-  if (gamma != 1.f) c = fast_pow(fmaxf(c, 1e-12f), gamma);
-  return c;
-}
-
 // 4 values per thread (16-byte loads/stores); n4 = n/4 vectors, scalar tail handled by the last threads
 __global__ __launch_bounds__(256) void combine_fwd_kernel(int S, size_t n, const float* __restrict__ samples,
                                                           float gamma, float m, float* __restrict__ out) {
@@ -182,15 +170,6 @@ __global__ __launch_bounds__(256) void combine_fwd_kernel(int S, size_t n, const
       out[j] = gamma != 1.f ? fast_pow(acc, ig) : acc;
     }
   }
-}
-
-__device__ __forceinline__ float combine_grad(float c, float g, float gamma, float m) {
-  if (m > 0.f && c < m) return 0.f;
-  if (gamma != 1.f) {
-    if (c < 1e-12f) return 0.f;
-    g *= gamma * fast_pow(c, gamma - 1.f);
-  }
-  return g;
 }
 
 __global__ __launch_bounds__(256) void combine_bwd_kernel(int S, size_t n, const float* __restrict__ samples,

@@ -14,6 +14,12 @@ struct RasterParams {
   const int*   band_edges;   // [R+1] tile-row edges of the rolling-shutter bands
   const float* background;   // [3]
   int S, R, H, W, tiles_x, tiles_y;
+  // backward only: fold the gamma-space sub-frame average's backward into the pixel prologue.  With
+  // cmb_v_out != null the kernel's v_img argument holds the SAMPLE IMAGES [S,H,W,3] and every pixel derives its
+  // own d loss / d sample from the averaged image cmb_out [H,W,3] and its gradient cmb_v_out [H,W,3].
+  const float* cmb_v_out;
+  const float* cmb_out;
+  float cmb_gamma, cmb_min;
 };
 
 __device__ __forceinline__ int find_band(const int* __restrict__ edges, int R, int ty) {
@@ -37,6 +43,39 @@ __device__ __forceinline__ Rec9 load_rec(const float* __restrict__ records, int 
 }
 
 
+// ---------------------------------------------------------------------------
+// sub-frame averaging in linearised colour:
+//   out = ( mean_k max(C_k, m)^gamma )^(1/gamma),  m = min_rgb_level/255
+// ---------------------------------------------------------------------------
+// x^y for x > 0 as exp2(y*log2(x)) on the hardware transcendentals (HIP's __powf expands to the
+// full-precision ocml pow, ~100 instructions)
+__device__ __forceinline__ float fast_pow(float x, float y) {
+  return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+}
+
+__device__ __forceinline__ float combine_lin(float c, float gamma, float m) {
+  if (m > 0.f) c = fmaxf(c, m);
+  if (gamma != 1.f) c = fast_pow(fmaxf(c, 1e-12f), gamma);
+  return c;
+}
+
+__device__ __forceinline__ float combine_grad(float c, float g, float gamma, float m) {
+  if (m > 0.f && c < m) return 0.f;
+  if (gamma != 1.f) {
+    if (c < 1e-12f) return 0.f;
+    g *= gamma * fast_pow(c, gamma - 1.f);
+  }
+  return g;
+}
+
+// d loss / d sample value c, given the averaged value o and its gradient vo (what combine_bwd_kernel writes)
+__device__ __forceinline__ float combine_sample_grad(float c, float o, float vo, float invS, float gamma, float m) {
+  float d = invS;
+  if (gamma != 1.f) d *= fast_pow(fmaxf(o, 1e-12f), 1.f - gamma) / gamma;
+  d *= vo;
+  return combine_grad(c, d, gamma, m);
+}
+
 // fills the launch parameters shared by every compositing entry point
 static inline RasterParams make_raster_params(const float* records, const int* sorted_vals, const int* tile_bins,
                                               const int* band_edges, const float* background, int S, int R, int H,
@@ -47,6 +86,7 @@ static inline RasterParams make_raster_params(const float* records, const int* s
   prm.band_edges = band_edges; prm.background = background;
   prm.S = S; prm.R = R; prm.H = H; prm.W = W;
   prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
+  prm.cmb_v_out = nullptr; prm.cmb_out = nullptr; prm.cmb_gamma = 1.f; prm.cmb_min = 0.f;
   return prm;
 }
 

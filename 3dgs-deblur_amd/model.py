@@ -116,7 +116,6 @@ class SplatfactoDeblurModel(nn.Module):
         else:
             self.velocity_adjustment = None
         self.radii: Optional[Tensor] = None
-        self.last_samples: Optional[Tensor] = None
         # densification statistics (densify.py): when enabled, every training render leaves the summed
         # screen-space centre gradient of its backward pass in self.xy_grad [N,2] (pixels)
         self.collect_densify_stats = False
@@ -202,17 +201,16 @@ class SplatfactoDeblurModel(nn.Module):
         self.xy_grad = None
         if self.training and self.collect_densify_stats:
             self.xy_grad = torch.zeros(self.num_points, 2, device=dev)
-        samples, alphas, radii = ops.render_subposes(
-            self.means, torch.exp(self.scales), self.quats, torch.sigmoid(self.opacities).reshape(-1), sh,
-            viewmats, bg, S, R, camera.fx, camera.fy, camera.cx, camera.cy, camera.height, camera.width,
-            sh_degree=cfg.sh_degree, antialiased=(cfg.rasterize_mode == "antialiased"), xy_grad_out=self.xy_grad)
-        self.radii = radii
-        self.last_size = (camera.width, camera.height)
-        self.last_samples = samples
         gamma = cfg.gamma if use_gamma else 1.0
         min_level = cfg.min_rgb_level if use_gamma else 0.0
-        rgb = ops.combine_samples(samples, gamma, min_level) if (S > 1 or gamma != 1.0 or min_level > 0) \
-            else samples[0]
+        # one autograd node for composite + gamma-space average: no [S,H,W,3] sample-gradient tensor in backward
+        rgb, alphas, radii = ops.render_combined(
+            self.means, torch.exp(self.scales), self.quats, torch.sigmoid(self.opacities).reshape(-1), sh,
+            viewmats, bg, S, R, camera.fx, camera.fy, camera.cx, camera.cy, camera.height, camera.width,
+            gamma=gamma, min_rgb_level=min_level, sh_degree=cfg.sh_degree,
+            antialiased=(cfg.rasterize_mode == "antialiased"), xy_grad_out=self.xy_grad)
+        self.radii = radii
+        self.last_size = (camera.width, camera.height)
         accumulation = alphas.mean(dim=0)[..., None]
         out = {"rgb": torch.clamp(rgb, max=1.0) if not self.training else rgb,
                "accumulation": accumulation, "background": bg}

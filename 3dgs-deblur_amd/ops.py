@@ -440,10 +440,13 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
 
 def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, img_width: int, bg: Tensor,
                     edges: Tensor, out_T: Tensor, v_img: Tensor, v_alpha: Optional[Tensor], v_records: Tensor,
-                    touched: Optional[Tensor] = None):
+                    touched: Optional[Tensor] = None, combine=None):
+    """combine = (v_rgb [H,W,3], rgb [H,W,3], gamma, m): v_img then holds the SAMPLE IMAGES and the kernel derives
+    each pixel's sample gradient itself (gs_combine_bwd folded into the compositor's backward)."""
     L = _L()
     H, W = img_height, img_width
     dev = records.device
+    cmb = combine if combine is not None else (None, None, 1.0, 0.0)
     # reverse-traversal state between slices: running T and (behind-colour . v_out), ONE float per pixel each;
     # a frame that needed a single slice (the common case) carries none
     bwd_T = bwd_B = None
@@ -459,7 +462,8 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
             _check(L.gs_rasterize_bwd_slice(_ptr(records), _ptr(sl["svals"]), _ptr(sl["bins"]), _ptr(edges), _ptr(bg),
                                             S, R, H, W, _ptr(out_T), _ptr(sl["fidx"]), _ptr(v_img), _ptr(v_alpha),
                                             _ptr(bwd_T), _ptr(bwd_B), _ptr(v_records), _ptr(sl["gi_of_e"]),
-                                            _ptr(tuples), _ptr(flags), RASTER_BWD_VARIANT, _stream()),
+                                            _ptr(tuples), _ptr(flags), RASTER_BWD_VARIANT, _ptr(cmb[0]), _ptr(cmb[1]),
+                                            cmb[2], cmb[3], _stream()),
                    "rasterize_bwd_slice")
         if tuples is not None:
             with _stage("grad_reduce"):
@@ -734,7 +738,10 @@ def subpose_schedule(blur_samples: int, exposure_time: float, rs_bands: int, rol
 class _RenderSubposes(Function):
     @staticmethod
     def forward(ctx, means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
-                img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out):
+                img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out, return_alpha,
+                gamma, min_rgb_level):
+        # an output the loss does not use arrives as None in backward instead of a materialised zero tensor
+        ctx.set_materialize_grads(False)
         means3d, scales, quats = _f32(means3d, "means3d"), _f32(scales, "scales"), _f32(quats, "quats")
         opacities, sh = _f32(opacities, "opacities").reshape(-1), _f32(sh, "sh")
         if xy_grad_out is not None:
@@ -770,23 +777,52 @@ class _RenderSubposes(Function):
         ctx.slices = slices
         svals = bins = fidx = torch.zeros(1, dtype=torch.int32, device=dev)
         n_isect = last_num_intersects
-        ctx.save_for_backward(means3d, scales, quats, opacities, sh, V, records, svals, bins, edges, bg, out_T, fidx)
+        ctx.combine = None
+        first = cmb_samples = cmb_rgb = out_img
+        if gamma is not None:
+            # fused sub-frame averaging: output 0 is the averaged image; backward never materialises the
+            # per-sample gradients (the compositor's backward derives them per pixel)
+            m = float(min_rgb_level) / 255.0
+            first = cmb_rgb = torch.empty(H, W, 3, device=dev)
+            _check(L.gs_combine_fwd(S, H * W * 3, _ptr(out_img), float(gamma), m, _ptr(first), _stream()), "combine_fwd")
+            ctx.combine = (float(gamma), m)
+        else:
+            cmb_samples = cmb_rgb = svals          # placeholders: nothing to keep
+        ctx.save_for_backward(means3d, scales, quats, opacities, sh, V, records, svals, bins, edges, bg, out_T, fidx,
+                              cmb_samples, cmb_rgb)
         ctx.args = args
         ctx.SR = (S, R)
         ctx.n_isect = n_isect
         ctx.bg_grad = background is not None and ctx.needs_input_grad[6]
         ctx.mark_non_differentiable(radii)
-        return out_img, 1.0 - out_T, radii
+        ctx.img_shape = (S, H, W, 3) if gamma is None else (H, W, 3)
+        return first, (1.0 - out_T) if return_alpha else None, radii
 
     @staticmethod
     def backward(ctx, v_img, v_alpha, _v_radii):
-        (means3d, scales, quats, opacities, sh, V, records, svals, bins, edges, bg, out_T, fidx) = ctx.saved_tensors
+        (means3d, scales, quats, opacities, sh, V, records, svals, bins, edges, bg, out_T, fidx, cmb_samples,
+         cmb_rgb) = ctx.saved_tensors
         N, P, glob, K, deg, fx, fy, cx, cy, H, W, clip, aa = ctx.args
         S, R = ctx.SR
         dev = means3d.device
         L = _L()
-        v_img = v_img.contiguous().float()
+        if v_img is None and v_alpha is None:
+            return (None,) * 23
+        v_img = torch.zeros(ctx.img_shape, device=dev) if v_img is None else v_img.contiguous().float()
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
+        combine = None
+        if ctx.combine is not None:
+            samples, rgb = cmb_samples, cmb_rgb
+            gamma, m = ctx.combine
+            if ctx.bg_grad:
+                # a learnable background needs the per-sample gradients themselves: two-step backward
+                v_samples = torch.empty_like(samples)
+                _check(L.gs_combine_bwd(S, rgb.numel(), _ptr(samples), gamma, m, _ptr(rgb), _ptr(v_img),
+                                        _ptr(v_samples), _stream()), "combine_bwd")
+                v_img = v_samples
+            else:
+                combine = (v_img, rgb, gamma, m)
+                v_img = samples
         # atomic-free path: only Gaussians the compositor touched get a gradient record (plain stores) and a
         # `touched` flag; the projection backward skips everything else, so v_records needs no 240 MB memset
         all_tuples = all(sl["gi_of_e"] is not None for sl in ctx.slices)
@@ -797,18 +833,20 @@ class _RenderSubposes(Function):
             v_records = torch.zeros(P * N, REC, device=dev)
             touched = None
         if ctx.sliced:
-            sliced_backward(records, ctx.slices, S, R, H, W, bg, edges, out_T, v_img, v_al, v_records, touched)
+            sliced_backward(records, ctx.slices, S, R, H, W, bg, edges, out_T, v_img, v_al, v_records, touched,
+                            combine)
         else:
             with _stage("raster_bwd"):
                 _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
                                           _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records),
                                           _stream()), "rasterize_bwd")
-        alloc = torch.zeros if touched is not None else torch.empty     # untouched Gaussians are skipped
-        v_means = alloc(N, 3, device=dev)
-        v_scales = alloc(N, 3, device=dev)
-        v_quats = alloc(N, 4, device=dev)
-        v_opac = alloc(N, device=dev)
-        v_sh = alloc(N, K, 3, device=dev)
+        # the five dense gradient outputs are carved out of ONE buffer: with touched flags the kernel skips
+        # untouched Gaussians, so the buffer is zero-filled (one fill instead of five)
+        alloc = torch.zeros if touched is not None else torch.empty
+        sizes = [3 * N, 3 * N, 4 * N, N, 3 * K * N]
+        flat = alloc(sum(sizes), device=dev)
+        v_means, v_scales, v_quats, v_opac, v_sh = (t.view(shape) for t, shape in zip(
+            flat.split(sizes), [(N, 3), (N, 3), (N, 4), (N,), (N, K, 3)]))
         need_v = ctx.needs_input_grad[5]
         v_V = torch.zeros(P, 4, 4, device=dev) if need_v else None
         xy_out = ctx.xy_grad_out
@@ -821,21 +859,38 @@ class _RenderSubposes(Function):
                                           _ptr(v_sh), _ptr(v_V), _ptr(touched), _ptr(xy_out), _stream()),
                    "project_fused_bwd")
         v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
-        return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 13
+        return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 16
 
 
 def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, sh: Tensor,
                     viewmats: Tensor, background: Optional[Tensor], blur_samples: int, rs_bands: int,
                     fx: float, fy: float, cx: float, cy: float, img_height: int, img_width: int,
                     sh_degree: int = 3, antialiased: bool = True, glob_scale: float = 1.0,
-                    clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None):
+                    clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None, return_alpha: bool = True):
     """Fused hot path: project N Gaussians under P=S*R sub-pose viewmats, bin, sort, composite.
     -> (samples [S,H,W,3], alphas [S,H,W], radii int32 [P,N]).  scales/opacities are activated values.
     xy_grad_out (optional float32 [N,2]) is OVERWRITTEN during backward with the sum over the sub-poses of
-    the screen-space centre gradient in pixels — what splatfacto's densification reads from ``xys.grad``."""
+    the screen-space centre gradient in pixels — what splatfacto's densification reads from ``xys.grad``.
+    return_alpha=False returns None for alphas (as gsplat's rasterize_gaussians does by default)."""
     S, R = max(1, int(blur_samples)), max(1, int(rs_bands))
     return _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
-                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out)
+                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
+                                 bool(return_alpha), None, None)
+
+
+def render_combined(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, sh: Tensor,
+                    viewmats: Tensor, background: Optional[Tensor], blur_samples: int, rs_bands: int,
+                    fx: float, fy: float, cx: float, cy: float, img_height: int, img_width: int,
+                    gamma: float = 1.0, min_rgb_level: float = 0.0, sh_degree: int = 3, antialiased: bool = True,
+                    glob_scale: float = 1.0, clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None,
+                    return_alpha: bool = True):
+    """render_subposes + combine_samples as ONE autograd node: -> (rgb [H,W,3], alphas [S,H,W] or None, radii).
+    Same values as the two-step form; the backward skips the [S,H,W,3] per-sample gradient tensor — the
+    compositor's backward derives every pixel's sample gradient from rgb and its gradient."""
+    S, R = max(1, int(blur_samples)), max(1, int(rs_bands))
+    return _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
+                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
+                                 bool(return_alpha), float(gamma), float(min_rgb_level))
 
 
 # --------------------------------------------------------------------------- #

@@ -173,11 +173,10 @@ def main():
         for p in all_params + [lin, ang, viewmat]:
             p.grad = None
         vms = gs.subpose_viewmats(viewmat, lin, ang, times_t)
-        samples, alphas, _ = gs.render_subposes(params["means"], params["log_scales"].exp(), params["quats"],
-                                                torch.sigmoid(params["opacity_logits"]), params["sh"], vms, bg, S, R,
-                                                sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, sh_degree=3,
-                                                antialiased=True)
-        out = gs.combine_samples(samples, 2.2, 10.0)
+        out, _, _ = gs.render_combined(params["means"], params["log_scales"].exp(), params["quats"],
+                                       torch.sigmoid(params["opacity_logits"]), params["sh"], vms, bg, S, R,
+                                       sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2, min_rgb_level=10.0,
+                                       sh_degree=3, antialiased=True, return_alpha=False)   # the loss reads RGB only
         loss = (out * wt).sum()
         loss.backward()
         if world > 1:

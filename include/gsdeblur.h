@@ -212,7 +212,11 @@ int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const i
                            const int* gi_of_e /*as in the forward*/,
                            float* tuples /*[I*12] or NULL*/, unsigned char* flags /*[I], zeroed, or NULL*/,
                            int variant /*0 = default; 2 = timing ablation: plain stores instead of atomics (wrong gradients)*/,
-                           void* stream);
+                           const float* cmb_v_out /*[H,W,3] or NULL.  Non-NULL folds gs_combine_bwd into this launch:
+                                                    v_img then holds the SAMPLE IMAGES [S,H,W,3] and each pixel derives
+                                                    its sample gradient from cmb_out and cmb_v_out*/,
+                           const float* cmb_out /*[H,W,3] averaged image (gs_combine_fwd output), NULL iff cmb_v_out is*/,
+                           float cmb_gamma, float cmb_min_level, void* stream);
 
 /* Atomic-free gradient accumulation: with gi_of_e, tuples and flags given, gs_rasterize_bwd_slice writes the 9
  * gradients of sorted entry i to tuples[e*12..] (e = sorted_vals[i]) and sets flags[e]; the tuples of slice

@@ -684,3 +684,44 @@ def test_dp_row_kernels_match_torch(gs, dev):
         assert torch.equal(a, b.cpu()), i
         want = sum(rank_grads[r][i] for r in range(world)) / world
         assert torch.allclose(a, want, atol=1e-6)
+
+
+@pytest.mark.parametrize("S,R,base,learn_bg", [(3, 2, 16, False), (4, 1, 512, False), (2, 1, 4, True)])
+def test_render_combined_equals_two_step(gs, oracle, dev, S, R, base, learn_bg):
+    """render_combined (one autograd node, sample gradients derived inside the compositor's backward) ==
+    render_subposes + combine_samples: same image bit for bit, same gradients; with a learnable background the
+    fused node falls back to the two-step backward."""
+    from gsdeblur_amd import ops
+    O = oracle
+    W, H, n = 144, 96, 2500
+    sc = O.synthetic_scene(n, W, H, seed=41 + S, scale_mult=6.0)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel", "viewmat"]
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, R, 1 / 30)
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(8)).to(dev)
+    wa = torch.rand(S, H, W, generator=torch.Generator().manual_seed(9)).to(dev)
+    old_base = ops.SLICE_BASE
+    ops.SLICE_BASE = base
+    try:
+        res = []
+        for fused in (False, True):
+            p = {k: sc[k].float().to(dev).requires_grad_(True) for k in names}
+            bgp = torch.tensor([0.2, 0.1, 0.3], device=dev, requires_grad=learn_bg)
+            vms = gs.subpose_viewmats(p["viewmat"], p["lin_vel"], p["ang_vel"], torch.tensor(times, device=dev))
+            args = (p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["opacity_logits"]), p["sh"], vms,
+                    bgp, S, R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W)
+            if fused:
+                rgb, alphas, radii = gs.render_combined(*args, gamma=2.2, min_rgb_level=10.0)
+            else:
+                samples, alphas, radii = gs.render_subposes(*args)
+                rgb = gs.combine_samples(samples, 2.2, 10.0)
+            ((rgb * wt).sum() + 0.3 * (alphas * wa).sum()).backward()
+            res.append((rgb.detach(), alphas.detach(), {k: v.grad for k, v in p.items()}, bgp.grad))
+    finally:
+        ops.SLICE_BASE = old_base
+    (rgb0, al0, g0, b0), (rgb1, al1, g1, b1) = res
+    assert torch.equal(rgb0, rgb1) and torch.equal(al0, al1)
+    for k in names:
+        assert rel_max(g1[k].cpu(), g0[k].cpu()) < 1e-6, k
+    if learn_bg:
+        assert rel_max(b1.cpu(), b0.cpu()) < 1e-6
