@@ -44,10 +44,11 @@ _SIGS = {
     "gs_emit_open_intersects": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, ctypes.c_uint, _I, _I, _P],
     "gs_slice_counts_exact": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     "gs_rasterize_fwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],
-    "gs_rasterize_bwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _F, _F, _P],
+    "gs_rasterize_bwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _F, _F, _P],
     "gs_reduce_grad_tuples": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "gs_combine_fwd": [_I, _L, _P, _F, _F, _P, _P],
     "gs_combine_bwd": [_I, _L, _P, _F, _F, _P, _P, _P, _P],
+    "gs_combine_bwd_scale": [_I, _L, _F, _P, _P, _P, _P],
     # host arrays (pointer table, widths) are passed as ctypes arrays -> plain pointers
     "gs_dp_row_mask": [_I, _I, _P, _P, _P, _P],
     "gs_dp_pack_rows": [_L, _P, _I, _P, _P, _P, _P],

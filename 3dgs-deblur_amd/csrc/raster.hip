@@ -183,12 +183,8 @@ __global__ __launch_bounds__(256) void combine_bwd_kernel(int S, size_t n, const
   if (i + 3 < n) {
     float4 o = *reinterpret_cast<const float4*>(out + i);
     float4 vo = *reinterpret_cast<const float4*>(v_out + i);
-    float4 d = make_float4(invS, invS, invS, invS);
-    if (gamma != 1.f) {
-      d.x *= fast_pow(fmaxf(o.x, 1e-12f), 1.f - gamma) / gamma; d.y *= fast_pow(fmaxf(o.y, 1e-12f), 1.f - gamma) / gamma;
-      d.z *= fast_pow(fmaxf(o.z, 1e-12f), 1.f - gamma) / gamma; d.w *= fast_pow(fmaxf(o.w, 1e-12f), 1.f - gamma) / gamma;
-    }
-    d.x *= vo.x; d.y *= vo.y; d.z *= vo.z; d.w *= vo.w;
+    float4 d = make_float4(combine_scale(o.x, vo.x, invS, gamma), combine_scale(o.y, vo.y, invS, gamma),
+                           combine_scale(o.z, vo.z, invS, gamma), combine_scale(o.w, vo.w, invS, gamma));
     for (int k = 0; k < S; ++k) {
       float4 c = *reinterpret_cast<const float4*>(samples + (size_t)k * n + i);
       float4 g = make_float4(combine_grad(c.x, d.x, gamma, m), combine_grad(c.y, d.y, gamma, m),
@@ -197,11 +193,17 @@ __global__ __launch_bounds__(256) void combine_bwd_kernel(int S, size_t n, const
     }
   } else {
     for (size_t j = i; j < n; ++j) {
-      float dm = invS * v_out[j];
-      if (gamma != 1.f) dm *= fast_pow(fmaxf(out[j], 1e-12f), 1.f - gamma) / gamma;
+      float dm = combine_scale(out[j], v_out[j], invS, gamma);
       for (int k = 0; k < S; ++k) v_samples[(size_t)k * n + j] = combine_grad(samples[(size_t)k * n + j], dm, gamma, m);
     }
   }
+}
+
+// the sample-independent factor of combine_bwd alone (consumed by the compositor's backward prologue)
+__global__ __launch_bounds__(256) void combine_scale_kernel(int S, size_t n, float gamma, const float* __restrict__ out,
+                                                            const float* __restrict__ v_out, float* __restrict__ scale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) scale[i] = combine_scale(out[i], v_out[i], 1.f / (float)S, gamma);
 }
 
 }  // namespace gs
@@ -269,5 +271,16 @@ GS_EXPORT int gs_combine_bwd(int S, long long n, const float* samples, float gam
   unsigned blocks = (unsigned)((n + 1023) / 1024);
   hipLaunchKernelGGL(combine_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, (size_t)n, samples,
                      gamma, min_level, out, v_out, v_samples);
+  return gs_launch_status();
+}
+
+// scale [n] = (1/S) * d out / d mean * v_out: what gs_rasterize_bwd_slice(cmb_scale=...) consumes to derive the
+// per-sample gradients itself instead of reading the [S,n] tensor gs_combine_bwd would write.
+GS_EXPORT int gs_combine_bwd_scale(int S, long long n, float gamma, const float* out, const float* v_out,
+                                   float* scale, void* stream) {
+  if (S <= 0 || n <= 0) return GS_ERR_INVALID;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(combine_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, (size_t)n, gamma, out,
+                     v_out, scale);
   return gs_launch_status();
 }

@@ -87,14 +87,13 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
       const float Tfin = out_T[pix];
       fin[k] = final_idx[pix];
       vr[k] = v_img[pix * 3 + 0]; vg[k] = v_img[pix * 3 + 1]; vb[k] = v_img[pix * 3 + 2];
-      if (prm.cmb_v_out) {
-        // v_img holds the sample image: derive d loss / d sample from the averaged image and its gradient
-        // (the arithmetic of combine_bwd_kernel, so the fused and the two-step backward agree bit for bit)
+      if (prm.cmb_scale) {
+        // v_img holds the sample image: d loss / d sample = combine_grad(sample, scale) — the arithmetic of
+        // combine_bwd_kernel, so the fused and the two-step backward agree bit for bit
         const size_t q = ((size_t)y * prm.W + px) * 3;
-        const float invS = 1.f / (float)prm.S;
-        vr[k] = combine_sample_grad(vr[k], prm.cmb_out[q + 0], prm.cmb_v_out[q + 0], invS, prm.cmb_gamma, prm.cmb_min);
-        vg[k] = combine_sample_grad(vg[k], prm.cmb_out[q + 1], prm.cmb_v_out[q + 1], invS, prm.cmb_gamma, prm.cmb_min);
-        vb[k] = combine_sample_grad(vb[k], prm.cmb_out[q + 2], prm.cmb_v_out[q + 2], invS, prm.cmb_gamma, prm.cmb_min);
+        vr[k] = combine_grad(vr[k], prm.cmb_scale[q + 0], prm.cmb_gamma, prm.cmb_min);
+        vg[k] = combine_grad(vg[k], prm.cmb_scale[q + 1], prm.cmb_gamma, prm.cmb_min);
+        vb[k] = combine_grad(vb[k], prm.cmb_scale[q + 2], prm.cmb_gamma, prm.cmb_min);
       }
       const float va_out = v_alpha ? v_alpha[pix] : 0.f;
       const float va = Tfin * (va_out - (bgr * vr[k] + bgg * vg[k] + bgb * vb[k]));
@@ -468,13 +467,12 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
                                      const float* out_T, const int* final_idx, const float* v_img,
                                      const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records,
                                      const int* gi_of_e, float* tuples, unsigned char* flags, int variant,
-                                     const float* cmb_v_out, const float* cmb_out, float cmb_gamma,
-                                     float cmb_min_level, void* stream) {
+                                     const float* cmb_scale, float cmb_gamma, float cmb_min_level,
+                                     void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
-  if ((cmb_v_out == nullptr) != (cmb_out == nullptr)) return GS_ERR_INVALID;
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
   prm.gi_of_e = gi_of_e;
-  prm.cmb_v_out = cmb_v_out; prm.cmb_out = cmb_out; prm.cmb_gamma = cmb_gamma; prm.cmb_min = cmb_min_level;
+  prm.cmb_scale = cmb_scale; prm.cmb_gamma = cmb_gamma; prm.cmb_min = cmb_min_level;
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
   hipStream_t st = (hipStream_t)stream;

@@ -15,10 +15,10 @@ struct RasterParams {
   const float* background;   // [3]
   int S, R, H, W, tiles_x, tiles_y;
   // backward only: fold the gamma-space sub-frame average's backward into the pixel prologue.  With
-  // cmb_v_out != null the kernel's v_img argument holds the SAMPLE IMAGES [S,H,W,3] and every pixel derives its
-  // own d loss / d sample from the averaged image cmb_out [H,W,3] and its gradient cmb_v_out [H,W,3].
-  const float* cmb_v_out;
-  const float* cmb_out;
+  // cmb_scale != null the kernel's v_img argument holds the SAMPLE IMAGES [S,H,W,3] and every pixel derives its
+  // own d loss / d sample from cmb_scale [H,W,3] = d loss / d (mean of the linearised samples) / S
+  // (gs_combine_bwd_scale: the part of the chain rule that is the same for all S samples).
+  const float* cmb_scale;
   float cmb_gamma, cmb_min;
 };
 
@@ -68,12 +68,12 @@ __device__ __forceinline__ float combine_grad(float c, float g, float gamma, flo
   return g;
 }
 
-// d loss / d sample value c, given the averaged value o and its gradient vo (what combine_bwd_kernel writes)
-__device__ __forceinline__ float combine_sample_grad(float c, float o, float vo, float invS, float gamma, float m) {
+// the sample-independent factor of the average's backward, given the averaged value o and its gradient vo:
+// (1/S) * d out / d mean * vo, with d out / d mean = (1/gamma) mean^(1/gamma - 1) = out^(1-gamma) / gamma
+__device__ __forceinline__ float combine_scale(float o, float vo, float invS, float gamma) {
   float d = invS;
   if (gamma != 1.f) d *= fast_pow(fmaxf(o, 1e-12f), 1.f - gamma) / gamma;
-  d *= vo;
-  return combine_grad(c, d, gamma, m);
+  return d * vo;
 }
 
 // fills the launch parameters shared by every compositing entry point
@@ -86,7 +86,7 @@ static inline RasterParams make_raster_params(const float* records, const int* s
   prm.band_edges = band_edges; prm.background = background;
   prm.S = S; prm.R = R; prm.H = H; prm.W = W;
   prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
-  prm.cmb_v_out = nullptr; prm.cmb_out = nullptr; prm.cmb_gamma = 1.f; prm.cmb_min = 0.f;
+  prm.cmb_scale = nullptr; prm.cmb_gamma = 1.f; prm.cmb_min = 0.f;
   return prm;
 }
 

@@ -441,12 +441,12 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
 def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, img_width: int, bg: Tensor,
                     edges: Tensor, out_T: Tensor, v_img: Tensor, v_alpha: Optional[Tensor], v_records: Tensor,
                     touched: Optional[Tensor] = None, combine=None):
-    """combine = (v_rgb [H,W,3], rgb [H,W,3], gamma, m): v_img then holds the SAMPLE IMAGES and the kernel derives
-    each pixel's sample gradient itself (gs_combine_bwd folded into the compositor's backward)."""
+    """combine = (scale [H,W,3], gamma, m): v_img then holds the SAMPLE IMAGES and the kernel derives each
+    pixel's sample gradient itself (gs_combine_bwd folded into the compositor's backward)."""
     L = _L()
     H, W = img_height, img_width
     dev = records.device
-    cmb = combine if combine is not None else (None, None, 1.0, 0.0)
+    cmb = combine if combine is not None else (None, 1.0, 0.0)
     # reverse-traversal state between slices: running T and (behind-colour . v_out), ONE float per pixel each;
     # a frame that needed a single slice (the common case) carries none
     bwd_T = bwd_B = None
@@ -462,8 +462,8 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
             _check(L.gs_rasterize_bwd_slice(_ptr(records), _ptr(sl["svals"]), _ptr(sl["bins"]), _ptr(edges), _ptr(bg),
                                             S, R, H, W, _ptr(out_T), _ptr(sl["fidx"]), _ptr(v_img), _ptr(v_alpha),
                                             _ptr(bwd_T), _ptr(bwd_B), _ptr(v_records), _ptr(sl["gi_of_e"]),
-                                            _ptr(tuples), _ptr(flags), RASTER_BWD_VARIANT, _ptr(cmb[0]), _ptr(cmb[1]),
-                                            cmb[2], cmb[3], _stream()),
+                                            _ptr(tuples), _ptr(flags), RASTER_BWD_VARIANT, _ptr(cmb[0]), cmb[1], cmb[2],
+                                            _stream()),
                    "rasterize_bwd_slice")
         if tuples is not None:
             with _stage("grad_reduce"):
@@ -821,7 +821,10 @@ class _RenderSubposes(Function):
                                         _ptr(v_samples), _stream()), "combine_bwd")
                 v_img = v_samples
             else:
-                combine = (v_img, rgb, gamma, m)
+                scale = torch.empty_like(rgb)
+                _check(L.gs_combine_bwd_scale(S, rgb.numel(), gamma, _ptr(rgb), _ptr(v_img), _ptr(scale), _stream()),
+                       "combine_bwd_scale")
+                combine = (scale, gamma, m)
                 v_img = samples
         # atomic-free path: only Gaussians the compositor touched get a gradient record (plain stores) and a
         # `touched` flag; the projection backward skips everything else, so v_records needs no 240 MB memset

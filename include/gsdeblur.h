@@ -212,10 +212,9 @@ int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const i
                            const int* gi_of_e /*as in the forward*/,
                            float* tuples /*[I*12] or NULL*/, unsigned char* flags /*[I], zeroed, or NULL*/,
                            int variant /*0 = default; 2 = timing ablation: plain stores instead of atomics (wrong gradients)*/,
-                           const float* cmb_v_out /*[H,W,3] or NULL.  Non-NULL folds gs_combine_bwd into this launch:
+                           const float* cmb_scale /*[H,W,3] or NULL.  Non-NULL folds gs_combine_bwd into this launch:
                                                     v_img then holds the SAMPLE IMAGES [S,H,W,3] and each pixel derives
-                                                    its sample gradient from cmb_out and cmb_v_out*/,
-                           const float* cmb_out /*[H,W,3] averaged image (gs_combine_fwd output), NULL iff cmb_v_out is*/,
+                                                    its sample gradient from cmb_scale (gs_combine_bwd_scale)*/,
                            float cmb_gamma, float cmb_min_level, void* stream);
 
 /* Atomic-free gradient accumulation: with gi_of_e, tuples and flags given, gs_rasterize_bwd_slice writes the 9
@@ -234,6 +233,9 @@ int gs_combine_fwd(int S, long long n, const float* samples /*S*n*/, float gamma
                    float* out /*n*/, void* stream);
 int gs_combine_bwd(int S, long long n, const float* samples, float gamma, float min_level,
                    const float* out, const float* v_out, float* v_samples /*S*n*/, void* stream);
+/* the sample-independent factor of gs_combine_bwd: scale[i] = (1/S) * out[i]^(1-gamma)/gamma * v_out[i] */
+int gs_combine_bwd_scale(int S, long long n, float gamma, const float* out, const float* v_out,
+                         float* scale /*n*/, void* stream);
 
 /* ---- data-parallel gradient exchange (no reference counterpart: the reference is single-GPU,
  *      train.py:114-122 passes no device / world-size flags) -------------------------------------------------
