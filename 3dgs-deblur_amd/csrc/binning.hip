@@ -661,15 +661,22 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
                                                                  const int* __restrict__ sat,            // nullable
                                                                  const unsigned char* __restrict__ done, // nullable
                                                                  int W, int H, unsigned* __restrict__ slice_gi,
-                                                                 unsigned* __restrict__ counts) {
+                                                                 unsigned* __restrict__ counts,
+                                                                 const unsigned* __restrict__ cum_rank,   // nullable
+                                                                 unsigned long long* __restrict__ masks,  // nullable
+                                                                 unsigned* __restrict__ mask_off) {
   const int lane = lane_id();
   const int j = WAVE_PER_G ? (lane == 0 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : n_slice)
                            : (int)(blockIdx.x * 256 + threadIdx.x);
-  unsigned gi = 0, lo = 0, hi = 0;
+  unsigned gi = 0, lo = 0, hi = 0, moff = 0;
   int area = 0;
   Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f};
   if (j < n_slice) {
-    gi = sorted_gi[slice_rank(sd, j)];
+    const int rank = slice_rank(sd, j);
+    gi = sorted_gi[rank];
+    // hit-mask words of this Gaussian (one bit per box tile, 64 tiles per word): cum_rank is the exclusive
+    // prefix of the BOX areas in rank order, so floor(cum/64) + j leaves every Gaussian ceil(area/64) words
+    if (masks) { moff = (cum_rank[rank] >> 6) + (unsigned)j; mask_off[j] = moff; }
     const float* rec = records + (size_t)gi * kRecFloats;
     lo = (unsigned)__float_as_int(rec[10]); hi = (unsigned)__float_as_int(rec[11]);
     const int x0 = lo & 0xFFFF, y0 = lo >> 16, x1 = hi & 0xFFFF, y1 = hi >> 16;
@@ -687,9 +694,15 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
   if (area > 0 && area <= kCountSolo) {
     const int x0 = lo & 0xFFFF, y0 = lo >> 16, x1 = hi & 0xFFFF, y1 = hi >> 16;
     const unsigned pbase = (gi / (unsigned)N) * T;
+    unsigned long long m = 0ull;
+    int t = 0;
     for (int y = y0; y < y1; ++y)
-      for (int x = x0; x < x1; ++x)
-        if ((!done || done[pbase + (unsigned)(y * tiles_x + x)] == 0) && tile_hit(el, x, y, W, H)) ++cnt;
+      for (int x = x0; x < x1; ++x, ++t)
+        if ((!done || done[pbase + (unsigned)(y * tiles_x + x)] == 0) && tile_hit(el, x, y, W, H)) {
+          ++cnt;
+          m |= 1ull << t;
+        }
+    if (masks) masks[moff] = m;                 // kCountSolo <= 64: one word
   }
   unsigned long long big = __ballot(area > kCountSolo);
   while (big) {
@@ -704,6 +717,7 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
     const int w = x1 - x0, a = w * (y1 - y0);
     const float rw = 1.0f / (float)w;
     const unsigned pbase = (g / (unsigned)N) * T;
+    const unsigned mo = (unsigned)readlane_i((int)moff, src);
     unsigned c = 0;
     for (int base = 0; base < a; base += 64) {
       const int t = base + lane;
@@ -713,7 +727,9 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
         const int tx = x0 + (t - q * w), ty = y0 + q;
         ok = (!done || done[pbase + (unsigned)(ty * tiles_x + tx)] == 0) && tile_hit(eg, tx, ty, W, H);
       }
-      c += (unsigned)__popcll(__ballot(ok));
+      const unsigned long long m = __ballot(ok);
+      if (masks && lane == 0) masks[mo + (unsigned)(base >> 6)] = m;
+      c += (unsigned)__popcll(m);
     }
     if (lane == src) cnt = c;
   }
@@ -731,11 +747,13 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
                                                         const float* __restrict__ records,
                                                         const unsigned char* __restrict__ done,
                                                         unsigned* __restrict__ keys, unsigned* __restrict__ vals,
-                                                        int W, int H, unsigned invalid_key, int compact) {
+                                                        int W, int H, unsigned invalid_key, int compact,
+                                                        const unsigned long long* __restrict__ masks,   // nullable
+                                                        const unsigned* __restrict__ mask_off) {
   const int lane = lane_id();
   const int j = WAVE_PER_G ? (lane == 0 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : n_slice)
                            : (int)(blockIdx.x * 256 + threadIdx.x);
-  unsigned cnt = 0, gi = 0, e0 = 0, lo = 0, hi = 0;
+  unsigned cnt = 0, gi = 0, e0 = 0, lo = 0, hi = 0, moff = 0;
   Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f};
   if (j < n_slice) {
     cnt = counts[j];
@@ -745,7 +763,8 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
       const float* rec = records + (size_t)gi * kRecFloats;
       lo = (unsigned)__float_as_int(rec[10]);
       hi = (unsigned)__float_as_int(rec[11]);
-      if (invalid_key) el = make_ellipse(rec);
+      if (masks) moff = mask_off[j];
+      else if (invalid_key) el = make_ellipse(rec);
     }
   }
   unsigned long long todo = __ballot(cnt != 0);
@@ -763,6 +782,24 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
     const int w = x1 - x0, area = w * (y1 - y0);
     const float rw = 1.0f / (float)w;
     const unsigned pbase = (g / (unsigned)N) * (unsigned)T;
+    if (masks) {
+      // the exact-count pass left one bit per box tile (open AND inside the ellipse): no second ellipse test,
+      // no tile_done reads — a word per 64 tiles drives the compaction directly
+      const unsigned mo = (unsigned)readlane_i((int)moff, src);
+      for (int base = 0; base < area; base += 64) {
+        const unsigned long long m = masks[mo + (unsigned)(base >> 6)];
+        if ((m >> lane) & 1ull) {
+          const int t = base + lane;
+          const int q = (int)(((float)t + 0.5f) * rw);
+          const int tx = x0 + (t - q * w), ty = y0 + q;
+          const unsigned dst = e + (unsigned)__popcll(m & lt_mask);
+          keys[dst] = pbase + (unsigned)(ty * tiles_x + tx);
+          vals[dst] = g;
+        }
+        e += (unsigned)__popcll(m);
+      }
+      continue;
+    }
     for (int base = 0; base < area; base += 64) {
       const int t = base + lane;
       bool open = false;
@@ -990,17 +1027,20 @@ GS_EXPORT int gs_slice_counts(int n_slice, int P, int N, const int* slice_begin,
 GS_EXPORT int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_begin, const int* slice_prefix,
                                     const unsigned* sorted_gi, const float* records, const int* sat,
                                     const unsigned char* tile_done, int H, int W, unsigned* slice_gi,
-                                    unsigned* counts, int wave_per_gaussian, void* stream) {
+                                    unsigned* counts, int wave_per_gaussian, const unsigned* cum_rank,
+                                    unsigned long long* hit_masks, unsigned* mask_off, void* stream) {
   if (n_slice <= 0 || P <= 0) return GS_ERR_INVALID;
+  if (hit_masks && (!cum_rank || !mask_off)) return GS_ERR_INVALID;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
   SliceDesc sd; sd.begin = slice_begin; sd.prefix = slice_prefix; sd.P = P;
   if (wave_per_gaussian)
     hipLaunchKernelGGL(slice_counts_exact_kernel<true>, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W, H, slice_gi, counts);
+                       n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W, H, slice_gi, counts,
+                       cum_rank, hit_masks, mask_off);
   else
     hipLaunchKernelGGL(slice_counts_exact_kernel<false>, dim3((n_slice + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W,
-                       H, slice_gi, counts);
+                       H, slice_gi, counts, cum_rank, hit_masks, mask_off);
   return gs_launch_status();
 }
 
@@ -1008,17 +1048,19 @@ GS_EXPORT int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_
 GS_EXPORT int gs_emit_open_intersects(int n_slice, int N, int H, int W, const unsigned* slice_gi,
                                       const unsigned* counts, const unsigned* cum_excl, const float* records,
                                       const unsigned char* tile_done, unsigned* keys, unsigned* vals,
-                                      unsigned invalid_key, int compact, int wave_per_gaussian, void* stream) {
+                                      unsigned invalid_key, int compact, int wave_per_gaussian,
+                                      const unsigned long long* hit_masks, const unsigned* mask_off, void* stream) {
   if (n_slice <= 0) return GS_ERR_INVALID;
+  if (hit_masks && (!mask_off || !compact)) return GS_ERR_INVALID;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
   if (wave_per_gaussian)
     hipLaunchKernelGGL(emit_open_kernel<true>, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream, n_slice, N,
                        tiles_x * tiles_y, tiles_x, slice_gi, counts, cum_excl, records, tile_done, keys, vals, W, H,
-                       invalid_key, compact);
+                       invalid_key, compact, hit_masks, mask_off);
   else
     hipLaunchKernelGGL(emit_open_kernel<false>, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice,
                        N, tiles_x * tiles_y, tiles_x, slice_gi, counts, cum_excl, records, tile_done, keys, vals, W, H,
-                       invalid_key, compact);
+                       invalid_key, compact, hit_masks, mask_off);
   return gs_launch_status();
 }
 

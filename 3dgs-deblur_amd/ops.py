@@ -39,6 +39,9 @@ GRAD_TUPLES = int(os.environ.get("GSD_GRAD_TUPLES", "1"))
 COMPACT_EMIT = int(os.environ.get("GSD_COMPACT_EMIT", "1"))
 # deferred SH colour: the fused projection skips SH, each depth slice colours only the Gaussians it emits
 DEFER_COLOR = int(os.environ.get("GSD_DEFER_COLOR", "1"))
+# the exact count leaves one bit per box tile (open AND inside the ellipse) and the emission compacts from those
+# bits instead of repeating the ellipse / tile_done tests (needs COMPACT_EMIT)
+HIT_MASKS = int(os.environ.get("GSD_HIT_MASKS", "1"))
 # depth pre-sort: 1 = per-sub-pose segments of 32-bit keys, 0 = one sort of 64-bit (sub-pose, depth) keys
 DEPTH_SORT_SEGMENTED = int(os.environ.get("GSD_DEPTH_SORT_SEGMENTED", "1"))
 last_slice_intersects = []
@@ -315,6 +318,8 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         rel_at = None
         K = 1
     last_num_intersects = n_total
+    # un-wrapped total (python ints) from the per-sub-pose totals of the plan; None when there is no plan
+    true_total = sum(rel_at[p][KMAX - 1] for p in range(P)) if rel_at is not None else None
     begins, prefixes, n_slices = [], [], []
     for k in range(K):
         lo = [0 if k == 0 else min(b[p][k - 1], N) for p in range(P)]
@@ -360,11 +365,18 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                 # few Gaussians with large boxes (the nearest slice): one wave per Gaussian
                 box_total = (n_total if K == 1 else sum(rel_at[p][0] for p in range(P))) if first else 0
                 wave_per_g = int(first and box_total > 32 * n_k)
+                masks = mask_off = None
                 if compact:
+                    if HIT_MASKS and true_total is not None and true_total < 2 ** 32 - 64:
+                        # one bit per box tile, written by the exact count and consumed by the emission; the
+                        # word offsets come from the u32 prefix `cum`, which must not have wrapped
+                        masks = torch.empty(true_total // 64 + n_k + 2, dtype=torch.int64, device=dev)
+                        mask_off = torch.empty(n_k, dtype=torch.int32, device=dev)
                     _check(L.gs_slice_counts_exact(n_k, P, N, _ptr(d), ctypes.c_void_p(d.data_ptr() + 4 * P),
                                                    _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None,
                                                    _ptr(tile_done) if have_holes else None, H, W, _ptr(slice_gi),
-                                                   _ptr(counts), wave_per_g, _stream()), "slice_counts_exact")
+                                                   _ptr(counts), wave_per_g, _ptr(cum) if masks is not None else None,
+                                                   _ptr(masks), _ptr(mask_off), _stream()), "slice_counts_exact")
                 else:
                     _check(L.gs_slice_counts(n_k, P, N, _ptr(d), ctypes.c_void_p(d.data_ptr() + 4 * P),
                                              _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None, H, W,
@@ -406,7 +418,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                                      _ptr(records),
                                                      _ptr(tile_done) if ((not first) or holes0) else None,
                                                      _ptr(keys), _ptr(vals), invalid_key, int(compact), wave_per_g,
-                                                     _stream()),
+                                                     _ptr(masks), _ptr(mask_off), _stream()),
                            "emit open intersects")
             with _stage("tile_sort"):
                 if use_tuples:

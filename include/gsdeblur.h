@@ -188,12 +188,20 @@ int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_begin, con
                           const unsigned* sorted_gi, const float* records, const int* sat,
                           const unsigned char* tile_done, int img_height, int img_width, unsigned* slice_gi,
                           unsigned* counts, int wave_per_gaussian /*1: one Gaussian per wave (few, large boxes)*/,
+                          const unsigned* cum_rank /*[P*N] exclusive prefix of num_tiles_hit in depth-rank order (the
+                                                     array gs_slice_plan reads); needed with hit_masks*/,
+                          unsigned long long* hit_masks /*NULL, or >= total/64 + n_slice + 1 words: one bit per box
+                                                          tile (open AND inside the ellipse) for gs_emit_open_intersects;
+                                                          requires the u32 prefix not to have wrapped (total < 2^32)*/,
+                          unsigned* mask_off /*[n_slice] first mask word of each slice Gaussian, or NULL*/,
                           void* stream);
 int gs_emit_open_intersects(int n_slice, int N, int img_height, int img_width, const unsigned* slice_gi,
                             const unsigned* counts, const unsigned* cum_excl, const float* records,
                             const unsigned char* tile_done /*NULL: all open*/, unsigned* keys, unsigned* vals,
                             unsigned invalid_key, int compact /*1: counts are exact, culled pairs take no slot*/,
-                            int wave_per_gaussian, void* stream);
+                            int wave_per_gaussian,
+                            const unsigned long long* hit_masks /*from gs_slice_counts_exact, or NULL: redo the tests*/,
+                            const unsigned* mask_off, void* stream);
 /* one launch per slice, front to back; out_img/out_T/live_T carry per-pixel state, tile_done is zeroed
  * by the caller before the first slice; first && last == the unsliced pass; final_idx is per slice */
 int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,

@@ -725,3 +725,73 @@ def test_render_combined_equals_two_step(gs, oracle, dev, S, R, base, learn_bg):
         assert rel_max(g1[k].cpu(), g0[k].cpu()) < 1e-6, k
     if learn_bg:
         assert rel_max(b1.cpu(), b0.cpu()) < 1e-6
+
+
+# --------------------------------------------------------------------------- #
+# edge cases of the fused path (empty / degenerate inputs)
+# --------------------------------------------------------------------------- #
+def _render_simple(gs, dev, means, log_scales, quats, opac_logit, sh, S, R, W, H, bg, lin=None, ang=None):
+    p = dict(means=means, log_scales=log_scales, quats=quats, opacity_logits=opac_logit, sh=sh)
+    p = {k: v.float().to(dev).requires_grad_(True) for k, v in p.items()}
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, R, 1 / 30)
+    vm = torch.eye(4, device=dev)
+    lin = torch.zeros(3) if lin is None else lin
+    ang = torch.zeros(3) if ang is None else ang
+    vms = gs.subpose_viewmats(vm, lin.to(dev), ang.to(dev), torch.tensor(times, device=dev))
+    rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
+                                            torch.sigmoid(p["opacity_logits"]), p["sh"], vms, bg.to(dev), S, R,
+                                            0.8 * W, 0.8 * W, W / 2, H / 2, H, W, gamma=2.2, min_rgb_level=0.0)
+    return rgb, alphas, radii, p
+
+
+@pytest.mark.parametrize("S,R", [(1, 1), (3, 2)])
+def test_fused_path_nothing_visible(gs, dev, S, R):
+    """every Gaussian behind the camera: image == background exactly, alpha == 0, all gradients exactly zero"""
+    n, W, H = 300, 70, 50                                        # neither dimension a multiple of 16
+    g = torch.Generator().manual_seed(3)
+    means = torch.randn(n, 3, generator=g)
+    means[:, 2] = -1.0 - torch.rand(n, generator=g)              # z < 0 in the camera frame
+    bg = torch.tensor([0.25, 0.5, 0.75])
+    rgb, alphas, radii, p = _render_simple(gs, dev, means, torch.full((n, 3), -3.0), torch.randn(n, 4, generator=g),
+                                           torch.zeros(n), torch.rand(n, 16, 3, generator=g), S, R, W, H, bg)
+    assert int(radii.abs().sum()) == 0
+    assert torch.allclose(rgb.cpu(), bg.expand(H, W, 3), atol=1e-6) and float(alphas.abs().max()) == 0.0
+    (rgb.sum() + alphas.sum()).backward()
+    for k, v in p.items():
+        assert v.grad is not None and float(v.grad.abs().max()) == 0.0, k
+
+
+def test_fused_path_single_gaussian_and_full_screen_gaussian(gs, oracle, dev):
+    """N = 1 (one tiny splat), and one opaque Gaussian larger than the whole image in front of many others:
+    every tile terminates on its first entry, the rest of the scene gets no gradient at all."""
+    O = oracle
+    W, H = 90, 60
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    one = dict(means=torch.tensor([[0.0, 0.0, 4.0]]), log_scales=torch.full((1, 3), math.log(0.05)),
+               quats=torch.tensor([[1.0, 0.0, 0.0, 0.0]]), opac=torch.tensor([3.0]), sh=torch.zeros(1, 16, 3))
+    one["sh"][0, 0] = torch.tensor([1.0, 0.5, -0.2])
+    rgb, alphas, radii, p = _render_simple(gs, dev, one["means"], one["log_scales"], one["quats"], one["opac"],
+                                           one["sh"], 1, 1, W, H, bg)
+    cfg = O.RenderConfig(H, W, 0.8 * W, 0.8 * W, W / 2, H / 2, blur_samples=1, rs_bands=1, gamma=2.2)
+    ref, ref_a = O.render(cfg, one["means"].double(), one["log_scales"].double().exp(), one["quats"].double(),
+                          torch.sigmoid(one["opac"].double()), one["sh"].double(), torch.eye(4).double(),
+                          torch.zeros(3).double(), torch.zeros(3).double(), background=bg.double())
+    assert (rgb.detach().cpu().double() - ref).abs().max() < 5e-4 and int(radii[0, 0]) > 0
+    rgb.sum().backward()
+    assert float(p["means"].grad.abs().sum()) > 0
+
+    sc = O.synthetic_scene(3000, W, H, seed=12, scale_mult=4.0)
+    means = torch.cat([torch.tensor([[0.0, 0.0, 0.5]]), sc["means"]])          # in front of everything (z >= 1)
+    log_scales = torch.cat([torch.full((1, 3), math.log(10.0)), sc["log_scales"]])
+    quats = torch.cat([torch.tensor([[1.0, 0.0, 0.0, 0.0]]), sc["quats"]])
+    opac = torch.cat([torch.tensor([20.0]), sc["opacity_logits"]])              # alpha clamps at 0.999
+    sh = torch.cat([torch.zeros(1, 16, 3), sc["sh"]])
+    rgb, alphas, radii, p = _render_simple(gs, dev, means, log_scales, quats, opac, sh, 2, 1, W, H, bg,
+                                           lin=torch.tensor([0.5, 0.0, 0.0]))
+    assert torch.isfinite(rgb).all() and float(alphas.min()) > 0.998
+    rgb.sum().backward()
+    g = p["means"].grad
+    assert torch.isfinite(g).all()
+    # T after the wall is 1e-3: a few Gaussians behind it still contribute until T <= 1e-4, but only a handful
+    touched = int((g[1:].abs().sum(dim=1) > 0).sum())
+    assert touched < 0.2 * (means.shape[0] - 1)
