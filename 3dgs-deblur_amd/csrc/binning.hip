@@ -412,20 +412,29 @@ __global__ __launch_bounds__(256) void gather_counts_kernel(size_t n, const unsi
 // slack keeps the test conservative against the compositor's float32 rounding: culled pairs
 // contribute exactly nothing, so images are unchanged.
 // ---------------------------------------------------------------------------
-struct Ellipse { float gx, gy, a, b, c, tau; };
+struct Ellipse { float gx, gy, a, b, c, tau, ra, rc; };   // ra = 1/a, rc = 1/c: no division per tile
 
 __device__ __forceinline__ Ellipse make_ellipse(const float* __restrict__ rec) {
   Ellipse e;
   e.gx = rec[0]; e.gy = rec[1]; e.a = rec[2]; e.b = rec[3]; e.c = rec[4];
   const float op = rec[5];
   e.tau = op > 0.f ? __logf(255.0f * op) : -1.f;
+  // threshold with the conservative slack folded in (tile_hit compares against it directly)
+  e.tau = e.tau < 0.f ? -1.f : e.tau * 1.001f + 1e-3f;
+  e.ra = 1.0f / e.a; e.rc = 1.0f / e.c;
   return e;
 }
 
-__device__ __forceinline__ float edge_min(float fixed, float lo, float hi, float qf, float qb, float qv) {
-  // min over v in [lo,hi] of 0.5*qf*fixed^2 + qb*fixed*v + 0.5*qv*v^2
-  float v = fminf(hi, fmaxf(lo, -qb * fixed / qv));
-  return 0.5f * qf * fixed * fixed + qb * fixed * v + 0.5f * qv * v * v;
+__device__ __forceinline__ float edge_min(float fixed, float lo, float hi, float qf, float qb, float qv, float rqv) {
+  // min over v in [lo,hi] of 0.5*qf*fixed^2 + qb*fixed*v + 0.5*qv*v^2   (rqv = 1/qv; the clamp makes the
+  // rounding of the stationary point harmless: any v in [lo,hi] gives an upper bound of the true minimum
+  // that is within the slack of it)
+  // The three terms cancel for elongated Gaussians (sigma small, terms large): float32 rounding is then a
+  // few ulps of the LARGEST term, so the slack scales with it (2e-6 * t0 >= ~16 ulps) and errs towards "hit".
+  const float bf = qb * fixed;
+  const float v = fminf(hi, fmaxf(lo, -bf * rqv));
+  const float t0 = 0.5f * qf * fixed * fixed;
+  return t0 * (1.0f - 2e-6f) + v * (bf + 0.5f * qv * v);
 }
 
 __device__ __forceinline__ bool tile_hit(const Ellipse& e, int tx, int ty, int W, int H) {
@@ -435,11 +444,11 @@ __device__ __forceinline__ bool tile_hit(const Ellipse& e, int tx, int ty, int W
   const float v0 = (float)(ty * K::kTile) + 0.5f - e.gy;
   const float v1 = fminf((float)(ty * K::kTile + K::kTile) - 0.5f, (float)H - 0.5f) - e.gy;
   if (u0 <= 0.f && u1 >= 0.f && v0 <= 0.f && v1 >= 0.f) return true;
-  float m = edge_min(u0, v0, v1, e.a, e.b, e.c);
-  m = fminf(m, edge_min(u1, v0, v1, e.a, e.b, e.c));
-  m = fminf(m, edge_min(v0, u0, u1, e.c, e.b, e.a));
-  m = fminf(m, edge_min(v1, u0, u1, e.c, e.b, e.a));
-  return m <= e.tau * 1.001f + 1e-3f;
+  float m = edge_min(u0, v0, v1, e.a, e.b, e.c, e.rc);
+  m = fminf(m, edge_min(u1, v0, v1, e.a, e.b, e.c, e.rc));
+  m = fminf(m, edge_min(v0, u0, u1, e.c, e.b, e.a, e.ra));
+  m = fminf(m, edge_min(v1, u0, u1, e.c, e.b, e.a, e.ra));
+  return m <= e.tau;
 }
 
 // Entry-parallel emission: a block owns kEmitChunk consecutive OUTPUT entries (so the grid scales with
@@ -485,7 +494,7 @@ __global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T
   for (unsigned wbase = g_lo; wbase <= g_hi; wbase += 256) {
     const unsigned r = wbase + threadIdx.x;
     unsigned gi = 0, c = 0xFFFFFFFFu, kbase = 0, w = 1, xy0 = 0;
-    Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f};
+    Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
     if (r <= g_hi) {
       gi = sorted_gi[r];
       c = cum[r];
@@ -528,6 +537,7 @@ __global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T
       if (invalid_key) {
         Ellipse el2;
         el2.gx = s_gx[a]; el2.gy = s_gy[a]; el2.a = s_a[a]; el2.b = s_b[a]; el2.c = s_c[a]; el2.tau = s_tau[a];
+        el2.ra = 1.0f / el2.a; el2.rc = 1.0f / el2.c;
         if (!tile_hit(el2, tx, ty, W, H)) key = invalid_key;
       }
       keys[e] = key;
@@ -670,7 +680,7 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
                            : (int)(blockIdx.x * 256 + threadIdx.x);
   unsigned gi = 0, lo = 0, hi = 0, moff = 0;
   int area = 0;
-  Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f};
+  Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
   if (j < n_slice) {
     const int rank = slice_rank(sd, j);
     gi = sorted_gi[rank];
@@ -713,6 +723,7 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
     Ellipse eg;
     eg.gx = readlane_f(el.gx, src); eg.gy = readlane_f(el.gy, src); eg.a = readlane_f(el.a, src);
     eg.b = readlane_f(el.b, src); eg.c = readlane_f(el.c, src); eg.tau = readlane_f(el.tau, src);
+    eg.ra = readlane_f(el.ra, src); eg.rc = readlane_f(el.rc, src);
     const int x0 = l & 0xFFFF, y0 = l >> 16, x1 = h & 0xFFFF, y1 = h >> 16;
     const int w = x1 - x0, a = w * (y1 - y0);
     const float rw = 1.0f / (float)w;
@@ -754,7 +765,7 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
   const int j = WAVE_PER_G ? (lane == 0 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : n_slice)
                            : (int)(blockIdx.x * 256 + threadIdx.x);
   unsigned cnt = 0, gi = 0, e0 = 0, lo = 0, hi = 0, moff = 0;
-  Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f};
+  Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
   if (j < n_slice) {
     cnt = counts[j];
     if (cnt) {
@@ -778,6 +789,7 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
     Ellipse eg;
     eg.gx = readlane_f(el.gx, src); eg.gy = readlane_f(el.gy, src); eg.a = readlane_f(el.a, src);
     eg.b = readlane_f(el.b, src); eg.c = readlane_f(el.c, src); eg.tau = readlane_f(el.tau, src);
+    eg.ra = readlane_f(el.ra, src); eg.rc = readlane_f(el.rc, src);
     const int x0 = l & 0xFFFF, y0 = l >> 16, x1 = h & 0xFFFF, y1 = h >> 16;
     const int w = x1 - x0, area = w * (y1 - y0);
     const float rw = 1.0f / (float)w;
