@@ -570,11 +570,22 @@ __global__ __launch_bounds__(256) void bin_edges_kernel(size_t n, const KeyT* __
 // proportional to what the compositor can still use.  Results are identical to the unsliced path:
 // every pixel sees the same Gaussians in the same order.
 // ---------------------------------------------------------------------------
+// passed BY VALUE in the kernel arguments (filled from host arrays): a slice is described on the host right
+// after the plan read-back, and an upload would put a host->device copy on the critical path of every slice
+constexpr int kMaxSubposes = 256;
 struct SliceDesc {
-  const int* begin;    // [P]   first depth rank (absolute index into sorted_gi) of the slice in sub-pose p
-  const int* prefix;   // [P+1] prefix sums of the per-sub-pose slice lengths
+  int begin[kMaxSubposes];        // first depth rank (absolute index into sorted_gi) of the slice in sub-pose p
+  int prefix[kMaxSubposes + 1];   // prefix sums of the per-sub-pose slice lengths
   int P;
 };
+
+static bool make_slice_desc(int P, const int* begin, const int* prefix, SliceDesc& sd) {
+  if (P <= 0 || P > kMaxSubposes || !begin || !prefix) return false;
+  for (int p = 0; p < P; ++p) { sd.begin[p] = begin[p]; sd.prefix[p] = prefix[p]; }
+  sd.prefix[P] = prefix[P];
+  sd.P = P;
+  return true;
+}
 
 __device__ __forceinline__ int slice_rank(const SliceDesc& sd, int j) {
   int p = 0;
@@ -1027,9 +1038,9 @@ GS_EXPORT int gs_tile_open_sat(int P, int H, int W, const unsigned char* tile_do
 GS_EXPORT int gs_slice_counts(int n_slice, int P, int N, const int* slice_begin, const int* slice_prefix,
                               const unsigned* sorted_gi, const float* records, const int* sat, int H, int W,
                               unsigned* slice_gi, unsigned* counts, void* stream) {
-  if (n_slice <= 0 || P <= 0) return GS_ERR_INVALID;
+  SliceDesc sd;
+  if (n_slice <= 0 || !make_slice_desc(P, slice_begin, slice_prefix, sd)) return GS_ERR_INVALID;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
-  SliceDesc sd; sd.begin = slice_begin; sd.prefix = slice_prefix; sd.P = P;
   hipLaunchKernelGGL(slice_counts_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice, sd,
                      N, tiles_x, tiles_y, sorted_gi, records, sat, slice_gi, counts);
   return gs_launch_status();
@@ -1041,10 +1052,10 @@ GS_EXPORT int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_
                                     const unsigned char* tile_done, int H, int W, unsigned* slice_gi,
                                     unsigned* counts, int wave_per_gaussian, const unsigned* cum_rank,
                                     unsigned long long* hit_masks, unsigned* mask_off, void* stream) {
-  if (n_slice <= 0 || P <= 0) return GS_ERR_INVALID;
+  SliceDesc sd;
+  if (n_slice <= 0 || !make_slice_desc(P, slice_begin, slice_prefix, sd)) return GS_ERR_INVALID;
   if (hit_masks && (!cum_rank || !mask_off)) return GS_ERR_INVALID;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
-  SliceDesc sd; sd.begin = slice_begin; sd.prefix = slice_prefix; sd.P = P;
   if (wave_per_gaussian)
     hipLaunchKernelGGL(slice_counts_exact_kernel<true>, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W, H, slice_gi, counts,

@@ -51,8 +51,9 @@ class StageProfiler:
     """Optional per-stage timing with HIP events recorded on the stream the kernels are launched on
     (torch's current stream).  Enabled by bench.py; `None` (default) costs nothing."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.events = {}
+        self.only = None if only is None else set(only)     # restrict to these stage names (others cost nothing)
 
     class _Ctx:
         def __init__(self, prof, name):
@@ -70,6 +71,8 @@ class StageProfiler:
             return False
 
     def stage(self, name):
+        if self.only is not None and name not in self.only:
+            return _NULL
         return StageProfiler._Ctx(self, name)
 
     def summary_ms(self):
@@ -292,6 +295,12 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     tx, ty = _tiles(H, W)
     T = tx * ty
     sorted_gi, cum, total = _depth_rank(records, depth_keys, num_tiles_hit, P, N)
+    # everything that does not depend on the plan is allocated BEFORE its read-back, while the GPU is still busy
+    out_img = torch.empty(S, H, W, 3, device=dev)
+    out_T = torch.empty(S, H, W, device=dev)
+    live_T = torch.empty(S, H, W, device=dev)
+    sat = torch.empty(P * (ty + 1) * (tx + 1), dtype=torch.int32, device=dev)
+    tile_done0 = torch.zeros(P * T, dtype=torch.uint8, device=dev) if R == 1 else None
     # slice boundaries in depth-rank space: cumulative intersections per sub-pose reach T*slice_base*2^k
     KMAX = 16
     if slice_base > 0:
@@ -330,11 +339,9 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
             pre.append(pre[-1] + max(0, hi[p] - lo[p]))
         prefixes.append(pre)
         n_slices.append(pre[-1])
-    desc = torch.tensor([bb + pp for bb, pp in zip(begins, prefixes)], dtype=torch.int32).to(dev)   # [K, 2P+1]
-    out_img = torch.empty(S, H, W, 3, device=dev)
-    out_T = torch.empty(S, H, W, device=dev)
-    live_T = torch.empty(S, H, W, device=dev)
-    sat = torch.empty(P * (ty + 1) * (tx + 1), dtype=torch.int32, device=dev)
+    # the slice descriptors stay on the host: they travel in the kernel arguments (no upload after the sync)
+    desc_begin = [(ctypes.c_int * P)(*bb) for bb in begins]
+    desc_prefix = [(ctypes.c_int * (P + 1))(*pp) for pp in prefixes]
     if R > 1:
         # rolling-shutter bands: sub-pose p = s*R + r only ever composites tile rows [edge[r], edge[r+1]);
         # every other tile of p is "done" from the start so the binning never emits for it
@@ -344,7 +351,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         tile_done = (~band_open).to(torch.uint8)[None, :, :, None].expand(S, R, ty, tx).reshape(-1).contiguous()
         _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _stream()), "tile_open_sat")
     else:
-        tile_done = torch.zeros(P * T, dtype=torch.uint8, device=dev)
+        tile_done = tile_done0
     holes0 = R > 1          # the very first slice already has closed tiles
     slices = []
     last_slice_intersects = []
@@ -360,7 +367,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
             with _stage("slice_count"):
                 slice_gi = torch.empty(n_k, dtype=torch.int32, device=dev)
                 counts = torch.empty(n_k, dtype=torch.int32, device=dev)
-                d = desc[k]
+                d_begin, d_prefix = desc_begin[k], desc_prefix[k]
                 have_holes = (not first) or holes0
                 # few Gaussians with large boxes (the nearest slice): one wave per Gaussian
                 box_total = (n_total if K == 1 else sum(rel_at[p][0] for p in range(P))) if first else 0
@@ -372,13 +379,13 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                         # word offsets come from the u32 prefix `cum`, which must not have wrapped
                         masks = torch.empty(true_total // 64 + n_k + 2, dtype=torch.int64, device=dev)
                         mask_off = torch.empty(n_k, dtype=torch.int32, device=dev)
-                    _check(L.gs_slice_counts_exact(n_k, P, N, _ptr(d), ctypes.c_void_p(d.data_ptr() + 4 * P),
+                    _check(L.gs_slice_counts_exact(n_k, P, N, d_begin, d_prefix,
                                                    _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None,
                                                    _ptr(tile_done) if have_holes else None, H, W, _ptr(slice_gi),
                                                    _ptr(counts), wave_per_g, _ptr(cum) if masks is not None else None,
                                                    _ptr(masks), _ptr(mask_off), _stream()), "slice_counts_exact")
                 else:
-                    _check(L.gs_slice_counts(n_k, P, N, _ptr(d), ctypes.c_void_p(d.data_ptr() + 4 * P),
+                    _check(L.gs_slice_counts(n_k, P, N, d_begin, d_prefix,
                                              _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None, H, W,
                                              _ptr(slice_gi), _ptr(counts), _stream()), "slice_counts")
                 cum_k, total_k = exclusive_scan_u32(counts)

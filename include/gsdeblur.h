@@ -177,14 +177,15 @@ int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl /*P*N, rank orde
 /* sat [P*(tiles_y+1)*(tiles_x+1)] = summed-area table of tiles NOT done (tile_done u8 [P*T]) */
 int gs_tile_open_sat(int P, int img_height, int img_width, const unsigned char* tile_done, int* sat,
                      void* stream);
-/* slice = for each sub-pose p the depth ranks sorted_gi[slice_begin[p] + i], i < prefix[p+1]-prefix[p];
+/* slice = for each sub-pose p the depth ranks sorted_gi[slice_begin[p] + i], i < prefix[p+1]-prefix[p]
+ * (slice_begin / slice_prefix are HOST arrays, P <= 256: they travel in the kernel arguments);
  * writes slice_gi[j] (global index) and counts[j] (open tiles; sat == NULL: all tiles open) */
-int gs_slice_counts(int n_slice, int P, int N, const int* slice_begin /*P*/, const int* slice_prefix /*P+1*/,
+int gs_slice_counts(int n_slice, int P, int N, const int* slice_begin /*P, HOST*/, const int* slice_prefix /*P+1, HOST*/,
                     const unsigned* sorted_gi, const float* records, const int* sat, int img_height,
                     int img_width, unsigned* slice_gi, unsigned* counts, void* stream);
 /* exact counts: tiles of the box that are open AND pass the ellipse test of gs_emit_*; with these counts and
  * compact != 0 the emission holds no culled pairs at all (sat / tile_done NULL: every tile is open) */
-int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_begin, const int* slice_prefix,
+int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_begin /*HOST*/, const int* slice_prefix /*HOST*/,
                           const unsigned* sorted_gi, const float* records, const int* sat,
                           const unsigned char* tile_done, int img_height, int img_width, unsigned* slice_gi,
                           unsigned* counts, int wave_per_gaussian /*1: one Gaussian per wave (few, large boxes)*/,
