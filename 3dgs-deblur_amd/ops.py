@@ -42,6 +42,17 @@ DEFER_COLOR = int(os.environ.get("GSD_DEFER_COLOR", "1"))
 # the exact count leaves one bit per box tile (open AND inside the ellipse) and the emission compacts from those
 # bits instead of repeating the ellipse / tile_done tests (needs COMPACT_EMIT)
 HIT_MASKS = int(os.environ.get("GSD_HIT_MASKS", "1"))
+# zero-fill the dense gradient outputs (236 B per Gaussian) on a second HIP stream while the compositor's
+# backward — VALU-bound, HBM mostly idle — runs on the main one
+ASYNC_ZERO_FILL = int(os.environ.get("GSD_ASYNC_ZERO_FILL", "1"))
+_side_streams = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    key = (dev.type, dev.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
 # depth pre-sort: 1 = per-sub-pose segments of 32-bit keys, 0 = one sort of 64-bit (sub-pose, depth) keys
 DEPTH_SORT_SEGMENTED = int(os.environ.get("GSD_DEPTH_SORT_SEGMENTED", "1"))
 last_slice_intersects = []
@@ -150,9 +161,9 @@ def exclusive_scan_u32(x: Tensor) -> Tuple[Tensor, Tensor]:
     assert x.dtype == torch.int32 and x.is_cuda and x.is_contiguous()
     n = x.numel()
     out = torch.empty_like(x)
-    total = torch.zeros(1, dtype=torch.int32, device=x.device)
     if n == 0:
-        return out, total
+        return out, torch.zeros(1, dtype=torch.int32, device=x.device)
+    total = torch.empty(1, dtype=torch.int32, device=x.device)        # written by the kernel
     ws_bytes = _L().gs_scan_workspace_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     _check(_L().gs_exclusive_scan_u32(n, _ptr(x), _ptr(out), _ptr(total), _ptr(ws), ws_bytes, _stream()), "scan")
@@ -264,14 +275,15 @@ def segmented_sort_pairs_u32(keys: Tensor, seg_len: int) -> Tuple[Tensor, Tensor
 
 
 def _depth_rank(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int):
-    """per-sub-pose depth pre-sort -> (sorted_gi [P*N], exclusive scan of tile counts in rank order, total)"""
+    """per-sub-pose depth pre-sort -> (sorted_gi [P*N], exclusive scan of tile counts in rank order, total).
+    depth_keys is consumed (the sort ping-pongs through it)."""
     L = _L()
     n = P * N
     dev = records.device
     with _stage("depth_sort"):
         if DEPTH_SORT_SEGMENTED:
             # P independent segments of 32-bit depth keys (culled = 0xFFFFFFFF sorts last), one set of launches
-            _, sorted_gi = segmented_sort_pairs_u32(depth_keys.clone(), N)
+            _, sorted_gi = segmented_sort_pairs_u32(depth_keys, N)          # clobbers depth_keys (a temporary)
         else:
             keys64 = torch.empty(n, dtype=torch.int64, device=dev)
             _check(L.gs_make_depth_keys64(n, N, _ptr(depth_keys), _ptr(keys64), _stream()), "depth keys")
@@ -854,6 +866,14 @@ class _RenderSubposes(Function):
         else:
             v_records = torch.zeros(P * N, REC, device=dev)
             touched = None
+        sizes = [3 * N, 3 * N, 4 * N, N, 3 * K * N]
+        flat = fill_done = None
+        if touched is not None and ASYNC_ZERO_FILL:
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            with torch.cuda.stream(side):
+                flat = torch.zeros(sum(sizes), device=dev)
+                fill_done = side.record_event()
+            flat.record_stream(main)
         if ctx.sliced:
             sliced_backward(records, ctx.slices, S, R, H, W, bg, edges, out_T, v_img, v_al, v_records, touched,
                             combine)
@@ -864,9 +884,10 @@ class _RenderSubposes(Function):
                                           _stream()), "rasterize_bwd")
         # the five dense gradient outputs are carved out of ONE buffer: with touched flags the kernel skips
         # untouched Gaussians, so the buffer is zero-filled (one fill instead of five)
-        alloc = torch.zeros if touched is not None else torch.empty
-        sizes = [3 * N, 3 * N, 4 * N, N, 3 * K * N]
-        flat = alloc(sum(sizes), device=dev)
+        if flat is None:
+            flat = (torch.zeros if touched is not None else torch.empty)(sum(sizes), device=dev)
+        else:
+            torch.cuda.current_stream(dev).wait_event(fill_done)
         v_means, v_scales, v_quats, v_opac, v_sh = (t.view(shape) for t, shape in zip(
             flat.split(sizes), [(N, 3), (N, 3), (N, 4), (N,), (N, K, 3)]))
         need_v = ctx.needs_input_grad[5]
