@@ -42,17 +42,6 @@ DEFER_COLOR = int(os.environ.get("GSD_DEFER_COLOR", "1"))
 # the exact count leaves one bit per box tile (open AND inside the ellipse) and the emission compacts from those
 # bits instead of repeating the ellipse / tile_done tests (needs COMPACT_EMIT)
 HIT_MASKS = int(os.environ.get("GSD_HIT_MASKS", "1"))
-# zero-fill the dense gradient outputs (236 B per Gaussian) on a second HIP stream while the compositor's
-# backward — VALU-bound, HBM mostly idle — runs on the main one
-ASYNC_ZERO_FILL = int(os.environ.get("GSD_ASYNC_ZERO_FILL", "1"))
-_side_streams = {}
-
-
-def _side_stream(dev) -> "torch.cuda.Stream":
-    key = (dev.type, dev.index)
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=dev)
-    return _side_streams[key]
 # depth pre-sort: 1 = per-sub-pose segments of 32-bit keys, 0 = one sort of 64-bit (sub-pose, depth) keys
 DEPTH_SORT_SEGMENTED = int(os.environ.get("GSD_DEPTH_SORT_SEGMENTED", "1"))
 last_slice_intersects = []
@@ -866,14 +855,7 @@ class _RenderSubposes(Function):
         else:
             v_records = torch.zeros(P * N, REC, device=dev)
             touched = None
-        sizes = [3 * N, 3 * N, 4 * N, N, 3 * K * N]
-        flat = fill_done = None
-        if touched is not None and ASYNC_ZERO_FILL:
-            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-            with torch.cuda.stream(side):
-                flat = torch.zeros(sum(sizes), device=dev)
-                fill_done = side.record_event()
-            flat.record_stream(main)
+
         if ctx.sliced:
             sliced_backward(records, ctx.slices, S, R, H, W, bg, edges, out_T, v_img, v_al, v_records, touched,
                             combine)
@@ -884,10 +866,10 @@ class _RenderSubposes(Function):
                                           _stream()), "rasterize_bwd")
         # the five dense gradient outputs are carved out of ONE buffer: with touched flags the kernel skips
         # untouched Gaussians, so the buffer is zero-filled (one fill instead of five)
-        if flat is None:
-            flat = (torch.zeros if touched is not None else torch.empty)(sum(sizes), device=dev)
-        else:
-            torch.cuda.current_stream(dev).wait_event(fill_done)
+        # (filling on a second stream under the VALU-bound compositor backward was measured: 3.10 vs 3.02 ms —
+        # the cross-stream event costs more than the 50 us fill; run 41)
+        sizes = [3 * N, 3 * N, 4 * N, N, 3 * K * N]
+        flat = (torch.zeros if touched is not None else torch.empty)(sum(sizes), device=dev)
         v_means, v_scales, v_quats, v_opac, v_sh = (t.view(shape) for t, shape in zip(
             flat.split(sizes), [(N, 3), (N, 3), (N, 4), (N,), (N, K, 3)]))
         need_v = ctx.needs_input_grad[5]
