@@ -26,7 +26,7 @@ constexpr int kRedG = GS_RED_G;             // Gaussians per transposed-reductio
 constexpr int kRedStride = 68;              // floats per row (64 + 4: 16-byte aligned, b128 conflict-free)
 constexpr int kRedFloats = kRedG * 9 * kRedStride + 64 * 9;
 
-// OUT = 0: 9 fp32 atomics per (Gaussian, tile) into v_records;  OUT = 2: timing ablation (plain stores);
+// OUT = 0: 9 fp32 atomics per (Gaussian, tile) into v_records (gsplat-compatible op: no emission index);
 // OUT = 1: no atomics at all — the entry's 9 gradients go to tuples[e] (48 B, e = emission index of the
 // entry, so the tuples of one Gaussian are CONTIGUOUS) and flags[e] = 1; gs_reduce_grad_tuples then sums
 // each Gaussian's segment.  At ~20 G atomic ops/s the atomics were 40 % of this kernel.
@@ -295,9 +295,7 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
         float* dst = v_records + (size_t)gid * kRecFloats;
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
-          if (OUT == 2) {                  // timing experiment only (wrong gradients): plain stores
-            if (a[c] != 0.f) dst[c] = a[c];
-          } else if (a[c] != 0.f) {
+          if (a[c] != 0.f) {
             atomic_add_f32(dst + c, a[c]);
           }
         }
@@ -476,11 +474,8 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
-  if (variant == 2) {          // ablation: plain stores instead of atomics (timing experiments only)
-    if (!bwd_T || !bwd_B) return GS_ERR_INVALID;
-    hipLaunchKernelGGL((raster_bwd_kernel_v2<true, 2>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx, v_img,
-                       v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);
-  } else if (tuples && flags && gi_of_e) {
+  (void)variant;               // reserved
+  if (tuples && flags && gi_of_e) {
     if (bwd_T && bwd_B)
       hipLaunchKernelGGL((raster_bwd_kernel_v2<true, 1>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx,
                          v_img, v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);

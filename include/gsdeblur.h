@@ -220,7 +220,7 @@ int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const i
                            const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records,
                            const int* gi_of_e /*as in the forward*/,
                            float* tuples /*[I*12] or NULL*/, unsigned char* flags /*[I], zeroed, or NULL*/,
-                           int variant /*0 = default; 2 = timing ablation: plain stores instead of atomics (wrong gradients)*/,
+                           int variant /*reserved, pass 0*/,
                            const float* cmb_scale /*[H,W,3] or NULL.  Non-NULL folds gs_combine_bwd into this launch:
                                                     v_img then holds the SAMPLE IMAGES [S,H,W,3] and each pixel derives
                                                     its sample gradient from cmb_scale (gs_combine_bwd_scale)*/,
