@@ -795,3 +795,46 @@ def test_fused_path_single_gaussian_and_full_screen_gaussian(gs, oracle, dev):
     # T after the wall is 1e-3: a few Gaussians behind it still contribute until T <= 1e-4, but only a handful
     touched = int((g[1:].abs().sum(dim=1) > 0).sum())
     assert touched < 0.2 * (means.shape[0] - 1)
+
+
+def test_full_size_fast_path_equals_plain_path(gs, oracle, dev):
+    """BASELINE.json's metric configuration (1M Gaussians, 1920x1080, 5 sub-poses): the default path (depth
+    slices, exact tile culling, compact emission from hit masks, deferred colour, gradient tuples) against the
+    plainest one (ONE slice holding all 238 M bounding-box intersections, no culling, colour in the projection,
+    fp32 atomics): identical images bit for bit, gradients equal up to the atomics' summation order."""
+    from gsdeblur_amd import ops
+    n, W, H, S = 1_000_000, 1920, 1080, 5
+    sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=1234), dev)
+    times, _, _ = gs.subpose_schedule(S, sc["exposure_time"], 1, sc["rolling_shutter_time"])
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+    knobs = ("SLICE_BASE", "EXACT_TILE_CULL", "COMPACT_EMIT", "HIT_MASKS", "GRAD_TUPLES", "DEFER_COLOR")
+    saved = {k: getattr(ops, k) for k in knobs}
+    res = []
+    try:
+        for plain in (False, True):
+            if plain:
+                for k in knobs:
+                    setattr(ops, k, 0)
+            p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+            vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"], sc["ang_vel"], torch.tensor(times, device=dev))
+            rgb, _, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
+                                               torch.sigmoid(p["opacity_logits"]), p["sh"], vms, None, S, 1, sc["fx"],
+                                               sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2, min_rgb_level=10.0,
+                                               return_alpha=False)
+            (rgb * wt).sum().backward()
+            res.append((rgb.detach().clone(), {k: v.grad.clone() for k, v in p.items()}, ops.last_num_intersects,
+                        list(ops.last_slice_intersects)))
+            del p, rgb
+            torch.cuda.empty_cache()
+    finally:
+        for k, v in saved.items():
+            setattr(ops, k, v)
+    (img_f, g_f, I_f, sl_f), (img_p, g_p, I_p, sl_p) = res
+    assert I_f == I_p and I_p > 200_000_000 and sl_p == [I_p]        # the plain path really sorted every pair
+    assert sum(sl_f) < 0.1 * I_p                                     # ... and the default path < 10 % of them
+    assert torch.equal(img_f, img_p)
+    for k in g_f:
+        assert rel_max(g_f[k].cpu(), g_p[k].cpu()) < GRAD_RTOL, k
+        touched_f = (g_f[k].reshape(n, -1) != 0).any(dim=1)
+        touched_p = (g_p[k].reshape(n, -1) != 0).any(dim=1)
+        assert torch.equal(touched_f, touched_p), k                  # the same Gaussians receive a gradient
