@@ -22,15 +22,19 @@ struct DpTable {
   int n, wtot;
 };
 
+// Grid-stride over every tensor's flat element space: adjacent lanes read adjacent floats (a thread-per-row
+// walk would touch 64 cache lines per load), a non-zero element stores 1 into its row's byte (benign race: every
+// writer stores the same value).  mask must be zeroed by the caller (gs_dp_row_mask does it).
 __global__ __launch_bounds__(256) void dp_row_mask_kernel(int N, DpTable tb, unsigned char* __restrict__ mask) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= N) return;
-  bool any = false;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (int t = 0; t < tb.n; ++t) {
-    const float* p = tb.ptr[t] + (size_t)row * tb.width[t];
-    for (int c = 0; c < tb.width[t]; ++c) any |= p[c] != 0.f;
+    const float* __restrict__ p = tb.ptr[t];
+    const unsigned w = (unsigned)tb.width[t];
+    const size_t total = (size_t)N * w;
+    for (size_t i = gid; i < total; i += stride)
+      if (p[i] != 0.f) mask[i / w] = 1;
   }
-  mask[row] = any ? 1 : 0;
 }
 
 // one thread per payload element; column wtot carries the row index
@@ -87,7 +91,9 @@ GS_EXPORT int gs_dp_row_mask(int N, int n_tensors, float* const* grads /*host ar
                              void* stream) {
   DpTable tb;
   if (N <= 0 || !make_table(n_tensors, grads, widths, tb)) return GS_ERR_INVALID;
-  hipLaunchKernelGGL(dp_row_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, tb, mask);
+  hipError_t me = hipMemsetAsync(mask, 0, (size_t)N, (hipStream_t)stream);
+  if (me != hipSuccess) return 1000 + (int)me;
+  hipLaunchKernelGGL(dp_row_mask_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, N, tb, mask);
   return gs_launch_status();
 }
 

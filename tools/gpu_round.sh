@@ -20,6 +20,10 @@ if [ "$MODE" = "full" ]; then
   echo "== atomic microbench ==" | tee -a $OUT/summary.log
   (hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics -Wno-unused-value tools/atomic_bench.hip -o /tmp/atomic_bench && timeout 120 /tmp/atomic_bench) 2>&1 | tail -12 | tee -a $OUT/summary.log
 fi
+if [ "$MODE" = "full" ]; then
+  echo "== dp exchange, device side ==" | tee -a $OUT/summary.log
+  timeout 120 python tools/dp_bench.py 2>&1 | tail -1 | tee -a $OUT/summary.log
+fi
 echo "== bench x2 (no cpu baseline) ==" | tee -a $OUT/summary.log
 for v in 1 2; do
   timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
