@@ -93,23 +93,6 @@ last_num_intersects: int = 0
 _NULL = _Null()
 
 
-_pinned_i32 = {}
-
-
-def _read_i32(t: Tensor) -> Tensor:
-    """Device int32 tensor -> host int32 tensor through a cached PINNED buffer (one async copy + one stream
-    sync; `.cpu()` / `.item()` stage through pageable memory).  The returned tensor is only valid until the
-    next call with the same length."""
-    n = t.numel()
-    buf = _pinned_i32.get(n)
-    if buf is None:
-        buf = torch.empty(n, dtype=torch.int32, pin_memory=True)
-        _pinned_i32[n] = buf
-    buf.copy_(t.reshape(-1), non_blocking=True)
-    torch.cuda.current_stream(t.device).synchronize()
-    return buf
-
-
 def _stage(name: str):
     return _NULL if profiler is None else profiler.stage(name)
 
@@ -329,7 +312,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
             _check(L.gs_slice_plan(P, N, KMAX, _ptr(cum), _ptr(total), T * slice_base, _ptr(plan_dev),
                                    ctypes.c_void_p(plan_dev.data_ptr() + 4 * P * KMAX), _stream()), "slice_plan")
             plan_dev[-1:] = total
-            plan = _read_i32(plan_dev).long() & 0xFFFFFFFF                              # one host sync
+            plan = plan_dev.cpu().long() & 0xFFFFFFFF                                    # one host sync
             rel_at = plan[P * KMAX:2 * P * KMAX].view(P, KMAX).tolist()
         n_total = int(plan[-1])
         b = plan[:P * KMAX].view(P, KMAX).tolist()
@@ -420,10 +403,10 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                 else:
                     I_k = sum(rel_at[p][0] for p in range(P))
             elif first:
-                I_k = int(_read_i32(total_k)[0])          # host sync
+                I_k = int(total_k.item())          # host sync
             else:
                 # same sync also fetches how many tiles are still open after the previous slice
-                both = _read_i32(torch.cat([total_k, sat.view(P, -1)[:, -1].sum(dtype=torch.int32).reshape(1)])).tolist()
+                both = torch.cat([total_k, sat.view(P, -1)[:, -1].sum(dtype=torch.int32).reshape(1)]).tolist()
                 I_k = int(both[0])
                 if both[1] == 0:
                     # every tile is done (each already received its background term): nothing left to do
