@@ -77,7 +77,15 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     if not path.exists():
         if not build_if_missing:
             raise HipLibraryError(f"{path} is missing; run __graft_entry__.build()")
-        build_library()
+        # one process per GPU: on a fresh checkout every rank gets here at once — exactly one may run hipcc
+        import fcntl
+        with open(str(LIB_PATH) + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if not path.exists():
+                    build_library()
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     try:
         lib = ctypes.CDLL(str(path))
     except OSError as e:  # pragma: no cover
