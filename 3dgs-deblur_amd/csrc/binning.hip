@@ -192,10 +192,18 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* _
   const unsigned seg = blockIdx.x / sg.nblk_seg, b = blockIdx.x % sg.nblk_seg;
   const size_t base = (size_t)seg * sg.seg_len + (size_t)b * (256 * R);
   const size_t limit = min(n, (size_t)(seg + 1) * sg.seg_len);
-#pragma unroll 8
+  // loads first, LDS atomics second: the compiler does not move a global load across an LDS atomic, and one
+  // load + wait per round serialises R HBM latencies
+  KeyT k[R];
+#pragma unroll
   for (int r = 0; r < R; ++r) {
     size_t i = base + (size_t)r * 256 + threadIdx.x;
-    if (i < limit) atomicAdd(&hist[(unsigned)(keys[i] >> shift) & mask], 1u);
+    k[r] = i < limit ? keys[i] : (KeyT)0;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    size_t i = base + (size_t)r * 256 + threadIdx.x;
+    if (i < limit) atomicAdd(&hist[(unsigned)(k[r] >> shift) & mask], 1u);
   }
   __syncthreads();
   for (int d = threadIdx.x; d < NB; d += 256) ghist[((size_t)seg * NB + d) * sg.nblk_seg + b] = hist[d];
@@ -228,11 +236,17 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   KeyT key[R];
   unsigned short pos[R];
+  // all R loads are issued before the ranking loop: its wave barriers are scheduling barriers, so a load inside
+  // it could not be hoisted and every round would wait out a full HBM latency on its own
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    size_t i = wbase + (size_t)r * 64 + lane;
+    key[r] = i < limit ? keys_in[i] : (KeyT)0;
+  }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     size_t i = wbase + (size_t)r * 64 + lane;
     bool valid = i < limit;
-    key[r] = valid ? keys_in[i] : (KeyT)0;
     unsigned digit = (unsigned)(key[r] >> shift) & mask;
     unsigned long long peers = __ballot(valid);
 #pragma unroll
