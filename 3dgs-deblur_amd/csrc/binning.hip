@@ -613,7 +613,8 @@ __device__ __forceinline__ int slice_rank(const SliceDesc& sd, int j) {
 // counts on the host the first slice needs no extra device->host sync for its size.
 __global__ void slice_plan_kernel(int P, int N, int K, const unsigned* __restrict__ cum,
                                   const unsigned* __restrict__ total, unsigned long long base,
-                                  int* __restrict__ bounds, unsigned* __restrict__ rels) {
+                                  int* __restrict__ bounds, unsigned* __restrict__ rels,
+                                  unsigned* __restrict__ seg_totals) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P * K) return;
   const int p = i / K, k = i % K;
@@ -628,6 +629,7 @@ __global__ void slice_plan_kernel(int P, int N, int K, const unsigned* __restric
   bounds[i] = lo;
   const unsigned seg_end = (p + 1 < P) ? c[N] : *total;
   rels[i] = (lo < N ? c[lo] : seg_end) - c0;
+  if (k == 0 && seg_totals) seg_totals[p] = seg_end - c0;     // the sub-pose's own total (mod 2^32)
 }
 
 // summed-area table of NOT-done tiles per sub-pose: sat[p][(y)*(tx+1)+x] = #open tiles in [0,y)x[0,x).
@@ -1026,10 +1028,10 @@ GS_EXPORT int gs_map_gaussian_to_intersects(int N, const float* xys, const float
 // ---- depth-sliced binning -------------------------------------------------------------------
 // bounds [P*K]: first depth rank of each sub-pose at which the cumulative intersection count reaches base<<k
 GS_EXPORT int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl, const unsigned* total, long long base,
-                            int* bounds, unsigned* rels, void* stream) {
+                            int* bounds, unsigned* rels, unsigned* seg_totals, void* stream) {
   if (P <= 0 || N <= 0 || K <= 0 || K > 32 || base <= 0) return GS_ERR_INVALID;
   hipLaunchKernelGGL(slice_plan_kernel, dim3((P * K + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, N, K, cum_excl,
-                     total, (unsigned long long)base, bounds, rels);
+                     total, (unsigned long long)base, bounds, rels, seg_totals);
   return gs_launch_status();
 }
 

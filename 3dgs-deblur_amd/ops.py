@@ -308,12 +308,15 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         with _stage("slice_plan"):
             # the scan is u32 (wraps above 2^32 total intersections): differences inside one sub-pose are
             # still exact modulo 2^32 as long as a single sub-pose has fewer than 2^32 intersections
-            plan_dev = torch.empty(2 * P * KMAX + 1, dtype=torch.int32, device=dev)     # bounds | rels | total
+            # bounds | rels | per-sub-pose totals | total
+            plan_dev = torch.empty(2 * P * KMAX + P + 1, dtype=torch.int32, device=dev)
             _check(L.gs_slice_plan(P, N, KMAX, _ptr(cum), _ptr(total), T * slice_base, _ptr(plan_dev),
-                                   ctypes.c_void_p(plan_dev.data_ptr() + 4 * P * KMAX), _stream()), "slice_plan")
+                                   ctypes.c_void_p(plan_dev.data_ptr() + 4 * P * KMAX),
+                                   ctypes.c_void_p(plan_dev.data_ptr() + 8 * P * KMAX), _stream()), "slice_plan")
             plan_dev[-1:] = total
             plan = plan_dev.cpu().long() & 0xFFFFFFFF                                    # one host sync
             rel_at = plan[P * KMAX:2 * P * KMAX].view(P, KMAX).tolist()
+            seg_totals = plan[2 * P * KMAX:2 * P * KMAX + P].tolist()
         n_total = int(plan[-1])
         b = plan[:P * KMAX].view(P, KMAX).tolist()
         # number of slices: up to the first k whose boundary reaches N in every sub-pose
@@ -326,10 +329,13 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         n_total = int(total.item()) & 0xFFFFFFFF
         b = [[N] for _ in range(P)]
         rel_at = None
+        seg_totals = None
         K = 1
     last_num_intersects = n_total
-    # un-wrapped total (python ints) from the per-sub-pose totals of the plan; None when there is no plan
-    true_total = sum(rel_at[p][KMAX - 1] for p in range(P)) if rel_at is not None else None
+    # un-wrapped total (python ints) from the per-sub-pose totals of the plan; None when there is no plan.
+    # (NOT rel_at[p][KMAX-1]: the last planned boundary lies before N when a sub-pose holds more than
+    # T*slice_base*2^(KMAX-1) intersections — fuzz seed 1 trial 328 overran the hit-mask buffer that way)
+    true_total = sum(seg_totals) if seg_totals is not None else None
     begins, prefixes, n_slices = [], [], []
     for k in range(K):
         lo = [0 if k == 0 else min(b[p][k - 1], N) for p in range(P)]

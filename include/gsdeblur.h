@@ -170,10 +170,12 @@ int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* ti
  * pixels have all stopped is flagged done and later slices emit no intersections for it.  Every
  * pixel still sees the same Gaussians in the same order, so results equal the unsliced pass. */
 /* bounds[p*K+k] = first depth rank of sub-pose p whose cumulative intersection count reaches base<<k;
- * rels[p*K+k] = that cumulative count at the boundary (sub-pose total when the boundary is N) */
+ * rels[p*K+k] = that cumulative count at the boundary (sub-pose total when the boundary is N — which the LAST
+ * boundary need not be: read the totals from seg_totals) */
 int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl /*P*N, rank order*/,
                   const unsigned* total /*device: grand total of the scan*/, long long base,
-                  int* bounds /*P*K*/, unsigned* rels /*P*K*/, void* stream);
+                  int* bounds /*P*K*/, unsigned* rels /*P*K*/,
+                  unsigned* seg_totals /*P or NULL: every sub-pose's own intersection total (mod 2^32)*/, void* stream);
 /* sat [P*(tiles_y+1)*(tiles_x+1)] = summed-area table of tiles NOT done (tile_done u8 [P*T]) */
 int gs_tile_open_sat(int P, int img_height, int img_width, const unsigned char* tile_done, int* sat,
                      void* stream);

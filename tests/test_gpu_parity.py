@@ -838,3 +838,39 @@ def test_full_size_fast_path_equals_plain_path(gs, oracle, dev):
         touched_f = (g_f[k].reshape(n, -1) != 0).any(dim=1)
         touched_p = (g_p[k].reshape(n, -1) != 0).any(dim=1)
         assert torch.equal(touched_f, touched_p), k                  # the same Gaussians receive a gradient
+
+
+def test_more_intersections_than_the_slice_plan_covers(gs, dev):
+    """Regression (found by tools/fuzz_paths.py, seed 1 trial 328): with a tiny slice budget the 16 planned
+    boundaries end before the last Gaussian of a sub-pose; the last slice takes the rest and every per-slice
+    buffer (hit masks!) must be sized from the sub-poses' real totals, not from the last boundary."""
+    from gsdeblur_amd import ops
+    n, W, H, S = 60000, 32, 32, 2                     # T = 4 tiles: budget 4 << 15 = 131k < ~240k box pairs per sub-pose
+    sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=5, scale_mult=12.0), dev)
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, 1, 0.0)
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    knobs = ("SLICE_BASE", "EXACT_TILE_CULL", "COMPACT_EMIT", "HIT_MASKS", "GRAD_TUPLES", "DEFER_COLOR")
+    saved = {k: getattr(ops, k) for k in knobs}
+    res = []
+    try:
+        for plain in (False, True):
+            for k in knobs:
+                setattr(ops, k, 0 if plain else saved[k])
+            if not plain:
+                ops.SLICE_BASE = 1
+            p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+            vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"] * 20, sc["ang_vel"] * 10,
+                                      torch.tensor(times, device=dev))
+            rgb, alphas, _ = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
+                                                torch.sigmoid(p["opacity_logits"]), p["sh"], vms, None, S, 1, sc["fx"],
+                                                sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2, min_rgb_level=10.0)
+            ((rgb * wt).sum() + alphas.sum()).backward()
+            res.append((rgb.detach().clone(), {k: v.grad.clone() for k, v in p.items()}, ops.last_num_intersects))
+    finally:
+        for k, v in saved.items():
+            setattr(ops, k, v)
+    (img_f, g_f, I_f), (img_p, g_p, I_p) = res
+    assert I_f == I_p and I_p > S * (4 << 15)           # really beyond the last planned boundary
+    assert torch.equal(img_f, img_p)
+    for k in g_f:
+        assert rel_max(g_f[k].cpu(), g_p[k].cpu()) < GRAD_RTOL, k

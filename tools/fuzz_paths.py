@@ -23,8 +23,8 @@ saved = {k: getattr(ops, k) for k in KNOBS}
 bad = 0
 t0 = time.time()
 for trial in range(trials):
-    n = rng.choice([1, 2, 7, 64, 300, 2000, 8000, 30000])
-    W, H = rng.randint(17, 420), rng.randint(17, 300)
+    n = rng.choice([1, 2, 7, 64, 300, 2000, 8000, 30000, 120000])
+    W, H = rng.randint(17, 900), rng.randint(17, 600)
     S, R = rng.choice([1, 2, 3]), rng.choice([1, 1, 2, 4])
     mult = rng.choice([1.0, 3.0, 6.0, 12.0])
     base = rng.choice([1, 4, 16, 64, 512])
