@@ -1,7 +1,9 @@
 """Randomised equivalence check of the default path (depth slices, exact culling, compact emission from hit
 masks, deferred colour, gradient tuples) against the plainest one (one slice, no culling, atomics) over random
 sizes / sub-pose layouts / slice budgets.  Images must be bit-identical, gradients equal up to summation order.
-usage: python tools/fuzz_paths.py [trials] [seed]"""
+With `oracle` as third argument the default path is ALSO held against the float64 CPU oracle (tiny sizes only;
+test infrastructure, never part of the product path).
+usage: python tools/fuzz_paths.py [trials] [seed] [oracle]"""
 import random
 import sys
 import time
@@ -16,6 +18,10 @@ from gsdeblur_amd import ops  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+with_oracle = len(sys.argv) > 3 and sys.argv[3] == "oracle"
+if with_oracle:
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "oracle"))
+    import gs_oracle as O  # noqa: E402
 rng = random.Random(seed)
 dev = torch.device("cuda", 0)
 KNOBS = ("SLICE_BASE", "EXACT_TILE_CULL", "COMPACT_EMIT", "HIT_MASKS", "GRAD_TUPLES", "DEFER_COLOR")
@@ -25,10 +31,17 @@ t0 = time.time()
 for trial in range(trials):
     n = rng.choice([1, 2, 7, 64, 300, 2000, 8000, 30000, 120000])
     W, H = rng.randint(17, 900), rng.randint(17, 600)
+    if with_oracle:
+        n, W, H = rng.choice([1, 5, 40, 200, 600]), rng.randint(17, 80), rng.randint(17, 64)
+    deg = rng.choice([0, 1, 2, 3, 3])
+    aa = rng.choice([True, True, False])
+    gamma, mlevel = rng.choice([(2.2, 10.0), (2.2, 0.0), (1.0, 0.0)])
+    bg = rng.choice([None, torch.tensor([0.1, 0.2, 0.3]), torch.tensor([1.0, 1.0, 1.0])])
     S, R = rng.choice([1, 2, 3]), rng.choice([1, 1, 2, 4])
     mult = rng.choice([1.0, 3.0, 6.0, 12.0])
     base = rng.choice([1, 4, 16, 64, 512])
-    sc = gs.data.synthetic_scene(n, W, H, seed=1000 + trial, scale_mult=mult)
+    sc = gs.data.synthetic_scene(n, W, H, sh_degree=deg, seed=1000 + trial, scale_mult=mult)
+    sc_cpu = sc
     sc = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
     times, _, _ = gs.subpose_schedule(S, 1 / 60, R, 1 / 30)
     wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(trial)).to(dev)
@@ -44,8 +57,9 @@ for trial in range(trials):
                                       torch.tensor(times, device=dev))
             rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
                                                     torch.sigmoid(p["opacity_logits"]), p["sh"], vms,
-                                                    torch.tensor([0.1, 0.2, 0.3], device=dev), S, R, sc["fx"], sc["fy"],
-                                                    sc["cx"], sc["cy"], H, W, gamma=2.2, min_rgb_level=10.0)
+                                                    None if bg is None else bg.to(dev), S, R, sc["fx"], sc["fy"],
+                                                    sc["cx"], sc["cy"], H, W, gamma=gamma, min_rgb_level=mlevel,
+                                                    sh_degree=deg, antialiased=aa)
             ((rgb * wt).sum() + 0.5 * alphas.sum()).backward()
             res.append((rgb.detach().clone(), alphas.detach().clone(), {k: v.grad.clone() for k, v in p.items()},
                         len(ops.last_slice_intersects)))
@@ -59,8 +73,29 @@ for trial in range(trials):
         a, b = g_f[k].double().cpu().numpy(), g_p[k].double().cpu().numpy()
         worst = max(worst, float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30)))
     ok = ok and worst < 3e-3 and all(torch.isfinite(v).all() for v in g_f.values())
+    extra = ""
+    if with_oracle:
+        cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], blur_samples=S, rs_bands=R,
+                             exposure_time=1 / 60, rolling_shutter_time=1 / 30, gamma=gamma, min_rgb_level=mlevel,
+                             sh_degree=deg, antialiased=aa)
+        q = {k: sc_cpu[k].double().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+        ref, ref_a, _, frag, _, _ = O.render(cfg, q["means"], q["log_scales"].exp(), q["quats"],
+                                             torch.sigmoid(q["opacity_logits"]), q["sh"], sc_cpu["viewmat"].double(),
+                                             (sc_cpu["lin_vel"] * 20).double(), (sc_cpu["ang_vel"] * 10).double(),
+                                             background=None if bg is None else bg.double(), return_parts=True)
+        ((ref * wt.cpu().double()).sum() + 0.5 * S * ref_a.sum()).backward()      # sum_s alpha_s = S * mean
+        good = ~frag
+        d_img = float((img_f.cpu().double() - ref)[good].abs().max()) if good.any() else 0.0
+        d_grad = 0.0
+        if float(frag.float().mean()) < 0.02:          # gradients are only comparable when no threshold decision is at risk
+            for k in g_f:
+                a, b = g_f[k].double().cpu().numpy(), q[k].grad.numpy()
+                d_grad = max(d_grad, float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30)))
+        ok = ok and d_img < 5e-4 and d_grad < 3e-3
+        extra = f" oracle: img {d_img:.1e} grad {d_grad:.1e} fragile {float(frag.float().mean()):.3f}"
     bad += 0 if ok else 1
     print(f"trial {trial:3d} n={n:6d} {W}x{H} S={S} R={R} mult={mult} base={base} slices={nsl} "
-          f"img_equal={torch.equal(img_f, img_p)} grad_rel={worst:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+          f"deg={deg} aa={int(aa)} gamma={gamma} img_equal={torch.equal(img_f, img_p)} grad_rel={worst:.1e}{extra} "
+          f"{'ok' if ok else 'FAIL'}", flush=True)
 print(f"fuzz: {trials - bad}/{trials} trials ok in {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
