@@ -20,6 +20,21 @@ IMG_ATOL = 2e-4       # rendered colour, absolute (values in [0,1])
 GRAD_RTOL = 3e-3      # gradients, relative to the tensor's max |g| (sums of ~1e3-1e5 fp32 atomics)
 
 
+def _fuzz_cases(tag, with_bg=False):
+    """GSD_FUZZ_CASES=N appends N seeded random (n, W, H, scale_mult) shapes to the compat-op parity tests
+    (ragged sizes, 1..20000 Gaussians); 0 / unset keeps the suite at its committed size."""
+    import os
+    import random
+    k = int(os.environ.get("GSD_FUZZ_CASES", "0"))
+    rng = random.Random(sum(map(ord, tag)) + 17)          # stable across processes (str hashes are salted)
+    out = []
+    for _ in range(k):
+        c = (rng.choice([1, 3, 50, 700, 4000, 20000]), rng.randint(16, 500), rng.randint(16, 300),
+             rng.choice([1.0, 2.0, 5.0, 12.0]))
+        out.append(c + (rng.random() < 0.5,) if with_bg else c)
+    return out
+
+
 def rel_max(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
@@ -116,7 +131,8 @@ def test_subpose_viewmats_fwd_bwd(gs, oracle, dev):
         assert rel_max(ad.grad.cpu(), a64.grad) < 1e-5
 
 
-@pytest.mark.parametrize("n,W,H,mult", [(5000, 256, 256, 4.0), (20000, 640, 360, 2.0), (7, 16, 16, 10.0)])
+@pytest.mark.parametrize("n,W,H,mult", [(5000, 256, 256, 4.0), (20000, 640, 360, 2.0), (7, 16, 16, 10.0)]
+                         + _fuzz_cases("project"))
 def test_project_gaussians_parity(gs, oracle, dev, n, W, H, mult):
     O = oracle
     sc = _scene(O, n, W, H, 7, mult, dev)
@@ -182,7 +198,8 @@ def test_spherical_harmonics_parity(gs, oracle, dev, deg, K):
 # --------------------------------------------------------------------------- #
 # binning: 64-bit upstream-format route and the 2-stage route agree with the oracle exactly
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("n,W,H,mult", [(5000, 256, 256, 4.0), (30000, 640, 368, 2.0), (3, 16, 16, 10.0)])
+@pytest.mark.parametrize("n,W,H,mult", [(5000, 256, 256, 4.0), (30000, 640, 368, 2.0), (3, 16, 16, 10.0)]
+                         + _fuzz_cases("binning"))
 def test_binning_keys_and_order_bit_exact(gs, oracle, dev, n, W, H, mult):
     O = oracle
     sc = _scene(O, n, W, H, 13, mult, dev)
@@ -232,7 +249,7 @@ def test_binning_keys_and_order_bit_exact(gs, oracle, dev, n, W, H, mult):
 # rasterize_gaussians forward / backward
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("n,W,H,mult,bg", [(5000, 256, 256, 4.0, True), (3000, 100, 60, 12.0, False),
-                                           (2000, 48, 40, 3.0, True)])
+                                           (2000, 48, 40, 3.0, True)] + _fuzz_cases("raster", with_bg=True))
 def test_rasterize_gaussians_parity(gs, oracle, dev, n, W, H, mult, bg):
     """config 1 of BASELINE.json (5k Gaussians, 256x256, 1 sub-pose) plus ragged image sizes."""
     O = oracle
