@@ -274,6 +274,7 @@ def get_tile_bin_edges(sorted_ids: np.ndarray, num_tiles: int) -> np.ndarray:
         starts = np.searchsorted(tid, np.arange(num_tiles), side="left")
         ends = np.searchsorted(tid, np.arange(num_tiles), side="right")
         bins[:, 0], bins[:, 1] = starts, ends
+        bins[starts == ends] = 0          # an empty tile keeps the zero-initialised [0,0), as upstream's kernel leaves it
     return bins
 
 

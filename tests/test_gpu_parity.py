@@ -22,14 +22,14 @@ GRAD_RTOL = 3e-3      # gradients, relative to the tensor's max |g| (sums of ~1e
 
 def _fuzz_cases(tag, with_bg=False):
     """GSD_FUZZ_CASES=N appends N seeded random (n, W, H, scale_mult) shapes to the compat-op parity tests
-    (ragged sizes, 1..20000 Gaussians); 0 / unset keeps the suite at its committed size."""
+    (ragged sizes, 50..20000 Gaussians, many empty tiles); 0 / unset keeps the suite at its committed size."""
     import os
     import random
     k = int(os.environ.get("GSD_FUZZ_CASES", "0"))
     rng = random.Random(sum(map(ord, tag)) + 17)          # stable across processes (str hashes are salted)
     out = []
     for _ in range(k):
-        c = (rng.choice([1, 3, 50, 700, 4000, 20000]), rng.randint(16, 500), rng.randint(16, 300),
+        c = (rng.choice([50, 200, 700, 4000, 20000]), rng.randint(16, 500), rng.randint(16, 300),
              rng.choice([1.0, 2.0, 5.0, 12.0]))
         out.append(c + (rng.random() < 0.5,) if with_bg else c)
     return out
