@@ -3,7 +3,7 @@ masks, deferred colour, gradient tuples) against the plainest one (one slice, no
 sizes / sub-pose layouts / slice budgets.  Images must be bit-identical, gradients equal up to summation order.
 With `oracle` as third argument the default path is ALSO held against the float64 CPU oracle (tiny sizes only;
 test infrastructure, never part of the product path).
-usage: python tools/fuzz_paths.py [trials] [seed] [oracle]"""
+usage: python tests/fuzz_paths.py [trials] [seed] [oracle]"""
 import random
 import sys
 import time

@@ -858,7 +858,7 @@ def test_full_size_fast_path_equals_plain_path(gs, oracle, dev):
 
 
 def test_more_intersections_than_the_slice_plan_covers(gs, dev):
-    """Regression (found by tools/fuzz_paths.py, seed 1 trial 328): with a tiny slice budget the 16 planned
+    """Regression (found by tests/fuzz_paths.py, seed 1 trial 328): with a tiny slice budget the 16 planned
     boundaries end before the last Gaussian of a sub-pose; the last slice takes the rest and every per-slice
     buffer (hit masks!) must be sized from the sub-poses' real totals, not from the last boundary."""
     from gsdeblur_amd import ops
