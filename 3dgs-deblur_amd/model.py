@@ -15,7 +15,6 @@ The forward/backward rendering surface; the densification step that follows it l
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass, field
 from typing import Dict, Optional
 

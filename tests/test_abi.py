@@ -1,7 +1,6 @@
 """C-ABI boundary checks that need no GPU: the library builds for gfx950, loads, and exports
 exactly the entry points include/gsdeblur.h declares; the product never touches the oracle and has
 no CPU fallback."""
-import ctypes
 import re
 from pathlib import Path
 
