@@ -184,3 +184,31 @@ def test_densify_world2_gloo_ranks_stay_identical():
         p.join(timeout=60)
     assert all(r[1] for r in res), res
     assert res[0][2] == res[1][2] and res[0][3] > 0      # same N on both ranks, and something was densified
+
+
+def test_step_callback_schedule(gs):
+    """statistics every step, refinement every `refine_every` steps after the warm-up, opacity reset one refine
+    interval into every reset period (splatfacto's AFTER_TRAIN_ITERATION order)"""
+    cfg = gs.densify.DensifyConfig(warmup_length=10, refine_every=5, reset_alpha_every=4, densify_grad_thresh=1e9)
+    model = _model(gs, 8)
+    opts = _prime_adam(gs, model)
+    st = gs.densify.DensifyState(8, "cpu")
+    refined, resets = [], []
+    for step in range(1, 51):
+        model.radii = torch.full((1, model.num_points), 3, dtype=torch.int32)
+        model.xy_grad = torch.zeros(model.num_points, 2)
+        model.last_size = (64, 48)
+        with torch.no_grad():
+            model.opacities.fill_(2.0)                      # "training" pushed the opacities back up
+        before = model.opacities.detach().clone()
+        r = gs.densify.step_callback(model, opts, st, step, cfg)
+        if r is not None:
+            refined.append(step)
+            assert float(st.vis_counts.sum()) == 0          # accumulators restart after every refinement
+        else:
+            assert float(st.vis_counts.min()) >= 1          # ... and grow on every other step
+        if not torch.equal(before, model.opacities.detach()):
+            resets.append(step)
+    assert refined == list(range(15, 51, 5))                # step > warmup and step % 5 == 0
+    assert resets == [25, 45]                               # step % (5*4) == 5, only on refinement steps
+    assert model.num_points == 8                            # nothing above the gradient threshold, nothing culled
