@@ -35,16 +35,18 @@ _SIGS = {
     "gs_emit_intersects": [_L, _I, _I, _I, _P, _P, _P, _L, _P, _P, ctypes.c_uint, _P],
     "gs_tile_bin_edges_u32": [_L, _P, _I, _P, _P],
     "gs_tile_bin_edges_u64": [_L, _P, _I, _P, _P],
+    "gs_tile_bin_edges_ids_u32": [_L, _P, _I, _P, _P, _P, _P, _P],
     "gs_map_gaussian_to_intersects": [_I, _P, _P, _P, _P, _I, _I, _P, _P, _P],
-    "gs_rasterize_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P],
-    "gs_rasterize_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "gs_rasterize_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P],
+    "gs_rasterize_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     "gs_slice_plan": [_I, _I, _I, _P, _P, _L, _P, _P, _P, _P],
     "gs_tile_open_sat": [_I, _I, _I, _P, _P, _P],
     "gs_slice_counts": [_I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "gs_emit_open_intersects": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, ctypes.c_uint, _I, _I, _P, _P, _P],
     "gs_slice_counts_exact": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P],
-    "gs_rasterize_fwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],
-    "gs_rasterize_bwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _F, _F, _P],
+    "gs_rasterize_fwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
+    "gs_rasterize_bwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I,
+                               _P, _F, _F, _P],
     "gs_reduce_grad_tuples": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "gs_combine_fwd": [_I, _L, _P, _F, _F, _P, _P],
     "gs_combine_bwd": [_I, _L, _P, _F, _F, _P, _P, _P, _P],
@@ -53,6 +55,8 @@ _SIGS = {
     "gs_dp_row_mask": [_I, _I, _P, _P, _P, _P],
     "gs_dp_pack_rows": [_L, _P, _I, _P, _P, _P, _P],
     "gs_dp_scatter_add_rows": [_L, _P, _I, _P, _P, _F, _P],
+    "gs_dp_pack_masked_rows": [_I, _P, _P, _I, _P, _I, _P, _P, _P, _P],
+    "gs_dp_scatter_add_payload": [_I, _P, _I, _P, _P, _F, _P],
 }
 _SIGS_LL = {
     "gs_scan_workspace_bytes": [_L],

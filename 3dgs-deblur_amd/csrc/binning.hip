@@ -577,6 +577,31 @@ __global__ __launch_bounds__(256) void bin_edges_kernel(size_t n, const KeyT* __
   if (i == n - 1) bins[t].y = (int)n;
 }
 
+// the same boundary test plus, for the depth-sliced path, the record index of every sorted entry: the tile sort
+// carries the EMISSION index e (the backward's tuple slot), the compositors want p*N+g = gi_of_e[e] through the
+// scalar cache without a dependent gather, so it is materialised once here; ids[n .. n+8) is zero padding (the
+// compositors read their lists in aligned groups of four)
+__global__ __launch_bounds__(256) void bin_edges_ids_kernel(size_t n, const unsigned* __restrict__ keys,
+                                                            int2* __restrict__ bins,
+                                                            const unsigned* __restrict__ sorted_vals,
+                                                            const unsigned* __restrict__ gi_of_e,
+                                                            unsigned* __restrict__ ids) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) {
+    if (i < n + 8) ids[i] = 0u;
+    return;
+  }
+  ids[i] = gi_of_e[sorted_vals[i]];
+  unsigned t = keys[i];
+  if (i == 0) {
+    bins[t].x = 0;
+  } else {
+    unsigned tp = keys[i - 1];
+    if (tp != t) { bins[t].x = (int)i; bins[tp].y = (int)i; }
+  }
+  if (i == n - 1) bins[t].y = (int)n;
+}
+
 // ---------------------------------------------------------------------------
 // depth-sliced binning (front-to-back slices; tiles whose pixels have all stopped are "done" and
 // receive no further intersections).  With early termination only a few percent of the
@@ -999,6 +1024,20 @@ GS_EXPORT int gs_tile_bin_edges_u32(long long n, const unsigned* sorted_keys, in
   if (n <= 0) return GS_OK;
   hipLaunchKernelGGL((bin_edges_kernel<unsigned, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, (size_t)n, sorted_keys, reinterpret_cast<int2*>(bins));
+  return gs_launch_status();
+}
+
+// gs_tile_bin_edges_u32 plus ids_out[i] = gi_of_e[sorted_vals[i]] for i < n and ids_out[n .. n+8) = 0
+// (ids_out holds n + 8 ints): the record index of every sorted entry, what gs_rasterize_*_slice take as sorted_ids.
+GS_EXPORT int gs_tile_bin_edges_ids_u32(long long n, const unsigned* sorted_keys, int num_bins, int* bins,
+                                        const unsigned* sorted_vals, const unsigned* gi_of_e, unsigned* ids_out,
+                                        void* stream) {
+  if (num_bins <= 0 || !sorted_vals || !gi_of_e || !ids_out) return GS_ERR_INVALID;
+  hipError_t e = hipMemsetAsync(bins, 0, (size_t)num_bins * 2 * sizeof(int), (hipStream_t)stream);
+  if (e != hipSuccess) return 1000 + (int)e;
+  if (n < 0) return GS_ERR_INVALID;
+  hipLaunchKernelGGL(bin_edges_ids_kernel, dim3((unsigned)((n + 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (size_t)n, sorted_keys, reinterpret_cast<int2*>(bins), sorted_vals, gi_of_e, ids_out);
   return gs_launch_status();
 }
 

@@ -67,6 +67,57 @@ __global__ __launch_bounds__(256) void dp_scatter_add_kernel(long long M, const 
   *dst += payload[e] * scale;
 }
 
+// ---- fixed-capacity, sync-free form (round 2): nothing about the number of rows ever reaches the host ----------
+// payload = [cap + 1][wtot + 1] floats; row 0 is a header (int bit patterns): [0] = rows with a gradient on the
+// sending rank (may exceed cap: the receiver can tell the payload was truncated), [1] = rows actually packed.
+// idx[pos[r]] = r for the masked rows whose rank pos[r] (exclusive scan of the mask) fits the capacity
+__global__ __launch_bounds__(256) void dp_compact_rows_kernel(int N, const unsigned char* __restrict__ mask,
+                                                              const int* __restrict__ pos, int cap,
+                                                              int* __restrict__ idx, float* __restrict__ header) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  if (mask[r] && pos[r] < cap) idx[pos[r]] = r;
+  if (r == N - 1) {
+    const int total = pos[r] + (mask[r] ? 1 : 0);
+    header[0] = __int_as_float(total);
+    header[1] = __int_as_float(total < cap ? total : cap);
+  }
+}
+
+// one thread per payload element of the cap data rows; the packed-row count is read from the header
+__global__ __launch_bounds__(256) void dp_pack_rows_dev_kernel(int cap, const int* __restrict__ idx, DpTable tb,
+                                                               float* __restrict__ payload) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int stride = tb.wtot + 1;
+  const int count = __float_as_int(payload[1]);
+  if (e >= (long long)count * stride) return;
+  const long long r = e / stride;
+  const int col = (int)(e - r * stride);
+  const int row = idx[r];
+  float* out = payload + stride;                       // data rows start after the header row
+  if (col == tb.wtot) { out[e] = __int_as_float(row); return; }
+  int t = 0;
+  while (t + 1 < tb.n && col >= tb.start[t + 1]) ++t;
+  out[e] = tb.ptr[t][(size_t)row * tb.width[t] + (col - tb.start[t])];
+}
+
+__global__ __launch_bounds__(256) void dp_scatter_add_dev_kernel(int cap, const float* __restrict__ payload,
+                                                                 DpTable tb, float scale) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int stride = tb.wtot + 1;
+  const int count = __float_as_int(payload[1]);
+  if (e >= (long long)count * stride) return;
+  const long long r = e / stride;
+  const int col = (int)(e - r * stride);
+  if (col == tb.wtot) return;
+  const float* rows = payload + stride;
+  const int row = __float_as_int(rows[r * stride + tb.wtot]);
+  int t = 0;
+  while (t + 1 < tb.n && col >= tb.start[t + 1]) ++t;
+  float* dst = tb.ptr[t] + (size_t)row * tb.width[t] + (col - tb.start[t]);
+  *dst += rows[e] * scale;
+}
+
 static bool make_table(int n, float* const* ptrs, const int* widths, DpTable& tb) {
   if (n <= 0 || n > kMaxDpTensors) return false;
   tb.n = n;
@@ -116,5 +167,32 @@ GS_EXPORT int gs_dp_scatter_add_rows(long long M, const float* payload /*M*(wtot
   const long long total = M * (tb.wtot + 1);
   hipLaunchKernelGGL(dp_scatter_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      M, payload, tb, scale);
+  return gs_launch_status();
+}
+
+// ---- fixed-capacity, sync-free form: the row count stays on the device ------------------------------------------
+// payload [(cap+1)*(wtot+1)]: row 0 = header {rows with a gradient, rows packed = min(that, cap)} as int bit patterns,
+// rows 1.. = the packed rows.  pos = exclusive prefix sum of mask (int32 [N]); idx_ws is scratch for cap ints.
+GS_EXPORT int gs_dp_pack_masked_rows(int N, const unsigned char* mask, const int* pos, int cap, int* idx_ws,
+                                     int n_tensors, float* const* grads, const int* widths, float* payload,
+                                     void* stream) {
+  DpTable tb;
+  if (N <= 0 || cap <= 0 || !make_table(n_tensors, grads, widths, tb)) return GS_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dp_compact_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, mask, pos, cap, idx_ws, payload);
+  const long long total = (long long)cap * (tb.wtot + 1);
+  hipLaunchKernelGGL(dp_pack_rows_dev_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cap, idx_ws, tb,
+                     payload);
+  return gs_launch_status();
+}
+
+// grads[t][row] += scale * row for the header[1] rows of a payload built by gs_dp_pack_masked_rows
+GS_EXPORT int gs_dp_scatter_add_payload(int cap, const float* payload, int n_tensors, float* const* grads,
+                                        const int* widths, float scale, void* stream) {
+  DpTable tb;
+  if (cap <= 0 || !make_table(n_tensors, grads, widths, tb)) return GS_ERR_INVALID;
+  const long long total = (long long)cap * (tb.wtot + 1);
+  hipLaunchKernelGGL(dp_scatter_add_dev_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, cap, payload, tb, scale);
   return gs_launch_status();
 }

@@ -143,6 +143,156 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
 }
 
 // ---------------------------------------------------------------------------
+// Forward compositor, scalar-cache variant (round 2).  tools/valu_bench.hip measured what the instructions of the
+// v_readlane kernel above cost on gfx950 (cycles per wave-instruction per SIMD, 4 waves/SIMD): v_fma/v_mul with VGPR
+// operands 1.9, the same with an SGPR operand / v_pk_* / v_min / v_cndmask 3.2, v_cmp -> SGPR 4.0, v_exp 6.3,
+// **v_readlane_b32 7.9** — the 9 broadcasts per list entry were a quarter of that kernel's issue time.  Here the
+// wave fetches each entry's record with SCALAR loads (s_load_dwordx8 + s_load_dword off the wave-uniform record
+// index): no VGPR gather, no v_readlane, no VALU slot at all.  The list is walked in aligned groups of four entries
+// (one s_load_dwordx4 of record indices per group); two register sets of two records each: while one pair is
+// blended the loads of the other are in flight (SMEM returns out of order, so every wait is lgkmcnt(0): the
+// `asm volatile` fences pin "wait for the pair, THEN issue the next loads, then blend").  The four pixels of a
+// lane are two hand-packed float2 pairs (v_pk_add/fma/mul_f32); a stopped pixel keeps its final transmittance as a
+// NEGATIVE T (one state register and one select less per pixel than the Tf/Tk pair above).  Arithmetic is
+// term-for-term that of raster_fwd_slice_kernel (same fma placement): images are bit-identical (tested).
+// ---------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct RecS { float x, y, cx, cy, cz, op, r, g, b; };
+
+__device__ __forceinline__ RecS load_rec_s(const float* __restrict__ records, unsigned gi) {
+  const float* p = records + (size_t)gi * kRecFloats;
+  RecS o;
+  o.x = p[0]; o.y = p[1]; o.cx = p[2]; o.cy = p[3]; o.cz = p[4]; o.op = p[5]; o.r = p[6]; o.g = p[7]; o.b = p[8];
+  return o;
+}
+
+struct PixPair { f2 T, Cr, Cg, Cb, py; int last0, last1; };
+
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ void blend_entry(const RecS& rc, float pxf, int idx1, PixPair (&pp)[2]) {
+  const float kL2E = -1.4426950408889634f;
+  const float qx = rc.cx * (0.5f * kL2E), qy = rc.cy * kL2E, qz = rc.cz * (0.5f * kL2E);
+  const float dx = rc.x - pxf;
+  const float hx = qx * dx * dx;
+  const float bx = qy * dx;
+  const f2 hx2 = {hx, hx}, bx2 = {bx, bx}, qz2 = {qz, qz}, gy2 = {rc.y, rc.y}, op2 = {rc.op, rc.op};
+  const f2 cr2 = {rc.r, rc.r}, cg2 = {rc.g, rc.g}, cb2 = {rc.b, rc.b};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    PixPair& q = pp[h];
+    const f2 dy = gy2 - q.py;
+    const f2 s2 = fma2(dy, fma2(qz2, dy, bx2), hx2);
+    const f2 ov = op2 * f2{__builtin_amdgcn_exp2f(s2.x), __builtin_amdgcn_exp2f(s2.y)};
+    const f2 alpha = {fminf(K::kAlphaMax, ov.x), fminf(K::kAlphaMax, ov.y)};
+    const bool v0 = (s2.x <= 0.f) && (alpha.x >= K::kAlphaMin), v1 = (s2.y <= 0.f) && (alpha.y >= K::kAlphaMin);
+    const f2 w0 = alpha * q.T;
+    const f2 nT = fma2(-q.T, alpha, q.T);
+    const bool u0 = v0 && (nT.x > K::kTMin), u1 = v1 && (nT.y > K::kTMin);
+    const f2 w = {u0 ? w0.x : 0.f, u1 ? w0.y : 0.f};
+    q.Cr = fma2(w, cr2, q.Cr); q.Cg = fma2(w, cg2, q.Cg); q.Cb = fma2(w, cb2, q.Cb);
+    // live pixel: T > 0.  A hit that would push T to <= 1e-4 stops the pixel: T := -|T| keeps the final value
+    q.T.x = u0 ? nT.x : (v0 ? -fabsf(q.T.x) : q.T.x);
+    q.T.y = u1 ? nT.y : (v1 ? -fabsf(q.T.y) : q.T.y);
+    q.last0 = u0 ? idx1 : q.last0;
+    q.last1 = u1 ? idx1 : q.last1;
+  }
+}
+
+__global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm, SliceState st,
+                                                               const int* __restrict__ ids,       // padded, see ABI
+                                                               const float* __restrict__ records, unsigned max_id,
+                                                               float* __restrict__ out_img,
+                                                               float* __restrict__ out_T,
+                                                               int* __restrict__ final_idx, unsigned n_blocks) {
+  const int lane = lane_id();
+  const int T = prm.tiles_x * prm.tiles_y;
+  const unsigned work = (unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6)));
+  if (work >= (unsigned)(prm.S * T)) return;
+  const int s = work / T, t = work % T;
+  const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
+  const int p = s * prm.R + find_band(prm.band_edges, prm.R, ty);
+  const size_t tkey = (size_t)p * T + t;
+  if (!st.first && st.tile_done[tkey]) return;
+  int2 range = prm.tile_bins[tkey];
+  range.x = __builtin_amdgcn_readfirstlane(range.x);
+  range.y = __builtin_amdgcn_readfirstlane(range.y);
+  if (!st.first && !st.last && range.y <= range.x) return;   // nothing for this tile in this slice
+
+  const int px = tx * K::kTile + (lane & 15);
+  const int py0 = ty * K::kTile + (lane >> 4) * 4;
+  const float pxf = (float)px + 0.5f;
+  PixPair pp[2];
+  bool inside[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    inside[k] = px < prm.W && (py0 + k) < prm.H;
+    float Tk = inside[k] ? 1.f : -1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    if (!st.first && inside[k]) {
+      size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
+      cr = out_img[pix * 3 + 0]; cg = out_img[pix * 3 + 1]; cb = out_img[pix * 3 + 2];
+      const float Tf = out_T[pix], lv = st.live_T[pix];
+      Tk = lv > 0.f ? lv : -Tf;
+    }
+    PixPair& q = pp[k >> 1];
+    if (k & 1) { q.T.y = Tk; q.Cr.y = cr; q.Cg.y = cg; q.Cb.y = cb; q.py.y = (float)(py0 + k) + 0.5f; q.last1 = range.x; }
+    else       { q.T.x = Tk; q.Cr.x = cr; q.Cg.x = cg; q.Cb.x = cb; q.py.x = (float)(py0 + k) + 0.5f; q.last0 = range.x; }
+  }
+  auto any_live = [&]() -> bool {
+    return __ballot(fmaxf(fmaxf(pp[0].T.x, pp[0].T.y), fmaxf(pp[1].T.x, pp[1].T.y)) > 0.f) != 0ull;
+  };
+  const unsigned n = (unsigned)(range.y - range.x);
+  if (n != 0u) {
+    int b = range.x & ~3;
+    const int4* __restrict__ ids4 = reinterpret_cast<const int4*>(ids);
+    int4 idv = ids4[b >> 2];
+    // indices read in front of / behind the tile's own range belong to other tiles (or to the padding): clamp, the
+    // record is loaded but never blended
+    RecS a0 = load_rec_s(records, min((unsigned)idv.x, max_id)), a1 = load_rec_s(records, min((unsigned)idv.y, max_id));
+    for (;;) {
+      // pair A (entries b, b+1) is ready; put pair B (b+2, b+3) and the indices of the next group in flight
+      asm volatile("" :: "s"(a0.x), "s"(a1.x) : "memory");
+      const RecS b0 = load_rec_s(records, min((unsigned)idv.z, max_id)), b1 = load_rec_s(records, min((unsigned)idv.w, max_id));
+      idv = ids4[(b >> 2) + 1];
+      asm volatile("" ::: "memory");
+      if ((unsigned)(b - range.x) < n) blend_entry(a0, pxf, b + 1, pp);
+      if ((unsigned)(b + 1 - range.x) < n) blend_entry(a1, pxf, b + 2, pp);
+      // pair B is ready; refill pair A from the next group
+      asm volatile("" :: "s"(b0.x), "s"(b1.x), "s"(idv.x) : "memory");
+      a0 = load_rec_s(records, min((unsigned)idv.x, max_id)); a1 = load_rec_s(records, min((unsigned)idv.y, max_id));
+      asm volatile("" ::: "memory");
+      if ((unsigned)(b + 2 - range.x) < n) blend_entry(b0, pxf, b + 3, pp);
+      if ((unsigned)(b + 3 - range.x) < n) blend_entry(b1, pxf, b + 4, pp);
+      b += 4;
+      if (b >= range.y) break;
+      if ((b & 12) == 12 && !any_live()) break;
+    }
+  }
+  const bool all_stopped = !any_live();
+  const bool finalize = all_stopped || st.last;
+  const float bgr = finalize ? prm.background[0] : 0.f, bgg = finalize ? prm.background[1] : 0.f,
+              bgb = finalize ? prm.background[2] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (inside[k]) {
+      const PixPair& q = pp[k >> 1];
+      const float Tk = (k & 1) ? q.T.y : q.T.x, Tf = fabsf(Tk);
+      const float cr = (k & 1) ? q.Cr.y : q.Cr.x, cg = (k & 1) ? q.Cg.y : q.Cg.x, cb = (k & 1) ? q.Cb.y : q.Cb.x;
+      size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
+      out_img[pix * 3 + 0] = cr + Tf * bgr;
+      out_img[pix * 3 + 1] = cg + Tf * bgg;
+      out_img[pix * 3 + 2] = cb + Tf * bgb;
+      out_T[pix] = Tf;
+      final_idx[pix] = (k & 1) ? q.last1 : q.last0;
+      if (!st.last) st.live_T[pix] = fmaxf(Tk, 0.f);
+    }
+  }
+  if (all_stopped && !st.last && lane == 0) st.tile_done[tkey] = 1;
+}
+
+// ---------------------------------------------------------------------------
 // sub-frame averaging in linearised colour:
 //   out = ( mean_k max(C_k, m)^gamma )^(1/gamma),  m = min_rgb_level/255
 // ---------------------------------------------------------------------------
@@ -213,21 +363,31 @@ using namespace gs;
 // C ABI -----------------------------------------------------------------------
 // Replaces the device side of gsplat.rasterize_gaussians' forward
 // (_C.rasterize_forward in the absent fork; SURVEY.md §8 a7, boundary §8b).
+static void launch_fwd(const RasterParams& prm, const SliceState& st, const int* ids, int n_records, float* out_img,
+                       float* out_T, int* final_idx, int variant, hipStream_t stream) {
+  unsigned work = (unsigned)(prm.S * prm.tiles_x * prm.tiles_y);
+  unsigned blocks = (work + 3) / 4;
+  if (variant == 0 && ids)
+    hipLaunchKernelGGL(raster_fwd_sload_kernel, dim3(blocks), dim3(256), 0, stream, prm, st, ids, prm.records,
+                       (unsigned)(n_records > 0 ? n_records - 1 : 0), out_img, out_T, final_idx, blocks);
+  else if (variant == 1)
+    hipLaunchKernelGGL(raster_fwd_slice_kernel<false>, dim3(blocks), dim3(256), 0, stream, prm, st, out_img, out_T,
+                       final_idx, blocks);
+  else
+    hipLaunchKernelGGL(raster_fwd_slice_kernel<true>, dim3(blocks), dim3(256), 0, stream, prm, st, out_img, out_T,
+                       final_idx, blocks);
+}
+
 GS_EXPORT int gs_rasterize_fwd(const float* records, const int* sorted_vals, const int* tile_bins,
                                const int* band_edges, const float* background, int S, int R, int H, int W,
-                               float* out_img, float* out_T, int* final_idx, int variant, void* stream) {
+                               float* out_img, float* out_T, int* final_idx, int n_records, int variant,
+                               void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
   // one pass over the complete tile lists = the sliced kernel with first == last (no persistent state)
   SliceState st; st.tile_done = nullptr; st.live_T = nullptr; st.first = 1; st.last = 1;
-  unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
-  unsigned blocks = (work + 3) / 4;
-  if (variant == 1)
-    hipLaunchKernelGGL(raster_fwd_slice_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, st,
-                       out_img, out_T, final_idx, blocks);
-  else
-    hipLaunchKernelGGL(raster_fwd_slice_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, st,
-                       out_img, out_T, final_idx, blocks);
+  launch_fwd(prm, st, n_records > 0 ? sorted_vals : nullptr, n_records, out_img, out_T, final_idx, variant,
+             (hipStream_t)stream);
   return gs_launch_status();
 }
 
@@ -239,20 +399,15 @@ GS_EXPORT int gs_rasterize_fwd(const float* records, const int* sorted_vals, con
 GS_EXPORT int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                                      const int* band_edges, const float* background, int S, int R, int H, int W,
                                      float* out_img, float* out_T, float* live_T, int* final_idx,
-                                     unsigned char* tile_done, int first, int last, const int* gi_of_e, int variant,
-                                     void* stream) {
+                                     unsigned char* tile_done, int first, int last, const int* gi_of_e,
+                                     const int* sorted_ids, int n_records, int variant, void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
-  unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
-  unsigned blocks = (work + 3) / 4;
   prm.gi_of_e = gi_of_e;
   SliceState st; st.tile_done = tile_done; st.live_T = live_T; st.first = first; st.last = last;
-  if (variant == 1)
-    hipLaunchKernelGGL(raster_fwd_slice_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, st,
-                       out_img, out_T, final_idx, blocks);
-  else
-    hipLaunchKernelGGL(raster_fwd_slice_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, st,
-                       out_img, out_T, final_idx, blocks);
+  const int* ids = sorted_ids ? sorted_ids : (gi_of_e ? nullptr : sorted_vals);
+  launch_fwd(prm, st, n_records > 0 ? ids : nullptr, n_records, out_img, out_T, final_idx, variant,
+             (hipStream_t)stream);
   return gs_launch_status();
 }
 

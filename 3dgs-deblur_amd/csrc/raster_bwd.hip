@@ -326,6 +326,229 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
 }
 
 // ---------------------------------------------------------------------------
+// Backward compositor, scalar-cache variant (round 2; see raster.hip "scalar-cache variant" for the measurements
+// behind it).  Same traversal and the same per-pixel recurrences as raster_bwd_kernel_v2, but
+//   * the entry's record comes through the scalar cache (s_load_dwordx8 + s_load_dword) instead of a per-lane
+//     gather + 12 v_readlane_b32 (7.9 cycles each); the list is walked backwards in aligned groups of four
+//     entries, two register sets of two records each (one pair in flight while the other is processed);
+//   * the five geometric gradients of a lane (x, y and the three conic terms) are built from THREE moments of
+//     v_sigma over the lane's four pixels (sum w, sum w*dy, sum w*dy^2; dx is a lane constant): 4 packed ops per
+//     pixel pair instead of 8, and 7 scalar ops per entry to expand them;
+//   * a reduction group is the four entries of a list group; lanes 0..35 sum the 36 rows and store their total
+//     STRAIGHT into the entry's gradient tuple (or atomically into v_records): no per-batch totals in LDS, no
+//     per-batch flush, no vector loads of ids / records at all.
+// LDS per wave: 36 rows x 68 floats = 9.6 KB (4 waves per SIMD, as before).
+// ---------------------------------------------------------------------------
+struct RecS { float x, y, cx, cy, cz, op, r, g, b; };
+
+__device__ __forceinline__ RecS load_rec_s(const float* __restrict__ records, unsigned gi) {
+  const float* p = records + (size_t)gi * kRecFloats;
+  RecS o;
+  o.x = p[0]; o.y = p[1]; o.cx = p[2]; o.cy = p[3]; o.cz = p[4]; o.op = p[5]; o.r = p[6]; o.g = p[7]; o.b = p[8];
+  return o;
+}
+
+constexpr int kRedG4 = 4;
+constexpr int kRedFloats4 = kRedG4 * 9 * kRedStride;
+
+struct BwdPair { f2 T, Dv, vr, vg, vb, py; int fin0, fin1; };
+
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// one list entry against the lane's four pixels; returns whether any lane of the wave was hit (then the lane's 9
+// partial sums are in LDS rows slot*9 .. slot*9+8, column `lane`)
+__device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, BwdPair (&pp)[2], float* __restrict__ red,
+                                          int slot, int lane) {
+  const float kL2E = -1.4426950408889634f;
+  const float qx = rc.cx * (0.5f * kL2E), qy = rc.cy * kL2E, qz = rc.cz * (0.5f * kL2E);
+  const float dx = rc.x - pxf;
+  const float hx = qx * dx * dx;             // exponent terms, pre-scaled by -log2(e)
+  const float bx = qy * dx;
+  const f2 hx2 = {hx, hx}, bx2 = {bx, bx}, qz2 = {qz, qz}, gy2 = {rc.y, rc.y}, op2 = {rc.op, rc.op};
+  f2 dy2[2], vis2[2], ov2[2];
+  bool hit[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    dy2[h] = gy2 - pp[h].py;
+    const f2 s2 = fma2(dy2[h], fma2(qz2, dy2[h], bx2), hx2);
+    vis2[h] = f2{__builtin_amdgcn_exp2f(s2.x), __builtin_amdgcn_exp2f(s2.y)};
+    ov2[h] = op2 * vis2[h];
+    hit[2 * h] = (idx < pp[h].fin0) && (s2.x <= 0.f) && (fminf(K::kAlphaMax, ov2[h].x) >= K::kAlphaMin);
+    hit[2 * h + 1] = (idx < pp[h].fin1) && (s2.y <= 0.f) && (fminf(K::kAlphaMax, ov2[h].y) >= K::kAlphaMin);
+  }
+  if (__ballot(hit[0] || hit[1] || hit[2] || hit[3]) == 0ull) return false;
+  const f2 cr2 = {rc.r, rc.r}, cg2 = {rc.g, rc.g}, cb2 = {rc.b, rc.b};
+  f2 q_op = {0.f, 0.f}, q_r = q_op, q_g = q_op, q_b = q_op, m0 = q_op, m1 = q_op, m2 = q_op;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    BwdPair& q = pp[h];
+    const bool h0 = hit[2 * h], h1 = hit[2 * h + 1];
+    // pixels that are not hit are neutralised by SELECTING alpha = 0 (1/(1-0) = 1 exactly, every contribution is
+    // an exact zero) instead of per-pixel exec regions
+    const f2 alpha = {h0 ? fminf(K::kAlphaMax, ov2[h].x) : 0.f, h1 ? fminf(K::kAlphaMax, ov2[h].y) : 0.f};
+    const f2 om = 1.f - alpha;
+    const f2 ra = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+    q.T *= ra;                               // transmittance in front of this Gaussian
+    const f2 fac = alpha * q.T;
+    q_r = fma2(fac, q.vr, q_r); q_g = fma2(fac, q.vg, q_g); q_b = fma2(fac, q.vb, q_b);
+    const f2 cv = fma2(cb2, q.vb, fma2(cg2, q.vg, cr2 * q.vr));
+    const f2 v_al = fma2(q.T, cv, -(ra * q.Dv));
+    q.Dv = fma2(fac, cv, q.Dv);
+    // d min(0.999, o*vis) = 0 when clamped
+    const bool f0 = h0 && ov2[h].x <= K::kAlphaMax, f1 = h1 && ov2[h].y <= K::kAlphaMax;
+    const f2 ovm = {f0 ? ov2[h].x : 0.f, f1 ? ov2[h].y : 0.f};
+    const f2 vism = {f0 ? vis2[h].x : 0.f, f1 ? vis2[h].y : 0.f};
+    const f2 v_sigma = -ovm * v_al;
+    q_op = fma2(vism, v_al, q_op);
+    // moments of v_sigma over the lane's pixels (dx is the same for all four)
+    m0 += v_sigma;
+    const f2 vsdy = v_sigma * dy2[h];
+    m1 += vsdy;
+    m2 = fma2(vsdy, dy2[h], m2);
+  }
+  const float M0 = m0.x + m0.y, M1 = m1.x + m1.y, M2 = m2.x + m2.y;
+  const float p_cx = (0.5f * dx * dx) * M0, p_cy = dx * M1, p_cz = 0.5f * M2;
+  const float p_x = (rc.cx * dx) * M0 + rc.cy * M1;
+  const float p_y = (rc.cy * dx) * M0 + rc.cz * M1;
+  float* r0 = red + slot * (9 * kRedStride) + lane;
+  r0[0 * kRedStride] = p_x;  r0[1 * kRedStride] = p_y;  r0[2 * kRedStride] = p_cx;
+  r0[3 * kRedStride] = p_cy; r0[4 * kRedStride] = p_cz; r0[5 * kRedStride] = q_op.x + q_op.y;
+  r0[6 * kRedStride] = q_r.x + q_r.y;  r0[7 * kRedStride] = q_g.x + q_g.y;  r0[8 * kRedStride] = q_b.x + q_b.y;
+  return true;
+}
+
+template <bool STATE, int OUT>
+__global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_sload_kernel(
+    RasterParams prm, const int* __restrict__ ids /*record index per sorted entry, padded*/,
+    const int* __restrict__ eids /*OUT==1: emission index per sorted entry (sorted_vals), padded*/,
+    const float* __restrict__ records, unsigned max_id, const float* __restrict__ out_T,
+    const int* __restrict__ final_idx, const float* __restrict__ v_img, const float* __restrict__ v_alpha,
+    float* __restrict__ v_records, unsigned n_blocks, float* __restrict__ bwd_T, float* __restrict__ bwd_B,
+    float* __restrict__ tuples, unsigned char* __restrict__ flags) {
+  __shared__ __attribute__((aligned(16))) float lds_all[4 * kRedFloats4];
+  const int lane = lane_id();
+  float* red = lds_all + (threadIdx.x >> 6) * kRedFloats4;   // wave-private
+  const int T = prm.tiles_x * prm.tiles_y;
+  const unsigned work = (unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6)));
+  if (work >= (unsigned)(prm.S * T)) return;
+  const int s = work / T, t = work % T;
+  const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
+  const int p = s * prm.R + find_band(prm.band_edges, prm.R, ty);
+  int2 range = prm.tile_bins[(size_t)p * T + t];
+  range.x = __builtin_amdgcn_readfirstlane(range.x);
+  range.y = __builtin_amdgcn_readfirstlane(range.y);
+  if (range.y <= range.x) return;
+
+  const int px = tx * K::kTile + (lane & 15);
+  const int py0 = ty * K::kTile + (lane >> 4) * 4;
+  const float pxf = (float)px + 0.5f;
+  const float bgr = prm.background[0], bgg = prm.background[1], bgb = prm.background[2];
+  BwdPair pp[2];
+  int my_end = range.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = py0 + k;
+    float Tk = 1.f, Dv = 0.f, vr = 0.f, vg = 0.f, vb = 0.f;
+    int fin = range.x;
+    if (px < prm.W && y < prm.H) {
+      size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
+      const float Tfin = out_T[pix];
+      fin = final_idx[pix];
+      vr = v_img[pix * 3 + 0]; vg = v_img[pix * 3 + 1]; vb = v_img[pix * 3 + 2];
+      if (prm.cmb_scale) {
+        const size_t q = ((size_t)y * prm.W + px) * 3;
+        vr = combine_grad(vr, prm.cmb_scale[q + 0], prm.cmb_gamma, prm.cmb_min);
+        vg = combine_grad(vg, prm.cmb_scale[q + 1], prm.cmb_gamma, prm.cmb_min);
+        vb = combine_grad(vb, prm.cmb_scale[q + 2], prm.cmb_gamma, prm.cmb_min);
+      }
+      const float va_out = v_alpha ? v_alpha[pix] : 0.f;
+      const float va = Tfin * (va_out - (bgr * vr + bgg * vg + bgb * vb));
+      Tk = Tfin;
+      Dv = -va;
+      if (STATE) {
+        Tk = bwd_T[pix];
+        Dv = bwd_B[pix] - va;
+      }
+    }
+    my_end = max(my_end, fin);
+    BwdPair& q = pp[k >> 1];
+    if (k & 1) { q.T.y = Tk; q.Dv.y = Dv; q.vr.y = vr; q.vg.y = vg; q.vb.y = vb; q.py.y = (float)y + 0.5f; q.fin1 = fin; }
+    else       { q.T.x = Tk; q.Dv.x = Dv; q.vr.x = vr; q.vg.x = vg; q.vb.x = vb; q.py.x = (float)y + 0.5f; q.fin0 = fin; }
+  }
+  const int wave_end = __builtin_amdgcn_readfirstlane(wave_max_i(my_end));
+  const unsigned n = (unsigned)(wave_end - range.x);       // entries [range.x, wave_end) reached some pixel's final index
+  const int row = lane;                                    // row-sum role: lanes 0..35
+  const int row_g = row / 9, row_c = row - row_g * 9;
+  if (n != 0u) {
+    const int4* __restrict__ ids4 = reinterpret_cast<const int4*>(ids);
+    const int4* __restrict__ eids4 = reinterpret_cast<const int4*>(eids);
+    int b = (wave_end - 1) & ~3;
+    const int b_last = range.x & ~3;
+    int4 idv = ids4[b >> 2];
+    RecS a0 = load_rec_s(records, min((unsigned)idv.w, max_id)), a1 = load_rec_s(records, min((unsigned)idv.z, max_id));
+    for (;;) {
+      // pair A (entries b+3, b+2) is ready; put pair B (b+1, b) and the indices of the next (lower) group in flight
+      asm volatile("" :: "s"(a0.x), "s"(a1.x) : "memory");
+      const RecS b0 = load_rec_s(records, min((unsigned)idv.y, max_id)), b1 = load_rec_s(records, min((unsigned)idv.x, max_id));
+      const int4 cur = idv;
+      int4 ev = cur;
+      if (OUT == 1) ev = eids4[b >> 2];
+      // (unconditional: a conditional refill turns into a phi whose copies wait for the loads right where they are
+      // issued; below the tile's first group the previous group — or group 0 again — is fetched and never used)
+      idv = ids4[max(b - 4, 0) >> 2];
+      asm volatile("" ::: "memory");
+      unsigned filled = 0;
+      if ((unsigned)(b + 3 - range.x) < n && bwd_entry(a0, pxf, b + 3, pp, red, 3, lane)) filled |= 8u;
+      if ((unsigned)(b + 2 - range.x) < n && bwd_entry(a1, pxf, b + 2, pp, red, 2, lane)) filled |= 4u;
+      // pair B is ready; refill pair A from the next group
+      asm volatile("" :: "s"(b0.x), "s"(b1.x), "s"(idv.x), "s"(ev.x) : "memory");
+      a0 = load_rec_s(records, min((unsigned)idv.w, max_id)); a1 = load_rec_s(records, min((unsigned)idv.z, max_id));
+      asm volatile("" ::: "memory");
+      if ((unsigned)(b + 1 - range.x) < n && bwd_entry(b0, pxf, b + 1, pp, red, 1, lane)) filled |= 2u;
+      if ((unsigned)(b - range.x) < n && bwd_entry(b1, pxf, b, pp, red, 0, lane)) filled |= 1u;
+      if (filled) {
+        __builtin_amdgcn_wave_barrier();
+        if (row < kRedG4 * 9 && ((filled >> row_g) & 1u)) {
+          const f4* rp = reinterpret_cast<const f4*>(red + row * kRedStride);
+          f4 s0 = rp[0], s1 = rp[1], s2 = rp[2], s3 = rp[3];
+#pragma unroll
+          for (int q = 4; q < 16; q += 4) { s0 += rp[q]; s1 += rp[q + 1]; s2 += rp[q + 2]; s3 += rp[q + 3]; }
+          const f4 v = (s0 + s1) + (s2 + s3);
+          const float sum = (v.x + v.y) + (v.z + v.w);
+          const int id_e = row_g == 0 ? ev.x : (row_g == 1 ? ev.y : (row_g == 2 ? ev.z : ev.w));
+          if (OUT == 1) {
+            tuples[(size_t)(unsigned)id_e * kRecFloats + row_c] = sum;
+            if (row_c == 0) flags[(unsigned)id_e] = 1;
+          } else {
+            if (sum != 0.f) atomic_add_f32(v_records + (size_t)(unsigned)id_e * kRecFloats + row_c, sum);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (b <= b_last) break;
+      b -= 4;
+    }
+  }
+  if (STATE) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int y = py0 + k;
+      if (px < prm.W && y < prm.H) {
+        const BwdPair& q = pp[k >> 1];
+        const float vr = (k & 1) ? q.vr.y : q.vr.x, vg = (k & 1) ? q.vg.y : q.vg.x, vb = (k & 1) ? q.vb.y : q.vb.x;
+        size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
+        const float Tfin = out_T[pix];
+        const float va_out = v_alpha ? v_alpha[pix] : 0.f;
+        const float va = Tfin * (va_out - (bgr * vr + bgg * vg + bgb * vb));
+        bwd_T[pix] = (k & 1) ? q.T.y : q.T.x;
+        bwd_B[pix] = ((k & 1) ? q.Dv.y : q.Dv.x) + va;       // behind-colour . v_out
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Segmented sum of the gradient tuples of one depth slice.  The tuples of slice Gaussian j occupy
 // [cum[j], cum[j]+counts[j]) (emission order); flags mark the entries the backward actually touched.
 // A wave owns 64 Gaussians: short segments are summed by their own lane, long ones (near Gaussians
@@ -443,18 +666,23 @@ using namespace gs;
 
 // Replaces _C.rasterize_backward: one pass over complete tile lists.  v_records must be
 // zeroed by the caller; gradients are accumulated with fp32 atomics (the gsplat-compatible op has no
-// emission-order index to build tuples from).
+// emission-order index to build tuples from).  n_records > 0: scalar-cache kernel (sorted_vals padded by 8 ints).
 GS_EXPORT int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* tile_bins,
                                const int* band_edges, const float* background, int S, int R, int H, int W,
                                const float* out_T, const int* final_idx, const float* v_img, const float* v_alpha,
-                               float* v_records, void* stream) {
+                               float* v_records, int n_records, int variant, void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
-  hipLaunchKernelGGL((raster_bwd_kernel_v2<false, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T,
-                     final_idx, v_img, v_alpha, v_records, blocks, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                     (unsigned char*)nullptr);
+  if (n_records > 0 && variant == 0)
+    hipLaunchKernelGGL((raster_bwd_sload_kernel<false, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm,
+                       sorted_vals, sorted_vals, records, (unsigned)(n_records - 1), out_T, final_idx, v_img, v_alpha,
+                       v_records, blocks, (float*)nullptr, (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr);
+  else
+    hipLaunchKernelGGL((raster_bwd_kernel_v2<false, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T,
+                       final_idx, v_img, v_alpha, v_records, blocks, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       (unsigned char*)nullptr);
   return gs_launch_status();
 }
 
@@ -464,7 +692,8 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
                                      const int* band_edges, const float* background, int S, int R, int H, int W,
                                      const float* out_T, const int* final_idx, const float* v_img,
                                      const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records,
-                                     const int* gi_of_e, float* tuples, unsigned char* flags, int variant,
+                                     const int* gi_of_e, float* tuples, unsigned char* flags,
+                                     const int* sorted_ids, int n_records, int variant,
                                      const float* cmb_scale, float cmb_gamma, float cmb_min_level,
                                      void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
@@ -474,16 +703,34 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
-  (void)variant;               // reserved
-  if (tuples && flags && gi_of_e) {
+  const bool tup = tuples && flags && gi_of_e;
+  if (!tup && (!bwd_T || !bwd_B)) return GS_ERR_INVALID;
+  // scalar-cache kernels: record index per sorted entry = sorted_ids, or sorted_vals itself when it holds Gaussian ids
+  const int* ids = sorted_ids ? sorted_ids : (gi_of_e ? nullptr : sorted_vals);
+  const unsigned max_id = (unsigned)(n_records > 0 ? n_records - 1 : 0);
+  if (variant == 0 && n_records > 0 && ids) {
+    if (tup) {
+      if (bwd_T && bwd_B)
+        hipLaunchKernelGGL((raster_bwd_sload_kernel<true, 1>), dim3(blocks), dim3(256), 0, st, prm, ids, sorted_vals,
+                           records, max_id, out_T, final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B, tuples,
+                           flags);
+      else          // the only slice: no reverse-traversal state to load or store
+        hipLaunchKernelGGL((raster_bwd_sload_kernel<false, 1>), dim3(blocks), dim3(256), 0, st, prm, ids, sorted_vals,
+                           records, max_id, out_T, final_idx, v_img, v_alpha, v_records, blocks, (float*)nullptr,
+                           (float*)nullptr, tuples, flags);
+    } else {
+      hipLaunchKernelGGL((raster_bwd_sload_kernel<true, 0>), dim3(blocks), dim3(256), 0, st, prm, ids, ids, records,
+                         max_id, out_T, final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);
+    }
+    return gs_launch_status();
+  }
+  if (tup) {
     if (bwd_T && bwd_B)
       hipLaunchKernelGGL((raster_bwd_kernel_v2<true, 1>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx,
                          v_img, v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);
-    else          // the only slice: no reverse-traversal state to load or store
+    else
       hipLaunchKernelGGL((raster_bwd_kernel_v2<false, 1>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx,
                          v_img, v_alpha, v_records, blocks, (float*)nullptr, (float*)nullptr, tuples, flags);
-  } else if (!bwd_T || !bwd_B) {
-    return GS_ERR_INVALID;
   } else {
     hipLaunchKernelGGL((raster_bwd_kernel_v2<true, 0>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx, v_img,
                        v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);

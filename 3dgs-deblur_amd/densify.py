@@ -49,6 +49,7 @@ class DensifyConfig:
     split_screen_size: float = 0.05
     stop_screen_size_at: int = 4000
     stop_split_at: int = 15000
+    num_train_data: int = 0                 # training images per pass (upstream's post-reset guard)
     seed: int = 0
 
 
@@ -131,23 +132,38 @@ def reset_opacities(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.op
 @torch.no_grad()
 def refine(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.Optimizer], state: DensifyState,
            step: int, cfg: DensifyConfig) -> Dict[str, int]:
-    """One refinement (split / duplicate / cull).  Returns the counts and leaves `state` reset for the new N."""
+    """One refinement (split / duplicate / cull) with nerfstudio v1.1.0 splatfacto's `refinement_after` rules
+    (recollected, SURVEY ⚠R):
+
+      * densify only while ``step < stop_split_at`` AND every training image has been seen since the last
+        opacity reset: ``step % reset_interval > num_train_data + refine_every``;
+      * ``splits = (big | on-screen-large [before stop_screen_size_at]) & high_grads``, ``dups = ~big & high_grads``
+        (a small Gaussian that is large on screen is split AND duplicated, as upstream);
+      * the cull runs over [old rows | split children | duplicates] — a child or duplicate that is itself
+        transparent or over-sized goes at once — and only when densification ran, or after ``stop_split_at``
+        with ``continue_cull_post_densification``; between an opacity reset and the next full pass over the
+        training images nothing is pruned.
+
+    Returns the counts and leaves `state` reset for the new N."""
     dev = model.means.device
     N = model.num_points
     names = list(model.gauss_params().keys())
     W, H = state.size
-    do_densify = step < cfg.stop_split_at
-    n_split = n_dup = 0
+    reset_interval = cfg.refine_every * cfg.reset_alpha_every
+    do_densify = step < cfg.stop_split_at and step % reset_interval > cfg.num_train_data + cfg.refine_every
+    do_cull = do_densify or (step >= cfg.stop_split_at and cfg.continue_cull_post_densification)
+    n_split = n_dup = n_new = 0
     split_mask = torch.zeros(N, dtype=torch.bool, device=dev)
     extra: Dict[str, Tensor] = {}
     if do_densify:
         avg_grad = state.xys_grad_norm / torch.clamp(state.vis_counts, min=1.0) * 0.5 * float(max(W, H))
         high = avg_grad > cfg.densify_grad_thresh
         big = torch.exp(model.scales).max(dim=-1).values > cfg.densify_size_thresh
-        split_mask = high & big
+        split_mask = big.clone()
         if step < cfg.stop_screen_size_at:
             split_mask |= state.max_2Dsize > cfg.split_screen_size
-        dup_mask = high & ~big & ~split_mask
+        split_mask &= high
+        dup_mask = high & ~big
         n_split, n_dup = int(split_mask.sum()), int(dup_mask.sum())
         k = cfg.n_split_samples
         # children of the split Gaussians: positions sampled inside the parent, scales / 1.6
@@ -165,30 +181,37 @@ def refine(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.Optim
             elif name == "scales":
                 rep = torch.log(torch.exp(src_split) / 1.6).repeat(k, 1)
             extra[name] = torch.cat([rep, p[dup_mask]])
-    n_new = k * n_split + n_dup if do_densify else 0
+        n_new = k * n_split + n_dup
 
-    # cull over [old rows | new rows]: split parents always go; new rows are never culled in this pass
-    opac = torch.sigmoid(model.opacities).reshape(-1)
-    cull_old = opac < cfg.cull_alpha_thresh
-    n_low = int(cull_old.sum())
-    n_big = 0
-    do_cull = do_densify or cfg.continue_cull_post_densification
-    if not do_cull:
-        cull_old = torch.zeros_like(cull_old)
-        n_low = 0
-    elif step > cfg.refine_every * cfg.reset_alpha_every:
-        too_big = torch.exp(model.scales).max(dim=-1).values > cfg.cull_scale_thresh
-        if step < cfg.stop_screen_size_at:
-            too_big |= state.max_2Dsize > cfg.cull_screen_size
-        n_big = int((too_big & ~cull_old).sum())
-        cull_old |= too_big
-    keep_old = ~(cull_old | split_mask)
-    for name in names:
-        p = getattr(model, name)
-        new_value = p.data[keep_old]
+    # cull over [old rows | new rows]; split parents always go
+    n_low = n_big = 0
+    cull_all = torch.zeros(N + n_new, dtype=torch.bool, device=dev)
+    if do_cull:
+        opac_all = model.opacities.data
+        scales_all = model.scales.data
         if n_new:
-            new_value = torch.cat([new_value, extra[name]])
-        _swap_parameter(model, optimizers, name, new_value, keep_old, n_new)
+            opac_all = torch.cat([opac_all, extra["opacities"]])
+            scales_all = torch.cat([scales_all, extra["scales"]])
+        cull_all = torch.sigmoid(opac_all).reshape(-1) < cfg.cull_alpha_thresh
+        n_low = int(cull_all.sum())
+        cull_all[:N] |= split_mask
+        if step > reset_interval:
+            too_big = torch.exp(scales_all).max(dim=-1).values > cfg.cull_scale_thresh
+            if step < cfg.stop_screen_size_at:
+                size2d = torch.cat([state.max_2Dsize, state.max_2Dsize.new_zeros(n_new)])   # new rows: not seen yet
+                too_big |= size2d > cfg.cull_screen_size
+            n_big = int((too_big & ~cull_all).sum())
+            cull_all |= too_big
+    keep_all = ~cull_all
+    keep_old, keep_new = keep_all[:N], keep_all[N:]
+    n_kept_new = int(keep_new.sum()) if n_new else 0
+    if do_cull or n_new:
+        for name in names:
+            p = getattr(model, name)
+            new_value = p.data[keep_old]
+            if n_kept_new:
+                new_value = torch.cat([new_value, extra[name][keep_new]])
+            _swap_parameter(model, optimizers, name, new_value, keep_old, n_kept_new)
     n_after = model.num_points
     fresh = DensifyState(n_after, dev)
     fresh.size = state.size

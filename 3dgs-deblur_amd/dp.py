@@ -58,9 +58,10 @@ def allreduce_gradients(params: Iterable[torch.Tensor], group: Optional[dist.Pro
                       (SURVEY.md §5 estimates ~6x less time than the ring at 2M Gaussians).
     mode="sparse":    early termination leaves all but a few percent of the Gaussians without any
                       gradient for a given view, so each rank all-gathers only its non-zero gradient
-                      ROWS (index + 59 floats) and every rank scatter-adds the union: ~13 MB per rank
-                      instead of a 236 MB dense bucket at 1M Gaussians.  Falls back to the dense
-                      all-reduce (same decision on every rank) when the rows are not sparse.
+                      ROWS (index + 59 floats, fixed-capacity payload, counts stay on the device — no host
+                      synchronisation inside the step, see SparseExchangeState) and every rank scatter-adds
+                      the union in rank order.  Falls back to the dense all-reduce (same decision on every
+                      rank, taken from the previous steps' counts) when the rows are not sparse.
     """
     params = [p for p in params if p.requires_grad]
     if not params or not dist.is_available() or not dist.is_initialized():
@@ -145,6 +146,41 @@ class _RowOps:
             pay[:M, self.wtot] = idx.to(torch.int32).view(torch.float32)
         return pay
 
+    def pack_masked(self, cap: int) -> torch.Tensor:
+        """[(cap + 1), wtot + 1] payload of the (at most cap) rows that hold a gradient; row 0 is the header
+        {rows with a gradient, rows packed} as int32 bit patterns.  No host synchronisation on the GPU path."""
+        stride = self.wtot + 1
+        mask = self.row_mask()
+        pay = torch.zeros(cap + 1, stride, dtype=torch.float32, device=self.dev)
+        if self.hip:
+            m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+            pos = torch.cumsum(m8, 0, dtype=torch.int32) - m8.to(torch.int32)
+            idx_ws = torch.empty(cap, dtype=torch.int32, device=self.dev)
+            self._check(self._L.gs_dp_pack_masked_rows(self.N, self._vp(m8.data_ptr()), self._vp(pos.data_ptr()), cap,
+                                                       self._vp(idx_ws.data_ptr()), len(self.grads), self._ptrs, self._w,
+                                                       self._vp(pay.data_ptr()), self._stream), "dp_pack_masked_rows")
+            return pay
+        idx = mask.nonzero(as_tuple=False).reshape(-1)
+        total = idx.numel()
+        idx = idx[:cap]
+        M = idx.numel()
+        hdr = torch.tensor([total, M], dtype=torch.int32).view(torch.float32)
+        pay[0, :2] = hdr
+        if M:
+            pay[1:1 + M, :self.wtot] = torch.cat([g.reshape(self.N, -1)[idx] for g in self.grads], dim=1)
+            pay[1:1 + M, self.wtot] = idx.to(torch.int32).view(torch.float32)
+        return pay
+
+    def scatter_add_payload(self, payload: torch.Tensor, cap: int, scale: float) -> None:
+        """grads[row] += scale * row for the rows of a pack_masked payload (count read from its header)"""
+        if self.hip:
+            payload = payload.contiguous()
+            self._check(self._L.gs_dp_scatter_add_payload(cap, self._vp(payload.data_ptr()), len(self.grads), self._ptrs,
+                                                          self._w, float(scale), self._stream), "dp_scatter_add_payload")
+            return
+        M = int(payload[0, 1].view(torch.int32))
+        self.scatter_add(payload[1:], M, scale)
+
     def scatter_add(self, payload: torch.Tensor, M: int, scale: float) -> None:
         """grads[row] += scale * payload[:M]; the M row indices of one payload are unique."""
         if M == 0:
@@ -160,33 +196,105 @@ class _RowOps:
             off += w
 
 
-def _allreduce_sparse_rows(params: Sequence[torch.Tensor], group, world: int, average: bool,
-                           dense_threshold: float = 0.25) -> bool:
-    """Row-sparse gradient exchange.  All params must share the leading (per-Gaussian) dimension.
-    Returns False (nothing changed) when the caller should use the dense path instead."""
+class SparseExchangeState:
+    """Capacity bookkeeping of the sync-free row-sparse exchange.
+
+    Nothing about the number of touched rows is read back inside the step: every rank packs at most `cap` rows
+    into a fixed-size payload whose header carries the true count, ONE all_gather_into_tensor moves the payloads, and
+    the scatter-add kernels read the counts from the device.  The headers of step t are copied to pinned host memory
+    asynchronously and looked at when step t+1 starts (that copy finished a whole step earlier, so waiting for it
+    does not drain the queue); every rank sees the same gathered headers, hence takes the same decisions:
+      * any count above the capacity that was used  -> the step's gradients were truncated: RuntimeError (strict),
+      * the capacity for the next steps = 2 x the largest count seen recently, rounded up to a power of two,
+      * counts so large that a dense all-reduce moves fewer bytes -> `dense` until the counts fall again.
+    The first step (no history) uses the largest sparse capacity, N * dense_fraction / world."""
+
+    def __init__(self, N: int, world: int, cap_min: int = 1024, dense_fraction: float = 0.25):
+        self.N, self.world = N, world
+        self.cap_max = max(1, int(N * dense_fraction / max(1, world)))
+        self.cap_min = min(cap_min, self.cap_max)
+        self.cap = self.cap_max
+        self.dense = False
+        self.pending = None          # (host tensor, event or None, capacity used)
+        self.history = []
+
+    def settle(self) -> None:
+        """Digest the counts of the previous exchange (blocks only if that exchange has not finished yet)."""
+        if self.pending is None:
+            return
+        host, ev, cap_used = self.pending
+        self.pending = None
+        if ev is not None:
+            ev.synchronize()
+        totals = [int(v) for v in host.tolist()]
+        if cap_used is not None and max(totals) > cap_used:
+            raise RuntimeError(f"row-sparse gradient exchange overflowed: a rank had {max(totals)} rows with a gradient, "
+                               f"capacity was {cap_used}; the previous step's gradients are incomplete "
+                               f"(raise cap_min / dense_fraction or use mode='allreduce')")
+        self.history = (self.history + [max(totals)])[-8:]
+        want = 2 * max(self.history)
+        if want > self.cap_max:
+            self.dense = True
+        else:
+            self.dense = False
+            cap = self.cap_min
+            while cap < want:
+                cap *= 2
+            self.cap = min(cap, self.cap_max)
+
+
+_SPARSE_STATES = {}
+
+
+def _sparse_state(N: int, world: int, group) -> SparseExchangeState:
+    key = (N, world, id(group))
+    st = _SPARSE_STATES.get(key)
+    if st is None:
+        st = _SPARSE_STATES[key] = SparseExchangeState(N, world)
+    return st
+
+
+def reset_sparse_exchange_state() -> None:
+    _SPARSE_STATES.clear()
+
+
+def _allreduce_sparse_rows(params: Sequence[torch.Tensor], group, world: int, average: bool) -> bool:
+    """Row-sparse gradient exchange, no host synchronisation inside the step.  All params must share the leading
+    (per-Gaussian) dimension.  Returns False (nothing changed) when the caller should use the dense path."""
     N = params[0].shape[0]
     if N == 0 or any(p.shape[0] != N for p in params):
         return False
+    st = _sparse_state(N, world, group)
+    st.settle()
     for p in params:            # a rank without a gradient for some tensor contributes zeros
         if p.grad is None:
             p.grad = torch.zeros_like(p)
         elif not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
             p.grad = p.grad.contiguous().float()
     ops = _RowOps([p.grad for p in params])
-    idx = ops.row_mask().nonzero(as_tuple=False).reshape(-1)
-    m_local = torch.tensor([idx.numel()], dtype=torch.int64, device=ops.dev)
-    counts_t = [torch.empty_like(m_local) for _ in range(world)]
-    dist.all_gather(counts_t, m_local, group=group)
-    counts = [int(c) for c in torch.stack(counts_t).reshape(-1).cpu()]
-    Mmax = max(counts)
-    if Mmax * world > dense_threshold * N:        # identical on every rank: the counts are global
+    stride = ops.wtot + 1
+    if not st.history:
+        # very first exchange for this (N, world): no counts to size the payload from — ONE synchronous look at
+        # them (every later step is sync-free)
+        total = ops.row_mask().sum(dtype=torch.int32).reshape(1)
+        totals = torch.empty(world, dtype=torch.int32, device=ops.dev)
+        dist.all_gather_into_tensor(totals, total, group=group)
+        st.pending = (totals.cpu(), None, None)
+        st.settle()
+    if st.dense:
+        # too many rows for the sparse form to pay: the caller runs the dense all-reduce; keep watching the counts
+        # (one tiny all_gather) so that the exchange can return to the sparse form
+        total = ops.row_mask().sum(dtype=torch.int32).reshape(1)
+        totals = torch.empty(world, dtype=torch.int32, device=ops.dev)
+        dist.all_gather_into_tensor(totals, total, group=group)
+        st.pending = _async_to_host(totals) + (None,)
         return False
-    if Mmax == 0:
-        return True
-    # one collective: a payload row = the 59 gradient floats + the row index as a float32 bit pattern
-    pay = ops.pack(idx, Mmax)
-    pay_all = [torch.empty_like(pay) for _ in range(world)]
-    dist.all_gather(pay_all, pay, group=group)
+    cap = st.cap
+    pay = ops.pack_masked(cap)                                   # [(cap + 1), stride], header in row 0
+    pay_all = torch.empty(world * (cap + 1) * stride, dtype=torch.float32, device=ops.dev)
+    dist.all_gather_into_tensor(pay_all, pay.reshape(-1), group=group)
+    pay_all = pay_all.view(world, cap + 1, stride)
+    st.pending = _async_to_host(pay_all[:, 0, 0].contiguous().view(torch.int32)) + (cap,)
     # Replicas must stay BIT-identical, so the sum has one fixed order on every rank: start from zero, add
     # rank 0's rows, then rank 1's, ...  A rank's row indices are unique, so no add collides (a single
     # scatter-add over the concatenation would add in atomic, i.e. arbitrary, order).
@@ -194,5 +302,37 @@ def _allreduce_sparse_rows(params: Sequence[torch.Tensor], group, world: int, av
         p.grad.zero_()
     scale = 1.0 / world if average else 1.0
     for r in range(world):
-        ops.scatter_add(pay_all[r], counts[r], scale)
+        ops.scatter_add_payload(pay_all[r], cap, scale)
     return True
+
+
+def _async_to_host(t: torch.Tensor):
+    """-> (host tensor, event or None): non-blocking device-to-host copy of a small tensor"""
+    if t.device.type != "cuda":
+        return t.clone(), None
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return host, ev
+
+
+def allreduce_dense_(tensors: Sequence[torch.Tensor], group: Optional[dist.ProcessGroup] = None,
+                     average: bool = False) -> None:
+    """In-place sum (or mean) of a few small tensors over the ranks through ONE flat bucket: the gradients of the
+    parameters that are not per-Gaussian rows (learnable background, pose and velocity adjustments)."""
+    tensors = [t for t in tensors if t is not None]
+    if not tensors or not dist.is_available() or not dist.is_initialized():
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    flat = torch.cat([t.reshape(-1).float() for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat.div_(world)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n

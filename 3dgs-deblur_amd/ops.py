@@ -124,6 +124,14 @@ def _tiles(h: int, w: int) -> Tuple[int, int]:
     return (w + TILE - 1) // TILE, (h + TILE - 1) // TILE
 
 
+IDS_PAD = 8   # the scalar-cache compositors read their tile lists in aligned groups of four: id arrays are over-allocated
+
+
+def _padded_i32(n: int, dev) -> Tensor:
+    """int32 [n] view of an [n + IDS_PAD] allocation (the tail only has to be readable, its values are clamped)"""
+    return torch.empty(n + IDS_PAD, dtype=torch.int32, device=dev)[:n]
+
+
 def _bits(n: int) -> int:
     return max(1, int(math.ceil(math.log2(max(2, n)))))
 
@@ -166,7 +174,7 @@ def radix_sort_pairs(keys: Tensor, vals: Optional[Tensor], begin_bit: int, end_b
     n = keys.numel()
     dev = keys.device
     if vals is None:
-        v0 = torch.empty(n, dtype=torch.int32, device=dev)
+        v0 = _padded_i32(n, dev)
         iota = 1
     else:
         assert vals.dtype == torch.int32 and vals.is_contiguous() and vals.numel() == n
@@ -174,7 +182,7 @@ def radix_sort_pairs(keys: Tensor, vals: Optional[Tensor], begin_bit: int, end_b
     if n == 0:
         return keys, v0
     k1 = torch.empty_like(keys)
-    v1 = torch.empty_like(v0)
+    v1 = _padded_i32(n, dev)
     L = _L()
     ws_bytes = L.gs_radix_sort_workspace_bytes(n, begin_bit, end_bit)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -220,7 +228,7 @@ def bin_and_sort_records(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
         raise OverflowError("more than 2^31-1 tile intersections; chunk the sub-poses")
     with _stage("emit"):
         keys = torch.empty(n_isect, dtype=torch.int32, device=dev)
-        vals = torch.empty(n_isect, dtype=torch.int32, device=dev)
+        vals = _padded_i32(n_isect, dev)
         _check(L.gs_emit_intersects(n, N, img_height, img_width, _ptr(sorted_gi), _ptr(cum), _ptr(records), n_isect,
                                     _ptr(keys), _ptr(vals), 0, _stream()), "emit intersects")
     with _stage("tile_sort"):
@@ -369,7 +377,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         first, last = k == 0, k == K - 1
         n_k = n_slices[k]
         I_k = 0
-        svals = bins = None
+        svals = bins = sorted_ids = None
         if n_k > 0:
             with _stage("slice_count"):
                 slice_gi = torch.empty(n_k, dtype=torch.int32, device=dev)
@@ -423,7 +431,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         if I_k > 0:
             with _stage("emit"):
                 keys = torch.empty(I_k, dtype=torch.int32, device=dev)
-                vals = torch.empty(I_k, dtype=torch.int32, device=dev)
+                vals = _padded_i32(I_k, dev)
                 if first and not holes0 and not compact:
                     _check(L.gs_emit_intersects(n_k, N, H, W, _ptr(slice_gi), _ptr(cum_k), _ptr(records), I_k,
                                                 _ptr(keys), _ptr(vals), invalid_key, _stream()), "emit intersects")
@@ -442,7 +450,13 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                     skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T + 1))
             with _stage("bin_edges"):
                 bins = torch.empty(P * T + 1, 2, dtype=torch.int32, device=dev)   # last row: culled pairs
-                _check(L.gs_tile_bin_edges_u32(I_k, _ptr(skeys), P * T + 1, _ptr(bins), _stream()), "bin edges")
+                if use_tuples:
+                    # + the record index of every sorted entry (the sort carried emission indices)
+                    sorted_ids = torch.empty(I_k + IDS_PAD, dtype=torch.int32, device=dev)
+                    _check(L.gs_tile_bin_edges_ids_u32(I_k, _ptr(skeys), P * T + 1, _ptr(bins), _ptr(svals), _ptr(vals),
+                                                       _ptr(sorted_ids), _stream()), "bin edges + ids")
+                else:
+                    _check(L.gs_tile_bin_edges_u32(I_k, _ptr(skeys), P * T + 1, _ptr(bins), _stream()), "bin edges")
         last_slice_intersects.append(I_k)
         if I_k == 0 and not (first or last):
             continue
@@ -454,10 +468,11 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
             _check(L.gs_rasterize_fwd_slice(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
                                             _ptr(out_img), _ptr(out_T), _ptr(live_T), _ptr(fidx), _ptr(tile_done),
                                             int(first), int(last), _ptr(vals) if (use_tuples and I_k > 0) else None,
-                                            RASTER_FWD_VARIANT, _stream()), "rasterize_fwd_slice")
+                                            _ptr(sorted_ids), P * N if I_k > 0 else 0, RASTER_FWD_VARIANT, _stream()),
+                   "rasterize_fwd_slice")
         if I_k > 0:
             slices.append(dict(svals=svals, bins=bins, fidx=fidx, I=I_k, gi_of_e=vals if use_tuples else None,
-                               slice_gi=slice_gi, counts=counts, cum=cum_k, n=n_k))
+                               sorted_ids=sorted_ids, slice_gi=slice_gi, counts=counts, cum=cum_k, n=n_k))
         if not last:
             with _stage("slice_sat"):
                 _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _stream()), "tile_open_sat")
@@ -488,8 +503,8 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
             _check(L.gs_rasterize_bwd_slice(_ptr(records), _ptr(sl["svals"]), _ptr(sl["bins"]), _ptr(edges), _ptr(bg),
                                             S, R, H, W, _ptr(out_T), _ptr(sl["fidx"]), _ptr(v_img), _ptr(v_alpha),
                                             _ptr(bwd_T), _ptr(bwd_B), _ptr(v_records), _ptr(sl["gi_of_e"]),
-                                            _ptr(tuples), _ptr(flags), RASTER_BWD_VARIANT, _ptr(cmb[0]), cmb[1], cmb[2],
-                                            _stream()),
+                                            _ptr(tuples), _ptr(flags), _ptr(sl["sorted_ids"]), records.shape[0],
+                                            RASTER_BWD_VARIANT, _ptr(cmb[0]), cmb[1], cmb[2], _stream()),
                    "rasterize_bwd_slice")
         if tuples is not None:
             with _stage("grad_reduce"):
@@ -619,8 +634,8 @@ class _RasterizeGaussians(Function):
         out_T = torch.empty(1, H, W, device=dev)
         fidx = torch.empty(1, H, W, dtype=torch.int32, device=dev)
         _check(L.gs_rasterize_fwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), 1, 1, H, W,
-                                  _ptr(out_img), _ptr(out_T), _ptr(fidx), RASTER_FWD_VARIANT, _stream()),
-               "rasterize_fwd")
+                                  _ptr(out_img), _ptr(out_T), _ptr(fidx), N if n_isect > 0 else 0, RASTER_FWD_VARIANT,
+                                  _stream()), "rasterize_fwd")
         ctx.save_for_backward(records, svals, bins, edges, bg, out_T, fidx)
         ctx.dims = (N, H, W)
         ctx.bg_grad = background is not None and ctx.needs_input_grad[10]
@@ -639,8 +654,8 @@ class _RasterizeGaussians(Function):
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
         v_records = torch.zeros(N, REC, device=dev)
         _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), 1, 1, H, W,
-                                  _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records), _stream()),
-               "rasterize_bwd")
+                                  _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records), N, RASTER_BWD_VARIANT,
+                                  _stream()), "rasterize_bwd")
         v_xys = torch.empty(N, 2, device=dev)
         v_conics = torch.empty(N, 3, device=dev)
         v_colors = torch.empty(N, 3, device=dev)
@@ -868,8 +883,8 @@ class _RenderSubposes(Function):
         else:
             with _stage("raster_bwd"):
                 _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
-                                          _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records),
-                                          _stream()), "rasterize_bwd")
+                                          _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records), 0,
+                                          RASTER_BWD_VARIANT, _stream()), "rasterize_bwd")
         # the five dense gradient outputs are carved out of ONE buffer: with touched flags the kernel skips
         # untouched Gaussians, so the buffer is zero-filled (one fill instead of five)
         # (filling on a second stream under the VALU-bound compositor backward was measured: 3.10 vs 3.02 ms —

@@ -84,6 +84,14 @@ def train_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.O
     if allreduce is not None:
         from . import dp
         dp.allreduce_gradients(list(model.gauss_params().values()), mode=allreduce, average=True)
+        # the parameters that are not per-Gaussian rows (learnable background, pose / velocity adjustments) see
+        # only this rank's views too: one small dense bucket, or the replicas drift apart silently
+        small = [p for p in (model.background_param, model.pose_adjustment, model.velocity_adjustment)
+                 if p is not None]
+        for p in small:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        dp.allreduce_dense_([p.grad for p in small], average=True)
     for o in optimizers.values():
         o.step()
     return {"loss": float(loss.item()), "psnr": psnr(out["rgb"].detach(), gt_image)}

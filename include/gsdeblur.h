@@ -145,6 +145,11 @@ int gs_tile_bin_edges_u32(long long n, const unsigned* sorted_keys, int num_bins
                           void* stream);
 int gs_tile_bin_edges_u64(long long n, const unsigned long long* sorted_isect_ids, int num_bins,
                           int* bins /*num_bins*2*/, void* stream);
+/* gs_tile_bin_edges_u32 fused with the gather ids_out[i] = gi_of_e[sorted_vals[i]] (i < n), ids_out[n..n+8) = 0:
+ * the record index of every sorted entry of a depth slice, read by the compositors through the scalar cache */
+int gs_tile_bin_edges_ids_u32(long long n, const unsigned* sorted_keys, int num_bins, int* bins /*num_bins*2*/,
+                              const unsigned* sorted_vals, const unsigned* gi_of_e, unsigned* ids_out /*n+8*/,
+                              void* stream);
 /* upstream-format ids: isect_id = tile<<32 | float_bits(depth); cum_tiles_hit is the INCLUSIVE cumsum */
 int gs_map_gaussian_to_intersects(int N, const float* xys, const float* depths, const int* radii,
                                   const int* cum_tiles_hit, int img_height, int img_width,
@@ -156,13 +161,19 @@ int gs_map_gaussian_to_intersects(int N, const float* xys, const float* depths, 
 int gs_rasterize_fwd(const float* records, const int* sorted_vals, const int* tile_bins,
                      const int* band_edges /*R+1*/, const float* background /*3*/, int S, int R,
                      int img_height, int img_width, float* out_img /*S*H*W*3*/, float* out_T /*S*H*W*/,
-                     int* final_idx /*S*H*W*/, int variant /*0 = default; 1 = without the empty-pair skip (A/B)*/,
+                     int* final_idx /*S*H*W*/,
+                     int n_records /*rows of `records`.  > 0 selects the scalar-cache compositor (variant 0), which
+                                     reads sorted_vals in aligned groups of four: the array must then have 8 readable
+                                     ints past its last entry (values are clamped to n_records-1, never blended)*/,
+                     int variant /*0 = default; 1, 2 = the v_readlane compositor without / with the empty-pair skip (A/B)*/,
                      void* stream);
 /* v_records [P*N*12] is accumulated into with fp32 atomics (caller zeroes); v_alpha may be NULL. */
 int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* tile_bins,
                      const int* band_edges, const float* background, int S, int R, int img_height,
                      int img_width, const float* out_T, const int* final_idx, const float* v_img,
-                     const float* v_alpha, float* v_records, void* stream);
+                     const float* v_alpha, float* v_records,
+                     int n_records /*as in gs_rasterize_fwd: > 0 selects the scalar-cache kernel (padded sorted_vals)*/,
+                     int variant /*0 = default; other = the v_readlane kernel of round 1 (A/B)*/, void* stream);
 
 /* ---- depth-sliced variant of the same path (MI355X design, no upstream counterpart) ----------
  * With early termination only a few percent of the (Gaussian, tile) intersections are ever
@@ -213,7 +224,12 @@ int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const i
                            unsigned char* tile_done, int first, int last,
                            const int* gi_of_e /*NULL: sorted_vals are Gaussian ids; else sorted_vals are emission
                                                 indices e and the Gaussian id is gi_of_e[e]*/,
-                           int variant /*0 = default (skips pairs that touch no pixel); 1 = no skip*/, void* stream);
+                           const int* sorted_ids /*[I+8] record index of every sorted entry (gs_tile_bin_edges_ids_u32),
+                                                   or NULL: taken from sorted_vals when gi_of_e is NULL (padded as in
+                                                   gs_rasterize_fwd), else the v_readlane compositor runs*/,
+                           int n_records /*rows of `records`; <= 0 forces the v_readlane compositor*/,
+                           int variant /*0 = default; 1, 2 = v_readlane compositor without / with the empty-pair skip*/,
+                           void* stream);
 /* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B [S,H,W] (behind-colour . v_out, init = 0)
  * carry the reverse-traversal state; both may be NULL on the tuple path when the frame has a single slice */
 int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
@@ -222,7 +238,8 @@ int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const i
                            const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records,
                            const int* gi_of_e /*as in the forward*/,
                            float* tuples /*[I*12] or NULL*/, unsigned char* flags /*[I], zeroed, or NULL*/,
-                           int variant /*reserved, pass 0*/,
+                           const int* sorted_ids /*as in gs_rasterize_fwd_slice*/, int n_records,
+                           int variant /*0 = default (scalar-cache kernel when ids are available); other = round-1 kernel*/,
                            const float* cmb_scale /*[H,W,3] or NULL.  Non-NULL folds gs_combine_bwd into this launch:
                                                     v_img then holds the SAMPLE IMAGES [S,H,W,3] and each pixel derives
                                                     its sample gradient from cmb_scale (gs_combine_bwd_scale)*/,
@@ -262,6 +279,13 @@ int gs_dp_pack_rows(long long M, const long long* row_idx /*M, device, int64*/, 
  * (no atomics).  Apply the ranks' payloads in rank order for a bit-identical sum on every rank. */
 int gs_dp_scatter_add_rows(long long M, const float* payload, int n_tensors, float* const* grads,
                            const int* widths, float scale, void* stream);
+/* Fixed-capacity, sync-free form of the same exchange (no row count ever reaches the host): payload is
+ * [(cap+1)*(wtot+1)] floats, row 0 a header of int bit patterns {rows with a gradient on the sender, rows packed =
+ * min(that, cap)}, rows 1.. the packed rows.  pos = exclusive prefix sum of mask (int32 [N]); idx_ws: cap ints. */
+int gs_dp_pack_masked_rows(int N, const unsigned char* mask, const int* pos, int cap, int* idx_ws, int n_tensors,
+                           float* const* grads, const int* widths, float* payload, void* stream);
+int gs_dp_scatter_add_payload(int cap, const float* payload, int n_tensors, float* const* grads, const int* widths,
+                              float scale, void* stream);
 
 #ifdef __cplusplus
 }

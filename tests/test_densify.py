@@ -56,7 +56,7 @@ def test_refine_split_duplicate_cull_and_adam_state(gs):
         model.scales[0] = math.log(0.05)        # big + high gradient  -> split
         model.scales[1] = math.log(0.05)        # big, low gradient    -> kept
         model.opacities[4] = -5.0               # transparent          -> culled
-        model.opacities[2] = -5.0               # high gradient AND transparent: duplicated, original culled
+        model.opacities[2] = -5.0               # high gradient AND transparent: duplicated, both copies culled
     st = gs.densify.DensifyState(n, "cpu")
     st.size = (100, 100)
     st.vis_counts += 2
@@ -64,28 +64,80 @@ def test_refine_split_duplicate_cull_and_adam_state(gs):
     old = {k: v.detach().clone() for k, v in model.gauss_params().items()}
     old_m = {k: opts[k].state[p]["exp_avg"].clone() for k, p in model.gauss_params().items()}
     res = gs.densify.refine(model, opts, st, step=600, cfg=cfg)
-    assert res == {"split": 1, "duplicated": 2, "culled_low_opacity": 2, "culled_too_big": 0, "before": 10, "after": 11}
-    assert model.num_points == 11 and st.vis_counts.shape == (11,) and float(st.vis_counts.sum()) == 0
+    # upstream culls over [old | children | duplicates]: the duplicate of the transparent Gaussian 2 goes with it
+    assert res == {"split": 1, "duplicated": 2, "culled_low_opacity": 3, "culled_too_big": 0, "before": 10, "after": 10}
+    assert model.num_points == 10 and st.vis_counts.shape == (10,) and float(st.vis_counts.sum()) == 0
     keep = [1, 3, 5, 6, 7, 8, 9]                # 0 split away, 2 and 4 culled
     for k, p in model.gauss_params().items():
-        assert p.shape[0] == 11 and p.requires_grad
+        assert p.shape[0] == 10 and p.requires_grad
         assert torch.equal(p[:7], old[k][keep])
         assert opts[k].param_groups[0]["params"][0] is p
         stt = opts[k].state[p]
         assert stt["exp_avg"].shape == p.shape and stt["exp_avg_sq"].shape == p.shape
         assert torch.equal(stt["exp_avg"][:7], old_m[k][keep])               # kept rows keep their moments
         assert float(stt["exp_avg"][7:].abs().sum()) == 0                    # new rows start from zero
-    # children: 2 samples of Gaussian 0 (scales / 1.6, same quat/colour), then the duplicates of 2 and 3
+    # children: 2 samples of Gaussian 0 (scales / 1.6, same quat/colour), then the surviving duplicate (of 3)
     assert torch.allclose(model.scales[7:9], old["scales"][0].expand(2, 3) - math.log(1.6))
     assert torch.equal(model.quats[7:9], old["quats"][0].expand(2, 4))
     assert not torch.equal(model.means[7], model.means[8])
     assert (model.means[7:9] - old["means"][0]).norm(dim=-1).max() < 0.05 * 6    # inside ~6 sigma of the parent
-    assert torch.equal(model.means[9:11], old["means"][[2, 3]])
+    assert torch.equal(model.means[9:10], old["means"][[3]])
     # the optimizers still step with the new shapes
     for p in model.gauss_params().values():
         p.grad = torch.ones_like(p)
     for o in opts.values():
         o.step()
+
+
+def test_split_needs_high_gradient_and_small_large_on_screen_is_split_and_duplicated(gs):
+    """nerfstudio 1.1.0: splits = (big | large-on-screen) & high_grads; dups = ~big & high_grads.  A low-gradient
+    Gaussian that is large on screen is left alone; a small high-gradient one that is large on screen is BOTH
+    split and duplicated (the screen-size term used to bypass the gradient gate)."""
+    n = 6
+    model = _model(gs, n)
+    opts = _prime_adam(gs, model)
+    cfg = gs.densify.DensifyConfig(n_split_samples=2)
+    st = gs.densify.DensifyState(n, "cpu")
+    st.size = (100, 100)
+    st.vis_counts += 1
+    st.max_2Dsize[0] = 0.2                      # large on screen, LOW gradient: untouched before step 4000
+    st.max_2Dsize[1] = 0.2                      # large on screen, small in world space, HIGH gradient
+    st.xys_grad_norm[1] = 1.0
+    res = gs.densify.refine(model, opts, st, step=600, cfg=cfg)
+    assert res["split"] == 1 and res["duplicated"] == 1
+    assert res["after"] == n - 1 + 2 + 1        # parent 1 removed, 2 children + 1 duplicate appended
+    # after stop_screen_size_at the screen term is gone: the same Gaussian is only duplicated
+    model = _model(gs, n)
+    opts = _prime_adam(gs, model)
+    st = gs.densify.DensifyState(n, "cpu")
+    st.size = (100, 100)
+    st.vis_counts += 1
+    st.max_2Dsize[1] = 0.2
+    st.xys_grad_norm[1] = 1.0
+    res = gs.densify.refine(model, opts, st, step=4600, cfg=cfg)
+    assert res["split"] == 0 and res["duplicated"] == 1 and res["after"] == n + 1
+
+
+def test_nothing_is_pruned_between_an_opacity_reset_and_a_full_pass_over_the_training_images(gs):
+    """upstream's guard: densify / cull only when step % reset_interval > num_train_data + refine_every (every image
+    has been seen since the opacities were clamped to <= 0.2); the cull otherwise only resumes after stop_split_at."""
+    cfg = gs.densify.DensifyConfig(num_train_data=150)          # reset_interval = 3000, guard = 250
+    for step, pruned in ((3100, False), (3200, False), (3300, True), (6200, False), (6300, True)):
+        model = _model(gs, 6)
+        opts = _prime_adam(gs, model)
+        with torch.no_grad():
+            model.opacities[0] = -6.0
+        st = gs.densify.DensifyState(6, "cpu")
+        st.size = (64, 64)
+        st.vis_counts += 1
+        st.xys_grad_norm[1] = 1.0
+        res = gs.densify.refine(model, opts, st, step=step, cfg=cfg)
+        if pruned:
+            assert res["culled_low_opacity"] == 1 and res["duplicated"] == 1 and model.num_points == 6
+        else:
+            assert res == {"split": 0, "duplicated": 0, "culled_low_opacity": 0, "culled_too_big": 0, "before": 6,
+                           "after": 6}
+            assert float(st.vis_counts.sum()) == 0                # the statistics still restart
 
 
 def test_refine_is_deterministic_in_step_and_seed(gs):
@@ -106,7 +158,7 @@ def test_refine_is_deterministic_in_step_and_seed(gs):
 
 def test_cull_scale_thresh_applies_after_first_opacity_reset(gs):
     cfg = gs.densify.DensifyConfig(cull_scale_thresh=0.5)            # train.py:18 sets 2.0 for some datasets
-    for step, expect in ((600, 6), (cfg.refine_every * cfg.reset_alpha_every + 100, 5)):
+    for step, expect in ((600, 6), (cfg.refine_every * cfg.reset_alpha_every + 200, 5)):     # +100 is still inside the post-reset guard
         model = _model(gs, 6)
         opts = _prime_adam(gs, model)
         with torch.no_grad():

@@ -412,6 +412,49 @@ def test_depth_sliced_equals_single_pass(gs, oracle, dev, S, R, base):
         assert rel_max(res["sliced"][2][k].cpu(), res["single"][2][k].cpu()) < 1e-4, k
 
 
+@pytest.mark.parametrize("S,R,base,W,H,n", [(2, 2, 8, 208, 144, 6000), (1, 1, 0, 131, 77, 900), (3, 1, 512, 320, 200, 20000)])
+def test_scalar_cache_compositor_equals_readlane_compositor(gs, oracle, dev, S, R, base, W, H, n):
+    """Round 2's compositors fetch the records through the scalar cache (s_load); the forward keeps one signed
+    transmittance per pixel.  The round-1 kernels broadcast the records with v_readlane.  Forward: same arithmetic,
+    term for term — sample images, alphas AND (behind the same backward) the gradients, which depend on every
+    pixel's final index, must be bit-identical; backward: equal up to fp32 summation order.  Single- and multi-slice
+    frames, ragged image sizes, rolling-shutter bands, tuple and atomics accumulation."""
+    from gsdeblur_amd import ops
+    O = oracle
+    sc = O.synthetic_scene(n, W, H, seed=21 + S, scale_mult=7.0)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10
+    bg = torch.tensor([0.2, 0.1, 0.4])
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(9))
+    res = {}
+    old = (ops.SLICE_BASE, ops.RASTER_FWD_VARIANT, ops.RASTER_BWD_VARIANT, ops.GRAD_TUPLES)
+    try:
+        ops.SLICE_BASE = base
+        for tuples in (1, 0):
+            ops.GRAD_TUPLES = tuples        # 0: the fp32-atomics backward (order-dependent sums)
+            for fv, bv in ((0, 2), (2, 2), (0, 0)):
+                ops.RASTER_FWD_VARIANT, ops.RASTER_BWD_VARIANT = fv, bv
+                out, alpha, samples, vms, p, radii = _run_full(gs, O, dev, sc, H, W, S, R, 1 / 60, 1 / 30, 2.2, 10.0,
+                                                               3, bg, wt)
+                res[(tuples, fv, bv)] = (samples.detach().clone(), alpha.detach().clone(),
+                                         {k: v.grad.detach().clone() for k, v in p.items()})
+    finally:
+        ops.SLICE_BASE, ops.RASTER_FWD_VARIANT, ops.RASTER_BWD_VARIANT, ops.GRAD_TUPLES = old
+    for tuples in (1, 0):
+        a, b, c = res[(tuples, 0, 2)], res[(tuples, 2, 2)], res[(tuples, 0, 0)]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+        for k in a[2]:
+            # same backward kernel behind both forwards: bit-identical Gaussian gradients on the deterministic tuple
+            # path (pose / velocity gradients end in a dozen fp32 atomics per block)
+            if tuples and k not in ("viewmat", "lin_vel", "ang_vel"):
+                assert torch.equal(a[2][k], b[2][k]), k
+            else:
+                assert rel_max(a[2][k].cpu(), b[2][k].cpu()) < 1e-4, k
+            # the scalar-cache backward sums the geometric terms through three moments per lane: same values up to
+            # fp32 summation order
+            assert rel_max(c[2][k].cpu(), a[2][k].cpu()) < (2e-5 if tuples else 1e-4), k
+
+
 def test_tuple_backward_equals_atomic_backward(gs, oracle, dev):
     """The atomic-free backward (per-entry gradient tuples + segmented reduce) and the fp32-atomics backward
     compute the same sums; only the summation order differs."""

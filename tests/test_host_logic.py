@@ -93,11 +93,15 @@ def _dp_sparse_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    N = 4000
-    shapes = [(N, 3), (N, 3), (N, 4), (N, 1), (N, 3), (N, 15, 3)]
+    N = 40000
+    shapes = [(N, 3), (N, 3), (N, 4), (N, 1), (N, 3), (N, 3, 3)]
     ok = True
-    for density, expect_sparse in ((0.01, True), (0.6, False)):
-        gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]
+    log = []
+    # a training run whose density drifts: sparse steps shrink the payload capacity, a denser phase flips the
+    # exchange to the dense bucket and back — every step's sum must be exact whatever form carried it
+    for step, density in enumerate((0.01, 0.012, 0.02, 0.03, 0.05, 0.09, 0.5, 0.6, 0.02, 0.01, 0.01, 0.01, 0.01,
+                                    0.01, 0.01, 0.01, 0.01, 0.01)):
+        gens = [torch.Generator().manual_seed(100 + 17 * step + r) for r in range(world)]
         all_grads = []
         for r in range(world):
             touched = torch.rand(N, generator=gens[r]) < density
@@ -109,25 +113,105 @@ def _dp_sparse_worker(rank, world, port, q):
         if rank == 1:
             params[4].grad = None                                           # a missing grad counts as zero
         gs.dp.allreduce_gradients(params, mode="sparse")
+        st = gs.dp._sparse_state(N, world, None)
+        log.append((st.dense, st.cap))
         for i, p in enumerate(params):
             want = sum(all_grads[r][i] for r in range(world))
             ok &= bool(torch.allclose(p.grad, want, atol=1e-6))
-    q.put((rank, ok))
+    gs.dp._sparse_state(N, world, None).settle()                            # the last step did not overflow either
+    q.put((rank, ok, log))
     dist.destroy_process_group()
 
 
 def test_sparse_gradient_exchange_world2_gloo():
-    """row-sparse all-gather exchange == dense sum, for a sparse case and for the dense fallback"""
+    """row-sparse fixed-capacity exchange == dense sum on every step of a run whose row density drifts up and down;
+    the capacity follows the counts of the PREVIOUS steps (no host sync inside a step) and both ranks take the same
+    sparse / dense decisions"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + (os.getpid() % 2000)
     procs = [ctx.Process(target=_dp_sparse_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert [(r[0], r[1]) for r in res] == [(0, True), (1, True)]
+    assert res[0][2] == res[1][2]                                           # identical decisions on both ranks
+    log = res[0][2]
+    assert any(d for d, _ in log) and not log[0][0] and not log[-1][0]     # went dense in the dense phase, came back
+    assert min(c for d, c in log if not d) < max(c for _, c in log)        # the capacity adapted
+
+
+def test_sparse_exchange_overflow_is_reported_loudly(gs):
+    """a count above the capacity that was used means the step's gradients were truncated: never silent"""
+    st = gs.dp.SparseExchangeState(100_000, 2)
+    st.pending = (torch.tensor([700, 300], dtype=torch.int32), None, None)   # first (synchronous) look
+    st.settle()
+    assert not st.dense and st.cap == 2048
+    st.pending = (torch.tensor([3000, 10], dtype=torch.int32), None, st.cap)
+    with pytest.raises(RuntimeError, match="overflowed"):
+        st.settle()
+    st.pending = (torch.tensor([9000, 10], dtype=torch.int32), None, None)
+    st.settle()
+    assert st.dense                                                          # 2 * 9000 > N / (4 * world) = 12500
+
+
+def _dp_small_worker(rank, world, port, q):
+    """train_step's DP branch with a CPU stand-in for the render: Gaussian rows go through the sparse exchange,
+    background / pose / velocity parameters through the small dense bucket (they used to be stepped
+    with rank-local gradients and the replicas drifted apart silently)"""
+    sys.path.insert(0, str(ROOT))
+    import gsdeblur_amd as gs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, H, W = 64, 8, 8
+    g = torch.Generator().manual_seed(3)
+    cfg = gs.SplatfactoDeblurConfig(sh_degree=1, background_color="auto")
+    cfg.camera_optimizer.mode = "SO3xR3"
+    cfg.camera_velocity_optimizer.enabled = True
+    model = gs.SplatfactoDeblurModel(cfg, torch.randn(n, 3, generator=g), torch.zeros(n, 3), torch.randn(n, 4, generator=g),
+                                     torch.zeros(n), torch.rand(n, 3, generator=g), torch.zeros(n, 3, 3), num_cameras=2)
+    opts = gs.training.make_optimizers(model)
+
+    def fake_outputs(camera):
+        i = camera.metadata["cam_idx"]
+        w = torch.zeros(n, 1)
+        w[i * 7:(i + 1) * 7 + 3] = 1.0                      # every view touches its own few Gaussians
+        col = (model.features_dc * w).sum(0) + model.means.mul(w).sum() * 0.01
+        bg = torch.sigmoid(model.background_param)
+        adj = model.pose_adjustment[i].sum() + 2.0 * model.velocity_adjustment[i].sum()
+        rgb = (0.1 * col + bg * (1.0 + adj))[None, None, :].expand(H, W, 3)
+        return {"rgb": rgb}
+
+    model.get_outputs = fake_outputs
+    c2w = torch.eye(4)[:3]
+    for step in range(4):
+        i = (step + rank) % 2                               # the ranks render DIFFERENT views
+        cam = gs.Camera(c2w, 10.0, 10.0, 4.0, 4.0, W, H, metadata={"cam_idx": i})
+        target = torch.full((H, W, 3), 0.2 + 0.5 * i)
+        gs.training.train_step(model, opts, cam, target, ssim_lambda=0.0, allreduce="sparse")
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    other = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    same = all(torch.equal(o, flat) for o in other)
+    moved = float(model.background_param.detach().abs().sum()) > 0 and float(model.pose_adjustment.detach().abs().sum()) > 0
+    q.put((rank, same, moved))
+    dist.destroy_process_group()
+
+
+def test_train_step_world2_gloo_keeps_background_pose_velocity_replicas_identical():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_small_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True, True), (1, True, True)]
 
 
 @pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
