@@ -129,13 +129,18 @@ def load_seed_points_ply(path: str) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def synthetic_scene(n: int, width: int, height: int, sh_degree: int = 3, seed: int = 1234,
-                    scale_mult: float = 1.0) -> Dict:
+                    scale_mult: float = 1.0, profile: str = "survey") -> Dict:
     """The seeded benchmark scene of SURVEY.md §8d (the inputs bench.py measures on): camera at the origin,
     OpenCV axes, fx = fy = 0.8*W; Gaussians uniform in the frustum slab z in [1,10] reaching 1.2x the field
     of view, log-scales ~ N(log(0.004 * 5.5 * scale_mult), 0.6^2), random unit quaternions, opacity logits
     ~ N(0, 2^2), SH dc ~ N(0, 0.5^2), higher bands ~ N(0, 0.05^2); camera velocity 0.1*U[-1,1]^3 m/s and
     0.2*U[-1,1]^3 rad/s, exposure 1/60 s, readout 1/30 s.  Raw (pre-activation) float32 parameters on the CPU.
-    The test oracle draws the same scene from the same generator sequence (tests/test_host_logic.py pins it)."""
+    The test oracle draws the same scene from the same generator sequence (tests/test_host_logic.py pins it).
+    profile="trained" keeps every random draw but shapes the scene like a fitted model instead of SURVEY §8d's
+    saturated one: world-space scale proportional to depth (0.006 * z: every Gaussian is ~7 px wide on screen,
+    none fills the view) and mostly translucent opacities (logits ~ N(-2.5, 1.5^2)) — pixels need hundreds of
+    list entries before they saturate, a large share of the Gaussians receives a gradient and the depth-sliced
+    path needs several slices (bench.py reports it as config.secondary)."""
     import math
     g = torch.Generator().manual_seed(seed)
     fx = fy = 0.8 * width
@@ -147,6 +152,11 @@ def synthetic_scene(n: int, width: int, height: int, sh_degree: int = 3, seed: i
     quats = torch.randn(n, 4, generator=g)
     quats = quats / quats.norm(dim=-1, keepdim=True)
     opacity_logits = 2.0 * torch.randn(n, generator=g)
+    if profile == "trained":
+        log_scales = log_scales - math.log(0.004 * 5.5) + torch.log(0.006 * z)[:, None]
+        opacity_logits = opacity_logits * 0.75 - 2.5
+    elif profile != "survey":
+        raise ValueError(f"unknown scene profile {profile!r}")
     K = (sh_degree + 1) ** 2
     sh = torch.cat([0.5 * torch.randn(n, 1, 3, generator=g), 0.05 * torch.randn(n, K - 1, 3, generator=g)], 1)
     lin_vel = 0.1 * (torch.rand(3, generator=g) * 2 - 1)

@@ -32,9 +32,59 @@ DOMINANT_STAGE = "raster_bwd"   # the kernel the roofline is quoted on (checked 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
-def make_scene(n, W, H, seed=1234):
+def make_scene(n, W, H, seed=1234, profile="survey"):
     from gsdeblur_amd import data
-    return data.synthetic_scene(n, W, H, sh_degree=3, seed=seed)
+    return data.synthetic_scene(n, W, H, sh_degree=3, seed=seed, profile=profile)
+
+
+class Workload:
+    """One camera view per rank of a replicated scene: parameters, view, fixed dL/d(image), and the step."""
+
+    def __init__(self, gs, dev, rank, world, N, W, H, S, R, profile, allreduce):
+        self.gs, self.world, self.allreduce = gs, world, allreduce
+        self.S, self.R, self.H, self.W = S, R, H, W
+        sc = self.sc = make_scene(N, W, H, profile=profile)
+        names = ["means", "log_scales", "quats", "opacity_logits", "sh"]
+        self.params = {k: sc[k].to(dev).requires_grad_(True) for k in names}
+        # every rank renders its own view: rotate / shift the camera and vary the velocity per rank
+        g = torch.Generator().manual_seed(1000 + rank)
+        self.lin = (sc["lin_vel"] * (1.0 + 0.1 * rank)).to(dev).requires_grad_(True)
+        self.ang = (sc["ang_vel"] * (1.0 + 0.1 * rank)).to(dev).requires_grad_(True)
+        # rank r looks at the scene from a pose moved by (0.05 r, 0, 0) m and rotated by 0.01 r rad about y
+        with torch.no_grad():
+            V0 = gs.subpose_viewmats(torch.eye(4, device=dev), torch.tensor([0.05 * rank, 0.0, 0.0], device=dev),
+                                     torch.tensor([0.0, 0.01 * rank, 0.0], device=dev), torch.ones(1, device=dev))[0]
+        self.viewmat = V0.clone().requires_grad_(True)
+        times, _, _ = gs.subpose_schedule(S, sc["exposure_time"], R, sc["rolling_shutter_time"])
+        self.times_t = torch.tensor(times, device=dev)
+        self.wt = torch.rand(H, W, 3, generator=g).to(dev)        # dL/d(image): fixed random weights
+        self.bg = torch.zeros(3, device=dev)
+        self.all_params = list(self.params.values())
+        self.exchange_events = []
+
+    def step(self):
+        gs, sc, params = self.gs, self.sc, self.params
+        for p in self.all_params + [self.lin, self.ang, self.viewmat]:
+            p.grad = None
+        vms = gs.subpose_viewmats(self.viewmat, self.lin, self.ang, self.times_t)
+        out, _, _ = gs.render_combined(params["means"], params["log_scales"].exp(), params["quats"],
+                                       torch.sigmoid(params["opacity_logits"]), params["sh"], vms, self.bg, self.S,
+                                       self.R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], self.H, self.W, gamma=2.2,
+                                       min_rgb_level=10.0, sh_degree=3, antialiased=True,
+                                       return_alpha=False)   # the loss reads RGB only
+        loss = (out * self.wt).sum()
+        loss.backward()
+        if self.world > 1:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            gs.dp.allreduce_gradients(self.all_params, mode=self.allreduce)
+            b.record()
+            self.exchange_events.append((a, b))
+        return loss
+
+    def rows_with_gradient(self):
+        g = self.params["means"].grad
+        return int((g != 0).any(dim=1).sum()) if g is not None else 0
 
 
 def _import_oracle():
@@ -79,7 +129,8 @@ def cpu_baseline():
             break
     dt = (time.perf_counter() - t0) / reps
     res = {"value": round(W * H / 1e6 / dt, 5), "unit": "MPix/s", "cores": cores, "kind": "port",
-           "sample": f"own CPU oracle (torch fp32, vectorised per tile), 5k Gaussians 256x256 1 sub-pose, "
+           "sample": f"own CPU oracle (torch fp32, vectorised per tile), BASELINE config 1: 5k Gaussians 256x256 "
+                     f"1 sub-pose (SURVEY 8d scene with scale_mult=4.0 so that 5k Gaussians cover the frame), "
                      f"fwd+bwd, mean of {reps} runs = {dt * 1e3:.0f} ms"}
     # parity of the measured path on the baseline's own workload: HIP render vs the oracle's render
     import gsdeblur_amd as gs
@@ -135,16 +186,35 @@ def main():
     ap.add_argument("--allreduce", default="sparse", choices=["sparse", "allreduce", "rs_ag"],
                     help="DP gradient exchange: row-sparse all-gather (default; dense fallback built in), "
                          "dense all-reduce, or reduce-scatter + all-gather")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the second (fitted-model-like) scene")
+    ap.add_argument("--scene", default="survey", choices=["survey", "trained"],
+                    help="scene profile of the timed workload (BASELINE metric: survey)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU over RCCL)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: they must agree")
+    if torch.cuda.device_count() < (local_rank + 1):
+        raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -152,37 +222,8 @@ def main():
     from gsdeblur_amd import ops
 
     N, W, H, S, R = args.gaussians, args.width, args.height, args.subposes, args.rs_bands
-    sc = make_scene(N, W, H)
-    names = ["means", "log_scales", "quats", "opacity_logits", "sh"]
-    params = {k: sc[k].to(dev).requires_grad_(True) for k in names}
-    # every rank renders its own view: rotate / shift the camera and vary the velocity per rank
-    g = torch.Generator().manual_seed(1000 + rank)
-    lin = (sc["lin_vel"] * (1.0 + 0.1 * rank)).to(dev).requires_grad_(True)
-    ang = (sc["ang_vel"] * (1.0 + 0.1 * rank)).to(dev).requires_grad_(True)
-    # rank r looks at the scene from a pose moved by (0.05 r, 0, 0) m and rotated by 0.01 r rad about y
-    with torch.no_grad():
-        V0 = gs.subpose_viewmats(torch.eye(4, device=dev), torch.tensor([0.05 * rank, 0.0, 0.0], device=dev),
-                                 torch.tensor([0.0, 0.01 * rank, 0.0], device=dev), torch.ones(1, device=dev))[0]
-    viewmat = V0.clone().requires_grad_(True)
-    times, _, _ = gs.subpose_schedule(S, sc["exposure_time"], R, sc["rolling_shutter_time"])
-    times_t = torch.tensor(times, device=dev)
-    wt = torch.rand(H, W, 3, generator=g).to(dev)        # dL/d(image): fixed random weights
-    bg = torch.zeros(3, device=dev)
-    all_params = list(params.values())
-
-    def step():
-        for p in all_params + [lin, ang, viewmat]:
-            p.grad = None
-        vms = gs.subpose_viewmats(viewmat, lin, ang, times_t)
-        out, _, _ = gs.render_combined(params["means"], params["log_scales"].exp(), params["quats"],
-                                       torch.sigmoid(params["opacity_logits"]), params["sh"], vms, bg, S, R,
-                                       sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2, min_rgb_level=10.0,
-                                       sh_degree=3, antialiased=True, return_alpha=False)   # the loss reads RGB only
-        loss = (out * wt).sum()
-        loss.backward()
-        if world > 1:
-            gs.dp.allreduce_gradients(all_params, mode=args.allreduce)
-        return loss
+    wl = Workload(gs, dev, rank, world, N, W, H, S, R, args.scene, args.allreduce)
+    sc, params, step = wl.sc, wl.params, wl.step
 
     for _ in range(args.warmup):
         step()
@@ -201,19 +242,65 @@ def main():
         dist.barrier(device_ids=[local_rank])
     dt = time.perf_counter() - t0
     timed_dom = ops.profiler.summary_ms()
+    exchange_ms = None
+    if wl.exchange_events:
+        torch.cuda.synchronize()
+        ev = wl.exchange_events[-args.steps:]
+        exchange_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     n_stage_steps = min(args.steps, 5)
     ops.profiler = ops.StageProfiler()
     for _ in range(n_stage_steps):
         step()
     stages = ops.profiler.summary_ms()
     ops.profiler = None
+    n_isect = ops.last_num_intersects
+    slice_isects = list(ops.last_slice_intersects)
+    rows_with_grad = wl.rows_with_gradient()
+    # second scene (reported beside the headline, never part of `value`): a fitted-model-like distribution in which
+    # a large share of the Gaussians receives a gradient and the depth-sliced path needs several slices
+    secondary = None
+    if not args.no_secondary and args.scene == "survey":
+        del wl, params, step
+        torch.cuda.empty_cache()
+        w2 = Workload(gs, dev, rank, world, N, W, H, S, R, "trained", args.allreduce)
+        for _ in range(2):
+            w2.step()
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+        k2 = max(3, min(args.steps, 10))
+        t2 = time.perf_counter()
+        for _ in range(k2):
+            w2.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        dt2 = time.perf_counter() - t2
+        if world > 1:
+            tt = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt2 = float(tt.item())
+        ops.profiler = ops.StageProfiler()
+        for _ in range(3):
+            w2.step()
+        st2 = ops.profiler.summary_ms()
+        ops.profiler = None
+        ms2 = dt2 / k2 * 1e3
+        secondary = {
+            "scene": "profile 'trained' (gsdeblur_amd.data.synthetic_scene): same seeded draws, world-space scale "
+                     "0.006*z per Gaussian (constant ~7 px screen size), opacity logits ~ N(-2.5, 1.5^2)",
+            "value": round(world * H * W / 1e6 / (ms2 / 1e3), 3), "unit": "MPix/s", "ms_per_step": round(ms2, 4),
+            "steps": k2, "tile_intersections_per_step": ops.last_num_intersects,
+            "tile_intersections_emitted": int(sum(ops.last_slice_intersects)),
+            "depth_slices": list(ops.last_slice_intersects), "gaussians_with_gradient": w2.rows_with_gradient(),
+            "stage_ms": {k: round(sum(v) / 3, 4) for k, v in st2.items()}}
+        del w2
+        torch.cuda.empty_cache()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    n_isect = ops.last_num_intersects
-    rows_with_grad = int((params["means"].grad != 0).any(dim=1).sum()) if params["means"].grad is not None else 0
 
     if rank == 0:
         npix = H * W
@@ -238,7 +325,7 @@ def main():
         #  * "survey": SURVEY §8d's formula with the measured total I of the unsliced algorithm (every
         #    (Gaussian, tile) bounding-box pair) — the definition north_star's ">= 50 % of roofline" uses;
         #    the sliced path AVOIDS most of those bytes rather than streaming them.
-        I_emit = int(sum(ops.last_slice_intersects)) if ops.last_slice_intersects else n_isect
+        I_emit = int(sum(slice_isects)) if slice_isects else n_isect
 
         def alg_bytes(I):
             return {
@@ -293,13 +380,15 @@ def main():
                                    f"fwd+bwd to all Gaussian params + viewmat + velocities",
                        "gaussians": N, "width": W, "height": H, "subposes": S, "rs_bands": R,
                        "tile_intersections_per_step": n_isect,
-                       "tile_intersections_emitted": int(sum(ops.last_slice_intersects)) if ops.SLICE_BASE > 0 else n_isect,
-                       "depth_slices": list(ops.last_slice_intersects) if ops.SLICE_BASE > 0 else None,
+                       "tile_intersections_emitted": int(sum(slice_isects)) if ops.SLICE_BASE > 0 else n_isect,
+                       "depth_slices": slice_isects if ops.SLICE_BASE > 0 else None,
                        "gaussians_with_gradient": rows_with_grad,
                        "views_per_step": world,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "gradient_exchange": args.allreduce if world > 1 else None,
-                       "subpose_MPix_per_s": round(value * S, 3)},
+                       "subpose_MPix_per_s": round(value * S, 3),
+                       "secondary": secondary},
+            "exchange_ms": None if exchange_ms is None else round(exchange_ms, 4),
             "stage_ms": stage_ms,
             "stage_ms_source": f"{n_stage_steps} extra steps with HIP events around every stage, after the timed region",
             "roofline": roofline,

@@ -522,7 +522,7 @@ def render(cfg: RenderConfig, means, scales, quats, opacities, sh_coeffs, viewma
 # seeded synthetic scenes
 # --------------------------------------------------------------------------- #
 def synthetic_scene(n: int, width: int, height: int, sh_degree: int = 3, seed: int = 1234, dtype=torch.float32,
-                    scale_mult: float = 1.0):
+                    scale_mult: float = 1.0, profile: str = "survey"):
     """Camera at origin, OpenCV axes, fx=fy=0.8*W.  Returns dict of raw (pre-activation) parameters.
     scale_mult enlarges the Gaussians (tests at tiny resolutions use it to get dense overlap and early
     termination; the benchmark scenes of SURVEY §8d use 1.0)."""
@@ -540,6 +540,11 @@ def synthetic_scene(n: int, width: int, height: int, sh_degree: int = 3, seed: i
     quats = torch.randn(n, 4, generator=g)
     quats = quats / quats.norm(dim=-1, keepdim=True)
     opacity_logits = 2.0 * torch.randn(n, generator=g)
+    if profile == "trained":       # fitted-model-like: screen size independent of depth, mostly translucent
+        log_scales = log_scales - math.log(0.004 * zbar) + torch.log(0.006 * z)[:, None]
+        opacity_logits = opacity_logits * 0.75 - 2.5
+    elif profile != "survey":
+        raise ValueError(f"unknown scene profile {profile!r}")
     K = (sh_degree + 1) ** 2
     sh = torch.cat([0.5 * torch.randn(n, 1, 3, generator=g), 0.05 * torch.randn(n, K - 1, 3, generator=g)], 1)
     lin_vel = 0.1 * (torch.rand(3, generator=g) * 2 - 1)

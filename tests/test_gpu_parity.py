@@ -746,6 +746,90 @@ def test_dp_row_kernels_match_torch(gs, dev):
         assert torch.allclose(a, want, atol=1e-6)
 
 
+def _nccl_worker(rank, world, port, q):
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    import gsdeblur_amd as gs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", rank)
+    N = 200_000
+    shapes = [(N, 3), (N, 3), (N, 4), (N, 1), (N, 3), (N, 15, 3)]
+    ok = True
+    for step, (mode, density) in enumerate((("sparse", 0.005), ("sparse", 0.006), ("sparse", 0.4), ("sparse", 0.01),
+                                            ("allreduce", 0.01), ("rs_ag", 0.01))):
+        grads = []
+        for r in range(world):
+            g = torch.Generator().manual_seed(7 + 31 * step + r)
+            touched = torch.rand(N, generator=g) < density
+            grads.append([torch.randn(s, generator=g) * touched.view(-1, *([1] * (len(s) - 1))) for s in shapes])
+        params = [torch.nn.Parameter(torch.zeros(s, device=dev)) for s in shapes]
+        for p, g in zip(params, grads[rank]):
+            p.grad = g.to(dev)
+        gs.dp.allreduce_gradients(params, mode=mode)
+        for i, p in enumerate(params):
+            want = sum(grads[r][i] for r in range(world))
+            ok &= bool(torch.allclose(p.grad.cpu(), want, atol=1e-5))
+    small = [torch.full((3,), float(rank + 1), device=dev), torch.full((2, 6), 2.0 * (rank + 1), device=dev)]
+    gs.dp.allreduce_dense_(small, average=True)
+    ok &= bool(torch.allclose(small[0].cpu(), torch.full((3,), (world + 1) / 2.0)))
+    gs.dp._sparse_state(N, world, None).settle()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_over_rccl_world2(gs, dev):
+    """the DP exchange (sync-free row-sparse form, its dense fallback, dense all-reduce, reduce-scatter + all-gather,
+    the small dense bucket) on the nccl (= RCCL) backend, two GPUs of one node; skipped on a single-GPU box"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_dp_masked_pack_and_payload_scatter_match_torch(gs, dev):
+    """sync-free exchange kernels on one GPU: fixed-capacity pack of the masked rows (header = true count, packed
+    count) and the count-from-header scatter-add, against plain torch ops; capacity below and above the row count"""
+    from gsdeblur_amd.dp import _RowOps
+    N = 50_000
+    g = torch.Generator().manual_seed(3)
+    touched = torch.rand(N, generator=g) < 0.02
+    shapes = [(N, 3), (N, 4), (N,), (N, 15, 3)]
+    grads = [(torch.randn(s, generator=g) * touched.view(-1, *([1] * (len(s) - 1)))).to(dev) for s in shapes]
+    total = int(touched.sum())
+    ops_ = _RowOps(grads)
+    ref_rows = torch.cat([x.reshape(N, -1) for x in grads], dim=1)[touched.to(dev)]
+    for cap in (total + 100, total // 2):
+        pay = ops_.pack_masked(cap)
+        hdr = pay[0, :2].view(torch.int32).tolist()
+        assert hdr == [total, min(total, cap)]
+        M = hdr[1]
+        assert torch.equal(pay[1:1 + M, :ops_.wtot], ref_rows[:M])
+        assert torch.equal(pay[1:1 + M, ops_.wtot].contiguous().view(torch.int32).cpu().long(),
+                           touched.nonzero().reshape(-1)[:M])
+        acc = [torch.zeros_like(x) for x in grads]
+        _RowOps(acc).scatter_add_payload(pay, cap, 0.5)
+        idx = touched.nonzero().reshape(-1)[:M].to(dev)
+        for a, x in zip(acc, grads):
+            want = torch.zeros_like(x)
+            want[idx] = x[idx] * 0.5
+            assert torch.equal(a, want)
+
+
 @pytest.mark.parametrize("S,R,base,learn_bg", [(3, 2, 16, False), (4, 1, 512, False), (2, 1, 4, True)])
 def test_render_combined_equals_two_step(gs, oracle, dev, S, R, base, learn_bg):
     """render_combined (one autograd node, sample gradients derived inside the compositor's backward) ==

@@ -231,9 +231,10 @@ def test_gradient_allreduce_world2_gloo(mode):
 def test_benchmark_scene_generator_is_the_oracles(gs, oracle):
     """bench.py draws its inputs from the package (the product never imports the oracle); the oracle's
     generator must yield the very same scene so that parity cases and the benchmark share inputs."""
-    for n, W, H, deg, seed, mult in ((1000, 256, 256, 3, 1234, 1.0), (17, 64, 48, 2, 7, 4.0)):
-        a = gs.data.synthetic_scene(n, W, H, sh_degree=deg, seed=seed, scale_mult=mult)
-        b = oracle.synthetic_scene(n, W, H, sh_degree=deg, seed=seed, scale_mult=mult)
+    for n, W, H, deg, seed, mult, prof in ((1000, 256, 256, 3, 1234, 1.0, "survey"), (17, 64, 48, 2, 7, 4.0, "survey"),
+                                           (500, 128, 96, 3, 1234, 1.0, "trained")):
+        a = gs.data.synthetic_scene(n, W, H, sh_degree=deg, seed=seed, scale_mult=mult, profile=prof)
+        b = oracle.synthetic_scene(n, W, H, sh_degree=deg, seed=seed, scale_mult=mult, profile=prof)
         assert set(a) == set(b)
         for k in a:
             if isinstance(a[k], torch.Tensor):
