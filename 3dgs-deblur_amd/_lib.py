@@ -29,6 +29,7 @@ _SIGS = {
     "gs_exclusive_scan_u32": [_L, _P, _P, _P, _P, _L, _P],
     "gs_radix_sort_pairs_u32": [_L, _P, _P, _P, _P, _I, _I, _I, _P, _L, ctypes.POINTER(_I), _P],
     "gs_radix_sort_pairs_u64": [_L, _P, _P, _P, _P, _I, _I, _I, _P, _L, ctypes.POINTER(_I), _P],
+    "gs_radix_sort_pairs_gather_u32": [_L, _P, _P, _P, _P, _I, _I, _I, _P, _L, ctypes.POINTER(_I), _P, _P, _P],
     "gs_segmented_sort_pairs_u32": [_L, _L, _P, _P, _P, _P, _I, _I, _I, _P, _L, ctypes.POINTER(_I), _P],
     "gs_make_depth_keys64": [_L, _I, _P, _P, _P],
     "gs_gather_counts": [_L, _P, _P, _P, _P],

@@ -215,7 +215,9 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
                                                             KeyT* __restrict__ keys_out,
                                                             unsigned* __restrict__ vals_out, int shift, unsigned mask,
                                                             SegInfo sg,
-                                                            const unsigned* __restrict__ ghist_scanned) {
+                                                            const unsigned* __restrict__ ghist_scanned,
+                                                            const unsigned* __restrict__ gather_src,  // nullable
+                                                            unsigned* __restrict__ gather_out) {
   constexpr int NB = 1 << BITS;
   constexpr int R = SortCfg<KeyT>::kRounds;
   constexpr int BK = 256 * R;
@@ -313,7 +315,11 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
       unsigned digit = (unsigned)(k >> shift) & mask;
       size_t dst = (size_t)s_gbase[digit] + (slot - s_dbase[digit]);
       keys_out[dst] = k;
-      vals_out[dst] = s_vals[slot];
+      const unsigned v = s_vals[slot];
+      vals_out[dst] = v;
+      // final pass of the tile sort: also leave gather_src[payload] in sorted order (the record index of every
+      // sorted entry, fetched here among the scatter's own latencies instead of in a separate pass over the list)
+      if (gather_out) gather_out[dst] = gather_src[v];
     }
   }
 }
@@ -360,7 +366,8 @@ static inline size_t radix_ws_bytes(size_t n, size_t seg_len, int bits, int max_
 
 template <typename KeyT, int BITS>
 static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned* vin, KeyT* kout, unsigned* vout,
-                       int shift, unsigned mask, void* ws, size_t hist_bytes, hipStream_t st) {
+                       int shift, unsigned mask, void* ws, size_t hist_bytes, hipStream_t st,
+                       const unsigned* gather_src = nullptr, unsigned* gather_out = nullptr) {
   SegInfo sg;
   unsigned nblk = sort_nblk_seg<KeyT>(n, seg_len, &sg.nblk_seg);
   sg.seg_len = (seg_len == 0 || seg_len >= n) ? n : seg_len;
@@ -370,7 +377,7 @@ static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned
   hipLaunchKernelGGL((radix_hist_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, shift, mask, sg, ghist);
   run_scan(hn, ghist, ghist, nullptr, scan_ws, st);
   hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, vin, kout, vout, shift,
-                     mask, sg, ghist);
+                     mask, sg, ghist, gather_src, gather_out);
 }
 
 // Sort bits [begin_bit, end_bit).  Ping-pongs between (k0,v0) and (k1,v1); returns the index
@@ -378,7 +385,7 @@ static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned
 template <typename KeyT>
 static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1, unsigned* v1, int v0_is_iota,
                       int begin_bit, int end_bit, void* ws, size_t ws_bytes, int* result_buf, hipStream_t st,
-                      int max_digit = 11) {
+                      int max_digit = 11, const unsigned* gather_src = nullptr, unsigned* gather_out = nullptr) {
   int bits = end_bit - begin_bit;
   if (bits <= 0) return GS_ERR_INVALID;
   if (ws_bytes < radix_ws_bytes<KeyT>(n, seg_len, bits, max_digit)) return GS_ERR_WORKSPACE;
@@ -393,11 +400,13 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
     if (shift + w > end_bit) w = end_bit - shift;
     const unsigned mask = (1u << w) - 1u;
     const unsigned* vin = (p == 0 && v0_is_iota) ? nullptr : vv[cur];
+    const unsigned* gs_ = (p == passes - 1) ? gather_src : nullptr;
+    unsigned* go_ = (p == passes - 1) ? gather_out : nullptr;
     switch (tb) {
-      case 8:  radix_pass<KeyT, 8>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
-      case 9:  radix_pass<KeyT, 9>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
-      case 10: radix_pass<KeyT, 10>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
-      default: radix_pass<KeyT, 11>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st); break;
+      case 8:  radix_pass<KeyT, 8>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_); break;
+      case 9:  radix_pass<KeyT, 9>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_); break;
+      case 10: radix_pass<KeyT, 10>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_); break;
+      default: radix_pass<KeyT, 11>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_); break;
     }
     shift += w;
     cur ^= 1;
@@ -426,43 +435,93 @@ __global__ __launch_bounds__(256) void gather_counts_kernel(size_t n, const unsi
 // slack keeps the test conservative against the compositor's float32 rounding: culled pairs
 // contribute exactly nothing, so images are unchanged.
 // ---------------------------------------------------------------------------
-struct Ellipse { float gx, gy, a, b, c, tau, ra, rc; };   // ra = 1/a, rc = 1/c: no division per tile
+struct Ellipse { float gx, gy, a, b, c, tau, ra, rc, ustar, vstar, vext; };
+// ustar = largest |u| on the ellipse (reached at v = -b*ustar/c), vext = largest |v|, vstar = b*ustar/c
+
+// everything the tile tests need beyond (gx, gy, a, b, c, tau): the same arithmetic wherever an ellipse is rebuilt
+// from those six numbers (LDS staging, v_readlane broadcast), so every copy takes identical decisions
+__device__ __forceinline__ void ellipse_derive(Ellipse& e) {
+#pragma clang fp contract(off)
+  e.ra = 1.0f / e.a; e.rc = 1.0f / e.c;
+  // sigma = (a u^2 + 2 b u v + c v^2)/2 <= tau:  extent in u is sqrt(2 tau c / det), in v sqrt(2 tau a / det)
+  const float det = e.a * e.c - e.b * e.b;
+  if (e.tau >= 0.f && det > 0.f && e.a > 0.f && e.c > 0.f) {
+    const float k = 2.0f * e.tau / det;
+    e.ustar = sqrtf(k * e.c) * 1.0001f;
+    e.vext = sqrtf(k * e.a) * 1.0001f;
+    e.vstar = e.b * e.ustar * e.rc;
+  } else {
+    e.ustar = e.vext = 3.0e38f;       // degenerate conic: never cull
+    e.vstar = 0.f;
+  }
+}
 
 __device__ __forceinline__ Ellipse make_ellipse(const float* __restrict__ rec) {
+#pragma clang fp contract(off)
   Ellipse e;
   e.gx = rec[0]; e.gy = rec[1]; e.a = rec[2]; e.b = rec[3]; e.c = rec[4];
   const float op = rec[5];
   e.tau = op > 0.f ? __logf(255.0f * op) : -1.f;
-  // threshold with the conservative slack folded in (tile_hit compares against it directly)
+  // threshold with the conservative slack folded in (the tile tests compare against it directly)
   e.tau = e.tau < 0.f ? -1.f : e.tau * 1.001f + 1e-3f;
-  e.ra = 1.0f / e.a; e.rc = 1.0f / e.c;
+  ellipse_derive(e);
   return e;
 }
 
-__device__ __forceinline__ float edge_min(float fixed, float lo, float hi, float qf, float qb, float qv, float rqv) {
-  // min over v in [lo,hi] of 0.5*qf*fixed^2 + qb*fixed*v + 0.5*qv*v^2   (rqv = 1/qv; the clamp makes the
-  // rounding of the stationary point harmless: any v in [lo,hi] gives an upper bound of the true minimum
-  // that is within the slack of it)
-  // The three terms cancel for elongated Gaussians (sigma small, terms large): float32 rounding is then a
-  // few ulps of the LARGEST term, so the slack scales with it (2e-6 * t0 >= ~16 ulps) and errs towards "hit".
-  const float bf = qb * fixed;
-  const float v = fminf(hi, fmaxf(lo, -bf * rqv));
-  const float t0 = 0.5f * qf * fixed * fixed;
-  return t0 * (1.0f - 2e-6f) + v * (bf + 0.5f * qv * v);
+// Columns of pixel centres a tile ROW can reach.  The part of the ellipse inside the band v in [v0,v1] is convex,
+// so its projection on u is ONE interval [ul, ur]: a tile of that row is hit iff its pixel-centre columns intersect
+// it.  ur is the ellipse's overall extreme ustar when the line v = -vstar (where it is attained) crosses the band,
+// else the larger of the two chord ends at the band edges; ul likewise with +vstar.  One evaluation per row (two
+// square roots) instead of four edge minima per tile; exact up to rounding, which the slack (the enlarged tau plus
+// an explicit margin on the interval) keeps on the conservative side.  Contraction is disabled: the count and the
+// emission must take the SAME decision for every tile wherever this is inlined.
+struct RowSpan { float ul, ur; };
+
+__device__ __forceinline__ RowSpan row_span(const Ellipse& e, int ty, int H) {
+#pragma clang fp contract(off)
+  RowSpan r;
+  r.ul = 1.f; r.ur = -1.f;                                 // empty
+  if (e.tau < 0.f) return r;
+  if (e.ustar > 1.0e37f) { r.ul = -3.0e38f; r.ur = 3.0e38f; return r; }
+  const float v0 = (float)(ty * K::kTile) + 0.5f - e.gy;
+  const float v1 = fminf((float)(ty * K::kTile + K::kTile) - 0.5f, (float)H - 0.5f) - e.gy;
+  if (v1 < -e.vext || v0 > e.vext) return r;
+  const float w0 = fmaxf(v0, -e.vext), w1 = fminf(v1, e.vext);
+  // chord of the ellipse on the line v = w: u = (-b w -/+ sqrt(2 a tau - det w^2)) / a
+  const float det = e.a * e.c - e.b * e.b;
+  const float k2 = 2.0f * e.a * e.tau;
+  const float d0 = sqrtf(fmaxf(k2 - det * w0 * w0, 0.f)), d1 = sqrtf(fmaxf(k2 - det * w1 * w1, 0.f));
+  const float c0 = -e.b * w0, c1 = -e.b * w1;
+  float ur = fmaxf((c0 + d0) * e.ra, (c1 + d1) * e.ra);
+  float ul = fminf((c0 - d0) * e.ra, (c1 - d1) * e.ra);
+  if (-e.vstar >= w0 && -e.vstar <= w1) ur = e.ustar;
+  if (e.vstar >= w0 && e.vstar <= w1) ul = -e.ustar;
+  const float eps = 2e-3f + 2e-6f * (fabsf(e.gx) + e.ustar);
+  r.ur = fmaxf(ur, ul) + eps;
+  r.ul = fminf(ul, ur) - eps;
+  return r;
+}
+
+// first / one-past-last tile column of row ty whose pixel centres intersect the span, clamped to [x0, x1)
+__device__ __forceinline__ void span_tiles(const Ellipse& e, const RowSpan& sp, int x0, int x1, int& t0, int& t1) {
+#pragma clang fp contract(off)
+  if (sp.ur < sp.ul) { t0 = t1 = x0; return; }
+  // tile tx holds pixel centres tx*16 + 0.5 .. tx*16 + 15.5 (the last column of the image may hold fewer: keeping
+  // the full width there is conservative)
+  const float lo = (sp.ul + e.gx - 15.5f) * (1.0f / (float)K::kTile);
+  const float hi = (sp.ur + e.gx - 0.5f) * (1.0f / (float)K::kTile);
+  const float flo = fminf(fmaxf(ceilf(lo), (float)x0), (float)x1);
+  const float fhi = fminf(fmaxf(floorf(hi) + 1.0f, (float)x0), (float)x1);
+  t0 = (int)flo; t1 = (int)fhi;
+  if (t1 < t0) t1 = t0;
 }
 
 __device__ __forceinline__ bool tile_hit(const Ellipse& e, int tx, int ty, int W, int H) {
-  if (e.tau < 0.f) return false;
-  const float u0 = (float)(tx * K::kTile) + 0.5f - e.gx;
-  const float u1 = fminf((float)(tx * K::kTile + K::kTile) - 0.5f, (float)W - 0.5f) - e.gx;
-  const float v0 = (float)(ty * K::kTile) + 0.5f - e.gy;
-  const float v1 = fminf((float)(ty * K::kTile + K::kTile) - 0.5f, (float)H - 0.5f) - e.gy;
-  if (u0 <= 0.f && u1 >= 0.f && v0 <= 0.f && v1 >= 0.f) return true;
-  float m = edge_min(u0, v0, v1, e.a, e.b, e.c, e.rc);
-  m = fminf(m, edge_min(u1, v0, v1, e.a, e.b, e.c, e.rc));
-  m = fminf(m, edge_min(v0, u0, u1, e.c, e.b, e.a, e.ra));
-  m = fminf(m, edge_min(v1, u0, u1, e.c, e.b, e.a, e.ra));
-  return m <= e.tau;
+  (void)W;
+  const RowSpan sp = row_span(e, ty, H);
+  int t0, t1;
+  span_tiles(e, sp, tx, tx + 1, t0, t1);
+  return t1 > t0;
 }
 
 // Entry-parallel emission: a block owns kEmitChunk consecutive OUTPUT entries (so the grid scales with
@@ -508,7 +567,7 @@ __global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T
   for (unsigned wbase = g_lo; wbase <= g_hi; wbase += 256) {
     const unsigned r = wbase + threadIdx.x;
     unsigned gi = 0, c = 0xFFFFFFFFu, kbase = 0, w = 1, xy0 = 0;
-    Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
+    Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f, 0.f, 0.f, 0.f};
     if (r <= g_hi) {
       gi = sorted_gi[r];
       c = cum[r];
@@ -551,7 +610,7 @@ __global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T
       if (invalid_key) {
         Ellipse el2;
         el2.gx = s_gx[a]; el2.gy = s_gy[a]; el2.a = s_a[a]; el2.b = s_b[a]; el2.c = s_c[a]; el2.tau = s_tau[a];
-        el2.ra = 1.0f / el2.a; el2.rc = 1.0f / el2.c;
+        ellipse_derive(el2);
         if (!tile_hit(el2, tx, ty, W, H)) key = invalid_key;
       }
       keys[e] = key;
@@ -713,6 +772,7 @@ __global__ __launch_bounds__(256) void slice_counts_kernel(int n_slice, SliceDes
 // table rejects Gaussians without open tiles with four loads, small boxes are walked by their own
 // lane, large boxes (the nearest Gaussians cover hundreds of tiles) by the whole wave, 64 tiles per step.
 constexpr int kCountSolo = 12;
+constexpr int kSpanRows = 272;      // tile rows a box may span for the LDS row table (4352 pixel rows)
 
 // WAVE_PER_G: one Gaussian per wave (lane 0 owns it) — for slices of few, large Gaussians, where 64 big
 // boxes per wave would serialise ~25k tile tests in each of only a few hundred waves.
@@ -727,12 +787,13 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
                                                                  const unsigned* __restrict__ cum_rank,   // nullable
                                                                  unsigned long long* __restrict__ masks,  // nullable
                                                                  unsigned* __restrict__ mask_off) {
+  __shared__ unsigned s_span[4][kSpanRows];
   const int lane = lane_id();
   const int j = WAVE_PER_G ? (lane == 0 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : n_slice)
                            : (int)(blockIdx.x * 256 + threadIdx.x);
   unsigned gi = 0, lo = 0, hi = 0, moff = 0;
   int area = 0;
-  Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
+  Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f, 0.f, 0.f, 0.f};
   if (j < n_slice) {
     const int rank = slice_rank(sd, j);
     gi = sorted_gi[rank];
@@ -755,18 +816,22 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
   unsigned cnt = 0;
   if (area > 0 && area <= kCountSolo) {
     const int x0 = lo & 0xFFFF, y0 = lo >> 16, x1 = hi & 0xFFFF, y1 = hi >> 16;
+    const int w = x1 - x0;
     const unsigned pbase = (gi / (unsigned)N) * T;
     unsigned long long m = 0ull;
-    int t = 0;
-    for (int y = y0; y < y1; ++y)
-      for (int x = x0; x < x1; ++x, ++t)
-        if ((!done || done[pbase + (unsigned)(y * tiles_x + x)] == 0) && tile_hit(el, x, y, W, H)) {
+    for (int y = y0; y < y1; ++y) {
+      int t0, t1;
+      span_tiles(el, row_span(el, y, H), x0, x1, t0, t1);       // one interval per tile row
+      for (int x = t0; x < t1; ++x)
+        if (!done || done[pbase + (unsigned)(y * tiles_x + x)] == 0) {
           ++cnt;
-          m |= 1ull << t;
+          m |= 1ull << ((y - y0) * w + (x - x0));
         }
+    }
     if (masks) masks[moff] = m;                 // kCountSolo <= 64: one word
   }
   unsigned long long big = __ballot(area > kCountSolo);
+  unsigned* span = s_span[threadIdx.x >> 6];
   while (big) {
     const int src = __ffsll((long long)big) - 1;
     big &= big - 1;
@@ -775,12 +840,23 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
     Ellipse eg;
     eg.gx = readlane_f(el.gx, src); eg.gy = readlane_f(el.gy, src); eg.a = readlane_f(el.a, src);
     eg.b = readlane_f(el.b, src); eg.c = readlane_f(el.c, src); eg.tau = readlane_f(el.tau, src);
-    eg.ra = readlane_f(el.ra, src); eg.rc = readlane_f(el.rc, src);
+    ellipse_derive(eg);
     const int x0 = l & 0xFFFF, y0 = l >> 16, x1 = h & 0xFFFF, y1 = h >> 16;
     const int w = x1 - x0, a = w * (y1 - y0);
     const float rw = 1.0f / (float)w;
     const unsigned pbase = (g / (unsigned)N) * T;
     const unsigned mo = (unsigned)readlane_i((int)moff, src);
+    // the tile columns each row of the box can reach, one lane per row, parked in wave-private LDS
+    const bool spans = (y1 - y0) <= kSpanRows;
+    if (spans) {
+      __builtin_amdgcn_wave_barrier();
+      for (int r = lane; r < y1 - y0; r += 64) {
+        int t0, t1;
+        span_tiles(eg, row_span(eg, y0 + r, H), x0, x1, t0, t1);
+        span[r] = (unsigned)t0 | ((unsigned)t1 << 16);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     unsigned c = 0;
     for (int base = 0; base < a; base += 64) {
       const int t = base + lane;
@@ -788,7 +864,10 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
       if (t < a) {
         const int q = (int)(((float)t + 0.5f) * rw);
         const int tx = x0 + (t - q * w), ty = y0 + q;
-        ok = (!done || done[pbase + (unsigned)(ty * tiles_x + tx)] == 0) && tile_hit(eg, tx, ty, W, H);
+        bool in;
+        if (spans) { const unsigned u = span[q]; in = tx >= (int)(u & 0xFFFFu) && tx < (int)(u >> 16); }
+        else in = tile_hit(eg, tx, ty, W, H);
+        ok = in && (!done || done[pbase + (unsigned)(ty * tiles_x + tx)] == 0);
       }
       const unsigned long long m = __ballot(ok);
       if (masks && lane == 0) masks[mo + (unsigned)(base >> 6)] = m;
@@ -817,7 +896,7 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
   const int j = WAVE_PER_G ? (lane == 0 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : n_slice)
                            : (int)(blockIdx.x * 256 + threadIdx.x);
   unsigned cnt = 0, gi = 0, e0 = 0, lo = 0, hi = 0, moff = 0;
-  Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f};
+  Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f, 0.f, 0.f, 0.f};
   if (j < n_slice) {
     cnt = counts[j];
     if (cnt) {
@@ -841,7 +920,7 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
     Ellipse eg;
     eg.gx = readlane_f(el.gx, src); eg.gy = readlane_f(el.gy, src); eg.a = readlane_f(el.a, src);
     eg.b = readlane_f(el.b, src); eg.c = readlane_f(el.c, src); eg.tau = readlane_f(el.tau, src);
-    eg.ra = readlane_f(el.ra, src); eg.rc = readlane_f(el.rc, src);
+    ellipse_derive(eg);
     const int x0 = l & 0xFFFF, y0 = l >> 16, x1 = h & 0xFFFF, y1 = h >> 16;
     const int w = x1 - x0, area = w * (y1 - y0);
     const float rw = 1.0f / (float)w;
@@ -957,6 +1036,17 @@ GS_EXPORT int gs_radix_sort_pairs_u32(long long n, unsigned* keys0, unsigned* va
   if (n <= 0 || begin_bit < 0 || end_bit > 32) return GS_ERR_INVALID;
   return radix_sort<unsigned>((size_t)n, 0, keys0, vals0, keys1, vals1, vals0_is_iota, begin_bit, end_bit, ws,
                               (size_t)ws_bytes, result_buf, (hipStream_t)stream);
+}
+
+// gs_radix_sort_pairs_u32 whose final pass also writes gather_out[i] = gather_src[sorted value i] (gather_out: n
+// ints; the tile sort of a depth slice sorts emission indices and leaves the record index of every sorted entry)
+GS_EXPORT int gs_radix_sort_pairs_gather_u32(long long n, unsigned* keys0, unsigned* vals0, unsigned* keys1,
+                                             unsigned* vals1, int vals0_is_iota, int begin_bit, int end_bit,
+                                             void* ws, long long ws_bytes, int* result_buf,
+                                             const unsigned* gather_src, unsigned* gather_out, void* stream) {
+  if (n <= 0 || begin_bit < 0 || end_bit > 32 || !gather_src || !gather_out) return GS_ERR_INVALID;
+  return radix_sort<unsigned>((size_t)n, 0, keys0, vals0, keys1, vals1, vals0_is_iota, begin_bit, end_bit, ws,
+                              (size_t)ws_bytes, result_buf, (hipStream_t)stream, 11, gather_src, gather_out);
 }
 
 GS_EXPORT int gs_radix_sort_pairs_u64(long long n, unsigned long long* keys0, unsigned* vals0,

@@ -167,9 +167,11 @@ def exclusive_scan_u32(x: Tensor) -> Tuple[Tensor, Tensor]:
     return out, total
 
 
-def radix_sort_pairs(keys: Tensor, vals: Optional[Tensor], begin_bit: int, end_bit: int) -> Tuple[Tensor, Tensor]:
+def radix_sort_pairs(keys: Tensor, vals: Optional[Tensor], begin_bit: int, end_bit: int,
+                     gather_src: Optional[Tensor] = None):
     """Stable ascending sort of (key, int32 value) pairs over key bits [begin_bit, end_bit).
-    keys int32 (treated as u32) or int64 (u64); vals None => iota.  Inputs are clobbered."""
+    keys int32 (treated as u32) or int64 (u64); vals None => iota.  Inputs are clobbered.
+    gather_src (int32 keys only): the final pass also returns gather_src[sorted values] as a third tensor."""
     assert keys.is_cuda and keys.is_contiguous() and keys.dtype in (torch.int32, torch.int64)
     n = keys.numel()
     dev = keys.device
@@ -187,6 +189,13 @@ def radix_sort_pairs(keys: Tensor, vals: Optional[Tensor], begin_bit: int, end_b
     ws_bytes = L.gs_radix_sort_workspace_bytes(n, begin_bit, end_bit)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     res = ctypes.c_int(0)
+    if gather_src is not None:
+        assert keys.dtype == torch.int32 and gather_src.dtype == torch.int32 and gather_src.is_contiguous()
+        gathered = _padded_i32(n, dev)
+        _check(L.gs_radix_sort_pairs_gather_u32(n, _ptr(keys), _ptr(v0), _ptr(k1), _ptr(v1), iota, begin_bit, end_bit,
+                                                _ptr(ws), ws_bytes, ctypes.byref(res), _ptr(gather_src), _ptr(gathered),
+                                                _stream()), "radix sort + gather")
+        return ((k1, v1) if res.value == 1 else (keys, v0)) + (gathered,)
     fn = L.gs_radix_sort_pairs_u32 if keys.dtype == torch.int32 else L.gs_radix_sort_pairs_u64
     _check(fn(n, _ptr(keys), _ptr(v0), _ptr(k1), _ptr(v1), iota, begin_bit, end_bit, _ptr(ws), ws_bytes,
               ctypes.byref(res), _stream()), "radix sort")
@@ -444,19 +453,14 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                            "emit open intersects")
             with _stage("tile_sort"):
                 if use_tuples:
-                    # payload = emission index e (iota); the Gaussian id of a sorted entry is vals[e]
-                    skeys, svals = radix_sort_pairs(keys, None, 0, _bits(P * T + 1))
+                    # payload = emission index e (iota); the Gaussian id of a sorted entry is vals[e]: the final
+                    # pass leaves it in sorted order for the scalar-cache compositors
+                    skeys, svals, sorted_ids = radix_sort_pairs(keys, None, 0, _bits(P * T + 1), gather_src=vals)
                 else:
                     skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T + 1))
             with _stage("bin_edges"):
                 bins = torch.empty(P * T + 1, 2, dtype=torch.int32, device=dev)   # last row: culled pairs
-                if use_tuples:
-                    # + the record index of every sorted entry (the sort carried emission indices)
-                    sorted_ids = torch.empty(I_k + IDS_PAD, dtype=torch.int32, device=dev)
-                    _check(L.gs_tile_bin_edges_ids_u32(I_k, _ptr(skeys), P * T + 1, _ptr(bins), _ptr(svals), _ptr(vals),
-                                                       _ptr(sorted_ids), _stream()), "bin edges + ids")
-                else:
-                    _check(L.gs_tile_bin_edges_u32(I_k, _ptr(skeys), P * T + 1, _ptr(bins), _stream()), "bin edges")
+                _check(L.gs_tile_bin_edges_u32(I_k, _ptr(skeys), P * T + 1, _ptr(bins), _stream()), "bin edges")
         last_slice_intersects.append(I_k)
         if I_k == 0 and not (first or last):
             continue

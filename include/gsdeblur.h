@@ -120,6 +120,13 @@ int gs_exclusive_scan_u32(long long n, const unsigned* in, unsigned* out, unsign
 int gs_radix_sort_pairs_u32(long long n, unsigned* keys0, unsigned* vals0, unsigned* keys1,
                             unsigned* vals1, int vals0_is_iota, int begin_bit, int end_bit, void* ws,
                             long long ws_bytes, int* result_buf /*host*/, void* stream);
+/* gs_radix_sort_pairs_u32 whose FINAL pass also writes gather_out[i] = gather_src[value of sorted pair i]
+ * (gather_out: n ints).  The tile sort of a depth slice sorts emission indices e and leaves the record index
+ * gi_of_e[e] of every sorted entry for the scalar-cache compositors (gs_rasterize_*_slice: sorted_ids). */
+int gs_radix_sort_pairs_gather_u32(long long n, unsigned* keys0, unsigned* vals0, unsigned* keys1, unsigned* vals1,
+                                   int vals0_is_iota, int begin_bit, int end_bit, void* ws, long long ws_bytes,
+                                   int* result_buf /*host*/, const unsigned* gather_src, unsigned* gather_out,
+                                   void* stream);
 int gs_radix_sort_pairs_u64(long long n, unsigned long long* keys0, unsigned* vals0,
                             unsigned long long* keys1, unsigned* vals1, int vals0_is_iota, int begin_bit,
                             int end_bit, void* ws, long long ws_bytes, int* result_buf /*host*/,

@@ -281,6 +281,10 @@ def get_tile_bin_edges(sorted_ids: np.ndarray, num_tiles: int) -> np.ndarray:
 # --------------------------------------------------------------------------- #
 # rasterize (App. A "Blend") — vectorised per tile, autograd bwd
 # --------------------------------------------------------------------------- #
+FRAGILE_ALPHA_BAND = 5e-5     # round 1 used 2e-4 / 2e-3 and excluded up to 10 % of the pixels of a 5-sample frame
+FRAGILE_T_BAND = 5e-4
+
+
 @dataclass
 class Rasterized:
     img: torch.Tensor        # [H,W,3]
@@ -351,8 +355,10 @@ def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.nda
             # fragile decisions (used only to exclude pixels from strict comparisons)
             with torch.no_grad():
                 reach = Texcl > T_MIN
-                f1 = (reach & ((alpha / ALPHA_MIN - 1.0).abs() < 2e-4)).any(dim=0)
-                f2 = (valid & reach & ((Tincl / T_MIN - 1.0).abs() < 2e-3)).any(dim=0)
+                # bands: ~50x the fp32 error of the quantity compared (alpha: ~1e-6 relative from the fast exp2 of
+                # an exponent of magnitude <= 8; T: a product of up to a few hundred fp32 factors, ~1e-5 relative)
+                f1 = (reach & ((alpha / ALPHA_MIN - 1.0).abs() < FRAGILE_ALPHA_BAND)).any(dim=0)
+                f2 = (valid & reach & ((Tincl / T_MIN - 1.0).abs() < FRAGILE_T_BAND)).any(dim=0)
                 f3 = (reach & (sigma.abs() < 1e-7) & (sigma != 0)).any(dim=0)
             tile_imgs.append(C.reshape(hh, ww, 3))
             tile_Ts.append(Tfin.reshape(hh, ww))

@@ -62,9 +62,84 @@ def make_case(name, n, W, H, cfg_kw, seed, sh_degree=3, scale_mult=16.0):
           "fragile px", int(frag.sum()))
 
 
+def make_large_case(name, n, W, H, cfg_kw, seed, sh_degree=3, scale_mult=2.0, vel_mult=(8.0, 4.0)):
+    """A fixture closer to the BASELINE shapes (>= 20k Gaussians, >= 640x360, 5 sub-poses).  The float64 autograd
+    graph of the whole frame does not fit in host memory, so the gradient is accumulated one sub-pose at a time:
+    pass 1 renders every sample without a graph, pass 2 re-renders each sub-pose WITH one and back-propagates
+    d loss / d sample (known in closed form from the gamma-space average) through it.  The scene itself is NOT
+    stored: the test rebuilds it from the seeded generator (gs_oracle.synthetic_scene == gsdeblur_amd.data's)."""
+    sc = O.synthetic_scene(n, W, H, sh_degree=sh_degree, seed=seed, scale_mult=scale_mult)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * vel_mult[0], sc["ang_vel"] * vel_mult[1]
+    cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], sh_degree=sh_degree, **cfg_kw)
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel", "viewmat"]
+    ps = {k: sc[k].double().requires_grad_(True) for k in names}
+    bg = torch.tensor([0.1, 0.2, 0.3], dtype=torch.float64)
+    times, samp, band = O.subpose_times(cfg.blur_samples, cfg.exposure_time, cfg.rs_bands, cfg.rolling_shutter_time)
+    rows = O.band_tile_rows(H, cfg.rs_bands)
+    S = max(1, cfg.blur_samples)
+
+    def render_subpose(p, q):
+        vms = O.subpose_viewmats(q["viewmat"], q["lin_vel"], q["ang_vel"], times)
+        V = vms[p]
+        pr = O.project_gaussians(q["means"], q["log_scales"].exp(), cfg.glob_scale, q["quats"], V, cfg.fx, cfg.fy, cfg.cx,
+                                 cfg.cy, H, W, O.TILE, cfg.clip_thresh)
+        cam_pos = -(V[:3, :3].detach().T @ V[:3, 3].detach())
+        rgb = torch.clamp(O.spherical_harmonics(cfg.sh_degree, q["means"].detach() - cam_pos[None, :], q["sh"]) + 0.5,
+                          min=0.0)
+        op = torch.sigmoid(q["opacity_logits"]).reshape(-1) * pr.compensation
+        keys, gids = O.map_gaussian_to_intersects(pr, W)
+        keys, gids = O.sort_intersects(keys, gids)
+        bins = O.get_tile_bin_edges(keys, ((W + O.TILE - 1) // O.TILE) * ((H + O.TILE - 1) // O.TILE))
+        return O.rasterize_sorted(pr.xys, pr.conics, rgb, op, gids, bins, H, W, bg, tile_rows=rows[band[p]]), vms, pr
+
+    with torch.no_grad():
+        imgs = [torch.zeros(H, W, 3, dtype=torch.float64) for _ in range(S)]
+        alphas = [torch.zeros(H, W, dtype=torch.float64) for _ in range(S)]
+        frag = torch.zeros(H, W, dtype=torch.bool)
+        for p in range(len(times)):
+            r, vms, pr = render_subpose(p, ps)
+            imgs[samp[p]] += r.img
+            alphas[samp[p]] += r.alpha
+            frag |= r.fragile
+            if p == 0:
+                radii0 = pr.radii.numpy().copy()
+    samples = torch.stack(imgs).requires_grad_(True)
+    out = O.combine_samples(samples, cfg.gamma, cfg.min_rgb_level)
+    g = torch.Generator().manual_seed(seed + 1)
+    wt = torch.rand(H, W, 3, generator=g, dtype=torch.float64) * (~frag)[..., None]
+    (out * wt).sum().backward()
+    v_samples = samples.grad.clone()
+    for p in range(len(times)):
+        r, _, _ = render_subpose(p, ps)
+        (r.img * v_samples[samp[p]]).sum().backward()
+        print("  sub-pose", p, "done", flush=True)
+    alpha = torch.stack(alphas).mean(dim=0)
+    d = dict(
+        scene=np.array([n, W, H, seed, sh_degree], dtype=np.int64), scene_f=np.array([scale_mult, *vel_mult]),
+        cfg=np.array([H, W, cfg.blur_samples, cfg.rs_bands, sh_degree], dtype=np.int64),
+        cfg_f=np.array([cfg.exposure_time, cfg.rolling_shutter_time, cfg.gamma, cfg.min_rgb_level], dtype=np.float64),
+        background=bg.numpy(), fragile=np.packbits(frag.numpy()), weights_seed=np.array([seed + 1]),
+        out=out.detach().numpy().astype(np.float32), alpha=alpha.numpy().astype(np.float32),
+        sample0=samples[0].detach().numpy().astype(np.float32),
+        samples_mean=samples.detach().mean(dim=(1, 2)).numpy(),
+        p0_radii=radii0.astype(np.int32))
+    for k in names:
+        d["g_" + k] = ps[k].grad.numpy().astype(np.float32 if ps[k].grad.numel() > 100 else np.float64)
+    np.savez_compressed(OUT / f"{name}.npz", **d)
+    rows_g = int((ps["means"].grad.abs().sum(1) > 0).sum())
+    print(name, "out mean", float(out.detach().mean()), "alpha mean", float(alpha.mean()), "fragile px",
+          int(frag.sum()), f"({float(frag.float().mean()):.4f})", "Gaussians with gradient", rows_g)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    make_case("static_small", 600, 64, 48, dict(blur_samples=1, rs_bands=1), seed=11, scale_mult=5.0)
-    make_case("blur_rs_small", 500, 80, 64,
-              dict(blur_samples=3, rs_bands=2, exposure_time=1 / 60, rolling_shutter_time=1 / 30, gamma=2.2,
-                   min_rgb_level=10.0), seed=12)
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only in (None, "small"):
+        make_case("static_small", 600, 64, 48, dict(blur_samples=1, rs_bands=1), seed=11, scale_mult=5.0)
+        make_case("blur_rs_small", 500, 80, 64,
+                  dict(blur_samples=3, rs_bands=2, exposure_time=1 / 60, rolling_shutter_time=1 / 30, gamma=2.2,
+                       min_rgb_level=10.0), seed=12)
+    if only in (None, "large"):
+        make_large_case("blur_large", 24000, 640, 368,
+                        dict(blur_samples=5, rs_bands=1, exposure_time=1 / 60, rolling_shutter_time=0.0, gamma=2.2,
+                             min_rgb_level=10.0), seed=13)

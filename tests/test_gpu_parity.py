@@ -41,6 +41,23 @@ def rel_max(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+# Per-ELEMENT gradient bar against the float64 oracle (a bound relative to the tensor's max says
+# nothing about small gradients): |got - ref| <= GRAD_EL_RTOL * |ref| + GRAD_EL_AFRAC * max|ref|.  The absolute
+# part is the fp32 noise floor of sums of 1e3..1e5 terms that partly cancel (measured worst case ~4e-6 of the
+# tensor's max, run r02_run6); the relative part binds every element above that floor.
+GRAD_EL_RTOL = 1e-4
+GRAD_EL_AFRAC = 1e-5
+FRAGILE_MAX = 0.10    # at most 10 % of the pixels may sit within rounding of a threshold decision
+
+
+def grad_el_ratio(got, ref):
+    """max over elements of |got-ref| / (rtol*|ref| + afrac*max|ref|)  (<= 1 passes)"""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    tol = GRAD_EL_RTOL * np.abs(ref) + GRAD_EL_AFRAC * (np.abs(ref).max() + 1e-300)
+    return float((np.abs(got - ref) / tol).max())
+
+
 def to_dev(sc, dev):
     return {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
 
@@ -271,7 +288,7 @@ def test_rasterize_gaussians_parity(gs, oracle, dev, n, W, H, mult, bg):
     img, alpha = gs.rasterize_gaussians(xd, pr.depths.to(dev), pr.radii.to(dev), cd, pr.num_tiles_hit.to(dev), cold,
                                         od[:, None], H, W, 16, bgd, return_alpha=True)
     good = ~r.fragile
-    assert good.float().mean() > 0.75
+    assert r.fragile.float().mean().item() <= FRAGILE_MAX
     d_img = (img.detach().cpu().double() - img_ref.detach()).abs()
     assert d_img[good].max().item() < IMG_ATOL
     assert (alpha.detach().cpu().double() - alpha_ref.detach()).abs()[good].max().item() < IMG_ATOL
@@ -348,6 +365,39 @@ def test_fused_path_matches_golden(gs, dev, name):
     assert rel_max(p["viewmat"].grad.cpu()[:3], d["g_viewmat"][:3]) < GRAD_RTOL
 
 
+def test_fused_path_matches_large_golden(gs, dev):
+    """24k Gaussians, 640x368, 5 motion-blur sub-poses, SH degree 3, gamma 2.2 (tests/golden/blur_large.npz, float64
+    oracle, generated one sub-pose at a time): image / alpha / first sample on the non-fragile pixels, every gradient
+    element-wise.  The scene is rebuilt from the seeded generator the fixture names (inputs are not stored)."""
+    d = np.load(GOLD / "blur_large.npz")
+    n, W, H, seed, deg = (int(v) for v in d["scene"])
+    mult, lv, av = (float(v) for v in d["scene_f"])
+    Hc, Wc, S, R, _ = (int(v) for v in d["cfg"])
+    et, rt, gamma, mlevel = (float(v) for v in d["cfg_f"])
+    assert (Hc, Wc) == (H, W) and n >= 20000 and W >= 640 and H >= 360 and S == 5
+    sc = gs.data.synthetic_scene(n, W, H, sh_degree=deg, seed=seed, scale_mult=mult)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * lv, sc["ang_vel"] * av
+    frag = np.unpackbits(d["fragile"])[:H * W].reshape(H, W).astype(bool)
+    assert frag.mean() <= FRAGILE_MAX
+    g = torch.Generator().manual_seed(int(d["weights_seed"][0]))
+    wt = torch.rand(H, W, 3, generator=g, dtype=torch.float64) * torch.from_numpy(~frag)[..., None]
+    out, alpha, samples, vms, p, radii = _run_full(gs, None, dev, sc, H, W, S, R, et, rt, gamma, mlevel, deg,
+                                                   torch.from_numpy(d["background"]), wt)
+    good = ~frag
+    assert np.abs(samples[0].detach().cpu().numpy() - d["sample0"])[good].max() < IMG_ATOL
+    assert np.abs(samples.detach().mean(dim=(1, 2)).cpu().numpy() - d["samples_mean"]).max() < 2e-5
+    assert np.abs(out.detach().cpu().numpy() - d["out"])[good].max() < 5e-4
+    assert np.abs(alpha.detach().cpu().numpy() - d["alpha"])[good].max() < IMG_ATOL
+    assert (radii[0].cpu().numpy() != d["p0_radii"]).mean() < 2e-3      # fp32 SE(3) vs float64: a ceil() may move
+    worst = {}
+    for k in ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel"]:
+        worst[k] = grad_el_ratio(p[k].grad.cpu().numpy(), d["g_" + k])
+    worst["viewmat"] = grad_el_ratio(p["viewmat"].grad.cpu().numpy()[:3], d["g_viewmat"][:3])
+    print("blur_large: per-element gradient error / tolerance:", {k: round(v, 3) for k, v in worst.items()})
+    for k, v in worst.items():
+        assert v <= 1.0, (k, v)
+
+
 @pytest.mark.parametrize("S,R,W,H,n", [(1, 1, 160, 96, 3000), (5, 1, 128, 128, 2000), (1, 6, 96, 200, 2000),
                                        (2, 3, 112, 80, 1500)])
 def test_fused_path_vs_oracle_integers_and_image(gs, oracle, dev, S, R, W, H, n):
@@ -376,9 +426,50 @@ def test_fused_path_vs_oracle_integers_and_image(gs, oracle, dev, S, R, W, H, n)
         torch.sigmoid(sc["opacity_logits"].double()), sc["sh"].double(), sc["viewmat"].double(),
         sc["lin_vel"].double(), sc["ang_vel"].double(), background=bg.double(), return_parts=True)
     good = ~frag
-    assert good.float().mean() > 0.75
+    assert frag.float().mean().item() <= FRAGILE_MAX
     assert (samples.detach().cpu().double() - ref_samples)[:, good].abs().max().item() < IMG_ATOL
     assert (out.detach().cpu().double() - ref)[good].abs().max().item() < 5e-4
+
+
+@pytest.mark.parametrize("tag,S,R,W,H,n,mult", [
+    ("config2: 5 motion-blur sub-poses", 5, 1, 240, 136, 6000, 5.0),
+    ("config3: 10 rolling-shutter bands", 1, 10, 160, 240, 5000, 5.0),
+    ("config4: 5 samples x 2 bands", 5, 2, 208, 128, 5000, 5.0),
+    ("config5: 10 motion-blur sub-poses", 10, 1, 192, 112, 4000, 5.0)])
+def test_baseline_configs_vs_float64_oracle_image_and_per_element_gradients(gs, oracle, dev, tag, S, R, W, H, n, mult):
+    """BASELINE.json configs 2-5 at reduced N / resolution with the SAME sub-pose structure (S, R), SH degree 3,
+    gamma 2.2, min-rgb 10: per-sample composites and the averaged image against the float64 oracle, and every
+    gradient ELEMENT-wise (|d| <= 1e-4 |g| + 1e-5 max|g|); at most 10 % of the pixels may be threshold-fragile."""
+    O = oracle
+    sc = O.synthetic_scene(n, W, H, seed=300 + S * 10 + R, scale_mult=mult)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10     # visible motion at this size
+    et, rt, gamma, mlevel = 1 / 60, 1 / 30, 2.2, 10.0
+    bg = torch.tensor([0.05, 0.1, 0.15])
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel", "viewmat"]
+    cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], blur_samples=S, rs_bands=R, exposure_time=et,
+                         rolling_shutter_time=rt, gamma=gamma, min_rgb_level=mlevel)
+    q = {k: sc[k].double().requires_grad_(True) for k in names}
+    ref, ref_alpha, ref_samples, frag, parts, _ = O.render(
+        cfg, q["means"], q["log_scales"].exp(), q["quats"], torch.sigmoid(q["opacity_logits"]), q["sh"], q["viewmat"],
+        q["lin_vel"], q["ang_vel"], background=bg.double(), return_parts=True)
+    good = ~frag
+    assert frag.float().mean().item() <= FRAGILE_MAX, f"{tag}: {frag.float().mean().item():.3f} of the pixels fragile"
+    # the loss ignores the fragile pixels on both sides (a flipped threshold there changes the gradient by O(1))
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)) * good[..., None]
+    (ref * wt.double()).sum().backward()
+    out, alpha, samples, vms, p, radii = _run_full(gs, O, dev, sc, H, W, S, R, et, rt, gamma, mlevel, 3, bg, wt)
+    assert (samples.detach().cpu().double() - ref_samples)[:, good].abs().max().item() < IMG_ATOL
+    assert (out.detach().cpu().double() - ref.detach())[good].abs().max().item() < 5e-4
+    worst = {}
+    for k in names:
+        g_hip, g_ref = p[k].grad.cpu().numpy(), q[k].grad.numpy()
+        if k == "viewmat":
+            g_hip, g_ref = g_hip[:3], g_ref[:3]
+        worst[k] = grad_el_ratio(g_hip, g_ref)
+    print(f"{tag}: per-element gradient error / tolerance:", {k: round(v, 3) for k, v in worst.items()},
+          f"fragile {frag.float().mean().item():.4f}")
+    for k, v in worst.items():
+        assert v <= 1.0, (tag, k, v)
 
 
 @pytest.mark.parametrize("S,R,base", [(1, 1, 4), (3, 2, 16), (2, 1, 1)])
@@ -982,6 +1073,84 @@ def test_full_size_fast_path_equals_plain_path(gs, oracle, dev):
         touched_f = (g_f[k].reshape(n, -1) != 0).any(dim=1)
         touched_p = (g_p[k].reshape(n, -1) != 0).any(dim=1)
         assert torch.equal(touched_f, touched_p), k                  # the same Gaussians receive a gradient
+
+
+_PATH_KNOBS = ("SLICE_BASE", "EXACT_TILE_CULL", "COMPACT_EMIT", "HIT_MASKS", "GRAD_TUPLES", "DEFER_COLOR",
+               "RASTER_FWD_VARIANT", "RASTER_BWD_VARIANT")
+
+
+def _full_size_two_paths(gs, dev, n, W, H, S, R, profile, other, min_slices=1, seed=1234):
+    """default path vs the path configured by `other` (knob -> value) on a full-size seeded scene: images must be
+    bit-identical, the same Gaussians must receive a gradient, gradients equal up to fp32 summation order"""
+    from gsdeblur_amd import ops
+    sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=seed, profile=profile), dev)
+    times, _, _ = gs.subpose_schedule(S, sc["exposure_time"], R, sc["rolling_shutter_time"])
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+    saved = {k: getattr(ops, k) for k in _PATH_KNOBS}
+    res = []
+    try:
+        for knobs in ({}, other):
+            for k, v in saved.items():
+                setattr(ops, k, knobs.get(k, v))
+            p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+            vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"], sc["ang_vel"], torch.tensor(times, device=dev))
+            rgb, _, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
+                                               torch.sigmoid(p["opacity_logits"]), p["sh"], vms, None, S, R, sc["fx"],
+                                               sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2, min_rgb_level=10.0,
+                                               return_alpha=False)
+            (rgb * wt).sum().backward()
+            res.append((rgb.detach().clone(), {k: v.grad.clone() for k, v in p.items()}, ops.last_num_intersects,
+                        list(ops.last_slice_intersects)))
+            del p, rgb, vms
+            torch.cuda.empty_cache()
+    finally:
+        for k, v in saved.items():
+            setattr(ops, k, v)
+    (img_f, g_f, I_f, sl_f), (img_o, g_o, I_o, sl_o) = res
+    assert I_f == I_o
+    assert sum(1 for x in sl_f if x > 0) >= min_slices, sl_f
+    assert torch.isfinite(img_f).all() and torch.equal(img_f, img_o)
+    for k in g_f:
+        assert rel_max(g_f[k].cpu(), g_o[k].cpu()) < GRAD_RTOL, k
+        touched_f = (g_f[k].reshape(n, -1) != 0).any(dim=1)
+        touched_o = (g_o[k].reshape(n, -1) != 0).any(dim=1)
+        assert torch.equal(touched_f, touched_o), k
+    return sl_f, sl_o, I_f, g_f
+
+
+_PLAIN = dict(SLICE_BASE=0, EXACT_TILE_CULL=0, COMPACT_EMIT=0, HIT_MASKS=0, GRAD_TUPLES=0, DEFER_COLOR=0,
+              RASTER_FWD_VARIANT=2, RASTER_BWD_VARIANT=2)
+
+
+def test_full_size_config3_rolling_shutter_bands_equals_plain_path(gs, dev):
+    """BASELINE.json config 3: 1M Gaussians, 1080p, 10 rolling-shutter row bands (S=1, R=10) — default path vs the
+    plainest one (one slice with every bounding-box pair, no culling, atomics, round-1 v_readlane compositors)."""
+    sl_f, sl_o, I, _ = _full_size_two_paths(gs, dev, 1_000_000, 1920, 1080, 1, 10, "survey", _PLAIN)
+    # plain path: ONE slice holding every bounding-box pair of every sub-pose's own row band (a tenth of all pairs)
+    assert len(sl_o) == 1 and 0.05 * I < sl_o[0] < 0.2 * I and sum(sl_f) < 0.3 * sl_o[0]
+
+
+def test_full_size_config4_blur_and_rolling_shutter_share_equals_plain_path(gs, dev):
+    """BASELINE.json config 4, one GPU's share (1 view): 2M Gaussians, 1080p, 5 samples x 2 bands."""
+    sl_f, sl_o, I, _ = _full_size_two_paths(gs, dev, 2_000_000, 1920, 1080, 5, 2, "survey", _PLAIN)
+    assert len(sl_o) == 1 and 0.3 * I < sl_o[0] < 0.7 * I and sum(sl_f) < 0.2 * sl_o[0]
+
+
+def test_full_size_config5_4k_10_subposes_two_slicings_agree(gs, dev):
+    """BASELINE.json config 5, one GPU's share: 5M Gaussians, 3840x2160, 10 sub-poses.  The plainest path cannot
+    hold its 4e9 bounding-box pairs in one 2^31-entry slice, so the default path is compared with a DIFFERENT
+    slicing (4x the budget), without hit masks / deferred colour / tuples and with the round-1 compositors."""
+    other = dict(SLICE_BASE=2048, HIT_MASKS=0, GRAD_TUPLES=0, DEFER_COLOR=0, RASTER_FWD_VARIANT=2, RASTER_BWD_VARIANT=2)
+    sl_f, sl_o, I, _ = _full_size_two_paths(gs, dev, 5_000_000, 3840, 2160, 10, 1, "survey", other)
+    assert I > 2 ** 31 and sum(sl_f) < 0.1 * I
+
+
+def test_full_size_multi_slice_frame_equals_plain_path(gs, dev):
+    """1M Gaussians, 1080p, 5 sub-poses of the fitted-model-like scene (small translucent Gaussians): the default
+    path needs at least three depth slices and a large share of the Gaussians receives a gradient."""
+    sl_f, sl_o, I, g = _full_size_two_paths(gs, dev, 1_000_000, 1920, 1080, 5, 1, "trained", _PLAIN, min_slices=3)
+    assert sl_o == [I]
+    assert (g["means"] != 0).any(dim=1).float().mean().item() > 0.2
 
 
 def test_more_intersections_than_the_slice_plan_covers(gs, dev):
