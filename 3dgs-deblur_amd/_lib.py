@@ -16,14 +16,18 @@ _SIGS = {
     "gs_subpose_viewmats_fwd": [_I, _P, _P, _P, _P, _P, _P],
     "gs_subpose_viewmats_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gs_project_fwd": [_I, _P, _P, _F, _P, _P, _F, _F, _F, _F, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "gs_project_bwd": [_I, _P, _P, _F, _P, _P, _F, _F, _F, _F, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gs_project_bwd": [_I, _P, _P, _F, _P, _P, _F, _F, _F, _F, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "gs_sh_fwd": [_I, _I, _I, _P, _P, _P, _P],
     "gs_sh_bwd": [_I, _I, _I, _P, _P, _P, _P],
     "gs_project_fused_fwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I, _I,
                              _P, _P, _P, _P, _P],
     "gs_slice_colors": [_I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P],
     "gs_project_fused_bwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I,
-                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "gs_project_pixvel_fwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P, _P, _F, _F, _F, _F, _I, _I, _F, _I, _I,
+                              _P, _P, _P, _P, _P],
+    "gs_project_pixvel_bwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P, _P, _F, _F, _F, _F, _I, _I, _F, _I,
+                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "gs_pack_records": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "gs_unpack_record_grads": [_I, _P, _P, _P, _P, _P, _P],
     "gs_exclusive_scan_u32": [_L, _P, _P, _P, _P, _L, _P],

@@ -95,7 +95,28 @@ struct ProjCtx {
   float a, b, c;    // cov2d after dilation
   float a0, c0;     // before dilation
   float det, det0;
+  float radf;       // 3-sigma radius in pixels (integer-valued)
+  int   geom_ok;    // 1 once centre / conic / radius are valid (a false return then only means "covers no tile")
 };
+
+// Tile bounding box of the 3-sigma circle (upstream rule): fills o.tmin/tmax/ntiles; false (and radius = 0, ntiles = 0)
+// when it covers no tile.  Separate from project_one because the pixel-velocity model re-centres the SAME splat
+// per sub-pose (xy + tau * pixel velocity) and only this part changes.
+GS_HD bool tile_bounds(float x, float y, float radf, int tiles_x, int tiles_y, Proj& o) {
+  const float inv_tile = 1.0f / (float)K::kTile;
+  float tcx = x * inv_tile, tcy = y * inv_tile, tr = radf * inv_tile;
+  int x0 = (int)(tcx - tr), x1 = (int)(tcx + tr + 1.0f);
+  int y0 = (int)(tcy - tr), y1 = (int)(tcy + tr + 1.0f);
+  x0 = x0 < 0 ? 0 : (x0 > tiles_x ? tiles_x : x0);
+  x1 = x1 < 0 ? 0 : (x1 > tiles_x ? tiles_x : x1);
+  y0 = y0 < 0 ? 0 : (y0 > tiles_y ? tiles_y : y0);
+  y1 = y1 < 0 ? 0 : (y1 > tiles_y ? tiles_y : y1);
+  int area = (x1 - x0) * (y1 - y0);
+  if (area <= 0) { o.radius = 0; o.ntiles = 0; o.tmin_x = o.tmin_y = o.tmax_x = o.tmax_y = 0; return false; }
+  o.ntiles = area;
+  o.tmin_x = x0; o.tmin_y = y0; o.tmax_x = x1; o.tmax_y = y1;
+  return true;
+}
 
 // Project one Gaussian with covariance c3 (6) under viewmat V (row-major 4x4,
 // rows 0..2 used).  Returns false when culled (near plane / singular / no tile).
@@ -103,6 +124,7 @@ GS_HD bool project_one(const float mean[3], const float c3[6], const float* V,
                        float fx, float fy, float cx, float cy, int img_w, int img_h,
                        int tiles_x, int tiles_y, float clip, Proj& o, ProjCtx& k) {
   o.radius = 0; o.ntiles = 0; o.tmin_x = o.tmin_y = o.tmax_x = o.tmax_y = 0;
+  k.geom_ok = 0; k.radf = 0.f;
   float px = ((V[0] * mean[0] + V[1] * mean[1]) + V[2] * mean[2]) + V[3];
   float py = ((V[4] * mean[0] + V[5] * mean[1]) + V[6] * mean[2]) + V[7];
   float pz = ((V[8] * mean[0] + V[9] * mean[1]) + V[10] * mean[2]) + V[11];
@@ -155,20 +177,9 @@ GS_HD bool project_one(const float mean[3], const float c3[6], const float* V,
   int radius = (int)radf;
   o.x = (fx * px) * rz + cx;
   o.y = (fy * py) * rz + cy;
-  // tile bounding box
-  const float inv_tile = 1.0f / (float)K::kTile;
-  float tcx = o.x * inv_tile, tcy = o.y * inv_tile, tr = radf * inv_tile;
-  int x0 = (int)(tcx - tr), x1 = (int)(tcx + tr + 1.0f);
-  int y0 = (int)(tcy - tr), y1 = (int)(tcy + tr + 1.0f);
-  x0 = x0 < 0 ? 0 : (x0 > tiles_x ? tiles_x : x0);
-  x1 = x1 < 0 ? 0 : (x1 > tiles_x ? tiles_x : x1);
-  y0 = y0 < 0 ? 0 : (y0 > tiles_y ? tiles_y : y0);
-  y1 = y1 < 0 ? 0 : (y1 > tiles_y ? tiles_y : y1);
-  int area = (x1 - x0) * (y1 - y0);
-  if (area <= 0) return false;
-  o.radius = radius; o.ntiles = area;
-  o.tmin_x = x0; o.tmin_y = y0; o.tmax_x = x1; o.tmax_y = y1;
-  return true;
+  o.radius = radius;
+  k.radf = radf; k.geom_ok = 1;
+  return tile_bounds(o.x, o.y, radf, tiles_x, tiles_y, o);
 }
 
 // ---- projection backward -----------------------------------------------------
@@ -176,10 +187,14 @@ GS_HD bool project_one(const float mean[3], const float c3[6], const float* V,
 // Out (accumulated with =, caller sums): v_mean[3], v_cov3d[6] (for upper-triangle
 // parametrisation: off-diagonals carry the sum of both symmetric entries),
 // v_V[12] (rows 0..2 of the viewmat).
+// v_pc_extra (nullable): an additional gradient on the camera-space mean (the pixel-velocity model's).
+// upstream_clamp_grad: gsplat 0.1.11 back-propagates through the fov clamp of x/z, y/z as if it were inactive
+// (DESIGN.md §1 deviation 2); false = the true derivative.
 GS_HD void project_one_bwd(const float mean[3], const float c3[6], const float* V,
                            float fx, float fy, const ProjCtx& k, float comp,
                            const float v_xy[2], float v_depth, const float v_conic[3], float v_comp,
-                           float v_mean[3], float v_c3[6], float v_V[12]) {
+                           float v_mean[3], float v_c3[6], float v_V[12],
+                           const float* v_pc_extra = nullptr, bool upstream_clamp_grad = false) {
   const float a = k.a, b = k.b, c = k.c, det = k.det;
   const float inv_det = 1.0f / det, inv_det2 = inv_det * inv_det;
   // conic -> (a,b,c)
@@ -233,12 +248,13 @@ GS_HD void project_one_bwd(const float mean[3], const float c3[6], const float* 
   float v_ty = -fy * rz2 * vJ12;
   float v_pz = -fx * rz2 * vJ00 - fy * rz2 * vJ11 + 2.f * fx * k.tx * rz3 * vJ02 + 2.f * fy * k.ty * rz3 * vJ12;
   float v_px = 0.f, v_py = 0.f;
-  if (k.clamp_x == 0) v_px += v_tx; else v_pz += v_tx * (k.tx * rz);  // tx = (+-lim) * z
-  if (k.clamp_y == 0) v_py += v_ty; else v_pz += v_ty * (k.ty * rz);
+  if (k.clamp_x == 0 || upstream_clamp_grad) v_px += v_tx; else v_pz += v_tx * (k.tx * rz);  // tx = (+-lim) * z
+  if (k.clamp_y == 0 || upstream_clamp_grad) v_py += v_ty; else v_pz += v_ty * (k.ty * rz);
   // pixel centre + depth
   v_px += fx * rz * v_xy[0];
   v_py += fy * rz * v_xy[1];
   v_pz += -(fx * px * rz2 * v_xy[0] + fy * py * rz2 * v_xy[1]) + v_depth;
+  if (v_pc_extra) { v_px += v_pc_extra[0]; v_py += v_pc_extra[1]; v_pz += v_pc_extra[2]; }
   // pc = W mean + t
   v_mean[0] = V[0] * v_px + V[4] * v_py + V[8] * v_pz;
   v_mean[1] = V[1] * v_px + V[5] * v_py + V[9] * v_pz;
@@ -248,9 +264,49 @@ GS_HD void project_one_bwd(const float mean[3], const float c3[6], const float* 
   v_V[8] = vW[6] + v_pz * mean[0]; v_V[9] = vW[7] + v_pz * mean[1]; v_V[10] = vW[8] + v_pz * mean[2]; v_V[11] = v_pz;
 }
 
+// ---- pixel velocity (the paper's first-order blur / rolling-shutter model) ------------------
+// A static point seen from a camera moving with body twist (lin, ang) (camera frame) moves in camera space with
+// velocity u = -(ang x pc + lin); its pixel moves with  pv = J u,  J = d(pixel)/d(pc) of the (unclamped) pinhole
+// projection.  The splat rendered at time tau sits at xy + tau * pv; covariance, opacity, colour and depth order are
+// those of the mid-exposure pose.
+GS_HD void pixel_velocity(const float pc[3], float rz, float fx, float fy, const float lin[3], const float ang[3],
+                          float pv[2]) {
+  const float ux = -(ang[1] * pc[2] - ang[2] * pc[1]) - lin[0];
+  const float uy = -(ang[2] * pc[0] - ang[0] * pc[2]) - lin[1];
+  const float uz = -(ang[0] * pc[1] - ang[1] * pc[0]) - lin[2];
+  const float rz2 = rz * rz;
+  pv[0] = (fx * rz) * ux - ((fx * pc[0]) * rz2) * uz;
+  pv[1] = (fy * rz) * uy - ((fy * pc[1]) * rz2) * uz;
+}
+
+// VJP of pixel_velocity: v_pv[2] -> v_pc[3] (=), v_lin[3] (=), v_ang[3] (=)
+GS_HD void pixel_velocity_bwd(const float pc[3], float rz, float fx, float fy, const float lin[3], const float ang[3],
+                              const float v_pv[2], float v_pc[3], float v_lin[3], float v_ang[3]) {
+  const float ux = -(ang[1] * pc[2] - ang[2] * pc[1]) - lin[0];
+  const float uy = -(ang[2] * pc[0] - ang[0] * pc[2]) - lin[1];
+  const float uz = -(ang[0] * pc[1] - ang[1] * pc[0]) - lin[2];
+  const float rz2 = rz * rz, rz3 = rz2 * rz;
+  const float gx = v_pv[0], gy = v_pv[1];
+  const float vu[3] = {fx * rz * gx, fy * rz * gy, -(fx * pc[0] * rz2 * gx + fy * pc[1] * rz2 * gy)};
+  // through J(pc)
+  v_pc[0] = -(fx * rz2 * uz) * gx;
+  v_pc[1] = -(fy * rz2 * uz) * gy;
+  v_pc[2] = gx * (-fx * rz2 * ux + 2.f * fx * pc[0] * rz3 * uz) + gy * (-fy * rz2 * uy + 2.f * fy * pc[1] * rz3 * uz);
+  // through u = -ang x pc - lin :  v_pc += ang x v_u ;  v_ang = v_u x pc ;  v_lin = -v_u
+  v_pc[0] += ang[1] * vu[2] - ang[2] * vu[1];
+  v_pc[1] += ang[2] * vu[0] - ang[0] * vu[2];
+  v_pc[2] += ang[0] * vu[1] - ang[1] * vu[0];
+  v_ang[0] = vu[1] * pc[2] - vu[2] * pc[1];
+  v_ang[1] = vu[2] * pc[0] - vu[0] * pc[2];
+  v_ang[2] = vu[0] * pc[1] - vu[1] * pc[0];
+  v_lin[0] = -vu[0]; v_lin[1] = -vu[1]; v_lin[2] = -vu[2];
+}
+
 // cov3d (upper-triangle grads as produced above) -> scale, quat grads.
+// raw_quat_grad: gsplat 0.1.11 returns the gradient w.r.t. the (assumed unit) quaternion without the projection
+// through q/|q| (DESIGN.md §1 deviation 3); false = gradient of the normalising kernel.
 GS_HD void cov3d_bwd(const float s[3], float glob, const float q[4], const float v_c3[6],
-                     float v_s[3], float v_q[4]) {
+                     float v_s[3], float v_q[4], bool raw_quat_grad = false) {
   float R[9], qn[4], inv;
   quat_to_rotmat(q, R, qn, &inv);
   float M[9], c3[6];
@@ -281,6 +337,7 @@ GS_HD void cov3d_bwd(const float s[3], float glob, const float q[4], const float
   g[1] = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[3] + vR[1]) + z * (vR[6] + vR[2]) + w * (vR[7] - vR[5]));
   g[2] = 2.f * (x * (vR[3] + vR[1]) - 2.f * y * (vR[0] + vR[8]) + z * (vR[7] + vR[5]) + w * (vR[2] - vR[6]));
   g[3] = 2.f * (x * (vR[6] + vR[2]) + y * (vR[7] + vR[5]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
+  if (raw_quat_grad) { v_q[0] = g[0]; v_q[1] = g[1]; v_q[2] = g[2]; v_q[3] = g[3]; return; }
   // through the normalisation q/|q|
   float dotp = g[0] * w + g[1] * x + g[2] * y + g[3] * z;
   v_q[0] = (g[0] - w * dotp) * inv;

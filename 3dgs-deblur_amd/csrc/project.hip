@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int N, const float* __
     const float* __restrict__ scales, float glob, const float* __restrict__ quats, const float* __restrict__ V,
     Intrin in, const float* __restrict__ v_xys, const float* __restrict__ v_depths,
     const float* __restrict__ v_conics, const float* __restrict__ v_comp, float* __restrict__ v_means,
-    float* __restrict__ v_scales, float* __restrict__ v_quats, float* __restrict__ v_V) {
+    float* __restrict__ v_scales, float* __restrict__ v_quats, float* __restrict__ v_V, int flags) {
   __shared__ float lds[48];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   float vV[12];
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int N, const float* __
       float vc[3] = {v_conics[3 * i], v_conics[3 * i + 1], v_conics[3 * i + 2]};
       float vc3[6];
       project_one_bwd(m, c3, Vm, in.fx, in.fy, k, o.comp, vxy, v_depths ? v_depths[i] : 0.f, vc,
-                      v_comp ? v_comp[i] : 0.f, vm, vc3, vV);
-      cov3d_bwd(s, glob, q, vc3, vs, vq);
+                      v_comp ? v_comp[i] : 0.f, vm, vc3, vV, nullptr, (flags & 1) != 0);
+      cov3d_bwd(s, glob, q, vc3, vs, vq, (flags & 2) != 0);
     }
     for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = vm[j]; v_scales[3 * i + j] = vs[j]; }
     for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = vq[j];
@@ -249,7 +249,16 @@ struct FusedParams {
   int K_stride, deg, antialiased;
   int defer_color;   // 1: leave rgb = 0, gs_slice_colors fills it for the Gaussians a depth slice actually emits
   Intrin in;
+  // pixel-velocity model (SURVEY App. A "Paper's blur/RS model"): ONE projection under viewmats[0] (mid-exposure),
+  // sub-pose p re-centres the splat at xy + times[p] * pixel_velocity; twist = {lin[3], ang[3]} (device)
+  int pixvel;
+  const float* twist;
+  const float* times;
+  int flags;         // GS_FLAG_* : upstream-compatible gradient conventions (backward only)
 };
+
+constexpr int GS_FLAG_UPSTREAM_FOV_CLAMP_GRAD = 1;   // back-propagate through the fov clamp as if inactive
+constexpr int GS_FLAG_RAW_QUAT_GRAD = 2;             // no projection of the quaternion gradient through q/|q|
 
 template <int MAXB>
 __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, float* __restrict__ records,
@@ -273,14 +282,41 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
 #pragma unroll
     for (int k = 0; k < MAXB * 3; ++k) coef[k] = 0.f;
   }
+  // pixel-velocity model: geometry of the mid-exposure pose once, then one re-centred record per sub-pose
+  Proj o0; ProjCtx k0;
+  float pv[2] = {0.f, 0.f};
+  if (fp.pixvel) {
+    float Vm0[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) Vm0[j] = fp.viewmats[j];
+    project_one(m, c3, Vm0, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x, fp.in.tiles_y,
+                fp.in.clip, o0, k0);
+    if (k0.geom_ok) {
+      const float lin[3] = {fp.twist[0], fp.twist[1], fp.twist[2]}, ang[3] = {fp.twist[3], fp.twist[4], fp.twist[5]};
+      pixel_velocity(k0.pc, k0.rz, fp.in.fx, fp.in.fy, lin, ang, pv);
+    }
+  }
   for (int p = 0; p < fp.P; ++p) {
-    const float* V = fp.viewmats + 16 * p;
+    const float* V = fp.viewmats + (fp.pixvel ? 0 : 16 * p);
     float Vm[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) Vm[j] = V[j];
     Proj o; ProjCtx k;
-    bool ok = project_one(m, c3, Vm, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x,
-                          fp.in.tiles_y, fp.in.clip, o, k);
+    bool ok;
+    if (fp.pixvel) {
+      o = o0; k = k0;
+      ok = k0.geom_ok != 0;
+      if (ok) {
+        const float tau = fp.times[p];
+        o.x = o0.x + tau * pv[0];
+        o.y = o0.y + tau * pv[1];
+        o.radius = (int)k0.radf;
+        ok = tile_bounds(o.x, o.y, k0.radf, fp.in.tiles_x, fp.in.tiles_y, o);
+      }
+    } else {
+      ok = project_one(m, c3, Vm, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x,
+                       fp.in.tiles_y, fp.in.clip, o, k);
+    }
     size_t idx = (size_t)p * fp.N + i;
     float4* r = reinterpret_cast<float4*>(records + idx * kRecFloats);
     if (ok) {
@@ -323,7 +359,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
     const float* __restrict__ v_records, float* __restrict__ v_means, float* __restrict__ v_scales,
     float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
     float* __restrict__ v_viewmats, const unsigned char* __restrict__ touched, float* __restrict__ v_xy_sum,
-    int i, bool live, float* lds) {
+    int i, bool live, float* lds, float* __restrict__ v_twist = nullptr) {
   const int ii = live ? i : 0;
   float m[3] = {0.f, 0.f, 1.f}, s[3] = {1.f, 1.f, 1.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, opac = 0.f;
   if (live) {
@@ -340,6 +376,69 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
 #pragma unroll
   for (int k = 0; k < MAXB * 3; ++k) vcoef[k] = 0.f;
   float vm[3] = {0.f, 0.f, 0.f}, vc3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vop = 0.f, vxs = 0.f, vys = 0.f;
+  const bool up_clamp = (fp.flags & GS_FLAG_UPSTREAM_FOV_CLAMP_GRAD) != 0;
+  if (fp.pixvel) {
+    // pixel-velocity model: the P records of a Gaussian are ONE projection re-centred at xy + tau_p * pv, so their
+    // gradients are summed first (d xy = sum_p, d pv = sum_p tau_p * d xy_p) and pushed through one projection
+    // backward plus the pixel-velocity VJP (-> camera-space mean, twist)
+    float Vm[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) Vm[j] = fp.viewmats[j];
+    float vV[12], vtw[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { vV[j] = 0.f; vtw[j] = 0.f; }
+    bool mine = false;
+    if (live)
+      for (int p = 0; p < fp.P; ++p) mine |= (!touched || touched[(size_t)p * fp.N + ii]);
+    if (mine) {
+      Proj o; ProjCtx k;
+      project_one(m, c3, Vm, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x, fp.in.tiles_y,
+                  fp.in.clip, o, k);
+      if (k.geom_ok) {
+        float vxy[2] = {0.f, 0.f}, vpv[2] = {0.f, 0.f}, vcon[3] = {0.f, 0.f, 0.f}, v_comp = 0.f;
+        float vr = 0.f, vg = 0.f, vb = 0.f;
+        for (int p = 0; p < fp.P; ++p) {
+          if (touched && !touched[(size_t)p * fp.N + ii]) continue;
+          const float tau = fp.times[p];
+          size_t idx = (size_t)p * fp.N + ii;
+          const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kRecFloats);
+          float4 ga = g4[0], gb = g4[1], gc = g4[2];
+          const float4* r4 = reinterpret_cast<const float4*>(records + idx * kRecFloats);
+          float4 ra = r4[0], rb = r4[1], rc = r4[2];
+          // a sub-pose in which the re-centred splat covers no tile has an all-zero record and takes no gradient
+          if (ra.z == 0.f && ra.w == 0.f && rb.x == 0.f) continue;
+          vr += rb.z > 0.f ? gb.z : 0.f; vg += rb.w > 0.f ? gb.w : 0.f; vb += rc.x > 0.f ? gc.x : 0.f;
+          if (fp.antialiased) { vop += gb.y * o.comp; v_comp += gb.y * opac; } else { vop += gb.y; }
+          vxy[0] += ga.x; vxy[1] += ga.y;
+          vpv[0] += tau * ga.x; vpv[1] += tau * ga.y;
+          vcon[0] += ga.z; vcon[1] += ga.w; vcon[2] += gb.x;
+        }
+        vxs = vxy[0]; vys = vxy[1];
+        if (vr != 0.f || vg != 0.f || vb != 0.f) {
+          float cxw = -(Vm[0] * Vm[3] + Vm[4] * Vm[7] + Vm[8] * Vm[11]);
+          float cyw = -(Vm[1] * Vm[3] + Vm[5] * Vm[7] + Vm[9] * Vm[11]);
+          float czw = -(Vm[2] * Vm[3] + Vm[6] * Vm[7] + Vm[10] * Vm[11]);
+          float dx = m[0] - cxw, dy = m[1] - cyw, dz = m[2] - czw;
+          float dinv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+          float B[MAXB];
+          sh_basis(fp.deg, dx * dinv, dy * dinv, dz * dinv, B);
+#pragma unroll
+          for (int b = 0; b < MAXB; ++b) {
+            if (b < nb) { vcoef[3 * b] += B[b] * vr; vcoef[3 * b + 1] += B[b] * vg; vcoef[3 * b + 2] += B[b] * vb; }
+          }
+        }
+        const float lin[3] = {fp.twist[0], fp.twist[1], fp.twist[2]}, ang[3] = {fp.twist[3], fp.twist[4], fp.twist[5]};
+        float vpc[3], vlin[3], vang[3];
+        pixel_velocity_bwd(k.pc, k.rz, fp.in.fx, fp.in.fy, lin, ang, vpv, vpc, vlin, vang);
+        vtw[0] = vlin[0]; vtw[1] = vlin[1]; vtw[2] = vlin[2]; vtw[3] = vang[0]; vtw[4] = vang[1]; vtw[5] = vang[2];
+        project_one_bwd(m, c3, Vm, fp.in.fx, fp.in.fy, k, o.comp, vxy, 0.f, vcon, v_comp, vm, vc3, vV, vpc, up_clamp);
+      }
+    }
+    if (__syncthreads_or(mine)) {
+      if (v_viewmats) reduce_vV(vV, v_viewmats, lds);
+      if (v_twist) reduce_vV(vtw, v_twist, lds);       // 6 components, padded to the reducer's 12
+    }
+  } else
   for (int p = 0; p < fp.P; ++p) {
     const float* V = fp.viewmats + 16 * p;
     float Vm[12];
@@ -382,7 +481,8 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
         vxs += ga.x; vys += ga.y;
         float vcon[3] = {ga.z, ga.w, gb.x};
         float vm1[3], vc31[6];
-        project_one_bwd(m, c3, Vm, fp.in.fx, fp.in.fy, k, o.comp, vxy, 0.f, vcon, v_comp, vm1, vc31, vV);
+        project_one_bwd(m, c3, Vm, fp.in.fx, fp.in.fy, k, o.comp, vxy, 0.f, vcon, v_comp, vm1, vc31, vV, nullptr,
+                        up_clamp);
         for (int j = 0; j < 3; ++j) vm[j] += vm1[j];
         for (int j = 0; j < 6; ++j) vc3[j] += vc31[j];
       }
@@ -392,7 +492,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
   }
   if (!live) return;
   float vs[3], vq[4];
-  cov3d_bwd(s, fp.glob, q, vc3, vs, vq);
+  cov3d_bwd(s, fp.glob, q, vc3, vs, vq, (fp.flags & GS_FLAG_RAW_QUAT_GRAD) != 0);
   for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = vm[j]; v_scales[3 * i + j] = vs[j]; }
   for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = vq[j];
   v_opac[i] = vop;
@@ -410,11 +510,12 @@ template <int MAXB>
 __global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, const float* __restrict__ records,
     const float* __restrict__ v_records, float* __restrict__ v_means, float* __restrict__ v_scales,
     float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
-    float* __restrict__ v_viewmats /* [P,16] accumulated, may be null */, float* __restrict__ v_xy_sum) {
+    float* __restrict__ v_viewmats /* [P,16] accumulated, may be null */, float* __restrict__ v_xy_sum,
+    float* __restrict__ v_twist) {
   __shared__ float lds[48];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   fused_bwd_body<MAXB>(fp, records, v_records, v_means, v_scales, v_quats, v_opac, v_sh, v_viewmats, nullptr,
-                       v_xy_sum, i, i < fp.N, lds);
+                       v_xy_sum, i, i < fp.N, lds, v_twist);
 }
 
 // sparse launch (touched flags; the caller pre-zeroes every output): under early termination ~1 % of the
@@ -428,7 +529,7 @@ __global__ __launch_bounds__(256) void project_fused_bwd_sparse_kernel(FusedPara
     const float* __restrict__ records, const float* __restrict__ v_records, float* __restrict__ v_means,
     float* __restrict__ v_scales, float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
     float* __restrict__ v_viewmats, const unsigned char* __restrict__ touched /* [P*N] */,
-    float* __restrict__ v_xy_sum) {
+    float* __restrict__ v_xy_sum, float* __restrict__ v_twist) {
   __shared__ float lds[48];
   __shared__ int list[kFusedChunk];
   __shared__ int wave_cnt[4];
@@ -454,7 +555,7 @@ __global__ __launch_bounds__(256) void project_fused_bwd_sparse_kernel(FusedPara
     const int k = k0 + (int)threadIdx.x;
     const bool live = k < n_list;
     fused_bwd_body<MAXB>(fp, records, v_records, v_means, v_scales, v_quats, v_opac, v_sh, v_viewmats, touched,
-                         v_xy_sum, live ? list[k] : 0, live, lds);
+                         v_xy_sum, live ? list[k] : 0, live, lds, v_twist);
   }
 }
 
@@ -540,12 +641,13 @@ GS_EXPORT int gs_project_fwd(int N, const float* means, const float* scales, flo
 GS_EXPORT int gs_project_bwd(int N, const float* means, const float* scales, float glob_scale, const float* quats,
                              const float* viewmat, float fx, float fy, float cx, float cy, int H, int W, float clip,
                              const float* v_xys, const float* v_depths, const float* v_conics, const float* v_comp,
-                             float* v_means, float* v_scales, float* v_quats, float* v_viewmat, void* stream) {
+                             float* v_means, float* v_scales, float* v_quats, float* v_viewmat, int grad_flags,
+                             void* stream) {
   if (N <= 0) return GS_ERR_INVALID;
   Intrin in = make_intrin(fx, fy, cx, cy, H, W, clip);
   hipLaunchKernelGGL(project_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, means, scales,
                      glob_scale, quats, viewmat, in, v_xys, v_depths, v_conics, v_comp, v_means, v_scales, v_quats,
-                     v_viewmat);
+                     v_viewmat, grad_flags);
   return gs_launch_status();
 }
 
@@ -594,6 +696,7 @@ static inline FusedParams make_fused(int N, int P, const float* means, const flo
   fp.viewmats = viewmats; fp.glob = glob; fp.K_stride = K_stride; fp.deg = deg; fp.antialiased = antialiased;
   fp.defer_color = defer_color;
   fp.in = make_intrin(fx, fy, cx, cy, H, W, clip);
+  fp.pixvel = 0; fp.twist = nullptr; fp.times = nullptr; fp.flags = 0;
   return fp;
 }
 
@@ -635,36 +738,91 @@ GS_EXPORT int gs_slice_colors(int n_slice, const unsigned* slice_gi, const unsig
   return gs_launch_status();
 }
 
+static int launch_fused_bwd(const FusedParams& fp, int sh_degree, const float* records, const float* v_records,
+                            float* v_means, float* v_scales, float* v_quats, float* v_opacities, float* v_sh,
+                            float* v_viewmats, const unsigned char* touched, float* v_xy_sum, float* v_twist,
+                            hipStream_t st) {
+  dim3 block(256);
+  const int N = fp.N;
+  if (touched) {
+    dim3 grid((N + kFusedChunk - 1) / kFusedChunk);
+    if (sh_degree <= 3)
+      hipLaunchKernelGGL(project_fused_bwd_sparse_kernel<16>, grid, block, 0, st, fp, records, v_records, v_means,
+                         v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched, v_xy_sum, v_twist);
+    else
+      hipLaunchKernelGGL(project_fused_bwd_sparse_kernel<25>, grid, block, 0, st, fp, records, v_records, v_means,
+                         v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched, v_xy_sum, v_twist);
+  } else {
+    dim3 grid((N + 255) / 256);
+    if (sh_degree <= 3)
+      hipLaunchKernelGGL(project_fused_bwd_kernel<16>, grid, block, 0, st, fp, records, v_records, v_means, v_scales,
+                         v_quats, v_opacities, v_sh, v_viewmats, v_xy_sum, v_twist);
+    else
+      hipLaunchKernelGGL(project_fused_bwd_kernel<25>, grid, block, 0, st, fp, records, v_records, v_means, v_scales,
+                         v_quats, v_opacities, v_sh, v_viewmats, v_xy_sum, v_twist);
+  }
+  return gs_launch_status();
+}
+
 // Backward of the fused projection.  v_viewmats [P,16] is accumulated into (caller zeroes; nullable).
+// grad_flags: 1 = back-propagate through the fov clamp as upstream gsplat 0.1.11 does (as if inactive), 2 = return
+// the quaternion gradient without the projection through q/|q| (deviations 2 and 3).
 GS_EXPORT int gs_project_fused_bwd(int N, int P, const float* means, const float* scales, float glob_scale,
                                    const float* quats, const float* opacities, const float* sh, int K_stride,
                                    int sh_degree, const float* viewmats, float fx, float fy, float cx, float cy,
                                    int H, int W, float clip, int antialiased, const float* records,
                                    const float* v_records, float* v_means, float* v_scales, float* v_quats,
                                    float* v_opacities, float* v_sh, float* v_viewmats,
-                                   const unsigned char* touched, float* v_xy_sum, void* stream) {
+                                   const unsigned char* touched, float* v_xy_sum, int grad_flags, void* stream) {
   if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride)
     return GS_ERR_INVALID;
   FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmats,
                               fx, fy, cx, cy, H, W, clip, antialiased);
-  dim3 block(256);
-  hipStream_t st = (hipStream_t)stream;
-  if (touched) {
-    dim3 grid((N + kFusedChunk - 1) / kFusedChunk);
-    if (sh_degree <= 3)
-      hipLaunchKernelGGL(project_fused_bwd_sparse_kernel<16>, grid, block, 0, st, fp, records, v_records, v_means,
-                         v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched, v_xy_sum);
-    else
-      hipLaunchKernelGGL(project_fused_bwd_sparse_kernel<25>, grid, block, 0, st, fp, records, v_records, v_means,
-                         v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched, v_xy_sum);
-  } else {
-    dim3 grid((N + 255) / 256);
-    if (sh_degree <= 3)
-      hipLaunchKernelGGL(project_fused_bwd_kernel<16>, grid, block, 0, st, fp, records, v_records, v_means, v_scales,
-                         v_quats, v_opacities, v_sh, v_viewmats, v_xy_sum);
-    else
-      hipLaunchKernelGGL(project_fused_bwd_kernel<25>, grid, block, 0, st, fp, records, v_records, v_means, v_scales,
-                         v_quats, v_opacities, v_sh, v_viewmats, v_xy_sum);
-  }
+  fp.flags = grad_flags;
+  return launch_fused_bwd(fp, sh_degree, records, v_records, v_means, v_scales, v_quats, v_opacities, v_sh, v_viewmats,
+                          touched, v_xy_sum, nullptr, (hipStream_t)stream);
+}
+
+// ---- pixel-velocity model (the paper's first-order blur / rolling-shutter model; SURVEY App. A, C1;
+// /root/reference/README.md:200 "Fixed a bug in pixel velocity formulas") ---------------------------------------------
+// ONE projection under `viewmat` (mid-exposure pose); sub-pose p's record is the same splat re-centred at
+// xy + times[p] * pv, pv = J(-(ang x pc + lin)); conic, opacity, colour and the depth key are shared by all P.
+GS_EXPORT int gs_project_pixvel_fwd(int N, int P, const float* means, const float* scales, float glob_scale,
+                                    const float* quats, const float* opacities, const float* sh, int K_stride,
+                                    int sh_degree, const float* viewmat, const float* twist, const float* times,
+                                    float fx, float fy, float cx, float cy, int H, int W, float clip, int antialiased,
+                                    int defer_color, float* records, unsigned* depth_keys, int* num_tiles_hit,
+                                    int* radii, void* stream) {
+  if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride || !twist ||
+      !times)
+    return GS_ERR_INVALID;
+  FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmat,
+                              fx, fy, cx, cy, H, W, clip, antialiased, defer_color);
+  fp.pixvel = 1; fp.twist = twist; fp.times = times;
+  dim3 grid((N + 255) / 256), block(256);
+  if (sh_degree <= 3)
+    hipLaunchKernelGGL(project_fused_fwd_kernel<16>, grid, block, 0, (hipStream_t)stream, fp, records, depth_keys,
+                       num_tiles_hit, radii);
+  else
+    hipLaunchKernelGGL(project_fused_fwd_kernel<25>, grid, block, 0, (hipStream_t)stream, fp, records, depth_keys,
+                       num_tiles_hit, radii);
   return gs_launch_status();
+}
+
+// v_viewmat [16] and v_twist [12: lin 3, ang 3, 6 unused] are accumulated into (caller zeroes; nullable)
+GS_EXPORT int gs_project_pixvel_bwd(int N, int P, const float* means, const float* scales, float glob_scale,
+                                    const float* quats, const float* opacities, const float* sh, int K_stride,
+                                    int sh_degree, const float* viewmat, const float* twist, const float* times,
+                                    float fx, float fy, float cx, float cy, int H, int W, float clip, int antialiased,
+                                    const float* records, const float* v_records, float* v_means, float* v_scales,
+                                    float* v_quats, float* v_opacities, float* v_sh, float* v_viewmat, float* v_twist,
+                                    const unsigned char* touched, float* v_xy_sum, int grad_flags, void* stream) {
+  if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride || !twist ||
+      !times)
+    return GS_ERR_INVALID;
+  FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmat,
+                              fx, fy, cx, cy, H, W, clip, antialiased);
+  fp.pixvel = 1; fp.twist = twist; fp.times = times; fp.flags = grad_flags;
+  return launch_fused_bwd(fp, sh_degree, records, v_records, v_means, v_scales, v_quats, v_opacities, v_sh, v_viewmat,
+                          touched, v_xy_sum, v_twist, (hipStream_t)stream);
 }

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
 #endif
   const int* __restrict__ vals = prm.sorted_vals;
   const float kL2E = -1.4426950408889634f;
+  const float agm = prm.alpha_grad_max;
   const int row = lane;                        // row-sum role: lanes 0..35
   const int row_g = row / 9, row_c = row - row_g * 9;
 
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
           const f2 v_al = Tk2[h] * cv - ra * Dv2[h];
           Dv2[h] += fac * cv;
           // d min(0.999, o*vis) = 0 when clamped
-          const bool f0 = h0 && ov2[h].x <= K::kAlphaMax, f1 = h1 && ov2[h].y <= K::kAlphaMax;
+          const bool f0 = h0 && ov2[h].x <= agm, f1 = h1 && ov2[h].y <= agm;
           const f2 ovm = {f0 ? ov2[h].x : 0.f, f1 ? ov2[h].y : 0.f};
           const f2 vism = {f0 ? vis2[h].x : 0.f, f1 ? vis2[h].y : 0.f};
           const f2 v_sigma = -ovm * v_al;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
             const float cv = cr * vr[k] + cg * vg[k] + cb * vb[k];
             const float v_al = Tk[k] * cv - ra * Dv[k];
             Dv[k] += fac * cv;
-            const bool free_ = ov[k] <= K::kAlphaMax;     // d min(0.999, o*vis) = 0 when clamped
+            const bool free_ = ov[k] <= agm;     // d min(0.999, o*vis) = 0 when clamped
             const float v_sigma = free_ ? -ov[k] * v_al : 0.f;
             p_op += free_ ? vis[k] * v_al : 0.f;
             const float vsdy = v_sigma * dy;
@@ -358,7 +359,7 @@ __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementw
 // one list entry against the lane's four pixels; returns whether any lane of the wave was hit (then the lane's 9
 // partial sums are in LDS rows slot*9 .. slot*9+8, column `lane`)
 __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, BwdPair (&pp)[2], float* __restrict__ red,
-                                          int slot, int lane) {
+                                          int slot, int lane, float agm) {
   const float kL2E = -1.4426950408889634f;
   const float qx = rc.cx * (0.5f * kL2E), qy = rc.cy * kL2E, qz = rc.cz * (0.5f * kL2E);
   const float dx = rc.x - pxf;
@@ -395,7 +396,7 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
     const f2 v_al = fma2(q.T, cv, -(ra * q.Dv));
     q.Dv = fma2(fac, cv, q.Dv);
     // d min(0.999, o*vis) = 0 when clamped
-    const bool f0 = h0 && ov2[h].x <= K::kAlphaMax, f1 = h1 && ov2[h].y <= K::kAlphaMax;
+    const bool f0 = h0 && ov2[h].x <= agm, f1 = h1 && ov2[h].y <= agm;
     const f2 ovm = {f0 ? ov2[h].x : 0.f, f1 ? ov2[h].y : 0.f};
     const f2 vism = {f0 ? vis2[h].x : 0.f, f1 ? vis2[h].y : 0.f};
     const f2 v_sigma = -ovm * v_al;
@@ -478,6 +479,7 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_sload_kernel(
   }
   const int wave_end = __builtin_amdgcn_readfirstlane(wave_max_i(my_end));
   const unsigned n = (unsigned)(wave_end - range.x);       // entries [range.x, wave_end) reached some pixel's final index
+  const float agm = prm.alpha_grad_max;
   const int row = lane;                                    // row-sum role: lanes 0..35
   const int row_g = row / 9, row_c = row - row_g * 9;
   if (n != 0u) {
@@ -499,14 +501,14 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_sload_kernel(
       idv = ids4[max(b - 4, 0) >> 2];
       asm volatile("" ::: "memory");
       unsigned filled = 0;
-      if ((unsigned)(b + 3 - range.x) < n && bwd_entry(a0, pxf, b + 3, pp, red, 3, lane)) filled |= 8u;
-      if ((unsigned)(b + 2 - range.x) < n && bwd_entry(a1, pxf, b + 2, pp, red, 2, lane)) filled |= 4u;
+      if ((unsigned)(b + 3 - range.x) < n && bwd_entry(a0, pxf, b + 3, pp, red, 3, lane, agm)) filled |= 8u;
+      if ((unsigned)(b + 2 - range.x) < n && bwd_entry(a1, pxf, b + 2, pp, red, 2, lane, agm)) filled |= 4u;
       // pair B is ready; refill pair A from the next group
       asm volatile("" :: "s"(b0.x), "s"(b1.x), "s"(idv.x), "s"(ev.x) : "memory");
       a0 = load_rec_s(records, min((unsigned)idv.w, max_id)); a1 = load_rec_s(records, min((unsigned)idv.z, max_id));
       asm volatile("" ::: "memory");
-      if ((unsigned)(b + 1 - range.x) < n && bwd_entry(b0, pxf, b + 1, pp, red, 1, lane)) filled |= 2u;
-      if ((unsigned)(b - range.x) < n && bwd_entry(b1, pxf, b, pp, red, 0, lane)) filled |= 1u;
+      if ((unsigned)(b + 1 - range.x) < n && bwd_entry(b0, pxf, b + 1, pp, red, 1, lane, agm)) filled |= 2u;
+      if ((unsigned)(b - range.x) < n && bwd_entry(b1, pxf, b, pp, red, 0, lane, agm)) filled |= 1u;
       if (filled) {
         __builtin_amdgcn_wave_barrier();
         if (row < kRedG4 * 9 && ((filled >> row_g) & 1u)) {
@@ -673,6 +675,7 @@ GS_EXPORT int gs_rasterize_bwd(const float* records, const int* sorted_vals, con
                                float* v_records, int n_records, int variant, void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
+  if (variant & 256) { prm.alpha_grad_max = 3.0e38f; variant &= ~256; }
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
   if (n_records > 0 && variant == 0)
@@ -700,6 +703,7 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
   prm.gi_of_e = gi_of_e;
   prm.cmb_scale = cmb_scale; prm.cmb_gamma = cmb_gamma; prm.cmb_min = cmb_min_level;
+  if (variant & 256) { prm.alpha_grad_max = 3.0e38f; variant &= ~256; }
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
   hipStream_t st = (hipStream_t)stream;

@@ -20,6 +20,9 @@ struct RasterParams {
   // (gs_combine_bwd_scale: the part of the chain rule that is the same for all S samples).
   const float* cmb_scale;
   float cmb_gamma, cmb_min;
+  // backward only: d min(0.999, o*vis) / d(o*vis) is 0 where the clamp is active (the true derivative, default:
+  // K::kAlphaMax); upstream gsplat 0.1.11 lets the gradient through (deviation 1): FLT_MAX
+  float alpha_grad_max;
 };
 
 __device__ __forceinline__ int find_band(const int* __restrict__ edges, int R, int ty) {
@@ -87,6 +90,7 @@ static inline RasterParams make_raster_params(const float* records, const int* s
   prm.S = S; prm.R = R; prm.H = H; prm.W = W;
   prm.tiles_x = (W + K::kTile - 1) / K::kTile; prm.tiles_y = (H + K::kTile - 1) / K::kTile;
   prm.cmb_scale = nullptr; prm.cmb_gamma = 1.f; prm.cmb_min = 0.f;
+  prm.alpha_grad_max = K::kAlphaMax;
   return prm;
 }
 

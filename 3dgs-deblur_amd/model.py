@@ -50,6 +50,10 @@ class SplatfactoDeblurConfig:
     cull_scale_thresh: float = 0.5           # train.py:18 (densification; carried for CLI parity)
     optimize_eval_velocities: bool = True    # train.py:20
     output_depth_during_training: bool = False
+    # how a sub-pose moves the splats: "se3" re-projects every Gaussian under the screw-interpolated pose
+    # (north_star), "pixel_velocity" is the paper's first-order model — one projection, centres shifted by
+    # t * pixel velocity, depth order / covariance / colour of the mid-exposure pose
+    motion_model: str = "se3"
     camera_optimizer: CameraOptimizerConfig = field(default_factory=CameraOptimizerConfig)
     camera_velocity_optimizer: CameraVelocityOptimizerConfig = field(default_factory=CameraVelocityOptimizerConfig)
 
@@ -193,7 +197,10 @@ class SplatfactoDeblurModel(nn.Module):
         viewmat, lin, ang = self._viewmat_and_velocity(camera)
         S, R, times = self._schedule(camera)
         times_t = torch.tensor(times, dtype=torch.float32, device=dev)
-        viewmats = ops.subpose_viewmats(viewmat, lin, ang, times_t)
+        pixvel = cfg.motion_model == "pixel_velocity"
+        if not pixvel and cfg.motion_model != "se3":
+            raise ValueError(f"unknown motion_model {cfg.motion_model!r}")
+        viewmats = viewmat if pixvel else ops.subpose_viewmats(viewmat, lin, ang, times_t)
         sh = torch.cat([self.features_dc[:, None, :], self.features_rest], dim=1)
         bg = self._background(dev)
         use_gamma = cfg.blur_samples > 0
@@ -207,7 +214,8 @@ class SplatfactoDeblurModel(nn.Module):
             self.means, torch.exp(self.scales), self.quats, torch.sigmoid(self.opacities).reshape(-1), sh,
             viewmats, bg, S, R, camera.fx, camera.fy, camera.cx, camera.cy, camera.height, camera.width,
             gamma=gamma, min_rgb_level=min_level, sh_degree=cfg.sh_degree,
-            antialiased=(cfg.rasterize_mode == "antialiased"), xy_grad_out=self.xy_grad)
+            antialiased=(cfg.rasterize_mode == "antialiased"), xy_grad_out=self.xy_grad,
+            lin_vel=lin if pixvel else None, ang_vel=ang if pixvel else None, times=times_t if pixvel else None)
         self.radii = radii
         self.last_size = (camera.width, camera.height)
         accumulation = alphas.mean(dim=0)[..., None]

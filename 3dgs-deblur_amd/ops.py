@@ -44,6 +44,14 @@ DEFER_COLOR = int(os.environ.get("GSD_DEFER_COLOR", "1"))
 HIT_MASKS = int(os.environ.get("GSD_HIT_MASKS", "1"))
 # depth pre-sort: 1 = per-sub-pose segments of 32-bit keys, 0 = one sort of 64-bit (sub-pose, depth) keys
 DEPTH_SORT_SEGMENTED = int(os.environ.get("GSD_DEPTH_SORT_SEGMENTED", "1"))
+# gradient conventions recollected from upstream gsplat 0.1.11, bit mask, default 0 = the true
+# derivatives: 1 = back-propagate through the fov clamp of x/z, y/z as if inactive; 2 = quaternion gradient without
+# the projection through q/|q|; 4 = let the gradient pass the alpha = min(0.999, .) clamp.  7 = all three.
+UPSTREAM_GRADS = int(os.environ.get("GSD_UPSTREAM_GRADS", "0"))
+
+
+def _bwd_variant() -> int:
+    return RASTER_BWD_VARIANT | (256 if (UPSTREAM_GRADS & 4) else 0)
 last_slice_intersects = []
 
 
@@ -508,7 +516,7 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
                                             S, R, H, W, _ptr(out_T), _ptr(sl["fidx"]), _ptr(v_img), _ptr(v_alpha),
                                             _ptr(bwd_T), _ptr(bwd_B), _ptr(v_records), _ptr(sl["gi_of_e"]),
                                             _ptr(tuples), _ptr(flags), _ptr(sl["sorted_ids"]), records.shape[0],
-                                            RASTER_BWD_VARIANT, _ptr(cmb[0]), cmb[1], cmb[2], _stream()),
+                                            _bwd_variant(), _ptr(cmb[0]), cmb[1], cmb[2], _stream()),
                    "rasterize_bwd_slice")
         if tuples is not None:
             with _stage("grad_reduce"):
@@ -565,7 +573,8 @@ class _ProjectGaussians(Function):
         v_V = torch.zeros(4, 4, device=dev) if need_v else None
         _check(_L().gs_project_bwd(N, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(V), fx, fy, cx, cy, H, W,
                                    clip, _ptr(v_xys), _ptr(v_depths), _ptr(v_conics), _ptr(v_comp), _ptr(v_means),
-                                   _ptr(v_scales), _ptr(v_quats), _ptr(v_V), _stream()), "project_bwd")
+                                   _ptr(v_scales), _ptr(v_quats), _ptr(v_V), UPSTREAM_GRADS & 3, _stream()),
+               "project_bwd")
         return (v_means, v_scales, None, v_quats, v_V, None, None, None, None, None, None, None, None)
 
 
@@ -658,7 +667,7 @@ class _RasterizeGaussians(Function):
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
         v_records = torch.zeros(N, REC, device=dev)
         _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), 1, 1, H, W,
-                                  _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records), N, RASTER_BWD_VARIANT,
+                                  _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records), N, _bwd_variant(),
                                   _stream()), "rasterize_bwd")
         v_xys = torch.empty(N, 2, device=dev)
         v_conics = torch.empty(N, 3, device=dev)
@@ -784,7 +793,7 @@ class _RenderSubposes(Function):
     @staticmethod
     def forward(ctx, means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out, return_alpha,
-                gamma, min_rgb_level):
+                gamma, min_rgb_level, lin_vel=None, ang_vel=None, times=None):
         # an output the loss does not use arrives as None in backward instead of a materialised zero tensor
         ctx.set_materialize_grads(False)
         means3d, scales, quats = _f32(means3d, "means3d"), _f32(scales, "scales"), _f32(quats, "quats")
@@ -794,11 +803,21 @@ class _RenderSubposes(Function):
                     or not xy_grad_out.is_contiguous() or xy_grad_out.device != means3d.device):
                 raise ValueError("xy_grad_out must be a contiguous float32 [N,2] tensor on the Gaussians' device")
         ctx.xy_grad_out = xy_grad_out
-        V = _f32(viewmats, "viewmats")
         N, K = means3d.shape[0], sh.shape[1]
         P = S * R
-        if V.shape != (P, 4, 4):
-            raise ValueError(f"viewmats must be [{P},4,4]")
+        # pixel-velocity model: ONE mid-exposure viewmat + the camera twist + the P sub-pose times
+        pixvel = times is not None
+        if pixvel:
+            V = _viewmat16(viewmats).reshape(4, 4)
+            twist = torch.cat([_f32(lin_vel, "lin_vel").reshape(3), _f32(ang_vel, "ang_vel").reshape(3)]).contiguous()
+            times = _f32(times, "times").reshape(-1)
+            if times.numel() != P:
+                raise ValueError(f"times must hold {P} sub-pose times")
+        else:
+            V = _f32(viewmats, "viewmats")
+            twist = None
+            if V.shape != (P, 4, 4):
+                raise ValueError(f"viewmats must be [{P},4,4]")
         H, W = int(img_height), int(img_width)
         dev = means3d.device
         L = _L()
@@ -809,15 +828,24 @@ class _RenderSubposes(Function):
         args = (N, P, float(glob_scale), K, int(sh_degree), float(fx), float(fy), float(cx), float(cy), H, W,
                 float(clip_thresh), int(bool(antialiased)))
         with _stage("project_fwd"):
-            _check(L.gs_project_fused_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
-                                          _ptr(sh), K, args[4], _ptr(V), args[5], args[6], args[7], args[8], H, W,
-                                          args[11], args[12], int(bool(DEFER_COLOR)), _ptr(records), _ptr(dkeys),
-                                          _ptr(ntiles), _ptr(radii), _stream()), "project_fused_fwd")
+            if pixvel:
+                _check(L.gs_project_pixvel_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
+                                               _ptr(sh), K, args[4], _ptr(V), _ptr(twist), _ptr(times), args[5], args[6],
+                                               args[7], args[8], H, W, args[11], args[12], int(bool(DEFER_COLOR)),
+                                               _ptr(records), _ptr(dkeys), _ptr(ntiles), _ptr(radii), _stream()),
+                       "project_pixvel_fwd")
+            else:
+                _check(L.gs_project_fused_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
+                                              _ptr(sh), K, args[4], _ptr(V), args[5], args[6], args[7], args[8], H, W,
+                                              args[11], args[12], int(bool(DEFER_COLOR)), _ptr(records), _ptr(dkeys),
+                                              _ptr(ntiles), _ptr(radii), _stream()), "project_fused_fwd")
         bg = _background(background, dev)
         edges = _band_edges(H, R, dev)
         # SLICE_BASE == 0: one slice holding every intersection, through the very same kernels
         ctx.sliced = True
-        color = (means3d, sh, K, args[4], V) if DEFER_COLOR else None
+        # deferred colour: the view direction of every sub-pose (pixel-velocity model: the mid-exposure pose for all)
+        V_col = V.reshape(1, 16).expand(P, 16).contiguous() if pixvel else V
+        color = (means3d, sh, K, args[4], V_col) if DEFER_COLOR else None
         out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE, color)
         ctx.slices = slices
         svals = bins = fidx = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -833,6 +861,7 @@ class _RenderSubposes(Function):
             ctx.combine = (float(gamma), m)
         else:
             cmb_samples = cmb_rgb = svals          # placeholders: nothing to keep
+        ctx.pixvel = (twist, times) if pixvel else None
         ctx.save_for_backward(means3d, scales, quats, opacities, sh, V, records, svals, bins, edges, bg, out_T, fidx,
                               cmb_samples, cmb_rgb)
         ctx.args = args
@@ -852,7 +881,7 @@ class _RenderSubposes(Function):
         dev = means3d.device
         L = _L()
         if v_img is None and v_alpha is None:
-            return (None,) * 23
+            return (None,) * 26
         v_img = torch.zeros(ctx.img_shape, device=dev) if v_img is None else v_img.contiguous().float()
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
         combine = None
@@ -888,7 +917,7 @@ class _RenderSubposes(Function):
             with _stage("raster_bwd"):
                 _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
                                           _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records), 0,
-                                          RASTER_BWD_VARIANT, _stream()), "rasterize_bwd")
+                                          _bwd_variant(), _stream()), "rasterize_bwd")
         # the five dense gradient outputs are carved out of ONE buffer: with touched flags the kernel skips
         # untouched Gaussians, so the buffer is zero-filled (one fill instead of five)
         # (filling on a second stream under the VALU-bound compositor backward was measured: 3.10 vs 3.02 ms —
@@ -898,34 +927,54 @@ class _RenderSubposes(Function):
         v_means, v_scales, v_quats, v_opac, v_sh = (t.view(shape) for t, shape in zip(
             flat.split(sizes), [(N, 3), (N, 3), (N, 4), (N,), (N, K, 3)]))
         need_v = ctx.needs_input_grad[5]
-        v_V = torch.zeros(P, 4, 4, device=dev) if need_v else None
         xy_out = ctx.xy_grad_out
         if xy_out is not None and touched is not None:
             xy_out.zero_()
+        v_lin = v_ang = None
         with _stage("project_bwd"):
-            _check(L.gs_project_fused_bwd(N, P, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(opacities),
-                                          _ptr(sh), K, deg, _ptr(V), fx, fy, cx, cy, H, W, clip, aa, _ptr(records),
-                                          _ptr(v_records), _ptr(v_means), _ptr(v_scales), _ptr(v_quats), _ptr(v_opac),
-                                          _ptr(v_sh), _ptr(v_V), _ptr(touched), _ptr(xy_out), _stream()),
-                   "project_fused_bwd")
+            if ctx.pixvel is not None:
+                twist, times = ctx.pixvel
+                v_V = torch.zeros(4, 4, device=dev) if need_v else None
+                need_tw = ctx.needs_input_grad[23] or ctx.needs_input_grad[24]
+                v_tw = torch.zeros(12, device=dev) if need_tw else None
+                _check(L.gs_project_pixvel_bwd(N, P, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(opacities),
+                                               _ptr(sh), K, deg, _ptr(V), _ptr(twist), _ptr(times), fx, fy, cx, cy, H, W,
+                                               clip, aa, _ptr(records), _ptr(v_records), _ptr(v_means), _ptr(v_scales),
+                                               _ptr(v_quats), _ptr(v_opac), _ptr(v_sh), _ptr(v_V), _ptr(v_tw),
+                                               _ptr(touched), _ptr(xy_out), UPSTREAM_GRADS & 3, _stream()),
+                       "project_pixvel_bwd")
+                if v_tw is not None:
+                    v_lin, v_ang = v_tw[0:3], v_tw[3:6]
+            else:
+                v_V = torch.zeros(P, 4, 4, device=dev) if need_v else None
+                _check(L.gs_project_fused_bwd(N, P, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(opacities),
+                                              _ptr(sh), K, deg, _ptr(V), fx, fy, cx, cy, H, W, clip, aa, _ptr(records),
+                                              _ptr(v_records), _ptr(v_means), _ptr(v_scales), _ptr(v_quats),
+                                              _ptr(v_opac), _ptr(v_sh), _ptr(v_V), _ptr(touched), _ptr(xy_out),
+                                              UPSTREAM_GRADS & 3, _stream()), "project_fused_bwd")
         v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
-        return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 16
+        return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 16 + (v_lin, v_ang, None)
 
 
 def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, sh: Tensor,
                     viewmats: Tensor, background: Optional[Tensor], blur_samples: int, rs_bands: int,
                     fx: float, fy: float, cx: float, cy: float, img_height: int, img_width: int,
                     sh_degree: int = 3, antialiased: bool = True, glob_scale: float = 1.0,
-                    clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None, return_alpha: bool = True):
+                    clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None, return_alpha: bool = True,
+                    lin_vel: Optional[Tensor] = None, ang_vel: Optional[Tensor] = None,
+                    times: Optional[Tensor] = None):
     """Fused hot path: project N Gaussians under P=S*R sub-pose viewmats, bin, sort, composite.
     -> (samples [S,H,W,3], alphas [S,H,W], radii int32 [P,N]).  scales/opacities are activated values.
     xy_grad_out (optional float32 [N,2]) is OVERWRITTEN during backward with the sum over the sub-poses of
     the screen-space centre gradient in pixels — what splatfacto's densification reads from ``xys.grad``.
-    return_alpha=False returns None for alphas (as gsplat's rasterize_gaussians does by default)."""
+    return_alpha=False returns None for alphas (as gsplat's rasterize_gaussians does by default).
+    Pixel-velocity model (the paper's first-order blur / rolling-shutter model): pass `times` [P] together with
+    lin_vel / ang_vel [3] (OpenCV camera frame) and ONE mid-exposure viewmat [4,4] as `viewmats`; every Gaussian is
+    projected once and sub-pose p renders it at xy + times[p] * pixel_velocity (gradients reach viewmat and twist)."""
     S, R = max(1, int(blur_samples)), max(1, int(rs_bands))
     return _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                                  img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
-                                 bool(return_alpha), None, None)
+                                 bool(return_alpha), None, None, lin_vel, ang_vel, times)
 
 
 def render_combined(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, sh: Tensor,
@@ -933,14 +982,15 @@ def render_combined(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
                     fx: float, fy: float, cx: float, cy: float, img_height: int, img_width: int,
                     gamma: float = 1.0, min_rgb_level: float = 0.0, sh_degree: int = 3, antialiased: bool = True,
                     glob_scale: float = 1.0, clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None,
-                    return_alpha: bool = True):
+                    return_alpha: bool = True, lin_vel: Optional[Tensor] = None, ang_vel: Optional[Tensor] = None,
+                    times: Optional[Tensor] = None):
     """render_subposes + combine_samples as ONE autograd node: -> (rgb [H,W,3], alphas [S,H,W] or None, radii).
     Same values as the two-step form; the backward skips the [S,H,W,3] per-sample gradient tensor — the
     compositor's backward derives every pixel's sample gradient from rgb and its gradient."""
     S, R = max(1, int(blur_samples)), max(1, int(rs_bands))
     return _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                                  img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
-                                 bool(return_alpha), float(gamma), float(min_rgb_level))
+                                 bool(return_alpha), float(gamma), float(min_rgb_level), lin_vel, ang_vel, times)
 
 
 # --------------------------------------------------------------------------- #

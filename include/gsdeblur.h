@@ -98,7 +98,28 @@ int gs_project_fused_bwd(int N, int P, const float* means3d, const float* scales
                          float* v_xy_sum /*[N*2] or NULL: sum over the sub-poses of the screen-space centre
                                            gradient (pixels) — the densification statistic splatfacto reads from
                                            xys.grad; same zeroing rule as the other outputs*/,
-                         void* stream);
+                         int grad_flags /*as in gs_project_bwd*/, void* stream);
+
+/* ---- pixel-velocity model: the paper's first-order blur / rolling-shutter model (the fork's
+ * own wording at /root/reference/README.md:200 "Fixed a bug in pixel velocity formulas").  ONE projection under the
+ * mid-exposure `viewmat`; the record of sub-pose p is the same splat re-centred at xy + times[p] * pv with
+ * pv = J * (-(ang x p_cam + lin)), J the pinhole Jacobian at the camera-space mean; conic, opacity, colour and the
+ * depth key are shared by the P records (fixed depth order and covariance).  twist = {lin[3], ang[3]} (device,
+ * OpenCV camera frame), times [P] (device, seconds).  Everything downstream (binning, compositor) is unchanged. */
+int gs_project_pixvel_fwd(int N, int P, const float* means3d, const float* scales, float glob_scale,
+                          const float* quats, const float* opacities, const float* sh, int K_stride, int sh_degree,
+                          const float* viewmat /*16*/, const float* twist /*6*/, const float* times /*P*/,
+                          float fx, float fy, float cx, float cy, int img_height, int img_width, float clip_thresh,
+                          int antialiased, int defer_color, float* records, unsigned* depth_keys,
+                          int* num_tiles_hit, int* radii, void* stream);
+/* v_viewmat [16] and v_twist [12 floats: lin 3, ang 3, 6 unused] are accumulated into (caller zeroes; NULL skips) */
+int gs_project_pixvel_bwd(int N, int P, const float* means3d, const float* scales, float glob_scale,
+                          const float* quats, const float* opacities, const float* sh, int K_stride, int sh_degree,
+                          const float* viewmat, const float* twist, const float* times, float fx, float fy,
+                          float cx, float cy, int img_height, int img_width, float clip_thresh, int antialiased,
+                          const float* records, const float* v_records, float* v_means3d, float* v_scales,
+                          float* v_quats, float* v_opacities, float* v_sh, float* v_viewmat, float* v_twist,
+                          const unsigned char* touched, float* v_xy_sum, int grad_flags, void* stream);
 
 /* ---- gsplat-array <-> record glue for the rasterize_gaussians signature -------- */
 int gs_pack_records(int N, const float* xys, const float* depths, const int* radii, const float* conics,
@@ -180,7 +201,9 @@ int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* ti
                      int img_width, const float* out_T, const int* final_idx, const float* v_img,
                      const float* v_alpha, float* v_records,
                      int n_records /*as in gs_rasterize_fwd: > 0 selects the scalar-cache kernel (padded sorted_vals)*/,
-                     int variant /*0 = default; other = the v_readlane kernel of round 1 (A/B)*/, void* stream);
+                     int variant /*0 = default; 2 = the v_readlane kernel of round 1 (A/B); + 256: let the gradient pass
+                                   the alpha = min(0.999, .) clamp as gsplat 0.1.11 does*/,
+                     void* stream);
 
 /* ---- depth-sliced variant of the same path (MI355X design, no upstream counterpart) ----------
  * With early termination only a few percent of the (Gaussian, tile) intersections are ever
@@ -246,7 +269,8 @@ int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const i
                            const int* gi_of_e /*as in the forward*/,
                            float* tuples /*[I*12] or NULL*/, unsigned char* flags /*[I], zeroed, or NULL*/,
                            const int* sorted_ids /*as in gs_rasterize_fwd_slice*/, int n_records,
-                           int variant /*0 = default (scalar-cache kernel when ids are available); other = round-1 kernel*/,
+                           int variant /*0 = default (scalar-cache kernel when ids are available); 2 = round-1 kernel;
+                                         + 256: upstream alpha-clamp gradient, as in gs_rasterize_bwd*/,
                            const float* cmb_scale /*[H,W,3] or NULL.  Non-NULL folds gs_combine_bwd into this launch:
                                                     v_img then holds the SAMPLE IMAGES [S,H,W,3] and each pixel derives
                                                     its sample gradient from cmb_scale (gs_combine_bwd_scale)*/,

@@ -98,8 +98,10 @@ class Projected:
 
 
 def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy,
-                      img_height, img_width, block_width=TILE, clip_thresh=0.01) -> Projected:
-    """Restates gsplat.project_gaussians (absent fork).  dtype follows inputs."""
+                      img_height, img_width, block_width=TILE, clip_thresh=0.01, keep_offscreen=False) -> Projected:
+    """Restates gsplat.project_gaussians (absent fork).  dtype follows inputs.
+    keep_offscreen=True keeps centre / conic / radius of Gaussians whose 3-sigma box covers no tile (only the
+    near-plane and singular-covariance culls apply): the pixel-velocity model re-centres them per sub-pose."""
     assert block_width == TILE
     dt = means3d.dtype
     V = viewmat.to(dt)
@@ -163,8 +165,16 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
     y0 = torch.trunc(tcy - tr).clamp(0, tiles_y).to(torch.int32)
     y1 = torch.trunc((tcy + tr) + 1.0).clamp(0, tiles_y).to(torch.int32)
     area = (x1 - x0) * (y1 - y0)
+    geom_valid = valid
     valid = valid & (area > 0)
     zi = torch.zeros_like(area)
+    if keep_offscreen:
+        gv = geom_valid.to(dt)
+        return Projected(xys=torch.stack([x, y], dim=-1) * gv[:, None], depths=pz,
+                         radii=torch.where(geom_valid, radf.to(torch.int32), zi), conics=conics * gv[:, None],
+                         compensation=comp * gv, num_tiles_hit=torch.where(valid, area, zi), cov3d=c3,
+                         tile_min=torch.stack([torch.where(valid, x0, zi), torch.where(valid, y0, zi)], dim=-1),
+                         tile_max=torch.stack([torch.where(valid, x1, zi), torch.where(valid, y1, zi)], dim=-1))
     radii = torch.where(valid, radf.to(torch.int32), zi)
     ntiles = torch.where(valid, area, zi)
     tmin = torch.stack([torch.where(valid, x0, zi), torch.where(valid, y0, zi)], dim=-1)
@@ -473,6 +483,10 @@ class RenderConfig:
     antialiased: bool = True         # train.py:119
     glob_scale: float = 1.0
     clip_thresh: float = 0.01
+    # "se3": every sub-pose re-projects the Gaussians under the screw-interpolated pose (north_star);
+    # "pixel_velocity": the paper's first-order model — ONE projection at the mid-exposure
+    # pose, sub-pose p re-centres each splat at xy + t_p * J(-(w x p_c + v)); depth order, covariance, colour fixed
+    motion_model: str = "se3"
 
 
 def combine_samples(samples: torch.Tensor, gamma: float, min_rgb_level: float) -> torch.Tensor:
@@ -486,9 +500,46 @@ def combine_samples(samples: torch.Tensor, gamma: float, min_rgb_level: float) -
     return x.pow(gamma).mean(dim=0).pow(1.0 / gamma)
 
 
+def pixel_velocity(means3d, viewmat, fx, fy, lin_vel, ang_vel, clip_thresh=0.01):
+    """[N,2] pixel velocity of every Gaussian centre under the camera's body twist (lin, ang in the OpenCV camera
+    frame): a static point moves in camera space with u = -(ang x p_c + lin), its pixel with J u (J = pinhole
+    Jacobian at p_c, no fov clamp).  Op order mirrors gs_math.h::pixel_velocity."""
+    dt = means3d.dtype
+    V = viewmat.to(dt)
+    mx, my, mz = means3d[:, 0], means3d[:, 1], means3d[:, 2]
+    px = ((V[0, 0] * mx + V[0, 1] * my) + V[0, 2] * mz) + V[0, 3]
+    py = ((V[1, 0] * mx + V[1, 1] * my) + V[1, 2] * mz) + V[1, 3]
+    pz = ((V[2, 0] * mx + V[2, 1] * my) + V[2, 2] * mz) + V[2, 3]
+    pz = torch.where(pz > clip_thresh, pz, torch.ones_like(pz))
+    rz = 1.0 / pz
+    lin, ang = lin_vel.to(dt), ang_vel.to(dt)
+    ux = -(ang[1] * pz - ang[2] * py) - lin[0]
+    uy = -(ang[2] * px - ang[0] * pz) - lin[1]
+    uz = -(ang[0] * py - ang[1] * px) - lin[2]
+    rz2 = rz * rz
+    one = torch.ones((), dtype=dt)
+    fx_t, fy_t = one * fx, one * fy
+    return torch.stack([(fx_t * rz) * ux - ((fx_t * px) * rz2) * uz, (fy_t * rz) * uy - ((fy_t * py) * rz2) * uz], dim=-1)
+
+
+def _recentre(pr: Projected, xys, img_height: int, img_width: int) -> Projected:
+    """the same splats at new centres: tile bounds (and the 'covers no tile' cull) recomputed, everything else kept"""
+    b = _bounds_from_xys_radii(xys, pr.depths, pr.radii, None, img_height, img_width)
+    ok = b.num_tiles_hit > 0
+    zi = torch.zeros_like(pr.radii)
+    return Projected(xys=xys, depths=pr.depths, radii=torch.where(ok, pr.radii, zi), conics=pr.conics,
+                     compensation=pr.compensation, num_tiles_hit=b.num_tiles_hit, cov3d=pr.cov3d,
+                     tile_min=b.tile_min * ok[:, None].to(torch.int32), tile_max=b.tile_max * ok[:, None].to(torch.int32))
+
+
 def render(cfg: RenderConfig, means, scales, quats, opacities, sh_coeffs, viewmat, lin_vel, ang_vel,
            background: Optional[torch.Tensor] = None, return_parts: bool = False):
     """Full oracle path.  scales/opacities are ACTIVATED values (exp / sigmoid applied by the caller)."""
+    if cfg.motion_model == "pixel_velocity":
+        return _render_pixel_velocity(cfg, means, scales, quats, opacities, sh_coeffs, viewmat, lin_vel, ang_vel,
+                                      background, return_parts)
+    if cfg.motion_model != "se3":
+        raise ValueError(f"unknown motion model {cfg.motion_model!r}")
     dt = means.dtype
     times, samp, band = subpose_times(cfg.blur_samples, cfg.exposure_time, cfg.rs_bands, cfg.rolling_shutter_time)
     vms = subpose_viewmats(viewmat, lin_vel, ang_vel, times)
@@ -521,6 +572,47 @@ def render(cfg: RenderConfig, means, scales, quats, opacities, sh_coeffs, viewma
     alpha = torch.stack(sample_alpha).mean(dim=0)
     if return_parts:
         return out, alpha, samples, frag, parts, vms
+    return out, alpha
+
+
+def _render_pixel_velocity(cfg: RenderConfig, means, scales, quats, opacities, sh_coeffs, viewmat, lin_vel, ang_vel,
+                           background, return_parts):
+    """The paper's model: one projection, per-sub-pose re-centred splats, same averaging."""
+    dt = means.dtype
+    times, samp, band = subpose_times(cfg.blur_samples, cfg.exposure_time, cfg.rs_bands, cfg.rolling_shutter_time)
+    rows = band_tile_rows(cfg.img_height, cfg.rs_bands)
+    S = max(1, cfg.blur_samples)
+    H, W = cfg.img_height, cfg.img_width
+    V = viewmat
+    pr0 = project_gaussians(means, scales, cfg.glob_scale, quats, V, cfg.fx, cfg.fy, cfg.cx, cfg.cy, H, W, TILE,
+                            cfg.clip_thresh, keep_offscreen=True)
+    pv = pixel_velocity(means, V, cfg.fx, cfg.fy, lin_vel, ang_vel, cfg.clip_thresh)
+    Rwc, twc = V[:3, :3].detach(), V[:3, 3].detach()
+    cam_pos = -(Rwc.T @ twc)
+    rgb = torch.clamp(spherical_harmonics(cfg.sh_degree, means.detach() - cam_pos[None, :], sh_coeffs) + 0.5, min=0.0)
+    op = opacities.reshape(-1) * (pr0.compensation if cfg.antialiased else 1.0)
+    tiles = ((W + TILE - 1) // TILE) * ((H + TILE - 1) // TILE)
+    sample_imgs = [torch.zeros(H, W, 3, dtype=dt) for _ in range(S)]
+    sample_alpha = [torch.zeros(H, W, dtype=dt) for _ in range(S)]
+    parts = []
+    frag = torch.zeros(H, W, dtype=torch.bool)
+    geom = (pr0.radii > 0).to(dt)[:, None]
+    for p, tau in enumerate(times):
+        xys = (pr0.xys + (torch.ones((), dtype=dt) * tau) * pv) * geom
+        pr = _recentre(pr0, xys, H, W)
+        keys, gids = map_gaussian_to_intersects(pr, W)
+        keys, gids = sort_intersects(keys, gids)
+        bins = get_tile_bin_edges(keys, tiles)
+        r = rasterize_sorted(pr.xys, pr.conics, rgb, op, gids, bins, H, W, background, tile_rows=rows[band[p]])
+        sample_imgs[samp[p]] = sample_imgs[samp[p]] + r.img
+        sample_alpha[samp[p]] = sample_alpha[samp[p]] + r.alpha
+        frag |= r.fragile
+        parts.append((pr, keys, gids, bins, r, rgb, op))
+    samples = torch.stack(sample_imgs)
+    out = combine_samples(samples, cfg.gamma, cfg.min_rgb_level)
+    alpha = torch.stack(sample_alpha).mean(dim=0)
+    if return_parts:
+        return out, alpha, samples, frag, parts, viewmat[None]
     return out, alpha
 
 

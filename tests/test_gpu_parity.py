@@ -472,6 +472,115 @@ def test_baseline_configs_vs_float64_oracle_image_and_per_element_gradients(gs, 
         assert v <= 1.0, (tag, k, v)
 
 
+@pytest.mark.parametrize("S,R,W,H,n", [(5, 1, 160, 96, 3000), (3, 2, 128, 96, 2500), (1, 4, 96, 144, 2000)])
+def test_pixel_velocity_model_vs_oracle(gs, oracle, dev, S, R, W, H, n):
+    """The paper's first-order model through the HIP path (gs_project_pixvel_fwd/bwd in front of the unchanged
+    binning + compositors): per-sub-pose radii / tile counts against the float32 oracle (integers), image and every
+    gradient — Gaussians, mid-exposure viewmat, linear and angular velocity — against the float64 oracle."""
+    O = oracle
+    sc = O.synthetic_scene(n, W, H, seed=500 + S * 10 + R, scale_mult=6.0)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10
+    et, rt, gamma, mlevel = 1 / 60, 1 / 30, 2.2, 10.0
+    bg = torch.tensor([0.05, 0.1, 0.15])
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel", "viewmat"]
+    cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], blur_samples=S, rs_bands=R, exposure_time=et,
+                         rolling_shutter_time=rt, gamma=gamma, min_rgb_level=mlevel, motion_model="pixel_velocity")
+    q = {k: sc[k].double().requires_grad_(True) for k in names}
+    ref, ref_alpha, ref_samples, frag, parts, _ = O.render(
+        cfg, q["means"], q["log_scales"].exp(), q["quats"], torch.sigmoid(q["opacity_logits"]), q["sh"], q["viewmat"],
+        q["lin_vel"], q["ang_vel"], background=bg.double(), return_parts=True)
+    good = ~frag
+    assert frag.float().mean().item() <= FRAGILE_MAX
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)) * good[..., None]
+    (ref * wt.double()).sum().backward()
+    p = {k: sc[k].float().to(dev).requires_grad_(True) for k in names}
+    times, _, _ = gs.subpose_schedule(S, et, R, rt)
+    times_t = torch.tensor(times, device=dev)
+    samples, alphas, radii = gs.render_subposes(p["means"], p["log_scales"].exp(), p["quats"],
+                                                torch.sigmoid(p["opacity_logits"]), p["sh"], p["viewmat"], bg.to(dev),
+                                                S, R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, sh_degree=3,
+                                                lin_vel=p["lin_vel"], ang_vel=p["ang_vel"], times=times_t)
+    out = gs.combine_samples(samples, gamma, mlevel)
+    (out * wt.to(dev)).sum().backward()
+    # integers: the float32 oracle re-centres the same float32 projection
+    pr0 = O.project_gaussians(sc["means"], sc["log_scales"].exp(), 1.0, sc["quats"], sc["viewmat"], sc["fx"], sc["fy"],
+                              sc["cx"], sc["cy"], H, W, keep_offscreen=True)
+    pv = O.pixel_velocity(sc["means"], sc["viewmat"], sc["fx"], sc["fy"], sc["lin_vel"], sc["ang_vel"])
+    geom = (pr0.radii > 0).float()[:, None]
+    for pidx, tau in enumerate(times):
+        prp = O._recentre(pr0, (pr0.xys + torch.tensor(tau, dtype=torch.float32) * pv) * geom, H, W)
+        assert np.array_equal(radii[pidx].cpu().numpy(), prp.radii.numpy()), pidx
+    assert (samples.detach().cpu().double() - ref_samples)[:, good].abs().max().item() < IMG_ATOL
+    assert (out.detach().cpu().double() - ref.detach())[good].abs().max().item() < 5e-4
+    worst = {}
+    for k in names:
+        g_hip, g_ref = p[k].grad.cpu().numpy(), q[k].grad.numpy()
+        if k == "viewmat":
+            g_hip, g_ref = g_hip[:3], g_ref[:3]
+        worst[k] = grad_el_ratio(g_hip, g_ref)
+    print(f"pixel velocity S={S} R={R}: per-element gradient error / tolerance:", {k: round(v, 3) for k, v in worst.items()})
+    for k, v in worst.items():
+        assert v <= 1.0, (k, v)
+
+
+def test_upstream_gradient_convention_switches(gs, oracle, dev):
+    """three gradient conventions recollected from gsplat 0.1.11 can be switched on
+    (GSD_UPSTREAM_GRADS bit mask) for the day the fork's source is at hand.  Each switch changes exactly what it
+    says: (2) quaternion gradient without the projection through q/|q|, (1) fov-clamp treated as inactive,
+    (4) gradient passing the alpha = min(0.999, .) clamp."""
+    from gsdeblur_amd import ops
+    O = oracle
+    W, H, n = 96, 64, 400
+    sc = O.synthetic_scene(n, W, H, seed=9, scale_mult=6.0)
+    means = sc["means"].clone()
+    means[:40, 0] *= 3.0                                  # far outside the frustum: x/z beyond 1.3 * tan(fov/2)
+    quats = sc["quats"] * (0.5 + torch.rand(n, 1, generator=torch.Generator().manual_seed(1)))    # NOT unit
+    op_logit = sc["opacity_logits"].clone()
+    op_logit[40:80] = 12.0                                # opacity ~ 1: alpha clamps at 0.999 near the centre
+    V = sc["viewmat"].to(dev)
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+
+    def run(flags, aa=True):
+        old = ops.UPSTREAM_GRADS
+        ops.UPSTREAM_GRADS = flags
+        try:
+            p = {"means": means.to(dev).requires_grad_(True), "log_scales": sc["log_scales"].to(dev).requires_grad_(True),
+                 "quats": quats.to(dev).requires_grad_(True), "op": op_logit.to(dev).requires_grad_(True),
+                 "sh": sc["sh"].to(dev).requires_grad_(True)}
+            s_, _, _ = gs.render_subposes(p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["op"]), p["sh"],
+                                          V[None], None, 1, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W,
+                                          antialiased=aa)
+            (s_[0] * wt).sum().backward()
+            return s_.detach(), {k: v.grad.detach().cpu().double() for k, v in p.items()}
+        finally:
+            ops.UPSTREAM_GRADS = old
+
+    img0, g0 = run(0)
+    img2, g2 = run(2)
+    assert torch.equal(img0, img2)                        # forward untouched by any switch
+    qd = quats.double()
+    qn = qd / qd.norm(dim=1, keepdim=True)
+    proj = (g2["quats"] - qn * (qn * g2["quats"]).sum(1, keepdim=True)) / qd.norm(dim=1, keepdim=True)
+    assert (proj - g0["quats"]).abs().max().item() < 1e-5 * (g0["quats"].abs().max().item() + 1e-12)
+    assert (g2["quats"] - g0["quats"]).abs().max().item() > 1e-3 * g0["quats"].abs().max().item()
+    for k in ("means", "log_scales", "op", "sh"):
+        assert torch.equal(g2[k], g0[k]), k
+    _, g1 = run(1)
+    assert (g1["means"] - g0["means"]).abs().max().item() > 0          # clamped Gaussians see a different gradient
+    pr = O.project_gaussians(means, sc["log_scales"].exp(), 1.0, quats, sc["viewmat"], sc["fx"], sc["fy"], sc["cx"],
+                             sc["cy"], H, W)
+    xz = (means[:, 0] / means[:, 2]).abs()
+    yz = (means[:, 1] / means[:, 2]).abs()
+    inside = (xz < 1.25 * 0.5 * W / sc["fx"]) & (yz < 1.25 * 0.5 * H / sc["fy"])
+    assert torch.equal(g1["means"][inside], g0["means"][inside])       # ... and only they
+    # without the antialiasing compensation an opacity of ~1 really reaches the 0.999 clamp at the splat's centre
+    _, g0c = run(0, aa=False)
+    _, g4 = run(4, aa=False)
+    d_op = (g4["op"] - g0c["op"]).abs()
+    assert d_op[40:80].max().item() > 0
+    assert d_op[200:].max().item() < 1e-6 * (g0c["op"].abs().max().item() + 1e-12)   # unclamped splats: unchanged
+
+
 @pytest.mark.parametrize("S,R,base", [(1, 1, 4), (3, 2, 16), (2, 1, 1)])
 def test_depth_sliced_equals_single_pass(gs, oracle, dev, S, R, base):
     """Depth slicing only removes intersections the compositor would never reach: the forward image is
