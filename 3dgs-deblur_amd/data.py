@@ -12,7 +12,9 @@
               /root/reference/process_synthetic_inputs.py:287-293); "filename": eval_/train_ prefixes
               (/root/reference/train_eval_split_by_blur_score.py:34-37, /root/reference/train.py:169-172);
               "all" (/root/reference/train.py:164-167)
-Pure host code (json + torch tensors); no images are decoded here.
+Host code (json + torch tensors); `load_image` decodes the frames (PNG / JPEG through PIL, or .npy float arrays)
+and `write_transforms` / `write_seed_points_ply` emit the same wire format (used by the self-generated datasets of
+:mod:`synthetic_dataset`, the offline stand-in for the Zenodo downloads of /root/reference/download_data.py:21-33).
 """
 from __future__ import annotations
 
@@ -100,6 +102,67 @@ def load_transforms(path: str, eval_mode: str = "interval", eval_interval: int =
         ply_file_path=(os.path.normpath(os.path.join(root, meta["ply_file_path"])) if "ply_file_path" in meta else None),
         applied_transform=(torch.tensor(at, dtype=torch.float32) if at is not None else None),
     )
+
+
+def load_image(path: str, device="cpu") -> torch.Tensor:
+    """[H,W,3] float32 in 0..1.  `.npy` (float, already 0..1) or anything PIL decodes (8-bit PNG / JPEG)."""
+    if path.endswith(".npy"):
+        import numpy as np
+        return torch.from_numpy(np.load(path).astype("float32"))[..., :3].to(device)
+    import numpy as np
+    from PIL import Image
+    with Image.open(path) as im:
+        arr = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    return (torch.from_numpy(arr.copy()).to(device).float() / 255.0)
+
+
+def save_image(path: str, img: torch.Tensor) -> None:
+    """[H,W,3] float 0..1 -> 8-bit PNG (or .npy float32 when the name says so)"""
+    import numpy as np
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    a = img.detach().clamp(0, 1).cpu()
+    if path.endswith(".npy"):
+        np.save(path, a.numpy().astype("float32"))
+        return
+    from PIL import Image
+    Image.fromarray((a * 255.0 + 0.5).to(torch.uint8).numpy()).save(path)
+
+
+def write_transforms(root: str, width: int, height: int, fx: float, fy: float, cx: float, cy: float,
+                     exposure_time: float, rolling_shutter_time: float, frames: List[Dict],
+                     ply_file_path: Optional[str] = None) -> str:
+    """Write transforms.json with exactly the fields of /root/reference/process_synthetic_inputs.py:113-129 (top
+    level) and :171-176 (per frame: camera_linear_velocity, camera_angular_velocity, file_path, transform_matrix)."""
+    meta = {"aabb_scale": 16, "cx": float(cx), "cy": float(cy), "exposure_time": float(exposure_time),
+            "fl_x": float(fx), "fl_y": float(fy), "frames": [], "h": int(height), "k1": 0, "k2": 0,
+            "orientation_override": "none", "p1": 0, "p2": 0, "rolling_shutter_time": float(rolling_shutter_time),
+            "w": int(width)}
+    for fr in frames:
+        meta["frames"].append({
+            "camera_angular_velocity": [float(v) for v in fr["camera_angular_velocity"]],
+            "camera_linear_velocity": [float(v) for v in fr["camera_linear_velocity"]],
+            "file_path": fr["file_path"],
+            "transform_matrix": [[float(v) for v in row] for row in fr["transform_matrix"]]})
+    if ply_file_path is not None:
+        meta["ply_file_path"] = ply_file_path
+    os.makedirs(root, exist_ok=True)
+    out = os.path.join(root, "transforms.json")
+    with open(out, "wt") as f:
+        json.dump(meta, f, indent=4)
+    return out
+
+
+def write_seed_points_ply(path: str, xyz: torch.Tensor, rgb: torch.Tensor) -> None:
+    """ASCII PLY `x y z red green blue` like /root/reference/process_synthetic_inputs.py:203-219"""
+    n = xyz.shape[0]
+    lines = ["ply", "format ascii 1.0", f"element vertex {n}", "property float x", "property float y",
+             "property float z", "property uint8 red", "property uint8 green", "property uint8 blue", "end_header"]
+    c = (rgb.clamp(0, 1) * 255.0 + 0.5).to(torch.int64)
+    for i in range(n):
+        lines.append(f"{xyz[i, 0].item():.6f} {xyz[i, 1].item():.6f} {xyz[i, 2].item():.6f} "
+                     f"{int(c[i, 0])} {int(c[i, 1])} {int(c[i, 2])}")
+    with open(path, "wt") as f:
+        f.write("\n".join(lines) + "\n")
 
 
 def load_seed_points_ply(path: str) -> Tuple[torch.Tensor, torch.Tensor]:

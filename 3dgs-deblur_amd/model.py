@@ -191,7 +191,10 @@ class SplatfactoDeblurModel(nn.Module):
         return S, R, times
 
     # -- rendering ---------------------------------------------------------------------
-    def get_outputs(self, camera: Camera) -> Dict[str, Tensor]:
+    def get_outputs(self, camera: Camera, detach_gaussians: bool = False) -> Dict[str, Tensor]:
+        """detach_gaussians=True renders with the Gaussians as constants: only the camera-side parameters (pose /
+        velocity adjustment, background) receive a gradient — what the fork's `--optimize-eval-cameras`
+        (/root/reference/train.py:180-183, README.md:197) needs for the evaluation frames."""
         cfg = self.config
         dev = self.means.device
         viewmat, lin, ang = self._viewmat_and_velocity(camera)
@@ -202,16 +205,20 @@ class SplatfactoDeblurModel(nn.Module):
             raise ValueError(f"unknown motion_model {cfg.motion_model!r}")
         viewmats = viewmat if pixvel else ops.subpose_viewmats(viewmat, lin, ang, times_t)
         sh = torch.cat([self.features_dc[:, None, :], self.features_rest], dim=1)
+        gp = (self.means, self.scales, self.quats, self.opacities, sh)
+        if detach_gaussians:
+            gp = tuple(t.detach() for t in gp)
+        means_, scales_, quats_, opac_, sh = gp
         bg = self._background(dev)
         use_gamma = cfg.blur_samples > 0
         self.xy_grad = None
-        if self.training and self.collect_densify_stats:
+        if self.training and self.collect_densify_stats and not detach_gaussians:
             self.xy_grad = torch.zeros(self.num_points, 2, device=dev)
         gamma = cfg.gamma if use_gamma else 1.0
         min_level = cfg.min_rgb_level if use_gamma else 0.0
         # one autograd node for composite + gamma-space average: no [S,H,W,3] sample-gradient tensor in backward
         rgb, alphas, radii = ops.render_combined(
-            self.means, torch.exp(self.scales), self.quats, torch.sigmoid(self.opacities).reshape(-1), sh,
+            means_, torch.exp(scales_), quats_, torch.sigmoid(opac_).reshape(-1), sh,
             viewmats, bg, S, R, camera.fx, camera.fy, camera.cx, camera.cy, camera.height, camera.width,
             gamma=gamma, min_rgb_level=min_level, sh_degree=cfg.sh_degree,
             antialiased=(cfg.rasterize_mode == "antialiased"), xy_grad_out=self.xy_grad,

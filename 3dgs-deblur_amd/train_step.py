@@ -95,3 +95,77 @@ def train_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.O
     for o in optimizers.values():
         o.step()
     return {"loss": float(loss.item()), "psnr": psnr(out["rgb"].detach(), gt_image)}
+
+
+# --------------------------------------------------------------------------- #
+# whole-scene training / evaluation on a transforms.json dataset (the trainer-side callers of the hot path that the
+# end-to-end deblurring check needs; /root/reference/train.py:78-109 scores runs the same way: PSNR / SSIM of the
+# evaluation frames plus wall-clock time, stored as metrics.json)
+# --------------------------------------------------------------------------- #
+def eval_camera_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.Optimizer], camera: Camera,
+                     gt_image: Tensor, ssim_lambda: float = 0.2) -> float:
+    """`--optimize-eval-cameras` (/root/reference/train.py:180-183, README.md:197): one step on an EVALUATION frame
+    in which only its pose / velocity adjustment is updated — the Gaussians are constants (no gradient reaches them,
+    their optimizers do not step)."""
+    model.train()
+    cam_opts = [optimizers[k] for k in ("camera_opt", "camera_velocity_opt") if k in optimizers]
+    if not cam_opts:
+        return float("nan")
+    for o in cam_opts:
+        o.zero_grad(set_to_none=True)
+    out = model.get_outputs(camera, detach_gaussians=True)
+    loss = image_loss(out["rgb"], gt_image, ssim_lambda)
+    loss.backward()
+    for o in cam_opts:
+        o.step()
+    return float(loss.item())
+
+
+@torch.no_grad()
+def evaluate(model: SplatfactoDeblurModel, cameras, images, indices) -> Dict[str, float]:
+    """mean PSNR / SSIM of the model's renders of `indices` against their images (sharp frames in the synthetic sets)"""
+    ps, ss = [], []
+    for i in indices:
+        rgb = model.get_outputs_for_camera(cameras[i])["rgb"]
+        ps.append(psnr(rgb, images[i]))
+        ss.append(float(ssim(rgb.clamp(0, 1), images[i]).item()))
+    return {"psnr": sum(ps) / max(1, len(ps)), "ssim": sum(ss) / max(1, len(ss))}
+
+
+def train_scene(model: SplatfactoDeblurModel, scene, images, iterations: int, lr_scale: float = 1.0,
+                ssim_lambda: float = 0.2, optimize_eval_cameras: bool = False, eval_camera_every: int = 4,
+                densify=None, log_every: int = 0, seed: int = 0) -> Dict:
+    """Train on scene.train_indices (one view per step, seeded shuffle), optionally refining the evaluation cameras
+    in between; returns {'results': {psnr, ssim}, 'wall_clock_time_seconds', 'history'} like the reference's
+    metrics.json (/root/reference/train.py:87-100, parse_outputs.py:58)."""
+    import time
+    optimizers = make_optimizers(model, lr_scale)
+    g = torch.Generator().manual_seed(seed)
+    order = []
+    history = []
+    t0 = time.time()
+    state = None
+    if densify is not None:
+        from . import densify as D
+        model.collect_densify_stats = True
+        state = D.DensifyState(model.num_points, model.means.device)
+    ev_pos = 0
+    for it in range(1, iterations + 1):
+        if not order:
+            order = [scene.train_indices[j] for j in torch.randperm(len(scene.train_indices), generator=g).tolist()]
+        i = order.pop()
+        h = train_step(model, optimizers, scene.cameras[i], images[i], ssim_lambda)
+        if densify is not None:
+            from . import densify as D
+            D.step_callback(model, optimizers, state, it, densify)
+        if optimize_eval_cameras and scene.eval_indices and it % eval_camera_every == 0:
+            e = scene.eval_indices[ev_pos % len(scene.eval_indices)]
+            ev_pos += 1
+            eval_camera_step(model, optimizers, scene.cameras[e], images[e], ssim_lambda)
+        if log_every and it % log_every == 0:
+            history.append({"step": it, **h})
+    if model.means.is_cuda:
+        torch.cuda.synchronize()
+    wall = time.time() - t0
+    res = evaluate(model, scene.cameras, images, scene.eval_indices)
+    return {"results": res, "wall_clock_time_seconds": wall, "history": history}
