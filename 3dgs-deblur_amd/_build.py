@@ -42,7 +42,29 @@ def _stale(target: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
+HASH_PATH = PKG_DIR / "libgsdeblur_hip.so.srchash"
+
+
+def source_hash() -> str:
+    """content hash of every kernel source, header and of this file (the flags): what the binary was built from"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.h")) + [Path(__file__)]:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()
+
+
+def is_current() -> bool:
+    """True when the in-tree library exists and was built from exactly the sources that are on disk now (content,
+    not mtime: a repository snapshot copied to another box keeps the bytes but not necessarily the timestamps)"""
+    return LIB_PATH.exists() and HASH_PATH.exists() and HASH_PATH.read_text().strip() == source_hash()
+
+
 def build_library(force: bool = False, verbose: bool = False) -> Path:
+    if not force and is_current():
+        return LIB_PATH
+    force = force or LIB_PATH.exists()      # a stale binary: rebuild every object (mtimes cannot be trusted)
     headers = sorted(CSRC.glob("*.h"))
     objs = []
     hipcc = _hipcc()
@@ -62,6 +84,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    HASH_PATH.write_text(source_hash() + "\n")
     return LIB_PATH
 
 

@@ -49,7 +49,7 @@ _SIGS = {
     "gs_slice_counts": [_I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "gs_emit_open_intersects": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, ctypes.c_uint, _I, _I, _P, _P, _P],
     "gs_slice_counts_exact": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P],
-    "gs_rasterize_fwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _P],
+    "gs_rasterize_fwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _I, _P],
     "gs_rasterize_bwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I,
                                _P, _F, _F, _P],
     "gs_reduce_grad_tuples": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P],
@@ -82,19 +82,22 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     if _lib is not None:
         return _lib
     import os
-    path = Path(os.environ.get("GSD_LIB_PATH", LIB_PATH))   # override: A/B builds of the same sources
-    if not path.exists():
-        if not build_if_missing:
-            raise HipLibraryError(f"{path} is missing; run __graft_entry__.build()")
-        # one process per GPU: on a fresh checkout every rank gets here at once — exactly one may run hipcc
+    import shutil
+    override = os.environ.get("GSD_LIB_PATH")               # A/B builds of the same sources: used as they are
+    path = Path(override) if override else LIB_PATH
+    if not override and build_if_missing and shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        # the in-tree library is rebuilt whenever a source, a header or the build flags are newer than it (the mtime
+        # check is cheap), so an edited kernel never runs against a stale binary with the same export table.
+        # One process per GPU: on a fresh checkout every rank gets here at once — exactly one may run hipcc.
         import fcntl
-        with open(str(LIB_PATH) + ".lock", "w") as lock:
+        with open(str(path) + ".lock", "w") as lock:
             fcntl.flock(lock, fcntl.LOCK_EX)
             try:
-                if not path.exists():
-                    build_library()
+                build_library()
             finally:
                 fcntl.flock(lock, fcntl.LOCK_UN)
+    if not path.exists():
+        raise HipLibraryError(f"{path} is missing; run __graft_entry__.build()")
     try:
         lib = ctypes.CDLL(str(path))
     except OSError as e:  # pragma: no cover

@@ -158,19 +158,22 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
 // ---------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-struct RecS { float x, y, cx, cy, cz, op, r, g, b; };
+struct RecS { float x, y, cx, cy, cz, op, r, g, b, d; };
 
+template <bool DEPTH>
 __device__ __forceinline__ RecS load_rec_s(const float* __restrict__ records, unsigned gi) {
   const float* p = records + (size_t)gi * kRecFloats;
   RecS o;
   o.x = p[0]; o.y = p[1]; o.cx = p[2]; o.cy = p[3]; o.cz = p[4]; o.op = p[5]; o.r = p[6]; o.g = p[7]; o.b = p[8];
+  o.d = DEPTH ? p[9] : 0.f;             // camera-space depth of the splat (record float 9)
   return o;
 }
 
-struct PixPair { f2 T, Cr, Cg, Cb, py; int last0, last1; };
+struct PixPair { f2 T, Cr, Cg, Cb, Cd, py; int last0, last1; };
 
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+template <bool DEPTH>
 __device__ __forceinline__ void blend_entry(const RecS& rc, float pxf, int idx1, PixPair (&pp)[2]) {
   const float kL2E = -1.4426950408889634f;
   const float qx = rc.cx * (0.5f * kL2E), qy = rc.cy * kL2E, qz = rc.cz * (0.5f * kL2E);
@@ -192,6 +195,7 @@ __device__ __forceinline__ void blend_entry(const RecS& rc, float pxf, int idx1,
     const bool u0 = v0 && (nT.x > K::kTMin), u1 = v1 && (nT.y > K::kTMin);
     const f2 w = {u0 ? w0.x : 0.f, u1 ? w0.y : 0.f};
     q.Cr = fma2(w, cr2, q.Cr); q.Cg = fma2(w, cg2, q.Cg); q.Cb = fma2(w, cb2, q.Cb);
+    if (DEPTH) q.Cd = fma2(w, f2{rc.d, rc.d}, q.Cd);       // sum of weight * depth (expected depth = this / alpha)
     // live pixel: T > 0.  A hit that would push T to <= 1e-4 stops the pixel: T := -|T| keeps the final value
     q.T.x = u0 ? nT.x : (v0 ? -fabsf(q.T.x) : q.T.x);
     q.T.y = u1 ? nT.y : (v1 ? -fabsf(q.T.y) : q.T.y);
@@ -200,12 +204,14 @@ __device__ __forceinline__ void blend_entry(const RecS& rc, float pxf, int idx1,
   }
 }
 
+template <bool DEPTH>
 __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm, SliceState st,
                                                                const int* __restrict__ ids,       // padded, see ABI
                                                                const float* __restrict__ records, unsigned max_id,
                                                                float* __restrict__ out_img,
                                                                float* __restrict__ out_T,
-                                                               int* __restrict__ final_idx, unsigned n_blocks) {
+                                                               int* __restrict__ final_idx, unsigned n_blocks,
+                                                               float* __restrict__ out_depth) {
   const int lane = lane_id();
   const int T = prm.tiles_x * prm.tiles_y;
   const unsigned work = (unsigned)__builtin_amdgcn_readfirstlane(
@@ -229,16 +235,17 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     inside[k] = px < prm.W && (py0 + k) < prm.H;
-    float Tk = inside[k] ? 1.f : -1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    float Tk = inside[k] ? 1.f : -1.f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f;
     if (!st.first && inside[k]) {
       size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
       cr = out_img[pix * 3 + 0]; cg = out_img[pix * 3 + 1]; cb = out_img[pix * 3 + 2];
+      if (DEPTH) cd = out_depth[pix];
       const float Tf = out_T[pix], lv = st.live_T[pix];
       Tk = lv > 0.f ? lv : -Tf;
     }
     PixPair& q = pp[k >> 1];
-    if (k & 1) { q.T.y = Tk; q.Cr.y = cr; q.Cg.y = cg; q.Cb.y = cb; q.py.y = (float)(py0 + k) + 0.5f; q.last1 = range.x; }
-    else       { q.T.x = Tk; q.Cr.x = cr; q.Cg.x = cg; q.Cb.x = cb; q.py.x = (float)(py0 + k) + 0.5f; q.last0 = range.x; }
+    if (k & 1) { q.T.y = Tk; q.Cr.y = cr; q.Cg.y = cg; q.Cb.y = cb; q.Cd.y = cd; q.py.y = (float)(py0 + k) + 0.5f; q.last1 = range.x; }
+    else       { q.T.x = Tk; q.Cr.x = cr; q.Cg.x = cg; q.Cb.x = cb; q.Cd.x = cd; q.py.x = (float)(py0 + k) + 0.5f; q.last0 = range.x; }
   }
   auto any_live = [&]() -> bool {
     return __ballot(fmaxf(fmaxf(pp[0].T.x, pp[0].T.y), fmaxf(pp[1].T.x, pp[1].T.y)) > 0.f) != 0ull;
@@ -250,21 +257,21 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
     int4 idv = ids4[b >> 2];
     // indices read in front of / behind the tile's own range belong to other tiles (or to the padding): clamp, the
     // record is loaded but never blended
-    RecS a0 = load_rec_s(records, min((unsigned)idv.x, max_id)), a1 = load_rec_s(records, min((unsigned)idv.y, max_id));
+    RecS a0 = load_rec_s<DEPTH>(records, min((unsigned)idv.x, max_id)), a1 = load_rec_s<DEPTH>(records, min((unsigned)idv.y, max_id));
     for (;;) {
       // pair A (entries b, b+1) is ready; put pair B (b+2, b+3) and the indices of the next group in flight
       asm volatile("" :: "s"(a0.x), "s"(a1.x) : "memory");
-      const RecS b0 = load_rec_s(records, min((unsigned)idv.z, max_id)), b1 = load_rec_s(records, min((unsigned)idv.w, max_id));
+      const RecS b0 = load_rec_s<DEPTH>(records, min((unsigned)idv.z, max_id)), b1 = load_rec_s<DEPTH>(records, min((unsigned)idv.w, max_id));
       idv = ids4[(b >> 2) + 1];
       asm volatile("" ::: "memory");
-      if ((unsigned)(b - range.x) < n) blend_entry(a0, pxf, b + 1, pp);
-      if ((unsigned)(b + 1 - range.x) < n) blend_entry(a1, pxf, b + 2, pp);
+      if ((unsigned)(b - range.x) < n) blend_entry<DEPTH>(a0, pxf, b + 1, pp);
+      if ((unsigned)(b + 1 - range.x) < n) blend_entry<DEPTH>(a1, pxf, b + 2, pp);
       // pair B is ready; refill pair A from the next group
       asm volatile("" :: "s"(b0.x), "s"(b1.x), "s"(idv.x) : "memory");
-      a0 = load_rec_s(records, min((unsigned)idv.x, max_id)); a1 = load_rec_s(records, min((unsigned)idv.y, max_id));
+      a0 = load_rec_s<DEPTH>(records, min((unsigned)idv.x, max_id)); a1 = load_rec_s<DEPTH>(records, min((unsigned)idv.y, max_id));
       asm volatile("" ::: "memory");
-      if ((unsigned)(b + 2 - range.x) < n) blend_entry(b0, pxf, b + 3, pp);
-      if ((unsigned)(b + 3 - range.x) < n) blend_entry(b1, pxf, b + 4, pp);
+      if ((unsigned)(b + 2 - range.x) < n) blend_entry<DEPTH>(b0, pxf, b + 3, pp);
+      if ((unsigned)(b + 3 - range.x) < n) blend_entry<DEPTH>(b1, pxf, b + 4, pp);
       b += 4;
       if (b >= range.y) break;
       if ((b & 12) == 12 && !any_live()) break;
@@ -285,6 +292,7 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
       out_img[pix * 3 + 1] = cg + Tf * bgg;
       out_img[pix * 3 + 2] = cb + Tf * bgb;
       out_T[pix] = Tf;
+      if (DEPTH) out_depth[pix] = (k & 1) ? q.Cd.y : q.Cd.x;
       final_idx[pix] = (k & 1) ? q.last1 : q.last0;
       if (!st.last) st.live_T[pix] = fmaxf(Tk, 0.f);
     }
@@ -363,19 +371,25 @@ using namespace gs;
 // C ABI -----------------------------------------------------------------------
 // Replaces the device side of gsplat.rasterize_gaussians' forward
 // (_C.rasterize_forward in the absent fork; SURVEY.md §8 a7, boundary §8b).
-static void launch_fwd(const RasterParams& prm, const SliceState& st, const int* ids, int n_records, float* out_img,
-                       float* out_T, int* final_idx, int variant, hipStream_t stream) {
+static int launch_fwd(const RasterParams& prm, const SliceState& st, const int* ids, int n_records, float* out_img,
+                      float* out_T, int* final_idx, int variant, hipStream_t stream, float* out_depth = nullptr) {
   unsigned work = (unsigned)(prm.S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
-  if (variant == 0 && ids)
-    hipLaunchKernelGGL(raster_fwd_sload_kernel, dim3(blocks), dim3(256), 0, stream, prm, st, ids, prm.records,
-                       (unsigned)(n_records > 0 ? n_records - 1 : 0), out_img, out_T, final_idx, blocks);
+  if (out_depth && !(variant == 0 && ids)) return GS_ERR_INVALID;   // the depth channel lives in the scalar-cache kernel
+  if (variant == 0 && ids && out_depth)
+    hipLaunchKernelGGL(raster_fwd_sload_kernel<true>, dim3(blocks), dim3(256), 0, stream, prm, st, ids, prm.records,
+                       (unsigned)(n_records > 0 ? n_records - 1 : 0), out_img, out_T, final_idx, blocks, out_depth);
+  else if (variant == 0 && ids)
+    hipLaunchKernelGGL(raster_fwd_sload_kernel<false>, dim3(blocks), dim3(256), 0, stream, prm, st, ids, prm.records,
+                       (unsigned)(n_records > 0 ? n_records - 1 : 0), out_img, out_T, final_idx, blocks,
+                       (float*)nullptr);
   else if (variant == 1)
     hipLaunchKernelGGL(raster_fwd_slice_kernel<false>, dim3(blocks), dim3(256), 0, stream, prm, st, out_img, out_T,
                        final_idx, blocks);
   else
     hipLaunchKernelGGL(raster_fwd_slice_kernel<true>, dim3(blocks), dim3(256), 0, stream, prm, st, out_img, out_T,
                        final_idx, blocks);
+  return GS_OK;
 }
 
 GS_EXPORT int gs_rasterize_fwd(const float* records, const int* sorted_vals, const int* tile_bins,
@@ -400,14 +414,16 @@ GS_EXPORT int gs_rasterize_fwd_slice(const float* records, const int* sorted_val
                                      const int* band_edges, const float* background, int S, int R, int H, int W,
                                      float* out_img, float* out_T, float* live_T, int* final_idx,
                                      unsigned char* tile_done, int first, int last, const int* gi_of_e,
-                                     const int* sorted_ids, int n_records, int variant, void* stream) {
+                                     const int* sorted_ids, int n_records, float* out_depth, int variant,
+                                     void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
   prm.gi_of_e = gi_of_e;
   SliceState st; st.tile_done = tile_done; st.live_T = live_T; st.first = first; st.last = last;
   const int* ids = sorted_ids ? sorted_ids : (gi_of_e ? nullptr : sorted_vals);
-  launch_fwd(prm, st, n_records > 0 ? ids : nullptr, n_records, out_img, out_T, final_idx, variant,
-             (hipStream_t)stream);
+  int rc = launch_fwd(prm, st, n_records > 0 ? ids : nullptr, n_records, out_img, out_T, final_idx, variant,
+                      (hipStream_t)stream, out_depth);
+  if (rc != GS_OK) return rc;
   return gs_launch_status();
 }
 

@@ -38,6 +38,7 @@ class CameraVelocityOptimizerConfig:
 @dataclass
 class SplatfactoDeblurConfig:
     sh_degree: int = 3
+    sh_degree_interval: int = 0              # splatfacto raises the active SH degree every 1000 steps; 0 = all bands at once
     rasterize_mode: str = "antialiased"      # train.py:119 ("classic" disables the compensation factor)
     use_scale_regularization: bool = False   # train.py:120 (loss-side; carried for CLI parity)
     blur_samples: int = 5                    # train.py:46,51 ; 0 disables motion-blur sampling
@@ -118,6 +119,7 @@ class SplatfactoDeblurModel(nn.Module):
             self.velocity_adjustment = nn.Parameter(torch.zeros(num_cameras, 6))
         else:
             self.velocity_adjustment = None
+        self.step = 0                        # training iteration (advanced by train_step)
         self.radii: Optional[Tensor] = None
         # densification statistics (densify.py): when enabled, every training render leaves the summed
         # screen-space centre gradient of its backward pass in self.xy_grad [N,2] (pixels)
@@ -129,6 +131,13 @@ class SplatfactoDeblurModel(nn.Module):
     @property
     def num_points(self) -> int:
         return self.means.shape[0]
+
+    def active_sh_degree(self) -> int:
+        """splatfacto's progressive SH schedule: degree min(step // sh_degree_interval, sh_degree) while training"""
+        cfg = self.config
+        if not self.training or cfg.sh_degree_interval <= 0:
+            return cfg.sh_degree
+        return min(self.step // cfg.sh_degree_interval, cfg.sh_degree)
 
     def gauss_params(self) -> Dict[str, nn.Parameter]:
         return {"means": self.means, "scales": self.scales, "quats": self.quats, "opacities": self.opacities,
@@ -151,9 +160,10 @@ class SplatfactoDeblurModel(nn.Module):
         R_gl, t = c2w[:3, :3], c2w[:3, 3]
         cam_idx = int(camera.metadata.get("cam_idx", 0))
         if self.pose_adjustment is not None and 0 <= cam_idx < self.num_cameras:
+            # nerfstudio's camera optimizer composes in the CAMERA frame: c2w @ exp_map_SO3xR3(adj)
             adj = self.pose_adjustment[cam_idx]
-            R_gl = _so3_exp(adj[3:]) @ R_gl       # SO3xR3: rotate about the world axes, then translate
-            t = t + adj[:3]
+            t = t + R_gl @ adj[:3]
+            R_gl = R_gl @ _so3_exp(adj[3:])
         flip = torch.tensor([1.0, -1.0, -1.0], device=dev)
         R_cv = R_gl * flip[None, :]                # OpenGL -> OpenCV camera axes (x, -y, -z)
         R_wc = R_cv.T
@@ -217,40 +227,31 @@ class SplatfactoDeblurModel(nn.Module):
         gamma = cfg.gamma if use_gamma else 1.0
         min_level = cfg.min_rgb_level if use_gamma else 0.0
         # one autograd node for composite + gamma-space average: no [S,H,W,3] sample-gradient tensor in backward
-        rgb, alphas, radii = ops.render_combined(
+        want_depth = cfg.output_depth_during_training or not self.training
+        res = ops.render_combined(
             means_, torch.exp(scales_), quats_, torch.sigmoid(opac_).reshape(-1), sh,
             viewmats, bg, S, R, camera.fx, camera.fy, camera.cx, camera.cy, camera.height, camera.width,
-            gamma=gamma, min_rgb_level=min_level, sh_degree=cfg.sh_degree,
+            gamma=gamma, min_rgb_level=min_level, sh_degree=self.active_sh_degree(),
             antialiased=(cfg.rasterize_mode == "antialiased"), xy_grad_out=self.xy_grad,
-            lin_vel=lin if pixvel else None, ang_vel=ang if pixvel else None, times=times_t if pixvel else None)
+            lin_vel=lin if pixvel else None, ang_vel=ang if pixvel else None, times=times_t if pixvel else None,
+            return_depth=want_depth)
+        rgb, alphas, radii = res[:3]
+        depth_acc = res[3] if want_depth else None
         self.radii = radii
         self.last_size = (camera.width, camera.height)
         accumulation = alphas.mean(dim=0)[..., None]
-        out = {"rgb": torch.clamp(rgb, max=1.0) if not self.training else rgb,
+        out = {"rgb": torch.clamp(rgb, max=1.0),      # splatfacto clamps in training too
                "accumulation": accumulation, "background": bg}
-        if cfg.output_depth_during_training or not self.training:
-            out["depth"] = self._render_depth(camera, viewmat, accumulation)
+        if depth_acc is not None:
+            # expected depth of the blended splats, from the SAME depth-sliced pass as the colour (a fourth
+            # forward-only channel of the compositor): mean over the samples of sum(weight * depth), over alpha
+            d = depth_acc.mean(dim=0)[..., None].detach()
+            a = accumulation.detach()
+            far = d.max() / torch.clamp(a.max(), min=1e-10)
+            out["depth"] = torch.where(a > 0, d / torch.clamp(a, min=1e-10), far)
         else:
             out["depth"] = None
         return out
-
-    @torch.no_grad()
-    def _render_depth(self, camera: Camera, viewmat: Tensor, accumulation: Tensor) -> Tensor:
-        """Expected depth at the mid-exposure pose: rasterize colour := depth, divide by alpha
-        (how splatfacto 1.1.0 produces outputs['depth'], render_model.py:219)."""
-        xys, depths, radii, conics, comp, ntiles, _ = ops.project_gaussians(
-            self.means, torch.exp(self.scales), 1.0, self.quats, viewmat, camera.fx, camera.fy, camera.cx,
-            camera.cy, camera.height, camera.width, ops.TILE)
-        op = torch.sigmoid(self.opacities).reshape(-1)
-        if self.config.rasterize_mode == "antialiased":
-            op = op * comp
-        d3 = depths[:, None].repeat(1, 3)
-        img, alpha = ops.rasterize_gaussians(xys, depths, radii, conics, ntiles, d3, op[:, None], camera.height,
-                                             camera.width, ops.TILE, background=torch.zeros(3, device=xys.device),
-                                             return_alpha=True)
-        depth = img[..., 0:1]
-        a = alpha[..., None]
-        return torch.where(a > 0, depth / torch.clamp(a, min=1e-10), depth.detach().max())
 
     @torch.no_grad()
     def get_outputs_for_camera(self, camera: Camera) -> Dict[str, Tensor]:

@@ -144,8 +144,18 @@ def _bits(n: int) -> int:
     return max(1, int(math.ceil(math.log2(max(2, n)))))
 
 
+# GSD_SYNC_CHECK=1: synchronise after every C-ABI call so that an ASYNCHRONOUS HIP fault (illegal address, ...) is
+# reported with the stage that caused it instead of at the next unrelated synchronisation (debug aid; slow)
+SYNC_CHECK = int(os.environ.get("GSD_SYNC_CHECK", "0"))
+
+
 def _check(st: int, what: str):
     _lib.check(st, what)
+    if SYNC_CHECK:
+        try:
+            torch.cuda.synchronize()
+        except RuntimeError as e:
+            raise _lib.HipLibraryError(f"asynchronous HIP fault surfaced right after stage '{what}': {e}") from e
 
 
 def _viewmat16(viewmat: Tensor) -> Tensor:
@@ -310,7 +320,8 @@ def _depth_rank(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: i
 
 
 def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
-                   img_height: int, img_width: int, bg: Tensor, edges: Tensor, slice_base: int, color=None):
+                   img_height: int, img_width: int, bg: Tensor, edges: Tensor, slice_base: int, color=None,
+                   out_depth: Optional[Tensor] = None):
     """Front-to-back depth-sliced bin + sort + composite.
     -> (out_img [S,H,W,3], out_T [S,H,W], slices) ; slices = list of (sorted_vals, tile_bins, final_idx, I_k)
     that the backward walks in reverse."""
@@ -480,7 +491,8 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
             _check(L.gs_rasterize_fwd_slice(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
                                             _ptr(out_img), _ptr(out_T), _ptr(live_T), _ptr(fidx), _ptr(tile_done),
                                             int(first), int(last), _ptr(vals) if (use_tuples and I_k > 0) else None,
-                                            _ptr(sorted_ids), P * N if I_k > 0 else 0, RASTER_FWD_VARIANT, _stream()),
+                                            _ptr(sorted_ids), P * N if I_k > 0 else 0,
+                                            _ptr(out_depth) if I_k > 0 else None, RASTER_FWD_VARIANT, _stream()),
                    "rasterize_fwd_slice")
         if I_k > 0:
             slices.append(dict(svals=svals, bins=bins, fidx=fidx, I=I_k, gi_of_e=vals if use_tuples else None,
@@ -626,8 +638,7 @@ class _RasterizeGaussians(Function):
                 block_width, background, return_alpha):
         if block_width != TILE:
             raise ValueError("only block_width=16 is supported")
-        if colors.shape[-1] != 3:
-            raise ValueError("only 3-channel colours are supported (render depth as colour=depth.repeat(3))")
+        assert colors.shape[-1] == 3          # rasterize_gaussians splits other channel counts into passes of three
         xys, depths, conics = _f32(xys, "xys"), _f32(depths, "depths"), _f32(conics, "conics")
         colors, opacity = _f32(colors, "colors"), _f32(opacity, "opacity").reshape(-1)
         radii = radii.to(torch.int32).contiguous()
@@ -682,11 +693,31 @@ class _RasterizeGaussians(Function):
 def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor, num_tiles_hit: Tensor,
                         colors: Tensor, opacity: Tensor, img_height: int, img_width: int, block_width: int = TILE,
                         background: Optional[Tensor] = None, return_alpha: bool = False):
-    """gsplat.rasterize_gaussians (0.1.11 positional signature) -> out_img [H,W,3] (, out_alpha [H,W])."""
-    opacity_in = opacity
-    out = _RasterizeGaussians.apply(xys, depths, radii, conics, num_tiles_hit, colors, opacity_in.reshape(-1, 1),
-                                    img_height, img_width, block_width, background, return_alpha)
-    return out
+    """gsplat.rasterize_gaussians (0.1.11 positional signature) -> out_img [H,W,C] (, out_alpha [H,W]).
+    C = 3 is one pass of the compositor; any other channel count (upstream's nd_rasterize path: depth, features, ...)
+    is composited three channels at a time over the same geometry — every channel sees exactly the weights of the
+    RGB path, the shared inputs' gradients accumulate over the passes through autograd."""
+    C = colors.shape[-1]
+    if C == 3:
+        return _RasterizeGaussians.apply(xys, depths, radii, conics, num_tiles_hit, colors, opacity.reshape(-1, 1),
+                                         img_height, img_width, block_width, background, return_alpha)
+    if background is not None and background.numel() != C:
+        raise ValueError(f"background must have {C} channels")
+    imgs, alpha = [], None
+    for c0 in range(0, C, 3):
+        n = min(3, C - c0)
+        col = colors[:, c0:c0 + n]
+        bg = None if background is None else background.reshape(-1)[c0:c0 + n]
+        if n < 3:
+            col = torch.cat([col, col.new_zeros(col.shape[0], 3 - n)], dim=1)
+            bg = None if bg is None else torch.cat([bg, bg.new_zeros(3 - n)])
+        res = _RasterizeGaussians.apply(xys, depths, radii, conics, num_tiles_hit, col, opacity.reshape(-1, 1),
+                                        img_height, img_width, block_width, bg, return_alpha and alpha is None)
+        if return_alpha and alpha is None:
+            res, alpha = res
+        imgs.append(res[..., :n])
+    out = torch.cat(imgs, dim=-1)
+    return (out, alpha) if return_alpha else out
 
 
 # --------------------------------------------------------------------------- #
@@ -793,7 +824,7 @@ class _RenderSubposes(Function):
     @staticmethod
     def forward(ctx, means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out, return_alpha,
-                gamma, min_rgb_level, lin_vel=None, ang_vel=None, times=None):
+                gamma, min_rgb_level, lin_vel=None, ang_vel=None, times=None, return_depth=False):
         # an output the loss does not use arrives as None in backward instead of a materialised zero tensor
         ctx.set_materialize_grads(False)
         means3d, scales, quats = _f32(means3d, "means3d"), _f32(scales, "scales"), _f32(quats, "quats")
@@ -846,7 +877,10 @@ class _RenderSubposes(Function):
         # deferred colour: the view direction of every sub-pose (pixel-velocity model: the mid-exposure pose for all)
         V_col = V.reshape(1, 16).expand(P, 16).contiguous() if pixvel else V
         color = (means3d, sh, K, args[4], V_col) if DEFER_COLOR else None
-        out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE, color)
+        # optional fourth channel: sum of weight * camera-space depth per sample image (forward only)
+        depth_acc = torch.zeros(S, H, W, device=dev) if return_depth else None
+        out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE, color,
+                                                depth_acc)
         ctx.slices = slices
         svals = bins = fidx = torch.zeros(1, dtype=torch.int32, device=dev)
         n_isect = last_num_intersects
@@ -869,11 +903,13 @@ class _RenderSubposes(Function):
         ctx.n_isect = n_isect
         ctx.bg_grad = background is not None and ctx.needs_input_grad[6]
         ctx.mark_non_differentiable(radii)
+        if depth_acc is not None:
+            ctx.mark_non_differentiable(depth_acc)
         ctx.img_shape = (S, H, W, 3) if gamma is None else (H, W, 3)
-        return first, (1.0 - out_T) if return_alpha else None, radii
+        return first, (1.0 - out_T) if return_alpha else None, radii, depth_acc
 
     @staticmethod
-    def backward(ctx, v_img, v_alpha, _v_radii):
+    def backward(ctx, v_img, v_alpha, _v_radii, _v_depth=None):
         (means3d, scales, quats, opacities, sh, V, records, svals, bins, edges, bg, out_T, fidx, cmb_samples,
          cmb_rgb) = ctx.saved_tensors
         N, P, glob, K, deg, fx, fy, cx, cy, H, W, clip, aa = ctx.args
@@ -881,7 +917,7 @@ class _RenderSubposes(Function):
         dev = means3d.device
         L = _L()
         if v_img is None and v_alpha is None:
-            return (None,) * 26
+            return (None,) * 27
         v_img = torch.zeros(ctx.img_shape, device=dev) if v_img is None else v_img.contiguous().float()
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
         combine = None
@@ -953,7 +989,7 @@ class _RenderSubposes(Function):
                                               _ptr(v_opac), _ptr(v_sh), _ptr(v_V), _ptr(touched), _ptr(xy_out),
                                               UPSTREAM_GRADS & 3, _stream()), "project_fused_bwd")
         v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
-        return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 16 + (v_lin, v_ang, None)
+        return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 16 + (v_lin, v_ang, None, None)
 
 
 def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, sh: Tensor,
@@ -962,7 +998,7 @@ def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
                     sh_degree: int = 3, antialiased: bool = True, glob_scale: float = 1.0,
                     clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None, return_alpha: bool = True,
                     lin_vel: Optional[Tensor] = None, ang_vel: Optional[Tensor] = None,
-                    times: Optional[Tensor] = None):
+                    times: Optional[Tensor] = None, return_depth: bool = False):
     """Fused hot path: project N Gaussians under P=S*R sub-pose viewmats, bin, sort, composite.
     -> (samples [S,H,W,3], alphas [S,H,W], radii int32 [P,N]).  scales/opacities are activated values.
     xy_grad_out (optional float32 [N,2]) is OVERWRITTEN during backward with the sum over the sub-poses of
@@ -970,11 +1006,14 @@ def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
     return_alpha=False returns None for alphas (as gsplat's rasterize_gaussians does by default).
     Pixel-velocity model (the paper's first-order blur / rolling-shutter model): pass `times` [P] together with
     lin_vel / ang_vel [3] (OpenCV camera frame) and ONE mid-exposure viewmat [4,4] as `viewmats`; every Gaussian is
-    projected once and sub-pose p renders it at xy + times[p] * pixel_velocity (gradients reach viewmat and twist)."""
+    projected once and sub-pose p renders it at xy + times[p] * pixel_velocity (gradients reach viewmat and twist).
+    return_depth=True appends a 4th result [S,H,W]: per sample the sum over the blended splats of weight *
+    camera-space depth (no gradient); expected depth = that / alpha (splatfacto's outputs["depth"])."""
     S, R = max(1, int(blur_samples)), max(1, int(rs_bands))
-    return _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
-                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
-                                 bool(return_alpha), None, None, lin_vel, ang_vel, times)
+    out = _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
+                                img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
+                                bool(return_alpha), None, None, lin_vel, ang_vel, times, bool(return_depth))
+    return out if return_depth else out[:3]
 
 
 def render_combined(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, sh: Tensor,
@@ -983,14 +1022,16 @@ def render_combined(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
                     gamma: float = 1.0, min_rgb_level: float = 0.0, sh_degree: int = 3, antialiased: bool = True,
                     glob_scale: float = 1.0, clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None,
                     return_alpha: bool = True, lin_vel: Optional[Tensor] = None, ang_vel: Optional[Tensor] = None,
-                    times: Optional[Tensor] = None):
+                    times: Optional[Tensor] = None, return_depth: bool = False):
     """render_subposes + combine_samples as ONE autograd node: -> (rgb [H,W,3], alphas [S,H,W] or None, radii).
     Same values as the two-step form; the backward skips the [S,H,W,3] per-sample gradient tensor — the
     compositor's backward derives every pixel's sample gradient from rgb and its gradient."""
     S, R = max(1, int(blur_samples)), max(1, int(rs_bands))
-    return _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
-                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
-                                 bool(return_alpha), float(gamma), float(min_rgb_level), lin_vel, ang_vel, times)
+    out = _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
+                                img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
+                                bool(return_alpha), float(gamma), float(min_rgb_level), lin_vel, ang_vel, times,
+                                bool(return_depth))
+    return out if return_depth else out[:3]
 
 
 # --------------------------------------------------------------------------- #

@@ -94,6 +94,7 @@ def train_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.O
         dp.allreduce_dense_([p.grad for p in small], average=True)
     for o in optimizers.values():
         o.step()
+    model.step += 1
     return {"loss": float(loss.item()), "psnr": psnr(out["rgb"].detach(), gt_image)}
 
 

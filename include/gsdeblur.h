@@ -258,6 +258,10 @@ int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const i
                                                    or NULL: taken from sorted_vals when gi_of_e is NULL (padded as in
                                                    gs_rasterize_fwd), else the v_readlane compositor runs*/,
                            int n_records /*rows of `records`; <= 0 forces the v_readlane compositor*/,
+                           float* out_depth /*[S*H*W] or NULL: sum over the blended entries of weight * camera-space
+                                              depth (record float 9), carried between slices like out_img; expected
+                                              depth = this / alpha — what splatfacto returns as outputs["depth"]
+                                              (/root/reference/render_model.py:219).  Scalar-cache compositor only*/,
                            int variant /*0 = default; 1, 2 = v_readlane compositor without / with the empty-pair skip*/,
                            void* stream);
 /* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B [S,H,W] (behind-colour . v_out, init = 0)

@@ -824,6 +824,86 @@ def test_model_get_outputs(gs, oracle, dev):
     assert (ev["depth"][ev["accumulation"] > 0.5] > 0.9).all()
 
 
+@pytest.mark.parametrize("S,R,base", [(1, 1, 512), (3, 2, 8)])
+def test_depth_channel_of_the_sliced_path_matches_oracle(gs, oracle, dev, S, R, base):
+    """outputs["depth"] (/root/reference/render_model.py:219) comes out of the SAME depth-sliced pass as the colour:
+    a fourth, forward-only channel sum(weight * camera-space depth).  Against the float64 oracle compositing the
+    per-Gaussian depth as a colour, single- and multi-slice, with rolling-shutter bands."""
+    from gsdeblur_amd import ops
+    O = oracle
+    W, H, n = 176, 112, 4000
+    sc = O.synthetic_scene(n, W, H, seed=41, scale_mult=6.0)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10
+    et, rt = 1 / 60, 1 / 30
+    times, samp, band = gs.subpose_schedule(S, et, R, rt)
+    p = {k: sc[k].to(dev) for k in ("means", "log_scales", "quats", "opacity_logits", "sh", "viewmat", "lin_vel", "ang_vel")}
+    vms = gs.subpose_viewmats(p["viewmat"], p["lin_vel"], p["ang_vel"], torch.tensor(times, device=dev))
+    old = ops.SLICE_BASE
+    try:
+        ops.SLICE_BASE = base
+        samples, alphas, radii, depth_acc = gs.render_subposes(
+            p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["opacity_logits"]), p["sh"], vms, None, S, R,
+            sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, return_depth=True)
+        if base < 512:
+            assert sum(1 for x in ops.last_slice_intersects if x > 0) >= 2
+    finally:
+        ops.SLICE_BASE = old
+    rows = O.band_tile_rows(H, R)
+    ref = torch.zeros(S, H, W, dtype=torch.float64)
+    frag = torch.zeros(H, W, dtype=torch.bool)
+    vms64 = vms.cpu().double()
+    for pi in range(S * R):
+        pr = O.project_gaussians(sc["means"].double(), sc["log_scales"].double().exp(), 1.0, sc["quats"].double(),
+                                 vms64[pi], sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W)
+        op = torch.sigmoid(sc["opacity_logits"].double()) * pr.compensation
+        keys, gids = O.sort_intersects(*O.map_gaussian_to_intersects(pr, W))
+        bins = O.get_tile_bin_edges(keys, ((W + 15) // 16) * ((H + 15) // 16))
+        r = O.rasterize_sorted(pr.xys, pr.conics, pr.depths[:, None].repeat(1, 3), op, gids, bins, H, W, None,
+                               tile_rows=rows[band[pi]])
+        ref[samp[pi]] += r.img[..., 0]
+        frag |= r.fragile
+    good = ~frag
+    err = (depth_acc.cpu().double() - ref)[:, good].abs().max().item()
+    assert err < 2e-4 * ref.max().item(), err
+
+
+@pytest.mark.parametrize("C", [1, 2, 5])
+def test_rasterize_gaussians_other_channel_counts(gs, oracle, dev, C):
+    """upstream's nd_rasterize surface: colours with C != 3 channels (depth, features) composite with exactly the
+    RGB path's weights, forward and backward, three channels per pass"""
+    O = oracle
+    n, W, H = 1500, 96, 80
+    sc = _scene(O, n, W, H, 13, 8.0, dev)
+    pr = O.project_gaussians(sc["means"], sc["log_scales"].exp(), 1.0, sc["quats"], torch.eye(4), sc["fx"], sc["fy"],
+                             sc["cx"], sc["cy"], H, W)
+    g = torch.Generator().manual_seed(C)
+    colors = torch.rand(n, C, generator=g)
+    opac = torch.sigmoid(sc["opacity_logits"])
+    bg = torch.rand(C, generator=g)
+    wt = torch.rand(H, W, C, generator=g)
+    xd, cd, cold, od = (t.to(dev).requires_grad_(True) for t in (pr.xys, pr.conics, colors, opac))
+    img, alpha = gs.rasterize_gaussians(xd, pr.depths.to(dev), pr.radii.to(dev), cd, pr.num_tiles_hit.to(dev), cold,
+                                        od[:, None], H, W, 16, bg.to(dev), return_alpha=True)
+    assert img.shape == (H, W, C)
+    x64, c64, col64, o64 = (t.double().requires_grad_(True) for t in (pr.xys, pr.conics, colors, opac))
+    ref = []
+    frag = torch.zeros(H, W, dtype=torch.bool)
+    for c in range(C):
+        i3, r = O.rasterize_gaussians(x64, pr.depths, pr.radii, c64, pr.num_tiles_hit, col64[:, c:c + 1].repeat(1, 3),
+                                      o64, H, W, background=bg[c].double().repeat(3), proj=pr)
+        ref.append(i3[..., 0])
+        frag |= r.fragile
+    ref = torch.stack(ref, dim=-1)
+    good = ~frag
+    assert (img.detach().cpu().double() - ref.detach())[good].abs().max().item() < IMG_ATOL
+    wt = wt * good[..., None]
+    (img * wt.to(dev)).sum().backward()
+    (ref * wt.double()).sum().backward()
+    for got, want, name in ((xd.grad, x64.grad, "xys"), (cd.grad, c64.grad, "conics"), (cold.grad, col64.grad, "colors"),
+                            (od.grad, o64.grad, "opacity")):
+        assert rel_max(got.cpu(), want) < 1e-4, name
+
+
 # --------------------------------------------------------------------------- #
 # SURVEY §8 f3: densification statistic out of the HIP projection backward, and the refine step in a loop
 # --------------------------------------------------------------------------- #
