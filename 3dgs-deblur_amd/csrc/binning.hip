@@ -49,10 +49,21 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned& total,
   return woff + inc - v;
 }
 
+// device-side length of a radix-sort histogram: NB rows x ceil(keys / keys_per_block) blocks, keys read on the device
+struct DevLen { const unsigned* keys; unsigned keys_per_block; unsigned rows; };
+
+__device__ __forceinline__ size_t dev_len(size_t n, const DevLen& dl) {
+  if (!dl.keys) return n;
+  const size_t k = *dl.keys;
+  return min(n, (size_t)dl.rows * ((k + dl.keys_per_block - 1) / dl.keys_per_block));
+}
+
 __global__ __launch_bounds__(256) void scan_reduce_kernel(size_t n, const unsigned* __restrict__ in,
-                                                          unsigned* __restrict__ bsum) {
+                                                          unsigned* __restrict__ bsum, DevLen dl) {
   __shared__ unsigned lds[8];
+  n = dev_len(n, dl);
   size_t base = (size_t)blockIdx.x * kScanBlock;
+  if (base >= n) return;
   unsigned s = 0;
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
@@ -112,8 +123,10 @@ constexpr size_t kScanFusedMaxBlocks = 8192;
 __global__ __launch_bounds__(256) void scan_apply_fused_kernel(size_t n, const unsigned* __restrict__ in,
                                                                const unsigned* __restrict__ bsum_raw,
                                                                unsigned* __restrict__ out,
-                                                               unsigned* __restrict__ total_out) {
+                                                               unsigned* __restrict__ total_out, DevLen dl) {
   __shared__ unsigned lds[8];
+  n = dev_len(n, dl);
+  if ((size_t)blockIdx.x * kScanBlock >= n) return;
   unsigned part = 0;
   for (unsigned b = threadIdx.x; b < blockIdx.x; b += 256) part += bsum_raw[b];
   unsigned prefix;
@@ -135,7 +148,8 @@ __global__ __launch_bounds__(256) void scan_apply_fused_kernel(size_t n, const u
     if (i < n) out[i] = ex;
     ex += v[k];
   }
-  if (total_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = prefix + total;
+  const size_t last_block = n ? (n - 1) / kScanBlock : 0;
+  if (total_out && blockIdx.x == last_block && threadIdx.x == 0) *total_out = prefix + total;
 }
 
 static inline size_t scan_ws_bytes(size_t n) {
@@ -143,12 +157,13 @@ static inline size_t scan_ws_bytes(size_t n) {
   return (nb + 1) * sizeof(unsigned);
 }
 
-static int run_scan(size_t n, const unsigned* in, unsigned* out, unsigned* total_out, void* ws, hipStream_t st) {
+static int run_scan(size_t n, const unsigned* in, unsigned* out, unsigned* total_out, void* ws, hipStream_t st,
+                    DevLen dl = DevLen{nullptr, 1u, 1u}) {
   size_t nb = (n + kScanBlock - 1) / kScanBlock;
   unsigned* bsum = reinterpret_cast<unsigned*>(ws);
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum);
-  if (nb <= kScanFusedMaxBlocks) {
-    hipLaunchKernelGGL(scan_apply_fused_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, out, total_out);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, dl);
+  if (nb <= kScanFusedMaxBlocks || dl.keys) {
+    hipLaunchKernelGGL(scan_apply_fused_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, out, total_out, dl);
   } else {
     hipLaunchKernelGGL(scan_bsums_kernel, dim3(1), dim3(256), 0, st, (unsigned)nb, bsum, total_out);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, out);
@@ -183,9 +198,19 @@ struct SegInfo { size_t seg_len; unsigned nblk_seg; };
 template <typename KeyT, int BITS>
 __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* __restrict__ keys, int shift,
                                                          unsigned mask, SegInfo sg,
-                                                         unsigned* __restrict__ ghist) {
+                                                         unsigned* __restrict__ ghist,
+                                                         const unsigned* __restrict__ n_dev) {
   constexpr int NB = 1 << BITS;
   constexpr int R = SortCfg<KeyT>::kRounds;
+  // n_dev (nullable): the real element count lives on the device (n is then the capacity the grid was sized for);
+  // blocks beyond it contribute an all-zero histogram
+  if (n_dev) {
+    // (unsegmented sorts only) the histogram is laid out for the blocks that really hold keys, so that the scan
+    // between the two kernels costs what the real count costs, not what the capacity would
+    n = min(n, (size_t)*n_dev);
+    sg.nblk_seg = (unsigned)((n + 256 * R - 1) / (256 * R));
+    if (blockIdx.x >= sg.nblk_seg) return;
+  }
   __shared__ unsigned hist[NB];
   for (int d = threadIdx.x; d < NB; d += 256) hist[d] = 0;
   __syncthreads();
@@ -217,10 +242,16 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
                                                             SegInfo sg,
                                                             const unsigned* __restrict__ ghist_scanned,
                                                             const unsigned* __restrict__ gather_src,  // nullable
-                                                            unsigned* __restrict__ gather_out) {
+                                                            unsigned* __restrict__ gather_out,
+                                                            const unsigned* __restrict__ n_dev) {
   constexpr int NB = 1 << BITS;
   constexpr int R = SortCfg<KeyT>::kRounds;
   constexpr int BK = 256 * R;
+  if (n_dev) {
+    n = min(n, (size_t)*n_dev);
+    sg.nblk_seg = (unsigned)((n + BK - 1) / BK);
+    if (blockIdx.x >= sg.nblk_seg) return;
+  }
   constexpr int DPT = NB / 256;                 // digits per thread in the offset phase
   __shared__ KeyT s_keys[BK];
   __shared__ unsigned s_vals[BK];
@@ -367,17 +398,20 @@ static inline size_t radix_ws_bytes(size_t n, size_t seg_len, int bits, int max_
 template <typename KeyT, int BITS>
 static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned* vin, KeyT* kout, unsigned* vout,
                        int shift, unsigned mask, void* ws, size_t hist_bytes, hipStream_t st,
-                       const unsigned* gather_src = nullptr, unsigned* gather_out = nullptr) {
+                       const unsigned* gather_src = nullptr, unsigned* gather_out = nullptr,
+                       const unsigned* n_dev = nullptr) {
   SegInfo sg;
   unsigned nblk = sort_nblk_seg<KeyT>(n, seg_len, &sg.nblk_seg);
   sg.seg_len = (seg_len == 0 || seg_len >= n) ? n : seg_len;
   unsigned* ghist = reinterpret_cast<unsigned*>(ws);
   size_t hn = ((size_t)1 << BITS) * nblk;
   void* scan_ws = reinterpret_cast<char*>(ws) + hist_bytes;
-  hipLaunchKernelGGL((radix_hist_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, shift, mask, sg, ghist);
-  run_scan(hn, ghist, ghist, nullptr, scan_ws, st);
+  hipLaunchKernelGGL((radix_hist_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, shift, mask, sg, ghist,
+                     n_dev);
+  run_scan(hn, ghist, ghist, nullptr, scan_ws, st,
+           DevLen{n_dev, (unsigned)sort_block_keys<KeyT>(), (unsigned)(1u << BITS)});
   hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, vin, kout, vout, shift,
-                     mask, sg, ghist, gather_src, gather_out);
+                     mask, sg, ghist, gather_src, gather_out, n_dev);
 }
 
 // Sort bits [begin_bit, end_bit).  Ping-pongs between (k0,v0) and (k1,v1); returns the index
@@ -385,7 +419,8 @@ static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned
 template <typename KeyT>
 static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1, unsigned* v1, int v0_is_iota,
                       int begin_bit, int end_bit, void* ws, size_t ws_bytes, int* result_buf, hipStream_t st,
-                      int max_digit = 11, const unsigned* gather_src = nullptr, unsigned* gather_out = nullptr) {
+                      int max_digit = 11, const unsigned* gather_src = nullptr, unsigned* gather_out = nullptr,
+                      const unsigned* n_dev = nullptr) {
   int bits = end_bit - begin_bit;
   if (bits <= 0) return GS_ERR_INVALID;
   if (ws_bytes < radix_ws_bytes<KeyT>(n, seg_len, bits, max_digit)) return GS_ERR_WORKSPACE;
@@ -403,10 +438,10 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
     const unsigned* gs_ = (p == passes - 1) ? gather_src : nullptr;
     unsigned* go_ = (p == passes - 1) ? gather_out : nullptr;
     switch (tb) {
-      case 8:  radix_pass<KeyT, 8>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_); break;
-      case 9:  radix_pass<KeyT, 9>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_); break;
-      case 10: radix_pass<KeyT, 10>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_); break;
-      default: radix_pass<KeyT, 11>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_); break;
+      case 8:  radix_pass<KeyT, 8>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev); break;
+      case 9:  radix_pass<KeyT, 9>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev); break;
+      case 10: radix_pass<KeyT, 10>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev); break;
+      default: radix_pass<KeyT, 11>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev); break;
     }
     shift += w;
     cur ^= 1;
@@ -623,7 +658,9 @@ __global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T
 // a key change between i-1 and i closes tile key[i-1] and opens tile key[i].
 template <typename KeyT, int SHIFT>
 __global__ __launch_bounds__(256) void bin_edges_kernel(size_t n, const KeyT* __restrict__ keys,
-                                                        int2* __restrict__ bins) {
+                                                        int2* __restrict__ bins,
+                                                        const unsigned* __restrict__ n_dev = nullptr) {
+  if (n_dev) n = min(n, (size_t)*n_dev);
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   unsigned t = (unsigned)(keys[i] >> SHIFT);
@@ -718,12 +755,26 @@ __global__ void slice_plan_kernel(int P, int N, int K, const unsigned* __restric
 
 // summed-area table of NOT-done tiles per sub-pose: sat[p][(y)*(tx+1)+x] = #open tiles in [0,y)x[0,x).
 // One block per sub-pose, table built in LDS (dynamic, (tx+1)*(ty+1) ints), written out coalesced.
+// open_bits (nullable) [p][tiles_y][ceil(tiles_x/64)] u64: bit x of row y set <=> tile (x, y) is still open — the exact
+// count ANDs a whole tile row of a Gaussian's box against it instead of loading one byte per tile.
 __global__ __launch_bounds__(256) void tile_sat_kernel(int tiles_x, int tiles_y, const unsigned char* __restrict__ done,
-                                                       int* __restrict__ sat) {
+                                                       int* __restrict__ sat, unsigned long long* __restrict__ open_bits) {
   extern __shared__ int s[];
   const int p = blockIdx.x;
   const int T = tiles_x * tiles_y, SW = tiles_x + 1, SH = tiles_y + 1;
   const unsigned char* d = done + (size_t)p * T;
+  if (open_bits) {
+    const int W64 = (tiles_x + 63) >> 6;
+    for (int i = threadIdx.x; i < tiles_y * W64; i += 256) {
+      const int y = i / W64, w = i - y * W64;
+      unsigned long long m = 0ull;
+      for (int b = 0; b < 64; ++b) {
+        const int x = w * 64 + b;
+        if (x < tiles_x && d[y * tiles_x + x] == 0) m |= 1ull << b;
+      }
+      open_bits[((size_t)p * tiles_y + y) * W64 + w] = m;
+    }
+  }
   for (int i = threadIdx.x; i < SW * SH; i += 256) {
     int y = i / SW, x = i % SW;
     s[i] = (y > 0 && x > 0) ? (d[(y - 1) * tiles_x + (x - 1)] ? 0 : 1) : 0;
@@ -772,7 +823,15 @@ __global__ __launch_bounds__(256) void slice_counts_kernel(int n_slice, SliceDes
 // table rejects Gaussians without open tiles with four loads, small boxes are walked by their own
 // lane, large boxes (the nearest Gaussians cover hundreds of tiles) by the whole wave, 64 tiles per step.
 constexpr int kCountSolo = 12;
-constexpr int kSpanRows = 272;      // tile rows a box may span for the LDS row table (4352 pixel rows)
+constexpr int kMaskWords = 512;     // box-local hit-bit string assembled in LDS: boxes of up to 32768 tiles (4K: 32400)
+
+// w (<= 64) bits of a tile row's open mask starting at column x0
+__device__ __forceinline__ unsigned long long row_window(const unsigned long long* __restrict__ row, int x0, int w) {
+  const int wi = x0 >> 6, sh = x0 & 63;
+  unsigned long long v = row[wi] >> sh;
+  if (sh && sh + w > 64) v |= row[wi + 1] << (64 - sh);
+  return w == 64 ? v : (v & ((1ull << w) - 1ull));
+}
 
 // WAVE_PER_G: one Gaussian per wave (lane 0 owns it) — for slices of few, large Gaussians, where 64 big
 // boxes per wave would serialise ~25k tile tests in each of only a few hundred waves.
@@ -786,8 +845,9 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
                                                                  unsigned* __restrict__ counts,
                                                                  const unsigned* __restrict__ cum_rank,   // nullable
                                                                  unsigned long long* __restrict__ masks,  // nullable
-                                                                 unsigned* __restrict__ mask_off) {
-  __shared__ unsigned s_span[4][kSpanRows];
+                                                                 unsigned* __restrict__ mask_off,
+                                                                 const unsigned long long* __restrict__ open_bits) {
+  __shared__ unsigned long long s_words[4][kMaskWords];
   const int lane = lane_id();
   const int j = WAVE_PER_G ? (lane == 0 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : n_slice)
                            : (int)(blockIdx.x * 256 + threadIdx.x);
@@ -813,25 +873,27 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
     if (el.tau < 0.f) area = 0;
   }
   const unsigned T = (unsigned)(tiles_x * tiles_y);
+  const int W64 = (tiles_x + 63) >> 6;
   unsigned cnt = 0;
   if (area > 0 && area <= kCountSolo) {
+    // small box (one mask word): per tile ROW, the columns the ellipse reaches AND the open tiles, as bits
     const int x0 = lo & 0xFFFF, y0 = lo >> 16, x1 = hi & 0xFFFF, y1 = hi >> 16;
     const int w = x1 - x0;
-    const unsigned pbase = (gi / (unsigned)N) * T;
+    const unsigned pidx = gi / (unsigned)N;
     unsigned long long m = 0ull;
     for (int y = y0; y < y1; ++y) {
       int t0, t1;
-      span_tiles(el, row_span(el, y, H), x0, x1, t0, t1);       // one interval per tile row
-      for (int x = t0; x < t1; ++x)
-        if (!done || done[pbase + (unsigned)(y * tiles_x + x)] == 0) {
-          ++cnt;
-          m |= 1ull << ((y - y0) * w + (x - x0));
-        }
+      span_tiles(el, row_span(el, y, H), x0, x1, t0, t1);
+      if (t1 <= t0) continue;
+      unsigned long long rowbits = (((1ull << (t1 - t0)) - 1ull) << (t0 - x0));           // w <= 12
+      if (open_bits) rowbits &= row_window(open_bits + ((size_t)pidx * tiles_y + y) * W64, x0, w);
+      cnt += (unsigned)__popcll(rowbits);
+      m |= rowbits << ((y - y0) * w);
     }
     if (masks) masks[moff] = m;                 // kCountSolo <= 64: one word
   }
   unsigned long long big = __ballot(area > kCountSolo);
-  unsigned* span = s_span[threadIdx.x >> 6];
+  unsigned long long* words = s_words[threadIdx.x >> 6];
   while (big) {
     const int src = __ffsll((long long)big) - 1;
     big &= big - 1;
@@ -842,36 +904,58 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
     eg.b = readlane_f(el.b, src); eg.c = readlane_f(el.c, src); eg.tau = readlane_f(el.tau, src);
     ellipse_derive(eg);
     const int x0 = l & 0xFFFF, y0 = l >> 16, x1 = h & 0xFFFF, y1 = h >> 16;
-    const int w = x1 - x0, a = w * (y1 - y0);
-    const float rw = 1.0f / (float)w;
-    const unsigned pbase = (g / (unsigned)N) * T;
+    const int w = x1 - x0, rows = y1 - y0, a = w * rows;
+    const unsigned pidx = g / (unsigned)N;
     const unsigned mo = (unsigned)readlane_i((int)moff, src);
-    // the tile columns each row of the box can reach, one lane per row, parked in wave-private LDS
-    const bool spans = (y1 - y0) <= kSpanRows;
-    if (spans) {
+    const int nwords = (a + 63) >> 6;
+    unsigned c = 0;
+    if (nwords <= kMaskWords) {
+      // one lane per tile ROW of the box: the row's hit bits (ellipse span AND open tiles, up to w bits) are OR-ed
+      // into the box-local bit string (bit (y-y0)*w + (x-x0)) assembled in wave-private LDS, then written out
       __builtin_amdgcn_wave_barrier();
-      for (int r = lane; r < y1 - y0; r += 64) {
+      for (int k = lane; k < nwords; k += 64) words[k] = 0ull;
+      __builtin_amdgcn_wave_barrier();
+      for (int r = lane; r < rows; r += 64) {
         int t0, t1;
         span_tiles(eg, row_span(eg, y0 + r, H), x0, x1, t0, t1);
-        span[r] = (unsigned)t0 | ((unsigned)t1 << 16);
+        const unsigned long long* orow = open_bits ? open_bits + ((size_t)pidx * tiles_y + (y0 + r)) * W64 : nullptr;
+        // the row's local bits in chunks of 64 columns
+        for (int c0 = 0; c0 < w; c0 += 64) {
+          const int cw = min(64, w - c0);
+          const int lo_c = max(t0 - x0 - c0, 0), hi_c = min(t1 - x0 - c0, cw);
+          if (hi_c <= lo_c) continue;
+          unsigned long long bits = (hi_c - lo_c == 64 ? ~0ull : ((1ull << (hi_c - lo_c)) - 1ull)) << lo_c;
+          if (orow) bits &= row_window(orow, x0 + c0, cw);
+          if (!bits) continue;
+          const int bit0 = r * w + c0;                       // position of the chunk in the box-local bit string
+          const int wi = bit0 >> 6, sh = bit0 & 63;
+          atomicOr(&words[wi], bits << sh);
+          if (sh && (bits >> (64 - sh))) atomicOr(&words[wi + 1], bits >> (64 - sh));
+        }
       }
       __builtin_amdgcn_wave_barrier();
-    }
-    unsigned c = 0;
-    for (int base = 0; base < a; base += 64) {
-      const int t = base + lane;
-      bool ok = false;
-      if (t < a) {
-        const int q = (int)(((float)t + 0.5f) * rw);
-        const int tx = x0 + (t - q * w), ty = y0 + q;
-        bool in;
-        if (spans) { const unsigned u = span[q]; in = tx >= (int)(u & 0xFFFFu) && tx < (int)(u >> 16); }
-        else in = tile_hit(eg, tx, ty, W, H);
-        ok = in && (!done || done[pbase + (unsigned)(ty * tiles_x + tx)] == 0);
+      for (int k = lane; k < nwords; k += 64) {
+        const unsigned long long m = words[k];
+        if (masks) masks[mo + (unsigned)k] = m;
+        c += (unsigned)__popcll(m);
       }
-      const unsigned long long m = __ballot(ok);
-      if (masks && lane == 0) masks[mo + (unsigned)(base >> 6)] = m;
-      c += (unsigned)__popcll(m);
+      c = (unsigned)wave_sum_i((int)c);
+    } else {
+      // boxes beyond the LDS bit string (> 32768 tiles): one tile per lane and step
+      const float rw = 1.0f / (float)w;
+      const unsigned pbase = pidx * T;
+      for (int base = 0; base < a; base += 64) {
+        const int t = base + lane;
+        bool ok = false;
+        if (t < a) {
+          const int q = (int)(((float)t + 0.5f) * rw);
+          const int tx = x0 + (t - q * w), ty = y0 + q;
+          ok = tile_hit(eg, tx, ty, W, H) && (!done || done[pbase + (unsigned)(ty * tiles_x + tx)] == 0);
+        }
+        const unsigned long long m = __ballot(ok);
+        if (masks && lane == 0) masks[mo + (unsigned)(base >> 6)] = m;
+        c += (unsigned)__popcll(m);
+      }
     }
     if (lane == src) cnt = c;
   }
@@ -1043,10 +1127,11 @@ GS_EXPORT int gs_radix_sort_pairs_u32(long long n, unsigned* keys0, unsigned* va
 GS_EXPORT int gs_radix_sort_pairs_gather_u32(long long n, unsigned* keys0, unsigned* vals0, unsigned* keys1,
                                              unsigned* vals1, int vals0_is_iota, int begin_bit, int end_bit,
                                              void* ws, long long ws_bytes, int* result_buf,
-                                             const unsigned* gather_src, unsigned* gather_out, void* stream) {
+                                             const unsigned* gather_src, unsigned* gather_out,
+                                             const unsigned* n_dev, void* stream) {
   if (n <= 0 || begin_bit < 0 || end_bit > 32 || !gather_src || !gather_out) return GS_ERR_INVALID;
   return radix_sort<unsigned>((size_t)n, 0, keys0, vals0, keys1, vals1, vals0_is_iota, begin_bit, end_bit, ws,
-                              (size_t)ws_bytes, result_buf, (hipStream_t)stream, 11, gather_src, gather_out);
+                              (size_t)ws_bytes, result_buf, (hipStream_t)stream, 11, gather_src, gather_out, n_dev);
 }
 
 GS_EXPORT int gs_radix_sort_pairs_u64(long long n, unsigned long long* keys0, unsigned* vals0,
@@ -1107,13 +1192,14 @@ GS_EXPORT int gs_emit_intersects(long long n_ranked, int N, int H, int W, const 
 }
 
 // bins[t] = [start,end) of key t in the sorted u32 keys; bins are zeroed here first.
-GS_EXPORT int gs_tile_bin_edges_u32(long long n, const unsigned* sorted_keys, int num_bins, int* bins, void* stream) {
+GS_EXPORT int gs_tile_bin_edges_u32(long long n, const unsigned* sorted_keys, int num_bins, int* bins,
+                                    const unsigned* n_dev, void* stream) {
   if (num_bins <= 0) return GS_ERR_INVALID;
   hipError_t e = hipMemsetAsync(bins, 0, (size_t)num_bins * 2 * sizeof(int), (hipStream_t)stream);
   if (e != hipSuccess) return 1000 + (int)e;
   if (n <= 0) return GS_OK;
   hipLaunchKernelGGL((bin_edges_kernel<unsigned, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, (size_t)n, sorted_keys, reinterpret_cast<int2*>(bins));
+                     (hipStream_t)stream, (size_t)n, sorted_keys, reinterpret_cast<int2*>(bins), n_dev);
   return gs_launch_status();
 }
 
@@ -1165,7 +1251,8 @@ GS_EXPORT int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl, const
 }
 
 // sat [P*(tiles_y+1)*(tiles_x+1)]: summed-area table of tiles that are NOT done.
-GS_EXPORT int gs_tile_open_sat(int P, int H, int W, const unsigned char* tile_done, int* sat, void* stream) {
+GS_EXPORT int gs_tile_open_sat(int P, int H, int W, const unsigned char* tile_done, int* sat,
+                               unsigned long long* open_bits, void* stream) {
   if (P <= 0) return GS_ERR_INVALID;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
   size_t lds = (size_t)(tiles_x + 1) * (tiles_y + 1) * sizeof(int);
@@ -1173,7 +1260,8 @@ GS_EXPORT int gs_tile_open_sat(int P, int H, int W, const unsigned char* tile_do
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-  hipLaunchKernelGGL(tile_sat_kernel, dim3(P), dim3(256), lds, (hipStream_t)stream, tiles_x, tiles_y, tile_done, sat);
+  hipLaunchKernelGGL(tile_sat_kernel, dim3(P), dim3(256), lds, (hipStream_t)stream, tiles_x, tiles_y, tile_done, sat,
+                     open_bits);
   return gs_launch_status();
 }
 
@@ -1196,19 +1284,21 @@ GS_EXPORT int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_
                                     const unsigned* sorted_gi, const float* records, const int* sat,
                                     const unsigned char* tile_done, int H, int W, unsigned* slice_gi,
                                     unsigned* counts, int wave_per_gaussian, const unsigned* cum_rank,
-                                    unsigned long long* hit_masks, unsigned* mask_off, void* stream) {
+                                    unsigned long long* hit_masks, unsigned* mask_off,
+                                    const unsigned long long* open_bits, void* stream) {
   SliceDesc sd;
   if (n_slice <= 0 || !make_slice_desc(P, slice_begin, slice_prefix, sd)) return GS_ERR_INVALID;
   if (hit_masks && (!cum_rank || !mask_off)) return GS_ERR_INVALID;
+  if ((tile_done != nullptr) != (open_bits != nullptr)) return GS_ERR_INVALID;   // both describe the same closed tiles
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
   if (wave_per_gaussian)
     hipLaunchKernelGGL(slice_counts_exact_kernel<true>, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W, H, slice_gi, counts,
-                       cum_rank, hit_masks, mask_off);
+                       cum_rank, hit_masks, mask_off, open_bits);
   else
     hipLaunchKernelGGL(slice_counts_exact_kernel<false>, dim3((n_slice + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W,
-                       H, slice_gi, counts, cum_rank, hit_masks, mask_off);
+                       H, slice_gi, counts, cum_rank, hit_masks, mask_off, open_bits);
   return gs_launch_status();
 }
 

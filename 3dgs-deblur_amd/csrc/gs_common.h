@@ -50,6 +50,12 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 }
 __device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
 __device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

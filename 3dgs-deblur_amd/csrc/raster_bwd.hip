@@ -374,8 +374,9 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
     const f2 s2 = fma2(dy2[h], fma2(qz2, dy2[h], bx2), hx2);
     vis2[h] = f2{__builtin_amdgcn_exp2f(s2.x), __builtin_amdgcn_exp2f(s2.y)};
     ov2[h] = op2 * vis2[h];
-    hit[2 * h] = (idx < pp[h].fin0) && (s2.x <= 0.f) && (fminf(K::kAlphaMax, ov2[h].x) >= K::kAlphaMin);
-    hit[2 * h + 1] = (idx < pp[h].fin1) && (s2.y <= 0.f) && (fminf(K::kAlphaMax, ov2[h].y) >= K::kAlphaMin);
+    // min(0.999, ov) >= 1/255  <=>  ov >= 1/255: the clamp is only applied where alpha itself is needed
+    hit[2 * h] = (idx < pp[h].fin0) && (s2.x <= 0.f) && (ov2[h].x >= K::kAlphaMin);
+    hit[2 * h + 1] = (idx < pp[h].fin1) && (s2.y <= 0.f) && (ov2[h].y >= K::kAlphaMin);
   }
   if (__ballot(hit[0] || hit[1] || hit[2] || hit[3]) == 0ull) return false;
   const f2 cr2 = {rc.r, rc.r}, cg2 = {rc.g, rc.g}, cb2 = {rc.b, rc.b};
@@ -397,8 +398,8 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
     q.Dv = fma2(fac, cv, q.Dv);
     // d min(0.999, o*vis) = 0 when clamped
     const bool f0 = h0 && ov2[h].x <= agm, f1 = h1 && ov2[h].y <= agm;
-    const f2 ovm = {f0 ? ov2[h].x : 0.f, f1 ? ov2[h].y : 0.f};
     const f2 vism = {f0 ? vis2[h].x : 0.f, f1 ? vis2[h].y : 0.f};
+    const f2 ovm = op2 * vism;               // == ov where the gradient flows (the same product), 0 elsewhere
     const f2 v_sigma = -ovm * v_al;
     q_op = fma2(vism, v_al, q_op);
     // moments of v_sigma over the lane's pixels (dx is the same for all four)

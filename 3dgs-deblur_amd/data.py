@@ -201,7 +201,7 @@ def synthetic_scene(n: int, width: int, height: int, sh_degree: int = 3, seed: i
     The test oracle draws the same scene from the same generator sequence (tests/test_host_logic.py pins it).
     profile="trained" keeps every random draw but shapes the scene like a fitted model instead of SURVEY §8d's
     saturated one: world-space scale proportional to depth (0.006 * z: every Gaussian is ~7 px wide on screen,
-    none fills the view) and mostly translucent opacities (logits ~ N(-2.5, 1.5^2)) — pixels need hundreds of
+    none fills the view) and mostly translucent opacities (logits ~ N(-3.3, 1.5^2)) — pixels need hundreds of
     list entries before they saturate, a large share of the Gaussians receives a gradient and the depth-sliced
     path needs several slices (bench.py reports it as config.secondary)."""
     import math
@@ -217,7 +217,7 @@ def synthetic_scene(n: int, width: int, height: int, sh_degree: int = 3, seed: i
     opacity_logits = 2.0 * torch.randn(n, generator=g)
     if profile == "trained":
         log_scales = log_scales - math.log(0.004 * 5.5) + torch.log(0.006 * z)[:, None]
-        opacity_logits = opacity_logits * 0.75 - 2.5
+        opacity_logits = opacity_logits * 0.75 - 3.3
     elif profile != "survey":
         raise ValueError(f"unknown scene profile {profile!r}")
     K = (sh_degree + 1) ** 2

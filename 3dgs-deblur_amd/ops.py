@@ -44,6 +44,9 @@ DEFER_COLOR = int(os.environ.get("GSD_DEFER_COLOR", "1"))
 HIT_MASKS = int(os.environ.get("GSD_HIT_MASKS", "1"))
 # depth pre-sort: 1 = per-sub-pose segments of 32-bit keys, 0 = one sort of 64-bit (sub-pose, depth) keys
 DEPTH_SORT_SEGMENTED = int(os.environ.get("GSD_DEPTH_SORT_SEGMENTED", "1"))
+# 1: a depth slice's emitted-intersection count stays on the device (buffers / grids sized by the slice's bounding-box
+# count from the plan); 0: read it back (exact sizes, one more host synchronisation per slice) — A/B switch
+DEVICE_SIZES = int(os.environ.get("GSD_DEVICE_SIZES", "1"))
 # gradient conventions recollected from upstream gsplat 0.1.11, bit mask, default 0 = the true
 # derivatives: 1 = back-propagate through the fov clamp of x/z, y/z as if inactive; 2 = quaternion gradient without
 # the projection through q/|q|; 4 = let the gradient pass the alpha = min(0.999, .) clamp.  7 = all three.
@@ -52,7 +55,18 @@ UPSTREAM_GRADS = int(os.environ.get("GSD_UPSTREAM_GRADS", "0"))
 
 def _bwd_variant() -> int:
     return RASTER_BWD_VARIANT | (256 if (UPSTREAM_GRADS & 4) else 0)
-last_slice_intersects = []
+# per-slice emitted intersection counts of the last frame: ints, or 1-element device tensors that are only read back
+# when somebody asks (module attribute `last_slice_intersects`, see __getattr__ below) — the frame itself never waits
+_slice_totals = []
+
+
+def __getattr__(name):
+    if name == "last_slice_intersects":
+        for i, v in enumerate(_slice_totals):
+            if isinstance(v, torch.Tensor):
+                _slice_totals[i] = int(v.item()) & 0xFFFFFFFF
+        return list(_slice_totals)
+    raise AttributeError(name)
 
 
 class StageProfiler:
@@ -186,7 +200,7 @@ def exclusive_scan_u32(x: Tensor) -> Tuple[Tensor, Tensor]:
 
 
 def radix_sort_pairs(keys: Tensor, vals: Optional[Tensor], begin_bit: int, end_bit: int,
-                     gather_src: Optional[Tensor] = None):
+                     gather_src: Optional[Tensor] = None, n_dev: Optional[Tensor] = None):
     """Stable ascending sort of (key, int32 value) pairs over key bits [begin_bit, end_bit).
     keys int32 (treated as u32) or int64 (u64); vals None => iota.  Inputs are clobbered.
     gather_src (int32 keys only): the final pass also returns gather_src[sorted values] as a third tensor."""
@@ -212,7 +226,7 @@ def radix_sort_pairs(keys: Tensor, vals: Optional[Tensor], begin_bit: int, end_b
         gathered = _padded_i32(n, dev)
         _check(L.gs_radix_sort_pairs_gather_u32(n, _ptr(keys), _ptr(v0), _ptr(k1), _ptr(v1), iota, begin_bit, end_bit,
                                                 _ptr(ws), ws_bytes, ctypes.byref(res), _ptr(gather_src), _ptr(gathered),
-                                                _stream()), "radix sort + gather")
+                                                _ptr(n_dev), _stream()), "radix sort + gather")
         return ((k1, v1) if res.value == 1 else (keys, v0)) + (gathered,)
     fn = L.gs_radix_sort_pairs_u32 if keys.dtype == torch.int32 else L.gs_radix_sort_pairs_u64
     _check(fn(n, _ptr(keys), _ptr(v0), _ptr(k1), _ptr(v1), iota, begin_bit, end_bit, _ptr(ws), ws_bytes,
@@ -261,7 +275,7 @@ def bin_and_sort_records(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     with _stage("tile_sort"):
         skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T))
     with _stage("bin_edges"):
-        _check(L.gs_tile_bin_edges_u32(n_isect, _ptr(skeys), P * T, _ptr(bins), _stream()), "bin edges")
+        _check(L.gs_tile_bin_edges_u32(n_isect, _ptr(skeys), P * T, _ptr(bins), None, _stream()), "bin edges")
     return svals, bins, n_isect, skeys
 
 
@@ -325,7 +339,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     """Front-to-back depth-sliced bin + sort + composite.
     -> (out_img [S,H,W,3], out_T [S,H,W], slices) ; slices = list of (sorted_vals, tile_bins, final_idx, I_k)
     that the backward walks in reverse."""
-    global last_num_intersects, last_slice_intersects
+    global last_num_intersects, _slice_totals
     L = _L()
     dev = records.device
     H, W = img_height, img_width
@@ -337,6 +351,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     out_T = torch.empty(S, H, W, device=dev)
     live_T = torch.empty(S, H, W, device=dev)
     sat = torch.empty(P * (ty + 1) * (tx + 1), dtype=torch.int32, device=dev)
+    open_bits = torch.empty(P * ty * ((tx + 63) // 64), dtype=torch.int64, device=dev)   # one bit per tile: still open
     tile_done0 = torch.zeros(P * T, dtype=torch.uint8, device=dev) if R == 1 else None
     # slice boundaries in depth-rank space: cumulative intersections per sub-pose reach T*slice_base*2^k
     KMAX = 16
@@ -392,19 +407,25 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         rows = torch.arange(ty, device=dev)
         band_open = torch.stack([(rows >= e[r]) & (rows < e[r + 1]) for r in range(R)])          # [R, ty]
         tile_done = (~band_open).to(torch.uint8)[None, :, :, None].expand(S, R, ty, tx).reshape(-1).contiguous()
-        _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _stream()), "tile_open_sat")
+        _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _ptr(open_bits), _stream()), "tile_open_sat")
     else:
         tile_done = tile_done0
     holes0 = R > 1          # the very first slice already has closed tiles
     slices = []
-    last_slice_intersects = []
+    _slice_totals = []
     invalid_key = P * T if EXACT_TILE_CULL else 0
     use_tuples = bool(GRAD_TUPLES)
     compact = bool(COMPACT_EMIT) and bool(EXACT_TILE_CULL)
+    # default path (compact emission + gradient tuples): a slice's size never comes back to the host.  Its buffers
+    # and grids are sized by the slice's BOUNDING-BOX intersection count, which the plan read-back already put on
+    # the host, and the kernels read the real count from the device.  What is left per frame: the plan read-back,
+    # plus one look at the open-tile count after every slice that is not the last planned one.
+    device_sizes = compact and use_tuples and rel_at is not None and bool(DEVICE_SIZES)
     for k in range(K):
         first, last = k == 0, k == K - 1
         n_k = n_slices[k]
         I_k = 0
+        n_dev = None
         svals = bins = sorted_ids = None
         if n_k > 0:
             with _stage("slice_count"):
@@ -426,7 +447,8 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                                    _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None,
                                                    _ptr(tile_done) if have_holes else None, H, W, _ptr(slice_gi),
                                                    _ptr(counts), wave_per_g, _ptr(cum) if masks is not None else None,
-                                                   _ptr(masks), _ptr(mask_off), _stream()), "slice_counts_exact")
+                                                   _ptr(masks), _ptr(mask_off), _ptr(open_bits) if have_holes else None,
+                                                   _stream()), "slice_counts_exact")
                 else:
                     _check(L.gs_slice_counts(n_k, P, N, d_begin, d_prefix,
                                              _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None, H, W,
@@ -437,7 +459,12 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                     c_means, c_sh, c_K, c_deg, c_V = color
                     _check(L.gs_slice_colors(n_k, _ptr(slice_gi), _ptr(counts), N, _ptr(c_means), _ptr(c_sh), c_K,
                                              c_deg, _ptr(c_V), _ptr(records), _stream()), "slice_colors")
-            if first and not holes0 and not compact:
+            if device_sizes:
+                hi_rel = [seg_totals[p] if last else rel_at[p][k] for p in range(P)]
+                lo_rel = [0 if first else rel_at[p][k - 1] for p in range(P)]
+                I_k = sum((hi_rel[p] - lo_rel[p]) & 0xFFFFFFFF for p in range(P))     # upper bound (box pairs)
+                n_dev = total_k
+            elif first and not holes0 and not compact:
                 # every tile is open: the slice holds exactly the bounding-box intersections of its ranks,
                 # already known on the host from the plan read-back -> no sync
                 if K == 1:
@@ -452,7 +479,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                 I_k = int(both[0])
                 if both[1] == 0:
                     # every tile is done (each already received its background term): nothing left to do
-                    last_slice_intersects.append(0)
+                    _slice_totals.append(0)
                     break
         if I_k >= 2 ** 31 or I_k < 0:
             raise OverflowError(f"depth slice {k} holds {I_k} tile intersections (limit 2^31-1): lower GSD_SLICE_BASE")
@@ -474,13 +501,15 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                 if use_tuples:
                     # payload = emission index e (iota); the Gaussian id of a sorted entry is vals[e]: the final
                     # pass leaves it in sorted order for the scalar-cache compositors
-                    skeys, svals, sorted_ids = radix_sort_pairs(keys, None, 0, _bits(P * T + 1), gather_src=vals)
+                    skeys, svals, sorted_ids = radix_sort_pairs(keys, None, 0, _bits(P * T + 1), gather_src=vals,
+                                                                n_dev=n_dev)
                 else:
                     skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T + 1))
             with _stage("bin_edges"):
                 bins = torch.empty(P * T + 1, 2, dtype=torch.int32, device=dev)   # last row: culled pairs
-                _check(L.gs_tile_bin_edges_u32(I_k, _ptr(skeys), P * T + 1, _ptr(bins), _stream()), "bin edges")
-        last_slice_intersects.append(I_k)
+                _check(L.gs_tile_bin_edges_u32(I_k, _ptr(skeys), P * T + 1, _ptr(bins), _ptr(n_dev), _stream()),
+                       "bin edges")
+        _slice_totals.append(n_dev if n_dev is not None else I_k)
         if I_k == 0 and not (first or last):
             continue
         if I_k == 0:
@@ -499,7 +528,14 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                sorted_ids=sorted_ids, slice_gi=slice_gi, counts=counts, cum=cum_k, n=n_k))
         if not last:
             with _stage("slice_sat"):
-                _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _stream()), "tile_open_sat")
+                _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _ptr(open_bits), _stream()),
+                       "tile_open_sat")
+            if device_sizes:
+                # the only per-slice read-back left: are there open tiles for the next planned slice?  It is issued
+                # AFTER this slice's whole pipeline, so the GPU works through it while the host waits
+                if int(sat.view(P, -1)[:, -1].sum(dtype=torch.int32).item()) == 0:
+                    _slice_totals.append(0)
+                    break
     return out_img, out_T, slices
 
 

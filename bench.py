@@ -288,7 +288,7 @@ def main():
         ms2 = dt2 / k2 * 1e3
         secondary = {
             "scene": "profile 'trained' (gsdeblur_amd.data.synthetic_scene): same seeded draws, world-space scale "
-                     "0.006*z per Gaussian (constant ~7 px screen size), opacity logits ~ N(-2.5, 1.5^2)",
+                     "0.006*z per Gaussian (constant ~7 px screen size), opacity logits ~ N(-3.3, 1.5^2)",
             "value": round(world * H * W / 1e6 / (ms2 / 1e3), 3), "unit": "MPix/s", "ms_per_step": round(ms2, 4),
             "steps": k2, "tile_intersections_per_step": ops.last_num_intersects,
             "tile_intersections_emitted": int(sum(ops.last_slice_intersects)),

@@ -147,6 +147,7 @@ int gs_radix_sort_pairs_u32(long long n, unsigned* keys0, unsigned* vals0, unsig
 int gs_radix_sort_pairs_gather_u32(long long n, unsigned* keys0, unsigned* vals0, unsigned* keys1, unsigned* vals1,
                                    int vals0_is_iota, int begin_bit, int end_bit, void* ws, long long ws_bytes,
                                    int* result_buf /*host*/, const unsigned* gather_src, unsigned* gather_out,
+                                   const unsigned* n_dev /*NULL, or the real pair count on the device (n = capacity)*/,
                                    void* stream);
 int gs_radix_sort_pairs_u64(long long n, unsigned long long* keys0, unsigned* vals0,
                             unsigned long long* keys1, unsigned* vals1, int vals0_is_iota, int begin_bit,
@@ -170,6 +171,8 @@ int gs_emit_intersects(long long n_ranked, int N, int img_height, int img_width,
                        const unsigned* cum_excl, const float* records, long long n_isect, unsigned* keys,
                        unsigned* vals, unsigned invalid_key, void* stream);
 int gs_tile_bin_edges_u32(long long n, const unsigned* sorted_keys, int num_bins, int* bins /*num_bins*2*/,
+                          const unsigned* n_dev /*NULL, or the real entry count on the DEVICE (n is then the capacity
+                                                  the launch is sized for): no host read-back of a slice's size*/,
                           void* stream);
 int gs_tile_bin_edges_u64(long long n, const unsigned long long* sorted_isect_ids, int num_bins,
                           int* bins /*num_bins*2*/, void* stream);
@@ -219,6 +222,8 @@ int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl /*P*N, rank orde
                   unsigned* seg_totals /*P or NULL: every sub-pose's own intersection total (mod 2^32)*/, void* stream);
 /* sat [P*(tiles_y+1)*(tiles_x+1)] = summed-area table of tiles NOT done (tile_done u8 [P*T]) */
 int gs_tile_open_sat(int P, int img_height, int img_width, const unsigned char* tile_done, int* sat,
+                     unsigned long long* open_bits /*NULL or [P*tiles_y*ceil(tiles_x/64)]: bit x of row y set while
+                                                     tile (x, y) is open (consumed by gs_slice_counts_exact)*/,
                      void* stream);
 /* slice = for each sub-pose p the depth ranks sorted_gi[slice_begin[p] + i], i < prefix[p+1]-prefix[p]
  * (slice_begin / slice_prefix are HOST arrays, P <= 256: they travel in the kernel arguments);
@@ -238,6 +243,7 @@ int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_begin /*HO
                                                           tile (open AND inside the ellipse) for gs_emit_open_intersects;
                                                           requires the u32 prefix not to have wrapped (total < 2^32)*/,
                           unsigned* mask_off /*[n_slice] first mask word of each slice Gaussian, or NULL*/,
+                          const unsigned long long* open_bits /*from gs_tile_open_sat; NULL exactly when tile_done is*/,
                           void* stream);
 int gs_emit_open_intersects(int n_slice, int N, int img_height, int img_width, const unsigned* slice_gi,
                             const unsigned* counts, const unsigned* cum_excl, const float* records,

@@ -640,7 +640,7 @@ def synthetic_scene(n: int, width: int, height: int, sh_degree: int = 3, seed: i
     opacity_logits = 2.0 * torch.randn(n, generator=g)
     if profile == "trained":       # fitted-model-like: screen size independent of depth, mostly translucent
         log_scales = log_scales - math.log(0.004 * zbar) + torch.log(0.006 * z)[:, None]
-        opacity_logits = opacity_logits * 0.75 - 2.5
+        opacity_logits = opacity_logits * 0.75 - 3.3
     elif profile != "survey":
         raise ValueError(f"unknown scene profile {profile!r}")
     K = (sh_degree + 1) ** 2

@@ -1339,7 +1339,7 @@ def test_full_size_multi_slice_frame_equals_plain_path(gs, dev):
     path needs at least three depth slices and a large share of the Gaussians receives a gradient."""
     sl_f, sl_o, I, g = _full_size_two_paths(gs, dev, 1_000_000, 1920, 1080, 5, 1, "trained", _PLAIN, min_slices=3)
     assert sl_o == [I]
-    assert (g["means"] != 0).any(dim=1).float().mean().item() > 0.2
+    assert (g["means"] != 0).any(dim=1).float().mean().item() > 0.3
 
 
 def test_more_intersections_than_the_slice_plan_covers(gs, dev):
