@@ -341,7 +341,9 @@ def main():
                     a["project_bwd"])
 
         alg, alg_survey = alg_bytes(I_emit), alg_bytes(n_isect)
-        kname = {"raster_bwd": "raster_bwd_kernel_v2", "raster_fwd": "raster_fwd_slice_kernel",
+        scalar_cache = ops.RASTER_BWD_VARIANT == 0 and ops.RASTER_FWD_VARIANT == 0
+        kname = {"raster_bwd": "raster_bwd_sload_kernel" if scalar_cache else "raster_bwd_kernel_v2",
+                 "raster_fwd": "raster_fwd_sload_kernel" if scalar_cache else "raster_fwd_slice_kernel",
                  "project_fwd": "project_fused_fwd_kernel", "project_bwd": "project_fused_bwd_sparse_kernel"}[dom]
         achieved = alg[dom] / (single[dom] * 1e-3) / 1e9
         traffic = None
@@ -353,11 +355,29 @@ def main():
                     traffic = tj["hbm_bytes_per_step"].get(kname)
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": kname,
+        # VALU issue side of the same kernel: wave-instructions per launch from the PMC pass
+        # (profiles/traffic.json), priced (a) at the guide's 2 cycles per wave64 instruction and (b) at the issue rates
+        # tools/valu_bench.hip measured for the kernel's own instruction mix (tools/valu_mix.py), over the 1024 SIMDs
+        valu = None
+        try:
+            tj = json.loads(tfile.read_text()) if tfile.exists() else {}
+            vi = tj.get("valu", {}).get(kname)
+            if vi and tj.get("workload") == [N, W, H, S, R]:
+                simd_cycles = single[dom] * 1e-3 * tj["valu"].get("clock_hz", 2.1e9) * 1024 / max(1.0, launches.get(dom, 1.0))
+                valu = {"wave_instructions_per_launch": vi["insts_valu"],
+                        "issue_frac_at_2_cycles": round(vi["insts_valu"] * 2.0 / simd_cycles, 4),
+                        "mix_cycles_per_instruction": vi["mix_cycles_per_inst"],
+                        "issue_frac_at_measured_mix": round(vi["insts_valu"] * vi["mix_cycles_per_inst"] / simd_cycles, 4),
+                        "clock_hz_assumed": tj["valu"].get("clock_hz", 2.1e9),
+                        "sq_wait_inst_any_frac": vi.get("wait_inst_any_frac"), "waves_per_simd": vi.get("waves_per_simd"),
+                        "source": tj["valu"].get("source")}
+        except Exception:
+            valu = None
+        roofline = {"bound": "hbm", "kernel": kname, "valu": valu,
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_basis": "intersections emitted into the tile lists (after depth slicing + exact "
-                                         "tile culling); kernel is VALU/LDS-bound, see DESIGN.md §5",
+                                         "tile culling); the kernel is VALU-issue-bound (roofline.valu), see DESIGN.md §5",
                     "algorithmic_bytes_per_step": alg[dom], "kernel_ms_per_step": single[dom],
                     "kernel_time_source": dom_source,
                     "launches_per_step": launches.get(dom, 1.0),

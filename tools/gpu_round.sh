@@ -37,16 +37,17 @@ timeout 600 python bench.py > $OUT/bench.log 2>&1
 tail -2 $OUT/bench.log | cut -c1-2500 | tee -a $OUT/summary.log
 if [ "$MODE" != "quick" ]; then
   echo "== rocprofv3 kernel trace ==" | tee -a $OUT/summary.log
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline) > $OUT/rocprof.log 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary) > $OUT/rocprof.log 2>&1
   grep -o '{"metric.*' $OUT/rocprof.log | cut -c1-400 | tee -a $OUT/summary.log
   for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -22 $f | cut -c1-220 | tee -a $OUT/summary.log; done
   for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR"; do
     tag=$(echo $pmc | cut -d' ' -f1)
     echo "== rocprofv3 pmc $tag ==" | tee -a $OUT/summary.log
-    (cd /tmp && timeout 600 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $R/$OUT/pmc_$tag -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $OUT/pmc_$tag.log 2>&1
+    (cd /tmp && timeout 600 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $R/$OUT/pmc_$tag -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary) > $OUT/pmc_$tag.log 2>&1
     tail -2 $OUT/pmc_$tag.log | cut -c1-300 | tee -a $OUT/summary.log
     find $OUT/pmc_$tag -name "*.csv" | head -5 | tee -a $OUT/summary.log
   done
   python tools/pmc_summary.py $OUT 2>&1 | tail -40 | tee -a $OUT/summary.log
+  python tools/make_traffic.py $OUT "round 2 ${TAG:-final}" > $OUT/traffic.json 2>/dev/null; head -c 600 $OUT/traffic.json | tee -a $OUT/summary.log
 fi
 echo "== done ==" | tee -a $OUT/summary.log

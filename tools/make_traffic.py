@@ -10,8 +10,13 @@ import sys
 from collections import defaultdict
 
 out, tag = sys.argv[1], sys.argv[2]
-KERNELS = ["raster_bwd_kernel_v2", "raster_fwd_slice_kernel", "project_fused_fwd_kernel", "project_fused_bwd_sparse_kernel",
-           "slice_counts_exact_kernel", "slice_colors_kernel", "emit_open_kernel", "reduce_tuples_wave_kernel"]
+KERNELS = ["raster_bwd_sload_kernel", "raster_fwd_sload_kernel", "raster_bwd_kernel_v2", "raster_fwd_slice_kernel",
+           "project_fused_fwd_kernel", "project_fused_bwd_sparse_kernel", "slice_counts_exact_kernel",
+           "slice_colors_kernel", "emit_open_kernel", "reduce_tuples_wave_kernel", "radix_scatter_kernel",
+           "radix_hist_kernel"]
+# issue cycles per VALU wave-instruction of the kernel's inner-loop mix (tools/valu_mix.py x tools/valu_bench.hip)
+MIX = {"raster_fwd_sload_kernel": 886.7 / 253, "raster_bwd_sload_kernel": 1561.5 / 464,
+       "raster_fwd_slice_kernel": 328.7 / 82, "raster_bwd_kernel_v2": 480.4 / 125}
 
 
 def mean_per_kernel(counter):
@@ -30,11 +35,40 @@ def mean_per_kernel(counter):
 
 
 fetch, write = mean_per_kernel("FETCH_SIZE"), mean_per_kernel("WRITE_SIZE")
+
+
+def sq(counter):
+    acc = defaultdict(list)
+    for f in glob.glob(f"{out}/pmc_SQ_WAVES/**/*counter_collection*.csv", recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") == counter:
+                    acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    res = {}
+    for k in KERNELS:
+        vals = [v for name, vs in acc.items() if k in name for v in vs]
+        if vals:
+            res[k] = sum(vals) / len(vals)
+    return res
+
+
+insts, wcyc, wait, busy = sq("SQ_INSTS_VALU"), sq("SQ_WAVE_CYCLES"), sq("SQ_WAIT_INST_ANY"), sq("SQ_BUSY_CYCLES")
+valu = {"clock_hz": 2.1e9,
+        "source": f"rocprofv3 --pmc SQ_* pass of {tag}; mix_cycles_per_inst = issue cycles of the inner loop's static "
+                  "instruction mix (tools/valu_mix.py) priced with tools/valu_bench.hip (profiles/r02_run1_valu_bench.log); "
+                  "clock: s_memtime vs wall in the same micro-benchmark (~2.1 GHz under load)"}
+for k in MIX:
+    if k in insts:
+        valu[k] = {"insts_valu": int(insts[k]), "mix_cycles_per_inst": round(MIX[k], 3),
+                   "wait_inst_any_frac": round(wait[k] / wcyc[k], 3) if k in wait and k in wcyc else None,
+                   # SQ_WAVE_CYCLES counts quad-cycles summed over waves; SQ_BUSY_CYCLES is per shader engine (32)
+                   "waves_per_simd": round(wcyc[k] * 4 / (busy[k] / 32.0) / 1024, 2) if k in busy and k in wcyc else None}
 doc = {
     "workload": [1000000, 1920, 1080, 5, 1],
-    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), round 1 {tag}; "
+    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), {tag}; "
               "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per launch: FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section "
               "(gfx950 counts 128-B requests as 64 B), WRITE_SIZE uncalibrated; tools/make_traffic.py",
     "hbm_bytes_per_step": {k: int((2 * fetch.get(k, 0) + write.get(k, 0)) * 1024) for k in KERNELS if k in fetch or k in write},
+    "valu": valu,
 }
 print(json.dumps(doc, indent=1))
