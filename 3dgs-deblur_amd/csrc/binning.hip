@@ -58,17 +58,49 @@ __device__ __forceinline__ size_t dev_len(size_t n, const DevLen& dl) {
   return min(n, (size_t)dl.rows * ((k + dl.keys_per_block - 1) / dl.keys_per_block));
 }
 
+// Partly filled segments (the compacting depth pre-sort leaves cnt[s] live ranks at the start of every seg_len-long
+// segment): elements behind a segment's live part count as ZERO and are never read.
+struct SegMask { const unsigned* cnt; size_t seg_len; };
+
+struct BlockLive {       // which elements of one scan block are live
+  size_t vend;           // uniform case: live iff i < vend
+  bool mixed;            // the block straddles a segment boundary: test every element
+};
+
+__device__ __forceinline__ BlockLive block_live(size_t base, size_t n, const SegMask& sm) {
+  BlockLive bl{n, false};
+  if (sm.cnt) {
+    const size_t last = min(base + (size_t)kScanBlock, n) - 1;
+    const size_t s0 = base / sm.seg_len, s1 = last / sm.seg_len;
+    if (s0 == s1) bl.vend = min(n, s0 * sm.seg_len + sm.cnt[s0]);
+    else bl.mixed = true;
+  }
+  return bl;
+}
+
+__device__ __forceinline__ bool elem_live(size_t i, size_t n, const BlockLive& bl, const SegMask& sm) {
+  if (!bl.mixed) return i < bl.vend;
+  if (i >= n) return false;
+  const size_t sidx = i / sm.seg_len;
+  return i - sidx * sm.seg_len < (size_t)sm.cnt[sidx];
+}
+
 __global__ __launch_bounds__(256) void scan_reduce_kernel(size_t n, const unsigned* __restrict__ in,
-                                                          unsigned* __restrict__ bsum, DevLen dl) {
+                                                          unsigned* __restrict__ bsum, DevLen dl, SegMask sm) {
   __shared__ unsigned lds[8];
   n = dev_len(n, dl);
   size_t base = (size_t)blockIdx.x * kScanBlock;
   if (base >= n) return;
+  const BlockLive bl = block_live(base, n, sm);
+  if (!bl.mixed && base >= bl.vend) {
+    if (threadIdx.x == 0) bsum[blockIdx.x] = 0u;
+    return;
+  }
   unsigned s = 0;
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     size_t i = base + (size_t)k * 256 + threadIdx.x;
-    s += i < n ? in[i] : 0u;
+    s += elem_live(i, n, bl, sm) ? in[i] : 0u;
   }
   unsigned total;
   block_excl_scan(s, total, lds);
@@ -123,7 +155,8 @@ constexpr size_t kScanFusedMaxBlocks = 8192;
 __global__ __launch_bounds__(256) void scan_apply_fused_kernel(size_t n, const unsigned* __restrict__ in,
                                                                const unsigned* __restrict__ bsum_raw,
                                                                unsigned* __restrict__ out,
-                                                               unsigned* __restrict__ total_out, DevLen dl) {
+                                                               unsigned* __restrict__ total_out, DevLen dl,
+                                                               SegMask sm) {
   __shared__ unsigned lds[8];
   n = dev_len(n, dl);
   if ((size_t)blockIdx.x * kScanBlock >= n) return;
@@ -131,13 +164,14 @@ __global__ __launch_bounds__(256) void scan_apply_fused_kernel(size_t n, const u
   for (unsigned b = threadIdx.x; b < blockIdx.x; b += 256) part += bsum_raw[b];
   unsigned prefix;
   block_excl_scan(part, prefix, lds);              // total over the block = sum of the preceding block sums
+  const BlockLive bl = block_live((size_t)blockIdx.x * kScanBlock, n, sm);
   size_t base = (size_t)blockIdx.x * kScanBlock + (size_t)threadIdx.x * kScanItems;
   unsigned v[kScanItems];
   unsigned s = 0;
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     size_t i = base + k;
-    v[k] = i < n ? in[i] : 0u;
+    v[k] = elem_live(i, n, bl, sm) ? in[i] : 0u;   // (a block with no live element reads nothing: out is flat there)
     s += v[k];
   }
   unsigned total;
@@ -158,12 +192,13 @@ static inline size_t scan_ws_bytes(size_t n) {
 }
 
 static int run_scan(size_t n, const unsigned* in, unsigned* out, unsigned* total_out, void* ws, hipStream_t st,
-                    DevLen dl = DevLen{nullptr, 1u, 1u}) {
+                    DevLen dl = DevLen{nullptr, 1u, 1u}, SegMask sm = SegMask{nullptr, 1}) {
   size_t nb = (n + kScanBlock - 1) / kScanBlock;
   unsigned* bsum = reinterpret_cast<unsigned*>(ws);
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, dl);
-  if (nb <= kScanFusedMaxBlocks || dl.keys) {
-    hipLaunchKernelGGL(scan_apply_fused_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, out, total_out, dl);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, dl, sm);
+  if (nb <= kScanFusedMaxBlocks || dl.keys || sm.cnt) {
+    hipLaunchKernelGGL(scan_apply_fused_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, out, total_out, dl,
+                       sm);
   } else {
     hipLaunchKernelGGL(scan_bsums_kernel, dim3(1), dim3(256), 0, st, (unsigned)nb, bsum, total_out);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, out);
@@ -195,11 +230,23 @@ template <typename KeyT> constexpr int sort_block_keys() { return 256 * SortCfg<
 // their length).
 struct SegInfo { size_t seg_len; unsigned nblk_seg; };
 
+// Compacting segmented sort (depth pre-sort): most keys of a segment are the "culled" sentinel.  The FIRST pass
+// skips them (they take no histogram count and no output slot) and leaves every segment's survivors packed at the
+// segment's start, counting them in cnt_out[segment]; the later passes read that count back (cnt_in) and touch
+// only the survivors.  Segments stay seg_len apart, so a block's global offset is its scanned histogram entry
+// re-based from "keys before me in the whole array" to "keys before me in my segment".
+struct SegDev {
+  const unsigned* cnt_in;    // per-segment key count on the device (NULL: segments are full)
+  unsigned* cnt_out;         // compacting pass: per-segment survivor count (written by the scatter kernel), else NULL
+  const unsigned* total;     // compacting pass: grand total of the pass's histogram scan (device)
+  unsigned long long skip;   // compacting pass: the key value that is dropped
+};
+
 template <typename KeyT, int BITS>
 __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* __restrict__ keys, int shift,
                                                          unsigned mask, SegInfo sg,
                                                          unsigned* __restrict__ ghist,
-                                                         const unsigned* __restrict__ n_dev) {
+                                                         const unsigned* __restrict__ n_dev, SegDev sd) {
   constexpr int NB = 1 << BITS;
   constexpr int R = SortCfg<KeyT>::kRounds;
   // n_dev (nullable): the real element count lives on the device (n is then the capacity the grid was sized for);
@@ -212,11 +259,16 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* _
     if (blockIdx.x >= sg.nblk_seg) return;
   }
   __shared__ unsigned hist[NB];
-  for (int d = threadIdx.x; d < NB; d += 256) hist[d] = 0;
-  __syncthreads();
   const unsigned seg = blockIdx.x / sg.nblk_seg, b = blockIdx.x % sg.nblk_seg;
   const size_t base = (size_t)seg * sg.seg_len + (size_t)b * (256 * R);
-  const size_t limit = min(n, (size_t)(seg + 1) * sg.seg_len);
+  size_t limit = min(n, (size_t)(seg + 1) * sg.seg_len);
+  if (sd.cnt_in) limit = min(limit, (size_t)seg * sg.seg_len + sd.cnt_in[seg]);
+  if (base >= limit) {                  // behind the segment's keys: an all-zero column
+    for (int d = threadIdx.x; d < NB; d += 256) ghist[((size_t)seg * NB + d) * sg.nblk_seg + b] = 0u;
+    return;
+  }
+  for (int d = threadIdx.x; d < NB; d += 256) hist[d] = 0;
+  __syncthreads();
   // loads first, LDS atomics second: the compiler does not move a global load across an LDS atomic, and one
   // load + wait per round serialises R HBM latencies
   KeyT k[R];
@@ -225,10 +277,43 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* _
     size_t i = base + (size_t)r * 256 + threadIdx.x;
     k[r] = i < limit ? keys[i] : (KeyT)0;
   }
+  const int lane = lane_id();
+  // Same-address LDS atomics serialise (~5 cycles per lane): a digit that takes three values over a whole block
+  // — the top byte of a depth key — made this kernel 2.5x slower than on uniform digits.  A wave whose first
+  // round is that skewed counts every round's lanes in groups (ONE atomic per distinct digit among the first few
+  // groups); the others keep the plain per-lane atomic, which is what uniform digits want.
+  bool skewed;
+  {
+    const size_t i0 = base + threadIdx.x;
+    const bool ok0 = i0 < limit && !(sd.cnt_out && k[0] == (KeyT)sd.skip);
+    const unsigned d = (unsigned)(k[0] >> shift) & mask;
+    const unsigned long long m = __ballot(ok0);
+    const unsigned d0 = (unsigned)readlane_i((int)d, m ? __ffsll((long long)m) - 1 : 0);
+    skewed = __popcll(__ballot(ok0 && d == d0)) >= 16;
+  }
+  if (skewed) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    size_t i = base + (size_t)r * 256 + threadIdx.x;
-    if (i < limit) atomicAdd(&hist[(unsigned)(k[r] >> shift) & mask], 1u);
+    for (int r = 0; r < R; ++r) {
+      size_t i = base + (size_t)r * 256 + threadIdx.x;
+      const bool ok = i < limit && !(sd.cnt_out && k[r] == (KeyT)sd.skip);
+      const unsigned d = (unsigned)(k[r] >> shift) & mask;
+      unsigned long long todo = __ballot(ok);
+#pragma unroll 1
+      for (int it = 0; it < 4 && todo; ++it) {
+        const int src = __ffsll((long long)todo) - 1;
+        const unsigned d0 = (unsigned)readlane_i((int)d, src);
+        const unsigned long long same = __ballot(ok && d == d0) & todo;
+        if (lane == src) atomicAdd(&hist[d0], (unsigned)__popcll(same));
+        todo &= ~same;
+      }
+      if ((todo >> lane) & 1ull) atomicAdd(&hist[d], 1u);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      size_t i = base + (size_t)r * 256 + threadIdx.x;
+      if (i < limit && !(sd.cnt_out && k[r] == (KeyT)sd.skip)) atomicAdd(&hist[(unsigned)(k[r] >> shift) & mask], 1u);
+    }
   }
   __syncthreads();
   for (int d = threadIdx.x; d < NB; d += 256) ghist[((size_t)seg * NB + d) * sg.nblk_seg + b] = hist[d];
@@ -243,7 +328,9 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
                                                             const unsigned* __restrict__ ghist_scanned,
                                                             const unsigned* __restrict__ gather_src,  // nullable
                                                             unsigned* __restrict__ gather_out,
-                                                            const unsigned* __restrict__ n_dev) {
+                                                            const unsigned* __restrict__ n_dev, SegDev sd,
+                                                            const unsigned* __restrict__ p2_in,   // nullable: a second
+                                                            unsigned* __restrict__ p2_out) {      // payload per key
   constexpr int NB = 1 << BITS;
   constexpr int R = SortCfg<KeyT>::kRounds;
   constexpr int BK = 256 * R;
@@ -251,6 +338,10 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
     n = min(n, (size_t)*n_dev);
     sg.nblk_seg = (unsigned)((n + BK - 1) / BK);
     if (blockIdx.x >= sg.nblk_seg) return;
+  }
+  {
+    const unsigned seg0 = blockIdx.x / sg.nblk_seg, blk0 = blockIdx.x % sg.nblk_seg;
+    if (sd.cnt_in && (size_t)blk0 * BK >= (size_t)sd.cnt_in[seg0]) return;     // behind the segment's keys
   }
   constexpr int DPT = NB / 256;                 // digits per thread in the offset phase
   __shared__ KeyT s_keys[BK];
@@ -264,7 +355,10 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
   __syncthreads();
   const unsigned seg = blockIdx.x / sg.nblk_seg, blk = blockIdx.x % sg.nblk_seg;
   const size_t bbase = (size_t)seg * sg.seg_len + (size_t)blk * BK;
-  const size_t limit = min(n, (size_t)(seg + 1) * sg.seg_len);
+  size_t limit = min(n, (size_t)(seg + 1) * sg.seg_len);
+  if (sd.cnt_in) limit = min(limit, (size_t)seg * sg.seg_len + sd.cnt_in[seg]);
+  const bool compacting = sd.cnt_out != nullptr;
+  const KeyT skip = (KeyT)sd.skip;
   const size_t wbase = bbase + (size_t)wave * (R * 64);
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   KeyT key[R];
@@ -279,7 +373,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     size_t i = wbase + (size_t)r * 64 + lane;
-    bool valid = i < limit;
+    bool valid = i < limit && !(compacting && key[r] == skip);
     unsigned digit = (unsigned)(key[r] >> shift) & mask;
     unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -309,11 +403,22 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
     }
     unsigned tot;
     unsigned ex = block_excl_scan(sum, tot, s_scan);
+    if (threadIdx.x == 0) s_scan[4] = tot;          // keys this block really moves (block_excl_scan uses [0..3])
+    // the flat scan counts the keys of all earlier segments; the segment itself starts at seg*seg_len
+    const size_t seg_first = (size_t)seg * NB * sg.nblk_seg;
+    const unsigned seg_base = ghist_scanned[seg_first];
+    if (compacting && blk == 0 && threadIdx.x == 0) {
+      // survivors of this segment = what the flat scan counts between this segment's first entry and the next one's
+      const unsigned nseg = gridDim.x / sg.nblk_seg;
+      const unsigned next = seg + 1 < nseg ? ghist_scanned[seg_first + (size_t)NB * sg.nblk_seg] : *sd.total;
+      sd.cnt_out[seg] = next - seg_base;
+    }
+    const unsigned seg_org = (unsigned)((size_t)seg * sg.seg_len);
 #pragma unroll
     for (int j = 0; j < DPT; ++j) {
       int d = threadIdx.x * DPT + j;
       s_dbase[d] = ex;
-      s_gbase[d] = ghist_scanned[((size_t)seg * NB + d) * sg.nblk_seg + blk];
+      s_gbase[d] = ghist_scanned[seg_first + (size_t)d * sg.nblk_seg + blk] - seg_base + seg_org;
       unsigned run = ex;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
@@ -329,7 +434,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     size_t i = wbase + (size_t)r * 64 + lane;
-    if (i < limit) {
+    if (i < limit && !(compacting && key[r] == skip)) {
       unsigned digit = (unsigned)(key[r] >> shift) & mask;
       unsigned slot = cnt[wave][digit] + pos[r];
       s_keys[slot] = key[r];
@@ -337,7 +442,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
     }
   }
   __syncthreads();
-  const unsigned nvalid = bbase < limit ? (unsigned)min((size_t)BK, limit - bbase) : 0u;
+  const unsigned nvalid = s_scan[4];
 #pragma unroll 4
   for (int r = 0; r < R; ++r) {
     unsigned slot = (unsigned)r * 256 + threadIdx.x;
@@ -351,6 +456,29 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
       // final pass of the tile sort: also leave gather_src[payload] in sorted order (the record index of every
       // sorted entry, fetched here among the scatter's own latencies instead of in a separate pass over the list)
       if (gather_out) gather_out[dst] = gather_src[v];
+    }
+  }
+  if (p2_out) {
+    // the second payload takes the same trip through LDS (s_vals is free again once everyone has read it):
+    // sequential traffic instead of a random gather by payload afterwards
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      size_t i = wbase + (size_t)r * 64 + lane;
+      if (i < limit && !(compacting && key[r] == skip)) {
+        unsigned digit = (unsigned)(key[r] >> shift) & mask;
+        s_vals[cnt[wave][digit] + pos[r]] = p2_in[i];       // (loaded here: held since the top it costs 16 VGPRs
+                                                            //  and a fourth of the occupancy)
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < R; ++r) {
+      unsigned slot = (unsigned)r * 256 + threadIdx.x;
+      if (slot < nvalid) {
+        unsigned digit = (unsigned)(s_keys[slot] >> shift) & mask;
+        p2_out[(size_t)s_gbase[digit] + (slot - s_dbase[digit])] = s_vals[slot];
+      }
     }
   }
 }
@@ -399,7 +527,8 @@ template <typename KeyT, int BITS>
 static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned* vin, KeyT* kout, unsigned* vout,
                        int shift, unsigned mask, void* ws, size_t hist_bytes, hipStream_t st,
                        const unsigned* gather_src = nullptr, unsigned* gather_out = nullptr,
-                       const unsigned* n_dev = nullptr) {
+                       const unsigned* n_dev = nullptr, SegDev sd = SegDev{nullptr, nullptr, nullptr, 0ull},
+                       const unsigned* p2_in = nullptr, unsigned* p2_out = nullptr) {
   SegInfo sg;
   unsigned nblk = sort_nblk_seg<KeyT>(n, seg_len, &sg.nblk_seg);
   sg.seg_len = (seg_len == 0 || seg_len >= n) ? n : seg_len;
@@ -407,11 +536,11 @@ static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned
   size_t hn = ((size_t)1 << BITS) * nblk;
   void* scan_ws = reinterpret_cast<char*>(ws) + hist_bytes;
   hipLaunchKernelGGL((radix_hist_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, shift, mask, sg, ghist,
-                     n_dev);
-  run_scan(hn, ghist, ghist, nullptr, scan_ws, st,
+                     n_dev, sd);
+  run_scan(hn, ghist, ghist, sd.cnt_out ? const_cast<unsigned*>(sd.total) : nullptr, scan_ws, st,
            DevLen{n_dev, (unsigned)sort_block_keys<KeyT>(), (unsigned)(1u << BITS)});
   hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, vin, kout, vout, shift,
-                     mask, sg, ghist, gather_src, gather_out, n_dev);
+                     mask, sg, ghist, gather_src, gather_out, n_dev, sd, p2_in, p2_out);
 }
 
 // Sort bits [begin_bit, end_bit).  Ping-pongs between (k0,v0) and (k1,v1); returns the index
@@ -420,7 +549,13 @@ template <typename KeyT>
 static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1, unsigned* v1, int v0_is_iota,
                       int begin_bit, int end_bit, void* ws, size_t ws_bytes, int* result_buf, hipStream_t st,
                       int max_digit = 11, const unsigned* gather_src = nullptr, unsigned* gather_out = nullptr,
-                      const unsigned* n_dev = nullptr) {
+                      const unsigned* n_dev = nullptr, unsigned* seg_counts = nullptr,
+                      unsigned long long skip_key = 0ull, const unsigned* p2_src = nullptr, unsigned* p2_a = nullptr,
+                      unsigned* p2_b = nullptr, int* result_p2 = nullptr) {
+  // p2_src != NULL: a second payload travels with every key (p2_src[i] belongs to input element i); pass p writes it
+  // to p2_a (even p) / p2_b (odd p), *result_p2 = 0 / 1 says which of the two holds the sorted result
+  // seg_counts != NULL: compacting segmented sort (see SegDev) — keys equal to skip_key are dropped by the first
+  // pass, seg_counts[segment] receives the survivors, later passes only move those
   int bits = end_bit - begin_bit;
   if (bits <= 0) return GS_ERR_INVALID;
   if (ws_bytes < radix_ws_bytes<KeyT>(n, seg_len, bits, max_digit)) return GS_ERR_WORKSPACE;
@@ -437,16 +572,31 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
     const unsigned* vin = (p == 0 && v0_is_iota) ? nullptr : vv[cur];
     const unsigned* gs_ = (p == passes - 1) ? gather_src : nullptr;
     unsigned* go_ = (p == passes - 1) ? gather_out : nullptr;
+    SegDev sd{nullptr, nullptr, nullptr, 0ull};
+    if (seg_counts) {
+      // the pass's grand total lives in the slack at the end of the workspace
+      unsigned* total_dev = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) +
+                                                        radix_ws_bytes<KeyT>(n, seg_len, bits, max_digit) - 128);
+      if (p == 0) sd = SegDev{nullptr, seg_counts, total_dev, skip_key};
+      else sd = SegDev{seg_counts, nullptr, nullptr, 0ull};
+    }
+    const unsigned* p2i = nullptr;
+    unsigned* p2o = nullptr;
+    if (p2_src) {
+      p2o = (p & 1) ? p2_b : p2_a;
+      p2i = p == 0 ? p2_src : ((p & 1) ? p2_a : p2_b);
+    }
     switch (tb) {
-      case 8:  radix_pass<KeyT, 8>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev); break;
-      case 9:  radix_pass<KeyT, 9>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev); break;
-      case 10: radix_pass<KeyT, 10>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev); break;
-      default: radix_pass<KeyT, 11>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev); break;
+      case 8:  radix_pass<KeyT, 8>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
+      case 9:  radix_pass<KeyT, 9>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
+      case 10: radix_pass<KeyT, 10>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
+      default: radix_pass<KeyT, 11>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
     }
     shift += w;
     cur ^= 1;
   }
   *result_buf = cur;
+  if (result_p2) *result_p2 = (passes - 1) & 1;
   return gs_launch_status();
 }
 
@@ -735,21 +885,22 @@ __device__ __forceinline__ int slice_rank(const SliceDesc& sd, int j) {
 __global__ void slice_plan_kernel(int P, int N, int K, const unsigned* __restrict__ cum,
                                   const unsigned* __restrict__ total, unsigned long long base,
                                   int* __restrict__ bounds, unsigned* __restrict__ rels,
-                                  unsigned* __restrict__ seg_totals) {
+                                  unsigned* __restrict__ seg_totals, const unsigned* __restrict__ n_live) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P * K) return;
   const int p = i / K, k = i % K;
   const unsigned* c = cum + (size_t)p * N;
   const unsigned long long tgt = base << k;
   const unsigned c0 = c[0];
-  int lo = 0, hi = N;                 // first r in [0,N] with rel(r) >= tgt  (N if none)
+  const int M = n_live ? (int)min((unsigned)N, n_live[p]) : N;     // ranks [M, N) hold nothing
+  int lo = 0, hi = M;                 // first r in [0,M] with rel(r) >= tgt  (M if none)
   while (lo < hi) {
     int mid = (lo + hi) >> 1;
     if ((unsigned long long)(unsigned)(c[mid] - c0) >= tgt) hi = mid; else lo = mid + 1;
   }
   bounds[i] = lo;
   const unsigned seg_end = (p + 1 < P) ? c[N] : *total;
-  rels[i] = (lo < N ? c[lo] : seg_end) - c0;
+  rels[i] = (lo < M ? c[lo] : seg_end) - c0;
   if (k == 0 && seg_totals) seg_totals[p] = seg_end - c0;     // the sub-pose's own total (mod 2^32)
 }
 
@@ -975,11 +1126,13 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
                                                         unsigned* __restrict__ keys, unsigned* __restrict__ vals,
                                                         int W, int H, unsigned invalid_key, int compact,
                                                         const unsigned long long* __restrict__ masks,   // nullable
-                                                        const unsigned* __restrict__ mask_off) {
+                                                        const unsigned* __restrict__ mask_off,
+                                                        unsigned char* __restrict__ tile_hot) {         // nullable
   const int lane = lane_id();
   const int j = WAVE_PER_G ? (lane == 0 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : n_slice)
                            : (int)(blockIdx.x * 256 + threadIdx.x);
   unsigned cnt = 0, gi = 0, e0 = 0, lo = 0, hi = 0, moff = 0;
+  int hot = 0;             // opacity above the alpha clamp: the tiles it lands on need the clamping compositor loop
   Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f, 0.f, 0.f, 0.f};
   if (j < n_slice) {
     cnt = counts[j];
@@ -989,6 +1142,7 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
       const float* rec = records + (size_t)gi * kRecFloats;
       lo = (unsigned)__float_as_int(rec[10]);
       hi = (unsigned)__float_as_int(rec[11]);
+      hot = (tile_hot != nullptr && rec[5] > K::kAlphaMax) ? 1 : 0;
       if (masks) moff = mask_off[j];
       else if (invalid_key) el = make_ellipse(rec);
     }
@@ -1009,6 +1163,7 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
     const int w = x1 - x0, area = w * (y1 - y0);
     const float rw = 1.0f / (float)w;
     const unsigned pbase = (g / (unsigned)N) * (unsigned)T;
+    const bool hot_g = readlane_i(hot, src) != 0;          // rare
     if (masks) {
       // the exact-count pass left one bit per box tile (open AND inside the ellipse): no second ellipse test,
       // no tile_done reads — a word per 64 tiles drives the compaction directly
@@ -1020,8 +1175,10 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
           const int q = (int)(((float)t + 0.5f) * rw);
           const int tx = x0 + (t - q * w), ty = y0 + q;
           const unsigned dst = e + (unsigned)__popcll(m & lt_mask);
-          keys[dst] = pbase + (unsigned)(ty * tiles_x + tx);
+          const unsigned k = pbase + (unsigned)(ty * tiles_x + tx);
+          keys[dst] = k;
           vals[dst] = g;
+          if (hot_g) tile_hot[k] = 1;
         }
         e += (unsigned)__popcll(m);
       }
@@ -1046,6 +1203,7 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
         const unsigned dst = e + (unsigned)__popcll(m & lt_mask);
         keys[dst] = k;
         vals[dst] = g;
+        if (hot_g && (invalid_key == 0u || k != invalid_key)) tile_hot[k] = 1;
       }
       e += (unsigned)__popcll(m);
     }
@@ -1134,6 +1292,22 @@ GS_EXPORT int gs_radix_sort_pairs_gather_u32(long long n, unsigned* keys0, unsig
                               (size_t)ws_bytes, result_buf, (hipStream_t)stream, 11, gather_src, gather_out, n_dev);
 }
 
+// gs_radix_sort_pairs_u32 with a SECOND payload per key: payload2_in[i] belongs to input element i (not clobbered);
+// the passes ping-pong it through payload2_a / payload2_b (n ints each), *result_p2 (host) = 0 / 1 names the one
+// that holds it in sorted order.  The tile sort of a depth slice carries the record index of every entry this way
+// (8 sequential bytes per entry and pass instead of a random 4-byte gather per entry after the sort).
+GS_EXPORT int gs_radix_sort_pairs_carry_u32(long long n, unsigned* keys0, unsigned* vals0, unsigned* keys1,
+                                            unsigned* vals1, int vals0_is_iota, int begin_bit, int end_bit, void* ws,
+                                            long long ws_bytes, int* result_buf, const unsigned* payload2_in,
+                                            unsigned* payload2_a, unsigned* payload2_b, int* result_p2,
+                                            const unsigned* n_dev, void* stream) {
+  if (n <= 0 || begin_bit < 0 || end_bit > 32 || !payload2_in || !payload2_a || !payload2_b || !result_p2)
+    return GS_ERR_INVALID;
+  return radix_sort<unsigned>((size_t)n, 0, keys0, vals0, keys1, vals1, vals0_is_iota, begin_bit, end_bit, ws,
+                              (size_t)ws_bytes, result_buf, (hipStream_t)stream, 11, nullptr, nullptr, n_dev, nullptr,
+                              0ull, payload2_in, payload2_a, payload2_b, result_p2);
+}
+
 GS_EXPORT int gs_radix_sort_pairs_u64(long long n, unsigned long long* keys0, unsigned* vals0,
                                       unsigned long long* keys1, unsigned* vals1, int vals0_is_iota, int begin_bit,
                                       int end_bit, void* ws, long long ws_bytes, int* result_buf, void* stream) {
@@ -1158,6 +1332,34 @@ GS_EXPORT int gs_segmented_sort_pairs_u32(long long n, long long seg_len, unsign
   // (250 VGPRs, 80 KB LDS per block) — measured 0.51 ms vs 0.37 ms for the 64-bit route at 5M keys
   return radix_sort<unsigned>((size_t)n, (size_t)seg_len, keys0, vals0, keys1, vals1, vals0_is_iota, begin_bit,
                               end_bit, ws, (size_t)ws_bytes, result_buf, (hipStream_t)stream, 8);
+}
+
+// Compacting form for the depth pre-sort: keys equal to skip_key (culled Gaussians) are dropped by the first pass.
+// On return segment s holds its seg_counts[s] surviving keys sorted at [s*seg_len, s*seg_len + seg_counts[s]); what
+// lies behind them is unspecified.  Payload = global index (iota).  gather_src / gather_out (nullable together):
+// gather_out[slot] = gather_src[payload] for every sorted survivor, written by the last pass.
+GS_EXPORT int gs_segmented_sort_compact_u32(long long n, long long seg_len, unsigned* keys0, unsigned* vals0,
+                                            unsigned* keys1, unsigned* vals1, int begin_bit, int end_bit,
+                                            unsigned skip_key, unsigned* seg_counts, const unsigned* gather_src,
+                                            unsigned* gather_out, void* ws, long long ws_bytes, int* result_buf,
+                                            void* stream) {
+  if (n <= 0 || seg_len <= 0 || n % seg_len != 0 || begin_bit < 0 || end_bit > 32 || !seg_counts)
+    return GS_ERR_INVALID;
+  if ((gather_src != nullptr) != (gather_out != nullptr)) return GS_ERR_INVALID;
+  return radix_sort<unsigned>((size_t)n, (size_t)seg_len, keys0, vals0, keys1, vals1, 1, begin_bit, end_bit, ws,
+                              (size_t)ws_bytes, result_buf, (hipStream_t)stream, 8, gather_src, gather_out, nullptr,
+                              seg_counts, (unsigned long long)skip_key);
+}
+
+// Exclusive scan over n = k*seg_len values of which only the first seg_counts[s] of every segment are live: the rest
+// count as zero and are not read (out is still written everywhere).
+GS_EXPORT int gs_exclusive_scan_segments_u32(long long n, long long seg_len, const unsigned* seg_counts,
+                                             const unsigned* in, unsigned* out, unsigned* total_out, void* ws,
+                                             long long ws_bytes, void* stream) {
+  if (n <= 0 || seg_len <= 0 || n % seg_len != 0 || !seg_counts) return GS_ERR_INVALID;
+  if ((size_t)ws_bytes < scan_ws_bytes((size_t)n)) return GS_ERR_WORKSPACE;
+  return run_scan((size_t)n, in, out, total_out, ws, (hipStream_t)stream, DevLen{nullptr, 1u, 1u},
+                  SegMask{seg_counts, (size_t)seg_len});
 }
 
 // (sub-pose, depth) keys for the N-sized pre-sort: out[i] = (i / N) << 32 | depth_keys[i]
@@ -1243,10 +1445,10 @@ GS_EXPORT int gs_map_gaussian_to_intersects(int N, const float* xys, const float
 // ---- depth-sliced binning -------------------------------------------------------------------
 // bounds [P*K]: first depth rank of each sub-pose at which the cumulative intersection count reaches base<<k
 GS_EXPORT int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl, const unsigned* total, long long base,
-                            int* bounds, unsigned* rels, unsigned* seg_totals, void* stream) {
+                            int* bounds, unsigned* rels, unsigned* seg_totals, const unsigned* n_live, void* stream) {
   if (P <= 0 || N <= 0 || K <= 0 || K > 32 || base <= 0) return GS_ERR_INVALID;
   hipLaunchKernelGGL(slice_plan_kernel, dim3((P * K + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, N, K, cum_excl,
-                     total, (unsigned long long)base, bounds, rels, seg_totals);
+                     total, (unsigned long long)base, bounds, rels, seg_totals, n_live);
   return gs_launch_status();
 }
 
@@ -1307,18 +1509,19 @@ GS_EXPORT int gs_emit_open_intersects(int n_slice, int N, int H, int W, const un
                                       const unsigned* counts, const unsigned* cum_excl, const float* records,
                                       const unsigned char* tile_done, unsigned* keys, unsigned* vals,
                                       unsigned invalid_key, int compact, int wave_per_gaussian,
-                                      const unsigned long long* hit_masks, const unsigned* mask_off, void* stream) {
+                                      const unsigned long long* hit_masks, const unsigned* mask_off,
+                                      unsigned char* tile_hot, void* stream) {
   if (n_slice <= 0) return GS_ERR_INVALID;
   if (hit_masks && (!mask_off || !compact)) return GS_ERR_INVALID;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
   if (wave_per_gaussian)
     hipLaunchKernelGGL(emit_open_kernel<true>, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream, n_slice, N,
                        tiles_x * tiles_y, tiles_x, slice_gi, counts, cum_excl, records, tile_done, keys, vals, W, H,
-                       invalid_key, compact, hit_masks, mask_off);
+                       invalid_key, compact, hit_masks, mask_off, tile_hot);
   else
     hipLaunchKernelGGL(emit_open_kernel<false>, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice,
                        N, tiles_x * tiles_y, tiles_x, slice_gi, counts, cum_excl, records, tile_done, keys, vals, W, H,
-                       invalid_key, compact, hit_masks, mask_off);
+                       invalid_key, compact, hit_masks, mask_off, tile_hot);
   return gs_launch_status();
 }
 

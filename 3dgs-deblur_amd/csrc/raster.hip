@@ -173,7 +173,11 @@ struct PixPair { f2 T, Cr, Cg, Cb, Cd, py; int last0, last1; };
 
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <bool DEPTH>
+// CLAMP=false: no Gaussian of this tile's list has an opacity above 0.999 (the binning flags the tiles that do, see
+// tile_hot), so alpha = op * exp(..) <= op can never reach the clamp on a pixel that is blended (those have
+// s2 <= 0): min(0.999, .) is the identity there and is not issued.  The choice is made once per tile, outside the
+// loop: a per-entry branch costs more in merge copies than the two v_min it saves (measured, round 2 run 22).
+template <bool DEPTH, bool CLAMP>
 __device__ __forceinline__ void blend_entry(const RecS& rc, float pxf, int idx1, PixPair (&pp)[2]) {
   const float kL2E = -1.4426950408889634f;
   const float qx = rc.cx * (0.5f * kL2E), qy = rc.cy * kL2E, qz = rc.cz * (0.5f * kL2E);
@@ -188,7 +192,7 @@ __device__ __forceinline__ void blend_entry(const RecS& rc, float pxf, int idx1,
     const f2 dy = gy2 - q.py;
     const f2 s2 = fma2(dy, fma2(qz2, dy, bx2), hx2);
     const f2 ov = op2 * f2{__builtin_amdgcn_exp2f(s2.x), __builtin_amdgcn_exp2f(s2.y)};
-    const f2 alpha = {fminf(K::kAlphaMax, ov.x), fminf(K::kAlphaMax, ov.y)};
+    const f2 alpha = CLAMP ? f2{fminf(K::kAlphaMax, ov.x), fminf(K::kAlphaMax, ov.y)} : ov;
     const bool v0 = (s2.x <= 0.f) && (alpha.x >= K::kAlphaMin), v1 = (s2.y <= 0.f) && (alpha.y >= K::kAlphaMin);
     const f2 w0 = alpha * q.T;
     const f2 nT = fma2(-q.T, alpha, q.T);
@@ -204,6 +208,40 @@ __device__ __forceinline__ void blend_entry(const RecS& rc, float pxf, int idx1,
   }
 }
 
+__device__ __forceinline__ bool any_live(const PixPair (&pp)[2]) {
+  return __ballot(fmaxf(fmaxf(pp[0].T.x, pp[0].T.y), fmaxf(pp[1].T.x, pp[1].T.y)) > 0.f) != 0ull;
+}
+
+// the tile's list, front to back (n = range.y - range.x > 0 entries)
+template <bool DEPTH, bool CLAMP>
+__device__ __forceinline__ void fwd_walk(const int* __restrict__ ids, const float* __restrict__ records, unsigned max_id,
+                                         int2 range, unsigned n, float pxf, PixPair (&pp)[2]) {
+  int b = range.x & ~3;
+  const int4* __restrict__ ids4 = reinterpret_cast<const int4*>(ids);
+  int4 idv = ids4[b >> 2];
+  // indices read in front of / behind the tile's own range belong to other tiles (or to the padding): clamp, the
+  // record is loaded but never blended
+  RecS a0 = load_rec_s<DEPTH>(records, min((unsigned)idv.x, max_id)), a1 = load_rec_s<DEPTH>(records, min((unsigned)idv.y, max_id));
+  for (;;) {
+    // pair A (entries b, b+1) is ready; put pair B (b+2, b+3) and the indices of the next group in flight
+    asm volatile("" :: "s"(a0.x), "s"(a1.x) : "memory");
+    const RecS b0 = load_rec_s<DEPTH>(records, min((unsigned)idv.z, max_id)), b1 = load_rec_s<DEPTH>(records, min((unsigned)idv.w, max_id));
+    idv = ids4[(b >> 2) + 1];
+    asm volatile("" ::: "memory");
+    if ((unsigned)(b - range.x) < n) blend_entry<DEPTH, CLAMP>(a0, pxf, b + 1, pp);
+    if ((unsigned)(b + 1 - range.x) < n) blend_entry<DEPTH, CLAMP>(a1, pxf, b + 2, pp);
+    // pair B is ready; refill pair A from the next group
+    asm volatile("" :: "s"(b0.x), "s"(b1.x), "s"(idv.x) : "memory");
+    a0 = load_rec_s<DEPTH>(records, min((unsigned)idv.x, max_id)); a1 = load_rec_s<DEPTH>(records, min((unsigned)idv.y, max_id));
+    asm volatile("" ::: "memory");
+    if ((unsigned)(b + 2 - range.x) < n) blend_entry<DEPTH, CLAMP>(b0, pxf, b + 3, pp);
+    if ((unsigned)(b + 3 - range.x) < n) blend_entry<DEPTH, CLAMP>(b1, pxf, b + 4, pp);
+    b += 4;
+    if (b >= range.y) break;
+    if ((b & 12) == 12 && !any_live(pp)) break;
+  }
+}
+
 template <bool DEPTH>
 __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm, SliceState st,
                                                                const int* __restrict__ ids,       // padded, see ABI
@@ -211,7 +249,8 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
                                                                float* __restrict__ out_img,
                                                                float* __restrict__ out_T,
                                                                int* __restrict__ final_idx, unsigned n_blocks,
-                                                               float* __restrict__ out_depth) {
+                                                               float* __restrict__ out_depth,
+                                                               const unsigned char* __restrict__ tile_hot) {
   const int lane = lane_id();
   const int T = prm.tiles_x * prm.tiles_y;
   const unsigned work = (unsigned)__builtin_amdgcn_readfirstlane(
@@ -247,37 +286,13 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
     if (k & 1) { q.T.y = Tk; q.Cr.y = cr; q.Cg.y = cg; q.Cb.y = cb; q.Cd.y = cd; q.py.y = (float)(py0 + k) + 0.5f; q.last1 = range.x; }
     else       { q.T.x = Tk; q.Cr.x = cr; q.Cg.x = cg; q.Cb.x = cb; q.Cd.x = cd; q.py.x = (float)(py0 + k) + 0.5f; q.last0 = range.x; }
   }
-  auto any_live = [&]() -> bool {
-    return __ballot(fmaxf(fmaxf(pp[0].T.x, pp[0].T.y), fmaxf(pp[1].T.x, pp[1].T.y)) > 0.f) != 0ull;
-  };
   const unsigned n = (unsigned)(range.y - range.x);
   if (n != 0u) {
-    int b = range.x & ~3;
-    const int4* __restrict__ ids4 = reinterpret_cast<const int4*>(ids);
-    int4 idv = ids4[b >> 2];
-    // indices read in front of / behind the tile's own range belong to other tiles (or to the padding): clamp, the
-    // record is loaded but never blended
-    RecS a0 = load_rec_s<DEPTH>(records, min((unsigned)idv.x, max_id)), a1 = load_rec_s<DEPTH>(records, min((unsigned)idv.y, max_id));
-    for (;;) {
-      // pair A (entries b, b+1) is ready; put pair B (b+2, b+3) and the indices of the next group in flight
-      asm volatile("" :: "s"(a0.x), "s"(a1.x) : "memory");
-      const RecS b0 = load_rec_s<DEPTH>(records, min((unsigned)idv.z, max_id)), b1 = load_rec_s<DEPTH>(records, min((unsigned)idv.w, max_id));
-      idv = ids4[(b >> 2) + 1];
-      asm volatile("" ::: "memory");
-      if ((unsigned)(b - range.x) < n) blend_entry<DEPTH>(a0, pxf, b + 1, pp);
-      if ((unsigned)(b + 1 - range.x) < n) blend_entry<DEPTH>(a1, pxf, b + 2, pp);
-      // pair B is ready; refill pair A from the next group
-      asm volatile("" :: "s"(b0.x), "s"(b1.x), "s"(idv.x) : "memory");
-      a0 = load_rec_s<DEPTH>(records, min((unsigned)idv.x, max_id)); a1 = load_rec_s<DEPTH>(records, min((unsigned)idv.y, max_id));
-      asm volatile("" ::: "memory");
-      if ((unsigned)(b + 2 - range.x) < n) blend_entry<DEPTH>(b0, pxf, b + 3, pp);
-      if ((unsigned)(b + 3 - range.x) < n) blend_entry<DEPTH>(b1, pxf, b + 4, pp);
-      b += 4;
-      if (b >= range.y) break;
-      if ((b & 12) == 12 && !any_live()) break;
-    }
+    const bool hot = tile_hot == nullptr || __builtin_amdgcn_readfirstlane((int)tile_hot[tkey]) != 0;
+    if (hot) fwd_walk<DEPTH, true>(ids, records, max_id, range, n, pxf, pp);
+    else fwd_walk<DEPTH, false>(ids, records, max_id, range, n, pxf, pp);
   }
-  const bool all_stopped = !any_live();
+  const bool all_stopped = !any_live(pp);
   const bool finalize = all_stopped || st.last;
   const float bgr = finalize ? prm.background[0] : 0.f, bgg = finalize ? prm.background[1] : 0.f,
               bgb = finalize ? prm.background[2] : 0.f;
@@ -372,17 +387,19 @@ using namespace gs;
 // Replaces the device side of gsplat.rasterize_gaussians' forward
 // (_C.rasterize_forward in the absent fork; SURVEY.md §8 a7, boundary §8b).
 static int launch_fwd(const RasterParams& prm, const SliceState& st, const int* ids, int n_records, float* out_img,
-                      float* out_T, int* final_idx, int variant, hipStream_t stream, float* out_depth = nullptr) {
+                      float* out_T, int* final_idx, int variant, hipStream_t stream, float* out_depth = nullptr,
+                      const unsigned char* tile_hot = nullptr) {
   unsigned work = (unsigned)(prm.S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
   if (out_depth && !(variant == 0 && ids)) return GS_ERR_INVALID;   // the depth channel lives in the scalar-cache kernel
   if (variant == 0 && ids && out_depth)
     hipLaunchKernelGGL(raster_fwd_sload_kernel<true>, dim3(blocks), dim3(256), 0, stream, prm, st, ids, prm.records,
-                       (unsigned)(n_records > 0 ? n_records - 1 : 0), out_img, out_T, final_idx, blocks, out_depth);
+                       (unsigned)(n_records > 0 ? n_records - 1 : 0), out_img, out_T, final_idx, blocks, out_depth,
+                       tile_hot);
   else if (variant == 0 && ids)
     hipLaunchKernelGGL(raster_fwd_sload_kernel<false>, dim3(blocks), dim3(256), 0, stream, prm, st, ids, prm.records,
                        (unsigned)(n_records > 0 ? n_records - 1 : 0), out_img, out_T, final_idx, blocks,
-                       (float*)nullptr);
+                       (float*)nullptr, tile_hot);
   else if (variant == 1)
     hipLaunchKernelGGL(raster_fwd_slice_kernel<false>, dim3(blocks), dim3(256), 0, stream, prm, st, out_img, out_T,
                        final_idx, blocks);
@@ -410,19 +427,21 @@ GS_EXPORT int gs_rasterize_fwd(const float* records, const int* sorted_vals, con
 // state between launches; tile_done [S*R*T] (zeroed by the caller before the first slice) flags tiles
 // whose pixels have all stopped.  first/last mark the first and the final slice (first && last ==
 // the unsliced pass).  final_idx is per slice (the backward needs one per slice).
+// tile_hot (nullable) [S*R*T] u8, from gs_emit_open_intersects: non-zero where the tile's list of THIS slice holds
+// a Gaussian with opacity > 0.999; the other tiles run the loop version without the alpha clamp (NULL: all clamp).
 GS_EXPORT int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                                      const int* band_edges, const float* background, int S, int R, int H, int W,
                                      float* out_img, float* out_T, float* live_T, int* final_idx,
                                      unsigned char* tile_done, int first, int last, const int* gi_of_e,
-                                     const int* sorted_ids, int n_records, float* out_depth, int variant,
-                                     void* stream) {
+                                     const int* sorted_ids, int n_records, float* out_depth,
+                                     const unsigned char* tile_hot, int variant, void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
   prm.gi_of_e = gi_of_e;
   SliceState st; st.tile_done = tile_done; st.live_T = live_T; st.first = first; st.last = last;
   const int* ids = sorted_ids ? sorted_ids : (gi_of_e ? nullptr : sorted_vals);
   int rc = launch_fwd(prm, st, n_records > 0 ? ids : nullptr, n_records, out_img, out_T, final_idx, variant,
-                      (hipStream_t)stream, out_depth);
+                      (hipStream_t)stream, out_depth, tile_hot);
   if (rc != GS_OK) return rc;
   return gs_launch_status();
 }

@@ -358,6 +358,8 @@ __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementw
 
 // one list entry against the lane's four pixels; returns whether any lane of the wave was hit (then the lane's 9
 // partial sums are in LDS rows slot*9 .. slot*9+8, column `lane`)
+// CLAMP=false: no Gaussian of the tile's list has an opacity above 0.999 (tile_hot, see the forward)
+template <bool CLAMP>
 __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, BwdPair (&pp)[2], float* __restrict__ red,
                                           int slot, int lane, float agm) {
   const float kL2E = -1.4426950408889634f;
@@ -381,13 +383,10 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
   if (__ballot(hit[0] || hit[1] || hit[2] || hit[3]) == 0ull) return false;
   const f2 cr2 = {rc.r, rc.r}, cg2 = {rc.g, rc.g}, cb2 = {rc.b, rc.b};
   f2 q_op = {0.f, 0.f}, q_r = q_op, q_g = q_op, q_b = q_op, m0 = q_op, m1 = q_op, m2 = q_op;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  // pixels that are not hit are neutralised by SELECTING alpha = 0 (1/(1-0) = 1 exactly, every contribution is an
+  // exact zero) instead of per-pixel exec regions
+  auto pair = [&](int h, f2 alpha, f2 vism, f2 ovm) {
     BwdPair& q = pp[h];
-    const bool h0 = hit[2 * h], h1 = hit[2 * h + 1];
-    // pixels that are not hit are neutralised by SELECTING alpha = 0 (1/(1-0) = 1 exactly, every contribution is
-    // an exact zero) instead of per-pixel exec regions
-    const f2 alpha = {h0 ? fminf(K::kAlphaMax, ov2[h].x) : 0.f, h1 ? fminf(K::kAlphaMax, ov2[h].y) : 0.f};
     const f2 om = 1.f - alpha;
     const f2 ra = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
     q.T *= ra;                               // transmittance in front of this Gaussian
@@ -396,10 +395,6 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
     const f2 cv = fma2(cb2, q.vb, fma2(cg2, q.vg, cr2 * q.vr));
     const f2 v_al = fma2(q.T, cv, -(ra * q.Dv));
     q.Dv = fma2(fac, cv, q.Dv);
-    // d min(0.999, o*vis) = 0 when clamped
-    const bool f0 = h0 && ov2[h].x <= agm, f1 = h1 && ov2[h].y <= agm;
-    const f2 vism = {f0 ? vis2[h].x : 0.f, f1 ? vis2[h].y : 0.f};
-    const f2 ovm = op2 * vism;               // == ov where the gradient flows (the same product), 0 elsewhere
     const f2 v_sigma = -ovm * v_al;
     q_op = fma2(vism, v_al, q_op);
     // moments of v_sigma over the lane's pixels (dx is the same for all four)
@@ -407,6 +402,28 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
     const f2 vsdy = v_sigma * dy2[h];
     m1 += vsdy;
     m2 = fma2(vsdy, dy2[h], m2);
+  };
+  if (CLAMP) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool h0 = hit[2 * h], h1 = hit[2 * h + 1];
+      const f2 alpha = {h0 ? fminf(K::kAlphaMax, ov2[h].x) : 0.f, h1 ? fminf(K::kAlphaMax, ov2[h].y) : 0.f};
+      // d min(0.999, o*vis) = 0 when clamped
+      const bool f0 = h0 && ov2[h].x <= agm, f1 = h1 && ov2[h].y <= agm;
+      const f2 vism = {f0 ? vis2[h].x : 0.f, f1 ? vis2[h].y : 0.f};
+      pair(h, alpha, vism, op2 * vism);      // op*vism == ov where the gradient flows (the same product), 0 elsewhere
+    }
+  } else {
+    // opacity <= 0.999 (<= agm): alpha = op*vis <= op never reaches the clamp on a hit pixel (s2 <= 0), so
+    // min(0.999, ov) == ov, the clamp never blocks the gradient, and op*vism is alpha itself.  (Chosen per TILE:
+    // a per-entry branch leaves four 64-bit merge copies per entry behind.)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool h0 = hit[2 * h], h1 = hit[2 * h + 1];
+      const f2 alpha = {h0 ? ov2[h].x : 0.f, h1 ? ov2[h].y : 0.f};
+      const f2 vism = {h0 ? vis2[h].x : 0.f, h1 ? vis2[h].y : 0.f};
+      pair(h, alpha, vism, alpha);
+    }
   }
   const float M0 = m0.x + m0.y, M1 = m1.x + m1.y, M2 = m2.x + m2.y;
   const float p_cx = (0.5f * dx * dx) * M0, p_cy = dx * M1, p_cz = 0.5f * M2;
@@ -419,6 +436,65 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
   return true;
 }
 
+// the tile's list, back to front, entries [range_x, wave_end)
+template <bool CLAMP, int OUT>
+__device__ __forceinline__ void bwd_walk(const int* __restrict__ ids, const int* __restrict__ eids,
+                                         const float* __restrict__ records, unsigned max_id, int range_x, int wave_end,
+                                         unsigned n, float pxf, float agm, BwdPair (&pp)[2], float* __restrict__ red,
+                                         int lane, float* __restrict__ v_records, float* __restrict__ tuples,
+                                         unsigned char* __restrict__ flags) {
+  const int row = lane;                                    // row-sum role: lanes 0..35
+  const int row_g = row / 9, row_c = row - row_g * 9;
+  const int4* __restrict__ ids4 = reinterpret_cast<const int4*>(ids);
+  const int4* __restrict__ eids4 = reinterpret_cast<const int4*>(eids);
+  int b = (wave_end - 1) & ~3;
+  const int b_last = range_x & ~3;
+  int4 idv = ids4[b >> 2];
+  RecS a0 = load_rec_s(records, min((unsigned)idv.w, max_id)), a1 = load_rec_s(records, min((unsigned)idv.z, max_id));
+  for (;;) {
+    // pair A (entries b+3, b+2) is ready; put pair B (b+1, b) and the indices of the next (lower) group in flight
+    asm volatile("" :: "s"(a0.x), "s"(a1.x) : "memory");
+    const RecS b0 = load_rec_s(records, min((unsigned)idv.y, max_id)), b1 = load_rec_s(records, min((unsigned)idv.x, max_id));
+    const int4 cur = idv;
+    int4 ev = cur;
+    if (OUT == 1) ev = eids4[b >> 2];
+    // (unconditional: a conditional refill turns into a phi whose copies wait for the loads right where they are
+    // issued; below the tile's first group the previous group — or group 0 again — is fetched and never used)
+    idv = ids4[max(b - 4, 0) >> 2];
+    asm volatile("" ::: "memory");
+    unsigned filled = 0;
+    if ((unsigned)(b + 3 - range_x) < n && bwd_entry<CLAMP>(a0, pxf, b + 3, pp, red, 3, lane, agm)) filled |= 8u;
+    if ((unsigned)(b + 2 - range_x) < n && bwd_entry<CLAMP>(a1, pxf, b + 2, pp, red, 2, lane, agm)) filled |= 4u;
+    // pair B is ready; refill pair A from the next group
+    asm volatile("" :: "s"(b0.x), "s"(b1.x), "s"(idv.x), "s"(ev.x) : "memory");
+    a0 = load_rec_s(records, min((unsigned)idv.w, max_id)); a1 = load_rec_s(records, min((unsigned)idv.z, max_id));
+    asm volatile("" ::: "memory");
+    if ((unsigned)(b + 1 - range_x) < n && bwd_entry<CLAMP>(b0, pxf, b + 1, pp, red, 1, lane, agm)) filled |= 2u;
+    if ((unsigned)(b - range_x) < n && bwd_entry<CLAMP>(b1, pxf, b, pp, red, 0, lane, agm)) filled |= 1u;
+    if (filled) {
+      __builtin_amdgcn_wave_barrier();
+      if (row < kRedG4 * 9 && ((filled >> row_g) & 1u)) {
+        const f4* rp = reinterpret_cast<const f4*>(red + row * kRedStride);
+        f4 s0 = rp[0], s1 = rp[1], s2 = rp[2], s3 = rp[3];
+#pragma unroll
+        for (int q = 4; q < 16; q += 4) { s0 += rp[q]; s1 += rp[q + 1]; s2 += rp[q + 2]; s3 += rp[q + 3]; }
+        const f4 v = (s0 + s1) + (s2 + s3);
+        const float sum = (v.x + v.y) + (v.z + v.w);
+        const int id_e = row_g == 0 ? ev.x : (row_g == 1 ? ev.y : (row_g == 2 ? ev.z : ev.w));
+        if (OUT == 1) {
+          tuples[(size_t)(unsigned)id_e * kRecFloats + row_c] = sum;
+          if (row_c == 0) flags[(unsigned)id_e] = 1;
+        } else {
+          if (sum != 0.f) atomic_add_f32(v_records + (size_t)(unsigned)id_e * kRecFloats + row_c, sum);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (b <= b_last) break;
+    b -= 4;
+  }
+}
+
 template <bool STATE, int OUT>
 __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_sload_kernel(
     RasterParams prm, const int* __restrict__ ids /*record index per sorted entry, padded*/,
@@ -426,7 +502,7 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_sload_kernel(
     const float* __restrict__ records, unsigned max_id, const float* __restrict__ out_T,
     const int* __restrict__ final_idx, const float* __restrict__ v_img, const float* __restrict__ v_alpha,
     float* __restrict__ v_records, unsigned n_blocks, float* __restrict__ bwd_T, float* __restrict__ bwd_B,
-    float* __restrict__ tuples, unsigned char* __restrict__ flags) {
+    float* __restrict__ tuples, unsigned char* __restrict__ flags, const unsigned char* __restrict__ tile_hot) {
   __shared__ __attribute__((aligned(16))) float lds_all[4 * kRedFloats4];
   const int lane = lane_id();
   float* red = lds_all + (threadIdx.x >> 6) * kRedFloats4;   // wave-private
@@ -481,57 +557,10 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_sload_kernel(
   const int wave_end = __builtin_amdgcn_readfirstlane(wave_max_i(my_end));
   const unsigned n = (unsigned)(wave_end - range.x);       // entries [range.x, wave_end) reached some pixel's final index
   const float agm = prm.alpha_grad_max;
-  const int row = lane;                                    // row-sum role: lanes 0..35
-  const int row_g = row / 9, row_c = row - row_g * 9;
   if (n != 0u) {
-    const int4* __restrict__ ids4 = reinterpret_cast<const int4*>(ids);
-    const int4* __restrict__ eids4 = reinterpret_cast<const int4*>(eids);
-    int b = (wave_end - 1) & ~3;
-    const int b_last = range.x & ~3;
-    int4 idv = ids4[b >> 2];
-    RecS a0 = load_rec_s(records, min((unsigned)idv.w, max_id)), a1 = load_rec_s(records, min((unsigned)idv.z, max_id));
-    for (;;) {
-      // pair A (entries b+3, b+2) is ready; put pair B (b+1, b) and the indices of the next (lower) group in flight
-      asm volatile("" :: "s"(a0.x), "s"(a1.x) : "memory");
-      const RecS b0 = load_rec_s(records, min((unsigned)idv.y, max_id)), b1 = load_rec_s(records, min((unsigned)idv.x, max_id));
-      const int4 cur = idv;
-      int4 ev = cur;
-      if (OUT == 1) ev = eids4[b >> 2];
-      // (unconditional: a conditional refill turns into a phi whose copies wait for the loads right where they are
-      // issued; below the tile's first group the previous group — or group 0 again — is fetched and never used)
-      idv = ids4[max(b - 4, 0) >> 2];
-      asm volatile("" ::: "memory");
-      unsigned filled = 0;
-      if ((unsigned)(b + 3 - range.x) < n && bwd_entry(a0, pxf, b + 3, pp, red, 3, lane, agm)) filled |= 8u;
-      if ((unsigned)(b + 2 - range.x) < n && bwd_entry(a1, pxf, b + 2, pp, red, 2, lane, agm)) filled |= 4u;
-      // pair B is ready; refill pair A from the next group
-      asm volatile("" :: "s"(b0.x), "s"(b1.x), "s"(idv.x), "s"(ev.x) : "memory");
-      a0 = load_rec_s(records, min((unsigned)idv.w, max_id)); a1 = load_rec_s(records, min((unsigned)idv.z, max_id));
-      asm volatile("" ::: "memory");
-      if ((unsigned)(b + 1 - range.x) < n && bwd_entry(b0, pxf, b + 1, pp, red, 1, lane, agm)) filled |= 2u;
-      if ((unsigned)(b - range.x) < n && bwd_entry(b1, pxf, b, pp, red, 0, lane, agm)) filled |= 1u;
-      if (filled) {
-        __builtin_amdgcn_wave_barrier();
-        if (row < kRedG4 * 9 && ((filled >> row_g) & 1u)) {
-          const f4* rp = reinterpret_cast<const f4*>(red + row * kRedStride);
-          f4 s0 = rp[0], s1 = rp[1], s2 = rp[2], s3 = rp[3];
-#pragma unroll
-          for (int q = 4; q < 16; q += 4) { s0 += rp[q]; s1 += rp[q + 1]; s2 += rp[q + 2]; s3 += rp[q + 3]; }
-          const f4 v = (s0 + s1) + (s2 + s3);
-          const float sum = (v.x + v.y) + (v.z + v.w);
-          const int id_e = row_g == 0 ? ev.x : (row_g == 1 ? ev.y : (row_g == 2 ? ev.z : ev.w));
-          if (OUT == 1) {
-            tuples[(size_t)(unsigned)id_e * kRecFloats + row_c] = sum;
-            if (row_c == 0) flags[(unsigned)id_e] = 1;
-          } else {
-            if (sum != 0.f) atomic_add_f32(v_records + (size_t)(unsigned)id_e * kRecFloats + row_c, sum);
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      if (b <= b_last) break;
-      b -= 4;
-    }
+    const bool hot = tile_hot == nullptr || __builtin_amdgcn_readfirstlane((int)tile_hot[(size_t)p * T + t]) != 0;
+    if (hot) bwd_walk<true, OUT>(ids, eids, records, max_id, range.x, wave_end, n, pxf, agm, pp, red, lane, v_records, tuples, flags);
+    else bwd_walk<false, OUT>(ids, eids, records, max_id, range.x, wave_end, n, pxf, agm, pp, red, lane, v_records, tuples, flags);
   }
   if (STATE) {
 #pragma unroll
@@ -682,7 +711,8 @@ GS_EXPORT int gs_rasterize_bwd(const float* records, const int* sorted_vals, con
   if (n_records > 0 && variant == 0)
     hipLaunchKernelGGL((raster_bwd_sload_kernel<false, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm,
                        sorted_vals, sorted_vals, records, (unsigned)(n_records - 1), out_T, final_idx, v_img, v_alpha,
-                       v_records, blocks, (float*)nullptr, (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr);
+                       v_records, blocks, (float*)nullptr, (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr,
+                       (const unsigned char*)nullptr);
   else
     hipLaunchKernelGGL((raster_bwd_kernel_v2<false, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T,
                        final_idx, v_img, v_alpha, v_records, blocks, (float*)nullptr, (float*)nullptr, (float*)nullptr,
@@ -697,8 +727,8 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
                                      const float* out_T, const int* final_idx, const float* v_img,
                                      const float* v_alpha, float* bwd_T, float* bwd_B, float* v_records,
                                      const int* gi_of_e, float* tuples, unsigned char* flags,
-                                     const int* sorted_ids, int n_records, int variant,
-                                     const float* cmb_scale, float cmb_gamma, float cmb_min_level,
+                                     const int* sorted_ids, int n_records, const unsigned char* tile_hot,
+                                     int variant, const float* cmb_scale, float cmb_gamma, float cmb_min_level,
                                      void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
@@ -718,14 +748,15 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
       if (bwd_T && bwd_B)
         hipLaunchKernelGGL((raster_bwd_sload_kernel<true, 1>), dim3(blocks), dim3(256), 0, st, prm, ids, sorted_vals,
                            records, max_id, out_T, final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B, tuples,
-                           flags);
+                           flags, tile_hot);
       else          // the only slice: no reverse-traversal state to load or store
         hipLaunchKernelGGL((raster_bwd_sload_kernel<false, 1>), dim3(blocks), dim3(256), 0, st, prm, ids, sorted_vals,
                            records, max_id, out_T, final_idx, v_img, v_alpha, v_records, blocks, (float*)nullptr,
-                           (float*)nullptr, tuples, flags);
+                           (float*)nullptr, tuples, flags, tile_hot);
     } else {
       hipLaunchKernelGGL((raster_bwd_sload_kernel<true, 0>), dim3(blocks), dim3(256), 0, st, prm, ids, ids, records,
-                         max_id, out_T, final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);
+                         max_id, out_T, final_idx, v_img, v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags,
+                         tile_hot);
     }
     return gs_launch_status();
   }

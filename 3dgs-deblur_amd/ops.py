@@ -44,6 +44,10 @@ DEFER_COLOR = int(os.environ.get("GSD_DEFER_COLOR", "1"))
 HIT_MASKS = int(os.environ.get("GSD_HIT_MASKS", "1"))
 # depth pre-sort: 1 = per-sub-pose segments of 32-bit keys, 0 = one sort of 64-bit (sub-pose, depth) keys
 DEPTH_SORT_SEGMENTED = int(os.environ.get("GSD_DEPTH_SORT_SEGMENTED", "1"))
+# 1: the segmented depth pre-sort drops culled Gaussians in its first pass (0: sort all P*N keys, culled ones last)
+DEPTH_SORT_COMPACT = int(os.environ.get("GSD_DEPTH_SORT_COMPACT", "1"))
+# 1: the tile sort carries the record index of every entry as a second payload (0: gathers it in the final pass)
+TILE_SORT_CARRY = int(os.environ.get("GSD_TILE_SORT_CARRY", "1"))
 # 1: a depth slice's emitted-intersection count stays on the device (buffers / grids sized by the slice's bounding-box
 # count from the plan); 0: read it back (exact sizes, one more host synchronisation per slice) — A/B switch
 DEVICE_SIZES = int(os.environ.get("GSD_DEVICE_SIZES", "1"))
@@ -200,10 +204,13 @@ def exclusive_scan_u32(x: Tensor) -> Tuple[Tensor, Tensor]:
 
 
 def radix_sort_pairs(keys: Tensor, vals: Optional[Tensor], begin_bit: int, end_bit: int,
-                     gather_src: Optional[Tensor] = None, n_dev: Optional[Tensor] = None):
+                     gather_src: Optional[Tensor] = None, n_dev: Optional[Tensor] = None,
+                     carry: Optional[Tensor] = None):
     """Stable ascending sort of (key, int32 value) pairs over key bits [begin_bit, end_bit).
     keys int32 (treated as u32) or int64 (u64); vals None => iota.  Inputs are clobbered.
-    gather_src (int32 keys only): the final pass also returns gather_src[sorted values] as a third tensor."""
+    gather_src (int32 keys only): the final pass also returns gather_src[sorted values] as a third tensor.
+    carry (int32 keys only; carry[i] belongs to input element i, left intact): a second payload sorted along, returned
+    as a third tensor."""
     assert keys.is_cuda and keys.is_contiguous() and keys.dtype in (torch.int32, torch.int64)
     n = keys.numel()
     dev = keys.device
@@ -221,6 +228,15 @@ def radix_sort_pairs(keys: Tensor, vals: Optional[Tensor], begin_bit: int, end_b
     ws_bytes = L.gs_radix_sort_workspace_bytes(n, begin_bit, end_bit)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     res = ctypes.c_int(0)
+    if carry is not None:
+        assert keys.dtype == torch.int32 and carry.dtype == torch.int32 and carry.is_contiguous() and gather_src is None
+        assert carry.numel() >= n
+        pa, pb = _padded_i32(n, dev), _padded_i32(n, dev)
+        res2 = ctypes.c_int(0)
+        _check(L.gs_radix_sort_pairs_carry_u32(n, _ptr(keys), _ptr(v0), _ptr(k1), _ptr(v1), iota, begin_bit, end_bit,
+                                               _ptr(ws), ws_bytes, ctypes.byref(res), _ptr(carry), _ptr(pa), _ptr(pb),
+                                               ctypes.byref(res2), _ptr(n_dev), _stream()), "radix sort + carry")
+        return ((k1, v1) if res.value == 1 else (keys, v0)) + (pb if res2.value == 1 else pa,)
     if gather_src is not None:
         assert keys.dtype == torch.int32 and gather_src.dtype == torch.int32 and gather_src.is_contiguous()
         gathered = _padded_i32(n, dev)
@@ -313,11 +329,39 @@ def segmented_sort_pairs_u32(keys: Tensor, seg_len: int) -> Tuple[Tensor, Tensor
 
 
 def _depth_rank(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int):
-    """per-sub-pose depth pre-sort -> (sorted_gi [P*N], exclusive scan of tile counts in rank order, total).
-    depth_keys is consumed (the sort ping-pongs through it)."""
+    """per-sub-pose depth pre-sort -> (sorted_gi [P*N], exclusive scan of tile counts in rank order, total,
+    n_live [P] device or None).  depth_keys is consumed (the sort ping-pongs through it).
+
+    Compacting route (default): culled Gaussians (key 0xFFFFFFFF, typically 3 of 4) are dropped by the first radix
+    pass, so the other three passes, the count gather (folded into the last pass) and the scan only touch the
+    n_live[p] visible ones; ranks [n_live[p], N) of sorted_gi / counts are unspecified and must not be read."""
     L = _L()
     n = P * N
     dev = records.device
+    n_live = None
+    if DEPTH_SORT_SEGMENTED and DEPTH_SORT_COMPACT:
+        with _stage("depth_sort"):
+            v0 = torch.empty(n, dtype=torch.int32, device=dev)
+            k1 = torch.empty_like(depth_keys)
+            v1 = torch.empty_like(v0)
+            counts = torch.empty(n, dtype=torch.int32, device=dev)
+            n_live = torch.empty(P, dtype=torch.int32, device=dev)          # written by the sort
+            ws_bytes = L.gs_segmented_sort_workspace_bytes(n, N, 0, 32)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            res = ctypes.c_int(0)
+            _check(L.gs_segmented_sort_compact_u32(n, N, _ptr(depth_keys), _ptr(v0), _ptr(k1), _ptr(v1), 0, 32,
+                                                   0xFFFFFFFF, _ptr(n_live), _ptr(num_tiles_hit), _ptr(counts),
+                                                   _ptr(ws), ws_bytes, ctypes.byref(res), _stream()),
+                   "segmented sort (compacting)")
+            sorted_gi = v1 if res.value == 1 else v0
+        with _stage("count_scan"):
+            cum = torch.empty(n, dtype=torch.int32, device=dev)
+            total = torch.empty(1, dtype=torch.int32, device=dev)
+            sws_bytes = L.gs_scan_workspace_bytes(n)
+            sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)
+            _check(L.gs_exclusive_scan_segments_u32(n, N, _ptr(n_live), _ptr(counts), _ptr(cum), _ptr(total),
+                                                    _ptr(sws), sws_bytes, _stream()), "segment scan")
+        return sorted_gi, cum, total, n_live
     with _stage("depth_sort"):
         if DEPTH_SORT_SEGMENTED:
             # P independent segments of 32-bit depth keys (culled = 0xFFFFFFFF sorts last), one set of launches
@@ -330,7 +374,7 @@ def _depth_rank(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: i
         counts = torch.empty(n, dtype=torch.int32, device=dev)
         _check(L.gs_gather_counts(n, _ptr(sorted_gi), _ptr(num_tiles_hit), _ptr(counts), _stream()), "gather counts")
         cum, total = exclusive_scan_u32(counts)
-    return sorted_gi, cum, total
+    return sorted_gi, cum, total, n_live
 
 
 def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
@@ -345,40 +389,51 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     H, W = img_height, img_width
     tx, ty = _tiles(H, W)
     T = tx * ty
-    sorted_gi, cum, total = _depth_rank(records, depth_keys, num_tiles_hit, P, N)
+    sorted_gi, cum, total, n_live = _depth_rank(records, depth_keys, num_tiles_hit, P, N)
     # everything that does not depend on the plan is allocated BEFORE its read-back, while the GPU is still busy
     out_img = torch.empty(S, H, W, 3, device=dev)
     out_T = torch.empty(S, H, W, device=dev)
     live_T = torch.empty(S, H, W, device=dev)
     sat = torch.empty(P * (ty + 1) * (tx + 1), dtype=torch.int32, device=dev)
     open_bits = torch.empty(P * ty * ((tx + 63) // 64), dtype=torch.int64, device=dev)   # one bit per tile: still open
-    tile_done0 = torch.zeros(P * T, dtype=torch.uint8, device=dev) if R == 1 else None
-    # slice boundaries in depth-rank space: cumulative intersections per sub-pose reach T*slice_base*2^k
+    # one zero fill: tile_done of the first slice, and per planned slice one "this tile's list holds an opacity above
+    # the alpha clamp" flag per tile (written by the emission, read by both compositors to pick their loop version)
     KMAX = 16
+    zeros_u8 = torch.zeros((1 + KMAX) * P * T, dtype=torch.uint8, device=dev)
+    tile_done0 = zeros_u8[:P * T] if R == 1 else None
+    # slice boundaries in depth-rank space: cumulative intersections per sub-pose reach T*slice_base*2^k
     if slice_base > 0:
         with _stage("slice_plan"):
             # the scan is u32 (wraps above 2^32 total intersections): differences inside one sub-pose are
             # still exact modulo 2^32 as long as a single sub-pose has fewer than 2^32 intersections
-            # bounds | rels | per-sub-pose totals | total
-            plan_dev = torch.empty(2 * P * KMAX + P + 1, dtype=torch.int32, device=dev)
+            # bounds | rels | per-sub-pose totals | live ranks per sub-pose | total
+            plan_dev = torch.empty(2 * P * KMAX + 2 * P + 1, dtype=torch.int32, device=dev)
             _check(L.gs_slice_plan(P, N, KMAX, _ptr(cum), _ptr(total), T * slice_base, _ptr(plan_dev),
                                    ctypes.c_void_p(plan_dev.data_ptr() + 4 * P * KMAX),
-                                   ctypes.c_void_p(plan_dev.data_ptr() + 8 * P * KMAX), _stream()), "slice_plan")
+                                   ctypes.c_void_p(plan_dev.data_ptr() + 8 * P * KMAX), _ptr(n_live), _stream()),
+                   "slice_plan")
+            if n_live is not None:
+                plan_dev[2 * P * KMAX + P:2 * P * KMAX + 2 * P] = n_live
             plan_dev[-1:] = total
             plan = plan_dev.cpu().long() & 0xFFFFFFFF                                    # one host sync
             rel_at = plan[P * KMAX:2 * P * KMAX].view(P, KMAX).tolist()
             seg_totals = plan[2 * P * KMAX:2 * P * KMAX + P].tolist()
         n_total = int(plan[-1])
         b = plan[:P * KMAX].view(P, KMAX).tolist()
-        # number of slices: up to the first k whose boundary reaches N in every sub-pose
+        # NV[p]: ranks of sub-pose p that hold a Gaussian (everything behind them is unspecified after the
+        # compacting pre-sort; without it the culled Gaussians sit there with zero tiles)
+        NV = [min(N, int(v)) for v in plan[2 * P * KMAX + P:2 * P * KMAX + 2 * P].tolist()] if n_live is not None \
+            else [N] * P
+        # number of slices: up to the first k whose boundary reaches the last live rank in every sub-pose
         K = KMAX
         for k in range(KMAX):
-            if all(b[p][k] >= N for p in range(P)):
+            if all(b[p][k] >= NV[p] for p in range(P)):
                 K = k + 1
                 break
     else:
         n_total = int(total.item()) & 0xFFFFFFFF
-        b = [[N] for _ in range(P)]
+        NV = [min(N, int(v)) for v in n_live.tolist()] if n_live is not None else [N] * P
+        b = [[NV[p]] for p in range(P)]
         rel_at = None
         seg_totals = None
         K = 1
@@ -389,8 +444,8 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     true_total = sum(seg_totals) if seg_totals is not None else None
     begins, prefixes, n_slices = [], [], []
     for k in range(K):
-        lo = [0 if k == 0 else min(b[p][k - 1], N) for p in range(P)]
-        hi = [N if k == K - 1 else min(b[p][k], N) for p in range(P)]
+        lo = [0 if k == 0 else min(b[p][k - 1], NV[p]) for p in range(P)]
+        hi = [NV[p] if k == K - 1 else min(b[p][k], NV[p]) for p in range(P)]
         begins.append([p * N + lo[p] for p in range(P)])
         pre = [0]
         for p in range(P):
@@ -427,6 +482,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         I_k = 0
         n_dev = None
         svals = bins = sorted_ids = None
+        tile_hot = zeros_u8[(1 + k) * P * T:(2 + k) * P * T] if (compact and use_tuples) else None
         if n_k > 0:
             with _stage("slice_count"):
                 slice_gi = torch.empty(n_k, dtype=torch.int32, device=dev)
@@ -495,14 +551,18 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                                      _ptr(records),
                                                      _ptr(tile_done) if ((not first) or holes0) else None,
                                                      _ptr(keys), _ptr(vals), invalid_key, int(compact), wave_per_g,
-                                                     _ptr(masks), _ptr(mask_off), _stream()),
+                                                     _ptr(masks), _ptr(mask_off), _ptr(tile_hot), _stream()),
                            "emit open intersects")
             with _stage("tile_sort"):
                 if use_tuples:
                     # payload = emission index e (iota); the Gaussian id of a sorted entry is vals[e]: the final
                     # pass leaves it in sorted order for the scalar-cache compositors
-                    skeys, svals, sorted_ids = radix_sort_pairs(keys, None, 0, _bits(P * T + 1), gather_src=vals,
-                                                                n_dev=n_dev)
+                    if TILE_SORT_CARRY:
+                        skeys, svals, sorted_ids = radix_sort_pairs(keys, None, 0, _bits(P * T + 1), carry=vals,
+                                                                    n_dev=n_dev)
+                    else:
+                        skeys, svals, sorted_ids = radix_sort_pairs(keys, None, 0, _bits(P * T + 1), gather_src=vals,
+                                                                    n_dev=n_dev)
                 else:
                     skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T + 1))
             with _stage("bin_edges"):
@@ -521,11 +581,13 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                             _ptr(out_img), _ptr(out_T), _ptr(live_T), _ptr(fidx), _ptr(tile_done),
                                             int(first), int(last), _ptr(vals) if (use_tuples and I_k > 0) else None,
                                             _ptr(sorted_ids), P * N if I_k > 0 else 0,
-                                            _ptr(out_depth) if I_k > 0 else None, RASTER_FWD_VARIANT, _stream()),
+                                            _ptr(out_depth) if I_k > 0 else None,
+                                            _ptr(tile_hot) if I_k > 0 else None, RASTER_FWD_VARIANT, _stream()),
                    "rasterize_fwd_slice")
         if I_k > 0:
             slices.append(dict(svals=svals, bins=bins, fidx=fidx, I=I_k, gi_of_e=vals if use_tuples else None,
-                               sorted_ids=sorted_ids, slice_gi=slice_gi, counts=counts, cum=cum_k, n=n_k))
+                               sorted_ids=sorted_ids, slice_gi=slice_gi, counts=counts, cum=cum_k, n=n_k,
+                               tile_hot=tile_hot))
         if not last:
             with _stage("slice_sat"):
                 _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _ptr(open_bits), _stream()),
@@ -564,7 +626,8 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
                                             S, R, H, W, _ptr(out_T), _ptr(sl["fidx"]), _ptr(v_img), _ptr(v_alpha),
                                             _ptr(bwd_T), _ptr(bwd_B), _ptr(v_records), _ptr(sl["gi_of_e"]),
                                             _ptr(tuples), _ptr(flags), _ptr(sl["sorted_ids"]), records.shape[0],
-                                            _bwd_variant(), _ptr(cmb[0]), cmb[1], cmb[2], _stream()),
+                                            _ptr(sl["tile_hot"]), _bwd_variant(), _ptr(cmb[0]), cmb[1], cmb[2],
+                                            _stream()),
                    "rasterize_bwd_slice")
         if tuples is not None:
             with _stage("grad_reduce"):

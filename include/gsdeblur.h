@@ -149,6 +149,14 @@ int gs_radix_sort_pairs_gather_u32(long long n, unsigned* keys0, unsigned* vals0
                                    int* result_buf /*host*/, const unsigned* gather_src, unsigned* gather_out,
                                    const unsigned* n_dev /*NULL, or the real pair count on the device (n = capacity)*/,
                                    void* stream);
+/* gs_radix_sort_pairs_u32 with a second payload per key: payload2_in[i] belongs to input element i (read only); the
+ * passes ping-pong it through payload2_a / payload2_b (n ints each); *result_p2 (host) = 0 / 1: which of the two holds
+ * it in sorted order.  Used by the tile sort of a depth slice (payload = emission index, payload 2 = record index). */
+int gs_radix_sort_pairs_carry_u32(long long n, unsigned* keys0, unsigned* vals0, unsigned* keys1, unsigned* vals1,
+                                  int vals0_is_iota, int begin_bit, int end_bit, void* ws, long long ws_bytes,
+                                  int* result_buf /*host*/, const unsigned* payload2_in, unsigned* payload2_a,
+                                  unsigned* payload2_b, int* result_p2 /*host*/,
+                                  const unsigned* n_dev /*NULL, or the real pair count on the device*/, void* stream);
 int gs_radix_sort_pairs_u64(long long n, unsigned long long* keys0, unsigned* vals0,
                             unsigned long long* keys1, unsigned* vals1, int vals0_is_iota, int begin_bit,
                             int end_bit, void* ws, long long ws_bytes, int* result_buf /*host*/,
@@ -159,6 +167,20 @@ long long gs_segmented_sort_workspace_bytes(long long n, long long seg_len, int 
 int gs_segmented_sort_pairs_u32(long long n, long long seg_len, unsigned* keys0, unsigned* vals0,
                                 unsigned* keys1, unsigned* vals1, int vals0_is_iota, int begin_bit, int end_bit,
                                 void* ws, long long ws_bytes, int* result_buf /*host*/, void* stream);
+/* compacting form (the depth pre-sort of the sliced path): keys equal to skip_key — culled Gaussians — are dropped
+ * by the first pass; segment s ends up with its seg_counts[s] (device) surviving keys sorted at
+ * [s*seg_len, s*seg_len + seg_counts[s]), the rest of the segment is unspecified.  Payload = global index.
+ * gather_src/gather_out (NULL together): gather_out[slot] = gather_src[payload] of every sorted survivor. */
+int gs_segmented_sort_compact_u32(long long n, long long seg_len, unsigned* keys0, unsigned* vals0,
+                                  unsigned* keys1, unsigned* vals1, int begin_bit, int end_bit, unsigned skip_key,
+                                  unsigned* seg_counts /*device, n/seg_len*/, const unsigned* gather_src,
+                                  unsigned* gather_out, void* ws, long long ws_bytes, int* result_buf /*host*/,
+                                  void* stream);
+/* exclusive scan where only the first seg_counts[s] values of every seg_len-long segment are live (the rest count as
+ * zero and are never read; out is written everywhere) */
+int gs_exclusive_scan_segments_u32(long long n, long long seg_len, const unsigned* seg_counts /*device*/,
+                                   const unsigned* in, unsigned* out, unsigned* total_out /*device, 1*/, void* ws,
+                                   long long ws_bytes, void* stream);
 /* out[i] = (i / N) << 32 | depth_keys[i] : the (sub-pose, depth) key of the N-sized pre-sort (64-bit route) */
 int gs_make_depth_keys64(long long n, int N, const unsigned* depth_keys, unsigned long long* out,
                          void* stream);
@@ -219,7 +241,10 @@ int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* ti
 int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl /*P*N, rank order*/,
                   const unsigned* total /*device: grand total of the scan*/, long long base,
                   int* bounds /*P*K*/, unsigned* rels /*P*K*/,
-                  unsigned* seg_totals /*P or NULL: every sub-pose's own intersection total (mod 2^32)*/, void* stream);
+                  unsigned* seg_totals /*P or NULL: every sub-pose's own intersection total (mod 2^32)*/,
+                  const unsigned* n_live /*P or NULL: ranks [n_live[p], N) of sub-pose p hold nothing (compacting
+                                           pre-sort); boundaries then never exceed n_live[p]*/,
+                  void* stream);
 /* sat [P*(tiles_y+1)*(tiles_x+1)] = summed-area table of tiles NOT done (tile_done u8 [P*T]) */
 int gs_tile_open_sat(int P, int img_height, int img_width, const unsigned char* tile_done, int* sat,
                      unsigned long long* open_bits /*NULL or [P*tiles_y*ceil(tiles_x/64)]: bit x of row y set while
@@ -251,7 +276,11 @@ int gs_emit_open_intersects(int n_slice, int N, int img_height, int img_width, c
                             unsigned invalid_key, int compact /*1: counts are exact, culled pairs take no slot*/,
                             int wave_per_gaussian,
                             const unsigned long long* hit_masks /*from gs_slice_counts_exact, or NULL: redo the tests*/,
-                            const unsigned* mask_off, void* stream);
+                            const unsigned* mask_off,
+                            unsigned char* tile_hot /*NULL, or [S*R*T] zeroed by the caller: set to 1 for every tile that
+                                                      receives a Gaussian whose opacity exceeds the 0.999 alpha clamp;
+                                                      the compositors run their clamp-free loop on the other tiles*/,
+                            void* stream);
 /* one launch per slice, front to back; out_img/out_T/live_T carry per-pixel state, tile_done is zeroed
  * by the caller before the first slice; first && last == the unsliced pass; final_idx is per slice */
 int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
@@ -268,6 +297,8 @@ int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const i
                                               depth (record float 9), carried between slices like out_img; expected
                                               depth = this / alpha — what splatfacto returns as outputs["depth"]
                                               (/root/reference/render_model.py:219).  Scalar-cache compositor only*/,
+                           const unsigned char* tile_hot /*from gs_emit_open_intersects for THIS slice, or NULL: every
+                                                           tile runs the loop with the alpha clamp*/,
                            int variant /*0 = default; 1, 2 = v_readlane compositor without / with the empty-pair skip*/,
                            void* stream);
 /* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B [S,H,W] (behind-colour . v_out, init = 0)
@@ -279,6 +310,7 @@ int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const i
                            const int* gi_of_e /*as in the forward*/,
                            float* tuples /*[I*12] or NULL*/, unsigned char* flags /*[I], zeroed, or NULL*/,
                            const int* sorted_ids /*as in gs_rasterize_fwd_slice*/, int n_records,
+                           const unsigned char* tile_hot /*as in gs_rasterize_fwd_slice (same slice)*/,
                            int variant /*0 = default (scalar-cache kernel when ids are available); 2 = round-1 kernel;
                                          + 256: upstream alpha-clamp gradient, as in gs_rasterize_bwd*/,
                            const float* cmb_scale /*[H,W,3] or NULL.  Non-NULL folds gs_combine_bwd into this launch:

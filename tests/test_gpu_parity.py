@@ -99,6 +99,31 @@ def test_radix_sort_stable(gs, dev, n, bits, dtype):
     assert torch.equal(vs2.cpu().long(), order)
 
 
+@pytest.mark.parametrize("n,bits,cap", [(1, 8, 0), (4097, 16, 0), (300_001, 17, 0), (70_000, 16, 200_000),
+                                        (1_000_003, 24, 0)])
+def test_radix_sort_carries_a_second_payload(gs, dev, n, bits, cap):
+    """the tile sort's form: payload = input index (iota), second payload carried along with the keys through every
+    pass (instead of gathered by payload afterwards); optionally with the element count on the device"""
+    g = torch.Generator().manual_seed(n + bits)
+    keys = torch.randint(0, 2 ** bits, (n,), generator=g, dtype=torch.int64)
+    if n > 100:
+        keys[: n // 3] = keys[n // 3: 2 * (n // 3)]
+    second = torch.randint(0, 2 ** 31 - 1, (max(n, cap) + 8,), generator=g, dtype=torch.int32)
+    order = torch.sort(keys, stable=True).indices
+    kd = keys.to(torch.int32).to(dev)
+    n_dev = None
+    if cap:
+        kbuf = torch.full((cap,), 12345, dtype=torch.int32, device=dev)
+        kbuf[:n] = kd
+        kd, n_dev = kbuf, torch.tensor([n], dtype=torch.int32, device=dev)
+    src = second.to(dev)
+    ks, vs, ps = gs.radix_sort_pairs(kd, None, 0, bits, carry=src, n_dev=n_dev)
+    assert torch.equal(src.cpu(), second)                                  # input payload left intact
+    assert torch.equal(vs[:n].cpu().long(), order)
+    assert torch.equal(ks[:n].cpu().long(), keys[order])
+    assert torch.equal(ps[:n].cpu(), second[:n][order])
+
+
 @pytest.mark.parametrize("P,N", [(1, 5000), (5, 4097), (3, 100_003), (10, 4096)])
 def test_segmented_sort_stable(gs, dev, P, N):
     """every segment sorted independently, ascending, stable; payload = global index"""
@@ -113,6 +138,42 @@ def test_segmented_sort_stable(gs, dev, P, N):
         order = torch.sort(seg, stable=True).indices + p * N
         assert torch.equal(vs[p * N:(p + 1) * N].cpu().long(), order)
         assert torch.equal(ks[p * N:(p + 1) * N].cpu().long() & 0xFFFFFFFF, keys[order])
+
+
+@pytest.mark.parametrize("P,N,keep", [(1, 5000, 0.3), (5, 4097, 0.25), (3, 100_003, 0.27), (10, 4096, 0.0),
+                                      (4, 9000, 1.0), (6, 20_000, 0.01)])
+def test_depth_rank_compacting(gs, dev, P, N, keep):
+    """compacting depth pre-sort: culled keys dropped by the first pass, survivors sorted stably at the start of their
+    segment, their tile counts gathered by the last pass, the segment-aware scan treats everything behind as zero;
+    the result is the same ranking / prefix the full sort + gather + scan produce"""
+    from gsdeblur_amd import ops
+    g = torch.Generator().manual_seed(P * 11 + N)
+    keys = torch.randint(0, 2 ** 31, (P * N,), generator=g, dtype=torch.int64)
+    keys[: N // 2] = keys[N // 2: 2 * (N // 2)]                 # ties
+    culled = torch.rand(P * N, generator=g) >= keep
+    if P > 2:
+        culled[N:2 * N] = True                                  # one sub-pose sees nothing at all
+    keys[culled] = 0xFFFFFFFF
+    ntiles = torch.randint(1, 50, (P * N,), generator=g, dtype=torch.int32)
+    ntiles[culled] = 0
+    records = torch.zeros(1, device=dev)
+    old = ops.DEPTH_SORT_COMPACT
+    try:
+        ops.DEPTH_SORT_COMPACT = 1
+        sgi, cum, total, n_live = ops._depth_rank(records, keys.to(torch.int32).to(dev), ntiles.to(dev), P, N)
+        ops.DEPTH_SORT_COMPACT = 0
+        sgi0, cum0, total0, none = ops._depth_rank(records, keys.to(torch.int32).to(dev), ntiles.to(dev), P, N)
+    finally:
+        ops.DEPTH_SORT_COMPACT = old
+    assert none is None
+    live = n_live.cpu().long()
+    assert torch.equal(live, (~culled).view(P, N).sum(1))
+    assert int(total.item()) == int(total0.item()) == int(ntiles.sum())
+    # the prefix is the full one everywhere (flat behind the live ranks), the ranking only where it is defined
+    assert torch.equal(cum.cpu(), cum0.cpu())
+    for p in range(P):
+        m = int(live[p])
+        assert torch.equal(sgi[p * N:p * N + m].cpu(), sgi0[p * N:p * N + m].cpu())
 
 
 # --------------------------------------------------------------------------- #
@@ -612,17 +673,29 @@ def test_depth_sliced_equals_single_pass(gs, oracle, dev, S, R, base):
         assert rel_max(res["sliced"][2][k].cpu(), res["single"][2][k].cpu()) < 1e-4, k
 
 
-@pytest.mark.parametrize("S,R,base,W,H,n", [(2, 2, 8, 208, 144, 6000), (1, 1, 0, 131, 77, 900), (3, 1, 512, 320, 200, 20000)])
-def test_scalar_cache_compositor_equals_readlane_compositor(gs, oracle, dev, S, R, base, W, H, n):
+@pytest.mark.parametrize("S,R,base,W,H,n,hot", [(2, 2, 8, 208, 144, 6000, False), (1, 1, 0, 131, 77, 900, False),
+                                                 (3, 1, 512, 320, 200, 20000, False), (2, 1, 8, 176, 112, 5000, True),
+                                                 (1, 2, 512, 131, 90, 2500, True)])
+def test_scalar_cache_compositor_equals_readlane_compositor(gs, oracle, dev, S, R, base, W, H, n, hot):
     """Round 2's compositors fetch the records through the scalar cache (s_load); the forward keeps one signed
     transmittance per pixel.  The round-1 kernels broadcast the records with v_readlane.  Forward: same arithmetic,
     term for term — sample images, alphas AND (behind the same backward) the gradients, which depend on every
     pixel's final index, must be bit-identical; backward: equal up to fp32 summation order.  Single- and multi-slice
-    frames, ragged image sizes, rolling-shutter bands, tuple and atomics accumulation."""
+    frames, ragged image sizes, rolling-shutter bands, tuple and atomics accumulation.  hot: a few large Gaussians
+    have an opacity above the 0.999 alpha clamp — the tiles they land on take the clamping loop version, the others
+    the clamp-free one (tile_hot); the round-1 kernels always clamp."""
     from gsdeblur_amd import ops
     O = oracle
     sc = O.synthetic_scene(n, W, H, seed=21 + S, scale_mult=7.0)
     sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10
+    if hot:
+        sc["opacity_logits"], sc["log_scales"] = sc["opacity_logits"].clone(), sc["log_scales"].clone()
+        sc["opacity_logits"][::250] = 14.0
+        sc["log_scales"][::250] += 1.0        # large enough for the anti-aliasing compensation to stay above 0.999
+        pr = O.project_gaussians(sc["means"], sc["log_scales"].exp(), 1.0, sc["quats"], sc["viewmat"], sc["fx"],
+                                 sc["fy"], sc["cx"], sc["cy"], H, W)
+        n_hot = int(((torch.sigmoid(sc["opacity_logits"]) * pr.compensation > 0.999) & (pr.radii > 0)).sum())
+        assert n_hot >= 1, n_hot
     bg = torch.tensor([0.2, 0.1, 0.4])
     wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(9))
     res = {}
