@@ -37,7 +37,7 @@ _SIGS = {
     "gs_radix_sort_pairs_carry_u32": [_L, _P, _P, _P, _P, _I, _I, _I, _P, _L, ctypes.POINTER(_I), _P, _P, _P,
                                       ctypes.POINTER(_I), _P, _P],
     "gs_segmented_sort_pairs_u32": [_L, _L, _P, _P, _P, _P, _I, _I, _I, _P, _L, ctypes.POINTER(_I), _P],
-    "gs_segmented_sort_compact_u32": [_L, _L, _P, _P, _P, _P, _I, _I, ctypes.c_uint, _P, _P, _P, _P, _L,
+    "gs_segmented_sort_compact_u32": [_L, _L, _P, _P, _P, _P, _I, _I, _I, ctypes.c_uint, _P, _P, _P, _P, _L,
                                       ctypes.POINTER(_I), _P],
     "gs_exclusive_scan_segments_u32": [_L, _L, _P, _P, _P, _P, _P, _L, _P],
     "gs_make_depth_keys64": [_L, _I, _P, _P, _P],
@@ -49,13 +49,13 @@ _SIGS = {
     "gs_map_gaussian_to_intersects": [_I, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "gs_rasterize_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P],
     "gs_rasterize_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P],
-    "gs_slice_plan": [_I, _I, _I, _P, _P, _L, _P, _P, _P, _P, _P],
+    "gs_slice_plan": [_I, _I, _I, _P, _P, _L, _P, _P, _P, _P, _P, _P],
     "gs_tile_open_sat": [_I, _I, _I, _P, _P, _P, _P],
     "gs_slice_counts": [_I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "gs_emit_open_intersects": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, ctypes.c_uint, _I, _I, _P, _P, _P, _P],
     "gs_slice_counts_exact": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P],
-    "gs_rasterize_fwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _I,
-                               _P],
+    "gs_rasterize_fwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P,
+                               _I, _P],
     "gs_rasterize_bwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P,
                                _I, _P, _F, _F, _P],
     "gs_reduce_grad_tuples": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P],
@@ -73,6 +73,7 @@ _SIGS_LL = {
     "gs_scan_workspace_bytes": [_L],
     "gs_radix_sort_workspace_bytes": [_L, _I, _I],
     "gs_segmented_sort_workspace_bytes": [_L, _L, _I, _I],
+    "gs_segmented_sort_compact_workspace_bytes": [_L, _L, _I, _I, _I],
 }
 
 _lib = None

@@ -885,7 +885,8 @@ __device__ __forceinline__ int slice_rank(const SliceDesc& sd, int j) {
 __global__ void slice_plan_kernel(int P, int N, int K, const unsigned* __restrict__ cum,
                                   const unsigned* __restrict__ total, unsigned long long base,
                                   int* __restrict__ bounds, unsigned* __restrict__ rels,
-                                  unsigned* __restrict__ seg_totals, const unsigned* __restrict__ n_live) {
+                                  unsigned* __restrict__ seg_totals, const unsigned* __restrict__ n_live,
+                                  unsigned* __restrict__ tail /*nullable: [P] live ranks, then the grand total*/) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P * K) return;
   const int p = i / K, k = i % K;
@@ -902,6 +903,10 @@ __global__ void slice_plan_kernel(int P, int N, int K, const unsigned* __restric
   const unsigned seg_end = (p + 1 < P) ? c[N] : *total;
   rels[i] = (lo < M ? c[lo] : seg_end) - c0;
   if (k == 0 && seg_totals) seg_totals[p] = seg_end - c0;     // the sub-pose's own total (mod 2^32)
+  if (tail) {           // everything the host reads back sits in one buffer: one copy, no staging launches
+    if (k == 0) tail[p] = (unsigned)M;
+    if (i == 0) tail[P] = *total;
+  }
 }
 
 // summed-area table of NOT-done tiles per sub-pose: sat[p][(y)*(tx+1)+x] = #open tiles in [0,y)x[0,x).
@@ -1338,17 +1343,23 @@ GS_EXPORT int gs_segmented_sort_pairs_u32(long long n, long long seg_len, unsign
 // On return segment s holds its seg_counts[s] surviving keys sorted at [s*seg_len, s*seg_len + seg_counts[s]); what
 // lies behind them is unspecified.  Payload = global index (iota).  gather_src / gather_out (nullable together):
 // gather_out[slot] = gather_src[payload] for every sorted survivor, written by the last pass.
+GS_EXPORT long long gs_segmented_sort_compact_workspace_bytes(long long n, long long seg_len, int begin_bit,
+                                                              int end_bit, int max_digit_bits) {
+  if (n <= 0 || seg_len <= 0 || end_bit <= begin_bit) return 0;
+  return (long long)radix_ws_bytes<unsigned>((size_t)n, (size_t)seg_len, end_bit - begin_bit, max_digit_bits);
+}
+
 GS_EXPORT int gs_segmented_sort_compact_u32(long long n, long long seg_len, unsigned* keys0, unsigned* vals0,
                                             unsigned* keys1, unsigned* vals1, int begin_bit, int end_bit,
-                                            unsigned skip_key, unsigned* seg_counts, const unsigned* gather_src,
-                                            unsigned* gather_out, void* ws, long long ws_bytes, int* result_buf,
-                                            void* stream) {
+                                            int max_digit_bits, unsigned skip_key, unsigned* seg_counts,
+                                            const unsigned* gather_src, unsigned* gather_out, void* ws,
+                                            long long ws_bytes, int* result_buf, void* stream) {
   if (n <= 0 || seg_len <= 0 || n % seg_len != 0 || begin_bit < 0 || end_bit > 32 || !seg_counts)
     return GS_ERR_INVALID;
   if ((gather_src != nullptr) != (gather_out != nullptr)) return GS_ERR_INVALID;
   return radix_sort<unsigned>((size_t)n, (size_t)seg_len, keys0, vals0, keys1, vals1, 1, begin_bit, end_bit, ws,
-                              (size_t)ws_bytes, result_buf, (hipStream_t)stream, 8, gather_src, gather_out, nullptr,
-                              seg_counts, (unsigned long long)skip_key);
+                              (size_t)ws_bytes, result_buf, (hipStream_t)stream, max_digit_bits, gather_src,
+                              gather_out, nullptr, seg_counts, (unsigned long long)skip_key);
 }
 
 // Exclusive scan over n = k*seg_len values of which only the first seg_counts[s] of every segment are live: the rest
@@ -1445,10 +1456,11 @@ GS_EXPORT int gs_map_gaussian_to_intersects(int N, const float* xys, const float
 // ---- depth-sliced binning -------------------------------------------------------------------
 // bounds [P*K]: first depth rank of each sub-pose at which the cumulative intersection count reaches base<<k
 GS_EXPORT int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl, const unsigned* total, long long base,
-                            int* bounds, unsigned* rels, unsigned* seg_totals, const unsigned* n_live, void* stream) {
+                            int* bounds, unsigned* rels, unsigned* seg_totals, const unsigned* n_live,
+                            unsigned* tail, void* stream) {
   if (P <= 0 || N <= 0 || K <= 0 || K > 32 || base <= 0) return GS_ERR_INVALID;
   hipLaunchKernelGGL(slice_plan_kernel, dim3((P * K + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, N, K, cum_excl,
-                     total, (unsigned long long)base, bounds, rels, seg_totals, n_live);
+                     total, (unsigned long long)base, bounds, rels, seg_totals, n_live, tail);
   return gs_launch_status();
 }
 

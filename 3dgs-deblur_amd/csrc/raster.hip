@@ -28,6 +28,7 @@ struct SliceState {
   unsigned char* tile_done;   // [P*T]
   float* live_T;              // [S,H,W]  0 once a pixel has stopped
   int first, last;
+  int* open_flag;             // nullable (zeroed by the caller): set to 1 when this launch leaves any tile open
 };
 
 template <bool SKIP_EMPTY>
@@ -50,7 +51,10 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
   int2 range = prm.tile_bins[tkey];
   range.x = __builtin_amdgcn_readfirstlane(range.x);
   range.y = __builtin_amdgcn_readfirstlane(range.y);
-  if (!st.first && !st.last && range.y <= range.x) return;   // nothing for this tile in this slice
+  if (!st.first && !st.last && range.y <= range.x) {         // nothing for this tile in this slice: it stays open
+    if (st.open_flag && lane == 0) *st.open_flag = 1;
+    return;
+  }
 
   const int px = tx * K::kTile + (lane & 15);
   const int py0 = ty * K::kTile + (lane >> 4) * 4;
@@ -139,7 +143,10 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
       if (!st.last) st.live_T[pix] = Tk[k];
     }
   }
-  if (all_stopped && !st.last && lane == 0) st.tile_done[tkey] = 1;
+  if (!st.last && lane == 0) {
+    if (all_stopped) st.tile_done[tkey] = 1;
+    else if (st.open_flag) *st.open_flag = 1;      // (plain store of the same value from every open tile)
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -264,7 +271,10 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
   int2 range = prm.tile_bins[tkey];
   range.x = __builtin_amdgcn_readfirstlane(range.x);
   range.y = __builtin_amdgcn_readfirstlane(range.y);
-  if (!st.first && !st.last && range.y <= range.x) return;   // nothing for this tile in this slice
+  if (!st.first && !st.last && range.y <= range.x) {         // nothing for this tile in this slice: it stays open
+    if (st.open_flag && lane == 0) *st.open_flag = 1;
+    return;
+  }
 
   const int px = tx * K::kTile + (lane & 15);
   const int py0 = ty * K::kTile + (lane >> 4) * 4;
@@ -312,7 +322,10 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
       if (!st.last) st.live_T[pix] = fmaxf(Tk, 0.f);
     }
   }
-  if (all_stopped && !st.last && lane == 0) st.tile_done[tkey] = 1;
+  if (!st.last && lane == 0) {
+    if (all_stopped) st.tile_done[tkey] = 1;
+    else if (st.open_flag) *st.open_flag = 1;      // (plain store of the same value from every open tile)
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -416,7 +429,7 @@ GS_EXPORT int gs_rasterize_fwd(const float* records, const int* sorted_vals, con
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
   // one pass over the complete tile lists = the sliced kernel with first == last (no persistent state)
-  SliceState st; st.tile_done = nullptr; st.live_T = nullptr; st.first = 1; st.last = 1;
+  SliceState st; st.tile_done = nullptr; st.live_T = nullptr; st.first = 1; st.last = 1; st.open_flag = nullptr;
   launch_fwd(prm, st, n_records > 0 ? sorted_vals : nullptr, n_records, out_img, out_T, final_idx, variant,
              (hipStream_t)stream);
   return gs_launch_status();
@@ -429,16 +442,18 @@ GS_EXPORT int gs_rasterize_fwd(const float* records, const int* sorted_vals, con
 // the unsliced pass).  final_idx is per slice (the backward needs one per slice).
 // tile_hot (nullable) [S*R*T] u8, from gs_emit_open_intersects: non-zero where the tile's list of THIS slice holds
 // a Gaussian with opacity > 0.999; the other tiles run the loop version without the alpha clamp (NULL: all clamp).
+// open_flag (nullable, one int zeroed by the caller): set to 1 if any tile is still open after this slice — the
+// one word the host reads to decide whether the next planned slice has anything to do.
 GS_EXPORT int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                                      const int* band_edges, const float* background, int S, int R, int H, int W,
                                      float* out_img, float* out_T, float* live_T, int* final_idx,
                                      unsigned char* tile_done, int first, int last, const int* gi_of_e,
                                      const int* sorted_ids, int n_records, float* out_depth,
-                                     const unsigned char* tile_hot, int variant, void* stream) {
+                                     const unsigned char* tile_hot, int* open_flag, int variant, void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
   prm.gi_of_e = gi_of_e;
-  SliceState st; st.tile_done = tile_done; st.live_T = live_T; st.first = first; st.last = last;
+  SliceState st; st.tile_done = tile_done; st.live_T = live_T; st.first = first; st.last = last; st.open_flag = open_flag;
   const int* ids = sorted_ids ? sorted_ids : (gi_of_e ? nullptr : sorted_vals);
   int rc = launch_fwd(prm, st, n_records > 0 ? ids : nullptr, n_records, out_img, out_T, final_idx, variant,
                       (hipStream_t)stream, out_depth, tile_hot);

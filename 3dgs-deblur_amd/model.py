@@ -154,6 +154,18 @@ class SplatfactoDeblurModel(nn.Module):
         return torch.zeros(3, device=device)
 
     # -- camera handling -------------------------------------------------------------
+    def _const(self, values) -> Tensor:
+        """small constant on the parameters' device, uploaded once (a fresh torch.tensor(list, device=...) is a
+        pageable host->device copy, i.e. a stream synchronisation, every frame)"""
+        key = (tuple(float(v) for v in values), str(self.means.device))
+        cache = self.__dict__.setdefault("_const_cache", {})
+        t = cache.get(key)
+        if t is None:
+            if len(cache) > 256:
+                cache.clear()
+            t = cache[key] = torch.tensor(key[0], dtype=torch.float32, device=self.means.device)
+        return t
+
     def _viewmat_and_velocity(self, camera: Camera):
         dev = self.means.device
         c2w = camera.camera_to_world.to(device=dev, dtype=torch.float32)
@@ -164,14 +176,14 @@ class SplatfactoDeblurModel(nn.Module):
             adj = self.pose_adjustment[cam_idx]
             t = t + R_gl @ adj[:3]
             R_gl = R_gl @ _so3_exp(adj[3:])
-        flip = torch.tensor([1.0, -1.0, -1.0], device=dev)
+        flip = self._const([1.0, -1.0, -1.0])
         R_cv = R_gl * flip[None, :]                # OpenGL -> OpenCV camera axes (x, -y, -z)
         R_wc = R_cv.T
         t_wc = -(R_wc @ t)
         viewmat = torch.eye(4, device=dev)
         viewmat = torch.cat([torch.cat([R_wc, t_wc[:, None]], dim=1), viewmat[3:4]], dim=0)
         md = camera.metadata
-        zero3 = torch.zeros(3, device=dev)
+        zero3 = self._const([0.0, 0.0, 0.0])
         use_data_vel = not self.config.camera_velocity_optimizer.zero_initial_velocities
         lin = torch.as_tensor(md.get("camera_linear_velocity", zero3), dtype=torch.float32, device=dev)
         ang = torch.as_tensor(md.get("camera_angular_velocity", zero3), dtype=torch.float32, device=dev)
@@ -209,7 +221,7 @@ class SplatfactoDeblurModel(nn.Module):
         dev = self.means.device
         viewmat, lin, ang = self._viewmat_and_velocity(camera)
         S, R, times = self._schedule(camera)
-        times_t = torch.tensor(times, dtype=torch.float32, device=dev)
+        times_t = self._const(times)
         pixvel = cfg.motion_model == "pixel_velocity"
         if not pixvel and cfg.motion_model != "se3":
             raise ValueError(f"unknown motion_model {cfg.motion_model!r}")

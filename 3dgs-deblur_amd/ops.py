@@ -46,6 +46,8 @@ HIT_MASKS = int(os.environ.get("GSD_HIT_MASKS", "1"))
 DEPTH_SORT_SEGMENTED = int(os.environ.get("GSD_DEPTH_SORT_SEGMENTED", "1"))
 # 1: the segmented depth pre-sort drops culled Gaussians in its first pass (0: sort all P*N keys, culled ones last)
 DEPTH_SORT_COMPACT = int(os.environ.get("GSD_DEPTH_SORT_COMPACT", "1"))
+# widest radix digit of the compacting depth pre-sort: 8 -> 4 passes of 8 bits, 11 -> 3 passes of 11/10/10 bits
+DEPTH_SORT_DIGIT = int(os.environ.get("GSD_DEPTH_SORT_DIGIT", "8"))
 # 1: the tile sort carries the record index of every entry as a second payload (0: gathers it in the final pass)
 TILE_SORT_CARRY = int(os.environ.get("GSD_TILE_SORT_CARRY", "1"))
 # 1: a depth slice's emitted-intersection count stays on the device (buffers / grids sized by the slice's bounding-box
@@ -295,11 +297,23 @@ def bin_and_sort_records(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     return svals, bins, n_isect, skeys
 
 
+_band_edge_cache = {}
+
+
 def _band_edges(img_height: int, rs_bands: int, device) -> Tensor:
-    _, ty = _tiles(img_height, 1)
-    R = max(1, int(rs_bands))
-    edges = [(r * ty) // R for r in range(R + 1)]
-    return torch.tensor(edges, dtype=torch.int32, device=device)
+    """tile-row edges of the rolling-shutter bands, on the device.  Cached: building it anew is a pageable
+    host->device copy, i.e. a full stream synchronisation right after the projection launch of EVERY frame (the
+    host then runs just in time behind the GPU for the rest of the step instead of ahead of it)."""
+    key = (int(img_height), max(1, int(rs_bands)), str(device))
+    t = _band_edge_cache.get(key)
+    if t is None:
+        _, ty = _tiles(img_height, 1)
+        R = key[1]
+        t = torch.tensor([(r * ty) // R for r in range(R + 1)], dtype=torch.int32, device=device)
+        if len(_band_edge_cache) > 64:
+            _band_edge_cache.clear()
+        _band_edge_cache[key] = t
+    return t
 
 
 def _background(background: Optional[Tensor], device) -> Tensor:
@@ -346,11 +360,12 @@ def _depth_rank(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: i
             v1 = torch.empty_like(v0)
             counts = torch.empty(n, dtype=torch.int32, device=dev)
             n_live = torch.empty(P, dtype=torch.int32, device=dev)          # written by the sort
-            ws_bytes = L.gs_segmented_sort_workspace_bytes(n, N, 0, 32)
+            # visible keys are positive floats: bit 31 is never set (the culled marker is dropped, not sorted)
+            ws_bytes = L.gs_segmented_sort_compact_workspace_bytes(n, N, 0, 31, DEPTH_SORT_DIGIT)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             res = ctypes.c_int(0)
-            _check(L.gs_segmented_sort_compact_u32(n, N, _ptr(depth_keys), _ptr(v0), _ptr(k1), _ptr(v1), 0, 32,
-                                                   0xFFFFFFFF, _ptr(n_live), _ptr(num_tiles_hit), _ptr(counts),
+            _check(L.gs_segmented_sort_compact_u32(n, N, _ptr(depth_keys), _ptr(v0), _ptr(k1), _ptr(v1), 0, 31,
+                                                   DEPTH_SORT_DIGIT, 0xFFFFFFFF, _ptr(n_live), _ptr(num_tiles_hit), _ptr(counts),
                                                    _ptr(ws), ws_bytes, ctypes.byref(res), _stream()),
                    "segmented sort (compacting)")
             sorted_gi = v1 if res.value == 1 else v0
@@ -399,8 +414,11 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     # one zero fill: tile_done of the first slice, and per planned slice one "this tile's list holds an opacity above
     # the alpha clamp" flag per tile (written by the emission, read by both compositors to pick their loop version)
     KMAX = 16
-    zeros_u8 = torch.zeros((1 + KMAX) * P * T, dtype=torch.uint8, device=dev)
+    # ... and one "a tile is still open after this slice" word per slice, set by the forward compositor
+    flag_off = ((1 + KMAX) * P * T + 3) & ~3
+    zeros_u8 = torch.zeros(flag_off + 4 * KMAX, dtype=torch.uint8, device=dev)
     tile_done0 = zeros_u8[:P * T] if R == 1 else None
+    open_flags = zeros_u8[flag_off:].view(torch.int32)
     # slice boundaries in depth-rank space: cumulative intersections per sub-pose reach T*slice_base*2^k
     if slice_base > 0:
         with _stage("slice_plan"):
@@ -410,11 +428,9 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
             plan_dev = torch.empty(2 * P * KMAX + 2 * P + 1, dtype=torch.int32, device=dev)
             _check(L.gs_slice_plan(P, N, KMAX, _ptr(cum), _ptr(total), T * slice_base, _ptr(plan_dev),
                                    ctypes.c_void_p(plan_dev.data_ptr() + 4 * P * KMAX),
-                                   ctypes.c_void_p(plan_dev.data_ptr() + 8 * P * KMAX), _ptr(n_live), _stream()),
+                                   ctypes.c_void_p(plan_dev.data_ptr() + 8 * P * KMAX), _ptr(n_live),
+                                   ctypes.c_void_p(plan_dev.data_ptr() + 8 * P * KMAX + 4 * P), _stream()),
                    "slice_plan")
-            if n_live is not None:
-                plan_dev[2 * P * KMAX + P:2 * P * KMAX + 2 * P] = n_live
-            plan_dev[-1:] = total
             plan = plan_dev.cpu().long() & 0xFFFFFFFF                                    # one host sync
             rel_at = plan[P * KMAX:2 * P * KMAX].view(P, KMAX).tolist()
             seg_totals = plan[2 * P * KMAX:2 * P * KMAX + P].tolist()
@@ -422,8 +438,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         b = plan[:P * KMAX].view(P, KMAX).tolist()
         # NV[p]: ranks of sub-pose p that hold a Gaussian (everything behind them is unspecified after the
         # compacting pre-sort; without it the culled Gaussians sit there with zero tiles)
-        NV = [min(N, int(v)) for v in plan[2 * P * KMAX + P:2 * P * KMAX + 2 * P].tolist()] if n_live is not None \
-            else [N] * P
+        NV = [min(N, int(v)) for v in plan[2 * P * KMAX + P:2 * P * KMAX + 2 * P].tolist()]
         # number of slices: up to the first k whose boundary reaches the last live rank in every sub-pose
         K = KMAX
         for k in range(KMAX):
@@ -582,22 +597,25 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                             int(first), int(last), _ptr(vals) if (use_tuples and I_k > 0) else None,
                                             _ptr(sorted_ids), P * N if I_k > 0 else 0,
                                             _ptr(out_depth) if I_k > 0 else None,
-                                            _ptr(tile_hot) if I_k > 0 else None, RASTER_FWD_VARIANT, _stream()),
+                                            _ptr(tile_hot) if I_k > 0 else None,
+                                            ctypes.c_void_p(open_flags.data_ptr() + 4 * k) if not last else None,
+                                            RASTER_FWD_VARIANT, _stream()),
                    "rasterize_fwd_slice")
         if I_k > 0:
             slices.append(dict(svals=svals, bins=bins, fidx=fidx, I=I_k, gi_of_e=vals if use_tuples else None,
                                sorted_ids=sorted_ids, slice_gi=slice_gi, counts=counts, cum=cum_k, n=n_k,
                                tile_hot=tile_hot))
         if not last:
+            if device_sizes:
+                # the only per-slice read-back left: are there open tiles for the next planned slice?  One word,
+                # written by the compositor itself; it is read AFTER this slice's whole pipeline was issued, so the
+                # GPU works through it while the host waits
+                if int(open_flags[k].item()) == 0:
+                    _slice_totals.append(0)
+                    break
             with _stage("slice_sat"):
                 _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _ptr(open_bits), _stream()),
                        "tile_open_sat")
-            if device_sizes:
-                # the only per-slice read-back left: are there open tiles for the next planned slice?  It is issued
-                # AFTER this slice's whole pipeline, so the GPU works through it while the host waits
-                if int(sat.view(P, -1)[:, -1].sum(dtype=torch.int32).item()) == 0:
-                    _slice_totals.append(0)
-                    break
     return out_img, out_T, slices
 
 

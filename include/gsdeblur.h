@@ -171,8 +171,12 @@ int gs_segmented_sort_pairs_u32(long long n, long long seg_len, unsigned* keys0,
  * by the first pass; segment s ends up with its seg_counts[s] (device) surviving keys sorted at
  * [s*seg_len, s*seg_len + seg_counts[s]), the rest of the segment is unspecified.  Payload = global index.
  * gather_src/gather_out (NULL together): gather_out[slot] = gather_src[payload] of every sorted survivor. */
+long long gs_segmented_sort_compact_workspace_bytes(long long n, long long seg_len, int begin_bit, int end_bit,
+                                                    int max_digit_bits);
 int gs_segmented_sort_compact_u32(long long n, long long seg_len, unsigned* keys0, unsigned* vals0,
-                                  unsigned* keys1, unsigned* vals1, int begin_bit, int end_bit, unsigned skip_key,
+                                  unsigned* keys1, unsigned* vals1, int begin_bit, int end_bit,
+                                  int max_digit_bits /*8..11: widest radix digit (fewest passes of equal width)*/,
+                                  unsigned skip_key,
                                   unsigned* seg_counts /*device, n/seg_len*/, const unsigned* gather_src,
                                   unsigned* gather_out, void* ws, long long ws_bytes, int* result_buf /*host*/,
                                   void* stream);
@@ -244,6 +248,9 @@ int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl /*P*N, rank orde
                   unsigned* seg_totals /*P or NULL: every sub-pose's own intersection total (mod 2^32)*/,
                   const unsigned* n_live /*P or NULL: ranks [n_live[p], N) of sub-pose p hold nothing (compacting
                                            pre-sort); boundaries then never exceed n_live[p]*/,
+                  unsigned* tail /*NULL, or P+1: receives the live rank count of every sub-pose (N without n_live) and
+                                   then the grand total — so that one device->host copy of a buffer holding bounds,
+                                   rels, seg_totals and tail back to back brings the whole plan over*/,
                   void* stream);
 /* sat [P*(tiles_y+1)*(tiles_x+1)] = summed-area table of tiles NOT done (tile_done u8 [P*T]) */
 int gs_tile_open_sat(int P, int img_height, int img_width, const unsigned char* tile_done, int* sat,
@@ -299,6 +306,8 @@ int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const i
                                               (/root/reference/render_model.py:219).  Scalar-cache compositor only*/,
                            const unsigned char* tile_hot /*from gs_emit_open_intersects for THIS slice, or NULL: every
                                                            tile runs the loop with the alpha clamp*/,
+                           int* open_flag /*NULL, or one int zeroed by the caller: set to 1 when any tile is still open
+                                            after this slice (last == 0 only)*/,
                            int variant /*0 = default; 1, 2 = v_readlane compositor without / with the empty-pair skip*/,
                            void* stream);
 /* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B [S,H,W] (behind-colour . v_out, init = 0)

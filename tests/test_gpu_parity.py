@@ -140,9 +140,10 @@ def test_segmented_sort_stable(gs, dev, P, N):
         assert torch.equal(ks[p * N:(p + 1) * N].cpu().long() & 0xFFFFFFFF, keys[order])
 
 
+@pytest.mark.parametrize("digit", [8, 11])
 @pytest.mark.parametrize("P,N,keep", [(1, 5000, 0.3), (5, 4097, 0.25), (3, 100_003, 0.27), (10, 4096, 0.0),
                                       (4, 9000, 1.0), (6, 20_000, 0.01)])
-def test_depth_rank_compacting(gs, dev, P, N, keep):
+def test_depth_rank_compacting(gs, dev, P, N, keep, digit):
     """compacting depth pre-sort: culled keys dropped by the first pass, survivors sorted stably at the start of their
     segment, their tile counts gathered by the last pass, the segment-aware scan treats everything behind as zero;
     the result is the same ranking / prefix the full sort + gather + scan produce"""
@@ -157,14 +158,14 @@ def test_depth_rank_compacting(gs, dev, P, N, keep):
     ntiles = torch.randint(1, 50, (P * N,), generator=g, dtype=torch.int32)
     ntiles[culled] = 0
     records = torch.zeros(1, device=dev)
-    old = ops.DEPTH_SORT_COMPACT
+    old = ops.DEPTH_SORT_COMPACT, ops.DEPTH_SORT_DIGIT
     try:
-        ops.DEPTH_SORT_COMPACT = 1
+        ops.DEPTH_SORT_COMPACT, ops.DEPTH_SORT_DIGIT = 1, digit      # 4 passes of 8 bits / 3 passes of 11, 11, 9
         sgi, cum, total, n_live = ops._depth_rank(records, keys.to(torch.int32).to(dev), ntiles.to(dev), P, N)
         ops.DEPTH_SORT_COMPACT = 0
         sgi0, cum0, total0, none = ops._depth_rank(records, keys.to(torch.int32).to(dev), ntiles.to(dev), P, N)
     finally:
-        ops.DEPTH_SORT_COMPACT = old
+        ops.DEPTH_SORT_COMPACT, ops.DEPTH_SORT_DIGIT = old
     assert none is None
     live = n_live.cpu().long()
     assert torch.equal(live, (~culled).view(P, N).sum(1))
