@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
 //   * a reduction group is the four entries of a list group; lanes 0..35 sum the 36 rows and store their total
 //     STRAIGHT into the entry's gradient tuple (or atomically into v_records): no per-batch totals in LDS, no
 //     per-batch flush, no vector loads of ids / records at all.
-// LDS per wave: 36 rows x 68 floats = 9.6 KB (4 waves per SIMD, as before).
+// LDS per wave: 36 rows x 36 floats = 5.1 KB (GS_BWD_PAIRSUM; 36 x 68 floats = 9.6 KB without).
 // ---------------------------------------------------------------------------
 struct RecS { float x, y, cx, cy, cz, op, r, g, b; };
 
@@ -350,7 +350,38 @@ __device__ __forceinline__ RecS load_rec_s(const float* __restrict__ records, un
 }
 
 constexpr int kRedG4 = 4;
-constexpr int kRedFloats4 = kRedG4 * 9 * kRedStride;
+// GS_BWD_PAIRSUM: horizontally adjacent lanes add their partial sums in registers (one DPP add per value) before
+// the trip through LDS: 32 columns per row instead of 64 -> 5.1 KB of LDS per wave instead of 9.6 KB, so the
+// occupancy limit moves from LDS (4 waves per SIMD) to the VGPRs (5), and the row sums read half as much.
+#ifndef GS_BWD_PAIRSUM
+#define GS_BWD_PAIRSUM 1
+#endif
+#if GS_BWD_PAIRSUM
+constexpr int kRedCols4 = 32, kRedStride4 = 36;    // 36 = 32 + 4: rows 16-byte aligned, b128 row reads conflict-free
+#define GS_BWD_SLOAD_WAVES 5
+#else
+constexpr int kRedCols4 = 64, kRedStride4 = kRedStride;
+#define GS_BWD_SLOAD_WAVES GS_BWD_WAVES
+#endif
+constexpr int kRedFloats4 = kRedG4 * 9 * kRedStride4;
+
+// w[i] = v[i](lane) + v[i](lane ^ 1) for nine values: nine v_add_f32_dpp in one block (the DPP combiner leaves most
+// of them as v_mov_b32_dpp + v_add_f32 otherwise).  The s_nop covers the VALU-write -> DPP-read hazard, which the
+// compiler's hazard recogniser cannot see inside inline assembly.
+__device__ __forceinline__ void pair_sum9(float (&v)[9]) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+}
 
 struct BwdPair { f2 T, Dv, vr, vg, vb, py; int fin0, fin1; };
 
@@ -429,10 +460,20 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
   const float p_cx = (0.5f * dx * dx) * M0, p_cy = dx * M1, p_cz = 0.5f * M2;
   const float p_x = (rc.cx * dx) * M0 + rc.cy * M1;
   const float p_y = (rc.cy * dx) * M0 + rc.cz * M1;
+#if GS_BWD_PAIRSUM
+  float w[9] = {p_x, p_y, p_cx, p_cy, p_cz, q_op.x + q_op.y, q_r.x + q_r.y, q_g.x + q_g.y, q_b.x + q_b.y};
+  pair_sum9(w);
+  if ((lane & 1) == 0) {
+    float* r0 = red + slot * (9 * kRedStride4) + (lane >> 1);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) r0[c * kRedStride4] = w[c];
+  }
+#else
   float* r0 = red + slot * (9 * kRedStride) + lane;
   r0[0 * kRedStride] = p_x;  r0[1 * kRedStride] = p_y;  r0[2 * kRedStride] = p_cx;
   r0[3 * kRedStride] = p_cy; r0[4 * kRedStride] = p_cz; r0[5 * kRedStride] = q_op.x + q_op.y;
   r0[6 * kRedStride] = q_r.x + q_r.y;  r0[7 * kRedStride] = q_g.x + q_g.y;  r0[8 * kRedStride] = q_b.x + q_b.y;
+#endif
   return true;
 }
 
@@ -474,10 +515,10 @@ __device__ __forceinline__ void bwd_walk(const int* __restrict__ ids, const int*
     if (filled) {
       __builtin_amdgcn_wave_barrier();
       if (row < kRedG4 * 9 && ((filled >> row_g) & 1u)) {
-        const f4* rp = reinterpret_cast<const f4*>(red + row * kRedStride);
+        const f4* rp = reinterpret_cast<const f4*>(red + row * kRedStride4);
         f4 s0 = rp[0], s1 = rp[1], s2 = rp[2], s3 = rp[3];
 #pragma unroll
-        for (int q = 4; q < 16; q += 4) { s0 += rp[q]; s1 += rp[q + 1]; s2 += rp[q + 2]; s3 += rp[q + 3]; }
+        for (int q = 4; q < kRedCols4 / 4; q += 4) { s0 += rp[q]; s1 += rp[q + 1]; s2 += rp[q + 2]; s3 += rp[q + 3]; }
         const f4 v = (s0 + s1) + (s2 + s3);
         const float sum = (v.x + v.y) + (v.z + v.w);
         const int id_e = row_g == 0 ? ev.x : (row_g == 1 ? ev.y : (row_g == 2 ? ev.z : ev.w));
@@ -496,7 +537,7 @@ __device__ __forceinline__ void bwd_walk(const int* __restrict__ ids, const int*
 }
 
 template <bool STATE, int OUT>
-__global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_sload_kernel(
+__global__ __launch_bounds__(256, GS_BWD_SLOAD_WAVES) void raster_bwd_sload_kernel(
     RasterParams prm, const int* __restrict__ ids /*record index per sorted entry, padded*/,
     const int* __restrict__ eids /*OUT==1: emission index per sorted entry (sorted_vals), padded*/,
     const float* __restrict__ records, unsigned max_id, const float* __restrict__ out_T,

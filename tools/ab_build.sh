@@ -6,13 +6,13 @@ mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
 C="3dgs-deblur_amd/csrc"; B="3dgs-deblur_amd/build"
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fvisibility=hidden"
-declare -A V=( [pk1]="-fno-slp-vectorize" [pk0]="-fno-slp-vectorize -DGS_BWD_PK=0" [pk1slp]="" )
+declare -A V=( [ps1]="-fno-slp-vectorize" [ps0]="-fno-slp-vectorize -DGS_BWD_PAIRSUM=0" )
 for t in "${!V[@]}"; do
-  hipcc $FL ${V[$t]} -c $C/raster_bwd.hip -o /tmp/raster_bwd_$t.o && hipcc --offload-arch=gfx950 -shared -fPIC $B/project.o $B/binning.o $B/raster.o /tmp/raster_bwd_$t.o -o /tmp/libgsd_$t.so
+  hipcc $FL ${V[$t]} -c $C/raster_bwd.hip -o /tmp/raster_bwd_$t.o && hipcc --offload-arch=gfx950 -shared -fPIC $B/project.o $B/binning.o $B/raster.o /tmp/raster_bwd_$t.o $B/dp_exchange.o -o /tmp/libgsd_$t.so
 done
 for rep in 1 2; do
-for t in pk1 pk0 pk1slp; do
-  GSD_LIB_PATH=/tmp/libgsd_$t.so timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+for t in ps1 ps0; do
+  GSD_LIB_PATH=/tmp/libgsd_$t.so timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
