@@ -811,16 +811,18 @@ __global__ __launch_bounds__(256) void bin_edges_kernel(size_t n, const KeyT* __
                                                         int2* __restrict__ bins,
                                                         const unsigned* __restrict__ n_dev = nullptr) {
   if (n_dev) n = min(n, (size_t)*n_dev);
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  unsigned t = (unsigned)(keys[i] >> SHIFT);
-  if (i == 0) {
-    bins[t].x = 0;
-  } else {
-    unsigned tp = (unsigned)(keys[i - 1] >> SHIFT);
-    if (tp != t) { bins[t].x = (int)i; bins[tp].y = (int)i; }
+  // grid-stride: with the count on the device the launch is sized for the CAPACITY (4x the real count in the
+  // benchmark scene) — a capped grid that strides costs what the real count costs
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    unsigned t = (unsigned)(keys[i] >> SHIFT);
+    if (i == 0) {
+      bins[t].x = 0;
+    } else {
+      unsigned tp = (unsigned)(keys[i - 1] >> SHIFT);
+      if (tp != t) { bins[t].x = (int)i; bins[tp].y = (int)i; }
+    }
+    if (i == n - 1) bins[t].y = (int)n;
   }
-  if (i == n - 1) bins[t].y = (int)n;
 }
 
 // the same boundary test plus, for the depth-sliced path, the record index of every sorted entry: the tile sort
@@ -1411,7 +1413,9 @@ GS_EXPORT int gs_tile_bin_edges_u32(long long n, const unsigned* sorted_keys, in
   hipError_t e = hipMemsetAsync(bins, 0, (size_t)num_bins * 2 * sizeof(int), (hipStream_t)stream);
   if (e != hipSuccess) return 1000 + (int)e;
   if (n <= 0) return GS_OK;
-  hipLaunchKernelGGL((bin_edges_kernel<unsigned, 0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (n_dev && blocks > 8192u) blocks = 8192u;
+  hipLaunchKernelGGL((bin_edges_kernel<unsigned, 0>), dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, (size_t)n, sorted_keys, reinterpret_cast<int2*>(bins), n_dev);
   return gs_launch_status();
 }

@@ -975,17 +975,22 @@ class _RenderSubposes(Function):
         radii = torch.empty(P, N, dtype=torch.int32, device=dev)
         args = (N, P, float(glob_scale), K, int(sh_degree), float(fx), float(fy), float(cx), float(cy), H, W,
                 float(clip_thresh), int(bool(antialiased)))
+        # bit 1: culled (Gaussian, sub-pose) pairs get no record at all.  Safe when nothing downstream looks at them:
+        # the compacting pre-sort never ranks them and the tuple backward only visits rows the compositor touched
+        # (the atomics backward of the pixel-velocity model tells "covers no tile" by an all-zero record)
+        lean = DEPTH_SORT_SEGMENTED and DEPTH_SORT_COMPACT and GRAD_TUPLES and COMPACT_EMIT and EXACT_TILE_CULL
+        defer_flags = int(bool(DEFER_COLOR)) | (2 if lean else 0)
         with _stage("project_fwd"):
             if pixvel:
                 _check(L.gs_project_pixvel_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
                                                _ptr(sh), K, args[4], _ptr(V), _ptr(twist), _ptr(times), args[5], args[6],
-                                               args[7], args[8], H, W, args[11], args[12], int(bool(DEFER_COLOR)),
+                                               args[7], args[8], H, W, args[11], args[12], defer_flags,
                                                _ptr(records), _ptr(dkeys), _ptr(ntiles), _ptr(radii), _stream()),
                        "project_pixvel_fwd")
             else:
                 _check(L.gs_project_fused_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
                                               _ptr(sh), K, args[4], _ptr(V), args[5], args[6], args[7], args[8], H, W,
-                                              args[11], args[12], int(bool(DEFER_COLOR)), _ptr(records), _ptr(dkeys),
+                                              args[11], args[12], defer_flags, _ptr(records), _ptr(dkeys),
                                               _ptr(ntiles), _ptr(radii), _stream()), "project_fused_fwd")
         bg = _background(background, dev)
         edges = _band_edges(H, R, dev)

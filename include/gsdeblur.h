@@ -77,7 +77,10 @@ int gs_project_fused_fwd(int N, int P, const float* means3d, const float* scales
                          const float* sh /*N*K_stride*3*/, int K_stride, int sh_degree,
                          const float* viewmats /*P*16*/, float fx, float fy, float cx, float cy,
                          int img_height, int img_width, float clip_thresh, int antialiased,
-                         int defer_color /*1: leave rgb = 0 and skip the SH read; gs_slice_colors fills it later*/,
+                         int defer_color /*bit 0: leave rgb = 0 and skip the SH read; gs_slice_colors fills it later.
+                                           bit 1: write NO record for a culled (Gaussian, sub-pose) pair — its 48 bytes
+                                           stay uninitialised; only for callers that never look at them (the sliced
+                                           path behind gs_segmented_sort_compact_u32, which drops culled keys)*/,
                          float* records /*P*N*12*/, unsigned* depth_keys /*P*N*/,
                          int* num_tiles_hit /*P*N*/, int* radii /*P*N or NULL*/, void* stream);
 /* deferred SH colour of the slice Gaussians with counts[j] > 0 (global index slice_gi[j] = p*N + g) */
