@@ -15,7 +15,7 @@ KERNELS = ["raster_bwd_sload_kernel", "raster_fwd_sload_kernel", "raster_bwd_ker
            "slice_colors_kernel", "emit_open_kernel", "reduce_tuples_wave_kernel", "radix_scatter_kernel",
            "radix_hist_kernel"]
 # issue cycles per VALU wave-instruction of the kernel's inner-loop mix (tools/valu_mix.py x tools/valu_bench.hip)
-MIX = {"raster_fwd_sload_kernel": 861.1 / 245, "raster_bwd_sload_kernel": 1369.2 / 408,
+MIX = {"raster_fwd_sload_kernel": 861.1 / 245, "raster_bwd_sload_kernel": 1429.0 / 441,
        "raster_fwd_slice_kernel": 328.7 / 82, "raster_bwd_kernel_v2": 480.4 / 125}
 
 
