@@ -981,6 +981,12 @@ __global__ __launch_bounds__(256) void slice_counts_kernel(int n_slice, SliceDes
 // table rejects Gaussians without open tiles with four loads, small boxes are walked by their own
 // lane, large boxes (the nearest Gaussians cover hundreds of tiles) by the whole wave, 64 tiles per step.
 constexpr int kCountSolo = 12;
+// A wave with SEVERAL mid-sized boxes (13..64 tiles: one mask word) walks them in their own lanes too: taking them
+// one after the other through the wave-cooperative path costs ~200 cycles each, and a scene of uniformly small
+// splats (bench.py --scene trained: ~4x4 boxes) has dozens per wave — that path made the count of its later slices
+// 3x slower than the rest of the binning together.
+constexpr int kCountSoloMax = 64;
+constexpr int kCountSoloMany = 4;
 constexpr int kMaskWords = 512;     // box-local hit-bit string assembled in LDS: boxes of up to 32768 tiles (4K: 32400)
 
 // w (<= 64) bits of a tile row's open mask starting at column x0
@@ -1033,7 +1039,10 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
   const unsigned T = (unsigned)(tiles_x * tiles_y);
   const int W64 = (tiles_x + 63) >> 6;
   unsigned cnt = 0;
-  if (area > 0 && area <= kCountSolo) {
+  const int solo_limit =
+      (!WAVE_PER_G && __popcll(__ballot(area > kCountSolo && area <= kCountSoloMax)) >= kCountSoloMany) ? kCountSoloMax
+                                                                                                       : kCountSolo;
+  if (area > 0 && area <= solo_limit) {
     // small box (one mask word): per tile ROW, the columns the ellipse reaches AND the open tiles, as bits
     const int x0 = lo & 0xFFFF, y0 = lo >> 16, x1 = hi & 0xFFFF, y1 = hi >> 16;
     const int w = x1 - x0;
@@ -1043,14 +1052,14 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
       int t0, t1;
       span_tiles(el, row_span(el, y, H), x0, x1, t0, t1);
       if (t1 <= t0) continue;
-      unsigned long long rowbits = (((1ull << (t1 - t0)) - 1ull) << (t0 - x0));           // w <= 12
+      unsigned long long rowbits = (t1 - t0 >= 64 ? ~0ull : ((1ull << (t1 - t0)) - 1ull)) << (t0 - x0);   // w <= 64
       if (open_bits) rowbits &= row_window(open_bits + ((size_t)pidx * tiles_y + y) * W64, x0, w);
       cnt += (unsigned)__popcll(rowbits);
       m |= rowbits << ((y - y0) * w);
     }
-    if (masks) masks[moff] = m;                 // kCountSolo <= 64: one word
+    if (masks) masks[moff] = m;                 // area <= 64: one word
   }
-  unsigned long long big = __ballot(area > kCountSolo);
+  unsigned long long big = __ballot(area > solo_limit);
   unsigned long long* words = s_words[threadIdx.x >> 6];
   while (big) {
     const int src = __ffsll((long long)big) - 1;
@@ -1152,6 +1161,33 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
       hot = (tile_hot != nullptr && rec[5] > K::kAlphaMax) ? 1 : 0;
       if (masks) moff = mask_off[j];
       else if (invalid_key) el = make_ellipse(rec);
+    }
+  }
+  if (masks && !WAVE_PER_G) {
+    // boxes of one mask word (<= 64 tiles), when the wave holds several: every lane expands its own word — up to 64
+    // Gaussians in ~cnt steps instead of one wave-wide step each (a scene of uniformly small splats has dozens per
+    // wave).  Same (y, x) order inside a Gaussian; the writes of neighbouring lanes land in neighbouring ranges.
+    const int x0 = lo & 0xFFFF, y0 = lo >> 16, x1 = hi & 0xFFFF, y1 = hi >> 16;
+    const int w = x1 - x0, area = w * (y1 - y0);
+    const bool small = cnt != 0 && area <= kCountSoloMax;
+    if (__popcll(__ballot(small)) >= kCountSoloMany) {
+      if (small) {
+        unsigned long long m = masks[moff];
+        const float rw = 1.0f / (float)w;
+        const unsigned pbase = (gi / (unsigned)N) * (unsigned)T;
+        unsigned e = e0;
+        while (m) {
+          const int b = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          const int q = (int)(((float)b + 0.5f) * rw);
+          const unsigned k = pbase + (unsigned)((y0 + q) * tiles_x + x0 + (b - q * w));
+          keys[e] = k;
+          vals[e] = gi;
+          if (hot) tile_hot[k] = 1;
+          ++e;
+        }
+        cnt = 0;
+      }
     }
   }
   unsigned long long todo = __ballot(cnt != 0);

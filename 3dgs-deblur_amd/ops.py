@@ -506,7 +506,9 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                 have_holes = (not first) or holes0
                 # few Gaussians with large boxes (the nearest slice): one wave per Gaussian
                 box_total = (n_total if K == 1 else sum(rel_at[p][0] for p in range(P))) if first else 0
-                wave_per_g = int(first and box_total > 32 * n_k)
+                # (boxes of up to 64 tiles are walked by single lanes where a wave holds several of them: only slices
+                #  of really large boxes — hundreds of tiles each — are better off with a wave per Gaussian)
+                wave_per_g = int(first and box_total > 128 * n_k)
                 masks = mask_off = None
                 if compact:
                     if HIT_MASKS and true_total is not None and true_total < 2 ** 32 - 64:
