@@ -261,7 +261,9 @@ struct FusedParams {
 constexpr int GS_FLAG_UPSTREAM_FOV_CLAMP_GRAD = 1;   // back-propagate through the fov clamp as if inactive
 constexpr int GS_FLAG_RAW_QUAT_GRAD = 2;             // no projection of the quaternion gradient through q/|q|
 
-template <int MAXB>
+// DEFER (== fp.defer_color, as a template parameter): the SH coefficients are neither loaded nor held — 48 VGPRs of
+// zeros otherwise, a third of the kernel's 153 and the difference between 3 and 5 waves per SIMD.
+template <int MAXB, bool DEFER>
 __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, float* __restrict__ records,
     unsigned* __restrict__ depth_keys, int* __restrict__ ntiles, int* __restrict__ radii) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -274,14 +276,11 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
   quat_to_rotmat(q, R, qn, &inv);
   scale_rot_to_cov3d(s, fp.glob, R, M, c3);
   const int nb = (fp.deg + 1) * (fp.deg + 1);
-  float coef[MAXB * 3];
-  if (!fp.defer_color) {
+  float coef[DEFER ? 1 : MAXB * 3];
+  if (!DEFER) {
     const float* c = fp.sh + (size_t)i * fp.K_stride * 3;
 #pragma unroll
-    for (int k = 0; k < MAXB * 3; ++k) coef[k] = (k < nb * 3) ? c[k] : 0.f;
-  } else {
-#pragma unroll
-    for (int k = 0; k < MAXB * 3; ++k) coef[k] = 0.f;
+    for (int k = 0; k < MAXB * 3; ++k) coef[DEFER ? 0 : k] = (k < nb * 3) ? c[k] : 0.f;
   }
   // pixel-velocity model: geometry of the mid-exposure pose once, then one re-centred record per sub-pose
   Proj o0; ProjCtx k0;
@@ -328,13 +327,16 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
       float dx = m[0] - cxw, dy = m[1] - cyw, dz = m[2] - czw;
       float dinv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
       float cr = 0.f, cg = 0.f, cb = 0.f;
-      if (!fp.defer_color) {
+      if (!DEFER) {
         float B[MAXB];
         sh_basis(fp.deg, dx * dinv, dy * dinv, dz * dinv, B);
         cr = 0.5f; cg = 0.5f; cb = 0.5f;
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) {
-          if (b < nb) { cr += B[b] * coef[3 * b]; cg += B[b] * coef[3 * b + 1]; cb += B[b] * coef[3 * b + 2]; }
+          if (b < nb) {
+            cr += B[b] * coef[DEFER ? 0 : 3 * b]; cg += B[b] * coef[DEFER ? 0 : 3 * b + 1];
+            cb += B[b] * coef[DEFER ? 0 : 3 * b + 2];
+          }
         }
         cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
       }
@@ -716,12 +718,15 @@ GS_EXPORT int gs_project_fused_fwd(int N, int P, const float* means, const float
   FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmats,
                               fx, fy, cx, cy, H, W, clip, antialiased, defer_color);
   dim3 grid((N + 255) / 256), block(256);
-  if (sh_degree <= 3)
-    hipLaunchKernelGGL(project_fused_fwd_kernel<16>, grid, block, 0, (hipStream_t)stream, fp, records, depth_keys,
-                       num_tiles_hit, radii);
+  if (fp.defer_color)       // the SH degree plays no part: one instantiation
+    hipLaunchKernelGGL((project_fused_fwd_kernel<16, true>), grid, block, 0, (hipStream_t)stream, fp, records,
+                       depth_keys, num_tiles_hit, radii);
+  else if (sh_degree <= 3)
+    hipLaunchKernelGGL((project_fused_fwd_kernel<16, false>), grid, block, 0, (hipStream_t)stream, fp, records,
+                       depth_keys, num_tiles_hit, radii);
   else
-    hipLaunchKernelGGL(project_fused_fwd_kernel<25>, grid, block, 0, (hipStream_t)stream, fp, records, depth_keys,
-                       num_tiles_hit, radii);
+    hipLaunchKernelGGL((project_fused_fwd_kernel<25, false>), grid, block, 0, (hipStream_t)stream, fp, records,
+                       depth_keys, num_tiles_hit, radii);
   return gs_launch_status();
 }
 
@@ -804,12 +809,15 @@ GS_EXPORT int gs_project_pixvel_fwd(int N, int P, const float* means, const floa
                               fx, fy, cx, cy, H, W, clip, antialiased, defer_color);
   fp.pixvel = 1; fp.twist = twist; fp.times = times;
   dim3 grid((N + 255) / 256), block(256);
-  if (sh_degree <= 3)
-    hipLaunchKernelGGL(project_fused_fwd_kernel<16>, grid, block, 0, (hipStream_t)stream, fp, records, depth_keys,
-                       num_tiles_hit, radii);
+  if (fp.defer_color)       // the SH degree plays no part: one instantiation
+    hipLaunchKernelGGL((project_fused_fwd_kernel<16, true>), grid, block, 0, (hipStream_t)stream, fp, records,
+                       depth_keys, num_tiles_hit, radii);
+  else if (sh_degree <= 3)
+    hipLaunchKernelGGL((project_fused_fwd_kernel<16, false>), grid, block, 0, (hipStream_t)stream, fp, records,
+                       depth_keys, num_tiles_hit, radii);
   else
-    hipLaunchKernelGGL(project_fused_fwd_kernel<25>, grid, block, 0, (hipStream_t)stream, fp, records, depth_keys,
-                       num_tiles_hit, radii);
+    hipLaunchKernelGGL((project_fused_fwd_kernel<25, false>), grid, block, 0, (hipStream_t)stream, fp, records,
+                       depth_keys, num_tiles_hit, radii);
   return gs_launch_status();
 }
 

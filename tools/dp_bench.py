@@ -1,5 +1,7 @@
-"""Device-side cost of the row-sparse gradient exchange on ONE GPU (everything but the collective):
-row mask over the six gradient tensors, nonzero, pack, zero-fill, and `world` scatter-adds.
+"""Device-side cost of the row-sparse gradient exchange on ONE GPU (everything but the collective).
+First line: the sync-free form dp.allreduce_gradients(mode="sparse") uses (masked pack into a fixed-capacity payload with
+a header, zero-fill, `world` count-from-header scatter-adds).  Second line: the index-list form (row mask, nonzero —
+a host sync —, pack, zero-fill, scatter-adds) kept for comparison.
 usage: python tools/dp_bench.py [N] [rows] [world]"""
 import sys
 import time
@@ -33,12 +35,21 @@ def timed(fn, reps=20):
     return (time.perf_counter() - t0) / reps * 1e6, out
 
 
+cap = int(rows * 1.25) + 64
+t_pm, pay_m = timed(lambda: ops.pack_masked(cap))
+t_zero0, _ = timed(lambda: [x.zero_() for x in grads])
+t_sc0, _ = timed(lambda: [ops.scatter_add_payload(pay_m, cap, 1.0 / world) for _ in range(world)])
+print(f"dp exchange, device side, sync-free, N={N} rows={rows} cap={cap} world={world}: mask + masked pack {t_pm:.0f} us, "
+      f"zero-fill {t_zero0:.0f} us, {world} payload scatter-adds {t_sc0:.0f} us, total {t_pm + t_zero0 + t_sc0:.0f} us; "
+      f"payload per rank {pay_m.numel() * 4 / 1e6:.2f} MB")
+grads = [(torch.randn(s, generator=g) * touched.view(-1, *([1] * (len(s) - 1)))).to(dev) for s in shapes]
+ops = _RowOps(grads)
 t_mask, mask = timed(ops.row_mask)
 t_nz, idx = timed(lambda: mask.nonzero(as_tuple=False).reshape(-1))
 t_pack, pay = timed(lambda: ops.pack(idx, idx.numel()))
 t_zero, _ = timed(lambda: [x.zero_() for x in grads])
 t_scatter, _ = timed(lambda: [ops.scatter_add(pay, idx.numel(), 1.0 / world) for _ in range(world)])
 total = t_mask + t_nz + t_pack + t_zero + t_scatter
-print(f"dp exchange, device side, N={N} rows={idx.numel()} world={world}: row_mask {t_mask:.0f} us, nonzero {t_nz:.0f} us, "
+print(f"dp exchange, device side, index-list form, N={N} rows={idx.numel()} world={world}: row_mask {t_mask:.0f} us, nonzero {t_nz:.0f} us, "
       f"pack {t_pack:.0f} us, zero-fill {t_zero:.0f} us, {world} scatter-adds {t_scatter:.0f} us, total {total:.0f} us; "
       f"payload per rank {pay.numel() * 4 / 1e6:.2f} MB (dense bucket {sum(x.numel() for x in grads) * 4 / 1e6:.0f} MB)")

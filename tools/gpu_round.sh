@@ -22,7 +22,7 @@ if [ "$MODE" = "full" ]; then
 fi
 if [ "$MODE" = "full" ]; then
   echo "== dp exchange, device side ==" | tee -a $OUT/summary.log
-  timeout 120 python tools/dp_bench.py 2>&1 | tail -1 | tee -a $OUT/summary.log
+  timeout 120 python tools/dp_bench.py 2>&1 | tail -2 | tee -a $OUT/summary.log
 fi
 echo "== bench x2 (no cpu baseline) ==" | tee -a $OUT/summary.log
 for v in 1 2; do
