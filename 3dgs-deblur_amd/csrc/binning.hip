@@ -916,8 +916,10 @@ __global__ void slice_plan_kernel(int P, int N, int K, const unsigned* __restric
 // open_bits (nullable) [p][tiles_y][ceil(tiles_x/64)] u64: bit x of row y set <=> tile (x, y) is still open — the exact
 // count ANDs a whole tile row of a Gaussian's box against it instead of loading one byte per tile.
 __global__ __launch_bounds__(256) void tile_sat_kernel(int tiles_x, int tiles_y, const unsigned char* __restrict__ done,
-                                                       int* __restrict__ sat, unsigned long long* __restrict__ open_bits) {
+                                                       int* __restrict__ sat, unsigned long long* __restrict__ open_bits,
+                                                       const int* __restrict__ gate) {
   extern __shared__ int s[];
+  if (gate && *gate == 0) return;      // no tile is open any more: nobody will look at the table
   const int p = blockIdx.x;
   const int T = tiles_x * tiles_y, SW = tiles_x + 1, SH = tiles_y + 1;
   const unsigned char* d = done + (size_t)p * T;
@@ -1010,11 +1012,18 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
                                                                  const unsigned* __restrict__ cum_rank,   // nullable
                                                                  unsigned long long* __restrict__ masks,  // nullable
                                                                  unsigned* __restrict__ mask_off,
-                                                                 const unsigned long long* __restrict__ open_bits) {
+                                                                 const unsigned long long* __restrict__ open_bits,
+                                                                 const int* __restrict__ gate) {
   __shared__ unsigned long long s_words[4][kMaskWords];
   const int lane = lane_id();
   const int j = WAVE_PER_G ? (lane == 0 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : n_slice)
                            : (int)(blockIdx.x * 256 + threadIdx.x);
+  if (gate && *gate == 0) {
+    // the previous slice closed the last open tile: this slice was launched without anybody waiting for that
+    // answer; all it has to do is say "nothing" (everything downstream works off the counts)
+    if (j < n_slice) counts[j] = 0u;
+    return;
+  }
   unsigned gi = 0, lo = 0, hi = 0, moff = 0;
   int area = 0;
   Ellipse el = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 1.f, 1.f, 0.f, 0.f, 0.f};
@@ -1506,7 +1515,7 @@ GS_EXPORT int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl, const
 
 // sat [P*(tiles_y+1)*(tiles_x+1)]: summed-area table of tiles that are NOT done.
 GS_EXPORT int gs_tile_open_sat(int P, int H, int W, const unsigned char* tile_done, int* sat,
-                               unsigned long long* open_bits, void* stream) {
+                               unsigned long long* open_bits, const int* gate, void* stream) {
   if (P <= 0) return GS_ERR_INVALID;
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
   size_t lds = (size_t)(tiles_x + 1) * (tiles_y + 1) * sizeof(int);
@@ -1515,7 +1524,7 @@ GS_EXPORT int gs_tile_open_sat(int P, int H, int W, const unsigned char* tile_do
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tile_sat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
   hipLaunchKernelGGL(tile_sat_kernel, dim3(P), dim3(256), lds, (hipStream_t)stream, tiles_x, tiles_y, tile_done, sat,
-                     open_bits);
+                     open_bits, gate);
   return gs_launch_status();
 }
 
@@ -1539,7 +1548,7 @@ GS_EXPORT int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_
                                     const unsigned char* tile_done, int H, int W, unsigned* slice_gi,
                                     unsigned* counts, int wave_per_gaussian, const unsigned* cum_rank,
                                     unsigned long long* hit_masks, unsigned* mask_off,
-                                    const unsigned long long* open_bits, void* stream) {
+                                    const unsigned long long* open_bits, const int* gate, void* stream) {
   SliceDesc sd;
   if (n_slice <= 0 || !make_slice_desc(P, slice_begin, slice_prefix, sd)) return GS_ERR_INVALID;
   if (hit_masks && (!cum_rank || !mask_off)) return GS_ERR_INVALID;
@@ -1548,11 +1557,11 @@ GS_EXPORT int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_
   if (wave_per_gaussian)
     hipLaunchKernelGGL(slice_counts_exact_kernel<true>, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W, H, slice_gi, counts,
-                       cum_rank, hit_masks, mask_off, open_bits);
+                       cum_rank, hit_masks, mask_off, open_bits, gate);
   else
     hipLaunchKernelGGL(slice_counts_exact_kernel<false>, dim3((n_slice + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W,
-                       H, slice_gi, counts, cum_rank, hit_masks, mask_off, open_bits);
+                       H, slice_gi, counts, cum_rank, hit_masks, mask_off, open_bits, gate);
   return gs_launch_status();
 }
 

@@ -48,6 +48,11 @@ DEPTH_SORT_SEGMENTED = int(os.environ.get("GSD_DEPTH_SORT_SEGMENTED", "1"))
 DEPTH_SORT_COMPACT = int(os.environ.get("GSD_DEPTH_SORT_COMPACT", "1"))
 # widest radix digit of the compacting depth pre-sort: 8 -> 4 passes of 8 bits, 11 -> 3 passes of 11/10/10 bits
 DEPTH_SORT_DIGIT = int(os.environ.get("GSD_DEPTH_SORT_DIGIT", "8"))
+# 1: depth slices after the first are launched without waiting for "is any tile still open?" (device-gated, at most
+# one slice ahead of the words coming back); 0 (default): one read-back of that word per slice.  Measured: +1 % on a
+# frame that needs all its planned slices (bench.py --scene trained), -1..2 % on the headline, whose plan holds five
+# slices of which one is used — the gated no-op slice costs the GPU about what the wait did.
+SPECULATE = int(os.environ.get("GSD_SPECULATE", "0"))
 # 1: the tile sort carries the record index of every entry as a second payload (0: gathers it in the final pass)
 TILE_SORT_CARRY = int(os.environ.get("GSD_TILE_SORT_CARRY", "1"))
 # 1: a depth slice's emitted-intersection count stays on the device (buffers / grids sized by the slice's bounding-box
@@ -477,7 +482,8 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
         rows = torch.arange(ty, device=dev)
         band_open = torch.stack([(rows >= e[r]) & (rows < e[r + 1]) for r in range(R)])          # [R, ty]
         tile_done = (~band_open).to(torch.uint8)[None, :, :, None].expand(S, R, ty, tx).reshape(-1).contiguous()
-        _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _ptr(open_bits), _stream()), "tile_open_sat")
+        _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _ptr(open_bits), None, _stream()),
+               "tile_open_sat")
     else:
         tile_done = tile_done0
     holes0 = R > 1          # the very first slice already has closed tiles
@@ -491,11 +497,32 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     # the host, and the kernels read the real count from the device.  What is left per frame: the plan read-back,
     # plus one look at the open-tile count after every slice that is not the last planned one.
     device_sizes = compact and use_tuples and rel_at is not None and bool(DEVICE_SIZES)
+    # SPECULATE (opt-in, see its definition): nobody waits for "is any tile still open?" either.  The word a slice's compositor leaves
+    # travels to pinned host memory on its own; the next planned slice is launched right away, GATED on the device by
+    # that word (its count kernel then answers "nothing" without looking, and everything downstream works off the
+    # counts: ~20 near-empty launches), and the loop stops launching slices as soon as a word that has arrived says the
+    # frame is complete — it runs at most ONE slice ahead of the words.  The wait it replaces cost ~0.2 ms of GPU idle per frame on the headline: the host could
+    # not queue the rest of the forward, the loss and the backward behind the 0.4 ms compositor launch.
+    speculate = device_sizes and bool(SPECULATE) and K > 1
+    flags_host = torch.empty(KMAX, dtype=torch.int32, pin_memory=True) if speculate else None
+    pending = []          # (event, slice index) of the flag words on their way to flags_host
+    gate_k = None         # slice whose compositor wrote the latest flag word
     for k in range(K):
         first, last = k == 0, k == K - 1
         n_k = n_slices[k]
         I_k = 0
         n_dev = None
+        gate = None
+        if speculate and gate_k is not None:
+            # ONE slice of speculation: the word of the slice before the previous one must be in (by now it usually
+            # is: the host spent a slice's worth of launches since); a frame whose plan holds many slices it does not
+            # need (the headline: 5 planned, 1 used) would otherwise pay for every one of them
+            if len(pending) >= 2:
+                pending[-2][0].synchronize()
+            if any(ev.query() and int(flags_host[kk]) == 0 for ev, kk in pending):
+                _slice_totals.append(0)          # a word that came back says every tile is done
+                break
+            gate = ctypes.c_void_p(open_flags.data_ptr() + 4 * gate_k)
         svals = bins = sorted_ids = None
         tile_hot = zeros_u8[(1 + k) * P * T:(2 + k) * P * T] if (compact and use_tuples) else None
         if n_k > 0:
@@ -521,7 +548,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                                    _ptr(tile_done) if have_holes else None, H, W, _ptr(slice_gi),
                                                    _ptr(counts), wave_per_g, _ptr(cum) if masks is not None else None,
                                                    _ptr(masks), _ptr(mask_off), _ptr(open_bits) if have_holes else None,
-                                                   _stream()), "slice_counts_exact")
+                                                   gate, _stream()), "slice_counts_exact")
                 else:
                     _check(L.gs_slice_counts(n_k, P, N, d_begin, d_prefix,
                                              _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None, H, W,
@@ -604,19 +631,29 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                             RASTER_FWD_VARIANT, _stream()),
                    "rasterize_fwd_slice")
         if I_k > 0:
+            # gated: (event, pinned words, index) of the flag this slice was launched behind — the backward drops the
+            # slice if the word says it had nothing to do
             slices.append(dict(svals=svals, bins=bins, fidx=fidx, I=I_k, gi_of_e=vals if use_tuples else None,
                                sorted_ids=sorted_ids, slice_gi=slice_gi, counts=counts, cum=cum_k, n=n_k,
-                               tile_hot=tile_hot))
+                               tile_hot=tile_hot,
+                               gated=(pending[-1][0], flags_host, gate_k) if gate is not None else None))
         if not last:
-            if device_sizes:
-                # the only per-slice read-back left: are there open tiles for the next planned slice?  One word,
-                # written by the compositor itself; it is read AFTER this slice's whole pipeline was issued, so the
-                # GPU works through it while the host waits
+            sat_gate = None
+            if speculate:
+                flags_host[k:k + 1].copy_(open_flags[k:k + 1], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                pending.append((ev, k))
+                gate_k = k
+                sat_gate = ctypes.c_void_p(open_flags.data_ptr() + 4 * k)
+            elif device_sizes:
+                # one read-back per slice: are there open tiles for the next planned slice?  One word, written by
+                # the compositor itself, read AFTER this slice's whole pipeline was issued
                 if int(open_flags[k].item()) == 0:
                     _slice_totals.append(0)
                     break
             with _stage("slice_sat"):
-                _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _ptr(open_bits), _stream()),
+                _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _ptr(open_bits), sat_gate, _stream()),
                        "tile_open_sat")
     return out_img, out_T, slices
 
@@ -632,6 +669,15 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
     cmb = combine if combine is not None else (None, 1.0, 0.0)
     # reverse-traversal state between slices: running T and (behind-colour . v_out), ONE float per pixel each;
     # a frame that needed a single slice (the common case) carries none
+    # a slice launched behind a gate that turned out closed did nothing: by now its word has long arrived
+    def _ran(sl):
+        g = sl.get("gated")
+        if g is None:
+            return True
+        ev, words, kk = g
+        ev.synchronize()
+        return int(words[kk]) != 0
+    slices = [sl for sl in slices if _ran(sl)]
     bwd_T = bwd_B = None
     if len(slices) > 1 or any(sl["gi_of_e"] is None for sl in slices):
         bwd_T = out_T.clone()

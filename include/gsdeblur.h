@@ -259,6 +259,8 @@ int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl /*P*N, rank orde
 int gs_tile_open_sat(int P, int img_height, int img_width, const unsigned char* tile_done, int* sat,
                      unsigned long long* open_bits /*NULL or [P*tiles_y*ceil(tiles_x/64)]: bit x of row y set while
                                                      tile (x, y) is open (consumed by gs_slice_counts_exact)*/,
+                     const int* gate /*NULL, or the open_flag word of the previous slice's forward compositor: 0 there
+                                       = no tile is open, the launch does nothing*/,
                      void* stream);
 /* slice = for each sub-pose p the depth ranks sorted_gi[slice_begin[p] + i], i < prefix[p+1]-prefix[p]
  * (slice_begin / slice_prefix are HOST arrays, P <= 256: they travel in the kernel arguments);
@@ -279,6 +281,9 @@ int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_begin /*HO
                                                           requires the u32 prefix not to have wrapped (total < 2^32)*/,
                           unsigned* mask_off /*[n_slice] first mask word of each slice Gaussian, or NULL*/,
                           const unsigned long long* open_bits /*from gs_tile_open_sat; NULL exactly when tile_done is*/,
+                          const int* gate /*NULL, or the previous slice's open_flag word (device): 0 there = every
+                                            count is 0 without looking at anything — a slice launched before anybody
+                                            knows whether it is needed costs next to nothing when it is not*/,
                           void* stream);
 int gs_emit_open_intersects(int n_slice, int N, int img_height, int img_width, const unsigned* slice_gi,
                             const unsigned* counts, const unsigned* cum_excl, const float* records,

@@ -674,6 +674,40 @@ def test_depth_sliced_equals_single_pass(gs, oracle, dev, S, R, base):
         assert rel_max(res["sliced"][2][k].cpu(), res["single"][2][k].cpu()) < 1e-4, k
 
 
+@pytest.mark.parametrize("S,R,base", [(2, 1, 4), (3, 2, 16), (1, 1, 512)])
+def test_speculative_slices_change_nothing(gs, oracle, dev, S, R, base):
+    """GSD_SPECULATE=1: slices after the first are launched behind a device-side gate (the previous compositor's
+    "a tile is still open" word) instead of after a host read-back, and the backward drops the ones whose gate was
+    closed: images and gradients identical to the default path, whether the frame needs all its planned slices (small
+    base), a few of them, or one"""
+    from gsdeblur_amd import ops
+    O = oracle
+    W, H, n = 192, 128, 6000
+    sc = O.synthetic_scene(n, W, H, seed=77 + S, scale_mult=7.0)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3))
+    res = {}
+    old = (ops.SLICE_BASE, ops.SPECULATE)
+    try:
+        ops.SLICE_BASE = base
+        for spec in (0, 1):
+            ops.SPECULATE = spec
+            out, alpha, samples, vms, p, radii = _run_full(gs, O, dev, sc, H, W, S, R, 1 / 60, 1 / 30, 2.2, 10.0, 3, bg, wt)
+            res[spec] = (samples.detach().clone(), alpha.detach().clone(), {k: v.grad.detach().clone() for k, v in p.items()},
+                         list(ops.last_slice_intersects))
+    finally:
+        ops.SLICE_BASE, ops.SPECULATE = old
+    a, b = res[0], res[1]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert [t for t in a[3] if t] == [t for t in b[3] if t]            # the same non-empty slices
+    for k in a[2]:
+        if k in ("viewmat", "lin_vel", "ang_vel"):                      # a dozen fp32 atomics per block
+            assert rel_max(a[2][k].cpu(), b[2][k].cpu()) < 1e-4, k
+        else:
+            assert torch.equal(a[2][k], b[2][k]), k
+
+
 @pytest.mark.parametrize("S,R,base,W,H,n,hot", [(2, 2, 8, 208, 144, 6000, False), (1, 1, 0, 131, 77, 900, False),
                                                  (3, 1, 512, 320, 200, 20000, False), (2, 1, 8, 176, 112, 5000, True),
                                                  (1, 2, 512, 131, 90, 2500, True)])
