@@ -53,6 +53,11 @@ DEPTH_SORT_DIGIT = int(os.environ.get("GSD_DEPTH_SORT_DIGIT", "8"))
 # frame that needs all its planned slices (bench.py --scene trained), -1..2 % on the headline, whose plan holds five
 # slices of which one is used — the gated no-op slice costs the GPU about what the wait did.
 SPECULATE = int(os.environ.get("GSD_SPECULATE", "0"))
+# 1: the forward of a frame that will be differentiated also sets up the backward's per-slice buffers (gradient tuples,
+# flags) and the frame's touched flags, while the GPU is busy with the compositor (see sliced_forward); 0: the backward
+# allocates them itself
+PREALLOC_BWD = int(os.environ.get("GSD_PREALLOC_BWD", "1"))
+PREALLOC_MAX_BYTES = 4 << 30          # per slice; larger tuple buffers are left to the backward
 # 1: the tile sort carries the record index of every entry as a second payload (0: gathers it in the final pass)
 TILE_SORT_CARRY = int(os.environ.get("GSD_TILE_SORT_CARRY", "1"))
 # 1: a depth slice's emitted-intersection count stays on the device (buffers / grids sized by the slice's bounding-box
@@ -399,7 +404,7 @@ def _depth_rank(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: i
 
 def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
                    img_height: int, img_width: int, bg: Tensor, edges: Tensor, slice_base: int, color=None,
-                   out_depth: Optional[Tensor] = None):
+                   out_depth: Optional[Tensor] = None, prealloc: Optional[dict] = None):
     """Front-to-back depth-sliced bin + sort + composite.
     -> (out_img [S,H,W,3], out_T [S,H,W], slices) ; slices = list of (sorted_vals, tile_bins, final_idx, I_k)
     that the backward walks in reverse."""
@@ -630,12 +635,23 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                             ctypes.c_void_p(open_flags.data_ptr() + 4 * k) if not last else None,
                                             RASTER_FWD_VARIANT, _stream()),
                    "rasterize_fwd_slice")
+        tuples_k = flags_k = None
+        if prealloc is not None and use_tuples and I_k > 0 and I_k * REC * 4 <= PREALLOC_MAX_BYTES:
+            # the backward's buffers of this slice (and the frame's, once) are set up HERE, while the GPU works
+            # through the compositor just launched: behind the open-tile read-back the host is on the critical path
+            # (rest of the forward, loss, backward prologue), and every allocation / fill taken out of that window
+            # shortens the GPU's wait for the backward compositor
+            tuples_k = torch.empty(I_k * REC, device=dev)
+            flags_k = torch.zeros(I_k, dtype=torch.uint8, device=dev)
+            if "touched" not in prealloc:
+                prealloc["touched"] = torch.zeros(P * N, dtype=torch.uint8, device=dev)
+                prealloc["v_records"] = torch.empty(P * N, REC, device=dev)
         if I_k > 0:
             # gated: (event, pinned words, index) of the flag this slice was launched behind — the backward drops the
             # slice if the word says it had nothing to do
             slices.append(dict(svals=svals, bins=bins, fidx=fidx, I=I_k, gi_of_e=vals if use_tuples else None,
                                sorted_ids=sorted_ids, slice_gi=slice_gi, counts=counts, cum=cum_k, n=n_k,
-                               tile_hot=tile_hot,
+                               tile_hot=tile_hot, tuples=tuples_k, flags=flags_k,
                                gated=(pending[-1][0], flags_host, gate_k) if gate is not None else None))
         if not last:
             sat_gate = None
@@ -685,8 +701,12 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
     for sl in reversed(slices):
         tuples = flags = None
         if sl["gi_of_e"] is not None:
-            tuples = torch.empty(sl["I"] * REC, device=dev)
-            flags = torch.zeros(sl["I"], dtype=torch.uint8, device=dev)
+            # set up by the forward when it could (single use: a second backward through the same graph allocates)
+            tuples, flags = sl.get("tuples"), sl.get("flags")
+            sl["tuples"] = sl["flags"] = None
+            if tuples is None:
+                tuples = torch.empty(sl["I"] * REC, device=dev)
+                flags = torch.zeros(sl["I"], dtype=torch.uint8, device=dev)
         with _stage("raster_bwd"):
             _check(L.gs_rasterize_bwd_slice(_ptr(records), _ptr(sl["svals"]), _ptr(sl["bins"]), _ptr(edges), _ptr(bg),
                                             S, R, H, W, _ptr(out_T), _ptr(sl["fidx"]), _ptr(v_img), _ptr(v_alpha),
@@ -1049,8 +1069,9 @@ class _RenderSubposes(Function):
         color = (means3d, sh, K, args[4], V_col) if DEFER_COLOR else None
         # optional fourth channel: sum of weight * camera-space depth per sample image (forward only)
         depth_acc = torch.zeros(S, H, W, device=dev) if return_depth else None
+        ctx.prealloc = {} if (PREALLOC_BWD and any(ctx.needs_input_grad)) else None
         out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE, color,
-                                                depth_acc)
+                                                depth_acc, ctx.prealloc)
         ctx.slices = slices
         svals = bins = fidx = torch.zeros(1, dtype=torch.int32, device=dev)
         n_isect = last_num_intersects
@@ -1109,7 +1130,11 @@ class _RenderSubposes(Function):
         # atomic-free path: only Gaussians the compositor touched get a gradient record (plain stores) and a
         # `touched` flag; the projection backward skips everything else, so v_records needs no 240 MB memset
         all_tuples = all(sl["gi_of_e"] is not None for sl in ctx.slices)
-        if all_tuples:
+        pre = ctx.prealloc if ctx.prealloc else {}
+        ctx.prealloc = None
+        if all_tuples and "touched" in pre:
+            v_records, touched = pre["v_records"], pre["touched"]
+        elif all_tuples:
             v_records = torch.empty(P * N, REC, device=dev)
             touched = torch.zeros(P * N, dtype=torch.uint8, device=dev)
         else:
