@@ -326,6 +326,25 @@ def _band_edges(img_height: int, rs_bands: int, device) -> Tensor:
     return t
 
 
+_band_done_cache = {}
+
+
+def _band_tile_done(S: int, R: int, ty: int, tx: int, dev) -> Tensor:
+    """u8 [S*R*ty*tx]: 1 for every tile of sub-pose (s, r) outside band r's tile rows — the initial tile_done of a
+    rolling-shutter frame.  Cached (a dozen small torch ops per frame otherwise, behind the plan read-back)."""
+    key = (S, R, ty, tx, str(dev))
+    t = _band_done_cache.get(key)
+    if t is None:
+        e = [(r * ty) // R for r in range(R + 1)]       # same formula as _band_edges
+        rows = torch.arange(ty, device=dev)
+        band_open = torch.stack([(rows >= e[r]) & (rows < e[r + 1]) for r in range(R)])          # [R, ty]
+        t = (~band_open).to(torch.uint8)[None, :, :, None].expand(S, R, ty, tx).reshape(-1).contiguous()
+        if len(_band_done_cache) > 16:
+            _band_done_cache.clear()
+        _band_done_cache[key] = t
+    return t
+
+
 def _background(background: Optional[Tensor], device) -> Tensor:
     if background is None:
         return torch.zeros(3, dtype=torch.float32, device=device)
@@ -441,14 +460,17 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                    ctypes.c_void_p(plan_dev.data_ptr() + 8 * P * KMAX), _ptr(n_live),
                                    ctypes.c_void_p(plan_dev.data_ptr() + 8 * P * KMAX + 4 * P), _stream()),
                    "slice_plan")
-            plan = plan_dev.cpu().long() & 0xFFFFFFFF                                    # one host sync
-            rel_at = plan[P * KMAX:2 * P * KMAX].view(P, KMAX).tolist()
-            seg_totals = plan[2 * P * KMAX:2 * P * KMAX + P].tolist()
-        n_total = int(plan[-1])
-        b = plan[:P * KMAX].view(P, KMAX).tolist()
+            # one host sync; everything after it is plain Python on one list (the GPU is idle until the first launch
+            # of the slice pipeline: a handful of CPU-tensor ops here cost more than the whole planning)
+            plan = [v & 0xFFFFFFFF for v in plan_dev.tolist()]
+            PK = P * KMAX
+            rel_at = [plan[PK + p * KMAX:PK + (p + 1) * KMAX] for p in range(P)]
+            seg_totals = plan[2 * PK:2 * PK + P]
+        n_total = plan[-1]
+        b = [plan[p * KMAX:(p + 1) * KMAX] for p in range(P)]
         # NV[p]: ranks of sub-pose p that hold a Gaussian (everything behind them is unspecified after the
         # compacting pre-sort; without it the culled Gaussians sit there with zero tiles)
-        NV = [min(N, int(v)) for v in plan[2 * P * KMAX + P:2 * P * KMAX + 2 * P].tolist()]
+        NV = [min(N, v) for v in plan[2 * PK + P:2 * PK + 2 * P]]
         # number of slices: up to the first k whose boundary reaches the last live rank in every sub-pose
         K = KMAX
         for k in range(KMAX):
@@ -483,10 +505,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     if R > 1:
         # rolling-shutter bands: sub-pose p = s*R + r only ever composites tile rows [edge[r], edge[r+1]);
         # every other tile of p is "done" from the start so the binning never emits for it
-        e = [(r * ty) // R for r in range(R + 1)]       # same formula as _band_edges (no device sync)
-        rows = torch.arange(ty, device=dev)
-        band_open = torch.stack([(rows >= e[r]) & (rows < e[r + 1]) for r in range(R)])          # [R, ty]
-        tile_done = (~band_open).to(torch.uint8)[None, :, :, None].expand(S, R, ty, tx).reshape(-1).contiguous()
+        tile_done = _band_tile_done(S, R, ty, tx, dev).clone()      # (the kernels write into it)
         _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _ptr(open_bits), None, _stream()),
                "tile_open_sat")
     else:
