@@ -674,6 +674,45 @@ def test_depth_sliced_equals_single_pass(gs, oracle, dev, S, R, base):
         assert rel_max(res["sliced"][2][k].cpu(), res["single"][2][k].cpu()) < 1e-4, k
 
 
+@pytest.mark.parametrize("knob,value", [("DEVICE_SIZES", 0), ("DEPTH_SORT_COMPACT", 0), ("DEPTH_SORT_SEGMENTED", 0),
+                                        ("TILE_SORT_CARRY", 0), ("PREALLOC_BWD", 0), ("HIT_MASKS", 0),
+                                        ("DEFER_COLOR", 0), ("DEPTH_SORT_DIGIT", 11)])
+@pytest.mark.parametrize("S,R,base", [(2, 2, 8), (3, 1, 512)])
+def test_every_runtime_knob_gives_the_default_result(gs, oracle, dev, knob, value, S, R, base):
+    """the A/B switches of ops.py (environment variables GSD_*) select alternative routes through the same pipeline —
+    read-backs instead of device-side counts, the full instead of the compacting depth pre-sort, the 64-bit sort
+    route, the gathered instead of the carried record index, backward-side allocation, emission without hit masks,
+    SH colour in the projection: every one of them must give the default path's images and gradients, on a
+    multi-slice rolling-shutter frame and on a single-slice one"""
+    from gsdeblur_amd import ops
+    O = oracle
+    W, H, n = 176, 144, 5000
+    sc = O.synthetic_scene(n, W, H, seed=31 + S, scale_mult=7.0)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10
+    bg = torch.tensor([0.1, 0.3, 0.2])
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(4))
+    res = {}
+    old = (ops.SLICE_BASE, getattr(ops, knob))
+    try:
+        ops.SLICE_BASE = base
+        for v in (old[1], value):
+            setattr(ops, knob, v)
+            out, alpha, samples, vms, p, radii = _run_full(gs, O, dev, sc, H, W, S, R, 1 / 60, 1 / 30, 2.2, 10.0, 3, bg, wt)
+            res[v] = (samples.detach().clone(), alpha.detach().clone(), {k: g.grad.detach().clone() for k, g in p.items()})
+    finally:
+        ops.SLICE_BASE = old[0]
+        setattr(ops, knob, old[1])
+    a, b = res[old[1]], res[value]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        # images are bit-identical; gradients agree up to fp32 summation order (the tuple reduce picks its segment
+        # strategy by the buffer size it is given — a capacity on the default path, the exact count with
+        # DEVICE_SIZES=0 —, SH colour evaluated in the projection rounds differently, pose / velocity gradients end
+        # in fp32 atomics)
+        tol = 1e-4 if (knob == "DEFER_COLOR" or k in ("viewmat", "lin_vel", "ang_vel")) else 2e-5
+        assert rel_max(a[2][k].cpu(), b[2][k].cpu()) < tol, k
+
+
 @pytest.mark.parametrize("S,R,base", [(2, 1, 4), (3, 2, 16), (1, 1, 512)])
 def test_speculative_slices_change_nothing(gs, oracle, dev, S, R, base):
     """GSD_SPECULATE=1: slices after the first are launched behind a device-side gate (the previous compositor's
