@@ -326,6 +326,18 @@ def _band_edges(img_height: int, rs_bands: int, device) -> Tensor:
     return t
 
 
+_placeholder_cache = {}
+
+
+def _placeholder_i32(dev) -> Tensor:
+    """a one-element int32 tensor per device for save_for_backward slots that hold nothing (a fresh torch.zeros is a
+    fill launch per frame, issued on the host's critical path behind the last read-back)"""
+    t = _placeholder_cache.get(str(dev))
+    if t is None:
+        t = _placeholder_cache[str(dev)] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
+
+
 _band_done_cache = {}
 
 
@@ -1092,7 +1104,7 @@ class _RenderSubposes(Function):
         out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE, color,
                                                 depth_acc, ctx.prealloc)
         ctx.slices = slices
-        svals = bins = fidx = torch.zeros(1, dtype=torch.int32, device=dev)
+        svals = bins = fidx = _placeholder_i32(dev)       # nothing to keep: the slices hold their own lists
         n_isect = last_num_intersects
         ctx.combine = None
         first = cmb_samples = cmb_rgb = out_img
