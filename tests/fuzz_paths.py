@@ -3,7 +3,7 @@ masks, deferred colour, gradient tuples) against the plainest one (one slice, no
 sizes / sub-pose layouts / slice budgets.  Images must be bit-identical, gradients equal up to summation order.
 With `oracle` as third argument the default path is ALSO held against the float64 CPU oracle (tiny sizes only;
 test infrastructure, never part of the product path).
-usage: python tests/fuzz_paths.py [trials] [seed] [oracle]"""
+usage: python tests/fuzz_paths.py [trials] [seed] [oracle] [only:<trial>]   (only: replay the draws, run that trial alone)"""
 import random
 import sys
 import time
@@ -19,13 +19,16 @@ from gsdeblur_amd import ops  # noqa: E402
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 with_oracle = len(sys.argv) > 3 and sys.argv[3] == "oracle"
+only = next((int(a[5:]) for a in sys.argv[1:] if a.startswith("only:")), None)
 if with_oracle:
     sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "oracle"))
     import gs_oracle as O  # noqa: E402
 rng = random.Random(seed)
 dev = torch.device("cuda", 0)
 KNOBS = ("SLICE_BASE", "EXACT_TILE_CULL", "COMPACT_EMIT", "HIT_MASKS", "GRAD_TUPLES", "DEFER_COLOR")
-saved = {k: getattr(ops, k) for k in KNOBS}
+# route switches that must not change anything: drawn at random for the default-path side of every trial
+ROUTES = ("SPECULATE", "TILE_SORT_CARRY", "DEPTH_SORT_COMPACT", "DEVICE_SIZES", "PREALLOC_BWD")
+saved = {k: getattr(ops, k) for k in KNOBS + ROUTES}
 bad = 0
 t0 = time.time()
 for trial in range(trials):
@@ -40,8 +43,17 @@ for trial in range(trials):
     S, R = rng.choice([1, 2, 3]), rng.choice([1, 1, 2, 4])
     mult = rng.choice([1.0, 3.0, 6.0, 12.0])
     base = rng.choice([1, 4, 16, 64, 512])
-    sc = gs.data.synthetic_scene(n, W, H, sh_degree=deg, seed=1000 + trial, scale_mult=mult)
+    sc = gs.data.synthetic_scene(n, W, H, sh_degree=deg, seed=1000 + trial, scale_mult=mult,
+                                 profile=rng.choice(["survey", "survey", "trained"]))
+    if rng.random() < 0.3:            # a few opacities above the 0.999 alpha clamp (tile_hot / clamping loop version)
+        sc["opacity_logits"] = sc["opacity_logits"].clone()
+        # 7.5: sigmoid = 0.99945 (above the clamp) while torch's own fp32 sigmoid backward, y*(1-y), still resolves
+        # 1-y to 1e-4 relative (at logit 14 it does not, and the oracle comparison of that gradient measures torch)
+        sc["opacity_logits"][::rng.choice([3, 17, 101])] = 7.5
+    routes = {k: rng.choice([0, 1]) for k in ROUTES}
     sc_cpu = sc
+    if only is not None and trial != only:
+        continue
     sc = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
     times, _, _ = gs.subpose_schedule(S, 1 / 60, R, 1 / 30)
     wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(trial)).to(dev)
@@ -50,6 +62,8 @@ for trial in range(trials):
         for plain in (False, True):
             for k in KNOBS:
                 setattr(ops, k, 0 if plain else saved[k])
+            for k in ROUTES:
+                setattr(ops, k, saved[k] if plain else routes[k])
             if not plain:
                 ops.SLICE_BASE = base
             p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
@@ -68,10 +82,16 @@ for trial in range(trials):
             setattr(ops, k, v)
     (img_f, al_f, g_f, nsl), (img_p, al_p, g_p, _) = res
     ok = torch.equal(img_f, img_p) and torch.equal(al_f, al_p)
-    worst = 0.0
+    worst, worst_key = 0.0, ""
     for k in g_f:
         a, b = g_f[k].double().cpu().numpy(), g_p[k].double().cpu().numpy()
-        worst = max(worst, float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30)))
+        d = float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+        if d > worst:
+            worst, worst_key = d, k
+        if only is not None:
+            i = int(np.abs(a - b).reshape(a.shape[0], -1).max(1).argmax())
+            print(f"   {k}: rel {d:.2e}  max|b| {np.abs(b).max():.3e}  worst row {i}: fast {a.reshape(a.shape[0], -1)[i][:4]} plain "
+                  f"{b.reshape(b.shape[0], -1)[i][:4]}  logit {float(sc_cpu['opacity_logits'][i]):.2f}")
     ok = ok and worst < 3e-3 and all(torch.isfinite(v).all() for v in g_f.values())
     extra = ""
     if with_oracle:
@@ -95,7 +115,7 @@ for trial in range(trials):
         extra = f" oracle: img {d_img:.1e} grad {d_grad:.1e} fragile {float(frag.float().mean()):.3f}"
     bad += 0 if ok else 1
     print(f"trial {trial:3d} n={n:6d} {W}x{H} S={S} R={R} mult={mult} base={base} slices={nsl} "
-          f"deg={deg} aa={int(aa)} gamma={gamma} img_equal={torch.equal(img_f, img_p)} grad_rel={worst:.1e}{extra} "
+          f"deg={deg} aa={int(aa)} gamma={gamma} routes={''.join(str(routes[k]) for k in ROUTES)} img_equal={torch.equal(img_f, img_p)} grad_rel={worst:.1e} ({worst_key}){extra} "
           f"{'ok' if ok else 'FAIL'}", flush=True)
 print(f"fuzz: {trials - bad}/{trials} trials ok in {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
