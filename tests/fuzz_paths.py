@@ -20,6 +20,7 @@ trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 with_oracle = len(sys.argv) > 3 and sys.argv[3] == "oracle"
 only = next((int(a[5:]) for a in sys.argv[1:] if a.startswith("only:")), None)
+dump = next((a[5:] for a in sys.argv[1:] if a.startswith("dump:")), None)     # with only: save the trial's inputs + gradients
 if with_oracle:
     sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "oracle"))
     import gs_oracle as O  # noqa: E402
@@ -93,6 +94,13 @@ for trial in range(trials):
             print(f"   {k}: rel {d:.2e}  max|b| {np.abs(b).max():.3e}  worst row {i}: fast {a.reshape(a.shape[0], -1)[i][:4]} plain "
                   f"{b.reshape(b.shape[0], -1)[i][:4]}  logit {float(sc_cpu['opacity_logits'][i]):.2f}")
     ok = ok and worst < 3e-3 and all(torch.isfinite(v).all() for v in g_f.values())
+    if dump and only is not None:
+        np.savez_compressed(dump, W=W, H=H, S=S, R=R, deg=deg, aa=int(aa), gamma=gamma, mlevel=mlevel, base=base,
+                            bg=np.zeros(0) if bg is None else bg.numpy(), wt=wt.cpu().numpy(),
+                            **{"in_" + k: v.numpy() for k, v in sc_cpu.items() if isinstance(v, torch.Tensor)},
+                            **{"sc_" + k: float(v) for k, v in sc_cpu.items() if not isinstance(v, torch.Tensor)},
+                            **{"fast_" + k: v.cpu().numpy() for k, v in g_f.items()},
+                            **{"plain_" + k: v.cpu().numpy() for k, v in g_p.items()})
     extra = ""
     if with_oracle:
         cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], blur_samples=S, rs_bands=R,
