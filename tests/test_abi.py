@@ -33,6 +33,13 @@ def test_workspace_queries_are_pure_host_calls(gs):
     a = lib.gs_radix_sort_workspace_bytes(150_000_000, 0, 16)
     b = lib.gs_radix_sort_workspace_bytes(150_000_000, 0, 17)
     assert 0 < a < b < 2 ** 31
+    # compacting depth pre-sort: wider digits need a larger histogram; both cover the scan space + the slack that holds
+    # the first pass's grand total
+    c8 = lib.gs_segmented_sort_compact_workspace_bytes(5_000_000, 1_000_000, 0, 31, 8)
+    c11 = lib.gs_segmented_sort_compact_workspace_bytes(5_000_000, 1_000_000, 0, 31, 11)
+    assert 0 < c8 < c11
+    assert c8 == lib.gs_segmented_sort_workspace_bytes(5_000_000, 1_000_000, 0, 31)
+    assert lib.gs_segmented_sort_compact_workspace_bytes(0, 1, 0, 31, 8) == 0
 
 
 def test_product_never_imports_oracle_or_reference():
