@@ -319,6 +319,9 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* _
   for (int d = threadIdx.x; d < NB; d += 256) ghist[((size_t)seg * NB + d) * sg.nblk_seg + b] = hist[d];
 }
 
+// (the batched payload loads below take the 8-bit u32 kernel from 126 to ~140 VGPRs, i.e. from four to three waves per
+//  SIMD; forcing it back to 128 with a launch bound spills 16 registers and was measured slower: tile sort 0.191 ms
+//  against 0.186 without the bound and 0.199 before the loads were batched)
 template <typename KeyT, int BITS>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT* __restrict__ keys_in,
                                                             const unsigned* __restrict__ vals_in,  // null => iota
@@ -430,15 +433,28 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
     }
   }
   __syncthreads();
-  // stage keys + payloads in LDS in sorted-by-digit order
+  // stage keys + payloads in LDS in sorted-by-digit order.  The payload loads are issued TOGETHER, unconditionally
+  // (clamped index), four at a time, before the LDS writes that use them: inside the per-key branch every load waited
+  // for its own round trip (s_waitcnt vmcnt(0) sixteen times per thread — most of a pass's ~25 us latency floor).
+  constexpr int RB = R >= 4 ? 4 : R;        // loads in flight per batch (more of them cost the kernel a wave per SIMD)
+  unsigned pv[RB];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    size_t i = wbase + (size_t)r * 64 + lane;
-    if (i < limit && !(compacting && key[r] == skip)) {
-      unsigned digit = (unsigned)(key[r] >> shift) & mask;
-      unsigned slot = cnt[wave][digit] + pos[r];
-      s_keys[slot] = key[r];
-      s_vals[slot] = vals_in ? vals_in[i] : (unsigned)i;
+  for (int r0 = 0; r0 < R; r0 += RB) {
+    if (vals_in) {
+      const size_t last = limit ? limit - 1 : 0;
+#pragma unroll
+      for (int q = 0; q < RB; ++q) pv[q] = vals_in[min(wbase + (size_t)(r0 + q) * 64 + lane, last)];
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      const int r = r0 + q;
+      size_t i = wbase + (size_t)r * 64 + lane;
+      if (i < limit && !(compacting && key[r] == skip)) {
+        unsigned digit = (unsigned)(key[r] >> shift) & mask;
+        unsigned slot = cnt[wave][digit] + pos[r];
+        s_keys[slot] = key[r];
+        s_vals[slot] = vals_in ? pv[q] : (unsigned)i;
+      }
     }
   }
   __syncthreads();
@@ -462,13 +478,21 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
     // the second payload takes the same trip through LDS (s_vals is free again once everyone has read it):
     // sequential traffic instead of a random gather by payload afterwards
     __syncthreads();
+    // (loaded here, a batch at a time: held since the top of the kernel they cost 16 VGPRs through the ranking loop
+    //  and a fourth of the occupancy)
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      size_t i = wbase + (size_t)r * 64 + lane;
-      if (i < limit && !(compacting && key[r] == skip)) {
-        unsigned digit = (unsigned)(key[r] >> shift) & mask;
-        s_vals[cnt[wave][digit] + pos[r]] = p2_in[i];       // (loaded here: held since the top it costs 16 VGPRs
-                                                            //  and a fourth of the occupancy)
+    for (int r0 = 0; r0 < R; r0 += RB) {
+      const size_t last = limit ? limit - 1 : 0;
+#pragma unroll
+      for (int q = 0; q < RB; ++q) pv[q] = p2_in[min(wbase + (size_t)(r0 + q) * 64 + lane, last)];
+#pragma unroll
+      for (int q = 0; q < RB; ++q) {
+        const int r = r0 + q;
+        size_t i = wbase + (size_t)r * 64 + lane;
+        if (i < limit && !(compacting && key[r] == skip)) {
+          unsigned digit = (unsigned)(key[r] >> shift) & mask;
+          s_vals[cnt[wave][digit] + pos[r]] = pv[q];
+        }
       }
     }
     __syncthreads();
