@@ -590,10 +590,15 @@ __global__ __launch_bounds__(256) void slice_colors_kernel(int n_slice, const un
   sh_basis(deg, dx * dinv, dy * dinv, dz * dinv, B);
   const int nb = (deg + 1) * (deg + 1);
   const float* c = sh + (size_t)g * K_stride * 3;
+  // all coefficient loads in flight together (clamped index, no branch): inside the `b < nb` branch every load waited
+  // for its own round trip — 3*nb serialized HBM latencies per thread (seen in the ISA: one s_waitcnt vmcnt(0) per load)
+  float coef[MAXB * 3];
+#pragma unroll
+  for (int k = 0; k < MAXB * 3; ++k) coef[k] = c[min(k, nb * 3 - 1)];
   float cr = 0.5f, cg = 0.5f, cb = 0.5f;
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
-    if (b < nb) { cr += B[b] * c[3 * b]; cg += B[b] * c[3 * b + 1]; cb += B[b] * c[3 * b + 2]; }
+    if (b < nb) { cr += B[b] * coef[3 * b]; cg += B[b] * coef[3 * b + 1]; cb += B[b] * coef[3 * b + 2]; }
   }
   float* r = records + (size_t)gi * kRecFloats;
   r[6] = fmaxf(cr, 0.f); r[7] = fmaxf(cg, 0.f); r[8] = fmaxf(cb, 0.f);
