@@ -93,16 +93,33 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
     override = os.environ.get("GSD_LIB_PATH")               # A/B builds of the same sources: used as they are
     path = Path(override) if override else LIB_PATH
     if not override and build_if_missing and shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
-        # the in-tree library is rebuilt whenever a source, a header or the build flags are newer than it (the mtime
-        # check is cheap), so an edited kernel never runs against a stale binary with the same export table.
-        # One process per GPU: on a fresh checkout every rank gets here at once — exactly one may run hipcc.
-        import fcntl
-        with open(str(path) + ".lock", "w") as lock:
-            fcntl.flock(lock, fcntl.LOCK_EX)
+        # the in-tree library is rebuilt when the sources on disk are not the ones it was built from (content hash),
+        # so an edited kernel never runs against a stale binary with the same export table.  The common case — the
+        # library is current — touches nothing: no lock file, no hipcc.  A prebuilt library WITHOUT the hash sidecar
+        # (an install made elsewhere) is used as it is unless a source is newer than it.
+        from ._build import is_current, HASH_PATH, CSRC
+        stale = not is_current()
+        if stale and path.exists() and not HASH_PATH.exists():
+            t = path.stat().st_mtime
+            stale = any(f.stat().st_mtime > t for f in list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")))
+        if stale:
+            # one process per GPU: on a fresh checkout every rank gets here at once — exactly one may run hipcc
+            import fcntl
             try:
-                build_library()
-            finally:
-                fcntl.flock(lock, fcntl.LOCK_UN)
+                lock = open(str(path) + ".lock", "w")
+            except OSError as e:
+                # read-only install: nothing can be rebuilt here; an existing library is loaded with a warning
+                if not path.exists():
+                    raise HipLibraryError(f"{path} is missing and {path.parent} is not writable: {e}") from e
+                import warnings
+                warnings.warn(f"{path} may be older than its sources and {path.parent} is not writable; loading it as is")
+            else:
+                with lock:
+                    fcntl.flock(lock, fcntl.LOCK_EX)
+                    try:
+                        build_library()          # re-checks the hash under the lock: only the first rank compiles
+                    finally:
+                        fcntl.flock(lock, fcntl.LOCK_UN)
     if not path.exists():
         raise HipLibraryError(f"{path} is missing; run __graft_entry__.build()")
     try:

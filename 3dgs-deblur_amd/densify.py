@@ -224,7 +224,8 @@ def step_callback(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.opti
                   step: int, cfg: DensifyConfig, group=None) -> Optional[Dict[str, int]]:
     """Call once per training step AFTER backward + optimizer step (what splatfacto registers as its
     AFTER_TRAIN_ITERATION callbacks): accumulates the statistics of the step's render and refines on schedule."""
-    if model.xy_grad is not None and model.radii is not None:
+    # upstream's after_train returns early once densification has stopped: no statistics are gathered any more
+    if step < cfg.stop_split_at and model.xy_grad is not None and model.radii is not None:
         state.after_backward(model.radii, model.xy_grad, *model.last_size)
     result = None
     if step > cfg.warmup_length and step % cfg.refine_every == 0:
@@ -233,4 +234,8 @@ def step_callback(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.opti
         reset_interval = cfg.refine_every * cfg.reset_alpha_every
         if step < cfg.stop_split_at and step % reset_interval == cfg.refine_every:
             reset_opacities(model, optimizers, cfg)
+        # N changed and / or every opacity dropped to ~0.02: the share of Gaussians with a gradient is about to jump
+        # (early termination stops), so the row-sparse gradient exchange must not size its payload from old counts
+        from . import dp
+        dp.notify_regime_change()
     return result

@@ -49,7 +49,7 @@ def unflatten_grads(flat: torch.Tensor, params: Sequence[torch.Tensor]) -> None:
 
 
 def allreduce_gradients(params: Iterable[torch.Tensor], group: Optional[dist.ProcessGroup] = None,
-                        mode: str = "allreduce", average: bool = False) -> None:
+                        mode: str = "allreduce", average: bool = False, sync_free: Optional[bool] = None) -> None:
     """Sum (or average) the gradients of `params` over all ranks with a single bucket.
 
     mode="allreduce": one dist.all_reduce (ring on RCCL, bound by one xGMI link).
@@ -58,10 +58,11 @@ def allreduce_gradients(params: Iterable[torch.Tensor], group: Optional[dist.Pro
                       (SURVEY.md §5 estimates ~6x less time than the ring at 2M Gaussians).
     mode="sparse":    early termination leaves all but a few percent of the Gaussians without any
                       gradient for a given view, so each rank all-gathers only its non-zero gradient
-                      ROWS (index + 59 floats, fixed-capacity payload, counts stay on the device — no host
-                      synchronisation inside the step, see SparseExchangeState) and every rank scatter-adds
-                      the union in rank order.  Falls back to the dense all-reduce (same decision on every
-                      rank, taken from the previous steps' counts) when the rows are not sparse.
+                      ROWS (index + 59 floats, fixed-capacity payload sized from the previous steps' counts,
+                      see SparseExchangeState) and every rank scatter-adds the union in rank order.  Falls
+                      back to the dense all-reduce (same decision on every rank) when the rows are not sparse
+                      or — guarded mode, the default — when a payload turned out too small for this step.
+                      sync_free=True (or GSD_DP_SYNC_FREE=1) skips the per-step look at the headers.
     """
     params = [p for p in params if p.requires_grad]
     if not params or not dist.is_available() or not dist.is_initialized():
@@ -70,7 +71,7 @@ def allreduce_gradients(params: Iterable[torch.Tensor], group: Optional[dist.Pro
     if world == 1:
         return
     if mode == "sparse":
-        if _allreduce_sparse_rows(params, group, world, average):
+        if _allreduce_sparse_rows(params, group, world, average, sync_free):
             return
         mode = "allreduce"
     flat = flatten_grads(params)
@@ -197,17 +198,23 @@ class _RowOps:
 
 
 class SparseExchangeState:
-    """Capacity bookkeeping of the sync-free row-sparse exchange.
+    """Capacity bookkeeping of the row-sparse exchange.
 
-    Nothing about the number of touched rows is read back inside the step: every rank packs at most `cap` rows
-    into a fixed-size payload whose header carries the true count, ONE all_gather_into_tensor moves the payloads, and
-    the scatter-add kernels read the counts from the device.  The headers of step t are copied to pinned host memory
-    asynchronously and looked at when step t+1 starts (that copy finished a whole step earlier, so waiting for it
-    does not drain the queue); every rank sees the same gathered headers, hence takes the same decisions:
-      * any count above the capacity that was used  -> the step's gradients were truncated: RuntimeError (strict),
+    Every rank packs at most `cap` rows into a fixed-size payload whose header carries the true count, ONE
+    all_gather_into_tensor moves the payloads, and the scatter-add kernels read the counts from the device.  Every
+    rank sees the same gathered headers, hence takes the same decisions:
       * the capacity for the next steps = 2 x the largest count seen recently, rounded up to a power of two,
-      * counts so large that a dense all-reduce moves fewer bytes -> `dense` until the counts fall again.
-    The first step (no history) uses the largest sparse capacity, N * dense_fraction / world."""
+      * counts so large that a dense all-reduce moves fewer bytes -> `dense` until the counts fall again,
+      * a count above the capacity that was used means a truncated payload.
+    Two ways of looking at the headers:
+      * guarded (default): the `world` header words are read back right after the all-gather, BEFORE any gradient is
+        modified; on overflow the caller runs the dense bucket in the same step (never a truncated update) and the
+        capacity follows the new counts.  One small device->host copy per step.
+      * sync_free: the headers travel to pinned memory asynchronously and are digested when the NEXT step starts; an
+        overflow can then only be reported one step late (RuntimeError) — for runs whose row density is known not to
+        jump; `notify_regime_change()` (called by the densifier after an opacity reset / refinement) makes the next
+        exchange take the synchronous first look again.
+    The first exchange (no history) looks at the counts synchronously and sizes its payload from them."""
 
     def __init__(self, N: int, world: int, cap_min: int = 1024, dense_fraction: float = 0.25):
         self.N, self.world = N, world
@@ -217,6 +224,27 @@ class SparseExchangeState:
         self.dense = False
         self.pending = None          # (host tensor, event or None, capacity used)
         self.history = []
+        self.overflows = 0           # exchanges that fell back to the dense bucket because a payload was too small
+
+    def observe(self, totals) -> None:
+        """Fold the per-rank row counts of one exchange into the capacity / dense decision of the next ones."""
+        self.history = (self.history + [max(int(v) for v in totals)])[-8:]
+        want = 2 * max(self.history)
+        if want > self.cap_max:
+            self.dense = True
+        else:
+            self.dense = False
+            cap = self.cap_min
+            while cap < want:
+                cap *= 2
+            self.cap = min(cap, self.cap_max)
+
+    def forget(self) -> None:
+        """Drop the count history (regime change): the next exchange looks at the counts synchronously first."""
+        self.pending = None
+        self.history = []
+        self.dense = False
+        self.cap = self.cap_max
 
     def settle(self) -> None:
         """Digest the counts of the previous exchange (blocks only if that exchange has not finished yet)."""
@@ -228,28 +256,24 @@ class SparseExchangeState:
             ev.synchronize()
         totals = [int(v) for v in host.tolist()]
         if cap_used is not None and max(totals) > cap_used:
+            self.forget()
             raise RuntimeError(f"row-sparse gradient exchange overflowed: a rank had {max(totals)} rows with a gradient, "
                                f"capacity was {cap_used}; the previous step's gradients are incomplete "
-                               f"(raise cap_min / dense_fraction or use mode='allreduce')")
-        self.history = (self.history + [max(totals)])[-8:]
-        want = 2 * max(self.history)
-        if want > self.cap_max:
-            self.dense = True
-        else:
-            self.dense = False
-            cap = self.cap_min
-            while cap < want:
-                cap *= 2
-            self.cap = min(cap, self.cap_max)
+                               f"(use the guarded exchange, raise cap_min / dense_fraction or mode='allreduce')")
+        self.observe(totals)
 
 
+# one state per (world, group); it is re-created whenever N changes (every refinement does that), so no stale
+# history / capacity / pending header of an earlier N is ever reused and nothing accumulates over a long run
 _SPARSE_STATES = {}
+# sync-free header handling (see SparseExchangeState); default: guarded
+SYNC_FREE = bool(int(__import__("os").environ.get("GSD_DP_SYNC_FREE", "0")))
 
 
 def _sparse_state(N: int, world: int, group) -> SparseExchangeState:
-    key = (N, world, id(group))
+    key = (world, id(group))
     st = _SPARSE_STATES.get(key)
-    if st is None:
+    if st is None or st.N != N:
         st = _SPARSE_STATES[key] = SparseExchangeState(N, world)
     return st
 
@@ -258,12 +282,22 @@ def reset_sparse_exchange_state() -> None:
     _SPARSE_STATES.clear()
 
 
-def _allreduce_sparse_rows(params: Sequence[torch.Tensor], group, world: int, average: bool) -> bool:
-    """Row-sparse gradient exchange, no host synchronisation inside the step.  All params must share the leading
-    (per-Gaussian) dimension.  Returns False (nothing changed) when the caller should use the dense path."""
+def notify_regime_change() -> None:
+    """The row density is about to jump (opacity reset, refinement): forget the count history of every exchange
+    state so that the next exchange sizes its payload from a synchronous look at the counts."""
+    for st in _SPARSE_STATES.values():
+        st.forget()
+
+
+def _allreduce_sparse_rows(params: Sequence[torch.Tensor], group, world: int, average: bool,
+                           sync_free: Optional[bool] = None) -> bool:
+    """Row-sparse gradient exchange.  All params must share the leading (per-Gaussian) dimension.  Returns False
+    (gradients untouched) when the caller should use the dense path — rows not sparse, or (guarded mode) a payload
+    that turned out too small for this step's rows."""
     N = params[0].shape[0]
     if N == 0 or any(p.shape[0] != N for p in params):
         return False
+    sync_free = SYNC_FREE if sync_free is None else bool(sync_free)
     st = _sparse_state(N, world, group)
     st.settle()
     for p in params:            # a rank without a gradient for some tensor contributes zeros
@@ -274,13 +308,12 @@ def _allreduce_sparse_rows(params: Sequence[torch.Tensor], group, world: int, av
     ops = _RowOps([p.grad for p in params])
     stride = ops.wtot + 1
     if not st.history:
-        # very first exchange for this (N, world): no counts to size the payload from — ONE synchronous look at
-        # them (every later step is sync-free)
+        # first exchange for this (N, world) or after a regime change: no counts to size the payload from — ONE
+        # synchronous look at them
         total = ops.row_mask().sum(dtype=torch.int32).reshape(1)
         totals = torch.empty(world, dtype=torch.int32, device=ops.dev)
         dist.all_gather_into_tensor(totals, total, group=group)
-        st.pending = (totals.cpu(), None, None)
-        st.settle()
+        st.observe(totals.cpu().tolist())
     if st.dense:
         # too many rows for the sparse form to pay: the caller runs the dense all-reduce; keep watching the counts
         # (one tiny all_gather) so that the exchange can return to the sparse form
@@ -294,7 +327,17 @@ def _allreduce_sparse_rows(params: Sequence[torch.Tensor], group, world: int, av
     pay_all = torch.empty(world * (cap + 1) * stride, dtype=torch.float32, device=ops.dev)
     dist.all_gather_into_tensor(pay_all, pay.reshape(-1), group=group)
     pay_all = pay_all.view(world, cap + 1, stride)
-    st.pending = _async_to_host(pay_all[:, 0, 0].contiguous().view(torch.int32)) + (cap,)
+    headers = pay_all[:, 0, 0].contiguous().view(torch.int32)
+    if sync_free:
+        st.pending = _async_to_host(headers) + (cap,)
+    else:
+        # guarded: the gradients have not been modified yet — a payload that was too small costs this step the
+        # dense bucket (same decision on every rank: they all hold the same headers), never a truncated update
+        totals = headers.cpu().tolist()
+        st.observe(totals)
+        if max(totals) > cap:
+            st.overflows += 1
+            return False
     # Replicas must stay BIT-identical, so the sum has one fixed order on every rank: start from zero, add
     # rank 0's rows, then rank 1's, ...  A rank's row indices are unique, so no add collides (a single
     # scatter-add over the concatenation would add in atomic, i.e. arbitrary, order).

@@ -259,7 +259,9 @@ class SplatfactoDeblurModel(nn.Module):
             # forward-only channel of the compositor): mean over the samples of sum(weight * depth), over alpha
             d = depth_acc.mean(dim=0)[..., None].detach()
             a = accumulation.detach()
-            far = d.max() / torch.clamp(a.max(), min=1e-10)
+            # zero-alpha pixels: splatfacto 1.1.0 fills with depth_im.detach().max(), the UN-normalised accumulated
+            # maximum (what render_model.py:219's colour maps are normalised against)
+            far = d.max()
             out["depth"] = torch.where(a > 0, d / torch.clamp(a, min=1e-10), far)
         else:
             out["depth"] = None

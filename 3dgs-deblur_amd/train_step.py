@@ -150,6 +150,11 @@ def train_scene(model: SplatfactoDeblurModel, scene, images, iterations: int, lr
         from . import densify as D
         model.collect_densify_stats = True
         state = D.DensifyState(model.num_points, model.means.device)
+        if densify.num_train_data <= 0:
+            # upstream's post-reset guard counts in passes over the training images (nerfstudio sets num_train_data
+            # from the datamanager); the in-tree trainer knows the number right here
+            import dataclasses
+            densify = dataclasses.replace(densify, num_train_data=len(scene.train_indices))
     ev_pos = 0
     for it in range(1, iterations + 1):
         if not order:

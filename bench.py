@@ -172,6 +172,25 @@ def guarded_cpu_baseline(limit_s: int = 150):
         signal.signal(signal.SIGALRM, old)
 
 
+def launcher_argv(gpus: int, argv, environ, port=None):
+    """`python bench.py --gpus N` without a launcher becomes the launcher: -> the torch.distributed.run command line
+    (one rank per GPU over RCCL, rendezvous on 127.0.0.1), or None when this process already is a rank / N == 1."""
+    if gpus <= 1 or "WORLD_SIZE" in environ:
+        return None
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+
+
+def check_world(gpus: int, world: int) -> None:
+    if world != gpus:
+        raise SystemExit(f"bench.py --gpus {gpus} launched with WORLD_SIZE={world}: they must agree")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,23 +210,16 @@ def main():
                     help="scene profile of the timed workload (BASELINE metric: survey)")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU over RCCL)
-        import socket
+    cmd = launcher_argv(args.gpus, sys.argv[1:], os.environ)
+    if cmd is not None:
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
-    if world != args.gpus:
-        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: they must agree")
+    check_world(args.gpus, world)
     if torch.cuda.device_count() < (local_rank + 1):
         raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
     if world > 1:

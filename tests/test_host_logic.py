@@ -87,7 +87,7 @@ def _dp_worker(rank, world, port, mode, q):
     dist.destroy_process_group()
 
 
-def _dp_sparse_worker(rank, world, port, q):
+def _dp_sparse_worker(rank, world, port, q, sync_free=False, schedule=None):
     sys.path.insert(0, str(ROOT))
     import gsdeblur_amd as gs
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -99,8 +99,9 @@ def _dp_sparse_worker(rank, world, port, q):
     log = []
     # a training run whose density drifts: sparse steps shrink the payload capacity, a denser phase flips the
     # exchange to the dense bucket and back — every step's sum must be exact whatever form carried it
-    for step, density in enumerate((0.01, 0.012, 0.02, 0.03, 0.05, 0.09, 0.5, 0.6, 0.02, 0.01, 0.01, 0.01, 0.01,
-                                    0.01, 0.01, 0.01, 0.01, 0.01)):
+    schedule = schedule or (0.01, 0.012, 0.02, 0.03, 0.05, 0.09, 0.5, 0.6, 0.02, 0.01, 0.01, 0.01, 0.01,
+                            0.01, 0.01, 0.01, 0.01, 0.01)
+    for step, density in enumerate(schedule):
         gens = [torch.Generator().manual_seed(100 + 17 * step + r) for r in range(world)]
         all_grads = []
         for r in range(world):
@@ -112,9 +113,9 @@ def _dp_sparse_worker(rank, world, port, q):
         all_grads[1][4] = torch.zeros(shapes[4])                            # rank 1 has no grad for param 4
         if rank == 1:
             params[4].grad = None                                           # a missing grad counts as zero
-        gs.dp.allreduce_gradients(params, mode="sparse")
+        gs.dp.allreduce_gradients(params, mode="sparse", sync_free=sync_free)
         st = gs.dp._sparse_state(N, world, None)
-        log.append((st.dense, st.cap))
+        log.append((st.dense, st.cap, st.overflows))
         for i, p in enumerate(params):
             want = sum(all_grads[r][i] for r in range(world))
             ok &= bool(torch.allclose(p.grad, want, atol=1e-6))
@@ -123,14 +124,11 @@ def _dp_sparse_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sparse_gradient_exchange_world2_gloo():
-    """row-sparse fixed-capacity exchange == dense sum on every step of a run whose row density drifts up and down;
-    the capacity follows the counts of the PREVIOUS steps (no host sync inside a step) and both ranks take the same
-    sparse / dense decisions"""
+def _run_sparse_world2(port_base, **kw):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_dp_sparse_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = port_base + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_sparse_worker, args=(r, 2, port, q), kwargs=kw) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=180) for _ in procs)
@@ -138,9 +136,27 @@ def test_sparse_gradient_exchange_world2_gloo():
         p.join(timeout=60)
     assert [(r[0], r[1]) for r in res] == [(0, True), (1, True)]
     assert res[0][2] == res[1][2]                                           # identical decisions on both ranks
-    log = res[0][2]
-    assert any(d for d, _ in log) and not log[0][0] and not log[-1][0]     # went dense in the dense phase, came back
-    assert min(c for d, c in log if not d) < max(c for _, c in log)        # the capacity adapted
+    return res[0][2]
+
+
+@pytest.mark.parametrize("sync_free", [False, True])
+def test_sparse_gradient_exchange_world2_gloo(sync_free):
+    """row-sparse fixed-capacity exchange == dense sum on every step of a run whose row density drifts up and down;
+    the capacity follows the counts of the previous steps and both ranks take the same sparse / dense decisions —
+    guarded (headers read back inside the step) and sync-free (headers digested one step later)"""
+    log = _run_sparse_world2(31500 + 2500 * int(sync_free), sync_free=sync_free)
+    assert any(d for d, _, _ in log) and not log[0][0] and not log[-1][0]  # went dense in the dense phase, came back
+    assert min(c for d, c, _ in log if not d) < max(c for _, c, _ in log)  # the capacity adapted
+
+
+def test_sparse_exchange_survives_a_sudden_density_jump_world2_gloo():
+    """an opacity reset makes nearly every visible Gaussian receive a gradient from one step to the
+    next — far beyond 2x the recent counts, with a history that still says 'sparse'.  The guarded exchange notices
+    the too-small payload BEFORE touching the gradients and runs that step through the dense bucket: the sum is
+    exact on every step and nothing raises."""
+    log = _run_sparse_world2(36500, schedule=(0.01,) * 10 + (0.2, 0.2, 0.01, 0.01))
+    assert log[9][2] == 0 and log[10][2] == 1                               # exactly the jump step overflowed ...
+    assert not log[9][0]                                                    # ... out of a sparse regime
 
 
 def test_sparse_exchange_overflow_is_reported_loudly(gs):
@@ -152,9 +168,46 @@ def test_sparse_exchange_overflow_is_reported_loudly(gs):
     st.pending = (torch.tensor([3000, 10], dtype=torch.int32), None, st.cap)
     with pytest.raises(RuntimeError, match="overflowed"):
         st.settle()
+    assert not st.history                                                    # the stale history is gone with it
     st.pending = (torch.tensor([9000, 10], dtype=torch.int32), None, None)
     st.settle()
     assert st.dense                                                          # 2 * 9000 > N / (4 * world) = 12500
+
+
+def test_sparse_exchange_state_is_per_group_and_follows_N(gs):
+    """one state per (world, group); a refinement changes N and must start from a clean state
+    (no stale capacity / history / pending header), and a regime change (opacity reset) drops the history"""
+    gs.dp.reset_sparse_exchange_state()
+    a = gs.dp._sparse_state(1000, 2, None)
+    a.observe([10, 20])
+    assert gs.dp._sparse_state(1000, 2, None) is a
+    b = gs.dp._sparse_state(1200, 2, None)                                   # N changed: a fresh state replaces it
+    assert b is not a and not b.history and len(gs.dp._SPARSE_STATES) == 1
+    assert gs.dp._sparse_state(1000, 2, None) is not a                       # returning to an old N does not resurrect it
+    b = gs.dp._sparse_state(1200, 2, None)
+    b.observe([5, 5])
+    gs.dp.notify_regime_change()
+    assert not b.history and b.pending is None and b.cap == b.cap_max
+    gs.dp.reset_sparse_exchange_state()
+
+
+def test_bench_launcher_argv_and_world_check():
+    """`python bench.py --gpus N` without a launcher re-executes itself under
+    torch.distributed.run with one rank per GPU on 127.0.0.1; a rank whose WORLD_SIZE disagrees with --gpus exits"""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    assert bench.launcher_argv(1, ["--steps", "3"], {}) is None
+    assert bench.launcher_argv(4, [], {"WORLD_SIZE": "4"}) is None            # already a rank
+    cmd = bench.launcher_argv(4, ["--gpus", "4", "--steps", "3"], {}, port=29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5] == str(ROOT / "bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    port = int(bench.launcher_argv(2, [], {})[8])                             # a free port is picked when none is given
+    assert 1024 < port < 65536
+    bench.check_world(4, 4)
+    with pytest.raises(SystemExit, match="must agree"):
+        bench.check_world(4, 2)
 
 
 def _dp_small_worker(rank, world, port, q):
