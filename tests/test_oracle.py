@@ -277,3 +277,66 @@ def test_pixel_velocity_render_static_limit_and_autograd(oracle):
                 fm = (O.render(cfg_pv, *base, *lm)[0] * wt).sum()
             fd = ((fp - fm) / 2e-6).item()
             assert abs(fd - x.grad[j].item()) < 1e-4 * (abs(fd) + 1e-3), (name, j, fd, x.grad[j].item())
+
+
+def _pixel_loop():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pixel_loop_oracle",
+                                                  Path(__file__).resolve().parents[1] / "oracle" / "pixel_loop_oracle.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("seed,n,H,W,hot", [(3, 100, 40, 56, False), (11, 90, 33, 47, True)])
+def test_vectorised_oracle_equals_independent_pixel_loop(oracle, seed, n, H, W, hot):
+    """VERDICT round 2 'Missing 6': `rasterize_sorted` (vectorised per tile, autograd backward) against a literal
+    per-pixel / per-Gaussian loop with a real `break` and a hand-derived reverse loop, written from SURVEY App. A
+    alone (oracle/pixel_loop_oracle.py shares no code with gs_oracle.py).  Binning: sorted ids and bin edges against
+    a brute-force "members of every tile, ordered by (depth bits, id)"; compositing: image, final T and final index;
+    gradients of a random loss (image + alpha) with respect to xy, conic, colour and opacity.  Ragged image sizes,
+    opacities above the 0.999 clamp in the second case (both clamp-gradient conventions)."""
+    O, PL = oracle, _pixel_loop()
+    sc = O.synthetic_scene(n, W, H, seed=seed, dtype=torch.float64, scale_mult=20.0)
+    sc["opacity_logits"] = sc["opacity_logits"] + 1.5
+    if hot:
+        sc["opacity_logits"] = sc["opacity_logits"] + 6.0              # many opacities > 0.999: the clamp is active
+    pr = O.project_gaussians(sc["means"], sc["log_scales"].exp(), 1.0, sc["quats"], sc["viewmat"], sc["fx"], sc["fy"],
+                             sc["cx"], sc["cy"], H, W)
+    g = torch.Generator().manual_seed(seed)
+    colors = torch.rand(n, 3, generator=g, dtype=torch.float64)
+    opac = torch.sigmoid(sc["opacity_logits"])
+    bg = torch.tensor([0.3, 0.1, 0.6], dtype=torch.float64)
+    # --- binning
+    keys, gids = O.sort_intersects(*O.map_gaussian_to_intersects(pr, W))
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    bins = O.get_tile_bin_edges(keys, T)
+    ids_bf, bins_bf = PL.tile_lists_by_brute_force(pr.tile_min.numpy(), pr.tile_max.numpy(), pr.depths.numpy(),
+                                                   (pr.num_tiles_hit > 0).numpy(), H, W)
+    assert np.array_equal(ids_bf, gids) and np.array_equal(bins_bf, bins)
+    assert len(gids) > 4 * T                                            # lists are long enough to mean something
+    # --- forward
+    leaves = [t.clone().requires_grad_(True) for t in (pr.xys.detach(), pr.conics.detach(), colors, opac)]
+    r = O.rasterize_sorted(leaves[0], leaves[1], leaves[2], leaves[3], gids, bins, H, W, bg)
+    xys, conics = pr.xys.detach().numpy(), pr.conics.detach().numpy()
+    f = PL.composite_pixel_loop(xys, conics, colors.numpy(), opac.numpy(), gids, bins, H, W, bg.tolist())
+    assert np.array_equal(f["final_idx"], r.final_idx.numpy())
+    assert np.abs(f["img"] - r.img.detach().numpy()).max() < 1e-13
+    assert np.abs(f["final_T"] - r.final_T.detach().numpy()).max() < 1e-13
+    assert f["stops"] > (0.02 if hot else 0.0) * H * W                  # the early stop is exercised
+    # --- backward: random loss on image and alpha
+    v_img = torch.rand(H, W, 3, generator=g, dtype=torch.float64) - 0.3
+    v_alpha = torch.rand(H, W, generator=g, dtype=torch.float64) - 0.5
+    ((r.img * v_img).sum() + (r.alpha * v_alpha).sum()).backward()
+    b = PL.composite_backward_pixel_loop(xys, conics, colors.numpy(), opac.numpy(), gids, bins, H, W, f, v_img.numpy(),
+                                         v_alpha.numpy(), bg.tolist(), clamp_blocks_gradient=True)
+    for name, leaf in zip(("v_xy", "v_conic", "v_colors", "v_opacity"), leaves):
+        want = leaf.grad.numpy().reshape(b[name].shape)
+        assert np.abs(b[name] - want).max() <= 1e-11 * max(1.0, np.abs(want).max()), name
+    if hot:
+        # upstream's convention lets the gradient through the clamp: it must differ exactly on the clamped Gaussians
+        bu = PL.composite_backward_pixel_loop(xys, conics, colors.numpy(), opac.numpy(), gids, bins, H, W, f,
+                                              v_img.numpy(), v_alpha.numpy(), bg.tolist(), clamp_blocks_gradient=False)
+        changed = np.abs(bu["v_opacity"] - b["v_opacity"]) > 0
+        assert changed.any() and not changed[opac.numpy() <= 0.999].any()
+        assert np.array_equal(bu["v_colors"], b["v_colors"])
