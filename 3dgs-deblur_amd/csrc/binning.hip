@@ -1081,14 +1081,44 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
     const int w = x1 - x0;
     const unsigned pidx = gi / (unsigned)N;
     unsigned long long m = 0ull;
-    for (int y = y0; y < y1; ++y) {
-      int t0, t1;
-      span_tiles(el, row_span(el, y, H), x0, x1, t0, t1);
-      if (t1 <= t0) continue;
-      unsigned long long rowbits = (t1 - t0 >= 64 ? ~0ull : ((1ull << (t1 - t0)) - 1ull)) << (t0 - x0);   // w <= 64
-      if (open_bits) rowbits &= row_window(open_bits + ((size_t)pidx * tiles_y + y) * W64, x0, w);
-      cnt += (unsigned)__popcll(rowbits);
-      m |= rowbits << ((y - y0) * w);
+    if (open_bits) {
+      // four tile rows per step, their open-tile words fetched TOGETHER and before any of them is used: one lane per
+      // Gaussian walks ~8 rows, and a load per row inside the loop was one full memory round trip per row — the kernel
+      // sat on ~15 serialized latencies per wave (0.2 - 0.6 ms per slice of the fitted-model-like scene)
+      const int wi = x0 >> 6, sh = x0 & 63, wi1 = min(wi + 1, W64 - 1);
+      const unsigned long long wmask = w == 64 ? ~0ull : ((1ull << w) - 1ull);
+      const unsigned long long* base = open_bits + (size_t)pidx * tiles_y * W64;
+      for (int yb = y0; yb < y1; yb += 4) {
+        unsigned long long a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned long long* row = base + (size_t)min(yb + k, y1 - 1) * W64;
+          a[k] = row[wi]; b[k] = row[wi1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int y = yb + k;
+          if (y >= y1) break;
+          int t0, t1;
+          span_tiles(el, row_span(el, y, H), x0, x1, t0, t1);
+          if (t1 <= t0) continue;
+          unsigned long long rowbits = (t1 - t0 >= 64 ? ~0ull : ((1ull << (t1 - t0)) - 1ull)) << (t0 - x0);   // w <= 64
+          unsigned long long win = a[k] >> sh;                     // row_window(row, x0, w) on the prefetched words
+          if (sh && sh + w > 64) win |= b[k] << (64 - sh);
+          rowbits &= win & wmask;
+          cnt += (unsigned)__popcll(rowbits);
+          m |= rowbits << ((y - y0) * w);
+        }
+      }
+    } else {
+      for (int y = y0; y < y1; ++y) {
+        int t0, t1;
+        span_tiles(el, row_span(el, y, H), x0, x1, t0, t1);
+        if (t1 <= t0) continue;
+        unsigned long long rowbits = (t1 - t0 >= 64 ? ~0ull : ((1ull << (t1 - t0)) - 1ull)) << (t0 - x0);   // w <= 64
+        cnt += (unsigned)__popcll(rowbits);
+        m |= rowbits << ((y - y0) * w);
+      }
     }
     if (masks) masks[moff] = m;                 // area <= 64: one word
   }

@@ -568,6 +568,14 @@ __global__ __launch_bounds__(256) void project_fused_bwd_sparse_kernel(FusedPara
 // the fused projection can skip the 192-byte SH read and the per-sub-pose evaluation for everyone and this
 // kernel colours just the Gaussians a depth slice emits (counts[j] > 0).  Same arithmetic as the fused
 // kernel (basis, +0.5, clamp >= 0).
+// One thread per slice Gaussian does the arithmetic (same order, term for term, as the fused kernel: the colours are
+// bit-identical), but the coefficient rows reach it through wave-private LDS: a lane that fetches its own row touches
+// 192 contiguous bytes at a random place, so each of its 48 loads costs the texture path 64 different cache lines
+// (this kernel was 0.56 ms per frame on the fitted-model-like scene, 1.2 TB/s).  Here 16 lanes fetch one row together
+// (12 bytes each, four rows per load instruction), park it in LDS with an odd row stride, and every lane then reads its
+// own row conflict-free.
+template <int MAXB> constexpr int slice_colors_waves() { return MAXB <= 16 ? 4 : 2; }     // 64 KB of static LDS at most
+
 template <int MAXB>
 __global__ __launch_bounds__(256) void slice_colors_kernel(int n_slice, const unsigned* __restrict__ slice_gi,
                                                            const unsigned* __restrict__ counts, int N,
@@ -575,10 +583,34 @@ __global__ __launch_bounds__(256) void slice_colors_kernel(int n_slice, const un
                                                            const float* __restrict__ sh, int K_stride, int deg,
                                                            const float* __restrict__ viewmats,
                                                            float* __restrict__ records) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_slice || counts[j] == 0) return;
-  const unsigned gi = slice_gi[j];
+  constexpr int kRow = MAXB * 3 + 1;                       // odd stride (49 / 76 -> 77): lane l reads bank (l*kRow + k) % 32
+  constexpr int kRowPad = (kRow & 1) ? kRow : kRow + 1;
+  __shared__ float s_coef[slice_colors_waves<MAXB>()][64 * kRowPad];
+  const int lane = threadIdx.x & 63;
+  float* rows = s_coef[threadIdx.x >> 6];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = j < n_slice && counts[j] != 0;
+  const unsigned gi = active ? slice_gi[j] : 0u;
   const unsigned p = gi / (unsigned)N, g = gi - p * (unsigned)N;
+  const int nb = (deg + 1) * (deg + 1);
+  // cooperative fetch: sub-lane q of a 16-lane group takes basis q (and q + 16 for degree 4) of the group's row
+  const int grp = lane >> 4, q = lane & 15;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int r = it * 4 + grp;                            // row (= lane of the wave that owns the Gaussian)
+    const unsigned g_r = (unsigned)__shfl((int)g, r);
+    const int act_r = __shfl((int)active, r);
+    if (act_r) {
+      const float* c = sh + (size_t)g_r * K_stride * 3;
+      for (int b = q; b < nb; b += 16) {
+        const float c0 = c[3 * b], c1 = c[3 * b + 1], c2 = c[3 * b + 2];
+        float* d = rows + r * kRowPad + 3 * b;
+        d[0] = c0; d[1] = c1; d[2] = c2;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (!active) return;
   const float* V = viewmats + 16 * p;
   const float m0 = means[3 * g], m1 = means[3 * g + 1], m2 = means[3 * g + 2];
   float cxw = -(V[0] * V[3] + V[4] * V[7] + V[8] * V[11]);
@@ -588,13 +620,7 @@ __global__ __launch_bounds__(256) void slice_colors_kernel(int n_slice, const un
   float dinv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
   float B[MAXB];
   sh_basis(deg, dx * dinv, dy * dinv, dz * dinv, B);
-  const int nb = (deg + 1) * (deg + 1);
-  const float* c = sh + (size_t)g * K_stride * 3;
-  // all coefficient loads in flight together (clamped index, no branch): inside the `b < nb` branch every load waited
-  // for its own round trip — 3*nb serialized HBM latencies per thread (seen in the ISA: one s_waitcnt vmcnt(0) per load)
-  float coef[MAXB * 3];
-#pragma unroll
-  for (int k = 0; k < MAXB * 3; ++k) coef[k] = c[min(k, nb * 3 - 1)];
+  const float* coef = rows + lane * kRowPad;
   float cr = 0.5f, cg = 0.5f, cb = 0.5f;
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
@@ -742,13 +768,15 @@ GS_EXPORT int gs_slice_colors(int n_slice, const unsigned* slice_gi, const unsig
                               const float* viewmats, float* records, void* stream) {
   if (n_slice <= 0 || N <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride)
     return GS_ERR_INVALID;
-  dim3 grid((n_slice + 255) / 256), block(256);
-  if (sh_degree <= 3)
-    hipLaunchKernelGGL(slice_colors_kernel<16>, grid, block, 0, (hipStream_t)stream, n_slice, slice_gi, counts, N,
-                       means, sh, K_stride, sh_degree, viewmats, records);
-  else
-    hipLaunchKernelGGL(slice_colors_kernel<25>, grid, block, 0, (hipStream_t)stream, n_slice, slice_gi, counts, N,
-                       means, sh, K_stride, sh_degree, viewmats, records);
+  if (sh_degree <= 3) {
+    const int th = 64 * slice_colors_waves<16>();
+    hipLaunchKernelGGL(slice_colors_kernel<16>, dim3((n_slice + th - 1) / th), dim3(th), 0, (hipStream_t)stream,
+                       n_slice, slice_gi, counts, N, means, sh, K_stride, sh_degree, viewmats, records);
+  } else {
+    const int th = 64 * slice_colors_waves<25>();
+    hipLaunchKernelGGL(slice_colors_kernel<25>, dim3((n_slice + th - 1) / th), dim3(th), 0, (hipStream_t)stream,
+                       n_slice, slice_gi, counts, N, means, sh, K_stride, sh_degree, viewmats, records);
+  }
   return gs_launch_status();
 }
 

@@ -31,11 +31,14 @@ struct SliceState {
   int* open_flag;             // nullable (zeroed by the caller): set to 1 when this launch leaves any tile open
 };
 
-template <bool SKIP_EMPTY>
+// STATS (debug, gs_rasterize_fwd_slice_stats): lane-utilisation counters of the walk, see kLaneStat* below
+constexpr int kLaneStats = 13;
+template <bool SKIP_EMPTY, bool STATS = false>
 __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm, SliceState st,
                                                                float* __restrict__ out_img,
                                                                float* __restrict__ out_T,
-                                                               int* __restrict__ final_idx, unsigned n_blocks) {
+                                                               int* __restrict__ final_idx, unsigned n_blocks,
+                                                               unsigned long long* __restrict__ stats = nullptr) {
   const int lane = lane_id();
   const int T = prm.tiles_x * prm.tiles_y;
   // wave-uniform tile index in an SGPR: the tile header loads become scalar loads and both loops
@@ -85,9 +88,22 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
   gi_next = to_gi(load_id(range.x + 64 + lane), range.x + 64 + lane);
   int id_next = load_id(range.x + 128 + lane);
   const float kL2E = -1.4426950408889634f;
+  // STATS: [0] entries walked, [1] live pixel hits, [2] geometric pixel hits (alpha >= 1/255, live or not),
+  // [3]/[4] 4x4 blocks / 8x8 quadrants with a geometric hit, [5]/[6] steps a 64-entry chunk would take if every 4x4
+  // block / 8x8 quadrant walked only its own entries in lock-step (max over the blocks of their entry counts),
+  // [7] chunks, [8] entries with a live hit, [9]/[10] blocks / quadrants with a live hit, [11]/[12] as [5]/[6] for
+  // live hits
+  unsigned long long sc[kLaneStats] = {0};
+  unsigned c4g[16], c8g[4], c4l[16], c8l[4];
 
   for (int batch = range.x; batch < range.y; batch += 64) {
     if (__ballot(fmaxf(fmaxf(Tk[0], Tk[1]), fmaxf(Tk[2], Tk[3])) > 0.f) == 0ull) break;
+    if (STATS) {
+#pragma unroll
+      for (int b = 0; b < 16; ++b) { c4g[b] = 0; c4l[b] = 0; }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { c8g[b] = 0; c8l[b] = 0; }
+    }
     Rec9 rec = rec_next;
     rec_next = load_rec(prm.records, gi_next, (batch + 64 + lane) < range.y);
     gi_next = to_gi(id_next, batch + 128 + lane);
@@ -111,6 +127,33 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
         alpha[k] = fminf(K::kAlphaMax, op * __builtin_amdgcn_exp2f(s2));
         valid[k] = (s2 <= 0.f) && (alpha[k] >= K::kAlphaMin);
       }
+      if (STATS) {
+        const bool l0 = valid[0] && Tk[0] > 0.f, l1 = valid[1] && Tk[1] > 0.f, l2 = valid[2] && Tk[2] > 0.f,
+                   l3 = valid[3] && Tk[3] > 0.f;
+        unsigned long long mg = __ballot(valid[0] || valid[1] || valid[2] || valid[3]), ml = __ballot(l0 || l1 || l2 || l3);
+        sc[0] += 1;
+        sc[1] += (unsigned)(__popcll(__ballot(l0)) + __popcll(__ballot(l1)) + __popcll(__ballot(l2)) + __popcll(__ballot(l3)));
+        sc[2] += (unsigned)(__popcll(__ballot(valid[0])) + __popcll(__ballot(valid[1])) + __popcll(__ballot(valid[2])) +
+                            __popcll(__ballot(valid[3])));
+        sc[8] += ml != 0ull;
+        // lanes 4b .. 4b+3 are the 4x4 pixel block b = (lane >> 4) * 4 + ((lane & 15) >> 2): fold every nibble to bit 0
+        mg |= mg >> 1; mg |= mg >> 2; mg &= 0x1111111111111111ull;
+        ml |= ml >> 1; ml |= ml >> 2; ml &= 0x1111111111111111ull;
+        sc[3] += (unsigned)__popcll(mg);
+        sc[9] += (unsigned)__popcll(ml);
+#pragma unroll
+        for (int b = 0; b < 16; ++b) { c4g[b] += (unsigned)((mg >> (4 * b)) & 1ull); c4l[b] += (unsigned)((ml >> (4 * b)) & 1ull); }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          // quadrant (qx, qy) = blocks (2qx, 2qy) .. (2qx+1, 2qy+1), block index by*4 + bx
+          const int b00 = (qd >> 1) * 8 + (qd & 1) * 2;
+          const unsigned long long sel = (1ull << (4 * b00)) | (1ull << (4 * (b00 + 1))) | (1ull << (4 * (b00 + 4))) |
+                                         (1ull << (4 * (b00 + 5)));
+          const unsigned hg = (mg & sel) != 0ull, hl = (ml & sel) != 0ull;
+          c8g[qd] += hg; c8l[qd] += hl;
+          sc[4] += hg; sc[10] += hl;
+        }
+      }
       // the tile list comes from a bounding BOX: many (Gaussian, tile) pairs touch no pixel at all
       if (SKIP_EMPTY && __ballot(valid[0] || valid[1] || valid[2] || valid[3]) == 0ull) continue;
       const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
@@ -126,6 +169,18 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
         last[k] = upd ? idx1 : last[k];
       }
     }
+    if (STATS) {
+      unsigned m4g = 0, m8g = 0, m4l = 0, m8l = 0;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) { m4g = max(m4g, c4g[b]); m4l = max(m4l, c4l[b]); }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { m8g = max(m8g, c8g[b]); m8l = max(m8l, c8l[b]); }
+      sc[5] += m4g; sc[6] += m8g; sc[11] += m4l; sc[12] += m8l; sc[7] += 1;
+    }
+  }
+  if (STATS && stats && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < kLaneStats; ++i) atomicAdd(stats + i, sc[i]);
   }
   const bool all_stopped = __ballot(fmaxf(fmaxf(Tk[0], Tk[1]), fmaxf(Tk[2], Tk[3])) > 0.f) == 0ull;
   const bool finalize = all_stopped || st.last;
@@ -407,9 +462,15 @@ using namespace gs;
 // (_C.rasterize_forward in the absent fork; SURVEY.md §8 a7, boundary §8b).
 static int launch_fwd(const RasterParams& prm, const SliceState& st, const int* ids, int n_records, float* out_img,
                       float* out_T, int* final_idx, int variant, hipStream_t stream, float* out_depth = nullptr,
-                      const unsigned char* tile_hot = nullptr) {
+                      const unsigned char* tile_hot = nullptr, unsigned long long* stats = nullptr) {
   unsigned work = (unsigned)(prm.S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
+  if (stats) {
+    if (out_depth) return GS_ERR_INVALID;
+    hipLaunchKernelGGL((raster_fwd_slice_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, prm, st, out_img,
+                       out_T, final_idx, blocks, stats);
+    return GS_OK;
+  }
   if (out_depth && !(variant == 0 && ids)) return GS_ERR_INVALID;   // the depth channel lives in the scalar-cache kernel
   if (variant == 0 && ids && out_depth)
     hipLaunchKernelGGL(raster_fwd_sload_kernel<true>, dim3(blocks), dim3(256), 0, stream, prm, st, ids, prm.records,
@@ -463,6 +524,22 @@ GS_EXPORT int gs_rasterize_fwd_slice(const float* records, const int* sorted_val
   const int* ids = sorted_ids ? sorted_ids : (gi_of_e ? nullptr : sorted_vals);
   int rc = launch_fwd(prm, st, n_records > 0 ? ids : nullptr, n_records, out_img, out_T, final_idx, variant,
                       (hipStream_t)stream, out_depth, tile_hot);
+  if (rc != GS_OK) return rc;
+  return gs_launch_status();
+}
+
+// Debug twin of gs_rasterize_fwd_slice (same results through the round-1 compositor) that also accumulates the
+// lane-utilisation counters of its walk into stats[13] (u64, caller zeroes; see raster_fwd_slice_kernel STATS).
+GS_EXPORT int gs_rasterize_fwd_slice_stats(const float* records, const int* sorted_vals, const int* tile_bins,
+                                           const int* band_edges, const float* background, int S, int R, int H, int W,
+                                           float* out_img, float* out_T, float* live_T, int* final_idx,
+                                           unsigned char* tile_done, int first, int last, const int* gi_of_e,
+                                           int* open_flag, unsigned long long* stats, void* stream) {
+  if (S <= 0 || R <= 0 || H <= 0 || W <= 0 || !stats) return GS_ERR_INVALID;
+  RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
+  prm.gi_of_e = gi_of_e;
+  SliceState st; st.tile_done = tile_done; st.live_T = live_T; st.first = first; st.last = last; st.open_flag = open_flag;
+  int rc = launch_fwd(prm, st, nullptr, 0, out_img, out_T, final_idx, 1, (hipStream_t)stream, nullptr, nullptr, stats);
   if (rc != GS_OK) return rc;
   return gs_launch_status();
 }

@@ -69,6 +69,12 @@ DEVICE_SIZES = int(os.environ.get("GSD_DEVICE_SIZES", "1"))
 UPSTREAM_GRADS = int(os.environ.get("GSD_UPSTREAM_GRADS", "0"))
 
 
+# debug: GSD_LANE_STATS=1 routes the forward compositor through gs_rasterize_fwd_slice_stats and accumulates its
+# lane-utilisation counters in `lane_stats` (u64 [13] on the device, see include/gsdeblur.h); slow, measurement only
+LANE_STATS = int(os.environ.get("GSD_LANE_STATS", "0"))
+lane_stats: Optional[Tensor] = None
+
+
 def _bwd_variant() -> int:
     return RASTER_BWD_VARIANT | (256 if (UPSTREAM_GRADS & 4) else 0)
 # per-slice emitted intersection counts of the last frame: ints, or 1-element device tensors that are only read back
@@ -656,16 +662,28 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
             svals = torch.zeros(1, dtype=torch.int32, device=dev)
             bins = torch.zeros(P * T, 2, dtype=torch.int32, device=dev)
         fidx = torch.empty(S, H, W, dtype=torch.int32, device=dev)
-        with _stage("raster_fwd"):
-            _check(L.gs_rasterize_fwd_slice(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
-                                            _ptr(out_img), _ptr(out_T), _ptr(live_T), _ptr(fidx), _ptr(tile_done),
-                                            int(first), int(last), _ptr(vals) if (use_tuples and I_k > 0) else None,
-                                            _ptr(sorted_ids), P * N if I_k > 0 else 0,
-                                            _ptr(out_depth) if I_k > 0 else None,
-                                            _ptr(tile_hot) if I_k > 0 else None,
-                                            ctypes.c_void_p(open_flags.data_ptr() + 4 * k) if not last else None,
-                                            RASTER_FWD_VARIANT, _stream()),
-                   "rasterize_fwd_slice")
+        if LANE_STATS and out_depth is None:
+            global lane_stats
+            if lane_stats is None or lane_stats.device != dev:
+                lane_stats = torch.zeros(13, dtype=torch.int64, device=dev)
+            _check(L.gs_rasterize_fwd_slice_stats(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H,
+                                                  W, _ptr(out_img), _ptr(out_T), _ptr(live_T), _ptr(fidx),
+                                                  _ptr(tile_done), int(first), int(last),
+                                                  _ptr(vals) if (use_tuples and I_k > 0) else None,
+                                                  ctypes.c_void_p(open_flags.data_ptr() + 4 * k) if not last else None,
+                                                  _ptr(lane_stats), _stream()), "rasterize_fwd_slice_stats")
+        else:
+            with _stage("raster_fwd"):
+                _check(L.gs_rasterize_fwd_slice(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H,
+                                                W, _ptr(out_img), _ptr(out_T), _ptr(live_T), _ptr(fidx),
+                                                _ptr(tile_done), int(first), int(last),
+                                                _ptr(vals) if (use_tuples and I_k > 0) else None,
+                                                _ptr(sorted_ids), P * N if I_k > 0 else 0,
+                                                _ptr(out_depth) if I_k > 0 else None,
+                                                _ptr(tile_hot) if I_k > 0 else None,
+                                                ctypes.c_void_p(open_flags.data_ptr() + 4 * k) if not last else None,
+                                                RASTER_FWD_VARIANT, _stream()),
+                       "rasterize_fwd_slice")
         tuples_k = flags_k = None
         if prealloc is not None and use_tuples and I_k > 0 and I_k * REC * 4 <= PREALLOC_MAX_BYTES:
             # the backward's buffers of this slice (and the frame's, once) are set up HERE, while the GPU works
@@ -682,7 +700,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
             # slice if the word says it had nothing to do
             slices.append(dict(svals=svals, bins=bins, fidx=fidx, I=I_k, gi_of_e=vals if use_tuples else None,
                                sorted_ids=sorted_ids, slice_gi=slice_gi, counts=counts, cum=cum_k, n=n_k,
-                               tile_hot=tile_hot, tuples=tuples_k, flags=flags_k,
+                               tile_hot=tile_hot, tuples=tuples_k, flags=flags_k, wave_per_g=bool(wave_per_g),
                                gated=(pending[-1][0], flags_host, gate_k) if gate is not None else None))
         if not last:
             sat_gate = None
@@ -748,9 +766,12 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
                    "rasterize_bwd_slice")
         if tuples is not None:
             with _stage("grad_reduce"):
+                # kernel form: a wave per Gaussian only for slices of few, large Gaussians (the choice the exact count
+                # made); sl["I"] is the slice's bounding-BOX pair count, not its emitted entries — sizing the choice by
+                # it sent every slice of a small-splat scene (7 entries per Gaussian) through 64-lane waves
                 _check(L.gs_reduce_grad_tuples(sl["n"], _ptr(sl["slice_gi"]), _ptr(sl["counts"]), _ptr(sl["cum"]),
-                                               _ptr(tuples), _ptr(flags), _ptr(v_records), _ptr(touched), sl["I"],
-                                               _stream()),
+                                               _ptr(tuples), _ptr(flags), _ptr(v_records), _ptr(touched),
+                                               sl["I"] if sl.get("wave_per_g", True) else 0, _stream()),
                        "reduce_grad_tuples")
 
 

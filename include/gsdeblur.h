@@ -318,6 +318,17 @@ int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const i
                                             after this slice (last == 0 only)*/,
                            int variant /*0 = default; 1, 2 = v_readlane compositor without / with the empty-pair skip*/,
                            void* stream);
+/* Debug twin of gs_rasterize_fwd_slice (no upstream counterpart; DESIGN.md section 5 "lane utilisation"): same outputs
+ * through the round-1 compositor, and the counters of its walk summed into stats[13] (u64, zeroed by the caller):
+ * [0] list entries walked, [1] pixels blended (hit and live), [2] pixels with alpha >= 1/255 (live or not), [3]/[4] 4x4
+ * pixel blocks / 8x8 quadrants with such a pixel, [5]/[6] steps a 64-entry chunk would take if every block / quadrant
+ * walked only its own entries in lock-step, [7] chunks, [8] entries with a live hit, [9]/[10] blocks / quadrants with a
+ * live hit, [11]/[12] as [5]/[6] for live hits. */
+int gs_rasterize_fwd_slice_stats(const float* records, const int* sorted_vals, const int* tile_bins,
+                                 const int* band_edges, const float* background, int S, int R, int img_height,
+                                 int img_width, float* out_img, float* out_T, float* live_T, int* final_idx,
+                                 unsigned char* tile_done, int first, int last, const int* gi_of_e, int* open_flag,
+                                 unsigned long long* stats, void* stream);
 /* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B [S,H,W] (behind-colour . v_out, init = 0)
  * carry the reverse-traversal state; both may be NULL on the tuple path when the frame has a single slice */
 int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
