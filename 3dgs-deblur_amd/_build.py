@@ -24,6 +24,7 @@ SOURCES = [
     ("raster_bwd.hip", ["-fno-slp-vectorize"]),
     # x*scale + y must round twice, like the torch ops it replaces (tests compare bit for bit)
     ("dp_exchange.hip", ["-ffp-contract=off"]),
+    ("train.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fvisibility=hidden"]
 

@@ -1,7 +1,12 @@
 """Loss + optimizer step around the hot path: what the nerfstudio fork's trainer
 does right after `get_outputs` — splatfacto's `0.8*L1 + 0.2*(1-SSIM)` image loss, the scale
 regularisation switched on by /root/reference/train.py:120 (`use-scale-regularization`), and one Adam
-step per parameter group.  Plain torch on top of :mod:`model`; the render and its backward are the HIP path.
+step per parameter group.  On the GPU the loss (forward + backward) and the optimizer step are HIP kernels
+(:mod:`fused`, csrc/train.hip): two tile kernels instead of nine conv2d launches plus their autograd graph, one
+multi-tensor Adam launch instead of six foreach passes.  The torch formulations below are the same math for CPU
+tensors (the gloo host-logic tests drive `train_step` with a CPU stand-in for the render) and the oracle the HIP
+kernels are tested against; a CUDA tensor never takes them silently — `image_loss` / `make_optimizers` choose by
+device and the HIP side raises when the library is missing.
 """
 from __future__ import annotations
 
@@ -15,10 +20,10 @@ from torch import Tensor
 from .model import Camera, SplatfactoDeblurModel
 
 
-def _gauss_window(size: int = 11, sigma: float = 1.5, device=None) -> Tensor:
+def _gauss_window(size: int = 11, sigma: float = 1.5, device=None, dtype=torch.float32) -> Tensor:
     x = torch.arange(size, dtype=torch.float32, device=device) - (size - 1) / 2.0
     g = torch.exp(-(x * x) / (2 * sigma * sigma))
-    g = g / g.sum()
+    g = (g / g.sum()).to(dtype)          # the window is built in float32 (as pytorch_msssim does), whatever the images
     return (g[:, None] * g[None, :])[None, None]
 
 
@@ -26,7 +31,7 @@ def ssim(img: Tensor, ref: Tensor, window: int = 11) -> Tensor:
     """Mean SSIM of two [H,W,3] images in [0,1] (Gaussian 11x11 window, sigma 1.5, valid padding)."""
     x = img.permute(2, 0, 1)[None]
     y = ref.permute(2, 0, 1)[None]
-    w = _gauss_window(window, 1.5, img.device).expand(3, 1, window, window)
+    w = _gauss_window(window, 1.5, img.device, img.dtype).expand(3, 1, window, window)
     mu_x, mu_y = F.conv2d(x, w, groups=3), F.conv2d(y, w, groups=3)
     sxx = F.conv2d(x * x, w, groups=3) - mu_x * mu_x
     syy = F.conv2d(y * y, w, groups=3) - mu_y * mu_y
@@ -42,6 +47,14 @@ def psnr(img: Tensor, ref: Tensor) -> float:
 
 
 def image_loss(pred: Tensor, gt: Tensor, ssim_lambda: float = 0.2) -> Tensor:
+    if pred.is_cuda:
+        from . import fused
+        return fused.image_loss(pred, gt, ssim_lambda)
+    return image_loss_torch(pred, gt, ssim_lambda)
+
+
+def image_loss_torch(pred: Tensor, gt: Tensor, ssim_lambda: float = 0.2) -> Tensor:
+    """the same loss in plain torch ops (CPU tensors; reference for the HIP kernels' tests)"""
     l1 = torch.abs(gt - pred).mean()
     if ssim_lambda <= 0:
         return l1
@@ -56,18 +69,38 @@ def scale_regularization(log_scales: Tensor, max_gauss_ratio: float = 10.0) -> T
     return 0.1 * (torch.maximum(ratio, r) - r).mean()
 
 
-def make_optimizers(model: SplatfactoDeblurModel, lr_scale: float = 1.0) -> Dict[str, torch.optim.Optimizer]:
-    """One Adam per parameter group with splatfacto's default learning rates."""
+def make_optimizers(model: SplatfactoDeblurModel, lr_scale: float = 1.0,
+                    fused: Optional[bool] = None) -> Dict[str, torch.optim.Optimizer]:
+    """One Adam per parameter group with splatfacto's default learning rates.  fused (default: the parameters live on
+    a GPU): HipAdam — same update rule and state layout as torch.optim.Adam, stepped by ONE multi-tensor HIP launch
+    (`optimizers_step`); False: torch.optim.Adam (CPU tensors, A/B)."""
     lrs = {"means": 1.6e-4, "scales": 5e-3, "quats": 1e-3, "opacities": 5e-2, "features_dc": 2.5e-3,
            "features_rest": 2.5e-3 / 20}
-    opts = {k: torch.optim.Adam([p], lr=lrs[k] * lr_scale, eps=1e-15) for k, p in model.gauss_params().items()}
+    if fused is None:
+        fused = model.means.is_cuda
+    if fused:
+        from .fused import HipAdam as Adam
+    else:
+        Adam = torch.optim.Adam
+    opts = {k: Adam([p], lr=lrs[k] * lr_scale, eps=1e-15) for k, p in model.gauss_params().items()}
     if model.pose_adjustment is not None:
-        opts["camera_opt"] = torch.optim.Adam([model.pose_adjustment], lr=1e-4 * lr_scale, eps=1e-15)
+        opts["camera_opt"] = Adam([model.pose_adjustment], lr=1e-4 * lr_scale, eps=1e-15)
     if model.velocity_adjustment is not None:
-        opts["camera_velocity_opt"] = torch.optim.Adam([model.velocity_adjustment], lr=1e-3 * lr_scale, eps=1e-15)
+        opts["camera_velocity_opt"] = Adam([model.velocity_adjustment], lr=1e-3 * lr_scale, eps=1e-15)
     if model.background_param is not None:
-        opts["background"] = torch.optim.Adam([model.background_param], lr=1e-3 * lr_scale, eps=1e-15)
+        opts["background"] = Adam([model.background_param], lr=1e-3 * lr_scale, eps=1e-15)
     return opts
+
+
+def optimizers_step(optimizers) -> None:
+    """step every optimizer of the iteration; HipAdam instances share one multi-tensor launch"""
+    opts = list(optimizers)
+    if any(type(o).__name__ == "HipAdam" for o in opts):
+        from .fused import adam_step_all
+        adam_step_all(opts)
+    else:
+        for o in opts:
+            o.step()
 
 
 def train_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.Optimizer], camera: Camera,
@@ -92,8 +125,7 @@ def train_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.O
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         dp.allreduce_dense_([p.grad for p in small], average=True)
-    for o in optimizers.values():
-        o.step()
+    optimizers_step(optimizers.values())
     model.step += 1
     return {"loss": float(loss.item()), "psnr": psnr(out["rgb"].detach(), gt_image)}
 
@@ -117,8 +149,7 @@ def eval_camera_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.o
     out = model.get_outputs(camera, detach_gaussians=True)
     loss = image_loss(out["rgb"], gt_image, ssim_lambda)
     loss.backward()
-    for o in cam_opts:
-        o.step()
+    optimizers_step(cam_opts)
     return float(loss.item())
 
 

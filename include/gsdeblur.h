@@ -388,6 +388,23 @@ int gs_dp_pack_masked_rows(int N, const unsigned char* mask, const int* pos, int
 int gs_dp_scatter_add_payload(int cap, const float* payload, int n_tensors, float* const* grads, const int* widths,
                               float scale, void* stream);
 
+/* ---- the step after the path: image loss + optimizer ---------------------------------------------
+ * Replaces what the nerfstudio fork's trainer runs right after get_outputs (reached from /root/reference/train.py:115-122):
+ * splatfacto's loss  L = (1 - lambda) * mean|gt - pred| + lambda * (1 - SSIM(pred, gt))  (pytorch_msssim SSIM: 11x11
+ * Gaussian window, sigma 1.5, valid convolution, C1 = 0.01^2, C2 = 0.03^2, mean over the map) together with its
+ * backward, and torch.optim.Adam(eps = 1e-15) over the parameter groups. */
+long long gs_image_loss_workspace_bytes(int img_height, int img_width);
+/* pred, gt, v_pred [H,W,3] fp32 (device); v_pred = d loss / d pred; loss_out[3] = {loss, mean |gt - pred|, mean SSIM}
+ * (device).  ssim_lambda == 0: L1 only (any size); otherwise both sides must be >= 11. */
+int gs_image_loss_fwd_bwd(int img_height, int img_width, const float* pred, const float* gt, float ssim_lambda,
+                          float* v_pred, float* loss_out, void* workspace, long long workspace_bytes, void* stream);
+/* ONE Adam step over count (<= 8) tensors; params / grads / exp_avg / exp_avg_sq: HOST arrays of device pointers,
+ * numel / lr: host arrays; step = 1-based count of this update (bias corrections 1 - beta^step):
+ *   m = m + (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;  p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps) */
+int gs_adam_step(int count, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, const long long* numel, const float* lr, double beta1, double beta2, double eps,
+                 int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
