@@ -25,6 +25,7 @@ SOURCES = [
     # x*scale + y must round twice, like the torch ops it replaces (tests compare bit for bit)
     ("dp_exchange.hip", ["-ffp-contract=off"]),
     ("train.hip", []),
+    ("frame.hip", []),           # host-side frame orchestration (no kernels of its own)
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fvisibility=hidden"]
 
@@ -50,7 +51,8 @@ def source_hash() -> str:
     """content hash of every kernel source, header and of this file (the flags): what the binary was built from"""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.h")) + [Path(__file__)]:
+    for f in (sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "gsdeblur.h"]
+              + [Path(__file__)]):
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()
@@ -66,7 +68,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     if not force and is_current():
         return LIB_PATH
     force = force or LIB_PATH.exists()      # a stale binary: rebuild every object (mtimes cannot be trusted)
-    headers = sorted(CSRC.glob("*.h"))
+    headers = sorted(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "gsdeblur.h"]
     objs = []
     hipcc = _hipcc()
     build_dir = PKG_DIR / "build"

@@ -1013,6 +1013,7 @@ constexpr int kCountSolo = 12;
 // 3x slower than the rest of the binning together.
 constexpr int kCountSoloMax = 64;
 constexpr int kCountSoloMany = 4;
+constexpr int kCountMidMax = 256;   // up to four mask words: still one lane per box when its rows fit a word (w <= 64)
 constexpr int kMaskWords = 512;     // box-local hit-bit string assembled in LDS: boxes of up to 32768 tiles (4K: 32400)
 
 // w (<= 64) bits of a tile row's open mask starting at column x0
@@ -1039,6 +1040,7 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
                                                                  const unsigned long long* __restrict__ open_bits,
                                                                  const int* __restrict__ gate) {
   __shared__ unsigned long long s_words[4][kMaskWords];
+  __shared__ unsigned long long s_mid[WAVE_PER_G ? 1 : 4][256];      // lane-private bit strings of mid-sized boxes
   const int lane = lane_id();
   const int j = WAVE_PER_G ? (lane == 0 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) : n_slice)
                            : (int)(blockIdx.x * 256 + threadIdx.x);
@@ -1075,12 +1077,29 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
   const int solo_limit =
       (!WAVE_PER_G && __popcll(__ballot(area > kCountSolo && area <= kCountSoloMax)) >= kCountSoloMany) ? kCountSoloMax
                                                                                                        : kCountSolo;
-  if (area > 0 && area <= solo_limit) {
-    // small box (one mask word): per tile ROW, the columns the ellipse reaches AND the open tiles, as bits
+  // boxes of up to kCountMidMax tiles (up to four mask words) whose rows fit one 64-bit word: still ONE lane per box,
+  // the box-local bit string assembled in lane-private LDS words.  Taking them through the wave-cooperative path
+  // below costs ~1 us of a whole wave EACH, and a fitted-model-like scene has dozens of 65..256-tile boxes per wave
+  // (mean box 56 tiles): that path was most of this kernel's 0.86 ms per frame there.
+  const int box_w = (int)(hi & 0xFFFF) - (int)(lo & 0xFFFF);
+  const bool mid_box = !WAVE_PER_G && area > solo_limit && area <= kCountMidMax && box_w <= 64;
+  const bool mid = mid_box && __popcll(__ballot(mid_box)) >= kCountSoloMany;
+  if (area > 0 && (area <= solo_limit || mid)) {
+    // per tile ROW, the columns the ellipse reaches AND the open tiles, as bits
     const int x0 = lo & 0xFFFF, y0 = lo >> 16, x1 = hi & 0xFFFF, y1 = hi >> 16;
     const int w = x1 - x0;
     const unsigned pidx = gi / (unsigned)N;
-    unsigned long long m = 0ull;
+    unsigned long long m = 0ull;                  // the one word of a small box
+    unsigned long long* mw = &s_mid[0][threadIdx.x];          // word k of this lane: mw[k * 256]
+    if (mid) { mw[0] = 0ull; mw[256] = 0ull; mw[512] = 0ull; mw[768] = 0ull; }
+    auto put = [&](int y, unsigned long long rowbits) {
+      cnt += (unsigned)__popcll(rowbits);
+      const int bit0 = (y - y0) * w;
+      if (!mid) { m |= rowbits << bit0; return; }
+      const int wi = bit0 >> 6, sh = bit0 & 63;
+      mw[wi * 256] |= rowbits << sh;
+      if (sh && (rowbits >> (64 - sh))) mw[(wi + 1) * 256] |= rowbits >> (64 - sh);
+    };
     if (open_bits) {
       // four tile rows per step, their open-tile words fetched TOGETHER and before any of them is used: one lane per
       // Gaussian walks ~8 rows, and a load per row inside the loop was one full memory round trip per row — the kernel
@@ -1106,8 +1125,7 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
           unsigned long long win = a[k] >> sh;                     // row_window(row, x0, w) on the prefetched words
           if (sh && sh + w > 64) win |= b[k] << (64 - sh);
           rowbits &= win & wmask;
-          cnt += (unsigned)__popcll(rowbits);
-          m |= rowbits << ((y - y0) * w);
+          if (rowbits) put(y, rowbits);
         }
       }
     } else {
@@ -1115,14 +1133,18 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
         int t0, t1;
         span_tiles(el, row_span(el, y, H), x0, x1, t0, t1);
         if (t1 <= t0) continue;
-        unsigned long long rowbits = (t1 - t0 >= 64 ? ~0ull : ((1ull << (t1 - t0)) - 1ull)) << (t0 - x0);   // w <= 64
-        cnt += (unsigned)__popcll(rowbits);
-        m |= rowbits << ((y - y0) * w);
+        put(y, (t1 - t0 >= 64 ? ~0ull : ((1ull << (t1 - t0)) - 1ull)) << (t0 - x0));
       }
     }
-    if (masks) masks[moff] = m;                 // area <= 64: one word
+    if (masks) {
+      if (!mid) masks[moff] = m;                 // area <= 64: one word
+      else {
+        const int nwords = (area + 63) >> 6;
+        for (int k = 0; k < nwords; ++k) masks[moff + (unsigned)k] = mw[k * 256];
+      }
+    }
   }
-  unsigned long long big = __ballot(area > solo_limit);
+  unsigned long long big = __ballot(area > solo_limit && !mid);
   unsigned long long* words = s_words[threadIdx.x >> 6];
   while (big) {
     const int src = __ffsll((long long)big) - 1;
@@ -1230,6 +1252,8 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
     // boxes of one mask word (<= 64 tiles), when the wave holds several: every lane expands its own word — up to 64
     // Gaussians in ~cnt steps instead of one wave-wide step each (a scene of uniformly small splats has dozens per
     // wave).  Same (y, x) order inside a Gaussian; the writes of neighbouring lanes land in neighbouring ranges.
+    // (Boxes of two to four words stay with the wave-wide expansion below: per-lane expansion of those was measured
+    // slower, 0.33 -> 0.41 ms per frame on the fitted-model-like scene, run r3_run5.)
     const int x0 = lo & 0xFFFF, y0 = lo >> 16, x1 = hi & 0xFFFF, y1 = hi >> 16;
     const int w = x1 - x0, area = w * (y1 - y0);
     const bool small = cnt != 0 && area <= kCountSoloMax;

@@ -1,0 +1,486 @@
+// frame.hip — host-side orchestration of ONE frame's depth-sliced bin / sort / composite pipeline and of its backward,
+// behind two C-ABI entry points (gs_frame_forward / gs_frame_backward).
+//
+// Stands where the fork's Python layer stands between `project_gaussians` and the returned image ("the
+// caller owns all tensors; the library allocates nothing; workspace passed in"): the ~20 launches of the depth
+// pre-sort and the ~22 launches of every depth slice used to be issued one by one from Python (ops.sliced_forward: one
+// ctypes call and several torch allocations each), and the GPU idled behind the host for 0.15 ms of the 2.4 ms headline
+// step and 0.9 ms of the 11 ms fitted-model-like step.  Here the whole sequence is issued from C++ out of ONE
+// caller-owned arena (bump allocation, nothing is ever freed inside a frame), the slice plan and the one "is any tile
+// still open?" word per slice come back through caller-owned pinned memory, and the backward walks the slice table the
+// forward left in a plain host struct.  Every launch goes through the same exported entry points the Python
+// orchestration uses (binning.hip / raster.hip / raster_bwd.hip / project.hip), so the two orchestrations produce the
+// same bytes (tests compare them).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "../../include/gsdeblur.h"
+
+#define GS_OK 0
+#define GS_ERR_INVALID 1
+#define GS_ERR_WORKSPACE 3
+#define GS_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+constexpr int kTile = 16;
+constexpr int kKMax = GS_FRAME_MAX_SLICES;     // planned slices per frame (budget doubles per slice)
+constexpr int kIdsPad = 8;                     // the scalar-cache compositors read their lists in aligned groups of four
+
+struct Arena {
+  char* base;
+  long long cap, off;
+  bool ok;
+  Arena(void* b, long long c, long long start = 0) : base((char*)b), cap(c), off(start), ok(true) {}
+  static long long up(long long x) { return (x + 255) & ~255ll; }
+  // bytes the allocation WOULD end at (used to price a plan before committing to it)
+  template <typename T> T* take(long long count) {
+    const long long a = up(off), bytes = count * (long long)sizeof(T);
+    if (!ok || a + bytes > cap) { ok = false; off = a + bytes; return nullptr; }
+    off = a + bytes;
+    return reinterpret_cast<T*>(base + a);
+  }
+  long long offset_of(const void* p) const { return p ? (long long)((const char*)p - base) : -1; }
+};
+
+inline int bits_for(long long n) {
+  int b = 1;
+  while ((1ll << b) < std::max(2ll, n)) ++b;
+  return b;
+}
+
+inline int hip_status(hipError_t e) { return e == hipSuccess ? GS_OK : 1000 + (int)e; }
+
+// ---- optional stage timing (debug / bench): HIP events on the launch stream -------------------------------------
+struct StageEvents { int stage; hipEvent_t a, b; };
+unsigned g_profile_mask = 0;
+std::vector<StageEvents> g_events;            // recorded since the last read
+std::vector<StageEvents> g_pool;              // reusable event pairs
+
+struct StageScope {
+  hipStream_t st;
+  bool on;
+  StageEvents ev;
+  StageScope(int stage, hipStream_t s) : st(s), on((g_profile_mask >> stage) & 1u) {
+    if (!on) return;
+    if (!g_pool.empty()) { ev = g_pool.back(); g_pool.pop_back(); }
+    else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
+    ev.stage = stage;
+    (void)hipEventRecord(ev.a, st);
+  }
+  ~StageScope() {
+    if (!on) return;
+    (void)hipEventRecord(ev.b, st);
+    g_events.push_back(ev);
+  }
+};
+
+#define CHECK(call)            \
+  do {                         \
+    int _st = (call);          \
+    if (_st != GS_OK) return _st; \
+  } while (0)
+
+}  // namespace
+
+// stage ids of gs_frame_profile_*: depth_sort, count_scan, slice_plan, slice_count, emit, tile_sort, bin_edges,
+// raster_fwd, slice_sat, raster_bwd, grad_reduce
+enum { ST_DEPTH_SORT = 0, ST_COUNT_SCAN, ST_PLAN, ST_COUNT, ST_EMIT, ST_TILE_SORT, ST_BIN_EDGES, ST_RASTER_FWD, ST_SAT,
+       ST_RASTER_BWD, ST_REDUCE, ST_N };
+
+GS_EXPORT int gs_frame_profile_enable(unsigned stage_mask) {
+  g_profile_mask = stage_mask;
+  return GS_OK;
+}
+
+// Drains the event pairs recorded since the last call: stage_ids[i] / ms[i] for i < returned count (<= max_events;
+// the rest is dropped).  Synchronises on the recorded events.  Not thread-safe (measurement facility).
+GS_EXPORT int gs_frame_profile_read(int max_events, int* stage_ids, float* ms) {
+  int n = 0;
+  for (StageEvents& e : g_events) {
+    if (n < max_events && stage_ids && ms) {
+      (void)hipEventSynchronize(e.b);
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, e.a, e.b);
+      stage_ids[n] = e.stage;
+      ms[n] = t;
+      ++n;
+    }
+    g_pool.push_back(e);
+  }
+  g_events.clear();
+  return n;
+}
+
+// bytes of the arena one depth slice occupies in the forward (all of it stays allocated until the frame's backward ran)
+static long long slice_bytes(const gs_frame_desc& d, long long n_k, long long I_k, bool masks, long long true_total) {
+  const long long P = d.P, T = (long long)((d.W + kTile - 1) / kTile) * ((d.H + kTile - 1) / kTile);
+  long long b = 0;
+  auto add = [&](long long bytes) { b = Arena::up(b) + bytes; };
+  if (n_k > 0) {
+    add(4 * n_k); add(4 * n_k);                                   // slice_gi, counts
+    if (masks) { add(8 * (true_total / 64 + n_k + 2)); add(4 * n_k); }
+    add(4 * n_k); add(4); add(gs_scan_workspace_bytes(n_k));       // cum_k, total_k, scan workspace
+  }
+  if (I_k > 0) {
+    add(4 * I_k); add(4 * (I_k + kIdsPad));                       // keys, vals
+    add(4 * (I_k + kIdsPad)); add(4 * I_k); add(4 * (I_k + kIdsPad));   // v0, k1, v1
+    add(4 * (I_k + kIdsPad)); add(4 * (I_k + kIdsPad));           // carried payload a / b
+    add(gs_radix_sort_workspace_bytes(I_k, 0, bits_for(P * T + 1)));
+    add(8 * (P * T + 1));                                          // bins
+  } else {
+    add(4); add(8 * P * T);
+  }
+  add(4ll * d.S * d.H * d.W);                                      // final index
+  return Arena::up(b) + 256;
+}
+
+GS_EXPORT long long gs_frame_backward_bytes(const gs_frame_state* state) {
+  if (!state) return 0;
+  long long maxI = 0;
+  for (int k = 0; k < state->n_slices; ++k) maxI = std::max(maxI, state->slice[k].I);
+  long long b = Arena::up(48 * maxI) + Arena::up(maxI) + 512;
+  if (state->n_slices > 1) b += 2 * Arena::up(4ll * state->S * state->H * state->W);
+  return b;
+}
+
+// One frame, forward: depth pre-sort of the P*N (sub-pose, Gaussian) pairs, slice plan, and per depth slice exact
+// counts -> [deferred SH colour] -> compact emission -> stable tile sort -> bin edges -> compositor.
+// Replaces the binning + rasterize_forward part of the fork's rasterize_gaussians autograd.Function (SURVEY.md §8
+// a4-a7; the Python original is ops.sliced_forward).  records / depth_keys / num_tiles_hit come from
+// gs_project_fused_fwd or gs_project_pixvel_fwd; depth_keys is consumed.  Results: out_img [S,H,W,3], out_T [S,H,W]
+// (caller-owned), the slice table in *state.  GS_ERR_WORKSPACE: the arena is too small, state->arena_required says what
+// the frame needs as far as it is known (call again with a larger arena and FRESH projection outputs).
+GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned* depth_keys, const int* num_tiles_hit,
+                               const float* background, const int* band_edges, const unsigned char* band_tile_done,
+                               const float* color_means, const float* color_sh, int color_K, int color_degree,
+                               const float* color_viewmats, float* out_img, float* out_T, float* out_depth,
+                               void* arena_ptr, long long arena_bytes, void* host_pinned, long long host_pinned_bytes,
+                               gs_frame_state* state, void* stream_) {
+  if (!dp || !records || !depth_keys || !num_tiles_hit || !background || !band_edges || !out_img || !out_T ||
+      !arena_ptr || !host_pinned || !state)
+    return GS_ERR_INVALID;
+  const gs_frame_desc d = *dp;
+  if (d.N <= 0 || d.P <= 0 || d.S <= 0 || d.R <= 0 || d.P != d.S * d.R || d.H <= 0 || d.W <= 0 || d.P > 256)
+    return GS_ERR_INVALID;
+  if (d.R > 1 && !band_tile_done) return GS_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream_;
+  const int P = d.P, N = d.N, S = d.S, R = d.R, H = d.H, W = d.W;
+  const long long n = (long long)P * N;
+  const int tx = (W + kTile - 1) / kTile, ty = (H + kTile - 1) / kTile;
+  const long long T = (long long)tx * ty;
+  const long long plan_ints = 2ll * P * kKMax + 2 * P + 1;
+  if (host_pinned_bytes < 4 * plan_ints + 64) return GS_ERR_INVALID;
+  memset(state, 0, sizeof(*state));
+  state->P = P; state->N = N; state->S = S; state->R = R; state->H = H; state->W = W;
+  Arena A(arena_ptr, arena_bytes);
+
+  // ---- depth pre-sort (compacting, per sub-pose) + exclusive scan of the tile counts in rank order ----------------
+  unsigned* v0 = A.take<unsigned>(n);
+  unsigned* k1 = A.take<unsigned>(n);
+  unsigned* v1 = A.take<unsigned>(n);
+  unsigned* counts_r = A.take<unsigned>(n);
+  unsigned* n_live = A.take<unsigned>(P);
+  const int digit = d.depth_sort_digit >= 8 && d.depth_sort_digit <= 11 ? d.depth_sort_digit : 8;
+  const long long sort_ws_b = gs_segmented_sort_compact_workspace_bytes(n, N, 0, 31, digit);
+  char* sort_ws = A.take<char>(sort_ws_b);
+  unsigned* cum = A.take<unsigned>(n);
+  unsigned* total = A.take<unsigned>(1);
+  const long long scan_ws_b = gs_scan_workspace_bytes(n);
+  char* scan_ws = A.take<char>(scan_ws_b);
+  float* live_T = A.take<float>((long long)S * H * W);
+  int* sat = A.take<int>((long long)P * (ty + 1) * (tx + 1));
+  const long long w64 = (tx + 63) / 64;
+  unsigned long long* open_bits = A.take<unsigned long long>((long long)P * ty * w64);
+  const long long flag_off = ((1 + kKMax) * P * T + 3) & ~3ll;
+  unsigned char* zeros_u8 = A.take<unsigned char>(flag_off + 4 * kKMax);
+  int* plan_dev = A.take<int>(plan_ints);
+  unsigned char* tile_done_rs = R > 1 ? A.take<unsigned char>(P * T) : nullptr;
+  if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
+
+  int res = 0;
+  {
+    StageScope sc(ST_DEPTH_SORT, st);
+    // visible keys are positive floats: bit 31 is never set (the culled marker is dropped, not sorted)
+    CHECK(gs_segmented_sort_compact_u32(n, N, depth_keys, v0, k1, v1, 0, 31, digit, 0xFFFFFFFFu, n_live,
+                                        reinterpret_cast<const unsigned*>(num_tiles_hit), counts_r, sort_ws, sort_ws_b,
+                                        &res, st));
+  }
+  const unsigned* sorted_gi = res == 1 ? v1 : v0;
+  {
+    StageScope sc(ST_COUNT_SCAN, st);
+    CHECK(gs_exclusive_scan_segments_u32(n, N, n_live, counts_r, cum, total, scan_ws, scan_ws_b, st));
+  }
+  // one zero fill: tile_done of the first slice, one "tile holds an opacity above the alpha clamp" flag per tile and
+  // planned slice, one "a tile is still open" word per slice
+  CHECK(hip_status(hipMemsetAsync(zeros_u8, 0, flag_off + 4 * kKMax, st)));
+  int* open_flags = reinterpret_cast<int*>(zeros_u8 + flag_off);
+
+  // ---- slice plan: the ONE read-back every frame needs ---------------------------------------------------------------
+  unsigned* hp = reinterpret_cast<unsigned*>(host_pinned);
+  const long long PK = (long long)P * kKMax;
+  std::vector<long long> NV(P), seg_totals(P);
+  std::vector<std::vector<long long>> bnd(P), rel(P);
+  long long n_total = 0;
+  int K = 1;
+  const bool planned = d.slice_base > 0;
+  if (planned) {
+    StageScope sc(ST_PLAN, st);
+    CHECK(gs_slice_plan(P, N, kKMax, cum, total, (long long)T * d.slice_base, plan_dev,
+                        reinterpret_cast<unsigned*>(plan_dev + PK), reinterpret_cast<unsigned*>(plan_dev + 2 * PK),
+                        n_live, reinterpret_cast<unsigned*>(plan_dev + 2 * PK + P), st));
+    CHECK(hip_status(hipMemcpyAsync(hp, plan_dev, 4 * plan_ints, hipMemcpyDeviceToHost, st)));
+    CHECK(hip_status(hipStreamSynchronize(st)));
+    for (int p = 0; p < P; ++p) {
+      bnd[p].resize(kKMax); rel[p].resize(kKMax);
+      for (int k = 0; k < kKMax; ++k) { bnd[p][k] = hp[p * kKMax + k]; rel[p][k] = hp[PK + p * kKMax + k]; }
+      seg_totals[p] = hp[2 * PK + p];
+      NV[p] = std::min<long long>(N, hp[2 * PK + P + p]);
+    }
+    n_total = hp[plan_ints - 1];
+    K = kKMax;
+    for (int k = 0; k < kKMax; ++k) {
+      bool all = true;
+      for (int p = 0; p < P; ++p) all = all && bnd[p][k] >= NV[p];
+      if (all) { K = k + 1; break; }
+    }
+  } else {
+    CHECK(hip_status(hipMemcpyAsync(hp, total, 4, hipMemcpyDeviceToHost, st)));
+    CHECK(hip_status(hipMemcpyAsync(hp + 1, n_live, 4 * P, hipMemcpyDeviceToHost, st)));
+    CHECK(hip_status(hipStreamSynchronize(st)));
+    n_total = hp[0];
+    for (int p = 0; p < P; ++p) { NV[p] = std::min<long long>(N, hp[1 + p]); seg_totals[p] = 0; }
+  }
+  state->n_total = n_total;
+  long long true_total = 0;
+  for (int p = 0; p < P; ++p) true_total += seg_totals[p];
+  const bool use_masks = planned && true_total < 4294967296ll - 64;
+
+  // slice descriptors (host arrays: they travel in the kernel arguments) and the slices' list capacities
+  std::vector<std::vector<int>> begins(K, std::vector<int>(P)), prefixes(K, std::vector<int>(P + 1));
+  std::vector<long long> n_of(K), I_of(K);
+  for (int k = 0; k < K; ++k) {
+    prefixes[k][0] = 0;
+    long long I_k = 0;
+    for (int p = 0; p < P; ++p) {
+      const long long lo = k == 0 ? 0 : std::min(bnd[p].empty() ? NV[p] : bnd[p][k - 1], NV[p]);
+      const long long hi = (k == K - 1) ? NV[p] : std::min(bnd[p][k], NV[p]);
+      begins[k][p] = (int)((long long)p * N + lo);
+      prefixes[k][p + 1] = prefixes[k][p] + (int)std::max(0ll, hi - lo);
+      if (planned) {
+        const long long hi_rel = (k == K - 1) ? seg_totals[p] : rel[p][k];
+        const long long lo_rel = k == 0 ? 0 : rel[p][k - 1];
+        I_k += (hi_rel - lo_rel) & 0xFFFFFFFFll;                  // upper bound: the ranks' bounding-box pairs
+      }
+    }
+    n_of[k] = prefixes[k][P];
+    I_of[k] = planned ? I_k : n_total;
+    if (n_of[k] == 0) I_of[k] = 0;
+  }
+  // what a slice needs is priced right before it is issued (a frame rarely needs all its planned slices: the headline
+  // plans five and uses one); the arena must then also hold the backward's buffers for the slices issued so far
+  long long maxI_issued = 0;
+  auto fits = [&](int k) -> bool {
+    if (I_of[k] >= 2147483647ll - kIdsPad) return false;             // caught separately below
+    const long long mI = std::max(maxI_issued, I_of[k]);
+    const long long bwd = d.reserve_backward ? Arena::up(48 * mI) + Arena::up(mI) + 2 * Arena::up(4ll * S * H * W) + 1024 : 0;
+    const long long need = Arena::up(A.off) + slice_bytes(d, n_of[k], I_of[k], use_masks, true_total) + bwd;
+    if (need <= arena_bytes) return true;
+    // say what this slice AND the next planned one would take: one retry usually settles a new high-water mark
+    state->arena_required = need + (k + 1 < K && I_of[k + 1] < 2147483647ll
+                                        ? slice_bytes(d, n_of[k + 1], I_of[k + 1], use_masks, true_total) + 49 * I_of[k + 1]
+                                        : 0);
+    return false;
+  };
+
+  unsigned char* tile_done = zeros_u8;                               // [P*T], all open
+  const bool holes0 = R > 1;                                         // the very first slice already has closed tiles
+  if (R > 1) {
+    // rolling-shutter bands: sub-pose p = s*R + r only ever composites tile rows [edge[r], edge[r+1]); every other
+    // tile of p is "done" from the start so the binning never emits for it
+    tile_done = tile_done_rs;
+    CHECK(hip_status(hipMemcpyAsync(tile_done, band_tile_done, P * T, hipMemcpyDeviceToDevice, st)));
+    CHECK(gs_tile_open_sat(P, H, W, tile_done, sat, open_bits, nullptr, st));
+  }
+  const unsigned invalid_key = (unsigned)(P * T);
+  const int key_bits = bits_for(P * T + 1);
+  int n_out = 0;
+  for (int k = 0; k < K; ++k) {
+    const bool first = k == 0, last = k == K - 1;
+    const long long n_k = n_of[k], I_k = I_of[k];
+    if (I_k >= 2147483647ll - kIdsPad) return GS_ERR_INVALID;        // a slice list is indexed with 31 bits: lower slice_base
+    if (!fits(k)) return GS_ERR_WORKSPACE;
+    maxI_issued = std::max(maxI_issued, I_k);
+    unsigned *slice_gi = nullptr, *counts = nullptr, *cum_k = nullptr, *total_k = nullptr, *mask_off = nullptr;
+    unsigned long long* masks = nullptr;
+    unsigned *vals = nullptr, *svals = nullptr, *sorted_ids = nullptr;
+    int* bins = nullptr;
+    unsigned char* tile_hot = zeros_u8 + (1 + k) * P * T;
+    int wave_per_g = 0;
+    if (n_k > 0) {
+      StageScope sc(ST_COUNT, st);
+      slice_gi = A.take<unsigned>(n_k);
+      counts = A.take<unsigned>(n_k);
+      const bool have_holes = !first || holes0;
+      // few Gaussians with large boxes (the nearest slice): one wave per Gaussian (boxes of up to 256 tiles are walked
+      // by single lanes where a wave holds several)
+      long long box_total = 0;
+      if (first) {
+        if (K == 1 || !planned) box_total = n_total;
+        else for (int p = 0; p < P; ++p) box_total += rel[p][0];
+      }
+      wave_per_g = (first && box_total > 128 * n_k) ? 1 : 0;
+      if (use_masks) {
+        masks = A.take<unsigned long long>(true_total / 64 + n_k + 2);
+        mask_off = A.take<unsigned>(n_k);
+      }
+      cum_k = A.take<unsigned>(n_k);
+      total_k = A.take<unsigned>(1);
+      const long long ws_b = gs_scan_workspace_bytes(n_k);
+      char* ws = A.take<char>(ws_b);
+      if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
+      CHECK(gs_slice_counts_exact((int)n_k, P, N, begins[k].data(), prefixes[k].data(), sorted_gi, records,
+                                  have_holes ? sat : nullptr, have_holes ? tile_done : nullptr, H, W, slice_gi, counts,
+                                  wave_per_g, masks ? cum : nullptr, masks, mask_off, have_holes ? open_bits : nullptr,
+                                  nullptr, st));
+      CHECK(gs_exclusive_scan_u32(n_k, counts, cum_k, total_k, ws, ws_b, st));
+      if (color_means && color_sh && color_viewmats)
+        // deferred SH colour for exactly the Gaussians this slice emits
+        CHECK(gs_slice_colors((int)n_k, slice_gi, counts, N, color_means, color_sh, color_K, color_degree,
+                              color_viewmats, records, st));
+    }
+    if (I_k > 0) {
+      unsigned* keys = A.take<unsigned>(I_k);
+      vals = A.take<unsigned>(I_k + kIdsPad);
+      unsigned* s_v0 = A.take<unsigned>(I_k + kIdsPad);
+      unsigned* s_k1 = A.take<unsigned>(I_k);
+      unsigned* s_v1 = A.take<unsigned>(I_k + kIdsPad);
+      unsigned* pa = A.take<unsigned>(I_k + kIdsPad);
+      unsigned* pb = A.take<unsigned>(I_k + kIdsPad);
+      const long long ws_b = gs_radix_sort_workspace_bytes(I_k, 0, key_bits);
+      char* ws = A.take<char>(ws_b);
+      bins = A.take<int>(2 * (P * T + 1));
+      if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
+      {
+        StageScope sc(ST_EMIT, st);
+        CHECK(gs_emit_open_intersects((int)n_k, N, H, W, slice_gi, counts, cum_k, records,
+                                      (!first || holes0) ? tile_done : nullptr, keys, vals, invalid_key, 1, wave_per_g,
+                                      masks, mask_off, tile_hot, st));
+      }
+      int r1 = 0, r2 = 0;
+      {
+        // payload = emission index e (iota); the record index of a sorted entry travels as a second payload: the
+        // final pass leaves it in sorted order for the scalar-cache compositors
+        StageScope sc(ST_TILE_SORT, st);
+        CHECK(gs_radix_sort_pairs_carry_u32(I_k, keys, s_v0, s_k1, s_v1, 1, 0, key_bits, ws, ws_b, &r1, vals, pa, pb, &r2,
+                                            total_k, st));
+      }
+      const unsigned* skeys = r1 == 1 ? s_k1 : keys;
+      svals = r1 == 1 ? s_v1 : s_v0;
+      sorted_ids = r2 == 1 ? pb : pa;
+      {
+        StageScope sc(ST_BIN_EDGES, st);
+        CHECK(gs_tile_bin_edges_u32(I_k, skeys, (int)(P * T + 1), bins, total_k, st));   // last row: culled pairs
+      }
+    }
+    if (I_k == 0 && !(first || last)) continue;
+    if (I_k == 0) {
+      svals = A.take<unsigned>(1 + kIdsPad);
+      bins = A.take<int>(2 * P * T);
+      if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
+      CHECK(hip_status(hipMemsetAsync(svals, 0, 4 * (1 + kIdsPad), st)));
+      CHECK(hip_status(hipMemsetAsync(bins, 0, 8 * P * T, st)));
+    }
+    int* fidx = A.take<int>((long long)S * H * W);
+    if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
+    {
+      StageScope sc(ST_RASTER_FWD, st);
+      CHECK(gs_rasterize_fwd_slice(records, reinterpret_cast<const int*>(svals), bins, band_edges, background, S, R, H, W,
+                                   out_img, out_T, live_T, fidx, tile_done, first ? 1 : 0, last ? 1 : 0,
+                                   I_k > 0 ? reinterpret_cast<const int*>(vals) : nullptr,
+                                   reinterpret_cast<const int*>(sorted_ids), I_k > 0 ? (int)std::min(n, 2147483647ll) : 0,
+                                   I_k > 0 ? out_depth : nullptr, I_k > 0 ? tile_hot : nullptr,
+                                   last ? nullptr : open_flags + k, d.fwd_variant, st));
+    }
+    if (I_k > 0) {
+      gs_frame_slice& sl = state->slice[n_out++];
+      sl.I = I_k; sl.n = (int)n_k; sl.wave_per_gaussian = wave_per_g; sl.first = first; sl.last = last;
+      sl.svals = A.offset_of(svals); sl.bins = A.offset_of(bins); sl.fidx = A.offset_of(fidx);
+      sl.gi_of_e = A.offset_of(vals); sl.sorted_ids = A.offset_of(sorted_ids); sl.slice_gi = A.offset_of(slice_gi);
+      sl.counts = A.offset_of(counts); sl.cum = A.offset_of(cum_k); sl.tile_hot = A.offset_of(tile_hot);
+      sl.n_emitted_dev = A.offset_of(total_k);
+    }
+    if (!last) {
+      // one read-back per slice: are there open tiles for the next planned slice?  One word, written by the compositor
+      // itself, read AFTER this slice's whole pipeline was issued
+      CHECK(hip_status(hipMemcpyAsync(hp, open_flags + k, 4, hipMemcpyDeviceToHost, st)));
+      CHECK(hip_status(hipStreamSynchronize(st)));
+      if (hp[0] == 0u) break;
+      StageScope sc(ST_SAT, st);
+      CHECK(gs_tile_open_sat(P, H, W, tile_done, sat, open_bits, nullptr, st));
+    }
+  }
+  state->n_slices = n_out;
+  state->arena_used = Arena::up(A.off);
+  return GS_OK;
+}
+
+// One frame, backward of the compositing: the slices in reverse, gradient tuples + segmented reduce into v_records
+// [P*N,12] (plain stores; rows the compositor never touched are left as they are) and touched [P*N] (zeroed by the
+// caller).  Replaces the rasterize_backward part of the fork's autograd.Function (Python original:
+// ops.sliced_backward).  The arena is the forward's; this call allocates behind state->arena_used.
+GS_EXPORT int gs_frame_backward(const gs_frame_state* state, const float* records, const float* background,
+                                const int* band_edges, const float* out_T, const float* v_img, const float* v_alpha,
+                                const float* cmb_scale, float cmb_gamma, float cmb_min_level, int bwd_variant,
+                                float* v_records, unsigned char* touched, void* arena_ptr, long long arena_bytes,
+                                void* stream_) {
+  if (!state || !records || !background || !band_edges || !out_T || !v_img || !v_records || !arena_ptr)
+    return GS_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream_;
+  const int S = state->S, R = state->R, H = state->H, W = state->W;
+  const long long n_rec = (long long)state->P * state->N;
+  Arena A(arena_ptr, arena_bytes, state->arena_used);
+  char* base = (char*)arena_ptr;
+  long long maxI = 0;
+  for (int k = 0; k < state->n_slices; ++k) maxI = std::max(maxI, state->slice[k].I);
+  // reverse-traversal state between slices: running T and (behind-colour . v_out), ONE float per pixel each; a frame
+  // that needed a single slice (the common case) carries none
+  float *bwd_T = nullptr, *bwd_B = nullptr;
+  if (state->n_slices > 1) {
+    bwd_T = A.take<float>((long long)S * H * W);
+    bwd_B = A.take<float>((long long)S * H * W);
+  }
+  // ONE tuple buffer for all slices: a slice's tuples are reduced before the next (nearer) slice writes its own
+  float* tuples = A.take<float>(12 * maxI);
+  unsigned char* flags = A.take<unsigned char>(maxI);
+  if (!A.ok) return GS_ERR_WORKSPACE;
+  if (bwd_T) {
+    CHECK(hip_status(hipMemcpyAsync(bwd_T, out_T, 4ll * S * H * W, hipMemcpyDeviceToDevice, st)));
+    CHECK(hip_status(hipMemsetAsync(bwd_B, 0, 4ll * S * H * W, st)));
+  }
+  for (int k = state->n_slices - 1; k >= 0; --k) {
+    const gs_frame_slice& sl = state->slice[k];
+    CHECK(hip_status(hipMemsetAsync(flags, 0, sl.I, st)));
+    {
+      StageScope sc(ST_RASTER_BWD, st);
+      CHECK(gs_rasterize_bwd_slice(records, reinterpret_cast<const int*>(base + sl.svals),
+                                   reinterpret_cast<const int*>(base + sl.bins), band_edges, background, S, R, H, W, out_T,
+                                   reinterpret_cast<const int*>(base + sl.fidx), v_img, v_alpha, bwd_T, bwd_B, v_records,
+                                   reinterpret_cast<const int*>(base + sl.gi_of_e), tuples, flags,
+                                   reinterpret_cast<const int*>(base + sl.sorted_ids), (int)std::min(n_rec, 2147483647ll),
+                                   reinterpret_cast<const unsigned char*>(base + sl.tile_hot), bwd_variant, cmb_scale,
+                                   cmb_gamma, cmb_min_level, st));
+    }
+    {
+      StageScope sc(ST_REDUCE, st);
+      // kernel form: a wave per Gaussian only for slices of few, large Gaussians (the choice the exact count made)
+      CHECK(gs_reduce_grad_tuples(sl.n, reinterpret_cast<const unsigned*>(base + sl.slice_gi),
+                                  reinterpret_cast<const unsigned*>(base + sl.counts),
+                                  reinterpret_cast<const unsigned*>(base + sl.cum), tuples, flags, v_records, touched,
+                                  sl.wave_per_gaussian ? sl.I : 0, st));
+    }
+  }
+  return GS_OK;
+}

@@ -97,7 +97,10 @@ class StageProfiler:
 
     def __init__(self, only=None):
         self.events = {}
+        self.native = {}                                     # stage -> [ms] drained from the library's own events
         self.only = None if only is None else set(only)     # restrict to these stage names (others cost nothing)
+        if _lib._lib is not None:
+            _lib._lib.gs_frame_profile_read(0, None, None)   # forget event pairs of an earlier profiler
 
     class _Ctx:
         def __init__(self, prof, name):
@@ -121,7 +124,17 @@ class StageProfiler:
 
     def summary_ms(self):
         torch.cuda.synchronize()
-        return {k: [a.elapsed_time(b) for a, b in v] for k, v in self.events.items()}
+        out = {k: [a.elapsed_time(b) for a, b in v] for k, v in self.events.items()}
+        # stages issued by the library itself (gs_frame_forward / gs_frame_backward record their own HIP events)
+        L = _L()
+        cap = 1 << 16
+        ids, ms = (ctypes.c_int * cap)(), (ctypes.c_float * cap)()
+        n = L.gs_frame_profile_read(cap, ids, ms)
+        for i in range(n):
+            self.native.setdefault(FRAME_STAGES[ids[i]], []).append(float(ms[i]))
+        for k, v in self.native.items():
+            out.setdefault(k, []).extend(v)
+        return out
 
 
 class _Null:
@@ -437,6 +450,116 @@ def _depth_rank(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: i
         _check(L.gs_gather_counts(n, _ptr(sorted_gi), _ptr(num_tiles_hit), _ptr(counts), _stream()), "gather counts")
         cum, total = exclusive_scan_u32(counts)
     return sorted_gi, cum, total, n_live
+
+
+# 1 (default): the depth-sliced pipeline of a frame is issued by the library itself (csrc/frame.hip: gs_frame_forward /
+# gs_frame_backward, one caller-owned arena, ~45 launches per frame from C++ instead of one ctypes call + several torch
+# allocations each); 0: the Python orchestration below (sliced_forward / sliced_backward) — same kernels, same results,
+# kept for A/B, for the non-default switches above and for debugging (GSD_SYNC_CHECK).
+NATIVE_FRAME = int(os.environ.get("GSD_NATIVE_FRAME", "1"))
+FRAME_STAGES = ("depth_sort", "count_scan", "slice_plan", "slice_count", "emit", "tile_sort", "bin_edges", "raster_fwd",
+                "slice_sat", "raster_bwd", "grad_reduce")
+
+
+class _FrameDesc(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int) for k in ("N", "P", "S", "R", "H", "W", "slice_base", "depth_sort_digit",
+                                             "fwd_variant", "reserve_backward")]
+
+
+class _FrameSlice(ctypes.Structure):
+    _fields_ = ([("I", ctypes.c_longlong)] + [(k, ctypes.c_int) for k in ("n", "wave_per_gaussian", "first", "last")] +
+                [(k, ctypes.c_longlong) for k in ("svals", "bins", "fidx", "gi_of_e", "sorted_ids", "slice_gi", "counts",
+                                                  "cum", "tile_hot", "n_emitted_dev")])
+
+
+class _FrameState(ctypes.Structure):
+    _fields_ = ([(k, ctypes.c_int) for k in ("n_slices", "P", "N", "S", "R", "H", "W", "reserved")] +
+                [(k, ctypes.c_longlong) for k in ("n_total", "arena_used", "arena_required")] +
+                [("slice", _FrameSlice * 16)])
+
+
+class _ArenaTooSmall(Exception):
+    pass
+
+
+_arena_hint = {}        # (device, N, P, S, H, W) -> bytes that held the last frame of that shape (+ margin)
+_pinned_cache = {}
+
+
+def _native_frame_ok() -> bool:
+    return bool(NATIVE_FRAME and EXACT_TILE_CULL and GRAD_TUPLES and COMPACT_EMIT and HIT_MASKS and DEPTH_SORT_SEGMENTED
+                and DEPTH_SORT_COMPACT and TILE_SORT_CARRY and DEVICE_SIZES and not SPECULATE and not LANE_STATS
+                and not SYNC_CHECK)
+
+
+def _profile_mask() -> int:
+    if profiler is None:
+        return 0
+    names = FRAME_STAGES if profiler.only is None else [n for n in FRAME_STAGES if n in profiler.only]
+    return sum(1 << FRAME_STAGES.index(n) for n in names)
+
+
+def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
+                         H: int, W: int, bg: Tensor, edges: Tensor, slice_base: int, color=None,
+                         out_depth: Optional[Tensor] = None, reserve_backward: bool = True):
+    """gs_frame_forward: -> (out_img [S,H,W,3], out_T [S,H,W], frame) ; frame = dict(arena, state) for
+    native_frame_backward.  Raises _ArenaTooSmall (after recording a larger size) when the arena did not hold the frame:
+    the caller projects again (the depth keys were consumed) and calls once more."""
+    global last_num_intersects, _slice_totals
+    L = _L()
+    dev = records.device
+    tx, ty = _tiles(H, W)
+    key = (str(dev), N, P, S, H, W)
+    n = P * N
+    nbytes = _arena_hint.get(key)
+    if nbytes is None:
+        # depth pre-sort + plan + one slice of the default budget; the library prices the real plan and says so if this
+        # is short (one retry per new high-water mark)
+        I0 = max(1, slice_base) * tx * ty * P
+        nbytes = 40 * n + 16 * S * H * W + 80 * I0 + (64 << 20)
+    arena = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    pin = _pinned_cache.get(str(dev))
+    need_pin = 4 * (2 * P * 16 + 2 * P + 1) + 64
+    if pin is None or pin.numel() < need_pin:
+        pin = _pinned_cache[str(dev)] = torch.empty(max(8192, need_pin), dtype=torch.uint8, pin_memory=True)
+    desc = _FrameDesc(N, P, S, R, H, W, int(slice_base), DEPTH_SORT_DIGIT, RASTER_FWD_VARIANT, int(reserve_backward))
+    state = _FrameState()
+    out_img = torch.empty(S, H, W, 3, device=dev)
+    out_T = torch.empty(S, H, W, device=dev)
+    band_done = _band_tile_done(S, R, ty, tx, dev) if R > 1 else None
+    c_means = c_sh = c_V = None
+    c_K = c_deg = 0
+    if color is not None:
+        c_means, c_sh, c_K, c_deg, c_V = color
+    L.gs_frame_profile_enable(_profile_mask())
+    st = L.gs_frame_forward(ctypes.byref(desc), _ptr(records), _ptr(depth_keys), _ptr(num_tiles_hit), _ptr(bg), _ptr(edges),
+                            _ptr(band_done), _ptr(c_means), _ptr(c_sh), int(c_K), int(c_deg), _ptr(c_V), _ptr(out_img),
+                            _ptr(out_T), _ptr(out_depth), _ptr(arena), arena.numel(), ctypes.c_void_p(pin.data_ptr()),
+                            pin.numel(), ctypes.byref(state), _stream())
+    if st == 3:
+        _arena_hint[key] = int(state.arena_required * 1.15) + (32 << 20)
+        raise _ArenaTooSmall()
+    _check(st, "frame_forward")
+    _arena_hint[key] = max(int(nbytes), int((state.arena_used + L.gs_frame_backward_bytes(ctypes.byref(state))) * 1.15))
+    last_num_intersects = int(state.n_total)
+    _slice_totals = [arena[sl.n_emitted_dev:sl.n_emitted_dev + 4].view(torch.int32)
+                     for sl in (state.slice[i] for i in range(state.n_slices))]
+    return out_img, out_T, dict(arena=arena, state=state)
+
+
+def native_frame_backward(frame, records: Tensor, bg: Tensor, edges: Tensor, out_T: Tensor, v_img: Tensor,
+                          v_alpha: Optional[Tensor], v_records: Tensor, touched: Tensor, combine=None):
+    L = _L()
+    cmb = combine if combine is not None else (None, 1.0, 0.0)
+    arena, state = frame["arena"], frame["state"]
+    L.gs_frame_profile_enable(_profile_mask())
+    st = L.gs_frame_backward(ctypes.byref(state), _ptr(records), _ptr(bg), _ptr(edges), _ptr(out_T), _ptr(v_img),
+                             _ptr(v_alpha), _ptr(cmb[0]), float(cmb[1]), float(cmb[2]), _bwd_variant(), _ptr(v_records),
+                             _ptr(touched), _ptr(arena), arena.numel(), _stream())
+    if st == 3:
+        raise _lib.HipLibraryError("frame_backward: the forward's arena cannot hold the backward's buffers "
+                                   "(call native_frame_forward with reserve_backward=True)")
+    _check(st, "frame_backward")
 
 
 def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
@@ -1100,7 +1223,7 @@ class _RenderSubposes(Function):
         # (the atomics backward of the pixel-velocity model tells "covers no tile" by an all-zero record)
         lean = DEPTH_SORT_SEGMENTED and DEPTH_SORT_COMPACT and GRAD_TUPLES and COMPACT_EMIT and EXACT_TILE_CULL
         defer_flags = int(bool(DEFER_COLOR)) | (2 if lean else 0)
-        with _stage("project_fwd"):
+        def _project():
             if pixvel:
                 _check(L.gs_project_pixvel_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
                                                _ptr(sh), K, args[4], _ptr(V), _ptr(twist), _ptr(times), args[5], args[6],
@@ -1112,6 +1235,9 @@ class _RenderSubposes(Function):
                                               _ptr(sh), K, args[4], _ptr(V), args[5], args[6], args[7], args[8], H, W,
                                               args[11], args[12], defer_flags, _ptr(records), _ptr(dkeys),
                                               _ptr(ntiles), _ptr(radii), _stream()), "project_fused_fwd")
+
+        with _stage("project_fwd"):
+            _project()
         bg = _background(background, dev)
         edges = _band_edges(H, R, dev)
         # SLICE_BASE == 0: one slice holding every intersection, through the very same kernels
@@ -1122,8 +1248,27 @@ class _RenderSubposes(Function):
         # optional fourth channel: sum of weight * camera-space depth per sample image (forward only)
         depth_acc = torch.zeros(S, H, W, device=dev) if return_depth else None
         ctx.prealloc = {} if (PREALLOC_BWD and any(ctx.needs_input_grad)) else None
-        out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE, color,
-                                                depth_acc, ctx.prealloc)
+        ctx.frame = None
+        if _native_frame_ok():
+            for attempt in range(3):
+                try:
+                    out_img, out_T, ctx.frame = native_frame_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges,
+                                                                     SLICE_BASE, color, depth_acc,
+                                                                     any(ctx.needs_input_grad))
+                    break
+                except _ArenaTooSmall:
+                    if attempt == 2:
+                        raise _lib.HipLibraryError("frame_forward: the arena estimate did not converge")
+                    # the depth keys were consumed by the pre-sort: project again, then retry with the larger arena
+                    if depth_acc is not None:
+                        depth_acc.zero_()
+                    with _stage("project_fwd"):
+                        _project()
+            slices = []
+            ctx.prealloc = None
+        else:
+            out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE, color,
+                                                    depth_acc, ctx.prealloc)
         ctx.slices = slices
         svals = bins = fidx = _placeholder_i32(dev)       # nothing to keep: the slices hold their own lists
         n_isect = last_num_intersects
@@ -1181,7 +1326,7 @@ class _RenderSubposes(Function):
                 v_img = samples
         # atomic-free path: only Gaussians the compositor touched get a gradient record (plain stores) and a
         # `touched` flag; the projection backward skips everything else, so v_records needs no 240 MB memset
-        all_tuples = all(sl["gi_of_e"] is not None for sl in ctx.slices)
+        all_tuples = ctx.frame is not None or all(sl["gi_of_e"] is not None for sl in ctx.slices)
         pre = ctx.prealloc if ctx.prealloc else {}
         ctx.prealloc = None
         if all_tuples and "touched" in pre:
@@ -1193,7 +1338,9 @@ class _RenderSubposes(Function):
             v_records = torch.zeros(P * N, REC, device=dev)
             touched = None
 
-        if ctx.sliced:
+        if ctx.frame is not None:
+            native_frame_backward(ctx.frame, records, bg, edges, out_T, v_img, v_al, v_records, touched, combine)
+        elif ctx.sliced:
             sliced_backward(records, ctx.slices, S, R, H, W, bg, edges, out_T, v_img, v_al, v_records, touched,
                             combine)
         else:

@@ -388,6 +388,57 @@ int gs_dp_pack_masked_rows(int N, const unsigned char* mask, const int* pos, int
 int gs_dp_scatter_add_payload(int cap, const float* payload, int n_tensors, float* const* grads, const int* widths,
                               float scale, void* stream);
 
+/* ---- one frame's depth-sliced pipeline issued by the library itself (csrc/frame.hip) -------------------------------
+ * What the fork's Python layer does between project_gaussians and the returned image — binning, sorting and compositing
+ * (boundary §8b: "caller owns all tensors; the library allocates nothing; workspace passed in") — as
+ * TWO calls instead of ~45 per frame from the host language: every buffer comes out of ONE caller-owned arena (bump
+ * allocation), the slice plan and one word per depth slice come back through caller-owned pinned host memory, and the
+ * backward walks the slice table the forward leaves in *state (a plain host struct; byte offsets into the arena). */
+#define GS_FRAME_MAX_SLICES 16
+typedef struct gs_frame_desc {
+  int N, P, S, R, H, W;      /* Gaussians, sub-poses (= S*R), sample images, rolling-shutter bands, image size */
+  int slice_base;            /* average tile-list budget of the first depth slice (doubles per slice); 0: one slice */
+  int depth_sort_digit;      /* widest radix digit of the depth pre-sort (8..11) */
+  int fwd_variant;           /* as gs_rasterize_fwd_slice */
+  int reserve_backward;      /* 1: the arena must also hold what gs_frame_backward will take */
+} gs_frame_desc;
+typedef struct gs_frame_slice {
+  long long I;               /* capacity of the slice's lists (its ranks' bounding-box pairs); real count on the device */
+  int n, wave_per_gaussian, first, last;
+  long long svals, bins, fidx, gi_of_e, sorted_ids, slice_gi, counts, cum, tile_hot, n_emitted_dev;   /* arena offsets */
+} gs_frame_slice;
+typedef struct gs_frame_state {
+  int n_slices, P, N, S, R, H, W, reserved;
+  long long n_total;         /* bounding-box tile intersections of the frame */
+  long long arena_used;      /* bytes of the arena the forward occupies (kept alive until the backward ran) */
+  long long arena_required;  /* on GS_ERR_WORKSPACE (3): an arena size that holds the frame as far as it is known */
+  gs_frame_slice slice[GS_FRAME_MAX_SLICES];
+} gs_frame_state;
+/* records / depth_keys (consumed) / num_tiles_hit: outputs of gs_project_fused_fwd or gs_project_pixvel_fwd;
+ * band_tile_done [P*T] u8: initial done mask of a rolling-shutter frame (R > 1; NULL otherwise); color_*: deferred SH
+ * colour inputs (all NULL: records already hold colours); out_depth nullable [S*H*W] (zeroed by the caller);
+ * host_pinned: >= 4*(2*P*16 + 2*P + 1) + 64 bytes of pinned host memory.  On GS_ERR_WORKSPACE call again with a larger
+ * arena AND fresh projection outputs (depth_keys was consumed). */
+int gs_frame_forward(const gs_frame_desc* desc, float* records, unsigned* depth_keys, const int* num_tiles_hit,
+                     const float* background /*3*/, const int* band_edges /*R+1*/, const unsigned char* band_tile_done,
+                     const float* color_means, const float* color_sh, int color_K_stride, int color_sh_degree,
+                     const float* color_viewmats /*P*16*/, float* out_img /*S*H*W*3*/, float* out_T /*S*H*W*/,
+                     float* out_depth, void* arena, long long arena_bytes, void* host_pinned,
+                     long long host_pinned_bytes, gs_frame_state* state, void* stream);
+long long gs_frame_backward_bytes(const gs_frame_state* state);
+/* v_records [P*N*12] (rows the compositor never touched are left as they are), touched [P*N] u8 zeroed by the caller;
+ * v_img / cmb_* / bwd_variant as in gs_rasterize_bwd_slice; allocates behind state->arena_used of the SAME arena */
+int gs_frame_backward(const gs_frame_state* state, const float* records, const float* background, const int* band_edges,
+                      const float* out_T, const float* v_img, const float* v_alpha, const float* cmb_scale,
+                      float cmb_gamma, float cmb_min_level, int bwd_variant, float* v_records, unsigned char* touched,
+                      void* arena, long long arena_bytes, void* stream);
+/* measurement only (not thread-safe): HIP events around the stages of the two calls above.  stage_mask bit i enables
+ * stage i of {depth_sort, count_scan, slice_plan, slice_count, emit, tile_sort, bin_edges, raster_fwd, slice_sat,
+ * raster_bwd, grad_reduce}; gs_frame_profile_read drains the pairs recorded since the last call (synchronising on
+ * them) into stage_ids / ms and returns how many it wrote. */
+int gs_frame_profile_enable(unsigned stage_mask);
+int gs_frame_profile_read(int max_events, int* stage_ids, float* ms);
+
 /* ---- the step after the path: image loss + optimizer ---------------------------------------------
  * Replaces what the nerfstudio fork's trainer runs right after get_outputs (reached from /root/reference/train.py:115-122):
  * splatfacto's loss  L = (1 - lambda) * mean|gt - pred| + lambda * (1 - SSIM(pred, gt))  (pytorch_msssim SSIM: 11x11

@@ -1523,3 +1523,102 @@ def test_more_intersections_than_the_slice_plan_covers(gs, dev):
     assert torch.equal(img_f, img_p)
     for k in g_f:
         assert rel_max(g_f[k].cpu(), g_p[k].cpu()) < GRAD_RTOL, k
+
+
+@pytest.mark.parametrize("case", ["blur", "rolling_shutter", "multi_slice", "one_slice_no_plan", "pixel_velocity",
+                                  "tiny_budget"])
+def test_native_frame_orchestration_equals_python_orchestration(gs, dev, case):
+    """gs_frame_forward / gs_frame_backward (csrc/frame.hip: the slice pipeline issued from C++
+    out of ONE caller-owned arena) against ops.sliced_forward / sliced_backward (the same kernels launched one by one
+    from Python with torch allocations).  Same launches in the same order on the atomic-free path: images, alphas, the
+    depth channel, radii and EVERY gradient must be bit-identical; the per-slice emitted counts too.  Cases: motion
+    blur, rolling-shutter bands (initially closed tiles), a fitted-model-like scene that needs several depth slices,
+    slicing switched off, the pixel-velocity model, and a budget so small that the 16 planned boundaries end early."""
+    from gsdeblur_amd import ops
+    n, W, H, S, R, prof, base, mult = 30000, 200, 136, 3, 1, "survey", None, 3.0
+    if case == "rolling_shutter":
+        S, R = 2, 4
+    elif case == "multi_slice":
+        n, prof, base, mult = 60000, "trained", 24, 6.0
+    elif case == "one_slice_no_plan":
+        base = 0
+    elif case == "tiny_budget":
+        n, W, H, S, base, mult = 60000, 32, 32, 2, 1, 12.0
+    sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=11, scale_mult=mult, profile=prof), dev)
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, R, 1 / 30 if R > 1 else 0.0)
+    times_t = torch.tensor(times, device=dev)
+    g = torch.Generator().manual_seed(4)
+    wt, wa = torch.rand(H, W, 3, generator=g).to(dev), torch.rand(S, H, W, generator=g).to(dev)
+    saved = (ops.NATIVE_FRAME, ops.SLICE_BASE)
+    res = []
+    try:
+        for native in (1, 0):
+            ops.NATIVE_FRAME = native
+            if base is not None:
+                ops.SLICE_BASE = base
+            p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+            lin = (sc["lin_vel"] * 5).clone().requires_grad_(True)
+            ang = (sc["ang_vel"] * 3).clone().requires_grad_(True)
+            V = sc["viewmat"].clone().requires_grad_(True)
+            if case == "pixel_velocity":
+                out = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["opacity_logits"]),
+                                         p["sh"], V, None, S, R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2,
+                                         min_rgb_level=10.0, lin_vel=lin, ang_vel=ang, times=times_t, return_depth=True)
+            else:
+                vms = gs.subpose_viewmats(V, lin, ang, times_t)
+                out = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["opacity_logits"]),
+                                         p["sh"], vms, None, S, R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2,
+                                         min_rgb_level=10.0, return_depth=True)
+            rgb, alphas, radii, depth = out
+            assert (ops._native_frame_ok() and native == 1) or native == 0
+            ((rgb * wt).sum() + (alphas * wa).sum()).backward()
+            grads = {k: v.grad.clone() for k, v in p.items()}
+            grads.update(lin=lin.grad.clone(), ang=ang.grad.clone(), V=V.grad.clone())
+            res.append((rgb.detach().clone(), alphas.detach().clone(), radii.clone(), depth.clone(), grads,
+                        ops.last_num_intersects, [int(v) for v in ops.last_slice_intersects if int(v) > 0]))
+    finally:
+        ops.NATIVE_FRAME, ops.SLICE_BASE = saved
+    a, b = res
+    assert a[5] == b[5] and a[6] == b[6] and a[5] > 0
+    if case in ("multi_slice", "tiny_budget"):
+        assert len(a[6]) >= 2
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    for k in a[4]:
+        if k in ("lin", "ang", "V"):
+            # the viewmat gradient is summed over the Gaussians with fp32 atomics (order differs run to run)
+            assert rel_max(a[4][k].cpu(), b[4][k].cpu()) < 1e-4, k
+        else:
+            assert torch.equal(a[4][k], b[4][k]), k
+    assert float(a[0].abs().max()) > 0 and float(a[4]["means"].abs().max()) > 0
+
+
+def test_native_frame_grows_its_arena_and_reports_stage_times(gs, dev):
+    """the first frame of a new shape may not fit the arena estimate: the library prices the slice plan, says what it
+    needs, the host projects again and retries — the result is the one a large arena gives; the library's own HIP
+    events feed ops.StageProfiler like the Python orchestration's did"""
+    from gsdeblur_amd import ops
+    n, W, H, S = 40000, 160, 96, 2
+    sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=3, scale_mult=8.0), dev)
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, 1, 0.0)
+    vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"], sc["ang_vel"], torch.tensor(times, device=dev))
+
+    def render():
+        return gs.render_combined(sc["means"], sc["log_scales"].exp(), sc["quats"], torch.sigmoid(sc["opacity_logits"]),
+                                  sc["sh"], vms, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2)[0]
+    ref = render()
+    key = (str(dev), n, S, S, H, W)
+    assert key in ops._arena_hint
+    ops._arena_hint[key] = 1 << 20                      # far too small: forces the retry path
+    got = render()
+    assert torch.equal(ref, got) and ops._arena_hint[key] > (1 << 20)
+    ops.profiler = ops.StageProfiler()
+    try:
+        p = sc["means"].clone().requires_grad_(True)
+        img = gs.render_combined(p, sc["log_scales"].exp(), sc["quats"], torch.sigmoid(sc["opacity_logits"]), sc["sh"], vms,
+                                 None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2)[0]
+        img.sum().backward()
+        ms = ops.profiler.summary_ms()
+    finally:
+        ops.profiler = None
+    for stage in ("depth_sort", "slice_count", "tile_sort", "raster_fwd", "raster_bwd", "grad_reduce", "project_fwd"):
+        assert stage in ms and len(ms[stage]) >= 1 and all(t > 0 for t in ms[stage]), stage
