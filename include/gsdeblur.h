@@ -316,7 +316,9 @@ int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const i
                                                            tile runs the loop with the alpha clamp*/,
                            int* open_flag /*NULL, or one int zeroed by the caller: set to 1 when any tile is still open
                                             after this slice (last == 0 only)*/,
-                           int variant /*0 = default; 1, 2 = v_readlane compositor without / with the empty-pair skip*/,
+                           int variant /*0 = default; 1, 2 = v_readlane compositor without / with the empty-pair skip;
+                                         3 = the 4x4-block lock-step walk for slices of small splats (needs sorted_ids;
+                                         same images, bit for bit)*/,
                            void* stream);
 /* Debug twin of gs_rasterize_fwd_slice (no upstream counterpart; DESIGN.md section 5 "lane utilisation"): same outputs
  * through the round-1 compositor, and the counters of its walk summed into stats[13] (u64, zeroed by the caller):
@@ -399,7 +401,7 @@ typedef struct gs_frame_desc {
   int N, P, S, R, H, W;      /* Gaussians, sub-poses (= S*R), sample images, rolling-shutter bands, image size */
   int slice_base;            /* average tile-list budget of the first depth slice (doubles per slice); 0: one slice */
   int depth_sort_digit;      /* widest radix digit of the depth pre-sort (8..11) */
-  int fwd_variant;           /* as gs_rasterize_fwd_slice */
+  int fwd_variant;           /* as gs_rasterize_fwd_slice (3 = lock-step 4x4 blocks: same images, not faster) */
   int reserve_backward;      /* 1: the arena must also hold what gs_frame_backward will take */
 } gs_frame_desc;
 typedef struct gs_frame_slice {
