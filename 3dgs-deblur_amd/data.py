@@ -104,6 +104,45 @@ def load_transforms(path: str, eval_mode: str = "interval", eval_interval: int =
     )
 
 
+def undistort_image(img: torch.Tensor, fx: float, fy: float, cx: float, cy: float,
+                    distortion: Dict[str, float]) -> torch.Tensor:
+    """[H,W,3] image taken through OpenCV's radial-tangential lens model (k1, k2, k3, p1, p2 — the fields
+    /root/reference/process_synthetic_inputs.py:113-129 and combine.py:109-131 write) -> the image an ideal pinhole
+    camera with the SAME intrinsics would see (bilinear; pixels that fall outside the source stay black).  nerfstudio's
+    datamanager undistorts the training images once up front (cv2.undistort) — the rasterizer only knows pinhole
+    cameras.  All-zero coefficients return the input unchanged."""
+    k1, k2, k3 = (float(distortion.get(k, 0.0)) for k in ("k1", "k2", "k3"))
+    p1, p2 = float(distortion.get("p1", 0.0)), float(distortion.get("p2", 0.0))
+    if k1 == k2 == k3 == p1 == p2 == 0.0:
+        return img
+    H, W = img.shape[0], img.shape[1]
+    dev, dt = img.device, torch.float64
+    v, u = torch.meshgrid(torch.arange(H, device=dev, dtype=dt), torch.arange(W, device=dev, dtype=dt), indexing="ij")
+    # pixel CENTRES at +0.5 (the convention of the rasterizer and of nerfstudio's cameras)
+    x, y = (u + 0.5 - cx) / fx, (v + 0.5 - cy) / fy
+    r2 = x * x + y * y
+    radial = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3))
+    xd = x * radial + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
+    yd = y * radial + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
+    us, vs = xd * fx + cx - 0.5, yd * fy + cy - 0.5            # source pixel INDEX coordinates
+    grid = torch.stack([(us + 0.5) / W * 2.0 - 1.0, (vs + 0.5) / H * 2.0 - 1.0], dim=-1)[None].to(img.dtype)
+    out = torch.nn.functional.grid_sample(img.permute(2, 0, 1)[None], grid, mode="bilinear", padding_mode="zeros",
+                                          align_corners=False)
+    return out[0].permute(1, 2, 0).contiguous()
+
+
+def load_scene_images(scene: "TransformsScene", device="cpu", undistort: bool = True) -> List[torch.Tensor]:
+    """every frame's image, undistorted with the scene's lens coefficients when any is non-zero (what nerfstudio's
+    datamanager does before the first iteration)"""
+    out = []
+    for cam, path in zip(scene.cameras, scene.image_paths):
+        img = load_image(path, device)
+        if undistort and any(v != 0.0 for v in scene.distortion.values()):
+            img = undistort_image(img, cam.fx, cam.fy, cam.cx, cam.cy, scene.distortion)
+        out.append(img)
+    return out
+
+
 def load_image(path: str, device="cpu") -> torch.Tensor:
     """[H,W,3] float32 in 0..1.  `.npy` (float, already 0..1) or anything PIL decodes (8-bit PNG / JPEG)."""
     if path.endswith(".npy"):

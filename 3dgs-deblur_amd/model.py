@@ -47,7 +47,8 @@ class SplatfactoDeblurConfig:
     gamma: float = 2.2                       # train.py:62 (gamma=1 when gamma correction is off)
     min_rgb_level: float = 0.0               # train.py:60 (10 with gamma correction)
     background_color: str = "black"          # train.py:17 ("auto" = learnable)
-    num_downscales: int = 0                  # train.py:14 (resolution schedule lives in the trainer)
+    num_downscales: int = 0                  # train.py:14; splatfacto's default is 2: training starts at 1/2^n resolution
+    resolution_schedule: int = 3000          # ... and doubles every this many steps (nerfstudio 1.1.0 default)
     cull_scale_thresh: float = 0.5           # train.py:18 (densification; carried for CLI parity)
     optimize_eval_velocities: bool = True    # train.py:20
     output_depth_during_training: bool = False
@@ -72,6 +73,13 @@ class Camera:
     height: int
     metadata: Dict = field(default_factory=dict)  # cam_idx, camera_linear_velocity, camera_angular_velocity,
     #                                               exposure_time, rolling_shutter_time
+
+    def rescaled(self, d: int) -> "Camera":
+        """the same camera at 1/d of the resolution (nerfstudio's rescale_output_resolution(1/d), floor rounding):
+        what splatfacto renders while its resolution schedule is active"""
+        s = 1.0 / float(d)
+        return Camera(self.camera_to_world, self.fx * s, self.fy * s, self.cx * s, self.cy * s,
+                      int(self.width * s), int(self.height * s), self.metadata)
 
 
 def _skew(w: Tensor) -> Tensor:
@@ -219,6 +227,9 @@ class SplatfactoDeblurModel(nn.Module):
         (/root/reference/train.py:180-183, README.md:197) needs for the evaluation frames."""
         cfg = self.config
         dev = self.means.device
+        d = self.downscale_factor()
+        if d > 1:
+            camera = camera.rescaled(d)          # splatfacto: camera.rescale_output_resolution(1 / d) while training
         viewmat, lin, ang = self._viewmat_and_velocity(camera)
         S, R, times = self._schedule(camera)
         times_t = self._const(times)
@@ -266,6 +277,14 @@ class SplatfactoDeblurModel(nn.Module):
         else:
             out["depth"] = None
         return out
+
+    def downscale_factor(self) -> int:
+        """splatfacto's `_get_downscale_factor` (nerfstudio 1.1.0): while training, render (and compare) at
+        1 / 2^max(num_downscales - step // resolution_schedule, 0) of the camera's resolution; full size otherwise
+        (/root/reference/train.py:14 sets num-downscales 0 for the low-resolution synthetic sets)."""
+        if not self.training:
+            return 1
+        return 2 ** max(int(self.config.num_downscales) - int(self.step) // max(1, int(self.config.resolution_schedule)), 0)
 
     @torch.no_grad()
     def get_outputs_for_camera(self, camera: Camera) -> Dict[str, Tensor]:

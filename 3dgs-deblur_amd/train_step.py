@@ -61,6 +61,14 @@ def image_loss_torch(pred: Tensor, gt: Tensor, ssim_lambda: float = 0.2) -> Tens
     return (1.0 - ssim_lambda) * l1 + ssim_lambda * (1.0 - ssim(pred, gt))
 
 
+def downscale_image(img: Tensor, d: int) -> Tensor:
+    """[H,W,3] -> [H//d, W//d, 3] by averaging d x d blocks: splatfacto's `_downscale_if_required` / `resize_image`
+    (a stride-d convolution with uniform weights) applied to the ground truth while the resolution schedule is active"""
+    if d <= 1:
+        return img
+    return F.avg_pool2d(img.permute(2, 0, 1)[None], kernel_size=d, stride=d)[0].permute(1, 2, 0).contiguous()
+
+
 def scale_regularization(log_scales: Tensor, max_gauss_ratio: float = 10.0) -> Tensor:
     """Penalise needle-like Gaussians (PhysGaussian-style, as in splatfacto): mean(max(s_max/s_min, r) - r)."""
     s = torch.exp(log_scales)
@@ -110,6 +118,7 @@ def train_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.O
     for o in optimizers.values():
         o.zero_grad(set_to_none=True)
     out = model.get_outputs(camera)
+    gt_image = downscale_image(gt_image, model.downscale_factor())     # num_downscales resolution schedule
     loss = image_loss(out["rgb"], gt_image, ssim_lambda)
     if model.config.use_scale_regularization:
         loss = loss + scale_regularization(model.scales)
@@ -147,6 +156,7 @@ def eval_camera_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.o
     for o in cam_opts:
         o.zero_grad(set_to_none=True)
     out = model.get_outputs(camera, detach_gaussians=True)
+    gt_image = downscale_image(gt_image, model.downscale_factor())
     loss = image_loss(out["rgb"], gt_image, ssim_lambda)
     loss.backward()
     optimizers_step(cam_opts)

@@ -210,3 +210,59 @@ def test_optimize_eval_cameras_moves_only_the_eval_cameras(gs, dev, tmp_path):
         assert torch.equal(v.detach(), before[k]) and v.grad is None, k
     adj = model.pose_adjustment.detach()
     assert adj[e].abs().sum().item() > 0 and adj[[i for i in range(len(scene.cameras)) if i != e]].abs().sum().item() == 0
+
+
+def test_resolution_schedule_and_downscaled_ground_truth(gs):
+    """`num_downscales` (/root/reference/train.py:14; splatfacto 1.1.0 `_get_downscale_factor`): while training the
+    model renders at 1 / 2^max(n - step // schedule, 0) of the camera's resolution and the ground truth is averaged
+    over d x d blocks; evaluation is always full size"""
+    cfg = gs.SplatfactoDeblurConfig(num_downscales=2, resolution_schedule=100)
+    sc = gs.data.synthetic_scene(50, 64, 48, seed=1)
+    m = gs.SplatfactoDeblurModel.from_scene(cfg, sc, "cpu")
+    m.train()
+    got = []
+    for step in (0, 99, 100, 199, 200, 5000):
+        m.step = step
+        got.append(m.downscale_factor())
+    assert got == [4, 4, 2, 2, 1, 1]
+    m.eval()
+    m.step = 0
+    assert m.downscale_factor() == 1
+    cam = gs.Camera(torch.eye(4)[:3], 50.0, 52.0, 32.0, 24.0, 65, 49, {"cam_idx": 0})
+    c4 = cam.rescaled(4)
+    assert (c4.width, c4.height) == (16, 12) and c4.fx == 12.5 and c4.cy == 6.0 and c4.metadata is cam.metadata
+    img = torch.arange(49 * 65 * 3, dtype=torch.float32).reshape(49, 65, 3)
+    small = gs.training.downscale_image(img, 4)
+    assert small.shape == (12, 16, 3)
+    assert torch.allclose(small[2, 3], img[8:12, 12:16].reshape(-1, 3).mean(0))
+    assert gs.training.downscale_image(img, 1) is img
+
+
+def test_undistort_image_inverts_the_opencv_lens_model(gs):
+    """k1, k2, p1, p2 of transforms.json (/root/reference/process_synthetic_inputs.py:113-129; combine.py:109-131 may
+    carry COLMAP's estimates) are no longer parsed and ignored: `undistort_image` resamples a frame to the pinhole
+    camera the rasterizer models.  Check: render an analytic pattern THROUGH the lens model, undistort, compare with
+    the pattern seen by the ideal pinhole."""
+    H, W, fx, fy, cx, cy = 96, 128, 90.0, 92.0, 64.0, 48.0
+    dist = {"k1": -0.12, "k2": 0.03, "p1": 0.004, "p2": -0.003}
+
+    def pattern(x, y):                                   # smooth in normalised pinhole coordinates
+        return torch.stack([0.5 + 0.4 * torch.sin(5 * x) * torch.cos(4 * y), 0.5 + 0.4 * torch.cos(3 * x + 2 * y),
+                            0.5 + 0.3 * torch.sin(6 * y)], -1)
+
+    v, u = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    xd, yd = (u + 0.5 - cx) / fx, (v + 0.5 - cy) / fy     # what a distorted sensor pixel measures ...
+    x, y = xd.clone(), yd.clone()                         # ... is the scene point whose DISTORTED position it is:
+    for _ in range(30):                                   # invert the model by fixed-point iteration
+        r2 = x * x + y * y
+        rad = 1 + r2 * (dist["k1"] + r2 * dist["k2"])
+        dx = 2 * dist["p1"] * x * y + dist["p2"] * (r2 + 2 * x * x)
+        dy = dist["p1"] * (r2 + 2 * y * y) + 2 * dist["p2"] * x * y
+        x, y = (xd - dx) / rad, (yd - dy) / rad
+    distorted = pattern(x, y).float()
+    ideal = pattern(xd, yd).float()                       # the pinhole image on the same pixel grid
+    got = gs.data.undistort_image(distorted, fx, fy, cx, cy, dist)
+    inner = (slice(8, H - 8), slice(10, W - 10))          # away from the border (source pixels outside the frame)
+    assert (got[inner] - ideal[inner]).abs().max() < 2e-3
+    assert (distorted[inner] - ideal[inner]).abs().max() > 2e-2      # the lens really moved things
+    assert gs.data.undistort_image(distorted, fx, fy, cx, cy, {"k1": 0, "k2": 0, "p1": 0, "p2": 0}) is distorted

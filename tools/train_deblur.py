@@ -46,7 +46,7 @@ def main():
         SD.generate(root, dev, args.width, args.height, args.frames, args.gaussians, speed=args.speed,
                     rolling_shutter_time=args.rolling_shutter_time)
     scene = gs.load_transforms(root)
-    images = [gs.data.load_image(p, dev) for p in scene.image_paths]
+    images = gs.data.load_scene_images(scene, dev)          # undistorts when the scene carries lens coefficients
     xyz, rgb = gs.load_seed_points_ply(scene.ply_file_path)
     if args.pose_noise > 0:
         g = torch.Generator().manual_seed(3)
