@@ -346,6 +346,196 @@ GS_HD void cov3d_bwd(const float s[3], float glob, const float q[4], const float
   v_q[3] = (g[3] - z * dotp) * inv;
 }
 
+// ---- the covariance chain in a chosen precision (round 3: needle Gaussians) -----------------------------------------
+// The VJP  v_conic -> v_cov2d -> v_cov3d -> (v_scale, v_quat)  cancels catastrophically for a splat whose 2-D
+// covariance is ill conditioned (a needle: det = a c - b^2 is 1e-3 .. 1e-5 of a c): in fp32 the gradient along the
+// long axis — a small difference of large terms in every basis but the eigenbasis — comes out percent-level wrong
+// (found by tests/fuzz_paths.py in round 2, profiles/r02_run28_fuzz.log).  The functions below restate that chain
+// (same formulas as project_one / project_one_bwd / cov3d_bwd above) on a scalar type S; the kernels run them in
+// double for the Gaussians that need it, starting again from the fp32 PARAMETERS (the fp32 cov2d itself carries a
+// relative error of eps * cond, so the chain must not start from it).
+template <typename S> struct ProjCtxT {
+  S pc[3], rz, tx, ty;
+  int clamp_x, clamp_y;
+  S J00, J02, J11, J12, T[6], a, b, c, a0, c0, det, det0;
+};
+
+template <typename S> GS_HD S gs_sqrt_t(S x);
+template <> GS_HD float gs_sqrt_t<float>(float x) { return sqrtf(x); }
+template <> GS_HD double gs_sqrt_t<double>(double x) { return ::sqrt(x); }
+
+template <typename S>
+GS_HD void quat_to_rotmat_t(const float q[4], S R[9], S qn[4], S* inv_norm) {
+  const S q0 = (S)q[0], q1 = (S)q[1], q2 = (S)q[2], q3 = (S)q[3];
+  const S inv = S(1) / gs_sqrt_t<S>(((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3);
+  const S w = q0 * inv, x = q1 * inv, y = q2 * inv, z = q3 * inv;
+  qn[0] = w; qn[1] = x; qn[2] = y; qn[3] = z; *inv_norm = inv;
+  R[0] = S(1) - S(2) * (y * y + z * z); R[1] = S(2) * (x * y - w * z);        R[2] = S(2) * (x * z + w * y);
+  R[3] = S(2) * (x * y + w * z);        R[4] = S(1) - S(2) * (x * x + z * z); R[5] = S(2) * (y * z - w * x);
+  R[6] = S(2) * (x * z - w * y);        R[7] = S(2) * (y * z + w * x);        R[8] = S(1) - S(2) * (x * x + y * y);
+}
+
+template <typename S>
+GS_HD void scale_rot_to_cov3d_t(const float s[3], float glob, const S R[9], S M[9], S c[6]) {
+  const S s0 = (S)glob * (S)s[0], s1 = (S)glob * (S)s[1], s2 = (S)glob * (S)s[2];
+  M[0] = R[0] * s0; M[1] = R[1] * s1; M[2] = R[2] * s2;
+  M[3] = R[3] * s0; M[4] = R[4] * s1; M[5] = R[5] * s2;
+  M[6] = R[6] * s0; M[7] = R[7] * s1; M[8] = R[8] * s2;
+  c[0] = (M[0] * M[0] + M[1] * M[1]) + M[2] * M[2];
+  c[1] = (M[0] * M[3] + M[1] * M[4]) + M[2] * M[5];
+  c[2] = (M[0] * M[6] + M[1] * M[7]) + M[2] * M[8];
+  c[3] = (M[3] * M[3] + M[4] * M[4]) + M[5] * M[5];
+  c[4] = (M[3] * M[6] + M[4] * M[7]) + M[5] * M[8];
+  c[5] = (M[6] * M[6] + M[7] * M[7]) + M[8] * M[8];
+}
+
+// geometry of project_one without its culling decisions (the caller took those in fp32): camera-space mean, the
+// fov-clamped Jacobian, T = J W, cov2d before / after the dilation, both determinants
+template <typename S>
+GS_HD void project_ctx_t(const float mean[3], const S c3[6], const float* V, float fx_, float fy_, int img_w, int img_h,
+                         ProjCtxT<S>& k) {
+  const S fx = (S)fx_, fy = (S)fy_;
+  const S m0 = (S)mean[0], m1 = (S)mean[1], m2 = (S)mean[2];
+  const S px = (((S)V[0] * m0 + (S)V[1] * m1) + (S)V[2] * m2) + (S)V[3];
+  const S py = (((S)V[4] * m0 + (S)V[5] * m1) + (S)V[6] * m2) + (S)V[7];
+  const S pz = (((S)V[8] * m0 + (S)V[9] * m1) + (S)V[10] * m2) + (S)V[11];
+  k.pc[0] = px; k.pc[1] = py; k.pc[2] = pz;
+  const S rz = S(1) / pz;
+  k.rz = rz;
+  const S lim_x = (S)K::kFovLimit * (S(0.5) * (S)img_w / fx), lim_y = (S)K::kFovLimit * (S(0.5) * (S)img_h / fy);
+  const S xz = px * rz, yz = py * rz;
+  k.clamp_x = xz > lim_x ? 1 : (xz < -lim_x ? -1 : 0);
+  k.clamp_y = yz > lim_y ? 1 : (yz < -lim_y ? -1 : 0);
+  const S tx = pz * (xz > lim_x ? lim_x : (xz < -lim_x ? -lim_x : xz));
+  const S ty = pz * (yz > lim_y ? lim_y : (yz < -lim_y ? -lim_y : yz));
+  k.tx = tx; k.ty = ty;
+  const S rz2 = rz * rz;
+  k.J00 = fx * rz; k.J02 = -(fx * tx) * rz2; k.J11 = fy * rz; k.J12 = -(fy * ty) * rz2;
+  S* T = k.T;
+  T[0] = k.J00 * (S)V[0] + k.J02 * (S)V[8];
+  T[1] = k.J00 * (S)V[1] + k.J02 * (S)V[9];
+  T[2] = k.J00 * (S)V[2] + k.J02 * (S)V[10];
+  T[3] = k.J11 * (S)V[4] + k.J12 * (S)V[8];
+  T[4] = k.J11 * (S)V[5] + k.J12 * (S)V[9];
+  T[5] = k.J11 * (S)V[6] + k.J12 * (S)V[10];
+  const S U0 = (T[0] * c3[0] + T[1] * c3[1]) + T[2] * c3[2];
+  const S U1 = (T[0] * c3[1] + T[1] * c3[3]) + T[2] * c3[4];
+  const S U2 = (T[0] * c3[2] + T[1] * c3[4]) + T[2] * c3[5];
+  const S U3 = (T[3] * c3[0] + T[4] * c3[1]) + T[5] * c3[2];
+  const S U4 = (T[3] * c3[1] + T[4] * c3[3]) + T[5] * c3[4];
+  const S U5 = (T[3] * c3[2] + T[4] * c3[4]) + T[5] * c3[5];
+  k.a0 = (U0 * T[0] + U1 * T[1]) + U2 * T[2];
+  k.b = (U0 * T[3] + U1 * T[4]) + U2 * T[5];
+  k.c0 = (U3 * T[3] + U4 * T[4]) + U5 * T[5];
+  k.det0 = k.a0 * k.c0 - k.b * k.b;
+  k.a = k.a0 + (S)K::kDilation; k.c = k.c0 + (S)K::kDilation;
+  k.det = k.a * k.c - k.b * k.b;
+}
+
+// project_one_bwd on scalar type S (v_mean / v_c3 / v_V are ASSIGNED)
+template <typename S>
+GS_HD void project_one_bwd_t(const float mean[3], const S c3[6], const float* V, float fx_, float fy_,
+                             const ProjCtxT<S>& k, S comp, const S v_xy[2], S v_depth, const S v_conic[3], S v_comp,
+                             S v_mean[3], S v_c3[6], S v_V[12], const S* v_pc_extra, bool upstream_clamp_grad) {
+  const S fx = (S)fx_, fy = (S)fy_;
+  const S a = k.a, b = k.b, c = k.c, det = k.det;
+  const S inv_det = S(1) / det, inv_det2 = inv_det * inv_det;
+  const S v0 = v_conic[0], v1 = v_conic[1], v2 = v_conic[2];
+  S v_a = (-c * c * v0 + b * c * v1 - b * b * v2) * inv_det2;
+  S v_c = (-b * b * v0 + a * b * v1 - a * a * v2) * inv_det2;
+  S v_b = (S(2) * b * c * v0 - (a * c + b * b) * v1 + S(2) * a * b * v2) * inv_det2;
+  if (comp > S(0) && v_comp != S(0)) {
+    const S v_r = v_comp * S(0.5) / comp;
+    const S det0 = k.det0;
+    v_a += v_r * (k.c0 * inv_det - det0 * c * inv_det2);
+    v_c += v_r * (k.a0 * inv_det - det0 * a * inv_det2);
+    v_b += v_r * (-S(2) * b * inv_det + det0 * S(2) * b * inv_det2);
+  }
+  const S* T = k.T;
+  const S g00 = v_a, g01 = S(0.5) * v_b, g11 = v_c;
+  const S GT0 = g00 * T[0] + g01 * T[3], GT1 = g00 * T[1] + g01 * T[4], GT2 = g00 * T[2] + g01 * T[5];
+  const S GT3 = g01 * T[0] + g11 * T[3], GT4 = g01 * T[1] + g11 * T[4], GT5 = g01 * T[2] + g11 * T[5];
+  v_c3[0] = T[0] * GT0 + T[3] * GT3;
+  v_c3[1] = S(2) * (T[0] * GT1 + T[3] * GT4);
+  v_c3[2] = S(2) * (T[0] * GT2 + T[3] * GT5);
+  v_c3[3] = T[1] * GT1 + T[4] * GT4;
+  v_c3[4] = S(2) * (T[1] * GT2 + T[4] * GT5);
+  v_c3[5] = T[2] * GT2 + T[5] * GT5;
+  const S S00 = c3[0], S01 = c3[1], S02 = c3[2], S11 = c3[3], S12 = c3[4], S22 = c3[5];
+  const S vT0 = S(2) * (GT0 * S00 + GT1 * S01 + GT2 * S02);
+  const S vT1 = S(2) * (GT0 * S01 + GT1 * S11 + GT2 * S12);
+  const S vT2 = S(2) * (GT0 * S02 + GT1 * S12 + GT2 * S22);
+  const S vT3 = S(2) * (GT3 * S00 + GT4 * S01 + GT5 * S02);
+  const S vT4 = S(2) * (GT3 * S01 + GT4 * S11 + GT5 * S12);
+  const S vT5 = S(2) * (GT3 * S02 + GT4 * S12 + GT5 * S22);
+  const S vJ00 = vT0 * (S)V[0] + vT1 * (S)V[1] + vT2 * (S)V[2];
+  const S vJ02 = vT0 * (S)V[8] + vT1 * (S)V[9] + vT2 * (S)V[10];
+  const S vJ11 = vT3 * (S)V[4] + vT4 * (S)V[5] + vT5 * (S)V[6];
+  const S vJ12 = vT3 * (S)V[8] + vT4 * (S)V[9] + vT5 * (S)V[10];
+  S vW[9];
+  vW[0] = k.J00 * vT0; vW[1] = k.J00 * vT1; vW[2] = k.J00 * vT2;
+  vW[3] = k.J11 * vT3; vW[4] = k.J11 * vT4; vW[5] = k.J11 * vT5;
+  vW[6] = k.J02 * vT0 + k.J12 * vT3; vW[7] = k.J02 * vT1 + k.J12 * vT4; vW[8] = k.J02 * vT2 + k.J12 * vT5;
+  const S px = k.pc[0], py = k.pc[1], rz = k.rz;
+  const S rz2 = rz * rz, rz3 = rz2 * rz;
+  const S v_tx = -fx * rz2 * vJ02, v_ty = -fy * rz2 * vJ12;
+  S v_pz = -fx * rz2 * vJ00 - fy * rz2 * vJ11 + S(2) * fx * k.tx * rz3 * vJ02 + S(2) * fy * k.ty * rz3 * vJ12;
+  S v_px = S(0), v_py = S(0);
+  if (k.clamp_x == 0 || upstream_clamp_grad) v_px += v_tx; else v_pz += v_tx * (k.tx * rz);
+  if (k.clamp_y == 0 || upstream_clamp_grad) v_py += v_ty; else v_pz += v_ty * (k.ty * rz);
+  v_px += fx * rz * v_xy[0];
+  v_py += fy * rz * v_xy[1];
+  v_pz += -(fx * px * rz2 * v_xy[0] + fy * py * rz2 * v_xy[1]) + v_depth;
+  if (v_pc_extra) { v_px += v_pc_extra[0]; v_py += v_pc_extra[1]; v_pz += v_pc_extra[2]; }
+  v_mean[0] = (S)V[0] * v_px + (S)V[4] * v_py + (S)V[8] * v_pz;
+  v_mean[1] = (S)V[1] * v_px + (S)V[5] * v_py + (S)V[9] * v_pz;
+  v_mean[2] = (S)V[2] * v_px + (S)V[6] * v_py + (S)V[10] * v_pz;
+  const S m0 = (S)mean[0], m1 = (S)mean[1], m2 = (S)mean[2];
+  v_V[0] = vW[0] + v_px * m0; v_V[1] = vW[1] + v_px * m1; v_V[2]  = vW[2] + v_px * m2; v_V[3]  = v_px;
+  v_V[4] = vW[3] + v_py * m0; v_V[5] = vW[4] + v_py * m1; v_V[6]  = vW[5] + v_py * m2; v_V[7]  = v_py;
+  v_V[8] = vW[6] + v_pz * m0; v_V[9] = vW[7] + v_pz * m1; v_V[10] = vW[8] + v_pz * m2; v_V[11] = v_pz;
+}
+
+// cov3d_bwd on scalar type S
+template <typename S>
+GS_HD void cov3d_bwd_t(const float s[3], float glob_, const float q[4], const S v_c3[6], S v_s[3], S v_q[4],
+                       bool raw_quat_grad) {
+  S R[9], qn[4], inv, M[9], c3[6];
+  quat_to_rotmat_t<S>(q, R, qn, &inv);
+  scale_rot_to_cov3d_t<S>(s, glob_, R, M, c3);
+  const S glob = (S)glob_;
+  const S S00 = v_c3[0], S01 = S(0.5) * v_c3[1], S02 = S(0.5) * v_c3[2];
+  const S S11 = v_c3[3], S12 = S(0.5) * v_c3[4], S22 = v_c3[5];
+  S vM[9];
+  vM[0] = S(2) * (S00 * M[0] + S01 * M[3] + S02 * M[6]);
+  vM[1] = S(2) * (S00 * M[1] + S01 * M[4] + S02 * M[7]);
+  vM[2] = S(2) * (S00 * M[2] + S01 * M[5] + S02 * M[8]);
+  vM[3] = S(2) * (S01 * M[0] + S11 * M[3] + S12 * M[6]);
+  vM[4] = S(2) * (S01 * M[1] + S11 * M[4] + S12 * M[7]);
+  vM[5] = S(2) * (S01 * M[2] + S11 * M[5] + S12 * M[8]);
+  vM[6] = S(2) * (S02 * M[0] + S12 * M[3] + S22 * M[6]);
+  vM[7] = S(2) * (S02 * M[1] + S12 * M[4] + S22 * M[7]);
+  vM[8] = S(2) * (S02 * M[2] + S12 * M[5] + S22 * M[8]);
+  v_s[0] = glob * (vM[0] * R[0] + vM[3] * R[3] + vM[6] * R[6]);
+  v_s[1] = glob * (vM[1] * R[1] + vM[4] * R[4] + vM[7] * R[7]);
+  v_s[2] = glob * (vM[2] * R[2] + vM[5] * R[5] + vM[8] * R[8]);
+  const S s0 = glob * (S)s[0], s1 = glob * (S)s[1], s2 = glob * (S)s[2];
+  const S vR[9] = {vM[0] * s0, vM[1] * s1, vM[2] * s2, vM[3] * s0, vM[4] * s1, vM[5] * s2,
+                   vM[6] * s0, vM[7] * s1, vM[8] * s2};
+  const S w = qn[0], x = qn[1], y = qn[2], z = qn[3];
+  S g[4];
+  g[0] = S(2) * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
+  g[1] = S(2) * (-S(2) * x * (vR[4] + vR[8]) + y * (vR[3] + vR[1]) + z * (vR[6] + vR[2]) + w * (vR[7] - vR[5]));
+  g[2] = S(2) * (x * (vR[3] + vR[1]) - S(2) * y * (vR[0] + vR[8]) + z * (vR[7] + vR[5]) + w * (vR[2] - vR[6]));
+  g[3] = S(2) * (x * (vR[6] + vR[2]) + y * (vR[7] + vR[5]) - S(2) * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
+  if (raw_quat_grad) { v_q[0] = g[0]; v_q[1] = g[1]; v_q[2] = g[2]; v_q[3] = g[3]; return; }
+  const S dotp = g[0] * w + g[1] * x + g[2] * y + g[3] * z;
+  v_q[0] = (g[0] - w * dotp) * inv;
+  v_q[1] = (g[1] - x * dotp) * inv;
+  v_q[2] = (g[2] - y * dotp) * inv;
+  v_q[3] = (g[3] - z * dotp) * inv;
+}
+
 // ---- spherical harmonics (real, degree <= 4) ---------------------------------
 // basis values for unit direction (x,y,z); nb = (deg+1)^2.  Sloan-style
 // recurrences with the usual 3DGS sign convention.

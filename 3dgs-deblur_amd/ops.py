@@ -75,6 +75,16 @@ LANE_STATS = int(os.environ.get("GSD_LANE_STATS", "0"))
 lane_stats: Optional[Tensor] = None
 
 
+# 1 (default): Gaussians whose scales differ by more than 8x get the covariance part of their projection backward
+# (v_conic -> cov2d -> cov3d -> scale / quaternion / mean) recomputed in double (project_needle_hp_kernel): in fp32 that
+# chain is percent-level wrong along a needle's long axis.  0: fp32 everywhere (A/B, tests).
+NEEDLE_HP = int(os.environ.get("GSD_NEEDLE_HP", "1"))
+
+
+def _proj_grad_flags() -> int:
+    return (UPSTREAM_GRADS & 3) | (0 if NEEDLE_HP else 8)
+
+
 def _bwd_variant() -> int:
     return RASTER_BWD_VARIANT | (256 if (UPSTREAM_GRADS & 4) else 0)
 # per-slice emitted intersection counts of the last frame: ints, or 1-element device tensors that are only read back
@@ -1371,7 +1381,7 @@ class _RenderSubposes(Function):
                                                _ptr(sh), K, deg, _ptr(V), _ptr(twist), _ptr(times), fx, fy, cx, cy, H, W,
                                                clip, aa, _ptr(records), _ptr(v_records), _ptr(v_means), _ptr(v_scales),
                                                _ptr(v_quats), _ptr(v_opac), _ptr(v_sh), _ptr(v_V), _ptr(v_tw),
-                                               _ptr(touched), _ptr(xy_out), UPSTREAM_GRADS & 3, _stream()),
+                                               _ptr(touched), _ptr(xy_out), _proj_grad_flags(), _stream()),
                        "project_pixvel_bwd")
                 if v_tw is not None:
                     v_lin, v_ang = v_tw[0:3], v_tw[3:6]
@@ -1381,7 +1391,7 @@ class _RenderSubposes(Function):
                                               _ptr(sh), K, deg, _ptr(V), fx, fy, cx, cy, H, W, clip, aa, _ptr(records),
                                               _ptr(v_records), _ptr(v_means), _ptr(v_scales), _ptr(v_quats),
                                               _ptr(v_opac), _ptr(v_sh), _ptr(v_V), _ptr(touched), _ptr(xy_out),
-                                              UPSTREAM_GRADS & 3, _stream()), "project_fused_bwd")
+                                              _proj_grad_flags(), _stream()), "project_fused_bwd")
         v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
         return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 16 + (v_lin, v_ang, None, None)
 

@@ -101,7 +101,8 @@ int gs_project_fused_bwd(int N, int P, const float* means3d, const float* scales
                          float* v_xy_sum /*[N*2] or NULL: sum over the sub-poses of the screen-space centre
                                            gradient (pixels) — the densification statistic splatfacto reads from
                                            xys.grad; same zeroing rule as the other outputs*/,
-                         int grad_flags /*as in gs_project_bwd*/, void* stream);
+                         int grad_flags /*as in gs_project_bwd; + 8: skip the double-precision covariance chain that
+                                          Gaussians with a scale ratio above 8 (needles) get by default*/, void* stream);
 
 /* ---- pixel-velocity model: the paper's first-order blur / rolling-shutter model (the fork's
  * own wording at /root/reference/README.md:200 "Fixed a bug in pixel velocity formulas").  ONE projection under the
