@@ -1717,3 +1717,43 @@ def test_needle_gaussians_gradients_vs_float64_oracle(gs, oracle, dev, model):
     for k, v in worst[1].items():
         assert v <= 1.0, (k, v)
     assert max(worst[0]["log_scales"], worst[0]["quats"]) > 1.0          # the fp32 chain fails this scene
+
+
+def test_backward_transmittance_rebuild_over_a_500_entry_tile_vs_float64(gs, oracle, dev):
+    """the backward rebuilds the transmittance in front of every entry with T *= rcp(1 - alpha)
+    (v_rcp_f32, 1 ulp) — compounded over a list of several hundred entries.  One 16x16 tile, 700 overlapping translucent
+    Gaussians (alpha ~ 0.02: about 450 are blended before T falls under 1e-4): every gradient element against the
+    float64 oracle's autograd with the usual per-element bar."""
+    O = oracle
+    n, W, H = 700, 16, 16
+    g = torch.Generator().manual_seed(12)
+    sc = O.synthetic_scene(n, W, H, seed=12, scale_mult=1.0)
+    # all Gaussians in front of the camera on the axis, large on screen, depth-ordered by construction
+    sc["means"] = torch.stack([0.02 * torch.randn(n, generator=g), 0.02 * torch.randn(n, generator=g),
+                               2.0 + 3.0 * torch.rand(n, generator=g)], -1)
+    sc["log_scales"] = torch.log(torch.full((n, 3), 0.6)) + 0.35 * torch.randn(n, 3, generator=g)
+    sc["opacity_logits"] = torch.full((n,), -3.9) + 0.3 * torch.randn(n, generator=g)
+    sc["fx"] = sc["fy"] = 200.0                           # sigma ~ 30 px: every splat covers the whole tile
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel", "viewmat"]
+    bg = torch.tensor([0.2, 0.3, 0.1])
+    cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], blur_samples=1, rs_bands=1, exposure_time=0.0,
+                         rolling_shutter_time=0.0, gamma=1.0, min_rgb_level=0.0)
+    q = {k: sc[k].double().requires_grad_(True) for k in names}
+    ref, _, ref_samples, frag, _, _ = O.render(cfg, q["means"], q["log_scales"].exp(), q["quats"],
+                                               torch.sigmoid(q["opacity_logits"]), q["sh"], q["viewmat"], q["lin_vel"],
+                                               q["ang_vel"], background=bg.double(), return_parts=True)
+    good = ~frag
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)) * good[..., None]
+    (ref * wt.double()).sum().backward()
+    out, alpha, samples, vms, p, radii = _run_full(gs, O, dev, sc, H, W, 1, 1, 0.0, 0.0, 1.0, 0.0, 3, bg, wt)
+    from gsdeblur_amd import ops
+    blended = int((p["opacity_logits"].grad != 0).sum())
+    assert ops.last_num_intersects >= 600 and blended >= 350, (ops.last_num_intersects, blended)
+    assert float(alpha.detach().min()) > 0.99             # the whole tile saturates: the list is walked to the stop
+    assert (samples.detach().cpu().double() - ref_samples)[:, good].abs().max().item() < IMG_ATOL
+    worst = {k: grad_el_ratio(p[k].grad.cpu().numpy(), q[k].grad.numpy()) for k in
+             ("means", "log_scales", "quats", "opacity_logits", "sh")}
+    print("500-entry tile: per-element gradient error / tolerance:", {k: round(v, 3) for k, v in worst.items()},
+          "Gaussians with a gradient:", blended)
+    for k, v in worst.items():
+        assert v <= 1.0, (k, v)
