@@ -22,6 +22,7 @@ SOURCES = [
     # backward compositor: automatic SLP packing into v_pk_*_f32 costs v_mov shuffles and 29 VGPRs on gfx950
     # (A/B: 1.27 -> 1.09 ms); the packing is done by hand in the source instead (GS_BWD_PK)
     ("raster_bwd.hip", ["-fno-slp-vectorize"]),
+    ("raster_rs.hip", []),
     # x*scale + y must round twice, like the torch ops it replaces (tests compare bit for bit)
     ("dp_exchange.hip", ["-ffp-contract=off"]),
     ("train.hip", []),

@@ -25,7 +25,10 @@ _SIGS = {
     "gs_project_fused_bwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I,
                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "gs_project_pixvel_fwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P, _P, _F, _F, _F, _F, _I, _I, _F, _I, _I,
-                              _P, _P, _P, _P, _P],
+                              _P, _P, _P, _P, _F, _P, _P],
+    "gs_rasterize_fwd_rs_slice": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _F, _P],
+    "gs_rasterize_bwd_rs_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _F, _F,
+                                  _P, _I, _F, _P],
     "gs_project_pixvel_bwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P, _P, _F, _F, _F, _F, _I, _I, _F, _I,
                               _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "gs_pack_records": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],

@@ -118,6 +118,25 @@ GS_HD bool tile_bounds(float x, float y, float radf, int tiles_x, int tiles_y, P
   return true;
 }
 
+// tile_bounds for a splat whose centre sweeps the segment (xa, ya) - (xb, yb) while the rolling shutter reads the frame
+// out (exact per-row model, see project.hip / raster_rs.hip): the box of the 3-sigma circle dragged along the segment
+GS_HD bool tile_bounds_swept(float xa, float ya, float xb, float yb, float radf, int tiles_x, int tiles_y, Proj& o) {
+  const float inv_tile = 1.0f / (float)K::kTile;
+  const float xlo = fminf(xa, xb) * inv_tile, xhi = fmaxf(xa, xb) * inv_tile;
+  const float ylo = fminf(ya, yb) * inv_tile, yhi = fmaxf(ya, yb) * inv_tile, tr = radf * inv_tile;
+  int x0 = (int)(xlo - tr), x1 = (int)(xhi + tr + 1.0f);
+  int y0 = (int)(ylo - tr), y1 = (int)(yhi + tr + 1.0f);
+  x0 = x0 < 0 ? 0 : (x0 > tiles_x ? tiles_x : x0);
+  x1 = x1 < 0 ? 0 : (x1 > tiles_x ? tiles_x : x1);
+  y0 = y0 < 0 ? 0 : (y0 > tiles_y ? tiles_y : y0);
+  y1 = y1 < 0 ? 0 : (y1 > tiles_y ? tiles_y : y1);
+  int area = (x1 - x0) * (y1 - y0);
+  if (area <= 0) { o.radius = 0; o.ntiles = 0; o.tmin_x = o.tmin_y = o.tmax_x = o.tmax_y = 0; return false; }
+  o.ntiles = area;
+  o.tmin_x = x0; o.tmin_y = y0; o.tmax_x = x1; o.tmax_y = y1;
+  return true;
+}
+
 // Project one Gaussian with covariance c3 (6) under viewmat V (row-major 4x4,
 // rows 0..2 used).  Returns false when culled (near plane / singular / no tile).
 GS_HD bool project_one(const float mean[3], const float c3[6], const float* V,

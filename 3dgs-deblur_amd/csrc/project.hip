@@ -256,11 +256,18 @@ struct FusedParams {
   const float* twist;
   const float* times;
   int flags;         // GS_FLAG_* : upstream-compatible gradient conventions (backward only)
+  // exact per-row rolling shutter of the pixel-velocity model (rs_half = readout time / 2; 0: off): sub-pose p is the
+  // blur sample at times[p], every pixel ROW y then sees the splat at xy + (times[p] + tau(y)) * pv with
+  // tau(y) = ((y + 0.5) / H - 0.5) * T_ro — the compositors of raster_rs.hip add the row term, the projection only
+  // widens the tile box by the sweep and hands out pv [N,2]; the backward takes d loss / d pv from v_records[9..10]
+  float rs_half;
+  float* pix_vel_out;
 };
 
 constexpr int GS_FLAG_UPSTREAM_FOV_CLAMP_GRAD = 1;   // back-propagate through the fov clamp as if inactive
 constexpr int GS_FLAG_RAW_QUAT_GRAD = 2;             // no projection of the quaternion gradient through q/|q|
 constexpr int GS_FLAG_NO_NEEDLE_HP = 8;              // skip the double-precision covariance chain of needle Gaussians
+constexpr int GS_FLAG_RS_PIXVEL_GRAD = 16;           // pixel-velocity model, exact rolling shutter: v_records[9..10] = d loss / d pv
 constexpr float kNeedleRatio = 8.0f;                 // largest / smallest scale above which the chain runs in double
 
 // DEFER (== fp.defer_color, as a template parameter): the SH coefficients are neither loaded nor held — 48 VGPRs of
@@ -297,6 +304,7 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
       const float lin[3] = {fp.twist[0], fp.twist[1], fp.twist[2]}, ang[3] = {fp.twist[3], fp.twist[4], fp.twist[5]};
       pixel_velocity(k0.pc, k0.rz, fp.in.fx, fp.in.fy, lin, ang, pv);
     }
+    if (fp.pix_vel_out) { fp.pix_vel_out[2 * i] = pv[0]; fp.pix_vel_out[2 * i + 1] = pv[1]; }
   }
   for (int p = 0; p < fp.P; ++p) {
     const float* V = fp.viewmats + (fp.pixvel ? 0 : 16 * p);
@@ -313,7 +321,11 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
         o.x = o0.x + tau * pv[0];
         o.y = o0.y + tau * pv[1];
         o.radius = (int)k0.radf;
-        ok = tile_bounds(o.x, o.y, k0.radf, fp.in.tiles_x, fp.in.tiles_y, o);
+        if (fp.rs_half != 0.f)
+          ok = tile_bounds_swept(o.x - fp.rs_half * pv[0], o.y - fp.rs_half * pv[1], o.x + fp.rs_half * pv[0],
+                                 o.y + fp.rs_half * pv[1], k0.radf, fp.in.tiles_x, fp.in.tiles_y, o);
+        else
+          ok = tile_bounds(o.x, o.y, k0.radf, fp.in.tiles_x, fp.in.tiles_y, o);
       }
     } else {
       ok = project_one(m, c3, Vm, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x,
@@ -418,6 +430,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
           if (fp.antialiased) { vop += gb.y * o.comp; v_comp += gb.y * opac; } else { vop += gb.y; }
           vxy[0] += ga.x; vxy[1] += ga.y;
           vpv[0] += tau * ga.x; vpv[1] += tau * ga.y;
+          if (fp.flags & GS_FLAG_RS_PIXVEL_GRAD) { vpv[0] += gc.y; vpv[1] += gc.z; }   // the compositor's row-time term
           vcon[0] += ga.z; vcon[1] += ga.w; vcon[2] += gb.x;
         }
         vxs = vxy[0]; vys = vxy[1];
@@ -560,13 +573,14 @@ __global__ __launch_bounds__(128) void project_needle_hp_kernel(FusedParams fp, 
       if (touched && !touched[(size_t)p * fp.N + i]) continue;
       const size_t idx = (size_t)p * fp.N + i;
       const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kRecFloats);
-      const float4 ga = g4[0], gb = g4[1];
+      const float4 ga = g4[0], gb = g4[1], gc = g4[2];
       const float4* r4 = reinterpret_cast<const float4*>(records + idx * kRecFloats);
       const float4 ra = r4[0], rb = r4[1];
       if (ra.z == 0.f && ra.w == 0.f && rb.x == 0.f) continue;
       if (fp.antialiased) v_comp += (double)gb.y * (double)opac;
       vxy[0] += ga.x; vxy[1] += ga.y;
       vpv[0] += fp.times[p] * ga.x; vpv[1] += fp.times[p] * ga.y;
+      if (fp.flags & GS_FLAG_RS_PIXVEL_GRAD) { vpv[0] += gc.y; vpv[1] += gc.z; }
       vcon[0] += ga.z; vcon[1] += ga.w; vcon[2] += gb.x;
     }
     const float lin[3] = {fp.twist[0], fp.twist[1], fp.twist[2]}, ang[3] = {fp.twist[3], fp.twist[4], fp.twist[5]};
@@ -830,7 +844,7 @@ static inline FusedParams make_fused(int N, int P, const float* means, const flo
   fp.defer_color = defer_color & 1;
   fp.skip_culled = (defer_color >> 1) & 1;
   fp.in = make_intrin(fx, fy, cx, cy, H, W, clip);
-  fp.pixvel = 0; fp.twist = nullptr; fp.times = nullptr; fp.flags = 0;
+  fp.pixvel = 0; fp.twist = nullptr; fp.times = nullptr; fp.flags = 0; fp.rs_half = 0.f; fp.pix_vel_out = nullptr;
   return fp;
 }
 
@@ -935,13 +949,15 @@ GS_EXPORT int gs_project_pixvel_fwd(int N, int P, const float* means, const floa
                                     int sh_degree, const float* viewmat, const float* twist, const float* times,
                                     float fx, float fy, float cx, float cy, int H, int W, float clip, int antialiased,
                                     int defer_color, float* records, unsigned* depth_keys, int* num_tiles_hit,
-                                    int* radii, void* stream) {
+                                    int* radii, float rolling_shutter_time, float* pix_vel, void* stream) {
   if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride || !twist ||
       !times)
     return GS_ERR_INVALID;
+  if (rolling_shutter_time != 0.f && !pix_vel) return GS_ERR_INVALID;
   FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmat,
                               fx, fy, cx, cy, H, W, clip, antialiased, defer_color);
   fp.pixvel = 1; fp.twist = twist; fp.times = times;
+  fp.rs_half = 0.5f * rolling_shutter_time; fp.pix_vel_out = pix_vel;
   dim3 grid((N + 255) / 256), block(256);
   if (fp.defer_color)       // the SH degree plays no part: one instantiation
     hipLaunchKernelGGL((project_fused_fwd_kernel<16, true>), grid, block, 0, (hipStream_t)stream, fp, records,

@@ -629,6 +629,7 @@ __global__ __launch_bounds__(256, GS_BWD_SLOAD_WAVES) void raster_bwd_sload_kern
 // belongs to exactly one slice, so the result is a plain store into v_records — no atomics anywhere.
 // ---------------------------------------------------------------------------
 constexpr unsigned kReduceSolo = 16;
+constexpr int kTupleComp = 11;
 
 __global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const unsigned* __restrict__ slice_gi,
                                                             const unsigned* __restrict__ counts,
@@ -641,9 +642,11 @@ __global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const u
   const int j = blockIdx.x * 256 + threadIdx.x;
   unsigned cnt = 0, e0 = 0, gi = 0;
   if (j < n_slice) { cnt = counts[j]; e0 = cum[j]; gi = slice_gi[j]; }
-  float acc[9];
+  // 11 components: slots 9 and 10 carry d loss / d pixel-velocity of the exact rolling-shutter compositor
+  // (raster_rs.hip); the other compositors leave them unwritten and nobody reads their sums
+  float acc[kTupleComp];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) acc[c] = 0.f;
+  for (int c = 0; c < kTupleComp; ++c) acc[c] = 0.f;
   bool any = false;
   if (cnt && cnt <= kReduceSolo) {
     for (unsigned i = 0; i < cnt; ++i) {
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const u
         const float4* t = reinterpret_cast<const float4*>(tuples + (size_t)(e0 + i) * kRecFloats);
         float4 a = t[0], b = t[1], c = t[2];
         acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w; acc[8] += c.x;
+        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w; acc[8] += c.x; acc[9] += c.y; acc[10] += c.z;
         any = true;
       }
     }
@@ -661,22 +664,22 @@ __global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const u
     const int src = __ffsll((long long)big) - 1;
     big &= big - 1;
     const unsigned c_n = (unsigned)readlane_i((int)cnt, src), c_e = (unsigned)readlane_i((int)e0, src);
-    float part[9];
+    float part[kTupleComp];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) part[c] = 0.f;
+    for (int c = 0; c < kTupleComp; ++c) part[c] = 0.f;
     bool hit = false;
     for (unsigned i = lane; i < c_n; i += 64) {
       if (flags[c_e + i]) {
         const float4* t = reinterpret_cast<const float4*>(tuples + (size_t)(c_e + i) * kRecFloats);
         float4 a = t[0], b = t[1], c = t[2];
         part[0] += a.x; part[1] += a.y; part[2] += a.z; part[3] += a.w;
-        part[4] += b.x; part[5] += b.y; part[6] += b.z; part[7] += b.w; part[8] += c.x;
+        part[4] += b.x; part[5] += b.y; part[6] += b.z; part[7] += b.w; part[8] += c.x; part[9] += c.y; part[10] += c.z;
         hit = true;
       }
     }
     if (__ballot(hit) != 0ull) {
 #pragma unroll
-      for (int c = 0; c < 9; ++c) {
+      for (int c = 0; c < kTupleComp; ++c) {
         const float tsum = wave_sum_uniform(part[c]);
         if (lane == src) acc[c] = tsum;
       }
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const u
     float4* dst = reinterpret_cast<float4*>(v_records + (size_t)gi * kRecFloats);
     dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    dst[2] = make_float4(acc[8], 0.f, 0.f, 0.f);
+    dst[2] = make_float4(acc[8], acc[9], acc[10], 0.f);
     if (touched) touched[gi] = 1;
   }
 }
@@ -706,29 +709,29 @@ __global__ __launch_bounds__(256) void reduce_tuples_wave_kernel(int n_slice, co
   if (j >= n_slice) return;
   const unsigned c_n = counts[j], c_e = cum[j];
   if (c_n == 0) return;
-  float part[9];
+  float part[kTupleComp];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) part[c] = 0.f;
+  for (int c = 0; c < kTupleComp; ++c) part[c] = 0.f;
   bool hit = false;
   for (unsigned i = lane; i < c_n; i += 64) {
     if (flags[c_e + i]) {
       const float4* t = reinterpret_cast<const float4*>(tuples + (size_t)(c_e + i) * kRecFloats);
       float4 a = t[0], b = t[1], c = t[2];
       part[0] += a.x; part[1] += a.y; part[2] += a.z; part[3] += a.w;
-      part[4] += b.x; part[5] += b.y; part[6] += b.z; part[7] += b.w; part[8] += c.x;
+      part[4] += b.x; part[5] += b.y; part[6] += b.z; part[7] += b.w; part[8] += c.x; part[9] += c.y; part[10] += c.z;
       hit = true;
     }
   }
   if (__ballot(hit) == 0ull) return;
-  float tot[9];
+  float tot[kTupleComp];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) tot[c] = wave_sum_uniform(part[c]);
+  for (int c = 0; c < kTupleComp; ++c) tot[c] = wave_sum_uniform(part[c]);
   if (lane == 0) {
     const unsigned gi = slice_gi[j];
     float4* dst = reinterpret_cast<float4*>(v_records + (size_t)gi * kRecFloats);
     dst[0] = make_float4(tot[0], tot[1], tot[2], tot[3]);
     dst[1] = make_float4(tot[4], tot[5], tot[6], tot[7]);
-    dst[2] = make_float4(tot[8], 0.f, 0.f, 0.f);
+    dst[2] = make_float4(tot[8], tot[9], tot[10], 0.f);
     if (touched) touched[gi] = 1;
   }
 }

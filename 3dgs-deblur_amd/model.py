@@ -56,6 +56,10 @@ class SplatfactoDeblurConfig:
     # (north_star), "pixel_velocity" is the paper's first-order model — one projection, centres shifted by
     # t * pixel velocity, depth order / covariance / colour of the mid-exposure pose
     motion_model: str = "se3"
+    # rolling shutter (with rolling_shutter_compensation): "bands" = rs_bands tile-row bands, each its own sub-pose
+    # (both motion models); "exact" (pixel_velocity only) = continuous per-row time inside the compositor, ONE
+    # projection / sort per blur sample whatever the band count (SURVEY App. A "row time (y/H - 1/2) * T_ro")
+    rolling_shutter_mode: str = "bands"
     camera_optimizer: CameraOptimizerConfig = field(default_factory=CameraOptimizerConfig)
     camera_velocity_optimizer: CameraVelocityOptimizerConfig = field(default_factory=CameraVelocityOptimizerConfig)
 
@@ -217,8 +221,21 @@ class SplatfactoDeblurModel(nn.Module):
             S = 1
         if readout == 0.0:
             R = 1
+        if cfg.rolling_shutter_mode == "exact":
+            if cfg.motion_model != "pixel_velocity":
+                raise ValueError("rolling_shutter_mode='exact' needs motion_model='pixel_velocity'")
+            R = 1                                   # the row time lives in the compositor (see _rs_time)
+        elif cfg.rolling_shutter_mode != "bands":
+            raise ValueError(f"unknown rolling_shutter_mode {cfg.rolling_shutter_mode!r}")
         times, _, _ = ops.subpose_schedule(S, exposure, R, readout)
         return S, R, times
+
+    def _rs_time(self, camera: Camera) -> float:
+        """readout time handed to the exact rolling-shutter compositors (0: off)"""
+        cfg = self.config
+        if cfg.rolling_shutter_mode != "exact" or not cfg.rolling_shutter_compensation:
+            return 0.0
+        return float(camera.metadata.get("rolling_shutter_time", 0.0))
 
     # -- rendering ---------------------------------------------------------------------
     def get_outputs(self, camera: Camera, detach_gaussians: bool = False) -> Dict[str, Tensor]:
@@ -257,7 +274,7 @@ class SplatfactoDeblurModel(nn.Module):
             gamma=gamma, min_rgb_level=min_level, sh_degree=self.active_sh_degree(),
             antialiased=(cfg.rasterize_mode == "antialiased"), xy_grad_out=self.xy_grad,
             lin_vel=lin if pixvel else None, ang_vel=ang if pixvel else None, times=times_t if pixvel else None,
-            return_depth=want_depth)
+            return_depth=want_depth, rolling_shutter_time=self._rs_time(camera) if pixvel else 0.0)
         rgb, alphas, radii = res[:3]
         depth_acc = res[3] if want_depth else None
         self.radii = radii

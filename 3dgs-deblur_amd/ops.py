@@ -574,10 +574,13 @@ def native_frame_backward(frame, records: Tensor, bg: Tensor, edges: Tensor, out
 
 def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
                    img_height: int, img_width: int, bg: Tensor, edges: Tensor, slice_base: int, color=None,
-                   out_depth: Optional[Tensor] = None, prealloc: Optional[dict] = None):
+                   out_depth: Optional[Tensor] = None, prealloc: Optional[dict] = None, rs=None):
     """Front-to-back depth-sliced bin + sort + composite.
     -> (out_img [S,H,W,3], out_T [S,H,W], slices) ; slices = list of (sorted_vals, tile_bins, final_idx, I_k)
-    that the backward walks in reverse."""
+    that the backward walks in reverse.
+    rs = (pix_vel [N,2], rolling_shutter_time): exact per-row rolling shutter of the pixel-velocity model (R must be 1):
+    the compositors of raster_rs.hip add tau(row) * pix_vel to every splat centre.  The tile lists then come from the
+    (swept) bounding boxes without the exact ellipse culling — that test assumes one centre per tile."""
     global last_num_intersects, _slice_totals
     L = _L()
     dev = records.device
@@ -664,9 +667,12 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
     holes0 = R > 1          # the very first slice already has closed tiles
     slices = []
     _slice_totals = []
-    invalid_key = P * T if EXACT_TILE_CULL else 0
+    if rs is not None and (R != 1 or not GRAD_TUPLES):
+        raise ValueError("exact rolling shutter needs rs_bands == 1 and the gradient-tuple backward")
+    exact_cull = bool(EXACT_TILE_CULL) and rs is None
+    invalid_key = P * T if exact_cull else 0
     use_tuples = bool(GRAD_TUPLES)
-    compact = bool(COMPACT_EMIT) and bool(EXACT_TILE_CULL)
+    compact = bool(COMPACT_EMIT) and exact_cull
     # default path (compact emission + gradient tuples): a slice's size never comes back to the host.  Its buffers
     # and grids are sized by the slice's BOUNDING-BOX intersection count, which the plan read-back already put on
     # the host, and the kernels read the real count from the device.  What is left per frame: the plan read-back,
@@ -795,7 +801,14 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
             svals = torch.zeros(1, dtype=torch.int32, device=dev)
             bins = torch.zeros(P * T, 2, dtype=torch.int32, device=dev)
         fidx = torch.empty(S, H, W, dtype=torch.int32, device=dev)
-        if LANE_STATS and out_depth is None:
+        if rs is not None and I_k > 0:
+            with _stage("raster_fwd"):
+                _check(L.gs_rasterize_fwd_rs_slice(_ptr(records), _ptr(bins), _ptr(edges), _ptr(bg), S, H, W, _ptr(out_img),
+                                                   _ptr(out_T), _ptr(live_T), _ptr(fidx), _ptr(tile_done), int(first),
+                                                   int(last), _ptr(sorted_ids), P * N, _ptr(out_depth),
+                                                   ctypes.c_void_p(open_flags.data_ptr() + 4 * k) if not last else None,
+                                                   _ptr(rs[0]), N, float(rs[1]), _stream()), "rasterize_fwd_rs_slice")
+        elif LANE_STATS and out_depth is None:
             global lane_stats
             if lane_stats is None or lane_stats.device != dev:
                 lane_stats = torch.zeros(13, dtype=torch.int64, device=dev)
@@ -858,7 +871,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
 
 def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, img_width: int, bg: Tensor,
                     edges: Tensor, out_T: Tensor, v_img: Tensor, v_alpha: Optional[Tensor], v_records: Tensor,
-                    touched: Optional[Tensor] = None, combine=None):
+                    touched: Optional[Tensor] = None, combine=None, rs=None):
     """combine = (scale [H,W,3], gamma, m): v_img then holds the SAMPLE IMAGES and the kernel derives each
     pixel's sample gradient itself (gs_combine_bwd folded into the compositor's backward)."""
     L = _L()
@@ -889,14 +902,23 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
             if tuples is None:
                 tuples = torch.empty(sl["I"] * REC, device=dev)
                 flags = torch.zeros(sl["I"], dtype=torch.uint8, device=dev)
-        with _stage("raster_bwd"):
-            _check(L.gs_rasterize_bwd_slice(_ptr(records), _ptr(sl["svals"]), _ptr(sl["bins"]), _ptr(edges), _ptr(bg),
-                                            S, R, H, W, _ptr(out_T), _ptr(sl["fidx"]), _ptr(v_img), _ptr(v_alpha),
-                                            _ptr(bwd_T), _ptr(bwd_B), _ptr(v_records), _ptr(sl["gi_of_e"]),
-                                            _ptr(tuples), _ptr(flags), _ptr(sl["sorted_ids"]), records.shape[0],
-                                            _ptr(sl["tile_hot"]), _bwd_variant(), _ptr(cmb[0]), cmb[1], cmb[2],
-                                            _stream()),
-                   "rasterize_bwd_slice")
+        if rs is not None:
+            with _stage("raster_bwd"):
+                _check(L.gs_rasterize_bwd_rs_slice(_ptr(records), _ptr(sl["svals"]), _ptr(sl["bins"]), _ptr(edges), _ptr(bg),
+                                                   S, H, W, _ptr(out_T), _ptr(sl["fidx"]), _ptr(v_img), _ptr(v_alpha),
+                                                   _ptr(bwd_T), _ptr(bwd_B), _ptr(tuples), _ptr(flags),
+                                                   _ptr(sl["sorted_ids"]), records.shape[0], _bwd_variant() & 256,
+                                                   _ptr(cmb[0]), cmb[1], cmb[2], _ptr(rs[0]), rs[0].shape[0], float(rs[1]),
+                                                   _stream()), "rasterize_bwd_rs_slice")
+        else:
+            with _stage("raster_bwd"):
+                _check(L.gs_rasterize_bwd_slice(_ptr(records), _ptr(sl["svals"]), _ptr(sl["bins"]), _ptr(edges), _ptr(bg),
+                                                S, R, H, W, _ptr(out_T), _ptr(sl["fidx"]), _ptr(v_img), _ptr(v_alpha),
+                                                _ptr(bwd_T), _ptr(bwd_B), _ptr(v_records), _ptr(sl["gi_of_e"]),
+                                                _ptr(tuples), _ptr(flags), _ptr(sl["sorted_ids"]), records.shape[0],
+                                                _ptr(sl["tile_hot"]), _bwd_variant(), _ptr(cmb[0]), cmb[1], cmb[2],
+                                                _stream()),
+                       "rasterize_bwd_slice")
         if tuples is not None:
             with _stage("grad_reduce"):
                 # kernel form: a wave per Gaussian only for slices of few, large Gaussians (the choice the exact count
@@ -1194,7 +1216,7 @@ class _RenderSubposes(Function):
     @staticmethod
     def forward(ctx, means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out, return_alpha,
-                gamma, min_rgb_level, lin_vel=None, ang_vel=None, times=None, return_depth=False):
+                gamma, min_rgb_level, lin_vel=None, ang_vel=None, times=None, return_depth=False, rs_time=0.0):
         # an output the loss does not use arrives as None in backward instead of a materialised zero tensor
         ctx.set_materialize_grads(False)
         means3d, scales, quats = _f32(means3d, "means3d"), _f32(scales, "scales"), _f32(quats, "quats")
@@ -1208,6 +1230,10 @@ class _RenderSubposes(Function):
         P = S * R
         # pixel-velocity model: ONE mid-exposure viewmat + the camera twist + the P sub-pose times
         pixvel = times is not None
+        rs_time = float(rs_time or 0.0)
+        if rs_time != 0.0 and (not pixvel or R != 1):
+            raise ValueError("exact rolling shutter (rolling_shutter_time != 0) needs the pixel-velocity model "
+                             "(times / lin_vel / ang_vel) and rs_bands == 1")
         if pixvel:
             V = _viewmat16(viewmats).reshape(4, 4)
             twist = torch.cat([_f32(lin_vel, "lin_vel").reshape(3), _f32(ang_vel, "ang_vel").reshape(3)]).contiguous()
@@ -1233,12 +1259,17 @@ class _RenderSubposes(Function):
         # (the atomics backward of the pixel-velocity model tells "covers no tile" by an all-zero record)
         lean = DEPTH_SORT_SEGMENTED and DEPTH_SORT_COMPACT and GRAD_TUPLES and COMPACT_EMIT and EXACT_TILE_CULL
         defer_flags = int(bool(DEFER_COLOR)) | (2 if lean else 0)
+        pix_vel = torch.empty(N, 2, device=dev) if rs_time != 0.0 else None
+        rs = (pix_vel, rs_time) if rs_time != 0.0 else None
+        ctx.rs = rs
+
         def _project():
             if pixvel:
                 _check(L.gs_project_pixvel_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
                                                _ptr(sh), K, args[4], _ptr(V), _ptr(twist), _ptr(times), args[5], args[6],
                                                args[7], args[8], H, W, args[11], args[12], defer_flags,
-                                               _ptr(records), _ptr(dkeys), _ptr(ntiles), _ptr(radii), _stream()),
+                                               _ptr(records), _ptr(dkeys), _ptr(ntiles), _ptr(radii), rs_time,
+                                               _ptr(pix_vel), _stream()),
                        "project_pixvel_fwd")
             else:
                 _check(L.gs_project_fused_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
@@ -1259,7 +1290,7 @@ class _RenderSubposes(Function):
         depth_acc = torch.zeros(S, H, W, device=dev) if return_depth else None
         ctx.prealloc = {} if (PREALLOC_BWD and any(ctx.needs_input_grad)) else None
         ctx.frame = None
-        if _native_frame_ok():
+        if _native_frame_ok() and rs is None:
             for attempt in range(3):
                 try:
                     out_img, out_T, ctx.frame = native_frame_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges,
@@ -1278,7 +1309,7 @@ class _RenderSubposes(Function):
             ctx.prealloc = None
         else:
             out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE, color,
-                                                    depth_acc, ctx.prealloc)
+                                                    depth_acc, ctx.prealloc, rs)
         ctx.slices = slices
         svals = bins = fidx = _placeholder_i32(dev)       # nothing to keep: the slices hold their own lists
         n_isect = last_num_intersects
@@ -1315,7 +1346,7 @@ class _RenderSubposes(Function):
         dev = means3d.device
         L = _L()
         if v_img is None and v_alpha is None:
-            return (None,) * 27
+            return (None,) * 28
         v_img = torch.zeros(ctx.img_shape, device=dev) if v_img is None else v_img.contiguous().float()
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
         combine = None
@@ -1352,7 +1383,7 @@ class _RenderSubposes(Function):
             native_frame_backward(ctx.frame, records, bg, edges, out_T, v_img, v_al, v_records, touched, combine)
         elif ctx.sliced:
             sliced_backward(records, ctx.slices, S, R, H, W, bg, edges, out_T, v_img, v_al, v_records, touched,
-                            combine)
+                            combine, ctx.rs)
         else:
             with _stage("raster_bwd"):
                 _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H, W,
@@ -1381,7 +1412,8 @@ class _RenderSubposes(Function):
                                                _ptr(sh), K, deg, _ptr(V), _ptr(twist), _ptr(times), fx, fy, cx, cy, H, W,
                                                clip, aa, _ptr(records), _ptr(v_records), _ptr(v_means), _ptr(v_scales),
                                                _ptr(v_quats), _ptr(v_opac), _ptr(v_sh), _ptr(v_V), _ptr(v_tw),
-                                               _ptr(touched), _ptr(xy_out), _proj_grad_flags(), _stream()),
+                                               _ptr(touched), _ptr(xy_out),
+                                               _proj_grad_flags() | (16 if ctx.rs is not None else 0), _stream()),
                        "project_pixvel_bwd")
                 if v_tw is not None:
                     v_lin, v_ang = v_tw[0:3], v_tw[3:6]
@@ -1393,7 +1425,7 @@ class _RenderSubposes(Function):
                                               _ptr(v_opac), _ptr(v_sh), _ptr(v_V), _ptr(touched), _ptr(xy_out),
                                               _proj_grad_flags(), _stream()), "project_fused_bwd")
         v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
-        return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 16 + (v_lin, v_ang, None, None)
+        return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 16 + (v_lin, v_ang, None, None, None)
 
 
 def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, sh: Tensor,
@@ -1402,7 +1434,7 @@ def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
                     sh_degree: int = 3, antialiased: bool = True, glob_scale: float = 1.0,
                     clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None, return_alpha: bool = True,
                     lin_vel: Optional[Tensor] = None, ang_vel: Optional[Tensor] = None,
-                    times: Optional[Tensor] = None, return_depth: bool = False):
+                    times: Optional[Tensor] = None, return_depth: bool = False, rolling_shutter_time: float = 0.0):
     """Fused hot path: project N Gaussians under P=S*R sub-pose viewmats, bin, sort, composite.
     -> (samples [S,H,W,3], alphas [S,H,W], radii int32 [P,N]).  scales/opacities are activated values.
     xy_grad_out (optional float32 [N,2]) is OVERWRITTEN during backward with the sum over the sub-poses of
@@ -1412,11 +1444,15 @@ def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
     lin_vel / ang_vel [3] (OpenCV camera frame) and ONE mid-exposure viewmat [4,4] as `viewmats`; every Gaussian is
     projected once and sub-pose p renders it at xy + times[p] * pixel_velocity (gradients reach viewmat and twist).
     return_depth=True appends a 4th result [S,H,W]: per sample the sum over the blended splats of weight *
-    camera-space depth (no gradient); expected depth = that / alpha (splatfacto's outputs["depth"])."""
+    camera-space depth (no gradient); expected depth = that / alpha (splatfacto's outputs["depth"]).
+    rolling_shutter_time != 0 (pixel-velocity model, rs_bands == 1, times = the S blur-sample times): EXACT per-row
+    rolling shutter — pixel row y sees every splat at xy + (times[s] + tau(y)) * pixel_velocity with
+    tau(y) = ((y + 0.5) / H - 0.5) * rolling_shutter_time; one projection / sort / list per blur sample, whatever H."""
     S, R = max(1, int(blur_samples)), max(1, int(rs_bands))
     out = _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
-                                bool(return_alpha), None, None, lin_vel, ang_vel, times, bool(return_depth))
+                                bool(return_alpha), None, None, lin_vel, ang_vel, times, bool(return_depth),
+                                float(rolling_shutter_time))
     return out if return_depth else out[:3]
 
 
@@ -1426,7 +1462,7 @@ def render_combined(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
                     gamma: float = 1.0, min_rgb_level: float = 0.0, sh_degree: int = 3, antialiased: bool = True,
                     glob_scale: float = 1.0, clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None,
                     return_alpha: bool = True, lin_vel: Optional[Tensor] = None, ang_vel: Optional[Tensor] = None,
-                    times: Optional[Tensor] = None, return_depth: bool = False):
+                    times: Optional[Tensor] = None, return_depth: bool = False, rolling_shutter_time: float = 0.0):
     """render_subposes + combine_samples as ONE autograd node: -> (rgb [H,W,3], alphas [S,H,W] or None, radii).
     Same values as the two-step form; the backward skips the [S,H,W,3] per-sample gradient tensor — the
     compositor's backward derives every pixel's sample gradient from rgb and its gradient."""
@@ -1434,7 +1470,7 @@ def render_combined(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
     out = _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
                                 bool(return_alpha), float(gamma), float(min_rgb_level), lin_vel, ang_vel, times,
-                                bool(return_depth))
+                                bool(return_depth), float(rolling_shutter_time))
     return out if return_depth else out[:3]
 
 

@@ -102,7 +102,9 @@ int gs_project_fused_bwd(int N, int P, const float* means3d, const float* scales
                                            gradient (pixels) — the densification statistic splatfacto reads from
                                            xys.grad; same zeroing rule as the other outputs*/,
                          int grad_flags /*as in gs_project_bwd; + 8: skip the double-precision covariance chain that
-                                          Gaussians with a scale ratio above 8 (needles) get by default*/, void* stream);
+                                          Gaussians with a scale ratio above 8 (needles) get by default; + 16
+                                          (pixel-velocity model): v_records[.., 9..10] hold d loss / d pixel velocity
+                                          from gs_rasterize_bwd_rs_slice*/, void* stream);
 
 /* ---- pixel-velocity model: the paper's first-order blur / rolling-shutter model (the fork's
  * own wording at /root/reference/README.md:200 "Fixed a bug in pixel velocity formulas").  ONE projection under the
@@ -115,7 +117,13 @@ int gs_project_pixvel_fwd(int N, int P, const float* means3d, const float* scale
                           const float* viewmat /*16*/, const float* twist /*6*/, const float* times /*P*/,
                           float fx, float fy, float cx, float cy, int img_height, int img_width, float clip_thresh,
                           int antialiased, int defer_color, float* records, unsigned* depth_keys,
-                          int* num_tiles_hit, int* radii, void* stream);
+                          int* num_tiles_hit, int* radii, float rolling_shutter_time /*0: off.  != 0: EXACT per-row rolling shutter — sub-pose p is the blur
+                                                        sample at times[p], the tile boxes are widened by the sweep
+                                                        +- rolling_shutter_time / 2 * pixel velocity and the row term is
+                                                        added by gs_rasterize_fwd_rs_slice / gs_rasterize_bwd_rs_slice*/,
+                          float* pix_vel /*[N*2] out: pixel velocity of every Gaussian; NULL allowed when
+                                           rolling_shutter_time == 0*/,
+                          void* stream);
 /* v_viewmat [16] and v_twist [12 floats: lin 3, ang 3, 6 unused] are accumulated into (caller zeroes; NULL skips) */
 int gs_project_pixvel_bwd(int N, int P, const float* means3d, const float* scales, float glob_scale,
                           const float* quats, const float* opacities, const float* sh, int K_stride, int sh_degree,
@@ -332,6 +340,24 @@ int gs_rasterize_fwd_slice_stats(const float* records, const int* sorted_vals, c
                                  int img_width, float* out_img, float* out_T, float* live_T, int* final_idx,
                                  unsigned char* tile_done, int first, int last, const int* gi_of_e, int* open_flag,
                                  unsigned long long* stats, void* stream);
+/* ---- exact per-row rolling shutter of the pixel-velocity model (csrc/raster_rs.hip; SURVEY App. A "Paper's blur/RS
+ * model", flag /root/reference/train.py:56, field /root/reference/render_video.py:242-243).  ONE record per (blur
+ * sample, Gaussian); pixel row y evaluates the splat at xy + tau(y) * pix_vel[g], tau(y) = ((y + 0.5)/H - 0.5) * T_ro.
+ * Same slice / state protocol as gs_rasterize_fwd_slice / gs_rasterize_bwd_slice with R = 1; sorted_ids [I+8] is the
+ * record index of every sorted entry, sorted_vals its emission index (tuple slot).  The backward's tuples carry
+ * d loss / d pix_vel in slots 9 and 10 (gs_reduce_grad_tuples sums them into v_records[.., 9..10];
+ * gs_project_pixvel_bwd picks them up with grad_flags + 16). */
+int gs_rasterize_fwd_rs_slice(const float* records, const int* tile_bins, const int* band_edges, const float* background,
+                              int S, int img_height, int img_width, float* out_img, float* out_T, float* live_T,
+                              int* final_idx, unsigned char* tile_done, int first, int last, const int* sorted_ids,
+                              int n_records, float* out_depth, int* open_flag, const float* pix_vel, int N,
+                              float rolling_shutter_time, void* stream);
+int gs_rasterize_bwd_rs_slice(const float* records, const int* sorted_vals, const int* tile_bins, const int* band_edges,
+                              const float* background, int S, int img_height, int img_width, const float* out_T,
+                              const int* final_idx, const float* v_img, const float* v_alpha, float* bwd_T, float* bwd_B,
+                              float* tuples, unsigned char* flags, const int* sorted_ids, int n_records, int variant,
+                              const float* cmb_scale, float cmb_gamma, float cmb_min_level, const float* pix_vel, int N,
+                              float rolling_shutter_time, void* stream);
 /* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B [S,H,W] (behind-colour . v_out, init = 0)
  * carry the reverse-traversal state; both may be NULL on the tuple path when the frame has a single slice */
 int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,

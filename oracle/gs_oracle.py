@@ -306,8 +306,10 @@ class Rasterized:
 
 def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.ndarray, tile_bins: np.ndarray,
                      img_height: int, img_width: int, background: Optional[torch.Tensor] = None,
-                     tile_rows: Optional[Tuple[int, int]] = None) -> Rasterized:
-    """Front-to-back alpha compositing of pre-sorted intersections, differentiable by autograd."""
+                     tile_rows: Optional[Tuple[int, int]] = None, row_shift=None) -> Rasterized:
+    """Front-to-back alpha compositing of pre-sorted intersections, differentiable by autograd.
+    row_shift = (pix_vel [N,2], tau [H]): pixel row y evaluates every splat at xys + tau[y] * pix_vel (the exact
+    rolling-shutter form of the pixel-velocity model)."""
     dt = xys.dtype
     H, W = img_height, img_width
     tiles_x = (W + TILE - 1) // TILE
@@ -346,6 +348,11 @@ def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.nda
             cxx, cxy, cyy = conics[ids, 0], conics[ids, 1], conics[ids, 2]
             dx = gx[:, None] - PX[None, :]
             dy = gy[:, None] - PY[None, :]
+            if row_shift is not None:
+                pv_, tau_ = row_shift
+                TAU = tau_[y_lo:y_hi].to(dt)[:, None].expand(hh, ww).reshape(-1)
+                dx = dx + pv_[ids, 0][:, None] * TAU[None, :]
+                dy = dy + pv_[ids, 1][:, None] * TAU[None, :]
             sigma = 0.5 * (cxx[:, None] * dx * dx + cyy[:, None] * dy * dy) + cxy[:, None] * dx * dy
             vis = torch.exp(-sigma)
             alpha = torch.clamp(opac[ids][:, None] * vis, max=ALPHA_MAX)
@@ -413,6 +420,35 @@ def _bounds_from_xys_radii(xys, depths, radii, num_tiles_hit, H, W) -> Projected
     tmax = torch.stack([torch.where(ok, x1, zi), torch.where(ok, y1, zi)], -1)
     nt = (tmax[:, 0] - tmin[:, 0]) * (tmax[:, 1] - tmin[:, 1])
     return Projected(xys, depths, radii, None, None, nt.to(torch.int32), None, tmin, tmax)
+
+
+def _bounds_swept(pr: "Projected", xys, pv, half_time: float, H: int, W: int) -> "Projected":
+    """Tile boxes of splats whose centres sweep xys -/+ half_time * pv during the readout (float32, the op order of
+    gs_math.h::tile_bounds_swept): the box of the 3-sigma circle dragged along the segment."""
+    tiles_x = (W + TILE - 1) // TILE
+    tiles_y = (H + TILE - 1) // TILE
+    f32 = torch.float32
+    x = xys.detach().to(f32)
+    v = pv.detach().to(f32)
+    ht = torch.ones((), dtype=f32) * float(half_time)
+    xa, ya = x[:, 0] - ht * v[:, 0], x[:, 1] - ht * v[:, 1]
+    xb, yb = x[:, 0] + ht * v[:, 0], x[:, 1] + ht * v[:, 1]
+    inv_tile = torch.ones((), dtype=f32) / float(TILE)
+    tr = pr.radii.to(f32) * inv_tile
+    xlo, xhi = torch.minimum(xa, xb) * inv_tile, torch.maximum(xa, xb) * inv_tile
+    ylo, yhi = torch.minimum(ya, yb) * inv_tile, torch.maximum(ya, yb) * inv_tile
+    x0 = torch.trunc(xlo - tr).clamp(0, tiles_x).to(torch.int32)
+    x1 = torch.trunc((xhi + tr) + 1.0).clamp(0, tiles_x).to(torch.int32)
+    y0 = torch.trunc(ylo - tr).clamp(0, tiles_y).to(torch.int32)
+    y1 = torch.trunc((yhi + tr) + 1.0).clamp(0, tiles_y).to(torch.int32)
+    nt = (x1 - x0) * (y1 - y0)
+    ok = (pr.radii > 0) & (nt > 0)
+    zi = torch.zeros_like(x0)
+    tmin = torch.stack([torch.where(ok, x0, zi), torch.where(ok, y0, zi)], -1)
+    tmax = torch.stack([torch.where(ok, x1, zi), torch.where(ok, y1, zi)], -1)
+    return Projected(xys=xys, depths=pr.depths, radii=torch.where(ok, pr.radii, torch.zeros_like(pr.radii)),
+                     conics=pr.conics, compensation=pr.compensation, num_tiles_hit=torch.where(ok, nt, zi).to(torch.int32),
+                     cov3d=pr.cov3d, tile_min=tmin, tile_max=tmax)
 
 
 # --------------------------------------------------------------------------- #
@@ -487,6 +523,10 @@ class RenderConfig:
     # "pixel_velocity": the paper's first-order model — ONE projection at the mid-exposure
     # pose, sub-pose p re-centres each splat at xy + t_p * J(-(w x p_c + v)); depth order, covariance, colour fixed
     motion_model: str = "se3"
+    # pixel-velocity model only: the rolling shutter in its CONTINUOUS form (row time
+    # (y/H - 1/2) * T_ro) instead of rs_bands tile-row bands: pixel row y sees every splat at
+    # xy + (t_s + ((y + 0.5)/H - 0.5) * T_ro) * pixel_velocity; rs_bands is ignored
+    rs_exact: bool = False
 
 
 def combine_samples(samples: torch.Tensor, gamma: float, min_rgb_level: float) -> torch.Tensor:
@@ -579,11 +619,15 @@ def _render_pixel_velocity(cfg: RenderConfig, means, scales, quats, opacities, s
                            background, return_parts):
     """The paper's model: one projection, per-sub-pose re-centred splats, same averaging."""
     dt = means.dtype
-    times, samp, band = subpose_times(cfg.blur_samples, cfg.exposure_time, cfg.rs_bands, cfg.rolling_shutter_time)
-    rows = band_tile_rows(cfg.img_height, cfg.rs_bands)
+    exact = bool(cfg.rs_exact)
+    n_bands = 1 if exact else cfg.rs_bands
+    times, samp, band = subpose_times(cfg.blur_samples, cfg.exposure_time, n_bands, cfg.rolling_shutter_time)
+    rows = band_tile_rows(cfg.img_height, n_bands)
     S = max(1, cfg.blur_samples)
     H, W = cfg.img_height, cfg.img_width
     V = viewmat
+    # row time of every pixel row (pixel centres at +0.5), continuous form
+    tau_rows = ((torch.arange(H, dtype=dt) + 0.5) / H - 0.5) * cfg.rolling_shutter_time if exact else None
     pr0 = project_gaussians(means, scales, cfg.glob_scale, quats, V, cfg.fx, cfg.fy, cfg.cx, cfg.cy, H, W, TILE,
                             cfg.clip_thresh, keep_offscreen=True)
     pv = pixel_velocity(means, V, cfg.fx, cfg.fy, lin_vel, ang_vel, cfg.clip_thresh)
@@ -599,11 +643,15 @@ def _render_pixel_velocity(cfg: RenderConfig, means, scales, quats, opacities, s
     geom = (pr0.radii > 0).to(dt)[:, None]
     for p, tau in enumerate(times):
         xys = (pr0.xys + (torch.ones((), dtype=dt) * tau) * pv) * geom
-        pr = _recentre(pr0, xys, H, W)
+        if exact:
+            pr = _bounds_swept(pr0, xys, pv * geom, 0.5 * cfg.rolling_shutter_time, H, W)
+        else:
+            pr = _recentre(pr0, xys, H, W)
         keys, gids = map_gaussian_to_intersects(pr, W)
         keys, gids = sort_intersects(keys, gids)
         bins = get_tile_bin_edges(keys, tiles)
-        r = rasterize_sorted(pr.xys, pr.conics, rgb, op, gids, bins, H, W, background, tile_rows=rows[band[p]])
+        r = rasterize_sorted(pr.xys, pr.conics, rgb, op, gids, bins, H, W, background, tile_rows=rows[band[p]],
+                             row_shift=(pv * geom, tau_rows) if exact else None)
         sample_imgs[samp[p]] = sample_imgs[samp[p]] + r.img
         sample_alpha[samp[p]] = sample_alpha[samp[p]] + r.alpha
         frag |= r.fragile

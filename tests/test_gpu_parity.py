@@ -1757,3 +1757,111 @@ def test_backward_transmittance_rebuild_over_a_500_entry_tile_vs_float64(gs, ora
           "Gaussians with a gradient:", blended)
     for k, v in worst.items():
         assert v <= 1.0, (k, v)
+
+
+@pytest.mark.parametrize("S,W,H,n,base", [(1, 144, 128, 2500, None), (3, 128, 160, 3000, None), (2, 96, 128, 6000, 8)])
+def test_exact_rolling_shutter_pixel_velocity_vs_oracle(gs, oracle, dev, S, W, H, n, base):
+    """VERDICT round 2 'Missing 1' / item 5: exact per-row rolling-shutter time in the pixel-velocity model
+    (csrc/raster_rs.hip; gs_project_pixvel_fwd widens the tile boxes by the sweep and hands out the pixel velocity).
+    Per blur sample ONE projection: swept tile counts / radii against the float32 oracle (integers, exact), image and
+    every gradient — Gaussians, mid-exposure viewmat, linear and angular velocity (the row term adds
+    sum tau(y) * d/d centre to d loss / d pixel-velocity) — against the float64 oracle's continuous mode.  Last case: a
+    tiny slice budget, several depth slices with carried per-pixel state."""
+    from gsdeblur_amd import ops
+    O = oracle
+    sc = O.synthetic_scene(n, W, H, seed=900 + S, scale_mult=6.0)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 30, sc["ang_vel"] * 15
+    et, rt, gamma, mlevel = 1 / 60, 1 / 30, 2.2, 10.0
+    bg = torch.tensor([0.05, 0.1, 0.15])
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel", "viewmat"]
+    cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], blur_samples=S, rs_bands=1, exposure_time=et,
+                         rolling_shutter_time=rt, gamma=gamma, min_rgb_level=mlevel, motion_model="pixel_velocity",
+                         rs_exact=True)
+    q = {k: sc[k].double().requires_grad_(True) for k in names}
+    ref, _, ref_samples, frag, parts, _ = O.render(cfg, q["means"], q["log_scales"].exp(), q["quats"],
+                                                   torch.sigmoid(q["opacity_logits"]), q["sh"], q["viewmat"],
+                                                   q["lin_vel"], q["ang_vel"], background=bg.double(), return_parts=True)
+    good = ~frag
+    assert frag.float().mean().item() <= FRAGILE_MAX
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)) * good[..., None]
+    (ref * wt.double()).sum().backward()
+    p = {k: sc[k].float().to(dev).requires_grad_(True) for k in names}
+    times, _, _ = gs.subpose_schedule(S, et, 1, 0.0)
+    times_t = torch.tensor(times, device=dev)
+    saved = ops.SLICE_BASE
+    try:
+        if base is not None:
+            ops.SLICE_BASE = base
+        samples, alphas, radii = gs.render_subposes(p["means"], p["log_scales"].exp(), p["quats"],
+                                                    torch.sigmoid(p["opacity_logits"]), p["sh"], p["viewmat"], bg.to(dev),
+                                                    S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, sh_degree=3,
+                                                    lin_vel=p["lin_vel"], ang_vel=p["ang_vel"], times=times_t,
+                                                    rolling_shutter_time=rt)
+        out = gs.combine_samples(samples, gamma, mlevel)
+        (out * wt.to(dev)).sum().backward()
+        n_slices = sum(1 for v in ops.last_slice_intersects if int(v) > 0)
+        n_isect = ops.last_num_intersects
+    finally:
+        ops.SLICE_BASE = saved
+    if base is not None:
+        assert n_slices >= 3, n_slices
+    # integers: the float32 oracle sweeps the same float32 projection
+    pr0 = O.project_gaussians(sc["means"], sc["log_scales"].exp(), 1.0, sc["quats"], sc["viewmat"], sc["fx"], sc["fy"],
+                              sc["cx"], sc["cy"], H, W, keep_offscreen=True)
+    pv = O.pixel_velocity(sc["means"], sc["viewmat"], sc["fx"], sc["fy"], sc["lin_vel"], sc["ang_vel"])
+    geom = (pr0.radii > 0).float()[:, None]
+    total = 0
+    for s_i, tau in enumerate(times):
+        prs = O._bounds_swept(pr0, (pr0.xys + torch.tensor(tau, dtype=torch.float32) * pv) * geom, pv * geom, 0.5 * rt, H, W)
+        assert np.array_equal(radii[s_i].cpu().numpy(), prs.radii.numpy()), s_i
+        total += int(prs.num_tiles_hit.sum())
+    assert n_isect == total                                      # swept tile counts, bit-exact
+    assert (samples.detach().cpu().double() - ref_samples)[:, good].abs().max().item() < IMG_ATOL
+    assert (out.detach().cpu().double() - ref.detach())[good].abs().max().item() < 5e-4
+    # the bands model with one band is NOT this image: the row term is really there
+    with torch.no_grad():
+        flat, _, _ = gs.render_subposes(p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["opacity_logits"]),
+                                        p["sh"], p["viewmat"], bg.to(dev), S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"],
+                                        H, W, sh_degree=3, lin_vel=p["lin_vel"], ang_vel=p["ang_vel"], times=times_t)
+    assert (flat - samples.detach()).abs().max().item() > 0.05
+    worst = {}
+    for k in names:
+        g_hip, g_ref = p[k].grad.cpu().numpy(), q[k].grad.numpy()
+        if k == "viewmat":
+            g_hip, g_ref = g_hip[:3], g_ref[:3]
+        worst[k] = grad_el_ratio(g_hip, g_ref)
+    print(f"exact rolling shutter S={S}: per-element gradient error / tolerance:",
+          {k: round(v, 3) for k, v in worst.items()}, "slices", n_slices)
+    for k, v in worst.items():
+        assert v <= 1.0, (k, v)
+
+
+def test_model_exact_rolling_shutter_mode(gs, oracle, dev):
+    """SplatfactoDeblurConfig(rolling_shutter_mode='exact', motion_model='pixel_velocity'): get_outputs renders with
+    the continuous row time (one sub-pose per blur sample: radii is [S, N] whatever rs_bands says) and converges to
+    what many bands give; the SE(3) model refuses the mode."""
+    O = oracle
+    n, W, H = 3000, 128, 160
+    sc = O.synthetic_scene(n, W, H, seed=31, scale_mult=6.0)
+    c2w = torch.eye(4)[:3].clone()
+    c2w[:, 1] *= -1
+    c2w[:, 2] *= -1
+    cam = gs.Camera(c2w, sc["fx"], sc["fy"], sc["cx"], sc["cy"], W, H,
+                    metadata=dict(cam_idx=0, camera_linear_velocity=[0.8, 0.2, 0.0],
+                                  camera_angular_velocity=[0.0, 0.5, 0.2], exposure_time=1 / 60,
+                                  rolling_shutter_time=1 / 30))
+    imgs = {}
+    for mode, bands in (("exact", 10), ("bands", 10), ("bands", 1)):
+        cfg = gs.SplatfactoDeblurConfig(blur_samples=2, rs_bands=bands, gamma=2.2, min_rgb_level=10.0,
+                                        motion_model="pixel_velocity", rolling_shutter_mode=mode)
+        m = gs.SplatfactoDeblurModel.from_scene(cfg, sc, dev)
+        out = m.get_outputs_for_camera(cam)
+        imgs[(mode, bands)] = out["rgb"]
+        assert m.radii.shape == ((2, n) if mode == "exact" else (2 * bands, n))
+        assert out["depth"].shape == (H, W, 1) and torch.isfinite(out["depth"]).all()
+    e10 = (imgs[("exact", 10)] - imgs[("bands", 10)]).abs().mean().item()
+    e1 = (imgs[("exact", 10)] - imgs[("bands", 1)]).abs().mean().item()
+    assert e10 < 0.35 * e1 and e1 > 1e-3, (e10, e1)
+    with pytest.raises(ValueError, match="pixel_velocity"):
+        bad = gs.SplatfactoDeblurModel.from_scene(gs.SplatfactoDeblurConfig(rolling_shutter_mode="exact"), sc, dev)
+        bad.get_outputs_for_camera(cam)

@@ -340,3 +340,54 @@ def test_vectorised_oracle_equals_independent_pixel_loop(oracle, seed, n, H, W, 
         changed = np.abs(bu["v_opacity"] - b["v_opacity"]) > 0
         assert changed.any() and not changed[opac.numpy() <= 0.999].any()
         assert np.array_equal(bu["v_colors"], b["v_colors"])
+
+
+def test_exact_rolling_shutter_is_the_limit_of_row_bands_and_differentiable(oracle):
+    """VERDICT round 2 'Missing 1': the continuous per-row rolling shutter of the pixel-velocity model
+    (RenderConfig.rs_exact; SURVEY App. A 'row time (y/H - 1/2) T_ro').  Known answers:
+      * zero readout time -> exactly the render without rolling shutter;
+      * R tile-row bands converge to it: the gap shrinks as R grows (bands evaluate tau at their centre row, the exact
+        form at every row: first-order error ~ band height);
+      * autograd through the row term agrees with central finite differences (twist and a Gaussian centre)."""
+    O = oracle
+    H, W, n = 128, 96, 400
+    sc = O.synthetic_scene(n, W, H, seed=21, dtype=torch.float64, scale_mult=8.0)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 40, sc["ang_vel"] * 25          # ~10 px of readout motion
+    sc["sh"][:, 1:] = 0.0            # view-independent colour: the oracle (like splatfacto) detaches the view direction,
+    #                                  a finite difference of a mean would see that dependence
+    kw = dict(blur_samples=2, exposure_time=1 / 60, gamma=2.2, min_rgb_level=10.0, motion_model="pixel_velocity")
+    base = _cfg(O, sc, H, W, rs_bands=1, rolling_shutter_time=0.0, **kw)
+    exact0 = _cfg(O, sc, H, W, rs_bands=1, rolling_shutter_time=0.0, rs_exact=True, **kw)
+    img0, _ = _render64(O, sc, base)
+    img0e, _ = _render64(O, sc, exact0)
+    assert torch.equal(img0, img0e)
+    T_ro = 1 / 30
+    exact = _cfg(O, sc, H, W, rs_bands=1, rolling_shutter_time=T_ro, rs_exact=True, **kw)
+    ref, _ = _render64(O, sc, exact)
+    assert (ref - img0).abs().max() > 0.05                     # the readout really moves things
+    gaps = []
+    for R in (1, 2, 4, 8):
+        img, _ = _render64(O, sc, _cfg(O, sc, H, W, rs_bands=R, rolling_shutter_time=T_ro, **kw))
+        gaps.append(float((img - ref).abs().mean()))
+    assert gaps[0] > gaps[1] > gaps[2] > gaps[3] and gaps[3] < 0.3 * gaps[0], gaps
+    # gradients through the row term: d/d lin_vel and d/d one mean, against central differences
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    lin = sc["lin_vel"].clone().requires_grad_(True)
+    means = sc["means"].clone().requires_grad_(True)
+    out, _ = O.render(exact, means, sc["log_scales"].exp(), sc["quats"], torch.sigmoid(sc["opacity_logits"]), sc["sh"],
+                      sc["viewmat"], lin, sc["ang_vel"])
+    (out * wt).sum().backward()
+
+    def loss(lv, mm):
+        o, _ = O.render(exact, mm, sc["log_scales"].exp(), sc["quats"], torch.sigmoid(sc["opacity_logits"]), sc["sh"],
+                        sc["viewmat"], lv, sc["ang_vel"])
+        return float((o * wt).sum())
+    eps = 1e-6
+    for j in range(3):
+        d = torch.zeros(3, dtype=torch.float64); d[j] = eps
+        fd = (loss(sc["lin_vel"] + d, sc["means"]) - loss(sc["lin_vel"] - d, sc["means"])) / (2 * eps)
+        assert abs(fd - float(lin.grad[j])) <= 2e-4 * max(1.0, abs(fd)), (j, fd, float(lin.grad[j]))
+    g_idx = int(means.grad.abs().sum(dim=1).argmax())
+    d = torch.zeros_like(sc["means"]); d[g_idx, 0] = eps
+    fd = (loss(sc["lin_vel"], sc["means"] + d) - loss(sc["lin_vel"], sc["means"] - d)) / (2 * eps)
+    assert abs(fd - float(means.grad[g_idx, 0])) <= 2e-4 * max(1.0, abs(fd))
