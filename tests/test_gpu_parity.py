@@ -1847,8 +1847,8 @@ def test_model_exact_rolling_shutter_mode(gs, oracle, dev):
     c2w[:, 1] *= -1
     c2w[:, 2] *= -1
     cam = gs.Camera(c2w, sc["fx"], sc["fy"], sc["cx"], sc["cy"], W, H,
-                    metadata=dict(cam_idx=0, camera_linear_velocity=[0.8, 0.2, 0.0],
-                                  camera_angular_velocity=[0.0, 0.5, 0.2], exposure_time=1 / 60,
+                    metadata=dict(cam_idx=0, camera_linear_velocity=[2.5, 0.6, 0.0],
+                                  camera_angular_velocity=[0.0, 1.5, 0.6], exposure_time=1 / 60,
                                   rolling_shutter_time=1 / 30))
     imgs = {}
     for mode, bands in (("exact", 10), ("bands", 10), ("bands", 1)):
