@@ -172,6 +172,52 @@ def guarded_cpu_baseline(limit_s: int = 150):
         signal.signal(signal.SIGALRM, old)
 
 
+def train_step_timing(gs, dev, sc, N, W, H, S, steps=5):
+    """One full training iteration on the secondary scene through the model surface: render (HIP) -> image loss
+    (0.8 L1 + 0.2 (1 - SSIM)) -> backward -> Adam on the six Gaussian groups; once with the HIP loss / optimizer kernels
+    (csrc/train.hip), once with the torch formulations they replace (conv2d SSIM + autograd, six torch.optim.Adam)."""
+    import time as _t
+    cfg = gs.SplatfactoDeblurConfig(blur_samples=S, rolling_shutter_compensation=False, gamma=2.2, min_rgb_level=10.0)
+    c2w = torch.eye(4)[:3].clone()
+    c2w[:, 1] *= -1
+    c2w[:, 2] *= -1
+    cam = gs.Camera(c2w, sc["fx"], sc["fy"], sc["cx"], sc["cy"], W, H,
+                    metadata=dict(cam_idx=0, camera_linear_velocity=[float(v) for v in sc["lin_vel"] * torch.tensor([1., -1., -1.])],
+                                  camera_angular_velocity=[float(v) for v in sc["ang_vel"] * torch.tensor([1., -1., -1.])],
+                                  exposure_time=sc["exposure_time"], rolling_shutter_time=0.0))
+    target = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(7)).to(dev)
+    res = {}
+    for tag, fused in (("hip_loss_and_adam", True), ("torch_loss_and_adam", False)):
+        model = gs.SplatfactoDeblurModel.from_scene(cfg, sc, dev)
+        opts = gs.training.make_optimizers(model, fused=fused)
+
+        def one():
+            if fused:
+                gs.training.train_step(model, opts, cam, target, 0.2)
+                return
+            model.train()
+            for o in opts.values():
+                o.zero_grad(set_to_none=True)
+            out = model.get_outputs(cam)
+            gs.training.image_loss_torch(out["rgb"], target, 0.2).backward()
+            for o in opts.values():
+                o.step()
+            model.step += 1
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        res[tag + "_ms"] = round((_t.perf_counter() - t0) / steps * 1e3, 3)
+        del model, opts
+        torch.cuda.empty_cache()
+    res["note"] = ("full iteration on the secondary scene: render + loss + backward + optimizer step; train_step also "
+                   "reads the loss back for logging")
+    return res
+
+
 def launcher_argv(gpus: int, argv, environ, port=None):
     """`python bench.py --gpus N` without a launcher becomes the launcher: -> the torch.distributed.run command line
     (one rank per GPU over RCCL, rendezvous on 127.0.0.1), or None when this process already is a rank / N == 1."""
@@ -298,6 +344,20 @@ def main():
         st2 = ops.profiler.summary_ms()
         ops.profiler = None
         ms2 = dt2 / k2 * 1e3
+        # the secondary scene's own roofline block: its dominant kernel on the same bytes formula
+        st2m = {k: sum(v) / 3 for k, v in st2.items()}
+        I2 = int(sum(ops.last_slice_intersects))
+        npix2 = H * W
+        bwd_bytes2 = 40 * I2 + S * 32 * npix2 + 36 * S * R * N
+        sec_roofline = None
+        if st2m.get("raster_bwd"):
+            ach2 = bwd_bytes2 / (st2m["raster_bwd"] * 1e-3) / 1e9
+            sec_roofline = {"bound": "hbm", "kernel": "raster_bwd_sload_kernel", "achieved": round(ach2, 2),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach2 / HBM_PEAK_GBS, 5),
+                            "algorithmic_bytes_per_step": bwd_bytes2, "kernel_ms_per_step": round(st2m["raster_bwd"], 4),
+                            "launches_per_step": len(st2["raster_bwd"]) / 3,
+                            "kernel_time_source": "HIP events around every launch, 3 steps after the timed region"}
+        train = train_step_timing(gs, dev, w2.sc, N, W, H, S) if world == 1 else None
         secondary = {
             "scene": "profile 'trained' (gsdeblur_amd.data.synthetic_scene): same seeded draws, world-space scale "
                      "0.006*z per Gaussian (constant ~7 px screen size), opacity logits ~ N(-3.3, 1.5^2)",
@@ -305,7 +365,8 @@ def main():
             "steps": k2, "tile_intersections_per_step": ops.last_num_intersects,
             "tile_intersections_emitted": int(sum(ops.last_slice_intersects)),
             "depth_slices": list(ops.last_slice_intersects), "gaussians_with_gradient": w2.rows_with_gradient(),
-            "stage_ms": {k: round(sum(v) / 3, 4) for k, v in st2.items()}}
+            "stage_ms": {k: round(sum(v) / 3, 4) for k, v in st2.items()},
+            "roofline": sec_roofline, "train_step": train}
         del w2
         torch.cuda.empty_cache()
     if world > 1:
@@ -363,7 +424,8 @@ def main():
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
-                if tj.get("workload") == [N, W, H, S, R]:
+                from gsdeblur_amd import _build as _gsd_build
+                if tj.get("workload") == [N, W, H, S, R] and tj.get("lib_source_hash") == _gsd_build.source_hash():
                     traffic = tj["hbm_bytes_per_step"].get(kname)
             except Exception:
                 traffic = None
@@ -374,7 +436,12 @@ def main():
         try:
             tj = json.loads(tfile.read_text()) if tfile.exists() else {}
             vi = tj.get("valu", {}).get(kname)
-            if vi and tj.get("workload") == [N, W, H, S, R]:
+            from gsdeblur_amd import _build as _gsd_build
+            fresh = tj.get("lib_source_hash") == _gsd_build.source_hash()
+            if vi and tj.get("workload") == [N, W, H, S, R] and not fresh:
+                valu = {"stale": "profiles/traffic.json was measured on other kernel sources (lib_source_hash differs): "
+                                 "re-run tools/gpu_round.sh pmc"}
+            elif vi and tj.get("workload") == [N, W, H, S, R]:
                 simd_cycles = single[dom] * 1e-3 * tj["valu"].get("clock_hz", 2.1e9) * 1024 / max(1.0, launches.get(dom, 1.0))
                 valu = {"wave_instructions_per_launch": vi["insts_valu"],
                         "issue_frac_at_2_cycles": round(vi["insts_valu"] * 2.0 / simd_cycles, 4),
@@ -402,6 +469,19 @@ def main():
                                        "pipeline_bytes": pipeline_bytes(n_isect),
                                        "pipeline_frac": round(pipeline_bytes(n_isect) / (ms_per_step * 1e-3) / 1e9 /
                                                               HBM_PEAK_GBS, 5)}}
+        lane_util = None
+        lf = ROOT / "profiles" / "lane_stats.jsonl"
+        if lf.exists():
+            try:
+                lane_util = {"source": "profiles/lane_stats.jsonl (tools/lane_stats.py: gs_rasterize_fwd_slice_stats "
+                                       "counters of one forward per scene; committed measurement, not this run)"}
+                for ln in lf.read_text().splitlines():
+                    dj = json.loads(ln)
+                    lane_util[dj["scene"]] = {k: dj[k] for k in ("pixel_utilisation_live", "blocks4x4_per_entry_geometric",
+                                                                 "quads8x8_per_entry_geometric", "lockstep_speedup_4x4",
+                                                                 "lockstep_speedup_8x8") if k in dj}
+            except Exception:
+                lane_util = None
         line = {
             "metric": "fwd+bwd rasterize MPix/s at 1M Gaussians, 1080p, 5 sub-poses",
             "value": round(value, 3), "unit": "MPix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -424,6 +504,7 @@ def main():
             "stage_ms": stage_ms,
             "stage_ms_source": f"{n_stage_steps} extra steps with HIP events around every stage, after the timed region",
             "roofline": roofline,
+            "lane_utilisation": lane_util,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = guarded_cpu_baseline()

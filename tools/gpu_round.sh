@@ -48,6 +48,12 @@ if [ "$MODE" != "quick" ]; then
     find $OUT/pmc_$tag -name "*.csv" | head -5 | tee -a $OUT/summary.log
   done
   python tools/pmc_summary.py $OUT 2>&1 | tail -40 | tee -a $OUT/summary.log
-  python tools/make_traffic.py $OUT "round 2 ${TAG:-final}" > $OUT/traffic.json 2>/dev/null; head -c 600 $OUT/traffic.json | tee -a $OUT/summary.log
+  python tools/make_traffic.py $OUT "round 3 ${TAG:-final}" > $OUT/traffic.json 2>/dev/null; head -c 600 $OUT/traffic.json | tee -a $OUT/summary.log
+  echo "== rocprofv3 kernel trace, fitted-model-like scene ==" | tee -a $OUT/summary.log
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_trained -o trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --scene trained) > $OUT/rocprof_trained.log 2>&1
+  for f in $(find $OUT/prof_trained -name "*kernel_stats*.csv" | head -1); do head -16 $f | cut -c1-200 | tee -a $OUT/summary.log; cp $f $OUT/kernel_stats_trained.csv; done
+  for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats.csv; done
+  python tools/trace_step.py $OUT/prof > $OUT/timeline.txt 2>/dev/null; tail -1 $OUT/timeline.txt | tee -a $OUT/summary.log
+  rm -rf $OUT/prof_trained/*/*kernel_trace* $OUT/prof/*/*kernel_trace* 2>/dev/null
 fi
 echo "== done ==" | tee -a $OUT/summary.log

@@ -8,6 +8,9 @@ import glob
 import json
 import sys
 from collections import defaultdict
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 
 out, tag = sys.argv[1], sys.argv[2]
 KERNELS = ["raster_bwd_sload_kernel", "raster_fwd_sload_kernel", "raster_bwd_kernel_v2", "raster_fwd_slice_kernel",
@@ -15,8 +18,8 @@ KERNELS = ["raster_bwd_sload_kernel", "raster_fwd_sload_kernel", "raster_bwd_ker
            "slice_colors_kernel", "emit_open_kernel", "reduce_tuples_wave_kernel", "radix_scatter_kernel",
            "radix_hist_kernel"]
 # issue cycles per VALU wave-instruction of the kernel's inner-loop mix (tools/valu_mix.py x tools/valu_bench.hip)
-MIX = {"raster_fwd_sload_kernel": 861.1 / 245, "raster_bwd_sload_kernel": 1429.0 / 441,
-       "raster_fwd_slice_kernel": 328.7 / 82, "raster_bwd_kernel_v2": 480.4 / 125}
+MIX = {"raster_fwd_sload_kernel": 859.8 / 245, "raster_bwd_sload_kernel": 1483.9 / 441,
+       "raster_fwd_slice_kernel": 346.5 / 90, "raster_bwd_kernel_v2": 489.4 / 125}      # profiles/r03_valu_mix.txt
 
 
 def mean_per_kernel(counter):
@@ -55,7 +58,7 @@ def sq(counter):
 insts, wcyc, wait, busy = sq("SQ_INSTS_VALU"), sq("SQ_WAVE_CYCLES"), sq("SQ_WAIT_INST_ANY"), sq("SQ_BUSY_CYCLES")
 valu = {"clock_hz": 2.1e9,
         "source": f"rocprofv3 --pmc SQ_* pass of {tag}; mix_cycles_per_inst = issue cycles of the inner loop's static "
-                  "instruction mix (tools/valu_mix.py) priced with tools/valu_bench.hip (profiles/r02_run1_valu_bench.log); "
+                  "instruction mix (tools/valu_mix.py) priced with tools/valu_bench3.hip (profiles/r03_run3_valu_bench3.log); "
                   "clock: s_memtime vs wall in the same micro-benchmark (~2.1 GHz under load)"}
 for k in MIX:
     if k in insts:
@@ -63,8 +66,18 @@ for k in MIX:
                    "wait_inst_any_frac": round(wait[k] / wcyc[k], 3) if k in wait and k in wcyc else None,
                    # SQ_WAVE_CYCLES counts quad-cycles summed over waves; SQ_BUSY_CYCLES is per shader engine (32)
                    "waves_per_simd": round(wcyc[k] * 4 / (busy[k] / 32.0) / 1024, 2) if k in busy and k in wcyc else None}
+def _lib_hash():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_gsd_build", Path(__file__).resolve().parents[1] / "3dgs-deblur_amd" / "_build.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_hash()
+
+
 doc = {
     "workload": [1000000, 1920, 1080, 5, 1],
+    # the kernels these counters were measured on: bench.py only quotes them while the sources still hash to this
+    "lib_source_hash": _lib_hash(),
     "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), {tag}; "
               "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per launch: FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section "
               "(gfx950 counts 128-B requests as 64 B), WRITE_SIZE uncalibrated; tools/make_traffic.py",

@@ -12,9 +12,12 @@ import sys
 from collections import Counter
 from pathlib import Path
 
-COST = {  # measured, valu_bench.hip, w/SIMD=4 column
-    "fma/mul/add, VGPR operands": 1.93, "fma/mul/add, SGPR operand": 3.25, "v_pk_*_f32": 3.24,
-    "v_min/max/cndmask/mov/other": 3.20, "v_cmp": 4.00, "v_exp/v_rcp": 6.29, "v_readlane": 7.89}
+COST = {  # measured, w/SIMD=4 column.  Round 3 re-measured them on pinned registers (tools/valu_bench3.hip,
+    # profiles/r03_run3_valu_bench3.log): two-source mul / add / mov / integer ops 2.17, fma 2.08 when its second and
+    # third source sit in registers of different parity (3.03 otherwise: priced at the mean), anything with an SGPR
+    # operand / v_min / v_max / v_cndmask / DPP 3.2-3.6, v_cmp 3.2-3.4 (round 2 said 4.0), v_pk_* 3.49, v_exp / v_rcp 6.45
+    "fma/mul/add, VGPR operands": 2.3, "fma/mul/add, SGPR operand": 3.25, "v_pk_*_f32": 3.49,
+    "v_min/max/cndmask/mov/other": 3.30, "v_cmp": 3.30, "v_exp/v_rcp": 6.45, "v_readlane": 7.89}
 
 
 def classify(line):
