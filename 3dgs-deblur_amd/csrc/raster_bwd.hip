@@ -2,7 +2,7 @@
 // Split from raster.hip because this translation unit is compiled with -fno-slp-vectorize: left to itself the
 // SLP vectoriser packs the four per-pixel chains into v_pk_*_f32 pairs but needs v_mov shuffles to assemble
 // them (128 -> 99 VGPRs, -14 % kernel time with SLP off).  The packing that pays is done BY HAND instead
-// (GS_BWD_PK: the lane's four pixels are two float2 pairs from load to store, non-hit pixels neutralised by
+// (hand-packed: the lane's four pixels are two float2 pairs from load to store, non-hit pixels neutralised by
 // selects instead of exec regions: ~160 -> ~126 VALU per hit entry, -5 % kernel time measured, run 29).
 #include "raster_common.h"
 
@@ -30,9 +30,6 @@ constexpr int kRedFloats = kRedG * 9 * kRedStride + 64 * 9;
 // OUT = 1: no atomics at all — the entry's 9 gradients go to tuples[e] (48 B, e = emission index of the
 // entry, so the tuples of one Gaussian are CONTIGUOUS) and flags[e] = 1; gs_reduce_grad_tuples then sums
 // each Gaussian's segment.  At ~20 G atomic ops/s the atomics were 40 % of this kernel.
-#ifndef GS_BWD_PK
-#define GS_BWD_PK 1     // 1: hand-packed float2 hit part + row sums (v_pk_*_f32); 0: scalar chains with per-pixel exec regions
-#endif
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef GS_BWD_WAVES
@@ -73,9 +70,7 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
   // behind-colour with v_out is ever needed, so one float replaces the three colour channels.
   float Tk[4], Dv[4], vr[4], vg[4], vb[4], pyf[4];
   int fin[4];
-#if GS_BWD_PK
   f2 Tk2[2], Dv2[2], vr2[2], vg2[2], vb2[2], pyf2[2];
-#endif
   int my_end = range.x;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -107,14 +102,12 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
     my_end = max(my_end, fin[k]);
   }
   const int wave_end = __builtin_amdgcn_readfirstlane(wave_max_i(my_end));
-#if GS_BWD_PK
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     Tk2[h] = f2{Tk[2 * h], Tk[2 * h + 1]}; Dv2[h] = f2{Dv[2 * h], Dv[2 * h + 1]};
     vr2[h] = f2{vr[2 * h], vr[2 * h + 1]}; vg2[h] = f2{vg[2 * h], vg[2 * h + 1]}; vb2[h] = f2{vb[2 * h], vb[2 * h + 1]};
     pyf2[h] = f2{pyf[2 * h], pyf[2 * h + 1]};
   }
-#endif
   const int* __restrict__ vals = prm.sorted_vals;
   const float kL2E = -1.4426950408889634f;
   const float agm = prm.alpha_grad_max;
@@ -141,7 +134,6 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
       const float dx = gx - pxf;
       const float hx = qx * dx * dx;             // exponent terms, pre-scaled by -log2(e)
       const float bx = qy * dx;
-#if GS_BWD_PK
       // hand-packed variant: the four pixels of a lane are two float2 pairs, every multiply-add of the hit
       // part is one v_pk_*_f32 per pair; pixels that are not hit are neutralised by SELECTING alpha = 0
       // (1/(1-0) = 1 exactly, every contribution is an exact zero) instead of per-pixel exec regions
@@ -196,78 +188,16 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
         r0[3 * kRedStride] = p_cy; r0[4 * kRedStride] = p_cz; r0[5 * kRedStride] = p_op;
         r0[6 * kRedStride] = p_r;  r0[7 * kRedStride] = p_g;  r0[8 * kRedStride] = p_b;
       }
-#else
-      float vis[4], ov[4];
-      bool hit[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float dy = gy - pyf[k];
-        const float s2 = hx + dy * (bx + qz * dy);
-        vis[k] = __builtin_amdgcn_exp2f(s2);
-        ov[k] = op * vis[k];
-        hit[k] = (idx_j < fin[k]) && (s2 <= 0.f) && (fminf(K::kAlphaMax, ov[k]) >= K::kAlphaMin);
-      }
-      if (__ballot(hit[0] || hit[1] || hit[2] || hit[3]) != 0ull) {
-        const float cx = readlane_f(rec.cx, j), cy = readlane_f(rec.cy, j), cz = readlane_f(rec.cz, j);
-        const float cr = readlane_f(rec.r, j), cg = readlane_f(rec.g, j), cb = readlane_f(rec.b, j);
-        const float hdx2 = 0.5f * dx * dx;
-        const float cxdx = cx * dx, cydx = cy * dx;
-        float p_x = 0.f, p_y = 0.f, p_cx = 0.f, p_cy = 0.f, p_cz = 0.f, p_op = 0.f, p_r = 0.f, p_g = 0.f, p_b = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (hit[k]) {
-            const float dy = gy - pyf[k];
-            const float alpha = fminf(K::kAlphaMax, ov[k]);
-            const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
-            Tk[k] *= ra;                       // transmittance in front of this Gaussian
-            const float fac = alpha * Tk[k];
-            p_r += fac * vr[k]; p_g += fac * vg[k]; p_b += fac * vb[k];
-            const float cv = cr * vr[k] + cg * vg[k] + cb * vb[k];
-            const float v_al = Tk[k] * cv - ra * Dv[k];
-            Dv[k] += fac * cv;
-            const bool free_ = ov[k] <= agm;     // d min(0.999, o*vis) = 0 when clamped
-            const float v_sigma = free_ ? -ov[k] * v_al : 0.f;
-            p_op += free_ ? vis[k] * v_al : 0.f;
-            const float vsdy = v_sigma * dy;
-            p_cx += v_sigma * hdx2;
-            p_cy += vsdy * dx;
-            p_cz += vsdy * (0.5f * dy);
-            p_x += v_sigma * (cxdx + cy * dy);
-            p_y += v_sigma * (cydx + cz * dy);
-          }
-        }
-        filled |= 1u << g;
-        float* r0 = red + g * (9 * kRedStride) + lane;
-        r0[0 * kRedStride] = p_x;  r0[1 * kRedStride] = p_y;  r0[2 * kRedStride] = p_cx;
-        r0[3 * kRedStride] = p_cy; r0[4 * kRedStride] = p_cz; r0[5 * kRedStride] = p_op;
-        r0[6 * kRedStride] = p_r;  r0[7 * kRedStride] = p_g;  r0[8 * kRedStride] = p_b;
-      }
-#endif
       if (g == kRedG - 1 || j == n - 1) {
         if (filled) {
           __builtin_amdgcn_wave_barrier();
           if (row < kRedG * 9 && ((filled >> row_g) & 1u)) {
-#if GS_BWD_PK
             const f4* rp = reinterpret_cast<const f4*>(red + row * kRedStride);
             f4 a0 = rp[0], a1 = rp[1], a2 = rp[2], a3 = rp[3];
 #pragma unroll
             for (int q = 4; q < 16; q += 4) { a0 += rp[q]; a1 += rp[q + 1]; a2 += rp[q + 2]; a3 += rp[q + 3]; }
             const f4 v = (a0 + a1) + (a2 + a3);
             const float sum = (v.x + v.y) + (v.z + v.w);
-#else
-            const float4* rp = reinterpret_cast<const float4*>(red + row * kRedStride);
-            float4 a0 = rp[0], a1 = rp[1], a2 = rp[2], a3 = rp[3];
-#pragma unroll
-            for (int q = 4; q < 16; q += 4) {
-              float4 b0 = rp[q], b1 = rp[q + 1], b2 = rp[q + 2], b3 = rp[q + 3];
-              a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
-              a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
-              a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w;
-              a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
-            }
-            const float sum = ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) +
-                              ((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w));
-#endif
             const int jj = gbase + row_g;                   // batch position of this row's Gaussian
             tot[jj * 9 + row_c] = sum;
           }
@@ -305,12 +235,10 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
     __builtin_amdgcn_wave_barrier();
   }
   if (STATE) {
-#if GS_BWD_PK
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       Tk[2 * h] = Tk2[h].x; Tk[2 * h + 1] = Tk2[h].y; Dv[2 * h] = Dv2[h].x; Dv[2 * h + 1] = Dv2[h].y;
     }
-#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int y = py0 + k;
@@ -338,7 +266,7 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
 //   * a reduction group is the four entries of a list group; lanes 0..35 sum the 36 rows and store their total
 //     STRAIGHT into the entry's gradient tuple (or atomically into v_records): no per-batch totals in LDS, no
 //     per-batch flush, no vector loads of ids / records at all.
-// LDS per wave: 36 rows x 36 floats = 5.1 KB (GS_BWD_PAIRSUM; 36 x 68 floats = 9.6 KB without).
+// LDS per wave: 36 rows x 36 floats = 5.1 KB (pair sums in registers first; 36 x 68 floats = 9.6 KB without).
 // ---------------------------------------------------------------------------
 struct RecS { float x, y, cx, cy, cz, op, r, g, b; };
 
@@ -350,19 +278,11 @@ __device__ __forceinline__ RecS load_rec_s(const float* __restrict__ records, un
 }
 
 constexpr int kRedG4 = 4;
-// GS_BWD_PAIRSUM: horizontally adjacent lanes add their partial sums in registers (one DPP add per value) before
-// the trip through LDS: 32 columns per row instead of 64 -> 5.1 KB of LDS per wave instead of 9.6 KB, so the
-// occupancy limit moves from LDS (4 waves per SIMD) to the VGPRs (5), and the row sums read half as much.
-#ifndef GS_BWD_PAIRSUM
-#define GS_BWD_PAIRSUM 1
-#endif
-#if GS_BWD_PAIRSUM
+// Horizontally adjacent lanes add their partial sums in registers (one DPP add per value) before the trip through
+// LDS: 32 columns per row instead of 64 -> 5.1 KB of LDS per wave instead of 9.6 KB, so the occupancy limit moves
+// from LDS (4 waves per SIMD) to the VGPRs (5), and the row sums read half as much.
 constexpr int kRedCols4 = 32, kRedStride4 = 36;    // 36 = 32 + 4: rows 16-byte aligned, b128 row reads conflict-free
 #define GS_BWD_SLOAD_WAVES 5
-#else
-constexpr int kRedCols4 = 64, kRedStride4 = kRedStride;
-#define GS_BWD_SLOAD_WAVES GS_BWD_WAVES
-#endif
 constexpr int kRedFloats4 = kRedG4 * 9 * kRedStride4;
 
 // w[i] = v[i](lane) + v[i](lane ^ 1) for nine values: nine v_add_f32_dpp in one block (the DPP combiner leaves most
@@ -460,7 +380,6 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
   const float p_cx = (0.5f * dx * dx) * M0, p_cy = dx * M1, p_cz = 0.5f * M2;
   const float p_x = (rc.cx * dx) * M0 + rc.cy * M1;
   const float p_y = (rc.cy * dx) * M0 + rc.cz * M1;
-#if GS_BWD_PAIRSUM
   float w[9] = {p_x, p_y, p_cx, p_cy, p_cz, q_op.x + q_op.y, q_r.x + q_r.y, q_g.x + q_g.y, q_b.x + q_b.y};
   pair_sum9(w);
   if ((lane & 1) == 0) {
@@ -468,12 +387,6 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
 #pragma unroll
     for (int c = 0; c < 9; ++c) r0[c * kRedStride4] = w[c];
   }
-#else
-  float* r0 = red + slot * (9 * kRedStride) + lane;
-  r0[0 * kRedStride] = p_x;  r0[1 * kRedStride] = p_y;  r0[2 * kRedStride] = p_cx;
-  r0[3 * kRedStride] = p_cy; r0[4 * kRedStride] = p_cz; r0[5 * kRedStride] = q_op.x + q_op.y;
-  r0[6 * kRedStride] = q_r.x + q_r.y;  r0[7 * kRedStride] = q_g.x + q_g.y;  r0[8 * kRedStride] = q_b.x + q_b.y;
-#endif
   return true;
 }
 

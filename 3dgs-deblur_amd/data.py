@@ -14,7 +14,7 @@
               "all" (/root/reference/train.py:164-167)
 Host code (json + torch tensors); `load_image` decodes the frames (PNG / JPEG through PIL, or .npy float arrays)
 and `write_transforms` / `write_seed_points_ply` emit the same wire format (used by the self-generated datasets of
-:mod:`synthetic_dataset`, the offline stand-in for the Zenodo downloads of /root/reference/download_data.py:21-33).
+``tools/synthetic_dataset.py``, the offline stand-in for the Zenodo downloads of /root/reference/download_data.py:21-33).
 """
 from __future__ import annotations
 

@@ -4,7 +4,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
-for p in (ROOT, ROOT / "oracle"):
+for p in (ROOT, ROOT / "oracle", ROOT / "tools"):
     if str(p) not in sys.path:
         sys.path.insert(0, str(p))
 

@@ -160,7 +160,7 @@ def test_end_to_end_deblurring_on_a_self_generated_dataset(gs, dev, tmp_path):
     ground-truth scene) and whose EVALUATION frames (i % 8 == 0) are sharp; the same initial model is trained with
     blur_samples = 0 (no compensation) and 5 (the default), with both motion models, and scored on the sharp
     frames.  Modelling the blur must pay: >= 1 dB PSNR and a higher SSIM."""
-    from gsdeblur_amd import synthetic_dataset as SD
+    import synthetic_dataset as SD          # tools/synthetic_dataset.py (conftest puts tools/ on sys.path)
     root = str(tmp_path / "ds")
     info = SD.generate(root, dev, width=160, height=120, n_frames=17, n_gaussians=4000, speed=1.5, dense_samples=64)
     scene = gs.load_transforms(root)
@@ -188,7 +188,7 @@ def test_end_to_end_deblurring_on_a_self_generated_dataset(gs, dev, tmp_path):
 def test_optimize_eval_cameras_moves_only_the_eval_cameras(gs, dev, tmp_path):
     """--optimize-eval-cameras (/root/reference/train.py:180-183): a step on an evaluation frame updates that
     frame's pose / velocity adjustment and nothing else — no gradient reaches the Gaussians"""
-    from gsdeblur_amd import synthetic_dataset as SD
+    import synthetic_dataset as SD          # tools/synthetic_dataset.py (conftest puts tools/ on sys.path)
     root = str(tmp_path / "ds")
     info = SD.generate(root, dev, width=96, height=64, n_frames=9, n_gaussians=1500, speed=1.0, dense_samples=16)
     scene = gs.load_transforms(root)

@@ -11,7 +11,7 @@ echo "== build ==" | tee $OUT/summary.log
 timeout 300 python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -2 | tee -a $OUT/summary.log
 if [ "$MODE" != "pmc" ]; then
 echo "== pytest -m gpu ==" | tee -a $OUT/summary.log
-timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -s > $OUT/pytest_gpu.log 2>&1
+timeout 1800 python -m pytest tests -m gpu -q --timeout 900 -p no:cacheprovider -s > $OUT/pytest_gpu.log 2>&1
 grep -E "ulp diffs|^FAILED|^ERROR|passed|failed" $OUT/pytest_gpu.log | tail -30 | tee -a $OUT/summary.log
 echo "== smoke ==" | tee -a $OUT/summary.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee -a $OUT/summary.log
@@ -23,6 +23,8 @@ fi
 if [ "$MODE" = "full" ]; then
   echo "== dp exchange, device side ==" | tee -a $OUT/summary.log
   timeout 120 python tools/dp_bench.py 2>&1 | tail -2 | tee -a $OUT/summary.log
+  echo "== dp exchange, device side, fitted-model-like density (33 % of the rows) ==" | tee -a $OUT/summary.log
+  timeout 120 python tools/dp_bench.py 1000000 330000 8 2>&1 | tail -2 | tee -a $OUT/summary.log
 fi
 echo "== bench x2 (no cpu baseline) ==" | tee -a $OUT/summary.log
 for v in 1 2; do

@@ -23,8 +23,12 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import data as _data
-from .model import Camera, SplatfactoDeblurConfig, SplatfactoDeblurModel
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from gsdeblur_amd import data as _data  # noqa: E402
+from gsdeblur_amd.model import Camera, SplatfactoDeblurConfig, SplatfactoDeblurModel  # noqa: E402
 
 SH_C0 = 0.28209479177387814
 

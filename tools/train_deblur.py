@@ -19,7 +19,8 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import gsdeblur_amd as gs  # noqa: E402
-from gsdeblur_amd import synthetic_dataset as SD  # noqa: E402
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import synthetic_dataset as SD  # noqa: E402  (test / demo data generation: not part of the product package)
 
 
 def main():
