@@ -530,95 +530,168 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
 // `ratio_limit` and that received a gradient, v_means / v_scales / v_quats are recomputed with the covariance chain
 // of gs_math.h (project_ctx_t / project_one_bwd_t / cov3d_bwd_t) in DOUBLE, from the fp32 parameters, and overwrite
 // what the fp32 kernel above wrote for that row.  The inputs (the compositor's v_xy / v_conic / v_opacity sums in
-// v_records) are the same; only the ill-conditioned part of the chain changes precision.  One thread per Gaussian:
-// needles are a minority and the work is a few hundred double operations per (Gaussian, sub-pose).
+// v_records) are the same; only the ill-conditioned part of the chain changes precision.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void project_needle_hp_kernel(FusedParams fp, const float* __restrict__ records,
-    const float* __restrict__ v_records, float* __restrict__ v_means, float* __restrict__ v_scales,
-    float* __restrict__ v_quats, const unsigned char* __restrict__ touched, float ratio_limit) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= fp.N) return;
+// work item of the SE(3) model: ONE (needle, sub-pose) pair -> its contribution to v_mean[3] and v_cov3d[6], in double
+__device__ __forceinline__ void needle_item_se3(const FusedParams& fp, const float* __restrict__ records,
+                                                const float* __restrict__ v_records,
+                                                const unsigned char* __restrict__ touched, int i, int p, double out[9]) {
+#pragma unroll
+  for (int j = 0; j < 9; ++j) out[j] = 0.0;
+  if (touched && !touched[(size_t)p * fp.N + i]) return;
   const float s[3] = {fp.scales[3 * i], fp.scales[3 * i + 1], fp.scales[3 * i + 2]};
-  const float smax = fmaxf(s[0], fmaxf(s[1], s[2])), smin = fminf(s[0], fminf(s[1], s[2]));
-  if (!(smax > ratio_limit * smin)) return;
-  bool mine = touched == nullptr;
-  for (int p = 0; p < fp.P && !mine; ++p) mine = touched[(size_t)p * fp.N + i] != 0;
-  if (!mine) return;
   const float m[3] = {fp.means[3 * i], fp.means[3 * i + 1], fp.means[3 * i + 2]};
   const float q[4] = {fp.quats[4 * i], fp.quats[4 * i + 1], fp.quats[4 * i + 2], fp.quats[4 * i + 3]};
-  const float opac = fp.opacities[i];
   // fp32 covariance for the culling decisions (exactly what the forward took), double covariance for the chain
   float R[9], qn[4], inv, M[9], c3[6];
   quat_to_rotmat(q, R, qn, &inv);
   scale_rot_to_cov3d(s, fp.glob, R, M, c3);
+  const float* V = fp.viewmats + 16 * p;
+  float Vm[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) Vm[j] = V[j];
+  Proj o; ProjCtx k;
+  if (!project_one(m, c3, Vm, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x, fp.in.tiles_y,
+                   fp.in.clip, o, k))
+    return;
   double Rd[9], qnd[4], invd, Md[9], c3d[6];
   quat_to_rotmat_t<double>(q, Rd, qnd, &invd);
   scale_rot_to_cov3d_t<double>(s, fp.glob, Rd, Md, c3d);
-  const bool up_clamp = (fp.flags & GS_FLAG_UPSTREAM_FOV_CLAMP_GRAD) != 0;
-  double vm[3] = {0., 0., 0.}, vc3[6] = {0., 0., 0., 0., 0., 0.};
-  if (fp.pixvel) {
-    float Vm[12];
-    for (int j = 0; j < 12; ++j) Vm[j] = fp.viewmats[j];
-    Proj o; ProjCtx k;
-    project_one(m, c3, Vm, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x, fp.in.tiles_y,
-                fp.in.clip, o, k);
-    if (!k.geom_ok) return;
-    ProjCtxT<double> kd;
-    project_ctx_t<double>(m, c3d, Vm, fp.in.fx, fp.in.fy, fp.in.W, fp.in.H, kd);
-    kd.clamp_x = k.clamp_x; kd.clamp_y = k.clamp_y;
-    const double comp = ::sqrt(fmax(0.0, kd.det0 / kd.det));
-    double vxy[2] = {0., 0.}, vcon[3] = {0., 0., 0.}, v_comp = 0.;
-    float vpv[2] = {0.f, 0.f};
-    for (int p = 0; p < fp.P; ++p) {
-      if (touched && !touched[(size_t)p * fp.N + i]) continue;
-      const size_t idx = (size_t)p * fp.N + i;
-      const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kRecFloats);
-      const float4 ga = g4[0], gb = g4[1], gc = g4[2];
-      const float4* r4 = reinterpret_cast<const float4*>(records + idx * kRecFloats);
-      const float4 ra = r4[0], rb = r4[1];
-      if (ra.z == 0.f && ra.w == 0.f && rb.x == 0.f) continue;
-      if (fp.antialiased) v_comp += (double)gb.y * (double)opac;
-      vxy[0] += ga.x; vxy[1] += ga.y;
-      vpv[0] += fp.times[p] * ga.x; vpv[1] += fp.times[p] * ga.y;
-      if (fp.flags & GS_FLAG_RS_PIXVEL_GRAD) { vpv[0] += gc.y; vpv[1] += gc.z; }
-      vcon[0] += ga.z; vcon[1] += ga.w; vcon[2] += gb.x;
+  ProjCtxT<double> kd;
+  project_ctx_t<double>(m, c3d, Vm, fp.in.fx, fp.in.fy, fp.in.W, fp.in.H, kd);
+  kd.clamp_x = k.clamp_x; kd.clamp_y = k.clamp_y;
+  const double comp = ::sqrt(fmax(0.0, kd.det0 / kd.det));
+  const size_t idx = (size_t)p * fp.N + i;
+  const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kRecFloats);
+  const float4 ga = g4[0], gb = g4[1];
+  const double vxy[2] = {ga.x, ga.y}, vcon[3] = {ga.z, ga.w, gb.x};
+  const double v_comp = fp.antialiased ? (double)gb.y * (double)fp.opacities[i] : 0.0;
+  double vV[12];
+  project_one_bwd_t<double>(m, c3d, Vm, fp.in.fx, fp.in.fy, kd, comp, vxy, 0.0, vcon, v_comp, out, out + 3, vV, nullptr,
+                            (fp.flags & GS_FLAG_UPSTREAM_FOV_CLAMP_GRAD) != 0);
+}
+
+// work item of the pixel-velocity model: ONE needle (its P records are one projection: their gradients are summed first)
+__device__ __forceinline__ void needle_item_pixvel(const FusedParams& fp, const float* __restrict__ records,
+                                                   const float* __restrict__ v_records,
+                                                   const unsigned char* __restrict__ touched, int i, double out[9]) {
+#pragma unroll
+  for (int j = 0; j < 9; ++j) out[j] = 0.0;
+  const float s[3] = {fp.scales[3 * i], fp.scales[3 * i + 1], fp.scales[3 * i + 2]};
+  const float m[3] = {fp.means[3 * i], fp.means[3 * i + 1], fp.means[3 * i + 2]};
+  const float q[4] = {fp.quats[4 * i], fp.quats[4 * i + 1], fp.quats[4 * i + 2], fp.quats[4 * i + 3]};
+  const float opac = fp.opacities[i];
+  float R[9], qn[4], inv, M[9], c3[6];
+  quat_to_rotmat(q, R, qn, &inv);
+  scale_rot_to_cov3d(s, fp.glob, R, M, c3);
+  float Vm[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) Vm[j] = fp.viewmats[j];
+  Proj o; ProjCtx k;
+  project_one(m, c3, Vm, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x, fp.in.tiles_y,
+              fp.in.clip, o, k);
+  if (!k.geom_ok) return;
+  double Rd[9], qnd[4], invd, Md[9], c3d[6];
+  quat_to_rotmat_t<double>(q, Rd, qnd, &invd);
+  scale_rot_to_cov3d_t<double>(s, fp.glob, Rd, Md, c3d);
+  ProjCtxT<double> kd;
+  project_ctx_t<double>(m, c3d, Vm, fp.in.fx, fp.in.fy, fp.in.W, fp.in.H, kd);
+  kd.clamp_x = k.clamp_x; kd.clamp_y = k.clamp_y;
+  const double comp = ::sqrt(fmax(0.0, kd.det0 / kd.det));
+  double vxy[2] = {0., 0.}, vcon[3] = {0., 0., 0.}, v_comp = 0.;
+  float vpv[2] = {0.f, 0.f};
+  for (int p = 0; p < fp.P; ++p) {
+    if (touched && !touched[(size_t)p * fp.N + i]) continue;
+    const size_t idx = (size_t)p * fp.N + i;
+    const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kRecFloats);
+    const float4 ga = g4[0], gb = g4[1], gc = g4[2];
+    const float4* r4 = reinterpret_cast<const float4*>(records + idx * kRecFloats);
+    const float4 ra = r4[0], rb = r4[1];
+    if (ra.z == 0.f && ra.w == 0.f && rb.x == 0.f) continue;
+    if (fp.antialiased) v_comp += (double)gb.y * (double)opac;
+    vxy[0] += ga.x; vxy[1] += ga.y;
+    vpv[0] += fp.times[p] * ga.x; vpv[1] += fp.times[p] * ga.y;
+    if (fp.flags & GS_FLAG_RS_PIXVEL_GRAD) { vpv[0] += gc.y; vpv[1] += gc.z; }
+    vcon[0] += ga.z; vcon[1] += ga.w; vcon[2] += gb.x;
+  }
+  const float lin[3] = {fp.twist[0], fp.twist[1], fp.twist[2]}, ang[3] = {fp.twist[3], fp.twist[4], fp.twist[5]};
+  float vpc[3], vlin[3], vang[3];
+  pixel_velocity_bwd(k.pc, k.rz, fp.in.fx, fp.in.fy, lin, ang, vpv, vpc, vlin, vang);
+  const double vpcd[3] = {vpc[0], vpc[1], vpc[2]};
+  double vV[12];
+  project_one_bwd_t<double>(m, c3d, Vm, fp.in.fx, fp.in.fy, kd, comp, vxy, 0.0, vcon, v_comp, out, out + 3, vV, vpcd,
+                            (fp.flags & GS_FLAG_UPSTREAM_FOV_CLAMP_GRAD) != 0);
+}
+
+// A block owns kNeedleChunk consecutive Gaussians.  Phase 1: every thread looks at eight of them (their touched flags
+// come as one 8-byte word per sub-pose: a frame in which half a percent of the Gaussians carry a gradient costs a few
+// microseconds) and appends the touched ones whose scale ratio exceeds the limit to a list in LDS.  Phase 2: the list
+// is worked off in rounds of 256 (needle, sub-pose) ITEMS — one double-precision chain per thread, so a needle's
+// latency is one sub-pose's, not P of them in a row — whose partial sums a needle's owner thread adds up in sub-pose
+// order (deterministic) before it runs the covariance -> scale / quaternion step and writes the three rows.
+constexpr int kNeedleChunk = 2048;
+
+__global__ __launch_bounds__(256) void project_needle_hp_kernel(FusedParams fp, const float* __restrict__ records,
+    const float* __restrict__ v_records, float* __restrict__ v_means, float* __restrict__ v_scales,
+    float* __restrict__ v_quats, const unsigned char* __restrict__ touched, float ratio_limit) {
+  __shared__ int list[kNeedleChunk];
+  __shared__ int n_list;
+  __shared__ double part[256][9];
+  if (threadIdx.x == 0) n_list = 0;
+  __syncthreads();
+  const int i0 = blockIdx.x * kNeedleChunk + (int)threadIdx.x * 8;
+  if (i0 < fp.N) {
+    unsigned long long any = ~0ull;
+    if (touched) {
+      any = 0ull;
+      const bool word = (fp.N % 8) == 0 && i0 + 8 <= fp.N;
+      for (int p = 0; p < fp.P; ++p) {
+        const unsigned char* t = touched + (size_t)p * fp.N + i0;
+        if (word) any |= *reinterpret_cast<const unsigned long long*>(t);
+        else for (int j = 0; j < 8 && i0 + j < fp.N; ++j) any |= (unsigned long long)t[j] << (8 * j);
+      }
     }
-    const float lin[3] = {fp.twist[0], fp.twist[1], fp.twist[2]}, ang[3] = {fp.twist[3], fp.twist[4], fp.twist[5]};
-    float vpc[3], vlin[3], vang[3];
-    pixel_velocity_bwd(k.pc, k.rz, fp.in.fx, fp.in.fy, lin, ang, vpv, vpc, vlin, vang);
-    const double vpcd[3] = {vpc[0], vpc[1], vpc[2]};
-    double vV[12];
-    project_one_bwd_t<double>(m, c3d, Vm, fp.in.fx, fp.in.fy, kd, comp, vxy, 0.0, vcon, v_comp, vm, vc3, vV, vpcd, up_clamp);
-  } else {
-    for (int p = 0; p < fp.P; ++p) {
-      if (touched && !touched[(size_t)p * fp.N + i]) continue;
-      const float* V = fp.viewmats + 16 * p;
-      float Vm[12];
-      for (int j = 0; j < 12; ++j) Vm[j] = V[j];
-      Proj o; ProjCtx k;
-      if (!project_one(m, c3, Vm, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x,
-                       fp.in.tiles_y, fp.in.clip, o, k))
-        continue;
-      ProjCtxT<double> kd;
-      project_ctx_t<double>(m, c3d, Vm, fp.in.fx, fp.in.fy, fp.in.W, fp.in.H, kd);
-      kd.clamp_x = k.clamp_x; kd.clamp_y = k.clamp_y;
-      const double comp = ::sqrt(fmax(0.0, kd.det0 / kd.det));
-      const size_t idx = (size_t)p * fp.N + i;
-      const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kRecFloats);
-      const float4 ga = g4[0], gb = g4[1];
-      const double vxy[2] = {ga.x, ga.y}, vcon[3] = {ga.z, ga.w, gb.x};
-      const double v_comp = fp.antialiased ? (double)gb.y * (double)opac : 0.0;
-      double vm1[3], vc31[6], vV[12];
-      project_one_bwd_t<double>(m, c3d, Vm, fp.in.fx, fp.in.fy, kd, comp, vxy, 0.0, vcon, v_comp, vm1, vc31, vV, nullptr,
-                                up_clamp);
-      for (int j = 0; j < 3; ++j) vm[j] += vm1[j];
-      for (int j = 0; j < 6; ++j) vc3[j] += vc31[j];
+    if (any != 0ull) {
+      for (int j = 0; j < 8 && i0 + j < fp.N; ++j) {
+        if (((any >> (8 * j)) & 0xFFull) == 0ull) continue;
+        const int i = i0 + j;
+        const float s0 = fp.scales[3 * i], s1 = fp.scales[3 * i + 1], s2 = fp.scales[3 * i + 2];
+        const float smax = fmaxf(s0, fmaxf(s1, s2)), smin = fminf(s0, fminf(s1, s2));
+        if (smax > ratio_limit * smin) list[atomicAdd(&n_list, 1)] = i;
+      }
     }
   }
-  double vs[3], vq[4];
-  cov3d_bwd_t<double>(s, fp.glob, q, vc3, vs, vq, (fp.flags & GS_FLAG_RAW_QUAT_GRAD) != 0);
-  for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = (float)vm[j]; v_scales[3 * i + j] = (float)vs[j]; }
-  for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = (float)vq[j];
+  __syncthreads();
+  const int n = n_list;
+  if (n == 0) return;
+  const int items_per = fp.pixvel ? 1 : fp.P;                  // <= 256 (kMaxSubposes)
+  const int per_round = max(1, 256 / items_per);               // needles per round
+  for (int base = 0; base < n; base += per_round) {
+    const int cnt = min(per_round, n - base);
+    const int a = (int)threadIdx.x / items_per, p = (int)threadIdx.x - a * items_per;
+    if (a < cnt) {
+      double o9[9];
+      if (fp.pixvel) needle_item_pixvel(fp, records, v_records, touched, list[base + a], o9);
+      else needle_item_se3(fp, records, v_records, touched, list[base + a], p, o9);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) part[threadIdx.x][j] = o9[j];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cnt) {
+      const int i = list[base + threadIdx.x];
+      double acc[9] = {0., 0., 0., 0., 0., 0., 0., 0., 0.};
+      for (int pp = 0; pp < items_per; ++pp)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[j] += part[threadIdx.x * items_per + pp][j];
+      const float s[3] = {fp.scales[3 * i], fp.scales[3 * i + 1], fp.scales[3 * i + 2]};
+      const float q[4] = {fp.quats[4 * i], fp.quats[4 * i + 1], fp.quats[4 * i + 2], fp.quats[4 * i + 3]};
+      double vs[3], vq[4];
+      cov3d_bwd_t<double>(s, fp.glob, q, acc + 3, vs, vq, (fp.flags & GS_FLAG_RAW_QUAT_GRAD) != 0);
+      for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = (float)acc[j]; v_scales[3 * i + j] = (float)vs[j]; }
+      for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = (float)vq[j];
+    }
+    __syncthreads();
+  }
 }
 
 // dense launch: one thread per Gaussian (no touched flags: every Gaussian gets its gradient written)
@@ -916,8 +989,8 @@ static int launch_fused_bwd(const FusedParams& fp, int sh_degree, const float* r
   }
   if (!(fp.flags & GS_FLAG_NO_NEEDLE_HP))
     // needles (scale ratio above kNeedleRatio) get their means / scales / quaternion gradients again, in double
-    hipLaunchKernelGGL(project_needle_hp_kernel, dim3((N + 127) / 128), dim3(128), 0, st, fp, records, v_records,
-                       v_means, v_scales, v_quats, touched, kNeedleRatio);
+    hipLaunchKernelGGL(project_needle_hp_kernel, dim3((N + kNeedleChunk - 1) / kNeedleChunk), dim3(256), 0, st, fp, records,
+                       v_records, v_means, v_scales, v_quats, touched, kNeedleRatio);
   return gs_launch_status();
 }
 
