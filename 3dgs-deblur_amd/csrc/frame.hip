@@ -282,17 +282,36 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   // what a slice needs is priced right before it is issued (a frame rarely needs all its planned slices: the headline
   // plans five and uses one); the arena must then also hold the backward's buffers for the slices issued so far
   long long maxI_issued = 0;
-  auto fits = [&](int k) -> bool {
-    if (I_of[k] >= 2147483647ll - kIdsPad) return false;             // caught separately below
-    const long long mI = std::max(maxI_issued, I_of[k]);
+  auto fits = [&](long long n_s, long long I_s, int k_next) -> bool {
+    if (I_s >= 2147483647ll - kIdsPad) return false;                 // caught separately below
+    const long long mI = std::max(maxI_issued, I_s);
     const long long bwd = d.reserve_backward ? Arena::up(48 * mI) + Arena::up(mI) + 2 * Arena::up(4ll * S * H * W) + 1024 : 0;
-    const long long need = Arena::up(A.off) + slice_bytes(d, n_of[k], I_of[k], use_masks, true_total) + bwd;
+    const long long need = Arena::up(A.off) + slice_bytes(d, n_s, I_s, use_masks, true_total) + bwd;
     if (need <= arena_bytes) return true;
     // say what this slice AND the next planned one would take: one retry usually settles a new high-water mark
-    state->arena_required = need + (k + 1 < K && I_of[k + 1] < 2147483647ll
-                                        ? slice_bytes(d, n_of[k + 1], I_of[k + 1], use_masks, true_total) + 49 * I_of[k + 1]
+    state->arena_required = need + (k_next < K && I_of[k_next] < 2147483647ll
+                                        ? slice_bytes(d, n_of[k_next], I_of[k_next], use_masks, true_total) + 49 * I_of[k_next]
                                         : 0);
     return false;
+  };
+  // Planned slices [k0, k1) issued as ONE slice.  The plan's budgets double because a tile usually saturates within
+  // its first few hundred entries; a frame whose tiles do NOT saturate (a fitted model seen through many faint
+  // splats) gains nothing from a slice boundary and pays ~0.15 ms for each (count, scan, colour, emit, two sort
+  // passes, bin edges, a compositor launch with state reload, one more tuple reduce): when a slice leaves at least
+  // merge_open_fraction of the tiles it started with open, the next issued slice spans twice as many planned ones.
+  // Images do not depend on where the boundaries are (bit-identical); gradient sums change their order.
+  auto merged = [&](int k0, int k1, std::vector<int>& beg, std::vector<int>& pre, long long& n_s, long long& I_s) {
+    beg = begins[k0];
+    pre.assign(P + 1, 0);
+    I_s = 0;
+    for (int p = 0; p < P; ++p) {
+      int cnt = 0;
+      for (int k = k0; k < k1; ++k) cnt += prefixes[k][p + 1] - prefixes[k][p];
+      pre[p + 1] = pre[p] + cnt;
+    }
+    for (int k = k0; k < k1; ++k) I_s += I_of[k];
+    n_s = pre[P];
+    if (n_s == 0) I_s = 0;
   };
 
   unsigned char* tile_done = zeros_u8;                               // [P*T], all open
@@ -307,11 +326,17 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   const unsigned invalid_key = (unsigned)(P * T);
   const int key_bits = bits_for(P * T + 1);
   int n_out = 0;
-  for (int k = 0; k < K; ++k) {
-    const bool first = k == 0, last = k == K - 1;
-    const long long n_k = n_of[k], I_k = I_of[k];
+  int span = 1;                                                      // planned slices per issued slice
+  long long open_before = (long long)S * T;                          // tiles a compositor launch visits
+  std::vector<int> beg_s, pre_s;
+  for (int k = 0, k1 = 0; k < K; k = k1) {
+    long long n_k = 0, I_k = 0;
+    k1 = std::min(K, k + span);
+    merged(k, k1, beg_s, pre_s, n_k, I_k);
+    while (k1 > k + 1 && I_k >= 2147483647ll - kIdsPad) merged(k, --k1, beg_s, pre_s, n_k, I_k);
+    const bool first = k == 0, last = k1 == K;
     if (I_k >= 2147483647ll - kIdsPad) return GS_ERR_INVALID;        // a slice list is indexed with 31 bits: lower slice_base
-    if (!fits(k)) return GS_ERR_WORKSPACE;
+    if (!fits(n_k, I_k, k1)) return GS_ERR_WORKSPACE;
     maxI_issued = std::max(maxI_issued, I_k);
     unsigned *slice_gi = nullptr, *counts = nullptr, *cum_k = nullptr, *total_k = nullptr, *mask_off = nullptr;
     unsigned long long* masks = nullptr;
@@ -341,7 +366,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
       const long long ws_b = gs_scan_workspace_bytes(n_k);
       char* ws = A.take<char>(ws_b);
       if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
-      CHECK(gs_slice_counts_exact((int)n_k, P, N, begins[k].data(), prefixes[k].data(), sorted_gi, records,
+      CHECK(gs_slice_counts_exact((int)n_k, P, N, beg_s.data(), pre_s.data(), sorted_gi, records,
                                   have_holes ? sat : nullptr, have_holes ? tile_done : nullptr, H, W, slice_gi, counts,
                                   wave_per_g, masks ? cum : nullptr, masks, mask_off, have_holes ? open_bits : nullptr,
                                   nullptr, st));
@@ -421,7 +446,11 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
       // itself, read AFTER this slice's whole pipeline was issued
       CHECK(hip_status(hipMemcpyAsync(hp, open_flags + k, 4, hipMemcpyDeviceToHost, st)));
       CHECK(hip_status(hipStreamSynchronize(st)));
-      if (hp[0] == 0u) break;
+      const long long open_now = hp[0];                              // tiles the compositor left open
+      if (open_now == 0) break;
+      span = (d.merge_open_fraction > 0.f && (double)open_now >= (double)d.merge_open_fraction * (double)open_before)
+                 ? 2 * (k1 - k) : 1;
+      open_before = open_now;
       StageScope sc(ST_SAT, st);
       CHECK(gs_tile_open_sat(P, H, W, tile_done, sat, open_bits, nullptr, st));
     }

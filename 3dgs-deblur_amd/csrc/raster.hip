@@ -28,7 +28,7 @@ struct SliceState {
   unsigned char* tile_done;   // [P*T]
   float* live_T;              // [S,H,W]  0 once a pixel has stopped
   int first, last;
-  int* open_flag;             // nullable (zeroed by the caller): set to 1 when this launch leaves any tile open
+  int* open_flag;             // nullable (zeroed by the caller): += 1 for every tile this launch leaves open
 };
 
 // STATS (debug, gs_rasterize_fwd_slice_stats): lane-utilisation counters of the walk, see kLaneStat* below
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
   range.x = __builtin_amdgcn_readfirstlane(range.x);
   range.y = __builtin_amdgcn_readfirstlane(range.y);
   if (!st.first && !st.last && range.y <= range.x) {         // nothing for this tile in this slice: it stays open
-    if (st.open_flag && lane == 0) *st.open_flag = 1;
+    if (st.open_flag && lane == 0) atomicAdd(st.open_flag, 1);
     return;
   }
 
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
   }
   if (!st.last && lane == 0) {
     if (all_stopped) st.tile_done[tkey] = 1;
-    else if (st.open_flag) *st.open_flag = 1;      // (plain store of the same value from every open tile)
+    else if (st.open_flag) atomicAdd(st.open_flag, 1);      // the word counts the tiles left open
   }
 }
 
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
   range.x = __builtin_amdgcn_readfirstlane(range.x);
   range.y = __builtin_amdgcn_readfirstlane(range.y);
   if (!st.first && !st.last && range.y <= range.x) {         // nothing for this tile in this slice: it stays open
-    if (st.open_flag && lane == 0) *st.open_flag = 1;
+    if (st.open_flag && lane == 0) atomicAdd(st.open_flag, 1);
     return;
   }
 
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
   }
   if (!st.last && lane == 0) {
     if (all_stopped) st.tile_done[tkey] = 1;
-    else if (st.open_flag) *st.open_flag = 1;      // (plain store of the same value from every open tile)
+    else if (st.open_flag) atomicAdd(st.open_flag, 1);      // the word counts the tiles left open
   }
 }
 
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void raster_fwd_quad_kernel(RasterParams prm, 
   range.x = __builtin_amdgcn_readfirstlane(range.x);
   range.y = __builtin_amdgcn_readfirstlane(range.y);
   if (!st.first && !st.last && range.y <= range.x) {         // nothing for this tile in this slice: it stays open
-    if (st.open_flag && lane == 0) *st.open_flag = 1;
+    if (st.open_flag && lane == 0) atomicAdd(st.open_flag, 1);
     return;
   }
   const int px = tx * K::kTile + (lane & 15);
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void raster_fwd_quad_kernel(RasterParams prm, 
   }
   if (!st.last && lane == 0) {
     if (all_stopped) st.tile_done[tkey] = 1;
-    else if (st.open_flag) *st.open_flag = 1;      // (plain store of the same value from every open tile)
+    else if (st.open_flag) atomicAdd(st.open_flag, 1);      // the word counts the tiles left open
   }
 }
 
@@ -716,7 +716,7 @@ GS_EXPORT int gs_rasterize_fwd(const float* records, const int* sorted_vals, con
 // the unsliced pass).  final_idx is per slice (the backward needs one per slice).
 // tile_hot (nullable) [S*R*T] u8, from gs_emit_open_intersects: non-zero where the tile's list of THIS slice holds
 // a Gaussian with opacity > 0.999; the other tiles run the loop version without the alpha clamp (NULL: all clamp).
-// open_flag (nullable, one int zeroed by the caller): set to 1 if any tile is still open after this slice — the
+// open_flag (nullable, one int zeroed by the caller): the number of tiles still open after this slice — the
 // one word the host reads to decide whether the next planned slice has anything to do.
 GS_EXPORT int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                                      const int* band_edges, const float* background, int S, int R, int H, int W,

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void raster_fwd_rs_kernel(RasterParams prm, Rs
   range.x = __builtin_amdgcn_readfirstlane(range.x);
   range.y = __builtin_amdgcn_readfirstlane(range.y);
   if (!st.first && !st.last && range.y <= range.x) {
-    if (st.open_flag && lane == 0) *st.open_flag = 1;
+    if (st.open_flag && lane == 0) atomicAdd(st.open_flag, 1);
     return;
   }
   const int px = tx * K::kTile + (lane & 15);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void raster_fwd_rs_kernel(RasterParams prm, Rs
   }
   if (!st.last && lane == 0) {
     if (all_stopped) st.tile_done[tkey] = 1;
-    else if (st.open_flag) *st.open_flag = 1;
+    else if (st.open_flag) atomicAdd(st.open_flag, 1);      // the word counts the tiles left open
   }
 }
 

@@ -31,6 +31,10 @@ RASTER_BWD_VARIANT = int(os.environ.get("GSD_RASTER_BWD_VARIANT", "0"))
 # depth slicing of the fused path: average tile-list length budget of the first slice (doubling per
 # slice); 0 disables slicing (single pass over all intersections)
 SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "512"))
+# gs_frame_forward only: a slice that leaves at least this fraction of its open tiles open makes the next issued slice
+# span twice as many planned ones (a frame whose tiles do not saturate pays ~0.15 ms per slice boundary for nothing);
+# 0 = every planned slice on its own, which is what the Python orchestration does.  Images are the same bit for bit.
+SLICE_MERGE = float(os.environ.get("GSD_SLICE_MERGE", "0.75"))
 # exact ellipse-vs-tile culling of (Gaussian, tile) pairs in the fused path (images unchanged)
 EXACT_TILE_CULL = int(os.environ.get("GSD_EXACT_TILE_CULL", "1"))
 # atomic-free backward: per-entry gradient tuples + segmented reduce (0 = fp32 atomics into v_records)
@@ -473,7 +477,7 @@ FRAME_STAGES = ("depth_sort", "count_scan", "slice_plan", "slice_count", "emit",
 
 class _FrameDesc(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int) for k in ("N", "P", "S", "R", "H", "W", "slice_base", "depth_sort_digit",
-                                             "fwd_variant", "reserve_backward")]
+                                             "fwd_variant", "reserve_backward")] + [("merge_open_fraction", ctypes.c_float)]
 
 
 class _FrameSlice(ctypes.Structure):
@@ -532,7 +536,8 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     need_pin = 4 * (2 * P * 16 + 2 * P + 1) + 64
     if pin is None or pin.numel() < need_pin:
         pin = _pinned_cache[str(dev)] = torch.empty(max(8192, need_pin), dtype=torch.uint8, pin_memory=True)
-    desc = _FrameDesc(N, P, S, R, H, W, int(slice_base), DEPTH_SORT_DIGIT, RASTER_FWD_VARIANT, int(reserve_backward))
+    desc = _FrameDesc(N, P, S, R, H, W, int(slice_base), DEPTH_SORT_DIGIT, RASTER_FWD_VARIANT, int(reserve_backward),
+                      float(SLICE_MERGE))
     state = _FrameState()
     out_img = torch.empty(S, H, W, 3, device=dev)
     out_T = torch.empty(S, H, W, device=dev)

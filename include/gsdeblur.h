@@ -323,8 +323,8 @@ int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const i
                                               (/root/reference/render_model.py:219).  Scalar-cache compositor only*/,
                            const unsigned char* tile_hot /*from gs_emit_open_intersects for THIS slice, or NULL: every
                                                            tile runs the loop with the alpha clamp*/,
-                           int* open_flag /*NULL, or one int zeroed by the caller: set to 1 when any tile is still open
-                                            after this slice (last == 0 only)*/,
+                           int* open_flag /*NULL, or one int zeroed by the caller: receives the number of tiles still
+                                            open after this slice (last == 0 only)*/,
                            int variant /*0 = default; 1, 2 = v_readlane compositor without / with the empty-pair skip;
                                          3 = the 4x4-block lock-step walk for slices of small splats (needs sorted_ids;
                                          same images, bit for bit)*/,
@@ -430,6 +430,9 @@ typedef struct gs_frame_desc {
   int depth_sort_digit;      /* widest radix digit of the depth pre-sort (8..11) */
   int fwd_variant;           /* as gs_rasterize_fwd_slice (3 = lock-step 4x4 blocks: same images, not faster) */
   int reserve_backward;      /* 1: the arena must also hold what gs_frame_backward will take */
+  float merge_open_fraction; /* > 0: a slice that leaves at least this fraction of its open tiles open makes the next
+                                issued slice span twice as many planned ones (frames whose tiles do not saturate gain
+                                nothing from slice boundaries); 0: every planned slice is issued on its own */
 } gs_frame_desc;
 typedef struct gs_frame_slice {
   long long I;               /* capacity of the slice's lists (its ranks' bounding-box pairs); real count on the device */

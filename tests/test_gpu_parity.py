@@ -727,16 +727,16 @@ def test_speculative_slices_change_nothing(gs, oracle, dev, S, R, base):
     bg = torch.tensor([0.3, 0.2, 0.1])
     wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3))
     res = {}
-    old = (ops.SLICE_BASE, ops.SPECULATE)
+    old = (ops.SLICE_BASE, ops.SPECULATE, ops.SLICE_MERGE)
     try:
-        ops.SLICE_BASE = base
+        ops.SLICE_BASE, ops.SLICE_MERGE = base, 0.0         # speculation runs the planned slices one by one
         for spec in (0, 1):
             ops.SPECULATE = spec
             out, alpha, samples, vms, p, radii = _run_full(gs, O, dev, sc, H, W, S, R, 1 / 60, 1 / 30, 2.2, 10.0, 3, bg, wt)
             res[spec] = (samples.detach().clone(), alpha.detach().clone(), {k: v.grad.detach().clone() for k, v in p.items()},
                          list(ops.last_slice_intersects))
     finally:
-        ops.SLICE_BASE, ops.SPECULATE = old
+        ops.SLICE_BASE, ops.SPECULATE, ops.SLICE_MERGE = old
     a, b = res[0], res[1]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert [t for t in a[3] if t] == [t for t in b[3] if t]            # the same non-empty slices
@@ -1572,9 +1572,10 @@ def test_native_frame_orchestration_equals_python_orchestration(gs, dev, case):
     times_t = torch.tensor(times, device=dev)
     g = torch.Generator().manual_seed(4)
     wt, wa = torch.rand(H, W, 3, generator=g).to(dev), torch.rand(S, H, W, generator=g).to(dev)
-    saved = (ops.NATIVE_FRAME, ops.SLICE_BASE)
+    saved = (ops.NATIVE_FRAME, ops.SLICE_BASE, ops.SLICE_MERGE)
     res = []
     try:
+        ops.SLICE_MERGE = 0.0                              # the Python orchestration issues every planned slice
         for native in (1, 0):
             ops.NATIVE_FRAME = native
             if base is not None:
@@ -1600,7 +1601,7 @@ def test_native_frame_orchestration_equals_python_orchestration(gs, dev, case):
             res.append((rgb.detach().clone(), alphas.detach().clone(), radii.clone(), depth.clone(), grads,
                         ops.last_num_intersects, [int(v) for v in ops.last_slice_intersects if int(v) > 0]))
     finally:
-        ops.NATIVE_FRAME, ops.SLICE_BASE = saved
+        ops.NATIVE_FRAME, ops.SLICE_BASE, ops.SLICE_MERGE = saved
     a, b = res
     assert a[5] == b[5] and a[6] == b[6] and a[5] > 0
     if case in ("multi_slice", "tiny_budget"):
@@ -1645,6 +1646,44 @@ def test_native_frame_grows_its_arena_and_reports_stage_times(gs, dev):
         ops.profiler = None
     for stage in ("depth_sort", "slice_count", "tile_sort", "raster_fwd", "raster_bwd", "grad_reduce", "project_fwd"):
         assert stage in ms and len(ms[stage]) >= 1 and all(t > 0 for t in ms[stage]), stage
+
+
+def test_native_frame_merges_slices_of_a_frame_that_does_not_saturate(gs, dev):
+    """round 3: planned depth slices are issued together once a slice leaves most tiles open (gs_frame_desc.
+    merge_open_fraction).  A fitted-model-like scene with a small budget plans many slices and closes few tiles: with
+    merging fewer slices are issued (a merged slice may emit more entries: tiles that close inside it are only known
+    afterwards), the image is the same bit for bit and the
+    gradients agree up to the order of their sums; a threshold of 0 reproduces the planned slices one by one."""
+    from gsdeblur_amd import ops
+    n, W, H, S = 60000, 200, 136, 3
+    sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=11, scale_mult=6.0, profile="trained"), dev)
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, 1, 0.0)
+    times_t = torch.tensor(times, device=dev)
+    g = torch.Generator().manual_seed(5)
+    wt = torch.rand(H, W, 3, generator=g).to(dev)
+    saved = (ops.NATIVE_FRAME, ops.SLICE_BASE, ops.SLICE_MERGE)
+    res = {}
+    try:
+        ops.NATIVE_FRAME, ops.SLICE_BASE = 1, 8
+        for merge in (0.0, 0.75):
+            ops.SLICE_MERGE = merge
+            p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+            vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"] * 5, sc["ang_vel"] * 3, times_t)
+            rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
+                                                    torch.sigmoid(p["opacity_logits"]), p["sh"], vms, None, S, 1, sc["fx"],
+                                                    sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2, min_rgb_level=10.0)
+            assert ops._native_frame_ok()
+            (rgb * wt).sum().backward()
+            res[merge] = (rgb.detach().clone(), alphas.detach().clone(), {k: v.grad.clone() for k, v in p.items()},
+                          [int(v) for v in ops.last_slice_intersects if int(v) > 0])
+    finally:
+        ops.NATIVE_FRAME, ops.SLICE_BASE, ops.SLICE_MERGE = saved
+    a, b = res[0.0], res[0.75]
+    assert len(a[3]) >= 4 and len(b[3]) < len(a[3]), (a[3], b[3])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert rel_max(a[2][k].cpu(), b[2][k].cpu()) < GRAD_RTOL, k
+    assert float(a[2]["means"].abs().max()) > 0
 
 
 @pytest.mark.parametrize("model", ["se3", "pixel_velocity"])
