@@ -156,8 +156,8 @@ GS_EXPORT long long gs_frame_backward_bytes(const gs_frame_state* state) {
 GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned* depth_keys, const int* num_tiles_hit,
                                const float* background, const int* band_edges, const unsigned char* band_tile_done,
                                const float* color_means, const float* color_sh, int color_K, int color_degree,
-                               const float* color_viewmats, float* out_img, float* out_T, float* out_depth,
-                               void* arena_ptr, long long arena_bytes, void* host_pinned, long long host_pinned_bytes,
+                               const float* color_viewmats, const float* pix_vel, float* out_img, float* out_T,
+                               float* out_depth, void* arena_ptr, long long arena_bytes, void* host_pinned, long long host_pinned_bytes,
                                gs_frame_state* state, void* stream_) {
   if (!dp || !records || !depth_keys || !num_tiles_hit || !background || !band_edges || !out_img || !out_T ||
       !arena_ptr || !host_pinned || !state)
@@ -166,6 +166,10 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   if (d.N <= 0 || d.P <= 0 || d.S <= 0 || d.R <= 0 || d.P != d.S * d.R || d.H <= 0 || d.W <= 0 || d.P > 256)
     return GS_ERR_INVALID;
   if (d.R > 1 && !band_tile_done) return GS_ERR_INVALID;
+  // exact per-row rolling shutter (pixel-velocity model, raster_rs.hip): the records' tile boxes are swept boxes, so
+  // the lists are built from the boxes themselves (no ellipse test, no hit masks) and the rs compositors run
+  const bool rs = pix_vel != nullptr && d.rolling_shutter_time != 0.f;
+  if (rs && d.R != 1) return GS_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream_;
   const int P = d.P, N = d.N, S = d.S, R = d.R, H = d.H, W = d.W;
   const long long n = (long long)P * N;
@@ -175,6 +179,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   if (host_pinned_bytes < 4 * plan_ints + 64) return GS_ERR_INVALID;
   memset(state, 0, sizeof(*state));
   state->P = P; state->N = N; state->S = S; state->R = R; state->H = H; state->W = W;
+  state->rolling_shutter_time = rs ? d.rolling_shutter_time : 0.f;
   Arena A(arena_ptr, arena_bytes);
 
   // ---- depth pre-sort (compacting, per sub-pose) + exclusive scan of the tile counts in rank order ----------------
@@ -256,7 +261,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   state->n_total = n_total;
   long long true_total = 0;
   for (int p = 0; p < P; ++p) true_total += seg_totals[p];
-  const bool use_masks = planned && true_total < 4294967296ll - 64;
+  const bool use_masks = planned && !rs && true_total < 4294967296ll - 64;
 
   // slice descriptors (host arrays: they travel in the kernel arguments) and the slices' list capacities
   std::vector<std::vector<int>> begins(K, std::vector<int>(P)), prefixes(K, std::vector<int>(P + 1));
@@ -323,7 +328,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
     CHECK(hip_status(hipMemcpyAsync(tile_done, band_tile_done, P * T, hipMemcpyDeviceToDevice, st)));
     CHECK(gs_tile_open_sat(P, H, W, tile_done, sat, open_bits, nullptr, st));
   }
-  const unsigned invalid_key = (unsigned)(P * T);
+  const unsigned invalid_key = rs ? 0u : (unsigned)(P * T);
   const int key_bits = bits_for(P * T + 1);
   int n_out = 0;
   int span = 1;                                                      // planned slices per issued slice
@@ -366,10 +371,14 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
       const long long ws_b = gs_scan_workspace_bytes(n_k);
       char* ws = A.take<char>(ws_b);
       if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
-      CHECK(gs_slice_counts_exact((int)n_k, P, N, beg_s.data(), pre_s.data(), sorted_gi, records,
-                                  have_holes ? sat : nullptr, have_holes ? tile_done : nullptr, H, W, slice_gi, counts,
-                                  wave_per_g, masks ? cum : nullptr, masks, mask_off, have_holes ? open_bits : nullptr,
-                                  nullptr, st));
+      if (rs)
+        CHECK(gs_slice_counts((int)n_k, P, N, beg_s.data(), pre_s.data(), sorted_gi, records,
+                              have_holes ? sat : nullptr, H, W, slice_gi, counts, st));
+      else
+        CHECK(gs_slice_counts_exact((int)n_k, P, N, beg_s.data(), pre_s.data(), sorted_gi, records,
+                                    have_holes ? sat : nullptr, have_holes ? tile_done : nullptr, H, W, slice_gi, counts,
+                                    wave_per_g, masks ? cum : nullptr, masks, mask_off, have_holes ? open_bits : nullptr,
+                                    nullptr, st));
       CHECK(gs_exclusive_scan_u32(n_k, counts, cum_k, total_k, ws, ws_b, st));
       if (color_means && color_sh && color_viewmats)
         // deferred SH colour for exactly the Gaussians this slice emits
@@ -390,9 +399,13 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
       if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
       {
         StageScope sc(ST_EMIT, st);
-        CHECK(gs_emit_open_intersects((int)n_k, N, H, W, slice_gi, counts, cum_k, records,
-                                      (!first || holes0) ? tile_done : nullptr, keys, vals, invalid_key, 1, wave_per_g,
-                                      masks, mask_off, tile_hot, st));
+        if (rs && first && !holes0)
+          // every tile is open and the counts are the boxes: the slice holds exactly its ranks' box pairs
+          CHECK(gs_emit_intersects(n_k, N, H, W, slice_gi, cum_k, records, I_k, keys, vals, invalid_key, st));
+        else
+          CHECK(gs_emit_open_intersects((int)n_k, N, H, W, slice_gi, counts, cum_k, records,
+                                        (!first || holes0) ? tile_done : nullptr, keys, vals, invalid_key, rs ? 0 : 1,
+                                        wave_per_g, masks, mask_off, rs ? nullptr : tile_hot, st));
       }
       int r1 = 0, r2 = 0;
       {
@@ -426,6 +439,12 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
     const int fwd_variant = (I_k == 0 && d.fwd_variant == 3) ? 0 : d.fwd_variant;
     {
       StageScope sc(ST_RASTER_FWD, st);
+      if (rs && I_k > 0)
+        CHECK(gs_rasterize_fwd_rs_slice(records, bins, band_edges, background, S, H, W, out_img, out_T, live_T, fidx,
+                                        tile_done, first ? 1 : 0, last ? 1 : 0, reinterpret_cast<const int*>(sorted_ids),
+                                        (int)std::min(n, 2147483647ll), out_depth, last ? nullptr : open_flags + k,
+                                        pix_vel, N, d.rolling_shutter_time, st));
+      else
       CHECK(gs_rasterize_fwd_slice(records, reinterpret_cast<const int*>(svals), bins, band_edges, background, S, R, H, W,
                                    out_img, out_T, live_T, fidx, tile_done, first ? 1 : 0, last ? 1 : 0,
                                    I_k > 0 ? reinterpret_cast<const int*>(vals) : nullptr,
@@ -467,8 +486,8 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
 GS_EXPORT int gs_frame_backward(const gs_frame_state* state, const float* records, const float* background,
                                 const int* band_edges, const float* out_T, const float* v_img, const float* v_alpha,
                                 const float* cmb_scale, float cmb_gamma, float cmb_min_level, int bwd_variant,
-                                float* v_records, unsigned char* touched, void* arena_ptr, long long arena_bytes,
-                                void* stream_) {
+                                float* v_records, unsigned char* touched, const float* pix_vel, void* arena_ptr,
+                                long long arena_bytes, void* stream_) {
   if (!state || !records || !background || !band_edges || !out_T || !v_img || !v_records || !arena_ptr)
     return GS_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream_;
@@ -498,6 +517,15 @@ GS_EXPORT int gs_frame_backward(const gs_frame_state* state, const float* record
     CHECK(hip_status(hipMemsetAsync(flags, 0, sl.I, st)));
     {
       StageScope sc(ST_RASTER_BWD, st);
+      if (state->rolling_shutter_time != 0.f) {
+        if (!pix_vel) return GS_ERR_INVALID;
+        CHECK(gs_rasterize_bwd_rs_slice(records, reinterpret_cast<const int*>(base + sl.svals),
+                                        reinterpret_cast<const int*>(base + sl.bins), band_edges, background, S, H, W, out_T,
+                                        reinterpret_cast<const int*>(base + sl.fidx), v_img, v_alpha, bwd_T, bwd_B, tuples,
+                                        flags, reinterpret_cast<const int*>(base + sl.sorted_ids),
+                                        (int)std::min(n_rec, 2147483647ll), bwd_variant & 256, cmb_scale, cmb_gamma,
+                                        cmb_min_level, pix_vel, state->N, state->rolling_shutter_time, st));
+      } else
       CHECK(gs_rasterize_bwd_slice(records, reinterpret_cast<const int*>(base + sl.svals),
                                    reinterpret_cast<const int*>(base + sl.bins), band_edges, background, S, R, H, W, out_T,
                                    reinterpret_cast<const int*>(base + sl.fidx), v_img, v_alpha, bwd_T, bwd_B, v_records,

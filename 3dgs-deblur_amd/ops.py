@@ -477,7 +477,8 @@ FRAME_STAGES = ("depth_sort", "count_scan", "slice_plan", "slice_count", "emit",
 
 class _FrameDesc(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int) for k in ("N", "P", "S", "R", "H", "W", "slice_base", "depth_sort_digit",
-                                             "fwd_variant", "reserve_backward")] + [("merge_open_fraction", ctypes.c_float)]
+                                             "fwd_variant", "reserve_backward")] + [("merge_open_fraction", ctypes.c_float),
+                                                                                     ("rolling_shutter_time", ctypes.c_float)]
 
 
 class _FrameSlice(ctypes.Structure):
@@ -487,7 +488,8 @@ class _FrameSlice(ctypes.Structure):
 
 
 class _FrameState(ctypes.Structure):
-    _fields_ = ([(k, ctypes.c_int) for k in ("n_slices", "P", "N", "S", "R", "H", "W", "reserved")] +
+    _fields_ = ([(k, ctypes.c_int) for k in ("n_slices", "P", "N", "S", "R", "H", "W")] +
+                [("rolling_shutter_time", ctypes.c_float)] +
                 [(k, ctypes.c_longlong) for k in ("n_total", "arena_used", "arena_required")] +
                 [("slice", _FrameSlice * 16)])
 
@@ -515,8 +517,8 @@ def _profile_mask() -> int:
 
 def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
                          H: int, W: int, bg: Tensor, edges: Tensor, slice_base: int, color=None,
-                         out_depth: Optional[Tensor] = None, reserve_backward: bool = True):
-    """gs_frame_forward: -> (out_img [S,H,W,3], out_T [S,H,W], frame) ; frame = dict(arena, state) for
+                         out_depth: Optional[Tensor] = None, reserve_backward: bool = True, rs=None):
+    """rs = (pix_vel [N,2], rolling_shutter_time) as in sliced_forward.  gs_frame_forward: -> (out_img [S,H,W,3], out_T [S,H,W], frame) ; frame = dict(arena, state) for
     native_frame_backward.  Raises _ArenaTooSmall (after recording a larger size) when the arena did not hold the frame:
     the caller projects again (the depth keys were consumed) and calls once more."""
     global last_num_intersects, _slice_totals
@@ -537,7 +539,7 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     if pin is None or pin.numel() < need_pin:
         pin = _pinned_cache[str(dev)] = torch.empty(max(8192, need_pin), dtype=torch.uint8, pin_memory=True)
     desc = _FrameDesc(N, P, S, R, H, W, int(slice_base), DEPTH_SORT_DIGIT, RASTER_FWD_VARIANT, int(reserve_backward),
-                      float(SLICE_MERGE))
+                      float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0)
     state = _FrameState()
     out_img = torch.empty(S, H, W, 3, device=dev)
     out_T = torch.empty(S, H, W, device=dev)
@@ -548,9 +550,10 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
         c_means, c_sh, c_K, c_deg, c_V = color
     L.gs_frame_profile_enable(_profile_mask())
     st = L.gs_frame_forward(ctypes.byref(desc), _ptr(records), _ptr(depth_keys), _ptr(num_tiles_hit), _ptr(bg), _ptr(edges),
-                            _ptr(band_done), _ptr(c_means), _ptr(c_sh), int(c_K), int(c_deg), _ptr(c_V), _ptr(out_img),
-                            _ptr(out_T), _ptr(out_depth), _ptr(arena), arena.numel(), ctypes.c_void_p(pin.data_ptr()),
-                            pin.numel(), ctypes.byref(state), _stream())
+                            _ptr(band_done), _ptr(c_means), _ptr(c_sh), int(c_K), int(c_deg), _ptr(c_V),
+                            _ptr(rs[0]) if rs is not None else None, _ptr(out_img), _ptr(out_T), _ptr(out_depth),
+                            _ptr(arena), arena.numel(), ctypes.c_void_p(pin.data_ptr()), pin.numel(), ctypes.byref(state),
+                            _stream())
     if st == 3:
         _arena_hint[key] = int(state.arena_required * 1.15) + (32 << 20)
         raise _ArenaTooSmall()
@@ -559,7 +562,7 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     last_num_intersects = int(state.n_total)
     _slice_totals = [arena[sl.n_emitted_dev:sl.n_emitted_dev + 4].view(torch.int32)
                      for sl in (state.slice[i] for i in range(state.n_slices))]
-    return out_img, out_T, dict(arena=arena, state=state)
+    return out_img, out_T, dict(arena=arena, state=state, pix_vel=rs[0] if rs is not None else None)
 
 
 def native_frame_backward(frame, records: Tensor, bg: Tensor, edges: Tensor, out_T: Tensor, v_img: Tensor,
@@ -570,7 +573,7 @@ def native_frame_backward(frame, records: Tensor, bg: Tensor, edges: Tensor, out
     L.gs_frame_profile_enable(_profile_mask())
     st = L.gs_frame_backward(ctypes.byref(state), _ptr(records), _ptr(bg), _ptr(edges), _ptr(out_T), _ptr(v_img),
                              _ptr(v_alpha), _ptr(cmb[0]), float(cmb[1]), float(cmb[2]), _bwd_variant(), _ptr(v_records),
-                             _ptr(touched), _ptr(arena), arena.numel(), _stream())
+                             _ptr(touched), _ptr(frame.get("pix_vel")), _ptr(arena), arena.numel(), _stream())
     if st == 3:
         raise _lib.HipLibraryError("frame_backward: the forward's arena cannot hold the backward's buffers "
                                    "(call native_frame_forward with reserve_backward=True)")
@@ -1295,12 +1298,12 @@ class _RenderSubposes(Function):
         depth_acc = torch.zeros(S, H, W, device=dev) if return_depth else None
         ctx.prealloc = {} if (PREALLOC_BWD and any(ctx.needs_input_grad)) else None
         ctx.frame = None
-        if _native_frame_ok() and rs is None:
+        if _native_frame_ok() and (rs is None or R == 1):
             for attempt in range(3):
                 try:
                     out_img, out_T, ctx.frame = native_frame_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges,
                                                                      SLICE_BASE, color, depth_acc,
-                                                                     any(ctx.needs_input_grad))
+                                                                     any(ctx.needs_input_grad), rs)
                     break
                 except _ArenaTooSmall:
                     if attempt == 2:

@@ -433,6 +433,8 @@ typedef struct gs_frame_desc {
   float merge_open_fraction; /* > 0: a slice that leaves at least this fraction of its open tiles open makes the next
                                 issued slice span twice as many planned ones (frames whose tiles do not saturate gain
                                 nothing from slice boundaries); 0: every planned slice is issued on its own */
+  float rolling_shutter_time;/* != 0 (with pix_vel != NULL, R == 1): exact per-row rolling shutter of the pixel-velocity
+                                model — box lists + the gs_rasterize_*_rs_slice compositors */
 } gs_frame_desc;
 typedef struct gs_frame_slice {
   long long I;               /* capacity of the slice's lists (its ranks' bounding-box pairs); real count on the device */
@@ -440,7 +442,8 @@ typedef struct gs_frame_slice {
   long long svals, bins, fidx, gi_of_e, sorted_ids, slice_gi, counts, cum, tile_hot, n_emitted_dev;   /* arena offsets */
 } gs_frame_slice;
 typedef struct gs_frame_state {
-  int n_slices, P, N, S, R, H, W, reserved;
+  int n_slices, P, N, S, R, H, W;
+  float rolling_shutter_time;/* copied from the descriptor (0: not an exact-rolling-shutter frame) */
   long long n_total;         /* bounding-box tile intersections of the frame */
   long long arena_used;      /* bytes of the arena the forward occupies (kept alive until the backward ran) */
   long long arena_required;  /* on GS_ERR_WORKSPACE (3): an arena size that holds the frame as far as it is known */
@@ -454,8 +457,9 @@ typedef struct gs_frame_state {
 int gs_frame_forward(const gs_frame_desc* desc, float* records, unsigned* depth_keys, const int* num_tiles_hit,
                      const float* background /*3*/, const int* band_edges /*R+1*/, const unsigned char* band_tile_done,
                      const float* color_means, const float* color_sh, int color_K_stride, int color_sh_degree,
-                     const float* color_viewmats /*P*16*/, float* out_img /*S*H*W*3*/, float* out_T /*S*H*W*/,
-                     float* out_depth, void* arena, long long arena_bytes, void* host_pinned,
+                     const float* color_viewmats /*P*16*/,
+                     const float* pix_vel /*NULL, or [N*2] from gs_project_pixvel_fwd(rolling_shutter_time != 0)*/,
+                     float* out_img /*S*H*W*3*/, float* out_T /*S*H*W*/, float* out_depth, void* arena, long long arena_bytes, void* host_pinned,
                      long long host_pinned_bytes, gs_frame_state* state, void* stream);
 long long gs_frame_backward_bytes(const gs_frame_state* state);
 /* v_records [P*N*12] (rows the compositor never touched are left as they are), touched [P*N] u8 zeroed by the caller;
@@ -463,7 +467,7 @@ long long gs_frame_backward_bytes(const gs_frame_state* state);
 int gs_frame_backward(const gs_frame_state* state, const float* records, const float* background, const int* band_edges,
                       const float* out_T, const float* v_img, const float* v_alpha, const float* cmb_scale,
                       float cmb_gamma, float cmb_min_level, int bwd_variant, float* v_records, unsigned char* touched,
-                      void* arena, long long arena_bytes, void* stream);
+                      const float* pix_vel /*as in the forward*/, void* arena, long long arena_bytes, void* stream);
 /* measurement only (not thread-safe): HIP events around the stages of the two calls above.  stage_mask bit i enables
  * stage i of {depth_sort, count_scan, slice_plan, slice_count, emit, tile_sort, bin_edges, raster_fwd, slice_sat,
  * raster_bwd, grad_reduce}; gs_frame_profile_read drains the pairs recorded since the last call (synchronising on

@@ -1549,7 +1549,7 @@ def test_more_intersections_than_the_slice_plan_covers(gs, dev):
 
 
 @pytest.mark.parametrize("case", ["blur", "rolling_shutter", "multi_slice", "one_slice_no_plan", "pixel_velocity",
-                                  "tiny_budget"])
+                                  "tiny_budget", "exact_rolling_shutter", "exact_rolling_shutter_multi_slice"])
 def test_native_frame_orchestration_equals_python_orchestration(gs, dev, case):
     """gs_frame_forward / gs_frame_backward (csrc/frame.hip: the slice pipeline issued from C++
     out of ONE caller-owned arena) against ops.sliced_forward / sliced_backward (the same kernels launched one by one
@@ -1567,6 +1567,8 @@ def test_native_frame_orchestration_equals_python_orchestration(gs, dev, case):
         base = 0
     elif case == "tiny_budget":
         n, W, H, S, base, mult = 60000, 32, 32, 2, 1, 12.0
+    elif case == "exact_rolling_shutter_multi_slice":
+        n, prof, base, mult = 60000, "trained", 24, 6.0
     sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=11, scale_mult=mult, profile=prof), dev)
     times, _, _ = gs.subpose_schedule(S, 1 / 60, R, 1 / 30 if R > 1 else 0.0)
     times_t = torch.tensor(times, device=dev)
@@ -1584,7 +1586,13 @@ def test_native_frame_orchestration_equals_python_orchestration(gs, dev, case):
             lin = (sc["lin_vel"] * 5).clone().requires_grad_(True)
             ang = (sc["ang_vel"] * 3).clone().requires_grad_(True)
             V = sc["viewmat"].clone().requires_grad_(True)
-            if case == "pixel_velocity":
+            if case.startswith("exact_rolling_shutter"):
+                # continuous row time of the pixel-velocity model: box lists + the raster_rs.hip compositors
+                out = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["opacity_logits"]),
+                                         p["sh"], V, None, S, R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2,
+                                         min_rgb_level=10.0, lin_vel=lin, ang_vel=ang, times=times_t, return_depth=True,
+                                         rolling_shutter_time=1 / 30)
+            elif case == "pixel_velocity":
                 out = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["opacity_logits"]),
                                          p["sh"], V, None, S, R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2,
                                          min_rgb_level=10.0, lin_vel=lin, ang_vel=ang, times=times_t, return_depth=True)
