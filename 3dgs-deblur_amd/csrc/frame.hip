@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <time.h>
 #include <algorithm>
 #include <vector>
 #include "../../include/gsdeblur.h"
@@ -76,6 +77,56 @@ struct StageScope {
     g_events.push_back(ev);
   }
 };
+
+// ---- read-backs without a stream synchronisation -------------------------------------------------------------------
+// hipMemcpyAsync(device -> pinned) + hipStreamSynchronize costs a blit kernel, a completion signal and the runtime's
+// wake-up before the host may issue the next launch (~40-50 us of GPU idle per read-back in the step timelines).
+// Instead a one-block kernel copies the words straight into the caller's pinned buffer (device-visible host memory)
+// and then releases a sequence word at system scope; the host polls that word.  If the word does not arrive within
+// kPollTimeoutUs the host falls back to the stream synchronisation (the words are there after it either way).
+constexpr long long kPollTimeoutUs = 50000;
+
+__global__ __launch_bounds__(256) void publish_words_kernel(const unsigned* __restrict__ src, unsigned* dst, int n,
+                                                            unsigned seq) {
+  // dst[0] = sequence word, dst[1..n] = payload
+  for (int i = threadIdx.x; i < n; i += 256)
+    __hip_atomic_store(dst + 1 + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(dst, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+inline long long now_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (long long)ts.tv_sec * 1000000ll + ts.tv_nsec / 1000;
+}
+
+// device words [n] -> host_pinned[1..n] (host_pinned[0] is the sequence word); returns when they are readable
+inline int read_back(const unsigned* src_dev, unsigned* host_pinned, int n, bool poll, hipStream_t st) {
+  if (!poll) {
+    hipError_t e = hipMemcpyAsync(host_pinned + 1, src_dev, 4ll * n, hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return 1000 + (int)e;
+    return hip_status(hipStreamSynchronize(st));
+  }
+  volatile unsigned* seqw = host_pinned;
+  *seqw = 0u;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(256), 0, st, src_dev, host_pinned, n, 1u);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return 1000 + (int)e;
+  const long long t0 = now_us();
+  unsigned spins = 0;
+  while (__atomic_load_n(host_pinned, __ATOMIC_ACQUIRE) != 1u) {
+    __builtin_ia32_pause();
+    if ((++spins & 1023u) == 0 && now_us() - t0 > kPollTimeoutUs) {
+      int r = hip_status(hipStreamSynchronize(st));
+      if (r != GS_OK) return r;
+      return __atomic_load_n(host_pinned, __ATOMIC_ACQUIRE) == 1u ? GS_OK : GS_ERR_INVALID;
+    }
+  }
+  return GS_OK;
+}
 
 #define CHECK(call)            \
   do {                         \
@@ -176,7 +227,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   const int tx = (W + kTile - 1) / kTile, ty = (H + kTile - 1) / kTile;
   const long long T = (long long)tx * ty;
   const long long plan_ints = 2ll * P * kKMax + 2 * P + 1;
-  if (host_pinned_bytes < 4 * plan_ints + 64) return GS_ERR_INVALID;
+  if (host_pinned_bytes < 4 * (plan_ints + 1) + 64) return GS_ERR_INVALID;
   memset(state, 0, sizeof(*state));
   state->P = P; state->N = N; state->S = S; state->R = R; state->H = H; state->W = W;
   state->rolling_shutter_time = rs ? d.rolling_shutter_time : 0.f;
@@ -224,7 +275,10 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   int* open_flags = reinterpret_cast<int*>(zeros_u8 + flag_off);
 
   // ---- slice plan: the ONE read-back every frame needs ---------------------------------------------------------------
-  unsigned* hp = reinterpret_cast<unsigned*>(host_pinned);
+  // word 0 of the pinned buffer is the sequence word of the polled read-backs, the payload follows
+  unsigned* hp = reinterpret_cast<unsigned*>(host_pinned) + 1;
+  unsigned* hp_seq = reinterpret_cast<unsigned*>(host_pinned);
+  const bool poll = d.poll_readback != 0;
   const long long PK = (long long)P * kKMax;
   std::vector<long long> NV(P), seg_totals(P);
   std::vector<std::vector<long long>> bnd(P), rel(P);
@@ -236,8 +290,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
     CHECK(gs_slice_plan(P, N, kKMax, cum, total, (long long)T * d.slice_base, plan_dev,
                         reinterpret_cast<unsigned*>(plan_dev + PK), reinterpret_cast<unsigned*>(plan_dev + 2 * PK),
                         n_live, reinterpret_cast<unsigned*>(plan_dev + 2 * PK + P), st));
-    CHECK(hip_status(hipMemcpyAsync(hp, plan_dev, 4 * plan_ints, hipMemcpyDeviceToHost, st)));
-    CHECK(hip_status(hipStreamSynchronize(st)));
+    CHECK(read_back(reinterpret_cast<const unsigned*>(plan_dev), hp_seq, (int)plan_ints, poll, st));
     for (int p = 0; p < P; ++p) {
       bnd[p].resize(kKMax); rel[p].resize(kKMax);
       for (int k = 0; k < kKMax; ++k) { bnd[p][k] = hp[p * kKMax + k]; rel[p][k] = hp[PK + p * kKMax + k]; }
@@ -463,8 +516,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
     if (!last) {
       // one read-back per slice: are there open tiles for the next planned slice?  One word, written by the compositor
       // itself, read AFTER this slice's whole pipeline was issued
-      CHECK(hip_status(hipMemcpyAsync(hp, open_flags + k, 4, hipMemcpyDeviceToHost, st)));
-      CHECK(hip_status(hipStreamSynchronize(st)));
+      CHECK(read_back(reinterpret_cast<const unsigned*>(open_flags + k), hp_seq, 1, poll, st));
       const long long open_now = hp[0];                              // tiles the compositor left open
       if (open_now == 0) break;
       span = (d.merge_open_fraction > 0.f && (double)open_now >= (double)d.merge_open_fraction * (double)open_before)

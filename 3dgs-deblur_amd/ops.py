@@ -35,6 +35,9 @@ SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "512"))
 # span twice as many planned ones (a frame whose tiles do not saturate pays ~0.15 ms per slice boundary for nothing);
 # 0 = every planned slice on its own, which is what the Python orchestration does.  Images are the same bit for bit.
 SLICE_MERGE = float(os.environ.get("GSD_SLICE_MERGE", "0.75"))
+# gs_frame_forward only: 1 = its two read-backs (slice plan, open-tile count) are written into pinned host memory by a
+# one-block kernel and the host polls a sequence word; 0 = hipMemcpyAsync + hipStreamSynchronize
+FRAME_POLL = int(os.environ.get("GSD_FRAME_POLL", "1"))
 # exact ellipse-vs-tile culling of (Gaussian, tile) pairs in the fused path (images unchanged)
 EXACT_TILE_CULL = int(os.environ.get("GSD_EXACT_TILE_CULL", "1"))
 # atomic-free backward: per-entry gradient tuples + segmented reduce (0 = fp32 atomics into v_records)
@@ -478,7 +481,8 @@ FRAME_STAGES = ("depth_sort", "count_scan", "slice_plan", "slice_count", "emit",
 class _FrameDesc(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int) for k in ("N", "P", "S", "R", "H", "W", "slice_base", "depth_sort_digit",
                                              "fwd_variant", "reserve_backward")] + [("merge_open_fraction", ctypes.c_float),
-                                                                                     ("rolling_shutter_time", ctypes.c_float)]
+                                                                                     ("rolling_shutter_time", ctypes.c_float),
+                                                                                     ("poll_readback", ctypes.c_int)]
 
 
 class _FrameSlice(ctypes.Structure):
@@ -535,11 +539,11 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
         nbytes = 40 * n + 16 * S * H * W + 80 * I0 + (64 << 20)
     arena = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
     pin = _pinned_cache.get(str(dev))
-    need_pin = 4 * (2 * P * 16 + 2 * P + 1) + 64
+    need_pin = 4 * (2 * P * 16 + 2 * P + 2) + 64
     if pin is None or pin.numel() < need_pin:
         pin = _pinned_cache[str(dev)] = torch.empty(max(8192, need_pin), dtype=torch.uint8, pin_memory=True)
     desc = _FrameDesc(N, P, S, R, H, W, int(slice_base), DEPTH_SORT_DIGIT, RASTER_FWD_VARIANT, int(reserve_backward),
-                      float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0)
+                      float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0, int(FRAME_POLL))
     state = _FrameState()
     out_img = torch.empty(S, H, W, 3, device=dev)
     out_T = torch.empty(S, H, W, device=dev)

@@ -435,6 +435,9 @@ typedef struct gs_frame_desc {
                                 nothing from slice boundaries); 0: every planned slice is issued on its own */
   float rolling_shutter_time;/* != 0 (with pix_vel != NULL, R == 1): exact per-row rolling shutter of the pixel-velocity
                                 model — box lists + the gs_rasterize_*_rs_slice compositors */
+  int poll_readback;         /* 1: the plan and the open-tile count reach the host through a one-block kernel that
+                                writes into host_pinned and a sequence word the host polls (no stream synchronisation
+                                per read-back); 0: hipMemcpyAsync + hipStreamSynchronize */
 } gs_frame_desc;
 typedef struct gs_frame_slice {
   long long I;               /* capacity of the slice's lists (its ranks' bounding-box pairs); real count on the device */
@@ -452,7 +455,7 @@ typedef struct gs_frame_state {
 /* records / depth_keys (consumed) / num_tiles_hit: outputs of gs_project_fused_fwd or gs_project_pixvel_fwd;
  * band_tile_done [P*T] u8: initial done mask of a rolling-shutter frame (R > 1; NULL otherwise); color_*: deferred SH
  * colour inputs (all NULL: records already hold colours); out_depth nullable [S*H*W] (zeroed by the caller);
- * host_pinned: >= 4*(2*P*16 + 2*P + 1) + 64 bytes of pinned host memory.  On GS_ERR_WORKSPACE call again with a larger
+ * host_pinned: >= 4*(2*P*16 + 2*P + 2) + 64 bytes of pinned, device-visible host memory (hipHostMalloc / torch pin_memory).  On GS_ERR_WORKSPACE call again with a larger
  * arena AND fresh projection outputs (depth_keys was consumed). */
 int gs_frame_forward(const gs_frame_desc* desc, float* records, unsigned* depth_keys, const int* num_tiles_hit,
                      const float* background /*3*/, const int* band_edges /*R+1*/, const unsigned char* band_tile_done,
