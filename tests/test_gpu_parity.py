@@ -75,10 +75,21 @@ def test_exclusive_scan(gs, dev, n):
     assert int(total.item()) == int(x.long().sum())
 
 
+@pytest.fixture(params=[0, 1], ids=["three_kernel_passes", "single_pass"])
+def sort_form(request, gs, dev):
+    """both forms of a radix pass (include/gsdeblur.h: gs_sort_set_single_pass): histogram + scan + scatter, and the
+    single-pass scatter with decoupled look-back — same results bit for bit"""
+    from gsdeblur_amd import _lib
+    L = _lib.load()
+    old = L.gs_sort_set_single_pass(request.param)
+    yield request.param
+    L.gs_sort_set_single_pass(old)
+
+
 @pytest.mark.parametrize("n,bits,dtype", [(1, 8, torch.int32), (4097, 16, torch.int32), (300_001, 17, torch.int32),
                                           (1_000_003, 32, torch.int32), (200_003, 45, torch.int64),
                                           (50_001, 35, torch.int64), (70_000, 13, torch.int32)])
-def test_radix_sort_stable(gs, dev, n, bits, dtype):
+def test_radix_sort_stable(gs, dev, sort_form, n, bits, dtype):
     """ascending, STABLE (ties keep input order), payload follows; keys limited to `bits` bits."""
     g = torch.Generator().manual_seed(bits * 1000 + n % 997)
     hi = 2 ** min(bits, 62)
@@ -101,7 +112,7 @@ def test_radix_sort_stable(gs, dev, n, bits, dtype):
 
 @pytest.mark.parametrize("n,bits,cap", [(1, 8, 0), (4097, 16, 0), (300_001, 17, 0), (70_000, 16, 200_000),
                                         (1_000_003, 24, 0)])
-def test_radix_sort_carries_a_second_payload(gs, dev, n, bits, cap):
+def test_radix_sort_carries_a_second_payload(gs, dev, sort_form, n, bits, cap):
     """the tile sort's form: payload = input index (iota), second payload carried along with the keys through every
     pass (instead of gathered by payload afterwards); optionally with the element count on the device"""
     g = torch.Generator().manual_seed(n + bits)
@@ -125,7 +136,7 @@ def test_radix_sort_carries_a_second_payload(gs, dev, n, bits, cap):
 
 
 @pytest.mark.parametrize("P,N", [(1, 5000), (5, 4097), (3, 100_003), (10, 4096)])
-def test_segmented_sort_stable(gs, dev, P, N):
+def test_segmented_sort_stable(gs, dev, sort_form, P, N):
     """every segment sorted independently, ascending, stable; payload = global index"""
     from gsdeblur_amd import ops
     g = torch.Generator().manual_seed(P * 7 + N)
@@ -143,7 +154,7 @@ def test_segmented_sort_stable(gs, dev, P, N):
 @pytest.mark.parametrize("digit", [8, 11])
 @pytest.mark.parametrize("P,N,keep", [(1, 5000, 0.3), (5, 4097, 0.25), (3, 100_003, 0.27), (10, 4096, 0.0),
                                       (4, 9000, 1.0), (6, 20_000, 0.01)])
-def test_depth_rank_compacting(gs, dev, P, N, keep, digit):
+def test_depth_rank_compacting(gs, dev, sort_form, P, N, keep, digit):
     """compacting depth pre-sort: culled keys dropped by the first pass, survivors sorted stably at the start of their
     segment, their tile counts gathered by the last pass, the segment-aware scan treats everything behind as zero;
     the result is the same ranking / prefix the full sort + gather + scan produce"""
@@ -1654,6 +1665,43 @@ def test_native_frame_grows_its_arena_and_reports_stage_times(gs, dev):
         ops.profiler = None
     for stage in ("depth_sort", "slice_count", "tile_sort", "raster_fwd", "raster_bwd", "grad_reduce", "project_fwd"):
         assert stage in ms and len(ms[stage]) >= 1 and all(t > 0 for t in ms[stage]), stage
+
+
+def test_single_pass_sorts_give_the_same_frame(gs, dev):
+    """the radix passes as single kernels (decoupled look-back).  Measured slower on the tile
+    sort at this pipeline's sizes, so not the default; the whole frame through them — multi-slice, rolling-shutter
+    bands — must equal the default frame bit for bit (sorting is exact integer work)."""
+    from gsdeblur_amd import ops, _lib
+    L = _lib.load()
+    n, W, H, S, R = 60000, 208, 144, 2, 2
+    sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=17, scale_mult=6.0, profile="trained"), dev)
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, R, 1 / 30)
+    times_t = torch.tensor(times, device=dev)
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(6)).to(dev)
+    saved = ops.SLICE_BASE
+    res = []
+    try:
+        ops.SLICE_BASE = 16
+        for form in (0, 1):
+            old = L.gs_sort_set_single_pass(form)
+            try:
+                p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+                vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"] * 5, sc["ang_vel"] * 3, times_t)
+                rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
+                                                        torch.sigmoid(p["opacity_logits"]), p["sh"], vms, None, S, R,
+                                                        sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2)
+                (rgb * wt).sum().backward()
+                res.append((rgb.detach().clone(), alphas.detach().clone(), {k: v.grad.clone() for k, v in p.items()},
+                            [int(v) for v in ops.last_slice_intersects if int(v) > 0]))
+            finally:
+                L.gs_sort_set_single_pass(old)
+    finally:
+        ops.SLICE_BASE = saved
+    a, b = res
+    assert len(a[3]) >= 2 and a[3] == b[3]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
 
 
 def test_native_frame_merges_slices_of_a_frame_that_does_not_saturate(gs, dev):
