@@ -447,6 +447,11 @@ def main():
                         "issue_frac_at_2_cycles": round(vi["insts_valu"] * 2.0 / simd_cycles, 4),
                         "mix_cycles_per_instruction": vi["mix_cycles_per_inst"],
                         "issue_frac_at_measured_mix": round(vi["insts_valu"] * vi["mix_cycles_per_inst"] / simd_cycles, 4),
+                        # the same with the mix priced in wall ns (no clock assumed; the micro-benchmark's wall time
+                        # includes its launch tails, so this one over-estimates: the truth lies between the two)
+                        "issue_frac_at_measured_mix_wall_ns": (round(vi["insts_valu"] * vi["mix_wall_ns_per_inst"] /
+                                                                     (simd_cycles / tj["valu"].get("clock_hz", 2.1e9) * 1e9), 4)
+                                                               if "mix_wall_ns_per_inst" in vi else None),
                         "clock_hz_assumed": tj["valu"].get("clock_hz", 2.1e9),
                         "sq_wait_inst_any_frac": vi.get("wait_inst_any_frac"), "waves_per_simd": vi.get("waves_per_simd"),
                         "source": tj["valu"].get("source")}

@@ -18,9 +18,12 @@ KERNELS = ["raster_bwd_sload_kernel", "raster_fwd_sload_kernel", "raster_bwd_ker
            "slice_colors_kernel", "emit_open_kernel", "reduce_tuples_wave_kernel", "radix_scatter_kernel",
            "radix_hist_kernel"]
 # issue cycles per VALU wave-instruction of the kernel's inner-loop mix (tools/valu_mix.py x tools/valu_bench.hip)
-MIX = {"raster_fwd_sload_kernel": 859.8 / 245, "raster_bwd_sload_kernel": 1483.9 / 441,
-       "raster_fwd_slice_kernel": 346.5 / 90, "raster_bwd_kernel_v2": 489.4 / 125}      # profiles/r03_valu_mix.txt
-
+MIX = {"raster_fwd_sload_kernel": 844.7 / 245, "raster_bwd_sload_kernel": 1502.1 / 441,
+       "raster_fwd_slice_kernel": 345.8 / 90, "raster_bwd_kernel_v2": 485.5 / 125}      # profiles/r03_valu_mix.txt
+# the same mixes in WALL nanoseconds per wave-instruction and SIMD (no clock assumed; an upper bound: the
+# micro-benchmark's wall time includes its launch tails)
+MIX_NS = {"raster_fwd_sload_kernel": 500.0 / 245, "raster_bwd_sload_kernel": 891.9 / 441,
+          "raster_fwd_slice_kernel": 203.9 / 90, "raster_bwd_kernel_v2": 288.2 / 125}
 
 def mean_per_kernel(counter):
     acc = defaultdict(list)
@@ -63,6 +66,7 @@ valu = {"clock_hz": 2.1e9,
 for k in MIX:
     if k in insts:
         valu[k] = {"insts_valu": int(insts[k]), "mix_cycles_per_inst": round(MIX[k], 3),
+                   "mix_wall_ns_per_inst": round(MIX_NS[k], 3),
                    "wait_inst_any_frac": round(wait[k] / wcyc[k], 3) if k in wait and k in wcyc else None,
                    # SQ_WAVE_CYCLES counts quad-cycles summed over waves; SQ_BUSY_CYCLES is per shader engine (32)
                    "waves_per_simd": round(wcyc[k] * 4 / (busy[k] / 32.0) / 1024, 2) if k in busy and k in wcyc else None}

@@ -16,8 +16,13 @@ COST = {  # measured, w/SIMD=4 column.  Round 3 re-measured them on pinned regis
     # profiles/r03_run3_valu_bench3.log): two-source mul / add / mov / integer ops 2.17, fma 2.08 when its second and
     # third source sit in registers of different parity (3.03 otherwise: priced at the mean), anything with an SGPR
     # operand / v_min / v_max / v_cndmask / DPP 3.2-3.6, v_cmp 3.2-3.4 (round 2 said 4.0), v_pk_* 3.49, v_exp / v_rcp 6.45
-    "fma/mul/add, VGPR operands": 2.3, "fma/mul/add, SGPR operand": 3.25, "v_pk_*_f32": 3.49,
-    "v_min/max/cndmask/mov/other": 3.30, "v_cmp": 3.30, "v_exp/v_rcp": 6.45, "v_readlane": 7.89}
+    "mul/add/fmac, VGPR operands": 2.17, "fma (VOP3), VGPR operands": 2.55, "fma/mul/add, SGPR operand": 3.25,
+    "v_pk_*_f32": 3.49, "v_min/max/cndmask/dpp": 3.30, "v_mov/int/other": 2.17, "v_cmp": 3.30, "v_exp/v_rcp": 6.45,
+    "v_readlane": 7.89}
+# the same classes in WALL nanoseconds per wave-instruction and SIMD (the bench's hipEvent column: no clock assumed)
+NS = {"mul/add/fmac, VGPR operands": 1.17, "fma (VOP3), VGPR operands": 1.58, "fma/mul/add, SGPR operand": 1.95,
+      "v_pk_*_f32": 2.15, "v_min/max/cndmask/dpp": 1.93, "v_mov/int/other": 1.15, "v_cmp": 1.92, "v_exp/v_rcp": 3.8,
+      "v_readlane": 4.6}
 
 
 def classify(line):
@@ -32,11 +37,17 @@ def classify(line):
         return "v_cmp"
     if op.startswith("v_pk_"):
         return "v_pk_*_f32"
+    args = line.split(None, 1)[1] if len(line.split(None, 1)) > 1 else ""
     if re.match(r"v_(fma|fmac|mul|add|sub|mac|mad)_f32", op):
-        args = line.split(None, 1)[1] if len(line.split(None, 1)) > 1 else ""
         srcs = args.split(",")[1:]
-        return "fma/mul/add, SGPR operand" if any(re.search(r"\bs\d+|\bs\[", a) for a in srcs) else "fma/mul/add, VGPR operands"
-    return "v_min/max/cndmask/mov/other"
+        if any(re.search(r"\bs\d+|\bs\[", a) for a in srcs):
+            return "fma/mul/add, SGPR operand"
+        if "dpp" in line or "quad_perm" in line or "row_" in line:
+            return "v_min/max/cndmask/dpp"
+        return "fma (VOP3), VGPR operands" if op.startswith("v_fma_") else "mul/add/fmac, VGPR operands"
+    if re.match(r"v_(min|max|med3|cndmask)", op) or "dpp" in line or "quad_perm" in line or "row_" in line:
+        return "v_min/max/cndmask/dpp"
+    return "v_mov/int/other"
 
 
 def loops(body):
@@ -87,12 +98,13 @@ def main(d):
                     vmem += 1
             total = sum(cnt.values())
             cyc = sum(COST[k] * v for k, v in cnt.items())
+            ns = sum(NS[k] * v for k, v in cnt.items())
             short = re.sub(r"^_ZN2gs\d+", "", name)[:44]
             print(f"{short:46s} loop lines {b - a + 1:5d}  VALU {total:4d}  issue cycles {cyc:7.1f}  "
-                  f"(at 2 cyc: {2 * total:5d})  SALU {salu:4d} SMEM {smem:3d} LDS {lds:3d} VMEM {vmem:3d}")
+                  f"wall ns {ns:7.1f}  SALU {salu:4d} SMEM {smem:3d} LDS {lds:3d} VMEM {vmem:3d}")
             for k in COST:
                 if cnt[k]:
-                    print(f"    {k:32s} {cnt[k]:4d} x {COST[k]:.2f} = {cnt[k] * COST[k]:7.1f}")
+                    print(f"    {k:32s} {cnt[k]:4d} x {COST[k]:.2f} cyc = {cnt[k] * COST[k]:7.1f}    x {NS[k]:.2f} ns = {cnt[k] * NS[k]:7.1f}")
 
 
 if __name__ == "__main__":
