@@ -20,7 +20,7 @@ for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     gap = (s - prev) if prev else 0
     ksum += e - s
-    name = r["Kernel_Name"].split("(")[0][-58:]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-58:]
     print(f"{(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:8.1f}  gap {gap / 1e3:7.1f}  grid {r['Grid_Size_X']:>9} {name}")
     prev = e
 span = int(rows[b]["Start_Timestamp"]) - t0
