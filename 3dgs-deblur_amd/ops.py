@@ -503,6 +503,7 @@ class _ArenaTooSmall(Exception):
 
 
 _arena_hint = {}        # (device, N, P, S, H, W) -> bytes that held the last frame of that shape (+ margin)
+_ARENA_ATTEMPTS = 16    # first frame of a new shape: projections + partial frames until the arena holds every slice
 _pinned_cache = {}
 
 
@@ -559,7 +560,9 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
                             _ptr(arena), arena.numel(), ctypes.c_void_p(pin.data_ptr()), pin.numel(), ctypes.byref(state),
                             _stream())
     if st == 3:
-        _arena_hint[key] = int(state.arena_required * 1.15) + (32 << 20)
+        # the library prices one slice ahead; a frame that needs many (ever larger) slices is settled in several steps,
+        # each at least half as large again as the last, so the number of retries is logarithmic in the final size
+        _arena_hint[key] = max(int(state.arena_required * 1.15) + (32 << 20), int(nbytes * 1.5))
         raise _ArenaTooSmall()
     _check(st, "frame_forward")
     _arena_hint[key] = max(int(nbytes), int((state.arena_used + L.gs_frame_backward_bytes(ctypes.byref(state))) * 1.15))
@@ -1303,14 +1306,14 @@ class _RenderSubposes(Function):
         ctx.prealloc = {} if (PREALLOC_BWD and any(ctx.needs_input_grad)) else None
         ctx.frame = None
         if _native_frame_ok() and (rs is None or R == 1):
-            for attempt in range(3):
+            for attempt in range(_ARENA_ATTEMPTS):
                 try:
                     out_img, out_T, ctx.frame = native_frame_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges,
                                                                      SLICE_BASE, color, depth_acc,
                                                                      any(ctx.needs_input_grad), rs)
                     break
                 except _ArenaTooSmall:
-                    if attempt == 2:
+                    if attempt == _ARENA_ATTEMPTS - 1:
                         raise _lib.HipLibraryError("frame_forward: the arena estimate did not converge")
                     # the depth keys were consumed by the pre-sort: project again, then retry with the larger arena
                     if depth_acc is not None:

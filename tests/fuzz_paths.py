@@ -29,7 +29,12 @@ dev = torch.device("cuda", 0)
 KNOBS = ("SLICE_BASE", "EXACT_TILE_CULL", "COMPACT_EMIT", "HIT_MASKS", "GRAD_TUPLES", "DEFER_COLOR")
 # route switches that must not change anything: drawn at random for the default-path side of every trial
 ROUTES = ("SPECULATE", "TILE_SORT_CARRY", "DEPTH_SORT_COMPACT", "DEVICE_SIZES", "PREALLOC_BWD")
-saved = {k: getattr(ops, k) for k in KNOBS + ROUTES}
+# round 3: half of the trials go through the C++ frame orchestration (gs_frame_forward / gs_frame_backward; it needs the
+# default routes) with slice merging and the polled read-backs drawn at random; the radix passes run in either form
+FRAME = ("NATIVE_FRAME", "SLICE_MERGE", "FRAME_POLL")
+saved = {k: getattr(ops, k) for k in KNOBS + ROUTES + FRAME}
+from gsdeblur_amd import _lib  # noqa: E402
+_L = _lib.load()
 bad = 0
 t0 = time.time()
 for trial in range(trials):
@@ -52,6 +57,11 @@ for trial in range(trials):
         # 1-y to 1e-4 relative (at logit 14 it does not, and the oracle comparison of that gradient measures torch)
         sc["opacity_logits"][::rng.choice([3, 17, 101])] = 7.5
     routes = {k: rng.choice([0, 1]) for k in ROUTES}
+    native = rng.random() < 0.5
+    frame = {"NATIVE_FRAME": int(native), "SLICE_MERGE": rng.choice([0.0, 0.3, 0.75]), "FRAME_POLL": rng.choice([0, 1])}
+    single_pass = rng.choice([0, 1])
+    if native:
+        routes = {k: saved[k] for k in ROUTES}
     sc_cpu = sc
     if only is not None and trial != only:
         continue
@@ -65,6 +75,9 @@ for trial in range(trials):
                 setattr(ops, k, 0 if plain else saved[k])
             for k in ROUTES:
                 setattr(ops, k, saved[k] if plain else routes[k])
+            for k in FRAME:
+                setattr(ops, k, (0 if k == "NATIVE_FRAME" else saved[k]) if plain else frame[k])
+            _L.gs_sort_set_single_pass(0 if plain else single_pass)
             if not plain:
                 ops.SLICE_BASE = base
             p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
@@ -81,6 +94,7 @@ for trial in range(trials):
     finally:
         for k, v in saved.items():
             setattr(ops, k, v)
+        _L.gs_sort_set_single_pass(0)
     (img_f, al_f, g_f, nsl), (img_p, al_p, g_p, _) = res
     ok = torch.equal(img_f, img_p) and torch.equal(al_f, al_p)
     worst, worst_key = 0.0, ""
@@ -123,7 +137,8 @@ for trial in range(trials):
         extra = f" oracle: img {d_img:.1e} grad {d_grad:.1e} fragile {float(frag.float().mean()):.3f}"
     bad += 0 if ok else 1
     print(f"trial {trial:3d} n={n:6d} {W}x{H} S={S} R={R} mult={mult} base={base} slices={nsl} "
-          f"deg={deg} aa={int(aa)} gamma={gamma} routes={''.join(str(routes[k]) for k in ROUTES)} img_equal={torch.equal(img_f, img_p)} grad_rel={worst:.1e} ({worst_key}){extra} "
+          f"deg={deg} aa={int(aa)} gamma={gamma} routes={''.join(str(routes[k]) for k in ROUTES)} "
+          f"frame={int(native)}/{frame['SLICE_MERGE']}/{frame['FRAME_POLL']} sort1p={single_pass} img_equal={torch.equal(img_f, img_p)} grad_rel={worst:.1e} ({worst_key}){extra} "
           f"{'ok' if ok else 'FAIL'}", flush=True)
 print(f"fuzz: {trials - bad}/{trials} trials ok in {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)

@@ -1667,6 +1667,37 @@ def test_native_frame_grows_its_arena_and_reports_stage_times(gs, dev):
         assert stage in ms and len(ms[stage]) >= 1 and all(t > 0 for t in ms[stage]), stage
 
 
+def test_native_frame_arena_converges_over_many_ever_larger_slices(gs, dev):
+    """found by tests/fuzz_paths.py (round 3): the library prices ONE slice ahead, so a first frame that needs many
+    slices of doubling size (tiny budget, translucent scene, merging on) takes several arena retries — the host used
+    to give up after three.  Start from a 1 MB arena: the frame must come out, equal to the Python orchestration's."""
+    from gsdeblur_amd import ops
+    n, W, H, S = 60000, 160, 112, 2
+    sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=23, scale_mult=8.0, profile="trained"), dev)
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, 1, 0.0)
+    vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"], sc["ang_vel"], torch.tensor(times, device=dev))
+    saved = (ops.NATIVE_FRAME, ops.SLICE_BASE)
+    key = (str(dev), n, S, S, H, W)
+
+    def render():
+        return gs.render_combined(sc["means"], sc["log_scales"].exp(), sc["quats"], torch.sigmoid(sc["opacity_logits"]),
+                                  sc["sh"], vms, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2)[0]
+    try:
+        ops.SLICE_BASE = 2
+        ops.NATIVE_FRAME = 0
+        ref = render()
+        planned = sum(1 for v in ops.last_slice_intersects if int(v) > 0)
+        ops.NATIVE_FRAME = 1
+        ops._arena_hint[key] = 1 << 20
+        got = render()
+        assert ops._native_frame_ok()
+    finally:
+        ops.NATIVE_FRAME, ops.SLICE_BASE = saved
+        ops._arena_hint.pop(key, None)
+    assert planned >= 6, planned
+    assert torch.equal(ref, got)
+
+
 def test_single_pass_sorts_give_the_same_frame(gs, dev):
     """the radix passes as single kernels (decoupled look-back).  Measured slower on the tile
     sort at this pipeline's sizes, so not the default; the whole frame through them — multi-slice, rolling-shutter
