@@ -3,7 +3,10 @@ masks, deferred colour, gradient tuples) against the plainest one (one slice, no
 sizes / sub-pose layouts / slice budgets.  Images must be bit-identical, gradients equal up to summation order.
 With `oracle` as third argument the default path is ALSO held against the float64 CPU oracle (tiny sizes only;
 test infrastructure, never part of the product path).
-usage: python tests/fuzz_paths.py [trials] [seed] [oracle] [only:<trial>]   (only: replay the draws, run that trial alone)"""
+With `pixvel` as an argument the trials render the paper's pixel-velocity model instead of the SE(3) re-projection, a
+third of them with EXACT per-row rolling shutter (round 3); the exact mode has no atomics path, so its other side is the
+Python orchestration rendering ONE slice.
+usage: python tests/fuzz_paths.py [trials] [seed] [oracle] [pixvel] [only:<trial>]   (only: replay the draws, run that trial alone)"""
 import random
 import sys
 import time
@@ -19,6 +22,7 @@ from gsdeblur_amd import ops  # noqa: E402
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 with_oracle = len(sys.argv) > 3 and sys.argv[3] == "oracle"
+pixvel = "pixvel" in sys.argv[1:]
 only = next((int(a[5:]) for a in sys.argv[1:] if a.startswith("only:")), None)
 dump = next((a[5:] for a in sys.argv[1:] if a.startswith("dump:")), None)     # with only: save the trial's inputs + gradients
 if with_oracle:
@@ -60,6 +64,12 @@ for trial in range(trials):
     native = rng.random() < 0.5
     frame = {"NATIVE_FRAME": int(native), "SLICE_MERGE": rng.choice([0.0, 0.3, 0.75]), "FRAME_POLL": rng.choice([0, 1])}
     single_pass = rng.choice([0, 1])
+    rs_time = 0.0
+    if pixvel:
+        rs_time = rng.choice([0.0, 0.0, 1 / 30])
+        if rs_time:
+            R = 1
+            routes = {k: saved[k] for k in ROUTES}       # (the A/B routes are not wired for the exact mode)
     if native:
         routes = {k: saved[k] for k in ROUTES}
     sc_cpu = sc
@@ -77,17 +87,32 @@ for trial in range(trials):
                 setattr(ops, k, saved[k] if plain else routes[k])
             for k in FRAME:
                 setattr(ops, k, (0 if k == "NATIVE_FRAME" else saved[k]) if plain else frame[k])
+            if plain and rs_time:
+                # exact rolling shutter needs the tuple backward and box lists: its "plain" side is the Python
+                # orchestration with every planned slice folded into one
+                for k in KNOBS:
+                    setattr(ops, k, saved[k])
+                ops.SLICE_BASE = 0
             _L.gs_sort_set_single_pass(0 if plain else single_pass)
             if not plain:
                 ops.SLICE_BASE = base
             p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
-            vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"] * 20, sc["ang_vel"] * 10,
-                                      torch.tensor(times, device=dev))
-            rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
-                                                    torch.sigmoid(p["opacity_logits"]), p["sh"], vms,
-                                                    None if bg is None else bg.to(dev), S, R, sc["fx"], sc["fy"],
-                                                    sc["cx"], sc["cy"], H, W, gamma=gamma, min_rgb_level=mlevel,
-                                                    sh_degree=deg, antialiased=aa)
+            if pixvel:
+                rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
+                                                        torch.sigmoid(p["opacity_logits"]), p["sh"], sc["viewmat"],
+                                                        None if bg is None else bg.to(dev), S, R, sc["fx"], sc["fy"],
+                                                        sc["cx"], sc["cy"], H, W, gamma=gamma, min_rgb_level=mlevel,
+                                                        sh_degree=deg, antialiased=aa, lin_vel=sc["lin_vel"] * 20,
+                                                        ang_vel=sc["ang_vel"] * 10, times=torch.tensor(times, device=dev),
+                                                        rolling_shutter_time=rs_time)
+            else:
+                vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"] * 20, sc["ang_vel"] * 10,
+                                          torch.tensor(times, device=dev))
+                rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
+                                                        torch.sigmoid(p["opacity_logits"]), p["sh"], vms,
+                                                        None if bg is None else bg.to(dev), S, R, sc["fx"], sc["fy"],
+                                                        sc["cx"], sc["cy"], H, W, gamma=gamma, min_rgb_level=mlevel,
+                                                        sh_degree=deg, antialiased=aa)
             ((rgb * wt).sum() + 0.5 * alphas.sum()).backward()
             res.append((rgb.detach().clone(), alphas.detach().clone(), {k: v.grad.clone() for k, v in p.items()},
                         len(ops.last_slice_intersects)))
@@ -138,7 +163,8 @@ for trial in range(trials):
     bad += 0 if ok else 1
     print(f"trial {trial:3d} n={n:6d} {W}x{H} S={S} R={R} mult={mult} base={base} slices={nsl} "
           f"deg={deg} aa={int(aa)} gamma={gamma} routes={''.join(str(routes[k]) for k in ROUTES)} "
-          f"frame={int(native)}/{frame['SLICE_MERGE']}/{frame['FRAME_POLL']} sort1p={single_pass} img_equal={torch.equal(img_f, img_p)} grad_rel={worst:.1e} ({worst_key}){extra} "
+          f"frame={int(native)}/{frame['SLICE_MERGE']}/{frame['FRAME_POLL']} sort1p={single_pass} "
+          f"{'pixvel rs=%.3f ' % rs_time if pixvel else ''}img_equal={torch.equal(img_f, img_p)} grad_rel={worst:.1e} ({worst_key}){extra} "
           f"{'ok' if ok else 'FAIL'}", flush=True)
 print(f"fuzz: {trials - bad}/{trials} trials ok in {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
