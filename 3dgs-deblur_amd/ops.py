@@ -1321,7 +1321,11 @@ class _RenderSubposes(Function):
                     with _stage("project_fwd"):
                         _project()
             slices = []
-            ctx.prealloc = None
+            # the backward's frame-sized buffers are set up here, not in the window between the forward and the backward
+            # compositor where the GPU waits for the host (the Python orchestration does the same, see sliced_forward)
+            ctx.prealloc = ({"touched": torch.zeros(P * N, dtype=torch.uint8, device=dev),
+                             "v_records": torch.empty(P * N, REC, device=dev)}
+                            if (PREALLOC_BWD and any(ctx.needs_input_grad)) else None)
         else:
             out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE, color,
                                                     depth_acc, ctx.prealloc, rs)
