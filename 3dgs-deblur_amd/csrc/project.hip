@@ -300,6 +300,10 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
     for (int j = 0; j < 12; ++j) Vm0[j] = fp.viewmats[j];
     project_one(m, c3, Vm0, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x, fp.in.tiles_y,
                 fp.in.clip, o0, k0);
+    // A Gaussian outside the projection's fov guard band (|x/z| or |y/z| beyond 1.3 tan(fov/2) at the mid-exposure pose)
+    // is culled for the whole frame: x/z is unbounded at grazing angles, and the first-order pixel motion of such a
+    // point (thousands of pixels per frame) would drag a splat that never comes near the image straight across it.
+    if (k0.clamp_x != 0 || k0.clamp_y != 0) k0.geom_ok = 0;
     if (k0.geom_ok) {
       const float lin[3] = {fp.twist[0], fp.twist[1], fp.twist[2]}, ang[3] = {fp.twist[3], fp.twist[4], fp.twist[5]};
       pixel_velocity(k0.pc, k0.rz, fp.in.fx, fp.in.fy, lin, ang, pv);

@@ -25,6 +25,7 @@ import os
 
 TILE = 16
 REC = 12  # floats per rasterizer record
+MAX_SUBPOSES = 256   # blur samples x rolling-shutter bands per frame (SliceDesc in csrc/binning.hip)
 # kernel variant selector for A/B measurements (0 = default)
 RASTER_FWD_VARIANT = int(os.environ.get("GSD_RASTER_FWD_VARIANT", "0"))
 RASTER_BWD_VARIANT = int(os.environ.get("GSD_RASTER_BWD_VARIANT", "0"))
@@ -1243,6 +1244,9 @@ class _RenderSubposes(Function):
         ctx.xy_grad_out = xy_grad_out
         N, K = means3d.shape[0], sh.shape[1]
         P = S * R
+        if P > MAX_SUBPOSES:
+            raise ValueError(f"{S} blur samples x {R} row bands = {P} sub-poses per frame; the slice descriptors travel "
+                             f"in kernel arguments and hold at most {MAX_SUBPOSES} (kMaxSubposes, csrc/binning.hip)")
         # pixel-velocity model: ONE mid-exposure viewmat + the camera twist + the P sub-pose times
         pixvel = times is not None
         rs_time = float(rs_time or 0.0)

@@ -11,6 +11,7 @@ device and the HIP side raises when the library is missing.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -46,8 +47,12 @@ def psnr(img: Tensor, ref: Tensor) -> float:
     return float("inf") if mse == 0 else -10.0 * math.log10(mse)
 
 
+# A/B switch: GSD_TORCH_TRAIN=1 runs the loss as torch ops and the optimizers as torch.optim.Adam on the GPU too
+TORCH_TRAIN = int(os.environ.get("GSD_TORCH_TRAIN", "0"))
+
+
 def image_loss(pred: Tensor, gt: Tensor, ssim_lambda: float = 0.2) -> Tensor:
-    if pred.is_cuda:
+    if pred.is_cuda and not TORCH_TRAIN:
         from . import fused
         return fused.image_loss(pred, gt, ssim_lambda)
     return image_loss_torch(pred, gt, ssim_lambda)
@@ -85,7 +90,7 @@ def make_optimizers(model: SplatfactoDeblurModel, lr_scale: float = 1.0,
     lrs = {"means": 1.6e-4, "scales": 5e-3, "quats": 1e-3, "opacities": 5e-2, "features_dc": 2.5e-3,
            "features_rest": 2.5e-3 / 20}
     if fused is None:
-        fused = model.means.is_cuda
+        fused = model.means.is_cuda and not TORCH_TRAIN
     if fused:
         from .fused import HipAdam as Adam
     else:

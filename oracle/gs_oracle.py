@@ -640,7 +640,25 @@ def _render_pixel_velocity(cfg: RenderConfig, means, scales, quats, opacities, s
     sample_alpha = [torch.zeros(H, W, dtype=dt) for _ in range(S)]
     parts = []
     frag = torch.zeros(H, W, dtype=torch.bool)
-    geom = (pr0.radii > 0).to(dt)[:, None]
+    # outside the projection's fov guard band at the mid-exposure pose (|x/z| or |y/z| beyond FOV_LIMIT * tan(fov/2)):
+    # culled for the whole frame — x/z is unbounded at grazing angles and the first-order pixel motion of such a point
+    # is meaningless (project.hip: project_fused_fwd_kernel, k0.clamp_x / clamp_y)
+    one = torch.ones((), dtype=dt)
+    Vd = V.to(dt)
+    pcx = ((Vd[0, 0] * means[:, 0] + Vd[0, 1] * means[:, 1]) + Vd[0, 2] * means[:, 2]) + Vd[0, 3]
+    pcy = ((Vd[1, 0] * means[:, 0] + Vd[1, 1] * means[:, 1]) + Vd[1, 2] * means[:, 2]) + Vd[1, 3]
+    pcz = ((Vd[2, 0] * means[:, 0] + Vd[2, 1] * means[:, 1]) + Vd[2, 2] * means[:, 2]) + Vd[2, 3]
+    rz = 1.0 / torch.where(pcz > cfg.clip_thresh, pcz, torch.ones_like(pcz))
+    lim_x = (one * FOV_LIMIT) * ((one * 0.5) * float(W) / (one * cfg.fx))
+    lim_y = (one * FOV_LIMIT) * ((one * 0.5) * float(H) / (one * cfg.fy))
+    inband = ((pcx * rz).detach().abs() <= lim_x) & ((pcy * rz).detach().abs() <= lim_y)
+    geom = ((pr0.radii > 0) & inband).to(dt)[:, None]
+    if not bool(inband.all()):
+        zi = torch.zeros_like(pr0.radii)
+        pr0 = Projected(xys=pr0.xys, depths=pr0.depths, radii=torch.where(inband, pr0.radii, zi), conics=pr0.conics,
+                        compensation=pr0.compensation, num_tiles_hit=torch.where(inband, pr0.num_tiles_hit, zi),
+                        cov3d=pr0.cov3d, tile_min=pr0.tile_min * inband[:, None].to(torch.int32),
+                        tile_max=pr0.tile_max * inband[:, None].to(torch.int32))
     for p, tau in enumerate(times):
         xys = (pr0.xys + (torch.ones((), dtype=dt) * tau) * pv) * geom
         if exact:

@@ -248,6 +248,75 @@ def test_pixel_velocity_agrees_with_se3_reprojection_to_second_order(oracle):
     assert 3.5 < gaps[0] / gaps[1] < 4.5 and 3.5 < gaps[1] / gaps[2] < 4.5
 
 
+def _posed(sc, O):
+    """the scene seen from a rotated and translated camera: world = R^T (camera - t), viewmat = [R | t] (every other
+    oracle test renders from the identity pose, where pre- and post-multiplication of the pose cannot be told apart)"""
+    import math
+
+    def rot(ax, a):
+        c, s_ = math.cos(a), math.sin(a)
+        R = torch.eye(3, dtype=torch.float64)
+        i, j = [(1, 2), (0, 2), (0, 1)][ax]
+        R[i, i] = c; R[j, j] = c; R[i, j] = -s_; R[j, i] = s_
+        return R
+    R = rot(1, 0.7) @ rot(0, -0.4) @ rot(2, 1.1)
+    t = torch.tensor([0.3, -0.2, 0.5], dtype=torch.float64)
+    V = torch.eye(4, dtype=torch.float64)
+    V[:3, :3], V[:3, 3] = R, t
+    out = dict(sc)
+    out["means"] = (sc["means"] - t) @ R
+    out["viewmat"] = V
+    return out
+
+
+def test_pixel_velocity_follows_se3_from_a_real_pose_and_ignores_grazing_gaussians(oracle):
+    """round 3, found end to end (tools/rs_forward_check.py): from a real camera pose, inside a cloud of Gaussians, the
+    pixel-velocity frame was 11 dB away from the SE(3) frame although every far Gaussian's centre followed to 0.2 px.
+    Cause: Gaussians just in front of the camera plane at grazing angles (z = 0.02, |x| = 2: x/z = 100) — far off screen
+    in every true sub-pose, but their first-order pixel velocity is 1e5 px/s and dragged them across the image.  The
+    model now culls what lies outside the projection's own fov guard band (1.3 tan(fov/2)) at the mid-exposure pose.
+    Known answers: (1) identity and non-identity pose: the pixel-velocity render is much closer to the SE(3) render
+    than the static render is; (2) adding grazing Gaussians changes neither render."""
+    O = oracle
+    H, W, n = 64, 96, 500
+    sc = O.synthetic_scene(n, W, H, seed=3, dtype=torch.float64, scale_mult=8.0)
+    lin, ang = sc["lin_vel"] * 40, sc["ang_vel"] * 40
+    # two row bands rendered a fifth of a second apart: the frame differs from the static one at FIRST order in the
+    # twist (a symmetric blur alone only differs at second order, like the model's own error)
+    kw = dict(blur_samples=2, exposure_time=1 / 30, rs_bands=2, rolling_shutter_time=1 / 5, gamma=2.2, min_rgb_level=0.0)
+
+    def renders(s_):
+        base = (s_["means"], s_["log_scales"].exp(), s_["quats"], torch.sigmoid(s_["opacity_logits"]), s_["sh"], s_["viewmat"])
+        z = torch.zeros(3, dtype=torch.float64)
+        mk = lambda mm: O.RenderConfig(H, W, s_["fx"], s_["fy"], s_["cx"], s_["cy"], motion_model=mm, **kw)   # noqa: E731
+        return (O.render(mk("se3"), *base, lin, ang)[0], O.render(mk("pixel_velocity"), *base, lin, ang)[0],
+                O.render(mk("se3"), *base, z, z)[0])
+    mse = lambda a, b: float(((a - b) ** 2).mean())     # noqa: E731
+    for posed in (False, True):
+        s0 = _posed(sc, O) if posed else sc
+        se3, pv, static = renders(s0)
+        # (the model moves centres only — shapes, opacities and depth order stay those of the mid pose —, so it closes
+        #  about two thirds of the gap, whatever the twist's magnitude)
+        assert mse(pv, se3) < 0.5 * mse(static, se3), (posed, mse(pv, se3), mse(static, se3))
+        # grazing Gaussians: camera-space z = 0.02 .. 0.05, |x| or |y| around 2 (x/z up to 100), large and opaque
+        g = torch.Generator().manual_seed(5)
+        k = 40
+        pc = torch.stack([(torch.rand(k, generator=g, dtype=torch.float64) * 2 + 1) * torch.sign(torch.rand(k, generator=g, dtype=torch.float64) - 0.5),
+                          (torch.rand(k, generator=g, dtype=torch.float64) * 2 - 1) * 2,
+                          0.02 + 0.03 * torch.rand(k, generator=g, dtype=torch.float64)], dim=1)
+        Vm = s0["viewmat"]
+        world = (pc - Vm[:3, 3]) @ Vm[:3, :3]
+        s1 = dict(s0)
+        s1["means"] = torch.cat([s0["means"], world])
+        s1["log_scales"] = torch.cat([s0["log_scales"], torch.full((k, 3), -2.5, dtype=torch.float64)])
+        s1["quats"] = torch.cat([s0["quats"], s0["quats"][:k]])
+        s1["opacity_logits"] = torch.cat([s0["opacity_logits"], torch.full((k,), 4.0, dtype=torch.float64)])
+        s1["sh"] = torch.cat([s0["sh"], s0["sh"][:k] + 0.5])
+        se3_g, pv_g, _ = renders(s1)
+        assert mse(se3_g, se3) < 1e-8, posed                 # they are never on screen in a true sub-pose ...
+        assert mse(pv_g, pv) < 1e-8, posed                   # ... and no longer in the first-order model's either
+
+
 def test_pixel_velocity_render_static_limit_and_autograd(oracle):
     """zero twist: every sub-pose renders the static frame; non-zero twist: autograd of the render w.r.t. the
     twist matches central finite differences"""

@@ -99,6 +99,31 @@ def trajectory(n_frames: int, speed: float = 1.0, seed: int = 0) -> List[Dict]:
 
 
 @torch.no_grad()
+def render_rolling_shutter_frame(model, cam, exposure_time: float, readout_time: float, gamma: float,
+                                 n_times: int = 192) -> torch.Tensor:
+    """Ground truth of a rolling-shutter frame, independent of the renderer's own rolling-shutter machinery: n_times
+    SHARP full frames along the SE(3) screw motion over [-(e + T_ro)/2, (e + T_ro)/2]; pixel row y integrates (in linear
+    light) the frames whose time lies in its own exposure window [tau(y) - e/2, tau(y) + e/2], tau(y) = ((y + 0.5)/H -
+    0.5) * T_ro — the continuous row time of a real sensor, no row bands."""
+    from gsdeblur_amd import ops
+    viewmat, lin, ang = model._viewmat_and_velocity(cam)
+    span = exposure_time + readout_time
+    times = torch.tensor([((k + 0.5) / n_times - 0.5) * span for k in range(n_times)], device=viewmat.device)
+    vms = ops.subpose_viewmats(viewmat, lin, ang, times)
+    sh = torch.cat([model.features_dc[:, None, :], model.features_rest], dim=1)
+    bg = model._background(viewmat.device)
+    samples, _, _ = ops.render_subposes(model.means, torch.exp(model.scales), model.quats,
+                                        torch.sigmoid(model.opacities).reshape(-1), sh, vms, bg, n_times, 1, cam.fx,
+                                        cam.fy, cam.cx, cam.cy, cam.height, cam.width, sh_degree=model.active_sh_degree(),
+                                        antialiased=True, return_alpha=False)
+    lin_img = samples.clamp(min=0.0) ** gamma                                        # [K,H,W,3]
+    tau = ((torch.arange(cam.height, device=times.device) + 0.5) / cam.height - 0.5) * readout_time
+    w = ((times[:, None] - tau[None, :]).abs() <= 0.5 * exposure_time + 1e-9).float()     # [K,H]
+    img = (lin_img * w[:, :, None, None]).sum(0) / w.sum(0).clamp(min=1.0)[:, None, None]
+    return torch.clamp(img ** (1.0 / gamma), max=1.0)
+
+
+@torch.no_grad()
 def generate(root: str, device, width: int = 160, height: int = 120, n_frames: int = 16, n_gaussians: int = 6000,
              exposure_time: float = 1.0 / 15.0, rolling_shutter_time: float = 0.0, dense_samples: int = 64,
              speed: float = 1.0, seed: int = 0, eval_interval: int = 8, seed_points: int = 3000,
@@ -107,9 +132,10 @@ def generate(root: str, device, width: int = 160, height: int = 120, n_frames: i
     gt = make_gt_scene(n_gaussians, seed)
     fx = fy = 0.75 * width
     cx, cy = width / 2.0, height / 2.0
+    rs_bands = min(8, (height + 15) // 16)
     cfg = SplatfactoDeblurConfig(sh_degree=3, blur_samples=dense_samples,
                                  rolling_shutter_compensation=rolling_shutter_time > 0,
-                                 rs_bands=min(8, (height + 15) // 16), gamma=2.2, min_rgb_level=0.0,
+                                 rs_bands=rs_bands, gamma=2.2, min_rgb_level=0.0,
                                  background_color="black")
     model = SplatfactoDeblurModel.from_scene(cfg, gt, device).eval()
     traj = trajectory(n_frames, speed, seed)
@@ -121,7 +147,10 @@ def generate(root: str, device, width: int = 160, height: int = 120, n_frames: i
         cam = Camera(fr["c2w"][:3], fx, fy, cx, cy, width, height,
                      metadata=dict(cam_idx=0, camera_linear_velocity=lin.tolist(), camera_angular_velocity=ang.tolist(),
                                    exposure_time=exposure_time, rolling_shutter_time=rolling_shutter_time))
-        rgb = model.get_outputs(cam)["rgb"]
+        if rolling_shutter_time > 0:
+            rgb = render_rolling_shutter_frame(model, cam, exposure_time, rolling_shutter_time, cfg.gamma)
+        else:
+            rgb = model.get_outputs(cam)["rgb"]
         name = f"images/{i:03d}.{image_ext}"
         _data.save_image(os.path.join(root, name), rgb)
         frames_json.append(dict(file_path=f"./{name}", transform_matrix=fr["c2w"].tolist(),

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--rolling-shutter-time", type=float, default=0.0)
     ap.add_argument("--blur-samples", type=int, nargs="+", default=[0, 5, 10])
     ap.add_argument("--motion-model", default="se3", choices=["se3", "pixel_velocity"])
+    ap.add_argument("--rolling-shutter-mode", default="bands", choices=["bands", "exact", "off"],
+                    help="bands: R row bands; exact: per pixel row (pixel_velocity model only); off: no compensation")
     ap.add_argument("--iterations", type=int, default=1500)
     ap.add_argument("--optimize-eval-cameras", action="store_true")
     ap.add_argument("--pose-noise", type=float, default=0.0, help="std (m / rad) of noise on the evaluation poses")
@@ -57,7 +59,10 @@ def main():
     table = {}
     for bs in args.blur_samples:
         cfg = gs.SplatfactoDeblurConfig(sh_degree=3, blur_samples=bs, gamma=2.2 if bs > 0 else 1.0,
-                                        min_rgb_level=0.0, rolling_shutter_compensation=args.rolling_shutter_time > 0,
+                                        min_rgb_level=0.0,
+                                        rolling_shutter_compensation=(args.rolling_shutter_time > 0 and
+                                                                      args.rolling_shutter_mode != "off"),
+                                        rolling_shutter_mode="exact" if args.rolling_shutter_mode == "exact" else "bands",
                                         rs_bands=min(8, (scene.cameras[0].height + 15) // 16),
                                         motion_model=args.motion_model, use_scale_regularization=True)
         if args.optimize_eval_cameras:
@@ -65,7 +70,8 @@ def main():
         model = SD.init_from_seed_points(cfg, xyz, rgb, dev, num_cameras=len(scene.cameras))
         res = gs.training.train_scene(model, scene, images, args.iterations,
                                       optimize_eval_cameras=args.optimize_eval_cameras, log_every=100)
-        name = f"blur_samples_{bs}" + ("_pixvel" if args.motion_model == "pixel_velocity" else "")
+        name = (f"blur_samples_{bs}" + ("_pixvel" if args.motion_model == "pixel_velocity" else "") +
+                ("" if args.rolling_shutter_time <= 0 else f"_rs_{args.rolling_shutter_mode}"))
         with open(os.path.join(args.out, f"metrics_{name}.json"), "wt") as f:
             json.dump({"results": res["results"], "wall_clock_time_seconds": res["wall_clock_time_seconds"]}, f)
         table[name] = res["results"] | {"time": round(res["wall_clock_time_seconds"], 1)}
