@@ -239,6 +239,68 @@ def test_velocity_optimizer_recovers_known_velocities_from_rolling_shutter_frame
 
 
 @pytest.mark.gpu
+def test_pose_optimizer_pulls_perturbed_cameras_back_to_the_true_pose(gs, dev):
+    """--camera-optimizer.mode=SO3xR3 (/root/reference/train.py:40), end to end: ground-truth Gaussians (constants),
+    sharp frames rendered from the TRUE poses, cameras handed to the model with a known perturbation (composed in the
+    camera frame, c2w @ exp(delta), as nerfstudio's camera optimizer does).  Through the rasterizer's viewmat gradients
+    alone the pose adjustment must undo it: the composed pose c2w_perturbed @ exp(adj) ends closer to the true pose in
+    translation AND rotation — which pins the viewmat gradient's frame, sign and the OpenGL -> OpenCV flip."""
+    import math
+    import synthetic_dataset as SD          # tools/synthetic_dataset.py (conftest puts tools/ on sys.path)
+    from gsdeblur_amd.model import Camera, _so3_exp
+    H, W = 120, 160
+    gt = SD.make_gt_scene(4000, 0)
+    traj = SD.trajectory(9, 1.0, 0)
+    frames = [1, 3, 5, 7]
+    cfg = gs.SplatfactoDeblurConfig(sh_degree=3, blur_samples=0, gamma=1.0, min_rgb_level=0.0, background_color="black",
+                                    rolling_shutter_compensation=False)
+    ref_model = gs.SplatfactoDeblurModel.from_scene(cfg, gt, dev).eval()
+    cfg2 = gs.SplatfactoDeblurConfig(sh_degree=3, blur_samples=0, gamma=1.0, min_rgb_level=0.0, background_color="black",
+                                     rolling_shutter_compensation=False)
+    cfg2.camera_optimizer.mode = "SO3xR3"
+    model = gs.SplatfactoDeblurModel.from_scene(cfg2, gt, dev, num_cameras=len(traj))
+    opts = gs.training.make_optimizers(model, lr_scale=10.0)
+    g = torch.Generator().manual_seed(2)
+    cams, imgs, true_c2w, pert_c2w = {}, {}, {}, {}
+    z3 = [0.0, 0.0, 0.0]
+    with torch.no_grad():
+        for i in frames:
+            c2w = traj[i]["c2w"][:3].clone()
+            md = dict(cam_idx=i, camera_linear_velocity=z3, camera_angular_velocity=z3, exposure_time=0.0,
+                      rolling_shutter_time=0.0)
+            imgs[i] = ref_model.get_outputs(Camera(c2w, 0.75 * W, 0.75 * W, W / 2.0, H / 2.0, W, H, metadata=md))["rgb"]
+            d_t = 0.03 * (torch.rand(3, generator=g) - 0.5)
+            d_r = 0.03 * (torch.rand(3, generator=g) - 0.5)
+            p = c2w.clone()
+            p[:, 3] = c2w[:, 3] + c2w[:, :3] @ d_t
+            p[:, :3] = c2w[:, :3] @ _so3_exp(d_r)
+            true_c2w[i], pert_c2w[i] = c2w, p
+            cams[i] = Camera(p, 0.75 * W, 0.75 * W, W / 2.0, H / 2.0, W, H, metadata=md)
+    first = {}
+    for it in range(300):
+        for i in frames:
+            loss = gs.training.eval_camera_step(model, opts, cams[i], imgs[i])
+            first.setdefault(i, loss)
+
+    def pose_error(a, b):
+        dr = a[:, :3].T @ b[:, :3]
+        ang = math.acos(max(-1.0, min(1.0, (float(dr.trace()) - 1.0) / 2.0)))
+        return float((a[:, 3] - b[:, 3]).norm()), ang
+    for i in frames:
+        adj = model.pose_adjustment[i].detach().cpu()
+        cur = pert_c2w[i].clone()
+        cur[:, 3] = pert_c2w[i][:, 3] + pert_c2w[i][:, :3] @ adj[:3]
+        cur[:, :3] = pert_c2w[i][:, :3] @ _so3_exp(adj[3:])
+        t0, r0 = pose_error(pert_c2w[i], true_c2w[i])
+        t1, r1 = pose_error(cur, true_c2w[i])
+        last = gs.training.eval_camera_step(model, opts, cams[i], imgs[i])
+        print(f"frame {i}: loss {first[i]:.4f} -> {last:.4f}; translation error {t0 * 100:.2f} -> {t1 * 100:.2f} cm, "
+              f"rotation error {math.degrees(r0):.2f} -> {math.degrees(r1):.2f} deg")
+        assert last < 0.5 * first[i], (i, first[i], last)
+        assert t1 < 0.6 * t0 and r1 < 0.6 * r0, (i, t0, t1, r0, r1)
+
+
+@pytest.mark.gpu
 def test_optimize_eval_cameras_moves_only_the_eval_cameras(gs, dev, tmp_path):
     """--optimize-eval-cameras (/root/reference/train.py:180-183): a step on an evaluation frame updates that
     frame's pose / velocity adjustment and nothing else — no gradient reaches the Gaussians"""
