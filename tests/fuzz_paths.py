@@ -61,6 +61,21 @@ for trial in range(trials):
         # 1-y to 1e-4 relative (at logit 14 it does not, and the oracle comparison of that gradient measures torch)
         sc["opacity_logits"][::rng.choice([3, 17, 101])] = 7.5
     routes = {k: rng.choice([0, 1]) for k in ROUTES}
+    # half of the trials see the scene from a random rigid pose (world = R^T (camera - t), viewmat = [R | t]): from the
+    # identity pose a pose applied from the wrong side or a camera centre read from the wrong column cannot show
+    if rng.random() < 0.5:
+        import math
+        ax, ang_ = [rng.uniform(-1, 1) for _ in range(3)], rng.uniform(0.2, 2.5)
+        nrm = math.sqrt(sum(a * a for a in ax)) + 1e-9
+        kx, ky, kz = (a / nrm for a in ax)
+        Kc = torch.tensor([[0.0, -kz, ky], [kz, 0.0, -kx], [-ky, kx, 0.0]])
+        Rm = torch.eye(3) + math.sin(ang_) * Kc + (1 - math.cos(ang_)) * (Kc @ Kc)
+        tv = torch.tensor([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-1, 1)])
+        sc = dict(sc)
+        sc["means"] = (sc["means"] - tv) @ Rm
+        Vp = torch.eye(4)
+        Vp[:3, :3], Vp[:3, 3] = Rm, tv
+        sc["viewmat"] = Vp
     native = rng.random() < 0.5
     frame = {"NATIVE_FRAME": int(native), "SLICE_MERGE": rng.choice([0.0, 0.3, 0.75]), "FRAME_POLL": rng.choice([0, 1])}
     single_pass = rng.choice([0, 1])
