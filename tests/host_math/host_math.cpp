@@ -95,4 +95,78 @@ int hm_subpose_viewmats_bwd(int P, const float* V0, const float* lin, const floa
   }
   return 0;
 }
+
+// ---- round 3: pixel velocity, swept tile boxes, the double-precision chain of the needle fix-up --------------------
+int hm_pixel_velocity(int n, const float* means, const float* V, float fx, float fy, const float* lin,
+                      const float* ang, float clip, float* pv) {
+  for (int i = 0; i < n; ++i) {
+    const float* m = means + 3 * i;
+    float pc[3];
+    pc[0] = ((V[0] * m[0] + V[1] * m[1]) + V[2] * m[2]) + V[3];
+    pc[1] = ((V[4] * m[0] + V[5] * m[1]) + V[6] * m[2]) + V[7];
+    pc[2] = ((V[8] * m[0] + V[9] * m[1]) + V[10] * m[2]) + V[11];
+    pv[2 * i] = 0.f; pv[2 * i + 1] = 0.f;
+    if (!(pc[2] > clip)) continue;
+    pixel_velocity(pc, 1.0f / pc[2], fx, fy, lin, ang, pv + 2 * i);
+  }
+  return 0;
+}
+
+// v_pc [n,3] per point; v_lin / v_ang [3] summed over the points
+int hm_pixel_velocity_bwd(int n, const float* means, const float* V, float fx, float fy, const float* lin,
+                          const float* ang, float clip, const float* v_pv, float* v_pc, float* v_lin, float* v_ang) {
+  for (int j = 0; j < 3; ++j) { v_lin[j] = 0.f; v_ang[j] = 0.f; }
+  for (int i = 0; i < n; ++i) {
+    const float* m = means + 3 * i;
+    float pc[3];
+    pc[0] = ((V[0] * m[0] + V[1] * m[1]) + V[2] * m[2]) + V[3];
+    pc[1] = ((V[4] * m[0] + V[5] * m[1]) + V[6] * m[2]) + V[7];
+    pc[2] = ((V[8] * m[0] + V[9] * m[1]) + V[10] * m[2]) + V[11];
+    for (int j = 0; j < 3; ++j) v_pc[3 * i + j] = 0.f;
+    if (!(pc[2] > clip)) continue;
+    float vl[3], va[3];
+    pixel_velocity_bwd(pc, 1.0f / pc[2], fx, fy, lin, ang, v_pv + 2 * i, v_pc + 3 * i, vl, va);
+    for (int j = 0; j < 3; ++j) { v_lin[j] += vl[j]; v_ang[j] += va[j]; }
+  }
+  return 0;
+}
+
+int hm_tile_bounds_swept(int n, const float* xa, const float* xb, const float* radf, int tiles_x, int tiles_y,
+                         int* tbounds, int* ntiles) {
+  for (int i = 0; i < n; ++i) {
+    Proj o;
+    memset(&o, 0, sizeof(o));
+    bool ok = tile_bounds_swept(xa[2 * i], xa[2 * i + 1], xb[2 * i], xb[2 * i + 1], radf[i], tiles_x, tiles_y, o);
+    ntiles[i] = ok ? o.ntiles : 0;
+    tbounds[4 * i] = o.tmin_x; tbounds[4 * i + 1] = o.tmin_y; tbounds[4 * i + 2] = o.tmax_x; tbounds[4 * i + 3] = o.tmax_y;
+  }
+  return 0;
+}
+
+// the projection VJP and the covariance VJP on doubles (what project_needle_hp_kernel runs for thin Gaussians)
+int hm_project_bwd_f64(int n, const float* means, const float* scales, float glob, const float* quats, const float* V,
+                       float fx, float fy, int W, int H, float clip, const double* v_xys, const double* v_depths,
+                       const double* v_conics, const double* v_comp, double* v_means, double* v_scales,
+                       double* v_quats, int* visible) {
+  for (int i = 0; i < n; ++i) {
+    double R[9], qn[4], inv, M[9], c3[6];
+    quat_to_rotmat_t<double>(quats + 4 * i, R, qn, &inv);
+    scale_rot_to_cov3d_t<double>(scales + 3 * i, glob, R, M, c3);
+    ProjCtxT<double> k;
+    project_ctx_t<double>(means + 3 * i, c3, V, fx, fy, W, H, k);
+    for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = 0; v_scales[3 * i + j] = 0; }
+    for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = 0;
+    visible[i] = (k.pc[2] > (double)clip && k.det != 0.0) ? 1 : 0;
+    if (!visible[i]) continue;
+    const double r = k.det0 / k.det;
+    const double comp = ::sqrt(r > 0.0 ? r : 0.0);
+    double vm[3], vc3[6], vV[12], vs[3], vq[4];
+    project_one_bwd_t<double>(means + 3 * i, c3, V, fx, fy, k, comp, v_xys + 2 * i, v_depths[i], v_conics + 3 * i,
+                              v_comp[i], vm, vc3, vV, nullptr, false);
+    cov3d_bwd_t<double>(scales + 3 * i, glob, quats + 4 * i, vc3, vs, vq, false);
+    for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = vm[j]; v_scales[3 * i + j] = vs[j]; }
+    for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = vq[j];
+  }
+  return 0;
+}
 }

@@ -128,3 +128,119 @@ def test_se3_closed_form_vs_matrix_exp(hm, oracle, scene, zero_ang):
     assert rel(vV0[:12], Vd.grad.numpy()[:3].reshape(-1)) < 1e-5
     assert rel(vl, ld.grad.numpy()) < 1e-5
     assert rel(va, ad.grad.numpy()) < 1e-5
+
+
+def _posed_view(O):
+    """a strongly non-identity world -> camera transform (every kernel-vs-oracle comparison on the GPU used to render
+    from near the identity pose)"""
+    V = O.subpose_viewmats(torch.eye(4, dtype=torch.float64), torch.tensor([0.4, -0.3, 0.6], dtype=torch.float64),
+                           torch.tensor([0.9, -1.3, 0.7], dtype=torch.float64), [1.0])[0]
+    return V
+
+
+def test_pixel_velocity_and_its_vjp_from_a_real_pose(hm, oracle, scene):
+    """gs_math.h::pixel_velocity / pixel_velocity_bwd (the paper's first-order model) against the oracle from a rotated,
+    translated camera: values to float32 round-off, the hand-derived VJP (d/d camera-space point, d/d twist) against
+    float64 autograd"""
+    O, sc = oracle, scene["sc"]
+    V64 = _posed_view(O)
+    R, t = V64[:3, :3], V64[:3, 3]
+    n = 4000
+    cam_pts = scene["means"][:n].double()                       # where the points should be in CAMERA space
+    world = ((cam_pts - t) @ R).float()                         # R^T (pc - t)
+    V = V64.float()
+    lin = torch.tensor([0.7, -0.4, 1.1]); ang = torch.tensor([0.5, -0.8, 0.3])
+    ref = O.pixel_velocity(world, V, sc["fx"], sc["fy"], lin, ang)
+    pv = np.zeros((n, 2), np.float32)
+    args = (n, P(np.ascontiguousarray(world.numpy())), P(np.ascontiguousarray(V.numpy())), f(sc["fx"]), f(sc["fy"]),
+            P(np.ascontiguousarray(lin.numpy())), P(np.ascontiguousarray(ang.numpy())), f(0.01))
+    hm.hm_pixel_velocity(*args, P(pv))
+    front = (world.double() @ R.T + t)[:, 2].numpy() > 0.01
+    assert front.sum() > 3000 and (~front).sum() > 10
+    assert np.abs(pv[front] - ref.numpy()[front]).max() <= 1e-5 * np.abs(ref.numpy()[front]).max()
+    assert (pv[~front] == 0).all()
+    # VJP
+    w64 = world.double().requires_grad_(True)
+    l64, a64 = lin.double().requires_grad_(True), ang.double().requires_grad_(True)
+    g = torch.Generator().manual_seed(2)
+    vpv = torch.randn(n, 2, generator=g) * torch.from_numpy(front)[:, None]
+    (O.pixel_velocity(w64, V64, sc["fx"], sc["fy"], l64, a64) * vpv.double()).sum().backward()
+    v_pc = np.zeros((n, 3), np.float32); v_lin = np.zeros(3, np.float32); v_ang = np.zeros(3, np.float32)
+    hm.hm_pixel_velocity_bwd(*args, P(np.ascontiguousarray(vpv.numpy())), P(v_pc), P(v_lin), P(v_ang))
+    want_pc = (w64.grad @ R.T).numpy()                          # v_world = R^T v_pc  ->  v_pc = R v_world
+    assert rel(v_pc, want_pc) < 2e-5
+    assert rel(v_lin, l64.grad.numpy()) < 2e-5 and rel(v_ang, a64.grad.numpy()) < 2e-5
+
+
+def test_swept_tile_boxes_bit_exact(hm, oracle, scene):
+    """gs_math.h::tile_bounds_swept (exact rolling shutter: the box of the 3-sigma circle dragged along the centre's
+    path during the readout) against the oracle's _bounds_swept: integers, bit for bit"""
+    O, sc, W, H = oracle, scene["sc"], scene["W"], scene["H"]
+    pr = O.project_gaussians(scene["means"], scene["scales"], 1.0, scene["quats"], scene["V"], sc["fx"], sc["fy"],
+                             sc["cx"], sc["cy"], H, W, keep_offscreen=True)
+    n = scene["means"].shape[0]
+    g = torch.Generator().manual_seed(4)
+    pv = torch.randn(n, 2, generator=g) * 400.0                 # px / s
+    half = 1.0 / 60.0
+    ref = O._bounds_swept(pr, pr.xys, pv, half, H, W)
+    ht = torch.ones((), dtype=torch.float32) * float(half)
+    xa = torch.stack([pr.xys[:, 0] - ht * pv[:, 0], pr.xys[:, 1] - ht * pv[:, 1]], -1)
+    xb = torch.stack([pr.xys[:, 0] + ht * pv[:, 0], pr.xys[:, 1] + ht * pv[:, 1]], -1)
+    tb = np.zeros((n, 4), np.int32); nt = np.zeros(n, np.int32)
+    hm.hm_tile_bounds_swept(n, P(np.ascontiguousarray(xa.numpy())), P(np.ascontiguousarray(xb.numpy())),
+                            P(np.ascontiguousarray(pr.radii.float().numpy())), (W + 15) // 16, (H + 15) // 16, P(tb), P(nt))
+    vis = (pr.radii > 0).numpy()
+    assert vis.sum() > 10000
+    want_nt = ref.num_tiles_hit.numpy()
+    assert (nt[vis] == want_nt[vis]).all()
+    hit = vis & (want_nt > 0)
+    assert hit.sum() > 5000 and (want_nt[vis] == 0).sum() > 10          # some sweep entirely off screen
+    assert (tb[hit, :2] == ref.tile_min.numpy()[hit]).all() and (tb[hit, 2:] == ref.tile_max.numpy()[hit]).all()
+
+
+def test_double_precision_projection_chain_of_the_needle_fix(hm, oracle, scene):
+    """project_ctx_t / project_one_bwd_t / cov3d_bwd_t instantiated on double — the chain project_needle_hp_kernel runs
+    for Gaussians whose scale ratio exceeds 8 — against float64 autograd, from a real pose, on needles (ratios 30..80):
+    agreement to 2e-7 of the largest gradient, where the float32 chain is percent-level wrong on such splats"""
+    O, sc, W, H = oracle, scene["sc"], scene["W"], scene["H"]
+    n = 3000
+    V64 = _posed_view(O)
+    R, t = V64[:3, :3], V64[:3, 3]
+    world = ((scene["means"][:n].double() - t) @ R).float()
+    g = torch.Generator().manual_seed(6)
+    scales = scene["scales"][:n].clone()
+    scales[:, 0] *= 30.0 + 50.0 * torch.rand(n, generator=g)     # needles
+    quats = scene["quats"][:n].clone()
+    V = V64.float()
+    md = world.double().requires_grad_(True); sd = scales.double().requires_grad_(True)
+    qd = quats.double().requires_grad_(True)
+    prd = O.project_gaussians(md, sd, 1.0, qd, V.double(), sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, keep_offscreen=True)
+    vx, vdp, vc, vcomp = (torch.randn(*shp, generator=g, dtype=torch.float64) for shp in ((n, 2), (n,), (n, 3), (n,)))
+    vis_t = prd.radii > 0
+    loss = ((prd.xys * vx).sum(-1) * vis_t).sum() + (prd.depths * vdp * vis_t).sum() + \
+        ((prd.conics * vc).sum(-1) * vis_t).sum() + (prd.compensation * vcomp * vis_t).sum()
+    loss.backward()
+    vm = np.zeros((n, 3)); vs = np.zeros((n, 3)); vq = np.zeros((n, 4)); vis = np.zeros(n, np.int32)
+    hm.hm_project_bwd_f64(n, P(np.ascontiguousarray(world.numpy())), P(np.ascontiguousarray(scales.numpy())), f(1.0),
+                          P(np.ascontiguousarray(quats.numpy())), P(np.ascontiguousarray(V.numpy())), f(sc["fx"]),
+                          f(sc["fy"]), W, H, f(0.01), P(np.ascontiguousarray(vx.numpy())),
+                          P(np.ascontiguousarray(vdp.numpy())), P(np.ascontiguousarray(vc.numpy())),
+                          P(np.ascontiguousarray(vcomp.numpy())), P(vm), P(vs), P(vq), P(vis))
+    both = vis_t.numpy() & (vis > 0)
+    assert both.sum() > 2000
+    for got, want in ((vm, md.grad.numpy()), (vs, sd.grad.numpy()), (vq, qd.grad.numpy())):
+        # (the kernel's constants are float32 values widened to double — focal length 204.8f, dilation 0.3f — where the
+        #  oracle holds the decimal ones: 1e-8 relative; the float32 chain is off by 1e-2 on these splats)
+        assert np.abs(got[both] - want[both]).max() <= 2e-7 * np.abs(want[both]).max()
+    # the float32 chain on the same splats, for scale: it is the reason the fix-up exists
+    vm32 = np.zeros((n, 3), np.float32); vs32 = np.zeros((n, 3), np.float32); vq32 = np.zeros((n, 4), np.float32)
+    vV32 = np.zeros(12, np.float32)
+    hm.hm_project_bwd(n, P(np.ascontiguousarray(world.numpy())), P(np.ascontiguousarray(scales.numpy())), f(1.0),
+                      P(np.ascontiguousarray(quats.numpy())), P(np.ascontiguousarray(V.numpy())), f(sc["fx"]), f(sc["fy"]),
+                      f(sc["cx"]), f(sc["cy"]), W, H, f(0.01), P(np.ascontiguousarray(vx.float().numpy())),
+                      P(np.ascontiguousarray(vdp.float().numpy())), P(np.ascontiguousarray(vc.float().numpy())),
+                      P(np.ascontiguousarray(vcomp.float().numpy())), P(vm32), P(vs32), P(vq32), P(vV32))
+    on = both & (prd.num_tiles_hit.numpy() > 0)
+    per_el = np.abs(vs32[on] - sd.grad.numpy()[on]) / (np.abs(sd.grad.numpy()[on]) + 1e-3 * np.abs(sd.grad.numpy()[on]).max())
+    print("float32 chain on needles: worst per-element error of d/d scale", float(per_el.max()))
+    assert per_el.max() > 1e-4
