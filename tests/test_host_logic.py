@@ -58,6 +58,72 @@ def test_camera_convention_opengl_to_opencv(gs):
     assert model._schedule(cam)[:2] == (1, 1)
 
 
+def test_data_velocities_reproduce_the_first_and_last_pose_of_the_exposure(gs, oracle):
+    """The reference DEFINES a frame's velocities from the first and last pose of its exposure
+    (/root/reference/process_synthetic_inputs.py:157-165: v_w = (p_last - p_first) / T, w_w = rotvec(R_last R_first^T) / T,
+    both rotated into the camera frame with R_w2c of the frame's pose; OpenGL axes, :230-256).  Fed through the model's
+    pose / velocity handling (OpenGL -> OpenCV flip of pose AND twist) and the screw interpolation the kernels use,
+    the sub-pose at -T/2 must land on the first pose and the one at +T/2 on the last — from a general pose, with
+    rotation about every axis.  Flipping the sign of either velocity, or skipping the axis flip, fails by an order of
+    magnitude: this pins the absolute frame and sign conventions against the reference's own definition, which no
+    self-consistent render test can."""
+    import math
+    O = oracle
+
+    def rotvec_to_R(w):
+        th = float(w.norm())
+        Kx = torch.tensor([[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]], dtype=torch.float64)
+        if th < 1e-12:
+            return torch.eye(3, dtype=torch.float64) + Kx
+        return torch.eye(3, dtype=torch.float64) + math.sin(th) / th * Kx + (1 - math.cos(th)) / th ** 2 * (Kx @ Kx)
+
+    def gl_c2w_to_cv_viewmat(c2w):
+        Rcv = c2w[:3, :3] * torch.tensor([1.0, -1.0, -1.0], dtype=torch.float64)[None, :]
+        V = torch.eye(4, dtype=torch.float64)
+        V[:3, :3] = Rcv.T
+        V[:3, 3] = -(Rcv.T @ c2w[:3, 3])
+        return V
+    T = 0.1
+    R_mid = rotvec_to_R(torch.tensor([0.4, -0.9, 0.3], dtype=torch.float64))        # a general OpenGL camera-to-world pose
+    p_mid = torch.tensor([1.0, -2.0, 0.5], dtype=torch.float64)
+    v_w = torch.tensor([0.8, -0.5, 0.6], dtype=torch.float64)                       # world frame, m/s
+    w_w = torch.tensor([0.7, 0.9, -0.5], dtype=torch.float64)                       # world frame, rad/s
+
+    def pose_at(t):
+        c = torch.eye(4, dtype=torch.float64)
+        c[:3, :3] = rotvec_to_R(w_w * t) @ R_mid
+        c[:3, 3] = p_mid + v_w * t
+        return c
+    first, last, mid = pose_at(-T / 2), pose_at(T / 2), pose_at(0.0)
+    # the reference's definition, restated
+    velocity_w = (last[:3, 3] - first[:3, 3]) / T
+    rot = last[:3, :3] @ first[:3, :3].T
+    ang_ = math.acos(max(-1.0, min(1.0, (float(rot.trace()) - 1) / 2)))
+    axis = torch.tensor([rot[2, 1] - rot[1, 2], rot[0, 2] - rot[2, 0], rot[1, 0] - rot[0, 1]], dtype=torch.float64) / (2 * math.sin(ang_))
+    ang_vel_w = axis * ang_ / T
+    R_w2c = mid[:3, :3].T
+    velocity_cam, ang_vel_cam = R_w2c @ velocity_w, R_w2c @ ang_vel_w
+    cfg = gs.SplatfactoDeblurConfig(background_color="black")
+    model = gs.SplatfactoDeblurModel(cfg, torch.zeros(4, 3), torch.zeros(4, 3), torch.ones(4, 4), torch.zeros(4),
+                                     torch.zeros(4, 3), torch.zeros(4, 15, 3))
+    cam = gs.Camera(mid[:3].float(), 100, 100, 32, 32, 64, 64,
+                    metadata=dict(camera_linear_velocity=velocity_cam.tolist(), camera_angular_velocity=ang_vel_cam.tolist(),
+                                  exposure_time=T, rolling_shutter_time=0.0))
+    V, lin, ang = model._viewmat_and_velocity(cam)
+    assert torch.allclose(V.double(), gl_c2w_to_cv_viewmat(mid), atol=1e-6)
+    want = torch.stack([gl_c2w_to_cv_viewmat(first), gl_c2w_to_cv_viewmat(last)])
+    span = float((want[1] - want[0]).abs().max())
+
+    def gap(l, a):
+        got = O.subpose_viewmats(V.double(), l.double(), a.double(), [-T / 2, T / 2])
+        return float((got - want).abs().max())
+    good = gap(lin, ang)
+    assert span > 0.05 and good < 0.05 * span, (good, span)           # second-order small against the motion itself
+    for l2, a2 in ((-lin, ang), (lin, -ang), (-lin, -ang), (lin * torch.tensor([1.0, -1.0, -1.0]), ang),
+                   (lin, ang * torch.tensor([1.0, -1.0, -1.0]))):
+        assert gap(l2, a2) > 5 * good, (gap(l2, a2), good)
+
+
 def test_shard_views_covers_every_view_once(gs):
     for world in (1, 2, 3, 8):
         got = sorted(i for r in range(world) for i in gs.dp.shard_views(8, r, world))
