@@ -25,8 +25,31 @@ def scene_arrays(sc):
     return {k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in sc.items()}
 
 
-def make_case(name, n, W, H, cfg_kw, seed, sh_degree=3, scale_mult=16.0):
+def posed(sc):
+    """the scene seen from a rotated and translated camera: world = R^T (camera - t), viewmat = [R | t]"""
+    import math
+
+    def rot(ax, a):
+        c, s_ = math.cos(a), math.sin(a)
+        Rm = torch.eye(3)
+        i, j = [(1, 2), (0, 2), (0, 1)][ax]
+        Rm[i, i] = c; Rm[j, j] = c; Rm[i, j] = -s_; Rm[j, i] = s_
+        return Rm
+    Rm = rot(1, 0.7) @ rot(0, -0.4) @ rot(2, 1.1)
+    t = torch.tensor([0.3, -0.2, 0.5])
+    out = dict(sc)
+    out["means"] = ((sc["means"] - t) @ Rm).contiguous()
+    V = torch.eye(4)
+    V[:3, :3], V[:3, 3] = Rm, t
+    out["viewmat"] = V
+    return out
+
+
+def make_case(name, n, W, H, cfg_kw, seed, sh_degree=3, scale_mult=16.0, from_a_real_pose=False, vel_mult=(1.0, 1.0)):
     sc = O.synthetic_scene(n, W, H, sh_degree=sh_degree, seed=seed, scale_mult=scale_mult)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * vel_mult[0], sc["ang_vel"] * vel_mult[1]
+    if from_a_real_pose:
+        sc = posed(sc)
     cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], sh_degree=sh_degree, **cfg_kw)
     names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel"]
     ps = {k: sc[k].double().requires_grad_(True) for k in names}
@@ -47,6 +70,7 @@ def make_case(name, n, W, H, cfg_kw, seed, sh_degree=3, scale_mult=16.0):
     d.update(
         cfg=np.array([H, W, cfg.blur_samples, cfg.rs_bands, sh_degree], dtype=np.int64),
         cfg_f=np.array([cfg.exposure_time, cfg.rolling_shutter_time, cfg.gamma, cfg.min_rgb_level], dtype=np.float64),
+        cfg_model=np.array([int(cfg.motion_model == "pixel_velocity"), int(bool(cfg.rs_exact))], dtype=np.int64),
         background=bg.numpy(), weights=wt.numpy(), fragile=frag.numpy(),
         out=out.detach().numpy(), alpha=alpha.detach().numpy(), samples=samples.detach().numpy(),
         viewmats=vms.detach().numpy(),
@@ -139,6 +163,12 @@ if __name__ == "__main__":
         make_case("blur_rs_small", 500, 80, 64,
                   dict(blur_samples=3, rs_bands=2, exposure_time=1 / 60, rolling_shutter_time=1 / 30, gamma=2.2,
                        min_rgb_level=10.0), seed=12)
+    if only in (None, "pixvel"):
+        # round 3: the paper's pixel-velocity model with EXACT per-row rolling shutter, from a real camera pose
+        make_case("pixvel_exact_rs_posed_small", 500, 80, 64,
+                  dict(blur_samples=3, rs_bands=1, exposure_time=1 / 60, rolling_shutter_time=1 / 30, gamma=2.2,
+                       min_rgb_level=10.0, motion_model="pixel_velocity", rs_exact=True), seed=14,
+                  from_a_real_pose=True, vel_mult=(20.0, 10.0))
     if only in (None, "large"):
         make_large_case("blur_large", 24000, 640, 368,
                         dict(blur_samples=5, rs_bands=1, exposure_time=1 / 60, rolling_shutter_time=0.0, gamma=2.2,

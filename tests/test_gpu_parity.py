@@ -438,6 +438,36 @@ def test_fused_path_matches_golden(gs, dev, name):
     assert rel_max(p["viewmat"].grad.cpu()[:3], d["g_viewmat"][:3]) < GRAD_RTOL
 
 
+def test_pixel_velocity_exact_rolling_shutter_matches_golden(gs, dev):
+    """tests/golden/pixvel_exact_rs_posed_small.npz (round 3): the paper's pixel-velocity model with exact per-row
+    rolling shutter, three blur samples, seen from a rotated and translated camera — committed float64 oracle numbers:
+    sample images, averaged image, alpha and every gradient (Gaussians, viewmat, twist)."""
+    d = np.load(GOLD / "pixvel_exact_rs_posed_small.npz")
+    H, W, S, R, deg = (int(v) for v in d["cfg"])
+    et, rt, gamma, mlevel = (float(v) for v in d["cfg_f"])
+    assert [int(v) for v in d["cfg_model"]] == [1, 1] and R == 1
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel", "viewmat"]
+    p = {k: torch.from_numpy(d[k]).float().to(dev).requires_grad_(True) for k in names}
+    times, _, _ = gs.subpose_schedule(S, et, 1, 0.0)
+    samples, alphas, radii = gs.render_subposes(p["means"], p["log_scales"].exp(), p["quats"],
+                                                torch.sigmoid(p["opacity_logits"]), p["sh"], p["viewmat"],
+                                                torch.from_numpy(d["background"]).float().to(dev), S, 1, float(d["fx"]),
+                                                float(d["fy"]), float(d["cx"]), float(d["cy"]), H, W, sh_degree=deg,
+                                                lin_vel=p["lin_vel"], ang_vel=p["ang_vel"],
+                                                times=torch.tensor(times, device=dev), rolling_shutter_time=rt)
+    out = gs.combine_samples(samples, gamma, mlevel)
+    (out * torch.from_numpy(d["weights"]).float().to(dev)).sum().backward()
+    good = ~d["fragile"]
+    assert good.mean() > 0.9
+    assert np.abs(samples.detach().cpu().numpy() - d["samples"])[:, good].max() < IMG_ATOL
+    assert np.abs(out.detach().cpu().numpy() - d["out"])[good].max() < 5e-4
+    assert np.abs(alphas.mean(0).detach().cpu().numpy() - d["alpha"])[good].max() < IMG_ATOL
+    for k in names[:-1]:
+        assert rel_max(p[k].grad.cpu(), d["g_" + k]) < GRAD_RTOL, k
+    assert rel_max(p["viewmat"].grad.cpu()[:3], d["g_viewmat"][:3]) < GRAD_RTOL
+    assert float(np.abs(d["g_ang_vel"]).max()) > 0 and float(np.abs(d["g_viewmat"]).max()) > 0
+
+
 def test_fused_path_matches_large_golden(gs, dev):
     """24k Gaussians, 640x368, 5 motion-blur sub-poses, SH degree 3, gamma 2.2 (tests/golden/blur_large.npz, float64
     oracle, generated one sub-pose at a time): image / alpha / first sample on the non-fragile pixels, every gradient

@@ -204,16 +204,17 @@ def test_binning_consistency(oracle):
         assert (np.diff(d) >= 0).all()
 
 
-@pytest.mark.parametrize("name", ["static_small", "blur_rs_small"])
+@pytest.mark.parametrize("name", ["static_small", "blur_rs_small", "pixvel_exact_rs_posed_small"])
 def test_oracle_matches_committed_golden(oracle, name):
     """The oracle reproduces the committed fixtures (guards against silent drift of the checker)."""
     O = oracle
     d = np.load(GOLD / f"{name}.npz")
     H, W, S, R, deg = (int(v) for v in d["cfg"])
     et, rt, gamma, mlevel = (float(v) for v in d["cfg_f"])
+    pixvel, exact = (int(v) for v in d["cfg_model"]) if "cfg_model" in d.files else (0, 0)
     cfg = O.RenderConfig(H, W, float(d["fx"]), float(d["fy"]), float(d["cx"]), float(d["cy"]), sh_degree=deg,
                          blur_samples=S, rs_bands=R, exposure_time=et, rolling_shutter_time=rt, gamma=gamma,
-                         min_rgb_level=mlevel)
+                         min_rgb_level=mlevel, motion_model="pixel_velocity" if pixvel else "se3", rs_exact=bool(exact))
     t = lambda k: torch.from_numpy(d[k]).double()
     out, alpha = O.render(cfg, t("means"), t("log_scales").exp(), t("quats"), torch.sigmoid(t("opacity_logits")),
                           t("sh"), t("viewmat"), t("lin_vel"), t("ang_vel"), background=t("background"))
