@@ -159,7 +159,8 @@ for trial in range(trials):
     if with_oracle:
         cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], blur_samples=S, rs_bands=R,
                              exposure_time=1 / 60, rolling_shutter_time=1 / 30, gamma=gamma, min_rgb_level=mlevel,
-                             sh_degree=deg, antialiased=aa)
+                             sh_degree=deg, antialiased=aa, motion_model="pixel_velocity" if pixvel else "se3",
+                             rs_exact=bool(rs_time))
         q = {k: sc_cpu[k].double().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
         ref, ref_a, _, frag, _, _ = O.render(cfg, q["means"], q["log_scales"].exp(), q["quats"],
                                              torch.sigmoid(q["opacity_logits"]), q["sh"], sc_cpu["viewmat"].double(),
