@@ -22,6 +22,7 @@ from torch.autograd import Function
 from . import _lib
 
 import os
+import threading
 
 TILE = 16
 REC = 12  # floats per rasterizer record
@@ -540,10 +541,13 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
         I0 = max(1, slice_base) * tx * ty * P
         nbytes = 40 * n + 16 * S * H * W + 80 * I0 + (64 << 20)
     arena = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-    pin = _pinned_cache.get(str(dev))
+    # the read-back buffer is written by the GPU while gs_frame_forward polls it (ctypes releases the GIL for the call):
+    # one per device, host thread and stream, so that concurrent frames never share it
+    pin_key = (str(dev), threading.get_ident(), torch.cuda.current_stream().cuda_stream)
+    pin = _pinned_cache.get(pin_key)
     need_pin = 4 * (2 * P * 16 + 2 * P + 2) + 64
     if pin is None or pin.numel() < need_pin:
-        pin = _pinned_cache[str(dev)] = torch.empty(max(8192, need_pin), dtype=torch.uint8, pin_memory=True)
+        pin = _pinned_cache[pin_key] = torch.empty(max(8192, need_pin), dtype=torch.uint8, pin_memory=True)
     desc = _FrameDesc(N, P, S, R, H, W, int(slice_base), DEPTH_SORT_DIGIT, RASTER_FWD_VARIANT, int(reserve_backward),
                       float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0, int(FRAME_POLL))
     state = _FrameState()
