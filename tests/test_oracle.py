@@ -412,7 +412,8 @@ def test_vectorised_oracle_equals_independent_pixel_loop(oracle, seed, n, H, W, 
         assert np.array_equal(bu["v_colors"], b["v_colors"])
 
 
-def test_exact_rolling_shutter_is_the_limit_of_row_bands_and_differentiable(oracle):
+@pytest.mark.parametrize("real_pose", [False, True])
+def test_exact_rolling_shutter_is_the_limit_of_row_bands_and_differentiable(oracle, real_pose):
     """VERDICT round 2 'Missing 1': the continuous per-row rolling shutter of the pixel-velocity model
     (RenderConfig.rs_exact; SURVEY App. A 'row time (y/H - 1/2) T_ro').  Known answers:
       * zero readout time -> exactly the render without rolling shutter;
@@ -425,6 +426,8 @@ def test_exact_rolling_shutter_is_the_limit_of_row_bands_and_differentiable(orac
     sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 40, sc["ang_vel"] * 25          # ~10 px of readout motion
     sc["sh"][:, 1:] = 0.0            # view-independent colour: the oracle (like splatfacto) detaches the view direction,
     #                                  a finite difference of a mean would see that dependence
+    if real_pose:                    # (round 3) the same known answers from a rotated and translated camera
+        sc = _posed(sc, O)
     kw = dict(blur_samples=2, exposure_time=1 / 60, gamma=2.2, min_rgb_level=10.0, motion_model="pixel_velocity")
     base = _cfg(O, sc, H, W, rs_bands=1, rolling_shutter_time=0.0, **kw)
     exact0 = _cfg(O, sc, H, W, rs_bands=1, rolling_shutter_time=0.0, rs_exact=True, **kw)
