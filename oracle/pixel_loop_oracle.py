@@ -50,8 +50,10 @@ def tile_lists_by_brute_force(tile_min: np.ndarray, tile_max: np.ndarray, depths
 
 def composite_pixel_loop(xys: np.ndarray, conics: np.ndarray, colors: np.ndarray, opacities: np.ndarray,
                          ids_sorted: np.ndarray, tile_bins: np.ndarray, img_height: int, img_width: int,
-                         background: Optional[Sequence[float]] = None) -> Dict[str, np.ndarray]:
-    """App. A "Blend", one pixel at a time.  -> {'img' [H,W,3], 'final_T' [H,W], 'final_idx' [H,W] int32,
+                         background: Optional[Sequence[float]] = None, pix_vel: Optional[np.ndarray] = None,
+                         row_time: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
+    """App. A "Blend", one pixel at a time.  pix_vel [N,2] + row_time [H] (both or neither): the exact per-row rolling
+    shutter of the paper's model, App. A "plus row time" — pixel row i sees every splat at xy + row_time[i] * pix_vel.  -> {'img' [H,W,3], 'final_T' [H,W], 'final_idx' [H,W] int32,
     'stops': pixels that hit the transmittance stop}.
     final_idx is ONE PAST the last blended list position (the tile's list start when nothing was blended)."""
     H, W = img_height, img_width
@@ -68,10 +70,14 @@ def composite_pixel_loop(xys: np.ndarray, conics: np.ndarray, colors: np.ndarray
             T = 1.0
             C = [0.0, 0.0, 0.0]
             last = start
+            tau = 0.0 if row_time is None else float(row_time[i])
             for k in range(start, end):
                 g = int(ids_sorted[k])
                 dx = float(xys[g, 0]) - px
                 dy = float(xys[g, 1]) - py
+                if pix_vel is not None:
+                    dx += tau * float(pix_vel[g, 0])
+                    dy += tau * float(pix_vel[g, 1])
                 sigma = (0.5 * (float(conics[g, 0]) * dx * dx + float(conics[g, 2]) * dy * dy)
                          + float(conics[g, 1]) * dx * dy)
                 if sigma < 0.0:
@@ -100,7 +106,8 @@ def composite_backward_pixel_loop(xys: np.ndarray, conics: np.ndarray, colors: n
                                   fwd: Dict[str, np.ndarray], v_img: np.ndarray,
                                   v_alpha: Optional[np.ndarray] = None,
                                   background: Optional[Sequence[float]] = None,
-                                  clamp_blocks_gradient: bool = True) -> Dict[str, np.ndarray]:
+                                  clamp_blocks_gradient: bool = True, pix_vel: Optional[np.ndarray] = None,
+                                  row_time: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
     """App. A "Backward": every pixel walks its list from final_idx back to the tile start.
     With T = transmittance in front of the Gaussian, S = colour accumulated BEHIND it, ra = 1/(1-alpha):
         v_rgb += alpha*T * v_C
@@ -108,12 +115,15 @@ def composite_backward_pixel_loop(xys: np.ndarray, conics: np.ndarray, colors: n
         v_sigma = -o*e^{-sigma} * v_alpha_i,  v_o = e^{-sigma} * v_alpha_i   (zero through an ACTIVE 0.999 clamp when
         clamp_blocks_gradient, the true derivative — this repo's default; upstream lets it pass)
         v_conic = (0.5 v_sigma dx^2, v_sigma dx dy, 0.5 v_sigma dy^2),  v_xy = v_sigma * (cx dx + cy dy, cy dx + cz dy)
+    With pix_vel / row_time (exact rolling shutter) the centre a pixel of row i sees is xy + row_time[i] * pix_vel, so
+    v_pix_vel = sum over its pixels of row_time[i] * (that pixel's v_xy contribution): returned as 'v_pix_vel' [N,2].
     -> {'v_xy' [N,2], 'v_conic' [N,3], 'v_colors' [N,3], 'v_opacity' [N]} (image-plane alpha output = 1 - final_T)."""
     H, W = img_height, img_width
     tiles_x = (W + _BLOCK - 1) // _BLOCK
     bg = (0.0, 0.0, 0.0) if background is None else tuple(float(b) for b in background)
     N = xys.shape[0]
     v_xy = np.zeros((N, 2)); v_conic = np.zeros((N, 3)); v_colors = np.zeros((N, 3)); v_opacity = np.zeros(N)
+    v_pv = np.zeros((N, 2))
     for i in range(H):
         for j in range(W):
             start, _ = (int(v) for v in tile_bins[(i // _BLOCK) * tiles_x + (j // _BLOCK)])
@@ -124,10 +134,14 @@ def composite_backward_pixel_loop(xys: np.ndarray, conics: np.ndarray, colors: n
             va_out = 0.0 if v_alpha is None else float(v_alpha[i, j])
             T = T_final
             S = [0.0, 0.0, 0.0]
+            tau = 0.0 if row_time is None else float(row_time[i])
             for k in range(int(fwd["final_idx"][i, j]) - 1, start - 1, -1):
                 g = int(ids_sorted[k])
                 dx = float(xys[g, 0]) - px
                 dy = float(xys[g, 1]) - py
+                if pix_vel is not None:
+                    dx += tau * float(pix_vel[g, 0])
+                    dy += tau * float(pix_vel[g, 1])
                 cx_, cy_, cz_ = float(conics[g, 0]), float(conics[g, 1]), float(conics[g, 2])
                 sigma = 0.5 * (cx_ * dx * dx + cz_ * dy * dy) + cy_ * dx * dy
                 if sigma < 0.0:
@@ -153,6 +167,9 @@ def composite_backward_pixel_loop(xys: np.ndarray, conics: np.ndarray, colors: n
                 v_conic[g, 0] += 0.5 * v_sigma * dx * dx
                 v_conic[g, 1] += v_sigma * dx * dy
                 v_conic[g, 2] += 0.5 * v_sigma * dy * dy
-                v_xy[g, 0] += v_sigma * (cx_ * dx + cy_ * dy)
-                v_xy[g, 1] += v_sigma * (cy_ * dx + cz_ * dy)
-    return {"v_xy": v_xy, "v_conic": v_conic, "v_colors": v_colors, "v_opacity": v_opacity}
+                gx, gy = v_sigma * (cx_ * dx + cy_ * dy), v_sigma * (cy_ * dx + cz_ * dy)
+                v_xy[g, 0] += gx
+                v_xy[g, 1] += gy
+                v_pv[g, 0] += tau * gx
+                v_pv[g, 1] += tau * gy
+    return {"v_xy": v_xy, "v_conic": v_conic, "v_colors": v_colors, "v_opacity": v_opacity, "v_pix_vel": v_pv}

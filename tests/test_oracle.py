@@ -412,6 +412,50 @@ def test_vectorised_oracle_equals_independent_pixel_loop(oracle, seed, n, H, W, 
         assert np.array_equal(bu["v_colors"], b["v_colors"])
 
 
+def test_exact_rolling_shutter_compositing_equals_independent_pixel_loop(oracle):
+    """round 3: the per-row centre shift of the exact rolling-shutter mode (`rasterize_sorted(row_shift=...)`, what
+    raster_rs.hip is held against) against the independent per-pixel loop with the same shift written out literally —
+    image, final T, final index, and the gradients to xy, conic, colour, opacity AND pixel velocity (the loop's
+    hand-derived v_pix_vel = sum over pixels of tau(row) * v_xy)."""
+    O, PL = oracle, _pixel_loop()
+    H, W, n, seed = 40, 56, 100, 8
+    sc = O.synthetic_scene(n, W, H, seed=seed, dtype=torch.float64, scale_mult=20.0)
+    sc["opacity_logits"] = sc["opacity_logits"] + 1.5
+    pr = O.project_gaussians(sc["means"], sc["log_scales"].exp(), 1.0, sc["quats"], sc["viewmat"], sc["fx"], sc["fy"],
+                             sc["cx"], sc["cy"], H, W, keep_offscreen=True)
+    g = torch.Generator().manual_seed(seed)
+    colors = torch.rand(n, 3, generator=g, dtype=torch.float64)
+    opac = torch.sigmoid(sc["opacity_logits"])
+    bg = torch.tensor([0.3, 0.1, 0.6], dtype=torch.float64)
+    pv = (torch.rand(n, 2, generator=g, dtype=torch.float64) - 0.5) * 600.0             # px / s
+    T_ro = 1 / 30
+    tau = ((torch.arange(H, dtype=torch.float64) + 0.5) / H - 0.5) * T_ro
+    prs = O._bounds_swept(pr, pr.xys.detach(), pv, 0.5 * T_ro, H, W)                     # swept tile boxes
+    keys, gids = O.sort_intersects(*O.map_gaussian_to_intersects(prs, W))
+    Tn = ((W + 15) // 16) * ((H + 15) // 16)
+    bins = O.get_tile_bin_edges(keys, Tn)
+    leaves = [t.clone().requires_grad_(True) for t in (pr.xys.detach(), pr.conics.detach(), colors, opac, pv)]
+    r = O.rasterize_sorted(leaves[0], leaves[1], leaves[2], leaves[3], gids, bins, H, W, bg, row_shift=(leaves[4], tau))
+    xys, conics = pr.xys.detach().numpy(), pr.conics.detach().numpy()
+    f = PL.composite_pixel_loop(xys, conics, colors.numpy(), opac.numpy(), gids, bins, H, W, bg.tolist(),
+                                pix_vel=pv.numpy(), row_time=tau.numpy())
+    still = PL.composite_pixel_loop(xys, conics, colors.numpy(), opac.numpy(), gids, bins, H, W, bg.tolist())
+    assert np.abs(f["img"] - still["img"]).max() > 0.05                  # the shift really moves things
+    assert np.array_equal(f["final_idx"], r.final_idx.numpy())
+    assert np.abs(f["img"] - r.img.detach().numpy()).max() < 1e-13
+    assert np.abs(f["final_T"] - r.final_T.detach().numpy()).max() < 1e-13
+    v_img = torch.rand(H, W, 3, generator=g, dtype=torch.float64) - 0.3
+    v_alpha = torch.rand(H, W, generator=g, dtype=torch.float64) - 0.5
+    ((r.img * v_img).sum() + (r.alpha * v_alpha).sum()).backward()
+    b = PL.composite_backward_pixel_loop(xys, conics, colors.numpy(), opac.numpy(), gids, bins, H, W, f, v_img.numpy(),
+                                         v_alpha.numpy(), bg.tolist(), clamp_blocks_gradient=True, pix_vel=pv.numpy(),
+                                         row_time=tau.numpy())
+    for name, leaf in zip(("v_xy", "v_conic", "v_colors", "v_opacity", "v_pix_vel"), leaves):
+        want = leaf.grad.numpy().reshape(b[name].shape)
+        assert np.abs(want).max() > 0, name
+        assert np.abs(b[name] - want).max() <= 1e-11 * max(1.0, np.abs(want).max()), name
+
+
 @pytest.mark.parametrize("real_pose", [False, True])
 def test_exact_rolling_shutter_is_the_limit_of_row_bands_and_differentiable(oracle, real_pose):
     """VERDICT round 2 'Missing 1': the continuous per-row rolling shutter of the pixel-velocity model
