@@ -62,7 +62,7 @@ _SIGS = {
     "gs_rasterize_bwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P,
                                _I, _P, _F, _F, _P],
     "gs_rasterize_fwd_slice_stats": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
-    "gs_reduce_grad_tuples": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P],
+    "gs_reduce_grad_tuples": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "gs_combine_fwd": [_I, _L, _P, _F, _F, _P, _P],
     "gs_combine_bwd": [_I, _L, _P, _F, _F, _P, _P, _P, _P],
     "gs_combine_bwd_scale": [_I, _L, _F, _P, _P, _P, _P],

@@ -592,7 +592,7 @@ GS_EXPORT int gs_frame_backward(const gs_frame_state* state, const float* record
       CHECK(gs_reduce_grad_tuples(sl.n, reinterpret_cast<const unsigned*>(base + sl.slice_gi),
                                   reinterpret_cast<const unsigned*>(base + sl.counts),
                                   reinterpret_cast<const unsigned*>(base + sl.cum), tuples, flags, v_records, touched,
-                                  sl.wave_per_gaussian ? sl.I : 0, st));
+                                  sl.wave_per_gaussian ? sl.I : 0, records, st));
     }
   }
   return GS_OK;

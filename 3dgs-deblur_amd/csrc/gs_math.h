@@ -43,11 +43,21 @@ struct K {
   static constexpr int   kTile       = 16;      // block_width
 };
 
-// Per-Gaussian projected record consumed by the rasterizer: 12 floats = 48 B,
-// three 16-byte loads per gather.
+// Per-Gaussian projected record consumed by the rasterizer: 16 floats = 64 B (one cache line, four 16-byte
+// loads per gather; the compositors fetch dwords 0..8(9) and 12..15 through the scalar cache).
 //   [0] x  [1] y  [2] conic.x  [3] conic.y | [4] conic.z [5] opacity [6] r [7] g |
-//   [8] b  [9] depth [10] radius(int bits) [11] tiles(int bits)
-constexpr int kRecFloats = 12;
+//   [8] b  [9] depth [10] tile box min (x | y<<16) [11] tile box max | [12] nmid [13] kmul [14] qx [15] qz
+// [12..15] are the compositors' per-entry constants (round 4), functions of [2],[4],[5] alone (rec_aux below):
+// with s2 = -log2(e) * sigma (sigma = the conic form of the pixel offset) the blend needs
+//   alpha = op * 2^s2   and the test   sigma >= 0  and  alpha >= 1/255   <=>   -log2(255 op) <= s2 <= 0 .
+// The interval is made symmetric: nmid = log2(255 op) / 2, u = s2 + nmid, and the test is ONE compare |u| <= nmid
+// (absolute value is a free source modifier), alpha = kmul * 2^u with kmul = op * 2^-nmid = sqrt(op / 255).
+// An opacity below 1/255 gives nmid < 0: never valid.  qx, qz = conic.x, conic.z pre-scaled by -log2(e) / 2.
+constexpr int kRecFloats = 16;
+// gradient records / gradient tuples keep 12 floats (x y conic3 opacity rgb | two pixel-velocity slots | pad)
+constexpr int kGradFloats = 12;
+constexpr int kRecNmid = 12, kRecKmul = 13, kRecQx = 14, kRecQz = 15;
+constexpr float kNegLog2e = -1.4426950408889634f;
 
 struct Proj {
   float x, y, depth;
@@ -58,6 +68,16 @@ struct Proj {
   int   ntiles;
   float cov3d[6];
 };
+
+// the compositors' per-entry constants of a record, see the layout above
+GS_HD void rec_aux(float op, float conic_x, float conic_z, float out[4]) {
+  float nmid = -1.0f, kmul = 0.0f;
+  if (op >= K::kAlphaMin) {              // (NaN and op < 1/255: never blended)
+    nmid = 0.5f * log2f(255.0f * op);
+    kmul = op * exp2f(-nmid);
+  }
+  out[0] = nmid; out[1] = kmul; out[2] = conic_x * (0.5f * kNegLog2e); out[3] = conic_z * (0.5f * kNegLog2e);
+}
 
 // normalised quaternion (w,x,y,z) -> rotation matrix, row-major R[9]
 GS_HD void quat_to_rotmat(const float q[4], float R[9], float qn[4], float* inv_norm) {

@@ -213,8 +213,11 @@ __global__ __launch_bounds__(256) void pack_records_kernel(int N, const float* _
     r[0] = make_float4(x, y, conics[3 * i], conics[3 * i + 1]);
     r[1] = make_float4(conics[3 * i + 2], opacity[i], colors[3 * i], colors[3 * i + 1]);
     r[2] = make_float4(colors[3 * i + 2], d, __int_as_float(x0 | (y0 << 16)), __int_as_float(x1 | (y1 << 16)));
+    float aux[4];
+    rec_aux(opacity[i], conics[3 * i], conics[3 * i + 2], aux);
+    r[3] = make_float4(aux[0], aux[1], aux[2], aux[3]);
   } else {
-    r[0] = make_float4(0.f, 0.f, 0.f, 0.f); r[1] = r[0]; r[2] = r[0];
+    r[0] = make_float4(0.f, 0.f, 0.f, 0.f); r[1] = r[0]; r[2] = r[0]; r[3] = r[0];
   }
   depth_keys[i] = ok ? (unsigned)__float_as_int(d) : 0xFFFFFFFFu;
   ntiles[i] = ok ? area : 0;
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int N, const float* _
     float* __restrict__ v_opacity) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  const float4* r = reinterpret_cast<const float4*>(v_records + (size_t)i * kRecFloats);
+  const float4* r = reinterpret_cast<const float4*>(v_records + (size_t)i * kGradFloats);
   float4 a = r[0], b = r[1], c = r[2];
   v_xys[2 * i] = a.x; v_xys[2 * i + 1] = a.y;
   v_conics[3 * i] = a.z; v_conics[3 * i + 1] = a.w; v_conics[3 * i + 2] = b.x;
@@ -363,11 +366,14 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
       r[1] = make_float4(o.conic_z, op, cr, cg);
       r[2] = make_float4(cb, o.depth, __int_as_float(o.tmin_x | (o.tmin_y << 16)),
                          __int_as_float(o.tmax_x | (o.tmax_y << 16)));
+      float aux[4];
+      rec_aux(op, o.conic_x, o.conic_z, aux);
+      r[3] = make_float4(aux[0], aux[1], aux[2], aux[3]);
     } else if (!fp.skip_culled) {
       // (three of four pairs in the benchmark scene: 48 bytes each that nothing reads once the depth pre-sort
       //  drops culled Gaussians — the caller says so with defer_color bit 1)
       float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      r[0] = z; r[1] = z; r[2] = z;
+      r[0] = z; r[1] = z; r[2] = z; r[3] = z;
     }
     depth_keys[idx] = ok ? (unsigned)__float_as_int(o.depth) : 0xFFFFFFFFu;
     ntiles[idx] = ok ? o.ntiles : 0;
@@ -424,7 +430,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
           if (touched && !touched[(size_t)p * fp.N + ii]) continue;
           const float tau = fp.times[p];
           size_t idx = (size_t)p * fp.N + ii;
-          const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kRecFloats);
+          const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kGradFloats);
           float4 ga = g4[0], gb = g4[1], gc = g4[2];
           const float4* r4 = reinterpret_cast<const float4*>(records + idx * kRecFloats);
           float4 ra = r4[0], rb = r4[1], rc = r4[2];
@@ -480,7 +486,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
                             fp.in.tiles_y, fp.in.clip, o, k);
       if (ok) {
         size_t idx = (size_t)p * fp.N + ii;
-        const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kRecFloats);
+        const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kGradFloats);
         float4 ga = g4[0], gb = g4[1], gc = g4[2];
         const float4* r4 = reinterpret_cast<const float4*>(records + idx * kRecFloats);
         float4 rb = r4[1], rc = r4[2];
@@ -566,7 +572,7 @@ __device__ __forceinline__ void needle_item_se3(const FusedParams& fp, const flo
   kd.clamp_x = k.clamp_x; kd.clamp_y = k.clamp_y;
   const double comp = ::sqrt(fmax(0.0, kd.det0 / kd.det));
   const size_t idx = (size_t)p * fp.N + i;
-  const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kRecFloats);
+  const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kGradFloats);
   const float4 ga = g4[0], gb = g4[1];
   const double vxy[2] = {ga.x, ga.y}, vcon[3] = {ga.z, ga.w, gb.x};
   const double v_comp = fp.antialiased ? (double)gb.y * (double)fp.opacities[i] : 0.0;
@@ -607,7 +613,7 @@ __device__ __forceinline__ void needle_item_pixvel(const FusedParams& fp, const 
   for (int p = 0; p < fp.P; ++p) {
     if (touched && !touched[(size_t)p * fp.N + i]) continue;
     const size_t idx = (size_t)p * fp.N + i;
-    const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kRecFloats);
+    const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kGradFloats);
     const float4 ga = g4[0], gb = g4[1], gc = g4[2];
     const float4* r4 = reinterpret_cast<const float4*>(records + idx * kRecFloats);
     const float4 ra = r4[0], rb = r4[1];

@@ -205,33 +205,46 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
 }
 
 // ---------------------------------------------------------------------------
-// Forward compositor, scalar-cache variant (round 2).  tools/valu_bench.hip measured what the instructions of the
-// v_readlane kernel above cost on gfx950 (cycles per wave-instruction per SIMD, 4 waves/SIMD): v_fma/v_mul with VGPR
-// operands 1.9, the same with an SGPR operand / v_pk_* / v_min / v_cndmask 3.2, v_cmp -> SGPR 4.0, v_exp 6.3,
-// **v_readlane_b32 7.9** — the 9 broadcasts per list entry were a quarter of that kernel's issue time.  Here the
-// wave fetches each entry's record with SCALAR loads (s_load_dwordx8 + s_load_dword off the wave-uniform record
-// index): no VGPR gather, no v_readlane, no VALU slot at all.  The list is walked in aligned groups of four entries
-// (one s_load_dwordx4 of record indices per group); two register sets of two records each: while one pair is
-// blended the loads of the other are in flight (SMEM returns out of order, so every wait is lgkmcnt(0): the
-// `asm volatile` fences pin "wait for the pair, THEN issue the next loads, then blend").  The four pixels of a
-// lane are two hand-packed float2 pairs (v_pk_add/fma/mul_f32); a stopped pixel keeps its final transmittance as a
-// NEGATIVE T (one state register and one select less per pixel than the Tf/Tk pair above).  Arithmetic is
-// term-for-term that of raster_fwd_slice_kernel (same fma placement): images are bit-identical (tested).
+// Forward compositor, scalar-cache variant (round 2; inner loop rewritten in round 4).  tools/valu_bench*.hip measured
+// what instructions cost on gfx950 (wall ns per wave-instruction and SIMD at 4 waves): plain mul / add / mov / int 1.15,
+// v_fma 1.36, v_pk_*_f32 2.15, **v_cmp / v_cndmask / v_min / v_max / any SGPR operand 1.9-2.0**, v_exp / v_rcp 3.8,
+// **v_readlane_b32 4.6**.  So:
+//   * the wave fetches each entry's record with SCALAR loads (s_load_dwordx8 + x2 + x4 off the wave-uniform record
+//     index): no VGPR gather, no v_readlane, no VALU slot at all.  The list is walked in aligned groups of four
+//     entries (one s_load_dwordx4 of record indices per group); two register sets of two records each: while one pair
+//     is blended the loads of the other are in flight (SMEM returns out of order, so every wait is lgkmcnt(0): the
+//     `asm volatile` fences pin "wait for the pair, THEN issue the next loads, then blend");
+//   * the four pixels of a lane are two hand-packed float2 pairs (v_pk_add/fma/mul_f32);
+//   * round 4 — compares and selects were half of the loop's issue time (profiles/r03_valu_mix.txt: 3 compares and 4
+//     selects per pixel and entry).  Now ONE compare decides `sigma >= 0 and alpha >= 1/255` (|u| <= nmid on the
+//     shifted exponent u = s2 + nmid, constants from the record, gs_math.h rec_aux), alpha = kmul * 2^u needs no
+//     separate opacity product, the transmittance update is T -= w (w already gated), and everything a STOPPING
+//     pixel needs — its stop index and its removal from the walk — happens in a wave-uniform branch that only runs
+//     for entries at which some pixel of the tile stops: a stopped pixel's row coordinate becomes NaN, so it fails
+//     the one compare for the rest of the list without any per-entry bookkeeping.  Per pixel and entry: 2 compares,
+//     1 select (was 3 + 4).  final_idx now holds, per pixel, the list position at which it stopped (exclusive end of
+//     its contributing entries), or the end of the tile's list when it never did: the backward re-tests validity
+//     per entry anyway, so `idx < final_idx and valid` selects exactly the entries that were blended.
+// Arithmetic differs from the round-1 kernel (raster_fwd_slice_kernel) in rounding only: the exponent carries the
+// shift nmid (|nmid| <= 4: 2.4e-7 absolute on u, 1.7e-7 relative on alpha) and T(1 - alpha) is T - alpha T.
 // ---------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-struct RecS { float x, y, cx, cy, cz, op, r, g, b, d; };
+struct RecS { float x, y, cy, r, g, b, d, nmid, kmul, qx, qz; };
 
 template <bool DEPTH>
 __device__ __forceinline__ RecS load_rec_s(const float* __restrict__ records, unsigned gi) {
   const float* p = records + (size_t)gi * kRecFloats;
   RecS o;
-  o.x = p[0]; o.y = p[1]; o.cx = p[2]; o.cy = p[3]; o.cz = p[4]; o.op = p[5]; o.r = p[6]; o.g = p[7]; o.b = p[8];
+  o.x = p[0]; o.y = p[1]; o.cy = p[3]; o.r = p[6]; o.g = p[7]; o.b = p[8];
   o.d = DEPTH ? p[9] : 0.f;             // camera-space depth of the splat (record float 9)
+  o.nmid = p[kRecNmid]; o.kmul = p[kRecKmul]; o.qx = p[kRecQx]; o.qz = p[kRecQz];
   return o;
 }
 
-struct PixPair { f2 T, Cr, Cg, Cb, Cd, py; int last0, last1; };
+// py: pixel-centre row coordinate, NaN once the pixel has stopped (or lies outside the image); T: transmittance
+// (of a stopped pixel: its final value); fin: see above
+struct PixPair { f2 T, Cr, Cg, Cb, Cd, py; };
 
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -239,46 +252,66 @@ __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementw
 // tile_hot), so alpha = op * exp(..) <= op can never reach the clamp on a pixel that is blended (those have
 // s2 <= 0): min(0.999, .) is the identity there and is not issued.  The choice is made once per tile, outside the
 // loop: a per-entry branch costs more in merge copies than the two v_min it saves (measured, round 2 run 22).
-// core of one (entry, lane) blend on PRE-SCALED conic terms q = {0.5 * -log2e * cx, -log2e * cy, 0.5 * -log2e * cz}
 template <bool DEPTH, bool CLAMP>
-__device__ __forceinline__ void blend_core(float gx, float gy, float qx, float qy, float qz, float op, float cr, float cg,
-                                           float cb, float cd, float pxf, int idx1, PixPair (&pp)[2]) {
-  const float dx = gx - pxf;
-  const float hx = qx * dx * dx;
-  const float bx = qy * dx;
-  const f2 hx2 = {hx, hx}, bx2 = {bx, bx}, qz2 = {qz, qz}, gy2 = {gy, gy}, op2 = {op, op};
-  const f2 cr2 = {cr, cr}, cg2 = {cg, cg}, cb2 = {cb, cb};
+__device__ __forceinline__ void blend_entry(const RecS& rc, float pxf, int idx, PixPair (&pp)[2], int* __restrict__ fin_out,
+                                            unsigned fin_off, unsigned fin_row) {
+  const float dx = rc.x - pxf;
+  const float hxm = fmaf(rc.qx * dx, dx, rc.nmid);          // exponent terms, pre-scaled by -log2(e), + the shift
+  const float bx = (rc.cy * kNegLog2e) * dx;
+  const f2 hx2 = {hxm, hxm}, bx2 = {bx, bx}, qz2 = {rc.qz, rc.qz}, gy2 = {rc.y, rc.y}, km2 = {rc.kmul, rc.kmul};
+  const f2 cr2 = {rc.r, rc.r}, cg2 = {rc.g, rc.g}, cb2 = {rc.b, rc.b};
+  f2 w[2], nT[2];
+  bool c[4];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     PixPair& q = pp[h];
     const f2 dy = gy2 - q.py;
-    const f2 s2 = fma2(dy, fma2(qz2, dy, bx2), hx2);
-    const f2 ov = op2 * f2{__builtin_amdgcn_exp2f(s2.x), __builtin_amdgcn_exp2f(s2.y)};
+    const f2 u = fma2(dy, fma2(qz2, dy, bx2), hx2);
+    const f2 ov = km2 * f2{__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)};
     const f2 alpha = CLAMP ? f2{fminf(K::kAlphaMax, ov.x), fminf(K::kAlphaMax, ov.y)} : ov;
-    const bool v0 = (s2.x <= 0.f) && (alpha.x >= K::kAlphaMin), v1 = (s2.y <= 0.f) && (alpha.y >= K::kAlphaMin);
-    const f2 w0 = alpha * q.T;
-    const f2 nT = fma2(-q.T, alpha, q.T);
-    const bool u0 = v0 && (nT.x > K::kTMin), u1 = v1 && (nT.y > K::kTMin);
-    const f2 w = {u0 ? w0.x : 0.f, u1 ? w0.y : 0.f};
-    q.Cr = fma2(w, cr2, q.Cr); q.Cg = fma2(w, cg2, q.Cg); q.Cb = fma2(w, cb2, q.Cb);
-    if (DEPTH) q.Cd = fma2(w, f2{cd, cd}, q.Cd);            // sum of weight * depth (expected depth = this / alpha)
-    // live pixel: T > 0.  A hit that would push T to <= 1e-4 stops the pixel: T := -|T| keeps the final value
-    q.T.x = u0 ? nT.x : (v0 ? -fabsf(q.T.x) : q.T.x);
-    q.T.y = u1 ? nT.y : (v1 ? -fabsf(q.T.y) : q.T.y);
-    q.last0 = u0 ? idx1 : q.last0;
-    q.last1 = u1 ? idx1 : q.last1;
+    // sigma >= 0 and alpha >= 1/255 (false for a stopped pixel: u is NaN)
+    const bool v0 = fabsf(u.x) <= rc.nmid, v1 = fabsf(u.y) <= rc.nmid;
+    const f2 ag = {v0 ? alpha.x : 0.f, v1 ? alpha.y : 0.f};
+    w[h] = ag * q.T;
+    nT[h] = q.T - w[h];
+    // T never falls to 1e-4 or below while a pixel is live, so "not greater" can only come from this entry's hit
+    c[2 * h] = nT[h].x > K::kTMin; c[2 * h + 1] = nT[h].y > K::kTMin;
   }
-}
-
-// CLAMP=false: no Gaussian of this tile's list has an opacity above 0.999 (the binning flags the tiles that do, see
-// tile_hot), so alpha = op * exp(..) <= op can never reach the clamp on a pixel that is blended (those have
-// s2 <= 0): min(0.999, .) is the identity there and is not issued.  The choice is made once per tile, outside the
-// loop: a per-entry branch costs more in merge copies than the two v_min it saves (measured, round 2 run 22).
-template <bool DEPTH, bool CLAMP>
-__device__ __forceinline__ void blend_entry(const RecS& rc, float pxf, int idx1, PixPair (&pp)[2]) {
-  const float kL2E = -1.4426950408889634f;
-  blend_core<DEPTH, CLAMP>(rc.x, rc.y, rc.cx * (0.5f * kL2E), rc.cy * kL2E, rc.cz * (0.5f * kL2E), rc.op, rc.r, rc.g, rc.b,
-                           rc.d, pxf, idx1, pp);
+  if (!(c[0] && c[1] && c[2] && c[3])) {
+    // some pixel of this lane stops at this entry (the block is skipped when no lane of the wave has one): it does not
+    // blend the entry, keeps its T, leaves the walk, and its stop index goes straight to final_idx — kept in a register
+    // and merged after this rarely taken block it cost eight register copies per entry on the path that skips it.
+    // In-place selects and an exec-masked store through inline assembly for the same reason (written as C++ the
+    // compiler also evaluates the negated compares on the path that skips the block).
+    const int idxv = idx;
+    static_assert(K::kTMin == 1e-4f, "the literal 0x38d1b717 below is 1e-4f");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      PixPair& q = pp[k >> 1];
+      float wk = (k & 1) ? w[k >> 1].y : w[k >> 1].x, pyk = (k & 1) ? q.py.y : q.py.x;
+      const float nTk = (k & 1) ? nT[k >> 1].y : nT[k >> 1].x;
+      unsigned long long saved;
+      asm volatile("v_cmp_lt_f32_e32 vcc, 0x38d1b717, %3\n\t"           // vcc: pixel k goes on (nT > 1e-4)
+                   "s_nop 1\n\t"       // gfx950: VALU write of an SGPR -> VALU read needs two wait states, and the
+                                        // hazard recogniser cannot see inside inline assembly
+                   "v_cndmask_b32_e32 %0, 0, %0, vcc\n\t"
+                   "v_cndmask_b32_e32 %1, -1, %1, vcc\n\t"              // all ones: a quiet NaN
+                   "s_andn1_saveexec_b64 %2, vcc\n\t"                   // exec := the lanes whose pixel k stops
+                   "global_store_dword %4, %5, %6\n\t"
+                   "s_mov_b64 exec, %2"
+                   : "+v"(wk), "+v"(pyk), "=&s"(saved)
+                   : "v"(nTk), "v"((fin_off + (unsigned)k * fin_row) * 4u) /*byte offset*/, "v"(idxv), "s"(fin_out)
+                   : "memory", "vcc");
+      if (k & 1) { w[k >> 1].y = wk; q.py.y = pyk; } else { w[k >> 1].x = wk; q.py.x = pyk; }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    PixPair& q = pp[h];
+    q.Cr = fma2(w[h], cr2, q.Cr); q.Cg = fma2(w[h], cg2, q.Cg); q.Cb = fma2(w[h], cb2, q.Cb);
+    if (DEPTH) q.Cd = fma2(w[h], f2{rc.d, rc.d}, q.Cd);     // sum of weight * depth (expected depth = this / alpha)
+    q.T -= w[h];                                            // (a stopping pixel's w is zero by now: it keeps its T)
+  }
 }
 
 // how often the walk asks "is any pixel of the tile still live?": b & MASK == MASK, b = list position in steps of 4
@@ -288,13 +321,16 @@ __device__ __forceinline__ void blend_entry(const RecS& rc, float pxf, int idx1,
 #define GS_FWD_LIVE_MASK 0
 #endif
 __device__ __forceinline__ bool any_live(const PixPair (&pp)[2]) {
-  return __ballot(fmaxf(fmaxf(pp[0].T.x, pp[0].T.y), fmaxf(pp[1].T.x, pp[1].T.y)) > 0.f) != 0ull;
+  // v_max returns the operand that is not NaN: the maximum is NaN only when all four rows are
+  const float m = fmaxf(fmaxf(pp[0].py.x, pp[0].py.y), fmaxf(pp[1].py.x, pp[1].py.y));
+  return __builtin_amdgcn_ballot_w64(m == m) != 0ull;
 }
 
-// the tile's list, front to back (n = range.y - range.x > 0 entries)
+// the tile's list, front to back (n = range.y - range.x > 0 entries); `idx` handed to an entry = its list position
 template <bool DEPTH, bool CLAMP>
 __device__ __forceinline__ void fwd_walk(const int* __restrict__ ids, const float* __restrict__ records, unsigned max_id,
-                                         int2 range, unsigned n, float pxf, PixPair (&pp)[2]) {
+                                         int2 range, unsigned n, float pxf, PixPair (&pp)[2], int* __restrict__ fin_out,
+                                         unsigned fin_off, unsigned fin_row) {
   int b = range.x & ~3;
   const int4* __restrict__ ids4 = reinterpret_cast<const int4*>(ids);
   int4 idv = ids4[b >> 2];
@@ -307,14 +343,14 @@ __device__ __forceinline__ void fwd_walk(const int* __restrict__ ids, const floa
     const RecS b0 = load_rec_s<DEPTH>(records, min((unsigned)idv.z, max_id)), b1 = load_rec_s<DEPTH>(records, min((unsigned)idv.w, max_id));
     idv = ids4[(b >> 2) + 1];
     asm volatile("" ::: "memory");
-    if ((unsigned)(b - range.x) < n) blend_entry<DEPTH, CLAMP>(a0, pxf, b + 1, pp);
-    if ((unsigned)(b + 1 - range.x) < n) blend_entry<DEPTH, CLAMP>(a1, pxf, b + 2, pp);
+    if ((unsigned)(b - range.x) < n) blend_entry<DEPTH, CLAMP>(a0, pxf, b, pp, fin_out, fin_off, fin_row);
+    if ((unsigned)(b + 1 - range.x) < n) blend_entry<DEPTH, CLAMP>(a1, pxf, b + 1, pp, fin_out, fin_off, fin_row);
     // pair B is ready; refill pair A from the next group
     asm volatile("" :: "s"(b0.x), "s"(b1.x), "s"(idv.x) : "memory");
     a0 = load_rec_s<DEPTH>(records, min((unsigned)idv.x, max_id)); a1 = load_rec_s<DEPTH>(records, min((unsigned)idv.y, max_id));
     asm volatile("" ::: "memory");
-    if ((unsigned)(b + 2 - range.x) < n) blend_entry<DEPTH, CLAMP>(b0, pxf, b + 3, pp);
-    if ((unsigned)(b + 3 - range.x) < n) blend_entry<DEPTH, CLAMP>(b1, pxf, b + 4, pp);
+    if ((unsigned)(b + 2 - range.x) < n) blend_entry<DEPTH, CLAMP>(b0, pxf, b + 2, pp, fin_out, fin_off, fin_row);
+    if ((unsigned)(b + 3 - range.x) < n) blend_entry<DEPTH, CLAMP>(b1, pxf, b + 3, pp, fin_out, fin_off, fin_row);
     b += 4;
     if (b >= range.y) break;
     if ((b & GS_FWD_LIVE_MASK) == GS_FWD_LIVE_MASK && !any_live(pp)) break;
@@ -351,28 +387,40 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
   const int px = tx * K::kTile + (lane & 15);
   const int py0 = ty * K::kTile + (lane >> 4) * 4;
   const float pxf = (float)px + 0.5f;
+  const float qnan = __builtin_nanf("");
+  // element offsets into final_idx [S,H,W] of the lane's first pixel, and of a row (32 bit: S*H*W < 2^31 is checked
+  // by the caller's buffer sizes)
+  const unsigned fin_off = ((unsigned)s * (unsigned)prm.H + (unsigned)py0) * (unsigned)prm.W + (unsigned)px;
+  const unsigned fin_row = (unsigned)prm.W;
+  int* __restrict__ fin_out = final_idx;
   PixPair pp[2];
   bool inside[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     inside[k] = px < prm.W && (py0 + k) < prm.H;
-    float Tk = inside[k] ? 1.f : -1.f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f;
+    float Tk = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f;
+    bool live = inside[k];
     if (!st.first && inside[k]) {
       size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
       cr = out_img[pix * 3 + 0]; cg = out_img[pix * 3 + 1]; cb = out_img[pix * 3 + 2];
       if (DEPTH) cd = out_depth[pix];
       const float Tf = out_T[pix], lv = st.live_T[pix];
-      Tk = lv > 0.f ? lv : -Tf;
+      live = lv > 0.f;
+      Tk = live ? lv : Tf;
     }
+    const float pyk = live ? (float)(py0 + k) + 0.5f : qnan;
+    // final_idx of a pixel that stopped in an earlier slice: it blends nothing of this one.  (A pixel that stops in
+    // this slice writes its stop index at that moment, one that stays live gets the end of the list below.)
+    if (inside[k] && !live) final_idx[fin_off + (unsigned)k * fin_row] = range.x;
     PixPair& q = pp[k >> 1];
-    if (k & 1) { q.T.y = Tk; q.Cr.y = cr; q.Cg.y = cg; q.Cb.y = cb; q.Cd.y = cd; q.py.y = (float)(py0 + k) + 0.5f; q.last1 = range.x; }
-    else       { q.T.x = Tk; q.Cr.x = cr; q.Cg.x = cg; q.Cb.x = cb; q.Cd.x = cd; q.py.x = (float)(py0 + k) + 0.5f; q.last0 = range.x; }
+    if (k & 1) { q.T.y = Tk; q.Cr.y = cr; q.Cg.y = cg; q.Cb.y = cb; q.Cd.y = cd; q.py.y = pyk; }
+    else       { q.T.x = Tk; q.Cr.x = cr; q.Cg.x = cg; q.Cb.x = cb; q.Cd.x = cd; q.py.x = pyk; }
   }
   const unsigned n = (unsigned)(range.y - range.x);
   if (n != 0u) {
     const bool hot = tile_hot == nullptr || __builtin_amdgcn_readfirstlane((int)tile_hot[tkey]) != 0;
-    if (hot) fwd_walk<DEPTH, true>(ids, records, max_id, range, n, pxf, pp);
-    else fwd_walk<DEPTH, false>(ids, records, max_id, range, n, pxf, pp);
+    if (hot) fwd_walk<DEPTH, true>(ids, records, max_id, range, n, pxf, pp, fin_out, fin_off, fin_row);
+    else fwd_walk<DEPTH, false>(ids, records, max_id, range, n, pxf, pp, fin_out, fin_off, fin_row);
   }
   const bool all_stopped = !any_live(pp);
   const bool finalize = all_stopped || st.last;
@@ -382,7 +430,7 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
   for (int k = 0; k < 4; ++k) {
     if (inside[k]) {
       const PixPair& q = pp[k >> 1];
-      const float Tk = (k & 1) ? q.T.y : q.T.x, Tf = fabsf(Tk);
+      const float Tf = (k & 1) ? q.T.y : q.T.x, pyk = (k & 1) ? q.py.y : q.py.x;
       const float cr = (k & 1) ? q.Cr.y : q.Cr.x, cg = (k & 1) ? q.Cg.y : q.Cg.x, cb = (k & 1) ? q.Cb.y : q.Cb.x;
       size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
       out_img[pix * 3 + 0] = cr + Tf * bgr;
@@ -390,197 +438,8 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
       out_img[pix * 3 + 2] = cb + Tf * bgb;
       out_T[pix] = Tf;
       if (DEPTH) out_depth[pix] = (k & 1) ? q.Cd.y : q.Cd.x;
-      final_idx[pix] = (k & 1) ? q.last1 : q.last0;
-      if (!st.last) st.live_T[pix] = fmaxf(Tk, 0.f);
-    }
-  }
-  if (!st.last && lane == 0) {
-    if (all_stopped) st.tile_done[tkey] = 1;
-    else if (st.open_flag) atomicAdd(st.open_flag, 1);      // the word counts the tiles left open
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Forward compositor for slices of SMALL splats (round 3): the 4x4-block lock-step walk.
-//
-// The walk above hands every list entry to all 256 pixels of the tile.  On a fitted-model-like scene (splats of a few
-// pixels) the lane-utilisation counters (gs_rasterize_fwd_slice_stats, profiles/r03_run1_lane_stats.jsonl) say that an
-// entry reaches 10 of the tile's sixteen 4x4 pixel blocks on average and that 48 % of the pixel slots do useful work.
-// A lane's four pixels are a column of one 4x4 block, so four consecutive lanes ARE a block.  Here the list is taken in
-// chunks of 64 entries: lane L fetches entry L's record, works out which of the 16 blocks its alpha >= 1/255 ellipse can
-// reach (the row-span test of the binning, per 4-pixel band), parks the record in wave-private LDS, and the wave builds
-// one compacted index list per block from 16 ballots.  Then the blocks walk their OWN lists in lock-step — in step k
-// quad b blends its k-th entry, four lanes reading that record from LDS — for max_b(len_b) steps instead of 64
-// (counter estimate: 37.5 steps per 53.5-entry chunk on that scene, 45 per 48 on the headline).  Per-pixel arithmetic
-// and order are those of the kernels above: images are bit-identical (tested); a block skips exactly the entries that
-// cannot change any of its pixels.
-// MEASURED (run r3_run9, 1M Gaussians / 1080p / 5 sub-poses, fitted-model-like scene): 2.46 ms against 2.49 ms for the
-// all-pixels walk — no gain.  The 1.43x fewer steps are paid back by the chunk prologue (block masks: four chord tests
-// per entry; sixteen ballots + LDS list writes: ~440 instructions per 64 entries, ~14 %), a costlier step (75 VALU vs
-// 61: register copies of the staged record, list / record addressing) and one wave per SIMD less (104 VGPRs).  Kept
-// as `variant 3` (A/B, tests), never selected by default; the utilisation counters stay the evidence of what a
-// sub-tile mapping could buy at most on this design.
-// ---------------------------------------------------------------------------
-constexpr int kQuadRecF4 = 3;                 // a staged record: {x, y, qx, qy} {qz, op, r, g} {b, depth, -, -}
-
-// bit (4*by + bx) set: the entry's alpha >= 1/255 region may reach a pixel centre of block (bx, by) of the tile at
-// (X0, Y0).  Conservative (never drops a block that holds a hit pixel): same chord arithmetic and slack as the tile
-// test of the binning (binning.hip row_span), on bands of four pixel rows.
-__device__ __forceinline__ unsigned block_mask16(float gx, float gy, float a, float b, float c, float op, float X0,
-                                                 float Y0) {
-  if (!(op > 0.f)) return 0u;
-  float tau = __logf(255.0f * op);
-  if (tau < 0.f) return 0u;                   // op < 1/255: alpha = op * e^{-sigma} never reaches the threshold
-  tau = tau * 1.001f + 1e-3f;
-  const float det = a * c - b * b;
-  if (!(det > 0.f && a > 0.f && c > 0.f)) return 0xFFFFu;          // degenerate conic: never cull
-  const float kk = 2.0f * tau / det;
-  const float ustar = sqrtf(kk * c) * 1.0001f, vext = sqrtf(kk * a) * 1.0001f;
-  const float ra = 1.0f / a, vstar = b * ustar / c;
-  const float k2 = 2.0f * a * tau;
-  const float eps = 2e-3f + 2e-6f * (fabsf(gx) + ustar);
-  unsigned mask = 0u;
-#pragma unroll
-  for (int by = 0; by < 4; ++by) {
-    const float v0 = Y0 + (float)(4 * by) + 0.5f - gy, v1 = v0 + 3.0f;
-    if (v1 < -vext || v0 > vext) continue;
-    const float w0 = fmaxf(v0, -vext), w1 = fminf(v1, vext);
-    const float d0 = sqrtf(fmaxf(k2 - det * w0 * w0, 0.f)), d1 = sqrtf(fmaxf(k2 - det * w1 * w1, 0.f));
-    const float c0 = -b * w0, c1 = -b * w1;
-    float ur = fmaxf((c0 + d0) * ra, (c1 + d1) * ra);
-    float ul = fminf((c0 - d0) * ra, (c1 - d1) * ra);
-    if (-vstar >= w0 && -vstar <= w1) ur = ustar;
-    if (vstar >= w0 && vstar <= w1) ul = -ustar;
-    const float hi_f = fmaxf(ur, ul) + eps, lo_f = fminf(ul, ur) - eps;
-    // block bx holds pixel centres X0 + 4 bx + 0.5 .. X0 + 4 bx + 3.5
-    const float lo = ceilf((gx + lo_f - 3.5f - X0) * 0.25f), hi = floorf((gx + hi_f - 0.5f - X0) * 0.25f);
-    const int l = (int)fmaxf(lo, 0.f), h = (int)fminf(hi, 3.f);
-    if (h >= l) mask |= (((2u << h) - 1u) & ~((1u << l) - 1u)) << (4 * by);
-  }
-  return mask;
-}
-
-template <bool DEPTH, bool CLAMP>
-__device__ __forceinline__ void fwd_walk_quads(const int* __restrict__ ids, const float* __restrict__ records, int2 range,
-                                               float pxf, float X0, float Y0, int lane, float4* __restrict__ s_rec,
-                                               unsigned char* __restrict__ s_list, PixPair (&pp)[2]) {
-  const float kL2E = -1.4426950408889634f;
-  const int myq = lane >> 2;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  unsigned char* my_list = s_list + myq * 64;
-  for (int c0 = range.x; c0 < range.y; c0 += 64) {
-    if (!any_live(pp)) break;
-    const int i = c0 + lane;
-    const bool in = i < range.y;
-    unsigned mask = 0u;
-    float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0;
-    if (in) {
-      const float4* p = reinterpret_cast<const float4*>(records + (size_t)(unsigned)ids[i] * kRecFloats);
-      r0 = p[0]; r1 = p[1]; r2 = p[2];
-      mask = block_mask16(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, X0, Y0);
-    }
-    // stage the record (conic pre-scaled exactly as blend_entry scales it) and an all-"null" list table
-    s_rec[lane * kQuadRecF4 + 0] = make_float4(r0.x, r0.y, r0.z * (0.5f * kL2E), r0.w * kL2E);
-    s_rec[lane * kQuadRecF4 + 1] = make_float4(r1.x * (0.5f * kL2E), r1.y, r1.z, r1.w);
-    s_rec[lane * kQuadRecF4 + 2] = make_float4(r2.x, r2.y, 0.f, 0.f);
-    reinterpret_cast<uint4*>(s_list)[lane] = make_uint4(0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u);
-    int nmax = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const bool bit = (mask >> q) & 1u;
-      const unsigned long long S = __ballot(bit);
-      if (bit) s_list[q * 64 + __popcll(S & lt)] = (unsigned char)lane;
-      nmax = max(nmax, (int)__popcll(S));
-    }
-    __builtin_amdgcn_wave_barrier();
-    // lock-step: quad b blends entry list_b[k]; a shorter list reads the null record (opacity 0: nothing is valid)
-    int jn = my_list[0];
-    float4 a0 = s_rec[jn * kQuadRecF4], a1 = s_rec[jn * kQuadRecF4 + 1], a2 = s_rec[jn * kQuadRecF4 + 2];
-    for (int k = 0; k < nmax; ++k) {
-      const float4 b0 = a0, b1 = a1, b2 = a2;
-      const int j = jn;
-      jn = my_list[min(k + 1, 63)];
-      a0 = s_rec[jn * kQuadRecF4]; a1 = s_rec[jn * kQuadRecF4 + 1]; a2 = s_rec[jn * kQuadRecF4 + 2];
-      blend_core<DEPTH, CLAMP>(b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, pxf, c0 + j + 1, pp);
-      if ((k & 15) == 15 && !any_live(pp)) break;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-template <bool DEPTH>
-__global__ __launch_bounds__(256) void raster_fwd_quad_kernel(RasterParams prm, SliceState st,
-                                                              const int* __restrict__ ids, const float* __restrict__ records,
-                                                              float* __restrict__ out_img, float* __restrict__ out_T,
-                                                              int* __restrict__ final_idx, unsigned n_blocks,
-                                                              float* __restrict__ out_depth,
-                                                              const unsigned char* __restrict__ tile_hot) {
-  __shared__ float4 s_rec_all[4][65 * kQuadRecF4];
-  __shared__ __attribute__((aligned(16))) unsigned char s_list_all[4][16 * 64];
-  const int lane = lane_id();
-  const int wv = threadIdx.x >> 6;
-  const int T = prm.tiles_x * prm.tiles_y;
-  const unsigned work = (unsigned)__builtin_amdgcn_readfirstlane(
-      (int)(xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6)));
-  if (work >= (unsigned)(prm.S * T)) return;
-  const int s = work / T, t = work % T;
-  const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
-  const int p = s * prm.R + find_band(prm.band_edges, prm.R, ty);
-  const size_t tkey = (size_t)p * T + t;
-  if (!st.first && st.tile_done[tkey]) return;
-  int2 range = prm.tile_bins[tkey];
-  range.x = __builtin_amdgcn_readfirstlane(range.x);
-  range.y = __builtin_amdgcn_readfirstlane(range.y);
-  if (!st.first && !st.last && range.y <= range.x) {         // nothing for this tile in this slice: it stays open
-    if (st.open_flag && lane == 0) atomicAdd(st.open_flag, 1);
-    return;
-  }
-  const int px = tx * K::kTile + (lane & 15);
-  const int py0 = ty * K::kTile + (lane >> 4) * 4;
-  const float pxf = (float)px + 0.5f;
-  PixPair pp[2];
-  bool inside[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    inside[k] = px < prm.W && (py0 + k) < prm.H;
-    float Tk = inside[k] ? 1.f : -1.f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f;
-    if (!st.first && inside[k]) {
-      size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
-      cr = out_img[pix * 3 + 0]; cg = out_img[pix * 3 + 1]; cb = out_img[pix * 3 + 2];
-      if (DEPTH) cd = out_depth[pix];
-      const float Tf = out_T[pix], lv = st.live_T[pix];
-      Tk = lv > 0.f ? lv : -Tf;
-    }
-    PixPair& q = pp[k >> 1];
-    if (k & 1) { q.T.y = Tk; q.Cr.y = cr; q.Cg.y = cg; q.Cb.y = cb; q.Cd.y = cd; q.py.y = (float)(py0 + k) + 0.5f; q.last1 = range.x; }
-    else       { q.T.x = Tk; q.Cr.x = cr; q.Cg.x = cg; q.Cb.x = cb; q.Cd.x = cd; q.py.x = (float)(py0 + k) + 0.5f; q.last0 = range.x; }
-  }
-  if (range.y > range.x) {
-    float4* s_rec = s_rec_all[wv];
-    if (lane < kQuadRecF4) s_rec[64 * kQuadRecF4 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);     // the null record
-    const bool hot = tile_hot == nullptr || __builtin_amdgcn_readfirstlane((int)tile_hot[tkey]) != 0;
-    const float X0 = (float)(tx * K::kTile), Y0 = (float)(ty * K::kTile);
-    if (hot) fwd_walk_quads<DEPTH, true>(ids, records, range, pxf, X0, Y0, lane, s_rec, s_list_all[wv], pp);
-    else fwd_walk_quads<DEPTH, false>(ids, records, range, pxf, X0, Y0, lane, s_rec, s_list_all[wv], pp);
-  }
-  const bool all_stopped = !any_live(pp);
-  const bool finalize = all_stopped || st.last;
-  const float bgr = finalize ? prm.background[0] : 0.f, bgg = finalize ? prm.background[1] : 0.f,
-              bgb = finalize ? prm.background[2] : 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (inside[k]) {
-      const PixPair& q = pp[k >> 1];
-      const float Tk = (k & 1) ? q.T.y : q.T.x, Tf = fabsf(Tk);
-      const float cr = (k & 1) ? q.Cr.y : q.Cr.x, cg = (k & 1) ? q.Cg.y : q.Cg.x, cb = (k & 1) ? q.Cb.y : q.Cb.x;
-      size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
-      out_img[pix * 3 + 0] = cr + Tf * bgr;
-      out_img[pix * 3 + 1] = cg + Tf * bgg;
-      out_img[pix * 3 + 2] = cb + Tf * bgb;
-      out_T[pix] = Tf;
-      if (DEPTH) out_depth[pix] = (k & 1) ? q.Cd.y : q.Cd.x;
-      final_idx[pix] = (k & 1) ? q.last1 : q.last0;
-      if (!st.last) st.live_T[pix] = fmaxf(Tk, 0.f);
+      if (pyk == pyk) final_idx[pix] = range.y;
+      if (!st.last) st.live_T[pix] = pyk == pyk ? Tf : 0.f;
     }
   }
   if (!st.last && lane == 0) {
@@ -671,15 +530,8 @@ static int launch_fwd(const RasterParams& prm, const SliceState& st, const int* 
                        out_T, final_idx, blocks, stats);
     return GS_OK;
   }
-  if (out_depth && !((variant == 0 || variant == 3) && ids)) return GS_ERR_INVALID;   // no depth channel in the round-1 kernel
-  if (variant == 3 && !ids) return GS_ERR_INVALID;
-  if (variant == 3 && out_depth)
-    hipLaunchKernelGGL(raster_fwd_quad_kernel<true>, dim3(blocks), dim3(256), 0, stream, prm, st, ids, prm.records,
-                       out_img, out_T, final_idx, blocks, out_depth, tile_hot);
-  else if (variant == 3)
-    hipLaunchKernelGGL(raster_fwd_quad_kernel<false>, dim3(blocks), dim3(256), 0, stream, prm, st, ids, prm.records,
-                       out_img, out_T, final_idx, blocks, (float*)nullptr, tile_hot);
-  else if (variant == 0 && ids && out_depth)
+  if (out_depth && !(variant == 0 && ids)) return GS_ERR_INVALID;   // no depth channel in the round-1 kernel
+  if (variant == 0 && ids && out_depth)
     hipLaunchKernelGGL(raster_fwd_sload_kernel<true>, dim3(blocks), dim3(256), 0, stream, prm, st, ids, prm.records,
                        (unsigned)(n_records > 0 ? n_records - 1 : 0), out_img, out_T, final_idx, blocks, out_depth,
                        tile_hot);

@@ -216,14 +216,14 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
       for (int c = 0; c < 9; ++c) { a[c] = tot[lane * 9 + c]; nz |= a[c] != 0.f; }
       if (OUT == 1) {
         if (nz) {
-          float4* dst = reinterpret_cast<float4*>(tuples + (size_t)eid * kRecFloats);
+          float4* dst = reinterpret_cast<float4*>(tuples + (size_t)eid * kGradFloats);
           dst[0] = make_float4(a[0], a[1], a[2], a[3]);
           dst[1] = make_float4(a[4], a[5], a[6], a[7]);
           dst[2] = make_float4(a[8], 0.f, 0.f, 0.f);
           flags[eid] = 1;
         }
       } else {
-        float* dst = v_records + (size_t)gid * kRecFloats;
+        float* dst = v_records + (size_t)gid * kGradFloats;
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
           if (a[c] != 0.f) {
@@ -268,12 +268,13 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
 //     per-batch flush, no vector loads of ids / records at all.
 // LDS per wave: 36 rows x 36 floats = 5.1 KB (pair sums in registers first; 36 x 68 floats = 9.6 KB without).
 // ---------------------------------------------------------------------------
-struct RecS { float x, y, cx, cy, cz, op, r, g, b; };
+struct RecS { float x, y, cx, cy, cz, op, r, g, b, nmid, kmul, qx, qz; };
 
 __device__ __forceinline__ RecS load_rec_s(const float* __restrict__ records, unsigned gi) {
   const float* p = records + (size_t)gi * kRecFloats;
   RecS o;
   o.x = p[0]; o.y = p[1]; o.cx = p[2]; o.cy = p[3]; o.cz = p[4]; o.op = p[5]; o.r = p[6]; o.g = p[7]; o.b = p[8];
+  o.nmid = p[kRecNmid]; o.kmul = p[kRecKmul]; o.qx = p[kRecQx]; o.qz = p[kRecQz];
   return o;
 }
 
@@ -308,35 +309,36 @@ struct BwdPair { f2 T, Dv, vr, vg, vb, py; int fin0, fin1; };
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // one list entry against the lane's four pixels; returns whether any lane of the wave was hit (then the lane's 9
-// partial sums are in LDS rows slot*9 .. slot*9+8, column `lane`)
+// partial sums are in LDS rows slot*9 .. slot*9+8, column `lane >> 1`)
 // CLAMP=false: no Gaussian of the tile's list has an opacity above 0.999 (tile_hot, see the forward)
-template <bool CLAMP>
+// Round 4: validity is the forward's ONE compare on the shifted exponent (raster.hip, gs_math.h rec_aux — the same
+// expression, so both directions take the same decision for every pixel and entry), alpha = kmul * 2^u; and because
+// v_sigma = -alpha * v_alpha and v_opacity = (alpha / op) * v_alpha under the same gate, the opacity gradient is
+// -(sum of v_sigma) / op: its own accumulator and its selects are gone, slot 5 carries RAW_OP ? the plain sum of
+// v_sigma (the tuple reduce divides by -op once per Gaussian) : the finished gradient.
+template <bool CLAMP, bool RAW_OP>
 __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, BwdPair (&pp)[2], float* __restrict__ red,
                                           int slot, int lane, float agm) {
-  const float kL2E = -1.4426950408889634f;
-  const float qx = rc.cx * (0.5f * kL2E), qy = rc.cy * kL2E, qz = rc.cz * (0.5f * kL2E);
   const float dx = rc.x - pxf;
-  const float hx = qx * dx * dx;             // exponent terms, pre-scaled by -log2(e)
-  const float bx = qy * dx;
-  const f2 hx2 = {hx, hx}, bx2 = {bx, bx}, qz2 = {qz, qz}, gy2 = {rc.y, rc.y}, op2 = {rc.op, rc.op};
-  f2 dy2[2], vis2[2], ov2[2];
+  const float hxm = fmaf(rc.qx * dx, dx, rc.nmid);         // exponent terms, pre-scaled by -log2(e), + the shift
+  const float bx = (rc.cy * kNegLog2e) * dx;
+  const f2 hx2 = {hxm, hxm}, bx2 = {bx, bx}, qz2 = {rc.qz, rc.qz}, gy2 = {rc.y, rc.y}, km2 = {rc.kmul, rc.kmul};
+  f2 dy2[2], ov2[2];
   bool hit[4];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     dy2[h] = gy2 - pp[h].py;
-    const f2 s2 = fma2(dy2[h], fma2(qz2, dy2[h], bx2), hx2);
-    vis2[h] = f2{__builtin_amdgcn_exp2f(s2.x), __builtin_amdgcn_exp2f(s2.y)};
-    ov2[h] = op2 * vis2[h];
-    // min(0.999, ov) >= 1/255  <=>  ov >= 1/255: the clamp is only applied where alpha itself is needed
-    hit[2 * h] = (idx < pp[h].fin0) && (s2.x <= 0.f) && (ov2[h].x >= K::kAlphaMin);
-    hit[2 * h + 1] = (idx < pp[h].fin1) && (s2.y <= 0.f) && (ov2[h].y >= K::kAlphaMin);
+    const f2 u = fma2(dy2[h], fma2(qz2, dy2[h], bx2), hx2);
+    ov2[h] = km2 * f2{__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)};
+    hit[2 * h] = (idx < pp[h].fin0) && (fabsf(u.x) <= rc.nmid);
+    hit[2 * h + 1] = (idx < pp[h].fin1) && (fabsf(u.y) <= rc.nmid);
   }
   if (__ballot(hit[0] || hit[1] || hit[2] || hit[3]) == 0ull) return false;
   const f2 cr2 = {rc.r, rc.r}, cg2 = {rc.g, rc.g}, cb2 = {rc.b, rc.b};
-  f2 q_op = {0.f, 0.f}, q_r = q_op, q_g = q_op, q_b = q_op, m0 = q_op, m1 = q_op, m2 = q_op;
+  f2 q_r = {0.f, 0.f}, q_g = q_r, q_b = q_r, m0 = q_r, m1 = q_r, m2 = q_r;
   // pixels that are not hit are neutralised by SELECTING alpha = 0 (1/(1-0) = 1 exactly, every contribution is an
   // exact zero) instead of per-pixel exec regions
-  auto pair = [&](int h, f2 alpha, f2 vism, f2 ovm) {
+  auto pair = [&](int h, f2 alpha, f2 ovm) {
     BwdPair& q = pp[h];
     const f2 om = 1.f - alpha;
     const f2 ra = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
@@ -347,7 +349,6 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
     const f2 v_al = fma2(q.T, cv, -(ra * q.Dv));
     q.Dv = fma2(fac, cv, q.Dv);
     const f2 v_sigma = -ovm * v_al;
-    q_op = fma2(vism, v_al, q_op);
     // moments of v_sigma over the lane's pixels (dx is the same for all four)
     m0 += v_sigma;
     const f2 vsdy = v_sigma * dy2[h];
@@ -361,26 +362,24 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
       const f2 alpha = {h0 ? fminf(K::kAlphaMax, ov2[h].x) : 0.f, h1 ? fminf(K::kAlphaMax, ov2[h].y) : 0.f};
       // d min(0.999, o*vis) = 0 when clamped
       const bool f0 = h0 && ov2[h].x <= agm, f1 = h1 && ov2[h].y <= agm;
-      const f2 vism = {f0 ? vis2[h].x : 0.f, f1 ? vis2[h].y : 0.f};
-      pair(h, alpha, vism, op2 * vism);      // op*vism == ov where the gradient flows (the same product), 0 elsewhere
+      pair(h, alpha, f2{f0 ? ov2[h].x : 0.f, f1 ? ov2[h].y : 0.f});
     }
   } else {
     // opacity <= 0.999 (<= agm): alpha = op*vis <= op never reaches the clamp on a hit pixel (s2 <= 0), so
-    // min(0.999, ov) == ov, the clamp never blocks the gradient, and op*vism is alpha itself.  (Chosen per TILE:
-    // a per-entry branch leaves four 64-bit merge copies per entry behind.)
+    // min(0.999, ov) == ov and the clamp never blocks the gradient.  (Chosen per TILE: a per-entry branch leaves
+    // four 64-bit merge copies per entry behind.)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const bool h0 = hit[2 * h], h1 = hit[2 * h + 1];
-      const f2 alpha = {h0 ? ov2[h].x : 0.f, h1 ? ov2[h].y : 0.f};
-      const f2 vism = {h0 ? vis2[h].x : 0.f, h1 ? vis2[h].y : 0.f};
-      pair(h, alpha, vism, alpha);
+      const f2 alpha = {hit[2 * h] ? ov2[h].x : 0.f, hit[2 * h + 1] ? ov2[h].y : 0.f};
+      pair(h, alpha, alpha);
     }
   }
   const float M0 = m0.x + m0.y, M1 = m1.x + m1.y, M2 = m2.x + m2.y;
   const float p_cx = (0.5f * dx * dx) * M0, p_cy = dx * M1, p_cz = 0.5f * M2;
   const float p_x = (rc.cx * dx) * M0 + rc.cy * M1;
   const float p_y = (rc.cy * dx) * M0 + rc.cz * M1;
-  float w[9] = {p_x, p_y, p_cx, p_cy, p_cz, q_op.x + q_op.y, q_r.x + q_r.y, q_g.x + q_g.y, q_b.x + q_b.y};
+  const float p_op = RAW_OP ? M0 : -M0 * __builtin_amdgcn_rcpf(rc.op);
+  float w[9] = {p_x, p_y, p_cx, p_cy, p_cz, p_op, q_r.x + q_r.y, q_g.x + q_g.y, q_b.x + q_b.y};
   pair_sum9(w);
   if ((lane & 1) == 0) {
     float* r0 = red + slot * (9 * kRedStride4) + (lane >> 1);
@@ -417,14 +416,14 @@ __device__ __forceinline__ void bwd_walk(const int* __restrict__ ids, const int*
     idv = ids4[max(b - 4, 0) >> 2];
     asm volatile("" ::: "memory");
     unsigned filled = 0;
-    if ((unsigned)(b + 3 - range_x) < n && bwd_entry<CLAMP>(a0, pxf, b + 3, pp, red, 3, lane, agm)) filled |= 8u;
-    if ((unsigned)(b + 2 - range_x) < n && bwd_entry<CLAMP>(a1, pxf, b + 2, pp, red, 2, lane, agm)) filled |= 4u;
+    if ((unsigned)(b + 3 - range_x) < n && bwd_entry<CLAMP, OUT == 1>(a0, pxf, b + 3, pp, red, 3, lane, agm)) filled |= 8u;
+    if ((unsigned)(b + 2 - range_x) < n && bwd_entry<CLAMP, OUT == 1>(a1, pxf, b + 2, pp, red, 2, lane, agm)) filled |= 4u;
     // pair B is ready; refill pair A from the next group
     asm volatile("" :: "s"(b0.x), "s"(b1.x), "s"(idv.x), "s"(ev.x) : "memory");
     a0 = load_rec_s(records, min((unsigned)idv.w, max_id)); a1 = load_rec_s(records, min((unsigned)idv.z, max_id));
     asm volatile("" ::: "memory");
-    if ((unsigned)(b + 1 - range_x) < n && bwd_entry<CLAMP>(b0, pxf, b + 1, pp, red, 1, lane, agm)) filled |= 2u;
-    if ((unsigned)(b - range_x) < n && bwd_entry<CLAMP>(b1, pxf, b, pp, red, 0, lane, agm)) filled |= 1u;
+    if ((unsigned)(b + 1 - range_x) < n && bwd_entry<CLAMP, OUT == 1>(b0, pxf, b + 1, pp, red, 1, lane, agm)) filled |= 2u;
+    if ((unsigned)(b - range_x) < n && bwd_entry<CLAMP, OUT == 1>(b1, pxf, b, pp, red, 0, lane, agm)) filled |= 1u;
     if (filled) {
       __builtin_amdgcn_wave_barrier();
       if (row < kRedG4 * 9 && ((filled >> row_g) & 1u)) {
@@ -436,10 +435,10 @@ __device__ __forceinline__ void bwd_walk(const int* __restrict__ ids, const int*
         const float sum = (v.x + v.y) + (v.z + v.w);
         const int id_e = row_g == 0 ? ev.x : (row_g == 1 ? ev.y : (row_g == 2 ? ev.z : ev.w));
         if (OUT == 1) {
-          tuples[(size_t)(unsigned)id_e * kRecFloats + row_c] = sum;
-          if (row_c == 0) flags[(unsigned)id_e] = 1;
+          tuples[(size_t)(unsigned)id_e * kGradFloats + row_c] = sum;
+          if (row_c == 0) flags[(unsigned)id_e] = 2;          // 2: slot 5 is the plain sum of v_sigma (see bwd_entry)
         } else {
-          if (sum != 0.f) atomic_add_f32(v_records + (size_t)(unsigned)id_e * kRecFloats + row_c, sum);
+          if (sum != 0.f) atomic_add_f32(v_records + (size_t)(unsigned)id_e * kGradFloats + row_c, sum);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -550,7 +549,8 @@ __global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const u
                                                             const float* __restrict__ tuples,
                                                             const unsigned char* __restrict__ flags,
                                                             float* __restrict__ v_records,
-                                                            unsigned char* __restrict__ touched) {
+                                                            unsigned char* __restrict__ touched,
+                                                            const float* __restrict__ records) {
   const int lane = lane_id();
   const int j = blockIdx.x * 256 + threadIdx.x;
   unsigned cnt = 0, e0 = 0, gi = 0;
@@ -560,15 +560,17 @@ __global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const u
   float acc[kTupleComp];
 #pragma unroll
   for (int c = 0; c < kTupleComp; ++c) acc[c] = 0.f;
-  bool any = false;
+  bool any = false, raw = false;     // raw: slot 5 holds the plain sum of v_sigma (flag value 2)
   if (cnt && cnt <= kReduceSolo) {
     for (unsigned i = 0; i < cnt; ++i) {
-      if (flags[e0 + i]) {
-        const float4* t = reinterpret_cast<const float4*>(tuples + (size_t)(e0 + i) * kRecFloats);
+      const unsigned char f = flags[e0 + i];
+      if (f) {
+        const float4* t = reinterpret_cast<const float4*>(tuples + (size_t)(e0 + i) * kGradFloats);
         float4 a = t[0], b = t[1], c = t[2];
         acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
         acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w; acc[8] += c.x; acc[9] += c.y; acc[10] += c.z;
         any = true;
+        raw |= f == 2;
       }
     }
   }
@@ -580,14 +582,16 @@ __global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const u
     float part[kTupleComp];
 #pragma unroll
     for (int c = 0; c < kTupleComp; ++c) part[c] = 0.f;
-    bool hit = false;
+    bool hit = false, hraw = false;
     for (unsigned i = lane; i < c_n; i += 64) {
-      if (flags[c_e + i]) {
-        const float4* t = reinterpret_cast<const float4*>(tuples + (size_t)(c_e + i) * kRecFloats);
+      const unsigned char f = flags[c_e + i];
+      if (f) {
+        const float4* t = reinterpret_cast<const float4*>(tuples + (size_t)(c_e + i) * kGradFloats);
         float4 a = t[0], b = t[1], c = t[2];
         part[0] += a.x; part[1] += a.y; part[2] += a.z; part[3] += a.w;
         part[4] += b.x; part[5] += b.y; part[6] += b.z; part[7] += b.w; part[8] += c.x; part[9] += c.y; part[10] += c.z;
         hit = true;
+        hraw |= f == 2;
       }
     }
     if (__ballot(hit) != 0ull) {
@@ -596,11 +600,14 @@ __global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const u
         const float tsum = wave_sum_uniform(part[c]);
         if (lane == src) acc[c] = tsum;
       }
-      if (lane == src) any = true;
+      const bool wraw = __ballot(hraw) != 0ull;
+      if (lane == src) { any = true; raw = wraw; }
     }
   }
   if (any) {
-    float4* dst = reinterpret_cast<float4*>(v_records + (size_t)gi * kRecFloats);
+    // slot 5 of the scalar-cache compositor's tuples is the plain sum of v_sigma: v_opacity = -sum / opacity
+    if (raw) acc[5] *= -__builtin_amdgcn_rcpf(records[(size_t)gi * kRecFloats + 5]);
+    float4* dst = reinterpret_cast<float4*>(v_records + (size_t)gi * kGradFloats);
     dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
     dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
     dst[2] = make_float4(acc[8], acc[9], acc[10], 0.f);
@@ -616,7 +623,8 @@ __global__ __launch_bounds__(256) void reduce_tuples_wave_kernel(int n_slice, co
                                                                  const float* __restrict__ tuples,
                                                                  const unsigned char* __restrict__ flags,
                                                                  float* __restrict__ v_records,
-                                                                 unsigned char* __restrict__ touched) {
+                                                                 unsigned char* __restrict__ touched,
+                                                                 const float* __restrict__ records) {
   const int lane = lane_id();
   const int j = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (j >= n_slice) return;
@@ -625,23 +633,27 @@ __global__ __launch_bounds__(256) void reduce_tuples_wave_kernel(int n_slice, co
   float part[kTupleComp];
 #pragma unroll
   for (int c = 0; c < kTupleComp; ++c) part[c] = 0.f;
-  bool hit = false;
+  bool hit = false, hraw = false;
   for (unsigned i = lane; i < c_n; i += 64) {
-    if (flags[c_e + i]) {
-      const float4* t = reinterpret_cast<const float4*>(tuples + (size_t)(c_e + i) * kRecFloats);
+    const unsigned char f = flags[c_e + i];
+    if (f) {
+      const float4* t = reinterpret_cast<const float4*>(tuples + (size_t)(c_e + i) * kGradFloats);
       float4 a = t[0], b = t[1], c = t[2];
       part[0] += a.x; part[1] += a.y; part[2] += a.z; part[3] += a.w;
       part[4] += b.x; part[5] += b.y; part[6] += b.z; part[7] += b.w; part[8] += c.x; part[9] += c.y; part[10] += c.z;
       hit = true;
+      hraw |= f == 2;
     }
   }
   if (__ballot(hit) == 0ull) return;
+  const bool raw = __ballot(hraw) != 0ull;
   float tot[kTupleComp];
 #pragma unroll
   for (int c = 0; c < kTupleComp; ++c) tot[c] = wave_sum_uniform(part[c]);
   if (lane == 0) {
     const unsigned gi = slice_gi[j];
-    float4* dst = reinterpret_cast<float4*>(v_records + (size_t)gi * kRecFloats);
+    if (raw) tot[5] *= -__builtin_amdgcn_rcpf(records[(size_t)gi * kRecFloats + 5]);
+    float4* dst = reinterpret_cast<float4*>(v_records + (size_t)gi * kGradFloats);
     dst[0] = make_float4(tot[0], tot[1], tot[2], tot[3]);
     dst[1] = make_float4(tot[4], tot[5], tot[6], tot[7]);
     dst[2] = make_float4(tot[8], tot[9], tot[10], 0.f);
@@ -733,16 +745,20 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
 
 // Sum each slice Gaussian's gradient tuples (written by gs_rasterize_bwd_slice with tuples != NULL) into
 // v_records[slice_gi[j]] (plain stores; Gaussians without a touched entry are left as they are).
+// flags[e] == 2 marks tuples of gs_rasterize_bwd_slice's scalar-cache kernel, whose slot 5 is the plain sum of v_sigma:
+// the reduce turns it into the opacity gradient, -sum / records[gi].opacity (flags[e] == 1: slot 5 already is the
+// opacity gradient — gs_rasterize_bwd_rs_slice, the round-1 kernel).
 GS_EXPORT int gs_reduce_grad_tuples(int n_slice, const unsigned* slice_gi, const unsigned* counts,
                                     const unsigned* cum_excl, const float* tuples, const unsigned char* flags,
-                                    float* v_records, unsigned char* touched, long long n_isect, void* stream) {
-  if (n_slice <= 0) return GS_ERR_INVALID;
+                                    float* v_records, unsigned char* touched, long long n_isect, const float* records,
+                                    void* stream) {
+  if (n_slice <= 0 || !records) return GS_ERR_INVALID;
   if (n_isect > 32ll * n_slice)    // few large Gaussians: one wave each
     hipLaunchKernelGGL(reduce_tuples_wave_kernel, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream, n_slice,
-                       slice_gi, counts, cum_excl, tuples, flags, v_records, touched);
+                       slice_gi, counts, cum_excl, tuples, flags, v_records, touched, records);
   else
     hipLaunchKernelGGL(reduce_tuples_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice,
-                       slice_gi, counts, cum_excl, tuples, flags, v_records, touched);
+                       slice_gi, counts, cum_excl, tuples, flags, v_records, touched, records);
   return gs_launch_status();
 }
 

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void raster_bwd_rs_kernel(
           const f4 v = (a0 + a1) + (a2 + a3);
           const float sum = (v.x + v.y) + (v.z + v.w);
           const unsigned e = (unsigned)eids[b + row_g];
-          tuples[(size_t)e * kRecFloats + row_c] = sum;
+          tuples[(size_t)e * kGradFloats + row_c] = sum;
           if (row_c == 0) flags[e] = 1;
         }
         __builtin_amdgcn_wave_barrier();

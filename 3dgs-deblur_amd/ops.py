@@ -25,7 +25,8 @@ import os
 import threading
 
 TILE = 16
-REC = 12  # floats per rasterizer record
+REC = 16   # floats per rasterizer record (gs_math.h kRecFloats)
+GRAD = 12  # floats per gradient record / gradient tuple (kGradFloats)
 MAX_SUBPOSES = 256   # blur samples x rolling-shutter bands per frame (SliceDesc in csrc/binning.hip)
 # kernel variant selector for A/B measurements (0 = default)
 RASTER_FWD_VARIANT = int(os.environ.get("GSD_RASTER_FWD_VARIANT", "0"))
@@ -851,16 +852,16 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                                 RASTER_FWD_VARIANT, _stream()),
                        "rasterize_fwd_slice")
         tuples_k = flags_k = None
-        if prealloc is not None and use_tuples and I_k > 0 and I_k * REC * 4 <= PREALLOC_MAX_BYTES:
+        if prealloc is not None and use_tuples and I_k > 0 and I_k * GRAD * 4 <= PREALLOC_MAX_BYTES:
             # the backward's buffers of this slice (and the frame's, once) are set up HERE, while the GPU works
             # through the compositor just launched: behind the open-tile read-back the host is on the critical path
             # (rest of the forward, loss, backward prologue), and every allocation / fill taken out of that window
             # shortens the GPU's wait for the backward compositor
-            tuples_k = torch.empty(I_k * REC, device=dev)
+            tuples_k = torch.empty(I_k * GRAD, device=dev)
             flags_k = torch.zeros(I_k, dtype=torch.uint8, device=dev)
             if "touched" not in prealloc:
                 prealloc["touched"] = torch.zeros(P * N, dtype=torch.uint8, device=dev)
-                prealloc["v_records"] = torch.empty(P * N, REC, device=dev)
+                prealloc["v_records"] = torch.empty(P * N, GRAD, device=dev)
         if I_k > 0:
             # gated: (event, pinned words, index) of the flag this slice was launched behind — the backward drops the
             # slice if the word says it had nothing to do
@@ -920,7 +921,7 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
             tuples, flags = sl.get("tuples"), sl.get("flags")
             sl["tuples"] = sl["flags"] = None
             if tuples is None:
-                tuples = torch.empty(sl["I"] * REC, device=dev)
+                tuples = torch.empty(sl["I"] * GRAD, device=dev)
                 flags = torch.zeros(sl["I"], dtype=torch.uint8, device=dev)
         if rs is not None:
             with _stage("raster_bwd"):
@@ -946,7 +947,7 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
                 # it sent every slice of a small-splat scene (7 entries per Gaussian) through 64-lane waves
                 _check(L.gs_reduce_grad_tuples(sl["n"], _ptr(sl["slice_gi"]), _ptr(sl["counts"]), _ptr(sl["cum"]),
                                                _ptr(tuples), _ptr(flags), _ptr(v_records), _ptr(touched),
-                                               sl["I"] if sl.get("wave_per_g", True) else 0, _stream()),
+                                               sl["I"] if sl.get("wave_per_g", True) else 0, _ptr(records), _stream()),
                        "reduce_grad_tuples")
 
 
@@ -1088,7 +1089,7 @@ class _RasterizeGaussians(Function):
         L = _L()
         v_img = v_img.contiguous().float()
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
-        v_records = torch.zeros(N, REC, device=dev)
+        v_records = torch.zeros(N, GRAD, device=dev)
         _check(L.gs_rasterize_bwd(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), 1, 1, H, W,
                                   _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), _ptr(v_records), N, _bwd_variant(),
                                   _stream()), "rasterize_bwd")
@@ -1332,7 +1333,7 @@ class _RenderSubposes(Function):
             # the backward's frame-sized buffers are set up here, not in the window between the forward and the backward
             # compositor where the GPU waits for the host (the Python orchestration does the same, see sliced_forward)
             ctx.prealloc = ({"touched": torch.zeros(P * N, dtype=torch.uint8, device=dev),
-                             "v_records": torch.empty(P * N, REC, device=dev)}
+                             "v_records": torch.empty(P * N, GRAD, device=dev)}
                             if (PREALLOC_BWD and any(ctx.needs_input_grad)) else None)
         else:
             out_img, out_T, slices = sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE, color,
@@ -1400,10 +1401,10 @@ class _RenderSubposes(Function):
         if all_tuples and "touched" in pre:
             v_records, touched = pre["v_records"], pre["touched"]
         elif all_tuples:
-            v_records = torch.empty(P * N, REC, device=dev)
+            v_records = torch.empty(P * N, GRAD, device=dev)
             touched = torch.zeros(P * N, dtype=torch.uint8, device=dev)
         else:
-            v_records = torch.zeros(P * N, REC, device=dev)
+            v_records = torch.zeros(P * N, GRAD, device=dev)
             touched = None
 
         if ctx.frame is not None:

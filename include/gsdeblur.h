@@ -389,6 +389,8 @@ int gs_reduce_grad_tuples(int n_slice, const unsigned* slice_gi, const unsigned*
                           const unsigned* cum_excl, const float* tuples, const unsigned char* flags,
                           float* v_records, unsigned char* touched /*[P*N] or NULL: set to 1 where written*/,
                           long long n_isect /*entries of the slice: picks the kernel form*/,
+                          const float* records /*[P*N,16]: flags[e] == 2 (tuples of the scalar-cache kernel) marks slot 5
+                                                 as the plain sum of v_sigma; the reduce divides it by -opacity*/,
                           void* stream);
 
 /* ---- sub-frame averaging in linearised colour (flags train.py:60,62) ---------

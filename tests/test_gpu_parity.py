@@ -318,7 +318,7 @@ def test_binning_keys_and_order_bit_exact(gs, oracle, dev, n, W, H, mult):
     # 2-stage route (depth pre-sort -> emit -> stable tile sort) yields the identical order
     from gsdeblur_amd import ops
     L = gs._lib.load()
-    rec = torch.empty(n, 12, device=dev)
+    rec = torch.empty(n, ops.REC, device=dev)
     dk = torch.empty(n, dtype=torch.int32, device=dev)
     nt2 = torch.empty(n, dtype=torch.int32, device=dev)
     col = torch.rand(n, 3, device=dev)
@@ -1023,7 +1023,7 @@ def test_properties_at_scale(gs, oracle, dev):
     assert torch.isfinite(s1).all() and s1.min() >= 0
     # binning invariants
     N = n
-    rec = torch.empty(N, 12, device=dev)
+    rec = torch.empty(N, ops.REC, device=dev)
     dk = torch.empty(N, dtype=torch.int32, device=dev)
     nt = torch.empty(N, dtype=torch.int32, device=dev)
     gs._lib.check(L.gs_project_fused_fwd(N, 1, ops._ptr(sc["means"]), ops._ptr(scales.contiguous()), 1.0,
@@ -2099,3 +2099,28 @@ def test_model_exact_rolling_shutter_mode(gs, oracle, dev):
     with pytest.raises(ValueError, match="pixel_velocity"):
         bad = gs.SplatfactoDeblurModel.from_scene(gs.SplatfactoDeblurConfig(rolling_shutter_mode="exact"), sc, dev)
         bad.get_outputs_for_camera(cam)
+
+
+@pytest.mark.gpu
+def test_reference_velocity_fixtures_through_the_hip_subposes(gs, dev):
+    """tests/golden/ref_add_velocities.json and ref_combine.json hold camera-frame velocities the REFERENCE computed
+    (render_video.py::add_velocities, combine.py::process; generator: tests/golden/make_reference_fixtures.py).
+    Through the model's pose / velocity handling and gs_subpose_viewmats_fwd — the kernel every frame's sub-poses come
+    from — each frame's pose is carried onto its neighbours' poses; every sign / axis flip fails."""
+    import test_reference_fixtures as RF
+
+    def sub(V, lin, ang, times):
+        return gs.subpose_viewmats(V.to(dev).float(), lin.to(dev).float(), ang.to(dev).float(),
+                                   torch.tensor(times, device=dev, dtype=torch.float32)).cpu()
+    n = 0
+    for tag, c2w, lin, ang, nb in RF.neighbour_cases():
+        RF.check_frame(gs, sub, c2w, lin, ang, nb, tag)
+        n += 1
+    for ci, case in enumerate(RF.combine_cases()):
+        frames = sorted(case["combined_transforms"]["frames"], key=lambda fr: fr["file_path"])
+        for i in range(1, len(frames) - 1):
+            nb = [(-1, frames[i - 1]["transform_matrix"]), (1, frames[i + 1]["transform_matrix"])]
+            RF.check_frame(gs, sub, frames[i]["transform_matrix"], frames[i]["camera_linear_velocity"],
+                           frames[i]["camera_angular_velocity"], nb, f"combine{ci}/frame{i}")
+            n += 1
+    assert n >= 20

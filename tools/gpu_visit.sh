@@ -1,0 +1,64 @@
+#!/bin/bash
+# One GPU-box visit, parametrised (replaces the round-3 one-off recipes).  Usage, from the repo root on the GPU box:
+#   bash tools/gpu_visit.sh <tag> [steps...]      steps: suite | tests:<pytest -k expr> | smoke | bench | benchq | ab:<ENV=V,...>
+#                                                        | prof | pmc | prof_trained | final
+# Everything lands in gpurun_out/<tag>/; a summary is printed at the end.
+set -u
+TAG=${1:-visit}; shift || true
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+S=$OUT/summary.log
+: > $S
+benchline() { python - "$1" "$2" <<'PY'
+import json, sys
+tag, path = sys.argv[1], sys.argv[2]
+for l in open(path):
+    if l.startswith('{'):
+        d = json.loads(l)
+        sec = d['config'].get('secondary') or {}
+        print(tag, 'ms', d['ms_per_step'], 'MPix/s', d['value'], 'stages', d.get('stage_ms'), 'slices', d['config'].get('depth_slices'))
+        if sec:
+            print(tag, 'secondary ms', sec.get('ms_per_step'), 'stages', sec.get('stage_ms'), 'slices', sec.get('depth_slices'))
+PY
+}
+for step in "$@"; do
+  echo "== $step ==" | tee -a $S
+  case $step in
+    suite)
+      timeout 1700 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 --tb=short > $OUT/pytest_gpu.log 2>&1
+      grep -E "^FAILED|^ERROR|passed|failed" $OUT/pytest_gpu.log | tail -60 | tee -a $S ;;
+    tests:*)
+      timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 --tb=short -k "${step#tests:}" > $OUT/pytest_sel.log 2>&1
+      grep -E "^FAILED|^ERROR|passed|failed" $OUT/pytest_sel.log | tail -40 | tee -a $S ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log | tee -a $S ;;
+    bench)
+      timeout 600 python bench.py > $OUT/bench.log 2>&1; grep '^{' $OUT/bench.log > $OUT/bench.json; benchline bench $OUT/bench.json | tee -a $S ;;
+    benchq)
+      for v in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/benchq$v.log 2>&1; benchline benchq$v $OUT/benchq$v.log | tee -a $S; done ;;
+    ab:*)
+      envs=$(echo "${step#ab:}" | tr ',' ' ')
+      for v in 1 2; do
+        timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/ab_base$v.log 2>&1; benchline base$v $OUT/ab_base$v.log | tee -a $S
+        env $envs timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/ab_alt$v.log 2>&1; benchline "alt$v($envs)" $OUT/ab_alt$v.log | tee -a $S
+      done ;;
+    prof|prof_trained)
+      extra=""; [ $step = prof_trained ] && extra="--scene trained"
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/$step -o trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary $extra) > $OUT/$step.log 2>&1
+      for f in $(find $OUT/$step -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_$step.csv; head -24 $f | cut -c1-200 | tee -a $S; done
+      [ $step = prof ] && python tools/trace_step.py $OUT/prof > $OUT/timeline.txt 2>/dev/null && tail -1 $OUT/timeline.txt | tee -a $S
+      rm -rf $OUT/$step/*/*kernel_trace* 2>/dev/null ;;
+    pmc)
+      for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR"; do
+        t=$(echo $pmc | cut -d' ' -f1)
+        (cd /tmp && timeout 600 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $R/$OUT/pmc_$t -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary) > $OUT/pmc_$t.log 2>&1
+        tail -1 $OUT/pmc_$t.log | cut -c1-200 | tee -a $S
+      done
+      python tools/pmc_summary.py $OUT 2>&1 | tail -40 | tee -a $S
+      python tools/make_traffic.py $OUT "round 4 $TAG" > $OUT/traffic.json 2>/dev/null; head -c 600 $OUT/traffic.json | tee -a $S ;;
+    *) echo "unknown step $step" | tee -a $S ;;
+  esac
+done
+echo "== done ==" | tee -a $S
