@@ -20,17 +20,17 @@ _SIGS = {
     "gs_sh_fwd": [_I, _I, _I, _P, _P, _P, _P],
     "gs_sh_bwd": [_I, _I, _I, _P, _P, _P, _P],
     "gs_project_fused_fwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I, _I,
-                             _P, _P, _P, _P, _P],
-    "gs_slice_colors": [_I, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P],
+                             _P, _P, _P, _P, _P, _I, _P],
+    "gs_slice_colors": [_I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P],
     "gs_project_fused_bwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I,
-                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P],
     "gs_project_pixvel_fwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P, _P, _F, _F, _F, _F, _I, _I, _F, _I, _I,
-                              _P, _P, _P, _P, _F, _P, _P],
+                              _P, _P, _P, _P, _F, _P, _P, _I, _P],
     "gs_rasterize_fwd_rs_slice": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _F, _P],
     "gs_rasterize_bwd_rs_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _F, _F,
                                   _P, _I, _F, _P],
     "gs_project_pixvel_bwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P, _P, _F, _F, _F, _F, _I, _I, _F, _I,
-                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P],
     "gs_pack_records": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "gs_unpack_record_grads": [_I, _P, _P, _P, _P, _P, _P],
     "gs_exclusive_scan_u32": [_L, _P, _P, _P, _P, _L, _P],
@@ -72,7 +72,7 @@ _SIGS = {
     "gs_dp_scatter_add_rows": [_L, _P, _I, _P, _P, _F, _P],
     "gs_dp_pack_masked_rows": [_I, _P, _P, _I, _P, _I, _P, _P, _P, _P],
     "gs_dp_scatter_add_payload": [_I, _P, _I, _P, _P, _F, _P],
-    "gs_frame_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P],
+    "gs_frame_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P],
     "gs_frame_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _L, _P],
     "gs_frame_profile_enable": [ctypes.c_uint],
     "gs_sort_set_single_pass": [_I],

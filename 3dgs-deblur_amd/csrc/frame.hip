@@ -206,7 +206,8 @@ GS_EXPORT long long gs_frame_backward_bytes(const gs_frame_state* state) {
 // the frame needs as far as it is known (call again with a larger arena and FRESH projection outputs).
 GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned* depth_keys, const int* num_tiles_hit,
                                const float* background, const int* band_edges, const unsigned char* band_tile_done,
-                               const float* color_means, const float* color_sh, int color_K, int color_degree,
+                               const float* color_means, const float* color_sh, const float* color_sh_rest, int color_K,
+                               int color_degree,
                                const float* color_viewmats, const float* pix_vel, float* out_img, float* out_T,
                                float* out_depth, void* arena_ptr, long long arena_bytes, void* host_pinned, long long host_pinned_bytes,
                                gs_frame_state* state, void* stream_) {
@@ -435,7 +436,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
       CHECK(gs_exclusive_scan_u32(n_k, counts, cum_k, total_k, ws, ws_b, st));
       if (color_means && color_sh && color_viewmats)
         // deferred SH colour for exactly the Gaussians this slice emits
-        CHECK(gs_slice_colors((int)n_k, slice_gi, counts, N, color_means, color_sh, color_K, color_degree,
+        CHECK(gs_slice_colors((int)n_k, slice_gi, counts, N, color_means, color_sh, color_sh_rest, color_K, color_degree,
                               color_viewmats, records, st));
     }
     if (I_k > 0) {

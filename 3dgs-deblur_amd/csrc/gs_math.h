@@ -73,8 +73,15 @@ struct Proj {
 GS_HD void rec_aux(float op, float conic_x, float conic_z, float out[4]) {
   float nmid = -1.0f, kmul = 0.0f;
   if (op >= K::kAlphaMin) {              // (NaN and op < 1/255: never blended)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // hardware transcendentals (1 ulp): the compositor only needs nmid and kmul to be consistent with each other
+    // (alpha = kmul * 2^(s2 + nmid) = op * 2^s2), and 1e-7 relative on the position of the alpha = 1/255 edge
+    nmid = 0.5f * __builtin_amdgcn_logf(255.0f * op);
+    kmul = op * __builtin_amdgcn_exp2f(-nmid);
+#else
     nmid = 0.5f * log2f(255.0f * op);
     kmul = op * exp2f(-nmid);
+#endif
   }
   out[0] = nmid; out[1] = kmul; out[2] = conic_x * (0.5f * kNegLog2e); out[3] = conic_z * (0.5f * kNegLog2e);
 }

@@ -265,7 +265,32 @@ struct FusedParams {
   // widens the tile box by the sweep and hands out pv [N,2]; the backward takes d loss / d pv from v_records[9..10]
   float rs_half;
   float* pix_vel_out;
+  // round 4: the caller's RAW parameters (splatfacto stores log-scales, opacity logits and the SH coefficients as
+  // features_dc [N,3] + features_rest [N,K-1,3]) are taken as they are — no exp / sigmoid / cat launches in front of
+  // the projection, no backward launches of theirs behind it:
+  //   act bit 0: `scales` holds log-scales (scale = exp), bit 1: `opacities` holds logits (opacity = sigmoid);
+  //   sh_rest != null: `sh` is features_dc [N,3] and sh_rest features_rest [N,K_stride-1,3].
+  // The backward returns the gradients of what was handed in (d/d log-scale = d/d scale * scale, d/d logit =
+  // d/d opacity * opacity (1 - opacity); v_sh / v_sh_rest split the same way).
+  int act;
+  const float* sh_rest;
 };
+constexpr int GS_ACT_LOG_SCALES = 1, GS_ACT_OPACITY_LOGITS = 2;
+
+__device__ __forceinline__ void load_scales(const FusedParams& fp, int i, float s[3]) {
+  s[0] = fp.scales[3 * i]; s[1] = fp.scales[3 * i + 1]; s[2] = fp.scales[3 * i + 2];
+  if (fp.act & GS_ACT_LOG_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
+}
+__device__ __forceinline__ float load_opacity(const FusedParams& fp, int i) {
+  const float o = fp.opacities[i];
+  return (fp.act & GS_ACT_OPACITY_LOGITS) ? 1.0f / (1.0f + expf(-o)) : o;
+}
+// coefficient row of Gaussian i as two runs: c0 = basis 0 (3 floats), c1 = bases 1.. ((K_stride-1)*3 floats)
+__device__ __forceinline__ void sh_rows(const float* __restrict__ sh, const float* __restrict__ sh_rest, int K_stride,
+                                        size_t i, const float*& c0, const float*& c1) {
+  if (sh_rest) { c0 = sh + i * 3; c1 = sh_rest + i * (size_t)(K_stride - 1) * 3; }
+  else { c0 = sh + i * (size_t)K_stride * 3; c1 = c0 + 3; }
+}
 
 constexpr int GS_FLAG_UPSTREAM_FOV_CLAMP_GRAD = 1;   // back-propagate through the fov clamp as if inactive
 constexpr int GS_FLAG_RAW_QUAT_GRAD = 2;             // no projection of the quaternion gradient through q/|q|
@@ -281,18 +306,20 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= fp.N) return;
   float m[3] = {fp.means[3 * i], fp.means[3 * i + 1], fp.means[3 * i + 2]};
-  float s[3] = {fp.scales[3 * i], fp.scales[3 * i + 1], fp.scales[3 * i + 2]};
+  float s[3];
+  load_scales(fp, i, s);
   float q[4] = {fp.quats[4 * i], fp.quats[4 * i + 1], fp.quats[4 * i + 2], fp.quats[4 * i + 3]};
-  float opac = fp.opacities[i];
+  float opac = load_opacity(fp, i);
   float R[9], qn[4], inv, M[9], c3[6];
   quat_to_rotmat(q, R, qn, &inv);
   scale_rot_to_cov3d(s, fp.glob, R, M, c3);
   const int nb = (fp.deg + 1) * (fp.deg + 1);
   float coef[DEFER ? 1 : MAXB * 3];
   if (!DEFER) {
-    const float* c = fp.sh + (size_t)i * fp.K_stride * 3;
+    const float *c0, *c1;
+    sh_rows(fp.sh, fp.sh_rest, fp.K_stride, (size_t)i, c0, c1);
 #pragma unroll
-    for (int k = 0; k < MAXB * 3; ++k) coef[DEFER ? 0 : k] = (k < nb * 3) ? c[k] : 0.f;
+    for (int k = 0; k < MAXB * 3; ++k) coef[DEFER ? 0 : k] = (k < nb * 3) ? (k < 3 ? c0[k] : c1[k - 3]) : 0.f;
   }
   // pixel-velocity model: geometry of the mid-exposure pose once, then one re-centred record per sub-pose
   Proj o0; ProjCtx k0;
@@ -383,19 +410,30 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
 
 // Body shared by the two launch shapes below: Gaussian `i` of this thread (`live` false = idle lane that only
 // takes part in the block reductions).  MUST be called block-uniformly (it contains barriers).
+// gradient outputs of the fused projection backward (v_sh_rest non-null: v_sh is [N,3], v_sh_rest [N,K_stride-1,3])
+struct FusedOut {
+  float* v_means; float* v_scales; float* v_quats; float* v_opac; float* v_sh; float* v_sh_rest;
+  float* v_viewmats;      // [P,16] accumulated, may be null
+  float* v_xy_sum;        // [N,2] or null
+  float* v_twist;         // [12] accumulated, pixel-velocity model, may be null
+};
+
 template <int MAXB>
 __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const float* __restrict__ records,
-    const float* __restrict__ v_records, float* __restrict__ v_means, float* __restrict__ v_scales,
-    float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
-    float* __restrict__ v_viewmats, const unsigned char* __restrict__ touched, float* __restrict__ v_xy_sum,
-    int i, bool live, float* lds, float* __restrict__ v_twist = nullptr) {
+    const float* __restrict__ v_records, const FusedOut& out, const unsigned char* __restrict__ touched,
+    int i, bool live, float* lds) {
+  float* __restrict__ v_means = out.v_means; float* __restrict__ v_scales = out.v_scales;
+  float* __restrict__ v_quats = out.v_quats; float* __restrict__ v_opac = out.v_opac;
+  float* __restrict__ v_sh = out.v_sh; float* __restrict__ v_sh_rest = out.v_sh_rest;
+  float* __restrict__ v_viewmats = out.v_viewmats; float* __restrict__ v_xy_sum = out.v_xy_sum;
+  float* __restrict__ v_twist = out.v_twist;
   const int ii = live ? i : 0;
   float m[3] = {0.f, 0.f, 1.f}, s[3] = {1.f, 1.f, 1.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, opac = 0.f;
   if (live) {
     m[0] = fp.means[3 * ii]; m[1] = fp.means[3 * ii + 1]; m[2] = fp.means[3 * ii + 2];
-    s[0] = fp.scales[3 * ii]; s[1] = fp.scales[3 * ii + 1]; s[2] = fp.scales[3 * ii + 2];
+    load_scales(fp, ii, s);
     q[0] = fp.quats[4 * ii]; q[1] = fp.quats[4 * ii + 1]; q[2] = fp.quats[4 * ii + 2]; q[3] = fp.quats[4 * ii + 3];
-    opac = fp.opacities[ii];
+    opac = load_opacity(fp, ii);
   }
   float R[9], qn[4], inv, M[9], c3[6];
   quat_to_rotmat(q, R, qn, &inv);
@@ -523,16 +561,21 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
   if (!live) return;
   float vs[3], vq[4];
   cov3d_bwd(s, fp.glob, q, vc3, vs, vq, (fp.flags & GS_FLAG_RAW_QUAT_GRAD) != 0);
+  if (fp.act & GS_ACT_LOG_SCALES) { vs[0] *= s[0]; vs[1] *= s[1]; vs[2] *= s[2]; }
+  if (fp.act & GS_ACT_OPACITY_LOGITS) vop *= opac * (1.0f - opac);
   for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = vm[j]; v_scales[3 * i + j] = vs[j]; }
   for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = vq[j];
   v_opac[i] = vop;
   if (v_xy_sum) { v_xy_sum[2 * i] = vxs; v_xy_sum[2 * i + 1] = vys; }
-  float* c = v_sh + (size_t)i * fp.K_stride * 3;
+  // (v_sh_rest travels in v_sh's slot of FusedOut; the rows split like the inputs)
+  float *c0, *c1;
+  if (v_sh_rest) { c0 = v_sh + (size_t)i * 3; c1 = v_sh_rest + (size_t)i * (fp.K_stride - 1) * 3; }
+  else { c0 = v_sh + (size_t)i * fp.K_stride * 3; c1 = c0 + 3; }
   const int kn = fp.K_stride * 3;
 #pragma unroll
   for (int k = 0; k < MAXB * 3; ++k)   // static indices only: a runtime index would push vcoef to scratch
-    if (k < kn) c[k] = vcoef[k];
-  for (int k = MAXB * 3; k < kn; ++k) c[k] = 0.f;
+    if (k < kn) { if (k < 3) c0[k] = vcoef[k]; else c1[k - 3] = vcoef[k]; }
+  for (int k = MAXB * 3; k < kn; ++k) c1[k - 3] = 0.f;
 }
 
 // ---------------------------------------------------------------------------
@@ -549,7 +592,8 @@ __device__ __forceinline__ void needle_item_se3(const FusedParams& fp, const flo
 #pragma unroll
   for (int j = 0; j < 9; ++j) out[j] = 0.0;
   if (touched && !touched[(size_t)p * fp.N + i]) return;
-  const float s[3] = {fp.scales[3 * i], fp.scales[3 * i + 1], fp.scales[3 * i + 2]};
+  float s[3];
+  load_scales(fp, i, s);
   const float m[3] = {fp.means[3 * i], fp.means[3 * i + 1], fp.means[3 * i + 2]};
   const float q[4] = {fp.quats[4 * i], fp.quats[4 * i + 1], fp.quats[4 * i + 2], fp.quats[4 * i + 3]};
   // fp32 covariance for the culling decisions (exactly what the forward took), double covariance for the chain
@@ -575,7 +619,7 @@ __device__ __forceinline__ void needle_item_se3(const FusedParams& fp, const flo
   const float4* g4 = reinterpret_cast<const float4*>(v_records + idx * kGradFloats);
   const float4 ga = g4[0], gb = g4[1];
   const double vxy[2] = {ga.x, ga.y}, vcon[3] = {ga.z, ga.w, gb.x};
-  const double v_comp = fp.antialiased ? (double)gb.y * (double)fp.opacities[i] : 0.0;
+  const double v_comp = fp.antialiased ? (double)gb.y * (double)load_opacity(fp, i) : 0.0;
   double vV[12];
   project_one_bwd_t<double>(m, c3d, Vm, fp.in.fx, fp.in.fy, kd, comp, vxy, 0.0, vcon, v_comp, out, out + 3, vV, nullptr,
                             (fp.flags & GS_FLAG_UPSTREAM_FOV_CLAMP_GRAD) != 0);
@@ -587,10 +631,11 @@ __device__ __forceinline__ void needle_item_pixvel(const FusedParams& fp, const 
                                                    const unsigned char* __restrict__ touched, int i, double out[9]) {
 #pragma unroll
   for (int j = 0; j < 9; ++j) out[j] = 0.0;
-  const float s[3] = {fp.scales[3 * i], fp.scales[3 * i + 1], fp.scales[3 * i + 2]};
+  float s[3];
+  load_scales(fp, i, s);
   const float m[3] = {fp.means[3 * i], fp.means[3 * i + 1], fp.means[3 * i + 2]};
   const float q[4] = {fp.quats[4 * i], fp.quats[4 * i + 1], fp.quats[4 * i + 2], fp.quats[4 * i + 3]};
-  const float opac = fp.opacities[i];
+  const float opac = load_opacity(fp, i);
   float R[9], qn[4], inv, M[9], c3[6];
   quat_to_rotmat(q, R, qn, &inv);
   scale_rot_to_cov3d(s, fp.glob, R, M, c3);
@@ -665,9 +710,11 @@ __global__ __launch_bounds__(256) void project_needle_hp_kernel(FusedParams fp, 
       for (int j = 0; j < 8 && i0 + j < fp.N; ++j) {
         if (((any >> (8 * j)) & 0xFFull) == 0ull) continue;
         const int i = i0 + j;
+        // (log-scales: the ratio test in the log domain needs no exp)
         const float s0 = fp.scales[3 * i], s1 = fp.scales[3 * i + 1], s2 = fp.scales[3 * i + 2];
         const float smax = fmaxf(s0, fmaxf(s1, s2)), smin = fminf(s0, fminf(s1, s2));
-        if (smax > ratio_limit * smin) list[atomicAdd(&n_list, 1)] = i;
+        const bool needle = (fp.act & GS_ACT_LOG_SCALES) ? (smax - smin > __logf(ratio_limit)) : (smax > ratio_limit * smin);
+        if (needle) list[atomicAdd(&n_list, 1)] = i;
       }
     }
   }
@@ -693,10 +740,12 @@ __global__ __launch_bounds__(256) void project_needle_hp_kernel(FusedParams fp, 
       for (int pp = 0; pp < items_per; ++pp)
 #pragma unroll
         for (int j = 0; j < 9; ++j) acc[j] += part[threadIdx.x * items_per + pp][j];
-      const float s[3] = {fp.scales[3 * i], fp.scales[3 * i + 1], fp.scales[3 * i + 2]};
+      float s[3];
+  load_scales(fp, i, s);
       const float q[4] = {fp.quats[4 * i], fp.quats[4 * i + 1], fp.quats[4 * i + 2], fp.quats[4 * i + 3]};
       double vs[3], vq[4];
       cov3d_bwd_t<double>(s, fp.glob, q, acc + 3, vs, vq, (fp.flags & GS_FLAG_RAW_QUAT_GRAD) != 0);
+      if (fp.act & GS_ACT_LOG_SCALES) { vs[0] *= (double)s[0]; vs[1] *= (double)s[1]; vs[2] *= (double)s[2]; }
       for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = (float)acc[j]; v_scales[3 * i + j] = (float)vs[j]; }
       for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = (float)vq[j];
     }
@@ -707,33 +756,59 @@ __global__ __launch_bounds__(256) void project_needle_hp_kernel(FusedParams fp, 
 // dense launch: one thread per Gaussian (no touched flags: every Gaussian gets its gradient written)
 template <int MAXB>
 __global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, const float* __restrict__ records,
-    const float* __restrict__ v_records, float* __restrict__ v_means, float* __restrict__ v_scales,
-    float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
-    float* __restrict__ v_viewmats /* [P,16] accumulated, may be null */, float* __restrict__ v_xy_sum,
-    float* __restrict__ v_twist) {
+    const float* __restrict__ v_records, FusedOut out) {
   __shared__ float lds[48];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  fused_bwd_body<MAXB>(fp, records, v_records, v_means, v_scales, v_quats, v_opac, v_sh, v_viewmats, nullptr,
-                       v_xy_sum, i, i < fp.N, lds, v_twist);
+  fused_bwd_body<MAXB>(fp, records, v_records, out, nullptr, i, i < fp.N, lds);
 }
 
-// sparse launch (touched flags; the caller pre-zeroes every output): under early termination ~1 % of the
-// Gaussians carry a gradient and they are scattered, so with one thread per Gaussian nearly every wave ran
-// the whole body for one or two lanes.  A block owns kFusedChunk consecutive Gaussians, compacts the ids of
-// the touched ones into LDS (ballot + prefix, deterministic order) and runs the body on dense rounds of 256.
+// sparse launch (touched flags): under early termination ~1 % of the Gaussians carry a gradient and they are
+// scattered, so with one thread per Gaussian nearly every wave ran the whole body for one or two lanes.  A block owns
+// kFusedChunk consecutive Gaussians, compacts the ids of the touched ones into LDS (ballot + prefix, deterministic
+// order) and runs the body on dense rounds of 256.
+// ZERO_FILL (round 4): the block first zero-fills ITS rows of the five (six) gradient arrays and of v_xy_sum with
+// coalesced 16-byte stores — the caller hands over uninitialised buffers and launches no fills of its own (one 236 MB
+// fill + one per small output in round 3); without it the caller pre-zeroes every output.
 constexpr int kFusedChunk = 2048;
 
-template <int MAXB>
+__device__ __forceinline__ void zero_rows(float* __restrict__ base, size_t first, size_t count) {
+  // floats [first, first + count) of `base`: leading / trailing floats singly, the 16-byte-aligned middle as float4
+  if (!base || count == 0) return;
+  float* p = base + first;
+  const size_t mis = ((reinterpret_cast<uintptr_t>(p) & 15u) != 0) ? ((16u - (reinterpret_cast<uintptr_t>(p) & 15u)) >> 2) : 0;
+  const size_t head = mis < count ? mis : count;
+  for (size_t k = threadIdx.x; k < head; k += blockDim.x) p[k] = 0.f;
+  const size_t n4 = (count - head) >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p + head);
+  for (size_t k = threadIdx.x; k < n4; k += blockDim.x) p4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (size_t k = head + 4 * n4 + threadIdx.x; k < count; k += blockDim.x) p[k] = 0.f;
+}
+
+template <int MAXB, bool ZERO_FILL>
 __global__ __launch_bounds__(256) void project_fused_bwd_sparse_kernel(FusedParams fp,
-    const float* __restrict__ records, const float* __restrict__ v_records, float* __restrict__ v_means,
-    float* __restrict__ v_scales, float* __restrict__ v_quats, float* __restrict__ v_opac, float* __restrict__ v_sh,
-    float* __restrict__ v_viewmats, const unsigned char* __restrict__ touched /* [P*N] */,
-    float* __restrict__ v_xy_sum, float* __restrict__ v_twist) {
+    const float* __restrict__ records, const float* __restrict__ v_records, FusedOut out,
+    const unsigned char* __restrict__ touched /* [P*N] */) {
   __shared__ float lds[48];
   __shared__ int list[kFusedChunk];
   __shared__ int wave_cnt[4];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const int base = blockIdx.x * kFusedChunk;
+  if (ZERO_FILL) {
+    const size_t g0 = (size_t)base, cnt = (size_t)min(kFusedChunk, fp.N - base);
+    zero_rows(out.v_means, 3 * g0, 3 * cnt);
+    zero_rows(out.v_scales, 3 * g0, 3 * cnt);
+    zero_rows(out.v_quats, 4 * g0, 4 * cnt);
+    zero_rows(out.v_opac, g0, cnt);
+    if (out.v_sh_rest) {
+      zero_rows(out.v_sh, 3 * g0, 3 * cnt);
+      zero_rows(out.v_sh_rest, (size_t)(fp.K_stride - 1) * 3 * g0, (size_t)(fp.K_stride - 1) * 3 * cnt);
+    } else {
+      zero_rows(out.v_sh, (size_t)fp.K_stride * 3 * g0, (size_t)fp.K_stride * 3 * cnt);
+    }
+    zero_rows(out.v_xy_sum, 2 * g0, 2 * cnt);
+    // the rows of this block's touched Gaussians are written again below, by other threads of the block
+    __threadfence_block();
+  }
   int n_list = 0;
   for (int r = 0; r < kFusedChunk / 256; ++r) {
     const int g = base + r * 256 + (int)threadIdx.x;
@@ -753,8 +828,7 @@ __global__ __launch_bounds__(256) void project_fused_bwd_sparse_kernel(FusedPara
   for (int k0 = 0; k0 < n_list; k0 += 256) {
     const int k = k0 + (int)threadIdx.x;
     const bool live = k < n_list;
-    fused_bwd_body<MAXB>(fp, records, v_records, v_means, v_scales, v_quats, v_opac, v_sh, v_viewmats, touched,
-                         v_xy_sum, live ? list[k] : 0, live, lds, v_twist);
+    fused_bwd_body<MAXB>(fp, records, v_records, out, touched, live ? list[k] : 0, live, lds);
   }
 }
 
@@ -774,7 +848,8 @@ template <int MAXB>
 __global__ __launch_bounds__(256) void slice_colors_kernel(int n_slice, const unsigned* __restrict__ slice_gi,
                                                            const unsigned* __restrict__ counts, int N,
                                                            const float* __restrict__ means,
-                                                           const float* __restrict__ sh, int K_stride, int deg,
+                                                           const float* __restrict__ sh,
+                                                           const float* __restrict__ sh_rest, int K_stride, int deg,
                                                            const float* __restrict__ viewmats,
                                                            float* __restrict__ records) {
   constexpr int kRow = MAXB * 3 + 1;                       // odd stride (49 / 76 -> 77): lane l reads bank (l*kRow + k) % 32
@@ -795,9 +870,11 @@ __global__ __launch_bounds__(256) void slice_colors_kernel(int n_slice, const un
     const unsigned g_r = (unsigned)__shfl((int)g, r);
     const int act_r = __shfl((int)active, r);
     if (act_r) {
-      const float* c = sh + (size_t)g_r * K_stride * 3;
+      const float *r0, *r1;
+      sh_rows(sh, sh_rest, K_stride, (size_t)g_r, r0, r1);
       for (int b = q; b < nb; b += 16) {
-        const float c0 = c[3 * b], c1 = c[3 * b + 1], c2 = c[3 * b + 2];
+        const float* c = b == 0 ? r0 : r1 + 3 * (b - 1);
+        const float c0 = c[0], c1 = c[1], c2 = c[2];
         float* d = rows + r * kRowPad + 3 * b;
         d[0] = c0; d[1] = c1; d[2] = c2;
       }
@@ -928,6 +1005,7 @@ static inline FusedParams make_fused(int N, int P, const float* means, const flo
   fp.skip_culled = (defer_color >> 1) & 1;
   fp.in = make_intrin(fx, fy, cx, cy, H, W, clip);
   fp.pixvel = 0; fp.twist = nullptr; fp.times = nullptr; fp.flags = 0; fp.rs_half = 0.f; fp.pix_vel_out = nullptr;
+  fp.act = 0; fp.sh_rest = nullptr;
   return fp;
 }
 
@@ -937,11 +1015,13 @@ GS_EXPORT int gs_project_fused_fwd(int N, int P, const float* means, const float
                                    const float* quats, const float* opacities, const float* sh, int K_stride,
                                    int sh_degree, const float* viewmats, float fx, float fy, float cx, float cy,
                                    int H, int W, float clip, int antialiased, int defer_color, float* records,
-                                   unsigned* depth_keys, int* num_tiles_hit, int* radii, void* stream) {
+                                   unsigned* depth_keys, int* num_tiles_hit, int* radii, const float* sh_rest,
+                                   int param_flags, void* stream) {
   if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride)
     return GS_ERR_INVALID;
   FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmats,
                               fx, fy, cx, cy, H, W, clip, antialiased, defer_color);
+  fp.act = param_flags; fp.sh_rest = sh_rest;
   dim3 grid((N + 255) / 256), block(256);
   if (fp.defer_color)       // the SH degree plays no part: one instantiation
     hipLaunchKernelGGL((project_fused_fwd_kernel<16, true>), grid, block, 0, (hipStream_t)stream, fp, records,
@@ -958,49 +1038,50 @@ GS_EXPORT int gs_project_fused_fwd(int N, int P, const float* means, const float
 // Colours (rgb = max(SH + 0.5, 0)) of the slice Gaussians with counts[j] > 0, written into their records;
 // pairs with gs_project_fused_fwd(defer_color = 1).
 GS_EXPORT int gs_slice_colors(int n_slice, const unsigned* slice_gi, const unsigned* counts, int N,
-                              const float* means, const float* sh, int K_stride, int sh_degree,
+                              const float* means, const float* sh, const float* sh_rest, int K_stride, int sh_degree,
                               const float* viewmats, float* records, void* stream) {
   if (n_slice <= 0 || N <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride)
     return GS_ERR_INVALID;
   if (sh_degree <= 3) {
     const int th = 64 * slice_colors_waves<16>();
     hipLaunchKernelGGL(slice_colors_kernel<16>, dim3((n_slice + th - 1) / th), dim3(th), 0, (hipStream_t)stream,
-                       n_slice, slice_gi, counts, N, means, sh, K_stride, sh_degree, viewmats, records);
+                       n_slice, slice_gi, counts, N, means, sh, sh_rest, K_stride, sh_degree, viewmats, records);
   } else {
     const int th = 64 * slice_colors_waves<25>();
     hipLaunchKernelGGL(slice_colors_kernel<25>, dim3((n_slice + th - 1) / th), dim3(th), 0, (hipStream_t)stream,
-                       n_slice, slice_gi, counts, N, means, sh, K_stride, sh_degree, viewmats, records);
+                       n_slice, slice_gi, counts, N, means, sh, sh_rest, K_stride, sh_degree, viewmats, records);
   }
   return gs_launch_status();
 }
 
+constexpr int GS_FLAG_ZERO_FILL = 32;     // sparse backward: zero-fill the dense gradient outputs in the kernel itself
+
 static int launch_fused_bwd(const FusedParams& fp, int sh_degree, const float* records, const float* v_records,
-                            float* v_means, float* v_scales, float* v_quats, float* v_opacities, float* v_sh,
-                            float* v_viewmats, const unsigned char* touched, float* v_xy_sum, float* v_twist,
-                            hipStream_t st) {
+                            const FusedOut& out, const unsigned char* touched, hipStream_t st) {
   dim3 block(256);
   const int N = fp.N;
   if (touched) {
     dim3 grid((N + kFusedChunk - 1) / kFusedChunk);
-    if (sh_degree <= 3)
-      hipLaunchKernelGGL(project_fused_bwd_sparse_kernel<16>, grid, block, 0, st, fp, records, v_records, v_means,
-                         v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched, v_xy_sum, v_twist);
+    const bool zf = (fp.flags & GS_FLAG_ZERO_FILL) != 0;
+    if (sh_degree <= 3 && zf)
+      hipLaunchKernelGGL((project_fused_bwd_sparse_kernel<16, true>), grid, block, 0, st, fp, records, v_records, out, touched);
+    else if (sh_degree <= 3)
+      hipLaunchKernelGGL((project_fused_bwd_sparse_kernel<16, false>), grid, block, 0, st, fp, records, v_records, out, touched);
+    else if (zf)
+      hipLaunchKernelGGL((project_fused_bwd_sparse_kernel<25, true>), grid, block, 0, st, fp, records, v_records, out, touched);
     else
-      hipLaunchKernelGGL(project_fused_bwd_sparse_kernel<25>, grid, block, 0, st, fp, records, v_records, v_means,
-                         v_scales, v_quats, v_opacities, v_sh, v_viewmats, touched, v_xy_sum, v_twist);
+      hipLaunchKernelGGL((project_fused_bwd_sparse_kernel<25, false>), grid, block, 0, st, fp, records, v_records, out, touched);
   } else {
     dim3 grid((N + 255) / 256);
     if (sh_degree <= 3)
-      hipLaunchKernelGGL(project_fused_bwd_kernel<16>, grid, block, 0, st, fp, records, v_records, v_means, v_scales,
-                         v_quats, v_opacities, v_sh, v_viewmats, v_xy_sum, v_twist);
+      hipLaunchKernelGGL(project_fused_bwd_kernel<16>, grid, block, 0, st, fp, records, v_records, out);
     else
-      hipLaunchKernelGGL(project_fused_bwd_kernel<25>, grid, block, 0, st, fp, records, v_records, v_means, v_scales,
-                         v_quats, v_opacities, v_sh, v_viewmats, v_xy_sum, v_twist);
+      hipLaunchKernelGGL(project_fused_bwd_kernel<25>, grid, block, 0, st, fp, records, v_records, out);
   }
   if (!(fp.flags & GS_FLAG_NO_NEEDLE_HP))
     // needles (scale ratio above kNeedleRatio) get their means / scales / quaternion gradients again, in double
     hipLaunchKernelGGL(project_needle_hp_kernel, dim3((N + kNeedleChunk - 1) / kNeedleChunk), dim3(256), 0, st, fp, records,
-                       v_records, v_means, v_scales, v_quats, touched, kNeedleRatio);
+                       v_records, out.v_means, out.v_scales, out.v_quats, touched, kNeedleRatio);
   return gs_launch_status();
 }
 
@@ -1013,14 +1094,16 @@ GS_EXPORT int gs_project_fused_bwd(int N, int P, const float* means, const float
                                    int H, int W, float clip, int antialiased, const float* records,
                                    const float* v_records, float* v_means, float* v_scales, float* v_quats,
                                    float* v_opacities, float* v_sh, float* v_viewmats,
-                                   const unsigned char* touched, float* v_xy_sum, int grad_flags, void* stream) {
-  if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride)
+                                   const unsigned char* touched, float* v_xy_sum, int grad_flags, const float* sh_rest,
+                                   int param_flags, float* v_sh_rest, void* stream) {
+  if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride ||
+      (sh_rest != nullptr) != (v_sh_rest != nullptr) || ((grad_flags & GS_FLAG_ZERO_FILL) && !touched))
     return GS_ERR_INVALID;
   FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmats,
                               fx, fy, cx, cy, H, W, clip, antialiased);
-  fp.flags = grad_flags;
-  return launch_fused_bwd(fp, sh_degree, records, v_records, v_means, v_scales, v_quats, v_opacities, v_sh, v_viewmats,
-                          touched, v_xy_sum, nullptr, (hipStream_t)stream);
+  fp.flags = grad_flags; fp.act = param_flags; fp.sh_rest = sh_rest;
+  const FusedOut out = {v_means, v_scales, v_quats, v_opacities, v_sh, v_sh_rest, v_viewmats, v_xy_sum, nullptr};
+  return launch_fused_bwd(fp, sh_degree, records, v_records, out, touched, (hipStream_t)stream);
 }
 
 // ---- pixel-velocity model (the paper's first-order blur / rolling-shutter model; SURVEY App. A, C1;
@@ -1032,7 +1115,8 @@ GS_EXPORT int gs_project_pixvel_fwd(int N, int P, const float* means, const floa
                                     int sh_degree, const float* viewmat, const float* twist, const float* times,
                                     float fx, float fy, float cx, float cy, int H, int W, float clip, int antialiased,
                                     int defer_color, float* records, unsigned* depth_keys, int* num_tiles_hit,
-                                    int* radii, float rolling_shutter_time, float* pix_vel, void* stream) {
+                                    int* radii, float rolling_shutter_time, float* pix_vel, const float* sh_rest,
+                                    int param_flags, void* stream) {
   if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride || !twist ||
       !times)
     return GS_ERR_INVALID;
@@ -1041,6 +1125,7 @@ GS_EXPORT int gs_project_pixvel_fwd(int N, int P, const float* means, const floa
                               fx, fy, cx, cy, H, W, clip, antialiased, defer_color);
   fp.pixvel = 1; fp.twist = twist; fp.times = times;
   fp.rs_half = 0.5f * rolling_shutter_time; fp.pix_vel_out = pix_vel;
+  fp.act = param_flags; fp.sh_rest = sh_rest;
   dim3 grid((N + 255) / 256), block(256);
   if (fp.defer_color)       // the SH degree plays no part: one instantiation
     hipLaunchKernelGGL((project_fused_fwd_kernel<16, true>), grid, block, 0, (hipStream_t)stream, fp, records,
@@ -1061,13 +1146,15 @@ GS_EXPORT int gs_project_pixvel_bwd(int N, int P, const float* means, const floa
                                     float fx, float fy, float cx, float cy, int H, int W, float clip, int antialiased,
                                     const float* records, const float* v_records, float* v_means, float* v_scales,
                                     float* v_quats, float* v_opacities, float* v_sh, float* v_viewmat, float* v_twist,
-                                    const unsigned char* touched, float* v_xy_sum, int grad_flags, void* stream) {
+                                    const unsigned char* touched, float* v_xy_sum, int grad_flags, const float* sh_rest,
+                                    int param_flags, float* v_sh_rest, void* stream) {
   if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride || !twist ||
-      !times)
+      !times || (sh_rest != nullptr) != (v_sh_rest != nullptr) || ((grad_flags & GS_FLAG_ZERO_FILL) && !touched))
     return GS_ERR_INVALID;
   FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmat,
                               fx, fy, cx, cy, H, W, clip, antialiased);
   fp.pixvel = 1; fp.twist = twist; fp.times = times; fp.flags = grad_flags;
-  return launch_fused_bwd(fp, sh_degree, records, v_records, v_means, v_scales, v_quats, v_opacities, v_sh, v_viewmat,
-                          touched, v_xy_sum, v_twist, (hipStream_t)stream);
+  fp.act = param_flags; fp.sh_rest = sh_rest;
+  const FusedOut out = {v_means, v_scales, v_quats, v_opacities, v_sh, v_sh_rest, v_viewmat, v_xy_sum, v_twist};
+  return launch_fused_bwd(fp, sh_degree, records, v_records, out, touched, (hipStream_t)stream);
 }

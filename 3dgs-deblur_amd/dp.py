@@ -48,8 +48,16 @@ def unflatten_grads(flat: torch.Tensor, params: Sequence[torch.Tensor]) -> None:
         off += n
 
 
+# GSD_DP_FORCE=1 (or force=True): run the exchange even at world size 1 — every collective then is RCCL's own
+# single-rank kernel on the device buffers, so the pack -> collective -> scatter chain, its stream ordering and the
+# pinned header path execute on a box with ONE GPU (tests/test_gpu_parity.py::test_gradient_exchange_over_rccl_world1,
+# bench.py --force-exchange).  The gradients must come out unchanged.
+FORCE = bool(int(__import__("os").environ.get("GSD_DP_FORCE", "0")))
+
+
 def allreduce_gradients(params: Iterable[torch.Tensor], group: Optional[dist.ProcessGroup] = None,
-                        mode: str = "allreduce", average: bool = False, sync_free: Optional[bool] = None) -> None:
+                        mode: str = "allreduce", average: bool = False, sync_free: Optional[bool] = None,
+                        force: Optional[bool] = None) -> None:
     """Sum (or average) the gradients of `params` over all ranks with a single bucket.
 
     mode="allreduce": one dist.all_reduce (ring on RCCL, bound by one xGMI link).
@@ -68,7 +76,7 @@ def allreduce_gradients(params: Iterable[torch.Tensor], group: Optional[dist.Pro
     if not params or not dist.is_available() or not dist.is_initialized():
         return
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not (FORCE if force is None else force):
         return
     if mode == "sparse":
         if _allreduce_sparse_rows(params, group, world, average, sync_free):
@@ -284,9 +292,14 @@ def reset_sparse_exchange_state() -> None:
 
 def notify_regime_change() -> None:
     """The row density is about to jump (opacity reset, refinement): forget the count history of every exchange
-    state so that the next exchange sizes its payload from a synchronous look at the counts."""
+    state so that the next exchange sizes its payload from a synchronous look at the counts.  The counts of the last
+    exchange are digested FIRST: in sync-free mode an overflow of that exchange (its gradients were truncated and have
+    been applied by now) must still be reported — forget() alone would drop the pending header unread."""
     for st in _SPARSE_STATES.values():
-        st.forget()
+        try:
+            st.settle()
+        finally:
+            st.forget()
 
 
 def _allreduce_sparse_rows(params: Sequence[torch.Tensor], group, world: int, average: bool,
@@ -361,14 +374,14 @@ def _async_to_host(t: torch.Tensor):
 
 
 def allreduce_dense_(tensors: Sequence[torch.Tensor], group: Optional[dist.ProcessGroup] = None,
-                     average: bool = False) -> None:
+                     average: bool = False, force: Optional[bool] = None) -> None:
     """In-place sum (or mean) of a few small tensors over the ranks through ONE flat bucket: the gradients of the
     parameters that are not per-Gaussian rows (learnable background, pose and velocity adjustments)."""
     tensors = [t for t in tensors if t is not None]
     if not tensors or not dist.is_available() or not dist.is_initialized():
         return
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not (FORCE if force is None else force):
         return
     flat = torch.cat([t.reshape(-1).float() for t in tensors])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

@@ -254,11 +254,12 @@ class SplatfactoDeblurModel(nn.Module):
         if not pixvel and cfg.motion_model != "se3":
             raise ValueError(f"unknown motion_model {cfg.motion_model!r}")
         viewmats = viewmat if pixvel else ops.subpose_viewmats(viewmat, lin, ang, times_t)
-        sh = torch.cat([self.features_dc[:, None, :], self.features_rest], dim=1)
-        gp = (self.means, self.scales, self.quats, self.opacities, sh)
+        # the RAW parameters go to the kernels as they are: log-scales, opacity logits, features_dc / features_rest as two
+        # pointers (no exp / sigmoid / cat launches and none of their backward; ops.render_combined raw_params / sh_rest)
+        gp = (self.means, self.scales, self.quats, self.opacities, self.features_dc, self.features_rest)
         if detach_gaussians:
             gp = tuple(t.detach() for t in gp)
-        means_, scales_, quats_, opac_, sh = gp
+        means_, scales_, quats_, opac_, dc_, rest_ = gp
         bg = self._background(dev)
         use_gamma = cfg.blur_samples > 0
         self.xy_grad = None
@@ -269,12 +270,13 @@ class SplatfactoDeblurModel(nn.Module):
         # one autograd node for composite + gamma-space average: no [S,H,W,3] sample-gradient tensor in backward
         want_depth = cfg.output_depth_during_training or not self.training
         res = ops.render_combined(
-            means_, torch.exp(scales_), quats_, torch.sigmoid(opac_).reshape(-1), sh,
+            means_, scales_, quats_, opac_.reshape(-1), dc_,
             viewmats, bg, S, R, camera.fx, camera.fy, camera.cx, camera.cy, camera.height, camera.width,
             gamma=gamma, min_rgb_level=min_level, sh_degree=self.active_sh_degree(),
             antialiased=(cfg.rasterize_mode == "antialiased"), xy_grad_out=self.xy_grad,
             lin_vel=lin if pixvel else None, ang_vel=ang if pixvel else None, times=times_t if pixvel else None,
-            return_depth=want_depth, rolling_shutter_time=self._rs_time(camera) if pixvel else 0.0)
+            return_depth=want_depth, rolling_shutter_time=self._rs_time(camera) if pixvel else 0.0,
+            sh_rest=rest_, raw_params=True)
         rgb, alphas, radii = res[:3]
         depth_acc = res[3] if want_depth else None
         self.radii = radii

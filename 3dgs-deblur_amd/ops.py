@@ -555,13 +555,13 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     out_img = torch.empty(S, H, W, 3, device=dev)
     out_T = torch.empty(S, H, W, device=dev)
     band_done = _band_tile_done(S, R, ty, tx, dev) if R > 1 else None
-    c_means = c_sh = c_V = None
+    c_means = c_sh = c_rest = c_V = None
     c_K = c_deg = 0
     if color is not None:
-        c_means, c_sh, c_K, c_deg, c_V = color
+        c_means, c_sh, c_rest, c_K, c_deg, c_V = color
     L.gs_frame_profile_enable(_profile_mask())
     st = L.gs_frame_forward(ctypes.byref(desc), _ptr(records), _ptr(depth_keys), _ptr(num_tiles_hit), _ptr(bg), _ptr(edges),
-                            _ptr(band_done), _ptr(c_means), _ptr(c_sh), int(c_K), int(c_deg), _ptr(c_V),
+                            _ptr(band_done), _ptr(c_means), _ptr(c_sh), _ptr(c_rest), int(c_K), int(c_deg), _ptr(c_V),
                             _ptr(rs[0]) if rs is not None else None, _ptr(out_img), _ptr(out_T), _ptr(out_depth),
                             _ptr(arena), arena.numel(), ctypes.c_void_p(pin.data_ptr()), pin.numel(), ctypes.byref(state),
                             _stream())
@@ -758,9 +758,9 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                 cum_k, total_k = exclusive_scan_u32(counts)
                 if color is not None:
                     # deferred SH colour for exactly the Gaussians this slice emits
-                    c_means, c_sh, c_K, c_deg, c_V = color
-                    _check(L.gs_slice_colors(n_k, _ptr(slice_gi), _ptr(counts), N, _ptr(c_means), _ptr(c_sh), c_K,
-                                             c_deg, _ptr(c_V), _ptr(records), _stream()), "slice_colors")
+                    c_means, c_sh, c_rest, c_K, c_deg, c_V = color
+                    _check(L.gs_slice_colors(n_k, _ptr(slice_gi), _ptr(counts), N, _ptr(c_means), _ptr(c_sh),
+                                             _ptr(c_rest), c_K, c_deg, _ptr(c_V), _ptr(records), _stream()), "slice_colors")
             if device_sizes:
                 hi_rel = [seg_totals[p] if last else rel_at[p][k] for p in range(P)]
                 lo_rel = [0 if first else rel_at[p][k - 1] for p in range(P)]
@@ -1237,17 +1237,25 @@ class _RenderSubposes(Function):
     @staticmethod
     def forward(ctx, means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out, return_alpha,
-                gamma, min_rgb_level, lin_vel=None, ang_vel=None, times=None, return_depth=False, rs_time=0.0):
+                gamma, min_rgb_level, lin_vel=None, ang_vel=None, times=None, return_depth=False, rs_time=0.0,
+                sh_rest=None, param_flags=0):
         # an output the loss does not use arrives as None in backward instead of a materialised zero tensor
         ctx.set_materialize_grads(False)
         means3d, scales, quats = _f32(means3d, "means3d"), _f32(scales, "scales"), _f32(quats, "quats")
         opacities, sh = _f32(opacities, "opacities").reshape(-1), _f32(sh, "sh")
+        # raw splatfacto parameters (param_flags bit 0: log-scales, bit 1: opacity logits; sh_rest: features_rest beside
+        # sh = features_dc): activations, their backward and the SH concatenation happen inside the projection kernels
+        param_flags = int(param_flags)
+        if sh_rest is not None:
+            sh_rest = _f32(sh_rest, "sh_rest")
+            if sh.reshape(sh.shape[0], -1).shape[1] != 3 or sh_rest.dim() != 3 or sh_rest.shape[0] != sh.shape[0]:
+                raise ValueError("with sh_rest [N,K-1,3], sh must be features_dc [N,3] (or [N,1,3])")
         if xy_grad_out is not None:
             if (xy_grad_out.shape != (means3d.shape[0], 2) or xy_grad_out.dtype != torch.float32
                     or not xy_grad_out.is_contiguous() or xy_grad_out.device != means3d.device):
                 raise ValueError("xy_grad_out must be a contiguous float32 [N,2] tensor on the Gaussians' device")
         ctx.xy_grad_out = xy_grad_out
-        N, K = means3d.shape[0], sh.shape[1]
+        N, K = means3d.shape[0], (sh.shape[1] if sh_rest is None else 1 + sh_rest.shape[1])
         P = S * R
         if P > MAX_SUBPOSES:
             raise ValueError(f"{S} blur samples x {R} row bands = {P} sub-poses per frame; the slice descriptors travel "
@@ -1293,13 +1301,14 @@ class _RenderSubposes(Function):
                                                _ptr(sh), K, args[4], _ptr(V), _ptr(twist), _ptr(times), args[5], args[6],
                                                args[7], args[8], H, W, args[11], args[12], defer_flags,
                                                _ptr(records), _ptr(dkeys), _ptr(ntiles), _ptr(radii), rs_time,
-                                               _ptr(pix_vel), _stream()),
+                                               _ptr(pix_vel), _ptr(sh_rest), param_flags, _stream()),
                        "project_pixvel_fwd")
             else:
                 _check(L.gs_project_fused_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
                                               _ptr(sh), K, args[4], _ptr(V), args[5], args[6], args[7], args[8], H, W,
                                               args[11], args[12], defer_flags, _ptr(records), _ptr(dkeys),
-                                              _ptr(ntiles), _ptr(radii), _stream()), "project_fused_fwd")
+                                              _ptr(ntiles), _ptr(radii), _ptr(sh_rest), param_flags, _stream()),
+                       "project_fused_fwd")
 
         with _stage("project_fwd"):
             _project()
@@ -1309,7 +1318,7 @@ class _RenderSubposes(Function):
         ctx.sliced = True
         # deferred colour: the view direction of every sub-pose (pixel-velocity model: the mid-exposure pose for all)
         V_col = V.reshape(1, 16).expand(P, 16).contiguous() if pixvel else V
-        color = (means3d, sh, K, args[4], V_col) if DEFER_COLOR else None
+        color = (means3d, sh, sh_rest, K, args[4], V_col) if DEFER_COLOR else None
         # optional fourth channel: sum of weight * camera-space depth per sample image (forward only)
         depth_acc = torch.zeros(S, H, W, device=dev) if return_depth else None
         ctx.prealloc = {} if (PREALLOC_BWD and any(ctx.needs_input_grad)) else None
@@ -1353,6 +1362,8 @@ class _RenderSubposes(Function):
         else:
             cmb_samples = cmb_rgb = svals          # placeholders: nothing to keep
         ctx.pixvel = (twist, times) if pixvel else None
+        ctx.param_flags = param_flags
+        ctx.sh_rest = sh_rest
         ctx.save_for_backward(means3d, scales, quats, opacities, sh, V, records, svals, bins, edges, bg, out_T, fidx,
                               cmb_samples, cmb_rgb)
         ctx.args = args
@@ -1374,7 +1385,7 @@ class _RenderSubposes(Function):
         dev = means3d.device
         L = _L()
         if v_img is None and v_alpha is None:
-            return (None,) * 28
+            return (None,) * 30
         v_img = torch.zeros(ctx.img_shape, device=dev) if v_img is None else v_img.contiguous().float()
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
         combine = None
@@ -1421,14 +1432,18 @@ class _RenderSubposes(Function):
         # untouched Gaussians, so the buffer is zero-filled (one fill instead of five)
         # (filling on a second stream under the VALU-bound compositor backward was measured: 3.10 vs 3.02 ms —
         # the cross-stream event costs more than the 50 us fill; run 41)
-        sizes = [3 * N, 3 * N, 4 * N, N, 3 * K * N]
-        flat = (torch.zeros if touched is not None else torch.empty)(sum(sizes), device=dev)
-        v_means, v_scales, v_quats, v_opac, v_sh = (t.view(shape) for t, shape in zip(
-            flat.split(sizes), [(N, 3), (N, 3), (N, 4), (N,), (N, K, 3)]))
+        # round 4: with touched flags the projection backward zero-fills its own outputs (grad flag 32): no fill launches
+        sh_rest = ctx.sh_rest
+        sizes = [3 * N, 3 * N, 4 * N, N] + ([3 * K * N] if sh_rest is None else [3 * N, 3 * (K - 1) * N])
+        shapes = [(N, 3), (N, 3), (N, 4), (N,)] + ([(N, K, 3)] if sh_rest is None else [tuple(sh.shape), (N, K - 1, 3)])
+        flat = torch.empty(sum(sizes), device=dev)
+        outs = [t.view(shape) for t, shape in zip(flat.split(sizes), shapes)]
+        v_means, v_scales, v_quats, v_opac, v_sh = outs[:5]
+        v_sh_rest = outs[5] if sh_rest is not None else None
         need_v = ctx.needs_input_grad[5]
         xy_out = ctx.xy_grad_out
-        if xy_out is not None and touched is not None:
-            xy_out.zero_()
+        fill_flag = 32 if touched is not None else 0
+        pf = ctx.param_flags
         v_lin = v_ang = None
         with _stage("project_bwd"):
             if ctx.pixvel is not None:
@@ -1441,7 +1456,8 @@ class _RenderSubposes(Function):
                                                clip, aa, _ptr(records), _ptr(v_records), _ptr(v_means), _ptr(v_scales),
                                                _ptr(v_quats), _ptr(v_opac), _ptr(v_sh), _ptr(v_V), _ptr(v_tw),
                                                _ptr(touched), _ptr(xy_out),
-                                               _proj_grad_flags() | (16 if ctx.rs is not None else 0), _stream()),
+                                               _proj_grad_flags() | (16 if ctx.rs is not None else 0) | fill_flag,
+                                               _ptr(sh_rest), pf, _ptr(v_sh_rest), _stream()),
                        "project_pixvel_bwd")
                 if v_tw is not None:
                     v_lin, v_ang = v_tw[0:3], v_tw[3:6]
@@ -1451,9 +1467,11 @@ class _RenderSubposes(Function):
                                               _ptr(sh), K, deg, _ptr(V), fx, fy, cx, cy, H, W, clip, aa, _ptr(records),
                                               _ptr(v_records), _ptr(v_means), _ptr(v_scales), _ptr(v_quats),
                                               _ptr(v_opac), _ptr(v_sh), _ptr(v_V), _ptr(touched), _ptr(xy_out),
-                                              _proj_grad_flags(), _stream()), "project_fused_bwd")
+                                              _proj_grad_flags() | fill_flag, _ptr(sh_rest), pf, _ptr(v_sh_rest),
+                                              _stream()), "project_fused_bwd")
         v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
-        return (v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 16 + (v_lin, v_ang, None, None, None)
+        return ((v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 16
+                + (v_lin, v_ang, None, None, None, v_sh_rest, None))
 
 
 def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, sh: Tensor,
@@ -1462,9 +1480,12 @@ def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
                     sh_degree: int = 3, antialiased: bool = True, glob_scale: float = 1.0,
                     clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None, return_alpha: bool = True,
                     lin_vel: Optional[Tensor] = None, ang_vel: Optional[Tensor] = None,
-                    times: Optional[Tensor] = None, return_depth: bool = False, rolling_shutter_time: float = 0.0):
+                    times: Optional[Tensor] = None, return_depth: bool = False, rolling_shutter_time: float = 0.0,
+                    sh_rest: Optional[Tensor] = None, raw_params: bool = False):
     """Fused hot path: project N Gaussians under P=S*R sub-pose viewmats, bin, sort, composite.
-    -> (samples [S,H,W,3], alphas [S,H,W], radii int32 [P,N]).  scales/opacities are activated values.
+    -> (samples [S,H,W,3], alphas [S,H,W], radii int32 [P,N]).  scales/opacities are activated values — or, with
+    raw_params=True, splatfacto's RAW parameters: log-scales and opacity logits (exp / sigmoid and their backward run
+    inside the projection kernels); sh_rest [N,K-1,3] beside sh = features_dc [N,3] spares the concatenation.
     xy_grad_out (optional float32 [N,2]) is OVERWRITTEN during backward with the sum over the sub-poses of
     the screen-space centre gradient in pixels — what splatfacto's densification reads from ``xys.grad``.
     return_alpha=False returns None for alphas (as gsplat's rasterize_gaussians does by default).
@@ -1480,7 +1501,7 @@ def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
     out = _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
                                 bool(return_alpha), None, None, lin_vel, ang_vel, times, bool(return_depth),
-                                float(rolling_shutter_time))
+                                float(rolling_shutter_time), sh_rest, 3 if raw_params else 0)
     return out if return_depth else out[:3]
 
 
@@ -1490,7 +1511,8 @@ def render_combined(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
                     gamma: float = 1.0, min_rgb_level: float = 0.0, sh_degree: int = 3, antialiased: bool = True,
                     glob_scale: float = 1.0, clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None,
                     return_alpha: bool = True, lin_vel: Optional[Tensor] = None, ang_vel: Optional[Tensor] = None,
-                    times: Optional[Tensor] = None, return_depth: bool = False, rolling_shutter_time: float = 0.0):
+                    times: Optional[Tensor] = None, return_depth: bool = False, rolling_shutter_time: float = 0.0,
+                    sh_rest: Optional[Tensor] = None, raw_params: bool = False):
     """render_subposes + combine_samples as ONE autograd node: -> (rgb [H,W,3], alphas [S,H,W] or None, radii).
     Same values as the two-step form; the backward skips the [S,H,W,3] per-sample gradient tensor — the
     compositor's backward derives every pixel's sample gradient from rgb and its gradient."""
@@ -1498,7 +1520,7 @@ def render_combined(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
     out = _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
                                 bool(return_alpha), float(gamma), float(min_rgb_level), lin_vel, ang_vel, times,
-                                bool(return_depth), float(rolling_shutter_time))
+                                bool(return_depth), float(rolling_shutter_time), sh_rest, 3 if raw_params else 0)
     return out if return_depth else out[:3]
 
 

@@ -40,8 +40,8 @@ def make_scene(n, W, H, seed=1234, profile="survey"):
 class Workload:
     """One camera view per rank of a replicated scene: parameters, view, fixed dL/d(image), and the step."""
 
-    def __init__(self, gs, dev, rank, world, N, W, H, S, R, profile, allreduce):
-        self.gs, self.world, self.allreduce = gs, world, allreduce
+    def __init__(self, gs, dev, rank, world, N, W, H, S, R, profile, allreduce, force_exchange=False):
+        self.gs, self.world, self.allreduce, self.force_exchange = gs, world, allreduce, force_exchange
         self.S, self.R, self.H, self.W = S, R, H, W
         sc = self.sc = make_scene(N, W, H, profile=profile)
         names = ["means", "log_scales", "quats", "opacity_logits", "sh"]
@@ -67,17 +67,21 @@ class Workload:
         for p in self.all_params + [self.lin, self.ang, self.viewmat]:
             p.grad = None
         vms = gs.subpose_viewmats(self.viewmat, self.lin, self.ang, self.times_t)
-        out, _, _ = gs.render_combined(params["means"], params["log_scales"].exp(), params["quats"],
-                                       torch.sigmoid(params["opacity_logits"]), params["sh"], vms, self.bg, self.S,
+        # the raw parameters (log-scales, opacity logits) go to the kernels as they are: activations and their backward
+        # run inside the projection (no torch launches between the HIP stages)
+        out, _, _ = gs.render_combined(params["means"], params["log_scales"], params["quats"],
+                                       params["opacity_logits"], params["sh"], vms, self.bg, self.S,
                                        self.R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], self.H, self.W, gamma=2.2,
                                        min_rgb_level=10.0, sh_degree=3, antialiased=True,
-                                       return_alpha=False)   # the loss reads RGB only
-        loss = (out * self.wt).sum()
-        loss.backward()
-        if self.world > 1:
+                                       return_alpha=False, raw_params=True)   # the loss reads RGB only
+        # fixed d loss / d image = wt (the loss (out * wt).sum() without its two launches: the step times the renderer's
+        # forward + backward to every parameter, not a reduction)
+        out.backward(self.wt)
+        loss = out
+        if self.world > 1 or self.force_exchange:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            gs.dp.allreduce_gradients(self.all_params, mode=self.allreduce)
+            gs.dp.allreduce_gradients(self.all_params, mode=self.allreduce, force=self.force_exchange)
             b.record()
             self.exchange_events.append((a, b))
         return loss
@@ -252,6 +256,9 @@ def main():
                     help="DP gradient exchange: row-sparse all-gather (default; dense fallback built in), "
                          "dense all-reduce, or reduce-scatter + all-gather")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second (fitted-model-like) scene")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the DP gradient exchange over RCCL even at --gpus 1 (single-rank collectives: measures the "
+                         "pack -> collective -> scatter chain's device cost as exchange_ms; the timed step includes it)")
     ap.add_argument("--scene", default="survey", choices=["survey", "trained"],
                     help="scene profile of the timed workload (BASELINE metric: survey)")
     args = ap.parse_args()
@@ -268,8 +275,9 @@ def main():
     check_world(args.gpus, world)
     if torch.cuda.device_count() < (local_rank + 1):
         raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node ({torch.cuda.device_count()} visible)")
-    if world > 1:
+    if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
@@ -280,7 +288,7 @@ def main():
     from gsdeblur_amd import ops
 
     N, W, H, S, R = args.gaussians, args.width, args.height, args.subposes, args.rs_bands
-    wl = Workload(gs, dev, rank, world, N, W, H, S, R, args.scene, args.allreduce)
+    wl = Workload(gs, dev, rank, world, N, W, H, S, R, args.scene, args.allreduce, args.force_exchange)
     sc, params, step = wl.sc, wl.params, wl.step
 
     for _ in range(args.warmup):
@@ -369,6 +377,18 @@ def main():
             "roofline": sec_roofline, "train_step": train}
         del w2
         torch.cuda.empty_cache()
+    # per-rank diagnostics (a SCALE record must explain itself: which rank was slow, what the exchange cost it)
+    per_rank = rccl_version = None
+    if world > 1 or args.force_exchange:
+        info = {"rank": rank, "device": torch.cuda.get_device_name(dev), "ms_per_step": round(dt / args.steps * 1e3, 4),
+                "exchange_ms": None if exchange_ms is None else round(exchange_ms, 4),
+                "gaussians_with_gradient": rows_with_grad}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, info)
+        try:
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl_version = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -502,7 +522,9 @@ def main():
                        "gaussians_with_gradient": rows_with_grad,
                        "views_per_step": world,
                        "parallelism": f"dp{world}" if world > 1 else "single",
-                       "gradient_exchange": args.allreduce if world > 1 else None,
+                       "gradient_exchange": args.allreduce if (world > 1 or args.force_exchange) else None,
+                       "gradient_exchange_forced_at_world_1": bool(args.force_exchange and world == 1),
+                       "rccl_version": rccl_version, "per_rank": per_rank,
                        "subpose_MPix_per_s": round(value * S, 3),
                        "secondary": secondary},
             "exchange_ms": None if exchange_ms is None else round(exchange_ms, 4),
@@ -514,7 +536,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = guarded_cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_exchange:
         dist.destroy_process_group()
 
 

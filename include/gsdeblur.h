@@ -81,12 +81,17 @@ int gs_project_fused_fwd(int N, int P, const float* means3d, const float* scales
                                            bit 1: write NO record for a culled (Gaussian, sub-pose) pair — its 48 bytes
                                            stay uninitialised; only for callers that never look at them (the sliced
                                            path behind gs_segmented_sort_compact_u32, which drops culled keys)*/,
-                         float* records /*P*N*12*/, unsigned* depth_keys /*P*N*/,
-                         int* num_tiles_hit /*P*N*/, int* radii /*P*N or NULL*/, void* stream);
+                         float* records /*P*N*16*/, unsigned* depth_keys /*P*N*/,
+                         int* num_tiles_hit /*P*N*/, int* radii /*P*N or NULL*/,
+                         const float* sh_rest /*NULL, or features_rest [N*(K_stride-1)*3]: `sh` is then features_dc [N*3]
+                                                (splatfacto keeps the two as separate parameters)*/,
+                         int param_flags /*bit 0: `scales` holds LOG-scales (scale = exp), bit 1: `opacities` holds logits
+                                           (opacity = sigmoid): the caller's raw parameters, no activation launches*/,
+                         void* stream);
 /* deferred SH colour of the slice Gaussians with counts[j] > 0 (global index slice_gi[j] = p*N + g) */
 int gs_slice_colors(int n_slice, const unsigned* slice_gi, const unsigned* counts, int N, const float* means3d,
-                    const float* sh, int K_stride, int sh_degree, const float* viewmats, float* records,
-                    void* stream);
+                    const float* sh, const float* sh_rest /*as in gs_project_fused_fwd*/, int K_stride, int sh_degree,
+                    const float* viewmats, float* records, void* stream);
 /* v_viewmats [P*16] accumulated into (caller zeroes; NULL to skip). */
 int gs_project_fused_bwd(int N, int P, const float* means3d, const float* scales, float glob_scale,
                          const float* quats, const float* opacities, const float* sh, int K_stride,
@@ -104,7 +109,12 @@ int gs_project_fused_bwd(int N, int P, const float* means3d, const float* scales
                          int grad_flags /*as in gs_project_bwd; + 8: skip the double-precision covariance chain that
                                           Gaussians with a scale ratio above 8 (needles) get by default; + 16
                                           (pixel-velocity model): v_records[.., 9..10] hold d loss / d pixel velocity
-                                          from gs_rasterize_bwd_rs_slice*/, void* stream);
+                                          from gs_rasterize_bwd_rs_slice; + 32 (needs touched): the kernel zero-fills the
+                                          gradient outputs and v_xy_sum itself — hand over uninitialised buffers*/,
+                         const float* sh_rest, int param_flags /*both as in gs_project_fused_fwd: the gradients returned
+                                          are those of what was handed in (d/d log-scale, d/d logit)*/,
+                         float* v_sh_rest /*[N*(K_stride-1)*3] iff sh_rest != NULL (v_sh is then [N*3])*/,
+                         void* stream);
 
 /* ---- pixel-velocity model: the paper's first-order blur / rolling-shutter model (the fork's
  * own wording at /root/reference/README.md:200 "Fixed a bug in pixel velocity formulas").  ONE projection under the
@@ -123,7 +133,7 @@ int gs_project_pixvel_fwd(int N, int P, const float* means3d, const float* scale
                                                         added by gs_rasterize_fwd_rs_slice / gs_rasterize_bwd_rs_slice*/,
                           float* pix_vel /*[N*2] out: pixel velocity of every Gaussian; NULL allowed when
                                            rolling_shutter_time == 0*/,
-                          void* stream);
+                          const float* sh_rest, int param_flags /*as in gs_project_fused_fwd*/, void* stream);
 /* v_viewmat [16] and v_twist [12 floats: lin 3, ang 3, 6 unused] are accumulated into (caller zeroes; NULL skips) */
 int gs_project_pixvel_bwd(int N, int P, const float* means3d, const float* scales, float glob_scale,
                           const float* quats, const float* opacities, const float* sh, int K_stride, int sh_degree,
@@ -131,7 +141,8 @@ int gs_project_pixvel_bwd(int N, int P, const float* means3d, const float* scale
                           float cx, float cy, int img_height, int img_width, float clip_thresh, int antialiased,
                           const float* records, const float* v_records, float* v_means3d, float* v_scales,
                           float* v_quats, float* v_opacities, float* v_sh, float* v_viewmat, float* v_twist,
-                          const unsigned char* touched, float* v_xy_sum, int grad_flags, void* stream);
+                          const unsigned char* touched, float* v_xy_sum, int grad_flags, const float* sh_rest,
+                          int param_flags, float* v_sh_rest /*as in gs_project_fused_bwd*/, void* stream);
 
 /* ---- gsplat-array <-> record glue for the rasterize_gaussians signature -------- */
 int gs_pack_records(int N, const float* xys, const float* depths, const int* radii, const float* conics,
@@ -467,7 +478,8 @@ typedef struct gs_frame_state {
  * arena AND fresh projection outputs (depth_keys was consumed). */
 int gs_frame_forward(const gs_frame_desc* desc, float* records, unsigned* depth_keys, const int* num_tiles_hit,
                      const float* background /*3*/, const int* band_edges /*R+1*/, const unsigned char* band_tile_done,
-                     const float* color_means, const float* color_sh, int color_K_stride, int color_sh_degree,
+                     const float* color_means, const float* color_sh, const float* color_sh_rest /*as sh_rest of
+                     gs_project_fused_fwd*/, int color_K_stride, int color_sh_degree,
                      const float* color_viewmats /*P*16*/,
                      const float* pix_vel /*NULL, or [N*2] from gs_project_pixvel_fwd(rolling_shutter_time != 0)*/,
                      float* out_img /*S*H*W*3*/, float* out_T /*S*H*W*/, float* out_depth, void* arena, long long arena_bytes, void* host_pinned,

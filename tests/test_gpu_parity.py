@@ -7,6 +7,7 @@ Pixels whose threshold decisions (alpha >= 1/255, T <= 1e-4) sit within rounding
 flagged by the oracle (`fragile`) and excluded from strict comparisons; everything else is compared.
 """
 import math
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -47,7 +48,45 @@ def rel_max(a, b):
 # tensor's max, run r02_run6); the relative part binds every element above that floor.
 GRAD_EL_RTOL = 1e-4
 GRAD_EL_AFRAC = 1e-5
-FRAGILE_MAX = 0.10    # at most 10 % of the pixels may sit within rounding of a threshold decision
+FRAGILE_MAX = 0.10    # default ceiling for a scene without an entry in FRAGILE_OBSERVED
+# Share of the pixels the ORACLE flags as within rounding of a threshold decision (alpha = 1/255, T = 1e-4), per test
+# scene: a property of the seeded scene and the oracle's bands, printed by every run ("[fragile <tag>]").  Each scene is
+# held to 2x the share observed (bound it near what is observed instead of a flat 10 %).
+FRAGILE_OBSERVED = {   # round 4, gpurun visit r4_v2 (profiles/r04_v2_suite_prints.log)
+    'baseline config2: 5 motion-blur sub-poses': 0.03839,
+    'baseline config3: 10 rolling-shutter bands': 0.00734,
+    'baseline config4: 5 samples x 2 bands': 0.03313,
+    'baseline config5: 10 motion-blur sub-poses': 0.07017,
+    'exact-rs S=1 144x128 n=2500 base=None': 0.00700,
+    'exact-rs S=2 96x128 n=6000 base=8': 0.01554,
+    'exact-rs S=3 128x160 n=3000 base=None': 0.02183,
+    'full-size full_size_headline.npz': 0.00851,       # a property of the committed fixture
+    'full-size full_size_config3.npz': 0.00849,       # a property of the committed fixture
+    'fused S=1 R=1 160x96 n=3000': 0.00684,
+    'fused S=1 R=6 96x200 n=2000': 0.00177,
+    'fused S=2 R=3 112x80 n=1500': 0.01060,
+    'fused S=5 R=1 128x128 n=2000': 0.02649,
+    'golden blur_large': 0.03741,
+    'needle pixel_velocity': 0.02300,
+    'needle se3': 0.02423,
+    'pixvel S=1 R=4 96x144 n=2000': 0.00239,
+    'pixvel S=3 R=2 128x96 n=2500': 0.02181,
+    'pixvel S=5 R=1 160x96 n=3000': 0.03294,
+    'posed pixel_velocity S=3 R=2': 0.02047,
+    'posed pixel_velocity S=5 R=1': 0.03501,
+    'posed se3 S=3 R=2': 0.02322,
+    'rasterize n=2000 48x40 mult=3.0': 0.00104,
+    'rasterize n=3000 100x60 mult=12.0': 0.00350,
+    'rasterize n=5000 256x256 mult=4.0': 0.00636,
+}
+
+
+def check_fragile(frag, tag):
+    f = float(np.asarray(frag, dtype=np.float64).mean()) if not isinstance(frag, torch.Tensor) else float(frag.double().mean())
+    bound = 2.0 * FRAGILE_OBSERVED[tag] + 1e-4 if tag in FRAGILE_OBSERVED else FRAGILE_MAX
+    print(f"[fragile {tag}] {f:.5f} (bound {bound:.5f})")
+    assert f <= bound, (tag, f, bound)
+    return f
 
 
 def grad_el_ratio(got, ref):
@@ -56,6 +95,22 @@ def grad_el_ratio(got, ref):
     ref = np.asarray(ref, np.float64)
     tol = GRAD_EL_RTOL * np.abs(ref) + GRAD_EL_AFRAC * (np.abs(ref).max() + 1e-300)
     return float((np.abs(got - ref) / tol).max())
+
+
+# Two fp32 compositor formulations (round 4: the scalar-cache kernels test `sigma >= 0 and alpha >= 1/255` with one
+# compare on a shifted exponent; the round-1 kernels with two compares on alpha) round differently, so a pixel within
+# an ulp of a threshold (alpha = 1/255, T = 1e-4) may take the other branch: such a pixel differs by up to one blend
+# weight.  Compared like the oracle comparisons: values within IMG_ATOL, except a bounded fraction of threshold
+# pixels.  The bound is 2x the largest fraction observed on the GPU (printed by every call; profiles/r04_*).
+KERNEL_FRAGILE_FRAC = 1e-5
+
+
+def images_close(a, b, atol, what, frac_max=KERNEL_FRAGILE_FRAC):
+    d = (a.double() - b.double()).abs()
+    frac = float((d > atol).double().mean())
+    print(f"[kernel-vs-kernel {what}] max|d| = {float(d.max()):.3e}, values over {atol:g}: {frac:.3e} of {d.numel()}")
+    assert torch.isfinite(a).all() and frac <= frac_max, (what, frac, float(d.max()))
+    return frac
 
 
 def to_dev(sc, dev):
@@ -361,7 +416,7 @@ def test_rasterize_gaussians_parity(gs, oracle, dev, n, W, H, mult, bg):
     img, alpha = gs.rasterize_gaussians(xd, pr.depths.to(dev), pr.radii.to(dev), cd, pr.num_tiles_hit.to(dev), cold,
                                         od[:, None], H, W, 16, bgd, return_alpha=True)
     good = ~r.fragile
-    assert r.fragile.float().mean().item() <= FRAGILE_MAX
+    check_fragile(r.fragile, f"rasterize n={n} {W}x{H} mult={mult}")
     d_img = (img.detach().cpu().double() - img_ref.detach()).abs()
     assert d_img[good].max().item() < IMG_ATOL
     assert (alpha.detach().cpu().double() - alpha_ref.detach()).abs()[good].max().item() < IMG_ATOL
@@ -481,7 +536,7 @@ def test_fused_path_matches_large_golden(gs, dev):
     sc = gs.data.synthetic_scene(n, W, H, sh_degree=deg, seed=seed, scale_mult=mult)
     sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * lv, sc["ang_vel"] * av
     frag = np.unpackbits(d["fragile"])[:H * W].reshape(H, W).astype(bool)
-    assert frag.mean() <= FRAGILE_MAX
+    check_fragile(frag, "golden blur_large")
     g = torch.Generator().manual_seed(int(d["weights_seed"][0]))
     wt = torch.rand(H, W, 3, generator=g, dtype=torch.float64) * torch.from_numpy(~frag)[..., None]
     out, alpha, samples, vms, p, radii = _run_full(gs, None, dev, sc, H, W, S, R, et, rt, gamma, mlevel, deg,
@@ -529,7 +584,7 @@ def test_fused_path_vs_oracle_integers_and_image(gs, oracle, dev, S, R, W, H, n)
         torch.sigmoid(sc["opacity_logits"].double()), sc["sh"].double(), sc["viewmat"].double(),
         sc["lin_vel"].double(), sc["ang_vel"].double(), background=bg.double(), return_parts=True)
     good = ~frag
-    assert frag.float().mean().item() <= FRAGILE_MAX
+    check_fragile(frag, f"fused S={S} R={R} {W}x{H} n={n}")
     assert (samples.detach().cpu().double() - ref_samples)[:, good].abs().max().item() < IMG_ATOL
     assert (out.detach().cpu().double() - ref)[good].abs().max().item() < 5e-4
 
@@ -556,7 +611,7 @@ def test_baseline_configs_vs_float64_oracle_image_and_per_element_gradients(gs, 
         cfg, q["means"], q["log_scales"].exp(), q["quats"], torch.sigmoid(q["opacity_logits"]), q["sh"], q["viewmat"],
         q["lin_vel"], q["ang_vel"], background=bg.double(), return_parts=True)
     good = ~frag
-    assert frag.float().mean().item() <= FRAGILE_MAX, f"{tag}: {frag.float().mean().item():.3f} of the pixels fragile"
+    check_fragile(frag, f"baseline {tag}")
     # the loss ignores the fragile pixels on both sides (a flipped threshold there changes the gradient by O(1))
     wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)) * good[..., None]
     (ref * wt.double()).sum().backward()
@@ -593,7 +648,7 @@ def test_pixel_velocity_model_vs_oracle(gs, oracle, dev, S, R, W, H, n):
         cfg, q["means"], q["log_scales"].exp(), q["quats"], torch.sigmoid(q["opacity_logits"]), q["sh"], q["viewmat"],
         q["lin_vel"], q["ang_vel"], background=bg.double(), return_parts=True)
     good = ~frag
-    assert frag.float().mean().item() <= FRAGILE_MAX
+    check_fragile(frag, f"pixvel S={S} R={R} {W}x{H} n={n}")
     wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)) * good[..., None]
     (ref * wt.double()).sum().backward()
     p = {k: sc[k].float().to(dev).requires_grad_(True) for k in names}
@@ -672,7 +727,7 @@ def test_real_camera_pose_and_grazing_gaussians_vs_oracle(gs, oracle, dev, model
         cfg, q["means"], q["log_scales"].exp(), q["quats"], torch.sigmoid(q["opacity_logits"]), q["sh"], q["viewmat"],
         q["lin_vel"], q["ang_vel"], background=bg.double(), return_parts=True)
     good = ~frag
-    assert frag.float().mean().item() <= FRAGILE_MAX
+    check_fragile(frag, f"posed {model} S={S} R={R}")
     wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)) * good[..., None]
     (ref * wt.double()).sum().backward()
     p = {k_: sc[k_].float().to(dev).requires_grad_(True) for k_ in names}
@@ -870,13 +925,14 @@ def test_speculative_slices_change_nothing(gs, oracle, dev, S, R, base):
                                                  (3, 1, 512, 320, 200, 20000, False), (2, 1, 8, 176, 112, 5000, True),
                                                  (1, 2, 512, 131, 90, 2500, True)])
 def test_scalar_cache_compositor_equals_readlane_compositor(gs, oracle, dev, S, R, base, W, H, n, hot):
-    """Round 2's compositors fetch the records through the scalar cache (s_load); the forward keeps one signed
-    transmittance per pixel.  The round-1 kernels broadcast the records with v_readlane.  Forward: same arithmetic,
-    term for term — sample images, alphas AND (behind the same backward) the gradients, which depend on every
-    pixel's final index, must be bit-identical; backward: equal up to fp32 summation order.  Single- and multi-slice
-    frames, ragged image sizes, rolling-shutter bands, tuple and atomics accumulation.  hot: a few large Gaussians
-    have an opacity above the 0.999 alpha clamp — the tiles they land on take the clamping loop version, the others
-    the clamp-free one (tile_hot); the round-1 kernels always clamp."""
+    """The scalar-cache compositors (records through s_load; round 4: one-compare validity on a shifted exponent, stop
+    handling in a rarely taken branch, final_idx = stop position) against the round-1 kernels (records broadcast with
+    v_readlane, alpha / sigma / T tests as three compares, final_idx = last blended entry + 1).  Two formulations of
+    the same blend in fp32: sample images and alphas agree within IMG_ATOL except threshold pixels (images_close),
+    gradients up to fp32 summation order and those pixels.  Single- and multi-slice frames, ragged image sizes,
+    rolling-shutter bands, tuple and atomics accumulation.  hot: a few large Gaussians have an opacity above the 0.999
+    alpha clamp — the tiles they land on take the clamping loop version, the others the clamp-free one (tile_hot); the
+    round-1 kernels always clamp."""
     from gsdeblur_amd import ops
     O = oracle
     sc = O.synthetic_scene(n, W, H, seed=21 + S, scale_mult=7.0)
@@ -897,7 +953,7 @@ def test_scalar_cache_compositor_equals_readlane_compositor(gs, oracle, dev, S, 
         ops.SLICE_BASE = base
         for tuples in (1, 0):
             ops.GRAD_TUPLES = tuples        # 0: the fp32-atomics backward (order-dependent sums)
-            for fv, bv in ((0, 2), (2, 2), (0, 0)):
+            for fv, bv in ((2, 2), (0, 0)):
                 ops.RASTER_FWD_VARIANT, ops.RASTER_BWD_VARIANT = fv, bv
                 out, alpha, samples, vms, p, radii = _run_full(gs, O, dev, sc, H, W, S, R, 1 / 60, 1 / 30, 2.2, 10.0,
                                                                3, bg, wt)
@@ -906,19 +962,18 @@ def test_scalar_cache_compositor_equals_readlane_compositor(gs, oracle, dev, S, 
     finally:
         ops.SLICE_BASE, ops.RASTER_FWD_VARIANT, ops.RASTER_BWD_VARIANT, ops.GRAD_TUPLES = old
     for tuples in (1, 0):
-        a, b, c = res[(tuples, 0, 2)], res[(tuples, 2, 2)], res[(tuples, 0, 0)]
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
-        for k in a[2]:
-            # same backward kernel behind both forwards: bit-identical Gaussian gradients on the deterministic tuple
-            # path (pose / velocity gradients end in a dozen fp32 atomics per block)
-            if tuples and k not in ("viewmat", "lin_vel", "ang_vel"):
-                assert torch.equal(a[2][k], b[2][k]), k
-            else:
-                assert rel_max(a[2][k].cpu(), b[2][k].cpu()) < 1e-4, k
-            # the scalar-cache backward sums the geometric terms through three moments per lane: same values up to
-            # fp32 summation order
-            assert rel_max(c[2][k].cpu(), a[2][k].cpu()) < (2e-5 if tuples else 1e-4), k
+        b, c = res[(tuples, 2, 2)], res[(tuples, 0, 0)]
+        # small frames: one threshold pixel of 30k is 3e-5
+        images_close(c[0], b[0], IMG_ATOL, f"samples tuples={tuples}", frac_max=1e-4)
+        images_close(c[1], b[1], IMG_ATOL, f"alpha tuples={tuples}", frac_max=1e-4)
+        for k in b[2]:
+            r = rel_max(c[2][k].cpu(), b[2][k].cpu())
+            print(f"[kernel-vs-kernel grad {k} tuples={tuples}] rel_max = {r:.3e}")
+            assert r < 5e-5, (k, r)              # observed: <= 5.6e-6 (visit r4_v2)
+    # the two accumulation routes behind the SAME kernels: fp32 summation order only
+    for k in res[(1, 0, 0)][2]:
+        assert rel_max(res[(0, 0, 0)][2][k].cpu(), res[(1, 0, 0)][2][k].cpu()) < 1e-4, k
+    assert torch.equal(res[(0, 0, 0)][0], res[(1, 0, 0)][0])
 
 
 def test_tuple_backward_equals_atomic_backward(gs, oracle, dev):
@@ -1029,7 +1084,7 @@ def test_properties_at_scale(gs, oracle, dev):
     gs._lib.check(L.gs_project_fused_fwd(N, 1, ops._ptr(sc["means"]), ops._ptr(scales.contiguous()), 1.0,
                                          ops._ptr(sc["quats"]), ops._ptr(opac.contiguous()), ops._ptr(sh), 16, 3,
                                          ops._ptr(vm1), sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, 0.01, 1, 0,
-                                         ops._ptr(rec), ops._ptr(dk), ops._ptr(nt), None, ops._stream()), "fused")
+                                         ops._ptr(rec), ops._ptr(dk), ops._ptr(nt), None, None, 0, ops._stream()), "fused")
     svals, bins, I, skeys = gs.bin_and_sort_records(rec, dk, nt, 1, N, H, W)
     assert I == int(nt.long().sum().item())
     sk = skeys.long()
@@ -1293,6 +1348,8 @@ def test_dp_row_kernels_match_torch(gs, dev):
 
 
 def _nccl_worker(rank, world, port, q):
+    """every exchange form of gsdeblur_amd.dp on the nccl (= RCCL) backend with device tensors.  world == 1: forced
+    (dp.allreduce_gradients(force=True)) — RCCL's single-rank collectives, gradients must come out bit-identical."""
     import os
     import sys
     import torch.distributed as dist
@@ -1303,11 +1360,21 @@ def _nccl_worker(rank, world, port, q):
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world)
     dev = torch.device("cuda", rank)
+    force = world == 1
     N = 200_000
     shapes = [(N, 3), (N, 3), (N, 4), (N, 1), (N, 3), (N, 15, 3)]
-    ok = True
-    for step, (mode, density) in enumerate((("sparse", 0.005), ("sparse", 0.006), ("sparse", 0.4), ("sparse", 0.01),
-                                            ("allreduce", 0.01), ("rs_ag", 0.01))):
+    ok = dist.get_backend() == "nccl"
+    names = set()
+    prof = None
+    try:                                                    # which device kernels / copies the exchange issues
+        from torch.profiler import ProfilerActivity, profile
+        prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA])
+        prof.__enter__()
+    except Exception:
+        prof = None
+    plan = (("sparse", 0.005, None), ("sparse", 0.006, None), ("sparse", 0.4, None), ("sparse", 0.01, None),
+            ("sparse", 0.012, True), ("sparse", 0.011, True), ("allreduce", 0.01, None), ("rs_ag", 0.01, None))
+    for step, (mode, density, sync_free) in enumerate(plan):
         grads = []
         for r in range(world):
             g = torch.Generator().manual_seed(7 + 31 * step + r)
@@ -1316,16 +1383,56 @@ def _nccl_worker(rank, world, port, q):
         params = [torch.nn.Parameter(torch.zeros(s, device=dev)) for s in shapes]
         for p, g in zip(params, grads[rank]):
             p.grad = g.to(dev)
-        gs.dp.allreduce_gradients(params, mode=mode)
+        gs.dp.allreduce_gradients(params, mode=mode, sync_free=sync_free, force=force)
         for i, p in enumerate(params):
             want = sum(grads[r][i] for r in range(world))
-            ok &= bool(torch.allclose(p.grad.cpu(), want, atol=1e-5))
+            if world == 1:
+                ok &= bool(torch.equal(p.grad.cpu(), want))          # one rank: the exchange must change nothing
+            else:
+                ok &= bool(torch.allclose(p.grad.cpu(), want, atol=1e-5))
     small = [torch.full((3,), float(rank + 1), device=dev), torch.full((2, 6), 2.0 * (rank + 1), device=dev)]
-    gs.dp.allreduce_dense_(small, average=True)
+    gs.dp.allreduce_dense_(small, average=True, force=force)
     ok &= bool(torch.allclose(small[0].cpu(), torch.full((3,), (world + 1) / 2.0)))
-    gs.dp._sparse_state(N, world, None).settle()
-    q.put((rank, ok))
+    st = gs.dp._sparse_state(N, world, None)
+    st.settle()
+    ok &= st.overflows == 0
+    if prof is not None:
+        try:
+            torch.cuda.synchronize()
+            prof.__exit__(None, None, None)
+            names = {e.key for e in prof.key_averages() if "nccl" in e.key.lower() or "rccl" in e.key.lower()
+                     or "gs_dp" in e.key or "dp_" in e.key}
+        except Exception:
+            names = set()
+    q.put((rank, ok, sorted(names)))
     dist.destroy_process_group()
+
+
+def _run_nccl_workers(world):
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    return res
+
+
+def test_gradient_exchange_over_rccl_world1(gs, dev):
+    """the RCCL path on the ONE GPU this build can reach.  A process group of world size 1 on the
+    nccl backend; dp.allreduce_gradients(force=True) drives all four exchange forms (guarded row-sparse, sync-free
+    row-sparse, reduce-scatter + all-gather, dense all-reduce) and the small dense bucket on device tensors: pack kernel
+    -> RCCL collective -> scatter kernel in stream order, headers through pinned memory.  The gradients must come out
+    bit-identical.  What RCCL itself launches for a single rank (a device kernel or a copy) is printed, not asserted:
+    no scaling curve is claimed from this."""
+    res = _run_nccl_workers(1)
+    assert len(res) == 1 and res[0][0] == 0 and res[0][1] is True, res
+    print(f"[rccl world 1] device-side names seen by the profiler: {res[0][2]}")
 
 
 def test_gradient_exchange_over_rccl_world2(gs, dev):
@@ -1333,18 +1440,8 @@ def test_gradient_exchange_over_rccl_world2(gs, dev):
     the small dense bucket) on the nccl (= RCCL) backend, two GPUs of one node; skipped on a single-GPU box"""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
-    import os
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 36500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=300) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-    assert res == [(0, True), (1, True)]
+    res = _run_nccl_workers(2)
+    assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)], res
 
 
 def test_dp_masked_pack_and_payload_scatter_match_torch(gs, dev):
@@ -1566,15 +1663,35 @@ def _full_size_two_paths(gs, dev, n, W, H, S, R, profile, other, min_slices=1, s
     (img_f, g_f, I_f, sl_f), (img_o, g_o, I_o, sl_o) = res
     assert I_f == I_o
     assert sum(1 for x in sl_f if x > 0) >= min_slices, sl_f
-    assert torch.isfinite(img_f).all() and torch.equal(img_f, img_o)
+    same_kernels = all(other.get(k, 0) == 0 for k in ("RASTER_FWD_VARIANT", "RASTER_BWD_VARIANT"))
+    tag = f"{n} {W}x{H} S={S} R={R} {profile}"
+    if same_kernels:
+        assert torch.isfinite(img_f).all() and torch.equal(img_f, img_o)       # same arithmetic, other binning
+    else:
+        images_close(img_f, img_o, 5e-4, tag)          # 5e-4: the gamma chain amplifies near the floor
     for k in g_f:
-        if el_bar:
-            assert grad_el_ratio(g_f[k].cpu().numpy(), g_o[k].cpu().numpy()) <= 1.0, k
+        gf, go = g_f[k].cpu().numpy(), g_o[k].cpu().numpy()
+        if same_kernels and el_bar:
+            assert grad_el_ratio(gf, go) <= 1.0, k
+        elif el_bar:
+            # per element, except the rows fed by a threshold pixel: a bounded share of the rows may exceed the bar
+            tol = GRAD_EL_RTOL * np.abs(go) + GRAD_EL_AFRAC * (np.abs(go).max() + 1e-300)
+            bad_rows = ((np.abs(gf.astype(np.float64) - go) / tol).reshape(n, -1).max(axis=1) > 1.0)
+            rows = int((np.abs(go).reshape(n, -1).max(axis=1) > 0).sum())
+            print(f"[kernel-vs-kernel grad {k} {tag}] rows over the per-element bar: {int(bad_rows.sum())} of {rows} "
+                  f"with a gradient, rel_max = {rel_max(gf, go):.3e}")
+            assert bad_rows.sum() <= max(2, 2e-3 * rows) and rel_max(gf, go) < GRAD_RTOL, k
         else:
-            assert rel_max(g_f[k].cpu(), g_o[k].cpu()) < GRAD_RTOL, k
+            assert rel_max(gf, go) < GRAD_RTOL, k
         touched_f = (g_f[k].reshape(n, -1) != 0).any(dim=1)
         touched_o = (g_o[k].reshape(n, -1) != 0).any(dim=1)
-        assert torch.equal(touched_f, touched_o), k
+        if same_kernels:
+            assert torch.equal(touched_f, touched_o), k
+        else:
+            # a Gaussian whose only blended pixel sits on a threshold may gain or lose its gradient
+            diff = int((touched_f != touched_o).sum())
+            print(f"[kernel-vs-kernel touched {k} {tag}] {diff} of {int(touched_o.sum())} rows differ")
+            assert diff <= max(2, 1e-3 * int(touched_o.sum())), (k, diff)
     return sl_f, sl_o, I_f, g_f
 
 
@@ -1914,7 +2031,7 @@ def test_needle_gaussians_gradients_vs_float64_oracle(gs, oracle, dev, model):
                                                torch.sigmoid(q["opacity_logits"]), q["sh"], q["viewmat"], q["lin_vel"],
                                                q["ang_vel"], background=bg.double(), return_parts=True)
     good = ~frag
-    assert frag.float().mean().item() <= FRAGILE_MAX
+    check_fragile(frag, f"needle {model}")
     wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)) * good[..., None]
     (ref * wt.double()).sum().backward()
     # the needles must matter: they are visible and carry a real share of the scale gradient
@@ -2016,7 +2133,7 @@ def test_exact_rolling_shutter_pixel_velocity_vs_oracle(gs, oracle, dev, S, W, H
                                                    torch.sigmoid(q["opacity_logits"]), q["sh"], q["viewmat"],
                                                    q["lin_vel"], q["ang_vel"], background=bg.double(), return_parts=True)
     good = ~frag
-    assert frag.float().mean().item() <= FRAGILE_MAX
+    check_fragile(frag, f"exact-rs S={S} {W}x{H} n={n} base={base}")
     wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)) * good[..., None]
     (ref * wt.double()).sum().backward()
     p = {k: sc[k].float().to(dev).requires_grad_(True) for k in names}
@@ -2124,3 +2241,174 @@ def test_reference_velocity_fixtures_through_the_hip_subposes(gs, dev):
                            frames[i]["camera_angular_velocity"], nb, f"combine{ci}/frame{i}")
             n += 1
     assert n >= 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["se3", "pixel_velocity"])
+def test_raw_parameters_equal_activated_parameters(gs, oracle, dev, model):
+    """Round 4: the projection kernels take splatfacto's RAW parameters (log-scales, opacity logits, features_dc +
+    features_rest as two pointers; gs_project_fused_fwd param_flags / sh_rest) and return the gradients of what was
+    handed in; the backward zero-fills its own outputs.  Against the round-3 route through torch (exp, sigmoid, cat in
+    front of the op, their autograd behind it): same image (the kernel's expf / sigmoid against torch's: a last-bit
+    difference in a scale may move a threshold pixel), gradients of the raw parameters within fp32 rounding — including
+    needles (double-precision chain) and Gaussians without any gradient (exact zeros)."""
+    O = oracle
+    n, W, H, S = 6000, 176, 128, 3
+    sc = O.synthetic_scene(n, W, H, seed=77, scale_mult=6.0)
+    sc["log_scales"] = sc["log_scales"].clone()
+    sc["log_scales"][::40, 0] += 2.5                                   # needles: scale ratio > 8
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, 1, 0.0)
+    tt = torch.tensor(times, device=dev)
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(4)).to(dev)
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh"]
+    res = []
+    for raw in (False, True):
+        p = {k: sc[k].float().to(dev).clone().requires_grad_(True) for k in names}
+        dc = p["sh"].detach()[:, 0, :].clone().requires_grad_(True)
+        rest = p["sh"].detach()[:, 1:, :].clone().requires_grad_(True)
+        V, lin, ang = (sc[k].float().to(dev) for k in ("viewmat", "lin_vel", "ang_vel"))
+        kw = dict(gamma=2.2, min_rgb_level=10.0, return_alpha=False)
+        if model == "pixel_velocity":
+            vm, kw2 = V, dict(lin_vel=lin, ang_vel=ang, times=tt)
+        else:
+            vm, kw2 = gs.subpose_viewmats(V, lin, ang, tt), {}
+        if raw:
+            rgb, _, _ = gs.render_combined(p["means"], p["log_scales"], p["quats"], p["opacity_logits"], dc, vm, None, S, 1,
+                                           sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, sh_rest=rest, raw_params=True,
+                                           **kw, **kw2)
+        else:
+            rgb, _, _ = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
+                                           torch.sigmoid(p["opacity_logits"]), torch.cat([dc[:, None, :], rest], dim=1),
+                                           vm, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, **kw, **kw2)
+        rgb.backward(wt)
+        g = {k: p[k].grad.clone() for k in names if k != "sh"}
+        g["features_dc"], g["features_rest"] = dc.grad.clone(), rest.grad.clone()
+        res.append((rgb.detach().clone(), g))
+    (img_a, g_a), (img_r, g_r) = res
+    images_close(img_r, img_a, 5e-6, f"raw vs activated parameters, {model}", frac_max=2e-4)
+    for k in g_a:
+        assert g_r[k].shape == g_a[k].shape, k
+        r = rel_max(g_r[k].cpu(), g_a[k].cpu())
+        print(f"[kernel-vs-kernel raw-params grad {k} {model}] rel_max = {r:.3e}")
+        assert r < 2e-5, (k, r)
+        rows_a = (g_a[k].reshape(n, -1) != 0).any(dim=1)
+        rows_r = (g_r[k].reshape(n, -1) != 0).any(dim=1)
+        assert int((rows_a != rows_r).sum()) <= 2, k                   # untouched rows: exact zeros from the kernel's own fill
+    assert 0.02 < float((g_a["means"] != 0).any(dim=1).float().mean()) < 0.98
+
+
+# --------------------------------------------------------------------------- #
+# the benchmark's own configurations at FULL size against oracle fixtures (VERDICT round 3 item 4)
+# --------------------------------------------------------------------------- #
+def _full_size_vs_oracle_fixture(gs, oracle, dev, name):
+    """tests/golden/<name> (make_full_size_fixtures.py): for 64 sampled tiles of the 1M-Gaussian 1080p scene the ORACLE's
+    complete tile lists (float32 projection: integers bit-exact) and its float64 composite of each tile.  Here the same
+    scene goes through the HIP path at full size, twice:
+      (a) projection + the unculled binning (depth pre-sort, emission of every bounding-box pair, stable tile sort, bin
+          edges) + ONE compositor pass over the complete lists — the lists must equal the oracle's (length, checksum over
+          the whole list, the ids a pixel can reach one by one), the composite must match colour / final T / stop index;
+      (b) the default path (depth slices, exact tile culling, deferred colour): its sample images must match the same
+          oracle tiles."""
+    import hashlib
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
+    import make_full_size_fixtures as MF
+    from gsdeblur_amd import ops
+    O = oracle
+    d = np.load(Path(__file__).resolve().parent / "golden" / name)
+    S, R, N, W, H = (int(d[k]) for k in ("S", "R", "N", "W", "H"))
+    P = S * R
+    sc = O.synthetic_scene(N, W, H, seed=int(d["seed"]))
+    scales, opac = MF.activate(sc)
+    mine = [f"{k}:{MF.tensor_hash(v)}" for k, v in (("means", sc["means"]), ("scales", scales), ("quats", sc["quats"]),
+                                                    ("opacities", opac), ("sh", sc["sh"]))]
+    same_inputs = mine == [str(x) for x in d["scene_hashes"]]
+    print(f"[full-size {name}] scene tensors regenerated on this host are bit-identical to the fixture's: {same_inputs}")
+    assert same_inputs, "the seeded scene differs from the one the fixture was made from (CPU-dependent torch kernels?)"
+    means, quats, sh = (sc[k].to(dev) for k in ("means", "quats", "sh"))
+    scales, opac = scales.to(dev), opac.to(dev)
+    vms = torch.from_numpy(d["viewmats"]).to(dev)
+    tiles = d["tiles"]
+    tx_n, ty_n = (W + 15) // 16, (H + 15) // 16
+    T = tx_n * ty_n
+    L = gs._lib.load()
+    # ---- (a) unculled lists + one compositor pass over them ----
+    rec = torch.empty(P * N, ops.REC, device=dev)
+    dk = torch.empty(P * N, dtype=torch.int32, device=dev)
+    nt = torch.empty(P * N, dtype=torch.int32, device=dev)
+    gs._lib.check(L.gs_project_fused_fwd(N, P, ops._ptr(means), ops._ptr(scales), 1.0, ops._ptr(quats), ops._ptr(opac),
+                                         ops._ptr(sh), 16, 3, ops._ptr(vms), sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W,
+                                         0.01, 1, 0, ops._ptr(rec), ops._ptr(dk), ops._ptr(nt), None, None, 0,
+                                         ops._stream()), "fused")
+    svals, bins, I, _ = gs.bin_and_sort_records(rec, dk, nt, P, N, H, W)
+    assert I == int(d["tile_intersections_per_step"]), (I, int(d["tile_intersections_per_step"]))
+    edges = ops._band_edges(H, R, dev)
+    bg = torch.zeros(3, device=dev)
+    out_img = torch.empty(S, H, W, 3, device=dev)
+    out_T = torch.empty(S, H, W, device=dev)
+    fidx = torch.empty(S, H, W, dtype=torch.int32, device=dev)
+    gs._lib.check(L.gs_rasterize_fwd(ops._ptr(rec), ops._ptr(svals), ops._ptr(bins), ops._ptr(edges), ops._ptr(bg), S, R,
+                                     H, W, ops._ptr(out_img), ops._ptr(out_T), ops._ptr(fidx), P * N, 0, ops._stream()),
+                  "rasterize_fwd")
+    # ---- (b) the default path ----
+    with torch.no_grad():
+        samples, _, _ = gs.render_subposes(means, scales, quats, opac, sh, vms, None, S, R, sc["fx"], sc["fy"], sc["cx"],
+                                           sc["cy"], H, W, return_alpha=False)
+    bins_c, svals_c = bins.cpu().numpy(), None
+    rows = O.band_tile_rows(H, R)
+    times, samp, band = O.subpose_times(S, sc["exposure_time"], R, sc["rolling_shutter_time"])
+    n_cmp = n_frag = n_px = 0
+    worst = dict(a_rgb=0.0, a_T=0.0, b_rgb=0.0)
+    for p in range(P):
+        ty0, ty1 = rows[band[p]]
+        s_img = samp[p]
+        for ti, t in enumerate(tiles):
+            ty, tx = divmod(int(t), tx_n)
+            key = f"t{ti}_p{p}"
+            if not (ty0 <= ty < ty1):
+                assert key + "_n" not in d.files
+                continue
+            b0, b1 = (int(v) for v in bins_c[p * T + int(t)])
+            n_list = int(d[key + "_n"])
+            assert b1 - b0 == n_list, (key, b1 - b0, n_list)                    # list length: bit-exact
+            ids = (svals[b0:b1].cpu().numpy().astype(np.int64) - p * N)
+            assert MF.list_checksum(ids) == int(d[key + "_sum"]), key            # the WHOLE list, in order
+            keep = d[key + "_ids"]
+            assert np.array_equal(ids[:keep.size], keep.astype(np.int64)), key   # ... and its reachable head, id by id
+            y0, x0 = ty * 16, tx * 16
+            hh, ww = d[key + "_T"].shape
+            frag = np.unpackbits(d[key + "_frag"])[:hh * ww].reshape(hh, ww).astype(bool)
+            good = torch.from_numpy(~frag)
+            ref_rgb = torch.from_numpy(d[key + "_rgb"])
+            ref_T = torch.from_numpy(d[key + "_T"])
+            a_rgb = out_img[s_img, y0:y0 + hh, x0:x0 + ww].cpu().double()
+            a_T = out_T[s_img, y0:y0 + hh, x0:x0 + ww].cpu().double()
+            a_stop = fidx[s_img, y0:y0 + hh, x0:x0 + ww].cpu().numpy().astype(np.int64) - b0
+            b_rgb = samples[s_img, y0:y0 + hh, x0:x0 + ww].cpu().double()
+            worst["a_rgb"] = max(worst["a_rgb"], float((a_rgb - ref_rgb).abs()[good].max()))
+            worst["a_T"] = max(worst["a_T"], float((a_T - ref_T).abs()[good].max()))
+            worst["b_rgb"] = max(worst["b_rgb"], float((b_rgb - ref_rgb).abs()[good].max()))
+            # stop index (list position at which the pixel stops; list length when it never does): bit-exact off the
+            # threshold pixels
+            assert np.array_equal(a_stop[~frag], d[key + "_stop"].astype(np.int64)[~frag]), key
+            n_cmp += 1
+            n_frag += int(frag.sum())
+            n_px += hh * ww
+    print(f"[full-size {name}] {n_cmp} (tile, sub-pose) lists bit-exact; max |colour - oracle| unculled pass "
+          f"{worst['a_rgb']:.2e}, default path {worst['b_rgb']:.2e}; max |T - oracle| {worst['a_T']:.2e}; "
+          f"threshold pixels {n_frag} of {n_px}")
+    assert n_cmp >= 64
+    assert worst["a_rgb"] < IMG_ATOL and worst["b_rgb"] < IMG_ATOL and worst["a_T"] < 2e-5, worst
+    check_fragile(np.array([n_frag / n_px]), f"full-size {name}")
+
+
+@pytest.mark.gpu
+def test_full_size_headline_vs_oracle_fixture(gs, oracle, dev):
+    """bench.py's timed configuration (1M Gaussians, 1920x1080, 5 motion-blur sub-poses, seed 1234) against the oracle"""
+    _full_size_vs_oracle_fixture(gs, oracle, dev, "full_size_headline.npz")
+
+
+@pytest.mark.gpu
+def test_full_size_config3_vs_oracle_fixture(gs, oracle, dev):
+    """BASELINE.json config 3 (1M Gaussians, 1080p, 10 rolling-shutter row bands) against the oracle"""
+    _full_size_vs_oracle_fixture(gs, oracle, dev, "full_size_config3.npz")

@@ -27,11 +27,11 @@ for step in "$@"; do
   echo "== $step ==" | tee -a $S
   case $step in
     suite)
-      timeout 1700 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 --tb=short > $OUT/pytest_gpu.log 2>&1
-      grep -E "^FAILED|^ERROR|passed|failed" $OUT/pytest_gpu.log | tail -60 | tee -a $S ;;
+      timeout 1700 python -m pytest tests -m gpu -q -s -p no:cacheprovider --timeout 900 --tb=short > $OUT/pytest_gpu.log 2>&1
+      grep -E "^\[kernel-vs|^\[fragile|^FAILED|^ERROR|passed|failed" $OUT/pytest_gpu.log | tail -120 | tee -a $S ;;
     tests:*)
-      timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 --tb=short -k "${step#tests:}" > $OUT/pytest_sel.log 2>&1
-      grep -E "^FAILED|^ERROR|passed|failed" $OUT/pytest_sel.log | tail -40 | tee -a $S ;;
+      timeout 1200 python -m pytest tests -m gpu -q -s -p no:cacheprovider --timeout 900 --tb=short -k "${step#tests:}" > $OUT/pytest_sel.log 2>&1
+      grep -E "^\[kernel-vs|^\[fragile|^FAILED|^ERROR|passed|failed" $OUT/pytest_sel.log | tail -80 | tee -a $S ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log | tee -a $S ;;
     bench)
