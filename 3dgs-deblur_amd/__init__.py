@@ -24,7 +24,8 @@ from .ops import (  # noqa: F401
 )
 from .model import Camera, SplatfactoDeblurConfig, SplatfactoDeblurModel  # noqa: F401
 from . import dp  # noqa: F401
-from . import data, densify, fused, train_step as training  # noqa: F401
+from . import data, densify, fused, step, train_step as training  # noqa: F401
+from .step import render_step  # noqa: F401
 from .data import load_transforms, load_seed_points_ply  # noqa: F401
 
 __version__ = "0.1.0"

@@ -104,41 +104,98 @@ def load_transforms(path: str, eval_mode: str = "interval", eval_interval: int =
     )
 
 
-def undistort_image(img: torch.Tensor, fx: float, fy: float, cx: float, cy: float,
-                    distortion: Dict[str, float]) -> torch.Tensor:
-    """[H,W,3] image taken through OpenCV's radial-tangential lens model (k1, k2, k3, p1, p2 — the fields
-    /root/reference/process_synthetic_inputs.py:113-129 and combine.py:109-131 write) -> the image an ideal pinhole
-    camera with the SAME intrinsics would see (bilinear; pixels that fall outside the source stay black).  nerfstudio's
-    datamanager undistorts the training images once up front (cv2.undistort) — the rasterizer only knows pinhole
-    cameras.  All-zero coefficients return the input unchanged."""
+def _undistort_grid(H: int, W: int, fx: float, fy: float, cx: float, cy: float, distortion: Dict[str, float], device):
+    """source pixel INDEX coordinates (us, vs) [H,W] float64 that the undistorted pixel grid samples"""
     k1, k2, k3 = (float(distortion.get(k, 0.0)) for k in ("k1", "k2", "k3"))
     p1, p2 = float(distortion.get("p1", 0.0)), float(distortion.get("p2", 0.0))
-    if k1 == k2 == k3 == p1 == p2 == 0.0:
-        return img
-    H, W = img.shape[0], img.shape[1]
-    dev, dt = img.device, torch.float64
-    v, u = torch.meshgrid(torch.arange(H, device=dev, dtype=dt), torch.arange(W, device=dev, dtype=dt), indexing="ij")
+    dt = torch.float64
+    v, u = torch.meshgrid(torch.arange(H, device=device, dtype=dt), torch.arange(W, device=device, dtype=dt), indexing="ij")
     # pixel CENTRES at +0.5 (the convention of the rasterizer and of nerfstudio's cameras)
     x, y = (u + 0.5 - cx) / fx, (v + 0.5 - cy) / fy
     r2 = x * x + y * y
     radial = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3))
     xd = x * radial + 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x)
     yd = y * radial + p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y
-    us, vs = xd * fx + cx - 0.5, yd * fy + cy - 0.5            # source pixel INDEX coordinates
+    return xd * fx + cx - 0.5, yd * fy + cy - 0.5
+
+
+def _has_distortion(distortion: Dict[str, float]) -> bool:
+    return any(float(distortion.get(k, 0.0)) != 0.0 for k in ("k1", "k2", "k3", "p1", "p2"))
+
+
+def undistort_roi(H: int, W: int, fx: float, fy: float, cx: float, cy: float,
+                  distortion: Dict[str, float]) -> Tuple[int, int, int, int]:
+    """(x0, y0, x1, y1): the largest axis-aligned rectangle of the undistorted frame, grown out from the principal
+    point, in which EVERY pixel samples inside the source image.  With pincushion (k1 > 0) or tangential terms the
+    border of the undistorted frame looks outside the sensor; nerfstudio's datamanager crops to the valid region
+    (cv2.getOptimalNewCameraMatrix(alpha=0) + its ROI) and adopts the new intrinsics, so no black, unmasked pixels reach
+    the loss.  Here the focal lengths stay and the frame is cropped: cx, cy shift by (x0, y0)."""
+    if not _has_distortion(distortion):
+        return 0, 0, W, H
+    us, vs = _undistort_grid(H, W, fx, fy, cx, cy, distortion, "cpu")
+    ok = (us >= 0.0) & (us <= W - 1.0) & (vs >= 0.0) & (vs <= H - 1.0)      # the bilinear footprint lies inside
+    x0, y0, x1, y1 = 0, 0, W, H
+    # shrink the side whose border line has the largest share of invalid pixels until all four lines are clean
+    while x1 - x0 > 2 and y1 - y0 > 2:
+        sides = {"l": (~ok[y0:y1, x0]).float().mean(), "r": (~ok[y0:y1, x1 - 1]).float().mean(),
+                 "t": (~ok[y0, x0:x1]).float().mean(), "b": (~ok[y1 - 1, x0:x1]).float().mean()}
+        side, bad = max(sides.items(), key=lambda kv: float(kv[1]))
+        if float(bad) == 0.0:
+            break
+        if side == "l":
+            x0 += 1
+        elif side == "r":
+            x1 -= 1
+        elif side == "t":
+            y0 += 1
+        else:
+            y1 -= 1
+    if not bool(ok[y0:y1, x0:x1].all()):
+        raise ValueError("lens distortion leaves no valid rectangle around the principal point")
+    return x0, y0, x1, y1
+
+
+def undistort_image(img: torch.Tensor, fx: float, fy: float, cx: float, cy: float,
+                    distortion: Dict[str, float], crop: bool = False):
+    """[H,W,3] image taken through OpenCV's radial-tangential lens model (k1, k2, k3, p1, p2 — the fields
+    /root/reference/process_synthetic_inputs.py:113-129 and combine.py:109-131 write) -> the image an ideal pinhole
+    camera with the SAME focal lengths would see (bilinear).  nerfstudio's datamanager undistorts the training images
+    once up front — the rasterizer only knows pinhole cameras.  All-zero coefficients return the input unchanged.
+    crop=False: same size and principal point; pixels that look outside the source stay black (no mask!).
+    crop=True: -> (image cropped to undistort_roi, (x0, y0, x1, y1)): every pixel valid; the caller shifts cx, cy by
+    (x0, y0) and adopts the new size (load_scene_images does)."""
+    H, W = img.shape[0], img.shape[1]
+    if not _has_distortion(distortion):
+        return (img, (0, 0, W, H)) if crop else img
+    us, vs = _undistort_grid(H, W, fx, fy, cx, cy, distortion, img.device)
     grid = torch.stack([(us + 0.5) / W * 2.0 - 1.0, (vs + 0.5) / H * 2.0 - 1.0], dim=-1)[None].to(img.dtype)
     out = torch.nn.functional.grid_sample(img.permute(2, 0, 1)[None], grid, mode="bilinear", padding_mode="zeros",
                                           align_corners=False)
-    return out[0].permute(1, 2, 0).contiguous()
+    out = out[0].permute(1, 2, 0).contiguous()
+    if not crop:
+        return out
+    x0, y0, x1, y1 = undistort_roi(H, W, fx, fy, cx, cy, distortion)
+    return out[y0:y1, x0:x1].contiguous(), (x0, y0, x1, y1)
 
 
 def load_scene_images(scene: "TransformsScene", device="cpu", undistort: bool = True) -> List[torch.Tensor]:
     """every frame's image, undistorted with the scene's lens coefficients when any is non-zero (what nerfstudio's
-    datamanager does before the first iteration)"""
+    datamanager does before the first iteration).  An undistorted frame is CROPPED to the rectangle in which every pixel
+    is valid and `scene.cameras[i]` is replaced by the camera of the cropped frame (cx, cy shifted, new width / height;
+    same focal lengths): no black border reaches the loss."""
     out = []
-    for cam, path in zip(scene.cameras, scene.image_paths):
+    lens = undistort and _has_distortion(scene.distortion)
+    for i, (cam, path) in enumerate(zip(scene.cameras, scene.image_paths)):
         img = load_image(path, device)
-        if undistort and any(v != 0.0 for v in scene.distortion.values()):
-            img = undistort_image(img, cam.fx, cam.fy, cam.cx, cam.cy, scene.distortion)
+        if lens and not cam.metadata.get("undistorted", False):
+            img, (x0, y0, x1, y1) = undistort_image(img, cam.fx, cam.fy, cam.cx, cam.cy, scene.distortion, crop=True)
+            md = dict(cam.metadata, undistorted=True, undistort_roi=(x0, y0, x1, y1))
+            scene.cameras[i] = Camera(cam.camera_to_world, cam.fx, cam.fy, cam.cx - x0, cam.cy - y0, x1 - x0, y1 - y0, md)
+        elif lens:
+            # the camera already describes the cropped frame (a second load of the same scene): same crop again
+            x0, y0, x1, y1 = cam.metadata["undistort_roi"]
+            full = undistort_image(img, cam.fx, cam.fy, cam.cx + x0, cam.cy + y0, scene.distortion)
+            img = full[y0:y1, x0:x1].contiguous()
         out.append(img)
     return out
 

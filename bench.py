@@ -40,8 +40,9 @@ def make_scene(n, W, H, seed=1234, profile="survey"):
 class Workload:
     """One camera view per rank of a replicated scene: parameters, view, fixed dL/d(image), and the step."""
 
-    def __init__(self, gs, dev, rank, world, N, W, H, S, R, profile, allreduce, force_exchange=False):
+    def __init__(self, gs, dev, rank, world, N, W, H, S, R, profile, allreduce, force_exchange=False, autograd=False):
         self.gs, self.world, self.allreduce, self.force_exchange = gs, world, allreduce, force_exchange
+        self.autograd = autograd
         self.S, self.R, self.H, self.W = S, R, H, W
         sc = self.sc = make_scene(N, W, H, profile=profile)
         names = ["means", "log_scales", "quats", "opacity_logits", "sh"]
@@ -66,6 +67,25 @@ class Workload:
         gs, sc, params = self.gs, self.sc, self.params
         for p in self.all_params + [self.lin, self.ang, self.viewmat]:
             p.grad = None
+        if not self.autograd:
+            # default: forward + backward of the frame as ONE host call (gsdeblur_amd.step.render_step: the same C-ABI
+            # calls as the autograd node below, issued back to back, no autograd engine between the two compositors);
+            # fixed d loss / d image = wt; every Gaussian parameter, the view matrix and the velocities get their gradient
+            out, g, _ = gs.render_step(params["means"], params["log_scales"], params["quats"], params["opacity_logits"],
+                                       params["sh"], self.viewmat, self.lin, self.ang, self.times_t, self.bg, self.S,
+                                       self.R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], self.H, self.W, self.wt, gamma=2.2,
+                                       min_rgb_level=10.0, sh_degree=3, antialiased=True, raw_params=True)
+            for k, name in (("means", "means"), ("log_scales", "scales"), ("quats", "quats"),
+                            ("opacity_logits", "opacities"), ("sh", "sh")):
+                params[k].grad = g[name]
+            self.viewmat.grad, self.lin.grad, self.ang.grad = g["viewmat"], g["lin_vel"], g["ang_vel"]
+            if self.world > 1 or self.force_exchange:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                gs.dp.allreduce_gradients(self.all_params, mode=self.allreduce, force=self.force_exchange)
+                b.record()
+                self.exchange_events.append((a, b))
+            return out
         vms = gs.subpose_viewmats(self.viewmat, self.lin, self.ang, self.times_t)
         # the raw parameters (log-scales, opacity logits) go to the kernels as they are: activations and their backward
         # run inside the projection (no torch launches between the HIP stages)
@@ -256,6 +276,9 @@ def main():
                     help="DP gradient exchange: row-sparse all-gather (default; dense fallback built in), "
                          "dense all-reduce, or reduce-scatter + all-gather")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second (fitted-model-like) scene")
+    ap.add_argument("--autograd", action="store_true",
+                    help="time the torch.autograd route (ops.render_combined + Tensor.backward) instead of the default "
+                         "one-call forward + backward (gsdeblur_amd.render_step); same kernels, more host glue")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the DP gradient exchange over RCCL even at --gpus 1 (single-rank collectives: measures the "
                          "pack -> collective -> scatter chain's device cost as exchange_ms; the timed step includes it)")
@@ -288,7 +311,7 @@ def main():
     from gsdeblur_amd import ops
 
     N, W, H, S, R = args.gaussians, args.width, args.height, args.subposes, args.rs_bands
-    wl = Workload(gs, dev, rank, world, N, W, H, S, R, args.scene, args.allreduce, args.force_exchange)
+    wl = Workload(gs, dev, rank, world, N, W, H, S, R, args.scene, args.allreduce, args.force_exchange, args.autograd)
     sc, params, step = wl.sc, wl.params, wl.step
 
     for _ in range(args.warmup):
@@ -328,7 +351,7 @@ def main():
     if not args.no_secondary and args.scene == "survey":
         del wl, params, step
         torch.cuda.empty_cache()
-        w2 = Workload(gs, dev, rank, world, N, W, H, S, R, "trained", args.allreduce)
+        w2 = Workload(gs, dev, rank, world, N, W, H, S, R, "trained", args.allreduce, False, args.autograd)
         for _ in range(2):
             w2.step()
         if world > 1:
@@ -520,6 +543,9 @@ def main():
                        "tile_intersections_emitted": int(sum(slice_isects)) if ops.SLICE_BASE > 0 else n_isect,
                        "depth_slices": slice_isects if ops.SLICE_BASE > 0 else None,
                        "gaussians_with_gradient": rows_with_grad,
+                       "api": ("ops.render_combined + Tensor.backward (torch.autograd)" if args.autograd else
+                               "gsdeblur_amd.render_step: forward + backward of the frame in one host call (same C-ABI "
+                               "calls as the autograd node, no autograd engine between the compositors)"),
                        "views_per_step": world,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "gradient_exchange": args.allreduce if (world > 1 or args.force_exchange) else None,

@@ -382,3 +382,46 @@ def test_undistort_image_inverts_the_opencv_lens_model(gs):
     assert (got[inner] - ideal[inner]).abs().max() < 2e-3
     assert (distorted[inner] - ideal[inner]).abs().max() > 2e-2      # the lens really moved things
     assert gs.data.undistort_image(distorted, fx, fy, cx, cy, {"k1": 0, "k2": 0, "p1": 0, "p2": 0}) is distorted
+
+
+def test_undistorted_frames_are_cropped_to_valid_pixels_and_the_camera_follows(gs, tmp_path):
+    """with pincushion (k1 > 0) or tangential coefficients the border of the undistorted frame looks
+    outside the sensor; left black and unmasked it pulls the model towards black at the edges.  load_scene_images crops
+    every undistorted frame to the rectangle in which all pixels are valid and replaces the scene's cameras by those of
+    the cropped frames (same focal lengths, principal point shifted by the crop origin) — nerfstudio's datamanager does
+    the equivalent with cv2.getOptimalNewCameraMatrix(alpha=0) + ROI.  A bright frame must come out without a single
+    dark pixel, and a 3D point must project to the same picture content before and after."""
+    import json
+    H, W, fx, fy, cx, cy = 90, 120, 100.0, 101.0, 61.0, 44.0
+    dist = {"k1": 0.15, "k2": 0.02, "p1": 0.01, "p2": -0.008}
+    x0, y0, x1, y1 = gs.data.undistort_roi(H, W, fx, fy, cx, cy, dist)
+    assert 0 < x0 < x1 < W and 0 < y0 < y1 < H and (x1 - x0) * (y1 - y0) > 0.5 * H * W
+    white = torch.ones(H, W, 3)
+    full = gs.data.undistort_image(white, fx, fy, cx, cy, dist)
+    assert full.min() < 0.5                                             # the uncropped frame HAS black border pixels
+    crop, roi = gs.data.undistort_image(white, fx, fy, cx, cy, dist, crop=True)
+    assert roi == (x0, y0, x1, y1) and crop.shape == (y1 - y0, x1 - x0, 3)
+    assert crop.min() > 1 - 1e-5                                        # ... the cropped one has none
+    # growing the rectangle by one pixel on any side brings an invalid pixel in
+    for dx0, dy0, dx1, dy1 in ((-1, 0, 0, 0), (0, -1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1)):
+        a, b, c, d = x0 + dx0, y0 + dy0, x1 + dx1, y1 + dy1
+        if a >= 0 and b >= 0 and c <= W and d <= H:
+            assert full[b:d, a:c].min() < 1 - 1e-5, (dx0, dy0, dx1, dy1)
+    # a scene on disk: the loader crops and the cameras follow
+    root = tmp_path / "scene"
+    (root / "images").mkdir(parents=True)
+    grad = torch.linspace(0.2, 1.0, W)[None, :, None].expand(H, W, 3).contiguous()
+    for i in range(2):
+        gs.data.save_image(str(root / "images" / f"f{i}.png"), grad)
+    meta = dict(w=W, h=H, fl_x=fx, fl_y=fy, cx=cx, cy=cy, **dist,
+                frames=[dict(file_path=f"./images/f{i}.png", transform_matrix=torch.eye(4).tolist()) for i in range(2)])
+    with open(root / "transforms.json", "wt") as f:
+        json.dump(meta, f)
+    scene = gs.data.load_transforms(str(root), eval_mode="all")
+    imgs = gs.data.load_scene_images(scene)
+    for cam, img in zip(scene.cameras, imgs):
+        assert (cam.width, cam.height) == (x1 - x0, y1 - y0) == (img.shape[1], img.shape[0])
+        assert cam.fx == fx and cam.fy == fy and cam.cx == cx - x0 and cam.cy == cy - y0
+        assert img.min() > 0.19
+    again = gs.data.load_scene_images(scene)                            # idempotent: the cameras are not cropped twice
+    assert torch.equal(again[0], imgs[0]) and scene.cameras[0].width == x1 - x0

@@ -38,6 +38,13 @@ for step in "$@"; do
       timeout 600 python bench.py > $OUT/bench.log 2>&1; grep '^{' $OUT/bench.log > $OUT/bench.json; benchline bench $OUT/bench.json | tee -a $S ;;
     benchq)
       for v in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/benchq$v.log 2>&1; benchline benchq$v $OUT/benchq$v.log | tee -a $S; done ;;
+    abflag:*)
+      # A/B of a bench.py command-line flag (e.g. abflag:--autograd), interleaved
+      fl="${step#abflag:}"
+      for v in 1 2; do
+        timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/abf_base$v.log 2>&1; benchline base$v $OUT/abf_base$v.log | tee -a $S
+        timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary $fl > $OUT/abf_alt$v.log 2>&1; benchline "alt$v($fl)" $OUT/abf_alt$v.log | tee -a $S
+      done ;;
     ab:*)
       envs=$(echo "${step#ab:}" | tr ',' ' ')
       for v in 1 2; do
