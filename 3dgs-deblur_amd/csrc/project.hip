@@ -389,12 +389,14 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
         cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
       }
       float op = fp.antialiased ? opac * o.comp : opac;
+      float aux[4];
+      rec_aux(op, o.conic_x, o.conic_z, aux);
+      // (all four 16-byte stores of the 64-byte record: leaving the last one out — or non-temporal stores — made this
+      //  kernel SLOWER, 0.107 -> 0.137 / 0.283 ms on the headline; visit r4_v4)
       r[0] = make_float4(o.x, o.y, o.conic_x, o.conic_y);
       r[1] = make_float4(o.conic_z, op, cr, cg);
       r[2] = make_float4(cb, o.depth, __int_as_float(o.tmin_x | (o.tmin_y << 16)),
                          __int_as_float(o.tmax_x | (o.tmax_y << 16)));
-      float aux[4];
-      rec_aux(op, o.conic_x, o.conic_z, aux);
       r[3] = make_float4(aux[0], aux[1], aux[2], aux[3]);
     } else if (!fp.skip_culled) {
       // (three of four pairs in the benchmark scene: 48 bytes each that nothing reads once the depth pre-sort

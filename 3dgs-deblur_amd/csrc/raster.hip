@@ -326,10 +326,15 @@ __device__ __forceinline__ bool any_live(const PixPair (&pp)[2]) {
   return __builtin_amdgcn_ballot_w64(m == m) != 0ull;
 }
 
+// (A quadrant mapping of the lane's four pixels — one per 8x8 quadrant of the tile, quadrants nobody touches skipped
+//  by a scalar branch — is what the BACKWARD uses, raster_bwd.hip.  Built for the forward too and measured, visit r4_v5:
+//  0.346 vs 0.328 ms on the benchmark scene, 2.10 vs 2.12 ms on the fitted-model-like one — the four branches cost the
+//  forward's short per-pixel chain more than the skipped quadrants save.  The two kernels meet in per-pixel arrays, so
+//  each keeps the mapping that suits it; both evaluate the validity test on bit-identical operands.)
 // the tile's list, front to back (n = range.y - range.x > 0 entries); `idx` handed to an entry = its list position
-template <bool DEPTH, bool CLAMP>
+template <bool DEPTH, bool CLAMP, class State>
 __device__ __forceinline__ void fwd_walk(const int* __restrict__ ids, const float* __restrict__ records, unsigned max_id,
-                                         int2 range, unsigned n, float pxf, PixPair (&pp)[2], int* __restrict__ fin_out,
+                                         int2 range, unsigned n, float pxf, State& pp, int* __restrict__ fin_out,
                                          unsigned fin_off, unsigned fin_row) {
   int b = range.x & ~3;
   const int4* __restrict__ ids4 = reinterpret_cast<const int4*>(ids);
@@ -356,6 +361,25 @@ __device__ __forceinline__ void fwd_walk(const int* __restrict__ ids, const floa
     if ((b & GS_FWD_LIVE_MASK) == GS_FWD_LIVE_MASK && !any_live(pp)) break;
   }
 }
+
+// per-pixel state accessors shared by the two lane -> pixel mappings
+struct PixCols { PixPair p[2]; };                // column mapping: four consecutive rows of one column, as two float2 pairs
+__device__ __forceinline__ void pix_set(PixCols& st, int k, float T, float cr, float cg, float cb, float cd, float py) {
+  PixPair& q = st.p[k >> 1];
+  if (k & 1) { q.T.y = T; q.Cr.y = cr; q.Cg.y = cg; q.Cb.y = cb; q.Cd.y = cd; q.py.y = py; }
+  else       { q.T.x = T; q.Cr.x = cr; q.Cg.x = cg; q.Cb.x = cb; q.Cd.x = cd; q.py.x = py; }
+}
+__device__ __forceinline__ void pix_get(const PixCols& st, int k, float& T, float& cr, float& cg, float& cb, float& cd, float& py) {
+  const PixPair& q = st.p[k >> 1];
+  if (k & 1) { T = q.T.y; cr = q.Cr.y; cg = q.Cg.y; cb = q.Cb.y; cd = q.Cd.y; py = q.py.y; }
+  else       { T = q.T.x; cr = q.Cr.x; cg = q.Cg.x; cb = q.Cb.x; cd = q.Cd.x; py = q.py.x; }
+}
+template <bool DEPTH, bool CLAMP>
+__device__ __forceinline__ void blend_entry(const RecS& rc, float pxf, int idx, PixCols& st, int* __restrict__ fin_out,
+                                            unsigned fin_off, unsigned fin_row) {
+  blend_entry<DEPTH, CLAMP>(rc, pxf, idx, st.p, fin_out, fin_off, fin_row);
+}
+__device__ __forceinline__ bool any_live(const PixCols& st) { return any_live(st.p); }
 
 template <bool DEPTH>
 __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm, SliceState st,
@@ -384,37 +408,39 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
     return;
   }
 
-  const int px = tx * K::kTile + (lane & 15);
+  // lane -> its four pixels: pixel k at (px0 + kx(k), py0 + ky(k))
+  const int px0 = tx * K::kTile + (lane & 15);
   const int py0 = ty * K::kTile + (lane >> 4) * 4;
-  const float pxf = (float)px + 0.5f;
+  auto kx = [](int) { return 0; };
+  auto ky = [](int k) { return k; };
+  const float pxf = (float)px0 + 0.5f;
   const float qnan = __builtin_nanf("");
   // element offsets into final_idx [S,H,W] of the lane's first pixel, and of a row (32 bit: S*H*W < 2^31 is checked
   // by the caller's buffer sizes)
-  const unsigned fin_off = ((unsigned)s * (unsigned)prm.H + (unsigned)py0) * (unsigned)prm.W + (unsigned)px;
+  const unsigned fin_off = ((unsigned)s * (unsigned)prm.H + (unsigned)py0) * (unsigned)prm.W + (unsigned)px0;
   const unsigned fin_row = (unsigned)prm.W;
   int* __restrict__ fin_out = final_idx;
-  PixPair pp[2];
+  PixCols pp;
   bool inside[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    inside[k] = px < prm.W && (py0 + k) < prm.H;
+    const int px = px0 + kx(k), py = py0 + ky(k);
+    inside[k] = px < prm.W && py < prm.H;
     float Tk = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f;
     bool live = inside[k];
     if (!st.first && inside[k]) {
-      size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
+      size_t pix = ((size_t)s * prm.H + py) * prm.W + px;
       cr = out_img[pix * 3 + 0]; cg = out_img[pix * 3 + 1]; cb = out_img[pix * 3 + 2];
       if (DEPTH) cd = out_depth[pix];
       const float Tf = out_T[pix], lv = st.live_T[pix];
       live = lv > 0.f;
       Tk = live ? lv : Tf;
     }
-    const float pyk = live ? (float)(py0 + k) + 0.5f : qnan;
+    const float pyk = live ? (float)py + 0.5f : qnan;
     // final_idx of a pixel that stopped in an earlier slice: it blends nothing of this one.  (A pixel that stops in
     // this slice writes its stop index at that moment, one that stays live gets the end of the list below.)
-    if (inside[k] && !live) final_idx[fin_off + (unsigned)k * fin_row] = range.x;
-    PixPair& q = pp[k >> 1];
-    if (k & 1) { q.T.y = Tk; q.Cr.y = cr; q.Cg.y = cg; q.Cb.y = cb; q.Cd.y = cd; q.py.y = pyk; }
-    else       { q.T.x = Tk; q.Cr.x = cr; q.Cg.x = cg; q.Cb.x = cb; q.Cd.x = cd; q.py.x = pyk; }
+    if (inside[k] && !live) final_idx[fin_off + (unsigned)ky(k) * fin_row + (unsigned)kx(k)] = range.x;
+    pix_set(pp, k, Tk, cr, cg, cb, cd, pyk);
   }
   const unsigned n = (unsigned)(range.y - range.x);
   if (n != 0u) {
@@ -429,15 +455,14 @@ __global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm,
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (inside[k]) {
-      const PixPair& q = pp[k >> 1];
-      const float Tf = (k & 1) ? q.T.y : q.T.x, pyk = (k & 1) ? q.py.y : q.py.x;
-      const float cr = (k & 1) ? q.Cr.y : q.Cr.x, cg = (k & 1) ? q.Cg.y : q.Cg.x, cb = (k & 1) ? q.Cb.y : q.Cb.x;
-      size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
+      float Tf, cr, cg, cb, cd, pyk;
+      pix_get(pp, k, Tf, cr, cg, cb, cd, pyk);
+      size_t pix = ((size_t)s * prm.H + (py0 + ky(k))) * prm.W + (px0 + kx(k));
       out_img[pix * 3 + 0] = cr + Tf * bgr;
       out_img[pix * 3 + 1] = cg + Tf * bgg;
       out_img[pix * 3 + 2] = cb + Tf * bgb;
       out_T[pix] = Tf;
-      if (DEPTH) out_depth[pix] = (k & 1) ? q.Cd.y : q.Cd.x;
+      if (DEPTH) out_depth[pix] = cd;
       if (pyk == pyk) final_idx[pix] = range.y;
       if (!st.last) st.live_T[pix] = pyk == pyk ? Tf : 0.f;
     }

@@ -283,7 +283,9 @@ constexpr int kRedG4 = 4;
 // LDS: 32 columns per row instead of 64 -> 5.1 KB of LDS per wave instead of 9.6 KB, so the occupancy limit moves
 // from LDS (4 waves per SIMD) to the VGPRs (5), and the row sums read half as much.
 constexpr int kRedCols4 = 32, kRedStride4 = 36;    // 36 = 32 + 4: rows 16-byte aligned, b128 row reads conflict-free
+#ifndef GS_BWD_SLOAD_WAVES
 #define GS_BWD_SLOAD_WAVES 5
+#endif
 constexpr int kRedFloats4 = kRedG4 * 9 * kRedStride4;
 
 // w[i] = v[i](lane) + v[i](lane ^ 1) for nine values: nine v_add_f32_dpp in one block (the DPP combiner leaves most
@@ -304,82 +306,72 @@ __device__ __forceinline__ void pair_sum9(float (&v)[9]) {
       : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
 }
 
-struct BwdPair { f2 T, Dv, vr, vg, vb, py; int fin0, fin1; };
+// ---------------------------------------------------------------------------
+// One list entry against the lane's four pixels (returns whether any lane of the wave was hit; then the lane's 9
+// partial sums are in LDS rows slot*9 .. slot*9+8, column `lane >> 1`).
+// Quadrant mapping (round 4): the lane's pixel k lies in the 8x8 quadrant (k & 1, k >> 1) of the tile (lane = (x8, y8)
+// inside a quadrant) instead of four consecutive rows of one column as in the forward.  A splat of a few pixels reaches
+// two or three of a tile's four quadrants (2.96 of 4 on the fitted-model-like scene, 3.7 on the benchmark scene:
+// profiles/lane_stats.jsonl), and with this mapping "nobody's pixel k blended this entry" is a WAVE-UNIFORM fact: a
+// quadrant without a hit is skipped by a scalar branch right after its validity test (two fma, two compares) — before
+// the exp, the reciprocal and the ~20 multiply-adds of the gradient terms.  Measured against the column mapping, visit
+// r4_v5: backward 4.33 vs 4.66 ms on the fitted-model-like scene, 0.70 vs 0.71 on the benchmark scene.  (An 8x8-tile
+// BINNING would skip the same work but sort and reduce ~3x the entries)  dx takes two values per
+// lane (left / right quadrants), so the moments of v_sigma are kept per column half: M0 and M1 twice, M2 once.
+// Validity is the forward's ONE compare on the shifted exponent (raster.hip, gs_math.h rec_aux) on bit-identical
+// operands (dx = x - pixel centre, never "left dx - 8"), so both directions take the same decision for every pixel and
+// entry; alpha = kmul * 2^u; and because v_sigma = -alpha * v_alpha and v_opacity = (alpha / op) * v_alpha under the
+// same gate, the opacity gradient is -(sum of v_sigma) / op: slot 5 carries RAW_OP ? the plain sum of v_sigma (the
+// tuple reduce divides by -op once per Gaussian) : the finished gradient.
+// CLAMP=false: no Gaussian of the tile's list has an opacity above 0.999 (tile_hot, see the forward).
+// ---------------------------------------------------------------------------
+struct BwdQuad { float T[4], Dv[4], vr[4], vg[4], vb[4], py[4]; int fin[4]; };
 
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-
-// one list entry against the lane's four pixels; returns whether any lane of the wave was hit (then the lane's 9
-// partial sums are in LDS rows slot*9 .. slot*9+8, column `lane >> 1`)
-// CLAMP=false: no Gaussian of the tile's list has an opacity above 0.999 (tile_hot, see the forward)
-// Round 4: validity is the forward's ONE compare on the shifted exponent (raster.hip, gs_math.h rec_aux — the same
-// expression, so both directions take the same decision for every pixel and entry), alpha = kmul * 2^u; and because
-// v_sigma = -alpha * v_alpha and v_opacity = (alpha / op) * v_alpha under the same gate, the opacity gradient is
-// -(sum of v_sigma) / op: its own accumulator and its selects are gone, slot 5 carries RAW_OP ? the plain sum of
-// v_sigma (the tuple reduce divides by -op once per Gaussian) : the finished gradient.
 template <bool CLAMP, bool RAW_OP>
-__device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, BwdPair (&pp)[2], float* __restrict__ red,
+__device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, BwdQuad& pp, float* __restrict__ red,
                                           int slot, int lane, float agm) {
-  const float dx = rc.x - pxf;
-  const float hxm = fmaf(rc.qx * dx, dx, rc.nmid);         // exponent terms, pre-scaled by -log2(e), + the shift
-  const float bx = (rc.cy * kNegLog2e) * dx;
-  const f2 hx2 = {hxm, hxm}, bx2 = {bx, bx}, qz2 = {rc.qz, rc.qz}, gy2 = {rc.y, rc.y}, km2 = {rc.kmul, rc.kmul};
-  f2 dy2[2], ov2[2];
-  bool hit[4];
+  // pxf: the lane's pixel-centre column in the LEFT quadrants; the right ones are 8 further (exact in fp32)
+  const float dxa = rc.x - pxf, dxb = rc.x - (pxf + 8.0f);
+  const float qyn = rc.cy * kNegLog2e;
+  const float hx[2] = {fmaf(rc.qx * dxa, dxa, rc.nmid), fmaf(rc.qx * dxb, dxb, rc.nmid)};
+  const float bx[2] = {qyn * dxa, qyn * dxb};
+  float m0[2] = {0.f, 0.f}, m1[2] = {0.f, 0.f}, m2 = 0.f, q_r = 0.f, q_g = 0.f, q_b = 0.f;
+  bool any = false;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    dy2[h] = gy2 - pp[h].py;
-    const f2 u = fma2(dy2[h], fma2(qz2, dy2[h], bx2), hx2);
-    ov2[h] = km2 * f2{__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)};
-    hit[2 * h] = (idx < pp[h].fin0) && (fabsf(u.x) <= rc.nmid);
-    hit[2 * h + 1] = (idx < pp[h].fin1) && (fabsf(u.y) <= rc.nmid);
+  for (int k = 0; k < 4; ++k) {
+    const float dy = rc.y - pp.py[k];
+    const float u = fmaf(dy, fmaf(rc.qz, dy, bx[k & 1]), hx[k & 1]);
+    const bool hit = (idx < pp.fin[k]) && (fabsf(u) <= rc.nmid);
+    if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;           // nobody's quadrant-k pixel blended this entry
+    any = true;
+    const float ov = rc.kmul * __builtin_amdgcn_exp2f(u);
+    // pixels that are not hit are neutralised by SELECTING alpha = 0 (1/(1-0) = 1 exactly, every term an exact zero)
+    const float alpha = hit ? (CLAMP ? fminf(K::kAlphaMax, ov) : ov) : 0.f;
+    const float ovm = CLAMP ? ((hit && ov <= agm) ? ov : 0.f) : alpha;   // d min(0.999, o*vis) = 0 when clamped
+    const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+    pp.T[k] *= ra;                               // transmittance in front of this Gaussian
+    const float fac = alpha * pp.T[k];
+    q_r = fmaf(fac, pp.vr[k], q_r); q_g = fmaf(fac, pp.vg[k], q_g); q_b = fmaf(fac, pp.vb[k], q_b);
+    const float cv = fmaf(rc.b, pp.vb[k], fmaf(rc.g, pp.vg[k], rc.r * pp.vr[k]));
+    const float v_al = fmaf(pp.T[k], cv, -(ra * pp.Dv[k]));
+    pp.Dv[k] = fmaf(fac, cv, pp.Dv[k]);
+    const float v_sigma = -ovm * v_al;
+    const float vsdy = v_sigma * dy;
+    m0[k & 1] += v_sigma;
+    m1[k & 1] += vsdy;
+    m2 = fmaf(vsdy, dy, m2);
   }
-  if (__ballot(hit[0] || hit[1] || hit[2] || hit[3]) == 0ull) return false;
-  const f2 cr2 = {rc.r, rc.r}, cg2 = {rc.g, rc.g}, cb2 = {rc.b, rc.b};
-  f2 q_r = {0.f, 0.f}, q_g = q_r, q_b = q_r, m0 = q_r, m1 = q_r, m2 = q_r;
-  // pixels that are not hit are neutralised by SELECTING alpha = 0 (1/(1-0) = 1 exactly, every contribution is an
-  // exact zero) instead of per-pixel exec regions
-  auto pair = [&](int h, f2 alpha, f2 ovm) {
-    BwdPair& q = pp[h];
-    const f2 om = 1.f - alpha;
-    const f2 ra = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-    q.T *= ra;                               // transmittance in front of this Gaussian
-    const f2 fac = alpha * q.T;
-    q_r = fma2(fac, q.vr, q_r); q_g = fma2(fac, q.vg, q_g); q_b = fma2(fac, q.vb, q_b);
-    const f2 cv = fma2(cb2, q.vb, fma2(cg2, q.vg, cr2 * q.vr));
-    const f2 v_al = fma2(q.T, cv, -(ra * q.Dv));
-    q.Dv = fma2(fac, cv, q.Dv);
-    const f2 v_sigma = -ovm * v_al;
-    // moments of v_sigma over the lane's pixels (dx is the same for all four)
-    m0 += v_sigma;
-    const f2 vsdy = v_sigma * dy2[h];
-    m1 += vsdy;
-    m2 = fma2(vsdy, dy2[h], m2);
-  };
-  if (CLAMP) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const bool h0 = hit[2 * h], h1 = hit[2 * h + 1];
-      const f2 alpha = {h0 ? fminf(K::kAlphaMax, ov2[h].x) : 0.f, h1 ? fminf(K::kAlphaMax, ov2[h].y) : 0.f};
-      // d min(0.999, o*vis) = 0 when clamped
-      const bool f0 = h0 && ov2[h].x <= agm, f1 = h1 && ov2[h].y <= agm;
-      pair(h, alpha, f2{f0 ? ov2[h].x : 0.f, f1 ? ov2[h].y : 0.f});
-    }
-  } else {
-    // opacity <= 0.999 (<= agm): alpha = op*vis <= op never reaches the clamp on a hit pixel (s2 <= 0), so
-    // min(0.999, ov) == ov and the clamp never blocks the gradient.  (Chosen per TILE: a per-entry branch leaves
-    // four 64-bit merge copies per entry behind.)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const f2 alpha = {hit[2 * h] ? ov2[h].x : 0.f, hit[2 * h + 1] ? ov2[h].y : 0.f};
-      pair(h, alpha, alpha);
-    }
-  }
-  const float M0 = m0.x + m0.y, M1 = m1.x + m1.y, M2 = m2.x + m2.y;
-  const float p_cx = (0.5f * dx * dx) * M0, p_cy = dx * M1, p_cz = 0.5f * M2;
-  const float p_x = (rc.cx * dx) * M0 + rc.cy * M1;
-  const float p_y = (rc.cy * dx) * M0 + rc.cz * M1;
+  if (!any) return false;
+  // sum over the lane's pixels of v_sigma * {1, dx, dx^2} and of v_sigma * dy * {1, dx}
+  const float M0 = m0[0] + m0[1], M1 = m1[0] + m1[1];
+  const float X0 = fmaf(dxb, m0[1], dxa * m0[0]);                     // sum v_sigma dx
+  const float X1 = fmaf(dxb, m1[1], dxa * m1[0]);                     // sum v_sigma dx dy
+  const float XX = fmaf(dxb * dxb, m0[1], (dxa * dxa) * m0[0]);       // sum v_sigma dx^2
+  const float p_cx = 0.5f * XX, p_cy = X1, p_cz = 0.5f * m2;
+  const float p_x = fmaf(rc.cx, X0, rc.cy * M1);
+  const float p_y = fmaf(rc.cy, X0, rc.cz * M1);
   const float p_op = RAW_OP ? M0 : -M0 * __builtin_amdgcn_rcpf(rc.op);
-  float w[9] = {p_x, p_y, p_cx, p_cy, p_cz, p_op, q_r.x + q_r.y, q_g.x + q_g.y, q_b.x + q_b.y};
+  float w[9] = {p_x, p_y, p_cx, p_cy, p_cz, p_op, q_r, q_g, q_b};
   pair_sum9(w);
   if ((lane & 1) == 0) {
     float* r0 = red + slot * (9 * kRedStride4) + (lane >> 1);
@@ -390,10 +382,10 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
 }
 
 // the tile's list, back to front, entries [range_x, wave_end)
-template <bool CLAMP, int OUT>
+template <bool CLAMP, int OUT, class State>
 __device__ __forceinline__ void bwd_walk(const int* __restrict__ ids, const int* __restrict__ eids,
                                          const float* __restrict__ records, unsigned max_id, int range_x, int wave_end,
-                                         unsigned n, float pxf, float agm, BwdPair (&pp)[2], float* __restrict__ red,
+                                         unsigned n, float pxf, float agm, State& pp, float* __restrict__ red,
                                          int lane, float* __restrict__ v_records, float* __restrict__ tuples,
                                          unsigned char* __restrict__ flags) {
   const int row = lane;                                    // row-sum role: lanes 0..35
@@ -448,6 +440,13 @@ __device__ __forceinline__ void bwd_walk(const int* __restrict__ ids, const int*
   }
 }
 
+// per-pixel state accessors
+__device__ __forceinline__ void pix_set(BwdQuad& st, int k, float T, float Dv, float vr, float vg, float vb, float py, int fin) {
+  st.T[k] = T; st.Dv[k] = Dv; st.vr[k] = vr; st.vg[k] = vg; st.vb[k] = vb; st.py[k] = py; st.fin[k] = fin;
+}
+__device__ __forceinline__ void pix_get(const BwdQuad& st, int k, float& T, float& Dv, float& vr, float& vg, float& vb) {
+  T = st.T[k]; Dv = st.Dv[k]; vr = st.vr[k]; vg = st.vg[k]; vb = st.vb[k];
+}
 template <bool STATE, int OUT>
 __global__ __launch_bounds__(256, GS_BWD_SLOAD_WAVES) void raster_bwd_sload_kernel(
     RasterParams prm, const int* __restrict__ ids /*record index per sorted entry, padded*/,
@@ -471,24 +470,27 @@ __global__ __launch_bounds__(256, GS_BWD_SLOAD_WAVES) void raster_bwd_sload_kern
   range.y = __builtin_amdgcn_readfirstlane(range.y);
   if (range.y <= range.x) return;
 
-  const int px = tx * K::kTile + (lane & 15);
-  const int py0 = ty * K::kTile + (lane >> 4) * 4;
-  const float pxf = (float)px + 0.5f;
+  // lane -> its four pixels, one per 8x8 quadrant: pixel k at (px0 + kx(k), py0 + ky(k))
+  const int px0 = tx * K::kTile + (lane & 7);
+  const int py0 = ty * K::kTile + (lane >> 3);
+  auto kx = [](int k) { return 8 * (k & 1); };
+  auto ky = [](int k) { return 8 * (k >> 1); };
+  const float pxf = (float)px0 + 0.5f;
   const float bgr = prm.background[0], bgg = prm.background[1], bgb = prm.background[2];
-  BwdPair pp[2];
+  BwdQuad pp;
   int my_end = range.x;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int y = py0 + k;
+    const int x = px0 + kx(k), y = py0 + ky(k);
     float Tk = 1.f, Dv = 0.f, vr = 0.f, vg = 0.f, vb = 0.f;
     int fin = range.x;
-    if (px < prm.W && y < prm.H) {
-      size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
+    if (x < prm.W && y < prm.H) {
+      size_t pix = ((size_t)s * prm.H + y) * prm.W + x;
       const float Tfin = out_T[pix];
       fin = final_idx[pix];
       vr = v_img[pix * 3 + 0]; vg = v_img[pix * 3 + 1]; vb = v_img[pix * 3 + 2];
       if (prm.cmb_scale) {
-        const size_t q = ((size_t)y * prm.W + px) * 3;
+        const size_t q = ((size_t)y * prm.W + x) * 3;
         vr = combine_grad(vr, prm.cmb_scale[q + 0], prm.cmb_gamma, prm.cmb_min);
         vg = combine_grad(vg, prm.cmb_scale[q + 1], prm.cmb_gamma, prm.cmb_min);
         vb = combine_grad(vb, prm.cmb_scale[q + 2], prm.cmb_gamma, prm.cmb_min);
@@ -503,9 +505,7 @@ __global__ __launch_bounds__(256, GS_BWD_SLOAD_WAVES) void raster_bwd_sload_kern
       }
     }
     my_end = max(my_end, fin);
-    BwdPair& q = pp[k >> 1];
-    if (k & 1) { q.T.y = Tk; q.Dv.y = Dv; q.vr.y = vr; q.vg.y = vg; q.vb.y = vb; q.py.y = (float)y + 0.5f; q.fin1 = fin; }
-    else       { q.T.x = Tk; q.Dv.x = Dv; q.vr.x = vr; q.vg.x = vg; q.vb.x = vb; q.py.x = (float)y + 0.5f; q.fin0 = fin; }
+    pix_set(pp, k, Tk, Dv, vr, vg, vb, (float)y + 0.5f, fin);
   }
   const int wave_end = __builtin_amdgcn_readfirstlane(wave_max_i(my_end));
   const unsigned n = (unsigned)(wave_end - range.x);       // entries [range.x, wave_end) reached some pixel's final index
@@ -518,16 +518,16 @@ __global__ __launch_bounds__(256, GS_BWD_SLOAD_WAVES) void raster_bwd_sload_kern
   if (STATE) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int y = py0 + k;
-      if (px < prm.W && y < prm.H) {
-        const BwdPair& q = pp[k >> 1];
-        const float vr = (k & 1) ? q.vr.y : q.vr.x, vg = (k & 1) ? q.vg.y : q.vg.x, vb = (k & 1) ? q.vb.y : q.vb.x;
-        size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
+      const int x = px0 + kx(k), y = py0 + ky(k);
+      if (x < prm.W && y < prm.H) {
+        float Tk, Dv, vr, vg, vb;
+        pix_get(pp, k, Tk, Dv, vr, vg, vb);
+        size_t pix = ((size_t)s * prm.H + y) * prm.W + x;
         const float Tfin = out_T[pix];
         const float va_out = v_alpha ? v_alpha[pix] : 0.f;
         const float va = Tfin * (va_out - (bgr * vr + bgg * vg + bgb * vb));
-        bwd_T[pix] = (k & 1) ? q.T.y : q.T.x;
-        bwd_B[pix] = ((k & 1) ? q.Dv.y : q.Dv.x) + va;       // behind-colour . v_out
+        bwd_T[pix] = Tk;
+        bwd_B[pix] = Dv + va;       // behind-colour . v_out
       }
     }
   }

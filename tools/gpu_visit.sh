@@ -11,6 +11,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 S=$OUT/summary.log
 : > $S
+ABB_ARGS=${ABB_ARGS---no-secondary}      # extra bench.py arguments of the abbuild step (default: headline only)
 benchline() { python - "$1" "$2" <<'PY'
 import json, sys
 tag, path = sys.argv[1], sys.argv[2]
@@ -38,6 +39,15 @@ for step in "$@"; do
       timeout 600 python bench.py > $OUT/bench.log 2>&1; grep '^{' $OUT/bench.log > $OUT/bench.json; benchline bench $OUT/bench.json | tee -a $S ;;
     benchq)
       for v in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/benchq$v.log 2>&1; benchline benchq$v $OUT/benchq$v.log | tee -a $S; done ;;
+    abbuild:*)
+      # A/B of a compile-time variant: abbuild:<file.hip>:<-DFLAG=V>[:<-DFLAG2>]  (tools/build_variant.py)
+      spec="${step#abbuild:}"; f="${spec%%:*}"; defs=$(echo "${spec#*:}" | tr ':' ' ')
+      alt=/tmp/libgsd_$(echo "$spec" | tr -c 'A-Za-z0-9' '_').so
+      python tools/build_variant.py $f $alt $defs > $OUT/abbuild.log 2>&1 || { tail -5 $OUT/abbuild.log | tee -a $S; continue; }
+      for v in 1 2; do
+        timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline $ABB_ARGS > $OUT/abb_base$v.log 2>&1; benchline base$v $OUT/abb_base$v.log | tee -a $S
+        GSD_LIB_PATH=$alt timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline $ABB_ARGS > $OUT/abb_alt$v.log 2>&1; benchline "alt$v($defs)" $OUT/abb_alt$v.log | tee -a $S
+      done ;;
     abflag:*)
       # A/B of a bench.py command-line flag (e.g. abflag:--autograd), interleaved
       fl="${step#abflag:}"
