@@ -92,5 +92,37 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     return LIB_PATH
 
 
+# ---- TEST infrastructure: the round-1 compositors (v_readlane kernels; the "plain path" of the equivalence tests and the
+# lane-utilisation counters) are compiled out of the product library (GS_ROUND1_KERNELS) and live in a library of their
+# own under tests/, built from the same two sources with -DGS_ROUND1_KERNELS=1 (tests/python_frame_path.py loads it).
+ROUND1_LIB_PATH = PKG_DIR.parent / "tests" / "libgsdeblur_round1.so"
+ROUND1_HASH_PATH = PKG_DIR.parent / "tests" / "libgsdeblur_round1.so.srchash"
+
+
+def build_round1_library(force: bool = False, verbose: bool = False) -> Path:
+    if not force and ROUND1_LIB_PATH.exists() and ROUND1_HASH_PATH.exists() and \
+            ROUND1_HASH_PATH.read_text().strip() == source_hash():
+        return ROUND1_LIB_PATH
+    hipcc = _hipcc()
+    build_dir = PKG_DIR / "build"
+    build_dir.mkdir(exist_ok=True)
+    flags = dict(SOURCES)
+    objs = []
+    for src in ("raster.hip", "raster_bwd.hip"):
+        o = build_dir / (Path(src).stem + "_round1.o")
+        cmd = [hipcc, *COMMON, *flags[src], "-DGS_ROUND1_KERNELS=1", "-c", str(CSRC / src), "-o", str(o)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(o)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(ROUND1_LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    ROUND1_HASH_PATH.write_text(source_hash() + "\n")
+    return ROUND1_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
+    print(build_round1_library(force=True, verbose=True))

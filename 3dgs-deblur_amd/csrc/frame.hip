@@ -55,10 +55,12 @@ inline int bits_for(long long n) {
 inline int hip_status(hipError_t e) { return e == hipSuccess ? GS_OK : 1000 + (int)e; }
 
 // ---- optional stage timing (debug / bench): HIP events on the launch stream -------------------------------------
+// Per HOST THREAD: concurrent callers (one thread per stream) neither see each other's mask nor race
+// on the vectors; a thread reads back what it recorded itself.
 struct StageEvents { int stage; hipEvent_t a, b; };
-unsigned g_profile_mask = 0;
-std::vector<StageEvents> g_events;            // recorded since the last read
-std::vector<StageEvents> g_pool;              // reusable event pairs
+thread_local unsigned g_profile_mask = 0;
+thread_local std::vector<StageEvents> g_events;            // recorded since the last read
+thread_local std::vector<StageEvents> g_pool;              // reusable event pairs
 
 struct StageScope {
   hipStream_t st;
@@ -102,7 +104,20 @@ inline long long now_us() {
   return (long long)ts.tv_sec * 1000000ll + ts.tv_nsec / 1000;
 }
 
-// device words [n] -> host_pinned[1..n] (host_pinned[0] is the sequence word); returns when they are readable
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  asm volatile("" ::: "memory");
+#endif
+}
+
+// device words [n] -> host_pinned[1..n] (host_pinned[0] is the sequence word); returns when they are readable.
+// poll: host_pinned must be host-coherent pinned memory the GPU can write at system scope (hipHostMalloc default /
+// torch pin_memory); with non-coherent pinned memory (HIP_HOST_COHERENT=0) the sequence word may never become visible
+// and every read-back waits out kPollTimeoutUs before falling back to hipStreamSynchronize — pass poll_readback = 0 then.
 inline int read_back(const unsigned* src_dev, unsigned* host_pinned, int n, bool poll, hipStream_t st) {
   if (!poll) {
     hipError_t e = hipMemcpyAsync(host_pinned + 1, src_dev, 4ll * n, hipMemcpyDeviceToHost, st);
@@ -118,7 +133,7 @@ inline int read_back(const unsigned* src_dev, unsigned* host_pinned, int n, bool
   const long long t0 = now_us();
   unsigned spins = 0;
   while (__atomic_load_n(host_pinned, __ATOMIC_ACQUIRE) != 1u) {
-    __builtin_ia32_pause();
+    cpu_relax();
     if ((++spins & 1023u) == 0 && now_us() - t0 > kPollTimeoutUs) {
       int r = hip_status(hipStreamSynchronize(st));
       if (r != GS_OK) return r;
@@ -147,7 +162,7 @@ GS_EXPORT int gs_frame_profile_enable(unsigned stage_mask) {
 }
 
 // Drains the event pairs recorded since the last call: stage_ids[i] / ms[i] for i < returned count (<= max_events;
-// the rest is dropped).  Synchronises on the recorded events.  Not thread-safe (measurement facility).
+// the rest is dropped).  Synchronises on the recorded events.  State is per host thread (measurement facility).
 GS_EXPORT int gs_frame_profile_read(int max_events, int* stage_ids, float* ms) {
   int n = 0;
   for (StageEvents& e : g_events) {

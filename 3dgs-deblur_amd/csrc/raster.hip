@@ -31,6 +31,14 @@ struct SliceState {
   int* open_flag;             // nullable (zeroed by the caller): += 1 for every tile this launch leaves open
 };
 
+// The round-1 compositor (records broadcast with v_readlane; alpha / sigma / T tests as three compares) is TEST
+// infrastructure since round 4: compiled only into tests/libgsdeblur_round1.so (-DGS_ROUND1_KERNELS=1, _build.py
+// build_round1_library) as the kernel side of the equivalence tests' "plain path" and of the lane-utilisation counters;
+// the product library answers GS_ERR_INVALID to variant != 0 and to gs_rasterize_fwd_slice_stats.
+#ifndef GS_ROUND1_KERNELS
+#define GS_ROUND1_KERNELS 0
+#endif
+#if GS_ROUND1_KERNELS
 // STATS (debug, gs_rasterize_fwd_slice_stats): lane-utilisation counters of the walk, see kLaneStat* below
 constexpr int kLaneStats = 13;
 template <bool SKIP_EMPTY, bool STATS = false>
@@ -203,6 +211,8 @@ __global__ __launch_bounds__(256) void raster_fwd_slice_kernel(RasterParams prm,
     else if (st.open_flag) atomicAdd(st.open_flag, 1);      // the word counts the tiles left open
   }
 }
+
+#endif  // GS_ROUND1_KERNELS
 
 // ---------------------------------------------------------------------------
 // Forward compositor, scalar-cache variant (round 2; inner loop rewritten in round 4).  tools/valu_bench*.hip measured
@@ -549,27 +559,39 @@ static int launch_fwd(const RasterParams& prm, const SliceState& st, const int* 
                       const unsigned char* tile_hot = nullptr, unsigned long long* stats = nullptr) {
   unsigned work = (unsigned)(prm.S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
+#if GS_ROUND1_KERNELS
   if (stats) {
     if (out_depth) return GS_ERR_INVALID;
     hipLaunchKernelGGL((raster_fwd_slice_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, prm, st, out_img,
                        out_T, final_idx, blocks, stats);
     return GS_OK;
   }
-  if (out_depth && !(variant == 0 && ids)) return GS_ERR_INVALID;   // no depth channel in the round-1 kernel
-  if (variant == 0 && ids && out_depth)
+#else
+  if (stats) return GS_ERR_INVALID;
+#endif
+  // n_records == 0: the caller says there is not a single list entry — every tile's range is empty and `ids` is never
+  // read (background only)
+  const bool sload = variant == 0 && (ids != nullptr || n_records == 0);
+  if (out_depth && !sload) return GS_ERR_INVALID;                   // no depth channel in the round-1 kernel
+  if (sload && out_depth)
     hipLaunchKernelGGL(raster_fwd_sload_kernel<true>, dim3(blocks), dim3(256), 0, stream, prm, st, ids, prm.records,
                        (unsigned)(n_records > 0 ? n_records - 1 : 0), out_img, out_T, final_idx, blocks, out_depth,
                        tile_hot);
-  else if (variant == 0 && ids)
+  else if (sload)
     hipLaunchKernelGGL(raster_fwd_sload_kernel<false>, dim3(blocks), dim3(256), 0, stream, prm, st, ids, prm.records,
                        (unsigned)(n_records > 0 ? n_records - 1 : 0), out_img, out_T, final_idx, blocks,
                        (float*)nullptr, tile_hot);
+#if GS_ROUND1_KERNELS
   else if (variant == 1)
     hipLaunchKernelGGL(raster_fwd_slice_kernel<false>, dim3(blocks), dim3(256), 0, stream, prm, st, out_img, out_T,
                        final_idx, blocks);
   else
     hipLaunchKernelGGL(raster_fwd_slice_kernel<true>, dim3(blocks), dim3(256), 0, stream, prm, st, out_img, out_T,
                        final_idx, blocks);
+#else
+  else
+    return GS_ERR_INVALID;      // the round-1 compositors (variant 1 / 2, or no record-index list) are not in this build
+#endif
   return GS_OK;
 }
 
@@ -581,8 +603,9 @@ GS_EXPORT int gs_rasterize_fwd(const float* records, const int* sorted_vals, con
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
   // one pass over the complete tile lists = the sliced kernel with first == last (no persistent state)
   SliceState st; st.tile_done = nullptr; st.live_T = nullptr; st.first = 1; st.last = 1; st.open_flag = nullptr;
-  launch_fwd(prm, st, n_records > 0 ? sorted_vals : nullptr, n_records, out_img, out_T, final_idx, variant,
-             (hipStream_t)stream);
+  int rc = launch_fwd(prm, st, n_records > 0 ? sorted_vals : nullptr, n_records, out_img, out_T, final_idx, variant,
+                      (hipStream_t)stream);
+  if (rc != GS_OK) return rc;
   return gs_launch_status();
 }
 

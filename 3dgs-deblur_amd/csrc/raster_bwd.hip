@@ -19,6 +19,14 @@ namespace gs {
 //     with 16 conflict-free ds_read_b128 and park the total in tot[j][c]; at the end of the batch
 //     lane j picks up its 9 totals.  ~20 issue slots per Gaussian instead of ~80.
 // ---------------------------------------------------------------------------
+// The round-1 backward (raster_bwd_kernel_v2 below) is TEST infrastructure since round 4, like the round-1 forward:
+// compiled only with -DGS_ROUND1_KERNELS=1 into tests/libgsdeblur_round1.so (see raster.hip).
+#ifndef GS_ROUND1_KERNELS
+#define GS_ROUND1_KERNELS 0
+#endif
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+#if GS_ROUND1_KERNELS
 #ifndef GS_RED_G
 #define GS_RED_G 3
 #endif
@@ -30,8 +38,6 @@ constexpr int kRedFloats = kRedG * 9 * kRedStride + 64 * 9;
 // OUT = 1: no atomics at all — the entry's 9 gradients go to tuples[e] (48 B, e = emission index of the
 // entry, so the tuples of one Gaussian are CONTIGUOUS) and flags[e] = 1; gs_reduce_grad_tuples then sums
 // each Gaussian's segment.  At ~20 G atomic ops/s the atomics were 40 % of this kernel.
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
 #ifndef GS_BWD_WAVES
 #define GS_BWD_WAVES 4   // 128 VGPRs + 38 KB LDS per block -> 4 waves per SIMD (+3.5 % measured)
 #endif
@@ -253,6 +259,8 @@ __global__ __launch_bounds__(256, GS_BWD_WAVES) void raster_bwd_kernel_v2(Raster
     }
   }
 }
+
+#endif  // GS_ROUND1_KERNELS
 
 // ---------------------------------------------------------------------------
 // Backward compositor, scalar-cache variant (round 2; see raster.hip "scalar-cache variant" for the measurements
@@ -677,15 +685,20 @@ GS_EXPORT int gs_rasterize_bwd(const float* records, const int* sorted_vals, con
   if (variant & 256) { prm.alpha_grad_max = 3.0e38f; variant &= ~256; }
   unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y);
   unsigned blocks = (work + 3) / 4;
+  if (n_records == 0 && variant == 0) return GS_OK;         // not a single list entry: no gradient (v_records stays zero)
   if (n_records > 0 && variant == 0)
     hipLaunchKernelGGL((raster_bwd_sload_kernel<false, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm,
                        sorted_vals, sorted_vals, records, (unsigned)(n_records - 1), out_T, final_idx, v_img, v_alpha,
                        v_records, blocks, (float*)nullptr, (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr,
                        (const unsigned char*)nullptr);
   else
+#if GS_ROUND1_KERNELS
     hipLaunchKernelGGL((raster_bwd_kernel_v2<false, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, out_T,
                        final_idx, v_img, v_alpha, v_records, blocks, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                        (unsigned char*)nullptr);
+#else
+    return GS_ERR_INVALID;      // the round-1 backward is not in this build
+#endif
   return gs_launch_status();
 }
 
@@ -729,6 +742,7 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
     }
     return gs_launch_status();
   }
+#if GS_ROUND1_KERNELS
   if (tup) {
     if (bwd_T && bwd_B)
       hipLaunchKernelGGL((raster_bwd_kernel_v2<true, 1>), dim3(blocks), dim3(256), 0, st, prm, out_T, final_idx,
@@ -741,6 +755,9 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
                        v_alpha, v_records, blocks, bwd_T, bwd_B, tuples, flags);
   }
   return gs_launch_status();
+#else
+  return GS_ERR_INVALID;        // the round-1 backward (variant 2, or no record-index list) is not in this build
+#endif
 }
 
 // Sum each slice Gaussian's gradient tuples (written by gs_rasterize_bwd_slice with tuples != NULL) into

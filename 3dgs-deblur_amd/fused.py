@@ -40,16 +40,21 @@ class _ImageLoss(Function):
         H, W = int(pred.shape[0]), int(pred.shape[1])
         lam = float(ssim_lambda)
         if lam != 0.0 and min(H, W) < 11:
-            raise ValueError("SSIM needs images of at least 11x11 pixels")
+            # the 11x11 SSIM window does not fit (frames this small only occur while splatfacto's resolution schedule
+            # has them downscaled): L1 only, as the window-less limit of the loss
+            lam = 0.0
         L = _lib.load()
         dev = pred.device
-        ws_bytes = L.gs_image_loss_workspace_bytes(H, W)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        v_pred = torch.empty_like(pred)
-        out = torch.empty(3, device=dev)
-        _lib.check(L.gs_image_loss_fwd_bwd(H, W, ctypes.c_void_p(pred.data_ptr()), ctypes.c_void_p(gt.data_ptr()), lam,
-                                           ctypes.c_void_p(v_pred.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                           ctypes.c_void_p(ws.data_ptr()), ws_bytes, _stream()), "image_loss_fwd_bwd")
+        if gt.device != dev:
+            raise ValueError("pred and gt must live on the same device")
+        with torch.cuda.device(dev):          # launch on pred's device and ITS current stream, whatever is current
+            ws_bytes = L.gs_image_loss_workspace_bytes(H, W)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            v_pred = torch.empty_like(pred)
+            out = torch.empty(3, device=dev)
+            _lib.check(L.gs_image_loss_fwd_bwd(H, W, ctypes.c_void_p(pred.data_ptr()), ctypes.c_void_p(gt.data_ptr()), lam,
+                                               ctypes.c_void_p(v_pred.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                               ctypes.c_void_p(ws.data_ptr()), ws_bytes, _stream()), "image_loss_fwd_bwd")
         ctx.save_for_backward(v_pred)
         parts = out[1:].clone()
         ctx.mark_non_differentiable(parts)

@@ -457,9 +457,7 @@ def main():
                     a["project_bwd"])
 
         alg, alg_survey = alg_bytes(I_emit), alg_bytes(n_isect)
-        scalar_cache = ops.RASTER_BWD_VARIANT == 0 and ops.RASTER_FWD_VARIANT == 0
-        kname = {"raster_bwd": "raster_bwd_sload_kernel" if scalar_cache else "raster_bwd_kernel_v2",
-                 "raster_fwd": "raster_fwd_sload_kernel" if scalar_cache else "raster_fwd_slice_kernel",
+        kname = {"raster_bwd": "raster_bwd_sload_kernel", "raster_fwd": "raster_fwd_sload_kernel",
                  "project_fwd": "project_fused_fwd_kernel", "project_bwd": "project_fused_bwd_sparse_kernel"}[dom]
         achieved = alg[dom] / (single[dom] * 1e-3) / 1e9
         traffic = None

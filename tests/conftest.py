@@ -4,7 +4,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
-for p in (ROOT, ROOT / "oracle", ROOT / "tools"):
+for p in (ROOT, ROOT / "oracle", ROOT / "tools", ROOT / "tests"):
     if str(p) not in sys.path:
         sys.path.insert(0, str(p))
 
@@ -22,6 +22,10 @@ def oracle():
 @pytest.fixture(scope="session")
 def gs():
     import gsdeblur_amd
+    # test infrastructure: the Python orchestration twin of the frame pipeline and its A/B switches (the "plain path" of
+    # the equivalence tests) plugs into ops.frame_backend; with every switch at its default the product path runs
+    import python_frame_path
+    python_frame_path.install()
     return gsdeblur_amd
 
 

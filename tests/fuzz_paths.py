@@ -18,6 +18,9 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import gsdeblur_amd as gs  # noqa: E402
 from gsdeblur_amd import ops  # noqa: E402
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import python_frame_path  # noqa: E402    (the Python orchestration twin and its switches: test infrastructure)
+python_frame_path.install()
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0

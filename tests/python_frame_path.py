@@ -1,0 +1,558 @@
+"""TEST INFRASTRUCTURE: the Python orchestration of the depth-sliced frame pipeline and its A/B switches.
+
+Rounds 1-3 issued a frame's slice pipeline (depth pre-sort, slice plan, exact counts, emission, tile sort, bin edges,
+compositor; backward in reverse) from Python, one ctypes call per kernel, with a dozen switches (one slice without any
+culling, fp32 atomics instead of gradient tuples, colour in the projection, the round-1 compositors, ...).  The product
+path is csrc/frame.hip (gs_frame_forward / gs_frame_backward) since round 3; round 4 moved this twin OUT of the package
+(VERDICT round 3 item 8): it lives on as an independently written route to the same images and gradients through the
+same C-ABI kernels — the "plain path" the equivalence tests compare the product path with at BASELINE.json's full
+sizes, tests/fuzz_paths.py's random configurations, and the lane-utilisation counters of tools/lane_stats.py.
+
+    import python_frame_path as PF
+    PF.install()            # ops.frame_backend = PF; the switches below become attributes of gsdeblur_amd.ops
+    ops.GRAD_TUPLES = 0     # any non-default switch routes render_subposes / render_combined through this module
+
+The product package never imports this file (tests/test_abi.py checks).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from gsdeblur_amd import ops
+from gsdeblur_amd.ops import (GRAD, _L, _band_tile_done, _bits, _bwd_variant, _check, _padded_i32, _ptr, _stage, _stream,
+                              _tiles, exclusive_scan_u32, radix_sort_pairs)
+
+# ---- the switches (defaults = what csrc/frame.hip does); install() puts them on gsdeblur_amd.ops ----------------------
+_DEFAULTS = dict(
+    # exact ellipse-vs-tile culling of (Gaussian, tile) pairs in the fused path (images unchanged)
+    EXACT_TILE_CULL=int(os.environ.get("GSD_EXACT_TILE_CULL", "1")),
+    # atomic-free backward: per-entry gradient tuples + segmented reduce (0 = fp32 atomics into v_records)
+    GRAD_TUPLES=int(os.environ.get("GSD_GRAD_TUPLES", "1")),
+    # exact per-Gaussian hit counts -> compact emission (no culled pairs in the sort); needs EXACT_TILE_CULL
+    COMPACT_EMIT=int(os.environ.get("GSD_COMPACT_EMIT", "1")),
+    # deferred SH colour: the fused projection skips SH, each depth slice colours only the Gaussians it emits
+    DEFER_COLOR=int(os.environ.get("GSD_DEFER_COLOR", "1")),
+    # the exact count leaves one bit per box tile (open AND inside the ellipse) and the emission compacts from those
+    # bits instead of repeating the ellipse / tile_done tests (needs COMPACT_EMIT)
+    HIT_MASKS=int(os.environ.get("GSD_HIT_MASKS", "1")),
+    # depth pre-sort: 1 = per-sub-pose segments of 32-bit keys, 0 = one sort of 64-bit (sub-pose, depth) keys
+    DEPTH_SORT_SEGMENTED=int(os.environ.get("GSD_DEPTH_SORT_SEGMENTED", "1")),
+    # 1: the segmented depth pre-sort drops culled Gaussians in its first pass (0: sort all P*N keys, culled ones last)
+    DEPTH_SORT_COMPACT=int(os.environ.get("GSD_DEPTH_SORT_COMPACT", "1")),
+    # widest radix digit of the compacting depth pre-sort: 8 -> 4 passes of 8 bits, 11 -> 3 passes of 11/10/10 bits
+    DEPTH_SORT_DIGIT=int(os.environ.get("GSD_DEPTH_SORT_DIGIT", "8")),
+    # 1: depth slices after the first are launched without waiting for "is any tile still open?" (device-gated, at most
+    # one slice ahead of the words coming back); 0 (default): one read-back of that word per slice.  Measured: +1 % on a
+    # frame that needs all its planned slices (bench.py --scene trained), -1..2 % on the headline, whose plan holds five
+    # slices of which one is used — the gated no-op slice costs the GPU about what the wait did.
+    SPECULATE=int(os.environ.get("GSD_SPECULATE", "0")),
+    # 1: the forward of a frame that will be differentiated also sets up the backward's per-slice buffers (gradient tuples,
+    # flags) and the frame's touched flags, while the GPU is busy with the compositor (see sliced_forward); 0: the backward
+    # allocates them itself
+    PREALLOC_BWD=int(os.environ.get("GSD_PREALLOC_BWD", "1")),
+    # 1: the tile sort carries the record index of every entry as a second payload (0: gathers it in the final pass)
+    TILE_SORT_CARRY=int(os.environ.get("GSD_TILE_SORT_CARRY", "1")),
+    # 1: a depth slice's emitted-intersection count stays on the device (buffers / grids sized by the slice's bounding-box
+    # count from the plan); 0: read it back (exact sizes, one more host synchronisation per slice) — A/B switch
+    DEVICE_SIZES=int(os.environ.get("GSD_DEVICE_SIZES", "1")),
+    # debug: 1 routes the forward compositor through gs_rasterize_fwd_slice_stats (round-1 kernel) and accumulates its
+    # lane-utilisation counters in ops.lane_stats (u64 [13] on the device, see include/gsdeblur.h); slow
+    LANE_STATS=int(os.environ.get("GSD_LANE_STATS", "0")),
+    # 0: this module orchestrates even when every other switch is at its default
+    NATIVE_FRAME=int(os.environ.get("GSD_NATIVE_FRAME", "1")),
+    # compositor kernels: 0 = the product's scalar-cache kernels, 2 (forward also 1) = the round-1 v_readlane kernels,
+    # which live in tests/libgsdeblur_round1.so (_build.build_round1_library), not in the product library
+    RASTER_FWD_VARIANT=int(os.environ.get("GSD_RASTER_FWD_VARIANT", "0")),
+    RASTER_BWD_VARIANT=int(os.environ.get("GSD_RASTER_BWD_VARIANT", "0")),
+)
+_PREALLOC_MAX_BYTES = 4 << 30          # per slice; larger tuple buffers are left to the backward
+
+
+def install() -> None:
+    """make this module the frame backend of gsdeblur_amd.ops and publish the switches as attributes of ops"""
+    for k, v in _DEFAULTS.items():
+        if not hasattr(ops, k):
+            setattr(ops, k, v)
+    if not hasattr(ops, "lane_stats"):
+        ops.lane_stats = None
+    ops.frame_backend = sys.modules[__name__]
+
+
+_round1 = None
+
+
+def _L_round1():
+    """ctypes handle of tests/libgsdeblur_round1.so: raster.hip + raster_bwd.hip compiled with -DGS_ROUND1_KERNELS=1 (the
+    round-1 compositors, compiled out of the product library); same entry points, same signatures"""
+    global _round1
+    if _round1 is None:
+        import importlib.util
+        from pathlib import Path
+        from gsdeblur_amd import _lib
+        root = Path(__file__).resolve().parents[1]
+        spec = importlib.util.spec_from_file_location("_gsd_build_t", root / "3dgs-deblur_amd" / "_build.py")
+        B = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(B)
+        path = B.ROUND1_LIB_PATH
+        if not path.exists():
+            path = B.build_round1_library()
+        lib = ctypes.CDLL(str(path))
+        for name in ("gs_rasterize_fwd", "gs_rasterize_bwd", "gs_rasterize_fwd_slice", "gs_rasterize_bwd_slice",
+                     "gs_rasterize_fwd_slice_stats"):
+            fn = getattr(lib, name)
+            fn.argtypes = _lib._SIGS[name]
+            fn.restype = ctypes.c_int
+        _round1 = lib
+    return _round1
+
+
+def native_ok() -> bool:
+    """True: every switch is at its default — the frame goes through csrc/frame.hip like in the product"""
+    return bool(ops.NATIVE_FRAME and ops.EXACT_TILE_CULL and ops.GRAD_TUPLES and ops.COMPACT_EMIT and ops.HIT_MASKS
+                and ops.DEPTH_SORT_SEGMENTED and ops.DEPTH_SORT_COMPACT and ops.TILE_SORT_CARRY and ops.DEVICE_SIZES
+                and ops.DEFER_COLOR and not ops.SPECULATE and not ops.LANE_STATS and not ops.SYNC_CHECK
+                and ops.RASTER_FWD_VARIANT == 0 and ops.RASTER_BWD_VARIANT == 0)
+
+
+def defer_flags() -> int:
+    """gs_project_fused_fwd's defer_color argument for the current switches (bit 0: SH colour deferred to the slices;
+    bit 1: culled (Gaussian, sub-pose) pairs get no record — safe when nothing downstream looks at them)"""
+    lean = (ops.DEPTH_SORT_SEGMENTED and ops.DEPTH_SORT_COMPACT and ops.GRAD_TUPLES and ops.COMPACT_EMIT
+            and ops.EXACT_TILE_CULL)
+    return int(bool(ops.DEFER_COLOR)) | (2 if lean else 0)
+
+
+def segmented_sort_pairs_u32(keys: Tensor, seg_len: int) -> Tuple[Tensor, Tensor]:
+    """Stable ascending sort of every seg_len-long segment of int32 (u32) keys; payload = global index.
+    Input is clobbered."""
+    n = keys.numel()
+    dev = keys.device
+    L = _L()
+    v0 = torch.empty(n, dtype=torch.int32, device=dev)
+    k1 = torch.empty_like(keys)
+    v1 = torch.empty_like(v0)
+    ws_bytes = L.gs_segmented_sort_workspace_bytes(n, seg_len, 0, 32)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    res = ctypes.c_int(0)
+    _check(L.gs_segmented_sort_pairs_u32(n, seg_len, _ptr(keys), _ptr(v0), _ptr(k1), _ptr(v1), 1, 0, 32, _ptr(ws),
+                                         ws_bytes, ctypes.byref(res), _stream()), "segmented sort")
+    return (k1, v1) if res.value == 1 else (keys, v0)
+
+
+def _depth_rank(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int):
+    """per-sub-pose depth pre-sort -> (sorted_gi [P*N], exclusive scan of tile counts in rank order, total,
+    n_live [P] device or None).  depth_keys is consumed (the sort ping-pongs through it).
+
+    Compacting route (default): culled Gaussians (key 0xFFFFFFFF, typically 3 of 4) are dropped by the first radix
+    pass, so the other three passes, the count gather (folded into the last pass) and the scan only touch the
+    n_live[p] visible ones; ranks [n_live[p], N) of sorted_gi / counts are unspecified and must not be read."""
+    L = _L()
+    n = P * N
+    dev = records.device
+    n_live = None
+    if ops.DEPTH_SORT_SEGMENTED and ops.DEPTH_SORT_COMPACT:
+        with _stage("depth_sort"):
+            v0 = torch.empty(n, dtype=torch.int32, device=dev)
+            k1 = torch.empty_like(depth_keys)
+            v1 = torch.empty_like(v0)
+            counts = torch.empty(n, dtype=torch.int32, device=dev)
+            n_live = torch.empty(P, dtype=torch.int32, device=dev)          # written by the sort
+            # visible keys are positive floats: bit 31 is never set (the culled marker is dropped, not sorted)
+            ws_bytes = L.gs_segmented_sort_compact_workspace_bytes(n, N, 0, 31, ops.DEPTH_SORT_DIGIT)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            res = ctypes.c_int(0)
+            _check(L.gs_segmented_sort_compact_u32(n, N, _ptr(depth_keys), _ptr(v0), _ptr(k1), _ptr(v1), 0, 31,
+                                                   ops.DEPTH_SORT_DIGIT, 0xFFFFFFFF, _ptr(n_live), _ptr(num_tiles_hit), _ptr(counts),
+                                                   _ptr(ws), ws_bytes, ctypes.byref(res), _stream()),
+                   "segmented sort (compacting)")
+            sorted_gi = v1 if res.value == 1 else v0
+        with _stage("count_scan"):
+            cum = torch.empty(n, dtype=torch.int32, device=dev)
+            total = torch.empty(1, dtype=torch.int32, device=dev)
+            sws_bytes = L.gs_scan_workspace_bytes(n)
+            sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)
+            _check(L.gs_exclusive_scan_segments_u32(n, N, _ptr(n_live), _ptr(counts), _ptr(cum), _ptr(total),
+                                                    _ptr(sws), sws_bytes, _stream()), "segment scan")
+        return sorted_gi, cum, total, n_live
+    with _stage("depth_sort"):
+        if ops.DEPTH_SORT_SEGMENTED:
+            # P independent segments of 32-bit depth keys (culled = 0xFFFFFFFF sorts last), one set of launches
+            _, sorted_gi = segmented_sort_pairs_u32(depth_keys, N)          # clobbers depth_keys (a temporary)
+        else:
+            keys64 = torch.empty(n, dtype=torch.int64, device=dev)
+            _check(L.gs_make_depth_keys64(n, N, _ptr(depth_keys), _ptr(keys64), _stream()), "depth keys")
+            _, sorted_gi = radix_sort_pairs(keys64, None, 0, 32 + (_bits(P) if P > 1 else 0))
+    with _stage("count_scan"):
+        counts = torch.empty(n, dtype=torch.int32, device=dev)
+        _check(L.gs_gather_counts(n, _ptr(sorted_gi), _ptr(num_tiles_hit), _ptr(counts), _stream()), "gather counts")
+        cum, total = exclusive_scan_u32(counts)
+    return sorted_gi, cum, total, n_live
+
+
+
+
+
+def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
+                   img_height: int, img_width: int, bg: Tensor, edges: Tensor, slice_base: int, color=None,
+                   out_depth: Optional[Tensor] = None, prealloc: Optional[dict] = None, rs=None):
+    """Front-to-back depth-sliced bin + sort + composite.
+    -> (out_img [S,H,W,3], out_T [S,H,W], slices) ; slices = list of (sorted_vals, tile_bins, final_idx, I_k)
+    that the backward walks in reverse.
+    rs = (pix_vel [N,2], rolling_shutter_time): exact per-row rolling shutter of the pixel-velocity model (R must be 1):
+    the compositors of raster_rs.hip add tau(row) * pix_vel to every splat centre.  The tile lists then come from the
+    (swept) bounding boxes without the exact ellipse culling — that test assumes one centre per tile."""
+    L = _L()
+    dev = records.device
+    H, W = img_height, img_width
+    tx, ty = _tiles(H, W)
+    T = tx * ty
+    sorted_gi, cum, total, n_live = _depth_rank(records, depth_keys, num_tiles_hit, P, N)
+    # everything that does not depend on the plan is allocated BEFORE its read-back, while the GPU is still busy
+    out_img = torch.empty(S, H, W, 3, device=dev)
+    out_T = torch.empty(S, H, W, device=dev)
+    live_T = torch.empty(S, H, W, device=dev)
+    sat = torch.empty(P * (ty + 1) * (tx + 1), dtype=torch.int32, device=dev)
+    open_bits = torch.empty(P * ty * ((tx + 63) // 64), dtype=torch.int64, device=dev)   # one bit per tile: still open
+    # one zero fill: tile_done of the first slice, and per planned slice one "this tile's list holds an opacity above
+    # the alpha clamp" flag per tile (written by the emission, read by both compositors to pick their loop version)
+    KMAX = 16
+    # ... and one "a tile is still open after this slice" word per slice, set by the forward compositor
+    flag_off = ((1 + KMAX) * P * T + 3) & ~3
+    zeros_u8 = torch.zeros(flag_off + 4 * KMAX, dtype=torch.uint8, device=dev)
+    tile_done0 = zeros_u8[:P * T] if R == 1 else None
+    open_flags = zeros_u8[flag_off:].view(torch.int32)
+    # slice boundaries in depth-rank space: cumulative intersections per sub-pose reach T*slice_base*2^k
+    if slice_base > 0:
+        with _stage("slice_plan"):
+            # the scan is u32 (wraps above 2^32 total intersections): differences inside one sub-pose are
+            # still exact modulo 2^32 as long as a single sub-pose has fewer than 2^32 intersections
+            # bounds | rels | per-sub-pose totals | live ranks per sub-pose | total
+            plan_dev = torch.empty(2 * P * KMAX + 2 * P + 1, dtype=torch.int32, device=dev)
+            _check(L.gs_slice_plan(P, N, KMAX, _ptr(cum), _ptr(total), T * slice_base, _ptr(plan_dev),
+                                   ctypes.c_void_p(plan_dev.data_ptr() + 4 * P * KMAX),
+                                   ctypes.c_void_p(plan_dev.data_ptr() + 8 * P * KMAX), _ptr(n_live),
+                                   ctypes.c_void_p(plan_dev.data_ptr() + 8 * P * KMAX + 4 * P), _stream()),
+                   "slice_plan")
+            # one host sync; everything after it is plain Python on one list (the GPU is idle until the first launch
+            # of the slice pipeline: a handful of CPU-tensor ops here cost more than the whole planning)
+            plan = [v & 0xFFFFFFFF for v in plan_dev.tolist()]
+            PK = P * KMAX
+            rel_at = [plan[PK + p * KMAX:PK + (p + 1) * KMAX] for p in range(P)]
+            seg_totals = plan[2 * PK:2 * PK + P]
+        n_total = plan[-1]
+        b = [plan[p * KMAX:(p + 1) * KMAX] for p in range(P)]
+        # NV[p]: ranks of sub-pose p that hold a Gaussian (everything behind them is unspecified after the
+        # compacting pre-sort; without it the culled Gaussians sit there with zero tiles)
+        NV = [min(N, v) for v in plan[2 * PK + P:2 * PK + 2 * P]]
+        # number of slices: up to the first k whose boundary reaches the last live rank in every sub-pose
+        K = KMAX
+        for k in range(KMAX):
+            if all(b[p][k] >= NV[p] for p in range(P)):
+                K = k + 1
+                break
+    else:
+        n_total = int(total.item()) & 0xFFFFFFFF
+        NV = [min(N, int(v)) for v in n_live.tolist()] if n_live is not None else [N] * P
+        b = [[NV[p]] for p in range(P)]
+        rel_at = None
+        seg_totals = None
+        K = 1
+    ops.last_num_intersects = n_total
+    # un-wrapped total (python ints) from the per-sub-pose totals of the plan; None when there is no plan.
+    # (NOT rel_at[p][KMAX-1]: the last planned boundary lies before N when a sub-pose holds more than
+    # T*slice_base*2^(KMAX-1) intersections — fuzz seed 1 trial 328 overran the hit-mask buffer that way)
+    true_total = sum(seg_totals) if seg_totals is not None else None
+    begins, prefixes, n_slices = [], [], []
+    for k in range(K):
+        lo = [0 if k == 0 else min(b[p][k - 1], NV[p]) for p in range(P)]
+        hi = [NV[p] if k == K - 1 else min(b[p][k], NV[p]) for p in range(P)]
+        begins.append([p * N + lo[p] for p in range(P)])
+        pre = [0]
+        for p in range(P):
+            pre.append(pre[-1] + max(0, hi[p] - lo[p]))
+        prefixes.append(pre)
+        n_slices.append(pre[-1])
+    # the slice descriptors stay on the host: they travel in the kernel arguments (no upload after the sync)
+    desc_begin = [(ctypes.c_int * P)(*bb) for bb in begins]
+    desc_prefix = [(ctypes.c_int * (P + 1))(*pp) for pp in prefixes]
+    if R > 1:
+        # rolling-shutter bands: sub-pose p = s*R + r only ever composites tile rows [edge[r], edge[r+1]);
+        # every other tile of p is "done" from the start so the binning never emits for it
+        tile_done = _band_tile_done(S, R, ty, tx, dev).clone()      # (the kernels write into it)
+        _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _ptr(open_bits), None, _stream()),
+               "tile_open_sat")
+    else:
+        tile_done = tile_done0
+    holes0 = R > 1          # the very first slice already has closed tiles
+    slices = []
+    ops._slice_totals = []
+    if rs is not None and (R != 1 or not ops.GRAD_TUPLES):
+        raise ValueError("exact rolling shutter needs rs_bands == 1 and the gradient-tuple backward")
+    exact_cull = bool(ops.EXACT_TILE_CULL) and rs is None
+    invalid_key = P * T if exact_cull else 0
+    use_tuples = bool(ops.GRAD_TUPLES)
+    compact = bool(ops.COMPACT_EMIT) and exact_cull
+    # default path (compact emission + gradient tuples): a slice's size never comes back to the host.  Its buffers
+    # and grids are sized by the slice's BOUNDING-BOX intersection count, which the plan read-back already put on
+    # the host, and the kernels read the real count from the device.  What is left per frame: the plan read-back,
+    # plus one look at the open-tile count after every slice that is not the last planned one.
+    device_sizes = compact and use_tuples and rel_at is not None and bool(ops.DEVICE_SIZES)
+    # ops.SPECULATE (opt-in, see its definition): nobody waits for "is any tile still open?" either.  The word a slice's compositor leaves
+    # travels to pinned host memory on its own; the next planned slice is launched right away, GATED on the device by
+    # that word (its count kernel then answers "nothing" without looking, and everything downstream works off the
+    # counts: ~20 near-empty launches), and the loop stops launching slices as soon as a word that has arrived says the
+    # frame is complete — it runs at most ONE slice ahead of the words.  The wait it replaces cost ~0.2 ms of GPU idle per frame on the headline: the host could
+    # not queue the rest of the forward, the loss and the backward behind the 0.4 ms compositor launch.
+    speculate = device_sizes and bool(ops.SPECULATE) and K > 1
+    flags_host = torch.empty(KMAX, dtype=torch.int32, pin_memory=True) if speculate else None
+    pending = []          # (event, slice index) of the flag words on their way to flags_host
+    gate_k = None         # slice whose compositor wrote the latest flag word
+    for k in range(K):
+        first, last = k == 0, k == K - 1
+        n_k = n_slices[k]
+        I_k = 0
+        n_dev = None
+        gate = None
+        if speculate and gate_k is not None:
+            # ONE slice of speculation: the word of the slice before the previous one must be in (by now it usually
+            # is: the host spent a slice's worth of launches since); a frame whose plan holds many slices it does not
+            # need (the headline: 5 planned, 1 used) would otherwise pay for every one of them
+            if len(pending) >= 2:
+                pending[-2][0].synchronize()
+            if any(ev.query() and int(flags_host[kk]) == 0 for ev, kk in pending):
+                ops._slice_totals.append(0)          # a word that came back says every tile is done
+                break
+            gate = ctypes.c_void_p(open_flags.data_ptr() + 4 * gate_k)
+        svals = bins = sorted_ids = None
+        tile_hot = zeros_u8[(1 + k) * P * T:(2 + k) * P * T] if (compact and use_tuples) else None
+        if n_k > 0:
+            with _stage("slice_count"):
+                slice_gi = torch.empty(n_k, dtype=torch.int32, device=dev)
+                counts = torch.empty(n_k, dtype=torch.int32, device=dev)
+                d_begin, d_prefix = desc_begin[k], desc_prefix[k]
+                have_holes = (not first) or holes0
+                # few Gaussians with large boxes (the nearest slice): one wave per Gaussian
+                box_total = (n_total if K == 1 else sum(rel_at[p][0] for p in range(P))) if first else 0
+                # (boxes of up to 64 tiles are walked by single lanes where a wave holds several of them: only slices
+                #  of really large boxes — hundreds of tiles each — are better off with a wave per Gaussian)
+                wave_per_g = int(first and box_total > 128 * n_k)
+                masks = mask_off = None
+                if compact:
+                    if ops.HIT_MASKS and true_total is not None and true_total < 2 ** 32 - 64:
+                        # one bit per box tile, written by the exact count and consumed by the emission; the
+                        # word offsets come from the u32 prefix `cum`, which must not have wrapped
+                        masks = torch.empty(true_total // 64 + n_k + 2, dtype=torch.int64, device=dev)
+                        mask_off = torch.empty(n_k, dtype=torch.int32, device=dev)
+                    _check(L.gs_slice_counts_exact(n_k, P, N, d_begin, d_prefix,
+                                                   _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None,
+                                                   _ptr(tile_done) if have_holes else None, H, W, _ptr(slice_gi),
+                                                   _ptr(counts), wave_per_g, _ptr(cum) if masks is not None else None,
+                                                   _ptr(masks), _ptr(mask_off), _ptr(open_bits) if have_holes else None,
+                                                   gate, _stream()), "slice_counts_exact")
+                else:
+                    _check(L.gs_slice_counts(n_k, P, N, d_begin, d_prefix,
+                                             _ptr(sorted_gi), _ptr(records), _ptr(sat) if have_holes else None, H, W,
+                                             _ptr(slice_gi), _ptr(counts), _stream()), "slice_counts")
+                cum_k, total_k = exclusive_scan_u32(counts)
+                if color is not None:
+                    # deferred SH colour for exactly the Gaussians this slice emits
+                    c_means, c_sh, c_rest, c_K, c_deg, c_V = color
+                    _check(L.gs_slice_colors(n_k, _ptr(slice_gi), _ptr(counts), N, _ptr(c_means), _ptr(c_sh),
+                                             _ptr(c_rest), c_K, c_deg, _ptr(c_V), _ptr(records), _stream()), "slice_colors")
+            if device_sizes:
+                hi_rel = [seg_totals[p] if last else rel_at[p][k] for p in range(P)]
+                lo_rel = [0 if first else rel_at[p][k - 1] for p in range(P)]
+                I_k = sum((hi_rel[p] - lo_rel[p]) & 0xFFFFFFFF for p in range(P))     # upper bound (box pairs)
+                n_dev = total_k
+            elif first and not holes0 and not compact:
+                # every tile is open: the slice holds exactly the bounding-box intersections of its ranks,
+                # already known on the host from the plan read-back -> no sync
+                if K == 1:
+                    I_k = n_total
+                else:
+                    I_k = sum(rel_at[p][0] for p in range(P))
+            elif first:
+                I_k = int(total_k.item())          # host sync
+            else:
+                # same sync also fetches how many tiles are still open after the previous slice
+                both = torch.cat([total_k, sat.view(P, -1)[:, -1].sum(dtype=torch.int32).reshape(1)]).tolist()
+                I_k = int(both[0])
+                if both[1] == 0:
+                    # every tile is done (each already received its background term): nothing left to do
+                    ops._slice_totals.append(0)
+                    break
+        if I_k >= 2 ** 31 or I_k < 0:
+            raise OverflowError(f"depth slice {k} holds {I_k} tile intersections (limit 2^31-1): lower GSD_SLICE_BASE")
+        if I_k > 0:
+            with _stage("emit"):
+                keys = torch.empty(I_k, dtype=torch.int32, device=dev)
+                vals = _padded_i32(I_k, dev)
+                if first and not holes0 and not compact:
+                    _check(L.gs_emit_intersects(n_k, N, H, W, _ptr(slice_gi), _ptr(cum_k), _ptr(records), I_k,
+                                                _ptr(keys), _ptr(vals), invalid_key, _stream()), "emit intersects")
+                else:
+                    _check(L.gs_emit_open_intersects(n_k, N, H, W, _ptr(slice_gi), _ptr(counts), _ptr(cum_k),
+                                                     _ptr(records),
+                                                     _ptr(tile_done) if ((not first) or holes0) else None,
+                                                     _ptr(keys), _ptr(vals), invalid_key, int(compact), wave_per_g,
+                                                     _ptr(masks), _ptr(mask_off), _ptr(tile_hot), _stream()),
+                           "emit open intersects")
+            with _stage("tile_sort"):
+                if use_tuples:
+                    # payload = emission index e (iota); the Gaussian id of a sorted entry is vals[e]: the final
+                    # pass leaves it in sorted order for the scalar-cache compositors
+                    if ops.TILE_SORT_CARRY:
+                        skeys, svals, sorted_ids = radix_sort_pairs(keys, None, 0, _bits(P * T + 1), carry=vals,
+                                                                    n_dev=n_dev)
+                    else:
+                        skeys, svals, sorted_ids = radix_sort_pairs(keys, None, 0, _bits(P * T + 1), gather_src=vals,
+                                                                    n_dev=n_dev)
+                else:
+                    skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T + 1))
+            with _stage("bin_edges"):
+                bins = torch.empty(P * T + 1, 2, dtype=torch.int32, device=dev)   # last row: culled pairs
+                _check(L.gs_tile_bin_edges_u32(I_k, _ptr(skeys), P * T + 1, _ptr(bins), _ptr(n_dev), _stream()),
+                       "bin edges")
+        ops._slice_totals.append(n_dev if n_dev is not None else I_k)
+        if I_k == 0 and not (first or last):
+            continue
+        if I_k == 0:
+            svals = torch.zeros(1, dtype=torch.int32, device=dev)
+            bins = torch.zeros(P * T, 2, dtype=torch.int32, device=dev)
+        fidx = torch.empty(S, H, W, dtype=torch.int32, device=dev)
+        if rs is not None and I_k > 0:
+            with _stage("raster_fwd"):
+                _check(L.gs_rasterize_fwd_rs_slice(_ptr(records), _ptr(bins), _ptr(edges), _ptr(bg), S, H, W, _ptr(out_img),
+                                                   _ptr(out_T), _ptr(live_T), _ptr(fidx), _ptr(tile_done), int(first),
+                                                   int(last), _ptr(sorted_ids), P * N, _ptr(out_depth),
+                                                   ctypes.c_void_p(open_flags.data_ptr() + 4 * k) if not last else None,
+                                                   _ptr(rs[0]), N, float(rs[1]), _stream()), "rasterize_fwd_rs_slice")
+        elif ops.LANE_STATS and out_depth is None:
+            if ops.lane_stats is None or ops.lane_stats.device != dev:
+                ops.lane_stats = torch.zeros(13, dtype=torch.int64, device=dev)
+            _check(_L_round1().gs_rasterize_fwd_slice_stats(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H,
+                                                  W, _ptr(out_img), _ptr(out_T), _ptr(live_T), _ptr(fidx),
+                                                  _ptr(tile_done), int(first), int(last),
+                                                  _ptr(vals) if (use_tuples and I_k > 0) else None,
+                                                  ctypes.c_void_p(open_flags.data_ptr() + 4 * k) if not last else None,
+                                                  _ptr(ops.lane_stats), _stream()), "rasterize_fwd_slice_stats")
+        else:
+            with _stage("raster_fwd"):
+                Lc = L if ops.RASTER_FWD_VARIANT == 0 else _L_round1()
+                _check(Lc.gs_rasterize_fwd_slice(_ptr(records), _ptr(svals), _ptr(bins), _ptr(edges), _ptr(bg), S, R, H,
+                                                W, _ptr(out_img), _ptr(out_T), _ptr(live_T), _ptr(fidx),
+                                                _ptr(tile_done), int(first), int(last),
+                                                _ptr(vals) if (use_tuples and I_k > 0) else None,
+                                                _ptr(sorted_ids), P * N if I_k > 0 else 0,
+                                                _ptr(out_depth) if I_k > 0 else None,
+                                                _ptr(tile_hot) if I_k > 0 else None,
+                                                ctypes.c_void_p(open_flags.data_ptr() + 4 * k) if not last else None,
+                                                ops.RASTER_FWD_VARIANT, _stream()),
+                       "rasterize_fwd_slice")
+        tuples_k = flags_k = None
+        if prealloc is not None and use_tuples and I_k > 0 and I_k * GRAD * 4 <= _PREALLOC_MAX_BYTES:
+            # the backward's buffers of this slice (and the frame's, once) are set up HERE, while the GPU works
+            # through the compositor just launched: behind the open-tile read-back the host is on the critical path
+            # (rest of the forward, loss, backward prologue), and every allocation / fill taken out of that window
+            # shortens the GPU's wait for the backward compositor
+            tuples_k = torch.empty(I_k * GRAD, device=dev)
+            flags_k = torch.zeros(I_k, dtype=torch.uint8, device=dev)
+            if "touched" not in prealloc:
+                prealloc["touched"] = torch.zeros(P * N, dtype=torch.uint8, device=dev)
+                prealloc["v_records"] = torch.empty(P * N, GRAD, device=dev)
+        if I_k > 0:
+            # gated: (event, pinned words, index) of the flag this slice was launched behind — the backward drops the
+            # slice if the word says it had nothing to do
+            slices.append(dict(svals=svals, bins=bins, fidx=fidx, I=I_k, gi_of_e=vals if use_tuples else None,
+                               sorted_ids=sorted_ids, slice_gi=slice_gi, counts=counts, cum=cum_k, n=n_k,
+                               tile_hot=tile_hot, tuples=tuples_k, flags=flags_k, wave_per_g=bool(wave_per_g),
+                               gated=(pending[-1][0], flags_host, gate_k) if gate is not None else None))
+        if not last:
+            sat_gate = None
+            if speculate:
+                flags_host[k:k + 1].copy_(open_flags[k:k + 1], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                pending.append((ev, k))
+                gate_k = k
+                sat_gate = ctypes.c_void_p(open_flags.data_ptr() + 4 * k)
+            elif device_sizes:
+                # one read-back per slice: are there open tiles for the next planned slice?  One word, written by
+                # the compositor itself, read AFTER this slice's whole pipeline was issued
+                if int(open_flags[k].item()) == 0:
+                    ops._slice_totals.append(0)
+                    break
+            with _stage("slice_sat"):
+                _check(L.gs_tile_open_sat(P, H, W, _ptr(tile_done), _ptr(sat), _ptr(open_bits), sat_gate, _stream()),
+                       "tile_open_sat")
+    return out_img, out_T, slices
+
+
+def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, img_width: int, bg: Tensor,
+                    edges: Tensor, out_T: Tensor, v_img: Tensor, v_alpha: Optional[Tensor], v_records: Tensor,
+                    touched: Optional[Tensor] = None, combine=None, rs=None):
+    """combine = (scale [H,W,3], gamma, m): v_img then holds the SAMPLE IMAGES and the kernel derives each
+    pixel's sample gradient itself (gs_combine_bwd folded into the compositor's backward)."""
+    L = _L()
+    H, W = img_height, img_width
+    dev = records.device
+    cmb = combine if combine is not None else (None, 1.0, 0.0)
+    # reverse-traversal state between slices: running T and (behind-colour . v_out), ONE float per pixel each;
+    # a frame that needed a single slice (the common case) carries none
+    # a slice launched behind a gate that turned out closed did nothing: by now its word has long arrived
+    def _ran(sl):
+        g = sl.get("gated")
+        if g is None:
+            return True
+        ev, words, kk = g
+        ev.synchronize()
+        return int(words[kk]) != 0
+    slices = [sl for sl in slices if _ran(sl)]
+    bwd_T = bwd_B = None
+    if len(slices) > 1 or any(sl["gi_of_e"] is None for sl in slices):
+        bwd_T = out_T.clone()
+        bwd_B = torch.zeros((S, H, W), device=dev)
+    for sl in reversed(slices):
+        tuples = flags = None
+        if sl["gi_of_e"] is not None:
+            # set up by the forward when it could (single use: a second backward through the same graph allocates)
+            tuples, flags = sl.get("tuples"), sl.get("flags")
+            sl["tuples"] = sl["flags"] = None
+            if tuples is None:
+                tuples = torch.empty(sl["I"] * GRAD, device=dev)
+                flags = torch.zeros(sl["I"], dtype=torch.uint8, device=dev)
+        if rs is not None:
+            with _stage("raster_bwd"):
+                _check(L.gs_rasterize_bwd_rs_slice(_ptr(records), _ptr(sl["svals"]), _ptr(sl["bins"]), _ptr(edges), _ptr(bg),
+                                                   S, H, W, _ptr(out_T), _ptr(sl["fidx"]), _ptr(v_img), _ptr(v_alpha),
+                                                   _ptr(bwd_T), _ptr(bwd_B), _ptr(tuples), _ptr(flags),
+                                                   _ptr(sl["sorted_ids"]), records.shape[0], _bwd_variant() & 256,
+                                                   _ptr(cmb[0]), cmb[1], cmb[2], _ptr(rs[0]), rs[0].shape[0], float(rs[1]),
+                                                   _stream()), "rasterize_bwd_rs_slice")
+        else:
+            with _stage("raster_bwd"):
+                Lc = L if ops.RASTER_BWD_VARIANT == 0 else _L_round1()
+                _check(Lc.gs_rasterize_bwd_slice(_ptr(records), _ptr(sl["svals"]), _ptr(sl["bins"]), _ptr(edges), _ptr(bg),
+                                                S, R, H, W, _ptr(out_T), _ptr(sl["fidx"]), _ptr(v_img), _ptr(v_alpha),
+                                                _ptr(bwd_T), _ptr(bwd_B), _ptr(v_records), _ptr(sl["gi_of_e"]),
+                                                _ptr(tuples), _ptr(flags), _ptr(sl["sorted_ids"]), records.shape[0],
+                                                _ptr(sl["tile_hot"]), _bwd_variant() | ops.RASTER_BWD_VARIANT, _ptr(cmb[0]), cmb[1], cmb[2],
+                                                _stream()),
+                       "rasterize_bwd_slice")
+        if tuples is not None:
+            with _stage("grad_reduce"):
+                # kernel form: a wave per Gaussian only for slices of few, large Gaussians (the choice the exact count
+                # made); sl["I"] is the slice's bounding-BOX pair count, not its emitted entries — sizing the choice by
+                # it sent every slice of a small-splat scene (7 entries per Gaussian) through 64-lane waves
+                _check(L.gs_reduce_grad_tuples(sl["n"], _ptr(sl["slice_gi"]), _ptr(sl["counts"]), _ptr(sl["cum"]),
+                                               _ptr(tuples), _ptr(flags), _ptr(v_records), _ptr(touched),
+                                               sl["I"] if sl.get("wave_per_g", True) else 0, _ptr(records), _stream()),
+                       "reduce_grad_tuples")
+
+

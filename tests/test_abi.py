@@ -48,6 +48,8 @@ def test_product_never_imports_oracle_or_reference():
         assert not re.search(r"^\s*(import|from)\s+gs_oracle", src, flags=re.M), p
         assert "oracle/" not in src.replace("oracle/gs_oracle.py::", "") or p.suffix in (".hip", ".h"), p
         assert not re.search(r"open\(.*/root/reference", src), p
+        # ... nor the test-only Python orchestration twin of the frame pipeline
+        assert not re.search(r"^\s*(import|from)\s+python_frame_path", src, flags=re.M), p
 
 
 def test_ops_fail_loudly_without_gpu_tensors(gs):

@@ -14,6 +14,8 @@ import numpy as np
 import pytest
 import torch
 
+import python_frame_path      # test infrastructure: the Python orchestration twin + its switches (conftest installs it)
+
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
 
@@ -198,7 +200,7 @@ def test_segmented_sort_stable(gs, dev, sort_form, P, N):
     keys = torch.randint(0, 2 ** 32, (P * N,), generator=g, dtype=torch.int64)
     keys[: N // 2] = keys[N // 2: 2 * (N // 2)]                 # ties
     keys[-3:] = 0xFFFFFFFF                                      # "culled" marker sorts last
-    ks, vs = ops.segmented_sort_pairs_u32(keys.to(torch.int32).to(dev), N)
+    ks, vs = python_frame_path.segmented_sort_pairs_u32(keys.to(torch.int32).to(dev), N)
     for p in range(P):
         seg = keys[p * N:(p + 1) * N]
         order = torch.sort(seg, stable=True).indices + p * N
@@ -227,9 +229,9 @@ def test_depth_rank_compacting(gs, dev, sort_form, P, N, keep, digit):
     old = ops.DEPTH_SORT_COMPACT, ops.DEPTH_SORT_DIGIT
     try:
         ops.DEPTH_SORT_COMPACT, ops.DEPTH_SORT_DIGIT = 1, digit      # 4 passes of 8 bits / 3 passes of 11, 11, 9
-        sgi, cum, total, n_live = ops._depth_rank(records, keys.to(torch.int32).to(dev), ntiles.to(dev), P, N)
+        sgi, cum, total, n_live = python_frame_path._depth_rank(records, keys.to(torch.int32).to(dev), ntiles.to(dev), P, N)
         ops.DEPTH_SORT_COMPACT = 0
-        sgi0, cum0, total0, none = ops._depth_rank(records, keys.to(torch.int32).to(dev), ntiles.to(dev), P, N)
+        sgi0, cum0, total0, none = python_frame_path._depth_rank(records, keys.to(torch.int32).to(dev), ntiles.to(dev), P, N)
     finally:
         ops.DEPTH_SORT_COMPACT, ops.DEPTH_SORT_DIGIT = old
     assert none is None
@@ -1788,7 +1790,7 @@ def test_more_intersections_than_the_slice_plan_covers(gs, dev):
                                   "tiny_budget", "exact_rolling_shutter", "exact_rolling_shutter_multi_slice"])
 def test_native_frame_orchestration_equals_python_orchestration(gs, dev, case):
     """gs_frame_forward / gs_frame_backward (csrc/frame.hip: the slice pipeline issued from C++
-    out of ONE caller-owned arena) against ops.sliced_forward / sliced_backward (the same kernels launched one by one
+    out of ONE caller-owned arena) against tests/python_frame_path.py's sliced_forward / sliced_backward (the same kernels launched one by one
     from Python with torch allocations).  Same launches in the same order on the atomic-free path: images, alphas, the
     depth channel, radii and EVERY gradient must be bit-identical; the per-slice emitted counts too.  Cases: motion
     blur, rolling-shutter bands (initially closed tiles), a fitted-model-like scene that needs several depth slices,
@@ -1838,7 +1840,7 @@ def test_native_frame_orchestration_equals_python_orchestration(gs, dev, case):
                                          p["sh"], vms, None, S, R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2,
                                          min_rgb_level=10.0, return_depth=True)
             rgb, alphas, radii, depth = out
-            assert (ops._native_frame_ok() and native == 1) or native == 0
+            assert (python_frame_path.native_ok() and native == 1) or native == 0
             ((rgb * wt).sum() + (alphas * wa).sum()).backward()
             grads = {k: v.grad.clone() for k, v in p.items()}
             grads.update(lin=lin.grad.clone(), ang=ang.grad.clone(), V=V.grad.clone())
@@ -1915,7 +1917,7 @@ def test_native_frame_arena_converges_over_many_ever_larger_slices(gs, dev):
         ops.NATIVE_FRAME = 1
         ops._arena_hint[key] = 1 << 20
         got = render()
-        assert ops._native_frame_ok()
+        assert python_frame_path.native_ok()
     finally:
         ops.NATIVE_FRAME, ops.SLICE_BASE = saved
         ops._arena_hint.pop(key, None)
@@ -1984,7 +1986,7 @@ def test_native_frame_merges_slices_of_a_frame_that_does_not_saturate(gs, dev):
             rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
                                                     torch.sigmoid(p["opacity_logits"]), p["sh"], vms, None, S, 1, sc["fx"],
                                                     sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2, min_rgb_level=10.0)
-            assert ops._native_frame_ok()
+            assert python_frame_path.native_ok()
             (rgb * wt).sum().backward()
             res[merge] = (rgb.detach().clone(), alphas.detach().clone(), {k: v.grad.clone() for k, v in p.items()},
                           [int(v) for v in ops.last_slice_intersects if int(v) > 0])

@@ -24,6 +24,9 @@ import bench  # noqa: E402
 def run(profile, N, W, H, S):
     import gsdeblur_amd as gs
     from gsdeblur_amd import ops
+    sys.path.insert(0, str(ROOT / "tests"))
+    import python_frame_path            # the counters are taken by the Python orchestration twin (GSD_LANE_STATS)
+    python_frame_path.install()
     dev = torch.device("cuda", 0)
     wl = bench.Workload(gs, dev, 0, 1, N, W, H, S, 1, profile, "sparse")
     ops.lane_stats = None

@@ -13,6 +13,9 @@ import torch
 sys.path.insert(0, ".")
 import gsdeblur_amd as gs                      # noqa: E402
 from gsdeblur_amd import ops                   # noqa: E402
+sys.path.insert(0, "tests")
+import python_frame_path                       # noqa: E402  (the Python depth pre-sort wrapper lives with the test twin)
+python_frame_path.install()
 
 cfg = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -55,5 +58,5 @@ else:
     keys, nt = keys.to(dev), nt.to(dev)
     rec = torch.zeros(1, device=dev)
     ops.DEPTH_SORT_COMPACT = 1 if cfg == "depthc" else 0
-    fn = lambda: ops._depth_rank(rec, keys.clone(), nt, P, N)                                        # noqa: E731
+    fn = lambda: python_frame_path._depth_rank(rec, keys.clone(), nt, P, N)                                        # noqa: E731
 print(cfg, f"{timed(fn):.4f} ms per call (includes one clone of the keys)")
