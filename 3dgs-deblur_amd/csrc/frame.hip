@@ -16,6 +16,8 @@
 #include <string.h>
 #include <time.h>
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <vector>
 #include "../../include/gsdeblur.h"
 
@@ -55,27 +57,33 @@ inline int bits_for(long long n) {
 inline int hip_status(hipError_t e) { return e == hipSuccess ? GS_OK : 1000 + (int)e; }
 
 // ---- optional stage timing (debug / bench): HIP events on the launch stream -------------------------------------
-// Per HOST THREAD: concurrent callers (one thread per stream) neither see each other's mask nor race
-// on the vectors; a thread reads back what it recorded itself.
+// Process-wide, mutex-guarded (concurrent callers raced on these; they cannot be thread-local — the
+// backward of a frame runs on torch's autograd thread while the reader sits on the thread that ran the forward).
 struct StageEvents { int stage; hipEvent_t a, b; };
-thread_local unsigned g_profile_mask = 0;
-thread_local std::vector<StageEvents> g_events;            // recorded since the last read
-thread_local std::vector<StageEvents> g_pool;              // reusable event pairs
+std::atomic<unsigned> g_profile_mask{0};
+std::mutex g_profile_mu;
+std::vector<StageEvents> g_events;            // recorded since the last read   (guarded by g_profile_mu)
+std::vector<StageEvents> g_pool;              // reusable event pairs           (guarded by g_profile_mu)
 
 struct StageScope {
   hipStream_t st;
   bool on;
   StageEvents ev;
-  StageScope(int stage, hipStream_t s) : st(s), on((g_profile_mask >> stage) & 1u) {
+  StageScope(int stage, hipStream_t s) : st(s), on((g_profile_mask.load(std::memory_order_relaxed) >> stage) & 1u) {
     if (!on) return;
-    if (!g_pool.empty()) { ev = g_pool.back(); g_pool.pop_back(); }
-    else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
+    bool have = false;
+    {
+      std::lock_guard<std::mutex> lk(g_profile_mu);
+      if (!g_pool.empty()) { ev = g_pool.back(); g_pool.pop_back(); have = true; }
+    }
+    if (!have) { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
     ev.stage = stage;
     (void)hipEventRecord(ev.a, st);
   }
   ~StageScope() {
     if (!on) return;
     (void)hipEventRecord(ev.b, st);
+    std::lock_guard<std::mutex> lk(g_profile_mu);
     g_events.push_back(ev);
   }
 };
@@ -157,14 +165,15 @@ enum { ST_DEPTH_SORT = 0, ST_COUNT_SCAN, ST_PLAN, ST_COUNT, ST_EMIT, ST_TILE_SOR
        ST_RASTER_BWD, ST_REDUCE, ST_N };
 
 GS_EXPORT int gs_frame_profile_enable(unsigned stage_mask) {
-  g_profile_mask = stage_mask;
+  g_profile_mask.store(stage_mask, std::memory_order_relaxed);
   return GS_OK;
 }
 
 // Drains the event pairs recorded since the last call: stage_ids[i] / ms[i] for i < returned count (<= max_events;
-// the rest is dropped).  Synchronises on the recorded events.  State is per host thread (measurement facility).
+// the rest is dropped).  Synchronises on the recorded events.  Process-wide state behind a mutex (measurement facility).
 GS_EXPORT int gs_frame_profile_read(int max_events, int* stage_ids, float* ms) {
   int n = 0;
+  std::lock_guard<std::mutex> lk(g_profile_mu);
   for (StageEvents& e : g_events) {
     if (n < max_events && stage_ids && ms) {
       (void)hipEventSynchronize(e.b);
