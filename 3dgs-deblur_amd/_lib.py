@@ -26,9 +26,10 @@ _SIGS = {
                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P],
     "gs_project_pixvel_fwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P, _P, _F, _F, _F, _F, _I, _I, _F, _I, _I,
                               _P, _P, _P, _P, _F, _P, _P, _I, _P],
-    "gs_rasterize_fwd_rs_slice": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _F, _P],
+    "gs_rasterize_fwd_rs_slice": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _F, _P,
+                                  _P],
     "gs_rasterize_bwd_rs_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _F, _F,
-                                  _P, _I, _F, _P],
+                                  _P, _I, _F, _P, _P],
     "gs_project_pixvel_bwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P, _P, _F, _F, _F, _F, _I, _I, _F, _I,
                               _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P],
     "gs_pack_records": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
@@ -62,7 +63,7 @@ _SIGS = {
     "gs_rasterize_bwd_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P,
                                _I, _P, _F, _F, _P],
     "gs_rasterize_fwd_slice_stats": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
-    "gs_reduce_grad_tuples": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
+    "gs_reduce_grad_tuples": [_I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _P],
     "gs_combine_fwd": [_I, _L, _P, _F, _F, _P, _P],
     "gs_combine_bwd": [_I, _L, _P, _F, _F, _P, _P, _P, _P],
     "gs_combine_bwd_scale": [_I, _L, _F, _P, _P, _P, _P],
@@ -72,8 +73,8 @@ _SIGS = {
     "gs_dp_scatter_add_rows": [_L, _P, _I, _P, _P, _F, _P],
     "gs_dp_pack_masked_rows": [_I, _P, _P, _I, _P, _I, _P, _P, _P, _P],
     "gs_dp_scatter_add_payload": [_I, _P, _I, _P, _P, _F, _P],
-    "gs_frame_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P],
-    "gs_frame_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _L, _P],
+    "gs_frame_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P],
+    "gs_frame_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _L, _P],
     "gs_frame_profile_enable": [ctypes.c_uint],
     "gs_sort_set_single_pass": [_I],
     "gs_frame_profile_read": [_I, _P, _P],

@@ -112,6 +112,15 @@ inline long long now_us() {
   return (long long)ts.tv_sec * 1000000ll + ts.tv_nsec / 1000;
 }
 
+// shared-list frames: the binning's tile_done [T] = every sample's compositor has finished the tile
+__global__ void and_tile_done_kernel(int S, int T, const unsigned char* __restrict__ done_s, unsigned char* __restrict__ done) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  unsigned char a = 1;
+  for (int s = 0; s < S; ++s) a &= done_s[(size_t)s * T + t] != 0;
+  done[t] = a;
+}
+
 inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
   __builtin_ia32_pause();
@@ -206,7 +215,7 @@ static long long slice_bytes(const gs_frame_desc& d, long long n_k, long long I_
     add(gs_radix_sort_workspace_bytes(I_k, 0, bits_for(P * T + 1)));
     add(8 * (P * T + 1));                                          // bins
   } else {
-    add(4); add(8 * P * T);
+    add(4); add(8 * (d.shared_list ? (long long)d.S : P) * T);
   }
   add(4ll * d.S * d.H * d.W);                                      // final index
   return Arena::up(b) + 256;
@@ -216,7 +225,8 @@ GS_EXPORT long long gs_frame_backward_bytes(const gs_frame_state* state) {
   if (!state) return 0;
   long long maxI = 0;
   for (int k = 0; k < state->n_slices; ++k) maxI = std::max(maxI, state->slice[k].I);
-  long long b = Arena::up(48 * maxI) + Arena::up(maxI) + 512;
+  const long long tpe = state->shared_list ? state->S : 1;          // gradient tuples per list entry
+  long long b = Arena::up(48 * maxI * tpe) + Arena::up(maxI * tpe) + 512;
   if (state->n_slices > 1) b += 2 * Arena::up(4ll * state->S * state->H * state->W);
   return b;
 }
@@ -232,19 +242,23 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
                                const float* background, const int* band_edges, const unsigned char* band_tile_done,
                                const float* color_means, const float* color_sh, const float* color_sh_rest, int color_K,
                                int color_degree,
-                               const float* color_viewmats, const float* pix_vel, float* out_img, float* out_T,
+                               const float* color_viewmats, const float* pix_vel, const float* sample_times,
+                               float* out_img, float* out_T,
                                float* out_depth, void* arena_ptr, long long arena_bytes, void* host_pinned, long long host_pinned_bytes,
                                gs_frame_state* state, void* stream_) {
   if (!dp || !records || !depth_keys || !num_tiles_hit || !background || !band_edges || !out_img || !out_T ||
       !arena_ptr || !host_pinned || !state)
     return GS_ERR_INVALID;
   const gs_frame_desc d = *dp;
-  if (d.N <= 0 || d.P <= 0 || d.S <= 0 || d.R <= 0 || d.P != d.S * d.R || d.H <= 0 || d.W <= 0 || d.P > 256)
-    return GS_ERR_INVALID;
+  // shared_list: ONE record set / depth sort / tile list (P == 1) for the S samples of a pixel-velocity frame
+  const bool shared = d.shared_list != 0;
+  if (d.N <= 0 || d.P <= 0 || d.S <= 0 || d.R <= 0 || d.H <= 0 || d.W <= 0 || d.P > 256 || d.S > 256) return GS_ERR_INVALID;
+  if (shared ? (d.P != 1 || d.R != 1 || !pix_vel || !sample_times) : (d.P != d.S * d.R)) return GS_ERR_INVALID;
   if (d.R > 1 && !band_tile_done) return GS_ERR_INVALID;
-  // exact per-row rolling shutter (pixel-velocity model, raster_rs.hip): the records' tile boxes are swept boxes, so
-  // the lists are built from the boxes themselves (no ellipse test, no hit masks) and the rs compositors run
-  const bool rs = pix_vel != nullptr && d.rolling_shutter_time != 0.f;
+  // exact per-row rolling shutter (pixel-velocity model, raster_rs.hip) and shared-list frames: the records' tile boxes
+  // are swept boxes, so the lists are built from the boxes themselves (no ellipse test, no hit masks) and the rs
+  // compositors run
+  const bool rs = pix_vel != nullptr && (d.rolling_shutter_time != 0.f || shared);
   if (rs && d.R != 1) return GS_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream_;
   const int P = d.P, N = d.N, S = d.S, R = d.R, H = d.H, W = d.W;
@@ -256,6 +270,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   memset(state, 0, sizeof(*state));
   state->P = P; state->N = N; state->S = S; state->R = R; state->H = H; state->W = W;
   state->rolling_shutter_time = rs ? d.rolling_shutter_time : 0.f;
+  state->shared_list = shared ? 1 : 0;
   Arena A(arena_ptr, arena_bytes);
 
   // ---- depth pre-sort (compacting, per sub-pose) + exclusive scan of the tile counts in rank order ----------------
@@ -279,7 +294,10 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   unsigned char* zeros_u8 = A.take<unsigned char>(flag_off + 4 * kKMax);
   int* plan_dev = A.take<int>(plan_ints);
   unsigned char* tile_done_rs = R > 1 ? A.take<unsigned char>(P * T) : nullptr;
+  // shared list: the compositor's done flags are per (sample, tile); the binning's [T] is their AND
+  unsigned char* tile_done_samples = shared ? A.take<unsigned char>((long long)S * T) : nullptr;
   if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
+  if (shared) CHECK(hip_status(hipMemsetAsync(tile_done_samples, 0, (long long)S * T, st)));
 
   int res = 0;
   {
@@ -368,7 +386,8 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   auto fits = [&](long long n_s, long long I_s, int k_next) -> bool {
     if (I_s >= 2147483647ll - kIdsPad) return false;                 // caught separately below
     const long long mI = std::max(maxI_issued, I_s);
-    const long long bwd = d.reserve_backward ? Arena::up(48 * mI) + Arena::up(mI) + 2 * Arena::up(4ll * S * H * W) + 1024 : 0;
+    const long long tpe = shared ? S : 1;                            // gradient tuples per list entry
+    const long long bwd = d.reserve_backward ? Arena::up(48 * mI * tpe) + Arena::up(mI * tpe) + 2 * Arena::up(4ll * S * H * W) + 1024 : 0;
     const long long need = Arena::up(A.off) + slice_bytes(d, n_s, I_s, use_masks, true_total) + bwd;
     if (need <= arena_bytes) return true;
     // say what this slice AND the next planned one would take: one retry usually settles a new high-water mark
@@ -503,11 +522,13 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
     }
     if (I_k == 0 && !(first || last)) continue;
     if (I_k == 0) {
+      // (an empty first / last slice goes through the plain compositor, which looks up one bin per (sample, tile))
+      const long long nb = (shared ? (long long)S : (long long)P) * T;
       svals = A.take<unsigned>(1 + kIdsPad);
-      bins = A.take<int>(2 * P * T);
+      bins = A.take<int>(2 * nb);
       if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
       CHECK(hip_status(hipMemsetAsync(svals, 0, 4 * (1 + kIdsPad), st)));
-      CHECK(hip_status(hipMemsetAsync(bins, 0, 8 * P * T, st)));
+      CHECK(hip_status(hipMemsetAsync(bins, 0, 8 * nb, st)));
     }
     int* fidx = A.take<int>((long long)S * H * W);
     if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
@@ -519,13 +540,14 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
       StageScope sc(ST_RASTER_FWD, st);
       if (rs && I_k > 0)
         CHECK(gs_rasterize_fwd_rs_slice(records, bins, band_edges, background, S, H, W, out_img, out_T, live_T, fidx,
-                                        tile_done, first ? 1 : 0, last ? 1 : 0, reinterpret_cast<const int*>(sorted_ids),
-                                        (int)std::min(n, 2147483647ll), out_depth, last ? nullptr : open_flags + k,
-                                        pix_vel, N, d.rolling_shutter_time, st));
+                                        shared ? tile_done_samples : tile_done, first ? 1 : 0, last ? 1 : 0,
+                                        reinterpret_cast<const int*>(sorted_ids), (int)std::min(n, 2147483647ll), out_depth,
+                                        last ? nullptr : open_flags + k, pix_vel, N, d.rolling_shutter_time,
+                                        shared ? sample_times : nullptr, st));
       else
       CHECK(gs_rasterize_fwd_slice(records, reinterpret_cast<const int*>(svals), bins, band_edges, background, S, R, H, W,
-                                   out_img, out_T, live_T, fidx, tile_done, first ? 1 : 0, last ? 1 : 0,
-                                   I_k > 0 ? reinterpret_cast<const int*>(vals) : nullptr,
+                                   out_img, out_T, live_T, fidx, shared ? tile_done_samples : tile_done, first ? 1 : 0,
+                                   last ? 1 : 0, I_k > 0 ? reinterpret_cast<const int*>(vals) : nullptr,
                                    reinterpret_cast<const int*>(sorted_ids), I_k > 0 ? (int)std::min(n, 2147483647ll) : 0,
                                    I_k > 0 ? out_depth : nullptr, I_k > 0 ? tile_hot : nullptr,
                                    last ? nullptr : open_flags + k, fwd_variant, st));
@@ -548,6 +570,9 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
                  ? 2 * (k1 - k) : 1;
       open_before = open_now;
       StageScope sc(ST_SAT, st);
+      if (shared)
+        hipLaunchKernelGGL(and_tile_done_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, S, (int)T,
+                           tile_done_samples, tile_done);
       CHECK(gs_tile_open_sat(P, H, W, tile_done, sat, open_bits, nullptr, st));
     }
   }
@@ -563,8 +588,8 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
 GS_EXPORT int gs_frame_backward(const gs_frame_state* state, const float* records, const float* background,
                                 const int* band_edges, const float* out_T, const float* v_img, const float* v_alpha,
                                 const float* cmb_scale, float cmb_gamma, float cmb_min_level, int bwd_variant,
-                                float* v_records, unsigned char* touched, const float* pix_vel, void* arena_ptr,
-                                long long arena_bytes, void* stream_) {
+                                float* v_records, unsigned char* touched, const float* pix_vel,
+                                const float* sample_times, void* arena_ptr, long long arena_bytes, void* stream_) {
   if (!state || !records || !background || !band_edges || !out_T || !v_img || !v_records || !arena_ptr)
     return GS_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream_;
@@ -582,8 +607,11 @@ GS_EXPORT int gs_frame_backward(const gs_frame_state* state, const float* record
     bwd_B = A.take<float>((long long)S * H * W);
   }
   // ONE tuple buffer for all slices: a slice's tuples are reduced before the next (nearer) slice writes its own
-  float* tuples = A.take<float>(12 * maxI);
-  unsigned char* flags = A.take<unsigned char>(maxI);
+  const bool shared = state->shared_list != 0;
+  if (shared && (!pix_vel || !sample_times)) return GS_ERR_INVALID;
+  const long long tpe = shared ? S : 1;                               // gradient tuples per list entry
+  float* tuples = A.take<float>(12 * maxI * tpe);
+  unsigned char* flags = A.take<unsigned char>(maxI * tpe);
   if (!A.ok) return GS_ERR_WORKSPACE;
   if (bwd_T) {
     CHECK(hip_status(hipMemcpyAsync(bwd_T, out_T, 4ll * S * H * W, hipMemcpyDeviceToDevice, st)));
@@ -591,17 +619,18 @@ GS_EXPORT int gs_frame_backward(const gs_frame_state* state, const float* record
   }
   for (int k = state->n_slices - 1; k >= 0; --k) {
     const gs_frame_slice& sl = state->slice[k];
-    CHECK(hip_status(hipMemsetAsync(flags, 0, sl.I, st)));
+    CHECK(hip_status(hipMemsetAsync(flags, 0, sl.I * tpe, st)));
     {
       StageScope sc(ST_RASTER_BWD, st);
-      if (state->rolling_shutter_time != 0.f) {
+      if (state->rolling_shutter_time != 0.f || shared) {
         if (!pix_vel) return GS_ERR_INVALID;
         CHECK(gs_rasterize_bwd_rs_slice(records, reinterpret_cast<const int*>(base + sl.svals),
                                         reinterpret_cast<const int*>(base + sl.bins), band_edges, background, S, H, W, out_T,
                                         reinterpret_cast<const int*>(base + sl.fidx), v_img, v_alpha, bwd_T, bwd_B, tuples,
                                         flags, reinterpret_cast<const int*>(base + sl.sorted_ids),
                                         (int)std::min(n_rec, 2147483647ll), bwd_variant & 256, cmb_scale, cmb_gamma,
-                                        cmb_min_level, pix_vel, state->N, state->rolling_shutter_time, st));
+                                        cmb_min_level, pix_vel, state->N, state->rolling_shutter_time,
+                                        shared ? sample_times : nullptr, st));
       } else
       CHECK(gs_rasterize_bwd_slice(records, reinterpret_cast<const int*>(base + sl.svals),
                                    reinterpret_cast<const int*>(base + sl.bins), band_edges, background, S, R, H, W, out_T,
@@ -617,7 +646,7 @@ GS_EXPORT int gs_frame_backward(const gs_frame_state* state, const float* record
       CHECK(gs_reduce_grad_tuples(sl.n, reinterpret_cast<const unsigned*>(base + sl.slice_gi),
                                   reinterpret_cast<const unsigned*>(base + sl.counts),
                                   reinterpret_cast<const unsigned*>(base + sl.cum), tuples, flags, v_records, touched,
-                                  sl.wave_per_gaussian ? sl.I : 0, records, st));
+                                  sl.wave_per_gaussian ? sl.I : 0, records, (int)tpe, st));
     }
   }
   return GS_OK;

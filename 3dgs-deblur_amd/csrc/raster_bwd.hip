@@ -558,11 +558,12 @@ __global__ __launch_bounds__(256) void reduce_tuples_kernel(int n_slice, const u
                                                             const unsigned char* __restrict__ flags,
                                                             float* __restrict__ v_records,
                                                             unsigned char* __restrict__ touched,
-                                                            const float* __restrict__ records) {
+                                                            const float* __restrict__ records, unsigned mult) {
   const int lane = lane_id();
   const int j = blockIdx.x * 256 + threadIdx.x;
   unsigned cnt = 0, e0 = 0, gi = 0;
-  if (j < n_slice) { cnt = counts[j]; e0 = cum[j]; gi = slice_gi[j]; }
+  // mult: tuples per list entry (gs_rasterize_bwd_rs_slice with one list for S samples writes S of them, adjacent)
+  if (j < n_slice) { cnt = counts[j] * mult; e0 = cum[j] * mult; gi = slice_gi[j]; }
   // 11 components: slots 9 and 10 carry d loss / d pixel-velocity of the exact rolling-shutter compositor
   // (raster_rs.hip); the other compositors leave them unwritten and nobody reads their sums
   float acc[kTupleComp];
@@ -632,11 +633,11 @@ __global__ __launch_bounds__(256) void reduce_tuples_wave_kernel(int n_slice, co
                                                                  const unsigned char* __restrict__ flags,
                                                                  float* __restrict__ v_records,
                                                                  unsigned char* __restrict__ touched,
-                                                                 const float* __restrict__ records) {
+                                                                 const float* __restrict__ records, unsigned mult) {
   const int lane = lane_id();
   const int j = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
   if (j >= n_slice) return;
-  const unsigned c_n = counts[j], c_e = cum[j];
+  const unsigned c_n = counts[j] * mult, c_e = cum[j] * mult;
   if (c_n == 0) return;
   float part[kTupleComp];
 #pragma unroll
@@ -768,14 +769,15 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
 GS_EXPORT int gs_reduce_grad_tuples(int n_slice, const unsigned* slice_gi, const unsigned* counts,
                                     const unsigned* cum_excl, const float* tuples, const unsigned char* flags,
                                     float* v_records, unsigned char* touched, long long n_isect, const float* records,
-                                    void* stream) {
-  if (n_slice <= 0 || !records) return GS_ERR_INVALID;
+                                    int tuples_per_entry, void* stream) {
+  if (n_slice <= 0 || !records || tuples_per_entry < 1) return GS_ERR_INVALID;
+  const unsigned mult = (unsigned)tuples_per_entry;
   if (n_isect > 32ll * n_slice)    // few large Gaussians: one wave each
     hipLaunchKernelGGL(reduce_tuples_wave_kernel, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream, n_slice,
-                       slice_gi, counts, cum_excl, tuples, flags, v_records, touched, records);
+                       slice_gi, counts, cum_excl, tuples, flags, v_records, touched, records, mult);
   else
     hipLaunchKernelGGL(reduce_tuples_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice,
-                       slice_gi, counts, cum_excl, tuples, flags, v_records, touched, records);
+                       slice_gi, counts, cum_excl, tuples, flags, v_records, touched, records, mult);
   return gs_launch_status();
 }
 

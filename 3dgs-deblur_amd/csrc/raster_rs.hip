@@ -21,6 +21,12 @@ struct RsParams {
   const float* pix_vel;   // [N,2] pixel velocity of every Gaussian (gs_project_pixvel_fwd)
   int N;
   float rs_time;          // readout time T_ro (same unit as the sub-pose times)
+  // round 4 — ONE list for all blur samples (the form the paper describes, SURVEY.md App. A: "depth order and
+  // covariance fixed across samples", /root/reference/README.md:196-200): the records are the mid-exposure splats (one
+  // per Gaussian, tile boxes swept over the whole exposure + readout), binned and sorted ONCE; sample s walks the same
+  // tile list and evaluates every splat at mu' + (times[s] + tau(y)) v'.  times == NULL: one record set and one list
+  // per sample (records already centred at mu' + t_s v'; round 3).
+  const float* times;     // [S] sample times, or NULL
 };
 
 struct RsSliceState {
@@ -67,7 +73,9 @@ __global__ __launch_bounds__(256) void raster_fwd_rs_kernel(RasterParams prm, Rs
   const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
   const size_t tkey = (size_t)s * T + t;                      // R == 1: sub-pose = sample
   if (!st.first && st.tile_done[tkey]) return;
-  int2 range = prm.tile_bins[tkey];
+  const bool shared = rs.times != nullptr;                    // all samples walk sub-pose 0's list
+  const float t_s = shared ? rs.times[s] : 0.f;
+  int2 range = prm.tile_bins[shared ? (size_t)t : tkey];
   range.x = __builtin_amdgcn_readfirstlane(range.x);
   range.y = __builtin_amdgcn_readfirstlane(range.y);
   if (!st.first && !st.last && range.y <= range.x) {
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256) void raster_fwd_rs_kernel(RasterParams prm, Rs
   for (int k = 0; k < 4; ++k) {
     inside[k] = px < prm.W && (py0 + k) < prm.H;
     pyf[k] = (float)(py0 + k) + 0.5f;
-    tau[k] = (pyf[k] / (float)prm.H - 0.5f) * rs.rs_time;
+    tau[k] = (pyf[k] / (float)prm.H - 0.5f) * rs.rs_time + t_s;
     Tk[k] = inside[k] ? 1.f : -1.f; Cr[k] = Cg[k] = Cb[k] = Cd[k] = 0.f; last[k] = range.x;
     if (!st.first && inside[k]) {
       const size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(256) void raster_fwd_rs_kernel(RasterParams prm, Rs
     }
   }
   auto any_live = [&]() { return __ballot(fmaxf(fmaxf(Tk[0], Tk[1]), fmaxf(Tk[2], Tk[3])) > 0.f) != 0ull; };
-  const unsigned s_base = (unsigned)s * (unsigned)rs.N;
+  const unsigned s_base = shared ? 0u : (unsigned)s * (unsigned)rs.N;
   for (int i = range.x; i < range.y; ++i) {
     if (((i - range.x) & 3) == 0 && !any_live()) break;
     const unsigned gi = min((unsigned)ids[i], max_id);
@@ -167,7 +175,9 @@ __global__ __launch_bounds__(256) void raster_bwd_rs_kernel(
   if (work >= (unsigned)(prm.S * T)) return;
   const int s = work / T, t = work % T;
   const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
-  int2 range = prm.tile_bins[(size_t)s * T + t];
+  const bool shared = rs.times != nullptr;
+  const float t_s = shared ? rs.times[s] : 0.f;
+  int2 range = prm.tile_bins[shared ? (size_t)t : (size_t)s * T + t];
   range.x = __builtin_amdgcn_readfirstlane(range.x);
   range.y = __builtin_amdgcn_readfirstlane(range.y);
   if (range.y <= range.x) return;
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(256) void raster_bwd_rs_kernel(
   for (int k = 0; k < 4; ++k) {
     const int y = py0 + k;
     pyf[k] = (float)y + 0.5f;
-    tau[k] = (pyf[k] / (float)prm.H - 0.5f) * rs.rs_time;
+    tau[k] = (pyf[k] / (float)prm.H - 0.5f) * rs.rs_time + t_s;
     Tk[k] = 1.f; Dv[k] = 0.f; fin[k] = range.x; vr[k] = vg[k] = vb[k] = 0.f;
     if (px < prm.W && y < prm.H) {
       const size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
@@ -205,7 +215,10 @@ __global__ __launch_bounds__(256) void raster_bwd_rs_kernel(
   }
   const int wave_end = __builtin_amdgcn_readfirstlane(wave_max_i(my_end));
   const float agm = prm.alpha_grad_max;
-  const unsigned s_base = (unsigned)s * (unsigned)rs.N;
+  const unsigned s_base = shared ? 0u : (unsigned)s * (unsigned)rs.N;
+  // shared list: the S samples' waves write the SAME entry's gradients — every (entry, sample) pair gets a tuple of its
+  // own, e * S + s (the S tuples of an entry are adjacent, a Gaussian's tuples stay one contiguous range)
+  const unsigned tmul = shared ? (unsigned)prm.S : 1u, tofs = shared ? (unsigned)s : 0u;
   const int row = lane;
   const int row_g = row / kRsComp, row_c = row - row_g * kRsComp;
   if (wave_end > range.x) {
@@ -267,8 +280,8 @@ __global__ __launch_bounds__(256) void raster_bwd_rs_kernel(
           for (int q = 4; q < 16; q += 4) { a0 += rp[q]; a1 += rp[q + 1]; a2 += rp[q + 2]; a3 += rp[q + 3]; }
           const f4 v = (a0 + a1) + (a2 + a3);
           const float sum = (v.x + v.y) + (v.z + v.w);
-          const unsigned e = (unsigned)eids[b + row_g];
-          tuples[(size_t)e * kGradFloats + row_c] = sum;
+          const size_t e = (size_t)(unsigned)eids[b + row_g] * tmul + tofs;
+          tuples[e * kGradFloats + row_c] = sum;
           if (row_c == 0) flags[e] = 1;
         }
         __builtin_amdgcn_wave_barrier();
@@ -303,10 +316,11 @@ GS_EXPORT int gs_rasterize_fwd_rs_slice(const float* records, const int* tile_bi
                                         const float* background, int S, int H, int W, float* out_img, float* out_T,
                                         float* live_T, int* final_idx, unsigned char* tile_done, int first, int last,
                                         const int* sorted_ids, int n_records, float* out_depth, int* open_flag,
-                                        const float* pix_vel, int N, float rolling_shutter_time, void* stream) {
+                                        const float* pix_vel, int N, float rolling_shutter_time,
+                                        const float* shared_list_times, void* stream) {
   if (S <= 0 || H <= 0 || W <= 0 || N <= 0 || !pix_vel || !sorted_ids || n_records <= 0) return GS_ERR_INVALID;
   RasterParams prm = make_raster_params(records, sorted_ids, tile_bins, band_edges, background, S, 1, H, W);
-  RsParams rs; rs.pix_vel = pix_vel; rs.N = N; rs.rs_time = rolling_shutter_time;
+  RsParams rs; rs.pix_vel = pix_vel; rs.N = N; rs.rs_time = rolling_shutter_time; rs.times = shared_list_times;
   RsSliceState st; st.tile_done = tile_done; st.live_T = live_T; st.first = first; st.last = last; st.open_flag = open_flag;
   const unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y), blocks = (work + 3) / 4;
   if (out_depth)
@@ -319,7 +333,7 @@ GS_EXPORT int gs_rasterize_fwd_rs_slice(const float* records, const int* tile_bi
 }
 
 // Backward of the same slice: tuples [I*12] (slots 0..8 as gs_rasterize_bwd_slice, 9..10 = d loss / d pixel velocity),
-// flags [I] zeroed by the caller; sorted_vals = emission index of every sorted entry; bwd_T / bwd_B as in
+// flags [I] zeroed by the caller — shared_list_times != NULL: tuples [I*S*12], flags [I*S], entry e / sample s at e*S+s; sorted_vals = emission index of every sorted entry; bwd_T / bwd_B as in
 // gs_rasterize_bwd_slice (both NULL for a one-slice frame); variant: + 256 = upstream alpha-clamp gradient.
 GS_EXPORT int gs_rasterize_bwd_rs_slice(const float* records, const int* sorted_vals, const int* tile_bins,
                                         const int* band_edges, const float* background, int S, int H, int W,
@@ -327,14 +341,15 @@ GS_EXPORT int gs_rasterize_bwd_rs_slice(const float* records, const int* sorted_
                                         const float* v_alpha, float* bwd_T, float* bwd_B, float* tuples,
                                         unsigned char* flags, const int* sorted_ids, int n_records, int variant,
                                         const float* cmb_scale, float cmb_gamma, float cmb_min_level,
-                                        const float* pix_vel, int N, float rolling_shutter_time, void* stream) {
+                                        const float* pix_vel, int N, float rolling_shutter_time,
+                                        const float* shared_list_times, void* stream) {
   if (S <= 0 || H <= 0 || W <= 0 || N <= 0 || !pix_vel || !sorted_ids || !tuples || !flags || n_records <= 0)
     return GS_ERR_INVALID;
   if ((bwd_T == nullptr) != (bwd_B == nullptr)) return GS_ERR_INVALID;
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, 1, H, W);
   prm.cmb_scale = cmb_scale; prm.cmb_gamma = cmb_gamma; prm.cmb_min = cmb_min_level;
   if (variant & 256) prm.alpha_grad_max = 3.0e38f;
-  RsParams rs; rs.pix_vel = pix_vel; rs.N = N; rs.rs_time = rolling_shutter_time;
+  RsParams rs; rs.pix_vel = pix_vel; rs.N = N; rs.rs_time = rolling_shutter_time; rs.times = shared_list_times;
   const unsigned work = (unsigned)(S * prm.tiles_x * prm.tiles_y), blocks = (work + 3) / 4;
   if (bwd_T)
     hipLaunchKernelGGL(raster_bwd_rs_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, prm, rs, sorted_ids,

@@ -60,6 +60,10 @@ class SplatfactoDeblurConfig:
     # (both motion models); "exact" (pixel_velocity only) = continuous per-row time inside the compositor, ONE
     # projection / sort per blur sample whatever the band count (SURVEY App. A "row time (y/H - 1/2) * T_ro")
     rolling_shutter_mode: str = "bands"
+    # pixel_velocity only: "per_sample" = one projection / sort / tile list per sub-pose; "shared" = ONE for the frame
+    # (tile boxes swept over the exposure + readout, every blur sample walks the same list — the form the paper
+    # describes; rolling shutter then only in its "exact" mode)
+    pixel_velocity_lists: str = "per_sample"
     camera_optimizer: CameraOptimizerConfig = field(default_factory=CameraOptimizerConfig)
     camera_velocity_optimizer: CameraVelocityOptimizerConfig = field(default_factory=CameraVelocityOptimizerConfig)
 
@@ -227,6 +231,12 @@ class SplatfactoDeblurModel(nn.Module):
             R = 1                                   # the row time lives in the compositor (see _rs_time)
         elif cfg.rolling_shutter_mode != "bands":
             raise ValueError(f"unknown rolling_shutter_mode {cfg.rolling_shutter_mode!r}")
+        if cfg.pixel_velocity_lists == "shared":
+            if cfg.motion_model != "pixel_velocity" or R != 1:
+                raise ValueError("pixel_velocity_lists='shared' needs motion_model='pixel_velocity' and, with a rolling "
+                                 "shutter, rolling_shutter_mode='exact'")
+        elif cfg.pixel_velocity_lists != "per_sample":
+            raise ValueError(f"unknown pixel_velocity_lists {cfg.pixel_velocity_lists!r}")
         times, _, _ = ops.subpose_schedule(S, exposure, R, readout)
         return S, R, times
 
@@ -254,6 +264,7 @@ class SplatfactoDeblurModel(nn.Module):
         if not pixvel and cfg.motion_model != "se3":
             raise ValueError(f"unknown motion_model {cfg.motion_model!r}")
         viewmats = viewmat if pixvel else ops.subpose_viewmats(viewmat, lin, ang, times_t)
+        shared = pixvel and cfg.pixel_velocity_lists == "shared"
         # the RAW parameters go to the kernels as they are: log-scales, opacity logits, features_dc / features_rest as two
         # pointers (no exp / sigmoid / cat launches and none of their backward; ops.render_combined raw_params / sh_rest)
         gp = (self.means, self.scales, self.quats, self.opacities, self.features_dc, self.features_rest)
@@ -274,9 +285,10 @@ class SplatfactoDeblurModel(nn.Module):
             viewmats, bg, S, R, camera.fx, camera.fy, camera.cx, camera.cy, camera.height, camera.width,
             gamma=gamma, min_rgb_level=min_level, sh_degree=self.active_sh_degree(),
             antialiased=(cfg.rasterize_mode == "antialiased"), xy_grad_out=self.xy_grad,
-            lin_vel=lin if pixvel else None, ang_vel=ang if pixvel else None, times=times_t if pixvel else None,
+            lin_vel=lin if pixvel else None, ang_vel=ang if pixvel else None,
+            times=(list(times) if shared else times_t) if pixvel else None,
             return_depth=want_depth, rolling_shutter_time=self._rs_time(camera) if pixvel else 0.0,
-            sh_rest=rest_, raw_params=True)
+            sh_rest=rest_, raw_params=True, shared_list=shared)
         rgb, alphas, radii = res[:3]
         depth_acc = res[3] if want_depth else None
         self.radii = radii

@@ -380,7 +380,8 @@ class _FrameDesc(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int) for k in ("N", "P", "S", "R", "H", "W", "slice_base", "depth_sort_digit",
                                              "fwd_variant", "reserve_backward")] + [("merge_open_fraction", ctypes.c_float),
                                                                                      ("rolling_shutter_time", ctypes.c_float),
-                                                                                     ("poll_readback", ctypes.c_int)]
+                                                                                     ("poll_readback", ctypes.c_int),
+                                                                                     ("shared_list", ctypes.c_int)]
 
 
 class _FrameSlice(ctypes.Structure):
@@ -391,7 +392,7 @@ class _FrameSlice(ctypes.Structure):
 
 class _FrameState(ctypes.Structure):
     _fields_ = ([(k, ctypes.c_int) for k in ("n_slices", "P", "N", "S", "R", "H", "W")] +
-                [("rolling_shutter_time", ctypes.c_float)] +
+                [("rolling_shutter_time", ctypes.c_float), ("shared_list", ctypes.c_int)] +
                 [(k, ctypes.c_longlong) for k in ("n_total", "arena_used", "arena_required")] +
                 [("slice", _FrameSlice * 16)])
 
@@ -415,21 +416,23 @@ def _profile_mask() -> int:
 def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
                          H: int, W: int, bg: Tensor, edges: Tensor, slice_base: int, color=None,
                          out_depth: Optional[Tensor] = None, reserve_backward: bool = True, rs=None):
-    """rs = (pix_vel [N,2], rolling_shutter_time) or None.  gs_frame_forward: -> (out_img [S,H,W,3], out_T [S,H,W], frame) ; frame = dict(arena, state) for
+    """rs = (pix_vel [N,2], rolling_shutter_time[, sample_times [S]]) or None; with sample_times the frame runs in the
+    shared-list mode (P == 1: one record set and one tile list for the S samples).  gs_frame_forward: -> (out_img [S,H,W,3], out_T [S,H,W], frame) ; frame = dict(arena, state) for
     native_frame_backward.  Raises _ArenaTooSmall (after recording a larger size) when the arena did not hold the frame:
     the caller projects again (the depth keys were consumed) and calls once more."""
     global last_num_intersects, _slice_totals
     L = _L()
     dev = records.device
     tx, ty = _tiles(H, W)
-    key = (str(dev), N, P, S, H, W)
+    shared = rs is not None and len(rs) > 2 and rs[2] is not None
+    key = (str(dev), N, P, S, H, W, shared)
     n = P * N
     nbytes = _arena_hint.get(key)
     if nbytes is None:
         # depth pre-sort + plan + one slice of the default budget; the library prices the real plan and says so if this
         # is short (one retry per new high-water mark)
         I0 = max(1, slice_base) * tx * ty * P
-        nbytes = 40 * n + 16 * S * H * W + 80 * I0 + (64 << 20)
+        nbytes = 40 * n + 16 * S * H * W + (80 + (56 * S if shared else 0)) * I0 + (64 << 20)
     arena = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
     # the read-back buffer is written by the GPU while gs_frame_forward polls it (ctypes releases the GIL for the call):
     # one per device, host thread and stream, so that concurrent frames never share it
@@ -439,7 +442,7 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     if pin is None or pin.numel() < need_pin:
         pin = _pinned_cache[pin_key] = torch.empty(max(8192, need_pin), dtype=torch.uint8, pin_memory=True)
     desc = _FrameDesc(N, P, S, R, H, W, int(slice_base), DEPTH_SORT_DIGIT, 0, int(reserve_backward),
-                      float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0, int(FRAME_POLL))
+                      float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0, int(FRAME_POLL), int(shared))
     state = _FrameState()
     out_img = torch.empty(S, H, W, 3, device=dev)
     out_T = torch.empty(S, H, W, device=dev)
@@ -451,7 +454,8 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     L.gs_frame_profile_enable(_profile_mask())
     st = L.gs_frame_forward(ctypes.byref(desc), _ptr(records), _ptr(depth_keys), _ptr(num_tiles_hit), _ptr(bg), _ptr(edges),
                             _ptr(band_done), _ptr(c_means), _ptr(c_sh), _ptr(c_rest), int(c_K), int(c_deg), _ptr(c_V),
-                            _ptr(rs[0]) if rs is not None else None, _ptr(out_img), _ptr(out_T), _ptr(out_depth),
+                            _ptr(rs[0]) if rs is not None else None, _ptr(rs[2]) if shared else None, _ptr(out_img),
+                            _ptr(out_T), _ptr(out_depth),
                             _ptr(arena), arena.numel(), ctypes.c_void_p(pin.data_ptr()), pin.numel(), ctypes.byref(state),
                             _stream())
     if st == 3:
@@ -464,7 +468,8 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     last_num_intersects = int(state.n_total)
     _slice_totals = [arena[sl.n_emitted_dev:sl.n_emitted_dev + 4].view(torch.int32)
                      for sl in (state.slice[i] for i in range(state.n_slices))]
-    return out_img, out_T, dict(arena=arena, state=state, pix_vel=rs[0] if rs is not None else None)
+    return out_img, out_T, dict(arena=arena, state=state, pix_vel=rs[0] if rs is not None else None,
+                                sample_times=rs[2] if shared else None)
 
 
 def native_frame_backward(frame, records: Tensor, bg: Tensor, edges: Tensor, out_T: Tensor, v_img: Tensor,
@@ -475,7 +480,8 @@ def native_frame_backward(frame, records: Tensor, bg: Tensor, edges: Tensor, out
     L.gs_frame_profile_enable(_profile_mask())
     st = L.gs_frame_backward(ctypes.byref(state), _ptr(records), _ptr(bg), _ptr(edges), _ptr(out_T), _ptr(v_img),
                              _ptr(v_alpha), _ptr(cmb[0]), float(cmb[1]), float(cmb[2]), _bwd_variant(), _ptr(v_records),
-                             _ptr(touched), _ptr(frame.get("pix_vel")), _ptr(arena), arena.numel(), _stream())
+                             _ptr(touched), _ptr(frame.get("pix_vel")), _ptr(frame.get("sample_times")), _ptr(arena),
+                             arena.numel(), _stream())
     if st == 3:
         raise _lib.HipLibraryError("frame_backward: the forward's arena cannot hold the backward's buffers "
                                    "(call native_frame_forward with reserve_backward=True)")
@@ -769,7 +775,7 @@ class _RenderSubposes(Function):
     def forward(ctx, means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out, return_alpha,
                 gamma, min_rgb_level, lin_vel=None, ang_vel=None, times=None, return_depth=False, rs_time=0.0,
-                sh_rest=None, param_flags=0):
+                sh_rest=None, param_flags=0, shared_list=False):
         # an output the loss does not use arrives as None in backward instead of a materialised zero tensor
         ctx.set_materialize_grads(False)
         means3d, scales, quats = _f32(means3d, "means3d"), _f32(scales, "scales"), _f32(quats, "quats")
@@ -797,6 +803,21 @@ class _RenderSubposes(Function):
         if rs_time != 0.0 and (not pixvel or R != 1):
             raise ValueError("exact rolling shutter (rolling_shutter_time != 0) needs the pixel-velocity model "
                              "(times / lin_vel / ang_vel) and rs_bands == 1")
+        # shared list (pixel-velocity model, rs_bands == 1): ONE record set, depth sort and tile list for the frame —
+        # the splats at the centre of the sampled time span, tile boxes swept over the whole span (+ readout); the
+        # compositor evaluates sample s at xy + (times[s] - centre + tau(y)) * pixel_velocity
+        shared = None
+        if shared_list:
+            if not pixvel or R != 1:
+                raise ValueError("shared_list needs the pixel-velocity model (times / lin_vel / ang_vel) and rs_bands == 1")
+            tl = [float(t) for t in (times.reshape(-1).tolist() if isinstance(times, Tensor) else times)]
+            if len(tl) != S:
+                raise ValueError(f"times must hold {S} sample times")
+            t_c = 0.5 * (min(tl) + max(tl))
+            shared = (torch.tensor([t - t_c for t in tl], dtype=torch.float32, device=means3d.device),
+                      (max(tl) - min(tl)) + abs(rs_time))
+            times = torch.tensor([t_c], dtype=torch.float32, device=means3d.device)
+            P = 1
         if pixvel:
             V = _viewmat16(viewmats).reshape(4, 4)
             twist = torch.cat([_f32(lin_vel, "lin_vel").reshape(3), _f32(ang_vel, "ang_vel").reshape(3)]).contiguous()
@@ -823,8 +844,11 @@ class _RenderSubposes(Function):
         # bit 0: SH colour deferred to the depth slices (gs_slice_colors colours only what a slice emits)
         backend = frame_backend if (frame_backend is not None and not frame_backend.native_ok()) else None
         defer_flags = 3 if backend is None else backend.defer_flags()
-        pix_vel = torch.empty(N, 2, device=dev) if rs_time != 0.0 else None
-        rs = (pix_vel, rs_time) if rs_time != 0.0 else None
+        if shared is not None and backend is not None:
+            raise ValueError("the shared-list mode runs through the library's frame path only")
+        pix_vel = torch.empty(N, 2, device=dev) if (rs_time != 0.0 or shared is not None) else None
+        rs = None if pix_vel is None else (pix_vel, rs_time) + ((shared[0],) if shared is not None else ())
+        box_sweep = shared[1] if shared is not None else rs_time      # what the projection widens the tile boxes by
         ctx.rs = rs
 
         def _project():
@@ -832,7 +856,7 @@ class _RenderSubposes(Function):
                 _check(L.gs_project_pixvel_fwd(N, P, _ptr(means3d), _ptr(scales), args[2], _ptr(quats), _ptr(opacities),
                                                _ptr(sh), K, args[4], _ptr(V), _ptr(twist), _ptr(times), args[5], args[6],
                                                args[7], args[8], H, W, args[11], args[12], defer_flags,
-                                               _ptr(records), _ptr(dkeys), _ptr(ntiles), _ptr(radii), rs_time,
+                                               _ptr(records), _ptr(dkeys), _ptr(ntiles), _ptr(radii), box_sweep,
                                                _ptr(pix_vel), _ptr(sh_rest), param_flags, _stream()),
                        "project_pixvel_fwd")
             else:
@@ -919,7 +943,7 @@ class _RenderSubposes(Function):
         dev = means3d.device
         L = _L()
         if v_img is None and v_alpha is None:
-            return (None,) * 30
+            return (None,) * 31
         v_img = torch.zeros(ctx.img_shape, device=dev) if v_img is None else v_img.contiguous().float()
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
         combine = None
@@ -997,7 +1021,7 @@ class _RenderSubposes(Function):
                                               _stream()), "project_fused_bwd")
         v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
         return ((v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 16
-                + (v_lin, v_ang, None, None, None, v_sh_rest, None))
+                + (v_lin, v_ang, None, None, None, v_sh_rest, None, None))
 
 
 def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, sh: Tensor,
@@ -1007,7 +1031,7 @@ def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
                     clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None, return_alpha: bool = True,
                     lin_vel: Optional[Tensor] = None, ang_vel: Optional[Tensor] = None,
                     times: Optional[Tensor] = None, return_depth: bool = False, rolling_shutter_time: float = 0.0,
-                    sh_rest: Optional[Tensor] = None, raw_params: bool = False):
+                    sh_rest: Optional[Tensor] = None, raw_params: bool = False, shared_list: bool = False):
     """Fused hot path: project N Gaussians under P=S*R sub-pose viewmats, bin, sort, composite.
     -> (samples [S,H,W,3], alphas [S,H,W], radii int32 [P,N]).  scales/opacities are activated values — or, with
     raw_params=True, splatfacto's RAW parameters: log-scales and opacity logits (exp / sigmoid and their backward run
@@ -1022,12 +1046,18 @@ def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
     camera-space depth (no gradient); expected depth = that / alpha (splatfacto's outputs["depth"]).
     rolling_shutter_time != 0 (pixel-velocity model, rs_bands == 1, times = the S blur-sample times): EXACT per-row
     rolling shutter — pixel row y sees every splat at xy + (times[s] + tau(y)) * pixel_velocity with
-    tau(y) = ((y + 0.5) / H - 0.5) * rolling_shutter_time; one projection / sort / list per blur sample, whatever H."""
+    tau(y) = ((y + 0.5) / H - 0.5) * rolling_shutter_time; one projection / sort / list per blur sample, whatever H.
+    shared_list=True (pixel-velocity model, rs_bands == 1, any rolling_shutter_time): ONE record set, sort and tile list
+    for the whole frame (tile boxes swept over the sampled span); the S samples walk it.  radii is then [1,N].  The
+    footprint of a splat is cut at the swept box instead of the per-sample box: contributions beyond 3 sigma inside
+    the swept box (alpha between 1/255 and opacity * exp(-4.5)) are kept, so values differ from the per-sample lists
+    by that fringe."""
     S, R = max(1, int(blur_samples)), max(1, int(rs_bands))
     out = _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
                                 bool(return_alpha), None, None, lin_vel, ang_vel, times, bool(return_depth),
-                                float(rolling_shutter_time), sh_rest, 3 if raw_params else 0)
+                                float(rolling_shutter_time), sh_rest, 3 if raw_params else 0,
+                                bool(shared_list))
     return out if return_depth else out[:3]
 
 
@@ -1038,7 +1068,7 @@ def render_combined(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
                     glob_scale: float = 1.0, clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None,
                     return_alpha: bool = True, lin_vel: Optional[Tensor] = None, ang_vel: Optional[Tensor] = None,
                     times: Optional[Tensor] = None, return_depth: bool = False, rolling_shutter_time: float = 0.0,
-                    sh_rest: Optional[Tensor] = None, raw_params: bool = False):
+                    sh_rest: Optional[Tensor] = None, raw_params: bool = False, shared_list: bool = False):
     """render_subposes + combine_samples as ONE autograd node: -> (rgb [H,W,3], alphas [S,H,W] or None, radii).
     Same values as the two-step form; the backward skips the [S,H,W,3] per-sample gradient tensor — the
     compositor's backward derives every pixel's sample gradient from rgb and its gradient."""
@@ -1046,7 +1076,8 @@ def render_combined(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
     out = _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
                                 bool(return_alpha), float(gamma), float(min_rgb_level), lin_vel, ang_vel, times,
-                                bool(return_depth), float(rolling_shutter_time), sh_rest, 3 if raw_params else 0)
+                                bool(return_depth), float(rolling_shutter_time), sh_rest, 3 if raw_params else 0,
+                                bool(shared_list))
     return out if return_depth else out[:3]
 
 

@@ -45,14 +45,14 @@ def render_step(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor,
                 sh_degree: int = 3, antialiased: bool = True, sh_rest: Optional[Tensor] = None, raw_params: bool = True,
                 motion_model: str = "se3", xy_grad_out: Optional[Tensor] = None, camera_grads: bool = True,
                 background_grad: bool = False, glob_scale: float = 1.0, clip_thresh: float = 0.01,
-                rolling_shutter_time: float = 0.0
+                rolling_shutter_time: float = 0.0, shared_list: bool = False
                 ) -> Tuple[Tensor, Dict[str, Optional[Tensor]], Tensor]:
     """One frame, forward and backward.  Arguments as ops.render_combined (raw_params: log-scales / opacity logits;
     sh_rest: features_rest beside sh = features_dc), but the camera comes as ONE mid-exposure `viewmat` [4,4] + body
     twist + the P sub-pose `times` for both motion models.  grad_image: d loss / d rgb [H,W,3], or a callable
     rgb -> d loss / d rgb that is invoked between the two halves.
     -> (rgb [H,W,3], gradients {means, scales, quats, opacities, sh, sh_rest, viewmat, lin_vel, ang_vel, background},
-        radii [P,N]) — gradients of exactly the tensors handed in (raw parameters with raw_params=True)."""
+        radii [P,N] ([1,N] with shared_list, see ops.render_subposes)) — gradients of exactly the tensors handed in (raw parameters with raw_params=True)."""
     S, R = max(1, int(blur_samples)), max(1, int(rs_bands))
     pixvel = motion_model == "pixel_velocity"
     if not pixvel and motion_model != "se3":
@@ -64,13 +64,13 @@ def render_step(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor,
         sub_ctx = _Ctx((camera_grads, camera_grads, camera_grads, False))
         vms = ops._SubposeViewmats.forward(sub_ctx, viewmat, lin_vel, ang_vel, times)
     needs = [True, True, True, True, True, camera_grads, background is not None and background_grad] + [False] * 16 + \
-            [camera_grads and pixvel, camera_grads and pixvel, False, False, False, sh_rest is not None, False]
+            [camera_grads and pixvel, camera_grads and pixvel, False, False, False, sh_rest is not None, False, False]
     ctx = _Ctx(needs)
     rgb, _alpha, radii, _depth = ops._RenderSubposes.forward(
         ctx, means, scales, quats, opacities, sh, vms, background, S, R, fx, fy, cx, cy, img_height, img_width,
         sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out, False, float(gamma), float(min_rgb_level),
         lin_vel if pixvel else None, ang_vel if pixvel else None, times if pixvel else None, False,
-        float(rolling_shutter_time), sh_rest, 3 if raw_params else 0)
+        float(rolling_shutter_time), sh_rest, 3 if raw_params else 0, bool(shared_list))
     v_rgb = grad_image(rgb) if callable(grad_image) else grad_image
     g = ops._RenderSubposes.backward(ctx, v_rgb, None, None, None)
     grads = {"means": g[0], "scales": g[1], "quats": g[2], "opacities": g[3], "sh": g[4], "background": g[6],

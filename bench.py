@@ -40,7 +40,9 @@ def make_scene(n, W, H, seed=1234, profile="survey"):
 class Workload:
     """One camera view per rank of a replicated scene: parameters, view, fixed dL/d(image), and the step."""
 
-    def __init__(self, gs, dev, rank, world, N, W, H, S, R, profile, allreduce, force_exchange=False, autograd=False):
+    def __init__(self, gs, dev, rank, world, N, W, H, S, R, profile, allreduce, force_exchange=False, autograd=False,
+                 motion="se3"):
+        self.motion = motion
         self.gs, self.world, self.allreduce, self.force_exchange = gs, world, allreduce, force_exchange
         self.autograd = autograd
         self.S, self.R, self.H, self.W = S, R, H, W
@@ -74,7 +76,9 @@ class Workload:
             out, g, _ = gs.render_step(params["means"], params["log_scales"], params["quats"], params["opacity_logits"],
                                        params["sh"], self.viewmat, self.lin, self.ang, self.times_t, self.bg, self.S,
                                        self.R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], self.H, self.W, self.wt, gamma=2.2,
-                                       min_rgb_level=10.0, sh_degree=3, antialiased=True, raw_params=True)
+                                       min_rgb_level=10.0, sh_degree=3, antialiased=True, raw_params=True,
+                                       motion_model="se3" if self.motion == "se3" else "pixel_velocity",
+                                       shared_list=self.motion == "pixel_velocity_shared")
             for k, name in (("means", "means"), ("log_scales", "scales"), ("quats", "quats"),
                             ("opacity_logits", "opacities"), ("sh", "sh")):
                 params[k].grad = g[name]
@@ -282,6 +286,9 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the DP gradient exchange over RCCL even at --gpus 1 (single-rank collectives: measures the "
                          "pack -> collective -> scatter chain's device cost as exchange_ms; the timed step includes it)")
+    ap.add_argument("--motion", default="se3", choices=["se3", "pixel_velocity", "pixel_velocity_shared"],
+                    help="how the sub-poses move the splats (BASELINE metric: se3 — every sub-pose re-projects); "
+                         "pixel_velocity: one projection, S lists; pixel_velocity_shared: one projection, ONE list")
     ap.add_argument("--scene", default="survey", choices=["survey", "trained"],
                     help="scene profile of the timed workload (BASELINE metric: survey)")
     args = ap.parse_args()
@@ -311,7 +318,8 @@ def main():
     from gsdeblur_amd import ops
 
     N, W, H, S, R = args.gaussians, args.width, args.height, args.subposes, args.rs_bands
-    wl = Workload(gs, dev, rank, world, N, W, H, S, R, args.scene, args.allreduce, args.force_exchange, args.autograd)
+    wl = Workload(gs, dev, rank, world, N, W, H, S, R, args.scene, args.allreduce, args.force_exchange, args.autograd,
+                  args.motion)
     sc, params, step = wl.sc, wl.params, wl.step
 
     for _ in range(args.warmup):
@@ -351,7 +359,7 @@ def main():
     if not args.no_secondary and args.scene == "survey":
         del wl, params, step
         torch.cuda.empty_cache()
-        w2 = Workload(gs, dev, rank, world, N, W, H, S, R, "trained", args.allreduce, False, args.autograd)
+        w2 = Workload(gs, dev, rank, world, N, W, H, S, R, "trained", args.allreduce, False, args.autograd, args.motion)
         for _ in range(2):
             w2.step()
         if world > 1:
@@ -537,6 +545,7 @@ def main():
                                    f"S={S} motion-blur sub-poses x R={R} row bands, SH degree 3, gamma 2.2, "
                                    f"fwd+bwd to all Gaussian params + viewmat + velocities",
                        "gaussians": N, "width": W, "height": H, "subposes": S, "rs_bands": R,
+                       "motion_model": args.motion,
                        "tile_intersections_per_step": n_isect,
                        "tile_intersections_emitted": int(sum(slice_isects)) if ops.SLICE_BASE > 0 else n_isect,
                        "depth_slices": slice_isects if ops.SLICE_BASE > 0 else None,

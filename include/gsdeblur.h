@@ -368,13 +368,21 @@ int gs_rasterize_fwd_rs_slice(const float* records, const int* tile_bins, const 
                               int S, int img_height, int img_width, float* out_img, float* out_T, float* live_T,
                               int* final_idx, unsigned char* tile_done, int first, int last, const int* sorted_ids,
                               int n_records, float* out_depth, int* open_flag, const float* pix_vel, int N,
-                              float rolling_shutter_time, void* stream);
+                              float rolling_shutter_time,
+                              const float* shared_list_times /*NULL, or [S] (device): ONE record set / tile list (that of
+                                 sub-pose 0: records [N], tile_bins [T]) for all S samples; sample s evaluates every splat
+                                 at xy + (shared_list_times[s] + tau(y)) * pix_vel[g].  tile_done stays [S*T]*/,
+                              void* stream);
 int gs_rasterize_bwd_rs_slice(const float* records, const int* sorted_vals, const int* tile_bins, const int* band_edges,
                               const float* background, int S, int img_height, int img_width, const float* out_T,
                               const int* final_idx, const float* v_img, const float* v_alpha, float* bwd_T, float* bwd_B,
                               float* tuples, unsigned char* flags, const int* sorted_ids, int n_records, int variant,
                               const float* cmb_scale, float cmb_gamma, float cmb_min_level, const float* pix_vel, int N,
-                              float rolling_shutter_time, void* stream);
+                              float rolling_shutter_time,
+                              const float* shared_list_times /*as in the forward; then tuples [I*S*12] / flags [I*S]: the
+                                 gradients of entry e from sample s land in tuple e*S + s (gs_reduce_grad_tuples with
+                                 tuples_per_entry = S)*/,
+                              void* stream);
 /* one launch per slice, back to front; bwd_T (init = out_T) and bwd_B [S,H,W] (behind-colour . v_out, init = 0)
  * carry the reverse-traversal state; both may be NULL on the tuple path when the frame has a single slice */
 int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const int* tile_bins,
@@ -402,6 +410,8 @@ int gs_reduce_grad_tuples(int n_slice, const unsigned* slice_gi, const unsigned*
                           long long n_isect /*entries of the slice: picks the kernel form*/,
                           const float* records /*[P*N,16]: flags[e] == 2 (tuples of the scalar-cache kernel) marks slot 5
                                                  as the plain sum of v_sigma; the reduce divides it by -opacity*/,
+                          int tuples_per_entry /*1; S for gs_rasterize_bwd_rs_slice with one list for S samples: entry e's
+                                                 tuples are e*S .. e*S+S-1*/,
                           void* stream);
 
 /* ---- sub-frame averaging in linearised colour (flags train.py:60,62) ---------
@@ -457,6 +467,11 @@ typedef struct gs_frame_desc {
   int poll_readback;         /* 1: the plan and the open-tile count reach the host through a one-block kernel that
                                 writes into host_pinned and a sequence word the host polls (no stream synchronisation
                                 per read-back); 0: hipMemcpyAsync + hipStreamSynchronize */
+  int shared_list;           /* 1 (pixel-velocity model, P == 1, R == 1, pix_vel and sample_times given): ONE record set
+                                (the mid-exposure splats, tile boxes swept over exposure + readout), ONE depth sort and ONE
+                                tile list for all S blur samples — the paper's form (depth order and covariance fixed
+                                across samples; SURVEY.md App. A, /root/reference/README.md:196-200); sample s evaluates
+                                every splat at mu' + (sample_times[s] + tau(y)) * pixel velocity inside the compositor */
 } gs_frame_desc;
 typedef struct gs_frame_slice {
   long long I;               /* capacity of the slice's lists (its ranks' bounding-box pairs); real count on the device */
@@ -466,6 +481,7 @@ typedef struct gs_frame_slice {
 typedef struct gs_frame_state {
   int n_slices, P, N, S, R, H, W;
   float rolling_shutter_time;/* copied from the descriptor (0: not an exact-rolling-shutter frame) */
+  int shared_list;           /* copied from the descriptor */
   long long n_total;         /* bounding-box tile intersections of the frame */
   long long arena_used;      /* bytes of the arena the forward occupies (kept alive until the backward ran) */
   long long arena_required;  /* on GS_ERR_WORKSPACE (3): an arena size that holds the frame as far as it is known */
@@ -482,6 +498,7 @@ int gs_frame_forward(const gs_frame_desc* desc, float* records, unsigned* depth_
                      gs_project_fused_fwd*/, int color_K_stride, int color_sh_degree,
                      const float* color_viewmats /*P*16*/,
                      const float* pix_vel /*NULL, or [N*2] from gs_project_pixvel_fwd(rolling_shutter_time != 0)*/,
+                     const float* sample_times /*[S] device, desc->shared_list only (NULL otherwise)*/,
                      float* out_img /*S*H*W*3*/, float* out_T /*S*H*W*/, float* out_depth, void* arena, long long arena_bytes, void* host_pinned,
                      long long host_pinned_bytes, gs_frame_state* state, void* stream);
 long long gs_frame_backward_bytes(const gs_frame_state* state);
@@ -490,7 +507,8 @@ long long gs_frame_backward_bytes(const gs_frame_state* state);
 int gs_frame_backward(const gs_frame_state* state, const float* records, const float* background, const int* band_edges,
                       const float* out_T, const float* v_img, const float* v_alpha, const float* cmb_scale,
                       float cmb_gamma, float cmb_min_level, int bwd_variant, float* v_records, unsigned char* touched,
-                      const float* pix_vel /*as in the forward*/, void* arena, long long arena_bytes, void* stream);
+                      const float* pix_vel /*as in the forward*/, const float* sample_times /*as in the forward*/,
+                      void* arena, long long arena_bytes, void* stream);
 /* measurement only (not thread-safe): HIP events around the stages of the two calls above.  stage_mask bit i enables
  * stage i of {depth_sort, count_scan, slice_plan, slice_count, emit, tile_sort, bin_edges, raster_fwd, slice_sat,
  * raster_bwd, grad_reduce}; gs_frame_profile_read drains the pairs recorded since the last call (synchronising on

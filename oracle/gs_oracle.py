@@ -527,6 +527,11 @@ class RenderConfig:
     # (y/H - 1/2) * T_ro) instead of rs_bands tile-row bands: pixel row y sees every splat at
     # xy + (t_s + ((y + 0.5)/H - 0.5) * T_ro) * pixel_velocity; rs_bands is ignored
     rs_exact: bool = False
+    # pixel-velocity model, rs_bands ignored: the form the paper describes (/root/reference/README.md:196-200, SURVEY
+    # App. A) — ONE binning for all blur samples: tile boxes of the splats swept over the sampled time span (+ readout),
+    # one sorted list per tile, every sample walks it and evaluates a splat at xy_c + (t_s - t_c + tau(y)) * velocity.
+    # The per-sample lists (shared_list False) cut each splat at its own 3-sigma box; this form cuts it at the swept box.
+    shared_list: bool = False
 
 
 def combine_samples(samples: torch.Tensor, gamma: float, min_rgb_level: float) -> torch.Tensor:
@@ -659,6 +664,26 @@ def _render_pixel_velocity(cfg: RenderConfig, means, scales, quats, opacities, s
                         compensation=pr0.compensation, num_tiles_hit=torch.where(inband, pr0.num_tiles_hit, zi),
                         cov3d=pr0.cov3d, tile_min=pr0.tile_min * inband[:, None].to(torch.int32),
                         tile_max=pr0.tile_max * inband[:, None].to(torch.int32))
+    if cfg.shared_list:
+        # float32 op order of csrc: the library projects at t_c with the box swept by (t_max - t_min) + |T_ro|
+        # (ops.py::_RenderSubposes, gs_project_pixvel_fwd) and the compositors add (t_s - t_c) + tau(y) per row
+        f32t = [float(np.float32(t)) for t in times]
+        t_c = 0.5 * (min(f32t) + max(f32t))
+        span = (max(f32t) - min(f32t)) + abs(cfg.rolling_shutter_time)
+        xys_c = (pr0.xys + (torch.ones((), dtype=dt) * float(np.float32(t_c))) * pv) * geom
+        pr = _bounds_swept(pr0, xys_c, pv * geom, 0.5 * float(np.float32(span)), H, W)
+        keys, gids = map_gaussian_to_intersects(pr, W)
+        keys, gids = sort_intersects(keys, gids)
+        bins = get_tile_bin_edges(keys, tiles)
+        row_tau = tau_rows if exact else torch.zeros(H, dtype=dt)
+        for p, tau in enumerate(f32t):
+            r = rasterize_sorted(pr.xys, pr.conics, rgb, op, gids, bins, H, W, background,
+                                 row_shift=(pv * geom, row_tau + float(np.float32(tau - t_c))))
+            sample_imgs[p] = sample_imgs[p] + r.img
+            sample_alpha[p] = sample_alpha[p] + r.alpha
+            frag |= r.fragile
+            parts.append((pr, keys, gids, bins, r, rgb, op))
+        times = []
     for p, tau in enumerate(times):
         xys = (pr0.xys + (torch.ones((), dtype=dt) * tau) * pv) * geom
         if exact:

@@ -432,7 +432,7 @@ def sliced_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P
                                                    _ptr(out_T), _ptr(live_T), _ptr(fidx), _ptr(tile_done), int(first),
                                                    int(last), _ptr(sorted_ids), P * N, _ptr(out_depth),
                                                    ctypes.c_void_p(open_flags.data_ptr() + 4 * k) if not last else None,
-                                                   _ptr(rs[0]), N, float(rs[1]), _stream()), "rasterize_fwd_rs_slice")
+                                                   _ptr(rs[0]), N, float(rs[1]), None, _stream()), "rasterize_fwd_rs_slice")
         elif ops.LANE_STATS and out_depth is None:
             if ops.lane_stats is None or ops.lane_stats.device != dev:
                 ops.lane_stats = torch.zeros(13, dtype=torch.int64, device=dev)
@@ -534,7 +534,7 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
                                                    _ptr(bwd_T), _ptr(bwd_B), _ptr(tuples), _ptr(flags),
                                                    _ptr(sl["sorted_ids"]), records.shape[0], _bwd_variant() & 256,
                                                    _ptr(cmb[0]), cmb[1], cmb[2], _ptr(rs[0]), rs[0].shape[0], float(rs[1]),
-                                                   _stream()), "rasterize_bwd_rs_slice")
+                                                   None, _stream()), "rasterize_bwd_rs_slice")
         else:
             with _stage("raster_bwd"):
                 Lc = L if ops.RASTER_BWD_VARIANT == 0 else _L_round1()
@@ -552,7 +552,7 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
                 # it sent every slice of a small-splat scene (7 entries per Gaussian) through 64-lane waves
                 _check(L.gs_reduce_grad_tuples(sl["n"], _ptr(sl["slice_gi"]), _ptr(sl["counts"]), _ptr(sl["cum"]),
                                                _ptr(tuples), _ptr(flags), _ptr(v_records), _ptr(touched),
-                                               sl["I"] if sl.get("wave_per_g", True) else 0, _ptr(records), _stream()),
+                                               sl["I"] if sl.get("wave_per_g", True) else 0, _ptr(records), 1, _stream()),
                        "reduce_grad_tuples")
 
 

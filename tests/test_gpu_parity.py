@@ -2189,6 +2189,84 @@ def test_exact_rolling_shutter_pixel_velocity_vs_oracle(gs, oracle, dev, S, W, H
         assert v <= 1.0, (k, v)
 
 
+@pytest.mark.parametrize("S,W,H,n,rt,base", [(3, 144, 128, 2500, 1 / 30, None), (5, 128, 160, 3000, 0.0, None),
+                                             (2, 96, 128, 6000, 1 / 30, 8)])
+def test_shared_list_pixel_velocity_vs_oracle(gs, oracle, dev, S, W, H, n, rt, base):
+    """VERDICT round 3 'What's missing 4': ONE binning for the S blur samples of a pixel-velocity frame
+    (render_subposes(shared_list=True): one projection at the centre of the sampled span, tile boxes swept over
+    span + readout, one depth sort, one tile list; csrc/raster_rs.hip walks it once per sample with
+    xy + (t_s - t_c + tau(y)) * velocity; the backward writes one gradient tuple per (entry, sample)).  Against the
+    oracle's shared_list mode: the swept box / radii / intersection count (integers, exact), the sample images, the
+    combined image and every gradient; with and without the rolling shutter; last case: several depth slices.  And
+    against the per-sample lists: the same picture up to the beyond-3-sigma fringe."""
+    from gsdeblur_amd import ops
+    O = oracle
+    sc = O.synthetic_scene(n, W, H, seed=950 + S, scale_mult=6.0)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 30, sc["ang_vel"] * 15
+    et, gamma, mlevel = 1 / 60, 2.2, 10.0
+    bg = torch.tensor([0.05, 0.1, 0.15])
+    names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel", "viewmat"]
+    cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], blur_samples=S, rs_bands=1, exposure_time=et,
+                         rolling_shutter_time=rt, gamma=gamma, min_rgb_level=mlevel, motion_model="pixel_velocity",
+                         rs_exact=rt != 0.0, shared_list=True)
+    q = {k: sc[k].double().requires_grad_(True) for k in names}
+    ref, _, ref_samples, frag, parts, _ = O.render(cfg, q["means"], q["log_scales"].exp(), q["quats"],
+                                                   torch.sigmoid(q["opacity_logits"]), q["sh"], q["viewmat"],
+                                                   q["lin_vel"], q["ang_vel"], background=bg.double(), return_parts=True)
+    good = ~frag
+    check_fragile(frag, f"shared-list S={S} {W}x{H} n={n} rt={rt:.4f} base={base}")
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)) * good[..., None]
+    (ref * wt.double()).sum().backward()
+    p = {k: sc[k].float().to(dev).requires_grad_(True) for k in names}
+    times, _, _ = gs.subpose_schedule(S, et, 1, 0.0)
+    times_t = torch.tensor(times, device=dev)
+    saved = ops.SLICE_BASE
+
+    def run(shared):
+        return gs.render_subposes(p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["opacity_logits"]),
+                                  p["sh"], p["viewmat"], bg.to(dev), S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W,
+                                  sh_degree=3, lin_vel=p["lin_vel"], ang_vel=p["ang_vel"], times=times_t,
+                                  rolling_shutter_time=rt, shared_list=shared)
+    try:
+        if base is not None:
+            ops.SLICE_BASE = base
+        samples, alphas, radii = run(True)
+        out = gs.combine_samples(samples, gamma, mlevel)
+        (out * wt.to(dev)).sum().backward()
+        n_slices = sum(1 for v in ops.last_slice_intersects if int(v) > 0)
+        n_isect = ops.last_num_intersects
+    finally:
+        ops.SLICE_BASE = saved
+    if base is not None:
+        assert n_slices >= 3, n_slices
+    # integers: ONE swept box per Gaussian — the oracle's list is the list the library walked
+    pr = parts[0][0]
+    assert radii.shape == (1, n)
+    assert np.array_equal(radii[0].cpu().numpy(), pr.radii.numpy())
+    assert n_isect == int(pr.num_tiles_hit.sum())
+    assert (samples.detach().cpu().double() - ref_samples)[:, good].abs().max().item() < IMG_ATOL
+    assert (out.detach().cpu().double() - ref.detach())[good].abs().max().item() < 5e-4
+    worst = {}
+    for k in names:
+        g_hip, g_ref = p[k].grad.cpu().numpy(), q[k].grad.numpy()
+        if k == "viewmat":
+            g_hip, g_ref = g_hip[:3], g_ref[:3]
+        worst[k] = grad_el_ratio(g_hip, g_ref)
+    print(f"shared list S={S} rt={rt:.4f}: per-element gradient error / tolerance:",
+          {k: round(v, 3) for k, v in worst.items()}, "slices", n_slices, "intersections", n_isect)
+    for k, v in worst.items():
+        assert v <= 1.0, (k, v)
+    # per-sample lists: S binnings of per-sample boxes; same picture up to the fringe the swept box keeps
+    with torch.no_grad():
+        per_sample, _, radii_ps = run(False)
+        per_isect = ops.last_num_intersects
+    d = (per_sample - samples.detach()).abs()
+    print(f"shared list vs per-sample lists: max {d.max().item():.4f} mean {d.mean().item():.2e}; "
+          f"intersections {n_isect} vs {per_isect}")
+    assert radii_ps.shape == (S, n) and n_isect < per_isect
+    assert d.mean().item() < 2e-3 and d.max().item() < 0.08
+
+
 def test_model_exact_rolling_shutter_mode(gs, oracle, dev):
     """SplatfactoDeblurConfig(rolling_shutter_mode='exact', motion_model='pixel_velocity'): get_outputs renders with
     the continuous row time (one sub-pose per blur sample: radii is [S, N] whatever rs_bands says) and converges to

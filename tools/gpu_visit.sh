@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit, parametrised (replaces the round-3 one-off recipes).  Usage, from the repo root on the GPU box:
 #   bash tools/gpu_visit.sh <tag> [steps...]      steps: suite | tests:<pytest -k expr> | smoke | bench | benchq | ab:<ENV=V,...>
-#                                                        | prof | pmc | prof_trained | final
+#                                                        | prof | pmc | prof_trained | motions
 # Everything lands in gpurun_out/<tag>/; a summary is printed at the end.
 set -u
 TAG=${1:-visit}; shift || true
@@ -47,6 +47,12 @@ for step in "$@"; do
       for v in 1 2; do
         timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline $ABB_ARGS > $OUT/abb_base$v.log 2>&1; benchline base$v $OUT/abb_base$v.log | tee -a $S
         GSD_LIB_PATH=$alt timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline $ABB_ARGS > $OUT/abb_alt$v.log 2>&1; benchline "alt$v($defs)" $OUT/abb_alt$v.log | tee -a $S
+      done ;;
+    motions)
+      # the three motion models on the headline scene and on the fitted-model-like one
+      for m in se3 pixel_velocity pixel_velocity_shared; do
+        timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --motion $m > $OUT/motion_$m.log 2>&1; benchline $m $OUT/motion_$m.log | tee -a $S
+        grep -E "Error|error" $OUT/motion_$m.log | tail -3 | tee -a $S
       done ;;
     abflag:*)
       # A/B of a bench.py command-line flag (e.g. abflag:--autograd), interleaved
