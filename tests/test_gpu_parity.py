@@ -59,6 +59,9 @@ FRAGILE_OBSERVED = {   # round 4, gpurun visit r4_v2 (profiles/r04_v2_suite_prin
     'baseline config3: 10 rolling-shutter bands': 0.00734,
     'baseline config4: 5 samples x 2 bands': 0.03313,
     'baseline config5: 10 motion-blur sub-poses': 0.07017,
+    'shared-list S=3 144x128 n=2500 rt=0.0333 base=None': 0.02317,
+    'shared-list S=5 128x160 n=3000 rt=0.0000 base=None': 0.03438,
+    'shared-list S=2 96x128 n=6000 rt=0.0333 base=8': 0.01595,
     'exact-rs S=1 144x128 n=2500 base=None': 0.00700,
     'exact-rs S=2 96x128 n=6000 base=8': 0.01554,
     'exact-rs S=3 128x160 n=3000 base=None': 0.02183,
@@ -1876,7 +1879,7 @@ def test_native_frame_grows_its_arena_and_reports_stage_times(gs, dev):
         return gs.render_combined(sc["means"], sc["log_scales"].exp(), sc["quats"], torch.sigmoid(sc["opacity_logits"]),
                                   sc["sh"], vms, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2)[0]
     ref = render()
-    key = (str(dev), n, S, S, H, W)
+    key = (str(dev), n, S, S, H, W, False)
     assert key in ops._arena_hint
     ops._arena_hint[key] = 1 << 20                      # far too small: forces the retry path
     got = render()
@@ -1904,7 +1907,7 @@ def test_native_frame_arena_converges_over_many_ever_larger_slices(gs, dev):
     times, _, _ = gs.subpose_schedule(S, 1 / 60, 1, 0.0)
     vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"], sc["ang_vel"], torch.tensor(times, device=dev))
     saved = (ops.NATIVE_FRAME, ops.SLICE_BASE)
-    key = (str(dev), n, S, S, H, W)
+    key = (str(dev), n, S, S, H, W, False)
 
     def render():
         return gs.render_combined(sc["means"], sc["log_scales"].exp(), sc["quats"], torch.sigmoid(sc["opacity_logits"]),
