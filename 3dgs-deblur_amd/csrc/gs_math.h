@@ -312,32 +312,42 @@ GS_HD void project_one_bwd(const float mean[3], const float c3[6], const float* 
 
 // ---- pixel velocity (the paper's first-order blur / rolling-shutter model) ------------------
 // A static point seen from a camera moving with body twist (lin, ang) (camera frame) moves in camera space with
-// velocity u = -(ang x pc + lin); its pixel moves with  pv = J u,  J = d(pixel)/d(pc) of the (unclamped) pinhole
-// projection.  The splat rendered at time tau sits at xy + tau * pv; covariance, opacity, colour and depth order are
-// those of the mid-exposure pose.
-GS_HD void pixel_velocity(const float pc[3], float rz, float fx, float fy, const float lin[3], const float ang[3],
-                          float pv[2]) {
+// velocity u = -(ang x pc + lin); its pixel moves with  pv = J u,  J = d(pixel)/d(pc) of the pinhole projection,
+// evaluated where the covariance projection evaluates its own Jacobian: at (jx, jy, z) = the camera-space centre with
+// x/z and y/z clamped to the fov guard band (project_one's tx, ty; inside the band jx = pc[0], jy = pc[1] exactly).
+// x/z is unbounded at grazing angles: with the unclamped J a large near splat whose centre lies beside the image would
+// be dragged across it at thousands of pixels per frame; round 3 culled such Gaussians altogether (and a floor whose
+// centre is out of band vanished) — now they move with the velocity of the band edge, bounded by 1/z > 1/clip.
+// The splat rendered at time tau sits at xy + tau * pv; covariance, opacity, colour and depth order are those of the
+// mid-exposure pose.
+GS_HD void pixel_velocity(const float pc[3], float jx, float jy, float rz, float fx, float fy, const float lin[3],
+                          const float ang[3], float pv[2]) {
   const float ux = -(ang[1] * pc[2] - ang[2] * pc[1]) - lin[0];
   const float uy = -(ang[2] * pc[0] - ang[0] * pc[2]) - lin[1];
   const float uz = -(ang[0] * pc[1] - ang[1] * pc[0]) - lin[2];
   const float rz2 = rz * rz;
-  pv[0] = (fx * rz) * ux - ((fx * pc[0]) * rz2) * uz;
-  pv[1] = (fy * rz) * uy - ((fy * pc[1]) * rz2) * uz;
+  pv[0] = (fx * rz) * ux - ((fx * jx) * rz2) * uz;
+  pv[1] = (fy * rz) * uy - ((fy * jy) * rz2) * uz;
 }
 
-// VJP of pixel_velocity: v_pv[2] -> v_pc[3] (=), v_lin[3] (=), v_ang[3] (=)
-GS_HD void pixel_velocity_bwd(const float pc[3], float rz, float fx, float fy, const float lin[3], const float ang[3],
+// VJP of pixel_velocity: v_pv[2] -> v_pc[3] (=), v_lin[3] (=), v_ang[3] (=).  clamp_x / clamp_y: which side of the guard
+// band jx / jy sit on (0: inside, jx = pc[0]); a clamped jx = +-lim * z passes its gradient to z (or, with
+// upstream_clamp_grad, to x as if the clamp were inactive — the rule of project_one_bwd).
+GS_HD void pixel_velocity_bwd(const float pc[3], float jx, float jy, int clamp_x, int clamp_y, bool upstream_clamp_grad,
+                              float rz, float fx, float fy, const float lin[3], const float ang[3],
                               const float v_pv[2], float v_pc[3], float v_lin[3], float v_ang[3]) {
   const float ux = -(ang[1] * pc[2] - ang[2] * pc[1]) - lin[0];
   const float uy = -(ang[2] * pc[0] - ang[0] * pc[2]) - lin[1];
   const float uz = -(ang[0] * pc[1] - ang[1] * pc[0]) - lin[2];
   const float rz2 = rz * rz, rz3 = rz2 * rz;
   const float gx = v_pv[0], gy = v_pv[1];
-  const float vu[3] = {fx * rz * gx, fy * rz * gy, -(fx * pc[0] * rz2 * gx + fy * pc[1] * rz2 * gy)};
-  // through J(pc)
-  v_pc[0] = -(fx * rz2 * uz) * gx;
-  v_pc[1] = -(fy * rz2 * uz) * gy;
-  v_pc[2] = gx * (-fx * rz2 * ux + 2.f * fx * pc[0] * rz3 * uz) + gy * (-fy * rz2 * uy + 2.f * fy * pc[1] * rz3 * uz);
+  const float vu[3] = {fx * rz * gx, fy * rz * gy, -(fx * jx * rz2 * gx + fy * jy * rz2 * gy)};
+  // through J(jx, jy, z)
+  const float v_jx = -(fx * rz2 * uz) * gx, v_jy = -(fy * rz2 * uz) * gy;
+  v_pc[0] = 0.f; v_pc[1] = 0.f;
+  v_pc[2] = gx * (-fx * rz2 * ux + 2.f * fx * jx * rz3 * uz) + gy * (-fy * rz2 * uy + 2.f * fy * jy * rz3 * uz);
+  if (clamp_x == 0 || upstream_clamp_grad) v_pc[0] += v_jx; else v_pc[2] += v_jx * (jx * rz);    // jx = (+-lim) * z
+  if (clamp_y == 0 || upstream_clamp_grad) v_pc[1] += v_jy; else v_pc[2] += v_jy * (jy * rz);
   // through u = -ang x pc - lin :  v_pc += ang x v_u ;  v_ang = v_u x pc ;  v_lin = -v_u
   v_pc[0] += ang[1] * vu[2] - ang[2] * vu[1];
   v_pc[1] += ang[2] * vu[0] - ang[0] * vu[2];

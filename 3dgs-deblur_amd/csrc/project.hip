@@ -330,13 +330,13 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
     for (int j = 0; j < 12; ++j) Vm0[j] = fp.viewmats[j];
     project_one(m, c3, Vm0, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x, fp.in.tiles_y,
                 fp.in.clip, o0, k0);
-    // A Gaussian outside the projection's fov guard band (|x/z| or |y/z| beyond 1.3 tan(fov/2) at the mid-exposure pose)
-    // is culled for the whole frame: x/z is unbounded at grazing angles, and the first-order pixel motion of such a
-    // point (thousands of pixels per frame) would drag a splat that never comes near the image straight across it.
-    if (k0.clamp_x != 0 || k0.clamp_y != 0) k0.geom_ok = 0;
+    // A centre outside the projection's fov guard band (|x/z| or |y/z| beyond 1.3 tan(fov/2) at the mid-exposure pose)
+    // moves with the Jacobian of the band edge (gs_math.h pixel_velocity): a sub-pose whose re-centred box misses the
+    // image drops it below, a large near splat that still covers the image stays.
     if (k0.geom_ok) {
       const float lin[3] = {fp.twist[0], fp.twist[1], fp.twist[2]}, ang[3] = {fp.twist[3], fp.twist[4], fp.twist[5]};
-      pixel_velocity(k0.pc, k0.rz, fp.in.fx, fp.in.fy, lin, ang, pv);
+      pixel_velocity(k0.pc, k0.clamp_x ? k0.tx : k0.pc[0], k0.clamp_y ? k0.ty : k0.pc[1], k0.rz, fp.in.fx, fp.in.fy,
+                     lin, ang, pv);
     }
     if (fp.pix_vel_out) { fp.pix_vel_out[2 * i] = pv[0]; fp.pix_vel_out[2 * i + 1] = pv[1]; }
   }
@@ -499,7 +499,8 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
         }
         const float lin[3] = {fp.twist[0], fp.twist[1], fp.twist[2]}, ang[3] = {fp.twist[3], fp.twist[4], fp.twist[5]};
         float vpc[3], vlin[3], vang[3];
-        pixel_velocity_bwd(k.pc, k.rz, fp.in.fx, fp.in.fy, lin, ang, vpv, vpc, vlin, vang);
+        pixel_velocity_bwd(k.pc, k.clamp_x ? k.tx : k.pc[0], k.clamp_y ? k.ty : k.pc[1], k.clamp_x, k.clamp_y, up_clamp,
+                           k.rz, fp.in.fx, fp.in.fy, lin, ang, vpv, vpc, vlin, vang);
         vtw[0] = vlin[0]; vtw[1] = vlin[1]; vtw[2] = vlin[2]; vtw[3] = vang[0]; vtw[4] = vang[1]; vtw[5] = vang[2];
         project_one_bwd(m, c3, Vm, fp.in.fx, fp.in.fy, k, o.comp, vxy, 0.f, vcon, v_comp, vm, vc3, vV, vpc, up_clamp);
       }
@@ -673,7 +674,9 @@ __device__ __forceinline__ void needle_item_pixvel(const FusedParams& fp, const 
   }
   const float lin[3] = {fp.twist[0], fp.twist[1], fp.twist[2]}, ang[3] = {fp.twist[3], fp.twist[4], fp.twist[5]};
   float vpc[3], vlin[3], vang[3];
-  pixel_velocity_bwd(k.pc, k.rz, fp.in.fx, fp.in.fy, lin, ang, vpv, vpc, vlin, vang);
+  pixel_velocity_bwd(k.pc, k.clamp_x ? k.tx : k.pc[0], k.clamp_y ? k.ty : k.pc[1], k.clamp_x, k.clamp_y,
+                     (fp.flags & GS_FLAG_UPSTREAM_FOV_CLAMP_GRAD) != 0, k.rz, fp.in.fx, fp.in.fy, lin, ang, vpv, vpc,
+                     vlin, vang);
   const double vpcd[3] = {vpc[0], vpc[1], vpc[2]};
   double vV[12];
   project_one_bwd_t<double>(m, c3d, Vm, fp.in.fx, fp.in.fy, kd, comp, vxy, 0.0, vcon, v_comp, out, out + 3, vV, vpcd,

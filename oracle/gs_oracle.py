@@ -545,10 +545,12 @@ def combine_samples(samples: torch.Tensor, gamma: float, min_rgb_level: float) -
     return x.pow(gamma).mean(dim=0).pow(1.0 / gamma)
 
 
-def pixel_velocity(means3d, viewmat, fx, fy, lin_vel, ang_vel, clip_thresh=0.01):
+def pixel_velocity(means3d, viewmat, fx, fy, lin_vel, ang_vel, clip_thresh=0.01, img_width=None, img_height=None):
     """[N,2] pixel velocity of every Gaussian centre under the camera's body twist (lin, ang in the OpenCV camera
-    frame): a static point moves in camera space with u = -(ang x p_c + lin), its pixel with J u (J = pinhole
-    Jacobian at p_c, no fov clamp).  Op order mirrors gs_math.h::pixel_velocity."""
+    frame): a static point moves in camera space with u = -(ang x p_c + lin), its pixel with J u, J = the pinhole
+    Jacobian where the covariance projection takes its own: at the centre with x/z, y/z clamped to the fov guard band
+    (img_width / img_height given; gs_math.h::pixel_velocity, project_one's tx / ty — inside the band the centre
+    itself, bit for bit).  Op order mirrors gs_math.h::pixel_velocity."""
     dt = means3d.dtype
     V = viewmat.to(dt)
     mx, my, mz = means3d[:, 0], means3d[:, 1], means3d[:, 2]
@@ -564,7 +566,14 @@ def pixel_velocity(means3d, viewmat, fx, fy, lin_vel, ang_vel, clip_thresh=0.01)
     rz2 = rz * rz
     one = torch.ones((), dtype=dt)
     fx_t, fy_t = one * fx, one * fy
-    return torch.stack([(fx_t * rz) * ux - ((fx_t * px) * rz2) * uz, (fy_t * rz) * uy - ((fy_t * py) * rz2) * uz], dim=-1)
+    jx, jy = px, py
+    if img_width is not None:
+        lim_x = (one * FOV_LIMIT) * ((one * 0.5) * float(img_width) / fx_t)
+        lim_y = (one * FOV_LIMIT) * ((one * 0.5) * float(img_height) / fy_t)
+        xz, yz = px * rz, py * rz
+        jx = torch.where(xz.detach().abs() > lim_x, pz * torch.minimum(lim_x, torch.maximum(-lim_x, xz)), px)
+        jy = torch.where(yz.detach().abs() > lim_y, pz * torch.minimum(lim_y, torch.maximum(-lim_y, yz)), py)
+    return torch.stack([(fx_t * rz) * ux - ((fx_t * jx) * rz2) * uz, (fy_t * rz) * uy - ((fy_t * jy) * rz2) * uz], dim=-1)
 
 
 def _recentre(pr: Projected, xys, img_height: int, img_width: int) -> Projected:
@@ -635,7 +644,7 @@ def _render_pixel_velocity(cfg: RenderConfig, means, scales, quats, opacities, s
     tau_rows = ((torch.arange(H, dtype=dt) + 0.5) / H - 0.5) * cfg.rolling_shutter_time if exact else None
     pr0 = project_gaussians(means, scales, cfg.glob_scale, quats, V, cfg.fx, cfg.fy, cfg.cx, cfg.cy, H, W, TILE,
                             cfg.clip_thresh, keep_offscreen=True)
-    pv = pixel_velocity(means, V, cfg.fx, cfg.fy, lin_vel, ang_vel, cfg.clip_thresh)
+    pv = pixel_velocity(means, V, cfg.fx, cfg.fy, lin_vel, ang_vel, cfg.clip_thresh, W, H)
     Rwc, twc = V[:3, :3].detach(), V[:3, 3].detach()
     cam_pos = -(Rwc.T @ twc)
     rgb = torch.clamp(spherical_harmonics(cfg.sh_degree, means.detach() - cam_pos[None, :], sh_coeffs) + 0.5, min=0.0)
@@ -645,25 +654,7 @@ def _render_pixel_velocity(cfg: RenderConfig, means, scales, quats, opacities, s
     sample_alpha = [torch.zeros(H, W, dtype=dt) for _ in range(S)]
     parts = []
     frag = torch.zeros(H, W, dtype=torch.bool)
-    # outside the projection's fov guard band at the mid-exposure pose (|x/z| or |y/z| beyond FOV_LIMIT * tan(fov/2)):
-    # culled for the whole frame — x/z is unbounded at grazing angles and the first-order pixel motion of such a point
-    # is meaningless (project.hip: project_fused_fwd_kernel, k0.clamp_x / clamp_y)
-    one = torch.ones((), dtype=dt)
-    Vd = V.to(dt)
-    pcx = ((Vd[0, 0] * means[:, 0] + Vd[0, 1] * means[:, 1]) + Vd[0, 2] * means[:, 2]) + Vd[0, 3]
-    pcy = ((Vd[1, 0] * means[:, 0] + Vd[1, 1] * means[:, 1]) + Vd[1, 2] * means[:, 2]) + Vd[1, 3]
-    pcz = ((Vd[2, 0] * means[:, 0] + Vd[2, 1] * means[:, 1]) + Vd[2, 2] * means[:, 2]) + Vd[2, 3]
-    rz = 1.0 / torch.where(pcz > cfg.clip_thresh, pcz, torch.ones_like(pcz))
-    lim_x = (one * FOV_LIMIT) * ((one * 0.5) * float(W) / (one * cfg.fx))
-    lim_y = (one * FOV_LIMIT) * ((one * 0.5) * float(H) / (one * cfg.fy))
-    inband = ((pcx * rz).detach().abs() <= lim_x) & ((pcy * rz).detach().abs() <= lim_y)
-    geom = ((pr0.radii > 0) & inband).to(dt)[:, None]
-    if not bool(inband.all()):
-        zi = torch.zeros_like(pr0.radii)
-        pr0 = Projected(xys=pr0.xys, depths=pr0.depths, radii=torch.where(inband, pr0.radii, zi), conics=pr0.conics,
-                        compensation=pr0.compensation, num_tiles_hit=torch.where(inband, pr0.num_tiles_hit, zi),
-                        cov3d=pr0.cov3d, tile_min=pr0.tile_min * inband[:, None].to(torch.int32),
-                        tile_max=pr0.tile_max * inband[:, None].to(torch.int32))
+    geom = (pr0.radii > 0).to(dt)[:, None]
     if cfg.shared_list:
         # float32 op order of csrc: the library projects at t_c with the box swept by (t_max - t_min) + |T_ro|
         # (ops.py::_RenderSubposes, gs_project_pixvel_fwd) and the compositors add (t_s - t_c) + tau(y) per row

@@ -97,8 +97,21 @@ int hm_subpose_viewmats_bwd(int P, const float* V0, const float* lin, const floa
 }
 
 // ---- round 3: pixel velocity, swept tile boxes, the double-precision chain of the needle fix-up --------------------
+// the Jacobian's x, y of project_one: the centre inside the fov guard band, (+-lim) * z outside (img_w <= 0: no band)
+static void band_xy(const float pc[3], float fx, float fy, int img_w, int img_h, float j[2], int c[2]) {
+  j[0] = pc[0]; j[1] = pc[1]; c[0] = c[1] = 0;
+  if (img_w <= 0) return;
+  const float rz = 1.0f / pc[2];
+  const float lim_x = K::kFovLimit * (0.5f * (float)img_w / fx), lim_y = K::kFovLimit * (0.5f * (float)img_h / fy);
+  const float xz = pc[0] * rz, yz = pc[1] * rz;
+  c[0] = xz > lim_x ? 1 : (xz < -lim_x ? -1 : 0);
+  c[1] = yz > lim_y ? 1 : (yz < -lim_y ? -1 : 0);
+  if (c[0]) j[0] = pc[2] * fminf(lim_x, fmaxf(-lim_x, xz));
+  if (c[1]) j[1] = pc[2] * fminf(lim_y, fmaxf(-lim_y, yz));
+}
+
 int hm_pixel_velocity(int n, const float* means, const float* V, float fx, float fy, const float* lin,
-                      const float* ang, float clip, float* pv) {
+                      const float* ang, float clip, int img_w, int img_h, float* pv) {
   for (int i = 0; i < n; ++i) {
     const float* m = means + 3 * i;
     float pc[3];
@@ -107,14 +120,17 @@ int hm_pixel_velocity(int n, const float* means, const float* V, float fx, float
     pc[2] = ((V[8] * m[0] + V[9] * m[1]) + V[10] * m[2]) + V[11];
     pv[2 * i] = 0.f; pv[2 * i + 1] = 0.f;
     if (!(pc[2] > clip)) continue;
-    pixel_velocity(pc, 1.0f / pc[2], fx, fy, lin, ang, pv + 2 * i);
+    float j[2]; int c[2];
+    band_xy(pc, fx, fy, img_w, img_h, j, c);
+    pixel_velocity(pc, j[0], j[1], 1.0f / pc[2], fx, fy, lin, ang, pv + 2 * i);
   }
   return 0;
 }
 
 // v_pc [n,3] per point; v_lin / v_ang [3] summed over the points
 int hm_pixel_velocity_bwd(int n, const float* means, const float* V, float fx, float fy, const float* lin,
-                          const float* ang, float clip, const float* v_pv, float* v_pc, float* v_lin, float* v_ang) {
+                          const float* ang, float clip, int img_w, int img_h, const float* v_pv, float* v_pc,
+                          float* v_lin, float* v_ang) {
   for (int j = 0; j < 3; ++j) { v_lin[j] = 0.f; v_ang[j] = 0.f; }
   for (int i = 0; i < n; ++i) {
     const float* m = means + 3 * i;
@@ -125,7 +141,9 @@ int hm_pixel_velocity_bwd(int n, const float* means, const float* V, float fx, f
     for (int j = 0; j < 3; ++j) v_pc[3 * i + j] = 0.f;
     if (!(pc[2] > clip)) continue;
     float vl[3], va[3];
-    pixel_velocity_bwd(pc, 1.0f / pc[2], fx, fy, lin, ang, v_pv + 2 * i, v_pc + 3 * i, vl, va);
+    float j[2]; int c[2];
+    band_xy(pc, fx, fy, img_w, img_h, j, c);
+    pixel_velocity_bwd(pc, j[0], j[1], c[0], c[1], false, 1.0f / pc[2], fx, fy, lin, ang, v_pv + 2 * i, v_pc + 3 * i, vl, va);
     for (int j = 0; j < 3; ++j) { v_lin[j] += vl[j]; v_ang[j] += va[j]; }
   }
   return 0;

@@ -77,9 +77,9 @@ FRAGILE_OBSERVED = {   # round 4, gpurun visit r4_v2 (profiles/r04_v2_suite_prin
     'pixvel S=1 R=4 96x144 n=2000': 0.00239,
     'pixvel S=3 R=2 128x96 n=2500': 0.02181,
     'pixvel S=5 R=1 160x96 n=3000': 0.03294,
-    'posed pixel_velocity S=3 R=2': 0.02047,
-    'posed pixel_velocity S=5 R=1': 0.03501,
-    'posed se3 S=3 R=2': 0.02322,
+    'posed pixel_velocity S=3 R=2': 0.02141,
+    'posed pixel_velocity S=5 R=1': 0.03400,
+    'posed se3 S=3 R=2': 0.02250,
     'rasterize n=2000 48x40 mult=3.0': 0.00104,
     'rasterize n=3000 100x60 mult=12.0': 0.00350,
     'rasterize n=5000 256x256 mult=4.0': 0.00636,
@@ -668,7 +668,7 @@ def test_pixel_velocity_model_vs_oracle(gs, oracle, dev, S, R, W, H, n):
     # integers: the float32 oracle re-centres the same float32 projection
     pr0 = O.project_gaussians(sc["means"], sc["log_scales"].exp(), 1.0, sc["quats"], sc["viewmat"], sc["fx"], sc["fy"],
                               sc["cx"], sc["cy"], H, W, keep_offscreen=True)
-    pv = O.pixel_velocity(sc["means"], sc["viewmat"], sc["fx"], sc["fy"], sc["lin_vel"], sc["ang_vel"])
+    pv = O.pixel_velocity(sc["means"], sc["viewmat"], sc["fx"], sc["fy"], sc["lin_vel"], sc["ang_vel"], 0.01, W, H)
     geom = (pr0.radii > 0).float()[:, None]
     for pidx, tau in enumerate(times):
         prp = O._recentre(pr0, (pr0.xys + torch.tensor(tau, dtype=torch.float32) * pv) * geom, H, W)
@@ -692,9 +692,12 @@ def test_real_camera_pose_and_grazing_gaussians_vs_oracle(gs, oracle, dev, model
     a camera centre taken from the wrong column or a world-frame / camera-frame mix-up cannot show.  Here the survey
     scene is seen from a rotated and translated camera (world = R^T (camera - t), viewmat = [R | t]) and forty large
     opaque Gaussians sit just in front of the camera plane at grazing angles (z = 0.02..0.05, x/z up to 100): never
-    on screen in a true sub-pose; the pixel-velocity model culls them by the projection's fov guard band (they used to
-    be dragged across the image by a first-order pixel velocity of 1e5 px/s: 11 dB against the SE(3) frame, found with
-    tools/rs_forward_check.py).  Image and every gradient, viewmat and twist included, against the float64 oracle."""
+    on screen in a true sub-pose; in the pixel-velocity model they move with the Jacobian of the fov guard band's edge
+    (gs_math.h pixel_velocity) and every re-centred box misses the image (with the unclamped Jacobian they were dragged
+    across it at 1e5 px/s: 11 dB against the SE(3) frame, tools/rs_forward_check.py; round 3 culled everything whose
+    centre is out of band).  Four more — large, a metre away, centre beside the image OUTSIDE the band, footprint well
+    inside it (a floor, a wall) — must stay in both models; their velocity gradient passes the clamp
+    to z.  Image and every gradient, viewmat and twist included, against the float64 oracle."""
     import math
     O = oracle
     W, H, n = 144, 96, 2500
@@ -713,12 +716,15 @@ def test_real_camera_pose_and_grazing_gaussians_vs_oracle(gs, oracle, dev, model
     k = 40
     pc = torch.stack([(torch.rand(k, generator=g) * 2 + 1) * torch.sign(torch.rand(k, generator=g) - 0.5),
                       (torch.rand(k, generator=g) * 2 - 1) * 2, 0.02 + 0.03 * torch.rand(k, generator=g)], dim=1)
-    cam_pts = torch.cat([sc["means"], pc])
+    k2 = 4                                    # x/z = +-1.0, y/z = +-0.75: outside the band (0.8125 x 0.8125 here)
+    wall = torch.tensor([[1.0, 0.1, 1.0], [-1.0, -0.2, 1.0], [0.15, 0.75, 1.0], [-0.1, -0.75, 1.0]]) * \
+        torch.tensor([1.0, 1.3, 0.9, 1.2])[:, None]
+    cam_pts = torch.cat([sc["means"], pc, wall])
     sc["means"] = (cam_pts - t) @ Rm
-    sc["log_scales"] = torch.cat([sc["log_scales"], torch.full((k, 3), -2.5)])
-    sc["quats"] = torch.cat([sc["quats"], sc["quats"][:k]])
-    sc["opacity_logits"] = torch.cat([sc["opacity_logits"], torch.full((k,), 4.0)])
-    sc["sh"] = torch.cat([sc["sh"], sc["sh"][:k] + 0.5])
+    sc["log_scales"] = torch.cat([sc["log_scales"], torch.full((k, 3), -2.5), torch.full((k2, 3), -1.0)])
+    sc["quats"] = torch.cat([sc["quats"], sc["quats"][:k + k2]])
+    sc["opacity_logits"] = torch.cat([sc["opacity_logits"], torch.full((k,), 4.0), torch.full((k2,), -0.5)])
+    sc["sh"] = torch.cat([sc["sh"], sc["sh"][:k + k2] + 0.5])
     V = torch.eye(4)
     V[:3, :3], V[:3, 3] = Rm, t
     sc["viewmat"] = V
@@ -747,7 +753,8 @@ def test_real_camera_pose_and_grazing_gaussians_vs_oracle(gs, oracle, dev, model
         samples, alphas, radii = gs.render_subposes(*common, p["viewmat"], bg.to(dev), S, R, sc["fx"], sc["fy"], sc["cx"],
                                                     sc["cy"], H, W, sh_degree=3, lin_vel=p["lin_vel"], ang_vel=p["ang_vel"],
                                                     times=times_t)
-        assert int(radii[:, n:].abs().sum()) == 0                # the grazing Gaussians are culled in every sub-pose
+        assert int(radii[:, n:n + k].abs().sum()) == 0           # the grazing Gaussians: no sub-pose reaches the image
+    assert int((radii[:, n + k:] > 0).sum()) == radii.shape[0] * k2, radii[:, n + k:]     # the walls: every sub-pose
     out = gs.combine_samples(samples, gamma, mlevel)
     (out * wt.to(dev)).sum().backward()
     assert (samples.detach().cpu().double() - ref_samples)[:, good].abs().max().item() < IMG_ATOL
@@ -2164,7 +2171,7 @@ def test_exact_rolling_shutter_pixel_velocity_vs_oracle(gs, oracle, dev, S, W, H
     # integers: the float32 oracle sweeps the same float32 projection
     pr0 = O.project_gaussians(sc["means"], sc["log_scales"].exp(), 1.0, sc["quats"], sc["viewmat"], sc["fx"], sc["fy"],
                               sc["cx"], sc["cy"], H, W, keep_offscreen=True)
-    pv = O.pixel_velocity(sc["means"], sc["viewmat"], sc["fx"], sc["fy"], sc["lin_vel"], sc["ang_vel"])
+    pv = O.pixel_velocity(sc["means"], sc["viewmat"], sc["fx"], sc["fy"], sc["lin_vel"], sc["ang_vel"], 0.01, W, H)
     geom = (pr0.radii > 0).float()[:, None]
     total = 0
     for s_i, tau in enumerate(times):

@@ -150,21 +150,28 @@ def test_pixel_velocity_and_its_vjp_from_a_real_pose(hm, oracle, scene):
     world = ((cam_pts - t) @ R).float()                         # R^T (pc - t)
     V = V64.float()
     lin = torch.tensor([0.7, -0.4, 1.1]); ang = torch.tensor([0.5, -0.8, 0.3])
-    ref = O.pixel_velocity(world, V, sc["fx"], sc["fy"], lin, ang)
+    W, H = scene["W"], scene["H"]
+    ref = O.pixel_velocity(world, V, sc["fx"], sc["fy"], lin, ang, 0.01, W, H)
+    free = O.pixel_velocity(world, V, sc["fx"], sc["fy"], lin, ang)
     pv = np.zeros((n, 2), np.float32)
     args = (n, P(np.ascontiguousarray(world.numpy())), P(np.ascontiguousarray(V.numpy())), f(sc["fx"]), f(sc["fy"]),
-            P(np.ascontiguousarray(lin.numpy())), P(np.ascontiguousarray(ang.numpy())), f(0.01))
+            P(np.ascontiguousarray(lin.numpy())), P(np.ascontiguousarray(ang.numpy())), f(0.01), W, H)
     hm.hm_pixel_velocity(*args, P(pv))
     front = (world.double() @ R.T + t)[:, 2].numpy() > 0.01
     assert front.sum() > 3000 and (~front).sum() > 10
     assert np.abs(pv[front] - ref.numpy()[front]).max() <= 1e-5 * np.abs(ref.numpy()[front]).max()
     assert (pv[~front] == 0).all()
+    # centres outside the fov guard band move with the Jacobian of the band edge (not the unbounded one of x/z), the
+    # rest bit for bit as without a band
+    out_band = front & ((ref != free).any(dim=-1)).numpy()
+    assert out_band.sum() > 20, out_band.sum()
+    assert np.array_equal(pv[front & ~out_band], free.numpy()[front & ~out_band])
     # VJP
     w64 = world.double().requires_grad_(True)
     l64, a64 = lin.double().requires_grad_(True), ang.double().requires_grad_(True)
     g = torch.Generator().manual_seed(2)
     vpv = torch.randn(n, 2, generator=g) * torch.from_numpy(front)[:, None]
-    (O.pixel_velocity(w64, V64, sc["fx"], sc["fy"], l64, a64) * vpv.double()).sum().backward()
+    (O.pixel_velocity(w64, V64, sc["fx"], sc["fy"], l64, a64, 0.01, W, H) * vpv.double()).sum().backward()
     v_pc = np.zeros((n, 3), np.float32); v_lin = np.zeros(3, np.float32); v_ang = np.zeros(3, np.float32)
     hm.hm_pixel_velocity_bwd(*args, P(np.ascontiguousarray(vpv.numpy())), P(v_pc), P(v_lin), P(v_ang))
     want_pc = (w64.grad @ R.T).numpy()                          # v_world = R^T v_pc  ->  v_pc = R v_world

@@ -275,9 +275,14 @@ def test_pixel_velocity_follows_se3_from_a_real_pose_and_ignores_grazing_gaussia
     pixel-velocity frame was 11 dB away from the SE(3) frame although every far Gaussian's centre followed to 0.2 px.
     Cause: Gaussians just in front of the camera plane at grazing angles (z = 0.02, |x| = 2: x/z = 100) — far off screen
     in every true sub-pose, but their first-order pixel velocity is 1e5 px/s and dragged them across the image.  The
-    model now culls what lies outside the projection's own fov guard band (1.3 tan(fov/2)) at the mid-exposure pose.
+    A centre outside the projection's own fov guard band (1.3 tan(fov/2)) now moves with the Jacobian of the band's
+    edge — where the covariance projection takes its Jacobian too (round 3 culled such Gaussians outright, and a floor
+    or wall whose centre lies beside the image vanished from this model only).
     Known answers: (1) identity and non-identity pose: the pixel-velocity render is much closer to the SE(3) render
-    than the static render is; (2) adding grazing Gaussians changes neither render."""
+    than the static render is; (2) adding grazing Gaussians changes neither render; (3) adding large Gaussians a metre
+    away whose centres are out of band but whose footprints reach well into the image changes BOTH renders, and the
+    first-order frame still follows the SE(3) frame better than the static frame does (the band-edge Jacobian
+    under-estimates the depth-motion term of such a centre by up to x/z : 0.8125 — a first-order model's price)."""
     O = oracle
     H, W, n = 64, 96, 500
     sc = O.synthetic_scene(n, W, H, seed=3, dtype=torch.float64, scale_mult=8.0)
@@ -316,6 +321,19 @@ def test_pixel_velocity_follows_se3_from_a_real_pose_and_ignores_grazing_gaussia
         se3_g, pv_g, _ = renders(s1)
         assert mse(se3_g, se3) < 1e-8, posed                 # they are never on screen in a true sub-pose ...
         assert mse(pv_g, pv) < 1e-8, posed                   # ... and no longer in the first-order model's either
+        # walls: x/z = +-1.0 or y/z = +-0.75 (band: 0.8125), one metre away, 0.37 m wide
+        wall = torch.tensor([[1.0, 0.1, 1.0], [-1.0, -0.2, 1.0], [0.15, 0.75, 1.0], [-0.1, -0.75, 1.0]], dtype=torch.float64)
+        k2 = wall.shape[0]
+        s2 = dict(s0)
+        s2["means"] = torch.cat([s0["means"], (wall - Vm[:3, 3]) @ Vm[:3, :3]])
+        s2["log_scales"] = torch.cat([s0["log_scales"], torch.full((k2, 3), -1.0, dtype=torch.float64)])
+        s2["quats"] = torch.cat([s0["quats"], s0["quats"][:k2]])
+        s2["opacity_logits"] = torch.cat([s0["opacity_logits"], torch.full((k2,), 0.5, dtype=torch.float64)])
+        s2["sh"] = torch.cat([s0["sh"], s0["sh"][:k2] + 0.5])
+        se3_w, pv_w, static_w = renders(s2)
+        assert mse(se3_w, se3) > 1e-4 and mse(pv_w, pv) > 1e-4, (posed, mse(se3_w, se3), mse(pv_w, pv))
+        print(f"walls posed={posed}: pixel velocity vs SE(3) {mse(pv_w, se3_w):.2e}, static vs SE(3) {mse(static_w, se3_w):.2e}")
+        assert mse(pv_w, se3_w) < 0.8 * mse(static_w, se3_w), (posed, mse(pv_w, se3_w), mse(static_w, se3_w))
 
 
 def test_pixel_velocity_render_static_limit_and_autograd(oracle):
