@@ -72,63 +72,10 @@ def __getattr__(name):
     raise AttributeError(name)
 
 
-class StageProfiler:
-    """Optional per-stage timing with HIP events recorded on the stream the kernels are launched on
-    (torch's current stream).  Enabled by bench.py; `None` (default) costs nothing."""
-
-    def __init__(self, only=None):
-        self.events = {}
-        self.native = {}                                     # stage -> [ms] drained from the library's own events
-        self.only = None if only is None else set(only)     # restrict to these stage names (others cost nothing)
-        if _lib._lib is not None:
-            _lib._lib.gs_frame_profile_read(0, None, None)   # forget event pairs of an earlier profiler
-
-    class _Ctx:
-        def __init__(self, prof, name):
-            self.prof, self.name = prof, name
-
-        def __enter__(self):
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.b = torch.cuda.Event(enable_timing=True)
-            self.a.record()
-            return self
-
-        def __exit__(self, *exc):
-            self.b.record()
-            self.prof.events.setdefault(self.name, []).append((self.a, self.b))
-            return False
-
-    def stage(self, name):
-        if self.only is not None and name not in self.only:
-            return _NULL
-        return StageProfiler._Ctx(self, name)
-
-    def summary_ms(self):
-        torch.cuda.synchronize()
-        out = {k: [a.elapsed_time(b) for a, b in v] for k, v in self.events.items()}
-        # stages issued by the library itself (gs_frame_forward / gs_frame_backward record their own HIP events)
-        L = _L()
-        cap = 1 << 16
-        ids, ms = (ctypes.c_int * cap)(), (ctypes.c_float * cap)()
-        n = L.gs_frame_profile_read(cap, ids, ms)
-        for i in range(n):
-            self.native.setdefault(FRAME_STAGES[ids[i]], []).append(float(ms[i]))
-        for k, v in self.native.items():
-            out.setdefault(k, []).extend(v)
-        return out
-
-
-class _Null:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
-
+from ._profile import FRAME_STAGES, StageProfiler, _NULL  # noqa: E402
 
 profiler: Optional[StageProfiler] = None
 last_num_intersects: int = 0
-_NULL = _Null()
 
 
 def _stage(name: str):
@@ -372,8 +319,6 @@ def _background(background: Optional[Tensor], device) -> Tensor:
 # Python slice loop with its A/B switches — one slice without culling, fp32 atomics, ...; an independent route to the
 # same images that the equivalence tests compare the product path with).  The product never sets it.
 frame_backend = None
-FRAME_STAGES = ("depth_sort", "count_scan", "slice_plan", "slice_count", "emit", "tile_sort", "bin_edges", "raster_fwd",
-                "slice_sat", "raster_bwd", "grad_reduce")
 
 
 class _FrameDesc(ctypes.Structure):

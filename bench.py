@@ -489,7 +489,7 @@ def main():
             fresh = tj.get("lib_source_hash") == _gsd_build.source_hash()
             if vi and tj.get("workload") == [N, W, H, S, R] and not fresh:
                 valu = {"stale": "profiles/traffic.json was measured on other kernel sources (lib_source_hash differs): "
-                                 "re-run tools/gpu_round.sh pmc"}
+                                 "re-run tools/gpu_visit.sh <tag> pmc"}
             elif vi and tj.get("workload") == [N, W, H, S, R]:
                 simd_cycles = single[dom] * 1e-3 * tj["valu"].get("clock_hz", 2.1e9) * 1024 / max(1.0, launches.get(dom, 1.0))
                 valu = {"wave_instructions_per_launch": vi["insts_valu"],
