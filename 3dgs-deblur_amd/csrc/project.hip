@@ -789,8 +789,11 @@ __device__ __forceinline__ void zero_rows(float* __restrict__ base, size_t first
   for (size_t k = head + 4 * n4 + threadIdx.x; k < count; k += blockDim.x) p[k] = 0.f;
 }
 
+// (256, 2): two waves per SIMD = at most 256 VGPRs.  The body sits right at that cliff (256 with the round-3 pixel-
+// velocity VJP, 258 with round 4's — one wave per SIMD, and the zero fill of the 236 MB of gradient outputs, which is
+// most of this kernel's time on a sparse frame, dropped from 3.3 to 2.3 TB/s: 72 -> 104 us, found by an on-GPU bisect)
 template <int MAXB, bool ZERO_FILL>
-__global__ __launch_bounds__(256) void project_fused_bwd_sparse_kernel(FusedParams fp,
+__global__ __launch_bounds__(256, 2) void project_fused_bwd_sparse_kernel(FusedParams fp,
     const float* __restrict__ records, const float* __restrict__ v_records, FusedOut out,
     const unsigned char* __restrict__ touched /* [P*N] */) {
   __shared__ float lds[48];
