@@ -391,8 +391,11 @@ __device__ __forceinline__ void blend_entry(const RecS& rc, float pxf, int idx, 
 }
 __device__ __forceinline__ bool any_live(const PixCols& st) { return any_live(st.p); }
 
+#ifndef GS_FWD_SLOAD_WAVES
+#define GS_FWD_SLOAD_WAVES 1      // no occupancy request: 65 VGPRs, 7 waves per SIMD (8 would need 64)
+#endif
 template <bool DEPTH>
-__global__ __launch_bounds__(256) void raster_fwd_sload_kernel(RasterParams prm, SliceState st,
+__global__ __launch_bounds__(256, GS_FWD_SLOAD_WAVES) void raster_fwd_sload_kernel(RasterParams prm, SliceState st,
                                                                const int* __restrict__ ids,       // padded, see ABI
                                                                const float* __restrict__ records, unsigned max_id,
                                                                float* __restrict__ out_img,

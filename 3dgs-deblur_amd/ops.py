@@ -826,6 +826,11 @@ class _RenderSubposes(Function):
         if backend is None:
             if rs is not None and R != 1:
                 raise ValueError("exact rolling shutter renders with rs_bands == 1")
+            # the backward's frame-sized buffers (and the one fill among them) are issued BEFORE the frame: behind the
+            # frame's last read-back nothing but the averaging and the backward's own launches are left for the host
+            ctx.prealloc = ({"touched": torch.zeros(P * N, dtype=torch.uint8, device=dev),
+                             "v_records": torch.empty(P * N, GRAD, device=dev)}
+                            if any(ctx.needs_input_grad) else None)
             for attempt in range(_ARENA_ATTEMPTS):
                 try:
                     out_img, out_T, ctx.frame = native_frame_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges,
@@ -841,11 +846,6 @@ class _RenderSubposes(Function):
                     with _stage("project_fwd"):
                         _project()
             slices = []
-            # the backward's frame-sized buffers are set up here, not in the window between the forward and the backward
-            # compositor where the GPU waits for the host
-            ctx.prealloc = ({"touched": torch.zeros(P * N, dtype=torch.uint8, device=dev),
-                             "v_records": torch.empty(P * N, GRAD, device=dev)}
-                            if any(ctx.needs_input_grad) else None)
         else:
             ctx.prealloc = {} if any(ctx.needs_input_grad) else None
             out_img, out_T, slices = backend.sliced_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges, SLICE_BASE,
@@ -860,7 +860,8 @@ class _RenderSubposes(Function):
             # per-sample gradients (the compositor's backward derives them per pixel)
             m = float(min_rgb_level) / 255.0
             first = cmb_rgb = torch.empty(H, W, 3, device=dev)
-            _check(L.gs_combine_fwd(S, H * W * 3, _ptr(out_img), float(gamma), m, _ptr(first), _stream()), "combine_fwd")
+            with _stage("combine"):
+                _check(L.gs_combine_fwd(S, H * W * 3, _ptr(out_img), float(gamma), m, _ptr(first), _stream()), "combine_fwd")
             ctx.combine = (float(gamma), m)
         else:
             cmb_samples = cmb_rgb = svals          # placeholders: nothing to keep
@@ -903,8 +904,9 @@ class _RenderSubposes(Function):
                 v_img = v_samples
             else:
                 scale = torch.empty_like(rgb)
-                _check(L.gs_combine_bwd_scale(S, rgb.numel(), gamma, _ptr(rgb), _ptr(v_img), _ptr(scale), _stream()),
-                       "combine_bwd_scale")
+                with _stage("combine"):
+                    _check(L.gs_combine_bwd_scale(S, rgb.numel(), gamma, _ptr(rgb), _ptr(v_img), _ptr(scale),
+                                                  _stream()), "combine_bwd_scale")
                 combine = (scale, gamma, m)
                 v_img = samples
         # atomic-free path: only Gaussians the compositor touched get a gradient record (plain stores) and a
