@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit, parametrised (replaces the round-3 one-off recipes).  Usage, from the repo root on the GPU box:
 #   bash tools/gpu_visit.sh <tag> [steps...]      steps: suite | tests:<pytest -k expr> | smoke | bench | benchq | ab:<ENV=V,...>
-#                                                        | prof | pmc | prof_trained | motions
+#                                                        | prof | pmc | prof_trained | prof_exchange | motions
 # Everything lands in gpurun_out/<tag>/; a summary is printed at the end.
 set -u
 TAG=${1:-visit}; shift || true
@@ -73,6 +73,20 @@ for step in "$@"; do
       for f in $(find $OUT/$step -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_$step.csv; head -24 $f | cut -c1-200 | tee -a $S; done
       [ $step = prof ] && python tools/trace_step.py $OUT/prof > $OUT/timeline.txt 2>/dev/null && tail -1 $OUT/timeline.txt | tee -a $S
       rm -rf $OUT/$step/*/*kernel_trace* 2>/dev/null ;;
+    prof_exchange)
+      # the DP gradient exchange over RCCL at world size 1 (bench.py --force-exchange): bench line + kernel table with
+      # the ncclDevKernel rows
+      timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --force-exchange > $OUT/bench_exchange.log 2>&1
+      python - $OUT/bench_exchange.log <<'PY' | tee -a $S
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith('{'):
+        d = json.loads(l); c = d['config']
+        print('force-exchange: ms', d['ms_per_step'], 'exchange_ms', d.get('exchange_ms'), 'mode', c.get('gradient_exchange'), 'rccl', c.get('rccl_version'), 'per_rank', c.get('per_rank'))
+PY
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_exchange -o trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --force-exchange) > $OUT/prof_exchange.log 2>&1
+      for f in $(find $OUT/prof_exchange -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_prof_exchange.csv; grep -i "nccl\|dp_" $f | cut -c1-160 | tee -a $S; done
+      rm -rf $OUT/prof_exchange/*/*kernel_trace* 2>/dev/null ;;
     pmc)
       for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR"; do
         t=$(echo $pmc | cut -d' ' -f1)
