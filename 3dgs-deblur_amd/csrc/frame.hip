@@ -135,10 +135,15 @@ inline void cpu_relax() {
 // poll: host_pinned must be host-coherent pinned memory the GPU can write at system scope (hipHostMalloc default /
 // torch pin_memory); with non-coherent pinned memory (HIP_HOST_COHERENT=0) the sequence word may never become visible
 // and every read-back waits out kPollTimeoutUs before falling back to hipStreamSynchronize — pass poll_readback = 0 then.
-inline int read_back(const unsigned* src_dev, unsigned* host_pinned, int n, bool poll, hipStream_t st) {
+// between: launched behind the copy / publish kernel and before the host starts to wait — work for the GPU while the
+// words travel and the host wakes up (gs_frame_forward: the averaging of the sample images).
+template <class Between>
+inline int read_back(const unsigned* src_dev, unsigned* host_pinned, int n, bool poll, hipStream_t st, Between between) {
   if (!poll) {
     hipError_t e = hipMemcpyAsync(host_pinned + 1, src_dev, 4ll * n, hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) return 1000 + (int)e;
+    int rb = between();
+    if (rb != GS_OK) return rb;
     return hip_status(hipStreamSynchronize(st));
   }
   volatile unsigned* seqw = host_pinned;
@@ -147,6 +152,8 @@ inline int read_back(const unsigned* src_dev, unsigned* host_pinned, int n, bool
   hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(256), 0, st, src_dev, host_pinned, n, 1u);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return 1000 + (int)e;
+  int rb = between();
+  if (rb != GS_OK) return rb;
   const long long t0 = now_us();
   unsigned spins = 0;
   while (__atomic_load_n(host_pinned, __ATOMIC_ACQUIRE) != 1u) {
@@ -158,6 +165,10 @@ inline int read_back(const unsigned* src_dev, unsigned* host_pinned, int n, bool
     }
   }
   return GS_OK;
+}
+
+inline int read_back(const unsigned* src_dev, unsigned* host_pinned, int n, bool poll, hipStream_t st) {
+  return read_back(src_dev, host_pinned, n, poll, st, [] { return GS_OK; });
 }
 
 #define CHECK(call)            \
@@ -244,7 +255,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
                                int color_degree,
                                const float* color_viewmats, const float* pix_vel, const float* sample_times,
                                float* out_img, float* out_T,
-                               float* out_depth, void* arena_ptr, long long arena_bytes, void* host_pinned, long long host_pinned_bytes,
+                               float* out_depth, float* out_combined, void* arena_ptr, long long arena_bytes, void* host_pinned, long long host_pinned_bytes,
                                gs_frame_state* state, void* stream_) {
   if (!dp || !records || !depth_keys || !num_tiles_hit || !background || !band_edges || !out_img || !out_T ||
       !arena_ptr || !host_pinned || !state)
@@ -560,10 +571,19 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
       sl.counts = A.offset_of(counts); sl.cum = A.offset_of(cum_k); sl.tile_hot = A.offset_of(tile_hot);
       sl.n_emitted_dev = A.offset_of(total_k);
     }
+    // out_combined: the gamma-space average of the sample images, launched behind EVERY slice's compositor — behind the
+    // open-tile word when one is read, so that it runs while the word travels and the host wakes up (26 us that used to
+    // sit on the critical path between the forward and the backward); a slice that turns out not to be the last one
+    // has its average overwritten by the next
+    auto average = [&]() -> int {
+      if (!out_combined) return GS_OK;
+      return gs_combine_fwd(S, 3ll * H * W, out_img, d.combine_gamma, d.combine_min_level, out_combined, st);
+    };
+    if (last) CHECK(average());
     if (!last) {
       // one read-back per slice: are there open tiles for the next planned slice?  One word, written by the compositor
       // itself, read AFTER this slice's whole pipeline was issued
-      CHECK(read_back(reinterpret_cast<const unsigned*>(open_flags + k), hp_seq, 1, poll, st));
+      CHECK(read_back(reinterpret_cast<const unsigned*>(open_flags + k), hp_seq, 1, poll, st, average));
       const long long open_now = hp[0];                              // tiles the compositor left open
       if (open_now == 0) break;
       span = (d.merge_open_fraction > 0.f && (double)open_now >= (double)d.merge_open_fraction * (double)open_before)

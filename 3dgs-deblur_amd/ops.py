@@ -326,7 +326,9 @@ class _FrameDesc(ctypes.Structure):
                                              "fwd_variant", "reserve_backward")] + [("merge_open_fraction", ctypes.c_float),
                                                                                      ("rolling_shutter_time", ctypes.c_float),
                                                                                      ("poll_readback", ctypes.c_int),
-                                                                                     ("shared_list", ctypes.c_int)]
+                                                                                     ("shared_list", ctypes.c_int),
+                                                                                     ("combine_gamma", ctypes.c_float),
+                                                                                     ("combine_min_level", ctypes.c_float)]
 
 
 class _FrameSlice(ctypes.Structure):
@@ -360,8 +362,9 @@ def _profile_mask() -> int:
 
 def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
                          H: int, W: int, bg: Tensor, edges: Tensor, slice_base: int, color=None,
-                         out_depth: Optional[Tensor] = None, reserve_backward: bool = True, rs=None):
-    """rs = (pix_vel [N,2], rolling_shutter_time[, sample_times [S]]) or None; with sample_times the frame runs in the
+                         out_depth: Optional[Tensor] = None, reserve_backward: bool = True, rs=None, combine=None):
+    """combine = (gamma, min_level, out [H,W,3]): the library launches the gamma-space average of the sample images itself,
+    behind every slice's compositor (it overlaps the open-tile read-back).  rs = (pix_vel [N,2], rolling_shutter_time[, sample_times [S]]) or None; with sample_times the frame runs in the
     shared-list mode (P == 1: one record set and one tile list for the S samples).  gs_frame_forward: -> (out_img [S,H,W,3], out_T [S,H,W], frame) ; frame = dict(arena, state) for
     native_frame_backward.  Raises _ArenaTooSmall (after recording a larger size) when the arena did not hold the frame:
     the caller projects again (the depth keys were consumed) and calls once more."""
@@ -387,7 +390,8 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     if pin is None or pin.numel() < need_pin:
         pin = _pinned_cache[pin_key] = torch.empty(max(8192, need_pin), dtype=torch.uint8, pin_memory=True)
     desc = _FrameDesc(N, P, S, R, H, W, int(slice_base), DEPTH_SORT_DIGIT, 0, int(reserve_backward),
-                      float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0, int(FRAME_POLL), int(shared))
+                      float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0, int(FRAME_POLL), int(shared),
+                      float(combine[0]) if combine is not None else 1.0, float(combine[1]) if combine is not None else 0.0)
     state = _FrameState()
     out_img = torch.empty(S, H, W, 3, device=dev)
     out_T = torch.empty(S, H, W, device=dev)
@@ -400,7 +404,7 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     st = L.gs_frame_forward(ctypes.byref(desc), _ptr(records), _ptr(depth_keys), _ptr(num_tiles_hit), _ptr(bg), _ptr(edges),
                             _ptr(band_done), _ptr(c_means), _ptr(c_sh), _ptr(c_rest), int(c_K), int(c_deg), _ptr(c_V),
                             _ptr(rs[0]) if rs is not None else None, _ptr(rs[2]) if shared else None, _ptr(out_img),
-                            _ptr(out_T), _ptr(out_depth),
+                            _ptr(out_T), _ptr(out_depth), _ptr(combine[2]) if combine is not None else None,
                             _ptr(arena), arena.numel(), ctypes.c_void_p(pin.data_ptr()), pin.numel(), ctypes.byref(state),
                             _stream())
     if st == 3:
@@ -831,11 +835,15 @@ class _RenderSubposes(Function):
             ctx.prealloc = ({"touched": torch.zeros(P * N, dtype=torch.uint8, device=dev),
                              "v_records": torch.empty(P * N, GRAD, device=dev)}
                             if any(ctx.needs_input_grad) else None)
+            # fused sub-frame averaging: the library launches it behind the last compositor (below: `averaged`)
+            averaged = None
+            if gamma is not None:
+                averaged = (float(gamma), float(min_rgb_level) / 255.0, torch.empty(H, W, 3, device=dev))
             for attempt in range(_ARENA_ATTEMPTS):
                 try:
                     out_img, out_T, ctx.frame = native_frame_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges,
                                                                      SLICE_BASE, color, depth_acc,
-                                                                     any(ctx.needs_input_grad), rs)
+                                                                     any(ctx.needs_input_grad), rs, averaged)
                     break
                 except _ArenaTooSmall:
                     if attempt == _ARENA_ATTEMPTS - 1:
@@ -859,9 +867,13 @@ class _RenderSubposes(Function):
             # fused sub-frame averaging: output 0 is the averaged image; backward never materialises the
             # per-sample gradients (the compositor's backward derives them per pixel)
             m = float(min_rgb_level) / 255.0
-            first = cmb_rgb = torch.empty(H, W, 3, device=dev)
-            with _stage("combine"):
-                _check(L.gs_combine_fwd(S, H * W * 3, _ptr(out_img), float(gamma), m, _ptr(first), _stream()), "combine_fwd")
+            if backend is None:
+                first = cmb_rgb = averaged[2]
+            else:
+                first = cmb_rgb = torch.empty(H, W, 3, device=dev)
+                with _stage("combine"):
+                    _check(L.gs_combine_fwd(S, H * W * 3, _ptr(out_img), float(gamma), m, _ptr(first), _stream()),
+                           "combine_fwd")
             ctx.combine = (float(gamma), m)
         else:
             cmb_samples = cmb_rgb = svals          # placeholders: nothing to keep

@@ -472,6 +472,8 @@ typedef struct gs_frame_desc {
                                 tile list for all S blur samples — the paper's form (depth order and covariance fixed
                                 across samples; SURVEY.md App. A, /root/reference/README.md:196-200); sample s evaluates
                                 every splat at mu' + (sample_times[s] + tau(y)) * pixel velocity inside the compositor */
+  float combine_gamma;       /* with out_combined != NULL: gs_combine_fwd(gamma, min_level) of the sample images is */
+  float combine_min_level;   /* launched behind every slice's compositor (it overlaps the open-tile read-back) */
 } gs_frame_desc;
 typedef struct gs_frame_slice {
   long long I;               /* capacity of the slice's lists (its ranks' bounding-box pairs); real count on the device */
@@ -499,7 +501,10 @@ int gs_frame_forward(const gs_frame_desc* desc, float* records, unsigned* depth_
                      const float* color_viewmats /*P*16*/,
                      const float* pix_vel /*NULL, or [N*2] from gs_project_pixvel_fwd(rolling_shutter_time != 0)*/,
                      const float* sample_times /*[S] device, desc->shared_list only (NULL otherwise)*/,
-                     float* out_img /*S*H*W*3*/, float* out_T /*S*H*W*/, float* out_depth, void* arena, long long arena_bytes, void* host_pinned,
+                     float* out_img /*S*H*W*3*/, float* out_T /*S*H*W*/, float* out_depth,
+                     float* out_combined /*NULL, or H*W*3: gs_combine_fwd(desc->combine_gamma, desc->combine_min_level) of
+                     out_img, launched by this call (see gs_frame_desc)*/,
+                     void* arena, long long arena_bytes, void* host_pinned,
                      long long host_pinned_bytes, gs_frame_state* state, void* stream);
 long long gs_frame_backward_bytes(const gs_frame_state* state);
 /* v_records [P*N*12] (rows the compositor never touched are left as they are), touched [P*N] u8 zeroed by the caller;
