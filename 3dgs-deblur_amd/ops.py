@@ -687,9 +687,8 @@ class _SubposeViewmats(Function):
         V, lin, ang, times = ctx.saved_tensors
         P = times.numel()
         dev = V.device
-        v_V = torch.zeros(4, 4, device=dev)
-        v_lin = torch.zeros(3, device=dev)
-        v_ang = torch.zeros(3, device=dev)
+        acc = torch.zeros(22, device=dev)                  # one fill for the three accumulators
+        v_V, v_lin, v_ang = acc[:16].view(4, 4), acc[16:19], acc[19:22]
         _check(_L().gs_subpose_viewmats_bwd(P, _ptr(V), _ptr(lin), _ptr(ang), _ptr(times),
                                             _ptr(v_out.contiguous().float()), _ptr(v_V), _ptr(v_lin), _ptr(v_ang),
                                             _stream()), "subpose_viewmats_bwd")

@@ -21,10 +21,14 @@
  * safe to call concurrently on different streams.  Return value: 0 = ok, 1 = invalid
  * argument, 3 = workspace too small, 1000+e = hipError_t e from the launch.
  *
- * Rasterizer record ("records"): 12 floats per (sub-pose p, Gaussian g), index p*N+g:
+ * Rasterizer record ("records"): 16 floats (64 bytes) per (sub-pose p, Gaussian g), index p*N+g:
  *   [0]x [1]y [2]conic.x [3]conic.y [4]conic.z [5]opacity [6]r [7]g [8]b [9]depth
  *   [10] int bits: tile_min.x | tile_min.y<<16   [11] int bits: tile_max.x | tile_max.y<<16
- * Gradient records use slots 0..8 of the same layout.
+ *   [12] nmid = log2(255 * opacity) / 2   [13] kmul = opacity * 2^-nmid
+ *   [14] qx = -log2(e)/2 * conic.x        [15] qz = -log2(e)/2 * conic.z
+ *   ([12..15]: per-entry constants of the compositors' validity test |u| <= nmid and of alpha = kmul * 2^u,
+ *    u = the exponent of alpha shifted by nmid; written by the projection / gs_pack_records; opacity < 1/255: nmid = -1)
+ * Gradient records / tuples: 12 floats, slots 0..8 of the same layout (9, 10: d loss / d pixel velocity).
  */
 #ifndef GSDEBLUR_H
 #define GSDEBLUR_H
@@ -78,7 +82,7 @@ int gs_project_fused_fwd(int N, int P, const float* means3d, const float* scales
                          const float* viewmats /*P*16*/, float fx, float fy, float cx, float cy,
                          int img_height, int img_width, float clip_thresh, int antialiased,
                          int defer_color /*bit 0: leave rgb = 0 and skip the SH read; gs_slice_colors fills it later.
-                                           bit 1: write NO record for a culled (Gaussian, sub-pose) pair — its 48 bytes
+                                           bit 1: write NO record for a culled (Gaussian, sub-pose) pair — its 64 bytes
                                            stay uninitialised; only for callers that never look at them (the sliced
                                            path behind gs_segmented_sort_compact_u32, which drops culled keys)*/,
                          float* records /*P*N*16*/, unsigned* depth_keys /*P*N*/,
@@ -147,7 +151,7 @@ int gs_project_pixvel_bwd(int N, int P, const float* means3d, const float* scale
 /* ---- gsplat-array <-> record glue for the rasterize_gaussians signature -------- */
 int gs_pack_records(int N, const float* xys, const float* depths, const int* radii, const float* conics,
                     const float* colors /*N*3*/, const float* opacity /*N*/, int img_height, int img_width,
-                    float* records /*N*12*/, unsigned* depth_keys /*N*/, int* num_tiles_hit /*N*/,
+                    float* records /*N*16*/, unsigned* depth_keys /*N*/, int* num_tiles_hit /*N*/,
                     void* stream);
 int gs_unpack_record_grads(int N, const float* v_records, float* v_xys, float* v_conics, float* v_colors,
                            float* v_opacity, void* stream);
@@ -251,7 +255,8 @@ int gs_rasterize_fwd(const float* records, const int* sorted_vals, const int* ti
                      int n_records /*rows of `records`.  > 0 selects the scalar-cache compositor (variant 0), which
                                      reads sorted_vals in aligned groups of four: the array must then have 8 readable
                                      ints past its last entry (values are clamped to n_records-1, never blended)*/,
-                     int variant /*0 = default; 1, 2 = the v_readlane compositor without / with the empty-pair skip (A/B)*/,
+                     int variant /*0.  (1, 2: the round-1 v_readlane compositors — compiled only into the test library
+                                   tests/libgsdeblur_round1.so, -DGS_ROUND1_KERNELS=1; the product returns GS_ERR_INVALID)*/,
                      void* stream);
 /* v_records [P*N*12] is accumulated into with fp32 atomics (caller zeroes); v_alpha may be NULL. */
 int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* tile_bins,
@@ -259,8 +264,8 @@ int gs_rasterize_bwd(const float* records, const int* sorted_vals, const int* ti
                      int img_width, const float* out_T, const int* final_idx, const float* v_img,
                      const float* v_alpha, float* v_records,
                      int n_records /*as in gs_rasterize_fwd: > 0 selects the scalar-cache kernel (padded sorted_vals)*/,
-                     int variant /*0 = default; 2 = the v_readlane kernel of round 1 (A/B); + 256: let the gradient pass
-                                   the alpha = min(0.999, .) clamp as gsplat 0.1.11 does*/,
+                     int variant /*0 (2: the round-1 kernel, test library only, see gs_rasterize_fwd); + 256: let the
+                                   gradient pass the alpha = min(0.999, .) clamp as gsplat 0.1.11 does*/,
                      void* stream);
 
 /* ---- depth-sliced variant of the same path (MI355X design, no upstream counterpart) ----------
@@ -342,9 +347,8 @@ int gs_rasterize_fwd_slice(const float* records, const int* sorted_vals, const i
                                                            tile runs the loop with the alpha clamp*/,
                            int* open_flag /*NULL, or one int zeroed by the caller: receives the number of tiles still
                                             open after this slice (last == 0 only)*/,
-                           int variant /*0 = default; 1, 2 = v_readlane compositor without / with the empty-pair skip;
-                                         3 = the 4x4-block lock-step walk for slices of small splats (needs sorted_ids;
-                                         same images, bit for bit)*/,
+                           int variant /*0 (1, 2: the round-1 v_readlane compositor, test library only, see
+                                         gs_rasterize_fwd; the lock-step walk of round 3, variant 3, was removed)*/,
                            void* stream);
 /* Debug twin of gs_rasterize_fwd_slice (no upstream counterpart; DESIGN.md section 5 "lane utilisation"): same outputs
  * through the round-1 compositor, and the counters of its walk summed into stats[13] (u64, zeroed by the caller):
@@ -393,8 +397,8 @@ int gs_rasterize_bwd_slice(const float* records, const int* sorted_vals, const i
                            float* tuples /*[I*12] or NULL*/, unsigned char* flags /*[I], zeroed, or NULL*/,
                            const int* sorted_ids /*as in gs_rasterize_fwd_slice*/, int n_records,
                            const unsigned char* tile_hot /*as in gs_rasterize_fwd_slice (same slice)*/,
-                           int variant /*0 = default (scalar-cache kernel when ids are available); 2 = round-1 kernel;
-                                         + 256: upstream alpha-clamp gradient, as in gs_rasterize_bwd*/,
+                           int variant /*0 (2: round-1 kernel, test library only); + 256: upstream alpha-clamp
+                                         gradient, as in gs_rasterize_bwd*/,
                            const float* cmb_scale /*[H,W,3] or NULL.  Non-NULL folds gs_combine_bwd into this launch:
                                                     v_img then holds the SAMPLE IMAGES [S,H,W,3] and each pixel derives
                                                     its sample gradient from cmb_scale (gs_combine_bwd_scale)*/,
@@ -457,7 +461,7 @@ typedef struct gs_frame_desc {
   int N, P, S, R, H, W;      /* Gaussians, sub-poses (= S*R), sample images, rolling-shutter bands, image size */
   int slice_base;            /* average tile-list budget of the first depth slice (doubles per slice); 0: one slice */
   int depth_sort_digit;      /* widest radix digit of the depth pre-sort (8..11) */
-  int fwd_variant;           /* as gs_rasterize_fwd_slice (3 = lock-step 4x4 blocks: same images, not faster) */
+  int fwd_variant;           /* as gs_rasterize_fwd_slice: 0 */
   int reserve_backward;      /* 1: the arena must also hold what gs_frame_backward will take */
   float merge_open_fraction; /* > 0: a slice that leaves at least this fraction of its open tiles open makes the next
                                 issued slice span twice as many planned ones (frames whose tiles do not saturate gain
