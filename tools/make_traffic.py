@@ -18,11 +18,12 @@ KERNELS = ["raster_bwd_sload_kernel", "raster_fwd_sload_kernel", "raster_bwd_ker
            "slice_colors_kernel", "emit_open_kernel", "reduce_tuples_wave_kernel", "radix_scatter_kernel",
            "radix_hist_kernel"]
 # issue cycles per VALU wave-instruction of the kernel's inner-loop mix (tools/valu_mix.py x tools/valu_bench.hip)
-MIX = {"raster_fwd_sload_kernel": 844.7 / 245, "raster_bwd_sload_kernel": 1502.1 / 441,
-       "raster_fwd_slice_kernel": 345.8 / 90, "raster_bwd_kernel_v2": 485.5 / 125}      # profiles/r03_valu_mix.txt
+# round 4 (profiles/r04_valu_mix.txt): static mix of the final inner loops, the backward's with all four quadrants hit
+MIX = {"raster_fwd_sload_kernel": 785.1 / 221, "raster_bwd_sload_kernel": 1708.0 / 599,
+       "raster_fwd_slice_kernel": 345.8 / 90, "raster_bwd_kernel_v2": 485.5 / 125}
 # the same mixes in WALL nanoseconds per wave-instruction and SIMD (no clock assumed; an upper bound: the
 # micro-benchmark's wall time includes its launch tails)
-MIX_NS = {"raster_fwd_sload_kernel": 500.0 / 245, "raster_bwd_sload_kernel": 891.9 / 441,
+MIX_NS = {"raster_fwd_sload_kernel": 467.7 / 221, "raster_bwd_sload_kernel": 981.9 / 599,
           "raster_fwd_slice_kernel": 203.9 / 90, "raster_bwd_kernel_v2": 288.2 / 125}
 
 def mean_per_kernel(counter):
