@@ -225,6 +225,54 @@ def test_sparse_exchange_survives_a_sudden_density_jump_world2_gloo():
     assert not log[9][0]                                                    # ... out of a sparse regime
 
 
+def _dp_forced_world1_worker(port, q):
+    sys.path.insert(0, str(ROOT))
+    import gsdeblur_amd as gs
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    N = 20000
+    shapes = [(N, 3), (N, 3), (N, 4), (N, 1), (N, 3), (N, 15, 3)]
+    g = torch.Generator().manual_seed(3)
+    res = {}
+    for mode, kw in (("sparse", {}), ("sparse", {"sync_free": True}), ("rs_ag", {}), ("allreduce", {})):
+        # (the sync-free form digests a step's row counts one step late: a 60x density jump would truncate that step and
+        #  raise at the next one — test_sparse_exchange_overflow_is_reported_loudly —, so it gets a steady density)
+        for density in ((0.01, 0.012) if kw else (0.01, 0.6)):
+            touched = torch.rand(N, generator=g) < density
+            grads = [torch.randn(s, generator=g) * touched.view(-1, *([1] * (len(s) - 1))) for s in shapes]
+            params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+            for p_, g_ in zip(params, grads):
+                p_.grad = g_.clone()
+            # without force a single rank returns before touching anything; with it the whole chain runs
+            gs.dp.allreduce_gradients(params, mode=mode, force=True, **kw)
+            key = f"{mode}{'/sync_free' if kw else ''}@{density}"
+            res[key] = all(torch.equal(p_.grad, g_) for p_, g_ in zip(params, grads))
+        gs.dp.reset_sparse_exchange_state()
+    small = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(4, 4))]
+    for p_ in small:
+        p_.grad = torch.randn(p_.shape, generator=g)
+    want = [p_.grad.clone() for p_ in small]
+    gs.dp.allreduce_dense_([p_.grad for p_ in small], force=True)
+    res["dense_small"] = all(torch.equal(p_.grad, w) for p_, w in zip(small, want))
+    st = gs.dp._sparse_state(N, 1, None)
+    q.put((res, st is not None))
+    dist.destroy_process_group()
+
+
+def test_forced_exchange_at_world_size_1_gloo():
+    """round 4, CPU side: allreduce_gradients(force=True) / allreduce_dense_(force=True) run the whole
+    exchange at world size 1 — all four forms, sparse and dense row densities — and a single rank's sum is its own
+    gradient, bit for bit (the `-m gpu` twin drives the same over RCCL: test_gradient_exchange_over_rccl_world1)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_dp_forced_world1_worker, args=(41000 + os.getpid() % 2000, q))
+    p.start()
+    res, have_state = q.get(timeout=180)
+    p.join(timeout=60)
+    assert have_state and len(res) == 9 and all(res.values()), res
+
+
 def test_sparse_exchange_overflow_is_reported_loudly(gs):
     """a count above the capacity that was used means the step's gradients were truncated: never silent"""
     st = gs.dp.SparseExchangeState(100_000, 2)
