@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit, parametrised (replaces the round-3 one-off recipes).  Usage, from the repo root on the GPU box:
 #   bash tools/gpu_visit.sh <tag> [steps...]      steps: suite | tests:<pytest -k expr> | smoke | bench | benchq | ab:<ENV=V,...>
-#                                                        | prof | pmc | prof_trained | prof_exchange | motions
+#                                                        | prof | pmc | prof_trained | prof_exchange | motions | fuzz
 # Everything lands in gpurun_out/<tag>/; a summary is printed at the end.
 set -u
 TAG=${1:-visit}; shift || true
@@ -73,6 +73,16 @@ for step in "$@"; do
       for f in $(find $OUT/$step -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_$step.csv; head -24 $f | cut -c1-200 | tee -a $S; done
       [ $step = prof ] && python tools/trace_step.py $OUT/prof > $OUT/timeline.txt 2>/dev/null && tail -1 $OUT/timeline.txt | tee -a $S
       rm -rf $OUT/$step/*/*kernel_trace* 2>/dev/null ;;
+    fuzz)
+      # randomised equivalence / oracle checks (tests/fuzz_paths.py): default path vs the plain one over random sizes and
+      # switches; with `oracle` tiny scenes are also held against the float64 oracle; `pixvel`: the pixel-velocity model
+      # (a third of those trials with exact rolling shutter).  Each leg stops after 140 s (a killed leg prints no total).
+      for leg in "400 41 oracle" "400 42" "300 43 oracle pixvel" "200 44 pixvel"; do
+        tag=$(echo $leg | tr ' ' '_')
+        timeout 140 python tests/fuzz_paths.py $leg > $OUT/fuzz_$tag.log 2>&1
+        echo "fuzz [$leg]: $(grep -c ' ok$' $OUT/fuzz_$tag.log) ok, $(grep -c 'FAIL$' $OUT/fuzz_$tag.log) FAIL; $(tail -1 $OUT/fuzz_$tag.log | cut -c1-120)" | tee -a $S
+        grep 'FAIL$' $OUT/fuzz_$tag.log | head -3 | cut -c1-300 | tee -a $S
+      done ;;
     prof_exchange)
       # the DP gradient exchange over RCCL at world size 1 (bench.py --force-exchange): bench line + kernel table with
       # the ncclDevKernel rows
