@@ -169,7 +169,12 @@ for trial in range(trials):
                                              torch.sigmoid(q["opacity_logits"]), q["sh"], sc_cpu["viewmat"].double(),
                                              (sc_cpu["lin_vel"] * 20).double(), (sc_cpu["ang_vel"] * 10).double(),
                                              background=None if bg is None else bg.double(), return_parts=True)
-        ((ref * wt.cpu().double()).sum() + 0.5 * S * ref_a.sum()).backward()      # sum_s alpha_s = S * mean
+        loss_ref = (ref * wt.cpu().double()).sum() + 0.5 * S * ref_a.sum()         # sum_s alpha_s = S * mean
+        if loss_ref.requires_grad:
+            loss_ref.backward()
+        for k in q:                                     # nothing on screen: the frame does not depend on the scene
+            if q[k].grad is None:
+                q[k].grad = torch.zeros_like(q[k])
         good = ~frag
         d_img = float((img_f.cpu().double() - ref)[good].abs().max()) if good.any() else 0.0
         d_grad = 0.0
