@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit, parametrised (replaces the round-3 one-off recipes).  Usage, from the repo root on the GPU box:
 #   bash tools/gpu_visit.sh <tag> [steps...]      steps: suite | tests:<pytest -k expr> | smoke | bench | benchq | ab:<ENV=V,...>
-#                                                        | prof | pmc | prof_trained | prof_exchange | motions | fuzz
+#                                                        | prof | pmc | prof_trained | prof_exchange | motions | fuzz | configs
 # Everything lands in gpurun_out/<tag>/; a summary is printed at the end.
 set -u
 TAG=${1:-visit}; shift || true
@@ -73,6 +73,16 @@ for step in "$@"; do
       for f in $(find $OUT/$step -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_$step.csv; head -24 $f | cut -c1-200 | tee -a $S; done
       [ $step = prof ] && python tools/trace_step.py $OUT/prof > $OUT/timeline.txt 2>/dev/null && tail -1 $OUT/timeline.txt | tee -a $S
       rm -rf $OUT/$step/*/*kernel_trace* 2>/dev/null ;;
+    configs)
+      # bench lines of the other BASELINE.json configurations on one GPU (their parity is tested by the suite; these are
+      # measurements only): config 3 = 1M, 1080p, 10 rolling-shutter row bands; config 4's per-GPU share = 2M, S=5 x R=2;
+      # config 5's per-GPU share = 5M, 3840x2160, S=10
+      for cfg in "c3 --gaussians 1000000 --subposes 1 --rs-bands 10" "c4 --gaussians 2000000 --subposes 5 --rs-bands 2" "c5 --gaussians 5000000 --width 3840 --height 2160 --subposes 10"; do
+        name=${cfg%% *}; fl=${cfg#* }
+        timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary $fl > $OUT/bench_$name.log 2>&1
+        benchline "$name($fl)" $OUT/bench_$name.log | tee -a $S
+        grep -E "Error|error" $OUT/bench_$name.log | tail -2 | tee -a $S
+      done ;;
     fuzz)
       # randomised equivalence / oracle checks (tests/fuzz_paths.py): default path vs the plain one over random sizes and
       # switches; with `oracle` tiny scenes are also held against the float64 oracle; `pixvel`: the pixel-velocity model
