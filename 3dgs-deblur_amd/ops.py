@@ -31,6 +31,30 @@ MAX_SUBPOSES = 256   # blur samples x rolling-shutter bands per frame (SliceDesc
 # depth slicing of the fused path: average tile-list length budget of the first slice (doubling per
 # slice); 0 disables slicing (single pass over all intersections)
 SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "512"))
+# the budget adapts across frames of one shape: a frame that issued two or more slices doubles it for the next ones, up
+# to 4x (a scene whose tiles do not saturate pays ~0.15 ms per slice boundary for nothing: fitted-model-like bench scene,
+# 512 / 1024 / 2048: 9.35 / 9.15 / 9.03 ms); a frame that stops after its first slice never grows it; forgotten every 256
+# frames.  Images do not depend on the slicing (bit for bit), gradients up to fp32 summation order.  0: fixed budget.
+SLICE_ADAPT = int(os.environ.get("GSD_SLICE_ADAPT", "1"))
+_slice_hint = {}
+
+
+def _slice_base_for(key) -> int:
+    if not SLICE_ADAPT or SLICE_BASE <= 0:
+        return SLICE_BASE
+    return SLICE_BASE * _slice_hint.get(key, (1, 0))[0]
+
+
+def _slice_feedback(key, n_issued: int):
+    if not SLICE_ADAPT or SLICE_BASE <= 0:
+        return
+    mult, age = _slice_hint.get(key, (1, 0))
+    age += 1
+    if age >= 256:
+        mult, age = 1, 0
+    elif n_issued >= 2 and mult < 4:
+        mult *= 2
+    _slice_hint[key] = (mult, age)
 # gs_frame_forward only: a slice that leaves at least this fraction of its open tiles open makes the next issued slice
 # span twice as many planned ones (a frame whose tiles do not saturate pays ~0.15 ms per slice boundary for nothing);
 # 0 = every planned slice on its own, which is what the Python orchestration does.  Images are the same bit for bit.
@@ -838,11 +862,13 @@ class _RenderSubposes(Function):
             averaged = None
             if gamma is not None:
                 averaged = (float(gamma), float(min_rgb_level) / 255.0, torch.empty(H, W, 3, device=dev))
+            hint_key = (str(dev), N, P, S, H, W)
             for attempt in range(_ARENA_ATTEMPTS):
                 try:
                     out_img, out_T, ctx.frame = native_frame_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges,
-                                                                     SLICE_BASE, color, depth_acc,
+                                                                     _slice_base_for(hint_key), color, depth_acc,
                                                                      any(ctx.needs_input_grad), rs, averaged)
+                    _slice_feedback(hint_key, int(ctx.frame["state"].n_slices))
                     break
                 except _ArenaTooSmall:
                     if attempt == _ARENA_ATTEMPTS - 1:

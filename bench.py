@@ -352,6 +352,7 @@ def main():
     ops.profiler = None
     n_isect = ops.last_num_intersects
     slice_isects = list(ops.last_slice_intersects)
+    slice_budget = ops.SLICE_BASE * max([m for m, _ in ops._slice_hint.values()] or [1])   # (ops.SLICE_ADAPT)
     rows_with_grad = wl.rows_with_gradient()
     # second scene (reported beside the headline, never part of `value`): a fitted-model-like distribution in which
     # a large share of the Gaussians receives a gradient and the depth-sliced path needs several slices
@@ -404,6 +405,8 @@ def main():
             "steps": k2, "tile_intersections_per_step": ops.last_num_intersects,
             "tile_intersections_emitted": int(sum(ops.last_slice_intersects)),
             "depth_slices": list(ops.last_slice_intersects), "gaussians_with_gradient": w2.rows_with_gradient(),
+            # ops.SLICE_ADAPT: the first slice's budget doubles (up to 4x) after a frame that issued two or more slices
+            "slice_budget": ops.SLICE_BASE * max([m for m, _ in ops._slice_hint.values()] or [1]),
             "stage_ms": {k: round(sum(v) / 3, 4) for k, v in st2.items()},
             "roofline": sec_roofline, "train_step": train}
         del w2
@@ -549,6 +552,7 @@ def main():
                        "tile_intersections_per_step": n_isect,
                        "tile_intersections_emitted": int(sum(slice_isects)) if ops.SLICE_BASE > 0 else n_isect,
                        "depth_slices": slice_isects if ops.SLICE_BASE > 0 else None,
+                       "slice_budget": slice_budget,
                        "gaussians_with_gradient": rows_with_grad,
                        "api": ("ops.render_combined + Tensor.backward (torch.autograd)" if args.autograd else
                                "gsdeblur_amd.render_step: forward + backward of the frame in one host call (same C-ABI "

@@ -26,6 +26,10 @@ def gs():
     # the equivalence tests) plugs into ops.frame_backend; with every switch at its default the product path runs
     import python_frame_path
     python_frame_path.install()
+    # the slice budget adapts across frames by default; the tests compare paths at the budget they set themselves
+    # (test_adaptive_slice_budget switches it back on)
+    from gsdeblur_amd import ops
+    ops.SLICE_ADAPT = 0
     return gsdeblur_amd
 
 

@@ -2277,6 +2277,51 @@ def test_shared_list_pixel_velocity_vs_oracle(gs, oracle, dev, S, W, H, n, rt, b
     assert d.mean().item() < 2e-3 and d.max().item() < 0.08
 
 
+def test_adaptive_slice_budget(gs, dev):
+    """ops.SLICE_ADAPT (default on in the product, off in this suite's fixture): a frame that issued two or more depth
+    slices doubles the first slice's budget for the next frames of that shape, up to 4x; a frame that stops after its
+    first slice leaves it alone.  The image does not depend on the slicing (bit for bit), the gradients only through the
+    order of fp32 sums."""
+    from gsdeblur_amd import ops
+    n, W, H, S = 60000, 160, 112, 2
+    sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=23, scale_mult=8.0, profile="trained"), dev)
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, 1, 0.0)
+    vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"], sc["ang_vel"], torch.tensor(times, device=dev))
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+    saved = (ops.SLICE_ADAPT, ops.SLICE_BASE)
+    key = (str(dev), n, S, S, H, W)
+    frames = []
+    try:
+        ops.SLICE_ADAPT, ops.SLICE_BASE = 1, 2
+        ops._slice_hint.pop(key, None)
+        for _ in range(4):
+            p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+            rgb = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["opacity_logits"]),
+                                     p["sh"], vms, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2)[0]
+            (rgb * wt).sum().backward()
+            frames.append((rgb.detach().clone(), {k: v.grad.clone() for k, v in p.items()},
+                           sum(1 for v in ops.last_slice_intersects if int(v) > 0), ops._slice_hint[key][0]))
+        # a scene that needs one slice at the same budget: nothing grows
+        few = to_dev(gs.data.synthetic_scene(300, W, H, seed=5, scale_mult=2.0), dev)
+        key2 = (str(dev), 300, S, S, H, W)
+        ops._slice_hint.pop(key2, None)
+        ops.SLICE_BASE = 512
+        for _ in range(2):
+            gs.render_combined(few["means"], few["log_scales"].exp(), few["quats"], torch.sigmoid(few["opacity_logits"]),
+                               few["sh"], vms, None, S, 1, few["fx"], few["fy"], few["cx"], few["cy"], H, W, gamma=2.2)
+        assert ops._slice_hint[key2][0] == 1
+    finally:
+        ops.SLICE_ADAPT, ops.SLICE_BASE = saved
+        ops._slice_hint.clear()
+    mults, slices = [f[3] for f in frames], [f[2] for f in frames]
+    print("adaptive slice budget: multiplier after each frame", mults, "issued slices", slices)
+    assert mults == [2, 4, 4, 4] and slices[0] >= 3 and slices[-1] < slices[0], (mults, slices)
+    for img, grads, _, _ in frames[1:]:
+        assert torch.equal(img, frames[0][0])
+        for k in grads:
+            assert grad_el_ratio(grads[k].cpu().numpy(), frames[0][1][k].cpu().numpy()) <= 1.0, k
+
+
 def test_model_exact_rolling_shutter_mode(gs, oracle, dev):
     """SplatfactoDeblurConfig(rolling_shutter_mode='exact', motion_model='pixel_velocity'): get_outputs renders with
     the continuous row time (one sub-pose per blur sample: radii is [S, N] whatever rs_bands says) and converges to
