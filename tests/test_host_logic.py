@@ -305,6 +305,41 @@ def test_sparse_exchange_state_is_per_group_and_follows_N(gs):
     gs.dp.reset_sparse_exchange_state()
 
 
+def test_adaptive_slice_budget_schedule(gs):
+    """ops.SLICE_ADAPT, the host-side rule alone: the first slice's budget doubles (up to 4x) after a frame that issued two
+    or more slices, stays after one-slice frames, is keyed by the frame's shape, is forgotten every 256 frames and does
+    nothing when switched off or when slicing itself is off (`-m gpu` twin: test_adaptive_slice_budget)"""
+    from gsdeblur_amd import ops
+    saved = (ops.SLICE_ADAPT, ops.SLICE_BASE, dict(ops._slice_hint))
+    try:
+        ops._slice_hint.clear()
+        ops.SLICE_ADAPT, ops.SLICE_BASE = 1, 512
+        a, b = ("cuda:0", 1000, 5, 5, 64, 64), ("cuda:0", 2000, 5, 5, 64, 64)
+        seen = []
+        for issued in (3, 2, 2, 1, 3):
+            seen.append(ops._slice_base_for(a))
+            ops._slice_feedback(a, issued)
+        assert seen == [512, 1024, 2048, 2048, 2048] and ops._slice_base_for(a) == 2048      # capped at 4x, never shrinks
+        for _ in range(5):
+            ops._slice_feedback(b, 1)
+        assert ops._slice_base_for(b) == 512                                                  # one-slice frames: untouched
+        for _ in range(256):
+            ops._slice_feedback(a, 1)
+        assert ops._slice_base_for(a) == 512                                                  # forgotten, re-learnt later
+        ops._slice_feedback(a, 4)
+        assert ops._slice_base_for(a) == 1024
+        ops.SLICE_ADAPT = 0
+        assert ops._slice_base_for(a) == 512
+        ops._slice_feedback(a, 4)
+        assert ops._slice_hint[a][0] == 2                                                     # off: no bookkeeping either
+        ops.SLICE_ADAPT, ops.SLICE_BASE = 1, 0
+        assert ops._slice_base_for(a) == 0                                                    # one slice for everything
+    finally:
+        ops.SLICE_ADAPT, ops.SLICE_BASE = saved[0], saved[1]
+        ops._slice_hint.clear()
+        ops._slice_hint.update(saved[2])
+
+
 def test_bench_launcher_argv_and_world_check():
     """`python bench.py --gpus N` without a launcher re-executes itself under
     torch.distributed.run with one rank per GPU on 127.0.0.1; a rank whose WORLD_SIZE disagrees with --gpus exits"""
