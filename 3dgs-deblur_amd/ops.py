@@ -32,9 +32,9 @@ MAX_SUBPOSES = 256   # blur samples x rolling-shutter bands per frame (SliceDesc
 # slice); 0 disables slicing (single pass over all intersections)
 SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "512"))
 # the budget adapts across frames of one shape: a frame that issued two or more slices doubles it for the next ones, up
-# to 4x (a scene whose tiles do not saturate pays ~0.15 ms per slice boundary for nothing: fitted-model-like bench scene,
-# 512 / 1024 / 2048: 9.35 / 9.15 / 9.03 ms); a frame that stops after its first slice never grows it; forgotten every 256
-# frames.  Images do not depend on the slicing (bit for bit), gradients up to fp32 summation order.  0: fixed budget.
+# to 8x (a scene whose tiles do not saturate pays ~0.15 ms per slice boundary for nothing: fitted-model-like bench scene,
+# 512 / 1024 / 2048 / 4096 / 8192: 9.35 / 9.15 / 9.05 / 8.8 / 9.1 ms); a frame that stops after its first slice never grows
+# it; forgotten every 256 frames.  Images do not depend on the slicing (bit for bit), gradients up to fp32 summation order.
 SLICE_ADAPT = int(os.environ.get("GSD_SLICE_ADAPT", "1"))
 _slice_hint = {}
 
@@ -52,7 +52,7 @@ def _slice_feedback(key, n_issued: int):
     age += 1
     if age >= 256:
         mult, age = 1, 0
-    elif n_issued >= 2 and mult < 4:
+    elif n_issued >= 2 and mult < 8:
         mult *= 2
     _slice_hint[key] = (mult, age)
 # gs_frame_forward only: a slice that leaves at least this fraction of its open tiles open makes the next issued slice

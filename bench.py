@@ -405,7 +405,7 @@ def main():
             "steps": k2, "tile_intersections_per_step": ops.last_num_intersects,
             "tile_intersections_emitted": int(sum(ops.last_slice_intersects)),
             "depth_slices": list(ops.last_slice_intersects), "gaussians_with_gradient": w2.rows_with_gradient(),
-            # ops.SLICE_ADAPT: the first slice's budget doubles (up to 4x) after a frame that issued two or more slices
+            # ops.SLICE_ADAPT: the first slice's budget doubles (up to 8x) after a frame that issued two or more slices
             "slice_budget": ops.SLICE_BASE * max([m for m, _ in ops._slice_hint.values()] or [1]),
             "stage_ms": {k: round(sum(v) / 3, 4) for k, v in st2.items()},
             "roofline": sec_roofline, "train_step": train}

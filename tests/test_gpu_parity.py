@@ -2279,7 +2279,7 @@ def test_shared_list_pixel_velocity_vs_oracle(gs, oracle, dev, S, W, H, n, rt, b
 
 def test_adaptive_slice_budget(gs, dev):
     """ops.SLICE_ADAPT (default on in the product, off in this suite's fixture): a frame that issued two or more depth
-    slices doubles the first slice's budget for the next frames of that shape, up to 4x; a frame that stops after its
+    slices doubles the first slice's budget for the next frames of that shape, up to 8x; a frame that stops after its
     first slice leaves it alone.  The image does not depend on the slicing (bit for bit), the gradients only through the
     order of fp32 sums."""
     from gsdeblur_amd import ops
@@ -2315,7 +2315,7 @@ def test_adaptive_slice_budget(gs, dev):
         ops._slice_hint.clear()
     mults, slices = [f[3] for f in frames], [f[2] for f in frames]
     print("adaptive slice budget: multiplier after each frame", mults, "issued slices", slices)
-    assert mults == [2, 4, 4, 4] and slices[0] >= 2, (mults, slices)
+    assert mults == [2, 4, 8, 8] and slices[0] >= 2, (mults, slices)
     for img, grads, _, _ in frames[1:]:
         assert torch.equal(img, frames[0][0])
         for k in grads:

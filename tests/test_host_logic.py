@@ -306,7 +306,7 @@ def test_sparse_exchange_state_is_per_group_and_follows_N(gs):
 
 
 def test_adaptive_slice_budget_schedule(gs):
-    """ops.SLICE_ADAPT, the host-side rule alone: the first slice's budget doubles (up to 4x) after a frame that issued two
+    """ops.SLICE_ADAPT, the host-side rule alone: the first slice's budget doubles (up to 8x) after a frame that issued two
     or more slices, stays after one-slice frames, is keyed by the frame's shape, is forgotten every 256 frames and does
     nothing when switched off or when slicing itself is off (`-m gpu` twin: test_adaptive_slice_budget)"""
     from gsdeblur_amd import ops
@@ -319,7 +319,7 @@ def test_adaptive_slice_budget_schedule(gs):
         for issued in (3, 2, 2, 1, 3):
             seen.append(ops._slice_base_for(a))
             ops._slice_feedback(a, issued)
-        assert seen == [512, 1024, 2048, 2048, 2048] and ops._slice_base_for(a) == 2048      # capped at 4x, never shrinks
+        assert seen == [512, 1024, 2048, 4096, 4096] and ops._slice_base_for(a) == 4096      # capped at 8x, never shrinks
         for _ in range(5):
             ops._slice_feedback(b, 1)
         assert ops._slice_base_for(b) == 512                                                  # one-slice frames: untouched
