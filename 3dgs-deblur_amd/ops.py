@@ -40,21 +40,15 @@ _slice_hint = {}
 
 
 def _slice_base_for(key) -> int:
-    if not SLICE_ADAPT or SLICE_BASE <= 0:
-        return SLICE_BASE
-    return SLICE_BASE * _slice_hint.get(key, (1, 0))[0]
+    return SLICE_BASE * (_slice_hint.get(key, (1, 0))[0] if SLICE_ADAPT and SLICE_BASE > 0 else 1)
 
 
 def _slice_feedback(key, n_issued: int):
-    if not SLICE_ADAPT or SLICE_BASE <= 0:
-        return
-    mult, age = _slice_hint.get(key, (1, 0))
-    age += 1
-    if age >= 256:
-        mult, age = 1, 0
-    elif n_issued >= 2 and mult < 8:
-        mult *= 2
-    _slice_hint[key] = (mult, age)
+    if SLICE_ADAPT and SLICE_BASE > 0:
+        mult, age = _slice_hint.get(key, (1, 0))
+        _slice_hint[key] = (1, 0) if age >= 255 else (mult * 2 if n_issued >= 2 and mult < 8 else mult, age + 1)
+
+
 # gs_frame_forward only: a slice that leaves at least this fraction of its open tiles open makes the next issued slice
 # span twice as many planned ones (a frame whose tiles do not saturate pays ~0.15 ms per slice boundary for nothing);
 # 0 = every planned slice on its own, which is what the Python orchestration does.  Images are the same bit for bit.
@@ -711,7 +705,8 @@ class _SubposeViewmats(Function):
         V, lin, ang, times = ctx.saved_tensors
         P = times.numel()
         dev = V.device
-        acc = torch.zeros(22, device=dev)                  # one fill for the three accumulators
+        acc = getattr(ctx, "acc", None)                     # (render_step: part of the frame's one zero fill)
+        acc = torch.zeros(22, device=dev) if acc is None else acc
         v_V, v_lin, v_ang = acc[:16].view(4, 4), acc[16:19], acc[19:22]
         _check(_L().gs_subpose_viewmats_bwd(P, _ptr(V), _ptr(lin), _ptr(ang), _ptr(times),
                                             _ptr(v_out.contiguous().float()), _ptr(v_V), _ptr(v_lin), _ptr(v_ang),
@@ -847,7 +842,7 @@ class _RenderSubposes(Function):
         color = (means3d, sh, sh_rest, K, args[4], V_col) if (defer_flags & 1) else None
         # optional fourth channel: sum of weight * camera-space depth per sample image (forward only)
         depth_acc = torch.zeros(S, H, W, device=dev) if return_depth else None
-        ctx.prealloc = None
+        ctx.prealloc = ctx.sub_acc = None
         ctx.frame = None
         ctx.backend = backend
         if backend is None:
@@ -855,9 +850,15 @@ class _RenderSubposes(Function):
                 raise ValueError("exact rolling shutter renders with rs_bands == 1")
             # the backward's frame-sized buffers (and the one fill among them) are issued BEFORE the frame: behind the
             # frame's last read-back nothing but the averaging and the backward's own launches are left for the host
-            ctx.prealloc = ({"touched": torch.zeros(P * N, dtype=torch.uint8, device=dev),
-                             "v_records": torch.empty(P * N, GRAD, device=dev)}
-                            if any(ctx.needs_input_grad) else None)
+            if any(ctx.needs_input_grad):
+                # ONE zero fill for everything the backward accumulates into: touched flags [P*N] u8 | 16 P + 12 floats of
+                # view-matrix / twist gradients | 22 floats for the sub-pose backward (step.render_step hands them on)
+                t_len = (P * N + 15) // 16 * 16
+                zbuf = torch.zeros(t_len + 4 * (16 * P + 12 + 22), dtype=torch.uint8, device=dev)
+                zf = zbuf[t_len:].view(torch.float32)
+                ctx.prealloc = {"touched": zbuf[:P * N], "v_records": torch.empty(P * N, GRAD, device=dev),
+                                "v_V": zf[:16 * P], "v_tw": zf[16 * P:16 * P + 12]}
+                ctx.sub_acc = zf[16 * P + 12:]
             # fused sub-frame averaging: the library launches it behind the last compositor (below: `averaged`)
             averaged = None
             if gamma is not None:
@@ -982,9 +983,9 @@ class _RenderSubposes(Function):
         with _stage("project_bwd"):
             if ctx.pixvel is not None:
                 twist, times = ctx.pixvel
-                v_V = torch.zeros(4, 4, device=dev) if need_v else None
+                v_V = (pre["v_V"][:16].view(4, 4) if "v_V" in pre else torch.zeros(4, 4, device=dev)) if need_v else None
                 need_tw = ctx.needs_input_grad[23] or ctx.needs_input_grad[24]
-                v_tw = torch.zeros(12, device=dev) if need_tw else None
+                v_tw = (pre["v_tw"] if "v_tw" in pre else torch.zeros(12, device=dev)) if need_tw else None
                 _check(L.gs_project_pixvel_bwd(N, P, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(opacities),
                                                _ptr(sh), K, deg, _ptr(V), _ptr(twist), _ptr(times), fx, fy, cx, cy, H, W,
                                                clip, aa, _ptr(records), _ptr(v_records), _ptr(v_means), _ptr(v_scales),
@@ -996,7 +997,7 @@ class _RenderSubposes(Function):
                 if v_tw is not None:
                     v_lin, v_ang = v_tw[0:3], v_tw[3:6]
             else:
-                v_V = torch.zeros(P, 4, 4, device=dev) if need_v else None
+                v_V = (pre["v_V"].view(P, 4, 4) if "v_V" in pre else torch.zeros(P, 4, 4, device=dev)) if need_v else None
                 _check(L.gs_project_fused_bwd(N, P, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(opacities),
                                               _ptr(sh), K, deg, _ptr(V), fx, fy, cx, cy, H, W, clip, aa, _ptr(records),
                                               _ptr(v_records), _ptr(v_means), _ptr(v_scales), _ptr(v_quats),
