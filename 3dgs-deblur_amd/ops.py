@@ -705,8 +705,7 @@ class _SubposeViewmats(Function):
         V, lin, ang, times = ctx.saved_tensors
         P = times.numel()
         dev = V.device
-        acc = getattr(ctx, "acc", None)                     # (render_step: part of the frame's one zero fill)
-        acc = torch.zeros(22, device=dev) if acc is None else acc
+        acc = torch.zeros(22, device=dev)                  # one fill for the three accumulators
         v_V, v_lin, v_ang = acc[:16].view(4, 4), acc[16:19], acc[19:22]
         _check(_L().gs_subpose_viewmats_bwd(P, _ptr(V), _ptr(lin), _ptr(ang), _ptr(times),
                                             _ptr(v_out.contiguous().float()), _ptr(v_V), _ptr(v_lin), _ptr(v_ang),
@@ -842,7 +841,7 @@ class _RenderSubposes(Function):
         color = (means3d, sh, sh_rest, K, args[4], V_col) if (defer_flags & 1) else None
         # optional fourth channel: sum of weight * camera-space depth per sample image (forward only)
         depth_acc = torch.zeros(S, H, W, device=dev) if return_depth else None
-        ctx.prealloc = ctx.sub_acc = None
+        ctx.prealloc = None
         ctx.frame = None
         ctx.backend = backend
         if backend is None:
@@ -851,14 +850,13 @@ class _RenderSubposes(Function):
             # the backward's frame-sized buffers (and the one fill among them) are issued BEFORE the frame: behind the
             # frame's last read-back nothing but the averaging and the backward's own launches are left for the host
             if any(ctx.needs_input_grad):
-                # ONE zero fill for everything the backward accumulates into: touched flags [P*N] u8 | 16 P + 12 floats of
-                # view-matrix / twist gradients | 22 floats for the sub-pose backward (step.render_step hands them on)
+                # ONE zero fill for what this node's backward accumulates into: touched flags [P*N] u8 | 16 P + 12 floats
+                # of view-matrix / twist gradients
                 t_len = (P * N + 15) // 16 * 16
-                zbuf = torch.zeros(t_len + 4 * (16 * P + 12 + 22), dtype=torch.uint8, device=dev)
+                zbuf = torch.zeros(t_len + 4 * (16 * P + 12), dtype=torch.uint8, device=dev)
                 zf = zbuf[t_len:].view(torch.float32)
                 ctx.prealloc = {"touched": zbuf[:P * N], "v_records": torch.empty(P * N, GRAD, device=dev),
                                 "v_V": zf[:16 * P], "v_tw": zf[16 * P:16 * P + 12]}
-                ctx.sub_acc = zf[16 * P + 12:]
             # fused sub-frame averaging: the library launches it behind the last compositor (below: `averaged`)
             averaged = None
             if gamma is not None:

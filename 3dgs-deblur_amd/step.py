@@ -78,6 +78,5 @@ def render_step(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor,
     if pixvel:
         grads["viewmat"], grads["lin_vel"], grads["ang_vel"] = g[5], g[23], g[24]
     elif camera_grads and g[5] is not None:
-        sub_ctx.acc = ctx.sub_acc
         grads["viewmat"], grads["lin_vel"], grads["ang_vel"], _ = ops._SubposeViewmats.backward(sub_ctx, g[5])
     return rgb, grads, radii
