@@ -67,3 +67,38 @@ def test_missing_library_raises(gs, monkeypatch, tmp_path):
     monkeypatch.setattr(gs._lib, "LIB_PATH", tmp_path / "nope.so")
     with pytest.raises(gs._lib.HipLibraryError):
         gs._lib.load(build_if_missing=False)
+
+
+def test_frame_structs_match_the_header_layout(gs, tmp_path):
+    """the ctypes mirrors of gs_frame_desc / gs_frame_slice / gs_frame_state (ops.py) against the C header itself: a tiny C
+    program compiled with gcc prints sizeof and the offset of every field; a field added on one side only (round 4 added
+    shared_list and the combine fields) shows up here, on CPU, instead of as a corrupted frame on the GPU"""
+    import ctypes
+    import shutil
+    import subprocess
+    from gsdeblur_amd import ops
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    structs = {"gs_frame_desc": ops._FrameDesc, "gs_frame_slice": ops._FrameSlice, "gs_frame_state": ops._FrameState}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT / "include" / "gsdeblur.h"}"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-o", str(exe), str(src)])
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), (cname, got[cname], ctypes.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+    # and the header has no field the mirrors lack: count the members between the braces
+    hdr = (ROOT / "include" / "gsdeblur.h").read_text()
+    for cname, cls in structs.items():
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        n_members = sum(len(decl.split(",")) for decl in body.split(";") if decl.strip())
+        assert n_members == len(cls._fields_), (cname, n_members, len(cls._fields_))
