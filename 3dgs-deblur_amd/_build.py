@@ -59,6 +59,19 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+def kernel_source_hash() -> str:
+    """content hash of what the DEVICE code is compiled from: csrc/*.hip, csrc/*.h and the compiler flags — not the public
+    header's prototypes and comments, not this file's text.  Gates the PMC-derived numbers of profiles/traffic.json
+    (bench.py roofline.traffic / roofline.valu): they stay valid across a header-only change."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.h")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    h.update(repr((SOURCES, COMMON)).encode())
+    return h.hexdigest()
+
+
 def is_current() -> bool:
     """True when the in-tree library exists and was built from exactly the sources that are on disk now (content,
     not mtime: a repository snapshot copied to another box keeps the bytes but not necessarily the timestamps)"""

@@ -32,6 +32,14 @@ DOMINANT_STAGE = "raster_bwd"   # the kernel the roofline is quoted on (checked 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
+def _counters_current(tj, build) -> bool:
+    """profiles/traffic.json was measured on the kernel sources that are on disk now (csrc + flags; a file from before
+    round 4's kernel_source_hash is gated on the hash of the whole library source, public header included)"""
+    if "kernel_source_hash" in tj:
+        return tj["kernel_source_hash"] == build.kernel_source_hash()
+    return tj.get("lib_source_hash") == build.source_hash()
+
+
 def make_scene(n, W, H, seed=1234, profile="survey"):
     from gsdeblur_amd import data
     return data.synthetic_scene(n, W, H, sh_degree=3, seed=seed, profile=profile)
@@ -477,7 +485,7 @@ def main():
             try:
                 tj = json.loads(tfile.read_text())
                 from gsdeblur_amd import _build as _gsd_build
-                if tj.get("workload") == [N, W, H, S, R] and tj.get("lib_source_hash") == _gsd_build.source_hash():
+                if tj.get("workload") == [N, W, H, S, R] and _counters_current(tj, _gsd_build):
                     traffic = tj["hbm_bytes_per_step"].get(kname)
             except Exception:
                 traffic = None
@@ -489,9 +497,9 @@ def main():
             tj = json.loads(tfile.read_text()) if tfile.exists() else {}
             vi = tj.get("valu", {}).get(kname)
             from gsdeblur_amd import _build as _gsd_build
-            fresh = tj.get("lib_source_hash") == _gsd_build.source_hash()
+            fresh = _counters_current(tj, _gsd_build)
             if vi and tj.get("workload") == [N, W, H, S, R] and not fresh:
-                valu = {"stale": "profiles/traffic.json was measured on other kernel sources (lib_source_hash differs): "
+                valu = {"stale": "profiles/traffic.json was measured on other kernel sources (kernel_source_hash differs): "
                                  "re-run tools/gpu_visit.sh <tag> pmc"}
             elif vi and tj.get("workload") == [N, W, H, S, R]:
                 simd_cycles = single[dom] * 1e-3 * tj["valu"].get("clock_hz", 2.1e9) * 1024 / max(1.0, launches.get(dom, 1.0))

@@ -64,7 +64,11 @@ int gs_project_bwd(int N, const float* means3d, const float* scales, float glob_
                    const float* viewmat, float fx, float fy, float cx, float cy, int img_height,
                    int img_width, float clip_thresh, const float* v_xys, const float* v_depths,
                    const float* v_conics, const float* v_comp, float* v_means3d, float* v_scales,
-                   float* v_quats, float* v_viewmat, void* stream);
+                   float* v_quats, float* v_viewmat,
+                   int grad_flags /*bit 0: back-propagate through the fov clamp as if inactive, bit 1: quaternion gradient
+                                    without the projection through q/|q| (gsplat 0.1.11's conventions);
+                                    0 = the true derivatives*/,
+                   void* stream);
 
 /* ---- gsplat.spherical_harmonics (upstream _C.compute_sh_forward/backward) ----
  * coeffs [N, K_stride, 3]; uses the first (degrees_to_use+1)^2 bases; dirs are normalised inside. */

@@ -102,3 +102,93 @@ def test_frame_structs_match_the_header_layout(gs, tmp_path):
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         n_members = sum(len(decl.split(",")) for decl in body.split(";") if decl.strip())
         assert n_members == len(cls._fields_), (cname, n_members, len(cls._fields_))
+
+
+def test_ctypes_signatures_match_the_header_prototypes(gs):
+    """_lib._SIGS (the ctypes argtypes of every entry point the Python side calls) against the prototypes in
+    include/gsdeblur.h: same number of parameters, and the same KIND in every position — pointer / int-like / float /
+    long long.  A parameter added to the header and not to the table (round 4 added nine) would otherwise shift every
+    later argument by one register on the GPU box, where it shows as a wrong picture or a fault."""
+    import ctypes
+    from gsdeblur_amd import _lib
+    hdr = (ROOT / "include" / "gsdeblur.h").read_text()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hdr = re.sub(r"//[^\n]*", "", hdr)
+    protos = {}
+    for m in re.finditer(r"\b(gs_\w+)\s*\(([^;{}]*?)\)\s*;", hdr):
+        params = [p.strip() for p in m.group(2).split(",")]
+        protos[m.group(1)] = [] if params in ([""], ["void"]) else params
+
+    def kind_of_param(p):
+        if "*" in p:
+            return "ptr"
+        if re.search(r"\bdouble\b", p):
+            return "double"
+        if re.search(r"\bfloat\b", p):
+            return "float"
+        if re.search(r"\blong long\b", p):
+            return "longlong"
+        if re.search(r"\b(int|unsigned)\b", p):
+            return "int"
+        raise AssertionError(f"unclassified parameter {p!r}")
+
+    def kind_of_ctype(t):
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or isinstance(t, type(ctypes.POINTER(ctypes.c_int))) and issubclass(t, ctypes._Pointer):
+            return "ptr"
+        if t is ctypes.c_double:
+            return "double"
+        if t is ctypes.c_float:
+            return "float"
+        if t in (ctypes.c_longlong, ctypes.c_ulonglong):
+            return "longlong"
+        if t in (ctypes.c_int, ctypes.c_uint):
+            return "int"
+        raise AssertionError(f"unclassified ctype {t!r}")
+    assert len(_lib._SIGS) >= 50
+    for name, argtypes in _lib._SIGS.items():
+        assert name in protos, f"{name} is bound by _lib.py but not declared in the header"
+        want = [kind_of_param(p) for p in protos[name]]
+        got = [kind_of_ctype(t) for t in argtypes]
+        assert got == want, (name, [(i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w], len(got), len(want))
+
+
+def test_definitions_match_the_header_prototypes():
+    """every `GS_EXPORT ... gs_*(...) {` definition in csrc/*.hip against its prototype in include/gsdeblur.h: parameter
+    count and kind (pointer / int / long long / float / double) position by position.  extern "C" symbols carry no
+    signature, so a definition that drifts from the header links and loads — and breaks the first C caller that trusts
+    the header (round 4 found gs_project_bwd's grad_flags missing from it this way)."""
+    def strip(txt):
+        return re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", txt, flags=re.S))
+
+    def kinds(params):
+        out = []
+        for p in params:
+            if "*" in p:
+                out.append("ptr")
+            elif re.search(r"\bdouble\b", p):
+                out.append("double")
+            elif re.search(r"\bfloat\b", p):
+                out.append("float")
+            elif re.search(r"\blong long\b", p):
+                out.append("longlong")
+            elif re.search(r"\b(int|unsigned)\b", p):
+                out.append("int")
+            else:
+                raise AssertionError(f"unclassified parameter {p!r}")
+        return out
+
+    def split(arglist):
+        ps = [p.strip() for p in arglist.split(",")]
+        return [] if ps in ([""], ["void"]) else ps
+    hdr = strip((ROOT / "include" / "gsdeblur.h").read_text())
+    protos = {m.group(1): kinds(split(m.group(2))) for m in re.finditer(r"\b(gs_\w+)\s*\(([^;{}]*?)\)\s*;", hdr)}
+    n = 0
+    for f in sorted((ROOT / "3dgs-deblur_amd" / "csrc").glob("*.hip")):
+        src = strip(f.read_text())
+        for m in re.finditer(r"GS_EXPORT\s+[\w\s\*]+?\b(gs_\w+)\s*\(([^{};]*?)\)\s*\{", src):
+            name, got = m.group(1), kinds(split(m.group(2)))
+            assert name in protos, f"{name} ({f.name}) is exported but not declared in the header"
+            assert got == protos[name], (name, f.name, len(got), len(protos[name]),
+                                         [(i, a, b) for i, (a, b) in enumerate(zip(got, protos[name])) if a != b])
+            n += 1
+    assert n == len(protos) == 63, (n, len(protos))

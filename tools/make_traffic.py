@@ -76,13 +76,14 @@ def _lib_hash():
     spec = importlib.util.spec_from_file_location("_gsd_build", Path(__file__).resolve().parents[1] / "3dgs-deblur_amd" / "_build.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.source_hash()
+    return mod.source_hash(), mod.kernel_source_hash()
 
 
 doc = {
     "workload": [1000000, 1920, 1080, 5, 1],
     # the kernels these counters were measured on: bench.py only quotes them while the sources still hash to this
-    "lib_source_hash": _lib_hash(),
+    "lib_source_hash": _lib_hash()[0],
+    "kernel_source_hash": _lib_hash()[1],       # csrc + flags: what bench.py gates roofline.traffic / .valu on
     "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), {tag}; "
               "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per launch: FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section "
               "(gfx950 counts 128-B requests as 64 B), WRITE_SIZE uncalibrated; tools/make_traffic.py",
