@@ -192,3 +192,28 @@ def test_definitions_match_the_header_prototypes():
                                          [(i, a, b) for i, (a, b) in enumerate(zip(got, protos[name])) if a != b])
             n += 1
     assert n == len(protos) == 63, (n, len(protos))
+
+
+def test_every_call_site_passes_as_many_arguments_as_the_signature_has():
+    """static check of the Python side: every `<lib>.gs_*(...)` call in the package, the test twin, bench.py and the tools
+    passes exactly as many positional arguments as `_lib._SIGS` (and therefore the header) declares — ctypes would only
+    say so at run time, on the GPU box, and only for the call sites a test happens to reach"""
+    import ast
+    import sys
+    sys.path.insert(0, str(ROOT))
+    from gsdeblur_amd import _lib
+    files = sorted((ROOT / "3dgs-deblur_amd").glob("*.py")) + [ROOT / "tests" / "python_frame_path.py", ROOT / "bench.py",
+                                                               ROOT / "__graft_entry__.py"] + \
+        sorted((ROOT / "tools").glob("*.py")) + sorted((ROOT / "tests").glob("test_*.py"))
+    n = 0
+    for f in files:
+        tree = ast.parse(f.read_text())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr.startswith("gs_"):
+                name = node.func.attr
+                if name not in _lib._SIGS or node.keywords or any(isinstance(a, ast.Starred) for a in node.args):
+                    continue
+                assert len(node.args) == len(_lib._SIGS[name]), (f.name, node.lineno, name, len(node.args),
+                                                                 len(_lib._SIGS[name]))
+                n += 1
+    assert n >= 60, n
