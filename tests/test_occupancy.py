@@ -36,8 +36,9 @@ def _metadata(asm: str):
     return out
 
 
-@pytest.mark.timeout(900)
-def test_hot_kernels_stay_inside_their_register_budgets(tmp_path):
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    """source name -> assembly text, compiled with the library's own flags"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("_gsd_build", ROOT / "3dgs-deblur_amd" / "_build.py")
     B = importlib.util.module_from_spec(spec)
@@ -46,12 +47,21 @@ def test_hot_kernels_stay_inside_their_register_budgets(tmp_path):
     if shutil.which(hipcc) is None or shutil.which("c++filt") is None:
         pytest.skip("no hipcc / c++filt on this host")
     flags = dict(B.SOURCES)
+    d = tmp_path_factory.mktemp("asm")
+    out = {}
+    for src in sorted({s for s, _ in BUDGET}):
+        f = d / (src + ".s")
+        subprocess.check_call([hipcc, *B.COMMON, *flags[src], "-S", "--cuda-device-only", str(B.CSRC / src), "-o", str(f)],
+                              stderr=subprocess.DEVNULL)
+        out[src] = f.read_text()
+    return out
+
+
+@pytest.mark.timeout(900)
+def test_hot_kernels_stay_inside_their_register_budgets(asm):
     seen = {}
     for src in sorted({s for s, _ in BUDGET}):
-        out = tmp_path / (src + ".s")
-        subprocess.check_call([hipcc, *B.COMMON, *flags[src], "-S", "--cuda-device-only", str(B.CSRC / src), "-o", str(out)],
-                              stderr=subprocess.DEVNULL)
-        meta = _metadata(out.read_text())
+        meta = _metadata(asm[src])
         names = list(meta)
         demangled = subprocess.check_output(["c++filt"], input="\n".join(names), text=True).splitlines()
         for mangled, dem in zip(names, demangled):
@@ -65,3 +75,30 @@ def test_hot_kernels_stay_inside_their_register_budgets(tmp_path):
             assert vgpr <= max_vgpr, (frag, vgpr, max_vgpr)
             assert may_spill or spill == 0, (frag, spill)
     print("\n".join(report))
+
+
+@pytest.mark.timeout(900)
+def test_compositor_inner_loops_keep_their_instruction_counts(asm):
+    """the VALU instructions of one trip of the compositors' hot loops (a group of four list entries; tools/valu_mix.py's
+    loop finder and profiles/r04_valu_mix.txt's numbers: forward 221, backward 599): round 4's work on them was removing
+    instructions the compiler adds when a branch merges values (8-30 v_mov per entry at one point) — a change that brings
+    them back shows here, not in a stage time a visit later"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("valu_mix", ROOT / "tools" / "valu_mix.py")
+    VM = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(VM)
+    limits = {("raster.hip", "_ZN2gs23raster_fwd_sload_kernelILb0EEE"): 232,
+              ("raster_bwd.hip", "_ZN2gs23raster_bwd_sload_kernelILb0ELi1EEE"): 625}
+    for (src, prefix), limit in limits.items():
+        m = re.search(r"^(%s\w*):[^\n]*\n(.*?)\.Lfunc_end" % prefix, asm[src], flags=re.S | re.M)
+        assert m, prefix
+        lines, ls = VM.loops(m.group(2))
+        ls = [r for r in ls if r[1] - r[0] < 1500]
+
+        def score(r):
+            return sum(1 for ln in lines[r[0]:r[1] + 1] if ln.strip().startswith(("v_exp", "v_rcp")))
+        a, b = max(ls, key=lambda r: (score(r), -(r[1] - r[0])))
+        n_valu = sum(1 for ln in lines[a:b + 1] if ln.strip() and not ln.strip().startswith((";", "."))
+                     and VM.classify(ln.strip()) is not None)
+        print(f"{prefix}: {n_valu} VALU instructions per group of four entries (limit {limit})")
+        assert n_valu <= limit, (prefix, n_valu, limit)
