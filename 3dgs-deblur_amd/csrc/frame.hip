@@ -266,6 +266,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   if (d.N <= 0 || d.P <= 0 || d.S <= 0 || d.R <= 0 || d.H <= 0 || d.W <= 0 || d.P > 256 || d.S > 256) return GS_ERR_INVALID;
   if (shared ? (d.P != 1 || d.R != 1 || !pix_vel || !sample_times) : (d.P != d.S * d.R)) return GS_ERR_INVALID;
   if (d.R > 1 && !band_tile_done) return GS_ERR_INVALID;
+  if ((long long)d.S * d.H * d.W >= (1ll << 30)) return GS_ERR_INVALID;   // 32-bit byte offsets into [S,H,W] (raster.hip)
   // exact per-row rolling shutter (pixel-velocity model, raster_rs.hip) and shared-list frames: the records' tile boxes
   // are swept boxes, so the lists are built from the boxes themselves (no ellipse test, no hit masks) and the rs
   // compositors run
@@ -449,6 +450,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
     while (k1 > k + 1 && I_k >= 2147483647ll - kIdsPad) merged(k, --k1, beg_s, pre_s, n_k, I_k);
     const bool first = k == 0, last = k1 == K;
     if (I_k >= 2147483647ll - kIdsPad) return GS_ERR_INVALID;        // a slice list is indexed with 31 bits: lower slice_base
+    if (shared && I_k * (long long)S >= 4294967296ll) return GS_ERR_INVALID;   // 32-bit tuple offsets (entry * S)
     if (!fits(n_k, I_k, k1)) return GS_ERR_WORKSPACE;
     maxI_issued = std::max(maxI_issued, I_k);
     unsigned *slice_gi = nullptr, *counts = nullptr, *cum_k = nullptr, *total_k = nullptr, *mask_off = nullptr;

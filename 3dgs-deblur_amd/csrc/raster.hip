@@ -628,6 +628,8 @@ GS_EXPORT int gs_rasterize_fwd_slice(const float* records, const int* sorted_val
                                      const int* sorted_ids, int n_records, float* out_depth,
                                      const unsigned char* tile_hot, int* open_flag, int variant, void* stream) {
   if (S <= 0 || R <= 0 || H <= 0 || W <= 0) return GS_ERR_INVALID;
+  // the stop-index store of the scalar-cache compositor forms a 32-bit BYTE offset into final_idx [S,H,W]
+  if ((long long)S * H * W >= (1ll << 30)) return GS_ERR_INVALID;
   RasterParams prm = make_raster_params(records, sorted_vals, tile_bins, band_edges, background, S, R, H, W);
   prm.gi_of_e = gi_of_e;
   SliceState st; st.tile_done = tile_done; st.live_T = live_T; st.first = first; st.last = last; st.open_flag = open_flag;

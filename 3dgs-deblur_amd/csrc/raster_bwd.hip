@@ -789,6 +789,8 @@ GS_EXPORT int gs_reduce_grad_tuples(int n_slice, const unsigned* slice_gi, const
                                     float* v_records, unsigned char* touched, long long n_isect, const float* records,
                                     int tuples_per_entry, void* stream) {
   if (n_slice <= 0 || !records || tuples_per_entry < 1) return GS_ERR_INVALID;
+  // the kernels index tuples and flags with 32-bit (entry * tuples_per_entry) offsets
+  if (n_isect > 0 && n_isect * (long long)tuples_per_entry >= 4294967296ll) return GS_ERR_INVALID;
   const unsigned mult = (unsigned)tuples_per_entry;
   if (n_isect > 32ll * n_slice)    // few large Gaussians: one wave each
     hipLaunchKernelGGL(reduce_tuples_wave_kernel, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream, n_slice,

@@ -72,12 +72,24 @@ __global__ __launch_bounds__(256) void raster_fwd_rs_kernel(RasterParams prm, Rs
   const int s = work / T, t = work % T;
   const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
   const size_t tkey = (size_t)s * T + t;                      // R == 1: sub-pose = sample
-  if (!st.first && st.tile_done[tkey]) return;
   const bool shared = rs.times != nullptr;                    // all samples walk sub-pose 0's list
-  const float t_s = shared ? rs.times[s] : 0.f;
   int2 range = prm.tile_bins[shared ? (size_t)t : tkey];
   range.x = __builtin_amdgcn_readfirstlane(range.x);
   range.y = __builtin_amdgcn_readfirstlane(range.y);
+  if (!st.first && st.tile_done[tkey]) {
+    // A finished (sample, tile) of a SHARED list: the tile's list still receives entries while any other sample's tile
+    // is open (the binning sees the AND over the samples), so this slice's backward walks a non-empty range for this
+    // sample too and reads this slice's stop indices — which are fresh, never memset arena memory.
+    // Every pixel stopped before this slice: its stop index is the slice's first entry.
+    if (shared) {
+      const int qx = tx * K::kTile + (lane & 15), qy0 = ty * K::kTile + (lane >> 4) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (qx < prm.W && (qy0 + k) < prm.H) final_idx[((size_t)s * prm.H + (qy0 + k)) * prm.W + qx] = range.x;
+    }
+    return;
+  }
+  const float t_s = shared ? rs.times[s] : 0.f;
   if (!st.first && !st.last && range.y <= range.x) {
     if (st.open_flag && lane == 0) atomicAdd(st.open_flag, 1);
     return;
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(256) void raster_bwd_rs_kernel(
     if (px < prm.W && y < prm.H) {
       const size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
       const float Tfin = out_T[pix];
-      fin[k] = final_idx[pix];
+      fin[k] = min(max(final_idx[pix], range.x), range.y);   // a stop index never leaves the tile's list
       vr[k] = v_img[pix * 3 + 0]; vg[k] = v_img[pix * 3 + 1]; vb[k] = v_img[pix * 3 + 2];
       if (prm.cmb_scale) {
         const size_t q = ((size_t)y * prm.W + px) * 3;

@@ -31,34 +31,41 @@ def _need_cuda(t: Tensor, name: str) -> Tensor:
     return t.contiguous()
 
 
+def image_loss_with_grad(pred: Tensor, gt: Tensor, ssim_lambda: float = 0.2):
+    """-> (loss [], d loss / d pred [H,W,3], parts [2] = {mean |gt - pred|, mean SSIM}): ONE pass of the two tile kernels
+    produces the value and the gradient (what step.render_step's grad_image callable returns)."""
+    pred, gt = _need_cuda(pred, "pred"), _need_cuda(gt, "gt")
+    if pred.dim() != 3 or pred.shape[-1] != 3 or gt.shape != pred.shape:
+        raise ValueError("pred and gt must both be [H,W,3]")
+    H, W = int(pred.shape[0]), int(pred.shape[1])
+    lam = float(ssim_lambda)
+    if lam != 0.0 and min(H, W) < 11:
+        # the 11x11 SSIM window does not fit (frames this small only occur while splatfacto's resolution schedule
+        # has them downscaled): L1 only, as the window-less limit of the loss
+        lam = 0.0
+    L = _lib.load()
+    dev = pred.device
+    if gt.device != dev:
+        raise ValueError("pred and gt must live on the same device")
+    with torch.cuda.device(dev):          # launch on pred's device and ITS current stream, whatever is current
+        ws_bytes = L.gs_image_loss_workspace_bytes(H, W)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        v_pred = torch.empty_like(pred)
+        out = torch.empty(3, device=dev)
+        _lib.check(L.gs_image_loss_fwd_bwd(H, W, ctypes.c_void_p(pred.data_ptr()), ctypes.c_void_p(gt.data_ptr()), lam,
+                                           ctypes.c_void_p(v_pred.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                           ctypes.c_void_p(ws.data_ptr()), ws_bytes, _stream()), "image_loss_fwd_bwd")
+    return out[0], v_pred, out[1:]
+
+
 class _ImageLoss(Function):
     @staticmethod
     def forward(ctx, pred, gt, ssim_lambda):
-        pred, gt = _need_cuda(pred, "pred"), _need_cuda(gt, "gt")
-        if pred.dim() != 3 or pred.shape[-1] != 3 or gt.shape != pred.shape:
-            raise ValueError("pred and gt must both be [H,W,3]")
-        H, W = int(pred.shape[0]), int(pred.shape[1])
-        lam = float(ssim_lambda)
-        if lam != 0.0 and min(H, W) < 11:
-            # the 11x11 SSIM window does not fit (frames this small only occur while splatfacto's resolution schedule
-            # has them downscaled): L1 only, as the window-less limit of the loss
-            lam = 0.0
-        L = _lib.load()
-        dev = pred.device
-        if gt.device != dev:
-            raise ValueError("pred and gt must live on the same device")
-        with torch.cuda.device(dev):          # launch on pred's device and ITS current stream, whatever is current
-            ws_bytes = L.gs_image_loss_workspace_bytes(H, W)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            v_pred = torch.empty_like(pred)
-            out = torch.empty(3, device=dev)
-            _lib.check(L.gs_image_loss_fwd_bwd(H, W, ctypes.c_void_p(pred.data_ptr()), ctypes.c_void_p(gt.data_ptr()), lam,
-                                               ctypes.c_void_p(v_pred.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                               ctypes.c_void_p(ws.data_ptr()), ws_bytes, _stream()), "image_loss_fwd_bwd")
+        loss, v_pred, parts = image_loss_with_grad(pred, gt, ssim_lambda)
         ctx.save_for_backward(v_pred)
-        parts = out[1:].clone()
+        parts = parts.clone()
         ctx.mark_non_differentiable(parts)
-        return out[0].clone(), parts
+        return loss.clone(), parts
 
     @staticmethod
     def backward(ctx, v_loss, _v_parts):

@@ -142,6 +142,9 @@ class SplatfactoDeblurModel(nn.Module):
         self.collect_densify_stats = False
         self.xy_grad: Optional[Tensor] = None
         self.last_size = (0, 0)
+        # frame-to-frame memory of THIS model's frames (adaptive slice budget, arena estimate): owned here, not by the
+        # binding's module state, so two models of one shape never share it
+        self.frame_hints = ops.FrameHints()
 
     # -- splatfacto-style accessors ------------------------------------------------
     @property
@@ -288,7 +291,7 @@ class SplatfactoDeblurModel(nn.Module):
             lin_vel=lin if pixvel else None, ang_vel=ang if pixvel else None,
             times=(list(times) if shared else times_t) if pixvel else None,
             return_depth=want_depth, rolling_shutter_time=self._rs_time(camera) if pixvel else 0.0,
-            sh_rest=rest_, raw_params=True, shared_list=shared)
+            sh_rest=rest_, raw_params=True, shared_list=shared, hints=self.frame_hints)
         rgb, alphas, radii = res[:3]
         depth_acc = res[3] if want_depth else None
         self.radii = radii
@@ -308,6 +311,64 @@ class SplatfactoDeblurModel(nn.Module):
         else:
             out["depth"] = None
         return out
+
+    def render_and_backward(self, camera: Camera, grad_image) -> Tensor:
+        """One TRAINING frame, forward and backward in one host call (step.render_step: the same C-ABI calls as
+        get_outputs + Tensor.backward, without the autograd engine between the two compositors — the entry bench.py
+        times).  grad_image: callable rgb [H,W,3] -> d loss / d rgb, where rgb is what get_outputs()["rgb"] would hold
+        (clamped at 1).  Gradients ACCUMULATE into .grad of the Gaussian parameters; pose / velocity adjustments and a
+        learnable background get theirs through the small torch graph of _viewmat_and_velocity / _background.
+        Returns rgb (detached).  Same values as the autograd route (tests: test_train_step_routes_agree)."""
+        from .step import render_step
+        cfg = self.config
+        dev = self.means.device
+        d = self.downscale_factor()
+        if d > 1:
+            camera = camera.rescaled(d)
+        viewmat, lin, ang = self._viewmat_and_velocity(camera)
+        S, R, times = self._schedule(camera)
+        pixvel = cfg.motion_model == "pixel_velocity"
+        if not pixvel and cfg.motion_model != "se3":
+            raise ValueError(f"unknown motion_model {cfg.motion_model!r}")
+        shared = pixvel and cfg.pixel_velocity_lists == "shared"
+        bg = self._background(dev)
+        use_gamma = cfg.blur_samples > 0
+        self.xy_grad = None
+        if self.training and self.collect_densify_stats:
+            self.xy_grad = torch.zeros(self.num_points, 2, device=dev)
+        cam_leaves = [t for t in (viewmat, lin, ang) if t.requires_grad]
+
+        def v_rgb(rgb):
+            # get_outputs clamps rgb at 1 before the loss sees it; the clamp's backward is the mask
+            v = grad_image(torch.clamp(rgb, max=1.0))
+            return v * (rgb <= 1.0)
+
+        rgb, g, radii = render_step(
+            self.means, self.scales, self.quats, self.opacities.reshape(-1), self.features_dc, viewmat.detach(),
+            lin.detach(), ang.detach(), list(times) if shared else self._const(times), bg.detach(), S, R,
+            camera.fx, camera.fy, camera.cx, camera.cy, camera.height, camera.width, v_rgb,
+            gamma=cfg.gamma if use_gamma else 1.0, min_rgb_level=cfg.min_rgb_level if use_gamma else 0.0,
+            sh_degree=self.active_sh_degree(), antialiased=(cfg.rasterize_mode == "antialiased"),
+            sh_rest=self.features_rest, raw_params=True, motion_model=cfg.motion_model, xy_grad_out=self.xy_grad,
+            camera_grads=bool(cam_leaves), background_grad=bg.requires_grad,
+            rolling_shutter_time=self._rs_time(camera) if pixvel else 0.0, shared_list=shared, hints=self.frame_hints)
+        for p, gr in ((self.means, g["means"]), (self.scales, g["scales"]), (self.quats, g["quats"]),
+                      (self.opacities, g["opacities"]), (self.features_dc, g["sh"]), (self.features_rest, g["sh_rest"])):
+            gr = gr.view_as(p)
+            p.grad = gr if p.grad is None else p.grad + gr
+        roots, seeds = [], []
+        for t, key in ((viewmat, "viewmat"), (lin, "lin_vel"), (ang, "ang_vel")):
+            if t.requires_grad and g[key] is not None:
+                roots.append(t)
+                seeds.append(g[key].view_as(t))
+        if bg.requires_grad and g["background"] is not None:
+            roots.append(bg)
+            seeds.append(g["background"].view_as(bg))
+        if roots:
+            torch.autograd.backward(roots, seeds)
+        self.radii = radii
+        self.last_size = (camera.width, camera.height)
+        return torch.clamp(rgb, max=1.0)
 
     def downscale_factor(self) -> int:
         """splatfacto's `_get_downscale_factor` (nerfstudio 1.1.0): while training, render (and compare) at

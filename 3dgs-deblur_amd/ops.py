@@ -31,22 +31,68 @@ MAX_SUBPOSES = 256   # blur samples x rolling-shutter bands per frame (SliceDesc
 # depth slicing of the fused path: average tile-list length budget of the first slice (doubling per
 # slice); 0 disables slicing (single pass over all intersections)
 SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "512"))
-# the budget adapts across frames of one shape: a frame that issued two or more slices doubles it for the next ones, up
-# to 8x (a scene whose tiles do not saturate pays ~0.15 ms per slice boundary for nothing: fitted-model-like bench scene,
-# 512 / 1024 / 2048 / 4096 / 8192: 9.35 / 9.15 / 9.05 / 8.8 / 9.1 ms); a frame that stops after its first slice never grows
-# it; forgotten every 256 frames.  Images do not depend on the slicing (bit for bit), gradients up to fp32 summation order.
+# the budget adapts across the frames of one scene (FrameHints below): a frame that issued two or more slices doubles it
+# for the next ones, up to 8x (a scene whose tiles do not saturate pays ~0.15 ms per slice boundary for nothing:
+# fitted-model-like bench scene, 512 / 1024 / 2048 / 4096 / 8192: 9.35 / 9.15 / 9.05 / 8.8 / 9.1 ms); a frame that stops
+# after its first slice never grows it; forgotten every 256 frames.  Images do not depend on the slicing (bit for bit),
+# gradients up to fp32 summation order.
 SLICE_ADAPT = int(os.environ.get("GSD_SLICE_ADAPT", "1"))
-_slice_hint = {}
+_state_lock = threading.Lock()     # guards every piece of frame-to-frame state of this module (hints, arena pool, caches)
 
 
-def _slice_base_for(key) -> int:
-    return SLICE_BASE * (_slice_hint.get(key, (1, 0))[0] if SLICE_ADAPT and SLICE_BASE > 0 else 1)
+class FrameHints:
+    """What ONE scene's frames teach the next frame of that scene: the adaptive slice-budget multiplier and the arena
+    size its frames needed.  The library is stateless; this is the binding's only frame-to-frame memory, and it has an
+    owner: SplatfactoDeblurModel and bench.Workload hold their own instance (`hints=` of render_subposes /
+    render_combined / render_step); callers that pass none share one per (device, frame shape, parameter storage) —
+    so two scenes of one shape never fight over one hint.  Thread-safe."""
+
+    __slots__ = ("mult", "age", "arena_bytes", "arena_retries", "frames", "_recent", "_lock")
+
+    def __init__(self):
+        self.mult, self.age, self.arena_bytes, self.arena_retries, self.frames = 1, 0, 0, 0, 0
+        self._recent = []               # (issued slices, budget multiplier, arena retries) of the last frames
+        self._lock = threading.Lock()
+
+    def slice_base(self) -> int:
+        return SLICE_BASE * (self.mult if SLICE_ADAPT and SLICE_BASE > 0 else 1)
+
+    def feedback(self, n_issued: int, retries: int = 0) -> None:
+        with self._lock:
+            self.frames += 1
+            self.arena_retries += retries
+            self._recent = (self._recent + [(int(n_issued), self.mult, int(retries))])[-4:]
+            if SLICE_ADAPT and SLICE_BASE > 0:
+                if self.age >= 255:
+                    self.mult, self.age = 1, 0
+                else:
+                    self.mult, self.age = (self.mult * 2 if n_issued >= 2 and self.mult < 8 else self.mult), self.age + 1
+
+    @property
+    def settled(self) -> bool:
+        """the last two frames issued the same number of slices at the budget the NEXT frame will use, without an arena
+        retry: what a caller that times frames waits for (bench.py)"""
+        with self._lock:
+            r = self._recent
+            return (len(r) >= 2 and r[-1][0] == r[-2][0] and r[-1][1] == r[-2][1] == self.mult
+                    and r[-1][2] == 0 and r[-2][2] == 0)
+
+    def reset(self) -> None:
+        with self._lock:
+            self.mult, self.age, self.arena_bytes, self._recent = 1, 0, 0, []
 
 
-def _slice_feedback(key, n_issued: int):
-    if SLICE_ADAPT and SLICE_BASE > 0:
-        mult, age = _slice_hint.get(key, (1, 0))
-        _slice_hint[key] = (1, 0) if age >= 255 else (mult * 2 if n_issued >= 2 and mult < 8 else mult, age + 1)
+_hints = {}          # default owner: (device, N, P, S, H, W, shared, storage of means3d) -> FrameHints
+
+
+def hints_for(key) -> FrameHints:
+    with _state_lock:
+        h = _hints.get(key)
+        if h is None:
+            if len(_hints) >= 64:
+                _hints.clear()
+            h = _hints[key] = FrameHints()
+        return h
 
 
 # gs_frame_forward only: a slice that leaves at least this fraction of its open tiles open makes the next issued slice
@@ -56,6 +102,31 @@ SLICE_MERGE = float(os.environ.get("GSD_SLICE_MERGE", "0.75"))
 # gs_frame_forward only: 1 = its two read-backs (slice plan, open-tile count) are written into pinned host memory by a
 # one-block kernel and the host polls a sequence word; 0 = hipMemcpyAsync + hipStreamSynchronize
 FRAME_POLL = int(os.environ.get("GSD_FRAME_POLL", "1"))
+
+
+def _host_cores() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def frame_poll() -> int:
+    """1 = polled read-backs.  A polling rank spins one host core while it waits (twice per frame, tens of microseconds):
+    with one process per GPU that is LOCAL_WORLD_SIZE spinning cores, so the default only polls when the affinity mask
+    holds at least two cores per local rank (one to spin, one for everything else); otherwise the read-backs go through
+    hipStreamSynchronize (the rank sleeps in the runtime).  GSD_FRAME_POLL set explicitly wins."""
+    if "GSD_FRAME_POLL" in os.environ or not FRAME_POLL:
+        return int(FRAME_POLL)
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    return 1 if _host_cores() >= 2 * local_world else 0
+
+
+def readback_mode() -> dict:
+    """how this process reads the slice plan / open-tile word back, and why (bench.py prints it per rank)"""
+    return {"poll": bool(frame_poll()), "host_cores": _host_cores(),
+            "local_world": int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1),
+            "forced": "GSD_FRAME_POLL" in os.environ}
 # widest radix digit of the compacting depth pre-sort: 8 -> 4 passes of 8 bits, 11 -> 3 passes of 11/10/10 bits
 DEPTH_SORT_DIGIT = int(os.environ.get("GSD_DEPTH_SORT_DIGIT", "8"))
 # gradient conventions recollected from upstream gsplat 0.1.11 (DESIGN.md section 1), bit mask, default 0 = the true
@@ -366,8 +437,68 @@ class _ArenaTooSmall(Exception):
     pass
 
 
-_arena_hint = {}        # (device, N, P, S, H, W) -> bytes that held the last frame of that shape (+ margin)
-_ARENA_ATTEMPTS = 16    # first frame of a new shape: projections + partial frames until the arena holds every slice
+_ARENA_ATTEMPTS = 16    # first frame of a new scene: projections + partial frames until the arena holds every slice
+# Frame arenas are PERSISTENT (a fresh multi-GB torch.empty per frame, and one more per retry,
+# put hipMallocs inside timed loops): one pool per (device, stream); a frame leases the largest free arena and hands it
+# back when its autograd node (or render_step's context) dies, so back-to-back frames — of any scene — run in the SAME
+# memory, which only ever grows (on GS_ERR_WORKSPACE).  Frames alive at the same time get an arena each; at most two
+# free ones are kept per pool.  release_arenas() gives the memory back.
+_arena_pool = {}
+
+
+_arena_gen = {}          # arena address -> how many frames have leased it (a frame knows when its arena was recycled)
+
+
+class _ArenaLease:
+    __slots__ = ("tensor", "key", "gen")
+
+    def __init__(self, tensor, key):
+        self.tensor, self.key = tensor, key
+        with _state_lock:
+            self.gen = _arena_gen[tensor.data_ptr()] = _arena_gen.get(tensor.data_ptr(), 0) + 1
+
+    def release(self):
+        """hand the arena back to the pool (idempotent); the frame keeps its own reference to the memory and can tell
+        through `recycled` whether a later frame has leased it since"""
+        try:
+            with _state_lock:
+                t, self.tensor = self.tensor, None
+                if t is None:
+                    return
+                free = _arena_pool.setdefault(self.key, [])
+                free.append(t)
+                if len(free) > 2:
+                    small = min(free, key=lambda x: x.numel())
+                    free.remove(small)
+                    _arena_gen.pop(small.data_ptr(), None)
+        except Exception:       # interpreter shutdown
+            pass
+
+    __del__ = release
+
+
+def _arena_acquire(dev, want_bytes: int) -> _ArenaLease:
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    with _state_lock:
+        free = _arena_pool.setdefault(key, [])
+        t = max(free, key=lambda x: x.numel()) if free else None
+        if t is not None:
+            free.remove(t)
+            if t.numel() < want_bytes:
+                _arena_gen.pop(t.data_ptr(), None)
+    if t is None or t.numel() < want_bytes:
+        t = None                # the short one goes back to torch's allocator before the larger one is requested
+        t = torch.empty(int(want_bytes), dtype=torch.uint8, device=dev)
+    return _ArenaLease(t, key)
+
+
+def release_arenas() -> None:
+    """drop every pooled frame arena (they return to torch's caching allocator)"""
+    with _state_lock:
+        _arena_pool.clear()
+        _arena_gen.clear()
+
+
 _pinned_cache = {}
 
 
@@ -380,7 +511,8 @@ def _profile_mask() -> int:
 
 def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
                          H: int, W: int, bg: Tensor, edges: Tensor, slice_base: int, color=None,
-                         out_depth: Optional[Tensor] = None, reserve_backward: bool = True, rs=None, combine=None):
+                         out_depth: Optional[Tensor] = None, reserve_backward: bool = True, rs=None, combine=None,
+                         hints: Optional[FrameHints] = None):
     """combine = (gamma, min_level, out [H,W,3]): the library launches the gamma-space average of the sample images itself,
     behind every slice's compositor (it overlaps the open-tile read-back).  rs = (pix_vel [N,2], rolling_shutter_time[, sample_times [S]]) or None; with sample_times the frame runs in the
     shared-list mode (P == 1: one record set and one tile list for the S samples).  gs_frame_forward: -> (out_img [S,H,W,3], out_T [S,H,W], frame) ; frame = dict(arena, state) for
@@ -391,15 +523,18 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     dev = records.device
     tx, ty = _tiles(H, W)
     shared = rs is not None and len(rs) > 2 and rs[2] is not None
-    key = (str(dev), N, P, S, H, W, shared)
+    if hints is None:
+        hints = hints_for((str(dev), N, P, S, H, W, shared))
     n = P * N
-    nbytes = _arena_hint.get(key)
-    if nbytes is None:
+    nbytes = hints.arena_bytes
+    if not nbytes:
         # depth pre-sort + plan + one slice of the default budget; the library prices the real plan and says so if this
         # is short (one retry per new high-water mark)
         I0 = max(1, slice_base) * tx * ty * P
         nbytes = 40 * n + 16 * S * H * W + (80 + (56 * S if shared else 0)) * I0 + (64 << 20)
-    arena = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+    lease = _arena_acquire(dev, nbytes)
+    arena = lease.tensor
+    nbytes = arena.numel()
     # the read-back buffer is written by the GPU while gs_frame_forward polls it (ctypes releases the GIL for the call):
     # one per device, host thread and stream, so that concurrent frames never share it
     pin_key = (str(dev), threading.get_ident(), torch.cuda.current_stream().cuda_stream)
@@ -408,7 +543,7 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     if pin is None or pin.numel() < need_pin:
         pin = _pinned_cache[pin_key] = torch.empty(max(8192, need_pin), dtype=torch.uint8, pin_memory=True)
     desc = _FrameDesc(N, P, S, R, H, W, int(slice_base), DEPTH_SORT_DIGIT, 0, int(reserve_backward),
-                      float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0, int(FRAME_POLL), int(shared),
+                      float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0, frame_poll(), int(shared),
                       float(combine[0]) if combine is not None else 1.0, float(combine[1]) if combine is not None else 0.0)
     state = _FrameState()
     out_img = torch.empty(S, H, W, 3, device=dev)
@@ -428,14 +563,15 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     if st == 3:
         # the library prices one slice ahead; a frame that needs many (ever larger) slices is settled in several steps,
         # each at least half as large again as the last, so the number of retries is logarithmic in the final size
-        _arena_hint[key] = max(int(state.arena_required * 1.15) + (32 << 20), int(nbytes * 1.5))
+        hints.arena_bytes = max(int(state.arena_required * 1.15) + (32 << 20), int(nbytes * 1.5))
         raise _ArenaTooSmall()
     _check(st, "frame_forward")
-    _arena_hint[key] = max(int(nbytes), int((state.arena_used + L.gs_frame_backward_bytes(ctypes.byref(state))) * 1.15))
+    hints.arena_bytes = max(int(hints.arena_bytes),
+                            int((state.arena_used + L.gs_frame_backward_bytes(ctypes.byref(state))) * 1.15))
     last_num_intersects = int(state.n_total)
     _slice_totals = [arena[sl.n_emitted_dev:sl.n_emitted_dev + 4].view(torch.int32)
                      for sl in (state.slice[i] for i in range(state.n_slices))]
-    return out_img, out_T, dict(arena=arena, state=state, pix_vel=rs[0] if rs is not None else None,
+    return out_img, out_T, dict(arena=arena, lease=lease, gen=lease.gen, state=state, pix_vel=rs[0] if rs is not None else None,
                                 sample_times=rs[2] if shared else None)
 
 
@@ -444,6 +580,13 @@ def native_frame_backward(frame, records: Tensor, bg: Tensor, edges: Tensor, out
     L = _L()
     cmb = combine if combine is not None else (None, 1.0, 0.0)
     arena, state = frame["arena"], frame["state"]
+    lease = frame["lease"]
+    if lease.tensor is None:
+        with _state_lock:
+            if _arena_gen.get(arena.data_ptr()) != frame["gen"]:
+                raise RuntimeError("this frame's arena was handed back after its first backward and a later frame has "
+                                   "used it since: a second backward of one frame (retain_graph=True) must run before "
+                                   "the next frame's forward")
     L.gs_frame_profile_enable(_profile_mask())
     st = L.gs_frame_backward(ctypes.byref(state), _ptr(records), _ptr(bg), _ptr(edges), _ptr(out_T), _ptr(v_img),
                              _ptr(v_alpha), _ptr(cmb[0]), float(cmb[1]), float(cmb[2]), _bwd_variant(), _ptr(v_records),
@@ -453,6 +596,9 @@ def native_frame_backward(frame, records: Tensor, bg: Tensor, edges: Tensor, out
         raise _lib.HipLibraryError("frame_backward: the forward's arena cannot hold the backward's buffers "
                                    "(call native_frame_forward with reserve_backward=True)")
     _check(st, "frame_backward")
+    # the compositing backward is done with the arena: the next frame's forward may lease it (everything is ordered on
+    # one stream), whether or not this frame's autograd node outlives the backward
+    lease.release()
 
 
 # --------------------------------------------------------------------------- #
@@ -741,7 +887,7 @@ class _RenderSubposes(Function):
     def forward(ctx, means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out, return_alpha,
                 gamma, min_rgb_level, lin_vel=None, ang_vel=None, times=None, return_depth=False, rs_time=0.0,
-                sh_rest=None, param_flags=0, shared_list=False):
+                sh_rest=None, param_flags=0, shared_list=False, hints=None):
         # an output the loss does not use arrives as None in backward instead of a materialised zero tensor
         ctx.set_materialize_grads(False)
         means3d, scales, quats = _f32(means3d, "means3d"), _f32(scales, "scales"), _f32(quats, "quats")
@@ -861,15 +1007,20 @@ class _RenderSubposes(Function):
             averaged = None
             if gamma is not None:
                 averaged = (float(gamma), float(min_rgb_level) / 255.0, torch.empty(H, W, 3, device=dev))
-            hint_key = (str(dev), N, P, S, H, W)
+            if hints is None:
+                # default owner of the frame-to-frame hints: the scene's shape AND its parameter storage, so that two
+                # scenes of one shape do not share a budget / arena estimate
+                hints = hints_for((str(dev), N, P, S, H, W, shared is not None, means3d.untyped_storage().data_ptr()))
+            retries = 0
             for attempt in range(_ARENA_ATTEMPTS):
                 try:
                     out_img, out_T, ctx.frame = native_frame_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges,
-                                                                     _slice_base_for(hint_key), color, depth_acc,
-                                                                     any(ctx.needs_input_grad), rs, averaged)
-                    _slice_feedback(hint_key, int(ctx.frame["state"].n_slices))
+                                                                     hints.slice_base(), color, depth_acc,
+                                                                     any(ctx.needs_input_grad), rs, averaged, hints)
+                    hints.feedback(int(ctx.frame["state"].n_slices), retries)
                     break
                 except _ArenaTooSmall:
+                    retries += 1
                     if attempt == _ARENA_ATTEMPTS - 1:
                         raise _lib.HipLibraryError("frame_forward: the arena estimate did not converge")
                     # the depth keys were consumed by the pre-sort: project again, then retry with the larger arena
@@ -925,7 +1076,7 @@ class _RenderSubposes(Function):
         dev = means3d.device
         L = _L()
         if v_img is None and v_alpha is None:
-            return (None,) * 31
+            return (None,) * 32
         v_img = torch.zeros(ctx.img_shape, device=dev) if v_img is None else v_img.contiguous().float()
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
         combine = None
@@ -1004,7 +1155,7 @@ class _RenderSubposes(Function):
                                               _stream()), "project_fused_bwd")
         v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
         return ((v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 16
-                + (v_lin, v_ang, None, None, None, v_sh_rest, None, None))
+                + (v_lin, v_ang, None, None, None, v_sh_rest, None, None, None))
 
 
 def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor, sh: Tensor,
@@ -1014,7 +1165,8 @@ def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
                     clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None, return_alpha: bool = True,
                     lin_vel: Optional[Tensor] = None, ang_vel: Optional[Tensor] = None,
                     times: Optional[Tensor] = None, return_depth: bool = False, rolling_shutter_time: float = 0.0,
-                    sh_rest: Optional[Tensor] = None, raw_params: bool = False, shared_list: bool = False):
+                    sh_rest: Optional[Tensor] = None, raw_params: bool = False, shared_list: bool = False,
+                    hints: Optional[FrameHints] = None):
     """Fused hot path: project N Gaussians under P=S*R sub-pose viewmats, bin, sort, composite.
     -> (samples [S,H,W,3], alphas [S,H,W], radii int32 [P,N]).  scales/opacities are activated values — or, with
     raw_params=True, splatfacto's RAW parameters: log-scales and opacity logits (exp / sigmoid and their backward run
@@ -1034,13 +1186,15 @@ def render_subposes(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
     for the whole frame (tile boxes swept over the sampled span); the S samples walk it.  radii is then [1,N].  The
     footprint of a splat is cut at the swept box instead of the per-sample box: contributions beyond 3 sigma inside
     the swept box (alpha between 1/255 and opacity * exp(-4.5)) are kept, so values differ from the per-sample lists
-    by that fringe."""
+    by that fringe.
+    hints: the caller's FrameHints (adaptive slice budget + arena estimate of ITS scene); None = one per (device, frame
+    shape, storage of means3d)."""
     S, R = max(1, int(blur_samples)), max(1, int(rs_bands))
     out = _RenderSubposes.apply(means3d, scales, quats, opacities, sh, viewmats, background, S, R, fx, fy, cx, cy,
                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
                                 bool(return_alpha), None, None, lin_vel, ang_vel, times, bool(return_depth),
                                 float(rolling_shutter_time), sh_rest, 3 if raw_params else 0,
-                                bool(shared_list))
+                                bool(shared_list), hints)
     return out if return_depth else out[:3]
 
 
@@ -1051,7 +1205,8 @@ def render_combined(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
                     glob_scale: float = 1.0, clip_thresh: float = 0.01, xy_grad_out: Optional[Tensor] = None,
                     return_alpha: bool = True, lin_vel: Optional[Tensor] = None, ang_vel: Optional[Tensor] = None,
                     times: Optional[Tensor] = None, return_depth: bool = False, rolling_shutter_time: float = 0.0,
-                    sh_rest: Optional[Tensor] = None, raw_params: bool = False, shared_list: bool = False):
+                    sh_rest: Optional[Tensor] = None, raw_params: bool = False, shared_list: bool = False,
+                    hints: Optional[FrameHints] = None):
     """render_subposes + combine_samples as ONE autograd node: -> (rgb [H,W,3], alphas [S,H,W] or None, radii).
     Same values as the two-step form; the backward skips the [S,H,W,3] per-sample gradient tensor — the
     compositor's backward derives every pixel's sample gradient from rgb and its gradient."""
@@ -1060,7 +1215,7 @@ def render_combined(means3d: Tensor, scales: Tensor, quats: Tensor, opacities: T
                                 img_height, img_width, sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out,
                                 bool(return_alpha), float(gamma), float(min_rgb_level), lin_vel, ang_vel, times,
                                 bool(return_depth), float(rolling_shutter_time), sh_rest, 3 if raw_params else 0,
-                                bool(shared_list))
+                                bool(shared_list), hints)
     return out if return_depth else out[:3]
 
 

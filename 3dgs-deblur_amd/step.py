@@ -45,7 +45,7 @@ def render_step(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor,
                 sh_degree: int = 3, antialiased: bool = True, sh_rest: Optional[Tensor] = None, raw_params: bool = True,
                 motion_model: str = "se3", xy_grad_out: Optional[Tensor] = None, camera_grads: bool = True,
                 background_grad: bool = False, glob_scale: float = 1.0, clip_thresh: float = 0.01,
-                rolling_shutter_time: float = 0.0, shared_list: bool = False
+                rolling_shutter_time: float = 0.0, shared_list: bool = False, hints: Optional["ops.FrameHints"] = None
                 ) -> Tuple[Tensor, Dict[str, Optional[Tensor]], Tensor]:
     """One frame, forward and backward.  Arguments as ops.render_combined (raw_params: log-scales / opacity logits;
     sh_rest: features_rest beside sh = features_dc), but the camera comes as ONE mid-exposure `viewmat` [4,4] + body
@@ -70,8 +70,17 @@ def render_step(means: Tensor, scales: Tensor, quats: Tensor, opacities: Tensor,
         ctx, means, scales, quats, opacities, sh, vms, background, S, R, fx, fy, cx, cy, img_height, img_width,
         sh_degree, antialiased, glob_scale, clip_thresh, xy_grad_out, False, float(gamma), float(min_rgb_level),
         lin_vel if pixvel else None, ang_vel if pixvel else None, times if pixvel else None, False,
-        float(rolling_shutter_time), sh_rest, 3 if raw_params else 0, bool(shared_list))
-    v_rgb = grad_image(rgb) if callable(grad_image) else grad_image
+        float(rolling_shutter_time), sh_rest, 3 if raw_params else 0, bool(shared_list), hints)
+    if callable(grad_image):
+        # the callable may use torch.autograd itself (rgb.requires_grad_() + autograd.grad): it sees a detached leaf and
+        # runs with gradient recording on (under this function's no_grad it silently got None)
+        with torch.enable_grad():
+            v_rgb = grad_image(rgb.detach())
+        if v_rgb is None:
+            raise ValueError("grad_image(rgb) returned None: it must return d loss / d rgb [H,W,3]")
+        v_rgb = v_rgb.detach()
+    else:
+        v_rgb = grad_image
     g = ops._RenderSubposes.backward(ctx, v_rgb, None, None, None)
     grads = {"means": g[0], "scales": g[1], "quats": g[2], "opacities": g[3], "sh": g[4], "background": g[6],
              "sh_rest": g[28], "viewmat": None, "lin_vel": None, "ang_vel": None}

@@ -116,18 +116,48 @@ def optimizers_step(optimizers) -> None:
             o.step()
 
 
+# GSD_TRAIN_AUTOGRAD=1: train_step goes through get_outputs + torch.autograd instead of the one-call route (A/B, tests)
+TRAIN_AUTOGRAD = int(os.environ.get("GSD_TRAIN_AUTOGRAD", "0"))
+
+
+def one_call_route(model: SplatfactoDeblurModel) -> bool:
+    """train_step renders through model.render_and_backward (step.render_step) unless the model lives on the CPU (host
+    logic tests with a stand-in render), the torch loss / autograd A/B switches are set, or training wants the depth
+    output (a forward-only extra the one-call route does not produce)"""
+    return (model.means.is_cuda and not TORCH_TRAIN and not TRAIN_AUTOGRAD
+            and not model.config.output_depth_during_training and "get_outputs" not in model.__dict__
+            and type(model).get_outputs is SplatfactoDeblurModel.get_outputs)
+
+
 def train_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.Optimizer], camera: Camera,
                gt_image: Tensor, ssim_lambda: float = 0.2, allreduce: Optional[str] = None) -> Dict[str, float]:
     """One training iteration: render (HIP) -> loss -> backward (HIP) -> [DP gradient all-reduce] -> Adam."""
     model.train()
     for o in optimizers.values():
         o.zero_grad(set_to_none=True)
-    out = model.get_outputs(camera)
     gt_image = downscale_image(gt_image, model.downscale_factor())     # num_downscales resolution schedule
-    loss = image_loss(out["rgb"], gt_image, ssim_lambda)
-    if model.config.use_scale_regularization:
-        loss = loss + scale_regularization(model.scales)
-    loss.backward()
+    if one_call_route(model):
+        # forward + backward of the frame as ONE host call (model.render_and_backward -> step.render_step): the HIP loss
+        # kernel's forward already produces d loss / d rgb, so it sits between the two halves as a plain callable
+        from . import fused
+        box = {}
+
+        def grad_image(rgb):
+            box["loss"], v, _ = fused.image_loss_with_grad(rgb, gt_image, ssim_lambda)
+            return v
+        rgb = model.render_and_backward(camera, grad_image)
+        loss = box["loss"]
+        if model.config.use_scale_regularization:
+            reg = scale_regularization(model.scales)
+            reg.backward()
+            loss = loss + reg.detach()
+    else:
+        out = model.get_outputs(camera)
+        rgb = out["rgb"].detach()
+        loss = image_loss(out["rgb"], gt_image, ssim_lambda)
+        if model.config.use_scale_regularization:
+            loss = loss + scale_regularization(model.scales)
+        loss.backward()
     if allreduce is not None:
         from . import dp
         dp.allreduce_gradients(list(model.gauss_params().values()), mode=allreduce, average=True)
@@ -141,7 +171,7 @@ def train_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.O
         dp.allreduce_dense_([p.grad for p in small], average=True)
     optimizers_step(optimizers.values())
     model.step += 1
-    return {"loss": float(loss.item()), "psnr": psnr(out["rgb"].detach(), gt_image)}
+    return {"loss": float(loss.item()), "psnr": psnr(rgb, gt_image)}
 
 
 # --------------------------------------------------------------------------- #

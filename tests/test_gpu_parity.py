@@ -1882,15 +1882,28 @@ def test_native_frame_grows_its_arena_and_reports_stage_times(gs, dev):
     times, _, _ = gs.subpose_schedule(S, 1 / 60, 1, 0.0)
     vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"], sc["ang_vel"], torch.tensor(times, device=dev))
 
+    hints = ops.FrameHints()
+    ops.release_arenas()
+
     def render():
         return gs.render_combined(sc["means"], sc["log_scales"].exp(), sc["quats"], torch.sigmoid(sc["opacity_logits"]),
-                                  sc["sh"], vms, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2)[0]
+                                  sc["sh"], vms, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2,
+                                  hints=hints)[0]
     ref = render()
-    key = (str(dev), n, S, S, H, W, False)
-    assert key in ops._arena_hint
-    ops._arena_hint[key] = 1 << 20                      # far too small: forces the retry path
+    assert hints.arena_bytes > (1 << 20) and hints.frames == 1
+    # a far too small arena forces the retry path: pool emptied, estimate forgotten
+    ops.release_arenas()
+    pool_key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    ops._arena_pool[pool_key] = [torch.empty(1 << 20, dtype=torch.uint8, device=dev)]
+    hints.arena_bytes = 1 << 20
     got = render()
-    assert torch.equal(ref, got) and ops._arena_hint[key] > (1 << 20)
+    assert torch.equal(ref, got) and hints.arena_bytes > (1 << 20) and hints.arena_retries >= 1
+    # the grown arena is the pool's: the next frame — of ANY scene on this stream — runs in it without a retry or a malloc
+    (pooled,) = ops._arena_pool[pool_key]
+    before = hints.arena_retries
+    got2 = render()
+    assert torch.equal(ref, got2) and hints.arena_retries == before
+    assert ops._arena_pool[pool_key][0].data_ptr() == pooled.data_ptr()
     ops.profiler = ops.StageProfiler()
     try:
         p = sc["means"].clone().requires_grad_(True)
@@ -1914,23 +1927,27 @@ def test_native_frame_arena_converges_over_many_ever_larger_slices(gs, dev):
     times, _, _ = gs.subpose_schedule(S, 1 / 60, 1, 0.0)
     vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"], sc["ang_vel"], torch.tensor(times, device=dev))
     saved = (ops.NATIVE_FRAME, ops.SLICE_BASE)
-    key = (str(dev), n, S, S, H, W, False)
+    hints = ops.FrameHints()
 
     def render():
         return gs.render_combined(sc["means"], sc["log_scales"].exp(), sc["quats"], torch.sigmoid(sc["opacity_logits"]),
-                                  sc["sh"], vms, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2)[0]
+                                  sc["sh"], vms, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2,
+                                  hints=hints)[0]
     try:
         ops.SLICE_BASE = 2
         ops.NATIVE_FRAME = 0
         ref = render()
         planned = sum(1 for v in ops.last_slice_intersects if int(v) > 0)
         ops.NATIVE_FRAME = 1
-        ops._arena_hint[key] = 1 << 20
+        ops.release_arenas()
+        ops._arena_pool[(str(dev), torch.cuda.current_stream(dev).cuda_stream)] = [torch.empty(1 << 20, dtype=torch.uint8,
+                                                                                               device=dev)]
+        hints.arena_bytes = 1 << 20
         got = render()
         assert python_frame_path.native_ok()
     finally:
         ops.NATIVE_FRAME, ops.SLICE_BASE = saved
-        ops._arena_hint.pop(key, None)
+        ops.release_arenas()
     assert planned >= 6, planned
     assert torch.equal(ref, got)
 
@@ -2240,6 +2257,11 @@ def test_shared_list_pixel_velocity_vs_oracle(gs, oracle, dev, S, W, H, n, rt, b
     try:
         if base is not None:
             ops.SLICE_BASE = base
+            # nothing in a multi-slice shared-list frame may depend on what its arena held before (a
+            # finished sample's tile used to leave this slice's stop indices unwritten: 0x7f7f7f7f = 2.1e9 as an index)
+            ops.release_arenas()
+            ops._arena_pool[(str(dev), torch.cuda.current_stream(dev).cuda_stream)] = [
+                torch.full((512 << 20,), 0x7f, dtype=torch.uint8, device=dev)]
         samples, alphas, radii = run(True)
         out = gs.combine_samples(samples, gamma, mlevel)
         (out * wt.to(dev)).sum().backward()
@@ -2289,30 +2311,29 @@ def test_adaptive_slice_budget(gs, dev):
     vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"], sc["ang_vel"], torch.tensor(times, device=dev))
     wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(2)).to(dev)
     saved = (ops.SLICE_ADAPT, ops.SLICE_BASE)
-    key = (str(dev), n, S, S, H, W)
+    hints = ops.FrameHints()
     frames = []
     try:
         ops.SLICE_ADAPT, ops.SLICE_BASE = 1, 2
-        ops._slice_hint.pop(key, None)
         for _ in range(4):
             p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
             rgb = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["opacity_logits"]),
-                                     p["sh"], vms, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2)[0]
+                                     p["sh"], vms, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2,
+                                     hints=hints)[0]
             (rgb * wt).sum().backward()
             frames.append((rgb.detach().clone(), {k: v.grad.clone() for k, v in p.items()},
-                           sum(1 for v in ops.last_slice_intersects if int(v) > 0), ops._slice_hint[key][0]))
-        # a scene that needs one slice at the same budget: nothing grows
+                           sum(1 for v in ops.last_slice_intersects if int(v) > 0), hints.mult))
+        # a scene that needs one slice at the same budget: nothing grows.  No hints handed in: the default owner is keyed
+        # by shape AND parameter storage, so the same tensors find the same hints frame after frame
         few = to_dev(gs.data.synthetic_scene(300, W, H, seed=5, scale_mult=2.0), dev)
-        key2 = (str(dev), 300, S, S, H, W)
-        ops._slice_hint.pop(key2, None)
         ops.SLICE_BASE = 512
-        for _ in range(2):
+        for _ in range(3):
             gs.render_combined(few["means"], few["log_scales"].exp(), few["quats"], torch.sigmoid(few["opacity_logits"]),
                                few["sh"], vms, None, S, 1, few["fx"], few["fy"], few["cx"], few["cy"], H, W, gamma=2.2)
-        assert ops._slice_hint[key2][0] == 1
+        h_few = ops.hints_for((str(dev), 300, S, S, H, W, False, few["means"].untyped_storage().data_ptr()))
+        assert h_few.mult == 1 and h_few.frames == 3 and h_few.settled
     finally:
         ops.SLICE_ADAPT, ops.SLICE_BASE = saved
-        ops._slice_hint.clear()
     mults, slices = [f[3] for f in frames], [f[2] for f in frames]
     print("adaptive slice budget: multiplier after each frame", mults, "issued slices", slices)
     assert mults == [2, 4, 8, 8] and slices[0] >= 2, (mults, slices)
@@ -2585,3 +2606,132 @@ def test_render_step_equals_autograd_route(gs, oracle, dev, model):
         assert torch.equal(g[name], p[k].grad), k
     for k in ("viewmat", "lin_vel", "ang_vel"):
         assert rel_max(g[k].cpu(), p[k].grad.cpu()) < 1e-5, k
+
+
+def test_render_step_callable_may_use_autograd(gs, oracle, dev):
+    """render_step runs under no_grad; a grad_image callable that gets d loss / d rgb from torch.autograd
+    (requires_grad_ + autograd.grad) must work — it sees a detached leaf with gradient recording switched on"""
+    O = oracle
+    n, W, H, S = 3000, 96, 64, 2
+    sc = O.synthetic_scene(n, W, H, seed=12, scale_mult=6.0)
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, 1, 0.0)
+    tt = torch.tensor(times, device=dev)
+    q = {k: sc[k].float().to(dev) for k in ("means", "log_scales", "quats", "opacity_logits", "sh", "viewmat", "lin_vel",
+                                              "ang_vel")}
+    target = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+
+    def by_autograd(rgb):
+        rgb = rgb.requires_grad_(True)
+        loss = ((rgb - target) ** 2).mean()
+        (v,) = torch.autograd.grad(loss, rgb)
+        return v
+
+    args = (q["means"], q["log_scales"], q["quats"], q["opacity_logits"], q["sh"], q["viewmat"], q["lin_vel"], q["ang_vel"],
+            tt, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W)
+    rgb_a, g_a, _ = gs.render_step(*args, by_autograd, gamma=2.2, min_rgb_level=10.0)
+    rgb_b, g_b, _ = gs.render_step(*args, lambda rgb: 2.0 * (rgb - target) / rgb.numel(), gamma=2.2, min_rgb_level=10.0)
+    assert torch.equal(rgb_a, rgb_b)
+    for k in ("means", "scales", "quats", "opacities", "sh"):
+        assert float(g_a[k].abs().max()) > 0 and rel_max(g_a[k].cpu(), g_b[k].cpu()) < 1e-6, k
+    with pytest.raises(ValueError):
+        gs.render_step(*args, lambda rgb: None, gamma=2.2, min_rgb_level=10.0)
+
+
+def test_train_step_routes_agree(gs, dev):
+    """training.train_step renders through model.render_and_backward -> step.render_step (ONE host
+    call, the entry bench.py times); with GSD_TRAIN_AUTOGRAD it goes through model.get_outputs + loss.backward().  Same
+    loss, same gradient for every Gaussian parameter, the pose / velocity adjustments and the learnable background, same
+    parameters after the Adam step."""
+    from gsdeblur_amd import train_step as T
+    n, W, H, S = 6000, 128, 96, 3
+    sc = gs.data.synthetic_scene(n, W, H, sh_degree=3, seed=31)
+    sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * 20, sc["ang_vel"] * 10
+    c2w = torch.eye(4)[:3].clone()
+    c2w[:, 1] *= -1
+    c2w[:, 2] *= -1
+    flip = torch.tensor([1.0, -1.0, -1.0])
+    cam = gs.Camera(c2w, sc["fx"], sc["fy"], sc["cx"], sc["cy"], W, H,
+                    metadata=dict(cam_idx=0, camera_linear_velocity=[float(v) for v in sc["lin_vel"] * flip],
+                                  camera_angular_velocity=[float(v) for v in sc["ang_vel"] * flip],
+                                  exposure_time=1 / 60, rolling_shutter_time=0.0))
+    target = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+    results = []
+    saved = T.TRAIN_AUTOGRAD
+    try:
+        for autograd_route in (0, 1):
+            T.TRAIN_AUTOGRAD = autograd_route
+            cfg = gs.SplatfactoDeblurConfig(blur_samples=S, rolling_shutter_compensation=False, gamma=2.2, min_rgb_level=10.0,
+                                            background_color="auto", use_scale_regularization=True)
+            cfg.camera_optimizer.mode = "SO3xR3"
+            cfg.camera_velocity_optimizer.enabled = True
+            model = gs.SplatfactoDeblurModel.from_scene(cfg, sc, dev)
+            model.collect_densify_stats = True
+            assert T.one_call_route(model) == (not autograd_route)
+            opts = T.make_optimizers(model)
+            h = [T.train_step(model, opts, cam, target, 0.2) for _ in range(2)]
+            grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+            params = {k: p.detach().clone() for k, p in model.named_parameters()}
+            results.append((h, grads, params, model.xy_grad.clone(), model.radii.clone()))
+    finally:
+        T.TRAIN_AUTOGRAD = saved
+    (h0, g0, p0, xy0, r0), (h1, g1, p1, xy1, r1) = results
+    assert set(g0) == set(g1) and {"means", "scales", "quats", "opacities", "features_dc", "features_rest",
+                                   "pose_adjustment", "velocity_adjustment", "background_param"} <= set(g0)
+    for a, b in zip(h0, h1):
+        assert abs(a["loss"] - b["loss"]) < 1e-6 and abs(a["psnr"] - b["psnr"]) < 1e-4
+    assert torch.equal(r0, r1) and rel_max(xy0.cpu(), xy1.cpu()) < 1e-5
+    for k in g0:
+        assert float(g0[k].abs().max()) > 0, k
+        assert rel_max(g0[k].cpu(), g1[k].cpu()) < 2e-5, k
+        assert rel_max(p0[k].cpu(), p1[k].cpu()) < 2e-5, k
+
+
+def test_alternating_scenes_of_one_shape_keep_their_frame_time(gs, dev):
+    """two scenes of ONE shape (a headline-like one that stops after its first slice, a
+    fitted-model-like one that wants a larger budget) rendered alternately, adaptive budget ON, nobody handing hints in:
+    each scene finds its own FrameHints (keyed by parameter storage), both run in the SAME pooled arena, and once the
+    budget and the arena have settled (four frames per scene at most) no frame pays for the other scene's frames —
+    no arena retry, no new arena, no frame slower than 1.3x its scene's median."""
+    import time
+    from gsdeblur_amd import ops
+    n, W, H, S = 200000, 640, 368, 3
+    saved = (ops.SLICE_ADAPT, ops.SLICE_BASE)
+    ops.release_arenas()
+    try:
+        ops.SLICE_ADAPT, ops.SLICE_BASE = 1, 64
+        scenes = []
+        for profile in ("survey", "trained"):
+            sc = gs.data.synthetic_scene(n, W, H, sh_degree=3, seed=77, profile=profile)
+            q = {k: sc[k].float().to(dev) for k in ("means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel")}
+            scenes.append((sc, q))
+        times, _, _ = gs.subpose_schedule(S, 1 / 60, 1, 0.0)
+        tt = torch.tensor(times, device=dev)
+        wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+        V = torch.eye(4, device=dev)
+        ms = ([], [])
+        slices = ([], [])
+        for frame in range(24):
+            i = frame % 2
+            sc, q = scenes[i]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gs.render_step(q["means"], q["log_scales"], q["quats"], q["opacity_logits"], q["sh"], V, q["lin_vel"],
+                           q["ang_vel"], tt, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, wt, gamma=2.2,
+                           min_rgb_level=10.0)
+            torch.cuda.synchronize()
+            ms[i].append((time.perf_counter() - t0) * 1e3)
+            slices[i].append(len(ops.last_slice_intersects))
+        hints = [ops.hints_for((str(dev), n, S, S, H, W, False, q["means"].untyped_storage().data_ptr())) for _, q in scenes]
+        pool = ops._arena_pool[(str(dev), torch.cuda.current_stream(dev).cuda_stream)]
+        print("alternating scenes: ms", [[round(v, 2) for v in m] for m in ms], "slices", slices,
+              "budget multipliers", [h.mult for h in hints], "retries", [h.arena_retries for h in hints])
+        assert hints[0] is not hints[1] and all(h.frames == 12 and h.settled for h in hints)
+        assert hints[1].mult >= hints[0].mult                 # each scene learnt ITS budget
+        assert len(pool) == 1                                 # one arena served all 24 frames
+        for i in (0, 1):
+            tail = sorted(ms[i][4:])
+            med = tail[len(tail) // 2]
+            assert max(ms[i][4:]) <= 1.3 * med + 0.05, (i, ms[i])
+    finally:
+        ops.SLICE_ADAPT, ops.SLICE_BASE = saved
+        ops.release_arenas()

@@ -306,38 +306,65 @@ def test_sparse_exchange_state_is_per_group_and_follows_N(gs):
 
 
 def test_adaptive_slice_budget_schedule(gs):
-    """ops.SLICE_ADAPT, the host-side rule alone: the first slice's budget doubles (up to 8x) after a frame that issued two
-    or more slices, stays after one-slice frames, is keyed by the frame's shape, is forgotten every 256 frames and does
-    nothing when switched off or when slicing itself is off (`-m gpu` twin: test_adaptive_slice_budget)"""
+    """ops.FrameHints, the host-side rule alone: the first slice's budget doubles (up to 8x) after a frame that issued two
+    or more slices, stays after one-slice frames, belongs to ONE owner (two scenes of one shape never share it), is
+    forgotten every 256 frames, does nothing when switched off or when slicing itself is off, and says when it has
+    settled (`-m gpu` twin: test_adaptive_slice_budget)"""
     from gsdeblur_amd import ops
-    saved = (ops.SLICE_ADAPT, ops.SLICE_BASE, dict(ops._slice_hint))
+    saved = (ops.SLICE_ADAPT, ops.SLICE_BASE)
     try:
-        ops._slice_hint.clear()
         ops.SLICE_ADAPT, ops.SLICE_BASE = 1, 512
-        a, b = ("cuda:0", 1000, 5, 5, 64, 64), ("cuda:0", 2000, 5, 5, 64, 64)
-        seen = []
-        for issued in (3, 2, 2, 1, 3):
-            seen.append(ops._slice_base_for(a))
-            ops._slice_feedback(a, issued)
-        assert seen == [512, 1024, 2048, 4096, 4096] and ops._slice_base_for(a) == 4096      # capped at 8x, never shrinks
+        a, b = ops.FrameHints(), ops.FrameHints()
+        seen, settled = [], []
+        for issued in (3, 2, 2, 1, 1, 3):
+            seen.append(a.slice_base())
+            a.feedback(issued)
+            settled.append(a.settled)
+        assert seen == [512, 1024, 2048, 4096, 4096, 4096] and a.slice_base() == 4096        # capped at 8x, never shrinks
+        # settled = the last two frames ran at the budget the next one will use, same slice count, no arena retry
+        assert settled == [False, False, False, False, True, False]
         for _ in range(5):
-            ops._slice_feedback(b, 1)
-        assert ops._slice_base_for(b) == 512                                                  # one-slice frames: untouched
+            b.feedback(1)
+        assert b.slice_base() == 512 and b.settled                                            # one-slice frames: untouched
+        b.feedback(1, retries=1)
+        assert not b.settled and b.arena_retries == 1                                         # an arena retry unsettles
         for _ in range(256):
-            ops._slice_feedback(a, 1)
-        assert ops._slice_base_for(a) == 512                                                  # forgotten, re-learnt later
-        ops._slice_feedback(a, 4)
-        assert ops._slice_base_for(a) == 1024
+            a.feedback(1)
+        assert a.slice_base() == 512                                                          # forgotten, re-learnt later
+        a.feedback(4)
+        assert a.slice_base() == 1024
         ops.SLICE_ADAPT = 0
-        assert ops._slice_base_for(a) == 512
-        ops._slice_feedback(a, 4)
-        assert ops._slice_hint[a][0] == 2                                                     # off: no bookkeeping either
+        assert a.slice_base() == 512
+        a.feedback(4)
+        assert a.mult == 2                                                                    # off: no bookkeeping either
         ops.SLICE_ADAPT, ops.SLICE_BASE = 1, 0
-        assert ops._slice_base_for(a) == 0                                                    # one slice for everything
+        assert a.slice_base() == 0                                                            # one slice for everything
+        # the default owner: one FrameHints per key, and the key separates scenes of one shape by parameter storage
+        k1, k2 = ("cuda:0", 1000, 5, 5, 64, 64, False, 0x1000), ("cuda:0", 1000, 5, 5, 64, 64, False, 0x2000)
+        assert ops.hints_for(k1) is ops.hints_for(k1) and ops.hints_for(k1) is not ops.hints_for(k2)
     finally:
-        ops.SLICE_ADAPT, ops.SLICE_BASE = saved[0], saved[1]
-        ops._slice_hint.clear()
-        ops._slice_hint.update(saved[2])
+        ops.SLICE_ADAPT, ops.SLICE_BASE = saved
+
+
+def test_polled_readbacks_need_two_cores_per_local_rank(gs, monkeypatch):
+    """a polling rank spins a host core while it waits; with N ranks on one host the default
+    only polls when the affinity mask holds two cores per local rank, GSD_FRAME_POLL set explicitly wins"""
+    from gsdeblur_amd import ops
+    monkeypatch.delenv("GSD_FRAME_POLL", raising=False)
+    monkeypatch.setattr(ops, "FRAME_POLL", 1)
+    monkeypatch.setattr(ops, "_host_cores", lambda: 16)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert ops.frame_poll() == 1 and ops.readback_mode() == {"poll": True, "host_cores": 16, "local_world": 8, "forced": False}
+    monkeypatch.setattr(ops, "_host_cores", lambda: 12)
+    assert ops.frame_poll() == 0
+    monkeypatch.setenv("GSD_FRAME_POLL", "1")
+    assert ops.frame_poll() == 1 and ops.readback_mode()["forced"]
+    monkeypatch.delenv("GSD_FRAME_POLL")
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    monkeypatch.setattr(ops, "_host_cores", lambda: 2)
+    assert ops.frame_poll() == 1
+    monkeypatch.setattr(ops, "FRAME_POLL", 0)
+    assert ops.frame_poll() == 0
 
 
 def test_bench_launcher_argv_and_world_check():
