@@ -129,10 +129,16 @@ def readback_mode() -> dict:
             "forced": "GSD_FRAME_POLL" in os.environ}
 # widest radix digit of the compacting depth pre-sort: 8 -> 4 passes of 8 bits, 11 -> 3 passes of 11/10/10 bits
 DEPTH_SORT_DIGIT = int(os.environ.get("GSD_DEPTH_SORT_DIGIT", "8"))
-# gradient conventions recollected from upstream gsplat 0.1.11, bit mask, default 0 = the true
-# derivatives: 1 = back-propagate through the fov clamp of x/z, y/z as if inactive; 2 = quaternion gradient without
-# the projection through q/|q|; 4 = let the gradient pass the alpha = min(0.999, .) clamp.  7 = all three.
-UPSTREAM_GRADS = int(os.environ.get("GSD_UPSTREAM_GRADS", "0"))
+# Gradient conventions (SURVEY App. A "Backward"), bit mask.  Default 7 = the REFERENCE's, as recollected
+# from upstream gsplat 0.1.11 — three places where its backward is not the derivative of its forward, each a
+# straight-through rule: 1 = back-propagate through the fov clamp of x/z, y/z as if inactive; 2 = quaternion gradient
+# w.r.t. the (assumed unit) quaternion, without the projection through q/|q|; 4 = let the gradient pass the
+# alpha = min(0.999, .) clamp.  0 = the true derivatives (opt-in: GSD_UPSTREAM_GRADS=0).  The oracle has the same
+# switch with the same default (its UP_* constants, RenderConfig.upstream_grads) and the `-m gpu` suite runs both.
+# Bit 2 only exists on the compat op (project_gaussians): the FUSED ops (render_subposes / render_combined / render_step)
+# take splatfacto's raw quaternions, i.e. they stand for `quats / quats.norm()` + the kernel, and the reference's
+# end-to-end gradient of that pair is J_norm^T g — exactly the gradient through the normalisation the fused kernels return.
+UPSTREAM_GRADS = int(os.environ.get("GSD_UPSTREAM_GRADS", "7"))
 
 
 # 1 (default): Gaussians whose scales differ by more than 8x get the covariance part of their projection backward
@@ -142,7 +148,8 @@ NEEDLE_HP = int(os.environ.get("GSD_NEEDLE_HP", "1"))
 
 
 def _proj_grad_flags() -> int:
-    return (UPSTREAM_GRADS & 3) | (0 if NEEDLE_HP else 8)
+    """gradient flags of the FUSED projection backward: bit 2 (raw quaternion gradient) never applies there"""
+    return (UPSTREAM_GRADS & 1) | (0 if NEEDLE_HP else 8)
 
 
 def _bwd_variant() -> int:

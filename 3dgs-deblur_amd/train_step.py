@@ -171,7 +171,10 @@ def train_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.O
         dp.allreduce_dense_([p.grad for p in small], average=True)
     optimizers_step(optimizers.values())
     model.step += 1
-    return {"loss": float(loss.item()), "psnr": psnr(rgb, gt_image)}
+    # ONE read-back for the step's two log values (each .item() is a stream synchronisation)
+    mse = torch.mean((rgb.clamp(0, 1) - gt_image.clamp(0, 1)) ** 2)
+    loss_v, mse_v = torch.stack([loss.detach().reshape(()).float(), mse.float()]).tolist()
+    return {"loss": float(loss_v), "psnr": float("inf") if mse_v == 0 else -10.0 * math.log10(mse_v)}
 
 
 # --------------------------------------------------------------------------- #

@@ -44,6 +44,38 @@ ALPHA_MIN = 1.0 / 255.0
 T_MIN = 1e-4
 TILE = 16
 
+# ---- gradient conventions (SURVEY.md App. A "Backward") -------------------------------------------------
+# Three places where the backward recollected from upstream gsplat 0.1.11 is NOT the derivative of its forward; each is
+# a straight-through rule (the forward value is kept, the backward treats the operation as the identity):
+#   UP_FOV_CLAMP  (1)  the clamp of x/z, y/z to +-1.3 tan(fov/2) in front of the EWA Jacobian
+#   UP_QUAT_RAW   (2)  the normalisation q/|q| inside the kernel: the gradient is returned w.r.t. the (assumed unit)
+#                      quaternion.  Only the compat op (project_gaussians) honours it: the FUSED path (render) takes
+#                      splatfacto's raw quaternions, i.e. it stands for `quats / quats.norm()` + the kernel, and the
+#                      reference's end-to-end gradient there is J_norm^T g — the true derivative of the normalising form
+#   UP_ALPHA_CLAMP (4) alpha = min(0.999, o e^{-sigma}): v_sigma = -o e^{-sigma} v_alpha with no clamp term
+# UPSTREAM = all three = the reference's conventions = the product's default (ops.UPSTREAM_GRADS = 7); 0 = the true
+# derivatives (what finite differences see; opt-in on the product side).
+UP_FOV_CLAMP, UP_QUAT_RAW, UP_ALPHA_CLAMP = 1, 2, 4
+UPSTREAM = 7
+
+
+class _StraightThrough(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, value, identity):
+        return value.detach().clone()          # the forward value, bit for bit
+
+    @staticmethod
+    def backward(ctx, v):
+        return None, v
+
+
+def _straight_through(value: torch.Tensor, identity: torch.Tensor) -> torch.Tensor:
+    """forward: `value` (exactly); backward: as if the result were `identity` (d result / d identity = 1, nothing
+    reaches `value`)"""
+    if not (torch.is_grad_enabled() and identity.requires_grad):
+        return value
+    return _StraightThrough.apply(value, identity)
+
 
 # --------------------------------------------------------------------------- #
 # projection  (SURVEY §8 a1; App. A "Projection", "Tile bbox")
@@ -58,11 +90,15 @@ def _sqrt(x: torch.Tensor) -> torch.Tensor:
     return torch.sqrt(x)
 
 
-def quat_to_rotmat(q: torch.Tensor) -> torch.Tensor:
-    """(w,x,y,z) -> R[...,3,3]; normalises like gs::quat_to_rotmat."""
+def quat_to_rotmat(q: torch.Tensor, raw_grad: bool = False) -> torch.Tensor:
+    """(w,x,y,z) -> R[...,3,3]; normalises like gs::quat_to_rotmat.  raw_grad (UP_QUAT_RAW): the gradient reaching q is
+    the one w.r.t. the normalised quaternion (gs::cov3d_bwd raw_quat_grad)."""
     n2 = ((q[..., 0] * q[..., 0] + q[..., 1] * q[..., 1]) + q[..., 2] * q[..., 2]) + q[..., 3] * q[..., 3]
     inv = 1.0 / _sqrt(n2)
-    w, x, y, z = q[..., 0] * inv, q[..., 1] * inv, q[..., 2] * inv, q[..., 3] * inv
+    qn = q * inv[..., None]
+    if raw_grad:
+        qn = _straight_through(qn, q)
+    w, x, y, z = qn[..., 0], qn[..., 1], qn[..., 2], qn[..., 3]
     R = torch.stack(
         [
             1.0 - 2.0 * (y * y + z * z), 2.0 * (x * y - w * z), 2.0 * (x * z + w * y),
@@ -74,9 +110,9 @@ def quat_to_rotmat(q: torch.Tensor) -> torch.Tensor:
     return R.reshape(q.shape[:-1] + (3, 3))
 
 
-def scale_rot_to_cov3d(scales: torch.Tensor, glob_scale: float, quats: torch.Tensor) -> torch.Tensor:
+def scale_rot_to_cov3d(scales: torch.Tensor, glob_scale: float, quats: torch.Tensor, raw_quat_grad: bool = False) -> torch.Tensor:
     """cov3d upper triangle [N,6] = (R S)(R S)^T, same association as gs::scale_rot_to_cov3d."""
-    R = quat_to_rotmat(quats)
+    R = quat_to_rotmat(quats, raw_quat_grad)
     s = glob_scale * scales
     M = R * s[..., None, :]
     def dot(i, j):
@@ -98,14 +134,17 @@ class Projected:
 
 
 def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy,
-                      img_height, img_width, block_width=TILE, clip_thresh=0.01, keep_offscreen=False) -> Projected:
+                      img_height, img_width, block_width=TILE, clip_thresh=0.01, keep_offscreen=False,
+                      upstream: int = UPSTREAM) -> Projected:
     """Restates gsplat.project_gaussians (absent fork).  dtype follows inputs.
     keep_offscreen=True keeps centre / conic / radius of Gaussians whose 3-sigma box covers no tile (only the
-    near-plane and singular-covariance culls apply): the pixel-velocity model re-centres them per sub-pose."""
+    near-plane and singular-covariance culls apply): the pixel-velocity model re-centres them per sub-pose.
+    upstream: bit mask of UP_FOV_CLAMP / UP_QUAT_RAW (gradient conventions only; every value is unchanged); default:
+    the reference's conventions, like the product's compat op."""
     assert block_width == TILE
     dt = means3d.dtype
     V = viewmat.to(dt)
-    c3 = scale_rot_to_cov3d(scales, glob_scale, quats)
+    c3 = scale_rot_to_cov3d(scales, glob_scale, quats, bool(upstream & UP_QUAT_RAW))
     mx, my, mz = means3d[:, 0], means3d[:, 1], means3d[:, 2]
     px = ((V[0, 0] * mx + V[0, 1] * my) + V[0, 2] * mz) + V[0, 3]
     py = ((V[1, 0] * mx + V[1, 1] * my) + V[1, 2] * mz) + V[1, 3]
@@ -119,6 +158,9 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
     fx_t, fy_t, cx_t, cy_t = one * fx, one * fy, one * cx, one * cy
     tx = pz_safe * torch.minimum(lim_x, torch.maximum(-lim_x, px * rz))
     ty = pz_safe * torch.minimum(lim_y, torch.maximum(-lim_y, py * rz))
+    if upstream & UP_FOV_CLAMP:
+        # gs::project_one_bwd upstream_clamp_grad: v_px += v_tx, v_py += v_ty whether or not the clamp is active
+        tx, ty = _straight_through(tx, px), _straight_through(ty, py)
     rz2 = rz * rz
     J00 = fx_t * rz
     J02 = -(fx_t * tx) * rz2
@@ -291,8 +333,20 @@ def get_tile_bin_edges(sorted_ids: np.ndarray, num_tiles: int) -> np.ndarray:
 # --------------------------------------------------------------------------- #
 # rasterize (App. A "Blend") — vectorised per tile, autograd bwd
 # --------------------------------------------------------------------------- #
-FRAGILE_ALPHA_BAND = 5e-5     # round 1 used 2e-4 / 2e-3 and excluded up to 10 % of the pixels of a 5-sample frame
-FRAGILE_T_BAND = 5e-4
+# Which pixels sit within fp32 rounding of a threshold decision (and are left out of strict comparisons).  Round 5: the
+# bands follow a rounding MODEL instead of flat widths (rounds 2-4: 5e-5 / 5e-4, which flagged 3-7 % of a multi-sample
+# frame, nine tenths of it through the T band):
+#  * alpha_i = o_i e^{-sigma_i}: an fp32 pipeline's sigma differs from float64's by 1e-6 (median) ... 1.2e-5 (p99) ...
+#    3e-5 (max) at the suite's sizes (measured, fp32 vs float64 projection of the test scenes) = alpha's RELATIVE error
+#    -> FRAGILE_ALPHA_BAND = 5e-5 on alpha / (1/255) stays;
+#  * T_k = prod_{i<=k} (1 - alpha_i): relative error = sum_i (alpha_i / (1 - alpha_i)) * err_i, signs random -> the band
+#    on T_k / 1e-4 is FRAGILE_T_FLOOR + FRAGILE_T_GAIN * sqrt(sum_i (alpha_i / (1 - alpha_i))^2) (an alpha sitting ON the
+#    0.999 clamp is exact on both sides and contributes nothing); GAIN = 3e-5 is ~10x the rms alpha error.  A pixel that
+#    stops after twenty entries of alpha ~0.4 gets 1e-4 (5x tighter than the flat band), one that crosses the threshold
+#    right behind an alpha = 0.99 entry gets 3e-3 (wider: there a 1e-5 error in alpha really moves T by 1e-3).
+FRAGILE_ALPHA_BAND = 5e-5
+FRAGILE_T_FLOOR = 2e-5
+FRAGILE_T_GAIN = 3e-5
 
 
 @dataclass
@@ -306,10 +360,12 @@ class Rasterized:
 
 def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.ndarray, tile_bins: np.ndarray,
                      img_height: int, img_width: int, background: Optional[torch.Tensor] = None,
-                     tile_rows: Optional[Tuple[int, int]] = None, row_shift=None) -> Rasterized:
+                     tile_rows: Optional[Tuple[int, int]] = None, row_shift=None, upstream: int = UPSTREAM) -> Rasterized:
     """Front-to-back alpha compositing of pre-sorted intersections, differentiable by autograd.
     row_shift = (pix_vel [N,2], tau [H]): pixel row y evaluates every splat at xys + tau[y] * pix_vel (the exact
-    rolling-shutter form of the pixel-velocity model)."""
+    rolling-shutter form of the pixel-velocity model).
+    upstream & UP_ALPHA_CLAMP: the gradient passes alpha = min(0.999, o e^{-sigma}) as if the clamp were inactive
+    (SURVEY App. A "Backward": v_sigma = -o e^{-sigma} v_alpha with no clamp term)."""
     dt = xys.dtype
     H, W = img_height, img_width
     tiles_x = (W + TILE - 1) // TILE
@@ -355,7 +411,10 @@ def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.nda
                 dy = dy + pv_[ids, 1][:, None] * TAU[None, :]
             sigma = 0.5 * (cxx[:, None] * dx * dx + cyy[:, None] * dy * dy) + cxy[:, None] * dx * dy
             vis = torch.exp(-sigma)
-            alpha = torch.clamp(opac[ids][:, None] * vis, max=ALPHA_MAX)
+            ov = opac[ids][:, None] * vis
+            alpha = torch.clamp(ov, max=ALPHA_MAX)
+            if upstream & UP_ALPHA_CLAMP:
+                alpha = _straight_through(alpha, ov)
             valid = (sigma >= 0) & (alpha >= ALPHA_MIN)
             a = torch.where(valid, alpha, torch.zeros_like(alpha))
             Tincl = torch.cumprod(1.0 - a, dim=0)
@@ -372,10 +431,11 @@ def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.nda
             # fragile decisions (used only to exclude pixels from strict comparisons)
             with torch.no_grad():
                 reach = Texcl > T_MIN
-                # bands: ~50x the fp32 error of the quantity compared (alpha: ~1e-6 relative from the fast exp2 of
-                # an exponent of magnitude <= 8; T: a product of up to a few hundred fp32 factors, ~1e-5 relative)
                 f1 = (reach & ((alpha / ALPHA_MIN - 1.0).abs() < FRAGILE_ALPHA_BAND)).any(dim=0)
-                f2 = (valid & reach & ((Tincl / T_MIN - 1.0).abs() < FRAGILE_T_BAND)).any(dim=0)
+                on_clamp = ov > ALPHA_MAX * (1.0 + 2.0 * FRAGILE_ALPHA_BAND)
+                amp = torch.where(on_clamp, torch.zeros_like(a), a / (1.0 - a))
+                band_T = FRAGILE_T_FLOOR + FRAGILE_T_GAIN * torch.sqrt(torch.cumsum(amp * amp, dim=0))
+                f2 = (valid & reach & ((Tincl / T_MIN - 1.0).abs() < band_T)).any(dim=0)
                 f3 = (reach & (sigma.abs() < 1e-7) & (sigma != 0)).any(dim=0)
             tile_imgs.append(C.reshape(hh, ww, 3))
             tile_Ts.append(Tfin.reshape(hh, ww))
@@ -389,7 +449,8 @@ def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.nda
 
 
 def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
-                        block_width=TILE, background=None, return_alpha=False, proj: Optional[Projected] = None):
+                        block_width=TILE, background=None, return_alpha=False, proj: Optional[Projected] = None,
+                        upstream: int = UPSTREAM):
     """gsplat.rasterize_gaussians restated (bin + sort + composite).  Needs tile bounds, which upstream
     recomputes from xys/radii; here they are recomputed the same way when `proj` is not given."""
     assert block_width == TILE
@@ -399,7 +460,7 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
     keys, gids = sort_intersects(keys, gids)
     tiles = ((img_width + TILE - 1) // TILE) * ((img_height + TILE - 1) // TILE)
     bins = get_tile_bin_edges(keys, tiles)
-    r = rasterize_sorted(xys, conics, colors, opacity, gids, bins, img_height, img_width, background)
+    r = rasterize_sorted(xys, conics, colors, opacity, gids, bins, img_height, img_width, background, upstream=upstream)
     return (r.img, r.alpha, r) if return_alpha else (r.img, r)
 
 
@@ -532,6 +593,9 @@ class RenderConfig:
     # one sorted list per tile, every sample walks it and evaluates a splat at xy_c + (t_s - t_c + tau(y)) * velocity.
     # The per-sample lists (shared_list False) cut each splat at its own 3-sigma box; this form cuts it at the swept box.
     shared_list: bool = False
+    # gradient conventions (bit mask, see UP_* at the top): UPSTREAM (7, default) = the reference's, as recollected —
+    # the product's default; 0 = true derivatives.  render() is the FUSED path: UP_QUAT_RAW does not apply to it.
+    upstream_grads: int = UPSTREAM
 
 
 def combine_samples(samples: torch.Tensor, gamma: float, min_rgb_level: float) -> torch.Tensor:
@@ -545,7 +609,8 @@ def combine_samples(samples: torch.Tensor, gamma: float, min_rgb_level: float) -
     return x.pow(gamma).mean(dim=0).pow(1.0 / gamma)
 
 
-def pixel_velocity(means3d, viewmat, fx, fy, lin_vel, ang_vel, clip_thresh=0.01, img_width=None, img_height=None):
+def pixel_velocity(means3d, viewmat, fx, fy, lin_vel, ang_vel, clip_thresh=0.01, img_width=None, img_height=None,
+                   upstream: int = UPSTREAM):
     """[N,2] pixel velocity of every Gaussian centre under the camera's body twist (lin, ang in the OpenCV camera
     frame): a static point moves in camera space with u = -(ang x p_c + lin), its pixel with J u, J = the pinhole
     Jacobian where the covariance projection takes its own: at the centre with x/z, y/z clamped to the fov guard band
@@ -573,6 +638,8 @@ def pixel_velocity(means3d, viewmat, fx, fy, lin_vel, ang_vel, clip_thresh=0.01,
         xz, yz = px * rz, py * rz
         jx = torch.where(xz.detach().abs() > lim_x, pz * torch.minimum(lim_x, torch.maximum(-lim_x, xz)), px)
         jy = torch.where(yz.detach().abs() > lim_y, pz * torch.minimum(lim_y, torch.maximum(-lim_y, yz)), py)
+        if upstream & UP_FOV_CLAMP:       # gs::pixel_velocity_bwd upstream_clamp_grad: the same rule as project_one_bwd
+            jx, jy = _straight_through(jx, px), _straight_through(jy, py)
     return torch.stack([(fx_t * rz) * ux - ((fx_t * jx) * rz2) * uz, (fy_t * rz) * uy - ((fy_t * jy) * rz2) * uz], dim=-1)
 
 
@@ -595,6 +662,7 @@ def render(cfg: RenderConfig, means, scales, quats, opacities, sh_coeffs, viewma
     if cfg.motion_model != "se3":
         raise ValueError(f"unknown motion model {cfg.motion_model!r}")
     dt = means.dtype
+    up = int(cfg.upstream_grads) & (UP_FOV_CLAMP | UP_ALPHA_CLAMP)       # fused path: UP_QUAT_RAW does not apply
     times, samp, band = subpose_times(cfg.blur_samples, cfg.exposure_time, cfg.rs_bands, cfg.rolling_shutter_time)
     vms = subpose_viewmats(viewmat, lin_vel, ang_vel, times)
     rows = band_tile_rows(cfg.img_height, cfg.rs_bands)
@@ -606,7 +674,7 @@ def render(cfg: RenderConfig, means, scales, quats, opacities, sh_coeffs, viewma
     frag = torch.zeros(H, W, dtype=torch.bool)
     for p, V in enumerate(vms):
         pr = project_gaussians(means, scales, cfg.glob_scale, quats, V, cfg.fx, cfg.fy, cfg.cx, cfg.cy,
-                               H, W, TILE, cfg.clip_thresh)
+                               H, W, TILE, cfg.clip_thresh, upstream=up & UP_FOV_CLAMP)
         Rwc, twc = V[:3, :3].detach(), V[:3, 3].detach()
         cam_pos = -(Rwc.T @ twc)
         dirs = means.detach() - cam_pos[None, :]
@@ -616,7 +684,8 @@ def render(cfg: RenderConfig, means, scales, quats, opacities, sh_coeffs, viewma
         keys, gids = sort_intersects(keys, gids)
         tiles = ((W + TILE - 1) // TILE) * ((H + TILE - 1) // TILE)
         bins = get_tile_bin_edges(keys, tiles)
-        r = rasterize_sorted(pr.xys, pr.conics, rgb, op, gids, bins, H, W, background, tile_rows=rows[band[p]])
+        r = rasterize_sorted(pr.xys, pr.conics, rgb, op, gids, bins, H, W, background, tile_rows=rows[band[p]],
+                             upstream=up)
         sample_imgs[samp[p]] = sample_imgs[samp[p]] + r.img
         sample_alpha[samp[p]] = sample_alpha[samp[p]] + r.alpha
         frag |= r.fragile
@@ -642,9 +711,10 @@ def _render_pixel_velocity(cfg: RenderConfig, means, scales, quats, opacities, s
     V = viewmat
     # row time of every pixel row (pixel centres at +0.5), continuous form
     tau_rows = ((torch.arange(H, dtype=dt) + 0.5) / H - 0.5) * cfg.rolling_shutter_time if exact else None
+    up = int(cfg.upstream_grads) & (UP_FOV_CLAMP | UP_ALPHA_CLAMP)       # fused path: UP_QUAT_RAW does not apply
     pr0 = project_gaussians(means, scales, cfg.glob_scale, quats, V, cfg.fx, cfg.fy, cfg.cx, cfg.cy, H, W, TILE,
-                            cfg.clip_thresh, keep_offscreen=True)
-    pv = pixel_velocity(means, V, cfg.fx, cfg.fy, lin_vel, ang_vel, cfg.clip_thresh, W, H)
+                            cfg.clip_thresh, keep_offscreen=True, upstream=up & UP_FOV_CLAMP)
+    pv = pixel_velocity(means, V, cfg.fx, cfg.fy, lin_vel, ang_vel, cfg.clip_thresh, W, H, upstream=up & UP_FOV_CLAMP)
     Rwc, twc = V[:3, :3].detach(), V[:3, 3].detach()
     cam_pos = -(Rwc.T @ twc)
     rgb = torch.clamp(spherical_harmonics(cfg.sh_degree, means.detach() - cam_pos[None, :], sh_coeffs) + 0.5, min=0.0)
@@ -669,7 +739,7 @@ def _render_pixel_velocity(cfg: RenderConfig, means, scales, quats, opacities, s
         row_tau = tau_rows if exact else torch.zeros(H, dtype=dt)
         for p, tau in enumerate(f32t):
             r = rasterize_sorted(pr.xys, pr.conics, rgb, op, gids, bins, H, W, background,
-                                 row_shift=(pv * geom, row_tau + float(np.float32(tau - t_c))))
+                                 row_shift=(pv * geom, row_tau + float(np.float32(tau - t_c))), upstream=up)
             sample_imgs[p] = sample_imgs[p] + r.img
             sample_alpha[p] = sample_alpha[p] + r.alpha
             frag |= r.fragile
@@ -685,7 +755,7 @@ def _render_pixel_velocity(cfg: RenderConfig, means, scales, quats, opacities, s
         keys, gids = sort_intersects(keys, gids)
         bins = get_tile_bin_edges(keys, tiles)
         r = rasterize_sorted(pr.xys, pr.conics, rgb, op, gids, bins, H, W, background, tile_rows=rows[band[p]],
-                             row_shift=(pv * geom, tau_rows) if exact else None)
+                             row_shift=(pv * geom, tau_rows) if exact else None, upstream=up)
         sample_imgs[samp[p]] = sample_imgs[samp[p]] + r.img
         sample_alpha[samp[p]] = sample_alpha[samp[p]] + r.alpha
         frag |= r.fragile

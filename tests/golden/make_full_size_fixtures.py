@@ -20,7 +20,7 @@ pixel of the tile can reach, + 8), and the pixel arrays.  tests/test_gpu_parity.
 scenes through the HIP path at full size and compares.  SELF-GOLDEN (oracle-made), like tests/golden/*.npz: parity
 with the absent fork stays unpinned.
 
-    python tests/golden/make_full_size_fixtures.py          (~2 min on 8 cores, build container or any CPU box)
+    python tests/golden/make_full_size_fixtures.py          (~3 min on 8 cores, build container or any CPU box)
 """
 import sys
 from pathlib import Path
@@ -57,6 +57,7 @@ def composite_tile(xy, conic, rgb, op, px, py, chunk=512):
     stop_pos = torch.full((P,), xy.shape[0], dtype=torch.int64)
     last = torch.zeros(P, dtype=torch.int64)
     frag = torch.zeros(P, dtype=torch.bool)
+    amp2 = torch.zeros(P, dtype=torch.float64)        # running sum of (alpha / (1 - alpha))^2 of the blended entries
     n = xy.shape[0]
     reached = 0
     for c0 in range(0, n, chunk):
@@ -66,7 +67,8 @@ def composite_tile(xy, conic, rgb, op, px, py, chunk=512):
         dx = xy[c0:c1, 0:1] - px[None, :]
         dy = xy[c0:c1, 1:2] - py[None, :]
         sigma = 0.5 * (conic[c0:c1, 0:1] * dx * dx + conic[c0:c1, 2:3] * dy * dy) + conic[c0:c1, 1:2] * dx * dy
-        alpha = torch.clamp(op[c0:c1, None] * torch.exp(-sigma), max=O.ALPHA_MAX)
+        ov = op[c0:c1, None] * torch.exp(-sigma)
+        alpha = torch.clamp(ov, max=O.ALPHA_MAX)
         valid = (sigma >= 0) & (alpha >= O.ALPHA_MIN)
         a = torch.where(valid, alpha, torch.zeros_like(alpha))
         Tincl = T[None, :] * torch.cumprod(1.0 - a, dim=0)
@@ -83,7 +85,14 @@ def composite_tile(xy, conic, rgb, op, px, py, chunk=512):
         last = torch.maximum(last, torch.where(blended, k + 1, torch.zeros_like(k)).max(dim=0).values)
         reach = (Texcl > O.T_MIN) & ~stopped[None, :] & (k <= torch.where(fd < n, fd, torch.full_like(fd, n))[None, :])
         f1 = (reach & ((alpha / O.ALPHA_MIN - 1.0).abs() < O.FRAGILE_ALPHA_BAND)).any(dim=0)
-        f2 = (valid & reach & ((Tincl / O.T_MIN - 1.0).abs() < O.FRAGILE_T_BAND)).any(dim=0)
+        # the oracle's rounding model of T (gs_oracle.rasterize_sorted): floor + gain * root-sum-square of the entries'
+        # alpha / (1 - alpha) so far (an alpha ON the clamp is exact and adds nothing)
+        on_clamp = ov > O.ALPHA_MAX * (1.0 + 2.0 * O.FRAGILE_ALPHA_BAND)
+        amp = torch.where(on_clamp, torch.zeros_like(a), a / (1.0 - a))
+        rss2 = amp2[None, :] + torch.cumsum(amp * amp, dim=0)
+        band_T = O.FRAGILE_T_FLOOR + O.FRAGILE_T_GAIN * torch.sqrt(rss2)
+        f2 = (valid & reach & ((Tincl / O.T_MIN - 1.0).abs() < band_T)).any(dim=0)
+        amp2 = torch.where(stopped, amp2, rss2[-1])
         f3 = (reach & (sigma.abs() < 1e-7) & (sigma != 0)).any(dim=0)
         frag |= f1 | f2 | f3
         # T after the chunk: the product over blended entries only
@@ -93,6 +102,12 @@ def composite_tile(xy, conic, rgb, op, px, py, chunk=512):
         stopped = stopped | newly
         reached = c1
     return C, T, stop_pos, last, frag, reached
+
+
+def tile_weights(ti: int, p: int, hh: int, ww: int) -> torch.Tensor:
+    """d loss / d rgb of one sampled (tile, sub-pose): seeded, float64 [hh,ww,3] in [0,1)"""
+    g = torch.Generator().manual_seed(100003 * int(p) + int(ti) + 17)
+    return torch.rand(hh, ww, 3, generator=g, dtype=torch.float64)
 
 
 def tensor_hash(t: torch.Tensor) -> str:
@@ -165,6 +180,26 @@ def make(tag, S, R, out_name):
             out[key + "_stop"] = stop_pos.reshape(hh, ww).numpy().astype(np.int32)
             out[key + "_last"] = last.reshape(hh, ww).numpy().astype(np.int32)
             out[key + "_frag"] = np.packbits(frag.numpy())
+            # ---- round 5: GRADIENTS at the bench's own size.  d (sum_pixels w . rgb) / d (record
+            # fields) of the tile's reachable entries — screen-space centre (2), conic (3), opacity (1), colour (3) — by
+            # float64 autograd through gs_oracle.rasterize_sorted on the tile alone, under both gradient conventions of
+            # the alpha clamp (_gu: the reference's = the product's default, _g: true derivatives).  w: seeded per
+            # (tile, sub-pose), zero on the fragile pixels.  The test feeds the SAME w (zero outside the sampled tiles) to
+            # the HIP backward of the full frame and compares the rows of these entries.
+            wt = tile_weights(ti, p, hh, ww) * (~frag).reshape(hh, ww, 1)
+            shift = torch.tensor([float(x_lo), float(y_lo)], dtype=torch.float64)
+            bins1 = np.array([[0, keep]], dtype=np.int32)
+            for conv, upflag in (("_gu", O.UP_ALPHA_CLAMP), ("_g", 0)):
+                leaves = [t[:keep].detach().clone().requires_grad_(True) for t in (pr64.xys, pr64.conics, rgb, op)]
+                r = O.rasterize_sorted(leaves[0] - shift[None, :], leaves[1], leaves[2], leaves[3],
+                                       np.arange(keep, dtype=np.int32), bins1, hh, ww, None, upstream=upflag)
+                if conv == "_gu":
+                    assert (r.img.detach().reshape(-1, 3) - C).abs().max() < 1e-12, key
+                (r.img * wt).sum().backward()
+                gmat = torch.cat([leaves[0].grad, leaves[1].grad, leaves[3].grad[:, None], leaves[2].grad],
+                                 dim=1).numpy().astype(np.float32)                    # [keep, 9]: xy, conic, opacity, rgb
+                if conv == "_gu" or not np.array_equal(gmat, out[key + "_gu"]):
+                    out[key + conv] = gmat        # _g is stored only where the clamp is reached (else: equal to _gu)
         print(f"{tag}: sub-pose {p + 1}/{S * R} done", flush=True)
     out["tile_intersections_per_step"] = np.int64(total_pairs)
     np.savez_compressed(HERE / out_name, **out)

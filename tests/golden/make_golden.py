@@ -50,7 +50,7 @@ def make_case(name, n, W, H, cfg_kw, seed, sh_degree=3, scale_mult=16.0, from_a_
     sc["lin_vel"], sc["ang_vel"] = sc["lin_vel"] * vel_mult[0], sc["ang_vel"] * vel_mult[1]
     if from_a_real_pose:
         sc = posed(sc)
-    cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], sh_degree=sh_degree, **cfg_kw)
+    cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], sh_degree=sh_degree, upstream_grads=0, **cfg_kw)
     names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel"]
     ps = {k: sc[k].double().requires_grad_(True) for k in names}
     V = sc["viewmat"].double().requires_grad_(True)
@@ -61,6 +61,16 @@ def make_case(name, n, W, H, cfg_kw, seed, sh_degree=3, scale_mult=16.0, from_a_
     g = torch.Generator().manual_seed(seed + 1)
     wt = torch.rand(H, W, 3, generator=g, dtype=torch.float64) * (~frag)[..., None]
     (out * wt).sum().backward()
+    # round 5: the same loss differentiated under the REFERENCE's gradient conventions (O.UPSTREAM: straight-through fov
+    # clamp and alpha clamp; the product's default) — stored as gu_*; g_* are the true derivatives
+    import dataclasses
+    pu = {k: sc[k].double().requires_grad_(True) for k in names}
+    Vu = sc["viewmat"].double().requires_grad_(True)
+    out_u, _ = O.render(dataclasses.replace(cfg, upstream_grads=O.UPSTREAM), pu["means"], pu["log_scales"].exp(),
+                        pu["quats"], torch.sigmoid(pu["opacity_logits"]), pu["sh"], Vu, pu["lin_vel"], pu["ang_vel"],
+                        background=bg)
+    assert torch.equal(out_u.detach(), out.detach())
+    (out_u * wt).sum().backward()
     # float32 integer parity data for sub-pose 0 (same viewmat in float32)
     pr32 = O.project_gaussians(sc["means"], sc["log_scales"].exp(), 1.0, sc["quats"], vms[0].detach().float(),
                                sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W)
@@ -78,6 +88,10 @@ def make_case(name, n, W, H, cfg_kw, seed, sh_degree=3, scale_mult=16.0, from_a_
         g_quats=ps["quats"].grad.numpy(), g_opacity_logits=ps["opacity_logits"].grad.numpy(),
         g_sh=ps["sh"].grad.numpy(), g_lin_vel=ps["lin_vel"].grad.numpy(), g_ang_vel=ps["ang_vel"].grad.numpy(),
         g_viewmat=V.grad.numpy(),
+        gu_means=pu["means"].grad.numpy(), gu_log_scales=pu["log_scales"].grad.numpy(),
+        gu_quats=pu["quats"].grad.numpy(), gu_opacity_logits=pu["opacity_logits"].grad.numpy(),
+        gu_sh=pu["sh"].grad.numpy(), gu_lin_vel=pu["lin_vel"].grad.numpy(), gu_ang_vel=pu["ang_vel"].grad.numpy(),
+        gu_viewmat=Vu.grad.numpy(),
         p0_radii=pr32.radii.numpy(), p0_num_tiles_hit=pr32.num_tiles_hit.numpy(),
         p0_sorted_isect_ids=skeys, p0_sorted_gaussian_ids=sgids,
     )
@@ -97,16 +111,17 @@ def make_large_case(name, n, W, H, cfg_kw, seed, sh_degree=3, scale_mult=2.0, ve
     cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], sh_degree=sh_degree, **cfg_kw)
     names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel", "viewmat"]
     ps = {k: sc[k].double().requires_grad_(True) for k in names}
+    pus = {k: sc[k].double().requires_grad_(True) for k in names}      # round 5: gradients under O.UPSTREAM (gu_*)
     bg = torch.tensor([0.1, 0.2, 0.3], dtype=torch.float64)
     times, samp, band = O.subpose_times(cfg.blur_samples, cfg.exposure_time, cfg.rs_bands, cfg.rolling_shutter_time)
     rows = O.band_tile_rows(H, cfg.rs_bands)
     S = max(1, cfg.blur_samples)
 
-    def render_subpose(p, q):
+    def render_subpose(p, q, up=0):
         vms = O.subpose_viewmats(q["viewmat"], q["lin_vel"], q["ang_vel"], times)
         V = vms[p]
         pr = O.project_gaussians(q["means"], q["log_scales"].exp(), cfg.glob_scale, q["quats"], V, cfg.fx, cfg.fy, cfg.cx,
-                                 cfg.cy, H, W, O.TILE, cfg.clip_thresh)
+                                 cfg.cy, H, W, O.TILE, cfg.clip_thresh, upstream=up & O.UP_FOV_CLAMP)
         cam_pos = -(V[:3, :3].detach().T @ V[:3, 3].detach())
         rgb = torch.clamp(O.spherical_harmonics(cfg.sh_degree, q["means"].detach() - cam_pos[None, :], q["sh"]) + 0.5,
                           min=0.0)
@@ -114,7 +129,8 @@ def make_large_case(name, n, W, H, cfg_kw, seed, sh_degree=3, scale_mult=2.0, ve
         keys, gids = O.map_gaussian_to_intersects(pr, W)
         keys, gids = O.sort_intersects(keys, gids)
         bins = O.get_tile_bin_edges(keys, ((W + O.TILE - 1) // O.TILE) * ((H + O.TILE - 1) // O.TILE))
-        return O.rasterize_sorted(pr.xys, pr.conics, rgb, op, gids, bins, H, W, bg, tile_rows=rows[band[p]]), vms, pr
+        return O.rasterize_sorted(pr.xys, pr.conics, rgb, op, gids, bins, H, W, bg, tile_rows=rows[band[p]],
+                                  upstream=up & O.UP_ALPHA_CLAMP), vms, pr
 
     with torch.no_grad():
         imgs = [torch.zeros(H, W, 3, dtype=torch.float64) for _ in range(S)]
@@ -136,6 +152,8 @@ def make_large_case(name, n, W, H, cfg_kw, seed, sh_degree=3, scale_mult=2.0, ve
     for p in range(len(times)):
         r, _, _ = render_subpose(p, ps)
         (r.img * v_samples[samp[p]]).sum().backward()
+        ru, _, _ = render_subpose(p, pus, O.UPSTREAM)
+        (ru.img * v_samples[samp[p]]).sum().backward()
         print("  sub-pose", p, "done", flush=True)
     alpha = torch.stack(alphas).mean(dim=0)
     d = dict(
@@ -149,6 +167,7 @@ def make_large_case(name, n, W, H, cfg_kw, seed, sh_degree=3, scale_mult=2.0, ve
         p0_radii=radii0.astype(np.int32))
     for k in names:
         d["g_" + k] = ps[k].grad.numpy().astype(np.float32 if ps[k].grad.numel() > 100 else np.float64)
+        d["gu_" + k] = pus[k].grad.numpy().astype(np.float32 if pus[k].grad.numel() > 100 else np.float64)
     np.savez_compressed(OUT / f"{name}.npz", **d)
     rows_g = int((ps["means"].grad.abs().sum(1) > 0).sum())
     print(name, "out mean", float(out.detach().mean()), "alpha mean", float(alpha.mean()), "fragile px",

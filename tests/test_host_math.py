@@ -52,7 +52,7 @@ def scene(oracle):
 def test_projection_integers_bit_exact(hm, oracle, scene):
     O, sc, W, H = oracle, scene["sc"], scene["W"], scene["H"]
     pr = O.project_gaussians(scene["means"], scene["scales"], 1.0, scene["quats"], scene["V"], sc["fx"], sc["fy"],
-                             sc["cx"], sc["cy"], H, W)
+                             sc["cx"], sc["cy"], H, W, upstream=0)
     n = scene["means"].shape[0]
     m, s, q, Vn = (np.ascontiguousarray(scene[k].numpy()) for k in ("means", "scales", "quats", "V"))
     xys = np.zeros((n, 2), np.float32); dep = np.zeros(n, np.float32); rad = np.zeros(n, np.int32)
@@ -78,7 +78,7 @@ def test_projection_backward_vs_autograd(hm, oracle, scene):
     sd = scene["scales"].double().requires_grad_(True)
     qd = scene["quats"].double().requires_grad_(True)
     Vd = scene["V"].double().requires_grad_(True)
-    prd = O.project_gaussians(md, sd, 1.0, qd, Vd, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W)
+    prd = O.project_gaussians(md, sd, 1.0, qd, Vd, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, upstream=0)
     g = torch.Generator().manual_seed(1)
     vx, vd, vc, vcomp = (torch.randn(*shp, generator=g) for shp in ((n, 2), (n,), (n, 3), (n,)))
     loss = (prd.xys * vx.double()).sum() + (prd.depths * vd.double() * (prd.radii > 0)).sum() + \
@@ -151,8 +151,8 @@ def test_pixel_velocity_and_its_vjp_from_a_real_pose(hm, oracle, scene):
     V = V64.float()
     lin = torch.tensor([0.7, -0.4, 1.1]); ang = torch.tensor([0.5, -0.8, 0.3])
     W, H = scene["W"], scene["H"]
-    ref = O.pixel_velocity(world, V, sc["fx"], sc["fy"], lin, ang, 0.01, W, H)
-    free = O.pixel_velocity(world, V, sc["fx"], sc["fy"], lin, ang)
+    ref = O.pixel_velocity(world, V, sc["fx"], sc["fy"], lin, ang, 0.01, W, H, upstream=0)
+    free = O.pixel_velocity(world, V, sc["fx"], sc["fy"], lin, ang, upstream=0)
     pv = np.zeros((n, 2), np.float32)
     args = (n, P(np.ascontiguousarray(world.numpy())), P(np.ascontiguousarray(V.numpy())), f(sc["fx"]), f(sc["fy"]),
             P(np.ascontiguousarray(lin.numpy())), P(np.ascontiguousarray(ang.numpy())), f(0.01), W, H)
@@ -171,7 +171,7 @@ def test_pixel_velocity_and_its_vjp_from_a_real_pose(hm, oracle, scene):
     l64, a64 = lin.double().requires_grad_(True), ang.double().requires_grad_(True)
     g = torch.Generator().manual_seed(2)
     vpv = torch.randn(n, 2, generator=g) * torch.from_numpy(front)[:, None]
-    (O.pixel_velocity(w64, V64, sc["fx"], sc["fy"], l64, a64, 0.01, W, H) * vpv.double()).sum().backward()
+    (O.pixel_velocity(w64, V64, sc["fx"], sc["fy"], l64, a64, 0.01, W, H, upstream=0) * vpv.double()).sum().backward()
     v_pc = np.zeros((n, 3), np.float32); v_lin = np.zeros(3, np.float32); v_ang = np.zeros(3, np.float32)
     hm.hm_pixel_velocity_bwd(*args, P(np.ascontiguousarray(vpv.numpy())), P(v_pc), P(v_lin), P(v_ang))
     want_pc = (w64.grad @ R.T).numpy()                          # v_world = R^T v_pc  ->  v_pc = R v_world
@@ -184,7 +184,7 @@ def test_swept_tile_boxes_bit_exact(hm, oracle, scene):
     path during the readout) against the oracle's _bounds_swept: integers, bit for bit"""
     O, sc, W, H = oracle, scene["sc"], scene["W"], scene["H"]
     pr = O.project_gaussians(scene["means"], scene["scales"], 1.0, scene["quats"], scene["V"], sc["fx"], sc["fy"],
-                             sc["cx"], sc["cy"], H, W, keep_offscreen=True)
+                             sc["cx"], sc["cy"], H, W, keep_offscreen=True, upstream=0)
     n = scene["means"].shape[0]
     g = torch.Generator().manual_seed(4)
     pv = torch.randn(n, 2, generator=g) * 400.0                 # px / s
@@ -221,7 +221,7 @@ def test_double_precision_projection_chain_of_the_needle_fix(hm, oracle, scene):
     V = V64.float()
     md = world.double().requires_grad_(True); sd = scales.double().requires_grad_(True)
     qd = quats.double().requires_grad_(True)
-    prd = O.project_gaussians(md, sd, 1.0, qd, V.double(), sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, keep_offscreen=True)
+    prd = O.project_gaussians(md, sd, 1.0, qd, V.double(), sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, keep_offscreen=True, upstream=0)
     vx, vdp, vc, vcomp = (torch.randn(*shp, generator=g, dtype=torch.float64) for shp in ((n, 2), (n,), (n, 3), (n,)))
     vis_t = prd.radii > 0
     loss = ((prd.xys * vx).sum(-1) * vis_t).sum() + (prd.depths * vdp * vis_t).sum() + \

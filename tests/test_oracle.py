@@ -10,6 +10,7 @@ GOLD = Path(__file__).resolve().parent / "golden"
 
 
 def _cfg(O, sc, H, W, **kw):
+    kw.setdefault("upstream_grads", 0)      # the known-answer tests differentiate: finite differences see TRUE derivatives
     return O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], **kw)
 
 
@@ -120,7 +121,8 @@ def test_finite_difference_gradients(oracle, sh_degree):
     W, H = 32, 32
     sc = O.synthetic_scene(40, W, H, seed=9, scale_mult=10.0, sh_degree=sh_degree)
     cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], sh_degree=sh_degree, blur_samples=2,
-                         rs_bands=2, exposure_time=0.02, rolling_shutter_time=0.02, gamma=2.2, min_rgb_level=5.0)
+                         rs_bands=2, exposure_time=0.02, rolling_shutter_time=0.02, gamma=2.2, min_rgb_level=5.0,
+                         upstream_grads=0)           # finite differences see the TRUE derivatives
     names = ["means", "log_scales", "quats", "opacity_logits", "sh", "lin_vel", "ang_vel"]
     fd_names = names if sh_degree == 0 else ["log_scales", "quats", "opacity_logits", "sh"]
     ps = {k: sc[k].double().clone().requires_grad_(True) for k in names}
@@ -342,7 +344,8 @@ def test_pixel_velocity_render_static_limit_and_autograd(oracle):
     O = oracle
     sc, W, H = _pv_scene(O, n=120, W=48, H=32)
     kw = dict(blur_samples=3, rs_bands=2, exposure_time=1 / 60, rolling_shutter_time=1 / 30, gamma=2.2, min_rgb_level=10.0)
-    cfg_pv = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], motion_model="pixel_velocity", **kw)
+    cfg_pv = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], motion_model="pixel_velocity", upstream_grads=0,
+                            **kw)
     cfg_static = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], gamma=2.2, min_rgb_level=10.0)
     base = (sc["means"], sc["log_scales"].exp(), sc["quats"], torch.sigmoid(sc["opacity_logits"]), sc["sh"], sc["viewmat"])
     z = torch.zeros(3, dtype=torch.float64)
@@ -405,7 +408,7 @@ def test_vectorised_oracle_equals_independent_pixel_loop(oracle, seed, n, H, W, 
     assert len(gids) > 4 * T                                            # lists are long enough to mean something
     # --- forward
     leaves = [t.clone().requires_grad_(True) for t in (pr.xys.detach(), pr.conics.detach(), colors, opac)]
-    r = O.rasterize_sorted(leaves[0], leaves[1], leaves[2], leaves[3], gids, bins, H, W, bg)
+    r = O.rasterize_sorted(leaves[0], leaves[1], leaves[2], leaves[3], gids, bins, H, W, bg, upstream=0)
     xys, conics = pr.xys.detach().numpy(), pr.conics.detach().numpy()
     f = PL.composite_pixel_loop(xys, conics, colors.numpy(), opac.numpy(), gids, bins, H, W, bg.tolist())
     assert np.array_equal(f["final_idx"], r.final_idx.numpy())
@@ -428,6 +431,16 @@ def test_vectorised_oracle_equals_independent_pixel_loop(oracle, seed, n, H, W, 
         changed = np.abs(bu["v_opacity"] - b["v_opacity"]) > 0
         assert changed.any() and not changed[opac.numpy() <= 0.999].any()
         assert np.array_equal(bu["v_colors"], b["v_colors"])
+        # ... and the vectorised oracle's UPSTREAM mode (round 5: straight-through min(0.999, .), the default of the
+        # oracle and of the product) is that convention: every gradient against the loop's hand-derived reverse pass
+        lu = [t.clone().requires_grad_(True) for t in (pr.xys.detach(), pr.conics.detach(), colors, opac)]
+        ru = O.rasterize_sorted(lu[0], lu[1], lu[2], lu[3], gids, bins, H, W, bg, upstream=O.UP_ALPHA_CLAMP)
+        assert torch.equal(ru.img.detach(), r.img.detach()) and torch.equal(ru.final_T.detach(), r.final_T.detach())
+        ((ru.img * v_img).sum() + (ru.alpha * v_alpha).sum()).backward()
+        for name, leaf in zip(("v_xy", "v_conic", "v_colors", "v_opacity"), lu):
+            want = leaf.grad.numpy().reshape(bu[name].shape)
+            assert np.abs(bu[name] - want).max() <= 1e-11 * max(1.0, np.abs(want).max()), name
+        assert (lu[3].grad - leaves[3].grad).abs().max() > 0
 
 
 def test_exact_rolling_shutter_compositing_equals_independent_pixel_loop(oracle):
@@ -495,7 +508,7 @@ def test_shared_list_mode_known_answers(oracle):
 
     def cfg(shared, rt=0.0):
         return O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], rolling_shutter_time=rt, rs_exact=rt != 0.0,
-                              shared_list=shared, **kw)
+                              shared_list=shared, upstream_grads=0, **kw)
     z = torch.zeros(3, dtype=torch.float64)
     a, _ = O.render(cfg(True), *base(sc), z, z)
     b, _ = O.render(cfg(False), *base(sc), z, z)
@@ -583,3 +596,76 @@ def test_exact_rolling_shutter_is_the_limit_of_row_bands_and_differentiable(orac
     d = torch.zeros_like(sc["means"]); d[g_idx, 0] = eps
     fd = (loss(sc["lin_vel"], sc["means"] + d) - loss(sc["lin_vel"], sc["means"] - d)) / (2 * eps)
     assert abs(fd - float(means.grad[g_idx, 0])) <= 2e-4 * max(1.0, abs(fd))
+
+
+def test_upstream_gradient_conventions_are_straight_through_rules(oracle):
+    """round 5: the oracle's UPSTREAM mode — the reference's gradient conventions as recollected
+    (SURVEY App. A "Backward"), the default of the oracle and of the product — against known answers:
+      * no value changes under any flag (forward identical bit for bit);
+      * UP_ALPHA_CLAMP: only Gaussians whose alpha reaches the 0.999 clamp see another gradient, and for ONE opaque
+        splat over a background the closed form: d C / d o = e^{-sigma} (rgb - bg) where alpha is clamped (true: 0);
+      * UP_QUAT_RAW: raw gradient g and true gradient are related by the normalisation's Jacobian,
+        v_q = (g - qn (g . qn)) / |q|, and g is NOT tangent to the sphere for a non-unit q;
+      * UP_FOV_CLAMP: only Gaussians outside the 1.3 tan(fov/2) guard band change, and there d tx / d px = 1;
+      * render() (the fused path) ignores UP_QUAT_RAW: it stands for splatfacto's q/|q| + the kernel."""
+    O = oracle
+    W, H, n = 64, 48, 300
+    sc = O.synthetic_scene(n, W, H, seed=21, dtype=torch.float64, scale_mult=8.0)
+    means = sc["means"].clone()
+    means[:30, 0] *= 3.0                                                 # beyond the guard band
+    quats = sc["quats"] * (0.5 + torch.rand(n, 1, generator=torch.Generator().manual_seed(1), dtype=torch.float64))
+    logits = sc["opacity_logits"].clone()
+    logits[30:90] = 12.0                                                 # opacity ~ 1: the alpha clamp is reached
+    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+
+    def grads(up):
+        p = {"means": means.clone().requires_grad_(True), "log_scales": sc["log_scales"].clone().requires_grad_(True),
+             "quats": quats.clone().requires_grad_(True), "logits": logits.clone().requires_grad_(True)}
+        cfg = O.RenderConfig(H, W, sc["fx"], sc["fy"], sc["cx"], sc["cy"], antialiased=False, upstream_grads=up)
+        out, _ = O.render(cfg, p["means"], p["log_scales"].exp(), p["quats"], torch.sigmoid(p["logits"]), sc["sh"],
+                          sc["viewmat"], sc["lin_vel"], sc["ang_vel"])
+        (out * wt).sum().backward()
+        return out.detach(), {k: v.grad.clone() for k, v in p.items()}
+    img0, g0 = grads(0)
+    img7, g7 = grads(O.UPSTREAM)
+    img2, g2 = grads(O.UP_QUAT_RAW)
+    assert torch.equal(img0, img7) and torch.equal(img0, img2)
+    for k in g0:
+        assert torch.equal(g2[k], g0[k]), k                              # the fused path ignores the quaternion flag
+    _, g4 = grads(O.UP_ALPHA_CLAMP)
+    d_op = (g4["logits"] - g0["logits"]).abs()
+    assert d_op[30:90].max() > 0 and d_op[90:].max() <= 1e-12 * d_op.max()
+    _, g1 = grads(O.UP_FOV_CLAMP)
+    lim_x, lim_y = 1.3 * 0.5 * W / sc["fx"], 1.3 * 0.5 * H / sc["fy"]
+    inside = ((means[:, 0] / means[:, 2]).abs() <= lim_x) & ((means[:, 1] / means[:, 2]).abs() <= lim_y)
+    d_m = (g1["means"] - g0["means"]).abs().sum(1)
+    assert d_m[~inside].max() > 0 and d_m[inside].max() <= 1e-12 * d_m.max()
+    # all three at once = the sum of what each does where it acts (they touch disjoint parts of the chain)
+    assert torch.allclose(g7["logits"], g4["logits"] + (g1["logits"] - g0["logits"]), rtol=0, atol=1e-12)
+    # compat op: raw quaternion gradient vs the normalisation's Jacobian
+    q_raw = quats.clone().requires_grad_(True)
+    q_true = quats.clone().requires_grad_(True)
+    wc = torch.rand(n, 3, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    for q_, up in ((q_raw, O.UP_QUAT_RAW), (q_true, 0)):
+        pr = O.project_gaussians(means, sc["log_scales"].exp(), 1.0, q_, sc["viewmat"], sc["fx"], sc["fy"], sc["cx"],
+                                 sc["cy"], H, W, upstream=up)
+        (pr.conics * wc).sum().backward()
+    g, nq = q_raw.grad, quats.norm(dim=1, keepdim=True)
+    qn = quats / nq
+    assert torch.allclose((g - qn * (qn * g).sum(1, keepdim=True)) / nq, q_true.grad, rtol=1e-9, atol=1e-12)
+    assert (qn * g).sum(1).abs().max() > 1e-3 * g.abs().max()           # raw: a radial component survives
+    assert (qn * q_true.grad).sum(1).abs().max() < 1e-9 * q_true.grad.abs().max()
+    # closed form, one opaque splat centred on a pixel over a background: the centre pixel's alpha sits on the clamp
+    H1 = W1 = 16
+    xy = torch.tensor([[8.5, 8.5]], dtype=torch.float64)
+    conic = torch.tensor([[0.05, 0.0, 0.05]], dtype=torch.float64)
+    rgb = torch.tensor([[0.9, 0.5, 0.2]], dtype=torch.float64)
+    bg = torch.tensor([0.1, 0.3, 0.6], dtype=torch.float64)
+    bins = np.array([[0, 1]], dtype=np.int32)
+    gid = np.array([0], dtype=np.int32)
+    for up, expect_centre in ((O.UP_ALPHA_CLAMP, 1.0), (0, 0.0)):
+        o = torch.tensor([0.9999], dtype=torch.float64, requires_grad=True)
+        r = O.rasterize_sorted(xy, conic, rgb, o, gid, bins, H1, W1, bg, upstream=up)
+        r.img[8, 8, 0].backward()
+        # C = alpha rgb + (1 - alpha) bg at the centre (sigma = 0): d C_r / d o = (rgb_r - bg_r) when the clamp lets it pass
+        assert abs(float(o.grad) - expect_centre * (0.9 - 0.1)) < 1e-12
