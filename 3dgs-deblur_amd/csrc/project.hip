@@ -252,6 +252,11 @@ struct FusedParams {
   int K_stride, deg, antialiased;
   int defer_color;   // 1: leave rgb = 0, gs_slice_colors fills it for the Gaussians a depth slice actually emits
   int skip_culled;   // 1: write no record for a culled (Gaussian, sub-pose) pair (its row stays uninitialised)
+  // > 1: sub-pose p = s * rs_bands + r only ever composites the tile rows of rolling-shutter band r
+  // ([r * tiles_y / R, (r + 1) * tiles_y / R), the formula of ops._band_edges): a pair whose tile box misses its band's
+  // rows is culled HERE (culled depth key, no tile count, no record) instead of being keyed, depth-sorted, scanned and
+  // planned for nothing, and a box that straddles the band is clipped to it.  radii keeps the un-banded definition.
+  int rs_bands;
   Intrin in;
   // pixel-velocity model (SURVEY App. A "Paper's blur/RS model"): ONE projection under viewmats[0] (mid-exposure),
   // sub-pose p re-centres the splat at xy + times[p] * pixel_velocity; twist = {lin[3], ang[3]} (device)
@@ -367,6 +372,15 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
     }
     size_t idx = (size_t)p * fp.N + i;
     float4* r = reinterpret_cast<float4*>(records + idx * kRecFloats);
+    const int radius_out = ok ? o.radius : 0;
+    if (ok && fp.rs_bands > 1) {
+      const int rb = p % fp.rs_bands;
+      const int by0 = (rb * fp.in.tiles_y) / fp.rs_bands, by1 = ((rb + 1) * fp.in.tiles_y) / fp.rs_bands;
+      o.tmin_y = max(o.tmin_y, by0);
+      o.tmax_y = min(o.tmax_y, by1);
+      ok = o.tmax_y > o.tmin_y;
+      o.ntiles = ok ? (o.tmax_x - o.tmin_x) * (o.tmax_y - o.tmin_y) : 0;
+    }
     if (ok) {
       // camera centre = -R^T t ; view direction = mean - centre (no gradient, like splatfacto's detach)
       float cxw = -(Vm[0] * Vm[3] + Vm[4] * Vm[7] + Vm[8] * Vm[11]);
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
     }
     depth_keys[idx] = ok ? (unsigned)__float_as_int(o.depth) : 0xFFFFFFFFu;
     ntiles[idx] = ok ? o.ntiles : 0;
-    if (radii) radii[idx] = ok ? o.radius : 0;
+    if (radii) radii[idx] = radius_out;
   }
 }
 
@@ -1011,6 +1025,7 @@ static inline FusedParams make_fused(int N, int P, const float* means, const flo
   fp.viewmats = viewmats; fp.glob = glob; fp.K_stride = K_stride; fp.deg = deg; fp.antialiased = antialiased;
   fp.defer_color = defer_color & 1;
   fp.skip_culled = (defer_color >> 1) & 1;
+  fp.rs_bands = (defer_color & 4) ? ((defer_color >> 8) & 0xFFFF) : 0;
   fp.in = make_intrin(fx, fy, cx, cy, H, W, clip);
   fp.pixvel = 0; fp.twist = nullptr; fp.times = nullptr; fp.flags = 0; fp.rs_half = 0.f; fp.pix_vel_out = nullptr;
   fp.act = 0; fp.sh_rest = nullptr;

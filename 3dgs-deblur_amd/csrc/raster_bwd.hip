@@ -297,6 +297,9 @@ constexpr int kRedCols4 = 32, kRedStride4 = 36;    // 36 = 32 + 4: rows 16-byte 
 #ifndef GS_BWD_VCOPY
 #define GS_BWD_VCOPY 0
 #endif
+#ifndef GS_BWD_EXEC
+#define GS_BWD_EXEC 0
+#endif
 constexpr int kRedFloats4 = kRedG4 * 9 * kRedStride4;
 
 // w[i] = v[i](lane) + v[i](lane ^ 1) for nine values: nine v_add_f32_dpp in one block (the DPP combiner leaves most
@@ -369,10 +372,19 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
     const bool hit = (idx < pp.fin[k]) && (fabsf(u) <= rc.nmid);
     if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;           // nobody's quadrant-k pixel blended this entry
     any = true;
+#if GS_BWD_EXEC
+    // A/B (round 5): lanes whose pixel k did not blend this entry sit the body out under the
+    // exec mask instead of running it with alpha SELECTED to 0 (saves the select(s), costs a saveexec / restore pair)
+    if (!hit) continue;
+    const float ov = GS_RQ.kmul * __builtin_amdgcn_exp2f(u);
+    const float alpha = CLAMP ? fminf(K::kAlphaMax, ov) : ov;
+    const float ovm = CLAMP ? (ov <= agm ? ov : 0.f) : alpha;
+#else
     const float ov = GS_RQ.kmul * __builtin_amdgcn_exp2f(u);
     // pixels that are not hit are neutralised by SELECTING alpha = 0 (1/(1-0) = 1 exactly, every term an exact zero)
     const float alpha = hit ? (CLAMP ? fminf(K::kAlphaMax, ov) : ov) : 0.f;
     const float ovm = CLAMP ? ((hit && ov <= agm) ? ov : 0.f) : alpha;   // d min(0.999, o*vis) = 0 when clamped
+#endif
     const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
     pp.T[k] *= ra;                               // transmittance in front of this Gaussian
     const float fac = alpha * pp.T[k];

@@ -141,6 +141,8 @@ DEPTH_SORT_DIGIT = int(os.environ.get("GSD_DEPTH_SORT_DIGIT", "8"))
 UPSTREAM_GRADS = int(os.environ.get("GSD_UPSTREAM_GRADS", "7"))
 
 
+# 1 (default): rolling-shutter bands — the projection culls (band, Gaussian) pairs outside their band's tile rows (A/B: 0)
+BAND_AWARE = int(os.environ.get("GSD_BAND_AWARE", "1"))
 # 1 (default): Gaussians whose scales differ by more than 8x get the covariance part of their projection backward
 # (v_conic -> cov2d -> cov3d -> scale / quaternion / mean) recomputed in double (project_needle_hp_kernel): in fp32 that
 # chain is percent-level wrong along a needle's long axis.  0: fp32 everywhere (A/B, tests).
@@ -309,11 +311,13 @@ def radix_sort_pairs(keys: Tensor, vals: Optional[Tensor], begin_bit: int, end_b
 # binning of rasterizer records (fast path shared by compat + fused ops)
 # --------------------------------------------------------------------------- #
 def bin_and_sort_records(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int,
-                         img_height: int, img_width: int):
+                         img_height: int, img_width: int, with_emission: bool = False):
     """-> (sorted_vals int32 [I], tile_bins int32 [P*T,2], n_isect, sorted_keys int32 [I]).
 
     Depth pre-sort (P*N keys) -> emission in depth order -> stable tile sort: the same total order
-    as upstream's 64-bit (tile<<32|depth) sort at a fraction of the HBM traffic (see binning.hip)."""
+    as upstream's 64-bit (tile<<32|depth) sort at a fraction of the HBM traffic (see binning.hip).
+    with_emission=True appends a dict for the gradient-tuple backward (gs_reduce_grad_tuples): `eids` = emission index of
+    every sorted entry, `sorted_gi` / `counts` / `cum` = record index, tile count and exclusive offset of every depth rank."""
     L = _L()
     dev = records.device
     n = P * N
@@ -335,7 +339,7 @@ def bin_and_sort_records(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     if n_isect == 0:
         bins.zero_()
         z = torch.zeros(1, dtype=torch.int32, device=dev)
-        return z, bins, 0, z.clone()
+        return (z, bins, 0, z.clone()) + ((None,) if with_emission else ())
     if n_isect < 0:
         raise OverflowError("more than 2^31-1 tile intersections; chunk the sub-poses")
     with _stage("emit"):
@@ -343,11 +347,17 @@ def bin_and_sort_records(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
         vals = _padded_i32(n_isect, dev)
         _check(L.gs_emit_intersects(n, N, img_height, img_width, _ptr(sorted_gi), _ptr(cum), _ptr(records), n_isect,
                                     _ptr(keys), _ptr(vals), 0, _stream()), "emit intersects")
+    extra = None
     with _stage("tile_sort"):
-        skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T))
+        if with_emission:
+            # payload = emission index (iota); the record index travels as a second payload
+            skeys, eids, svals = radix_sort_pairs(keys, None, 0, _bits(P * T), carry=vals)
+            extra = dict(eids=eids, sorted_gi=sorted_gi, counts=counts, cum=cum)
+        else:
+            skeys, svals = radix_sort_pairs(keys, vals, 0, _bits(P * T))
     with _stage("bin_edges"):
         _check(L.gs_tile_bin_edges_u32(n_isect, _ptr(skeys), P * T, _ptr(bins), None, _stream()), "bin edges")
-    return svals, bins, n_isect, skeys
+    return (svals, bins, n_isect, skeys) + ((extra,) if with_emission else ())
 
 
 _band_edge_cache = {}
@@ -660,13 +670,106 @@ class _ProjectGaussians(Function):
         return (v_means, v_scales, None, v_quats, v_V, None, None, None, None, None, None, None, None)
 
 
+def _sample_span(blur_samples: int, exposure_time: float, rolling_shutter_time: float):
+    """sample times of the fork-style compat calls (subpose_schedule's blur schedule, symmetric about the mid-exposure
+    pose, so the shared list's centre time is 0) and the time span the tile boxes are swept over"""
+    S = max(1, int(blur_samples))
+    times, _, _ = subpose_schedule(S, float(exposure_time), 1, 0.0)
+    return S, times, (max(times) - min(times)) + abs(float(rolling_shutter_time))
+
+
+class _ProjectGaussiansPixvel(Function):
+    """project_gaussians with the fork's velocity keywords: the pixel-velocity model's ONE projection (shared-list form,
+    gs_project_pixvel_fwd with P = 1 at the mid-exposure pose): centres / conics / compensation of every geometrically
+    valid Gaussian, radii / num_tiles_hit of the tile boxes SWEPT over the sampled span, and the pixel velocities."""
+
+    @staticmethod
+    def forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, clip, lin_vel, ang_vel, span):
+        means3d, scales, quats = _f32(means3d, "means3d"), _f32(scales, "scales"), _f32(quats, "quats")
+        V = _viewmat16(viewmat).reshape(4, 4)
+        N, dev, L = means3d.shape[0], means3d.device, _L()
+        twist = torch.cat([_f32(lin_vel, "lin_vel").reshape(3), _f32(ang_vel, "ang_vel").reshape(3)]).contiguous()
+        ones = torch.ones(N, device=dev)
+        sh0 = torch.zeros(N, 1, 3, device=dev)
+        t0 = torch.zeros(1, device=dev)
+        records = torch.empty(N, REC, device=dev)
+        dkeys = torch.empty(N, dtype=torch.int32, device=dev)
+        ntiles = torch.empty(N, dtype=torch.int32, device=dev)
+        radii = torch.empty(N, dtype=torch.int32, device=dev)
+        pix_vel = torch.empty(N, 2, device=dev)
+        # opacity 1 + antialiasing: the record's opacity slot is the compensation factor; colour deferred (never made)
+        _check(L.gs_project_pixvel_fwd(N, 1, _ptr(means3d), _ptr(scales), float(glob_scale), _ptr(quats), _ptr(ones),
+                                       _ptr(sh0), 1, 0, _ptr(V), _ptr(twist), _ptr(t0), float(fx), float(fy), float(cx),
+                                       float(cy), int(H), int(W), float(clip), 1, 1, _ptr(records), _ptr(dkeys),
+                                       _ptr(ntiles), _ptr(radii), float(span), _ptr(pix_vel), None, 0, _stream()),
+               "project_pixvel_fwd")
+        cov3d = torch.empty(N, 6, device=dev)
+        scratch = [torch.empty(N, 2, device=dev), torch.empty(N, device=dev), torch.empty(N, dtype=torch.int32, device=dev),
+                   torch.empty(N, 3, device=dev), torch.empty(N, device=dev), torch.empty(N, dtype=torch.int32, device=dev)]
+        _check(L.gs_project_fwd(N, _ptr(means3d), _ptr(scales), float(glob_scale), _ptr(quats), _ptr(V), float(fx),
+                                float(fy), float(cx), float(cy), int(H), int(W), float(clip), *(_ptr(t) for t in scratch),
+                                _ptr(cov3d), None, _stream()), "project_fwd")
+        depths = scratch[1]                                   # camera-space z of every Gaussian (culled ones too)
+        live = (radii > 0)[:, None]
+        xys = torch.where(live, records[:, 0:2], torch.zeros_like(pix_vel))
+        conics = torch.where(live, records[:, 2:5], torch.zeros(N, 3, device=dev))
+        comp = torch.where(live[:, 0], records[:, 5], torch.zeros(N, device=dev))
+        pix_vel = torch.where(live, pix_vel, torch.zeros_like(pix_vel))
+        ctx.save_for_backward(means3d, scales, quats, V, twist, records, ones, sh0, t0)
+        ctx.args = (float(glob_scale), float(fx), float(fy), float(cx), float(cy), int(H), int(W), float(clip))
+        ctx.mark_non_differentiable(radii, ntiles)
+        return xys.contiguous(), depths, radii, conics.contiguous(), comp.contiguous(), ntiles, cov3d, pix_vel
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_comp, v_ntiles, v_cov3d, v_pv):
+        means3d, scales, quats, V, twist, records, ones, sh0, t0 = ctx.saved_tensors
+        glob, fx, fy, cx, cy, H, W, clip = ctx.args
+        N, dev, L = means3d.shape[0], means3d.device, _L()
+        if v_depths is not None or v_cov3d is not None:
+            raise NotImplementedError("project_gaussians with velocity keywords: no gradient through depths / cov3d "
+                                      "(rasterize_gaussians produces none)")
+        v_rec = torch.zeros(N, GRAD, device=dev)
+        for g, sl in ((v_xys, slice(0, 2)), (v_conics, slice(2, 5)), (v_pv, slice(9, 11))):
+            if g is not None:
+                v_rec[:, sl] = g
+        if v_comp is not None:
+            v_rec[:, 5] = v_comp
+        v_means, v_scales = torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev)
+        v_quats, v_op, v_sh = torch.empty(N, 4, device=dev), torch.empty(N, device=dev), torch.empty(N, 1, 3, device=dev)
+        acc = torch.zeros(16 + 12, device=dev)
+        v_V, v_tw = acc[:16].view(4, 4), acc[16:]
+        _check(L.gs_project_pixvel_bwd(N, 1, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(ones), _ptr(sh0), 1, 0,
+                                       _ptr(V), _ptr(twist), _ptr(t0), fx, fy, cx, cy, H, W, clip, 1, _ptr(records),
+                                       _ptr(v_rec), _ptr(v_means), _ptr(v_scales), _ptr(v_quats), _ptr(v_op), _ptr(v_sh),
+                                       _ptr(v_V), _ptr(v_tw), None, None, (UPSTREAM_GRADS & 3) | 16 | (0 if NEEDLE_HP else 8),
+                                       None, 0, None, _stream()), "project_pixvel_bwd")
+        return (v_means, v_scales, None, v_quats, v_V, None, None, None, None, None, None, None, v_tw[0:3], v_tw[3:6], None)
+
+
 def project_gaussians(means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor, viewmat: Tensor,
                       fx: float, fy: float, cx: float, cy: float, img_height: int, img_width: int,
-                      block_width: int = TILE, clip_thresh: float = 0.01):
+                      block_width: int = TILE, clip_thresh: float = 0.01, *, lin_vel: Optional[Tensor] = None,
+                      ang_vel: Optional[Tensor] = None, exposure_time: float = 0.0, rolling_shutter_time: float = 0.0,
+                      blur_samples: int = 0):
     """gsplat.project_gaussians (0.1.11 positional signature).
-    -> (xys, depths, radii, conics, compensation, num_tiles_hit, cov3d)"""
-    return _ProjectGaussians.apply(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height,
-                                   img_width, block_width, clip_thresh)
+    -> (xys, depths, radii, conics, compensation, num_tiles_hit, cov3d)
+    Fork-style trailing keywords (the SpectacularAI fork's rasterizer takes the camera velocities,
+    /root/reference/README.md:196-200, train.py:46-70; their exact names are unknown, the defaults are today's static
+    behaviour bit for bit): with lin_vel / ang_vel [3] (OpenCV camera frame) the call is the pixel-velocity model's ONE
+    projection and returns an 8th tensor pix_vels [N,2] (differentiable; gradients reach viewmat and the velocities);
+    radii / num_tiles_hit then describe the tile boxes SWEPT over the blur_samples sample times of exposure_time plus the
+    rolling_shutter_time readout, and Gaussians whose static box misses the image keep their centre (they may move in).
+    Hand the same keywords and pix_vels to rasterize_gaussians."""
+    if lin_vel is None and ang_vel is None:
+        return _ProjectGaussians.apply(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height,
+                                       img_width, block_width, clip_thresh)
+    if lin_vel is None or ang_vel is None:
+        raise ValueError("lin_vel and ang_vel go together")
+    if block_width != TILE:
+        raise ValueError("only block_width=16 is supported")
+    _, _, span = _sample_span(blur_samples, exposure_time, rolling_shutter_time)
+    return _ProjectGaussiansPixvel.apply(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height,
+                                         img_width, clip_thresh, lin_vel, ang_vel, span)
 
 
 # --------------------------------------------------------------------------- #
@@ -760,13 +863,110 @@ class _RasterizeGaussians(Function):
         return (v_xys, None, None, v_conics, None, v_colors, v_opacity, None, None, None, v_bg, None)
 
 
+class _RasterizeGaussiansPixvel(Function):
+    """rasterize_gaussians with the fork's velocity keywords: ONE swept-box binning, the S blur samples (and the per-row
+    rolling-shutter time) inside the compositor — csrc/raster_rs.hip in its shared-list form, one slice."""
+
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, colors, opacity, pix_vels, H, W, background, times, rs_time, span):
+        xys, depths, conics = _f32(xys, "xys"), _f32(depths, "depths"), _f32(conics, "conics")
+        colors, opacity, pv = _f32(colors, "colors"), _f32(opacity, "opacity").reshape(-1), _f32(pix_vels, "pix_vels")
+        radii = radii.to(torch.int32).contiguous()
+        N, dev, L = xys.shape[0], xys.device, _L()
+        S = len(times)
+        tx, ty = _tiles(H, W)
+        # records [N,16] with the SWEPT tile box (gs_math.h::tile_bounds_swept, float32 op for op: the rolling-shutter
+        # compositors read floats 0..9 and the packed box only)
+        half = torch.tensor(0.5 * span, dtype=torch.float32, device=dev)
+        inv_tile = torch.tensor(1.0 / TILE, dtype=torch.float32, device=dev)
+        xa, xb = xys[:, 0] - half * pv[:, 0], xys[:, 0] + half * pv[:, 0]
+        ya, yb = xys[:, 1] - half * pv[:, 1], xys[:, 1] + half * pv[:, 1]
+        tr = radii.float() * inv_tile
+        x0 = torch.trunc(torch.minimum(xa, xb) * inv_tile - tr).clamp(0, tx).int()
+        x1 = torch.trunc((torch.maximum(xa, xb) * inv_tile + tr) + 1.0).clamp(0, tx).int()
+        y0 = torch.trunc(torch.minimum(ya, yb) * inv_tile - tr).clamp(0, ty).int()
+        y1 = torch.trunc((torch.maximum(ya, yb) * inv_tile + tr) + 1.0).clamp(0, ty).int()
+        area = (x1 - x0) * (y1 - y0)
+        ok = (radii > 0) & (area > 0)
+        records = torch.zeros(N, REC, device=dev)
+        records[:, 0:2], records[:, 2:5], records[:, 5], records[:, 6:9], records[:, 9] = xys, conics, opacity, colors, depths
+        records[:, 10:12] = torch.stack([x0 | (y0 << 16), x1 | (y1 << 16)], dim=1).view(torch.float32)
+        records = torch.where(ok[:, None], records, torch.zeros_like(records)).contiguous()
+        ntiles = torch.where(ok, area, torch.zeros_like(area)).contiguous()
+        dkeys = torch.where(ok, depths.view(torch.int32), torch.full_like(area, -1)).contiguous()
+        sorted_ids, bins, n_isect, _, em = bin_and_sort_records(records, dkeys, ntiles, 1, N, H, W, with_emission=True)
+        bg = _background(background, dev)
+        edges = _band_edges(H, 1, dev)
+        times_t = torch.tensor(times, dtype=torch.float32, device=dev)
+        out_img = torch.empty(S, H, W, 3, device=dev)
+        out_T = torch.empty(S, H, W, device=dev)
+        fidx = torch.empty(S, H, W, dtype=torch.int32, device=dev)
+        if n_isect > 0:
+            _check(L.gs_rasterize_fwd_rs_slice(_ptr(records), _ptr(bins), _ptr(edges), _ptr(bg), S, H, W, _ptr(out_img),
+                                               _ptr(out_T), None, _ptr(fidx), None, 1, 1, _ptr(sorted_ids), N, None, None,
+                                               _ptr(pv), N, float(rs_time), _ptr(times_t), _stream()), "rasterize_fwd_rs")
+        else:
+            out_img[:] = bg
+            out_T.fill_(1.0)
+        ctx.save_for_backward(records, sorted_ids, bins, edges, bg, out_T, fidx, pv, times_t)
+        ctx.em, ctx.dims, ctx.n_isect = em, (N, S, H, W, float(rs_time)), n_isect
+        ctx.bg_grad = background is not None and ctx.needs_input_grad[9]
+        return out_img, 1.0 - out_T
+
+    @staticmethod
+    def backward(ctx, v_img, v_alpha):
+        records, sorted_ids, bins, edges, bg, out_T, fidx, pv, times_t = ctx.saved_tensors
+        N, S, H, W, rs_time = ctx.dims
+        dev, L, em, I = records.device, _L(), ctx.em, ctx.n_isect
+        v_img = torch.zeros(S, H, W, 3, device=dev) if v_img is None else v_img.contiguous().float()
+        v_al = None if v_alpha is None else v_alpha.contiguous().float()
+        v_records = torch.zeros(N, GRAD, device=dev)
+        if I > 0:
+            tuples = torch.empty(I * S, GRAD, device=dev)
+            flags = torch.zeros(I * S, dtype=torch.uint8, device=dev)
+            _check(L.gs_rasterize_bwd_rs_slice(_ptr(records), _ptr(em["eids"]), _ptr(bins), _ptr(edges), _ptr(bg), S, H, W,
+                                               _ptr(out_T), _ptr(fidx), _ptr(v_img), _ptr(v_al), None, None, _ptr(tuples),
+                                               _ptr(flags), _ptr(sorted_ids), N, _bwd_variant(), None, 1.0, 0.0, _ptr(pv),
+                                               N, rs_time, _ptr(times_t), _stream()), "rasterize_bwd_rs")
+            _check(L.gs_reduce_grad_tuples(N, _ptr(em["sorted_gi"]), _ptr(em["counts"]), _ptr(em["cum"]), _ptr(tuples),
+                                           _ptr(flags), _ptr(v_records), None, I, _ptr(records), S, _stream()),
+                   "reduce_grad_tuples")
+        v_xys, v_conics = torch.empty(N, 2, device=dev), torch.empty(N, 3, device=dev)
+        v_colors, v_opacity = torch.empty(N, 3, device=dev), torch.empty(N, 1, device=dev)
+        _check(L.gs_unpack_record_grads(N, _ptr(v_records), _ptr(v_xys), _ptr(v_conics), _ptr(v_colors), _ptr(v_opacity),
+                                        _stream()), "unpack grads")
+        v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
+        return (v_xys, None, None, v_conics, v_colors, v_opacity, v_records[:, 9:11].contiguous(), None, None, v_bg, None,
+                None, None)
+
+
 def rasterize_gaussians(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor, num_tiles_hit: Tensor,
                         colors: Tensor, opacity: Tensor, img_height: int, img_width: int, block_width: int = TILE,
-                        background: Optional[Tensor] = None, return_alpha: bool = False):
+                        background: Optional[Tensor] = None, return_alpha: bool = False, *,
+                        pix_vels: Optional[Tensor] = None, exposure_time: float = 0.0, rolling_shutter_time: float = 0.0,
+                        blur_samples: int = 0, return_samples: bool = False):
     """gsplat.rasterize_gaussians (0.1.11 positional signature) -> out_img [H,W,C] (, out_alpha [H,W]).
     C = 3 is one pass of the compositor; any other channel count (upstream's nd_rasterize path: depth, features, ...)
     is composited three channels at a time over the same geometry — every channel sees exactly the weights of the
-    RGB path, the shared inputs' gradients accumulate over the passes through autograd."""
+    RGB path, the shared inputs' gradients accumulate over the passes through autograd.
+    Fork-style trailing keywords (defaults = the static behaviour bit for bit): pix_vels [N,2] from
+    project_gaussians(lin_vel=..., ang_vel=...) with the SAME exposure_time / rolling_shutter_time / blur_samples renders
+    the paper's model (/root/reference/README.md:196-200): one binning of the swept boxes, max(1,
+    blur_samples) sample times over the exposure plus the per-row readout time inside the compositor.  The result is the
+    plain mean of the sample images (linear colour; alpha likewise) or, with return_samples=True, the samples themselves
+    [S,H,W,3] (, [S,H,W]) for a gamma-space average (combine_samples).  C must be 3 in this mode."""
+    if pix_vels is not None:
+        if block_width != TILE:
+            raise ValueError("only block_width=16 is supported")
+        if colors.shape[-1] != 3:
+            raise ValueError("rasterize_gaussians with pix_vels composites 3 channels")
+        _, times, span = _sample_span(blur_samples, exposure_time, rolling_shutter_time)
+        img, alpha = _RasterizeGaussiansPixvel.apply(xys, depths, radii, conics, colors, opacity.reshape(-1, 1), pix_vels,
+                                                     int(img_height), int(img_width), background, times,
+                                                     float(rolling_shutter_time), span)
+        if not return_samples:
+            img, alpha = img.mean(dim=0), alpha.mean(dim=0)
+        return (img, alpha) if return_alpha else img
     C = colors.shape[-1]
     if C == 3:
         return _RasterizeGaussians.apply(xys, depths, radii, conics, num_tiles_hit, colors, opacity.reshape(-1, 1),
@@ -963,6 +1163,10 @@ class _RenderSubposes(Function):
         # bit 0: SH colour deferred to the depth slices (gs_slice_colors colours only what a slice emits)
         backend = frame_backend if (frame_backend is not None and not frame_backend.native_ok()) else None
         defer_flags = 3 if backend is None else backend.defer_flags()
+        # bit 2 + R in bits 8..23: band-aware projection (a (band, Gaussian) pair whose tile rows miss the band is culled
+        # before the depth pre-sort instead of being keyed, sorted, scanned and planned for nothing)
+        if backend is None and R > 1 and BAND_AWARE:
+            defer_flags |= 4 | (R << 8)
         if shared is not None and backend is not None:
             raise ValueError("the shared-list mode runs through the library's frame path only")
         pix_vel = torch.empty(N, 2, device=dev) if (rs_time != 0.0 or shared is not None) else None

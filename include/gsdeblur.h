@@ -88,7 +88,12 @@ int gs_project_fused_fwd(int N, int P, const float* means3d, const float* scales
                          int defer_color /*bit 0: leave rgb = 0 and skip the SH read; gs_slice_colors fills it later.
                                            bit 1: write NO record for a culled (Gaussian, sub-pose) pair — its 64 bytes
                                            stay uninitialised; only for callers that never look at them (the sliced
-                                           path behind gs_segmented_sort_compact_u32, which drops culled keys)*/,
+                                           path behind gs_segmented_sort_compact_u32, which drops culled keys).
+                                           bit 2 (round 5): band-aware — bits 8..23 hold R = rolling-shutter row bands;
+                                           sub-pose p = s*R + r only composites tile rows [r*ty/R, (r+1)*ty/R): a pair
+                                           whose tile box misses those rows is culled here (culled depth key, tile count
+                                           0, no record), a box that straddles them is clipped to them.  `radii` keeps
+                                           the un-banded value (the oracle's definition)*/,
                          float* records /*P*N*16*/, unsigned* depth_keys /*P*N*/,
                          int* num_tiles_hit /*P*N*/, int* radii /*P*N or NULL*/,
                          const float* sh_rest /*NULL, or features_rest [N*(K_stride-1)*3]: `sh` is then features_dc [N*3]
