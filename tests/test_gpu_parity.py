@@ -631,11 +631,14 @@ def test_fused_path_vs_oracle_integers_and_image(gs, oracle, dev, S, R, W, H, n)
     assert (out.detach().cpu().double() - ref)[good].abs().max().item() < 5e-4
 
 
+# (round 5: every case runs under both gradient conventions, so the sizes went down by about a third — the suite has 20
+#  minutes on the driver's box and the float64 oracle is what these tests wait for; gradients at the BENCH's size are
+#  oracle-checked by test_full_size_*_vs_oracle_fixture since this round)
 @pytest.mark.parametrize("tag,S,R,W,H,n,mult", [
-    ("config2: 5 motion-blur sub-poses", 5, 1, 240, 136, 6000, 5.0),
+    ("config2: 5 motion-blur sub-poses", 5, 1, 208, 120, 4200, 5.0),
     ("config3: 10 rolling-shutter bands", 1, 10, 160, 240, 5000, 5.0),
-    ("config4: 5 samples x 2 bands", 5, 2, 208, 128, 5000, 5.0),
-    ("config5: 10 motion-blur sub-poses", 10, 1, 192, 112, 4000, 5.0)])
+    ("config4: 5 samples x 2 bands", 5, 2, 176, 112, 3600, 5.0),
+    ("config5: 10 motion-blur sub-poses", 10, 1, 160, 96, 2800, 5.0)])
 @pytest.mark.parametrize("up", CONVENTIONS)
 def test_baseline_configs_vs_float64_oracle_image_and_per_element_gradients(gs, oracle, dev, tag, S, R, W, H, n, mult, up):
     """BASELINE.json configs 2-5 at reduced N / resolution with the SAME sub-pose structure (S, R), SH degree 3,
@@ -831,7 +834,9 @@ def test_upstream_gradient_convention_switches(gs, oracle, dev):
     W, H, n = 96, 64, 400
     sc = O.synthetic_scene(n, W, H, seed=9, scale_mult=6.0)
     means = sc["means"].clone()
-    means[:40, 0] *= 3.0                                  # far outside the frustum: x/z beyond 1.3 * tan(fov/2)
+    means[:40, 0] = means[:40, 0].sign() * means[:40, 2] * (1.45 * 0.5 * W / sc["fx"])    # x/z just beyond 1.3 tan(fov/2) ...
+    sc["log_scales"] = sc["log_scales"].clone()
+    sc["log_scales"][:40] += 1.2                          # ... and large enough to reach back into the image
     quats = sc["quats"] * (0.5 + torch.rand(n, 1, generator=torch.Generator().manual_seed(1)))    # NOT unit
     op_logit = sc["opacity_logits"].clone()
     op_logit[40:80] = 12.0                                # opacity ~ 1: alpha clamps at 0.999 near the centre
@@ -879,10 +884,25 @@ def test_upstream_gradient_convention_switches(gs, oracle, dev):
         for k, v in worst.items():
             assert v <= 1.0, (flags, k, v)
     # the modes differ where they should (otherwise the comparisons above would not tell them apart) ...
-    assert (ref[1]["means"] - ref[0]["means"]).abs().max() > 1e-3 * ref[0]["means"].abs().max()
-    assert (ref[4]["op"] - ref[0]["op"])[40:80].abs().max() > 1e-3 * ref[0]["op"].abs().max()
-    assert (hip[1]["means"] - hip[0]["means"]).abs().max() > 1e-3 * hip[0]["means"].abs().max()
-    assert (hip[4]["op"] - hip[0]["op"])[40:80].abs().max() > 1e-3 * hip[0]["op"].abs().max()
+    d_fov_ref = (ref[1]["means"] - ref[0]["means"]).abs().max() / ref[0]["means"].abs().max()
+    d_fov_hip = (hip[1]["means"] - hip[0]["means"]).abs().max() / hip[0]["means"].abs().max()
+    # the alpha clamp is only reached at the few pixels at an opaque splat's very centre: it moves those splats' centre
+    # gradients by ~3e-4 of the tensor's max and their logit gradients by ~1 % of THEIR max (sigmoid' is 6e-6 at a logit
+    # of 12, so that is 1e-8 of the tensor's max: the opaque splats' logits get a comparison of their own below)
+    d_alpha_ref = (ref[4]["means"] - ref[0]["means"])[40:80].abs().max() / ref[0]["means"].abs().max()
+    d_alpha_hip = (hip[4]["means"] - hip[0]["means"])[40:80].abs().max() / hip[0]["means"].abs().max()
+    d_op_ref = (ref[4]["op"] - ref[0]["op"])[40:80].abs().max() / ref[0]["op"][40:80].abs().max()
+    print(f"what the conventions change (relative to the tensor's max): fov clamp {float(d_fov_ref):.2e} (oracle) "
+          f"{float(d_fov_hip):.2e} (HIP); alpha clamp {float(d_alpha_ref):.2e} (oracle) {float(d_alpha_hip):.2e} (HIP), "
+          f"opaque splats' logits {float(d_op_ref):.2e} of their own max")
+    # well above the comparisons' per-element tolerance (1e-5 of the max) — the modes are told apart
+    assert d_fov_ref > 1e-4 and d_fov_hip > 1e-4 and d_alpha_ref > 1e-4 and d_alpha_hip > 1e-4 and d_op_ref > 3e-3
+    for flags in (0, 4):
+        r_op = grad_el_ratio(hip[flags]["op"][40:80].numpy(), ref[flags]["op"][40:80].numpy())
+        x_op = grad_el_ratio(hip[flags]["op"][40:80].numpy(), ref[4 - flags]["op"][40:80].numpy())
+        print(f"opaque splats' logit gradients, mask {flags}: error / tolerance vs the oracle in that mode {r_op:.3f}, "
+              f"vs the oracle in the OTHER mode {x_op:.1f}")
+        assert r_op <= 1.0 < x_op
     # ... and only there: Gaussians inside the guard band / opacities away from the clamp are untouched bit for bit
     xz = (means[:, 0] / means[:, 2]).abs()
     yz = (means[:, 1] / means[:, 2]).abs()

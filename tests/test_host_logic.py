@@ -153,13 +153,14 @@ def _dp_worker(rank, world, port, mode, q):
     dist.destroy_process_group()
 
 
-def _dp_sparse_worker(rank, world, port, q, sync_free=False, schedule=None):
+def _dp_sparse_worker(rank, world, port, q, sync_free=False, schedule=None, N=40000):
     sys.path.insert(0, str(ROOT))
     import gsdeblur_amd as gs
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if world > 2:
+        torch.set_num_threads(1)             # eight ranks on one small host: no thread oversubscription
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    N = 40000
     shapes = [(N, 3), (N, 3), (N, 4), (N, 1), (N, 3), (N, 3, 3)]
     ok = True
     log = []
@@ -185,6 +186,10 @@ def _dp_sparse_worker(rank, world, port, q, sync_free=False, schedule=None):
         for i, p in enumerate(params):
             want = sum(all_grads[r][i] for r in range(world))
             ok &= bool(torch.allclose(p.grad, want, atol=1e-6))
+        # every rank adds the ranks' rows in RANK ORDER: the replicas' sums are the same BITS, not just close
+        import hashlib
+        digest = hashlib.sha256(b"".join(p.grad.contiguous().numpy().tobytes() for p in params)).hexdigest()
+        log[-1] = log[-1] + (digest,)
     gs.dp._sparse_state(N, world, None).settle()                            # the last step did not overflow either
     q.put((rank, ok, log))
     dist.destroy_process_group()
@@ -201,8 +206,33 @@ def _run_sparse_world2(port_base, **kw):
     for p in procs:
         p.join(timeout=60)
     assert [(r[0], r[1]) for r in res] == [(0, True), (1, True)]
-    assert res[0][2] == res[1][2]                                           # identical decisions on both ranks
-    return res[0][2]
+    assert res[0][2] == res[1][2]                          # identical decisions AND bit-identical sums on both ranks
+    return [t[:3] for t in res[0][2]]
+
+
+def test_sparse_to_dense_fallback_world8_gloo():
+    """the exchange at the world size the scaling bench runs at (8 ranks, one host), on CPU: a
+    sparse regime, a 30x density jump (the guarded exchange sees 8 headers, finds one payload too small and every rank
+    takes the dense bucket for that step), a dense phase, and back.  Every step's sum is exact on every rank, the eight
+    ranks take identical decisions, and — the ranks' rows are added in rank order — end every step with the same BITS."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 45500 + (os.getpid() % 2000)
+    world = 8
+    sched = (0.004, 0.004, 0.004, 0.12, 0.12) + (0.004,) * 9
+    procs = [ctx.Process(target=_dp_sparse_worker, args=(r, world, port, q), kwargs=dict(schedule=sched, N=16000))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [(r[0], r[1]) for r in res] == [(r, True) for r in range(world)]
+    for r in range(1, world):
+        assert res[r][2] == res[0][2], r                   # decisions, capacities, overflow counts, gradient bits
+    log = res[0][2]
+    assert not log[2][0] and log[3][2] == 1                # the jump step overflowed out of a sparse regime ...
+    assert any(d for d, _, _, _ in log[3:6]) and not log[-1][0]     # ... the dense phase went dense, and it came back
 
 
 @pytest.mark.parametrize("sync_free", [False, True])
