@@ -342,7 +342,10 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   const bool planned = d.slice_base > 0;
   if (planned) {
     StageScope sc(ST_PLAN, st);
-    CHECK(gs_slice_plan(P, N, kKMax, cum, total, (long long)T * d.slice_base, plan_dev,
+    // budget of the first slice per sub-pose = its OPEN tiles * slice_base box pairs (a band-clipped rolling-shutter
+    // sub-pose owns T / R of the frame's tiles)
+    const long long plan_tiles = (d.band_clipped && R > 1) ? (T + R - 1) / R : T;
+    CHECK(gs_slice_plan(P, N, kKMax, cum, total, plan_tiles * d.slice_base, plan_dev,
                         reinterpret_cast<unsigned*>(plan_dev + PK), reinterpret_cast<unsigned*>(plan_dev + 2 * PK),
                         n_live, reinterpret_cast<unsigned*>(plan_dev + 2 * PK + P), st));
     CHECK(read_back(reinterpret_cast<const unsigned*>(plan_dev), hp_seq, (int)plan_ints, poll, st));

@@ -434,7 +434,8 @@ class _FrameDesc(ctypes.Structure):
                                                                                      ("poll_readback", ctypes.c_int),
                                                                                      ("shared_list", ctypes.c_int),
                                                                                      ("combine_gamma", ctypes.c_float),
-                                                                                     ("combine_min_level", ctypes.c_float)]
+                                                                                     ("combine_min_level", ctypes.c_float),
+                                                                                     ("band_clipped", ctypes.c_int)]
 
 
 class _FrameSlice(ctypes.Structure):
@@ -529,7 +530,7 @@ def _profile_mask() -> int:
 def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
                          H: int, W: int, bg: Tensor, edges: Tensor, slice_base: int, color=None,
                          out_depth: Optional[Tensor] = None, reserve_backward: bool = True, rs=None, combine=None,
-                         hints: Optional[FrameHints] = None):
+                         hints: Optional[FrameHints] = None, band_clipped: bool = False):
     """combine = (gamma, min_level, out [H,W,3]): the library launches the gamma-space average of the sample images itself,
     behind every slice's compositor (it overlaps the open-tile read-back).  rs = (pix_vel [N,2], rolling_shutter_time[, sample_times [S]]) or None; with sample_times the frame runs in the
     shared-list mode (P == 1: one record set and one tile list for the S samples).  gs_frame_forward: -> (out_img [S,H,W,3], out_T [S,H,W], frame) ; frame = dict(arena, state) for
@@ -561,7 +562,8 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
         pin = _pinned_cache[pin_key] = torch.empty(max(8192, need_pin), dtype=torch.uint8, pin_memory=True)
     desc = _FrameDesc(N, P, S, R, H, W, int(slice_base), DEPTH_SORT_DIGIT, 0, int(reserve_backward),
                       float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0, frame_poll(), int(shared),
-                      float(combine[0]) if combine is not None else 1.0, float(combine[1]) if combine is not None else 0.0)
+                      float(combine[0]) if combine is not None else 1.0, float(combine[1]) if combine is not None else 0.0,
+                      int(bool(band_clipped)))
     state = _FrameState()
     out_img = torch.empty(S, H, W, 3, device=dev)
     out_T = torch.empty(S, H, W, device=dev)
@@ -685,6 +687,7 @@ class _ProjectGaussiansPixvel(Function):
 
     @staticmethod
     def forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, clip, lin_vel, ang_vel, span):
+        ctx.set_materialize_grads(False)        # an output nobody differentiates arrives as None in backward
         means3d, scales, quats = _f32(means3d, "means3d"), _f32(scales, "scales"), _f32(quats, "quats")
         V = _viewmat16(viewmat).reshape(4, 4)
         N, dev, L = means3d.shape[0], means3d.device, _L()
@@ -869,6 +872,7 @@ class _RasterizeGaussiansPixvel(Function):
 
     @staticmethod
     def forward(ctx, xys, depths, radii, conics, colors, opacity, pix_vels, H, W, background, times, rs_time, span):
+        ctx.set_materialize_grads(False)
         xys, depths, conics = _f32(xys, "xys"), _f32(depths, "depths"), _f32(conics, "conics")
         colors, opacity, pv = _f32(colors, "colors"), _f32(opacity, "opacity").reshape(-1), _f32(pix_vels, "pix_vels")
         radii = radii.to(torch.int32).contiguous()
@@ -918,7 +922,10 @@ class _RasterizeGaussiansPixvel(Function):
         records, sorted_ids, bins, edges, bg, out_T, fidx, pv, times_t = ctx.saved_tensors
         N, S, H, W, rs_time = ctx.dims
         dev, L, em, I = records.device, _L(), ctx.em, ctx.n_isect
+        if v_img is None and v_alpha is None:
+            return (None,) * 13
         v_img = torch.zeros(S, H, W, 3, device=dev) if v_img is None else v_img.contiguous().float()
+        # (out_alpha = 1 - out_T: the compositor's v_alpha input is d loss / d alpha)
         v_al = None if v_alpha is None else v_alpha.contiguous().float()
         v_records = torch.zeros(N, GRAD, device=dev)
         if I > 0:
@@ -1227,7 +1234,8 @@ class _RenderSubposes(Function):
                 try:
                     out_img, out_T, ctx.frame = native_frame_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges,
                                                                      hints.slice_base(), color, depth_acc,
-                                                                     any(ctx.needs_input_grad), rs, averaged, hints)
+                                                                     any(ctx.needs_input_grad), rs, averaged, hints,
+                                                                     bool(defer_flags & 4))
                     hints.feedback(int(ctx.frame["state"].n_slices), retries)
                     break
                 except _ArenaTooSmall:

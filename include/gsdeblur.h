@@ -487,6 +487,10 @@ typedef struct gs_frame_desc {
                                 every splat at mu' + (sample_times[s] + tau(y)) * pixel velocity inside the compositor */
   float combine_gamma;       /* with out_combined != NULL: gs_combine_fwd(gamma, min_level) of the sample images is */
   float combine_min_level;   /* launched behind every slice's compositor (it overlaps the open-tile read-back) */
+  int band_clipped;          /* 1: the projection was band-aware (gs_project_fused_fwd defer_color bit 2): a sub-pose's
+                                tile counts only hold the pairs inside its rolling-shutter band, so a sub-pose owns T/R
+                                open tiles and the slice plan's budget per sub-pose is T/R * slice_base (0: T * slice_base,
+                                of which one pair in R lies inside the band) */
 } gs_frame_desc;
 typedef struct gs_frame_slice {
   long long I;               /* capacity of the slice's lists (its ranks' bounding-box pairs); real count on the device */

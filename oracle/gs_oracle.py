@@ -47,7 +47,8 @@ TILE = 16
 # ---- gradient conventions (SURVEY.md App. A "Backward") -------------------------------------------------
 # Three places where the backward recollected from upstream gsplat 0.1.11 is NOT the derivative of its forward; each is
 # a straight-through rule (the forward value is kept, the backward treats the operation as the identity):
-#   UP_FOV_CLAMP  (1)  the clamp of x/z, y/z to +-1.3 tan(fov/2) in front of the EWA Jacobian
+#   UP_FOV_CLAMP  (1)  the clamp of x/z, y/z to +-1.3 tan(fov/2) in front of the EWA Jacobian: the backward is the VJP of
+#                      the UNCLAMPED covariance projection (upstream's project_cov3d_ewa_vjp takes no fov argument)
 #   UP_QUAT_RAW   (2)  the normalisation q/|q| inside the kernel: the gradient is returned w.r.t. the (assumed unit)
 #                      quaternion.  Only the compat op (project_gaussians) honours it: the FUSED path (render) takes
 #                      splatfacto's raw quaternions, i.e. it stands for `quats / quats.norm()` + the kernel, and the
@@ -158,30 +159,36 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
     fx_t, fy_t, cx_t, cy_t = one * fx, one * fy, one * cx, one * cy
     tx = pz_safe * torch.minimum(lim_x, torch.maximum(-lim_x, px * rz))
     ty = pz_safe * torch.minimum(lim_y, torch.maximum(-lim_y, py * rz))
-    if upstream & UP_FOV_CLAMP:
-        # gs::project_one_bwd upstream_clamp_grad: v_px += v_tx, v_py += v_ty whether or not the clamp is active
-        tx, ty = _straight_through(tx, px), _straight_through(ty, py)
     rz2 = rz * rz
-    J00 = fx_t * rz
-    J02 = -(fx_t * tx) * rz2
-    J11 = fy_t * rz
-    J12 = -(fy_t * ty) * rz2
-    T0 = J00 * V[0, 0] + J02 * V[2, 0]
-    T1 = J00 * V[0, 1] + J02 * V[2, 1]
-    T2 = J00 * V[0, 2] + J02 * V[2, 2]
-    T3 = J11 * V[1, 0] + J12 * V[2, 0]
-    T4 = J11 * V[1, 1] + J12 * V[2, 1]
-    T5 = J11 * V[1, 2] + J12 * V[2, 2]
     S00, S01, S02, S11, S12, S22 = (c3[:, i] for i in range(6))
-    U0 = (T0 * S00 + T1 * S01) + T2 * S02
-    U1 = (T0 * S01 + T1 * S11) + T2 * S12
-    U2 = (T0 * S02 + T1 * S12) + T2 * S22
-    U3 = (T3 * S00 + T4 * S01) + T5 * S02
-    U4 = (T3 * S01 + T4 * S11) + T5 * S12
-    U5 = (T3 * S02 + T4 * S12) + T5 * S22
-    a0 = (U0 * T0 + U1 * T1) + U2 * T2
-    b = (U0 * T3 + U1 * T4) + U2 * T5
-    c0 = (U3 * T3 + U4 * T4) + U5 * T5
+
+    def ewa(tx_, ty_):
+        """cov2d before the dilation: J W Sigma W^T J^T with J taken at (tx_, ty_, z)"""
+        J00 = fx_t * rz
+        J02 = -(fx_t * tx_) * rz2
+        J11 = fy_t * rz
+        J12 = -(fy_t * ty_) * rz2
+        T0 = J00 * V[0, 0] + J02 * V[2, 0]
+        T1 = J00 * V[0, 1] + J02 * V[2, 1]
+        T2 = J00 * V[0, 2] + J02 * V[2, 2]
+        T3 = J11 * V[1, 0] + J12 * V[2, 0]
+        T4 = J11 * V[1, 1] + J12 * V[2, 1]
+        T5 = J11 * V[1, 2] + J12 * V[2, 2]
+        U0 = (T0 * S00 + T1 * S01) + T2 * S02
+        U1 = (T0 * S01 + T1 * S11) + T2 * S12
+        U2 = (T0 * S02 + T1 * S12) + T2 * S22
+        U3 = (T3 * S00 + T4 * S01) + T5 * S02
+        U4 = (T3 * S01 + T4 * S11) + T5 * S12
+        U5 = (T3 * S02 + T4 * S12) + T5 * S22
+        return ((U0 * T0 + U1 * T1) + U2 * T2, (U0 * T3 + U1 * T4) + U2 * T5, (U3 * T3 + U4 * T4) + U5 * T5)
+
+    a0, b, c0 = ewa(tx, ty)
+    if upstream & UP_FOV_CLAMP:
+        # gsplat 0.1.11's project_cov3d_ewa_vjp takes no fov argument: the backward is the VJP of the UNCLAMPED EWA
+        # projection (J rebuilt from the camera-space mean itself), applied to the cov2d gradient that the clamped
+        # forward's conic produced (gs::project_one_bwd upstream_clamp_grad).  Values: the clamped forward's, exactly.
+        au, bu, cu = ewa(px, py)
+        a0, b, c0 = _straight_through(a0, au), _straight_through(b, bu), _straight_through(c0, cu)
     det0 = a0 * c0 - b * b
     a = a0 + DILATION
     c = c0 + DILATION

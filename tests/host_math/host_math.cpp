@@ -60,6 +60,48 @@ int hm_project_bwd(int n, const float* means, const float* scales, float glob, c
   return 0;
 }
 
+// the same with the reference's gradient conventions switched on (grad_flags bit 0: fov clamp, bit 1: raw quaternion)
+int hm_project_bwd_flags(int n, const float* means, const float* scales, float glob, const float* quats,
+                         const float* V, float fx, float fy, float cx, float cy, int W, int H, float clip,
+                         const float* v_xys, const float* v_depths, const float* v_conics, const float* v_comp,
+                         float* v_means, float* v_scales, float* v_quats, float* v_V /*12*/, int grad_flags) {
+  int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+  for (int j = 0; j < 12; ++j) v_V[j] = 0.f;
+  for (int i = 0; i < n; ++i) {
+    float R[9], qn[4], inv, M[9], c3[6];
+    quat_to_rotmat(quats + 4 * i, R, qn, &inv);
+    scale_rot_to_cov3d(scales + 3 * i, glob, R, M, c3);
+    Proj o; ProjCtx k;
+    bool ok = project_one(means + 3 * i, c3, V, fx, fy, cx, cy, W, H, tiles_x, tiles_y, clip, o, k);
+    for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = 0; v_scales[3 * i + j] = 0; }
+    for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = 0;
+    if (!ok) continue;
+    float vm[3], vc3[6], vV[12], vs[3], vq[4];
+    project_one_bwd(means + 3 * i, c3, V, fx, fy, k, o.comp, v_xys + 2 * i, v_depths[i], v_conics + 3 * i,
+                    v_comp[i], vm, vc3, vV, nullptr, (grad_flags & 1) != 0);
+    cov3d_bwd(scales + 3 * i, glob, quats + 4 * i, vc3, vs, vq, (grad_flags & 2) != 0);
+    // the double-precision twin (needle Gaussians) must follow the same convention
+    double R64[9], qn64[4], inv64, M64[9], c364[6], vm64[3], vc364[6], vV64[12], vxy64[2], vcon64[3];
+    quat_to_rotmat_t<double>(quats + 4 * i, R64, qn64, &inv64);
+    scale_rot_to_cov3d_t<double>(scales + 3 * i, glob, R64, M64, c364);
+    ProjCtxT<double> k64;
+    project_ctx_t<double>(means + 3 * i, c364, V, fx, fy, W, H, k64);
+    vxy64[0] = v_xys[2 * i]; vxy64[1] = v_xys[2 * i + 1];
+    for (int j = 0; j < 3; ++j) vcon64[j] = v_conics[3 * i + j];
+    const double r64 = k64.det0 / k64.det;
+    project_one_bwd_t<double>(means + 3 * i, c364, V, fx, fy, k64, ::sqrt(r64 > 0.0 ? r64 : 0.0), vxy64,
+                              (double)v_depths[i], vcon64, (double)v_comp[i], vm64, vc364, vV64, nullptr,
+                              (grad_flags & 1) != 0);
+    for (int j = 0; j < 3; ++j)
+      if (::fabs(vm64[j] - (double)vm[j]) > 2e-4 * (::fabs(vm64[j]) + 1e-3 * (::fabs(vm64[0]) + ::fabs(vm64[1]) + ::fabs(vm64[2])) + 1e-12))
+        return 100 + i;     // the float and the double chain disagree on a mean gradient
+    for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = vm[j]; v_scales[3 * i + j] = vs[j]; }
+    for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = vq[j];
+    for (int j = 0; j < 12; ++j) v_V[j] += vV[j];
+  }
+  return 0;
+}
+
 int hm_sh_basis(int n, int deg, const float* dirs, float* B) {
   int nb = (deg + 1) * (deg + 1);
   for (int i = 0; i < n; ++i) sh_basis(deg, dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], B + nb * i);
