@@ -234,8 +234,10 @@ GS_HD bool project_one(const float mean[3], const float c3[6], const float* V,
 // parametrisation: off-diagonals carry the sum of both symmetric entries),
 // v_V[12] (rows 0..2 of the viewmat).
 // v_pc_extra (nullable): an additional gradient on the camera-space mean (the pixel-velocity model's).
-// upstream_clamp_grad: gsplat 0.1.11 back-propagates through the fov clamp of x/z, y/z as if it were inactive — its
-// EWA VJP is that of the UNCLAMPED projection; false = the true derivative.
+// upstream_clamp_grad: gsplat 0.1.11 back-propagates through the fov clamp of x/z, y/z as if it were inactive: a
+// straight-through rule on tx, ty (v_px += v_tx whether or not the clamp is active).  Round 5 also
+// built and measured the other reading — the VJP of the UNCLAMPED EWA projection (J rebuilt from px, py) — and dropped
+// it: no better evidence, and the end-to-end pose recovery it costs is worse; false = the true derivative.
 GS_HD void project_one_bwd(const float mean[3], const float c3[6], const float* V,
                            float fx, float fy, const ProjCtx& k, float comp,
                            const float v_xy[2], float v_depth, const float v_conic[3], float v_comp,
@@ -258,19 +260,6 @@ GS_HD void project_one_bwd(const float mean[3], const float c3[6], const float* 
   }
   // cov2d = T Sigma T^T ; Gc = [[v_a, v_b/2],[v_b/2, v_c]]
   const float* T = k.T;
-  float kJ02 = k.J02, kJ12 = k.J12, ktx = k.tx, kty = k.ty;
-  float Tu[6];
-  if (upstream_clamp_grad && (k.clamp_x | k.clamp_y)) {
-    // gsplat 0.1.11's project_cov3d_ewa_vjp takes no fov argument: it rebuilds J and T = J W from the UNCLAMPED
-    // camera-space mean and returns the VJP of that (unclamped) EWA projection for the cov2d gradient the clamped
-    // forward's conic produced — "as if the clamp were inactive" all the way, not a straight-through on tx alone
-    const float rz2u = k.rz * k.rz;
-    ktx = k.pc[0]; kty = k.pc[1];
-    kJ02 = -(fx * ktx) * rz2u; kJ12 = -(fy * kty) * rz2u;
-    Tu[0] = k.J00 * V[0] + kJ02 * V[8]; Tu[1] = k.J00 * V[1] + kJ02 * V[9]; Tu[2] = k.J00 * V[2] + kJ02 * V[10];
-    Tu[3] = k.J11 * V[4] + kJ12 * V[8]; Tu[4] = k.J11 * V[5] + kJ12 * V[9]; Tu[5] = k.J11 * V[6] + kJ12 * V[10];
-    T = Tu;
-  }
   float g00 = v_a, g01 = 0.5f * v_b, g11 = v_c;
   // v_Sigma = T^T Gc T  (3x3 symmetric) -> upper-triangle parametrisation
   float GT0 = g00 * T[0] + g01 * T[3], GT1 = g00 * T[1] + g01 * T[4], GT2 = g00 * T[2] + g01 * T[5];
@@ -299,13 +288,13 @@ GS_HD void project_one_bwd(const float mean[3], const float c3[6], const float* 
   float vW[9];
   vW[0] = k.J00 * vT0; vW[1] = k.J00 * vT1; vW[2] = k.J00 * vT2;
   vW[3] = k.J11 * vT3; vW[4] = k.J11 * vT4; vW[5] = k.J11 * vT5;
-  vW[6] = kJ02 * vT0 + kJ12 * vT3; vW[7] = kJ02 * vT1 + kJ12 * vT4; vW[8] = kJ02 * vT2 + kJ12 * vT5;
+  vW[6] = k.J02 * vT0 + k.J12 * vT3; vW[7] = k.J02 * vT1 + k.J12 * vT4; vW[8] = k.J02 * vT2 + k.J12 * vT5;
   // J(pc)
   const float px = k.pc[0], py = k.pc[1], pz = k.pc[2], rz = k.rz;
   const float rz2 = rz * rz, rz3 = rz2 * rz;
   float v_tx = -fx * rz2 * vJ02;
   float v_ty = -fy * rz2 * vJ12;
-  float v_pz = -fx * rz2 * vJ00 - fy * rz2 * vJ11 + 2.f * fx * ktx * rz3 * vJ02 + 2.f * fy * kty * rz3 * vJ12;
+  float v_pz = -fx * rz2 * vJ00 - fy * rz2 * vJ11 + 2.f * fx * k.tx * rz3 * vJ02 + 2.f * fy * k.ty * rz3 * vJ12;
   float v_px = 0.f, v_py = 0.f;
   if (k.clamp_x == 0 || upstream_clamp_grad) v_px += v_tx; else v_pz += v_tx * (k.tx * rz);  // tx = (+-lim) * z
   if (k.clamp_y == 0 || upstream_clamp_grad) v_py += v_ty; else v_pz += v_ty * (k.ty * rz);
@@ -521,16 +510,6 @@ GS_HD void project_one_bwd_t(const float mean[3], const S c3[6], const float* V,
     v_b += v_r * (-S(2) * b * inv_det + det0 * S(2) * b * inv_det2);
   }
   const S* T = k.T;
-  S kJ02 = k.J02, kJ12 = k.J12, ktx = k.tx, kty = k.ty;
-  S Tu[6];
-  if (upstream_clamp_grad && (k.clamp_x | k.clamp_y)) {        // (see project_one_bwd: the unclamped EWA projection's VJP)
-    const S rz2u = k.rz * k.rz;
-    ktx = k.pc[0]; kty = k.pc[1];
-    kJ02 = -(fx * ktx) * rz2u; kJ12 = -(fy * kty) * rz2u;
-    Tu[0] = k.J00 * (S)V[0] + kJ02 * (S)V[8]; Tu[1] = k.J00 * (S)V[1] + kJ02 * (S)V[9]; Tu[2] = k.J00 * (S)V[2] + kJ02 * (S)V[10];
-    Tu[3] = k.J11 * (S)V[4] + kJ12 * (S)V[8]; Tu[4] = k.J11 * (S)V[5] + kJ12 * (S)V[9]; Tu[5] = k.J11 * (S)V[6] + kJ12 * (S)V[10];
-    T = Tu;
-  }
   const S g00 = v_a, g01 = S(0.5) * v_b, g11 = v_c;
   const S GT0 = g00 * T[0] + g01 * T[3], GT1 = g00 * T[1] + g01 * T[4], GT2 = g00 * T[2] + g01 * T[5];
   const S GT3 = g01 * T[0] + g11 * T[3], GT4 = g01 * T[1] + g11 * T[4], GT5 = g01 * T[2] + g11 * T[5];
@@ -554,11 +533,11 @@ GS_HD void project_one_bwd_t(const float mean[3], const S c3[6], const float* V,
   S vW[9];
   vW[0] = k.J00 * vT0; vW[1] = k.J00 * vT1; vW[2] = k.J00 * vT2;
   vW[3] = k.J11 * vT3; vW[4] = k.J11 * vT4; vW[5] = k.J11 * vT5;
-  vW[6] = kJ02 * vT0 + kJ12 * vT3; vW[7] = kJ02 * vT1 + kJ12 * vT4; vW[8] = kJ02 * vT2 + kJ12 * vT5;
+  vW[6] = k.J02 * vT0 + k.J12 * vT3; vW[7] = k.J02 * vT1 + k.J12 * vT4; vW[8] = k.J02 * vT2 + k.J12 * vT5;
   const S px = k.pc[0], py = k.pc[1], rz = k.rz;
   const S rz2 = rz * rz, rz3 = rz2 * rz;
   const S v_tx = -fx * rz2 * vJ02, v_ty = -fy * rz2 * vJ12;
-  S v_pz = -fx * rz2 * vJ00 - fy * rz2 * vJ11 + S(2) * fx * ktx * rz3 * vJ02 + S(2) * fy * kty * rz3 * vJ12;
+  S v_pz = -fx * rz2 * vJ00 - fy * rz2 * vJ11 + S(2) * fx * k.tx * rz3 * vJ02 + S(2) * fy * k.ty * rz3 * vJ12;
   S v_px = S(0), v_py = S(0);
   if (k.clamp_x == 0 || upstream_clamp_grad) v_px += v_tx; else v_pz += v_tx * (k.tx * rz);
   if (k.clamp_y == 0 || upstream_clamp_grad) v_py += v_ty; else v_pz += v_ty * (k.ty * rz);

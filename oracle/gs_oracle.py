@@ -47,8 +47,7 @@ TILE = 16
 # ---- gradient conventions (SURVEY.md App. A "Backward") -------------------------------------------------
 # Three places where the backward recollected from upstream gsplat 0.1.11 is NOT the derivative of its forward; each is
 # a straight-through rule (the forward value is kept, the backward treats the operation as the identity):
-#   UP_FOV_CLAMP  (1)  the clamp of x/z, y/z to +-1.3 tan(fov/2) in front of the EWA Jacobian: the backward is the VJP of
-#                      the UNCLAMPED covariance projection (upstream's project_cov3d_ewa_vjp takes no fov argument)
+#   UP_FOV_CLAMP  (1)  the clamp of x/z, y/z to +-1.3 tan(fov/2) in front of the EWA Jacobian
 #   UP_QUAT_RAW   (2)  the normalisation q/|q| inside the kernel: the gradient is returned w.r.t. the (assumed unit)
 #                      quaternion.  Only the compat op (project_gaussians) honours it: the FUSED path (render) takes
 #                      splatfacto's raw quaternions, i.e. it stands for `quats / quats.norm()` + the kernel, and the
@@ -182,13 +181,10 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
         U5 = (T3 * S02 + T4 * S12) + T5 * S22
         return ((U0 * T0 + U1 * T1) + U2 * T2, (U0 * T3 + U1 * T4) + U2 * T5, (U3 * T3 + U4 * T4) + U5 * T5)
 
-    a0, b, c0 = ewa(tx, ty)
     if upstream & UP_FOV_CLAMP:
-        # gsplat 0.1.11's project_cov3d_ewa_vjp takes no fov argument: the backward is the VJP of the UNCLAMPED EWA
-        # projection (J rebuilt from the camera-space mean itself), applied to the cov2d gradient that the clamped
-        # forward's conic produced (gs::project_one_bwd upstream_clamp_grad).  Values: the clamped forward's, exactly.
-        au, bu, cu = ewa(px, py)
-        a0, b, c0 = _straight_through(a0, au), _straight_through(b, bu), _straight_through(c0, cu)
+        # gs::project_one_bwd upstream_clamp_grad: v_px += v_tx, v_py += v_ty whether or not the clamp is active
+        tx, ty = _straight_through(tx, px), _straight_through(ty, py)
+    a0, b, c0 = ewa(tx, ty)
     det0 = a0 * c0 - b * b
     a = a0 + DILATION
     c = c0 + DILATION

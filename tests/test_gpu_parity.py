@@ -1811,7 +1811,7 @@ def _full_size_two_paths(gs, dev, n, W, H, S, R, profile, other, min_slices=1, s
             diff = int((touched_f != touched_o).sum())
             print(f"[kernel-vs-kernel touched {k} {tag}] {diff} of {int(touched_o.sum())} rows differ")
             assert diff <= max(2, 1e-3 * int(touched_o.sum())), (k, diff)
-    return sl_f, sl_o, I_f, g_f
+    return sl_f, sl_o, I_o, g_f, I_f
 
 
 _PLAIN = dict(SLICE_BASE=0, EXACT_TILE_CULL=0, COMPACT_EMIT=0, HIT_MASKS=0, GRAD_TUPLES=0, DEFER_COLOR=0,
@@ -1825,29 +1825,32 @@ _PLAIN_DET = dict(_PLAIN, GRAD_TUPLES=1)
 def test_full_size_headline_equals_deterministic_plain_path_per_element(gs, dev):
     """BASELINE.json's metric configuration, default path vs the deterministic plain path: bit-identical image and the
     per-element gradient bar (not 3e-3 of the tensor's max).  238 M tuples of 48 bytes = 11.4 GB on the plain side."""
-    sl_f, sl_o, I, _ = _full_size_two_paths(gs, dev, 1_000_000, 1920, 1080, 5, 1, "survey", _PLAIN_DET, el_bar=True)
+    sl_f, sl_o, I, _, _ = _full_size_two_paths(gs, dev, 1_000_000, 1920, 1080, 5, 1, "survey", _PLAIN_DET, el_bar=True)
     assert sl_o == [I] and sum(sl_f) < 0.1 * I
 
 
 def test_full_size_multi_slice_equals_deterministic_plain_path_per_element(gs, dev):
     """the fitted-model-like scene (several depth slices, a third of the Gaussians with a gradient), same bar"""
-    sl_f, sl_o, I, g = _full_size_two_paths(gs, dev, 1_000_000, 1920, 1080, 5, 1, "trained", _PLAIN_DET, min_slices=3,
-                                            el_bar=True)
+    sl_f, sl_o, I, g, _ = _full_size_two_paths(gs, dev, 1_000_000, 1920, 1080, 5, 1, "trained", _PLAIN_DET, min_slices=3,
+                                               el_bar=True)
     assert sl_o == [I]
 
 
 def test_full_size_config3_rolling_shutter_bands_equals_plain_path(gs, dev):
     """BASELINE.json config 3: 1M Gaussians, 1080p, 10 rolling-shutter row bands (S=1, R=10) — default path vs the
     plainest one (one slice with every bounding-box pair, no culling, atomics, round-1 v_readlane compositors)."""
-    sl_f, sl_o, I, _ = _full_size_two_paths(gs, dev, 1_000_000, 1920, 1080, 1, 10, "survey", _PLAIN)
+    sl_f, sl_o, I, _, I_banded = _full_size_two_paths(gs, dev, 1_000_000, 1920, 1080, 1, 10, "survey", _PLAIN)
     # plain path: ONE slice holding every bounding-box pair of every sub-pose's own row band (a tenth of all pairs)
     assert len(sl_o) == 1 and 0.05 * I < sl_o[0] < 0.2 * I and sum(sl_f) < 0.3 * sl_o[0]
+    # round 5: the default path's band-aware projection counts exactly those pairs — the plain path's emission and the
+    # projection's clipped boxes are two routes to the same integer
+    assert I_banded == sl_o[0]
 
 
 def test_full_size_config4_blur_and_rolling_shutter_share_equals_plain_path(gs, dev):
     """BASELINE.json config 4, one GPU's share (1 view): 2M Gaussians, 1080p, 5 samples x 2 bands."""
-    sl_f, sl_o, I, _ = _full_size_two_paths(gs, dev, 2_000_000, 1920, 1080, 5, 2, "survey", _PLAIN)
-    assert len(sl_o) == 1 and 0.3 * I < sl_o[0] < 0.7 * I and sum(sl_f) < 0.2 * sl_o[0]
+    sl_f, sl_o, I, _, I_banded = _full_size_two_paths(gs, dev, 2_000_000, 1920, 1080, 5, 2, "survey", _PLAIN)
+    assert len(sl_o) == 1 and 0.3 * I < sl_o[0] < 0.7 * I and sum(sl_f) < 0.2 * sl_o[0] and I_banded == sl_o[0]
 
 
 def test_full_size_config5_4k_10_subposes_two_slicings_agree(gs, dev):
@@ -1855,14 +1858,14 @@ def test_full_size_config5_4k_10_subposes_two_slicings_agree(gs, dev):
     hold its 4e9 bounding-box pairs in one 2^31-entry slice, so the default path is compared with a DIFFERENT
     slicing (4x the budget), without hit masks / deferred colour / tuples and with the round-1 compositors."""
     other = dict(SLICE_BASE=2048, HIT_MASKS=0, GRAD_TUPLES=0, DEFER_COLOR=0, RASTER_FWD_VARIANT=2, RASTER_BWD_VARIANT=2)
-    sl_f, sl_o, I, _ = _full_size_two_paths(gs, dev, 5_000_000, 3840, 2160, 10, 1, "survey", other)
+    sl_f, sl_o, I, _, _ = _full_size_two_paths(gs, dev, 5_000_000, 3840, 2160, 10, 1, "survey", other)
     assert I > 2 ** 31 and sum(sl_f) < 0.1 * I
 
 
 def test_full_size_multi_slice_frame_equals_plain_path(gs, dev):
     """1M Gaussians, 1080p, 5 sub-poses of the fitted-model-like scene (small translucent Gaussians): the default
     path needs at least three depth slices and a large share of the Gaussians receives a gradient."""
-    sl_f, sl_o, I, g = _full_size_two_paths(gs, dev, 1_000_000, 1920, 1080, 5, 1, "trained", _PLAIN, min_slices=3)
+    sl_f, sl_o, I, g, _ = _full_size_two_paths(gs, dev, 1_000_000, 1920, 1080, 5, 1, "trained", _PLAIN, min_slices=3)
     assert sl_o == [I]
     assert (g["means"] != 0).any(dim=1).float().mean().item() > 0.3
 
@@ -3006,7 +3009,7 @@ def test_fork_style_keywords_on_the_compat_ops(gs, oracle, dev, S, rt):
         a = gs.project_gaussians(*args)
         b = gs.project_gaussians(*args, 16, 0.01, exposure_time=et, blur_samples=S)      # no velocities: still static
         assert len(a) == 7 and len(b) == 7 and all(torch.equal(x, y) for x, y in zip(a, b))
-        assert torch.allclose(a[6], cov3d_c, rtol=1e-5, atol=1e-12)       # (exp on the CPU vs on the GPU: an ulp)
+        assert torch.allclose(a[6], cov3d_c, rtol=1e-5, atol=1e-7)        # (exp on the CPU vs on the GPU: an ulp)
     with pytest.raises(ValueError):
         gs.project_gaussians(*args, lin_vel=sc["lin_vel"].to(dev))
 
