@@ -114,7 +114,7 @@ PY
         tail -1 $OUT/pmc_$t.log | cut -c1-200 | tee -a $S
       done
       python tools/pmc_summary.py $OUT 2>&1 | tail -40 | tee -a $S
-      python tools/make_traffic.py $OUT "round 4 $TAG" > $OUT/traffic.json 2>/dev/null; head -c 600 $OUT/traffic.json | tee -a $S ;;
+      python tools/make_traffic.py $OUT "round 5 $TAG" > $OUT/traffic.json 2>/dev/null; head -c 600 $OUT/traffic.json | tee -a $S ;;
     *) echo "unknown step $step" | tee -a $S ;;
   esac
 done
