@@ -667,13 +667,17 @@ GS_EXPORT int gs_frame_backward(const gs_frame_state* state, const float* record
     }
     {
       StageScope sc(ST_REDUCE, st);
-      // kernel form: a wave per Gaussian only for slices of few, large Gaussians (the choice the exact count made) —
-      // and not for rolling-shutter bands: a band-clipped box spans a few tile rows, a Gaussian emits a handful of
-      // tuples whatever its box says (config 3: 8 per Gaussian; 0.093 vs 0.023 ms, visit r5_v5)
+      // kernel form (gs_reduce_grad_tuples takes the wave-per-Gaussian kernel when n_isect > 32 * n_slice): a wave per
+      // Gaussian pays when a Gaussian owns tens of tuples AND the slice holds few Gaussians — the benchmark scene's
+      // first slice (50 k Gaussians, 170 tuples each), a band-clipped rolling-shutter slice (88 k, 19 each: 0.023 ms
+      // against 0.092 ms in the thread form, visit r5_prof) — and costs milliseconds on a slice of millions of small
+      // splats (fitted-model-like scene: 5 M Gaussians, 8 tuples each).  The list capacity is all the host knows: the
+      // exact count's own choice (few Gaussians with boxes of > 128 tiles), or a band-clipped slice of < 2^19 Gaussians.
       CHECK(gs_reduce_grad_tuples(sl.n, reinterpret_cast<const unsigned*>(base + sl.slice_gi),
                                   reinterpret_cast<const unsigned*>(base + sl.counts),
                                   reinterpret_cast<const unsigned*>(base + sl.cum), tuples, flags, v_records, touched,
-                                  (sl.wave_per_gaussian && R == 1) ? sl.I : 0, records, (int)tpe, st));
+                                  (sl.wave_per_gaussian || (R > 1 && sl.n < (1 << 19))) ? sl.I : 0, records, (int)tpe,
+                                  st));
     }
   }
   return GS_OK;
