@@ -172,7 +172,7 @@ def train_step(model: SplatfactoDeblurModel, optimizers: Dict[str, torch.optim.O
     optimizers_step(optimizers.values())
     model.step += 1
     # ONE read-back for the step's two log values (each .item() is a stream synchronisation)
-    mse = torch.mean((rgb.clamp(0, 1) - gt_image.clamp(0, 1)) ** 2)
+    mse = F.mse_loss(rgb.clamp(0, 1), gt_image.clamp(0, 1))
     loss_v, mse_v = torch.stack([loss.detach().reshape(()).float(), mse.float()]).tolist()
     return {"loss": float(loss_v), "psnr": float("inf") if mse_v == 0 else -10.0 * math.log10(mse_v)}
 
