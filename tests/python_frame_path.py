@@ -552,7 +552,8 @@ def sliced_backward(records: Tensor, slices, S: int, R: int, img_height: int, im
                 # it sent every slice of a small-splat scene (7 entries per Gaussian) through 64-lane waves
                 _check(L.gs_reduce_grad_tuples(sl["n"], _ptr(sl["slice_gi"]), _ptr(sl["counts"]), _ptr(sl["cum"]),
                                                _ptr(tuples), _ptr(flags), _ptr(v_records), _ptr(touched),
-                                               sl["I"] if sl.get("wave_per_g", True) else 0, _ptr(records), 1, _stream()),
+                                               sl["I"] if (sl.get("wave_per_g", True) or (R > 1 and sl["n"] < (1 << 19))) else 0,
+                                               _ptr(records), 1, _stream()),
                        "reduce_grad_tuples")
 
 
