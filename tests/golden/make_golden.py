@@ -174,6 +174,81 @@ def make_large_case(name, n, W, H, cfg_kw, seed, sh_degree=3, scale_mult=2.0, ve
           int(frag.sum()), f"({float(frag.float().mean()):.4f})", "Gaussians with gradient", rows_g)
 
 
+def _call_by_name(fn, available: dict):
+    """call a reference function whose exact signature is only recollected: bind its parameters BY NAME from what we
+    have; an unknown required parameter is reported with the full signature instead of guessed"""
+    import inspect
+    sig = inspect.signature(fn)
+    kwargs, missing = {}, []
+    for name, prm in sig.parameters.items():
+        if name in available:
+            kwargs[name] = available[name]
+        elif prm.default is inspect.Parameter.empty and prm.kind in (prm.POSITIONAL_OR_KEYWORD, prm.KEYWORD_ONLY):
+            missing.append(name)
+    if missing:
+        raise RuntimeError(f"{getattr(fn, '__name__', fn)}{sig}: no value for parameter(s) {missing}; extend the "
+                           f"name table in make_golden.regenerate_from_reference (have: {sorted(available)})")
+    return fn(**kwargs)
+
+
+def regenerate_from_reference(torch_impl, out_dir=None):
+    """The day a gsplat with `_torch_impl` imports (tests/golden/make_reference_fixtures.py calls this from its guarded
+    branch; VERDICT round 4 'missing 1'): run the STATIC fixture scene through the REFERENCE's own torch restatement —
+    `project_gaussians_forward` and `rasterize_forward`, gsplat 0.1.11 names — and write `ref_static_small.npz`:
+    the reference's xys / depths / radii / conics / compensation / num_tiles_hit and its composited image, next to the
+    oracle's values of the same scene and the largest differences.  That file is REFERENCE-golden: the tests that load
+    `static_small.npz` can then be pointed at it, and "parity unpinned" leaves the oracle's header.  Signatures are bound
+    by parameter name (they are recollected); a name this table does not know is reported, not guessed.
+    Exercised on CPU with a stand-in module of the recollected shape (tests/test_oracle.py)."""
+    out_dir = Path(out_dir) if out_dir is not None else OUT
+    n, W, H, seed, deg = 600, 64, 48, 11, 3
+    sc = O.synthetic_scene(n, W, H, sh_degree=deg, seed=seed, scale_mult=5.0)
+    scales, quats = sc["log_scales"].exp(), sc["quats"]
+    opac = torch.sigmoid(sc["opacity_logits"])
+    V = sc["viewmat"]
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    have = dict(means3d=sc["means"], scales=scales, glob_scale=1.0, quats=quats, viewmat=V,
+                intrins=(sc["fx"], sc["fy"], sc["cx"], sc["cy"]), fx=sc["fx"], fy=sc["fy"], cx=sc["cx"], cy=sc["cy"],
+                img_size=(W, H), img_height=H, img_width=W, block_width=O.TILE, tile_bounds=((W + 15) // 16, (H + 15) // 16, 1),
+                clip_thresh=0.01)
+    res = _call_by_name(torch_impl.project_gaussians_forward, have)
+    # 0.1.11: (cov3d, cov2d, xys, depths, radii, conics, compensation, num_tiles_hit, mask); older: without compensation
+    names9 = ["cov3d", "cov2d", "xys", "depths", "radii", "conics", "compensation", "num_tiles_hit", "mask"]
+    names8 = [k for k in names9 if k != "compensation"]
+    if len(res) not in (8, 9):
+        raise RuntimeError(f"project_gaussians_forward returned {len(res)} values; expected 9 (0.1.11) or 8")
+    ref = dict(zip(names9 if len(res) == 9 else names8, res))
+    ref.setdefault("compensation", torch.ones(n))
+    pr = O.project_gaussians(sc["means"], scales, 1.0, quats, V, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W)
+    cam = -(V[:3, :3].T @ V[:3, 3])
+    rgb = torch.clamp(O.spherical_harmonics(deg, sc["means"] - cam[None, :], sc["sh"]) + 0.5, min=0.0)
+    op = opac * pr.compensation
+    have_r = dict(xys=ref["xys"], depths=ref["depths"], radii=ref["radii"], conics=ref["conics"],
+                  num_tiles_hit=ref["num_tiles_hit"], colors=rgb, opacities=op[:, None], opacity=op[:, None],
+                  img_height=H, img_width=W, block_width=O.TILE, background=bg)
+    rres = _call_by_name(torch_impl.rasterize_forward, have_r)
+    ref_img = rres[0] if isinstance(rres, (tuple, list)) else rres
+    own_img, own = O.rasterize_gaussians(pr.xys, pr.depths, pr.radii, pr.conics, pr.num_tiles_hit, rgb, op, H, W,
+                                         background=bg, proj=pr)
+    vis = (pr.radii > 0) & (torch.as_tensor(ref["radii"]).reshape(-1) > 0)
+    diffs = {
+        "radii_mismatches": int((torch.as_tensor(ref["radii"]).reshape(-1).int() != pr.radii).sum()),
+        "num_tiles_hit_mismatches": int((torch.as_tensor(ref["num_tiles_hit"]).reshape(-1).int() != pr.num_tiles_hit).sum()),
+        "xys_max_abs": float((torch.as_tensor(ref["xys"]) - pr.xys)[vis].abs().max()),
+        "conics_max_rel": float(((torch.as_tensor(ref["conics"]) - pr.conics)[vis].abs().max()) / pr.conics[vis].abs().max()),
+        "image_max_abs_outside_fragile": float((torch.as_tensor(ref_img) - own_img)[~own.fragile].abs().max()),
+    }
+    d = scene_arrays(sc)
+    d.update({"ref_" + k: torch.as_tensor(v).detach().numpy() for k, v in ref.items() if k in ("xys", "depths", "radii", "conics",
+                                                                                         "compensation", "num_tiles_hit")})
+    d.update(ref_image=torch.as_tensor(ref_img).detach().numpy(), oracle_image=own_img.numpy(), fragile=own.fragile.numpy(),
+             background=bg.numpy(), colors=rgb.numpy(), opacities=op.numpy(),
+             diff_names=np.array(sorted(diffs)), diff_values=np.array([diffs[k] for k in sorted(diffs)]))
+    np.savez_compressed(out_dir / "ref_static_small.npz", **d)
+    print("reference-golden fixture written:", out_dir / "ref_static_small.npz", diffs)
+    return diffs
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1] if len(sys.argv) > 1 else None

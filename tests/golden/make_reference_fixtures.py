@@ -138,7 +138,7 @@ def main():
               "tests/golden/*.npz stay self-golden (make_golden.py)")
         return
     import make_golden                                   # type: ignore
-    make_golden.regenerate_from_reference(_torch_impl)   # to be written the day the fork is at hand
+    make_golden.regenerate_from_reference(_torch_impl)   # -> tests/golden/ref_static_small.npz (REFERENCE-golden)
 
 
 if __name__ == "__main__":

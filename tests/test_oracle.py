@@ -669,3 +669,44 @@ def test_upstream_gradient_conventions_are_straight_through_rules(oracle):
         r.img[8, 8, 0].backward()
         # C = alpha rgb + (1 - alpha) bg at the centre (sigma = 0): d C_r / d o = (rgb_r - bg_r) when the clamp lets it pass
         assert abs(float(o.grad) - expect_centre * (0.9 - 0.1)) < 1e-12
+
+
+def test_regenerate_from_reference_plumbing_with_a_stand_in_module(oracle, tmp_path):
+    """tests/golden/make_golden.regenerate_from_reference is the function tests/golden/make_reference_fixtures.py calls
+    the day a gsplat with `_torch_impl` imports (none does here: /root/reference's submodules are empty).  It cannot be
+    run against the reference today, so its PLUMBING is: a stand-in module with the recollected gsplat 0.1.11 names and
+    argument shapes (built on the oracle, so the differences it reports are zero) goes through it end to end — the
+    name-bound calls, the 9-tuple unpacking, the fixture file — and a signature with an unknown required parameter is
+    reported by name instead of guessed."""
+    import sys
+    import types
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
+    import make_golden as MG
+    O = oracle
+
+    def project_gaussians_forward(means3d, scales, glob_scale, quats, viewmat, intrins, img_size, block_width,
+                                  clip_thresh=0.01):
+        fx, fy, cx, cy = intrins
+        pr = O.project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_size[1], img_size[0],
+                                 block_width, clip_thresh)
+        return (pr.cov3d, None, pr.xys, pr.depths, pr.radii, pr.conics, pr.compensation, pr.num_tiles_hit, pr.radii > 0)
+
+    def rasterize_forward(xys, depths, radii, conics, num_tiles_hit, colors, opacities, img_height, img_width, block_width,
+                          background):
+        img, r = O.rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacities.reshape(-1), img_height,
+                                       img_width, block_width, background)
+        return img, r.final_T, r.final_idx
+
+    stand_in = types.SimpleNamespace(project_gaussians_forward=project_gaussians_forward, rasterize_forward=rasterize_forward)
+    diffs = MG.regenerate_from_reference(stand_in, out_dir=tmp_path)
+    assert diffs["radii_mismatches"] == 0 and diffs["num_tiles_hit_mismatches"] == 0
+    assert diffs["xys_max_abs"] == 0.0 and diffs["image_max_abs_outside_fragile"] < 1e-6
+    d = np.load(tmp_path / "ref_static_small.npz")
+    assert d["ref_image"].shape == (48, 64, 3) and d["ref_radii"].shape == (600,) and "diff_values" in d.files
+
+    def odd_signature(means3d, scales, quats, viewmat, something_new):
+        return None
+    with pytest.raises(RuntimeError, match="something_new"):
+        MG.regenerate_from_reference(types.SimpleNamespace(project_gaussians_forward=odd_signature,
+                                                           rasterize_forward=rasterize_forward), out_dir=tmp_path)
