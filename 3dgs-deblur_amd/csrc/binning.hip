@@ -734,9 +734,6 @@ static inline size_t radix_ws_bytes(size_t n, size_t seg_len, int bits, int max_
 // nothing else to do: a pass is one to three waves of co-resident blocks, so the wait is on the critical path, while
 // the histogram + scan it replaces cost ~20 us), the depth pre-sort from 0.242 to 0.230 ms.  Initial value from
 // GSD_SORT_SINGLE_PASS in the environment; gs_sort_set_single_pass() changes it (measurement / tests, not thread-safe).
-// A/B (GSD_COMPACT_GATHER=0): the compacting depth pre-sort gathers its second output inside the last scatter (rounds
-// 2-4) instead of carrying it as a payload from the first pass (round 5, default)
-static const int g_compact_gather_carry = [] { const char* e = getenv("GSD_COMPACT_GATHER"); return e ? atoi(e) != 0 : 1; }();
 static int g_sort_single_pass = -1;
 static inline bool sort_single_pass() {
   if (g_sort_single_pass < 0) {
@@ -1705,9 +1702,7 @@ GS_EXPORT int gs_segmented_sort_pairs_u32(long long n, long long seg_len, unsign
 GS_EXPORT long long gs_segmented_sort_compact_workspace_bytes(long long n, long long seg_len, int begin_bit,
                                                               int end_bit, int max_digit_bits) {
   if (n <= 0 || seg_len <= 0 || end_bit <= begin_bit) return 0;
-  // + one [n] buffer: the ping-pong partner of gather_out when the gathered values travel as a second payload
-  return (long long)radix_ws_bytes<unsigned>((size_t)n, (size_t)seg_len, end_bit - begin_bit, max_digit_bits) +
-         4ll * n + 256;
+  return (long long)radix_ws_bytes<unsigned>((size_t)n, (size_t)seg_len, end_bit - begin_bit, max_digit_bits);
 }
 
 GS_EXPORT int gs_segmented_sort_compact_u32(long long n, long long seg_len, unsigned* keys0, unsigned* vals0,
@@ -1718,27 +1713,9 @@ GS_EXPORT int gs_segmented_sort_compact_u32(long long n, long long seg_len, unsi
   if (n <= 0 || seg_len <= 0 || n % seg_len != 0 || begin_bit < 0 || end_bit > 32 || !seg_counts)
     return GS_ERR_INVALID;
   if ((gather_src != nullptr) != (gather_out != nullptr)) return GS_ERR_INVALID;
-  const size_t base_b = radix_ws_bytes<unsigned>((size_t)n, (size_t)seg_len, end_bit - begin_bit, max_digit_bits);
-  if (gather_src && g_compact_gather_carry) {
-    // Round 5: gather_out[r] = gather_src[sorted id of rank r] used to be a RANDOM gather inside the last pass's scatter
-    // (72.9 us against 28 us for the passes without it, profiles/r05_step_timeline.txt).  gather_src is indexed by the
-    // INPUT position, which is the order the first (compacting) pass reads its keys in: the values ride along as a
-    // second payload from there — a coalesced read in pass 1, 4 more bytes per surviving key and pass afterwards.
-    if ((size_t)ws_bytes < base_b + 4ull * (size_t)n) return GS_ERR_WORKSPACE;
-    int passes, per, tb;
-    radix_plan(end_bit - begin_bit, &passes, &per, &tb, max_digit_bits);
-    unsigned* spare = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + base_b);
-    // pass p writes the payload to p2_a (even p) / p2_b (odd p): the last pass must write gather_out
-    unsigned* p2_a = ((passes - 1) & 1) ? spare : gather_out;
-    unsigned* p2_b = ((passes - 1) & 1) ? gather_out : spare;
-    int rp2 = 0;
-    return radix_sort<unsigned>((size_t)n, (size_t)seg_len, keys0, vals0, keys1, vals1, 1, begin_bit, end_bit, ws,
-                                base_b, result_buf, (hipStream_t)stream, max_digit_bits, nullptr, nullptr, nullptr,
-                                seg_counts, (unsigned long long)skip_key, gather_src, p2_a, p2_b, &rp2);
-  }
   return radix_sort<unsigned>((size_t)n, (size_t)seg_len, keys0, vals0, keys1, vals1, 1, begin_bit, end_bit, ws,
-                              std::min((size_t)ws_bytes, base_b), result_buf, (hipStream_t)stream, max_digit_bits,
-                              gather_src, gather_out, nullptr, seg_counts, (unsigned long long)skip_key);
+                              (size_t)ws_bytes, result_buf, (hipStream_t)stream, max_digit_bits, gather_src,
+                              gather_out, nullptr, seg_counts, (unsigned long long)skip_key);
 }
 
 // Exclusive scan over n = k*seg_len values of which only the first seg_counts[s] of every segment are live: the rest

@@ -38,8 +38,7 @@ def test_workspace_queries_are_pure_host_calls(gs):
     c8 = lib.gs_segmented_sort_compact_workspace_bytes(5_000_000, 1_000_000, 0, 31, 8)
     c11 = lib.gs_segmented_sort_compact_workspace_bytes(5_000_000, 1_000_000, 0, 31, 11)
     assert 0 < c8 < c11
-    # (+ one [n] buffer: the ping-pong partner of gather_out while the gathered values travel as a second payload)
-    assert c8 == lib.gs_segmented_sort_workspace_bytes(5_000_000, 1_000_000, 0, 31) + 4 * 5_000_000 + 256
+    assert c8 == lib.gs_segmented_sort_workspace_bytes(5_000_000, 1_000_000, 0, 31)
     assert lib.gs_segmented_sort_compact_workspace_bytes(0, 1, 0, 31, 8) == 0
 
 
