@@ -80,6 +80,13 @@ class Workload:
         """untimed frames until the adaptive slice budget and the arena have converged (two consecutive frames with the
         same slice count, the budget the next frame will use, and no arena retry) -> frames run"""
         k = 0
+        if self.world > 1:
+            # a step holds a collective: every rank must run the SAME number of frames, and "settled" is a per-rank fact
+            # (each rank renders its own view) — a fixed count, longer than the budget's three doublings
+            for _ in range(max(at_least, 6)):
+                self.step()
+                k += 1
+            return k
         while k < at_least or (k < at_most and not self.hints.settled):
             self.step()
             k += 1
