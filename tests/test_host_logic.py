@@ -416,6 +416,41 @@ def test_bench_launcher_argv_and_world_check():
         bench.check_world(4, 2)
 
 
+def test_bench_warm_up_length_does_not_depend_on_the_rank(gs):
+    """bench.Workload.warm_until_settled: at N = 1 it warms until the scene's FrameHints say settled (budget and arena
+    converged: no allocation inside the timed region); at N > 1 a step holds a collective, "settled" is a per-rank fact
+    (every rank renders its own view) and a rank-dependent number of warm frames would leave the ranks in different
+    collectives — so the count is fixed there"""
+    sys.path.insert(0, str(ROOT))
+    import types
+    import bench
+    from gsdeblur_amd import ops
+
+    def workload(world, settle_after):
+        w = types.SimpleNamespace(world=world, hints=ops.FrameHints(), steps=0)
+
+        def step():
+            w.steps += 1
+            w.hints.feedback(2 if w.steps < settle_after else 1)
+        w.step = step
+        return w
+    saved = (ops.SLICE_ADAPT, ops.SLICE_BASE)
+    try:
+        ops.SLICE_ADAPT, ops.SLICE_BASE = 1, 512
+        for settle_after in (1, 3, 9):
+            a = workload(1, settle_after)
+            n = bench.Workload.warm_until_settled(a, 2)
+            assert n == a.steps and a.hints.settled and 2 <= n <= 16
+            counts = set()
+            for rank_settles_after in (1, 3, 9):                     # eight ranks, each with its own view
+                b = workload(8, rank_settles_after)
+                counts.add(bench.Workload.warm_until_settled(b, 5))
+            assert counts == {6}
+        assert bench.Workload.warm_until_settled(workload(8, 1), 20) == 20      # never fewer than the asked-for W
+    finally:
+        ops.SLICE_ADAPT, ops.SLICE_BASE = saved
+
+
 def _dp_small_worker(rank, world, port, q):
     """train_step's DP branch with a CPU stand-in for the render: Gaussian rows go through the sparse exchange,
     background / pose / velocity parameters through the small dense bucket (they used to be stepped
