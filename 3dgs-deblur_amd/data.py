@@ -182,7 +182,8 @@ def load_scene_images(scene: "TransformsScene", device="cpu", undistort: bool = 
     """every frame's image, undistorted with the scene's lens coefficients when any is non-zero (what nerfstudio's
     datamanager does before the first iteration).  An undistorted frame is CROPPED to the rectangle in which every pixel
     is valid and `scene.cameras[i]` is replaced by the camera of the cropped frame (cx, cy shifted, new width / height;
-    same focal lengths): no black border reaches the loss."""
+    same focal lengths): no black border reaches the loss.  undistort=False returns the frames as stored — cut to the
+    cropped cameras' rectangle if an earlier load of this scene object already replaced its cameras."""
     out = []
     lens = undistort and _has_distortion(scene.distortion)
     for i, (cam, path) in enumerate(zip(scene.cameras, scene.image_paths)):
@@ -196,6 +197,12 @@ def load_scene_images(scene: "TransformsScene", device="cpu", undistort: bool = 
             x0, y0, x1, y1 = cam.metadata["undistort_roi"]
             full = undistort_image(img, cam.fx, cam.fy, cam.cx + x0, cam.cy + y0, scene.distortion)
             img = full[y0:y1, x0:x1].contiguous()
+        elif cam.metadata.get("undistorted", False):
+            # undistort=False on a scene whose cameras an earlier load already replaced by those of the cropped frames
+            # (ADVICE round 4): the raw frame is cut to the same rectangle, so that image size and intrinsics agree —
+            # the pixels stay distorted, which is what the caller asked for
+            x0, y0, x1, y1 = cam.metadata["undistort_roi"]
+            img = img[y0:y1, x0:x1].contiguous()
         out.append(img)
     return out
 

@@ -449,3 +449,9 @@ def test_undistorted_frames_are_cropped_to_valid_pixels_and_the_camera_follows(g
         assert img.min() > 0.19
     again = gs.data.load_scene_images(scene)                            # idempotent: the cameras are not cropped twice
     assert torch.equal(again[0], imgs[0]) and scene.cameras[0].width == x1 - x0
+    # the raw frames of a scene whose cameras were already cropped come back in the cameras' size
+    raw = gs.data.load_scene_images(scene, undistort=False)
+    assert raw[0].shape == (y1 - y0, x1 - x0, 3) and scene.cameras[0].width == x1 - x0
+    assert torch.allclose(raw[0], grad[y0:y1, x0:x1], atol=1 / 255)   # ... untouched pixels of the stored frame
+    fresh = gs.data.load_transforms(str(root), eval_mode="all")
+    assert gs.data.load_scene_images(fresh, undistort=False)[0].shape == (H, W, 3) and fresh.cameras[0].width == W
