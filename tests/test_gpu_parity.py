@@ -115,10 +115,16 @@ def check_fragile(frag, tag):
 
 
 def grad_el_ratio(got, ref):
-    """max over elements of |got-ref| / (rtol*|ref| + afrac*max|ref|)  (<= 1 passes)"""
+    """max over elements of |got-ref| / (rtol*|ref| + afrac*max|ref|)  (<= 1 passes).
+    Camera-level tensors (view matrix, linear / angular velocity: <= 16 elements) are sums over EVERY Gaussian and sub-pose
+    whose last reduction is a few thousand fp32 atomics in an order that changes from run to run: the same test printed
+    0.43 and 0.90 of the bar on two boxes (viewmat, shared-list S=3; profiles/r05_suite_prints.log vs r04).  Their
+    absolute floor is 3e-5 of the tensor's max instead of 1e-5 so that the run-to-run spread cannot fail a suite; the
+    per-Gaussian tensors keep 1e-5."""
     got = np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
-    tol = GRAD_EL_RTOL * np.abs(ref) + GRAD_EL_AFRAC * (np.abs(ref).max() + 1e-300)
+    afrac = GRAD_EL_AFRAC * (3.0 if ref.size <= 16 else 1.0)
+    tol = GRAD_EL_RTOL * np.abs(ref) + afrac * (np.abs(ref).max() + 1e-300)
     return float((np.abs(got - ref) / tol).max())
 
 
