@@ -416,7 +416,13 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* _
 // (the batched payload loads below take the 8-bit u32 kernel from 126 to ~140 VGPRs, i.e. from four to three waves per
 //  SIMD; forcing it back to 128 with a launch bound spills 16 registers and was measured slower: tile sort 0.191 ms
 //  against 0.186 without the bound and 0.199 before the loads were batched)
-template <typename KeyT, int BITS>
+// PACK (compacting depth pre-sort, 32-bit keys): the tile count of every key rides in the free top bits of its payload
+// instead of being gathered at random (gather_src[payload], one 64-byte sector per 4-byte count) by the last pass.
+//   PACK = 1 (first pass, iota payload): payload = i | min(gather_src[i], cap) << pack_bits — a coalesced read;
+//   PACK = 2 (last pass): vals_out = payload & index mask, gather_out = the packed count, or gather_src[index] for the
+//                         few counts that reached cap = 2^(32 - pack_bits) - 1 (Gaussians covering hundreds of tiles).
+// The passes in between carry the payload as it is.  PACK = 0: nothing of this is compiled in (the tile sort's kernels).
+template <typename KeyT, int BITS, int PACK = 0>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT* __restrict__ keys_in,
                                                             const unsigned* __restrict__ vals_in,  // null => iota
                                                             KeyT* __restrict__ keys_out,
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
                                                             const unsigned* __restrict__ n_dev, SegDev sd,
                                                             const unsigned* __restrict__ p2_in,   // nullable: a second
                                                             unsigned* __restrict__ p2_out,        // payload per key
-                                                            Sweep sw) {
+                                                            Sweep sw, int pack_bits) {
   constexpr int NB = 1 << BITS;
   constexpr int R = SortCfg<KeyT>::kRounds;
   constexpr int BK = 256 * R;
@@ -568,10 +574,11 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
   unsigned pv[RB];
 #pragma unroll
   for (int r0 = 0; r0 < R; r0 += RB) {
-    if (vals_in) {
+    if (PACK == 1 || vals_in) {
+      const unsigned* __restrict__ src = PACK == 1 ? gather_src : vals_in;
       const size_t last = limit ? limit - 1 : 0;
 #pragma unroll
-      for (int q = 0; q < RB; ++q) pv[q] = vals_in[min(wbase + (size_t)(r0 + q) * 64 + lane, last)];
+      for (int q = 0; q < RB; ++q) pv[q] = src[min(wbase + (size_t)(r0 + q) * 64 + lane, last)];
     }
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
@@ -581,7 +588,8 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
         unsigned digit = (unsigned)(key[r] >> shift) & mask;
         unsigned slot = cnt[wave][digit] + pos[r];
         s_keys[slot] = key[r];
-        s_vals[slot] = vals_in ? pv[q] : (unsigned)i;
+        if (PACK == 1) s_vals[slot] = (unsigned)i | (min(pv[q], (1u << (32 - pack_bits)) - 1u) << pack_bits);
+        else s_vals[slot] = vals_in ? pv[q] : (unsigned)i;
       }
     }
   }
@@ -635,10 +643,16 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
       size_t dst = (size_t)s_gbase[digit] + (slot - s_dbase[digit]);
       keys_out[dst] = k;
       const unsigned v = s_vals[slot];
-      vals_out[dst] = v;
-      // final pass of the tile sort: also leave gather_src[payload] in sorted order (the record index of every
-      // sorted entry, fetched here among the scatter's own latencies instead of in a separate pass over the list)
-      if (gather_out) gather_out[dst] = gather_src[v];
+      if (PACK == 2) {
+        const unsigned idx = v & ((1u << pack_bits) - 1u), c = v >> pack_bits;
+        vals_out[dst] = idx;
+        gather_out[dst] = c == (1u << (32 - pack_bits)) - 1u ? gather_src[idx] : c;
+      } else {
+        vals_out[dst] = v;
+        // final pass of the tile sort: also leave gather_src[payload] in sorted order (the record index of every
+        // sorted entry, fetched here among the scatter's own latencies instead of in a separate pass over the list)
+        if (gather_out) gather_out[dst] = gather_src[v];
+      }
     }
   }
   if (p2_out) {
@@ -743,12 +757,19 @@ static inline bool sort_single_pass() {
   return g_sort_single_pass != 0;
 }
 
+// GSD_COMPACT_PACK=0: the depth pre-sort's last pass gathers the tile counts at random again (A/B)
+static inline bool compact_pack() {
+  static const int v = [] { const char* e = getenv("GSD_COMPACT_PACK"); return e ? (atoi(e) != 0) : 1; }();
+  return v != 0;
+}
+
 template <typename KeyT, int BITS>
 static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned* vin, KeyT* kout, unsigned* vout,
                        int shift, unsigned mask, void* ws, size_t hist_bytes, hipStream_t st,
                        const unsigned* gather_src = nullptr, unsigned* gather_out = nullptr,
                        const unsigned* n_dev = nullptr, SegDev sd = SegDev{nullptr, nullptr, nullptr, 0ull},
-                       const unsigned* p2_in = nullptr, unsigned* p2_out = nullptr, Sweep sw = Sweep{nullptr, nullptr}) {
+                       const unsigned* p2_in = nullptr, unsigned* p2_out = nullptr, Sweep sw = Sweep{nullptr, nullptr},
+                       int pack = 0, int pack_bits = 0) {
   SegInfo sg;
   unsigned nblk = sort_nblk_seg<KeyT>(n, seg_len, &sg.nblk_seg);
   sg.seg_len = (seg_len == 0 || seg_len >= n) ? n : seg_len;
@@ -761,8 +782,21 @@ static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned
     run_scan(hn, ghist, ghist, sd.cnt_out ? const_cast<unsigned*>(sd.total) : nullptr, scan_ws, st,
              DevLen{n_dev, (unsigned)sort_block_keys<KeyT>(), (unsigned)(1u << BITS)});
   }
+  if constexpr (BITS == 8 && sizeof(KeyT) == 4) {
+    // packed tile counts (see radix_scatter_kernel): only the 8-bit passes of the compacting 32-bit depth pre-sort
+    if (pack == 1) {
+      hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS, 1>), dim3(nblk), dim3(256), 0, st, n, kin, vin, kout, vout,
+                         shift, mask, sg, ghist, gather_src, gather_out, n_dev, sd, p2_in, p2_out, sw, pack_bits);
+      return;
+    }
+    if (pack == 2) {
+      hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS, 2>), dim3(nblk), dim3(256), 0, st, n, kin, vin, kout, vout,
+                         shift, mask, sg, ghist, gather_src, gather_out, n_dev, sd, p2_in, p2_out, sw, pack_bits);
+      return;
+    }
+  }
   hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, vin, kout, vout, shift,
-                     mask, sg, ghist, gather_src, gather_out, n_dev, sd, p2_in, p2_out, sw);
+                     mask, sg, ghist, gather_src, gather_out, n_dev, sd, p2_in, p2_out, sw, 0);
 }
 
 // Sort bits [begin_bit, end_bit).  Ping-pongs between (k0,v0) and (k1,v1); returns the index
@@ -787,6 +821,14 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
   KeyT* kk[2] = {k0, k1};
   unsigned* vv[2] = {v0, v1};
   int cur = 0, shift = begin_bit;
+  // packed tile counts: the compacting depth pre-sort with its count gather, 8-bit digits, at least two passes, and at
+  // least four payload bits to spare (cap >= 15)
+  int pack_bits = 0;
+  if (compact_pack() && sizeof(KeyT) == 4 && gather_src && gather_out && seg_counts && v0_is_iota && !p2_src &&
+      tb == 8 && passes >= 2) {
+    while (((size_t)1 << pack_bits) < n) ++pack_bits;
+    if (pack_bits > 28) pack_bits = 0;
+  }
   // single-pass form (see Sweep): look-back counts are 30-bit
   const bool sweep = sort_single_pass() && n < ((size_t)1 << 30);
   unsigned *sw_totals = nullptr, *sw_status = nullptr;
@@ -812,7 +854,8 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
     if (shift + w > end_bit) w = end_bit - shift;
     const unsigned mask = (1u << w) - 1u;
     const unsigned* vin = (p == 0 && v0_is_iota) ? nullptr : vv[cur];
-    const unsigned* gs_ = (p == passes - 1) ? gather_src : nullptr;
+    const int pack = pack_bits ? (p == 0 ? 1 : (p == passes - 1 ? 2 : 0)) : 0;
+    const unsigned* gs_ = (p == passes - 1 || pack == 1) ? gather_src : nullptr;
     unsigned* go_ = (p == passes - 1) ? gather_out : nullptr;
     SegDev sd{nullptr, nullptr, nullptr, 0ull};
     if (seg_counts) {
@@ -834,7 +877,7 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
       sw.status = sw_status + (size_t)p * nblk_all * ((size_t)1 << tb);
     }
     switch (tb) {
-      case 8:  radix_pass<KeyT, 8>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, sw); break;
+      case 8:  radix_pass<KeyT, 8>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, sw, pack, pack_bits); break;
       case 9:  radix_pass<KeyT, 9>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, sw); break;
       case 10: radix_pass<KeyT, 10>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, sw); break;
       default: radix_pass<KeyT, 11>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, sw); break;
