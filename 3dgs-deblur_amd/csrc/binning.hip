@@ -1096,22 +1096,50 @@ __global__ __launch_bounds__(256) void emit_kernel(size_t n_ranked, int N, int T
 
 // bins[t] = [start,end) of tile t in the sorted keys; one boundary test per element:
 // a key change between i-1 and i closes tile key[i-1] and opens tile key[i].
+// Self-zeroing (round 5): the bins of tiles WITHOUT a key — the gap in front of the first key, between two consecutive
+// distinct keys, behind the last key — are written (0, 0) by the wave that sees the boundary, all 64 lanes striding over
+// the gap; every bin field has exactly one writer, so the caller zeroes nothing (the hipMemsetAsync in front of this
+// kernel was two fill launches per slice).  Keys must be < num_bins, as they always had to be.
 template <typename KeyT, int SHIFT>
 __global__ __launch_bounds__(256) void bin_edges_kernel(size_t n, const KeyT* __restrict__ keys,
-                                                        int2* __restrict__ bins,
+                                                        int2* __restrict__ bins, unsigned num_bins,
                                                         const unsigned* __restrict__ n_dev = nullptr) {
   if (n_dev) n = min(n, (size_t)*n_dev);
-  // grid-stride: with the count on the device the launch is sized for the CAPACITY (4x the real count in the
-  // benchmark scene) — a capped grid that strides costs what the real count costs
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    unsigned t = (unsigned)(keys[i] >> SHIFT);
-    if (i == 0) {
-      bins[t].x = 0;
-    } else {
-      unsigned tp = (unsigned)(keys[i - 1] >> SHIFT);
-      if (tp != t) { bins[t].x = (int)i; bins[tp].y = (int)i; }
+  const int2 z = make_int2(0, 0);
+  if (n == 0) {                       // (device-side count of zero: nothing but empty bins)
+    for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < num_bins; b += (size_t)gridDim.x * 256) bins[b] = z;
+    return;
+  }
+  const int lane = lane_id();
+  // grid-stride over whole waves: with the count on the device the launch is sized for the CAPACITY (4x the real count
+  // in the benchmark scene) — a capped grid that strides costs what the real count costs
+  for (size_t base = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63u); base < n; base += (size_t)gridDim.x * 256) {
+    const size_t i = base + lane;
+    const bool valid = i < n;
+    unsigned t = 0, lo = 0, hi = 0;         // this lane's gap of key-less bins [lo, hi)
+    if (valid) {
+      t = (unsigned)(keys[i] >> SHIFT);
+      if (i == 0) {
+        bins[t].x = 0;
+        hi = t;
+      } else {
+        const unsigned tp = (unsigned)(keys[i - 1] >> SHIFT);
+        if (tp != t) { bins[t].x = (int)i; bins[tp].y = (int)i; lo = tp + 1; hi = t; }
+      }
+      if (i == n - 1) bins[t].y = (int)n;
     }
-    if (i == n - 1) bins[t].y = (int)n;
+    unsigned long long m = __ballot(hi > lo);
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const unsigned g_lo = (unsigned)readlane_i((int)lo, src), g_hi = (unsigned)readlane_i((int)hi, src);
+      for (unsigned b = g_lo + lane; b < g_hi; b += 64) bins[b] = z;
+    }
+    const unsigned long long last = __ballot(valid && i == n - 1);
+    if (last) {
+      const unsigned g_lo = (unsigned)readlane_i((int)t, __ffsll((long long)last) - 1) + 1u;
+      for (unsigned b = g_lo + lane; b < num_bins; b += 64) bins[b] = z;
+    }
   }
 }
 
@@ -1803,17 +1831,18 @@ GS_EXPORT int gs_emit_intersects(long long n_ranked, int N, int H, int W, const 
   return gs_launch_status();
 }
 
-// bins[t] = [start,end) of key t in the sorted u32 keys; bins are zeroed here first.
+// bins[t] = [start,end) of key t in the sorted u32 keys ((0, 0) for a key that does not occur; every bin is written).
 GS_EXPORT int gs_tile_bin_edges_u32(long long n, const unsigned* sorted_keys, int num_bins, int* bins,
                                     const unsigned* n_dev, void* stream) {
   if (num_bins <= 0) return GS_ERR_INVALID;
-  hipError_t e = hipMemsetAsync(bins, 0, (size_t)num_bins * 2 * sizeof(int), (hipStream_t)stream);
-  if (e != hipSuccess) return 1000 + (int)e;
-  if (n <= 0) return GS_OK;
+  if (n <= 0) {       // no key at all: every bin is empty (the kernel below zeroes the key-less bins itself)
+    hipError_t e = hipMemsetAsync(bins, 0, (size_t)num_bins * 2 * sizeof(int), (hipStream_t)stream);
+    return e == hipSuccess ? GS_OK : 1000 + (int)e;
+  }
   unsigned blocks = (unsigned)((n + 255) / 256);
   if (n_dev && blocks > 8192u) blocks = 8192u;
   hipLaunchKernelGGL((bin_edges_kernel<unsigned, 0>), dim3(blocks), dim3(256), 0,
-                     (hipStream_t)stream, (size_t)n, sorted_keys, reinterpret_cast<int2*>(bins), n_dev);
+                     (hipStream_t)stream, (size_t)n, sorted_keys, reinterpret_cast<int2*>(bins), (unsigned)num_bins, n_dev);
   return gs_launch_status();
 }
 
@@ -1835,11 +1864,12 @@ GS_EXPORT int gs_tile_bin_edges_ids_u32(long long n, const unsigned* sorted_keys
 GS_EXPORT int gs_tile_bin_edges_u64(long long n, const unsigned long long* sorted_ids, int num_bins, int* bins,
                                     void* stream) {
   if (num_bins <= 0) return GS_ERR_INVALID;
-  hipError_t e = hipMemsetAsync(bins, 0, (size_t)num_bins * 2 * sizeof(int), (hipStream_t)stream);
-  if (e != hipSuccess) return 1000 + (int)e;
-  if (n <= 0) return GS_OK;
+  if (n <= 0) {       // no key at all: every bin is empty (the kernel below zeroes the key-less bins itself)
+    hipError_t e = hipMemsetAsync(bins, 0, (size_t)num_bins * 2 * sizeof(int), (hipStream_t)stream);
+    return e == hipSuccess ? GS_OK : 1000 + (int)e;
+  }
   hipLaunchKernelGGL((bin_edges_kernel<unsigned long long, 32>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, (size_t)n, sorted_ids, reinterpret_cast<int2*>(bins));
+                     (hipStream_t)stream, (size_t)n, sorted_ids, reinterpret_cast<int2*>(bins), (unsigned)num_bins);
   return gs_launch_status();
 }
 

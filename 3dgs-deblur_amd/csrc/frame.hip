@@ -636,7 +636,7 @@ GS_EXPORT int gs_frame_backward(const gs_frame_state* state, const float* record
   if (shared && (!pix_vel || !sample_times)) return GS_ERR_INVALID;
   const long long tpe = shared ? S : 1;                               // gradient tuples per list entry
   float* tuples = A.take<float>(12 * maxI * tpe);
-  unsigned char* flags = A.take<unsigned char>(maxI * tpe);
+  unsigned char* flags = A.take<unsigned char>((maxI * tpe + 15) & ~15ll);      // (whole 16-byte words: see the fill below)
   if (!A.ok) return GS_ERR_WORKSPACE;
   if (bwd_T) {
     CHECK(hip_status(hipMemcpyAsync(bwd_T, out_T, 4ll * S * H * W, hipMemcpyDeviceToDevice, st)));
@@ -644,7 +644,8 @@ GS_EXPORT int gs_frame_backward(const gs_frame_state* state, const float* record
   }
   for (int k = state->n_slices - 1; k >= 0; --k) {
     const gs_frame_slice& sl = state->slice[k];
-    CHECK(hip_status(hipMemsetAsync(flags, 0, sl.I * tpe, st)));
+    // (a byte count that is a multiple of 16 is ONE fill launch instead of body + tail)
+    CHECK(hip_status(hipMemsetAsync(flags, 0, (sl.I * tpe + 15) & ~15ll, st)));
     {
       StageScope sc(ST_RASTER_BWD, st);
       if (state->rolling_shutter_time != 0.f || shared) {

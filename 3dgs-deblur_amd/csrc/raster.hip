@@ -545,9 +545,19 @@ __global__ __launch_bounds__(256) void combine_bwd_kernel(int S, size_t n, const
 
 // the sample-independent factor of combine_bwd alone (consumed by the compositor's backward prologue)
 __global__ __launch_bounds__(256) void combine_scale_kernel(int S, size_t n, float gamma, const float* __restrict__ out,
-                                                            const float* __restrict__ v_out, float* __restrict__ scale) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) scale[i] = combine_scale(out[i], v_out[i], 1.f / (float)S, gamma);
+                                                            const float* __restrict__ v_out, float* __restrict__ scale,
+                                                            bool vec /*all three pointers 16-byte aligned*/) {
+  // four elements per thread, 16-byte accesses (one element per thread ran at 3.5 TB/s: 21 us for a 1080p frame)
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float invS = 1.f / (float)S;
+  if (vec && i + 3 < n) {
+    const float4 o = *reinterpret_cast<const float4*>(out + i), v = *reinterpret_cast<const float4*>(v_out + i);
+    *reinterpret_cast<float4*>(scale + i) = make_float4(combine_scale(o.x, v.x, invS, gamma), combine_scale(o.y, v.y, invS, gamma),
+                                                        combine_scale(o.z, v.z, invS, gamma), combine_scale(o.w, v.w, invS, gamma));
+  } else {
+    for (size_t j = i; j < min(n, i + 4); ++j) scale[j] = combine_scale(out[j], v_out[j], invS, gamma);
+  }
 }
 
 }  // namespace gs
@@ -679,8 +689,11 @@ GS_EXPORT int gs_combine_bwd(int S, long long n, const float* samples, float gam
 GS_EXPORT int gs_combine_bwd_scale(int S, long long n, float gamma, const float* out, const float* v_out,
                                    float* scale, void* stream) {
   if (S <= 0 || n <= 0) return GS_ERR_INVALID;
-  unsigned blocks = (unsigned)((n + 255) / 256);
+  // float4 accesses when the three pointers allow it (a gradient that is a view into a larger tensor may not)
+  const bool vec = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(v_out) |
+                     reinterpret_cast<uintptr_t>(scale)) & 15u) == 0;
+  unsigned blocks = (unsigned)((n + 1023) / 1024);
   hipLaunchKernelGGL(combine_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, (size_t)n, gamma, out,
-                     v_out, scale);
+                     v_out, scale, vec);
   return gs_launch_status();
 }

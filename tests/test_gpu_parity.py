@@ -238,9 +238,12 @@ def test_segmented_sort_stable(gs, dev, sort_form, P, N):
 
 
 @pytest.mark.parametrize("digit", [8, 11])
-@pytest.mark.parametrize("P,N,keep", [(1, 5000, 0.3), (5, 4097, 0.25), (3, 100_003, 0.27), (10, 4096, 0.0),
-                                      (4, 9000, 1.0), (6, 20_000, 0.01)])
-def test_depth_rank_compacting(gs, dev, sort_form, P, N, keep, digit):
+@pytest.mark.parametrize("P,N,keep,max_tiles", [(1, 5000, 0.3, 50), (5, 4097, 0.25, 50), (3, 100_003, 0.27, 50),
+                                                (10, 4096, 0.0, 50), (4, 9000, 1.0, 50), (6, 20_000, 0.01, 50),
+                                                # 8.5 M keys = 24 index bits: the tile counts packed into the payload
+                                                # (round 5, 8-bit digits) saturate at 255 and are looked up instead
+                                                (5, 1_700_000, 0.25, 3000), (2, 300_000, 0.5, 9000)])
+def test_depth_rank_compacting(gs, dev, sort_form, P, N, keep, digit, max_tiles):
     """compacting depth pre-sort: culled keys dropped by the first pass, survivors sorted stably at the start of their
     segment, their tile counts gathered by the last pass, the segment-aware scan treats everything behind as zero;
     the result is the same ranking / prefix the full sort + gather + scan produce"""
@@ -252,7 +255,14 @@ def test_depth_rank_compacting(gs, dev, sort_form, P, N, keep, digit):
     if P > 2:
         culled[N:2 * N] = True                                  # one sub-pose sees nothing at all
     keys[culled] = 0xFFFFFFFF
-    ntiles = torch.randint(1, 50, (P * N,), generator=g, dtype=torch.int32)
+    ntiles = torch.randint(1, max_tiles, (P * N,), generator=g, dtype=torch.int32)
+    if max_tiles > 50:
+        # most Gaussians small, every value around the packed field's limit (2^(32 - index bits) - 1) present
+        ntiles[torch.rand(P * N, generator=g) < 0.9] = 3
+        cap = 2 ** (32 - max(1, (P * N - 1).bit_length())) - 1
+        ntiles[:6] = torch.tensor([cap - 1, cap, cap + 1, 1, max_tiles, cap], dtype=torch.int32)
+        culled[:6] = False
+        keys[:6] = torch.randint(0, 2 ** 31, (6,), generator=g, dtype=torch.int64)
     ntiles[culled] = 0
     records = torch.zeros(1, device=dev)
     old = ops.DEPTH_SORT_COMPACT, ops.DEPTH_SORT_DIGIT
@@ -272,6 +282,55 @@ def test_depth_rank_compacting(gs, dev, sort_form, P, N, keep, digit):
     for p in range(P):
         m = int(live[p])
         assert torch.equal(sgi[p * N:p * N + m].cpu(), sgi0[p * N:p * N + m].cpu())
+
+
+@pytest.mark.parametrize("n,num_bins,cap", [(1, 700, 0), (5000, 40_801, 0), (200_000, 40_801, 0), (3000, 40_801, 9000),
+                                            (0, 513, 64), (64, 64, 0), (70_000, 129, 100_000)])
+def test_bin_edges_write_every_bin_without_a_prior_fill(gs, dev, n, num_bins, cap):
+    """gs_tile_bin_edges_u32 (round 5: self-zeroing): [start, end) for every key that occurs, (0, 0) for every key that
+    does not — the gap in front of the first key, between keys, behind the last one — with the bins POISONED beforehand;
+    with the entry count on the host or on the device (n_dev, including a device-side count of zero)"""
+    from gsdeblur_amd import _lib
+    from gsdeblur_amd.ops import _ptr, _stream
+    L = _lib.load()
+    g = torch.Generator().manual_seed(n + num_bins)
+    keys = torch.sort(torch.randint(0, num_bins, (n,), generator=g, dtype=torch.int64)).values
+    if n > 100:
+        # long key-less stretches, the first and the last bin empty / occupied
+        keys = torch.sort(torch.where((keys > num_bins // 5) & (keys < num_bins // 2), keys[0], keys)).values
+        keys[-1] = num_bins - 1 if n % 2 else keys[-1]
+    kbuf = torch.full((max(n, cap, 1),), num_bins - 1, dtype=torch.int32, device=dev)
+    kbuf[:n] = keys.to(torch.int32).to(dev)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=dev) if cap else None
+    bins = torch.full((num_bins, 2), 0x7F7F7F7F, dtype=torch.int32, device=dev)
+    _lib.check(L.gs_tile_bin_edges_u32(max(n, cap), _ptr(kbuf), num_bins, _ptr(bins), _ptr(n_dev), _stream()), "bin edges")
+    lo = torch.searchsorted(keys, torch.arange(num_bins), right=False)
+    hi = torch.searchsorted(keys, torch.arange(num_bins), right=True)
+    want = torch.stack([lo, hi], 1)
+    want[hi == lo] = 0
+    assert torch.equal(bins.cpu().long(), want)
+
+
+def test_combine_bwd_scale_takes_unaligned_tensors(gs, dev):
+    """the averaging backward's per-pixel factor reads and writes 16 bytes per thread when its three tensors allow it;
+    views at odd offsets (a gradient that is a slice of a larger tensor) give the same values"""
+    from gsdeblur_amd import _lib
+    from gsdeblur_amd.ops import _ptr, _stream
+    L = _lib.load()
+    n = 3 * 37 * 53 + 2
+    g = torch.Generator().manual_seed(5)
+    out, v = torch.rand(n + 8, generator=g).to(dev), torch.randn(n + 8, generator=g).to(dev)
+    got = []
+    for off_o, off_v, off_s in ((0, 0, 0), (1, 0, 0), (0, 3, 0), (0, 0, 2), (1, 2, 3)):
+        o = torch.empty(n + 8, device=dev)[off_o:off_o + n].copy_(out[:n])
+        vv = torch.empty(n + 8, device=dev)[off_v:off_v + n].copy_(v[:n])
+        sc = torch.full((n + 8,), float("nan"), device=dev)[off_s:off_s + n]
+        _lib.check(L.gs_combine_bwd_scale(5, n, 2.2, _ptr(o), _ptr(vv), _ptr(sc), _stream()), "combine scale")
+        got.append(sc.cpu().clone())
+    want = (out[:n].double().clamp_min(1e-12) ** (1.0 - 2.2) / 2.2 / 5.0 * v[:n].double()).cpu()
+    assert torch.allclose(got[0].double(), want, rtol=2e-5, atol=1e-9)
+    for x in got[1:]:
+        assert torch.equal(x, got[0])
 
 
 # --------------------------------------------------------------------------- #
