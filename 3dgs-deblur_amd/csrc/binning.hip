@@ -1175,28 +1175,7 @@ __global__ __launch_bounds__(256) void bin_edges_ids_kernel(size_t n, const unsi
 // proportional to what the compositor can still use.  Results are identical to the unsliced path:
 // every pixel sees the same Gaussians in the same order.
 // ---------------------------------------------------------------------------
-// passed BY VALUE in the kernel arguments (filled from host arrays): a slice is described on the host right
-// after the plan read-back, and an upload would put a host->device copy on the critical path of every slice
-constexpr int kMaxSubposes = 256;
-struct SliceDesc {
-  int begin[kMaxSubposes];        // first depth rank (absolute index into sorted_gi) of the slice in sub-pose p
-  int prefix[kMaxSubposes + 1];   // prefix sums of the per-sub-pose slice lengths
-  int P;
-};
-
-static bool make_slice_desc(int P, const int* begin, const int* prefix, SliceDesc& sd) {
-  if (P <= 0 || P > kMaxSubposes || !begin || !prefix) return false;
-  for (int p = 0; p < P; ++p) { sd.begin[p] = begin[p]; sd.prefix[p] = prefix[p]; }
-  sd.prefix[P] = prefix[P];
-  sd.P = P;
-  return true;
-}
-
-__device__ __forceinline__ int slice_rank(const SliceDesc& sd, int j) {
-  int p = 0;
-  while (p + 1 < sd.P && j >= sd.prefix[p + 1]) ++p;
-  return sd.begin[p] + (j - sd.prefix[p]);
-}
+// (SliceDesc / make_slice_desc / slice_rank: gs_common.h — the lazy record projection of project.hip walks the same ranks)
 
 // slice boundaries: bounds[p*K + k] = first depth rank r of sub-pose p whose cumulative intersection count
 // (cum[p*N + r] - cum[p*N], modulo 2^32) reaches base << k, and rels[p*K + k] = that cumulative count at the

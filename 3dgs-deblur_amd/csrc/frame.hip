@@ -272,6 +272,9 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   // compositors run
   const bool rs = pix_vel != nullptr && (d.rolling_shutter_time != 0.f || shared);
   if (rs && d.R != 1) return GS_ERR_INVALID;
+  // lazy records: the projection wrote none; every issued slice projects its own pairs' first (SE(3) sub-poses only)
+  const gs_project_inputs* lazy = d.lazy_records;
+  if (lazy && (pix_vel || shared)) return GS_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream_;
   const int P = d.P, N = d.N, S = d.S, R = d.R, H = d.H, W = d.W;
   const long long n = (long long)P * N;
@@ -484,6 +487,8 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
       const long long ws_b = gs_scan_workspace_bytes(n_k);
       char* ws = A.take<char>(ws_b);
       if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
+      if (lazy)
+        CHECK(gs_slice_project_records((int)n_k, P, N, beg_s.data(), pre_s.data(), sorted_gi, lazy, H, W, records, st));
       if (rs)
         CHECK(gs_slice_counts((int)n_k, P, N, beg_s.data(), pre_s.data(), sorted_gi, records,
                               have_holes ? sat : nullptr, H, W, slice_gi, counts, st));

@@ -81,4 +81,28 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
   return base + i;
 }
 
+// ---- depth slices: which depth ranks of which sub-pose a slice holds --------------------------------------------
+// passed BY VALUE in the kernel arguments (filled from host arrays): a slice is described on the host right
+// after the plan read-back, and an upload would put a host->device copy on the critical path of every slice
+constexpr int kMaxSubposes = 256;
+struct SliceDesc {
+  int begin[kMaxSubposes];        // first depth rank (absolute index into sorted_gi) of the slice in sub-pose p
+  int prefix[kMaxSubposes + 1];   // prefix sums of the per-sub-pose slice lengths
+  int P;
+};
+
+static inline bool make_slice_desc(int P, const int* begin, const int* prefix, SliceDesc& sd) {
+  if (P <= 0 || P > kMaxSubposes || !begin || !prefix) return false;
+  for (int p = 0; p < P; ++p) { sd.begin[p] = begin[p]; sd.prefix[p] = prefix[p]; }
+  sd.prefix[P] = prefix[P];
+  sd.P = P;
+  return true;
+}
+
+__device__ __forceinline__ int slice_rank(const SliceDesc& sd, int j) {
+  int p = 0;
+  while (p + 1 < sd.P && j >= sd.prefix[p + 1]) ++p;
+  return sd.begin[p] + (j - sd.prefix[p]);
+}
+
 }  // namespace gs

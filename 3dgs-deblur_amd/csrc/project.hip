@@ -9,6 +9,7 @@
 // forward/backward kernels, compute_sh_forward/backward (SURVEY.md §2.3, §8 a1,
 // a3, a9; App. A) and the model-level sub-pose loop (§8 a2, a10; north_star).
 #include "gs_common.h"
+#include "../../include/gsdeblur.h"     // gs_project_inputs (the prototypes are checked against these definitions)
 
 namespace gs {
 
@@ -252,6 +253,10 @@ struct FusedParams {
   int K_stride, deg, antialiased;
   int defer_color;   // 1: leave rgb = 0, gs_slice_colors fills it for the Gaussians a depth slice actually emits
   int skip_culled;   // 1: write no record for a culled (Gaussian, sub-pose) pair (its row stays uninitialised)
+  // 1 (defer_color bit 4, round 5): write NO record at all — only depth keys, tile counts and radii.  The frame path then
+  // projects the records of the Gaussians a depth slice actually holds (gs_slice_project_records, same arithmetic):
+  // the benchmark scene writes 4 M records (256 MB of the kernel's 314 MB) and its one slice reads 55 k of them.
+  int no_records;
   // > 1: sub-pose p = s * rs_bands + r only ever composites the tile rows of rolling-shutter band r
   // ([r * tiles_y / R, (r + 1) * tiles_y / R), the formula of ops._band_edges): a pair whose tile box misses its band's
   // rows is culled HERE (culled depth key, no tile count, no record) instead of being keyed, depth-sorted, scanned and
@@ -381,7 +386,9 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
       ok = o.tmax_y > o.tmin_y;
       o.ntiles = ok ? (o.tmax_x - o.tmin_x) * (o.tmax_y - o.tmin_y) : 0;
     }
-    if (ok) {
+    if (fp.no_records) {
+      // (light mode: the record is projected again, by gs_slice_project_records, if a depth slice ever holds this pair)
+    } else if (ok) {
       // camera centre = -R^T t ; view direction = mean - centre (no gradient, like splatfacto's detach)
       float cxw = -(Vm[0] * Vm[3] + Vm[4] * Vm[7] + Vm[8] * Vm[11]);
       float cyw = -(Vm[1] * Vm[3] + Vm[5] * Vm[7] + Vm[9] * Vm[11]);
@@ -413,8 +420,8 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
                          __int_as_float(o.tmax_x | (o.tmax_y << 16)));
       r[3] = make_float4(aux[0], aux[1], aux[2], aux[3]);
     } else if (!fp.skip_culled) {
-      // (three of four pairs in the benchmark scene: 48 bytes each that nothing reads once the depth pre-sort
-      //  drops culled Gaussians — the caller says so with defer_color bit 1)
+      // (a fifth of the benchmark scene's pairs, nine in ten of a band-aware rolling-shutter frame's: 64 bytes each that
+      //  nothing reads once the depth pre-sort drops culled Gaussians — the caller says so with defer_color bit 1)
       float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       r[0] = z; r[1] = z; r[2] = z; r[3] = z;
     }
@@ -854,6 +861,58 @@ __global__ __launch_bounds__(256, 2) void project_fused_bwd_sparse_kernel(FusedP
   }
 }
 
+// Lazy records (round 5): the records of the n_slice (sub-pose, Gaussian) pairs a depth slice holds — pair j is depth
+// rank slice_rank(sd, j) of sorted_gi, the walk gs_slice_counts_exact makes right afterwards — projected by the SAME
+// expressions as project_fused_fwd_kernel<., DEFER = true> (quat_to_rotmat, scale_rot_to_cov3d, project_one, the band
+// clip, rec_aux), so a record written here is bit-identical to the one the eager kernel would have written.  Pairs with
+// a rank are visible by construction (their depth key was not the culled marker); should one fail here all the same, its
+// record is zero-filled (the count kernels then see an empty box).  Parameter reads are random gathers (44 bytes per
+// pair out of three arrays): fine for the tens of thousands of pairs of an early-terminating frame's slice, not for
+// millions — the caller only goes lazy for scenes whose frames stop within their first slice (ops.FrameHints).
+__global__ __launch_bounds__(256) void slice_records_kernel(int n_slice, SliceDesc sd, const unsigned* __restrict__ sorted_gi,
+                                                            FusedParams fp, float* __restrict__ records) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_slice) return;
+  const unsigned gi = sorted_gi[slice_rank(sd, j)];
+  const int p = (int)(gi / (unsigned)fp.N), i = (int)(gi - (unsigned)p * (unsigned)fp.N);
+  float m[3] = {fp.means[3 * i], fp.means[3 * i + 1], fp.means[3 * i + 2]};
+  float sc[3];
+  load_scales(fp, i, sc);
+  float q[4] = {fp.quats[4 * i], fp.quats[4 * i + 1], fp.quats[4 * i + 2], fp.quats[4 * i + 3]};
+  const float opac = load_opacity(fp, i);
+  float R[9], qn[4], inv, M[9], c3[6];
+  quat_to_rotmat(q, R, qn, &inv);
+  scale_rot_to_cov3d(sc, fp.glob, R, M, c3);
+  const float* V = fp.viewmats + 16 * p;
+  float Vm[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Vm[k] = V[k];
+  Proj o; ProjCtx k;
+  bool ok = project_one(m, c3, Vm, fp.in.fx, fp.in.fy, fp.in.cx, fp.in.cy, fp.in.W, fp.in.H, fp.in.tiles_x,
+                        fp.in.tiles_y, fp.in.clip, o, k);
+  if (ok && fp.rs_bands > 1) {
+    const int rb = p % fp.rs_bands;
+    const int by0 = (rb * fp.in.tiles_y) / fp.rs_bands, by1 = ((rb + 1) * fp.in.tiles_y) / fp.rs_bands;
+    o.tmin_y = max(o.tmin_y, by0);
+    o.tmax_y = min(o.tmax_y, by1);
+    ok = o.tmax_y > o.tmin_y;
+  }
+  float4* r = reinterpret_cast<float4*>(records + (size_t)gi * kRecFloats);
+  if (ok) {
+    const float op = fp.antialiased ? opac * o.comp : opac;
+    float aux[4];
+    rec_aux(op, o.conic_x, o.conic_z, aux);
+    r[0] = make_float4(o.x, o.y, o.conic_x, o.conic_y);
+    r[1] = make_float4(o.conic_z, op, 0.f, 0.f);
+    r[2] = make_float4(0.f, o.depth, __int_as_float(o.tmin_x | (o.tmin_y << 16)),
+                       __int_as_float(o.tmax_x | (o.tmax_y << 16)));
+    r[3] = make_float4(aux[0], aux[1], aux[2], aux[3]);
+  } else {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    r[0] = z; r[1] = z; r[2] = z; r[3] = z;
+  }
+}
+
 // Deferred SH colour: with early termination only a few percent of the Gaussians are ever composited, so
 // the fused projection can skip the 192-byte SH read and the per-sub-pose evaluation for everyone and this
 // kernel colours just the Gaussians a depth slice emits (counts[j] > 0).  Same arithmetic as the fused
@@ -1025,6 +1084,7 @@ static inline FusedParams make_fused(int N, int P, const float* means, const flo
   fp.viewmats = viewmats; fp.glob = glob; fp.K_stride = K_stride; fp.deg = deg; fp.antialiased = antialiased;
   fp.defer_color = defer_color & 1;
   fp.skip_culled = (defer_color >> 1) & 1;
+  fp.no_records = (defer_color >> 4) & 1;
   fp.rs_bands = (defer_color & 4) ? ((defer_color >> 8) & 0xFFFF) : 0;
   fp.in = make_intrin(fx, fy, cx, cy, H, W, clip);
   fp.pixvel = 0; fp.twist = nullptr; fp.times = nullptr; fp.flags = 0; fp.rs_half = 0.f; fp.pix_vel_out = nullptr;
@@ -1055,6 +1115,25 @@ GS_EXPORT int gs_project_fused_fwd(int N, int P, const float* means, const float
   else
     hipLaunchKernelGGL((project_fused_fwd_kernel<25, false>), grid, block, 0, (hipStream_t)stream, fp, records,
                        depth_keys, num_tiles_hit, radii);
+  return gs_launch_status();
+}
+
+// Records of the pairs of one depth slice, for a frame projected with defer_color bit 4 (no records): see
+// slice_records_kernel.  slice_begin / slice_prefix / sorted_gi as gs_slice_counts_exact takes them; `in` holds the
+// arguments the frame's gs_project_fused_fwd call was made with (colour deferred: rgb = 0, gs_slice_colors follows).
+GS_EXPORT int gs_slice_project_records(int n_slice, int P, int N, const int* slice_begin, const int* slice_prefix,
+                                       const unsigned* sorted_gi, const gs_project_inputs* in, int H, int W,
+                                       float* records, void* stream) {
+  SliceDesc sd;
+  if (n_slice <= 0 || N <= 0 || !in || !sorted_gi || !records || !make_slice_desc(P, slice_begin, slice_prefix, sd))
+    return GS_ERR_INVALID;
+  if (!in->means || !in->scales || !in->quats || !in->opacities || !in->viewmats) return GS_ERR_INVALID;
+  FusedParams fp = make_fused(N, P, in->means, in->scales, in->glob_scale, in->quats, in->opacities, nullptr, 1, 0,
+                              in->viewmats, in->fx, in->fy, in->cx, in->cy, H, W, in->clip_thresh, in->antialiased,
+                              in->defer_color | 1);
+  fp.act = in->param_flags;
+  hipLaunchKernelGGL(slice_records_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice, sd,
+                     sorted_gi, fp, records);
   return gs_launch_status();
 }
 

@@ -143,6 +143,13 @@ UPSTREAM_GRADS = int(os.environ.get("GSD_UPSTREAM_GRADS", "7"))
 
 # 1 (default): rolling-shutter bands — the projection culls (band, Gaussian) pairs outside their band's tile rows (A/B: 0)
 BAND_AWARE = int(os.environ.get("GSD_BAND_AWARE", "1"))
+# Lazy records (round 5).  The fused projection writes a 64-byte record for every visible (sub-pose, Gaussian) pair — 4 M
+# of them, 256 MB of the kernel's 314 MB of traffic, on the benchmark scene — and a frame that stops within its first
+# depth slice reads 55 k of them.  1 (default): a scene whose frames have not needed a larger first-slice budget
+# (FrameHints.mult == 1: its tiles saturate early) projects keys, tile counts and radii only, and every issued slice
+# projects the records of its own pairs (gs_slice_project_records: same arithmetic, bit-identical rows); a scene whose
+# budget has grown (most of its Gaussians are composited) keeps the eager projection.  0: always eager; 2: always lazy.
+LAZY_RECORDS = int(os.environ.get("GSD_LAZY_RECORDS", "1"))
 # 1 (default): Gaussians whose scales differ by more than 8x get the covariance part of their projection backward
 # (v_conic -> cov2d -> cov3d -> scale / quaternion / mean) recomputed in double (project_needle_hp_kernel): in fp32 that
 # chain is percent-level wrong along a needle's long axis.  0: fp32 everywhere (A/B, tests).
@@ -435,7 +442,15 @@ class _FrameDesc(ctypes.Structure):
                                                                                      ("shared_list", ctypes.c_int),
                                                                                      ("combine_gamma", ctypes.c_float),
                                                                                      ("combine_min_level", ctypes.c_float),
-                                                                                     ("band_clipped", ctypes.c_int)]
+                                                                                     ("band_clipped", ctypes.c_int),
+                                                                                     ("lazy_records", ctypes.c_void_p)]
+
+
+class _ProjectInputs(ctypes.Structure):
+    """gs_project_inputs (include/gsdeblur.h): what gs_project_fused_fwd was called with, for the lazy records"""
+    _fields_ = ([(k, ctypes.c_void_p) for k in ("means", "scales", "quats", "opacities", "viewmats")] +
+                [(k, ctypes.c_float) for k in ("glob_scale", "fx", "fy", "cx", "cy", "clip_thresh")] +
+                [(k, ctypes.c_int) for k in ("antialiased", "defer_color", "param_flags")])
 
 
 class _FrameSlice(ctypes.Structure):
@@ -530,7 +545,7 @@ def _profile_mask() -> int:
 def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
                          H: int, W: int, bg: Tensor, edges: Tensor, slice_base: int, color=None,
                          out_depth: Optional[Tensor] = None, reserve_backward: bool = True, rs=None, combine=None,
-                         hints: Optional[FrameHints] = None, band_clipped: bool = False):
+                         hints: Optional[FrameHints] = None, band_clipped: bool = False, lazy=None):
     """combine = (gamma, min_level, out [H,W,3]): the library launches the gamma-space average of the sample images itself,
     behind every slice's compositor (it overlaps the open-tile read-back).  rs = (pix_vel [N,2], rolling_shutter_time[, sample_times [S]]) or None; with sample_times the frame runs in the
     shared-list mode (P == 1: one record set and one tile list for the S samples).  gs_frame_forward: -> (out_img [S,H,W,3], out_T [S,H,W], frame) ; frame = dict(arena, state) for
@@ -563,7 +578,7 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     desc = _FrameDesc(N, P, S, R, H, W, int(slice_base), DEPTH_SORT_DIGIT, 0, int(reserve_backward),
                       float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0, frame_poll(), int(shared),
                       float(combine[0]) if combine is not None else 1.0, float(combine[1]) if combine is not None else 0.0,
-                      int(bool(band_clipped)))
+                      int(bool(band_clipped)), ctypes.addressof(lazy) if lazy is not None else None)
     state = _FrameState()
     out_img = torch.empty(S, H, W, 3, device=dev)
     out_T = torch.empty(S, H, W, device=dev)
@@ -1018,6 +1033,16 @@ class _RenderSubposes(Function):
         # before the depth pre-sort instead of being keyed, sorted, scanned and planned for nothing)
         if backend is None and R > 1 and BAND_AWARE:
             defer_flags |= 4 | (R << 8)
+        if backend is None and hints is None:
+            # default owner of the frame-to-frame hints: the scene's shape AND its parameter storage, so that two
+            # scenes of one shape do not share a budget / arena estimate
+            hints = hints_for((str(dev), N, P, S, H, W, shared is not None, means3d.untyped_storage().data_ptr()))
+        # lazy records (see LAZY_RECORDS): SE(3) sub-poses through the library's frame path, planned slices, and a scene
+        # whose frames have so far stopped within the default budget
+        lazy = None
+        if (backend is None and not pixvel and LAZY_RECORDS and hints.slice_base() > 0
+                and (LAZY_RECORDS == 2 or hints.mult == 1)):
+            defer_flags |= 16
         if shared is not None and backend is not None:
             raise ValueError("the shared-list mode runs through the library's frame path only")
         pix_vel = torch.empty(N, 2, device=dev) if (rs_time != 0.0 or shared is not None) else None
@@ -1042,6 +1067,10 @@ class _RenderSubposes(Function):
 
         with _stage("project_fwd"):
             _project()
+        if defer_flags & 16:
+            lazy = _ProjectInputs(means3d.data_ptr(), scales.data_ptr(), quats.data_ptr(), opacities.data_ptr(),
+                                  V.data_ptr(), args[2], args[5], args[6], args[7], args[8], args[11], args[12],
+                                  defer_flags & ~16, param_flags)
         bg = _background(background, dev)
         edges = _band_edges(H, R, dev)
         # deferred colour: the view direction of every sub-pose (pixel-velocity model: the mid-exposure pose for all)
@@ -1069,17 +1098,13 @@ class _RenderSubposes(Function):
             averaged = None
             if gamma is not None:
                 averaged = (float(gamma), float(min_rgb_level) / 255.0, torch.empty(H, W, 3, device=dev))
-            if hints is None:
-                # default owner of the frame-to-frame hints: the scene's shape AND its parameter storage, so that two
-                # scenes of one shape do not share a budget / arena estimate
-                hints = hints_for((str(dev), N, P, S, H, W, shared is not None, means3d.untyped_storage().data_ptr()))
             retries = 0
             for attempt in range(_ARENA_ATTEMPTS):
                 try:
                     out_img, out_T, ctx.frame = native_frame_forward(records, dkeys, ntiles, P, N, S, R, H, W, bg, edges,
                                                                      hints.slice_base(), color, depth_acc,
                                                                      any(ctx.needs_input_grad), rs, averaged, hints,
-                                                                     bool(defer_flags & 4))
+                                                                     bool(defer_flags & 4), lazy)
                     hints.feedback(int(ctx.frame["state"].n_slices), retries)
                     break
                 except _ArenaTooSmall:

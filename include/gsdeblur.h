@@ -93,7 +93,10 @@ int gs_project_fused_fwd(int N, int P, const float* means3d, const float* scales
                                            sub-pose p = s*R + r only composites tile rows [r*ty/R, (r+1)*ty/R): a pair
                                            whose tile box misses those rows is culled here (culled depth key, tile count
                                            0, no record), a box that straddles them is clipped to them.  `radii` keeps
-                                           the un-banded value (the oracle's definition)*/,
+                                           the un-banded value (the oracle's definition).
+                                           bit 4 (round 5): write NO record at all (depth keys, tile counts and radii
+                                           only): gs_frame_forward(desc->lazy_records) projects the records of the pairs
+                                           its depth slices hold (gs_slice_project_records)*/,
                          float* records /*P*N*16*/, unsigned* depth_keys /*P*N*/,
                          int* num_tiles_hit /*P*N*/, int* radii /*P*N or NULL*/,
                          const float* sh_rest /*NULL, or features_rest [N*(K_stride-1)*3]: `sh` is then features_dc [N*3]
@@ -459,6 +462,20 @@ int gs_dp_pack_masked_rows(int N, const unsigned char* mask, const int* pos, int
 int gs_dp_scatter_add_payload(int cap, const float* payload, int n_tensors, float* const* grads, const int* widths,
                               float scale, void* stream);
 
+/* ---- lazy records (round 5) ---------------------------------------------------------------------------------------
+ * A frame projected with gs_project_fused_fwd(defer_color bit 4) has depth keys, tile counts and radii but NO records;
+ * the records of the (sub-pose, Gaussian) pairs a depth slice holds are projected when the slice is issued, by the same
+ * arithmetic (bit-identical rows).  `gs_project_inputs` = the arguments of that gs_project_fused_fwd call. */
+typedef struct gs_project_inputs {
+  const float *means, *scales, *quats, *opacities, *viewmats;   /* as gs_project_fused_fwd (viewmats [P*16]) */
+  float glob_scale, fx, fy, cx, cy, clip_thresh;
+  int antialiased, defer_color, param_flags;
+} gs_project_inputs;
+/* slice_begin / slice_prefix / sorted_gi: as gs_slice_counts_exact; records [P*N*16] */
+int gs_slice_project_records(int n_slice, int P, int N, const int* slice_begin, const int* slice_prefix,
+                             const unsigned* sorted_gi, const gs_project_inputs* in, int img_height, int img_width,
+                             float* records, void* stream);
+
 /* ---- one frame's depth-sliced pipeline issued by the library itself (csrc/frame.hip) -------------------------------
  * What the fork's Python layer does between project_gaussians and the returned image — binning, sorting and compositing
  * (boundary §8b: "caller owns all tensors; the library allocates nothing; workspace passed in") — as
@@ -491,6 +508,9 @@ typedef struct gs_frame_desc {
                                 tile counts only hold the pairs inside its rolling-shutter band, so a sub-pose owns T/R
                                 open tiles and the slice plan's budget per sub-pose is T/R * slice_base (0: T * slice_base,
                                 of which one pair in R lies inside the band) */
+  const struct gs_project_inputs* lazy_records;   /* NULL, or (the projection ran with defer_color bit 4: `records` holds
+                                nothing yet) what it was called with: every issued slice first projects the records of
+                                its own pairs (gs_slice_project_records).  SE(3) sub-poses only (pix_vel == NULL) */
 } gs_frame_desc;
 typedef struct gs_frame_slice {
   long long I;               /* capacity of the slice's lists (its ranks' bounding-box pairs); real count on the device */

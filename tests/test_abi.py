@@ -191,7 +191,7 @@ def test_definitions_match_the_header_prototypes():
             assert got == protos[name], (name, f.name, len(got), len(protos[name]),
                                          [(i, a, b) for i, (a, b) in enumerate(zip(got, protos[name])) if a != b])
             n += 1
-    assert n == len(protos) == 63, (n, len(protos))
+    assert n == len(protos) == 64, (n, len(protos))
 
 
 def test_every_call_site_passes_as_many_arguments_as_the_signature_has():

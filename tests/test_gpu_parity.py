@@ -3102,6 +3102,57 @@ def test_fork_style_keywords_on_the_compat_ops(gs, oracle, dev, S, rt):
         gs.project_gaussians(*args, lin_vel=sc["lin_vel"].to(dev))
 
 
+@pytest.mark.parametrize("S,R,base", [(3, 1, 512), (3, 1, 24), (2, 5, 48), (1, 1, 0)])
+def test_lazy_records_give_the_same_frame(gs, dev, S, R, base):
+    """round 5: a frame projected WITHOUT records (gs_project_fused_fwd defer_color bit 4; GSD_LAZY_RECORDS) whose depth
+    slices project the records of their own pairs (gs_slice_project_records) against the eager projection: image, alphas,
+    radii and every Gaussian gradient bit for bit (the same slices hold the same rows), pose gradients to summation
+    order.  The lazy frame runs first, on record memory poisoned with NaNs: a row nobody projected would show.
+    One slice, many slices, rolling-shutter bands (band-aware), and SLICE_BASE = 0 (no plan: the frame stays eager)."""
+    from gsdeblur_amd import ops
+    n, W, H = 60000, 208, 176
+    sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=23, scale_mult=3.0), dev)
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, R, 1 / 30 if R > 1 else 0.0)
+    times_t = torch.tensor(times, device=dev)
+    g = torch.Generator().manual_seed(8)
+    wt, wa = torch.rand(H, W, 3, generator=g).to(dev), torch.rand(S, H, W, generator=g).to(dev)
+    saved = (ops.LAZY_RECORDS, ops.SLICE_BASE, ops.SLICE_ADAPT)
+    res = []
+    try:
+        ops.SLICE_BASE, ops.SLICE_ADAPT = base, 0
+        for lazy in (2, 0):
+            ops.LAZY_RECORDS = lazy
+            ops.release_arenas()
+            junk = torch.full((S * R * n * ops.REC,), float("nan"), device=dev)
+            del junk
+            p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+            lin = (sc["lin_vel"] * 5).clone().requires_grad_(True)
+            ang = (sc["ang_vel"] * 3).clone().requires_grad_(True)
+            V = sc["viewmat"].clone().requires_grad_(True)
+            vms = gs.subpose_viewmats(V, lin, ang, times_t)
+            rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"], p["quats"], p["opacity_logits"], p["sh"],
+                                                    vms, None, S, R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W,
+                                                    gamma=2.2, min_rgb_level=10.0, raw_params=True,
+                                                    hints=ops.FrameHints())
+            ((rgb * wt).sum() + (alphas * wa).sum()).backward()
+            grads = {k: v.grad.clone() for k, v in p.items()}
+            pose = dict(lin=lin.grad.clone(), ang=ang.grad.clone(), V=V.grad.clone())
+            res.append((rgb.detach().clone(), alphas.detach().clone(), radii.clone(), grads, pose,
+                        [int(v) for v in ops.last_slice_intersects if int(v) > 0]))
+    finally:
+        ops.LAZY_RECORDS, ops.SLICE_BASE, ops.SLICE_ADAPT = saved
+    a, b = res
+    print(f"lazy records S={S} R={R} base={base}: slices {a[5]}")
+    assert a[5] == b[5] and (len(a[5]) >= 2 or base != 24)
+    assert torch.isfinite(a[0]).all() and float(a[0].max()) > 0.05
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert float(a[3][k].abs().max()) > 0, k
+        assert torch.equal(a[3][k], b[3][k]), (k, float((a[3][k] - b[3][k]).abs().max()))
+    for k in a[4]:
+        assert rel_max(a[4][k].cpu(), b[4][k].cpu()) < GRAD_RTOL, k
+
+
 @pytest.mark.parametrize("model", ["se3", "pixel_velocity"])
 def test_band_aware_projection_gives_the_same_frame(gs, dev, model):
     """round 5: with rolling-shutter bands the projection culls a (band, Gaussian) pair whose tile

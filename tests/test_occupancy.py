@@ -22,7 +22,9 @@ BUDGET = {
     ("project.hip", "project_fused_fwd_kernel<16, true>"): (96, False),       # 5 waves
     ("project.hip", "project_fused_bwd_sparse_kernel<16, true>"): (256, True),   # 2 waves: the zero fill needs them
     ("project.hip", "project_needle_hp_kernel"): (168, False),                # 3 waves
-    ("binning.hip", "radix_scatter_kernel<unsigned int, 8>"): (168, False),   # 3 waves
+    ("binning.hip", "radix_scatter_kernel<unsigned int, 8, 0>"): (168, False),   # 3 waves (the tile sort's passes)
+    ("binning.hip", "radix_scatter_kernel<unsigned int, 8, 1>"): (168, False),   # depth pre-sort: counts packed ...
+    ("binning.hip", "radix_scatter_kernel<unsigned int, 8, 2>"): (168, False),   # ... and unpacked
     ("binning.hip", "slice_counts_exact_kernel<true>"): (80, False),          # 6 waves
 }
 
