@@ -72,6 +72,65 @@ def kernel_source_hash() -> str:
     return h.hexdigest()
 
 
+# ---- per-kernel ISA hashes ------------------------------------------------------------------------------------------
+# profiles/traffic.json holds PMC counters of single kernels.  kernel_source_hash() invalidates ALL of them whenever any
+# kernel source changes; a counter of kernel K only depends on K's machine code (and on K's inputs), so the file also
+# records the hash of K's gfx950 ISA, and bench.py accepts the counters of a kernel whose ISA is still the measured one.
+ISA_KERNELS = {"raster.hip": ("raster_fwd_sload_kernel",), "raster_bwd.hip": ("raster_bwd_sload_kernel",)}
+ISA_HASH_PATH = PKG_DIR / "libgsdeblur_hip.so.isahash"
+
+
+def kernel_isa_hashes(csrc: Path = CSRC) -> dict:
+    """{kernel name fragment: sha256 over the ISA text of every instantiation of that kernel} for ISA_KERNELS, compiled
+    from `csrc` with the library's flags (-S, device side only); comments dropped, basic-block labels renumbered"""
+    import hashlib
+    import re
+    import tempfile
+    flags = dict(SOURCES)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for src, frags in ISA_KERNELS.items():
+            f = Path(d) / (src + ".s")
+            subprocess.check_call([_hipcc(), *COMMON, *flags[src], "-S", "--cuda-device-only", str(csrc / src), "-o", str(f)],
+                                  stderr=subprocess.DEVNULL)
+            lines = f.read_text().split("\n")
+            bodies = {}
+            name = None
+            for ln in lines:
+                m = re.match(r"^(_Z\w+):", ln)
+                if m:
+                    name, bodies[m.group(1)] = m.group(1), []
+                    continue
+                if name is None:
+                    continue
+                if re.match(r"^\.Lfunc_end\d+:", ln):
+                    name = None
+                    continue
+                t = ln.split(";")[0].strip()
+                if t:
+                    bodies[name].append(re.sub(r"\.LBB\d+_", ".LBB_", t))
+            for frag in frags:
+                h = hashlib.sha256()
+                hits = sorted(k for k in bodies if frag in k)
+                if not hits:
+                    raise RuntimeError(f"{frag}: no kernel of that name in {src}")
+                for k in hits:
+                    h.update(k.encode())
+                    h.update("\n".join(bodies[k]).encode())
+                out[frag] = h.hexdigest()
+    return out
+
+
+def stored_isa_hashes() -> dict:
+    """the ISA hashes written next to the in-tree library by build_library() ({} when absent or stale)"""
+    import json
+    try:
+        d = json.loads(ISA_HASH_PATH.read_text())
+        return d["kernels"] if d.get("source_hash") == source_hash() else {}
+    except Exception:
+        return {}
+
+
 def is_current() -> bool:
     """True when the in-tree library exists and was built from exactly the sources that are on disk now (content,
     not mtime: a repository snapshot copied to another box keeps the bytes but not necessarily the timestamps)"""
@@ -102,6 +161,11 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     HASH_PATH.write_text(source_hash() + "\n")
+    try:
+        import json
+        ISA_HASH_PATH.write_text(json.dumps({"source_hash": source_hash(), "kernels": kernel_isa_hashes()}) + "\n")
+    except Exception:                       # the counters of profiles/traffic.json then fall back to kernel_source_hash
+        ISA_HASH_PATH.unlink(missing_ok=True)
     return LIB_PATH
 
 

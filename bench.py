@@ -32,11 +32,16 @@ DOMINANT_STAGE = "raster_bwd"   # the kernel the roofline is quoted on (checked 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
-def _counters_current(tj, build) -> bool:
+def _counters_current(tj, build, kname=None) -> bool:
     """profiles/traffic.json was measured on the kernel sources that are on disk now (csrc + flags; a file from before
-    round 4's kernel_source_hash is gated on the hash of the whole library source, public header included)"""
+    round 4's kernel_source_hash is gated on the hash of the whole library source, public header included) — or, for the
+    counters of ONE kernel, on that kernel's machine code: the file's kernel_isa_hash[kname] equals the hash of the ISA
+    the in-tree library was built with (_build.stored_isa_hashes; a change elsewhere in csrc/ leaves it valid)"""
     if "kernel_source_hash" in tj:
-        return tj["kernel_source_hash"] == build.kernel_source_hash()
+        if tj["kernel_source_hash"] == build.kernel_source_hash():
+            return True
+        want = (tj.get("kernel_isa_hash") or {}).get(kname) if kname else None
+        return bool(want) and build.stored_isa_hashes().get(kname) == want
     return tj.get("lib_source_hash") == build.source_hash()
 
 
@@ -541,7 +546,7 @@ def main():
             try:
                 tj = json.loads(tfile.read_text())
                 from gsdeblur_amd import _build as _gsd_build
-                if tj.get("workload") == [N, W, H, S, R] and _counters_current(tj, _gsd_build):
+                if tj.get("workload") == [N, W, H, S, R] and _counters_current(tj, _gsd_build, kname):
                     traffic = tj["hbm_bytes_per_step"].get(kname)
             except Exception:
                 traffic = None
@@ -553,7 +558,7 @@ def main():
             tj = json.loads(tfile.read_text()) if tfile.exists() else {}
             vi = tj.get("valu", {}).get(kname)
             from gsdeblur_amd import _build as _gsd_build
-            fresh = _counters_current(tj, _gsd_build)
+            fresh = _counters_current(tj, _gsd_build, kname)
             if vi and tj.get("workload") == [N, W, H, S, R] and not fresh:
                 valu = {"stale": "profiles/traffic.json was measured on other kernel sources (kernel_source_hash differs): "
                                  "re-run tools/gpu_visit.sh <tag> pmc"}
@@ -573,7 +578,15 @@ def main():
                         "source": tj["valu"].get("source")}
         except Exception:
             valu = None
-        roofline = {"bound": "hbm", "kernel": kname, "valu": valu,
+        counters_by = None
+        try:
+            if traffic is not None or (valu and "stale" not in valu):
+                counters_by = ("kernel_source_hash (every kernel source as measured)" if tj.get("kernel_source_hash") ==
+                               _gsd_build.kernel_source_hash() else
+                               "kernel_isa_hash (this kernel's machine code as measured; other kernel sources changed since)")
+        except Exception:
+            counters_by = None
+        roofline = {"bound": "hbm", "kernel": kname, "valu": valu, "counters_valid_by": counters_by,
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_basis": "intersections emitted into the tile lists (after depth slicing + exact "

@@ -542,3 +542,35 @@ def test_bench_main_leg_does_not_touch_the_oracle():
     main = src[src.index("def main():"):]
     assert "gs_oracle" not in main and "_import_oracle" not in main
     assert src.count("= _import_oracle()") == 1          # the cpu_baseline leg only
+
+
+@pytest.mark.timeout(900)
+def test_pmc_counters_are_gated_per_kernel_by_isa_hash(gs):
+    """profiles/traffic.json (PMC passes of a GPU visit) feeds bench.py's roofline.traffic / roofline.valu.  The counters of
+    kernel K stay valid while K's machine code is the measured one: bench._counters_current accepts them on the hash of
+    every kernel source (kernel_source_hash) OR, per kernel, on the hash of K's gfx950 ISA (kernel_isa_hash, compiled here
+    by hipcc without a GPU) — and rejects them when neither matches.  Also holds the committed file against the committed
+    tree: the dominant kernel's counters must be quotable by the bench line the driver prints."""
+    import importlib.util
+    import json
+    import shutil
+    from gsdeblur_amd import _build
+    if shutil.which(_build._hipcc()) is None:
+        pytest.skip("no hipcc on this host")
+    spec = importlib.util.spec_from_file_location("_bench_mod", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    stored = _build.stored_isa_hashes()
+    assert set(stored) == {"raster_fwd_sload_kernel", "raster_bwd_sload_kernel"}, "build() writes the ISA hashes next to the library"
+    assert stored == _build.kernel_isa_hashes()                       # deterministic, and the sidecar is the tree's
+    k = "raster_bwd_sload_kernel"
+    same_src = {"kernel_source_hash": _build.kernel_source_hash()}
+    assert bench._counters_current(same_src, _build) and bench._counters_current(same_src, _build, k)
+    other_src = {"kernel_source_hash": "0" * 64, "kernel_isa_hash": dict(stored)}
+    assert bench._counters_current(other_src, _build, k) and not bench._counters_current(other_src, _build)
+    assert not bench._counters_current(other_src, _build, "project_fused_fwd_kernel")     # no ISA hash recorded for it
+    other_isa = {"kernel_source_hash": "0" * 64, "kernel_isa_hash": {k: "1" * 64}}
+    assert not bench._counters_current(other_isa, _build, k)
+    tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+    assert bench._counters_current(tj, _build, k), \
+        "profiles/traffic.json no longer describes the dominant kernel of this tree: re-run the PMC passes (tools/gpu_visit.sh <tag> pmc)"
