@@ -47,19 +47,22 @@ class FrameHints:
     render_combined / render_step); callers that pass none share one per (device, frame shape, parameter storage) —
     so two scenes of one shape never fight over one hint.  Thread-safe."""
 
-    __slots__ = ("mult", "age", "arena_bytes", "arena_retries", "frames", "_recent", "_lock")
+    __slots__ = ("mult", "age", "arena_bytes", "arena_retries", "frames", "box_share", "_recent", "_lock")
 
     def __init__(self):
         self.mult, self.age, self.arena_bytes, self.arena_retries, self.frames = 1, 0, 0, 0, 0
+        self.box_share = None           # share of the last frame's bounding-box pairs its issued slices held (None: no frame yet)
         self._recent = []               # (issued slices, budget multiplier, arena retries) of the last frames
         self._lock = threading.Lock()
 
     def slice_base(self) -> int:
         return SLICE_BASE * (self.mult if SLICE_ADAPT and SLICE_BASE > 0 else 1)
 
-    def feedback(self, n_issued: int, retries: int = 0) -> None:
+    def feedback(self, n_issued: int, retries: int = 0, box_share: Optional[float] = None) -> None:
         with self._lock:
             self.frames += 1
+            if box_share is not None:
+                self.box_share = float(box_share)
             self.arena_retries += retries
             self._recent = (self._recent + [(int(n_issued), self.mult, int(retries))])[-4:]
             if SLICE_ADAPT and SLICE_BASE > 0:
@@ -77,9 +80,16 @@ class FrameHints:
             return (len(r) >= 2 and r[-1][0] == r[-2][0] and r[-1][1] == r[-2][1] == self.mult
                     and r[-1][2] == 0 and r[-2][2] == 0)
 
+    def lazy_records(self) -> bool:
+        """lazy records (LAZY_RECORDS) pay while a frame's slices hold a small share of its visible pairs: the scene's
+        frames have stopped within the default first-slice budget so far, and the last frame's issued slices held less
+        than a quarter of its bounding-box pairs (a scene that fits its first slice whole projects eagerly: every pair
+        would be projected again, by gathers)"""
+        return self.mult == 1 and (self.box_share is None or self.box_share < 0.25)
+
     def reset(self) -> None:
         with self._lock:
-            self.mult, self.age, self.arena_bytes, self._recent = 1, 0, 0, []
+            self.mult, self.age, self.arena_bytes, self._recent, self.box_share = 1, 0, 0, [], None
 
 
 _hints = {}          # default owner: (device, N, P, S, H, W, shared, storage of means3d) -> FrameHints
@@ -145,10 +155,11 @@ UPSTREAM_GRADS = int(os.environ.get("GSD_UPSTREAM_GRADS", "7"))
 BAND_AWARE = int(os.environ.get("GSD_BAND_AWARE", "1"))
 # Lazy records (round 5).  The fused projection writes a 64-byte record for every visible (sub-pose, Gaussian) pair — 4 M
 # of them, 256 MB of the kernel's 314 MB of traffic, on the benchmark scene — and a frame that stops within its first
-# depth slice reads 55 k of them.  1 (default): a scene whose frames have not needed a larger first-slice budget
-# (FrameHints.mult == 1: its tiles saturate early) projects keys, tile counts and radii only, and every issued slice
-# projects the records of its own pairs (gs_slice_project_records: same arithmetic, bit-identical rows); a scene whose
-# budget has grown (most of its Gaussians are composited) keeps the eager projection.  0: always eager; 2: always lazy.
+# depth slice reads 55 k of them.  1 (default): a scene whose frames have not needed a larger first-slice budget and
+# whose last frame's slices held less than a quarter of its bounding-box pairs (FrameHints.lazy_records: its tiles
+# saturate early) projects keys, tile counts and radii only, and every issued slice projects the records of its own pairs
+# (gs_slice_project_records: same arithmetic, bit-identical rows); a scene whose budget has grown, or that fits its first
+# slice whole, keeps the eager projection.  0: always eager; 2: always lazy.
 LAZY_RECORDS = int(os.environ.get("GSD_LAZY_RECORDS", "1"))
 # 1 (default): Gaussians whose scales differ by more than 8x get the covariance part of their projection backward
 # (v_conic -> cov2d -> cov3d -> scale / quaternion / mean) recomputed in double (project_needle_hp_kernel): in fp32 that
@@ -1041,7 +1052,7 @@ class _RenderSubposes(Function):
         # whose frames have so far stopped within the default budget
         lazy = None
         if (backend is None and not pixvel and LAZY_RECORDS and hints.slice_base() > 0
-                and (LAZY_RECORDS == 2 or hints.mult == 1)):
+                and (LAZY_RECORDS == 2 or hints.lazy_records())):
             defer_flags |= 16
         if shared is not None and backend is not None:
             raise ValueError("the shared-list mode runs through the library's frame path only")
@@ -1105,7 +1116,10 @@ class _RenderSubposes(Function):
                                                                      hints.slice_base(), color, depth_acc,
                                                                      any(ctx.needs_input_grad), rs, averaged, hints,
                                                                      bool(defer_flags & 4), lazy)
-                    hints.feedback(int(ctx.frame["state"].n_slices), retries)
+                    st_ = ctx.frame["state"]
+                    held = sum(int(st_.slice[i].I) for i in range(int(st_.n_slices)))
+                    hints.feedback(int(st_.n_slices), retries,
+                                   min(1.0, held / int(st_.n_total)) if int(st_.n_total) > 0 else None)
                     break
                 except _ArenaTooSmall:
                     retries += 1

@@ -358,6 +358,19 @@ def test_adaptive_slice_budget_schedule(gs):
         assert b.slice_base() == 512 and b.settled                                            # one-slice frames: untouched
         b.feedback(1, retries=1)
         assert not b.settled and b.arena_retries == 1                                         # an arena retry unsettles
+        # lazy records (round 5): while the budget has not grown AND the last frame's slices held under a quarter of its
+        # bounding-box pairs; a frame nobody has seen yet counts as early-terminating
+        c = ops.FrameHints()
+        assert c.lazy_records()
+        c.feedback(1, 0, 0.088)
+        assert c.lazy_records()                                                               # the benchmark scene: 8.8 %
+        c.feedback(1, 0, 1.0)
+        assert not c.lazy_records()                                                           # fits its first slice whole
+        c.feedback(1, 0, 0.1)
+        c.feedback(2, 0, 0.1)
+        assert c.mult == 2 and not c.lazy_records()                                           # the budget grew: eager
+        c.reset()
+        assert c.lazy_records() and c.box_share is None
         for _ in range(256):
             a.feedback(1)
         assert a.slice_base() == 512                                                          # forgotten, re-learnt later
