@@ -477,6 +477,16 @@ class _FrameState(ctypes.Structure):
                 [("slice", _FrameSlice * 16)])
 
 
+def _box_share(state) -> Optional[float]:
+    """share of a frame's bounding-box pairs that its issued depth slices held (gs_frame_state: the slices' list
+    capacities over n_total); None for a frame without pairs.  What FrameHints.lazy_records() goes by."""
+    n_total = int(state.n_total)
+    if n_total <= 0:
+        return None
+    held = sum(int(state.slice[i].I) for i in range(int(state.n_slices)))
+    return min(1.0, held / n_total)
+
+
 class _ArenaTooSmall(Exception):
     pass
 
@@ -1116,10 +1126,7 @@ class _RenderSubposes(Function):
                                                                      hints.slice_base(), color, depth_acc,
                                                                      any(ctx.needs_input_grad), rs, averaged, hints,
                                                                      bool(defer_flags & 4), lazy)
-                    st_ = ctx.frame["state"]
-                    held = sum(int(st_.slice[i].I) for i in range(int(st_.n_slices)))
-                    hints.feedback(int(st_.n_slices), retries,
-                                   min(1.0, held / int(st_.n_total)) if int(st_.n_total) > 0 else None)
+                    hints.feedback(int(ctx.frame["state"].n_slices), retries, _box_share(ctx.frame["state"]))
                     break
                 except _ArenaTooSmall:
                     retries += 1

@@ -371,6 +371,17 @@ def test_adaptive_slice_budget_schedule(gs):
         assert c.mult == 2 and not c.lazy_records()                                           # the budget grew: eager
         c.reset()
         assert c.lazy_records() and c.box_share is None
+        # the share itself, from the frame state the library fills: the slices' list capacities over the frame's pairs
+        st = ops._FrameState()
+        assert ops._box_share(st) is None                                                     # a frame without pairs
+        st.n_total, st.n_slices = 238_327_957, 1
+        st.slice[0].I = 20_889_600
+        assert abs(ops._box_share(st) - 0.0877) < 1e-3
+        st.n_slices = 3
+        st.slice[1].I, st.slice[2].I = 100_000_000, 200_000_000
+        assert ops._box_share(st) == 1.0                                                      # capacities are upper bounds
+        c.feedback(int(st.n_slices), 0, ops._box_share(st))
+        assert c.box_share == 1.0 and not c.lazy_records()
         for _ in range(256):
             a.feedback(1)
         assert a.slice_base() == 512                                                          # forgotten, re-learnt later
