@@ -38,7 +38,7 @@ KNOBS = ("SLICE_BASE", "EXACT_TILE_CULL", "COMPACT_EMIT", "HIT_MASKS", "GRAD_TUP
 ROUTES = ("SPECULATE", "TILE_SORT_CARRY", "DEPTH_SORT_COMPACT", "DEVICE_SIZES", "PREALLOC_BWD")
 # round 3: half of the trials go through the C++ frame orchestration (gs_frame_forward / gs_frame_backward; it needs the
 # default routes) with slice merging and the polled read-backs drawn at random; the radix passes run in either form
-FRAME = ("NATIVE_FRAME", "SLICE_MERGE", "FRAME_POLL")
+FRAME = ("NATIVE_FRAME", "SLICE_MERGE", "FRAME_POLL", "LAZY_RECORDS")
 saved = {k: getattr(ops, k) for k in KNOBS + ROUTES + FRAME}
 from gsdeblur_amd import _lib  # noqa: E402
 _L = _lib.load()
@@ -80,7 +80,10 @@ for trial in range(trials):
         Vp[:3, :3], Vp[:3, 3] = Rm, tv
         sc["viewmat"] = Vp
     native = rng.random() < 0.5
-    frame = {"NATIVE_FRAME": int(native), "SLICE_MERGE": rng.choice([0.0, 0.3, 0.75]), "FRAME_POLL": rng.choice([0, 1])}
+    frame = {"NATIVE_FRAME": int(native), "SLICE_MERGE": rng.choice([0.0, 0.3, 0.75]), "FRAME_POLL": rng.choice([0, 1]),
+             # round 5: lazy records (never / always), drawn from a generator of its own so that the older draws — and
+             # with them every trial of an earlier seed — stay what they were
+             "LAZY_RECORDS": random.Random(seed * 7919 + trial).choice([0, 2])}
     single_pass = rng.choice([0, 1])
     rs_time = 0.0
     if pixvel:
@@ -187,7 +190,7 @@ for trial in range(trials):
     bad += 0 if ok else 1
     print(f"trial {trial:3d} n={n:6d} {W}x{H} S={S} R={R} mult={mult} base={base} slices={nsl} "
           f"deg={deg} aa={int(aa)} gamma={gamma} routes={''.join(str(routes[k]) for k in ROUTES)} "
-          f"frame={int(native)}/{frame['SLICE_MERGE']}/{frame['FRAME_POLL']} sort1p={single_pass} "
+          f"frame={int(native)}/{frame['SLICE_MERGE']}/{frame['FRAME_POLL']}/lazy{frame['LAZY_RECORDS']} sort1p={single_pass} "
           f"{'pixvel rs=%.3f ' % rs_time if pixvel else ''}img_equal={torch.equal(img_f, img_p)} grad_rel={worst:.1e} ({worst_key}){extra} "
           f"{'ok' if ok else 'FAIL'}", flush=True)
 print(f"fuzz: {trials - bad}/{trials} trials ok in {time.time() - t0:.0f} s")
