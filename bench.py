@@ -413,7 +413,11 @@ def main():
     slice_isects = list(ops.last_slice_intersects)
     slice_budget = wl.hints.slice_base()                    # (ops.SLICE_ADAPT: doubles after multi-slice frames)
     headline_hints = {"frames": wl.hints.frames, "arena_retries": wl.hints.arena_retries,
-                      "arena_bytes": wl.hints.arena_bytes, "settled": wl.hints.settled, "warm_frames": warm_frames}
+                      "arena_bytes": wl.hints.arena_bytes, "settled": wl.hints.settled, "warm_frames": warm_frames,
+                      # lazy records: does this scene's next frame project without records, and on what grounds
+                      "lazy_records": bool(args.motion == "se3" and (ops.LAZY_RECORDS == 2 or
+                                                                       (ops.LAZY_RECORDS and wl.hints.lazy_records()))),
+                      "box_share_of_issued_slices": None if wl.hints.box_share is None else round(wl.hints.box_share, 4)}
     rows_with_grad = wl.rows_with_gradient()
     # second scene (reported beside the headline, never part of `value`): a fitted-model-like distribution in which
     # a large share of the Gaussians receives a gradient and the depth-sliced path needs several slices
@@ -461,7 +465,10 @@ def main():
             "stage_ms": {k: round(sum(v) / 3, 4) for k, v in st2.items()},
             "host_stall_ms": round(stall_of(ms2, st2, 3), 4), "timing_attempts_ms": attempts2,
             "frame_hints": {"frames": w2.hints.frames, "arena_retries": w2.hints.arena_retries,
-                            "arena_bytes": w2.hints.arena_bytes, "settled": w2.hints.settled, "warm_frames": warm2},
+                            "arena_bytes": w2.hints.arena_bytes, "settled": w2.hints.settled, "warm_frames": warm2,
+                            "lazy_records": bool(args.motion == "se3" and (ops.LAZY_RECORDS == 2 or
+                                                                             (ops.LAZY_RECORDS and w2.hints.lazy_records()))),
+                            "box_share_of_issued_slices": None if w2.hints.box_share is None else round(w2.hints.box_share, 4)},
             "roofline": sec_roofline, "train_step": train}
         del w2
         torch.cuda.empty_cache()
