@@ -70,7 +70,7 @@ def test_missing_library_raises(gs, monkeypatch, tmp_path):
 
 
 def test_frame_structs_match_the_header_layout(gs, tmp_path):
-    """the ctypes mirrors of gs_frame_desc / gs_frame_slice / gs_frame_state (ops.py) against the C header itself: a tiny C
+    """the ctypes mirrors of gs_frame_desc / gs_frame_slice / gs_frame_state / gs_project_inputs (ops.py) against the C header itself: a tiny C
     program compiled with gcc prints sizeof and the offset of every field; a field added on one side only (round 4 added
     shared_list and the combine fields) shows up here, on CPU, instead of as a corrupted frame on the GPU"""
     import ctypes
@@ -79,7 +79,8 @@ def test_frame_structs_match_the_header_layout(gs, tmp_path):
     from gsdeblur_amd import ops
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
-    structs = {"gs_frame_desc": ops._FrameDesc, "gs_frame_slice": ops._FrameSlice, "gs_frame_state": ops._FrameState}
+    structs = {"gs_frame_desc": ops._FrameDesc, "gs_frame_slice": ops._FrameSlice, "gs_frame_state": ops._FrameState,
+               "gs_project_inputs": ops._ProjectInputs}        # (round 5: what the lazy record projection is called with)
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT / "include" / "gsdeblur.h"}"', 'int main(void) {']
     for cname, cls in structs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
