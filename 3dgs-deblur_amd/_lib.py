@@ -77,7 +77,6 @@ _SIGS = {
     "gs_frame_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P],
     "gs_frame_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _L, _P],
     "gs_frame_profile_enable": [ctypes.c_uint],
-    "gs_sort_set_single_pass": [_I],
     "gs_frame_profile_read": [_I, _P, _P],
     "gs_image_loss_fwd_bwd": [_I, _I, _P, _P, _F, _P, _P, _P, _L, _P],
     "gs_adam_step": [_I, _P, _P, _P, _P, _P, _P, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P],

@@ -21,7 +21,6 @@
 // The radix sort is a 3-kernel LSD pass (histogram / scan / scatter) with
 // wave64 match-any ranking (ballot per digit bit), one contiguous key run per wave
 // so stability needs no block-wide exchange.
-#include <stdlib.h>
 #include <algorithm>
 #include "gs_common.h"
 
@@ -244,98 +243,6 @@ struct SegDev {
   unsigned long long skip;   // compacting pass: the key value that is dropped
 };
 
-// Single-pass form of a radix pass (decoupled look-back; round 3).  The three-kernel pass reads the keys twice and
-// spends two launches on the scan of its [digit][block] histogram: at the sizes of this pipeline (1-20 M keys, about
-// one wave of blocks) that is ~20 us of a ~50 us pass.  Here the digit TOTALS of every pass are counted once, up
-// front, by radix_digit_totals_kernel (they do not depend on the order the earlier passes leave), and a scatter block
-// gets the number of same-digit keys in the blocks before it by looking back over those blocks' published counts:
-// status[block][digit] = flag << 30 | count, flag 1 = the block's own count, 2 = inclusive prefix up to this block.
-// A block only ever waits for blocks with a smaller index of its own segment; the hardware dispatches workgroups in
-// index order, so those are running or done (the guarantee rocPRIM's look-back scan leans on, too).  A wait that
-// exceeds kSweepTimeoutTicks traps instead of hanging the queue.
-struct Sweep {
-  const unsigned* totals;    // [segments][NB] digit totals of THIS pass (NULL: three-kernel pass, ghist_scanned is used)
-  unsigned* status;          // [blocks][NB], zero on entry
-};
-constexpr unsigned kSweepPartial = 1u << 30, kSweepComplete = 2u << 30, kSweepValue = (1u << 30) - 1u;
-constexpr unsigned long long kSweepTimeoutTicks = 200000000ull;      // 2 s of the 100 MHz wall clock
-#ifndef GS_SWEEP_LOOK
-#define GS_SWEEP_LOOK 4
-#endif
-constexpr int kLook = GS_SWEEP_LOOK;                                 // predecessors examined per look-back round trip
-
-struct DigitPlan { int passes, begin_bit, end_bit, per, nb; };
-
-// digit totals of ALL passes in one read of the keys: out[(pass * segments + seg) * nb + digit] += count (zeroed by the
-// caller).  grid = (blocks per segment, segments); a block strides over its segment's 4096-key chunks.
-template <typename KeyT>
-__global__ __launch_bounds__(256) void radix_digit_totals_kernel(size_t n, const KeyT* __restrict__ keys, DigitPlan dp,
-                                                                 size_t seg_len, const unsigned* __restrict__ n_dev,
-                                                                 int compacting, unsigned long long skip_key,
-                                                                 unsigned* __restrict__ out) {
-  extern __shared__ unsigned dt_hist[];                      // [passes][nb]
-  constexpr int R = SortCfg<KeyT>::kRounds;
-  if (n_dev) n = min(n, (size_t)*n_dev);
-  const unsigned seg = blockIdx.y;
-  const size_t seg_base = (size_t)seg * seg_len;
-  const size_t limit = min(n, seg_base + seg_len);
-  for (int i = threadIdx.x; i < dp.passes * dp.nb; i += 256) dt_hist[i] = 0;
-  __syncthreads();
-  const int lane = lane_id();
-  const KeyT skip = (KeyT)skip_key;
-  for (size_t base = seg_base + (size_t)blockIdx.x * (256 * R); base < limit; base += (size_t)gridDim.x * (256 * R)) {
-    KeyT k[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const size_t i = base + (size_t)r * 256 + threadIdx.x;
-      k[r] = i < limit ? keys[i] : (KeyT)0;
-    }
-    for (int p = 0; p < dp.passes; ++p) {
-      const int shift = dp.begin_bit + p * dp.per;
-      const int w = min(dp.per, dp.end_bit - shift);
-      const unsigned mask = (1u << w) - 1u;
-      unsigned* h = dt_hist + p * dp.nb;
-      // a digit that takes a handful of values over the whole wave (the top byte of a depth key): same-address LDS
-      // atomics serialise, so such a wave counts its lanes in groups (see radix_hist_kernel)
-      bool skewed;
-      {
-        const size_t i0 = base + threadIdx.x;
-        const bool ok0 = i0 < limit && !(compacting && k[0] == skip);
-        const unsigned d = (unsigned)(k[0] >> shift) & mask;
-        const unsigned long long m = __ballot(ok0);
-        const unsigned d0 = (unsigned)readlane_i((int)d, m ? __ffsll((long long)m) - 1 : 0);
-        skewed = __popcll(__ballot(ok0 && d == d0)) >= 16;
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const size_t i = base + (size_t)r * 256 + threadIdx.x;
-        const bool ok = i < limit && !(compacting && k[r] == skip);
-        const unsigned d = (unsigned)(k[r] >> shift) & mask;
-        if (skewed) {
-          unsigned long long todo = __ballot(ok);
-#pragma unroll 1
-          for (int it = 0; it < 4 && todo; ++it) {
-            const int src = __ffsll((long long)todo) - 1;
-            const unsigned d0 = (unsigned)readlane_i((int)d, src);
-            const unsigned long long same = __ballot(ok && d == d0) & todo;
-            if (lane == src) atomicAdd(&h[d0], (unsigned)__popcll(same));
-            todo &= ~same;
-          }
-          if ((todo >> lane) & 1ull) atomicAdd(&h[d], 1u);
-        } else if (ok) {
-          atomicAdd(&h[d], 1u);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  const unsigned nseg = gridDim.y;
-  for (int i = threadIdx.x; i < dp.passes * dp.nb; i += 256) {
-    const unsigned c = dt_hist[i];
-    if (c) atomicAdd(&out[((size_t)(i / dp.nb) * nseg + seg) * dp.nb + (i % dp.nb)], c);
-  }
-}
-
 template <typename KeyT, int BITS>
 __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* __restrict__ keys, int shift,
                                                          unsigned mask, SegInfo sg,
@@ -434,7 +341,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
                                                             const unsigned* __restrict__ n_dev, SegDev sd,
                                                             const unsigned* __restrict__ p2_in,   // nullable: a second
                                                             unsigned* __restrict__ p2_out,        // payload per key
-                                                            Sweep sw, int pack_bits) {
+                                                            int pack_bits) {
   constexpr int NB = 1 << BITS;
   constexpr int R = SortCfg<KeyT>::kRounds;
   constexpr int BK = 256 * R;
@@ -496,7 +403,6 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
     pos[r] = (unsigned short)(base + prefix);
   }
   __syncthreads();
-  unsigned sweep_base[DPT], sweep_cnt[DPT];      // single-pass form: digit base in the segment, this block's count
   // per digit: block count -> LDS base (exclusive scan over digits), per-wave offsets, global base
   {
     unsigned c[DPT], sum = 0;
@@ -511,46 +417,18 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
     if (threadIdx.x == 0) s_scan[4] = tot;          // keys this block really moves (block_excl_scan uses [0..3])
     const unsigned seg_org = (unsigned)((size_t)seg * sg.seg_len);
     unsigned gb[DPT];              // first global slot of each of this thread's digits for this block
-    if (sw.totals) {
-      // single-pass form, first half: publish this block's digit counts NOW (the blocks behind it add them up) and get
-      // the digit bases inside the segment from the up-front totals.  The look-back itself waits until the keys are
-      // staged in LDS (below): staging needs no global position, and by then the blocks in front have usually
-      // published their prefixes — looking back right here cost the tile sort 15 us per pass.
-      unsigned* mine = sw.status + ((size_t)seg * sg.nblk_seg + blk) * NB + threadIdx.x * DPT;
-#pragma unroll
-      for (int j = 0; j < DPT; ++j)
-        __hip_atomic_store(mine + j, (blk == 0 ? kSweepComplete : kSweepPartial) | c[j], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      unsigned g[DPT], gsum = 0;
-#pragma unroll
-      for (int j = 0; j < DPT; ++j) {
-        g[j] = sw.totals[(size_t)seg * NB + threadIdx.x * DPT + j];
-        gsum += g[j];
-      }
-      unsigned gtot;
-      unsigned gex = block_excl_scan(gsum, gtot, s_scan);
-      if (compacting && blk == 0 && threadIdx.x == 0) sd.cnt_out[seg] = gtot;     // survivors of this segment
-#pragma unroll
-      for (int j = 0; j < DPT; ++j) {
-        gb[j] = seg_org + gex;
-        sweep_base[j] = gb[j];
-        sweep_cnt[j] = c[j];
-        gex += g[j];
-      }
-    } else {
-      // the flat scan counts the keys of all earlier segments; the segment itself starts at seg*seg_len
-      const size_t seg_first = (size_t)seg * NB * sg.nblk_seg;
-      const unsigned seg_base = ghist_scanned[seg_first];
-      if (compacting && blk == 0 && threadIdx.x == 0) {
-        // survivors of this segment = what the flat scan counts between this segment's first entry and the next one's
-        const unsigned nseg = gridDim.x / sg.nblk_seg;
-        const unsigned next = seg + 1 < nseg ? ghist_scanned[seg_first + (size_t)NB * sg.nblk_seg] : *sd.total;
-        sd.cnt_out[seg] = next - seg_base;
-      }
-#pragma unroll
-      for (int j = 0; j < DPT; ++j)
-        gb[j] = ghist_scanned[seg_first + (size_t)(threadIdx.x * DPT + j) * sg.nblk_seg + blk] - seg_base + seg_org;
+    // the flat scan counts the keys of all earlier segments; the segment itself starts at seg*seg_len
+    const size_t seg_first = (size_t)seg * NB * sg.nblk_seg;
+    const unsigned seg_base = ghist_scanned[seg_first];
+    if (compacting && blk == 0 && threadIdx.x == 0) {
+      // survivors of this segment = what the flat scan counts between this segment's first entry and the next one's
+      const unsigned nseg = gridDim.x / sg.nblk_seg;
+      const unsigned next = seg + 1 < nseg ? ghist_scanned[seg_first + (size_t)NB * sg.nblk_seg] : *sd.total;
+      sd.cnt_out[seg] = next - seg_base;
     }
+#pragma unroll
+    for (int j = 0; j < DPT; ++j)
+      gb[j] = ghist_scanned[seg_first + (size_t)(threadIdx.x * DPT + j) * sg.nblk_seg + blk] - seg_base + seg_org;
 #pragma unroll
     for (int j = 0; j < DPT; ++j) {
       int d = threadIdx.x * DPT + j;
@@ -591,45 +469,6 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
         if (PACK == 1) s_vals[slot] = (unsigned)i | (min(pv[q], (1u << (32 - pack_bits)) - 1u) << pack_bits);
         else s_vals[slot] = vals_in ? pv[q] : (unsigned)i;
       }
-    }
-  }
-  if (sw.totals && blk > 0) {
-    // single-pass form, second half: same-digit keys in the blocks before this one, by decoupled look-back
-    unsigned* mine = sw.status + ((size_t)seg * sg.nblk_seg + blk) * NB + threadIdx.x * DPT;
-#pragma unroll
-    for (int j = 0; j < DPT; ++j) {
-      const unsigned* col = sw.status + (size_t)seg * sg.nblk_seg * NB + threadIdx.x * DPT + j;
-      unsigned before = 0;
-      long long b = (long long)blk - 1;
-      unsigned long long t0 = 0;
-      while (b >= 0) {
-        // kLook predecessors per round trip: their words are independent loads
-        unsigned v[kLook];
-#pragma unroll
-        for (int q = 0; q < kLook; ++q)
-          v[q] = b - q >= 0 ? __hip_atomic_load(col + (size_t)(b - q) * NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                            : kSweepComplete;
-        int adv = 0;
-        bool done = false;
-#pragma unroll
-        for (int q = 0; q < kLook; ++q) {
-          if (!done && adv == q && (v[q] >> 30) != 0u) {
-            before += v[q] & kSweepValue;
-            ++adv;
-            done = (v[q] >> 30) == 2u;
-          }
-        }
-        if (done) break;
-        b -= adv;
-        if (adv == 0) {
-          __builtin_amdgcn_s_sleep(2);
-          const unsigned long long now = wall_clock64();
-          if (t0 == 0) t0 = now;
-          else if (now - t0 > kSweepTimeoutTicks) __builtin_trap();
-        }
-      }
-      __hip_atomic_store(mine + j, kSweepComplete | (before + sweep_cnt[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_gbase[threadIdx.x * DPT + j] = sweep_base[j] + before;
     }
   }
   __syncthreads();
@@ -719,62 +558,30 @@ static inline size_t radix_hist_bytes(size_t n, size_t seg_len, int bits, int ma
   return (b + 255) & ~(size_t)255;
 }
 
-// single-pass form: digit totals of every pass [passes][segments][NB] + look-back words [passes][blocks][NB]
-template <typename KeyT>
-static inline size_t radix_sweep_bytes(size_t n, size_t seg_len, int bits, int max_digit, size_t* totals_bytes) {
-  int ps, per, tb;
-  radix_plan(bits, &ps, &per, &tb, max_digit);
-  unsigned nbs;
-  const size_t nblk = sort_nblk_seg<KeyT>(n, seg_len, &nbs);
-  const size_t nseg = nbs ? nblk / nbs : 1;
-  const size_t tot = (((size_t)ps * nseg * ((size_t)1 << tb) * sizeof(unsigned)) + 255) & ~(size_t)255;
-  if (totals_bytes) *totals_bytes = tot;
-  return tot + (((size_t)ps * nblk * ((size_t)1 << tb) * sizeof(unsigned) + 255) & ~(size_t)255);
-}
-
 template <typename KeyT>
 static inline size_t radix_ws_bytes(size_t n, size_t seg_len, int bits, int max_digit = 11) {
   int ps, per, tb;
   radix_plan(bits, &ps, &per, &tb, max_digit);
   unsigned nbs;
-  const size_t three = radix_hist_bytes<KeyT>(n, seg_len, bits, max_digit) +
-                       scan_ws_bytes(((size_t)1 << tb) * sort_nblk_seg<KeyT>(n, seg_len, &nbs));
-  return std::max(three, radix_sweep_bytes<KeyT>(n, seg_len, bits, max_digit, nullptr)) + 256;
+  return radix_hist_bytes<KeyT>(n, seg_len, bits, max_digit) +
+         scan_ws_bytes(((size_t)1 << tb) * sort_nblk_seg<KeyT>(n, seg_len, &nbs)) + 256;
 }
 
-// Which form the passes take: 0 (default) = three kernels per pass, 1 = single-pass scatter with look-back.  Measured on
-// MI355X (profiles/r03_run15_*, r03_run16_*): at this pipeline's sizes the single-pass form is NOT faster — the tile
-// sort goes from 0.185 to 0.213 ms (every block waits ~10-20 us for the counts of the blocks in front of it, with
-// nothing else to do: a pass is one to three waves of co-resident blocks, so the wait is on the critical path, while
-// the histogram + scan it replaces cost ~20 us), the depth pre-sort from 0.242 to 0.230 ms.  Initial value from
-// GSD_SORT_SINGLE_PASS in the environment; gs_sort_set_single_pass() changes it (measurement / tests, not thread-safe).
-static int g_sort_single_pass = -1;
-static inline bool sort_single_pass() {
-  if (g_sort_single_pass < 0) {
-    const char* e = getenv("GSD_SORT_SINGLE_PASS");
-    g_sort_single_pass = e ? (atoi(e) != 0) : 0;
-  }
-  return g_sort_single_pass != 0;
-}
-
-// GSD_COMPACT_PACK=0: the depth pre-sort's last pass gathers the tile counts at random again (A/B)
-static inline bool compact_pack() {
-  static const int v = [] { const char* e = getenv("GSD_COMPACT_PACK"); return e ? (atoi(e) != 0) : 1; }();
-  return v != 0;
-}
-
+// (A radix pass is three kernels: histogram, scan, scatter.  The single-pass form — decoupled look-back over per-block
+//  digit counts — was built in round 3 and measured slower at this pipeline's sizes: tile sort 0.185 -> 0.213 ms, a pass
+//  being one to three waves of co-resident blocks whose look-back wait sits on the critical path; removed in round 6,
+//  profiles/r03_run15_*, r03_run16_* are the record.)
 template <typename KeyT, int BITS>
 static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned* vin, KeyT* kout, unsigned* vout,
                        int shift, unsigned mask, void* ws, size_t hist_bytes, hipStream_t st,
                        const unsigned* gather_src = nullptr, unsigned* gather_out = nullptr,
                        const unsigned* n_dev = nullptr, SegDev sd = SegDev{nullptr, nullptr, nullptr, 0ull},
-                       const unsigned* p2_in = nullptr, unsigned* p2_out = nullptr, Sweep sw = Sweep{nullptr, nullptr},
-                       int pack = 0, int pack_bits = 0) {
+                       const unsigned* p2_in = nullptr, unsigned* p2_out = nullptr, int pack = 0, int pack_bits = 0) {
   SegInfo sg;
   unsigned nblk = sort_nblk_seg<KeyT>(n, seg_len, &sg.nblk_seg);
   sg.seg_len = (seg_len == 0 || seg_len >= n) ? n : seg_len;
   unsigned* ghist = reinterpret_cast<unsigned*>(ws);
-  if (!sw.totals) {
+  {
     size_t hn = ((size_t)1 << BITS) * nblk;
     void* scan_ws = reinterpret_cast<char*>(ws) + hist_bytes;
     hipLaunchKernelGGL((radix_hist_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, shift, mask, sg, ghist,
@@ -786,17 +593,17 @@ static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned
     // packed tile counts (see radix_scatter_kernel): only the 8-bit passes of the compacting 32-bit depth pre-sort
     if (pack == 1) {
       hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS, 1>), dim3(nblk), dim3(256), 0, st, n, kin, vin, kout, vout,
-                         shift, mask, sg, ghist, gather_src, gather_out, n_dev, sd, p2_in, p2_out, sw, pack_bits);
+                         shift, mask, sg, ghist, gather_src, gather_out, n_dev, sd, p2_in, p2_out, pack_bits);
       return;
     }
     if (pack == 2) {
       hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS, 2>), dim3(nblk), dim3(256), 0, st, n, kin, vin, kout, vout,
-                         shift, mask, sg, ghist, gather_src, gather_out, n_dev, sd, p2_in, p2_out, sw, pack_bits);
+                         shift, mask, sg, ghist, gather_src, gather_out, n_dev, sd, p2_in, p2_out, pack_bits);
       return;
     }
   }
   hipLaunchKernelGGL((radix_scatter_kernel<KeyT, BITS>), dim3(nblk), dim3(256), 0, st, n, kin, vin, kout, vout, shift,
-                     mask, sg, ghist, gather_src, gather_out, n_dev, sd, p2_in, p2_out, sw, 0);
+                     mask, sg, ghist, gather_src, gather_out, n_dev, sd, p2_in, p2_out, 0);
 }
 
 // Sort bits [begin_bit, end_bit).  Ping-pongs between (k0,v0) and (k1,v1); returns the index
@@ -824,30 +631,10 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
   // packed tile counts: the compacting depth pre-sort with its count gather, 8-bit digits, at least two passes, and at
   // least four payload bits to spare (cap >= 15)
   int pack_bits = 0;
-  if (compact_pack() && sizeof(KeyT) == 4 && gather_src && gather_out && seg_counts && v0_is_iota && !p2_src &&
+  if (sizeof(KeyT) == 4 && gather_src && gather_out && seg_counts && v0_is_iota && !p2_src &&
       tb == 8 && passes >= 2) {
     while (((size_t)1 << pack_bits) < n) ++pack_bits;
     if (pack_bits > 28) pack_bits = 0;
-  }
-  // single-pass form (see Sweep): look-back counts are 30-bit
-  const bool sweep = sort_single_pass() && n < ((size_t)1 << 30);
-  unsigned *sw_totals = nullptr, *sw_status = nullptr;
-  unsigned nblk_all = 0, nblk_seg_all = 0;
-  size_t nseg_all = 1;
-  if (sweep) {
-    size_t tot_b = 0;
-    const size_t all_b = radix_sweep_bytes<KeyT>(n, seg_len, bits, max_digit, &tot_b);
-    nblk_all = sort_nblk_seg<KeyT>(n, seg_len, &nblk_seg_all);
-    nseg_all = nblk_seg_all ? nblk_all / nblk_seg_all : 1;
-    sw_totals = reinterpret_cast<unsigned*>(ws);
-    sw_status = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + tot_b);
-    if (hipMemsetAsync(ws, 0, all_b, st) != hipSuccess) return GS_ERR_INVALID;
-    DigitPlan dpl{passes, begin_bit, end_bit, per, 1 << tb};
-    const size_t seg_l = (seg_len == 0 || seg_len >= n) ? n : seg_len;
-    const unsigned gx = std::max(1u, std::min(nblk_seg_all, (unsigned)std::max<size_t>(1, 768 / nseg_all)));
-    hipLaunchKernelGGL((radix_digit_totals_kernel<KeyT>), dim3(gx, (unsigned)nseg_all), dim3(256),
-                       (size_t)passes * (1u << tb) * sizeof(unsigned), st, n, kk[0], dpl, seg_l, n_dev,
-                       seg_counts ? 1 : 0, skip_key, sw_totals);
   }
   for (int p = 0; p < passes; ++p) {
     int w = per;
@@ -871,16 +658,11 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
       p2o = (p & 1) ? p2_b : p2_a;
       p2i = p == 0 ? p2_src : ((p & 1) ? p2_a : p2_b);
     }
-    Sweep sw{nullptr, nullptr};
-    if (sweep) {
-      sw.totals = sw_totals + (size_t)p * nseg_all * ((size_t)1 << tb);
-      sw.status = sw_status + (size_t)p * nblk_all * ((size_t)1 << tb);
-    }
     switch (tb) {
-      case 8:  radix_pass<KeyT, 8>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, sw, pack, pack_bits); break;
-      case 9:  radix_pass<KeyT, 9>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, sw); break;
-      case 10: radix_pass<KeyT, 10>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, sw); break;
-      default: radix_pass<KeyT, 11>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, sw); break;
+      case 8:  radix_pass<KeyT, 8>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, pack, pack_bits); break;
+      case 9:  radix_pass<KeyT, 9>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
+      case 10: radix_pass<KeyT, 10>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
+      default: radix_pass<KeyT, 11>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
     }
     shift += w;
     cur ^= 1;
@@ -1118,15 +900,22 @@ __global__ __launch_bounds__(256) void bin_edges_kernel(size_t n, const KeyT* __
     const bool valid = i < n;
     unsigned t = 0, lo = 0, hi = 0;         // this lane's gap of key-less bins [lo, hi)
     if (valid) {
-      t = (unsigned)(keys[i] >> SHIFT);
+      // a key >= num_bins (caller-supplied ids through the compat entry gs_tile_bin_edges_u64) owns no bin: it writes
+      // nothing and its gaps end at num_bins (unclamped, a stray key made a whole wave zero-fill up to
+      // 2^32 bins past the buffer)
+      t = min((unsigned)(keys[i] >> SHIFT), num_bins);
       if (i == 0) {
-        bins[t].x = 0;
+        if (t < num_bins) bins[t].x = 0;
         hi = t;
       } else {
-        const unsigned tp = (unsigned)(keys[i - 1] >> SHIFT);
-        if (tp != t) { bins[t].x = (int)i; bins[tp].y = (int)i; lo = tp + 1; hi = t; }
+        const unsigned tp = min((unsigned)(keys[i - 1] >> SHIFT), num_bins);
+        if (tp != t) {
+          if (t < num_bins) bins[t].x = (int)i;
+          if (tp < num_bins) bins[tp].y = (int)i;
+          lo = min(tp + 1u, num_bins); hi = t;
+        }
       }
-      if (i == n - 1) bins[t].y = (int)n;
+      if (i == n - 1 && t < num_bins) bins[t].y = (int)n;
     }
     unsigned long long m = __ballot(hi > lo);
     while (m) {
@@ -1137,7 +926,7 @@ __global__ __launch_bounds__(256) void bin_edges_kernel(size_t n, const KeyT* __
     }
     const unsigned long long last = __ballot(valid && i == n - 1);
     if (last) {
-      const unsigned g_lo = (unsigned)readlane_i((int)t, __ffsll((long long)last) - 1) + 1u;
+      const unsigned g_lo = min((unsigned)readlane_i((int)t, __ffsll((long long)last) - 1) + 1u, num_bins);
       for (unsigned b = g_lo + lane; b < num_bins; b += 64) bins[b] = z;
     }
   }
@@ -1656,14 +1445,6 @@ using namespace gs;
 
 // C ABI -------------------------------------------------------------------------
 GS_EXPORT long long gs_scan_workspace_bytes(long long n) { return (long long)scan_ws_bytes((size_t)n) + 256; }
-// measurement / tests only (process-wide, not thread-safe): 1 = radix passes as ONE kernel each (decoupled look-back,
-// digit totals counted up front), 0 = histogram + scan + scatter.  Returns the previous setting.
-GS_EXPORT int gs_sort_set_single_pass(int on) {
-  const int old = sort_single_pass() ? 1 : 0;
-  g_sort_single_pass = on ? 1 : 0;
-  return old;
-}
-
 GS_EXPORT long long gs_radix_sort_workspace_bytes(long long n, int begin_bit, int end_bit) {
   if (n <= 0 || end_bit <= begin_bit) return 0;
   // sized for the larger (u64) layout so one query serves both key widths

@@ -294,12 +294,6 @@ constexpr int kRedCols4 = 32, kRedStride4 = 36;    // 36 = 32 + 4: rows 16-byte 
 #ifndef GS_BWD_SLOAD_WAVES
 #define GS_BWD_SLOAD_WAVES 5
 #endif
-#ifndef GS_BWD_VCOPY
-#define GS_BWD_VCOPY 0
-#endif
-#ifndef GS_BWD_EXEC
-#define GS_BWD_EXEC 0
-#endif
 constexpr int kRedFloats4 = kRedG4 * 9 * kRedStride4;
 
 // w[i] = v[i](lane) + v[i](lane ^ 1) for nine values: nine v_add_f32_dpp in one block (the DPP combiner leaves most
@@ -351,45 +345,25 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
   const float bx[2] = {qyn * dxa, qyn * dxb};
   float m0[2] = {0.f, 0.f}, m1[2] = {0.f, 0.f}, m2 = 0.f, q_r = 0.f, q_g = 0.f, q_b = 0.f;
   bool any = false;
-#if GS_BWD_VCOPY
-  // the six record fields every quadrant uses, copied to VGPRs once per entry (an SGPR operand makes a VALU
-  // instruction cost 1.95 ns instead of 1.17, tools/valu_bench3.hip; six v_mov against 24 such uses)
-  float vy, vqz, vkm, vr_, vg_, vb_;
-  asm volatile("v_mov_b32 %0, %6\n\tv_mov_b32 %1, %7\n\tv_mov_b32 %2, %8\n\tv_mov_b32 %3, %9\n\t"
-               "v_mov_b32 %4, %10\n\tv_mov_b32 %5, %11"
-               : "=v"(vy), "=v"(vqz), "=v"(vkm), "=v"(vr_), "=v"(vg_), "=v"(vb_)
-               : "s"(rc.y), "s"(rc.qz), "s"(rc.kmul), "s"(rc.r), "s"(rc.g), "s"(rc.b));
-  RecS rv = rc;
-  rv.y = vy; rv.qz = vqz; rv.kmul = vkm; rv.r = vr_; rv.g = vg_; rv.b = vb_;
-#define GS_RQ rv
-#else
-#define GS_RQ rc
-#endif
+  // (measured negatives, removed in round 6 — the records are in profiles/: the six per-entry record fields copied to
+  //  VGPRs once per entry instead of 24 SGPR-operand uses; lanes that did not blend the entry sitting the body out under
+  //  the exec mask instead of a selected alpha = 0: ISA 599 -> 607 VALU, 0.724 -> 0.737 ms, profiles/r05_exec_mask_ab.log)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const float dy = GS_RQ.y - pp.py[k];
-    const float u = fmaf(dy, fmaf(GS_RQ.qz, dy, bx[k & 1]), hx[k & 1]);
+    const float dy = rc.y - pp.py[k];
+    const float u = fmaf(dy, fmaf(rc.qz, dy, bx[k & 1]), hx[k & 1]);
     const bool hit = (idx < pp.fin[k]) && (fabsf(u) <= rc.nmid);
     if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;           // nobody's quadrant-k pixel blended this entry
     any = true;
-#if GS_BWD_EXEC
-    // A/B (round 5): lanes whose pixel k did not blend this entry sit the body out under the
-    // exec mask instead of running it with alpha SELECTED to 0 (saves the select(s), costs a saveexec / restore pair)
-    if (!hit) continue;
-    const float ov = GS_RQ.kmul * __builtin_amdgcn_exp2f(u);
-    const float alpha = CLAMP ? fminf(K::kAlphaMax, ov) : ov;
-    const float ovm = CLAMP ? (ov <= agm ? ov : 0.f) : alpha;
-#else
-    const float ov = GS_RQ.kmul * __builtin_amdgcn_exp2f(u);
+    const float ov = rc.kmul * __builtin_amdgcn_exp2f(u);
     // pixels that are not hit are neutralised by SELECTING alpha = 0 (1/(1-0) = 1 exactly, every term an exact zero)
     const float alpha = hit ? (CLAMP ? fminf(K::kAlphaMax, ov) : ov) : 0.f;
     const float ovm = CLAMP ? ((hit && ov <= agm) ? ov : 0.f) : alpha;   // d min(0.999, o*vis) = 0 when clamped
-#endif
     const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
     pp.T[k] *= ra;                               // transmittance in front of this Gaussian
     const float fac = alpha * pp.T[k];
     q_r = fmaf(fac, pp.vr[k], q_r); q_g = fmaf(fac, pp.vg[k], q_g); q_b = fmaf(fac, pp.vb[k], q_b);
-    const float cv = fmaf(GS_RQ.b, pp.vb[k], fmaf(GS_RQ.g, pp.vg[k], GS_RQ.r * pp.vr[k]));
+    const float cv = fmaf(rc.b, pp.vb[k], fmaf(rc.g, pp.vg[k], rc.r * pp.vr[k]));
     const float v_al = fmaf(pp.T[k], cv, -(ra * pp.Dv[k]));
     pp.Dv[k] = fmaf(fac, cv, pp.Dv[k]);
     const float v_sigma = -ovm * v_al;
@@ -398,7 +372,6 @@ __device__ __forceinline__ bool bwd_entry(const RecS& rc, float pxf, int idx, Bw
     m1[k & 1] += vsdy;
     m2 = fmaf(vsdy, dy, m2);
   }
-#undef GS_RQ
   if (!any) return false;
   // sum over the lane's pixels of v_sigma * {1, dx, dx^2} and of v_sigma * dy * {1, dx}
   const float M0 = m0[0] + m0[1], M1 = m1[0] + m1[1];

@@ -37,7 +37,9 @@ SLICE_BASE = int(os.environ.get("GSD_SLICE_BASE", "512"))
 # after its first slice never grows it; forgotten every 256 frames.  Images do not depend on the slicing (bit for bit),
 # gradients up to fp32 summation order.
 SLICE_ADAPT = int(os.environ.get("GSD_SLICE_ADAPT", "1"))
-_state_lock = threading.Lock()     # guards every piece of frame-to-frame state of this module (hints, arena pool, caches)
+# guards every piece of frame-to-frame state of this module (hints, arena pool, caches).  Re-entrant: _ArenaLease.__del__
+# takes it, and the cyclic GC may run a lease's finaliser on a thread that is already inside one of these blocks
+_state_lock = threading.RLock()
 
 
 class FrameHints:
@@ -139,16 +141,19 @@ def readback_mode() -> dict:
             "forced": "GSD_FRAME_POLL" in os.environ}
 # widest radix digit of the compacting depth pre-sort: 8 -> 4 passes of 8 bits, 11 -> 3 passes of 11/10/10 bits
 DEPTH_SORT_DIGIT = int(os.environ.get("GSD_DEPTH_SORT_DIGIT", "8"))
-# Gradient conventions (SURVEY App. A "Backward"), bit mask.  Default 7 = the REFERENCE's, as recollected
-# from upstream gsplat 0.1.11 — three places where its backward is not the derivative of its forward, each a
-# straight-through rule: 1 = back-propagate through the fov clamp of x/z, y/z as if inactive; 2 = quaternion gradient
-# w.r.t. the (assumed unit) quaternion, without the projection through q/|q|; 4 = let the gradient pass the
-# alpha = min(0.999, .) clamp.  0 = the true derivatives (opt-in: GSD_UPSTREAM_GRADS=0).  The oracle has the same
-# switch with the same default (its UP_* constants, RenderConfig.upstream_grads) and the `-m gpu` suite runs both.
+# Gradient conventions (SURVEY App. A "Backward"), bit mask: three places where upstream gsplat 0.1.11's
+# backward, as recollected, is not the derivative of its forward, each a straight-through rule: 1 = back-propagate
+# through the fov clamp of x/z, y/z as if inactive; 2 = quaternion gradient w.r.t. the (assumed unit) quaternion, without
+# the projection through q/|q|; 4 = let the gradient pass the alpha = min(0.999, .) clamp.  0 = the true derivatives.
+# Default 6 (round 6): bits 2 and 4 follow the reference as recollected; bit 1 stays OPT-IN
+# (GSD_UPSTREAM_GRADS=7) until it can be checked against the fork's source — it is the one rule whose effect was measured
+# end to end, and it pushes one of four perturbed cameras AWAY in the pose-optimizer test (1.3 -> 3.8 cm) where the true
+# derivative of the clamp recovers all four.  The oracle has the same switch with the same default (its UP_* constants,
+# RenderConfig.upstream_grads) and the `-m gpu` suite runs the fused path under 7, 6 and 0.
 # Bit 2 only exists on the compat op (project_gaussians): the FUSED ops (render_subposes / render_combined / render_step)
 # take splatfacto's raw quaternions, i.e. they stand for `quats / quats.norm()` + the kernel, and the reference's
 # end-to-end gradient of that pair is J_norm^T g — exactly the gradient through the normalisation the fused kernels return.
-UPSTREAM_GRADS = int(os.environ.get("GSD_UPSTREAM_GRADS", "7"))
+UPSTREAM_GRADS = int(os.environ.get("GSD_UPSTREAM_GRADS", "6"))
 
 
 # 1 (default): rolling-shutter bands — the projection culls (band, Gaussian) pairs outside their band's tile rows (A/B: 0)
@@ -500,31 +505,53 @@ _ARENA_ATTEMPTS = 16    # first frame of a new scene: projections + partial fram
 _arena_pool = {}
 
 
-_arena_gen = {}          # arena address -> how many frames have leased it (a frame knows when its arena was recycled)
+class _Arena:
+    """a pooled frame arena: the memory and the number of the lease that last took it.  Lease numbers come from ONE
+    process-wide counter and live on this object, not in a table keyed by address (a dropped arena's
+    address can be handed out again by the allocator, and a per-address generation restarted at 1 let a stale frame pass
+    the recycled check)."""
+    __slots__ = ("tensor", "gen")
+
+    def __init__(self, tensor):
+        self.tensor, self.gen = tensor, 0
+
+    def numel(self):
+        return self.tensor.numel()
+
+    def data_ptr(self):
+        return self.tensor.data_ptr()
+
+
+_lease_counter = 0       # guarded by _state_lock
 
 
 class _ArenaLease:
-    __slots__ = ("tensor", "key", "gen")
+    __slots__ = ("arena", "key", "gen")
 
-    def __init__(self, tensor, key):
-        self.tensor, self.key = tensor, key
+    def __init__(self, arena: _Arena, key):
+        global _lease_counter
+        self.arena, self.key = arena, key
         with _state_lock:
-            self.gen = _arena_gen[tensor.data_ptr()] = _arena_gen.get(tensor.data_ptr(), 0) + 1
+            _lease_counter += 1
+            self.gen = arena.gen = _lease_counter
+
+    @property
+    def tensor(self):
+        a = self.arena
+        return None if a is None else a.tensor
 
     def release(self):
-        """hand the arena back to the pool (idempotent); the frame keeps its own reference to the memory and can tell
-        through `recycled` whether a later frame has leased it since"""
+        """hand the arena back to the pool (idempotent); the frame keeps its own reference to the _Arena and can tell
+        through its lease number whether a later frame has leased it since"""
         try:
             with _state_lock:
-                t, self.tensor = self.tensor, None
-                if t is None:
+                a, self.arena = self.arena, None
+                if a is None:
                     return
                 free = _arena_pool.setdefault(self.key, [])
-                free.append(t)
+                free.append(a)
                 if len(free) > 2:
-                    small = min(free, key=lambda x: x.numel())
-                    free.remove(small)
-                    _arena_gen.pop(small.data_ptr(), None)
+                    free.remove(min(free, key=lambda x: x.numel()))
         except Exception:       # interpreter shutdown
             pass
 
@@ -535,22 +562,43 @@ def _arena_acquire(dev, want_bytes: int) -> _ArenaLease:
     key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
     with _state_lock:
         free = _arena_pool.setdefault(key, [])
-        t = max(free, key=lambda x: x.numel()) if free else None
-        if t is not None:
-            free.remove(t)
-            if t.numel() < want_bytes:
-                _arena_gen.pop(t.data_ptr(), None)
-    if t is None or t.numel() < want_bytes:
-        t = None                # the short one goes back to torch's allocator before the larger one is requested
-        t = torch.empty(int(want_bytes), dtype=torch.uint8, device=dev)
-    return _ArenaLease(t, key)
+        free[:] = [x if isinstance(x, _Arena) else _Arena(x) for x in free]     # (tests seed the pool with bare tensors)
+        a = max(free, key=lambda x: x.numel()) if free else None
+        if a is not None:
+            free.remove(a)
+    if a is None or a.numel() < want_bytes:
+        a = None                # the short one goes back to torch's allocator before the larger one is requested
+        a = _Arena(torch.empty(int(want_bytes), dtype=torch.uint8, device=dev))
+    return _ArenaLease(a, key)
+
+
+def _arena_relend(frame) -> bool:
+    """a frame whose lease was handed back (its first backward ran) wants its arena once more (a second backward under
+    retain_graph=True): take the _Arena out of the free pool for the duration, so that no other thread can lease it
+    meanwhile.  Raises when a later frame has leased it since (its memory is no longer this frame's)."""
+    a = frame["arena_obj"]
+    with _state_lock:
+        free = _arena_pool.get(frame["lease"].key, [])
+        if a.gen != frame["gen"] or a not in free:
+            raise RuntimeError("this frame's arena was handed back after its first backward and a later frame has "
+                               "used it since: a second backward of one frame (retain_graph=True) must run before "
+                               "the next frame's forward")
+        free.remove(a)
+    return True
+
+
+def _arena_return(frame) -> None:
+    with _state_lock:
+        free = _arena_pool.setdefault(frame["lease"].key, [])
+        free.append(frame["arena_obj"])
+        if len(free) > 2:
+            free.remove(min(free, key=lambda x: x.numel()))
 
 
 def release_arenas() -> None:
     """drop every pooled frame arena (they return to torch's caching allocator)"""
     with _state_lock:
         _arena_pool.clear()
-        _arena_gen.clear()
 
 
 _pinned_cache = {}
@@ -626,7 +674,8 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     last_num_intersects = int(state.n_total)
     _slice_totals = [arena[sl.n_emitted_dev:sl.n_emitted_dev + 4].view(torch.int32)
                      for sl in (state.slice[i] for i in range(state.n_slices))]
-    return out_img, out_T, dict(arena=arena, lease=lease, gen=lease.gen, state=state, pix_vel=rs[0] if rs is not None else None,
+    return out_img, out_T, dict(arena=arena, arena_obj=lease.arena, lease=lease, gen=lease.gen, state=state,
+                                pix_vel=rs[0] if rs is not None else None,
                                 sample_times=rs[2] if shared else None)
 
 
@@ -636,12 +685,19 @@ def native_frame_backward(frame, records: Tensor, bg: Tensor, edges: Tensor, out
     cmb = combine if combine is not None else (None, 1.0, 0.0)
     arena, state = frame["arena"], frame["state"]
     lease = frame["lease"]
-    if lease.tensor is None:
-        with _state_lock:
-            if _arena_gen.get(arena.data_ptr()) != frame["gen"]:
-                raise RuntimeError("this frame's arena was handed back after its first backward and a later frame has "
-                                   "used it since: a second backward of one frame (retain_graph=True) must run before "
-                                   "the next frame's forward")
+    relent = lease.arena is None and _arena_relend(frame)
+    try:
+        _native_frame_backward(L, frame, arena, state, records, bg, edges, out_T, v_img, v_alpha, v_records, touched, cmb)
+    finally:
+        if relent:
+            _arena_return(frame)
+        else:
+            # the compositing backward is done with the arena: the next frame's forward may lease it (everything is
+            # ordered on one stream), whether or not this frame's autograd node outlives the backward
+            lease.release()
+
+
+def _native_frame_backward(L, frame, arena, state, records, bg, edges, out_T, v_img, v_alpha, v_records, touched, cmb):
     L.gs_frame_profile_enable(_profile_mask())
     st = L.gs_frame_backward(ctypes.byref(state), _ptr(records), _ptr(bg), _ptr(edges), _ptr(out_T), _ptr(v_img),
                              _ptr(v_alpha), _ptr(cmb[0]), float(cmb[1]), float(cmb[2]), _bwd_variant(), _ptr(v_records),
@@ -651,9 +707,6 @@ def native_frame_backward(frame, records: Tensor, bg: Tensor, edges: Tensor, out
         raise _lib.HipLibraryError("frame_backward: the forward's arena cannot hold the backward's buffers "
                                    "(call native_frame_forward with reserve_backward=True)")
     _check(st, "frame_backward")
-    # the compositing backward is done with the arena: the next frame's forward may lease it (everything is ordered on
-    # one stream), whether or not this frame's autograd node outlives the backward
-    lease.release()
 
 
 # --------------------------------------------------------------------------- #

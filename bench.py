@@ -401,14 +401,16 @@ def main():
     def stall_of(ms, st, k, extra=0.0):
         return ms - sum(sum(v) for v in st.values()) / k - extra
 
+    # `value` is the FIRST attempt, whatever the retries show (taking the last of 1-3 attempts selected
+    # toward the fastest); the retries only tell whether a stall repeats
     attempts = [round(dt / args.steps * 1e3, 4)]
     while (world == 1 and len(attempts) < 3 and
            stall_of(attempts[-1], stages, n_stage_steps, exchange_ms or 0.0) > 0.10 * attempts[-1]):
         ops.profiler = ops.StageProfiler(only={DOMINANT_STAGE})
-        dt = timed_region(wl, args.steps)
-        timed_dom = ops.profiler.summary_ms()
+        dt_again = timed_region(wl, args.steps)
         ops.profiler = None
-        attempts.append(round(dt / args.steps * 1e3, 4))
+        attempts.append(round(dt_again / args.steps * 1e3, 4))
+    stall_survives = stall_of(attempts[-1], stages, n_stage_steps, exchange_ms or 0.0) > 0.10 * attempts[-1]
     n_isect = ops.last_num_intersects
     slice_isects = list(ops.last_slice_intersects)
     slice_budget = wl.hints.slice_base()                    # (ops.SLICE_ADAPT: doubles after multi-slice frames)
@@ -436,8 +438,8 @@ def main():
         st2 = stage_pass(w2, 3)
         attempts2 = [round(dt2 / k2 * 1e3, 4)]
         while world == 1 and len(attempts2) < 3 and stall_of(attempts2[-1], st2, 3) > 0.10 * attempts2[-1]:
-            dt2 = timed_region(w2, k2)
-            attempts2.append(round(dt2 / k2 * 1e3, 4))
+            attempts2.append(round(timed_region(w2, k2) / k2 * 1e3, 4))
+        stall2_survives = stall_of(attempts2[-1], st2, 3) > 0.10 * attempts2[-1]
         ms2 = dt2 / k2 * 1e3
         # the secondary scene's own roofline block: its dominant kernel on the same bytes formula
         st2m = {k: sum(v) / 3 for k, v in st2.items()}
@@ -464,6 +466,7 @@ def main():
             "slice_budget": w2.hints.slice_base(),
             "stage_ms": {k: round(sum(v) / 3, 4) for k, v in st2.items()},
             "host_stall_ms": round(stall_of(ms2, st2, 3), 4), "timing_attempts_ms": attempts2,
+            "host_stall_survives_retries": bool(stall2_survives),
             "frame_hints": {"frames": w2.hints.frames, "arena_retries": w2.hints.arena_retries,
                             "arena_bytes": w2.hints.arena_bytes, "settled": w2.hints.settled, "warm_frames": warm2,
                             "lazy_records": bool(args.motion == "se3" and (ops.LAZY_RECORDS == 2 or
@@ -502,11 +505,12 @@ def main():
         stall_check = "ok"
         if world == 1:
             bad = [f"{tag} scene: {st:.3f} ms of a {ms:.3f} ms step no stage accounts for"
-                   for tag, st, ms in (("headline", host_stall, ms_per_step),
-                                       ("secondary", (secondary or {}).get("host_stall_ms", 0.0),
-                                        (secondary or {}).get("ms_per_step", 1.0))) if st > 0.10 * ms]
+                   for tag, st, ms, surv in (("headline", host_stall, ms_per_step, stall_survives),
+                                             ("secondary", (secondary or {}).get("host_stall_ms", 0.0),
+                                              (secondary or {}).get("ms_per_step", 1.0),
+                                              (secondary or {}).get("host_stall_survives_retries", False))) if surv]
             if bad:
-                stall_check = "FAILED after 3 timing attempts: " + "; ".join(bad)
+                stall_check = "FAILED: the stall of the first attempt survived 3 timing attempts: " + "; ".join(bad)
         else:
             stall_check = "reported only (N > 1: rank skew and the exchange live in the same remainder; see per_rank)"
         # dominant kernel = the single-kernel stage with the largest time per step (a depth-sliced step
@@ -654,6 +658,7 @@ def main():
             "exchange_ms": None if exchange_ms is None else round(exchange_ms, 4),
             "stage_ms": stage_ms,
             "host_stall_ms": round(host_stall, 4), "timing_attempts_ms": attempts,
+            "timing_attempt_reported": "first (retries only diagnose a host stall; they never replace the value)",
             "host_stall_check": stall_check,
             "stage_ms_source": f"{n_stage_steps} extra steps with HIP events around every stage, after the timed region",
             "roofline": roofline,

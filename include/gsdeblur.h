@@ -171,12 +171,6 @@ int gs_unpack_record_grads(int N, const float* v_records, float* v_xys, float* v
 /* ---- binning + sort (upstream map_gaussian_to_intersects, torch.sort, get_tile_bin_edges,
  * compute_cumulative_intersects) ------------------------------------------- */
 long long gs_scan_workspace_bytes(long long n);
-/* measurement / tests only (process-wide, not thread-safe): 1 = every radix pass below runs as ONE kernel (digit totals
- * of all passes counted up front, same-digit keys of earlier blocks by decoupled look-back), 0 (default, or
- * GSD_SORT_SINGLE_PASS in the environment) = histogram + scan + scatter.  Same results bit for bit; measured slower on
- * the tile sort and 5 % faster on the depth pre-sort at this pipeline's sizes.  Returns the previous
- * setting. */
-int gs_sort_set_single_pass(int on);
 long long gs_radix_sort_workspace_bytes(long long n, int begin_bit, int end_bit);
 /* exclusive prefix sum; *total_out (device, nullable) receives the grand total; in == out allowed */
 int gs_exclusive_scan_u32(long long n, const unsigned* in, unsigned* out, unsigned* total_out, void* ws,

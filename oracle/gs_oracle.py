@@ -53,10 +53,13 @@ TILE = 16
 #                      splatfacto's raw quaternions, i.e. it stands for `quats / quats.norm()` + the kernel, and the
 #                      reference's end-to-end gradient there is J_norm^T g — the true derivative of the normalising form
 #   UP_ALPHA_CLAMP (4) alpha = min(0.999, o e^{-sigma}): v_sigma = -o e^{-sigma} v_alpha with no clamp term
-# UPSTREAM = all three = the reference's conventions = the product's default (ops.UPSTREAM_GRADS = 7); 0 = the true
-# derivatives (what finite differences see; opt-in on the product side).
+# UPSTREAM = all three = the reference's conventions as recollected (opt-in on the product side: GSD_UPSTREAM_GRADS=7);
+# DEFAULT_GRADS = 6 = the product's default (ops.UPSTREAM_GRADS; round 6): the fov rule is the one convention whose
+# effect was measured end to end (it breaks the pose optimizer on one of four cameras) and cannot be checked against the
+# fork's source, so it is not a default; 0 = the true derivatives (what finite differences see).
 UP_FOV_CLAMP, UP_QUAT_RAW, UP_ALPHA_CLAMP = 1, 2, 4
 UPSTREAM = 7
+DEFAULT_GRADS = UP_QUAT_RAW | UP_ALPHA_CLAMP
 
 
 class _StraightThrough(torch.autograd.Function):
@@ -135,12 +138,12 @@ class Projected:
 
 def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy,
                       img_height, img_width, block_width=TILE, clip_thresh=0.01, keep_offscreen=False,
-                      upstream: int = UPSTREAM) -> Projected:
+                      upstream: int = DEFAULT_GRADS) -> Projected:
     """Restates gsplat.project_gaussians (absent fork).  dtype follows inputs.
     keep_offscreen=True keeps centre / conic / radius of Gaussians whose 3-sigma box covers no tile (only the
     near-plane and singular-covariance culls apply): the pixel-velocity model re-centres them per sub-pose.
     upstream: bit mask of UP_FOV_CLAMP / UP_QUAT_RAW (gradient conventions only; every value is unchanged); default:
-    the reference's conventions, like the product's compat op."""
+    DEFAULT_GRADS, like the product's compat op."""
     assert block_width == TILE
     dt = means3d.dtype
     V = viewmat.to(dt)
@@ -363,7 +366,7 @@ class Rasterized:
 
 def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.ndarray, tile_bins: np.ndarray,
                      img_height: int, img_width: int, background: Optional[torch.Tensor] = None,
-                     tile_rows: Optional[Tuple[int, int]] = None, row_shift=None, upstream: int = UPSTREAM) -> Rasterized:
+                     tile_rows: Optional[Tuple[int, int]] = None, row_shift=None, upstream: int = DEFAULT_GRADS) -> Rasterized:
     """Front-to-back alpha compositing of pre-sorted intersections, differentiable by autograd.
     row_shift = (pix_vel [N,2], tau [H]): pixel row y evaluates every splat at xys + tau[y] * pix_vel (the exact
     rolling-shutter form of the pixel-velocity model).
@@ -453,7 +456,7 @@ def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.nda
 
 def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
                         block_width=TILE, background=None, return_alpha=False, proj: Optional[Projected] = None,
-                        upstream: int = UPSTREAM):
+                        upstream: int = DEFAULT_GRADS):
     """gsplat.rasterize_gaussians restated (bin + sort + composite).  Needs tile bounds, which upstream
     recomputes from xys/radii; here they are recomputed the same way when `proj` is not given."""
     assert block_width == TILE
@@ -596,9 +599,9 @@ class RenderConfig:
     # one sorted list per tile, every sample walks it and evaluates a splat at xy_c + (t_s - t_c + tau(y)) * velocity.
     # The per-sample lists (shared_list False) cut each splat at its own 3-sigma box; this form cuts it at the swept box.
     shared_list: bool = False
-    # gradient conventions (bit mask, see UP_* at the top): UPSTREAM (7, default) = the reference's, as recollected —
-    # the product's default; 0 = true derivatives.  render() is the FUSED path: UP_QUAT_RAW does not apply to it.
-    upstream_grads: int = UPSTREAM
+    # gradient conventions (bit mask, see UP_* at the top): DEFAULT_GRADS (6) = the product's default; UPSTREAM (7) = the
+    # reference's, as recollected; 0 = true derivatives.  render() is the FUSED path: UP_QUAT_RAW does not apply to it.
+    upstream_grads: int = DEFAULT_GRADS
 
 
 def combine_samples(samples: torch.Tensor, gamma: float, min_rgb_level: float) -> torch.Tensor:
@@ -613,7 +616,7 @@ def combine_samples(samples: torch.Tensor, gamma: float, min_rgb_level: float) -
 
 
 def pixel_velocity(means3d, viewmat, fx, fy, lin_vel, ang_vel, clip_thresh=0.01, img_width=None, img_height=None,
-                   upstream: int = UPSTREAM):
+                   upstream: int = DEFAULT_GRADS):
     """[N,2] pixel velocity of every Gaussian centre under the camera's body twist (lin, ang in the OpenCV camera
     frame): a static point moves in camera space with u = -(ang x p_c + lin), its pixel with J u, J = the pinhole
     Jacobian where the covariance projection takes its own: at the centre with x/z, y/z clamped to the fov guard band

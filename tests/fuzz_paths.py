@@ -84,7 +84,7 @@ for trial in range(trials):
              # round 5: lazy records (never / always), drawn from a generator of its own so that the older draws — and
              # with them every trial of an earlier seed — stay what they were
              "LAZY_RECORDS": random.Random(seed * 7919 + trial).choice([0, 2])}
-    single_pass = rng.choice([0, 1])
+    single_pass = rng.choice([0, 1])      # (round 6: the single-pass sort is gone; the draw stays so that earlier seeds replay)
     rs_time = 0.0
     if pixvel:
         rs_time = rng.choice([0.0, 0.0, 1 / 30])
@@ -114,7 +114,6 @@ for trial in range(trials):
                 for k in KNOBS:
                     setattr(ops, k, saved[k])
                 ops.SLICE_BASE = 0
-            _L.gs_sort_set_single_pass(0 if plain else single_pass)
             if not plain:
                 ops.SLICE_BASE = base
             p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
@@ -140,7 +139,6 @@ for trial in range(trials):
     finally:
         for k, v in saved.items():
             setattr(ops, k, v)
-        _L.gs_sort_set_single_pass(0)
     (img_f, al_f, g_f, nsl), (img_p, al_p, g_p, _) = res
     ok = torch.equal(img_f, img_p) and torch.equal(al_f, al_p)
     worst, worst_key = 0.0, ""

@@ -239,20 +239,21 @@ def test_velocity_optimizer_recovers_known_velocities_from_rolling_shutter_frame
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("convention", [0, 7])
+@pytest.mark.parametrize("convention", [0, 6, 7])
 def test_pose_optimizer_pulls_perturbed_cameras_back_to_the_true_pose(gs, dev, convention):
     """--camera-optimizer.mode=SO3xR3 (/root/reference/train.py:40), end to end: ground-truth Gaussians (constants),
     sharp frames rendered from the TRUE poses, cameras handed to the model with a known perturbation (composed in the
     camera frame, c2w @ exp(delta), as nerfstudio's camera optimizer does).  Through the rasterizer's viewmat gradients
     alone the pose adjustment must undo it: the composed pose c2w_perturbed @ exp(adj) ends closer to the true pose in
     translation AND rotation — which pins the viewmat gradient's frame, sign and the OpenGL -> OpenCV flip.
-    Round 5, `convention` = ops.UPSTREAM_GRADS: with the TRUE derivatives (0) all four frames recover (0.03-0.8 cm).  With
-    the reference's conventions as recollected (7, the product's default since round 5) three do and frame 3 — whose view
+    `convention` = ops.UPSTREAM_GRADS: with the TRUE derivatives (0) and with the product's DEFAULT (6, round 6) all four
+    frames must recover (0.03-0.8 cm) — the default configuration is not given a relaxed bar.  With all three of the
+    reference's conventions as recollected (7, opt-in) three do and frame 3 — whose view
     holds large splats centred beyond the 1.3 tan(fov/2) guard band — is pushed AWAY (1.3 -> 3.8 cm): the straight-through
     gradient of the fov clamp (bit 1) tells the optimizer that moving the camera changes those splats' footprints when it
     does not (bisected on the GPU: masks 7 and 3 fail, 6 and 0 recover; the other reading of "as if inactive", the VJP of
     the unclamped EWA projection, was built and loses 11.8 cm).  Recorded here as what that convention costs, DESIGN.md
-    §1.2; GSD_UPSTREAM_GRADS=6 keeps the other two conventions and the pose optimizer."""
+    §1.2; that measurement is why the default is 6."""
     import math
     from gsdeblur_amd import ops
     saved_convention = ops.UPSTREAM_GRADS
@@ -318,7 +319,7 @@ def _pose_optimizer_case(gs, dev, convention):
               f"rotation error {math.degrees(r0):.2f} -> {math.degrees(r1):.2f} deg")
         recovered[i] = last < 0.5 * first[i] and t1 < 0.6 * t0 and r1 < 0.6 * r0
     print(f"pose optimizer, gradient convention {convention}: frames recovered {recovered}")
-    if convention == 0:
+    if convention in (0, 6):
         assert all(recovered.values()), recovered
     else:
         assert sum(recovered.values()) >= 3 and recovered[1] and recovered[5], recovered

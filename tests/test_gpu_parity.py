@@ -46,9 +46,9 @@ def rel_max(a, b):
 
 import contextlib  # noqa: E402
 
-# the two gradient conventions every oracle comparison of the fused path can run under (round 5): 7 = the reference's, as
-# recollected (ops.UPSTREAM_GRADS default, oracle RenderConfig.upstream_grads default), 0 = the true derivatives;
-# a fixture stores the gradients of both (gu_* / g_*)
+# the two gradient conventions the FIXTURES store (gu_* / g_*): 7 = the reference's, as recollected (opt-in since round
+# 6), 0 = the true derivatives.  The default on both sides is 6 (ops.UPSTREAM_GRADS, oracle DEFAULT_GRADS: 7 without the
+# fov rule): the live-oracle comparisons (baseline configs, convention switches, smoke) run under it as well
 CONVENTIONS = [pytest.param(7, id="upstream-grads"), pytest.param(0, id="true-derivatives")]
 
 
@@ -161,21 +161,10 @@ def test_exclusive_scan(gs, dev, n):
     assert int(total.item()) == int(x.long().sum())
 
 
-@pytest.fixture(params=[0, 1], ids=["three_kernel_passes", "single_pass"])
-def sort_form(request, gs, dev):
-    """both forms of a radix pass (include/gsdeblur.h: gs_sort_set_single_pass): histogram + scan + scatter, and the
-    single-pass scatter with decoupled look-back — same results bit for bit"""
-    from gsdeblur_amd import _lib
-    L = _lib.load()
-    old = L.gs_sort_set_single_pass(request.param)
-    yield request.param
-    L.gs_sort_set_single_pass(old)
-
-
 @pytest.mark.parametrize("n,bits,dtype", [(1, 8, torch.int32), (4097, 16, torch.int32), (300_001, 17, torch.int32),
                                           (1_000_003, 32, torch.int32), (200_003, 45, torch.int64),
                                           (50_001, 35, torch.int64), (70_000, 13, torch.int32)])
-def test_radix_sort_stable(gs, dev, sort_form, n, bits, dtype):
+def test_radix_sort_stable(gs, dev, n, bits, dtype):
     """ascending, STABLE (ties keep input order), payload follows; keys limited to `bits` bits."""
     g = torch.Generator().manual_seed(bits * 1000 + n % 997)
     hi = 2 ** min(bits, 62)
@@ -198,7 +187,7 @@ def test_radix_sort_stable(gs, dev, sort_form, n, bits, dtype):
 
 @pytest.mark.parametrize("n,bits,cap", [(1, 8, 0), (4097, 16, 0), (300_001, 17, 0), (70_000, 16, 200_000),
                                         (1_000_003, 24, 0)])
-def test_radix_sort_carries_a_second_payload(gs, dev, sort_form, n, bits, cap):
+def test_radix_sort_carries_a_second_payload(gs, dev, n, bits, cap):
     """the tile sort's form: payload = input index (iota), second payload carried along with the keys through every
     pass (instead of gathered by payload afterwards); optionally with the element count on the device"""
     g = torch.Generator().manual_seed(n + bits)
@@ -222,7 +211,7 @@ def test_radix_sort_carries_a_second_payload(gs, dev, sort_form, n, bits, cap):
 
 
 @pytest.mark.parametrize("P,N", [(1, 5000), (5, 4097), (3, 100_003), (10, 4096)])
-def test_segmented_sort_stable(gs, dev, sort_form, P, N):
+def test_segmented_sort_stable(gs, dev, P, N):
     """every segment sorted independently, ascending, stable; payload = global index"""
     from gsdeblur_amd import ops
     g = torch.Generator().manual_seed(P * 7 + N)
@@ -243,7 +232,7 @@ def test_segmented_sort_stable(gs, dev, sort_form, P, N):
                                                 # 8.5 M keys = 24 index bits: the tile counts packed into the payload
                                                 # (round 5, 8-bit digits) saturate at 255 and are looked up instead
                                                 (5, 1_700_000, 0.25, 3000), (2, 300_000, 0.5, 9000)])
-def test_depth_rank_compacting(gs, dev, sort_form, P, N, keep, digit, max_tiles):
+def test_depth_rank_compacting(gs, dev, P, N, keep, digit, max_tiles):
     """compacting depth pre-sort: culled keys dropped by the first pass, survivors sorted stably at the start of their
     segment, their tile counts gathered by the last pass, the segment-aware scan treats everything behind as zero;
     the result is the same ranking / prefix the full sort + gather + scan produce"""
@@ -697,21 +686,22 @@ def test_fused_path_vs_oracle_integers_and_image(gs, oracle, dev, S, R, W, H, n)
     assert (out.detach().cpu().double() - ref)[good].abs().max().item() < 5e-4
 
 
-# (round 5: up = the gradient convention, 7 = the reference's (default on both sides), 0 = true derivatives; configs 3 and 4
-#  run under both, configs 2 and 5 — a minute of float64 oracle each — under the default; the golden fixtures, the
-#  full-size fixtures and test_upstream_gradient_convention_switches compare under both as well)
+# (up = the gradient convention on both sides: 6 = the default since round 6, 7 = the reference's as recollected, 0 = true
+#  derivatives; configs 3 and 4 run under 7 and 0, configs 2 and 5 — a minute of float64 oracle each — under the default;
+#  the golden fixtures and the full-size fixtures compare under 7 and 0, test_upstream_gradient_convention_switches under
+#  every mask)
 @pytest.mark.parametrize("tag,S,R,W,H,n,mult,up", [
-    ("config2: 5 motion-blur sub-poses", 5, 1, 240, 136, 6000, 5.0, 7),
+    ("config2: 5 motion-blur sub-poses", 5, 1, 240, 136, 6000, 5.0, 6),
     ("config3: 10 rolling-shutter bands", 1, 10, 160, 240, 5000, 5.0, 7),
     ("config3: 10 rolling-shutter bands", 1, 10, 160, 240, 5000, 5.0, 0),
     ("config4: 5 samples x 2 bands", 5, 2, 176, 112, 3600, 5.0, 7),
     ("config4: 5 samples x 2 bands", 5, 2, 176, 112, 3600, 5.0, 0),
-    ("config5: 10 motion-blur sub-poses", 10, 1, 160, 96, 2800, 5.0, 7)])
+    ("config5: 10 motion-blur sub-poses", 10, 1, 160, 96, 2800, 5.0, 6)])
 def test_baseline_configs_vs_float64_oracle_image_and_per_element_gradients(gs, oracle, dev, tag, S, R, W, H, n, mult, up):
     """BASELINE.json configs 2-5 at reduced N / resolution with the SAME sub-pose structure (S, R), SH degree 3,
     gamma 2.2, min-rgb 10: per-sample composites and the averaged image against the float64 oracle, and every
     gradient ELEMENT-wise (|d| <= 1e-4 |g| + 1e-5 max|g|); at most 10 % of the pixels may be threshold-fragile.
-    Round 5: `up` = the gradient convention on both sides (7: the reference's, the default; 0: true derivatives); a tenth
+    `up` = the gradient convention on both sides (6: the default; 7: the reference's as recollected; 0: true derivatives); a tenth
     of the opacities is raised to ~1 so that the alpha clamp the two differ on is really reached."""
     with grad_convention(up):
         _baseline_config_vs_oracle(gs, oracle, dev, tag, S, R, W, H, n, mult, up)
@@ -890,10 +880,10 @@ def test_real_camera_pose_and_grazing_gaussians_vs_oracle(gs, oracle, dev, model
 
 def test_upstream_gradient_convention_switches(gs, oracle, dev):
     """DESIGN.md §1.2, VERDICT round 4 item 2: the reference's three gradient conventions (recollected from gsplat
-    0.1.11; ops.UPSTREAM_GRADS bit mask, default 7 = all on) against the ORACLE's implementation of each
+    0.1.11; ops.UPSTREAM_GRADS bit mask, default 6 = all but the fov rule) against the ORACLE's implementation of each
     (gs_oracle.UP_*, straight-through rules), on a scene built so that every one of them matters: a tenth of the
     Gaussians beyond the 1.3 tan(fov/2) guard band, non-unit quaternions, opacities of ~1 (alpha reaches the 0.999 clamp;
-    no antialiasing compensation).  For every mask in {0, 1, 4, 5, 7}: same image, every gradient of the FUSED path per
+    no antialiasing compensation).  For every mask in {0, 1, 4, 5, 6, 7}: same image, every gradient of the FUSED path per
     element against the float64 oracle in that mode, and the modes really differ from each other.  Bit 2 (raw
     quaternion gradient) exists on the compat op only: there against the oracle's UP_QUAT_RAW; the fused path ignores it."""
     from gsdeblur_amd import ops
@@ -939,7 +929,7 @@ def test_upstream_gradient_convention_switches(gs, oracle, dev):
         return {k: v.grad.clone() for k, v in q.items()}
 
     hip, ref = {}, {}
-    for flags in (0, 1, 4, 5, 7):
+    for flags in (0, 1, 4, 5, 6, 7):
         img, hip[flags] = run(flags)
         ref[flags] = run_oracle(flags)
         if flags:
@@ -973,6 +963,7 @@ def test_upstream_gradient_convention_switches(gs, oracle, dev):
     assert (hip[4]["op"] - hip[0]["op"])[200:].abs().max().item() < 1e-6 * (hip[0]["op"].abs().max().item() + 1e-12)
     for k in hip[7]:
         assert torch.equal(hip[7][k], hip[5][k]), k        # bit 2 does not exist on the fused path
+        assert torch.equal(hip[6][k], hip[4][k]), k        # (the default, 6, is the alpha rule alone there)
     # compat op: raw quaternion gradient (bit 2) and straight-through fov clamp (bit 1) against the oracle's modes
     wc = torch.rand(n, 3, generator=torch.Generator().manual_seed(3))
     wx = torch.rand(n, 2, generator=torch.Generator().manual_seed(4))
@@ -2128,43 +2119,6 @@ def test_native_frame_arena_converges_over_many_ever_larger_slices(gs, dev):
         ops.release_arenas()
     assert planned >= 6, planned
     assert torch.equal(ref, got)
-
-
-def test_single_pass_sorts_give_the_same_frame(gs, dev):
-    """the radix passes as single kernels (decoupled look-back).  Measured slower on the tile
-    sort at this pipeline's sizes, so not the default; the whole frame through them — multi-slice, rolling-shutter
-    bands — must equal the default frame bit for bit (sorting is exact integer work)."""
-    from gsdeblur_amd import ops, _lib
-    L = _lib.load()
-    n, W, H, S, R = 60000, 208, 144, 2, 2
-    sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=17, scale_mult=6.0, profile="trained"), dev)
-    times, _, _ = gs.subpose_schedule(S, 1 / 60, R, 1 / 30)
-    times_t = torch.tensor(times, device=dev)
-    wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(6)).to(dev)
-    saved = ops.SLICE_BASE
-    res = []
-    try:
-        ops.SLICE_BASE = 16
-        for form in (0, 1):
-            old = L.gs_sort_set_single_pass(form)
-            try:
-                p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
-                vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"] * 5, sc["ang_vel"] * 3, times_t)
-                rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
-                                                        torch.sigmoid(p["opacity_logits"]), p["sh"], vms, None, S, R,
-                                                        sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2)
-                (rgb * wt).sum().backward()
-                res.append((rgb.detach().clone(), alphas.detach().clone(), {k: v.grad.clone() for k, v in p.items()},
-                            [int(v) for v in ops.last_slice_intersects if int(v) > 0]))
-            finally:
-                L.gs_sort_set_single_pass(old)
-    finally:
-        ops.SLICE_BASE = saved
-    a, b = res
-    assert len(a[3]) >= 2 and a[3] == b[3]
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    for k in a[2]:
-        assert torch.equal(a[2][k], b[2][k]), k
 
 
 def test_native_frame_merges_slices_of_a_frame_that_does_not_saturate(gs, dev):
