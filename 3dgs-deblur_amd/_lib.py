@@ -43,6 +43,9 @@ _SIGS = {
     "gs_segmented_sort_pairs_u32": [_L, _L, _P, _P, _P, _P, _I, _I, _I, _P, _L, ctypes.POINTER(_I), _P],
     "gs_segmented_sort_compact_u32": [_L, _L, _P, _P, _P, _P, _I, _I, _I, ctypes.c_uint, _P, _P, _P, _P, _L,
                                       ctypes.POINTER(_I), _P],
+    "gs_segmented_sort_select_u32": [_L, _L, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_uint, _P, _P, _P, _P, _P, _P, _L,
+                                     ctypes.POINTER(_I), _P],
+    "gs_depth_select": [_L, _L, _P, _P, _L, _P, _P, _P, _L, _P],
     "gs_exclusive_scan_segments_u32": [_L, _L, _P, _P, _P, _P, _P, _L, _P],
     "gs_make_depth_keys64": [_L, _I, _P, _P, _P],
     "gs_gather_counts": [_L, _P, _P, _P, _P],
@@ -54,6 +57,7 @@ _SIGS = {
     "gs_rasterize_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P],
     "gs_rasterize_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P],
     "gs_slice_plan": [_I, _I, _I, _P, _P, _L, _P, _P, _P, _P, _P, _P],
+    "gs_slice_plan_select": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gs_tile_open_sat": [_I, _I, _I, _P, _P, _P, _P, _P],
     "gs_slice_counts": [_I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "gs_emit_open_intersects": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, ctypes.c_uint, _I, _I, _P, _P, _P, _P],
@@ -86,6 +90,7 @@ _SIGS_LL = {
     "gs_radix_sort_workspace_bytes": [_L, _I, _I],
     "gs_segmented_sort_workspace_bytes": [_L, _L, _I, _I],
     "gs_segmented_sort_compact_workspace_bytes": [_L, _L, _I, _I, _I],
+    "gs_depth_select_workspace_bytes": [_I],
     "gs_image_loss_workspace_bytes": [_I, _I],
     "gs_frame_backward_bytes": [_P],
 }

@@ -241,6 +241,21 @@ struct SegDev {
   unsigned* cnt_out;         // compacting pass: per-segment survivor count (written by the scatter kernel), else NULL
   const unsigned* total;     // compacting pass: grand total of the pass's histogram scan (device)
   unsigned long long skip;   // compacting pass: the key value that is dropped
+  // compacting pass of a nearest-first selection (round 6, 32-bit keys): segment s only keeps keys in
+  // [key_lo[s], key_hi[s]) — either bound nullable (device arrays: the bounds come out of gs_depth_select)
+  const unsigned* key_lo;
+  const unsigned* key_hi;
+};
+
+// which keys the compacting first pass of a block drops: the skip marker, and what lies outside its segment's range
+template <typename KeyT>
+struct KeepTest {
+  KeyT skip, lo, hi;
+  bool on, has_hi;
+  __device__ __forceinline__ KeepTest(const SegDev& sd, unsigned seg)
+      : skip((KeyT)sd.skip), lo(sd.key_lo ? (KeyT)sd.key_lo[seg] : (KeyT)0), hi(sd.key_hi ? (KeyT)sd.key_hi[seg] : (KeyT)0),
+        on(sd.cnt_out != nullptr), has_hi(sd.key_hi != nullptr) {}
+  __device__ __forceinline__ bool drop(KeyT k) const { return on && (k == skip || k < lo || (has_hi && k >= hi)); }
 };
 
 template <typename KeyT, int BITS>
@@ -279,6 +294,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* _
     k[r] = i < limit ? keys[i] : (KeyT)0;
   }
   const int lane = lane_id();
+  const KeepTest<KeyT> keep(sd, seg);
   // Same-address LDS atomics serialise (~5 cycles per lane): a digit that takes three values over a whole block
   // — the top byte of a depth key — made this kernel 2.5x slower than on uniform digits.  A wave whose first
   // round is that skewed counts every round's lanes in groups (ONE atomic per distinct digit among the first few
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* _
   bool skewed;
   {
     const size_t i0 = base + threadIdx.x;
-    const bool ok0 = i0 < limit && !(sd.cnt_out && k[0] == (KeyT)sd.skip);
+    const bool ok0 = i0 < limit && !keep.drop(k[0]);
     const unsigned d = (unsigned)(k[0] >> shift) & mask;
     const unsigned long long m = __ballot(ok0);
     const unsigned d0 = (unsigned)readlane_i((int)d, m ? __ffsll((long long)m) - 1 : 0);
@@ -296,7 +312,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* _
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       size_t i = base + (size_t)r * 256 + threadIdx.x;
-      const bool ok = i < limit && !(sd.cnt_out && k[r] == (KeyT)sd.skip);
+      const bool ok = i < limit && !keep.drop(k[r]);
       const unsigned d = (unsigned)(k[r] >> shift) & mask;
       unsigned long long todo = __ballot(ok);
 #pragma unroll 1
@@ -313,7 +329,7 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(size_t n, const KeyT* _
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       size_t i = base + (size_t)r * 256 + threadIdx.x;
-      if (i < limit && !(sd.cnt_out && k[r] == (KeyT)sd.skip)) atomicAdd(&hist[(unsigned)(k[r] >> shift) & mask], 1u);
+      if (i < limit && !keep.drop(k[r])) atomicAdd(&hist[(unsigned)(k[r] >> shift) & mask], 1u);
     }
   }
   __syncthreads();
@@ -369,7 +385,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
   size_t limit = min(n, (size_t)(seg + 1) * sg.seg_len);
   if (sd.cnt_in) limit = min(limit, (size_t)seg * sg.seg_len + sd.cnt_in[seg]);
   const bool compacting = sd.cnt_out != nullptr;
-  const KeyT skip = (KeyT)sd.skip;
+  const KeepTest<KeyT> keep(sd, seg);
   const size_t wbase = bbase + (size_t)wave * (R * 64);
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   KeyT key[R];
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     size_t i = wbase + (size_t)r * 64 + lane;
-    bool valid = i < limit && !(compacting && key[r] == skip);
+    bool valid = i < limit && !keep.drop(key[r]);
     unsigned digit = (unsigned)(key[r] >> shift) & mask;
     unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -462,7 +478,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
     for (int q = 0; q < RB; ++q) {
       const int r = r0 + q;
       size_t i = wbase + (size_t)r * 64 + lane;
-      if (i < limit && !(compacting && key[r] == skip)) {
+      if (i < limit && !keep.drop(key[r])) {
         unsigned digit = (unsigned)(key[r] >> shift) & mask;
         unsigned slot = cnt[wave][digit] + pos[r];
         s_keys[slot] = key[r];
@@ -509,7 +525,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
       for (int q = 0; q < RB; ++q) {
         const int r = r0 + q;
         size_t i = wbase + (size_t)r * 64 + lane;
-        if (i < limit && !(compacting && key[r] == skip)) {
+        if (i < limit && !keep.drop(key[r])) {
           unsigned digit = (unsigned)(key[r] >> shift) & mask;
           s_vals[cnt[wave][digit] + pos[r]] = pv[q];
         }
@@ -575,7 +591,7 @@ template <typename KeyT, int BITS>
 static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned* vin, KeyT* kout, unsigned* vout,
                        int shift, unsigned mask, void* ws, size_t hist_bytes, hipStream_t st,
                        const unsigned* gather_src = nullptr, unsigned* gather_out = nullptr,
-                       const unsigned* n_dev = nullptr, SegDev sd = SegDev{nullptr, nullptr, nullptr, 0ull},
+                       const unsigned* n_dev = nullptr, SegDev sd = SegDev{nullptr, nullptr, nullptr, 0ull, nullptr, nullptr},
                        const unsigned* p2_in = nullptr, unsigned* p2_out = nullptr, int pack = 0, int pack_bits = 0) {
   SegInfo sg;
   unsigned nblk = sort_nblk_seg<KeyT>(n, seg_len, &sg.nblk_seg);
@@ -614,7 +630,10 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
                       int max_digit = 11, const unsigned* gather_src = nullptr, unsigned* gather_out = nullptr,
                       const unsigned* n_dev = nullptr, unsigned* seg_counts = nullptr,
                       unsigned long long skip_key = 0ull, const unsigned* p2_src = nullptr, unsigned* p2_a = nullptr,
-                      unsigned* p2_b = nullptr, int* result_p2 = nullptr) {
+                      unsigned* p2_b = nullptr, int* result_p2 = nullptr, const KeyT* k_src = nullptr,
+                      const unsigned* key_lo = nullptr, const unsigned* key_hi = nullptr) {
+  // k_src != NULL: the FIRST pass reads its keys from k_src (left intact) instead of k0 — k0 / k1 are both scratch then
+  // key_lo / key_hi (compacting sorts only, device arrays per segment, either nullable): see SegDev
   // p2_src != NULL: a second payload travels with every key (p2_src[i] belongs to input element i); pass p writes it
   // to p2_a (even p) / p2_b (odd p), *result_p2 = 0 / 1 says which of the two holds the sorted result
   // seg_counts != NULL: compacting segmented sort (see SegDev) — keys equal to skip_key are dropped by the first
@@ -649,8 +668,8 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
       // the pass's grand total lives in the slack at the end of the workspace
       unsigned* total_dev = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) +
                                                         radix_ws_bytes<KeyT>(n, seg_len, bits, max_digit) - 128);
-      if (p == 0) sd = SegDev{nullptr, seg_counts, total_dev, skip_key};
-      else sd = SegDev{seg_counts, nullptr, nullptr, 0ull};
+      if (p == 0) sd = SegDev{nullptr, seg_counts, total_dev, skip_key, key_lo, key_hi};
+      else sd = SegDev{seg_counts, nullptr, nullptr, 0ull, nullptr, nullptr};
     }
     const unsigned* p2i = nullptr;
     unsigned* p2o = nullptr;
@@ -658,11 +677,12 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
       p2o = (p & 1) ? p2_b : p2_a;
       p2i = p == 0 ? p2_src : ((p & 1) ? p2_a : p2_b);
     }
+    const KeyT* kin = (p == 0 && k_src) ? k_src : kk[cur];
     switch (tb) {
-      case 8:  radix_pass<KeyT, 8>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, pack, pack_bits); break;
-      case 9:  radix_pass<KeyT, 9>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
-      case 10: radix_pass<KeyT, 10>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
-      default: radix_pass<KeyT, 11>(n, seg_len, kk[cur], vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
+      case 8:  radix_pass<KeyT, 8>(n, seg_len, kin, vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, pack, pack_bits); break;
+      case 9:  radix_pass<KeyT, 9>(n, seg_len, kin, vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
+      case 10: radix_pass<KeyT, 10>(n, seg_len, kin, vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
+      default: radix_pass<KeyT, 11>(n, seg_len, kin, vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
     }
     shift += w;
     cur ^= 1;
@@ -974,7 +994,9 @@ __global__ void slice_plan_kernel(int P, int N, int K, const unsigned* __restric
                                   const unsigned* __restrict__ total, unsigned long long base,
                                   int* __restrict__ bounds, unsigned* __restrict__ rels,
                                   unsigned* __restrict__ seg_totals, const unsigned* __restrict__ n_live,
-                                  unsigned* __restrict__ tail /*nullable: [P] live ranks, then the grand total*/) {
+                                  unsigned* __restrict__ tail /*nullable: [P] live ranks, then the grand total*/,
+                                  const unsigned* __restrict__ grand /*nullable: the frame's total when `total` only
+                                                                       covers a selection of its pairs*/) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P * K) return;
   const int p = i / K, k = i % K;
@@ -993,7 +1015,7 @@ __global__ void slice_plan_kernel(int P, int N, int K, const unsigned* __restric
   if (k == 0 && seg_totals) seg_totals[p] = seg_end - c0;     // the sub-pose's own total (mod 2^32)
   if (tail) {           // everything the host reads back sits in one buffer: one copy, no staging launches
     if (k == 0) tail[p] = (unsigned)M;
-    if (i == 0) tail[P] = *total;
+    if (i == 0) tail[P] = grand ? *grand : *total;
   }
 }
 
@@ -1402,6 +1424,134 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Nearest-first selection (round 6).  A frame whose tiles saturate early composites a few percent of its visible
+// (sub-pose, Gaussian) pairs — the benchmark scene's one depth slice holds 55 k of 3.95 M — yet the depth pre-sort
+// ordered all of them (0.21 ms + a 5 M-rank count scan).  Here a two-level radix SELECT over the 31 key bits of the
+// visible pairs (bits 30..20, then 19..9: a float's exponent and 14 mantissa bits) finds, per sub-pose, the key bound
+// thr such that the pairs with key < thr hold at least `budget` bounding-box pairs (weights = num_tiles_hit) and no
+// whole 512-ulp bucket could be left out; the compacting sort then keeps and orders ONLY those (SegDev key_hi), and the
+// pairs behind the bound are sorted later, if the frame's first slice leaves a tile open (SegDev key_lo).  Where the
+// bound falls changes nothing in the images: a slice boundary never does.
+// Each level is ONE launch: blocks histogram their share of the segment in LDS (64-bit sums), add it to the segment's
+// global histogram, and the segment's last block to finish (ticket counter) walks the 2048 totals.
+// ---------------------------------------------------------------------------
+constexpr int kSelBits = 11, kSelBins = 1 << kSelBits;
+struct SelSeg {                                // per segment, zeroed by the caller before level 0
+  unsigned long long hist[2][kSelBins];
+  unsigned long long before;                   // level 0: weight of the buckets in front of b1
+  unsigned long long grand;                    // level 0: weight of every visible pair of the segment
+  unsigned done[2];
+  unsigned b1;                                 // level 0: the bucket the bound falls into (kSelBins: everything is selected)
+  unsigned pad;
+};
+
+__device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long long v, unsigned long long& total,
+                                                               unsigned long long* lds /*[8]*/) {
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  unsigned long long inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  const unsigned long long w0 = lds[0], w1 = lds[1], w2 = lds[2], w3 = lds[3];
+  const unsigned long long woff = wave == 0 ? 0ull : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+  total = w0 + w1 + w2 + w3;
+  __syncthreads();
+  return woff + inc - v;
+}
+
+constexpr int kSelRounds = 8;                  // keys per thread and chunk: 2048-key chunks
+template <int LEVEL>
+__global__ __launch_bounds__(256) void depth_select_kernel(size_t seg_len, const unsigned* __restrict__ keys,
+                                                           const unsigned* __restrict__ weights,
+                                                           unsigned long long budget, SelSeg* __restrict__ ws,
+                                                           unsigned* __restrict__ thr_out,
+                                                           unsigned* __restrict__ grand_out) {
+  __shared__ unsigned long long h[kSelBins];
+  __shared__ unsigned long long s_scan[8];
+  __shared__ unsigned s_flag, s_found;
+  const unsigned seg = blockIdx.y;
+  SelSeg& S = ws[seg];
+  unsigned b1 = 0;
+  if (LEVEL == 1) {
+    b1 = S.b1;                                 // (written by level 0's last block: a kernel boundary lies in between)
+    if (b1 >= (unsigned)kSelBins) {            // every visible pair is selected: level 0 wrote the bound already
+      return;
+    }
+  }
+  for (int d = threadIdx.x; d < kSelBins; d += 256) h[d] = 0ull;
+  __syncthreads();
+  const size_t seg_base = (size_t)seg * seg_len, limit = seg_base + seg_len;
+  for (size_t base = seg_base + (size_t)blockIdx.x * (256 * kSelRounds); base < limit;
+       base += (size_t)gridDim.x * (256 * kSelRounds)) {
+    unsigned k[kSelRounds], w[kSelRounds];
+#pragma unroll
+    for (int r = 0; r < kSelRounds; ++r) {
+      const size_t i = base + (size_t)r * 256 + threadIdx.x;
+      k[r] = i < limit ? keys[i] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int r = 0; r < kSelRounds; ++r) {
+      const size_t i = base + (size_t)r * 256 + threadIdx.x;
+      // (visible keys are positive floats: bit 31 marks a culled pair)
+      const bool ok = (k[r] >> 31) == 0u && (LEVEL == 0 || (k[r] >> 20) == b1);
+      w[r] = (ok && i < limit) ? weights[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < kSelRounds; ++r)
+      if (w[r]) atomicAdd(&h[LEVEL == 0 ? (k[r] >> 20) : ((k[r] >> 9) & (unsigned)(kSelBins - 1))], (unsigned long long)w[r]);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < kSelBins; d += 256)
+    if (h[d]) atomicAdd(&S.hist[LEVEL][d], h[d]);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_flag = atomicAdd(&S.done[LEVEL], 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_flag) return;
+  // ---- the segment's last block: where does the cumulative weight reach the target? ----
+  __threadfence();
+  if (threadIdx.x == 0) s_found = (unsigned)kSelBins;
+  constexpr int PER = kSelBins / 256;
+  unsigned long long c[PER], sum = 0ull;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    c[j] = __hip_atomic_load(&S.hist[LEVEL][threadIdx.x * PER + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sum += c[j];
+  }
+  unsigned long long total;
+  unsigned long long run = block_excl_scan64(sum, total, s_scan);      // (its barriers also publish s_found)
+  const unsigned long long before0 = LEVEL == 0 ? 0ull : S.before;
+  const unsigned long long target = budget > before0 ? budget - before0 : 1ull;
+  unsigned long long my_before = 0ull;
+  int mine = -1;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    if (mine < 0 && run < target && run + c[j] >= target) { mine = threadIdx.x * PER + j; my_before = run; }
+    run += c[j];
+  }
+  if (mine >= 0) s_found = (unsigned)mine;     // at most one thread: the crossing is unique
+  __syncthreads();
+  const unsigned found = s_found;
+  if (LEVEL == 0) {
+    if (mine >= 0) S.before = my_before;
+    if (threadIdx.x == 0) {
+      S.b1 = found;
+      S.grand = total;
+      if (grand_out) atomicAdd(grand_out, (unsigned)total);           // frame total of bounding-box pairs (mod 2^32)
+      if (found >= (unsigned)kSelBins) thr_out[seg] = 0x80000000u;    // the segment holds less than the budget: all of it
+    }
+  } else if (threadIdx.x == 0) {
+    // level 0 guarantees the crossing lies inside bucket b1; (b1, b2) + 1 is the exclusive bound in 512-ulp buckets
+    const unsigned b2 = found >= (unsigned)kSelBins ? (unsigned)(kSelBins - 1) : found;
+    thr_out[seg] = (((b1 << kSelBits) | b2) + 1u) << 9;
+  }
+}
+
 // upstream-compatible 64-bit intersection ids (one thread per Gaussian; API-parity path)
 __global__ __launch_bounds__(256) void map_isect_kernel(int N, const float* __restrict__ xys,
                                                         const float* __restrict__ depths,
@@ -1651,8 +1801,66 @@ GS_EXPORT int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl, const
                             unsigned* tail, void* stream) {
   if (P <= 0 || N <= 0 || K <= 0 || K > 32 || base <= 0) return GS_ERR_INVALID;
   hipLaunchKernelGGL(slice_plan_kernel, dim3((P * K + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, N, K, cum_excl,
-                     total, (unsigned long long)base, bounds, rels, seg_totals, n_live, tail);
+                     total, (unsigned long long)base, bounds, rels, seg_totals, n_live, tail, (const unsigned*)nullptr);
   return gs_launch_status();
+}
+
+// gs_slice_plan for a nearest-first selection (gs_depth_select + gs_segmented_sort_select_u32): the ranked pairs are the
+// selection only, so every boundary lies behind them (one slice = all of them) and the frame's total of bounding-box
+// pairs comes from the selection's own count (`grand`, device, = gs_depth_select's grand_out) instead of the scan's.
+GS_EXPORT int gs_slice_plan_select(int P, int N, int K, const unsigned* cum_excl, const unsigned* total, int* bounds,
+                                   unsigned* rels, unsigned* seg_totals, const unsigned* n_live, unsigned* tail,
+                                   const unsigned* grand, void* stream) {
+  if (P <= 0 || N <= 0 || K <= 0 || K > 32 || !n_live || !grand) return GS_ERR_INVALID;
+  hipLaunchKernelGGL(slice_plan_kernel, dim3((P * K + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, N, K, cum_excl,
+                     total, 1ull << 40, bounds, rels, seg_totals, n_live, tail, grand);
+  return gs_launch_status();
+}
+
+// ---- nearest-first selection ---------------------------------------------------------------------------
+GS_EXPORT long long gs_depth_select_workspace_bytes(int segments) {
+  return segments > 0 ? (long long)segments * (long long)sizeof(SelSeg) + 256 : 0;
+}
+
+// Per segment s of seg_len keys (n = segments * seg_len; keys with bit 31 set are culled pairs): thr_out[s] = the
+// smallest multiple of 512 such that the pairs with key < thr_out[s] carry at least `budget` of the weights (0x80000000:
+// the whole segment carries less, everything is selected).  *grand_out (device u32, nullable, ZEROED by the caller) +=
+// the weight of every visible pair.  ws: gs_depth_select_workspace_bytes(segments) bytes, ZEROED by the caller.
+GS_EXPORT int gs_depth_select(long long n, long long seg_len, const unsigned* keys, const unsigned* weights,
+                              long long budget, unsigned* thr_out, unsigned* grand_out, void* ws, long long ws_bytes,
+                              void* stream) {
+  if (n <= 0 || seg_len <= 0 || n % seg_len != 0 || budget <= 0 || !keys || !weights || !thr_out || !ws)
+    return GS_ERR_INVALID;
+  const long long segs = n / seg_len;
+  if (segs > 65535) return GS_ERR_INVALID;
+  if (ws_bytes < gs_depth_select_workspace_bytes((int)segs)) return GS_ERR_WORKSPACE;
+  const long long chunks = (seg_len + 256 * kSelRounds - 1) / (256 * kSelRounds);
+  // about two blocks per CU over all segments, at least two chunks per block
+  const unsigned gx = (unsigned)std::max(1ll, std::min((chunks + 1) / 2, std::max(1ll, 640 / segs)));
+  SelSeg* S = reinterpret_cast<SelSeg*>(ws);
+  hipLaunchKernelGGL(depth_select_kernel<0>, dim3(gx, (unsigned)segs), dim3(256), 0, (hipStream_t)stream, (size_t)seg_len,
+                     keys, weights, (unsigned long long)budget, S, thr_out, grand_out);
+  hipLaunchKernelGGL(depth_select_kernel<1>, dim3(gx, (unsigned)segs), dim3(256), 0, (hipStream_t)stream, (size_t)seg_len,
+                     keys, weights, (unsigned long long)budget, S, thr_out, (unsigned*)nullptr);
+  return gs_launch_status();
+}
+
+// gs_segmented_sort_compact_u32 restricted to a key range per segment: only keys in [key_lo[s], key_hi[s]) (device
+// arrays, either nullable; the skip key is dropped as well) are kept and sorted.  keys_src is read by the first pass and
+// left INTACT; keys0 / keys1 are scratch (n keys each).  Everything else as gs_segmented_sort_compact_u32.
+GS_EXPORT int gs_segmented_sort_select_u32(long long n, long long seg_len, const unsigned* keys_src, unsigned* keys0,
+                                           unsigned* vals0, unsigned* keys1, unsigned* vals1, int begin_bit, int end_bit,
+                                           int max_digit_bits, unsigned skip_key, const unsigned* key_lo,
+                                           const unsigned* key_hi, unsigned* seg_counts, const unsigned* gather_src,
+                                           unsigned* gather_out, void* ws, long long ws_bytes, int* result_buf,
+                                           void* stream) {
+  if (n <= 0 || seg_len <= 0 || n % seg_len != 0 || begin_bit < 0 || end_bit > 32 || !seg_counts || !keys_src)
+    return GS_ERR_INVALID;
+  if ((gather_src != nullptr) != (gather_out != nullptr)) return GS_ERR_INVALID;
+  return radix_sort<unsigned>((size_t)n, (size_t)seg_len, keys0, vals0, keys1, vals1, 1, begin_bit, end_bit, ws,
+                              (size_t)ws_bytes, result_buf, (hipStream_t)stream, max_digit_bits, gather_src,
+                              gather_out, nullptr, seg_counts, (unsigned long long)skip_key, nullptr, nullptr, nullptr,
+                              nullptr, keys_src, key_lo, key_hi);
 }
 
 // sat [P*(tiles_y+1)*(tiles_x+1)]: summed-area table of tiles that are NOT done.

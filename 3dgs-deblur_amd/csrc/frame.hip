@@ -289,6 +289,12 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   Arena A(arena_ptr, arena_bytes);
 
   // ---- depth pre-sort (compacting, per sub-pose) + exclusive scan of the tile counts in rank order ----------------
+  // Nearest-first selection (depth_select): phase 0 ranks only the pairs the first slice's budget reaches and issues
+  // them as ONE slice; phase 1 — entered only if that slice leaves a tile open — ranks and plans the pairs behind them.
+  // Without it there is one phase: every visible pair is ranked, the plan holds every slice.
+  const bool planned = d.slice_base > 0;
+  const bool select = planned && d.depth_select != 0;
+  unsigned* k0s = select ? A.take<unsigned>(n) : nullptr;       // scratch keys: depth_keys stay intact for phase 1
   unsigned* v0 = A.take<unsigned>(n);
   unsigned* k1 = A.take<unsigned>(n);
   unsigned* v1 = A.take<unsigned>(n);
@@ -305,32 +311,54 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   int* sat = A.take<int>((long long)P * (ty + 1) * (tx + 1));
   const long long w64 = (tx + 63) / 64;
   unsigned long long* open_bits = A.take<unsigned long long>((long long)P * ty * w64);
+  // ONE zero fill per frame: [selection workspace + its two words | tile_done of the first slice, one "tile holds an
+  // opacity above the alpha clamp" flag per tile and planned slice | one "a tile is still open" word per slice]
+  const long long sel_b = select ? Arena::up(gs_depth_select_workspace_bytes(P)) + 256 : 0;
   const long long flag_off = ((1 + kKMax) * P * T + 3) & ~3ll;
-  unsigned char* zeros_u8 = A.take<unsigned char>(flag_off + 4 * kKMax);
+  char* zero_blk = A.take<char>(sel_b + flag_off + 4 * kKMax);
+  unsigned char* zeros_u8 = reinterpret_cast<unsigned char*>(zero_blk) + sel_b;
+  unsigned* sel_grand = reinterpret_cast<unsigned*>(zero_blk + sel_b - 256);      // frame total of bounding-box pairs
+  unsigned* thr_dev = select ? A.take<unsigned>(P) : nullptr;
   int* plan_dev = A.take<int>(plan_ints);
   unsigned char* tile_done_rs = R > 1 ? A.take<unsigned char>(P * T) : nullptr;
   // shared list: the compositor's done flags are per (sample, tile); the binning's [T] is their AND
   unsigned char* tile_done_samples = shared ? A.take<unsigned char>((long long)S * T) : nullptr;
   if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
   if (shared) CHECK(hip_status(hipMemsetAsync(tile_done_samples, 0, (long long)S * T, st)));
+  CHECK(hip_status(hipMemsetAsync(zero_blk, 0, sel_b + flag_off + 4 * kKMax, st)));
+  int* open_flags = reinterpret_cast<int*>(zeros_u8 + flag_off);
+  // budget of the first slice per sub-pose = its OPEN tiles * slice_base box pairs (a band-clipped rolling-shutter
+  // sub-pose owns T / R of the frame's tiles)
+  const long long plan_tiles = (d.band_clipped && R > 1) ? (T + R - 1) / R : T;
+  const long long base0 = plan_tiles * (long long)std::max(1, d.slice_base);
 
-  int res = 0;
-  {
-    StageScope sc(ST_DEPTH_SORT, st);
-    // visible keys are positive floats: bit 31 is never set (the culled marker is dropped, not sorted)
-    CHECK(gs_segmented_sort_compact_u32(n, N, depth_keys, v0, k1, v1, 0, 31, digit, 0xFFFFFFFFu, n_live,
-                                        reinterpret_cast<const unsigned*>(num_tiles_hit), counts_r, sort_ws, sort_ws_b,
-                                        &res, st));
-  }
-  const unsigned* sorted_gi = res == 1 ? v1 : v0;
-  {
+  const unsigned* sorted_gi = nullptr;
+  // phase 0: everything (or the selection); phase 1: the pairs behind the selection
+  auto presort = [&](int phase) -> int {
+    int res = 0;
+    {
+      StageScope sc(ST_DEPTH_SORT, st);
+      // visible keys are positive floats: bit 31 is never set (the culled marker is dropped, not sorted)
+      if (!select) {
+        CHECK(gs_segmented_sort_compact_u32(n, N, depth_keys, v0, k1, v1, 0, 31, digit, 0xFFFFFFFFu, n_live,
+                                            reinterpret_cast<const unsigned*>(num_tiles_hit), counts_r, sort_ws, sort_ws_b,
+                                            &res, st));
+      } else {
+        if (phase == 0)
+          CHECK(gs_depth_select(n, N, depth_keys, reinterpret_cast<const unsigned*>(num_tiles_hit), base0, thr_dev,
+                                sel_grand, zero_blk, sel_b - 256, st));
+        CHECK(gs_segmented_sort_select_u32(n, N, depth_keys, k0s, v0, k1, v1, 0, 31, digit, 0xFFFFFFFFu,
+                                           phase == 0 ? nullptr : thr_dev, phase == 0 ? thr_dev : nullptr, n_live,
+                                           reinterpret_cast<const unsigned*>(num_tiles_hit), counts_r, sort_ws, sort_ws_b,
+                                           &res, st));
+      }
+    }
+    sorted_gi = res == 1 ? v1 : v0;
     StageScope sc(ST_COUNT_SCAN, st);
     CHECK(gs_exclusive_scan_segments_u32(n, N, n_live, counts_r, cum, total, scan_ws, scan_ws_b, st));
-  }
-  // one zero fill: tile_done of the first slice, one "tile holds an opacity above the alpha clamp" flag per tile and
-  // planned slice, one "a tile is still open" word per slice
-  CHECK(hip_status(hipMemsetAsync(zeros_u8, 0, flag_off + 4 * kKMax, st)));
-  int* open_flags = reinterpret_cast<int*>(zeros_u8 + flag_off);
+    return GS_OK;
+  };
+  CHECK(presort(0));
 
   // ---- slice plan: the ONE read-back every frame needs ---------------------------------------------------------------
   // word 0 of the pinned buffer is the sequence word of the polled read-backs, the payload follows
@@ -340,64 +368,82 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   const long long PK = (long long)P * kKMax;
   std::vector<long long> NV(P), seg_totals(P);
   std::vector<std::vector<long long>> bnd(P), rel(P);
-  long long n_total = 0;
+  long long n_total = 0, true_total = 0;
   int K = 1;
-  const bool planned = d.slice_base > 0;
-  if (planned) {
-    StageScope sc(ST_PLAN, st);
-    // budget of the first slice per sub-pose = its OPEN tiles * slice_base box pairs (a band-clipped rolling-shutter
-    // sub-pose owns T / R of the frame's tiles)
-    const long long plan_tiles = (d.band_clipped && R > 1) ? (T + R - 1) / R : T;
-    CHECK(gs_slice_plan(P, N, kKMax, cum, total, plan_tiles * d.slice_base, plan_dev,
-                        reinterpret_cast<unsigned*>(plan_dev + PK), reinterpret_cast<unsigned*>(plan_dev + 2 * PK),
-                        n_live, reinterpret_cast<unsigned*>(plan_dev + 2 * PK + P), st));
-    CHECK(read_back(reinterpret_cast<const unsigned*>(plan_dev), hp_seq, (int)plan_ints, poll, st));
-    for (int p = 0; p < P; ++p) {
-      bnd[p].resize(kKMax); rel[p].resize(kKMax);
-      for (int k = 0; k < kKMax; ++k) { bnd[p][k] = hp[p * kKMax + k]; rel[p][k] = hp[PK + p * kKMax + k]; }
-      seg_totals[p] = hp[2 * PK + p];
-      NV[p] = std::min<long long>(N, hp[2 * PK + P + p]);
-    }
-    n_total = hp[plan_ints - 1];
-    K = kKMax;
-    for (int k = 0; k < kKMax; ++k) {
-      bool all = true;
-      for (int p = 0; p < P; ++p) all = all && bnd[p][k] >= NV[p];
-      if (all) { K = k + 1; break; }
-    }
-  } else {
-    CHECK(hip_status(hipMemcpyAsync(hp, total, 4, hipMemcpyDeviceToHost, st)));
-    CHECK(hip_status(hipMemcpyAsync(hp + 1, n_live, 4 * P, hipMemcpyDeviceToHost, st)));
-    CHECK(hip_status(hipStreamSynchronize(st)));
-    n_total = hp[0];
-    for (int p = 0; p < P; ++p) { NV[p] = std::min<long long>(N, hp[1 + p]); seg_totals[p] = 0; }
-  }
-  state->n_total = n_total;
-  long long true_total = 0;
-  for (int p = 0; p < P; ++p) true_total += seg_totals[p];
-  const bool use_masks = planned && !rs && true_total < 4294967296ll - 64;
-
-  // slice descriptors (host arrays: they travel in the kernel arguments) and the slices' list capacities
-  std::vector<std::vector<int>> begins(K, std::vector<int>(P)), prefixes(K, std::vector<int>(P + 1));
-  std::vector<long long> n_of(K), I_of(K);
-  for (int k = 0; k < K; ++k) {
-    prefixes[k][0] = 0;
-    long long I_k = 0;
-    for (int p = 0; p < P; ++p) {
-      const long long lo = k == 0 ? 0 : std::min(bnd[p].empty() ? NV[p] : bnd[p][k - 1], NV[p]);
-      const long long hi = (k == K - 1) ? NV[p] : std::min(bnd[p][k], NV[p]);
-      begins[k][p] = (int)((long long)p * N + lo);
-      prefixes[k][p + 1] = prefixes[k][p] + (int)std::max(0ll, hi - lo);
-      if (planned) {
-        const long long hi_rel = (k == K - 1) ? seg_totals[p] : rel[p][k];
-        const long long lo_rel = k == 0 ? 0 : rel[p][k - 1];
-        I_k += (hi_rel - lo_rel) & 0xFFFFFFFFll;                  // upper bound: the ranks' bounding-box pairs
+  bool use_masks = false;
+  std::vector<std::vector<int>> begins, prefixes;
+  std::vector<long long> n_of, I_of;
+  // phase 0: the frame's plan (select: ONE slice, the selection); phase 1: the plan of the pairs behind the selection,
+  // its first slice twice the budget of the selection
+  auto make_plan = [&](int phase) -> int {
+    if (planned) {
+      StageScope sc(ST_PLAN, st);
+      if (select && phase == 0)
+        CHECK(gs_slice_plan_select(P, N, kKMax, cum, total, plan_dev, reinterpret_cast<unsigned*>(plan_dev + PK),
+                                   reinterpret_cast<unsigned*>(plan_dev + 2 * PK), n_live,
+                                   reinterpret_cast<unsigned*>(plan_dev + 2 * PK + P), sel_grand, st));
+      else
+        CHECK(gs_slice_plan(P, N, kKMax, cum, total, phase == 0 ? base0 : 2 * base0, plan_dev,
+                            reinterpret_cast<unsigned*>(plan_dev + PK), reinterpret_cast<unsigned*>(plan_dev + 2 * PK),
+                            n_live, reinterpret_cast<unsigned*>(plan_dev + 2 * PK + P), st));
+      CHECK(read_back(reinterpret_cast<const unsigned*>(plan_dev), hp_seq, (int)plan_ints, poll, st));
+      for (int p = 0; p < P; ++p) {
+        bnd[p].resize(kKMax); rel[p].resize(kKMax);
+        for (int k = 0; k < kKMax; ++k) { bnd[p][k] = hp[p * kKMax + k]; rel[p][k] = hp[PK + p * kKMax + k]; }
+        seg_totals[p] = hp[2 * PK + p];
+        NV[p] = std::min<long long>(N, hp[2 * PK + P + p]);
       }
+      if (phase == 0) n_total = hp[plan_ints - 1];
+      // (phase 1 keeps one planned slice for the selection's: tile_hot planes and open words are per issued slice)
+      const int k_cap = phase == 0 ? kKMax : kKMax - 1;
+      K = k_cap;
+      for (int k = 0; k < k_cap; ++k) {
+        bool all = true;
+        for (int p = 0; p < P; ++p) all = all && bnd[p][k] >= NV[p];
+        if (all) { K = k + 1; break; }
+      }
+    } else {
+      CHECK(hip_status(hipMemcpyAsync(hp, total, 4, hipMemcpyDeviceToHost, st)));
+      CHECK(hip_status(hipMemcpyAsync(hp + 1, n_live, 4 * P, hipMemcpyDeviceToHost, st)));
+      CHECK(hip_status(hipStreamSynchronize(st)));
+      n_total = hp[0];
+      for (int p = 0; p < P; ++p) { NV[p] = std::min<long long>(N, hp[1 + p]); seg_totals[p] = 0; }
+      K = 1;
     }
-    n_of[k] = prefixes[k][P];
-    I_of[k] = planned ? I_k : n_total;
-    if (n_of[k] == 0) I_of[k] = 0;
-  }
+    true_total = 0;
+    for (int p = 0; p < P; ++p) true_total += seg_totals[p];
+    use_masks = planned && !rs && true_total < 4294967296ll - 64;
+    // slice descriptors (host arrays: they travel in the kernel arguments) and the slices' list capacities
+    begins.assign(K, std::vector<int>(P));
+    prefixes.assign(K, std::vector<int>(P + 1));
+    n_of.assign(K, 0); I_of.assign(K, 0);
+    for (int k = 0; k < K; ++k) {
+      prefixes[k][0] = 0;
+      long long I_k = 0;
+      for (int p = 0; p < P; ++p) {
+        const long long lo = k == 0 ? 0 : std::min(bnd[p].empty() ? NV[p] : bnd[p][k - 1], NV[p]);
+        const long long hi = (k == K - 1) ? NV[p] : std::min(bnd[p][k], NV[p]);
+        begins[k][p] = (int)((long long)p * N + lo);
+        prefixes[k][p + 1] = prefixes[k][p] + (int)std::max(0ll, hi - lo);
+        if (planned) {
+          const long long hi_rel = (k == K - 1) ? seg_totals[p] : rel[p][k];
+          const long long lo_rel = k == 0 ? 0 : rel[p][k - 1];
+          I_k += (hi_rel - lo_rel) & 0xFFFFFFFFll;                  // upper bound: the ranks' bounding-box pairs
+        }
+      }
+      n_of[k] = prefixes[k][P];
+      I_of[k] = planned ? I_k : n_total;
+      if (n_of[k] == 0) I_of[k] = 0;
+    }
+    return GS_OK;
+  };
+  CHECK(make_plan(0));
+  state->n_total = n_total;
+  state->depth_select = select ? 1 : 0;
+  // select: are there visible pairs behind the selection?  (the frame's total against the selection's, both mod 2^32
+  // like every pair count of a frame)
+  bool rest_behind = select && ((n_total - true_total) & 0xFFFFFFFFll) != 0;
+
   // what a slice needs is priced right before it is issued (a frame rarely needs all its planned slices: the headline
   // plans five and uses one); the arena must then also hold the backward's buffers for the slices issued so far
   long long maxI_issued = 0;
@@ -449,12 +495,16 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   int span = 1;                                                      // planned slices per issued slice
   long long open_before = (long long)S * T;                          // tiles a compositor launch visits
   std::vector<int> beg_s, pre_s;
-  for (int k = 0, k1 = 0; k < K; k = k1) {
+  int slice_no = 0;                                                  // issued-slice counter over both phases
+  for (int phase = 0; phase < 2; ++phase) {
+  long long open_left = 0;                                           // tiles the phase's last compositor left open
+  for (int k = 0, k1 = 0; k < K; k = k1, ++slice_no) {
     long long n_k = 0, I_k = 0;
     k1 = std::min(K, k + span);
     merged(k, k1, beg_s, pre_s, n_k, I_k);
     while (k1 > k + 1 && I_k >= 2147483647ll - kIdsPad) merged(k, --k1, beg_s, pre_s, n_k, I_k);
-    const bool first = k == 0, last = k1 == K;
+    // the frame's last slice: the plan's last one — unless pairs wait behind a selection (phase 0 of a select frame)
+    const bool first = slice_no == 0, last = k1 == K && !(phase == 0 && rest_behind);
     if (I_k >= 2147483647ll - kIdsPad) return GS_ERR_INVALID;        // a slice list is indexed with 31 bits: lower slice_base
     if (shared && I_k * (long long)S >= 4294967296ll) return GS_ERR_INVALID;   // 32-bit tuple offsets (entry * S)
     if (!fits(n_k, I_k, k1)) return GS_ERR_WORKSPACE;
@@ -463,7 +513,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
     unsigned long long* masks = nullptr;
     unsigned *vals = nullptr, *svals = nullptr, *sorted_ids = nullptr;
     int* bins = nullptr;
-    unsigned char* tile_hot = zeros_u8 + (1 + k) * P * T;
+    unsigned char* tile_hot = zeros_u8 + (1 + slice_no) * P * T;
     int wave_per_g = 0;
     if (n_k > 0) {
       StageScope sc(ST_COUNT, st);
@@ -474,7 +524,8 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
       // by single lanes where a wave holds several)
       long long box_total = 0;
       if (first) {
-        if (K == 1 || !planned) box_total = n_total;
+        if (!planned) box_total = n_total;
+        else if (K == 1) box_total = true_total;
         else for (int p = 0; p < P; ++p) box_total += rel[p][0];
       }
       wave_per_g = (first && box_total > 128 * n_k) ? 1 : 0;
@@ -563,7 +614,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
         CHECK(gs_rasterize_fwd_rs_slice(records, bins, band_edges, background, S, H, W, out_img, out_T, live_T, fidx,
                                         shared ? tile_done_samples : tile_done, first ? 1 : 0, last ? 1 : 0,
                                         reinterpret_cast<const int*>(sorted_ids), (int)std::min(n, 2147483647ll), out_depth,
-                                        last ? nullptr : open_flags + k, pix_vel, N, d.rolling_shutter_time,
+                                        last ? nullptr : open_flags + slice_no, pix_vel, N, d.rolling_shutter_time,
                                         shared ? sample_times : nullptr, st));
       else
       CHECK(gs_rasterize_fwd_slice(records, reinterpret_cast<const int*>(svals), bins, band_edges, background, S, R, H, W,
@@ -571,9 +622,10 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
                                    last ? 1 : 0, I_k > 0 ? reinterpret_cast<const int*>(vals) : nullptr,
                                    reinterpret_cast<const int*>(sorted_ids), I_k > 0 ? (int)std::min(n, 2147483647ll) : 0,
                                    I_k > 0 ? out_depth : nullptr, I_k > 0 ? tile_hot : nullptr,
-                                   last ? nullptr : open_flags + k, fwd_variant, st));
+                                   last ? nullptr : open_flags + slice_no, fwd_variant, st));
     }
     if (I_k > 0) {
+      if (n_out >= GS_FRAME_MAX_SLICES) return GS_ERR_INVALID;
       gs_frame_slice& sl = state->slice[n_out++];
       sl.I = I_k; sl.n = (int)n_k; sl.wave_per_gaussian = wave_per_g; sl.first = first; sl.last = last;
       sl.svals = A.offset_of(svals); sl.bins = A.offset_of(bins); sl.fidx = A.offset_of(fidx);
@@ -593,9 +645,10 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
     if (!last) {
       // one read-back per slice: are there open tiles for the next planned slice?  One word, written by the compositor
       // itself, read AFTER this slice's whole pipeline was issued
-      CHECK(read_back(reinterpret_cast<const unsigned*>(open_flags + k), hp_seq, 1, poll, st, average));
+      CHECK(read_back(reinterpret_cast<const unsigned*>(open_flags + slice_no), hp_seq, 1, poll, st, average));
       const long long open_now = hp[0];                              // tiles the compositor left open
-      if (open_now == 0) break;
+      open_left = open_now;
+      if (open_now == 0) { ++slice_no; break; }
       span = (d.merge_open_fraction > 0.f && (double)open_now >= (double)d.merge_open_fraction * (double)open_before)
                  ? 2 * (k1 - k) : 1;
       open_before = open_now;
@@ -605,6 +658,14 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
                            tile_done_samples, tile_done);
       CHECK(gs_tile_open_sat(P, H, W, tile_done, sat, open_bits, nullptr, st));
     }
+  }
+  // phase 1 of a select frame: its one slice left tiles open and pairs wait behind the selection — rank and plan them
+  if (!(phase == 0 && rest_behind && open_left > 0)) break;
+  state->depth_select = 2;
+  rest_behind = false;
+  span = 1;
+  CHECK(presort(1));
+  CHECK(make_plan(1));
   }
   state->n_slices = n_out;
   state->arena_used = Arena::up(A.off);

@@ -49,20 +49,26 @@ class FrameHints:
     render_combined / render_step); callers that pass none share one per (device, frame shape, parameter storage) —
     so two scenes of one shape never fight over one hint.  Thread-safe."""
 
-    __slots__ = ("mult", "age", "arena_bytes", "arena_retries", "frames", "box_share", "_recent", "_lock")
+    __slots__ = ("mult", "age", "arena_bytes", "arena_retries", "frames", "box_share", "last_slices", "select_misses",
+                 "_recent", "_lock")
 
     def __init__(self):
         self.mult, self.age, self.arena_bytes, self.arena_retries, self.frames = 1, 0, 0, 0, 0
         self.box_share = None           # share of the last frame's bounding-box pairs its issued slices held (None: no frame yet)
+        self.last_slices = None         # slices the last frame issued (None: no frame yet)
+        self.select_misses = 0          # frames whose nearest-first selection had to be followed by the full sort
         self._recent = []               # (issued slices, budget multiplier, arena retries) of the last frames
         self._lock = threading.Lock()
 
     def slice_base(self) -> int:
         return SLICE_BASE * (self.mult if SLICE_ADAPT and SLICE_BASE > 0 else 1)
 
-    def feedback(self, n_issued: int, retries: int = 0, box_share: Optional[float] = None) -> None:
+    def feedback(self, n_issued: int, retries: int = 0, box_share: Optional[float] = None, select_state: int = 0) -> None:
         with self._lock:
             self.frames += 1
+            self.last_slices = int(n_issued)
+            if select_state == 2:
+                self.select_misses += 1
             if box_share is not None:
                 self.box_share = float(box_share)
             self.arena_retries += retries
@@ -89,9 +95,15 @@ class FrameHints:
         would be projected again, by gathers)"""
         return self.mult == 1 and (self.box_share is None or self.box_share < 0.25)
 
+    def depth_select(self) -> bool:
+        """nearest-first selection (DEPTH_SELECT) pays when the frame stops within its first slice and that slice is a
+        small part of the frame: the last frame issued ONE slice that held under half of its bounding-box pairs"""
+        return self.last_slices == 1 and self.box_share is not None and self.box_share < 0.5
+
     def reset(self) -> None:
         with self._lock:
             self.mult, self.age, self.arena_bytes, self._recent, self.box_share = 1, 0, 0, [], None
+            self.last_slices = None
 
 
 _hints = {}          # default owner: (device, N, P, S, H, W, shared, storage of means3d) -> FrameHints
@@ -166,6 +178,14 @@ BAND_AWARE = int(os.environ.get("GSD_BAND_AWARE", "1"))
 # (gs_slice_project_records: same arithmetic, bit-identical rows); a scene whose budget has grown, or that fits its first
 # slice whole, keeps the eager projection.  0: always eager; 2: always lazy.
 LAZY_RECORDS = int(os.environ.get("GSD_LAZY_RECORDS", "1"))
+# Nearest-first selection (round 6).  The depth pre-sort ordered every visible (sub-pose, Gaussian) pair — 3.95 M on the
+# benchmark scene, 0.21 ms + a 5 M-rank count scan — and that scene's one depth slice holds 55 k of them.  1 (default): a
+# scene whose LAST frame stopped within its first slice, that slice holding under half of the frame's bounding-box pairs
+# (FrameHints.depth_select), ranks only the pairs its first-slice budget reaches (gs_depth_select: a two-level radix
+# select over the depth keys, then the compacting sort over the selection); should that slice leave a tile open after
+# all, the pairs behind the selection are sorted and planned then (one more sort: the price of a wrong guess, and the
+# frame's feedback switches the selection off for the next one).  0: never; 2: always.  Images bit for bit the same.
+DEPTH_SELECT = int(os.environ.get("GSD_DEPTH_SELECT", "1"))
 # 1 (default): Gaussians whose scales differ by more than 8x get the covariance part of their projection backward
 # (v_conic -> cov2d -> cov3d -> scale / quaternion / mean) recomputed in double (project_needle_hp_kernel): in fp32 that
 # chain is percent-level wrong along a needle's long axis.  0: fp32 everywhere (A/B, tests).
@@ -197,6 +217,7 @@ from ._profile import FRAME_STAGES, StageProfiler, _NULL  # noqa: E402
 
 profiler: Optional[StageProfiler] = None
 last_num_intersects: int = 0
+last_depth_select: int = 0      # gs_frame_state.depth_select of the last frame (0 full sort, 1 selection, 2 selection + rest)
 
 
 def _stage(name: str):
@@ -459,6 +480,7 @@ class _FrameDesc(ctypes.Structure):
                                                                                      ("combine_gamma", ctypes.c_float),
                                                                                      ("combine_min_level", ctypes.c_float),
                                                                                      ("band_clipped", ctypes.c_int),
+                                                                                     ("depth_select", ctypes.c_int),
                                                                                      ("lazy_records", ctypes.c_void_p)]
 
 
@@ -477,7 +499,7 @@ class _FrameSlice(ctypes.Structure):
 
 class _FrameState(ctypes.Structure):
     _fields_ = ([(k, ctypes.c_int) for k in ("n_slices", "P", "N", "S", "R", "H", "W")] +
-                [("rolling_shutter_time", ctypes.c_float), ("shared_list", ctypes.c_int)] +
+                [("rolling_shutter_time", ctypes.c_float), ("shared_list", ctypes.c_int), ("depth_select", ctypes.c_int)] +
                 [(k, ctypes.c_longlong) for k in ("n_total", "arena_used", "arena_required")] +
                 [("slice", _FrameSlice * 16)])
 
@@ -614,26 +636,29 @@ def _profile_mask() -> int:
 def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Tensor, P: int, N: int, S: int, R: int,
                          H: int, W: int, bg: Tensor, edges: Tensor, slice_base: int, color=None,
                          out_depth: Optional[Tensor] = None, reserve_backward: bool = True, rs=None, combine=None,
-                         hints: Optional[FrameHints] = None, band_clipped: bool = False, lazy=None):
+                         hints: Optional[FrameHints] = None, band_clipped: bool = False, lazy=None,
+                         depth_select: Optional[bool] = None):
     """combine = (gamma, min_level, out [H,W,3]): the library launches the gamma-space average of the sample images itself,
     behind every slice's compositor (it overlaps the open-tile read-back).  rs = (pix_vel [N,2], rolling_shutter_time[, sample_times [S]]) or None; with sample_times the frame runs in the
     shared-list mode (P == 1: one record set and one tile list for the S samples).  gs_frame_forward: -> (out_img [S,H,W,3], out_T [S,H,W], frame) ; frame = dict(arena, state) for
     native_frame_backward.  Raises _ArenaTooSmall (after recording a larger size) when the arena did not hold the frame:
     the caller projects again (the depth keys were consumed) and calls once more."""
-    global last_num_intersects, _slice_totals
+    global last_num_intersects, _slice_totals, last_depth_select
     L = _L()
     dev = records.device
     tx, ty = _tiles(H, W)
     shared = rs is not None and len(rs) > 2 and rs[2] is not None
     if hints is None:
         hints = hints_for((str(dev), N, P, S, H, W, shared))
+    if depth_select is None:
+        depth_select = bool(DEPTH_SELECT == 2 or (DEPTH_SELECT and hints.depth_select()))
     n = P * N
     nbytes = hints.arena_bytes
     if not nbytes:
         # depth pre-sort + plan + one slice of the default budget; the library prices the real plan and says so if this
         # is short (one retry per new high-water mark)
         I0 = max(1, slice_base) * tx * ty * P
-        nbytes = 40 * n + 16 * S * H * W + (80 + (56 * S if shared else 0)) * I0 + (64 << 20)
+        nbytes = 44 * n + 16 * S * H * W + (80 + (56 * S if shared else 0)) * I0 + (64 << 20)
     lease = _arena_acquire(dev, nbytes)
     arena = lease.tensor
     nbytes = arena.numel()
@@ -647,7 +672,8 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     desc = _FrameDesc(N, P, S, R, H, W, int(slice_base), DEPTH_SORT_DIGIT, 0, int(reserve_backward),
                       float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0, frame_poll(), int(shared),
                       float(combine[0]) if combine is not None else 1.0, float(combine[1]) if combine is not None else 0.0,
-                      int(bool(band_clipped)), ctypes.addressof(lazy) if lazy is not None else None)
+                      int(bool(band_clipped)), int(bool(depth_select and slice_base > 0)),
+                      ctypes.addressof(lazy) if lazy is not None else None)
     state = _FrameState()
     out_img = torch.empty(S, H, W, 3, device=dev)
     out_T = torch.empty(S, H, W, device=dev)
@@ -672,6 +698,7 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
     hints.arena_bytes = max(int(hints.arena_bytes),
                             int((state.arena_used + L.gs_frame_backward_bytes(ctypes.byref(state))) * 1.15))
     last_num_intersects = int(state.n_total)
+    last_depth_select = int(state.depth_select)
     _slice_totals = [arena[sl.n_emitted_dev:sl.n_emitted_dev + 4].view(torch.int32)
                      for sl in (state.slice[i] for i in range(state.n_slices))]
     return out_img, out_T, dict(arena=arena, arena_obj=lease.arena, lease=lease, gen=lease.gen, state=state,
@@ -1179,7 +1206,8 @@ class _RenderSubposes(Function):
                                                                      hints.slice_base(), color, depth_acc,
                                                                      any(ctx.needs_input_grad), rs, averaged, hints,
                                                                      bool(defer_flags & 4), lazy)
-                    hints.feedback(int(ctx.frame["state"].n_slices), retries, _box_share(ctx.frame["state"]))
+                    hints.feedback(int(ctx.frame["state"].n_slices), retries, _box_share(ctx.frame["state"]),
+                                   int(ctx.frame["state"].depth_select))
                     break
                 except _ArenaTooSmall:
                     retries += 1

@@ -219,6 +219,28 @@ int gs_segmented_sort_compact_u32(long long n, long long seg_len, unsigned* keys
                                   unsigned* seg_counts /*device, n/seg_len*/, const unsigned* gather_src,
                                   unsigned* gather_out, void* ws, long long ws_bytes, int* result_buf /*host*/,
                                   void* stream);
+/* ---- nearest-first selection (round 6; MI355X design, no upstream counterpart: upstream sorts every intersection,
+ * SURVEY.md §8 a5) -----------------------------------------------------------------------------------------------
+ * A frame whose tiles saturate early composites a few percent of its visible (sub-pose, Gaussian) pairs.  Instead of
+ * ordering all of them, gs_depth_select finds per segment (sub-pose) the key bound below which the pairs carry `budget`
+ * of the weights (their bounding-box tile counts), two histogram launches over key bits 30..20 and 19..9;
+ * gs_segmented_sort_select_u32 then keeps and sorts only the keys inside a per-segment range — [0, bound) for the first
+ * depth slice, [bound, culled) for the rest, if the frame turns out to need it (gs_frame_forward, depth_select). */
+long long gs_depth_select_workspace_bytes(int segments);
+/* thr_out[s] = smallest multiple of 512 with: weight of the keys < thr_out[s] of segment s >= budget (0x80000000: the
+ * whole segment carries less).  Keys with bit 31 set are culled pairs.  *grand_out (device u32, nullable) += weight of
+ * every visible pair.  ws (gs_depth_select_workspace_bytes) and *grand_out must be ZERO on entry. */
+int gs_depth_select(long long n, long long seg_len, const unsigned* keys, const unsigned* weights, long long budget,
+                    unsigned* thr_out /*device, n/seg_len*/, unsigned* grand_out, void* ws, long long ws_bytes,
+                    void* stream);
+/* gs_segmented_sort_compact_u32 over the keys inside [key_lo[s], key_hi[s]) only (device arrays per segment, either
+ * NULL = unbounded; skip_key is dropped as well).  keys_src is read by the first pass and left INTACT, keys0 / keys1 are
+ * scratch of n keys each; workspace as gs_segmented_sort_compact_workspace_bytes. */
+int gs_segmented_sort_select_u32(long long n, long long seg_len, const unsigned* keys_src, unsigned* keys0,
+                                 unsigned* vals0, unsigned* keys1, unsigned* vals1, int begin_bit, int end_bit,
+                                 int max_digit_bits, unsigned skip_key, const unsigned* key_lo, const unsigned* key_hi,
+                                 unsigned* seg_counts, const unsigned* gather_src, unsigned* gather_out, void* ws,
+                                 long long ws_bytes, int* result_buf /*host*/, void* stream);
 /* exclusive scan where only the first seg_counts[s] values of every seg_len-long segment are live (the rest count as
  * zero and are never read; out is written everywhere) */
 int gs_exclusive_scan_segments_u32(long long n, long long seg_len, const unsigned* seg_counts /*device*/,
@@ -292,6 +314,11 @@ int gs_slice_plan(int P, int N, int K, const unsigned* cum_excl /*P*N, rank orde
                                    then the grand total — so that one device->host copy of a buffer holding bounds,
                                    rels, seg_totals and tail back to back brings the whole plan over*/,
                   void* stream);
+/* gs_slice_plan when the ranked pairs are a nearest-first selection: every boundary lies behind them (one slice holds
+ * the whole selection) and tail[P] = *grand (device: gs_depth_select's grand_out), the frame's total over ALL pairs */
+int gs_slice_plan_select(int P, int N, int K, const unsigned* cum_excl, const unsigned* total, int* bounds,
+                         unsigned* rels, unsigned* seg_totals, const unsigned* n_live, unsigned* tail,
+                         const unsigned* grand, void* stream);
 /* sat [P*(tiles_y+1)*(tiles_x+1)] = summed-area table of tiles NOT done (tile_done u8 [P*T]) */
 int gs_tile_open_sat(int P, int img_height, int img_width, const unsigned char* tile_done, int* sat,
                      unsigned long long* open_bits /*NULL or [P*tiles_y*ceil(tiles_x/64)]: bit x of row y set while
@@ -502,6 +529,10 @@ typedef struct gs_frame_desc {
                                 tile counts only hold the pairs inside its rolling-shutter band, so a sub-pose owns T/R
                                 open tiles and the slice plan's budget per sub-pose is T/R * slice_base (0: T * slice_base,
                                 of which one pair in R lies inside the band) */
+  int depth_select;          /* 1 (with slice_base > 0): nearest-first selection — the depth pre-sort only ranks the pairs
+                                the first slice's budget reaches (gs_depth_select + gs_segmented_sort_select_u32); the
+                                pairs behind them are sorted and planned (budget doubled) only if that slice leaves a
+                                tile open.  Same images bit for bit; for scenes whose frames stop in their first slice */
   const struct gs_project_inputs* lazy_records;   /* NULL, or (the projection ran with defer_color bit 4: `records` holds
                                 nothing yet) what it was called with: every issued slice first projects the records of
                                 its own pairs (gs_slice_project_records).  SE(3) sub-poses only (pix_vel == NULL) */
@@ -515,6 +546,8 @@ typedef struct gs_frame_state {
   int n_slices, P, N, S, R, H, W;
   float rolling_shutter_time;/* copied from the descriptor (0: not an exact-rolling-shutter frame) */
   int shared_list;           /* copied from the descriptor */
+  int depth_select;          /* 0: every visible pair was depth-sorted; 1: only the nearest-first selection; 2: the
+                                selection, and later the pairs behind it (the first slice left tiles open) */
   long long n_total;         /* bounding-box tile intersections of the frame */
   long long arena_used;      /* bytes of the arena the forward occupies (kept alive until the backward ran) */
   long long arena_required;  /* on GS_ERR_WORKSPACE (3): an arena size that holds the frame as far as it is known */

@@ -1,0 +1,295 @@
+"""GPU tests added in round 6 (same bars and fixtures as tests/test_gpu_parity.py: everything goes through the C ABI)."""
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def to_dev(sc, dev):
+    return {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
+
+
+# --------------------------------------------------------------------------- #
+# ADVICE round 5
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("n,num_bins", [(4000, 300), (70_000, 129)])
+def test_bin_edges_ignore_keys_beyond_the_last_bin(gs, dev, n, num_bins):
+    """gs_tile_bin_edges_u64 / _u32 take caller-supplied ids (ops.get_tile_bin_edges): a tile id >= num_bins owns no bin.
+    ADVICE round 5: the self-zeroing kernel strode over the gap up to such a key and zero-filled far past the buffer.
+    The bins sit in the middle of a poisoned guard region; every bin of a key < num_bins is exact, nothing outside moves."""
+    from gsdeblur_amd import _lib
+    from gsdeblur_amd.ops import _ptr, _stream
+    L = _lib.load()
+    g = torch.Generator().manual_seed(n)
+    keys = torch.sort(torch.randint(0, num_bins, (n,), generator=g, dtype=torch.int64)).values
+    stray = torch.tensor([num_bins, num_bins + 7, 5 * num_bins, 5 * num_bins, 2 ** 20 + 3], dtype=torch.int64)
+    allk = torch.cat([keys, stray])
+    guard = 4096
+    for width in (64, 32):
+        buf = torch.full((guard + num_bins + guard, 2), 0x7F7F7F7F, dtype=torch.int32, device=dev)
+        bins = buf[guard:guard + num_bins]
+        if width == 64:
+            ids = ((allk << 32) | 12345).to(dev)
+            _lib.check(L.gs_tile_bin_edges_u64(allk.numel(), _ptr(ids), num_bins, _ptr(bins), _stream()), "bin edges u64")
+        else:
+            ids = allk.to(torch.int32).to(dev)
+            _lib.check(L.gs_tile_bin_edges_u32(allk.numel(), _ptr(ids), num_bins, _ptr(bins), None, _stream()), "bin edges u32")
+        lo = torch.searchsorted(keys, torch.arange(num_bins), right=False)
+        hi = torch.searchsorted(keys, torch.arange(num_bins), right=True)
+        want = torch.stack([lo, hi], 1)
+        want[hi == lo] = 0
+        assert torch.equal(bins.cpu().long(), want), width
+        assert bool((buf[:guard] == 0x7F7F7F7F).all()) and bool((buf[guard + num_bins:] == 0x7F7F7F7F).all()), width
+
+
+def test_a_second_backward_of_one_frame_re_lends_its_arena(gs, dev):
+    """a frame's arena goes back to the pool after its first backward; a second backward
+    (retain_graph=True) takes it out of the pool again for its duration and gives the same gradients; once a LATER frame
+    has leased the arena, the old frame's backward must refuse (lease numbers come from one global counter: an address
+    handed out again by the allocator cannot make a stale frame look current)."""
+    from gsdeblur_amd import ops
+    n, W, H, S = 30000, 160, 96, 2
+    sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=5, scale_mult=8.0), dev)
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, 1, 0.0)
+    vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"], sc["ang_vel"], torch.tensor(times, device=dev))
+    ops.release_arenas()
+    hints = ops.FrameHints()
+    p = sc["means"].clone().requires_grad_(True)
+
+    def render(q):
+        return gs.render_combined(q, sc["log_scales"].exp(), sc["quats"], torch.sigmoid(sc["opacity_logits"]), sc["sh"],
+                                  vms, None, S, 1, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2, hints=hints)[0]
+    img = render(p)
+    loss = img.sum()
+    loss.backward(retain_graph=True)
+    g1 = p.grad.clone()
+    pool = ops._arena_pool[(str(dev), torch.cuda.current_stream(dev).cuda_stream)]
+    assert len(pool) == 1
+    p.grad = None
+    loss.backward(retain_graph=True)                       # re-lends the pooled arena, returns it afterwards
+    assert len(pool) == 1
+    tol = 1e-5 * float(g1.abs().max())
+    assert float((p.grad - g1).abs().max()) <= tol          # (same kernels; fp32 tuple sums in the same order)
+    # a later frame leases the arena: the old frame may not touch it any more
+    img2 = render(sc["means"].clone().requires_grad_(True))
+    with pytest.raises(RuntimeError, match="later frame"):
+        loss.backward()
+    img2.sum().backward()
+    ops.release_arenas()
+
+
+# --------------------------------------------------------------------------- #
+# nearest-first selection
+# --------------------------------------------------------------------------- #
+def _np_select_bound(keys, weights, budget):
+    """reference: smallest multiple of 512 whose keys below it carry >= budget of the weights (numpy)"""
+    import numpy as np
+    vis = keys < 2 ** 31
+    k, w = keys[vis], weights[vis].astype(np.int64)
+    if w.sum() < budget:
+        return 0x80000000, int(w.sum())
+    order = np.argsort(k >> 9, kind="stable")
+    b = (k >> 9)[order]
+    cw = np.cumsum(w[order])
+    first = int(np.searchsorted(cw, budget, side="left"))        # first element at which the cumulative weight reaches it
+    return (int(b[first]) + 1) << 9, int(w.sum())
+
+
+@pytest.mark.parametrize("P,N,budget,dist", [(1, 5000, 3000, "uniform"), (5, 100_003, 400_000, "uniform"),
+                                              (3, 70_001, 10 ** 9, "uniform"), (4, 50_000, 1, "narrow"),
+                                              (10, 30_000, 90_000, "narrow"), (2, 4096, 2 ** 33, "uniform")])
+def test_depth_select_bound_and_selective_sort(gs, dev, P, N, budget, dist):
+    """gs_depth_select + gs_segmented_sort_select_u32 at the C ABI against numpy: the bound of every segment (a multiple
+    of 512; 0x80000000 when the segment carries less than the budget), the frame's total weight, the selection sorted
+    stably with its packed / gathered counts, the complement [bound, culled) likewise, the source keys left intact."""
+    import ctypes
+    import numpy as np
+    from gsdeblur_amd import _lib
+    from gsdeblur_amd.ops import _ptr, _stream
+    L = _lib.load()
+    rng = np.random.default_rng(P * 1000 + N)
+    n = P * N
+    if dist == "uniform":
+        z = rng.uniform(0.02, 60.0, n).astype(np.float32)
+    else:
+        z = (1.0 + rng.uniform(0, 1e-3, n)).astype(np.float32)      # the whole segment inside a few level-1 buckets
+        z[rng.random(n) < 0.01] = np.float32(1.0)                   # ... with many equal keys
+    keys = z.view(np.uint32).astype(np.int64)
+    culled = rng.random(n) < 0.3
+    keys[culled] = 0xFFFFFFFF
+    w = np.where(rng.random(n) < 0.02, rng.integers(200, 600, n), rng.integers(1, 40, n)).astype(np.int64)
+    w[culled] = 0
+    dk = torch.from_numpy(keys.astype(np.uint32).view(np.int32)).to(dev)
+    dw = torch.from_numpy(w.astype(np.int32)).to(dev)
+    ws_b = L.gs_depth_select_workspace_bytes(P)
+    ws = torch.zeros(ws_b, dtype=torch.uint8, device=dev)
+    thr = torch.full((P,), -1, dtype=torch.int32, device=dev)
+    grand = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(L.gs_depth_select(n, N, _ptr(dk), _ptr(dw), int(budget), _ptr(thr), _ptr(grand), _ptr(ws), ws_b, _stream()),
+               "depth_select")
+    got_thr = thr.cpu().numpy().view(np.uint32).astype(np.int64)
+    tot = 0
+    for p in range(P):
+        want, seg_total = _np_select_bound(keys[p * N:(p + 1) * N], w[p * N:(p + 1) * N], budget)
+        tot += seg_total
+        assert int(got_thr[p]) == want, (p, hex(int(got_thr[p])), hex(want))
+    assert (int(grand.item()) & 0xFFFFFFFF) == (tot & 0xFFFFFFFF)
+    # the selective sort, both sides of the bound
+    sort_ws_b = L.gs_segmented_sort_compact_workspace_bytes(n, N, 0, 31, 8)
+    for side in ("below", "behind"):
+        k0, v0, k1, v1, cnt_out = (torch.full((n,), 0x7F7F7F7F, dtype=torch.int32, device=dev) for _ in range(5))
+        n_live = torch.zeros(P, dtype=torch.int32, device=dev)
+        sws = torch.empty(sort_ws_b, dtype=torch.uint8, device=dev)
+        res = ctypes.c_int(0)
+        lo, hi = (None, thr) if side == "below" else (thr, None)
+        _lib.check(L.gs_segmented_sort_select_u32(n, N, _ptr(dk), _ptr(k0), _ptr(v0), _ptr(k1), _ptr(v1), 0, 31, 8,
+                                                  0xFFFFFFFF, _ptr(lo), _ptr(hi), _ptr(n_live), _ptr(dw), _ptr(cnt_out),
+                                                  _ptr(sws), sort_ws_b, ctypes.byref(res), _stream()), "sort_select")
+        sk, sv = ((k1, v1) if res.value == 1 else (k0, v0))
+        sk, sv, cc, nl = sk.cpu().numpy().view(np.uint32), sv.cpu().numpy(), cnt_out.cpu().numpy(), n_live.cpu().numpy()
+        assert np.array_equal(dk.cpu().numpy().view(np.uint32).astype(np.int64), keys)       # source intact
+        for p in range(P):
+            seg = keys[p * N:(p + 1) * N]
+            t = int(got_thr[p])
+            keep = (seg < t) if side == "below" else ((seg >= t) & (seg < 2 ** 31))
+            idx = np.nonzero(keep)[0]
+            order = idx[np.argsort(seg[idx], kind="stable")]
+            m = order.size
+            assert int(nl[p]) == m, (side, p, int(nl[p]), m)
+            assert np.array_equal(sv[p * N:p * N + m].astype(np.int64), order + p * N), (side, p)
+            assert np.array_equal(sk[p * N:p * N + m].astype(np.int64), seg[order]), (side, p)
+            assert np.array_equal(cc[p * N:p * N + m].astype(np.int64), w[p * N:(p + 1) * N][order]), (side, p)
+
+
+def _saturating_scene(gs, dev, n, W, H, seed=23):
+    """the seeded scene with its nearest 3000 Gaussians made large and opaque: every pixel stops within a few dozen
+    entries, i.e. within the first depth slice of any budget — the shape of the benchmark frame at test size"""
+    sc = gs.data.synthetic_scene(n, W, H, seed=seed, scale_mult=3.0)
+    near = torch.argsort(sc["means"][:, 2])[:3000]
+    sc["log_scales"] = sc["log_scales"].clone()
+    sc["opacity_logits"] = sc["opacity_logits"].clone()
+    sc["log_scales"][near] += 2.5
+    sc["opacity_logits"][near] = 10.0
+    return to_dev(sc, dev)
+
+
+def _render_both_ways(gs, dev, sc, S, R, H, W, base, lazy, model="se3", shared=False):
+    """one frame with the nearest-first selection forced on (GSD_DEPTH_SELECT=2) and one with it off: results + states"""
+    from gsdeblur_amd import ops
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, R, 1 / 30 if R > 1 else 0.0)
+    times_t = torch.tensor(times, device=dev)
+    g = torch.Generator().manual_seed(8)
+    wt, wa = torch.rand(H, W, 3, generator=g).to(dev), torch.rand(S, H, W, generator=g).to(dev)
+    saved = (ops.DEPTH_SELECT, ops.SLICE_BASE, ops.SLICE_ADAPT, ops.LAZY_RECORDS)
+    res = []
+    try:
+        ops.SLICE_BASE, ops.SLICE_ADAPT, ops.LAZY_RECORDS = base, 0, lazy
+        for sel in (2, 0):
+            ops.DEPTH_SELECT = sel
+            ops.release_arenas()
+            p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+            lin = (sc["lin_vel"] * 5).clone().requires_grad_(True)
+            ang = (sc["ang_vel"] * 3).clone().requires_grad_(True)
+            V = sc["viewmat"].clone().requires_grad_(True)
+            kw = dict(gamma=2.2, min_rgb_level=10.0, raw_params=True, hints=ops.FrameHints())
+            if model == "se3":
+                vms = gs.subpose_viewmats(V, lin, ang, times_t)
+                rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"], p["quats"], p["opacity_logits"], p["sh"],
+                                                        vms, None, S, R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, **kw)
+            else:
+                rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"], p["quats"], p["opacity_logits"], p["sh"],
+                                                        V, None, S, R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W,
+                                                        lin_vel=lin, ang_vel=ang, times=times_t, shared_list=shared, **kw)
+            ((rgb * wt).sum() + (alphas * wa).sum()).backward()
+            res.append(dict(rgb=rgb.detach().clone(), alphas=alphas.detach().clone(), radii=radii.clone(),
+                            grads={k: v.grad.clone() for k, v in p.items()},
+                            pose=dict(lin=lin.grad.clone(), ang=ang.grad.clone(), V=V.grad.clone()),
+                            slices=[int(v) for v in ops.last_slice_intersects if int(v) > 0],
+                            state=ops.last_depth_select, n_total=ops.last_num_intersects))
+    finally:
+        ops.DEPTH_SELECT, ops.SLICE_BASE, ops.SLICE_ADAPT, ops.LAZY_RECORDS = saved
+        ops.release_arenas()
+    return res
+
+
+@pytest.mark.parametrize("tag,S,R,base,lazy,profile,model,shared,want_state", [
+    ("one slice", 3, 1, 512, 0, "saturating", "se3", False, 1),
+    ("one slice, lazy records", 3, 1, 512, 2, "saturating", "se3", False, 1),
+    ("the first slice leaves tiles open", 3, 1, 24, 0, "survey", "se3", False, 2),
+    ("the first slice leaves tiles open, lazy records", 2, 1, 16, 2, "trained", "se3", False, 2),
+    ("rolling-shutter bands", 2, 5, 48, 2, "survey", "se3", False, 2),
+    ("pixel velocity, per-sample lists", 3, 1, 32, 0, "survey", "pixel_velocity", False, 2),
+    ("pixel velocity, shared list", 3, 1, 32, 0, "survey", "pixel_velocity", True, 2),
+    ("a frame that fits its budget whole", 2, 1, 100_000, 0, "survey", "se3", False, 1)])
+def test_nearest_first_selection_gives_the_same_frame(gs, dev, tag, S, R, base, lazy, profile, model, shared, want_state):
+    """round 6: the depth pre-sort restricted to the pairs the first slice's budget reaches (gs_frame_desc.depth_select)
+    against the full pre-sort — image, alphas, radii bit for bit, the frame's pair total, every gradient (bit for bit
+    when the frame is one slice on both sides: the same Gaussians' tuples are summed in the same order; to fp32 summation
+    order when slice boundaries move).  Cases: one slice; a first slice that leaves tiles open, so that the pairs behind
+    the selection are sorted and planned afterwards (state 2); rolling-shutter bands; the pixel-velocity model with
+    per-sample and shared lists; a frame whose pairs all fit the budget (bound = everything)."""
+    n, W, H = 60000, 208, 176
+    if profile == "saturating":
+        sc = _saturating_scene(gs, dev, n, W, H)
+    else:
+        sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=23, scale_mult=3.0, profile=profile), dev)
+    a, b = _render_both_ways(gs, dev, sc, S, R, H, W, base, lazy, model, shared)
+    print(f"nearest-first selection [{tag}]: slices {a['slices']} (selection) vs {b['slices']} (full sort), "
+          f"state {a['state']}, pairs {a['n_total']}")
+    assert a["state"] == want_state and b["state"] == 0, (a["state"], b["state"])
+    assert a["n_total"] == b["n_total"]
+    assert torch.isfinite(a["rgb"]).all() and float(a["rgb"].max()) > 0.05
+    assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["alphas"], b["alphas"]) and torch.equal(a["radii"], b["radii"])
+    one_slice = len(a["slices"]) == 1 and len(b["slices"]) == 1
+    for k in a["grads"]:
+        ga, gb = a["grads"][k], b["grads"][k]
+        assert float(ga.abs().max()) > 0, k
+        if one_slice and model == "se3":
+            assert torch.equal(ga, gb), (k, float((ga - gb).abs().max()))
+        else:
+            assert float((ga - gb).abs().max()) <= 3e-5 * float(gb.abs().max()), (k, float((ga - gb).abs().max()))
+    for k in a["pose"]:
+        d = float((a["pose"][k] - b["pose"][k]).abs().max())
+        assert d <= 3e-3 * float(b["pose"][k].abs().max()) + 1e-12, (k, d)
+
+
+def test_frame_hints_switch_the_selection_on_and_off(gs, dev):
+    """FrameHints.depth_select(): the first frame of a scene sorts everything; a scene whose last frame stopped in ONE
+    slice holding under half of its pairs selects from the next frame on; a frame whose selection turns out short
+    (state 2) switches it off again (and, with SLICE_ADAPT, grows the budget) — all through ONE hints object, the way
+    SplatfactoDeblurModel owns one."""
+    from gsdeblur_amd import ops
+    n, W, H, S = 60000, 208, 176, 2
+    sc = _saturating_scene(gs, dev, n, W, H)
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, 1, 0.0)
+    vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"], sc["ang_vel"], torch.tensor(times, device=dev))
+    saved = (ops.DEPTH_SELECT, ops.SLICE_BASE, ops.SLICE_ADAPT)
+
+    def frame(h):
+        with torch.no_grad():
+            img = gs.render_combined(sc["means"], sc["log_scales"], sc["quats"], sc["opacity_logits"], sc["sh"], vms, None, S, 1,
+                                     sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2, raw_params=True, hints=h)[0]
+        return img, ops.last_depth_select, len([v for v in ops.last_slice_intersects if int(v) > 0])
+    try:
+        ops.DEPTH_SELECT, ops.SLICE_ADAPT = 1, 1
+        ops.SLICE_BASE = 512
+        h = ops.FrameHints()
+        img0, st0, k0 = frame(h)
+        assert st0 == 0 and k0 == 1 and h.depth_select()            # first frame: full sort; it stopped in one small slice
+        img1, st1, k1 = frame(h)
+        assert st1 == 1 and k1 == 1 and torch.equal(img0, img1)      # from now on: the selection
+        img2, st2, _ = frame(h)
+        assert st2 == 1 and torch.equal(img0, img2) and h.select_misses == 0 and h.settled
+        # a budget this scene does not stop within: the selection of the next frame falls short once, then it is off
+        ops.SLICE_BASE = 2
+        h2 = ops.FrameHints()
+        h2.last_slices, h2.box_share = 1, 0.1                        # (as if the last frame had stopped early)
+        img3, st3, k3 = frame(h2)
+        assert st3 == 2 and k3 >= 2 and h2.select_misses == 1 and not h2.depth_select()
+        img4, st4, _ = frame(h2)
+        assert st4 == 0 and torch.equal(img3, img4) and torch.equal(img3, img0)
+    finally:
+        ops.DEPTH_SELECT, ops.SLICE_BASE, ops.SLICE_ADAPT = saved
+        ops.release_arenas()
