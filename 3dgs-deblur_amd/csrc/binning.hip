@@ -1433,17 +1433,15 @@ __global__ __launch_bounds__(256) void emit_open_kernel(int n_slice, int N, int 
 // whole 512-ulp bucket could be left out; the compacting sort then keeps and orders ONLY those (SegDev key_hi), and the
 // pairs behind the bound are sorted later, if the frame's first slice leaves a tile open (SegDev key_lo).  Where the
 // bound falls changes nothing in the images: a slice boundary never does.
-// Each level is ONE launch: blocks histogram their share of the segment in LDS (64-bit sums), add it to the segment's
-// global histogram, and the segment's last block to finish (ticket counter) walks the 2048 totals.
+// Three launches, ordered by the stream alone: level-0 histogram (LDS, 64-bit sums, flushed with device-scope atomics),
+// level-1 histogram (every block first finds level 0's crossing for itself from the 2048 totals), and one block per
+// segment that walks both histograms and writes the bound.  (First built with a ticket counter and __threadfence() so
+// that a segment's last block did the walk: on this 8-XCD part an agent-scope fence is an L2 write-back, and 2560 waves
+// issuing one made each level a 50 us kernel; measured, profiles/r06_depth_select_fence.txt.)
 // ---------------------------------------------------------------------------
 constexpr int kSelBits = 11, kSelBins = 1 << kSelBits;
-struct SelSeg {                                // per segment, zeroed by the caller before level 0
+struct SelSeg {                                // per segment, zeroed by the caller
   unsigned long long hist[2][kSelBins];
-  unsigned long long before;                   // level 0: weight of the buckets in front of b1
-  unsigned long long grand;                    // level 0: weight of every visible pair of the segment
-  unsigned done[2];
-  unsigned b1;                                 // level 0: the bucket the bound falls into (kSelBins: everything is selected)
-  unsigned pad;
 };
 
 __device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long long v, unsigned long long& total,
@@ -1464,24 +1462,43 @@ __device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long lo
   return woff + inc - v;
 }
 
+// where the cumulative weight of a 2048-bin histogram reaches `target` (all 256 threads of the block): the bin, or
+// kSelBins when the whole histogram carries less; *before = weight in front of that bin, *total = weight of all bins
+__device__ __forceinline__ unsigned sel_crossing(const unsigned long long* __restrict__ hist, unsigned long long target,
+                                                 unsigned long long* s_scan /*[8]*/, unsigned long long* s_res /*[2]*/,
+                                                 unsigned long long& before, unsigned long long& total) {
+  constexpr int PER = kSelBins / 256;
+  if (threadIdx.x == 0) { s_res[0] = (unsigned long long)kSelBins; s_res[1] = 0ull; }
+  unsigned long long c[PER], sum = 0ull;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { c[j] = hist[threadIdx.x * PER + j]; sum += c[j]; }
+  unsigned long long run = block_excl_scan64(sum, total, s_scan);      // (its barriers also publish s_res)
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    if (run < target && run + c[j] >= target) { s_res[0] = (unsigned long long)(threadIdx.x * PER + j); s_res[1] = run; }
+    run += c[j];                                                       // (at most one thread: the crossing is unique)
+  }
+  __syncthreads();
+  before = s_res[1];
+  const unsigned found = (unsigned)s_res[0];
+  __syncthreads();
+  return found;
+}
+
 constexpr int kSelRounds = 8;                  // keys per thread and chunk: 2048-key chunks
 template <int LEVEL>
-__global__ __launch_bounds__(256) void depth_select_kernel(size_t seg_len, const unsigned* __restrict__ keys,
-                                                           const unsigned* __restrict__ weights,
-                                                           unsigned long long budget, SelSeg* __restrict__ ws,
-                                                           unsigned* __restrict__ thr_out,
-                                                           unsigned* __restrict__ grand_out) {
+__global__ __launch_bounds__(256) void depth_hist_kernel(size_t seg_len, const unsigned* __restrict__ keys,
+                                                         const unsigned* __restrict__ weights,
+                                                         unsigned long long budget, SelSeg* __restrict__ ws) {
   __shared__ unsigned long long h[kSelBins];
-  __shared__ unsigned long long s_scan[8];
-  __shared__ unsigned s_flag, s_found;
+  __shared__ unsigned long long s_scan[8], s_res[2];
   const unsigned seg = blockIdx.y;
   SelSeg& S = ws[seg];
   unsigned b1 = 0;
   if (LEVEL == 1) {
-    b1 = S.b1;                                 // (written by level 0's last block: a kernel boundary lies in between)
-    if (b1 >= (unsigned)kSelBins) {            // every visible pair is selected: level 0 wrote the bound already
-      return;
-    }
+    unsigned long long before, total;
+    b1 = sel_crossing(S.hist[0], budget, s_scan, s_res, before, total);
+    if (b1 >= (unsigned)kSelBins) return;      // the segment carries less than the budget: everything is selected
   }
   for (int d = threadIdx.x; d < kSelBins; d += 256) h[d] = 0ull;
   __syncthreads();
@@ -1492,14 +1509,15 @@ __global__ __launch_bounds__(256) void depth_select_kernel(size_t seg_len, const
 #pragma unroll
     for (int r = 0; r < kSelRounds; ++r) {
       const size_t i = base + (size_t)r * 256 + threadIdx.x;
-      k[r] = i < limit ? keys[i] : 0xFFFFFFFFu;
+      k[r] = keys[min(i, limit - 1)];
+      if (i >= limit) k[r] = 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int r = 0; r < kSelRounds; ++r) {
       const size_t i = base + (size_t)r * 256 + threadIdx.x;
       // (visible keys are positive floats: bit 31 marks a culled pair)
       const bool ok = (k[r] >> 31) == 0u && (LEVEL == 0 || (k[r] >> 20) == b1);
-      w[r] = (ok && i < limit) ? weights[i] : 0u;
+      w[r] = ok ? weights[min(i, limit - 1)] : 0u;
     }
 #pragma unroll
     for (int r = 0; r < kSelRounds; ++r)
@@ -1508,47 +1526,27 @@ __global__ __launch_bounds__(256) void depth_select_kernel(size_t seg_len, const
   __syncthreads();
   for (int d = threadIdx.x; d < kSelBins; d += 256)
     if (h[d]) atomicAdd(&S.hist[LEVEL][d], h[d]);
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_flag = atomicAdd(&S.done[LEVEL], 1u) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!s_flag) return;
-  // ---- the segment's last block: where does the cumulative weight reach the target? ----
-  __threadfence();
-  if (threadIdx.x == 0) s_found = (unsigned)kSelBins;
-  constexpr int PER = kSelBins / 256;
-  unsigned long long c[PER], sum = 0ull;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    c[j] = __hip_atomic_load(&S.hist[LEVEL][threadIdx.x * PER + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sum += c[j];
-  }
-  unsigned long long total;
-  unsigned long long run = block_excl_scan64(sum, total, s_scan);      // (its barriers also publish s_found)
-  const unsigned long long before0 = LEVEL == 0 ? 0ull : S.before;
-  const unsigned long long target = budget > before0 ? budget - before0 : 1ull;
-  unsigned long long my_before = 0ull;
-  int mine = -1;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    if (mine < 0 && run < target && run + c[j] >= target) { mine = threadIdx.x * PER + j; my_before = run; }
-    run += c[j];
-  }
-  if (mine >= 0) s_found = (unsigned)mine;     // at most one thread: the crossing is unique
-  __syncthreads();
-  const unsigned found = s_found;
-  if (LEVEL == 0) {
-    if (mine >= 0) S.before = my_before;
-    if (threadIdx.x == 0) {
-      S.b1 = found;
-      S.grand = total;
-      if (grand_out) atomicAdd(grand_out, (unsigned)total);           // frame total of bounding-box pairs (mod 2^32)
-      if (found >= (unsigned)kSelBins) thr_out[seg] = 0x80000000u;    // the segment holds less than the budget: all of it
-    }
-  } else if (threadIdx.x == 0) {
+}
+
+// one block per segment: the bound from the two histograms
+__global__ __launch_bounds__(256) void depth_find_kernel(unsigned long long budget, const SelSeg* __restrict__ ws,
+                                                         unsigned* __restrict__ thr_out,
+                                                         unsigned* __restrict__ grand_out) {
+  __shared__ unsigned long long s_scan[8], s_res[2];
+  const unsigned seg = blockIdx.x;
+  const SelSeg& S = ws[seg];
+  unsigned long long before0, total0, before1, total1;
+  const unsigned b1 = sel_crossing(S.hist[0], budget, s_scan, s_res, before0, total0);
+  unsigned thr = 0x80000000u;                  // the segment holds less than the budget: all of it
+  if (b1 < (unsigned)kSelBins) {
     // level 0 guarantees the crossing lies inside bucket b1; (b1, b2) + 1 is the exclusive bound in 512-ulp buckets
-    const unsigned b2 = found >= (unsigned)kSelBins ? (unsigned)(kSelBins - 1) : found;
-    thr_out[seg] = (((b1 << kSelBits) | b2) + 1u) << 9;
+    unsigned b2 = sel_crossing(S.hist[1], budget - before0, s_scan, s_res, before1, total1);
+    if (b2 >= (unsigned)kSelBins) b2 = (unsigned)(kSelBins - 1);
+    thr = (((b1 << kSelBits) | b2) + 1u) << 9;
+  }
+  if (threadIdx.x == 0) {
+    thr_out[seg] = thr;
+    if (grand_out) atomicAdd(grand_out, (unsigned)total0);            // frame total of bounding-box pairs (mod 2^32)
   }
 }
 
@@ -1835,13 +1833,15 @@ GS_EXPORT int gs_depth_select(long long n, long long seg_len, const unsigned* ke
   if (segs > 65535) return GS_ERR_INVALID;
   if (ws_bytes < gs_depth_select_workspace_bytes((int)segs)) return GS_ERR_WORKSPACE;
   const long long chunks = (seg_len + 256 * kSelRounds - 1) / (256 * kSelRounds);
-  // about two blocks per CU over all segments, at least two chunks per block
-  const unsigned gx = (unsigned)std::max(1ll, std::min((chunks + 1) / 2, std::max(1ll, 640 / segs)));
+  // about four blocks per CU over all segments, at least two chunks per block
+  const unsigned gx = (unsigned)std::max(1ll, std::min((chunks + 1) / 2, std::max(1ll, 1024 / segs)));
   SelSeg* S = reinterpret_cast<SelSeg*>(ws);
-  hipLaunchKernelGGL(depth_select_kernel<0>, dim3(gx, (unsigned)segs), dim3(256), 0, (hipStream_t)stream, (size_t)seg_len,
-                     keys, weights, (unsigned long long)budget, S, thr_out, grand_out);
-  hipLaunchKernelGGL(depth_select_kernel<1>, dim3(gx, (unsigned)segs), dim3(256), 0, (hipStream_t)stream, (size_t)seg_len,
-                     keys, weights, (unsigned long long)budget, S, thr_out, (unsigned*)nullptr);
+  hipLaunchKernelGGL(depth_hist_kernel<0>, dim3(gx, (unsigned)segs), dim3(256), 0, (hipStream_t)stream, (size_t)seg_len,
+                     keys, weights, (unsigned long long)budget, S);
+  hipLaunchKernelGGL(depth_hist_kernel<1>, dim3(gx, (unsigned)segs), dim3(256), 0, (hipStream_t)stream, (size_t)seg_len,
+                     keys, weights, (unsigned long long)budget, S);
+  hipLaunchKernelGGL(depth_find_kernel, dim3((unsigned)segs), dim3(256), 0, (hipStream_t)stream,
+                     (unsigned long long)budget, S, thr_out, grand_out);
   return gs_launch_status();
 }
 
