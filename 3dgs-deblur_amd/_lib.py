@@ -16,14 +16,14 @@ _SIGS = {
     "gs_subpose_viewmats_fwd": [_I, _P, _P, _P, _P, _P, _P],
     "gs_subpose_viewmats_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gs_project_fwd": [_I, _P, _P, _F, _P, _P, _F, _F, _F, _F, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "gs_project_bwd": [_I, _P, _P, _F, _P, _P, _F, _F, _F, _F, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "gs_project_bwd": [_I, _P, _P, _F, _P, _P, _F, _F, _F, _F, _I, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _P],
     "gs_sh_fwd": [_I, _I, _I, _P, _P, _P, _P],
     "gs_sh_bwd": [_I, _I, _I, _P, _P, _P, _P],
     "gs_project_fused_fwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I, _I,
                              _P, _P, _P, _P, _P, _I, _P],
     "gs_slice_colors": [_I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P],
     "gs_project_fused_bwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _F, _F, _F, _F, _I, _I, _F, _I,
-                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P],
+                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _L, _P],
     "gs_project_pixvel_fwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P, _P, _F, _F, _F, _F, _I, _I, _F, _I, _I,
                               _P, _P, _P, _P, _F, _P, _P, _I, _P],
     "gs_rasterize_fwd_rs_slice": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _F, _P,
@@ -31,7 +31,7 @@ _SIGS = {
     "gs_rasterize_bwd_rs_slice": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _F, _F,
                                   _P, _I, _F, _P, _P],
     "gs_project_pixvel_bwd": [_I, _I, _P, _P, _F, _P, _P, _P, _I, _I, _P, _P, _P, _F, _F, _F, _F, _I, _I, _F, _I,
-                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P],
+                              _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _L, _P],
     "gs_pack_records": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "gs_unpack_record_grads": [_I, _P, _P, _P, _P, _P, _P],
     "gs_exclusive_scan_u32": [_L, _P, _P, _P, _P, _L, _P],
@@ -91,6 +91,7 @@ _SIGS_LL = {
     "gs_segmented_sort_workspace_bytes": [_L, _L, _I, _I],
     "gs_segmented_sort_compact_workspace_bytes": [_L, _L, _I, _I, _I],
     "gs_depth_select_workspace_bytes": [_I],
+    "gs_project_pose_scratch_bytes": [_I, _I, _I],
     "gs_image_loss_workspace_bytes": [_I, _I],
     "gs_frame_backward_bytes": [_P],
 }

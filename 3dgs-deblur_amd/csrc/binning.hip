@@ -167,12 +167,25 @@ __global__ __launch_bounds__(256) void scan_apply_fused_kernel(size_t n, const u
   block_excl_scan(part, prefix, lds);              // total over the block = sum of the preceding block sums
   const BlockLive bl = block_live((size_t)blockIdx.x * kScanBlock, n, sm);
   size_t base = (size_t)blockIdx.x * kScanBlock + (size_t)threadIdx.x * kScanItems;
+  const size_t last_block = n ? (n - 1) / kScanBlock : 0;
+  if (sm.cnt && !bl.mixed && (size_t)blockIdx.x * kScanBlock >= bl.vend) {
+    // segmented scan, a block without a live element (round 6: a nearest-first selection leaves a few live blocks per
+    // segment, and writing the flat prefix behind them was 20 MB per frame): out is only defined for live ranks and at
+    // every segment's first rank (what the slice plan reads) — a block inside one segment holds at most one of those
+    const size_t b0 = (size_t)blockIdx.x * kScanBlock;
+    const size_t first = ((b0 + sm.seg_len - 1) / sm.seg_len) * sm.seg_len;       // first segment start at or behind b0
+    if (threadIdx.x == 0) {
+      if (first < min(b0 + (size_t)kScanBlock, n)) out[first] = prefix;
+      if (total_out && blockIdx.x == last_block) *total_out = prefix;
+    }
+    return;
+  }
   unsigned v[kScanItems];
   unsigned s = 0;
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     size_t i = base + k;
-    v[k] = elem_live(i, n, bl, sm) ? in[i] : 0u;   // (a block with no live element reads nothing: out is flat there)
+    v[k] = elem_live(i, n, bl, sm) ? in[i] : 0u;
     s += v[k];
   }
   unsigned total;
@@ -183,7 +196,6 @@ __global__ __launch_bounds__(256) void scan_apply_fused_kernel(size_t n, const u
     if (i < n) out[i] = ex;
     ex += v[k];
   }
-  const size_t last_block = n ? (n - 1) / kScanBlock : 0;
   if (total_out && blockIdx.x == last_block && threadIdx.x == 0) *total_out = prefix + total;
 }
 
@@ -1698,7 +1710,8 @@ GS_EXPORT int gs_segmented_sort_compact_u32(long long n, long long seg_len, unsi
 }
 
 // Exclusive scan over n = k*seg_len values of which only the first seg_counts[s] of every segment are live: the rest
-// count as zero and are not read (out is still written everywhere).
+// count as zero and are not read.  out is defined for the live ranks and at every segment's first rank; what lies
+// behind a segment's live ranks is unspecified (round 6: blocks without a live element write nothing else).
 GS_EXPORT int gs_exclusive_scan_segments_u32(long long n, long long seg_len, const unsigned* seg_counts,
                                              const unsigned* in, unsigned* out, unsigned* total_out, void* ws,
                                              long long ws_bytes, void* stream) {

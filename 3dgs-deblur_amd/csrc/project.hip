@@ -29,28 +29,39 @@ __global__ void subpose_fwd_kernel(int P, const float* __restrict__ V0, const fl
   out[16 * p + 12] = 0.f; out[16 * p + 13] = 0.f; out[16 * p + 14] = 0.f; out[16 * p + 15] = 1.f;
 }
 
-// one thread per (sub-pose, input tangent): thread (p, t) seeds input t of the 18 (12 viewmat, 3 lin, 3 ang)
+// one work item per (sub-pose, input tangent): item (p, t) seeds input t of the 18 (12 viewmat, 3 lin, 3 ang)
 // with a unit dual part and pushes it through the closed form — a Dual<1> chain is short enough to stay in
 // registers, where the former one-thread-per-sub-pose Dual<18> version spilled (41 us for 5 sub-poses).
-__global__ void subpose_bwd_kernel(int P, const float* __restrict__ V0, const float* __restrict__ lin,
+// ONE block (round 6): the P contributions to every tangent are parked in LDS and added up in sub-pose order by one
+// thread per tangent — the camera-level gradients are what the pose / velocity optimizers consume
+// (/root/reference/train.py:40,66), and fp32 atomics across sub-poses made them differ from run to run.
+__global__ __launch_bounds__(256) void subpose_bwd_kernel(int P, const float* __restrict__ V0, const float* __restrict__ lin,
                                    const float* __restrict__ ang, const float* __restrict__ times,
                                    const float* __restrict__ v_out, float* __restrict__ v_V0,
                                    float* __restrict__ v_lin, float* __restrict__ v_ang) {
   typedef Dual<1> D;
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= P * 18) return;
-  const int p = gid / 18, t = gid - p * 18;
-  D dV[12], dl[3], da[3], o[12];
-  for (int j = 0; j < 12; ++j) { dV[j] = D(V0[j]); dV[j].d[0] = (j == t) ? 1.f : 0.f; }
-  for (int j = 0; j < 3; ++j) {
-    dl[j] = D(lin[j]); dl[j].d[0] = (12 + j == t) ? 1.f : 0.f;
-    da[j] = D(ang[j]); da[j].d[0] = (15 + j == t) ? 1.f : 0.f;
+  extern __shared__ float sp_part[];          // [P][18]
+  for (int gid = threadIdx.x; gid < P * 18; gid += blockDim.x) {
+    const int p = gid / 18, t = gid - p * 18;
+    D dV[12], dl[3], da[3], o[12];
+    for (int j = 0; j < 12; ++j) { dV[j] = D(V0[j]); dV[j].d[0] = (j == t) ? 1.f : 0.f; }
+    for (int j = 0; j < 3; ++j) {
+      dl[j] = D(lin[j]); dl[j].d[0] = (12 + j == t) ? 1.f : 0.f;
+      da[j] = D(ang[j]); da[j].d[0] = (15 + j == t) ? 1.f : 0.f;
+    }
+    subpose_viewmat<D>(dV, dl, da, D(times[p]), o);
+    float acc = 0.f;
+    for (int j = 0; j < 12; ++j) acc += v_out[16 * p + j] * o[j].d[0];
+    sp_part[gid] = acc;
   }
-  subpose_viewmat<D>(dV, dl, da, D(times[p]), o);
-  float acc = 0.f;
-  for (int j = 0; j < 12; ++j) acc += v_out[16 * p + j] * o[j].d[0];
-  float* dst = t < 12 ? v_V0 + t : (t < 15 ? v_lin + (t - 12) : v_ang + (t - 15));
-  atomic_add_f32(dst, acc);
+  __syncthreads();
+  if (threadIdx.x < 18) {
+    const int t = threadIdx.x;
+    float sum = 0.f;
+    for (int p = 0; p < P; ++p) sum += sp_part[p * 18 + t];
+    float* dst = t < 12 ? v_V0 + t : (t < 15 ? v_lin + (t - 12) : v_ang + (t - 15));
+    *dst += sum;                               // (accumulating contract: the caller zeroes; single writer)
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -87,8 +98,13 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(int N, const float* __
   }
 }
 
-// block-reduce 12 viewmat-gradient components and add them to v_V (global, atomics)
-__device__ __forceinline__ void reduce_vV(const float vV[12], float* __restrict__ v_V, float* lds /*[4*12]*/) {
+// Camera-level gradients (view matrix, twist), deterministic since round 6: a block adds the 12 components of its
+// threads up in a fixed tree (DPP wave sums, then the four waves in order) into a block-private LDS accumulator
+// (`acc`, one writer per component; a block that runs the body several times adds its rounds in order), writes the
+// accumulator to ITS row of a caller-owned scratch array when it is done, and pose_reduce_kernel adds the rows up in
+// block order.  (Rounds 1-5: fp32 atomics onto v_V — the same frame gave gradients that differed in the last bits from
+// run to run, and the test bar of exactly these tensors had been widened 3x to absorb it.)
+__device__ __forceinline__ void reduce_vV(const float vV[12], float* __restrict__ acc /*LDS [12]*/, float* lds /*[4*12]*/) {
   const int lane = lane_id(), wave = threadIdx.x >> 6;
 #pragma unroll
   for (int j = 0; j < 12; ++j) {
@@ -96,19 +112,48 @@ __device__ __forceinline__ void reduce_vV(const float vV[12], float* __restrict_
     if (lane == 63) lds[wave * 12 + j] = t;
   }
   __syncthreads();
-  if (threadIdx.x < 12) {
-    float t = lds[threadIdx.x] + lds[12 + threadIdx.x] + lds[24 + threadIdx.x] + lds[36 + threadIdx.x];
-    if (t != 0.f) atomic_add_f32(v_V + threadIdx.x, t);
-  }
+  if (threadIdx.x < 12) acc[threadIdx.x] += (lds[threadIdx.x] + lds[12 + threadIdx.x]) + (lds[24 + threadIdx.x] + lds[36 + threadIdx.x]);
   __syncthreads();
+}
+
+// partial [nblocks][slots][12] (every row written by its block) -> dst(slot)[0..11] += sum over the blocks, in order:
+// thread t adds rows t, t + 256, ... ; the 256 partial sums then go through a fixed tree.  One block per slot.
+struct PoseDst { float* slot0; float* slot1; int stride; };   // slot s -> (s == 1 && slot1) ? slot1 : slot0 + s * stride
+__global__ __launch_bounds__(256) void pose_reduce_kernel(const float* __restrict__ partial, int nblocks, int slots,
+                                                          PoseDst dst) {
+  __shared__ double red[256][13];              // (double: the rows are fp32 block sums; adding thousands of them costs nothing)
+  const int sl = blockIdx.x;
+  float* out = (sl == 1 && dst.slot1) ? dst.slot1 : dst.slot0 + (size_t)sl * dst.stride;
+  if (!out) return;
+  double a[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) a[j] = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+    const float* row = partial + ((size_t)b * slots + sl) * 12;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) a[j] += (double)row[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 12; ++j) red[threadIdx.x][j] = a[j];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w)
+#pragma unroll
+      for (int j = 0; j < 12; ++j) red[threadIdx.x][j] += red[threadIdx.x + w][j];
+    __syncthreads();
+  }
+  if (threadIdx.x < 12) out[threadIdx.x] += (float)red[0][threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void project_bwd_kernel(int N, const float* __restrict__ means,
     const float* __restrict__ scales, float glob, const float* __restrict__ quats, const float* __restrict__ V,
     Intrin in, const float* __restrict__ v_xys, const float* __restrict__ v_depths,
     const float* __restrict__ v_conics, const float* __restrict__ v_comp, float* __restrict__ v_means,
-    float* __restrict__ v_scales, float* __restrict__ v_quats, float* __restrict__ v_V, int flags) {
+    float* __restrict__ v_scales, float* __restrict__ v_quats, float* __restrict__ v_V /*scratch row array or null*/,
+    int flags) {
   __shared__ float lds[48];
+  __shared__ float acc[12];
+  if (threadIdx.x < 12) acc[threadIdx.x] = 0.f;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   float vV[12];
   for (int j = 0; j < 12; ++j) vV[j] = 0.f;
@@ -135,7 +180,11 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int N, const float* __
     for (int j = 0; j < 3; ++j) { v_means[3 * i + j] = vm[j]; v_scales[3 * i + j] = vs[j]; }
     for (int j = 0; j < 4; ++j) v_quats[4 * i + j] = vq[j];
   }
-  if (v_V) reduce_vV(vV, v_V, lds);
+  if (v_V) {
+    __syncthreads();
+    reduce_vV(vV, acc, lds);
+    if (threadIdx.x < 12) v_V[(size_t)blockIdx.x * 12 + threadIdx.x] = acc[threadIdx.x];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -439,12 +488,13 @@ struct FusedOut {
   float* v_viewmats;      // [P,16] accumulated, may be null
   float* v_xy_sum;        // [N,2] or null
   float* v_twist;         // [12] accumulated, pixel-velocity model, may be null
+  float* pose_partial;    // scratch [blocks][slots][12] of the ordered pose-gradient reduction (with v_viewmats / v_twist)
 };
 
 template <int MAXB>
 __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const float* __restrict__ records,
     const float* __restrict__ v_records, const FusedOut& out, const unsigned char* __restrict__ touched,
-    int i, bool live, float* lds) {
+    int i, bool live, float* lds, float* __restrict__ blk_acc /*LDS [slots][12], see reduce_vV*/) {
   float* __restrict__ v_means = out.v_means; float* __restrict__ v_scales = out.v_scales;
   float* __restrict__ v_quats = out.v_quats; float* __restrict__ v_opac = out.v_opac;
   float* __restrict__ v_sh = out.v_sh; float* __restrict__ v_sh_rest = out.v_sh_rest;
@@ -527,8 +577,8 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
       }
     }
     if (__syncthreads_or(mine)) {
-      if (v_viewmats) reduce_vV(vV, v_viewmats, lds);
-      if (v_twist) reduce_vV(vtw, v_twist, lds);       // 6 components, padded to the reducer's 12
+      if (v_viewmats) reduce_vV(vV, blk_acc, lds);
+      if (v_twist) reduce_vV(vtw, blk_acc + 12, lds);  // 6 components, padded to the reducer's 12
     }
   } else
   for (int p = 0; p < fp.P; ++p) {
@@ -580,7 +630,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedParams& fp, const floa
       }
     }
     // block-uniform skip: most blocks hold nothing the compositor touched in this sub-pose
-    if (v_viewmats && __syncthreads_or(mine)) reduce_vV(vV, v_viewmats + 16 * p, lds);
+    if (v_viewmats && __syncthreads_or(mine)) reduce_vV(vV, blk_acc + 12 * p, lds);
   }
   if (!live) return;
   float vs[3], vq[4];
@@ -784,8 +834,14 @@ template <int MAXB>
 __global__ __launch_bounds__(256) void project_fused_bwd_kernel(FusedParams fp, const float* __restrict__ records,
     const float* __restrict__ v_records, FusedOut out) {
   __shared__ float lds[48];
+  extern __shared__ float blk_acc[];             // [slots][12]: this block's pose-gradient sums (reduce_vV)
+  const int slots = out.pose_partial ? (fp.pixvel ? 2 : fp.P) : 0;
+  for (int k = threadIdx.x; k < slots * 12; k += 256) blk_acc[k] = 0.f;
+  __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  fused_bwd_body<MAXB>(fp, records, v_records, out, nullptr, i, i < fp.N, lds);
+  fused_bwd_body<MAXB>(fp, records, v_records, out, nullptr, i, i < fp.N, lds, blk_acc);
+  __syncthreads();
+  for (int k = threadIdx.x; k < slots * 12; k += 256) out.pose_partial[(size_t)blockIdx.x * slots * 12 + k] = blk_acc[k];
 }
 
 // sparse launch (touched flags): under early termination ~1 % of the Gaussians carry a gradient and they are
@@ -820,6 +876,9 @@ __global__ __launch_bounds__(256, 2) void project_fused_bwd_sparse_kernel(FusedP
   __shared__ float lds[48];
   __shared__ int list[kFusedChunk];
   __shared__ int wave_cnt[4];
+  extern __shared__ float blk_acc[];             // [slots][12]: this block's pose-gradient sums (reduce_vV)
+  const int slots = out.pose_partial ? (fp.pixvel ? 2 : fp.P) : 0;
+  for (int k = threadIdx.x; k < slots * 12; k += 256) blk_acc[k] = 0.f;
   const int lane = lane_id(), wave = threadIdx.x >> 6;
   const int base = blockIdx.x * kFusedChunk;
   if (ZERO_FILL) {
@@ -857,8 +916,10 @@ __global__ __launch_bounds__(256, 2) void project_fused_bwd_sparse_kernel(FusedP
   for (int k0 = 0; k0 < n_list; k0 += 256) {
     const int k = k0 + (int)threadIdx.x;
     const bool live = k < n_list;
-    fused_bwd_body<MAXB>(fp, records, v_records, out, touched, live ? list[k] : 0, live, lds);
+    fused_bwd_body<MAXB>(fp, records, v_records, out, touched, live ? list[k] : 0, live, lds, blk_acc);
   }
+  __syncthreads();
+  for (int k = threadIdx.x; k < slots * 12; k += 256) out.pose_partial[(size_t)blockIdx.x * slots * 12 + k] = blk_acc[k];
 }
 
 // Lazy records (round 5): the records of the n_slice (sub-pose, Gaussian) pairs a depth slice holds — pair j is depth
@@ -1007,7 +1068,7 @@ GS_EXPORT int gs_subpose_viewmats_bwd(int P, const float* viewmat, const float* 
                                       const float* times, const float* v_out, float* v_viewmat, float* v_lin,
                                       float* v_ang, void* stream) {
   if (P <= 0) return GS_ERR_INVALID;
-  hipLaunchKernelGGL(subpose_bwd_kernel, dim3((P * 18 + 63) / 64), dim3(64), 0, (hipStream_t)stream, P, viewmat, lin_vel,
+  hipLaunchKernelGGL(subpose_bwd_kernel, dim3(1), dim3(256), (size_t)P * 18 * sizeof(float), (hipStream_t)stream, P, viewmat, lin_vel,
                      ang_vel, times, v_out, v_viewmat, v_lin, v_ang);
   return gs_launch_status();
 }
@@ -1030,12 +1091,21 @@ GS_EXPORT int gs_project_bwd(int N, const float* means, const float* scales, flo
                              const float* viewmat, float fx, float fy, float cx, float cy, int H, int W, float clip,
                              const float* v_xys, const float* v_depths, const float* v_conics, const float* v_comp,
                              float* v_means, float* v_scales, float* v_quats, float* v_viewmat, int grad_flags,
-                             void* stream) {
+                             void* pose_scratch, long long pose_scratch_bytes_, void* stream) {
   if (N <= 0) return GS_ERR_INVALID;
   Intrin in = make_intrin(fx, fy, cx, cy, H, W, clip);
-  hipLaunchKernelGGL(project_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, means, scales,
+  const int blocks = (N + 255) / 256;
+  // v_viewmat [16] is accumulated into (caller zeroes; nullable): the blocks' sums go through one scratch row each and
+  // are added up in block order (gs_project_pose_scratch_bytes(N, 1, 0))
+  if (v_viewmat && (!pose_scratch || pose_scratch_bytes_ < (long long)blocks * 12 * (long long)sizeof(float)))
+    return GS_ERR_WORKSPACE;
+  float* rows = v_viewmat ? reinterpret_cast<float*>(pose_scratch) : nullptr;
+  hipLaunchKernelGGL(project_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, means, scales,
                      glob_scale, quats, viewmat, in, v_xys, v_depths, v_conics, v_comp, v_means, v_scales, v_quats,
-                     v_viewmat, grad_flags);
+                     rows, grad_flags);
+  if (v_viewmat)
+    hipLaunchKernelGGL(pose_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rows, blocks, 1,
+                       PoseDst{v_viewmat, nullptr, 0});
   return gs_launch_status();
 }
 
@@ -1158,27 +1228,47 @@ GS_EXPORT int gs_slice_colors(int n_slice, const unsigned* slice_gi, const unsig
 
 constexpr int GS_FLAG_ZERO_FILL = 32;     // sparse backward: zero-fill the dense gradient outputs in the kernel itself
 
+// bytes of scratch the ordered pose-gradient reduction of a projection backward takes (reduce_vV / pose_reduce_kernel):
+// one row of 12 floats per block and slot.  with_touched: the sparse form (a block per kFusedChunk Gaussians) runs.
+static long long pose_scratch_bytes(int N, int P, bool pixvel, bool with_touched) {
+  const long long blocks = with_touched ? (N + kFusedChunk - 1) / kFusedChunk : (N + 255) / 256;
+  return blocks * (long long)(pixvel ? 2 : P) * 12 * (long long)sizeof(float);
+}
+
 static int launch_fused_bwd(const FusedParams& fp, int sh_degree, const float* records, const float* v_records,
-                            const FusedOut& out, const unsigned char* touched, hipStream_t st) {
+                            FusedOut out, const unsigned char* touched, void* scratch, long long scratch_bytes,
+                            hipStream_t st) {
   dim3 block(256);
   const int N = fp.N;
+  const bool pose = out.v_viewmats || out.v_twist;
+  const int slots = pose ? (fp.pixvel ? 2 : fp.P) : 0;
+  const size_t lds = (size_t)slots * 12 * sizeof(float);
+  if (pose) {
+    if (!scratch || scratch_bytes < pose_scratch_bytes(N, fp.P, fp.pixvel != 0, touched != nullptr)) return GS_ERR_WORKSPACE;
+    out.pose_partial = reinterpret_cast<float*>(scratch);
+  }
+  dim3 grid(touched ? (N + kFusedChunk - 1) / kFusedChunk : (N + 255) / 256);
   if (touched) {
-    dim3 grid((N + kFusedChunk - 1) / kFusedChunk);
     const bool zf = (fp.flags & GS_FLAG_ZERO_FILL) != 0;
     if (sh_degree <= 3 && zf)
-      hipLaunchKernelGGL((project_fused_bwd_sparse_kernel<16, true>), grid, block, 0, st, fp, records, v_records, out, touched);
+      hipLaunchKernelGGL((project_fused_bwd_sparse_kernel<16, true>), grid, block, lds, st, fp, records, v_records, out, touched);
     else if (sh_degree <= 3)
-      hipLaunchKernelGGL((project_fused_bwd_sparse_kernel<16, false>), grid, block, 0, st, fp, records, v_records, out, touched);
+      hipLaunchKernelGGL((project_fused_bwd_sparse_kernel<16, false>), grid, block, lds, st, fp, records, v_records, out, touched);
     else if (zf)
-      hipLaunchKernelGGL((project_fused_bwd_sparse_kernel<25, true>), grid, block, 0, st, fp, records, v_records, out, touched);
+      hipLaunchKernelGGL((project_fused_bwd_sparse_kernel<25, true>), grid, block, lds, st, fp, records, v_records, out, touched);
     else
-      hipLaunchKernelGGL((project_fused_bwd_sparse_kernel<25, false>), grid, block, 0, st, fp, records, v_records, out, touched);
+      hipLaunchKernelGGL((project_fused_bwd_sparse_kernel<25, false>), grid, block, lds, st, fp, records, v_records, out, touched);
   } else {
-    dim3 grid((N + 255) / 256);
     if (sh_degree <= 3)
-      hipLaunchKernelGGL(project_fused_bwd_kernel<16>, grid, block, 0, st, fp, records, v_records, out);
+      hipLaunchKernelGGL(project_fused_bwd_kernel<16>, grid, block, lds, st, fp, records, v_records, out);
     else
-      hipLaunchKernelGGL(project_fused_bwd_kernel<25>, grid, block, 0, st, fp, records, v_records, out);
+      hipLaunchKernelGGL(project_fused_bwd_kernel<25>, grid, block, lds, st, fp, records, v_records, out);
+  }
+  if (pose) {
+    // the blocks' rows, added up in block order: v_viewmats[p] (SE(3): one slot per sub-pose, 16 floats apart), or
+    // v_viewmat and v_twist (pixel-velocity model: slots 0 and 1)
+    PoseDst dst{out.v_viewmats, fp.pixvel ? out.v_twist : nullptr, fp.pixvel ? 0 : 16};
+    hipLaunchKernelGGL(pose_reduce_kernel, dim3(slots), dim3(256), 0, st, out.pose_partial, (int)grid.x, slots, dst);
   }
   if (!(fp.flags & GS_FLAG_NO_NEEDLE_HP))
     // needles (scale ratio above kNeedleRatio) get their means / scales / quaternion gradients again, in double
@@ -1187,7 +1277,16 @@ static int launch_fused_bwd(const FusedParams& fp, int sh_degree, const float* r
   return gs_launch_status();
 }
 
-// Backward of the fused projection.  v_viewmats [P,16] is accumulated into (caller zeroes; nullable).
+// Scratch of the deterministic pose-gradient reduction (gs_project_bwd: P = 1, with_touched = 0; gs_project_fused_bwd /
+// gs_project_pixvel_bwd: with_touched = whether touched flags are passed).  Needed only when a view-matrix / twist
+// gradient is asked for.
+GS_EXPORT long long gs_project_pose_scratch_bytes(int N, int P, int with_touched) {
+  if (N <= 0 || P <= 0) return 0;
+  return pose_scratch_bytes(N, std::max(P, 2), false, with_touched != 0) + 256;
+}
+
+// Backward of the fused projection.  v_viewmats [P,16] is accumulated into (caller zeroes; nullable; with it,
+// pose_scratch of gs_project_pose_scratch_bytes(N, P, touched != NULL) bytes: the sum over the Gaussians is ordered).
 // grad_flags: 1 = back-propagate through the fov clamp as upstream gsplat 0.1.11 does (as if inactive), 2 = return
 // the quaternion gradient without the projection through q/|q| (deviations 2 and 3).
 GS_EXPORT int gs_project_fused_bwd(int N, int P, const float* means, const float* scales, float glob_scale,
@@ -1197,15 +1296,17 @@ GS_EXPORT int gs_project_fused_bwd(int N, int P, const float* means, const float
                                    const float* v_records, float* v_means, float* v_scales, float* v_quats,
                                    float* v_opacities, float* v_sh, float* v_viewmats,
                                    const unsigned char* touched, float* v_xy_sum, int grad_flags, const float* sh_rest,
-                                   int param_flags, float* v_sh_rest, void* stream) {
+                                   int param_flags, float* v_sh_rest, void* pose_scratch, long long pose_scratch_bytes_,
+                                   void* stream) {
   if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride ||
       (sh_rest != nullptr) != (v_sh_rest != nullptr) || ((grad_flags & GS_FLAG_ZERO_FILL) && !touched))
     return GS_ERR_INVALID;
   FusedParams fp = make_fused(N, P, means, scales, glob_scale, quats, opacities, sh, K_stride, sh_degree, viewmats,
                               fx, fy, cx, cy, H, W, clip, antialiased);
   fp.flags = grad_flags; fp.act = param_flags; fp.sh_rest = sh_rest;
-  const FusedOut out = {v_means, v_scales, v_quats, v_opacities, v_sh, v_sh_rest, v_viewmats, v_xy_sum, nullptr};
-  return launch_fused_bwd(fp, sh_degree, records, v_records, out, touched, (hipStream_t)stream);
+  const FusedOut out = {v_means, v_scales, v_quats, v_opacities, v_sh, v_sh_rest, v_viewmats, v_xy_sum, nullptr, nullptr};
+  return launch_fused_bwd(fp, sh_degree, records, v_records, out, touched, pose_scratch, pose_scratch_bytes_,
+                          (hipStream_t)stream);
 }
 
 // ---- pixel-velocity model (the paper's first-order blur / rolling-shutter model; SURVEY App. A, C1;
@@ -1241,7 +1342,8 @@ GS_EXPORT int gs_project_pixvel_fwd(int N, int P, const float* means, const floa
   return gs_launch_status();
 }
 
-// v_viewmat [16] and v_twist [12: lin 3, ang 3, 6 unused] are accumulated into (caller zeroes; nullable)
+// v_viewmat [16] and v_twist [12: lin 3, ang 3, 6 unused] are accumulated into (caller zeroes; nullable; with either,
+// pose_scratch as in gs_project_fused_bwd)
 GS_EXPORT int gs_project_pixvel_bwd(int N, int P, const float* means, const float* scales, float glob_scale,
                                     const float* quats, const float* opacities, const float* sh, int K_stride,
                                     int sh_degree, const float* viewmat, const float* twist, const float* times,
@@ -1249,7 +1351,8 @@ GS_EXPORT int gs_project_pixvel_bwd(int N, int P, const float* means, const floa
                                     const float* records, const float* v_records, float* v_means, float* v_scales,
                                     float* v_quats, float* v_opacities, float* v_sh, float* v_viewmat, float* v_twist,
                                     const unsigned char* touched, float* v_xy_sum, int grad_flags, const float* sh_rest,
-                                    int param_flags, float* v_sh_rest, void* stream) {
+                                    int param_flags, float* v_sh_rest, void* pose_scratch, long long pose_scratch_bytes_,
+                                    void* stream) {
   if (N <= 0 || P <= 0 || sh_degree < 0 || sh_degree > 4 || (sh_degree + 1) * (sh_degree + 1) > K_stride || !twist ||
       !times || (sh_rest != nullptr) != (v_sh_rest != nullptr) || ((grad_flags & GS_FLAG_ZERO_FILL) && !touched))
     return GS_ERR_INVALID;
@@ -1257,6 +1360,7 @@ GS_EXPORT int gs_project_pixvel_bwd(int N, int P, const float* means, const floa
                               fx, fy, cx, cy, H, W, clip, antialiased);
   fp.pixvel = 1; fp.twist = twist; fp.times = times; fp.flags = grad_flags;
   fp.act = param_flags; fp.sh_rest = sh_rest;
-  const FusedOut out = {v_means, v_scales, v_quats, v_opacities, v_sh, v_sh_rest, v_viewmat, v_xy_sum, v_twist};
-  return launch_fused_bwd(fp, sh_degree, records, v_records, out, touched, (hipStream_t)stream);
+  const FusedOut out = {v_means, v_scales, v_quats, v_opacities, v_sh, v_sh_rest, v_viewmat, v_xy_sum, v_twist, nullptr};
+  return launch_fused_bwd(fp, sh_degree, records, v_records, out, touched, pose_scratch, pose_scratch_bytes_,
+                          (hipStream_t)stream);
 }

@@ -277,6 +277,12 @@ def _check(st: int, what: str):
             raise _lib.HipLibraryError(f"asynchronous HIP fault surfaced right after stage '{what}': {e}") from e
 
 
+def _pose_scratch(N: int, P: int, with_touched: bool, dev) -> Tensor:
+    """scratch of the ordered camera-gradient reduction of a projection backward (include/gsdeblur.h: pose_scratch)"""
+    return torch.empty(int(_L().gs_project_pose_scratch_bytes(int(N), int(P), int(bool(with_touched)))), dtype=torch.uint8,
+                       device=dev)
+
+
 def _viewmat16(viewmat: Tensor) -> Tensor:
     v = _f32(viewmat, "viewmat")
     if v.shape[-2:] == (3, 4):
@@ -781,9 +787,11 @@ class _ProjectGaussians(Function):
         v_quats = torch.empty(N, 4, device=dev)
         need_v = ctx.needs_input_grad[4]
         v_V = torch.zeros(4, 4, device=dev) if need_v else None
+        scratch = _pose_scratch(N, 1, False, dev) if need_v else None
         _check(_L().gs_project_bwd(N, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(V), fx, fy, cx, cy, H, W,
                                    clip, _ptr(v_xys), _ptr(v_depths), _ptr(v_conics), _ptr(v_comp), _ptr(v_means),
-                                   _ptr(v_scales), _ptr(v_quats), _ptr(v_V), UPSTREAM_GRADS & 3, _stream()),
+                                   _ptr(v_scales), _ptr(v_quats), _ptr(v_V), UPSTREAM_GRADS & 3, _ptr(scratch),
+                                   0 if scratch is None else scratch.numel(), _stream()),
                "project_bwd")
         return (v_means, v_scales, None, v_quats, v_V, None, None, None, None, None, None, None, None)
 
@@ -1194,7 +1202,8 @@ class _RenderSubposes(Function):
                 zbuf = torch.zeros(t_len + 4 * (16 * P + 12), dtype=torch.uint8, device=dev)
                 zf = zbuf[t_len:].view(torch.float32)
                 ctx.prealloc = {"touched": zbuf[:P * N], "v_records": torch.empty(P * N, GRAD, device=dev),
-                                "v_V": zf[:16 * P], "v_tw": zf[16 * P:16 * P + 12]}
+                                "v_V": zf[:16 * P], "v_tw": zf[16 * P:16 * P + 12],
+                                "pose_scratch": _pose_scratch(N, P, True, dev)}
             # fused sub-frame averaging: the library launches it behind the last compositor (below: `averaged`)
             averaged = None
             if gamma is not None:
@@ -1319,6 +1328,11 @@ class _RenderSubposes(Function):
         fill_flag = 32 if touched is not None else 0
         pf = ctx.param_flags
         v_lin = v_ang = None
+        # scratch of the ordered camera-gradient reduction (the sparse form runs when touched flags exist)
+        psc = pre.get("pose_scratch") if touched is not None else None
+        if psc is None and (need_v or ctx.needs_input_grad[23] or ctx.needs_input_grad[24]):
+            psc = _pose_scratch(N, P, touched is not None, dev)
+        psc_n = 0 if psc is None else psc.numel()
         with _stage("project_bwd"):
             if ctx.pixvel is not None:
                 twist, times = ctx.pixvel
@@ -1331,7 +1345,7 @@ class _RenderSubposes(Function):
                                                _ptr(v_quats), _ptr(v_opac), _ptr(v_sh), _ptr(v_V), _ptr(v_tw),
                                                _ptr(touched), _ptr(xy_out),
                                                _proj_grad_flags() | (16 if ctx.rs is not None else 0) | fill_flag,
-                                               _ptr(sh_rest), pf, _ptr(v_sh_rest), _stream()),
+                                               _ptr(sh_rest), pf, _ptr(v_sh_rest), _ptr(psc), psc_n, _stream()),
                        "project_pixvel_bwd")
                 if v_tw is not None:
                     v_lin, v_ang = v_tw[0:3], v_tw[3:6]
@@ -1342,7 +1356,7 @@ class _RenderSubposes(Function):
                                               _ptr(v_records), _ptr(v_means), _ptr(v_scales), _ptr(v_quats),
                                               _ptr(v_opac), _ptr(v_sh), _ptr(v_V), _ptr(touched), _ptr(xy_out),
                                               _proj_grad_flags() | fill_flag, _ptr(sh_rest), pf, _ptr(v_sh_rest),
-                                              _stream()), "project_fused_bwd")
+                                              _ptr(psc), psc_n, _stream()), "project_fused_bwd")
         v_bg = (out_T[..., None] * v_img).sum(dim=(0, 1, 2)) if ctx.bg_grad else None
         return ((v_means, v_scales, v_quats, v_opac, v_sh, v_V, v_bg) + (None,) * 16
                 + (v_lin, v_ang, None, None, None, v_sh_rest, None, None, None))

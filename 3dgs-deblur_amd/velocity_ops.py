@@ -87,11 +87,12 @@ class ProjectGaussiansPixvel(Function):
         v_quats, v_op, v_sh = torch.empty(N, 4, device=dev), torch.empty(N, device=dev), torch.empty(N, 1, 3, device=dev)
         acc = torch.zeros(16 + 12, device=dev)
         v_V, v_tw = acc[:16].view(4, 4), acc[16:]
+        psc = ops._pose_scratch(N, 1, False, dev)
         _check(L.gs_project_pixvel_bwd(N, 1, _ptr(means3d), _ptr(scales), glob, _ptr(quats), _ptr(ones), _ptr(sh0), 1, 0,
                                        _ptr(V), _ptr(twist), _ptr(t0), fx, fy, cx, cy, H, W, clip, 1, _ptr(records),
                                        _ptr(v_rec), _ptr(v_means), _ptr(v_scales), _ptr(v_quats), _ptr(v_op), _ptr(v_sh),
                                        _ptr(v_V), _ptr(v_tw), None, None, (ops.UPSTREAM_GRADS & 3) | 16 | (0 if ops.NEEDLE_HP else 8),
-                                       None, 0, None, _stream()), "project_pixvel_bwd")
+                                       None, 0, None, _ptr(psc), psc.numel(), _stream()), "project_pixvel_bwd")
         return (v_means, v_scales, None, v_quats, v_V, None, None, None, None, None, None, None, v_tw[0:3], v_tw[3:6], None)
 
 

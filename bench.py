@@ -142,9 +142,93 @@ class Workload:
             self.exchange_events.append((a, b))
         return loss
 
+    def sweep_views(self, n_views: int):
+        """n_views distinct cameras around this workload's own: an orbit of yaw / pitch / position about the scene
+        (amplitudes chosen so that most views stay inside the populated frustum slab and a few look past its edge), each
+        with its own velocity scale and sign — the camera batch a training loop cycles through (/root/reference/train.py:
+        115-116 -> ns-train: datamanager.next_train hands the model a DIFFERENT camera every iteration)"""
+        gs, dev = self.gs, self.viewmat.device
+        views = []
+        with torch.no_grad():
+            base = self.viewmat.detach().clone()
+            for v in range(n_views):
+                ph = 2.0 * math.pi * v / n_views
+                shift = torch.tensor([0.10 * math.cos(ph), 0.06 * math.sin(ph), 0.05 * (v % 3)], device=dev)
+                rot = torch.tensor([0.06 * math.cos(ph), 0.10 * math.sin(ph), 0.02 * ((v % 4) - 1.5)], device=dev)
+                V = gs.subpose_viewmats(base, shift, rot, torch.ones(1, device=dev))[0]
+                k = (1.0 + 0.1 * (v % 5)) * (-1.0 if v % 2 else 1.0)
+                views.append((V.clone(), (self.sc["lin_vel"] * k).to(dev), (self.sc["ang_vel"] * k).to(dev)))
+        return views
+
+    def set_view(self, view):
+        V, lin, ang = view
+        self.viewmat = V.clone().requires_grad_(True)
+        self.lin = lin.clone().requires_grad_(True)
+        self.ang = ang.clone().requires_grad_(True)
+
     def rows_with_gradient(self):
         g = self.params["means"].grad
         return int((g != 0).any(dim=1).sum()) if g is not None else 0
+
+
+def view_sweep(wl, ops, n_views=16, cycles=4, fixed_frames=6):
+    """A training-shaped sequence: n_views distinct cameras cycled through ONE FrameHints — the
+    way SplatfactoDeblurModel owns one for all its cameras — against every view's own fixed-view time (the same view
+    rendered back to back through a private FrameHints, which is what the headline measures).  Reported, never `value`."""
+    import statistics
+    gs = wl.gs
+    views = wl.sweep_views(n_views)
+    saved = (wl.viewmat, wl.lin, wl.ang, wl.hints)
+
+    def timed_step():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wl.step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+    fixed = []
+    for view in views:                                      # each view's own steady state
+        wl.set_view(view)
+        wl.hints = gs.ops.FrameHints()
+        ms = [timed_step() for _ in range(fixed_frames)]
+        fixed.append(min(ms[2:]))
+    wl.hints = gs.ops.FrameHints()                           # ONE hints object for the whole sweep
+    per_view = [[] for _ in views]
+    decisions, mults, slices, select_state = [], [], [], []
+    retries0 = 0
+    for c in range(cycles):
+        for i, view in enumerate(views):
+            wl.set_view(view)
+            decisions.append((bool(ops.LAZY_RECORDS and wl.hints.lazy_records()), bool(ops.DEPTH_SELECT and wl.hints.depth_select())))
+            ms = timed_step()
+            mults.append(wl.hints.mult)
+            slices.append(len([v for v in ops.last_slice_intersects if int(v) > 0]))
+            select_state.append(ops.last_depth_select)
+            if c == 0:
+                retries0 = wl.hints.arena_retries
+            else:
+                per_view[i].append(ms)
+    retries_all = wl.hints.arena_retries
+    wl.viewmat, wl.lin, wl.ang, wl.hints = saved
+    flat = [m for v in per_view for m in v]
+    ratio = [max(v) / f for v, f in zip(per_view, fixed)]
+    flips = lambda seq: sum(1 for a, b in zip(seq, seq[1:]) if a != b)
+    hist = []
+    for m in mults:
+        if not hist or hist[-1] != m:
+            hist.append(m)
+    return {"views": n_views, "cycles": cycles, "frames_timed": len(flat),
+            "ms_per_view": {"min": round(min(flat), 4), "median": round(statistics.median(flat), 4), "max": round(max(flat), 4)},
+            "fixed_view_ms": {"min": round(min(fixed), 4), "median": round(statistics.median(fixed), 4), "max": round(max(fixed), 4)},
+            "worst_view_over_its_fixed_time": round(max(ratio), 3),
+            "median_view_over_its_fixed_time": round(statistics.median(ratio), 3),
+            "slices_per_frame": {"min": min(slices), "max": max(slices)},
+            "lazy_eager_flips": flips([d[0] for d in decisions]), "selection_flips": flips([d[1] for d in decisions]),
+            "selection_misses": sum(1 for s_ in select_state if s_ == 2),
+            "budget_multiplier_history": hist, "arena_retries_first_cycle": retries0,
+            "arena_retries_later_cycles": retries_all - retries0,
+            "note": "wall clock per frame (synchronize around every step: includes launch latency the back-to-back "
+                    "headline loop hides); first cycle untimed; never part of `value`"}
 
 
 def _import_oracle():
@@ -312,6 +396,8 @@ def main():
                     help="DP gradient exchange: row-sparse all-gather (default; dense fallback built in), "
                          "dense all-reduce, or reduce-scatter + all-gather")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second (fitted-model-like) scene")
+    ap.add_argument("--no-view-sweep", action="store_true",
+                    help="skip the view sweep (16 cameras cycled through one FrameHints; reported beside the headline)")
     ap.add_argument("--autograd", action="store_true",
                     help="time the torch.autograd route (ops.render_combined + Tensor.backward) instead of the default "
                          "one-call forward + backward (gsdeblur_amd.render_step); same kernels, more host glue")
@@ -421,6 +507,9 @@ def main():
                                                                        (ops.LAZY_RECORDS and wl.hints.lazy_records()))),
                       "box_share_of_issued_slices": None if wl.hints.box_share is None else round(wl.hints.box_share, 4)}
     rows_with_grad = wl.rows_with_gradient()
+    sweep = None
+    if world == 1 and not args.no_view_sweep and args.motion == "se3":
+        sweep = view_sweep(wl, ops)
     # second scene (reported beside the headline, never part of `value`): a fitted-model-like distribution in which
     # a large share of the Gaussians receives a gradient and the depth-sliced path needs several slices
     secondary = None
@@ -654,6 +743,7 @@ def main():
                        "gradient_exchange_forced_at_world_1": bool(args.force_exchange and world == 1),
                        "rccl_version": rccl_version, "per_rank": per_rank,
                        "subpose_MPix_per_s": round(value * S, 3),
+                       "view_sweep": sweep,
                        "secondary": secondary},
             "exchange_ms": None if exchange_ms is None else round(exchange_ms, 4),
             "stage_ms": stage_ms,

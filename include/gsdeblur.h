@@ -59,6 +59,9 @@ int gs_project_fwd(int N, const float* means3d /*N*3*/, const float* scales /*N*
                    float* xys /*N*2*/, float* depths /*N*/, int* radii /*N*/, float* conics /*N*3*/,
                    float* compensation /*N*/, int* num_tiles_hit /*N*/, float* cov3d /*N*6*/,
                    int* tile_bounds /*N*4 or NULL*/, void* stream);
+/* scratch of the ordered camera-gradient reduction of the three projection backwards below (P = 1 and with_touched = 0
+ * for gs_project_bwd; with_touched = whether touched flags are passed) */
+long long gs_project_pose_scratch_bytes(int N, int P, int with_touched);
 /* v_viewmat[16] is accumulated into (caller zeroes; NULL to skip); v_depths / v_comp may be NULL. */
 int gs_project_bwd(int N, const float* means3d, const float* scales, float glob_scale, const float* quats,
                    const float* viewmat, float fx, float fy, float cx, float cy, int img_height,
@@ -68,7 +71,12 @@ int gs_project_bwd(int N, const float* means3d, const float* scales, float glob_
                    int grad_flags /*bit 0: back-propagate through the fov clamp as if inactive, bit 1: quaternion gradient
                                     without the projection through q/|q| (gsplat 0.1.11's conventions);
                                     0 = the true derivatives*/,
-                   void* stream);
+                   void* pose_scratch /*with v_viewmat(s) / v_twist: gs_project_pose_scratch_bytes bytes, uninitialised — the
+                                       camera-level gradients are summed over the Gaussians in a fixed order (block sums
+                                       through one scratch row each, rows added in block order; round 6: they were fp32
+                                       atomics whose order changed from run to run); NULL otherwise*/,
+                         long long pose_scratch_bytes,
+                         void* stream);
 
 /* ---- gsplat.spherical_harmonics (upstream _C.compute_sh_forward/backward) ----
  * coeffs [N, K_stride, 3]; uses the first (degrees_to_use+1)^2 bases; dirs are normalised inside. */
@@ -130,6 +138,11 @@ int gs_project_fused_bwd(int N, int P, const float* means3d, const float* scales
                          const float* sh_rest, int param_flags /*both as in gs_project_fused_fwd: the gradients returned
                                           are those of what was handed in (d/d log-scale, d/d logit)*/,
                          float* v_sh_rest /*[N*(K_stride-1)*3] iff sh_rest != NULL (v_sh is then [N*3])*/,
+                         void* pose_scratch /*with v_viewmat(s) / v_twist: gs_project_pose_scratch_bytes bytes, uninitialised — the
+                                       camera-level gradients are summed over the Gaussians in a fixed order (block sums
+                                       through one scratch row each, rows added in block order; round 6: they were fp32
+                                       atomics whose order changed from run to run); NULL otherwise*/,
+                         long long pose_scratch_bytes,
                          void* stream);
 
 /* ---- pixel-velocity model: the paper's first-order blur / rolling-shutter model (the fork's
@@ -158,7 +171,12 @@ int gs_project_pixvel_bwd(int N, int P, const float* means3d, const float* scale
                           const float* records, const float* v_records, float* v_means3d, float* v_scales,
                           float* v_quats, float* v_opacities, float* v_sh, float* v_viewmat, float* v_twist,
                           const unsigned char* touched, float* v_xy_sum, int grad_flags, const float* sh_rest,
-                          int param_flags, float* v_sh_rest /*as in gs_project_fused_bwd*/, void* stream);
+                          int param_flags, float* v_sh_rest /*as in gs_project_fused_bwd*/, void* pose_scratch /*with v_viewmat(s) / v_twist: gs_project_pose_scratch_bytes bytes, uninitialised — the
+                                       camera-level gradients are summed over the Gaussians in a fixed order (block sums
+                                       through one scratch row each, rows added in block order; round 6: they were fp32
+                                       atomics whose order changed from run to run); NULL otherwise*/,
+                         long long pose_scratch_bytes,
+                         void* stream);
 
 /* ---- gsplat-array <-> record glue for the rasterize_gaussians signature -------- */
 int gs_pack_records(int N, const float* xys, const float* depths, const int* radii, const float* conics,
@@ -242,7 +260,8 @@ int gs_segmented_sort_select_u32(long long n, long long seg_len, const unsigned*
                                  unsigned* seg_counts, const unsigned* gather_src, unsigned* gather_out, void* ws,
                                  long long ws_bytes, int* result_buf /*host*/, void* stream);
 /* exclusive scan where only the first seg_counts[s] values of every seg_len-long segment are live (the rest count as
- * zero and are never read; out is written everywhere) */
+ * zero and are never read).  out is defined for the live ranks and at every segment's first rank (the slice plan reads
+ * those); behind a segment's live ranks it is unspecified */
 int gs_exclusive_scan_segments_u32(long long n, long long seg_len, const unsigned* seg_counts /*device*/,
                                    const unsigned* in, unsigned* out, unsigned* total_out /*device, 1*/, void* ws,
                                    long long ws_bytes, void* stream);

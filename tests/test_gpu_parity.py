@@ -116,15 +116,13 @@ def check_fragile(frag, tag):
 
 def grad_el_ratio(got, ref):
     """max over elements of |got-ref| / (rtol*|ref| + afrac*max|ref|)  (<= 1 passes).
-    Camera-level tensors (view matrix, linear / angular velocity: <= 16 elements) are sums over EVERY Gaussian and sub-pose
-    whose last reduction is a few thousand fp32 atomics in an order that changes from run to run: the same test printed
-    0.43 and 0.90 of the bar on two boxes (viewmat, shared-list S=3; profiles/r05_suite_prints.log vs r04).  Their
-    absolute floor is 3e-5 of the tensor's max instead of 1e-5 so that the run-to-run spread cannot fail a suite; the
-    per-Gaussian tensors keep 1e-5."""
+    (Round 5 gave the camera-level tensors — view matrix, velocities: <= 16 elements — a 3x wider absolute floor because
+    their last reduction was fp32 atomics whose order changed from run to run; since round 6 those sums are ordered
+    (csrc/project.hip: reduce_vV / pose_reduce_kernel, subpose_bwd_kernel) and every tensor is held to the same bar;
+    tests/test_gpu_round6.py asserts that two runs of a frame give them bit for bit.)"""
     got = np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
-    afrac = GRAD_EL_AFRAC * (3.0 if ref.size <= 16 else 1.0)
-    tol = GRAD_EL_RTOL * np.abs(ref) + afrac * (np.abs(ref).max() + 1e-300)
+    tol = GRAD_EL_RTOL * np.abs(ref) + GRAD_EL_AFRAC * (np.abs(ref).max() + 1e-300)
     return float((np.abs(got - ref) / tol).max())
 
 
@@ -266,10 +264,10 @@ def test_depth_rank_compacting(gs, dev, P, N, keep, digit, max_tiles):
     live = n_live.cpu().long()
     assert torch.equal(live, (~culled).view(P, N).sum(1))
     assert int(total.item()) == int(total0.item()) == int(ntiles.sum())
-    # the prefix is the full one everywhere (flat behind the live ranks), the ranking only where it is defined
-    assert torch.equal(cum.cpu(), cum0.cpu())
+    # the prefix and the ranking where they are defined: the live ranks and every segment's first rank
     for p in range(P):
         m = int(live[p])
+        assert torch.equal(cum[p * N:p * N + max(m, 1)].cpu(), cum0[p * N:p * N + max(m, 1)].cpu())
         assert torch.equal(sgi[p * N:p * N + m].cpu(), sgi0[p * N:p * N + m].cpu())
 
 

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 S=$OUT/summary.log
 : > $S
-ABB_ARGS=${ABB_ARGS---no-secondary}      # extra bench.py arguments of the abbuild step (default: headline only)
+ABB_ARGS=${ABB_ARGS---no-secondary --no-view-sweep}      # extra bench.py arguments of the abbuild step (default: headline only)
 benchline() { python - "$1" "$2" <<'PY'
 import json, sys
 tag, path = sys.argv[1], sys.argv[2]
@@ -58,18 +58,18 @@ for step in "$@"; do
       # A/B of a bench.py command-line flag (e.g. abflag:--autograd), interleaved
       fl="${step#abflag:}"
       for v in 1 2; do
-        timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/abf_base$v.log 2>&1; benchline base$v $OUT/abf_base$v.log | tee -a $S
-        timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary $fl > $OUT/abf_alt$v.log 2>&1; benchline "alt$v($fl)" $OUT/abf_alt$v.log | tee -a $S
+        timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-view-sweep > $OUT/abf_base$v.log 2>&1; benchline base$v $OUT/abf_base$v.log | tee -a $S
+        timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-view-sweep $fl > $OUT/abf_alt$v.log 2>&1; benchline "alt$v($fl)" $OUT/abf_alt$v.log | tee -a $S
       done ;;
     ab:*)
       envs=$(echo "${step#ab:}" | tr ',' ' ')
       for v in 1 2; do
-        timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/ab_base$v.log 2>&1; benchline base$v $OUT/ab_base$v.log | tee -a $S
-        env $envs timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/ab_alt$v.log 2>&1; benchline "alt$v($envs)" $OUT/ab_alt$v.log | tee -a $S
+        timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-view-sweep > $OUT/ab_base$v.log 2>&1; benchline base$v $OUT/ab_base$v.log | tee -a $S
+        env $envs timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-view-sweep > $OUT/ab_alt$v.log 2>&1; benchline "alt$v($envs)" $OUT/ab_alt$v.log | tee -a $S
       done ;;
     prof|prof_trained)
       extra=""; [ $step = prof_trained ] && extra="--scene trained"
-      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/$step -o trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary $extra) > $OUT/$step.log 2>&1
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/$step -o trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-view-sweep $extra) > $OUT/$step.log 2>&1
       for f in $(find $OUT/$step -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_$step.csv; head -24 $f | cut -c1-200 | tee -a $S; done
       [ $step = prof ] && python tools/trace_step.py $OUT/prof > $OUT/timeline.txt 2>/dev/null && tail -1 $OUT/timeline.txt | tee -a $S
       rm -rf $OUT/$step/*/*kernel_trace* 2>/dev/null ;;
@@ -79,7 +79,7 @@ for step in "$@"; do
       # config 5's per-GPU share = 5M, 3840x2160, S=10
       for cfg in "c3 --gaussians 1000000 --subposes 1 --rs-bands 10" "c4 --gaussians 2000000 --subposes 5 --rs-bands 2" "c5 --gaussians 5000000 --width 3840 --height 2160 --subposes 10"; do
         name=${cfg%% *}; fl=${cfg#* }
-        timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary $fl > $OUT/bench_$name.log 2>&1
+        timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep $fl > $OUT/bench_$name.log 2>&1
         benchline "$name($fl)" $OUT/bench_$name.log | tee -a $S
         grep -E "Error|error" $OUT/bench_$name.log | tail -2 | tee -a $S
       done ;;
@@ -96,7 +96,7 @@ for step in "$@"; do
     prof_exchange)
       # the DP gradient exchange over RCCL at world size 1 (bench.py --force-exchange): bench line + kernel table with
       # the ncclDevKernel rows
-      timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --force-exchange > $OUT/bench_exchange.log 2>&1
+      timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-view-sweep --force-exchange > $OUT/bench_exchange.log 2>&1
       python - $OUT/bench_exchange.log <<'PY' | tee -a $S
 import json, sys
 for l in open(sys.argv[1]):
@@ -104,13 +104,13 @@ for l in open(sys.argv[1]):
         d = json.loads(l); c = d['config']
         print('force-exchange: ms', d['ms_per_step'], 'exchange_ms', d.get('exchange_ms'), 'mode', c.get('gradient_exchange'), 'rccl', c.get('rccl_version'), 'per_rank', c.get('per_rank'))
 PY
-      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_exchange -o trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --force-exchange) > $OUT/prof_exchange.log 2>&1
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_exchange -o trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-view-sweep --force-exchange) > $OUT/prof_exchange.log 2>&1
       for f in $(find $OUT/prof_exchange -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_prof_exchange.csv; grep -i "nccl\|dp_" $f | cut -c1-160 | tee -a $S; done
       rm -rf $OUT/prof_exchange/*/*kernel_trace* 2>/dev/null ;;
     pmc)
       for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR"; do
         t=$(echo $pmc | cut -d' ' -f1)
-        (cd /tmp && timeout 600 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $R/$OUT/pmc_$t -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary) > $OUT/pmc_$t.log 2>&1
+        (cd /tmp && timeout 600 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $R/$OUT/pmc_$t -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-view-sweep) > $OUT/pmc_$t.log 2>&1
         tail -1 $OUT/pmc_$t.log | cut -c1-200 | tee -a $S
       done
       python tools/pmc_summary.py $OUT 2>&1 | tail -40 | tee -a $S

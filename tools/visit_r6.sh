@@ -21,12 +21,12 @@ for step in "$@"; do
       grep -E "^nearest|^FAILED|^ERROR|passed|failed|Error|assert" $OUT/pytest_r6.log | tail -40 | tee -a $S ;;
     sel_ab)
       for v in 1 2; do for sel in 1 0; do
-        GSD_DEPTH_SELECT=$sel timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/h_s${sel}_$v.log 2>&1; line "headline sel=$sel" $OUT/h_s${sel}_$v.log | tee -a $S
-        GSD_DEPTH_SELECT=$sel timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --gaussians 1000000 --subposes 1 --rs-bands 10 > $OUT/c3_s${sel}_$v.log 2>&1; line "config3 sel=$sel" $OUT/c3_s${sel}_$v.log | tee -a $S
+        GSD_DEPTH_SELECT=$sel timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-view-sweep > $OUT/h_s${sel}_$v.log 2>&1; line "headline sel=$sel" $OUT/h_s${sel}_$v.log | tee -a $S
+        GSD_DEPTH_SELECT=$sel timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-view-sweep --gaussians 1000000 --subposes 1 --rs-bands 10 > $OUT/c3_s${sel}_$v.log 2>&1; line "config3 sel=$sel" $OUT/c3_s${sel}_$v.log | tee -a $S
       done; done
       for sel in 1 0; do
-        GSD_DEPTH_SELECT=$sel timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --gaussians 2000000 --subposes 5 --rs-bands 2 > $OUT/c4_s${sel}.log 2>&1; line "config4 sel=$sel" $OUT/c4_s${sel}.log | tee -a $S
-        GSD_DEPTH_SELECT=$sel timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --gaussians 5000000 --width 3840 --height 2160 --subposes 10 > $OUT/c5_s${sel}.log 2>&1; line "config5 sel=$sel" $OUT/c5_s${sel}.log | tee -a $S
+        GSD_DEPTH_SELECT=$sel timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --gaussians 2000000 --subposes 5 --rs-bands 2 > $OUT/c4_s${sel}.log 2>&1; line "config4 sel=$sel" $OUT/c4_s${sel}.log | tee -a $S
+        GSD_DEPTH_SELECT=$sel timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --gaussians 5000000 --width 3840 --height 2160 --subposes 10 > $OUT/c5_s${sel}.log 2>&1; line "config5 sel=$sel" $OUT/c5_s${sel}.log | tee -a $S
       done ;;
     *) rest+=("$step") ;;
   esac
