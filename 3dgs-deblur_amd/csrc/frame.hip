@@ -440,6 +440,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   CHECK(make_plan(0));
   state->n_total = n_total;
   state->depth_select = select ? 1 : 0;
+  state->open_after_first = -1.f;
   // select: are there visible pairs behind the selection?  (the frame's total against the selection's, both mod 2^32
   // like every pair count of a frame)
   bool rest_behind = select && ((n_total - true_total) & 0xFFFFFFFFll) != 0;
@@ -648,6 +649,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
       CHECK(read_back(reinterpret_cast<const unsigned*>(open_flags + slice_no), hp_seq, 1, poll, st, average));
       const long long open_now = hp[0];                              // tiles the compositor left open
       open_left = open_now;
+      if (slice_no == 0) state->open_after_first = (float)((double)open_now / (double)((long long)S * T));
       if (open_now == 0) { ++slice_no; break; }
       span = (d.merge_open_fraction > 0.f && (double)open_now >= (double)d.merge_open_fraction * (double)open_before)
                  ? 2 * (k1 - k) : 1;

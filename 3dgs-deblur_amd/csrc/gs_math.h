@@ -650,15 +650,23 @@ GS_HD void se3_exp(const S v[3], const S w[3], S E[12]) {
   // E = [R | V v] with R = I + A K + B K^2, V = I + B K + C K^2, K = [w]x
   S th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
   S A, B, C;
-  if (th2 < S(1e-8f)) {   // series, keeps derivatives finite at w = 0
-    A = S(1.f) - th2 * S(1.f / 6.f);
-    B = S(0.5f) - th2 * S(1.f / 24.f);
-    C = S(1.f / 6.f) - th2 * S(1.f / 120.f);
+  if (th2 < S(0.25f)) {
+    // Series in theta^2 up to theta^10 (theta < 0.5 rad per sub-pose: every realistic exposure; truncation < 2e-12).
+    // Round 6: the closed forms were taken from theta = 1e-4 on, and in fp32 (1 - cos theta) / theta^2 and
+    // (1 - sin theta / theta) / theta^2 lose their digits to cancellation exactly in the range a blurred frame lives
+    // in (theta = 7e-3: 3e-3 and 8e-3 relative).  The images hardly see it (B and C multiply second-order terms);
+    // the VELOCITY gradients do — they are differences between sub-poses, sum_p t_p g_p with symmetric t_p, so the
+    // first-order parts cancel and what is left carried an error of 9x the test bar (found by the camera-sequence test
+    // of tests/test_gpu_round6.py; these are the gradients the velocity optimizer consumes, /root/reference/train.py:66).
+    A = S(1.f) + th2 * (S(-1.f / 6.f) + th2 * (S(1.f / 120.f) + th2 * (S(-1.f / 5040.f) + th2 * (S(1.f / 362880.f) + th2 * S(-1.f / 39916800.f)))));
+    B = S(0.5f) + th2 * (S(-1.f / 24.f) + th2 * (S(1.f / 720.f) + th2 * (S(-1.f / 40320.f) + th2 * (S(1.f / 3628800.f) + th2 * S(-1.f / 479001600.f)))));
+    C = S(1.f / 6.f) + th2 * (S(-1.f / 120.f) + th2 * (S(1.f / 5040.f) + th2 * (S(-1.f / 362880.f) + th2 * (S(1.f / 39916800.f) + th2 * S(-1.f / 6227020800.f)))));
   } else {
     S th = sqrt(th2);
+    S sh = sin(th * S(0.5f));
     A = sin(th) / th;
-    B = (S(1.f) - cos(th)) / th2;
-    C = (S(1.f) - A) / th2;
+    B = S(2.f) * sh * sh / th2;          // (1 - cos theta) without the cancellation
+    C = (S(1.f) - A) / th2;              // theta >= 0.5: theta - sin theta keeps six digits
   }
   S K[9] = {S(0.f), -w[2], w[1], w[2], S(0.f), -w[0], -w[1], w[0], S(0.f)};
   S K2[9];

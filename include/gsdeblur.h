@@ -567,6 +567,8 @@ typedef struct gs_frame_state {
   int shared_list;           /* copied from the descriptor */
   int depth_select;          /* 0: every visible pair was depth-sorted; 1: only the nearest-first selection; 2: the
                                 selection, and later the pairs behind it (the first slice left tiles open) */
+  float open_after_first;    /* share of the (sample, tile) lists the frame's FIRST issued slice left open (its read-back:
+                                0 = every tile stopped within it); -1: the first slice was also the last, nothing was read */
   long long n_total;         /* bounding-box tile intersections of the frame */
   long long arena_used;      /* bytes of the arena the forward occupies (kept alive until the backward ran) */
   long long arena_required;  /* on GS_ERR_WORKSPACE (3): an arena size that holds the frame as far as it is known */

@@ -171,6 +171,35 @@ def test_se3_closed_form_vs_matrix_exp(hm, oracle, scene, zero_ang):
     assert rel(va, ad.grad.numpy()) < 1e-5
 
 
+def test_se3_velocity_gradients_survive_the_cancellation_between_sub_poses(hm, oracle, scene):
+    """round 6: the velocity gradients are sum_p t_p g_p over sub-pose times that are symmetric about zero — the first-
+    order parts cancel and what is left is second order in the rotation angle of a sub-pose (7e-3 rad here, a typical
+    blurred frame).  The closed forms (1 - cos)/theta^2 and (1 - sin/theta)/theta^2 lose their digits there in fp32
+    (3e-3 relative until round 6: the GPU suite saw 9x its bar on d loss / d ang_vel); the series does not."""
+    O = oracle
+    V = scene["V"]
+    lin = torch.tensor([0.8, -0.5, 1.1])
+    ang = torch.tensor([0.9, -1.2, 0.5])
+    times = np.array([-0.0055, 0.0055], np.float32)
+    V0 = np.ascontiguousarray(V.numpy())
+    linn, angn = np.ascontiguousarray(lin.numpy()), np.ascontiguousarray(ang.numpy())
+    Vd, ld, ad = (t.double().requires_grad_(True) for t in (V, lin, ang))
+    ref = O.subpose_viewmats(Vd, ld, ad, times.tolist())
+    g1 = torch.randn(4, 4, generator=torch.Generator().manual_seed(3)); g1[3, :] = 0
+    go = torch.stack([g1, g1])                           # the SAME cotangent at -t and +t: first order cancels
+    (ref * go.double()).sum().backward()
+    vV0 = np.zeros(16, np.float32); vl = np.zeros(3, np.float32); va = np.zeros(3, np.float32)
+    hm.hm_subpose_viewmats_bwd(2, P(V0), P(linn), P(angn), P(times), P(np.ascontiguousarray(go.numpy().reshape(2, 16))),
+                               P(vV0), P(vl), P(va))
+    assert float(ad.grad.abs().max()) < 1e-3 * float(Vd.grad.abs().max())       # (what is left really is second order)
+    assert rel(va, ad.grad.numpy()) < 2e-4, rel(va, ad.grad.numpy())
+    assert rel(vl, ld.grad.numpy()) < 2e-4, rel(vl, ld.grad.numpy())
+    # forward: the sub-pose matrices themselves, to fp32 rounding
+    out = np.zeros((2, 16), np.float32)
+    hm.hm_subpose_viewmats(2, P(V0), P(linn), P(angn), P(times), P(out))
+    assert np.abs(out.reshape(2, 4, 4) - ref.detach().numpy()).max() < 5e-7
+
+
 def _posed_view(O):
     """a strongly non-identity world -> camera transform (every kernel-vs-oracle comparison on the GPU used to render
     from near the identity pose)"""
