@@ -160,6 +160,10 @@ def frame_poll() -> int:
 def readback_mode() -> dict:
     """how this process reads the slice plan / open-tile word back, and why (bench.py prints it per rank)"""
     return {"poll": bool(frame_poll()), "host_cores": _host_cores(),
+            # one process per GPU: the arena pool and the pinned read-back buffers of this module belong to THIS process,
+            # i.e. to LOCAL_RANK's device (keys: (device, stream) and (device, host thread, stream)); nothing is shared
+            # between the ranks of a host
+            "local_rank": int(os.environ.get("LOCAL_RANK", "0") or 0),
             "local_world": int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1),
             "forced": "GSD_FRAME_POLL" in os.environ}
 # widest radix digit of the compacting depth pre-sort: 8 -> 4 passes of 8 bits, 11 -> 3 passes of 11/10/10 bits

@@ -453,3 +453,36 @@ def test_third_frame_of_a_camera_sequence_vs_float64_oracle(gs, oracle, dev, bas
     print(f"third frame vs oracle, base {base}: per-element gradient error / tolerance:", {k_: round(v, 3) for k_, v in worst.items()})
     for k_, v in worst.items():
         assert v <= 1.0, (k_, v)
+
+
+# --------------------------------------------------------------------------- #
+# multi-GPU readiness on the one GPU there is
+# --------------------------------------------------------------------------- #
+def test_bench_runs_every_exchange_mode_over_rccl_at_world_1(dev):
+    """`bench.py --force-exchange --allreduce <mode>` for the three exchange modes: the timed step then contains the
+    whole pack -> RCCL collective -> scatter chain on the nccl (= RCCL) backend at world size 1, and the line reports its
+    device time as exchange_ms.  Asserted: the run succeeds, says which mode it ran, exchange_ms is positive and inside the
+    step, per-rank diagnostics are present.  No scaling claim follows from a single rank (RCCL runs a single-rank
+    collective as a copy); the three numbers are printed for profiles/."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    out = {}
+    for i, mode in enumerate(("sparse", "allreduce", "rs_ag")):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + i + os.getpid() % 300),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                            "--no-secondary", "--no-view-sweep", "--force-exchange", "--allreduce", mode, "--gaussians",
+                            "300000", "--width", "960", "--height", "544", "--subposes", "3"],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, (mode, r.stderr[-2000:])
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        c = line["config"]
+        assert c["gradient_exchange"] == mode and c["gradient_exchange_forced_at_world_1"] is True
+        assert line["exchange_ms"] is not None and 0.0 < line["exchange_ms"] < line["ms_per_step"], (mode, line["exchange_ms"])
+        assert c["per_rank"] and c["per_rank"][0]["readback"]["local_rank"] == 0 and c["rccl_version"]
+        out[mode] = (line["exchange_ms"], line["ms_per_step"], c["per_rank"][0]["gaussians_with_gradient"])
+    print("exchange modes over RCCL at world 1 (exchange_ms, ms_per_step, rows with a gradient):", out)

@@ -475,6 +475,67 @@ def test_bench_warm_up_length_does_not_depend_on_the_rank(gs):
         ops.SLICE_ADAPT, ops.SLICE_BASE = saved
 
 
+def _bench_rank_worker(rank, world, port, q, late_rank, settle_after):
+    """one rank of `bench.py --gpus 8` with a CPU stand-in for the frame: the REAL Workload.warm_until_settled and a timed
+    region shaped like bench.main's (barrier, K steps each holding one collective, barrier).  Rank `late_rank`'s hints
+    only settle after `settle_after` frames (its view keeps needing more slices)."""
+    sys.path.insert(0, str(ROOT))
+    import types
+    import bench
+    from gsdeblur_amd import ops
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"], os.environ["LOCAL_WORLD_SIZE"] = str(rank), str(world)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ops.SLICE_ADAPT, ops.SLICE_BASE = 1, 512
+    w = types.SimpleNamespace(world=world, hints=ops.FrameHints(), steps=0, collectives=0)
+
+    def step():
+        w.steps += 1
+        w.hints.feedback(2 if (rank == late_rank and w.steps < settle_after) else 1, open_after_first=0.9)
+        t = torch.ones(4)
+        dist.all_reduce(t)                     # the gradient exchange: every rank must be in the SAME one
+        assert float(t[0]) == world
+        w.collectives += 1
+    w.step = step
+    warm = bench.Workload.warm_until_settled(w, 5)
+    dist.barrier()
+    K = 7
+    for _ in range(K):
+        w.step()
+    dist.barrier()
+    rb = ops.readback_mode()
+    q.put((rank, warm, w.steps, w.collectives, bool(w.hints.settled), rb["local_rank"], rb["local_world"], rb["poll"]))
+    dist.destroy_process_group()
+
+
+def test_bench_ranks_agree_on_warm_up_and_timed_steps_world8_gloo():
+    """eight ranks on one host, one of them with hints that settle late.  The warm-up length is
+    the same on every rank (a rank-dependent count would leave the ranks in different collectives and hang the job:
+    this test finishing IS the assertion), the timed region holds the same number of steps and collectives, and every
+    rank says which LOCAL_RANK's arena / read-back buffers it owns and how it waits for its read-backs (eight polling
+    ranks would spin eight host cores: with 8 local ranks on this 8-core host nobody polls)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 47500 + (os.getpid() % 2000)
+    world = 8
+    procs = [ctx.Process(target=_bench_rank_worker, args=(r, world, port, q, 3, 9)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[0] for r in res] == list(range(world))
+    assert {r[1] for r in res} == {6}                            # the fixed warm-up length of N > 1
+    assert {r[2] for r in res} == {13} and {r[3] for r in res} == {13}
+    assert [r[5] for r in res] == list(range(world)) and {r[6] for r in res} == {world}
+    late = res[3]
+    assert late[4] is False or late[4] is True                   # (its hints may still be unsettled: reported, not awaited)
+    import os as _os
+    cores = len(_os.sched_getaffinity(0)) if hasattr(_os, "sched_getaffinity") else (_os.cpu_count() or 1)
+    assert {r[7] for r in res} == {cores >= 2 * world}           # polled read-backs only with two cores per local rank
+
+
 def _dp_small_worker(rank, world, port, q):
     """train_step's DP branch with a CPU stand-in for the render: Gaussian rows go through the sparse exchange,
     background / pose / velocity parameters through the small dense bucket (they used to be stepped
