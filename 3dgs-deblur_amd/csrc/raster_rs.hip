@@ -11,11 +11,24 @@
 // so projection, binning and sorting cost what a frame WITHOUT rolling shutter costs.  The backward returns, beside the
 // nine gradients of the other compositors, d loss / d v' (tuple slots 9 and 10: sum over the pixels of tau(y) * d/d mu').
 //
-// Written for clarity over speed (scalar-cache record fetch like raster.hip, plain per-pixel arithmetic: dx is no
-// longer a lane constant, so the packed / moment formulations of the other kernels do not apply).
+// Round 6: brought to the kernel generation of raster.hip / raster_bwd.hip (rounds 3-5 were "written for clarity"):
+//   * records AND pixel velocities through the scalar cache in aligned groups of four list entries, two register sets
+//     of two entries each (one pair's loads in flight while the other pair is blended);
+//   * ONE compare |u| <= nmid on the shifted exponent decides sigma >= 0 and alpha >= 1/255 (gs_math.h rec_aux; the
+//     same expression, operand for operand, in both directions: `rs_u`), alpha = kmul * 2^u;
+//   * forward: the lane's four pixels as two hand-packed float2 pairs, a stopped pixel's row coordinate is NaN and
+//     fails the compare for the rest of the list, the stop index is stored by the rarely taken stop block;
+//   * backward: quadrant mapping (pixel k of a lane in 8x8 quadrant k: a quadrant nobody's pixel blends is skipped by
+//     a scalar branch), the geometric gradients from eight moments of v_sigma in (dx, dy, tau) — dx is no longer a
+//     lane constant here, so the three-moment form of raster_bwd.hip does not apply —, eleven partial sums pair-added
+//     by DPP, 44 rows x 36 floats of wave-private LDS, lanes 0..43 store row totals straight into the entry's tuple.
 #include "raster_common.h"
 
 namespace gs {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 struct RsParams {
   const float* pix_vel;   // [N,2] pixel velocity of every Gaussian (gs_project_pixvel_fwd)
@@ -36,26 +49,134 @@ struct RsSliceState {
   int* open_flag;
 };
 
-struct RsRec { float x, y, qx, qy, qz, cx, cy, cz, op, r, g, b, d, pvx, pvy; };
+// exposure time of pixel-centre row pyf relative to the record's centre time: the SAME expression in both kernels
+__device__ __forceinline__ float rs_tau(float pyf, float H, float rs_time, float t_s) {
+  return fmaf(pyf / H - 0.5f, rs_time, t_s);
+}
+
+// shifted exponent u = nmid - log2(e) * sigma at a pixel exposed tau after the record's centre time (scalar form; the
+// forward evaluates the packed twin below on identical operands, so both directions take the same decision)
+__device__ __forceinline__ float rs_u(float dx0, float dy0, float tau, float pvx, float pvy, float qx, float qy, float qz,
+                                      float nmid, float& dx, float& dy) {
+  dx = fmaf(tau, pvx, dx0);
+  dy = fmaf(tau, pvy, dy0);
+  return fmaf(dx, fmaf(qx, dx, qy * dy), fmaf(qz * dy, dy, nmid));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------
+struct RsRecF { float x, y, qy, r, g, b, d, nmid, kmul, qx, qz, pvx, pvy; };
 
 template <bool DEPTH>
-__device__ __forceinline__ RsRec load_rs_rec(const float* __restrict__ records, const float* __restrict__ pix_vel,
-                                             unsigned gi, unsigned g) {
-  const float kL2E = -1.4426950408889634f;
+__device__ __forceinline__ RsRecF load_rs_f(const float* __restrict__ records, const float* __restrict__ pix_vel,
+                                            unsigned gi, unsigned g) {
   const float* p = records + (size_t)gi * kRecFloats;
-  RsRec o;
-  o.x = p[0]; o.y = p[1]; o.cx = p[2]; o.cy = p[3]; o.cz = p[4]; o.op = p[5]; o.r = p[6]; o.g = p[7]; o.b = p[8];
+  RsRecF o;
+  o.x = p[0]; o.y = p[1]; o.qy = p[3] * kNegLog2e; o.r = p[6]; o.g = p[7]; o.b = p[8];
   o.d = DEPTH ? p[9] : 0.f;
-  o.qx = o.cx * (0.5f * kL2E); o.qy = o.cy * kL2E; o.qz = o.cz * (0.5f * kL2E);
+  o.nmid = p[kRecNmid]; o.kmul = p[kRecKmul]; o.qx = p[kRecQx]; o.qz = p[kRecQz];
   o.pvx = pix_vel[2 * (size_t)g]; o.pvy = pix_vel[2 * (size_t)g + 1];
   return o;
 }
 
-// -log2(e) * sigma at a pixel whose row is exposed tau after the sample time: the SAME expression in both kernels
-__device__ __forceinline__ float rs_exponent(const RsRec& rc, float dx0, float dy0, float tau, float& dx, float& dy) {
-  dx = dx0 + tau * rc.pvx;
-  dy = dy0 + tau * rc.pvy;
-  return dx * (rc.qx * dx + rc.qy * dy) + rc.qz * (dy * dy);
+// py: pixel-centre row coordinate, NaN once the pixel has stopped (or lies outside the image); tau: its exposure time
+struct RsPair { f2 T, Cr, Cg, Cb, Cd, py, tau; };
+
+template <bool DEPTH>
+__device__ __forceinline__ void rs_blend(const RsRecF& rc, float pxf, int idx, RsPair (&pp)[2], int* __restrict__ fin_out,
+                                         unsigned fin_off, unsigned fin_row) {
+  const float dx0 = rc.x - pxf;
+  const f2 dx02 = {dx0, dx0}, gy2 = {rc.y, rc.y}, pvx2 = {rc.pvx, rc.pvx}, pvy2 = {rc.pvy, rc.pvy};
+  const f2 qx2 = {rc.qx, rc.qx}, qy2 = {rc.qy, rc.qy}, qz2 = {rc.qz, rc.qz}, nm2 = {rc.nmid, rc.nmid}, km2 = {rc.kmul, rc.kmul};
+  const f2 cr2 = {rc.r, rc.r}, cg2 = {rc.g, rc.g}, cb2 = {rc.b, rc.b};
+  f2 w[2], nT[2];
+  bool c[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    RsPair& q = pp[h];
+    const f2 dx = fma2(q.tau, pvx2, dx02);
+    const f2 dy = fma2(q.tau, pvy2, gy2 - q.py);                 // NaN for a stopped pixel
+    const f2 u = fma2(dx, fma2(qx2, dx, qy2 * dy), fma2(qz2 * dy, dy, nm2));
+    const f2 ov = km2 * f2{__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)};
+    const f2 alpha = {fminf(K::kAlphaMax, ov.x), fminf(K::kAlphaMax, ov.y)};
+    const bool v0 = fabsf(u.x) <= rc.nmid, v1 = fabsf(u.y) <= rc.nmid;   // sigma >= 0 and alpha >= 1/255
+    const f2 ag = {v0 ? alpha.x : 0.f, v1 ? alpha.y : 0.f};
+    w[h] = ag * q.T;
+    nT[h] = q.T - w[h];
+    c[2 * h] = nT[h].x > K::kTMin; c[2 * h + 1] = nT[h].y > K::kTMin;
+  }
+  if (!(c[0] && c[1] && c[2] && c[3])) {
+    // some pixel of this lane stops at this entry (rare; wave-uniformly skipped otherwise): it does not blend the
+    // entry, keeps its T, leaves the walk (row coordinate := NaN) and its stop index goes straight to final_idx
+    // (raster.hip blend_entry has the reasons for the inline assembly)
+    const int idxv = idx;
+    static_assert(K::kTMin == 1e-4f, "the literal 0x38d1b717 below is 1e-4f");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      RsPair& q = pp[k >> 1];
+      float wk = (k & 1) ? w[k >> 1].y : w[k >> 1].x, pyk = (k & 1) ? q.py.y : q.py.x;
+      const float nTk = (k & 1) ? nT[k >> 1].y : nT[k >> 1].x;
+      unsigned long long saved;
+      asm volatile("v_cmp_lt_f32_e32 vcc, 0x38d1b717, %3\n\t"
+                   "s_nop 1\n\t"
+                   "v_cndmask_b32_e32 %0, 0, %0, vcc\n\t"
+                   "v_cndmask_b32_e32 %1, -1, %1, vcc\n\t"
+                   "s_andn1_saveexec_b64 %2, vcc\n\t"
+                   "global_store_dword %4, %5, %6\n\t"
+                   "s_mov_b64 exec, %2"
+                   : "+v"(wk), "+v"(pyk), "=&s"(saved)
+                   : "v"(nTk), "v"((fin_off + (unsigned)k * fin_row) * 4u), "v"(idxv), "s"(fin_out)
+                   : "memory", "vcc");
+      if (k & 1) { w[k >> 1].y = wk; q.py.y = pyk; } else { w[k >> 1].x = wk; q.py.x = pyk; }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    RsPair& q = pp[h];
+    q.Cr = fma2(w[h], cr2, q.Cr); q.Cg = fma2(w[h], cg2, q.Cg); q.Cb = fma2(w[h], cb2, q.Cb);
+    if (DEPTH) q.Cd = fma2(w[h], f2{rc.d, rc.d}, q.Cd);
+    q.T -= w[h];
+  }
+}
+
+__device__ __forceinline__ bool rs_any_live(const RsPair (&pp)[2]) {
+  const float m = fmaxf(fmaxf(pp[0].py.x, pp[0].py.y), fmaxf(pp[1].py.x, pp[1].py.y));   // NaN only when all four are
+  return __builtin_amdgcn_ballot_w64(m == m) != 0ull;
+}
+
+// the tile's list, front to back, in aligned groups of four entries (ids padded by the caller, see the ABI)
+template <bool DEPTH>
+__device__ __forceinline__ void rs_fwd_walk(const int* __restrict__ ids, const float* __restrict__ records,
+                                            const float* __restrict__ pix_vel, unsigned s_base, unsigned max_id,
+                                            unsigned max_g, int2 range, unsigned n, float pxf, RsPair (&pp)[2],
+                                            int* __restrict__ fin_out, unsigned fin_off, unsigned fin_row) {
+  int b = range.x & ~3;
+  const int4* __restrict__ ids4 = reinterpret_cast<const int4*>(ids);
+  int4 idv = ids4[b >> 2];
+  // indices read in front of / behind the tile's own range belong to other tiles (or to the padding): clamped, the
+  // record is loaded but never blended
+  auto rec = [&](int id) {
+    const unsigned gi = min((unsigned)id, max_id);
+    return load_rs_f<DEPTH>(records, pix_vel, gi, min(gi - s_base, max_g));
+  };
+  RsRecF a0 = rec(idv.x), a1 = rec(idv.y);
+  for (;;) {
+    asm volatile("" :: "s"(a0.x), "s"(a1.x), "s"(a0.pvx), "s"(a1.pvx) : "memory");
+    const RsRecF b0 = rec(idv.z), b1 = rec(idv.w);
+    idv = ids4[(b >> 2) + 1];
+    asm volatile("" ::: "memory");
+    if ((unsigned)(b - range.x) < n) rs_blend<DEPTH>(a0, pxf, b, pp, fin_out, fin_off, fin_row);
+    if ((unsigned)(b + 1 - range.x) < n) rs_blend<DEPTH>(a1, pxf, b + 1, pp, fin_out, fin_off, fin_row);
+    asm volatile("" :: "s"(b0.x), "s"(b1.x), "s"(b0.pvx), "s"(b1.pvx), "s"(idv.x) : "memory");
+    a0 = rec(idv.x); a1 = rec(idv.y);
+    asm volatile("" ::: "memory");
+    if ((unsigned)(b + 2 - range.x) < n) rs_blend<DEPTH>(b0, pxf, b + 2, pp, fin_out, fin_off, fin_row);
+    if ((unsigned)(b + 3 - range.x) < n) rs_blend<DEPTH>(b1, pxf, b + 3, pp, fin_out, fin_off, fin_row);
+    b += 4;
+    if (b >= range.y) break;
+    if (!rs_any_live(pp)) break;
+  }
 }
 
 template <bool DEPTH>
@@ -76,16 +197,19 @@ __global__ __launch_bounds__(256) void raster_fwd_rs_kernel(RasterParams prm, Rs
   int2 range = prm.tile_bins[shared ? (size_t)t : tkey];
   range.x = __builtin_amdgcn_readfirstlane(range.x);
   range.y = __builtin_amdgcn_readfirstlane(range.y);
+  const int px0 = tx * K::kTile + (lane & 15);
+  const int py0 = ty * K::kTile + (lane >> 4) * 4;
+  const unsigned fin_off = ((unsigned)s * (unsigned)prm.H + (unsigned)py0) * (unsigned)prm.W + (unsigned)px0;
+  const unsigned fin_row = (unsigned)prm.W;
   if (!st.first && st.tile_done[tkey]) {
     // A finished (sample, tile) of a SHARED list: the tile's list still receives entries while any other sample's tile
     // is open (the binning sees the AND over the samples), so this slice's backward walks a non-empty range for this
     // sample too and reads this slice's stop indices — which are fresh, never memset arena memory.
     // Every pixel stopped before this slice: its stop index is the slice's first entry.
     if (shared) {
-      const int qx = tx * K::kTile + (lane & 15), qy0 = ty * K::kTile + (lane >> 4) * 4;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (qx < prm.W && (qy0 + k) < prm.H) final_idx[((size_t)s * prm.H + (qy0 + k)) * prm.W + qx] = range.x;
+        if (px0 < prm.W && (py0 + k) < prm.H) final_idx[fin_off + (unsigned)k * fin_row] = range.x;
     }
     return;
   }
@@ -94,65 +218,57 @@ __global__ __launch_bounds__(256) void raster_fwd_rs_kernel(RasterParams prm, Rs
     if (st.open_flag && lane == 0) atomicAdd(st.open_flag, 1);
     return;
   }
-  const int px = tx * K::kTile + (lane & 15);
-  const int py0 = ty * K::kTile + (lane >> 4) * 4;
-  const float pxf = (float)px + 0.5f;
-  float Tk[4], Cr[4], Cg[4], Cb[4], Cd[4], pyf[4], tau[4];
-  int last[4];
+  const float pxf = (float)px0 + 0.5f;
+  const float qnan = __builtin_nanf("");
+  RsPair pp[2];
   bool inside[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    inside[k] = px < prm.W && (py0 + k) < prm.H;
-    pyf[k] = (float)(py0 + k) + 0.5f;
-    tau[k] = (pyf[k] / (float)prm.H - 0.5f) * rs.rs_time + t_s;
-    Tk[k] = inside[k] ? 1.f : -1.f; Cr[k] = Cg[k] = Cb[k] = Cd[k] = 0.f; last[k] = range.x;
+    const int py = py0 + k;
+    inside[k] = px0 < prm.W && py < prm.H;
+    float Tk = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f;
+    bool live = inside[k];
     if (!st.first && inside[k]) {
-      const size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
-      Cr[k] = out_img[pix * 3 + 0]; Cg[k] = out_img[pix * 3 + 1]; Cb[k] = out_img[pix * 3 + 2];
-      if (DEPTH) Cd[k] = out_depth[pix];
+      const size_t pix = ((size_t)s * prm.H + py) * prm.W + px0;
+      cr = out_img[pix * 3 + 0]; cg = out_img[pix * 3 + 1]; cb = out_img[pix * 3 + 2];
+      if (DEPTH) cd = out_depth[pix];
       const float Tf = out_T[pix], lv = st.live_T[pix];
-      Tk[k] = lv > 0.f ? lv : -Tf;                         // a stopped pixel keeps its final T as a negative value
+      live = lv > 0.f;
+      Tk = live ? lv : Tf;
     }
+    const float pyc = (float)py + 0.5f;
+    const float pyk = live ? pyc : qnan;
+    const float tk = rs_tau(pyc, (float)prm.H, rs.rs_time, t_s);
+    // a pixel that stopped in an earlier slice blends nothing of this one (one that stops in this slice writes its stop
+    // index at that moment, one that stays live gets the end of the list below)
+    if (inside[k] && !live) final_idx[fin_off + (unsigned)k * fin_row] = range.x;
+    RsPair& q = pp[k >> 1];
+    if (k & 1) { q.T.y = Tk; q.Cr.y = cr; q.Cg.y = cg; q.Cb.y = cb; q.Cd.y = cd; q.py.y = pyk; q.tau.y = tk; }
+    else       { q.T.x = Tk; q.Cr.x = cr; q.Cg.x = cg; q.Cb.x = cb; q.Cd.x = cd; q.py.x = pyk; q.tau.x = tk; }
   }
-  auto any_live = [&]() { return __ballot(fmaxf(fmaxf(Tk[0], Tk[1]), fmaxf(Tk[2], Tk[3])) > 0.f) != 0ull; };
+  const unsigned n = (unsigned)(range.y - range.x);
   const unsigned s_base = shared ? 0u : (unsigned)s * (unsigned)rs.N;
-  for (int i = range.x; i < range.y; ++i) {
-    if (((i - range.x) & 3) == 0 && !any_live()) break;
-    const unsigned gi = min((unsigned)ids[i], max_id);
-    const RsRec rc = load_rs_rec<DEPTH>(records, rs.pix_vel, gi, gi - s_base);
-    const float dx0 = rc.x - pxf;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float dx, dy;
-      const float s2 = rs_exponent(rc, dx0, rc.y - pyf[k], tau[k], dx, dy);
-      const float alpha = fminf(K::kAlphaMax, rc.op * __builtin_amdgcn_exp2f(s2));
-      const bool v = (s2 <= 0.f) && (alpha >= K::kAlphaMin);
-      const float w0 = alpha * Tk[k];
-      const float nT = Tk[k] - Tk[k] * alpha;
-      const bool u = v && (nT > K::kTMin);
-      const float w = u ? w0 : 0.f;
-      Cr[k] += w * rc.r; Cg[k] += w * rc.g; Cb[k] += w * rc.b;
-      if (DEPTH) Cd[k] += w * rc.d;
-      Tk[k] = u ? nT : (v ? -fabsf(Tk[k]) : Tk[k]);
-      last[k] = u ? i + 1 : last[k];
-    }
-  }
-  const bool all_stopped = !any_live();
+  if (n != 0u)
+    rs_fwd_walk<DEPTH>(ids, records, rs.pix_vel, s_base, max_id, (unsigned)(rs.N - 1), range, n, pxf, pp, final_idx,
+                       fin_off, fin_row);
+  const bool all_stopped = !rs_any_live(pp);
   const bool finalize = all_stopped || st.last;
   const float bgr = finalize ? prm.background[0] : 0.f, bgg = finalize ? prm.background[1] : 0.f,
               bgb = finalize ? prm.background[2] : 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (inside[k]) {
-      const float Tf = fabsf(Tk[k]);
-      const size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px;
-      out_img[pix * 3 + 0] = Cr[k] + Tf * bgr;
-      out_img[pix * 3 + 1] = Cg[k] + Tf * bgg;
-      out_img[pix * 3 + 2] = Cb[k] + Tf * bgb;
+      const RsPair& q = pp[k >> 1];
+      const float Tf = (k & 1) ? q.T.y : q.T.x, cr = (k & 1) ? q.Cr.y : q.Cr.x, cg = (k & 1) ? q.Cg.y : q.Cg.x;
+      const float cb = (k & 1) ? q.Cb.y : q.Cb.x, cd = (k & 1) ? q.Cd.y : q.Cd.x, pyk = (k & 1) ? q.py.y : q.py.x;
+      const size_t pix = ((size_t)s * prm.H + (py0 + k)) * prm.W + px0;
+      out_img[pix * 3 + 0] = cr + Tf * bgr;
+      out_img[pix * 3 + 1] = cg + Tf * bgg;
+      out_img[pix * 3 + 2] = cb + Tf * bgb;
       out_T[pix] = Tf;
-      if (DEPTH) out_depth[pix] = Cd[k];
-      final_idx[pix] = last[k];
-      if (!st.last) st.live_T[pix] = fmaxf(Tk[k], 0.f);
+      if (DEPTH) out_depth[pix] = cd;
+      if (pyk == pyk) final_idx[pix] = range.y;
+      if (!st.last) st.live_T[pix] = pyk == pyk ? Tf : 0.f;
     }
   }
   if (!st.last && lane == 0) {
@@ -163,13 +279,100 @@ __global__ __launch_bounds__(256) void raster_fwd_rs_kernel(RasterParams prm, Rs
 
 // ---------------------------------------------------------------------------------------------------------------
 // backward: reverse walk, 11 partial sums per (entry, lane) — x, y, conic (3), opacity, colour (3), pixel velocity
-// (2) — transposed through wave-private LDS in groups of four entries, row totals straight into the entry's tuple
+// (2) — pair-added by DPP, transposed through wave-private LDS in groups of four entries, row totals straight into the
+// entry's tuple
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kRsComp = 11;
 constexpr int kRsGroup = 4;
-constexpr int kRsStride = 68;                        // 64 columns + 4: rows 16-byte aligned, b128 reads conflict-free
+constexpr int kRsCols = 32, kRsStride = 36;          // 32 pair sums per row + 4: rows 16-byte aligned, b128 reads conflict-free
 constexpr int kRsFloats = kRsGroup * kRsComp * kRsStride;
-typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct RsRecB { float x, y, cx, cy, cz, r, g, b, nmid, kmul, qx, qz, pvx, pvy; };
+
+__device__ __forceinline__ RsRecB load_rs_b(const float* __restrict__ records, const float* __restrict__ pix_vel,
+                                            unsigned gi, unsigned g) {
+  const float* p = records + (size_t)gi * kRecFloats;
+  RsRecB o;
+  o.x = p[0]; o.y = p[1]; o.cx = p[2]; o.cy = p[3]; o.cz = p[4]; o.r = p[6]; o.g = p[7]; o.b = p[8];
+  o.nmid = p[kRecNmid]; o.kmul = p[kRecKmul]; o.qx = p[kRecQx]; o.qz = p[kRecQz];
+  o.pvx = pix_vel[2 * (size_t)g]; o.pvy = pix_vel[2 * (size_t)g + 1];
+  return o;
+}
+
+// w[i] = v[i](lane) + v[i](lane ^ 1) for eleven values (see raster_bwd.hip pair_sum9 for the s_nop)
+__device__ __forceinline__ void pair_sum11(float (&v)[11]) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %10, %10, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+        "+v"(v[9]), "+v"(v[10]));
+}
+
+// pixel k of a lane lies in the 8x8 quadrant (k & 1, k >> 1) of the tile; its row decides tau: two values per lane
+struct RsQuad { float T[4], Dv[4], vr[4], vg[4], vb[4], py[4], tau[2]; int fin[4]; };
+
+// One list entry against the lane's four pixels (returns whether any lane of the wave was hit; then the lane pair's 11
+// partial sums are in LDS rows slot*11 .. slot*11+10, column lane >> 1).  Slot 5 carries the plain sum of v_sigma (tuple
+// flag 2: the tuple reduce divides by -opacity once per Gaussian).
+__device__ __forceinline__ bool rs_bwd_entry(const RsRecB& rc, float pxf, int idx, RsQuad& pp, float* __restrict__ red,
+                                             int slot, int lane, float agm) {
+  const float dxa = rc.x - pxf, dxb = rc.x - (pxf + 8.0f);
+  const float qy = rc.cy * kNegLog2e;
+  float M00 = 0.f, M10 = 0.f, M01 = 0.f, M20 = 0.f, M11 = 0.f, M02 = 0.f, T10 = 0.f, T01 = 0.f;
+  float q_r = 0.f, q_g = 0.f, q_b = 0.f;
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float tk = pp.tau[k >> 1];
+    float dx, dy;
+    const float u = rs_u((k & 1) ? dxb : dxa, rc.y - pp.py[k], tk, rc.pvx, rc.pvy, rc.qx, qy, rc.qz, rc.nmid, dx, dy);
+    const bool hit = (idx < pp.fin[k]) && (fabsf(u) <= rc.nmid);
+    if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;           // nobody's quadrant-k pixel blended this entry
+    any = true;
+    const float ov = rc.kmul * __builtin_amdgcn_exp2f(u);
+    // pixels that are not hit are neutralised by SELECTING alpha = 0 (1/(1-0) = 1 exactly, every term an exact zero)
+    const float alpha = hit ? fminf(K::kAlphaMax, ov) : 0.f;
+    const float ovm = (hit && ov <= agm) ? ov : 0.f;                  // d min(0.999, o*vis) = 0 when clamped
+    const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+    pp.T[k] *= ra;                                                    // transmittance in front of this entry
+    const float fac = alpha * pp.T[k];
+    q_r = fmaf(fac, pp.vr[k], q_r); q_g = fmaf(fac, pp.vg[k], q_g); q_b = fmaf(fac, pp.vb[k], q_b);
+    const float cv = fmaf(rc.b, pp.vb[k], fmaf(rc.g, pp.vg[k], rc.r * pp.vr[k]));
+    const float v_al = fmaf(pp.T[k], cv, -(ra * pp.Dv[k]));
+    pp.Dv[k] = fmaf(fac, cv, pp.Dv[k]);
+    const float v_sigma = -ovm * v_al;
+    const float vsx = v_sigma * dx, vsy = v_sigma * dy;
+    M00 += v_sigma; M10 += vsx; M01 += vsy;
+    M20 = fmaf(vsx, dx, M20); M11 = fmaf(vsx, dy, M11); M02 = fmaf(vsy, dy, M02);
+    T10 = fmaf(tk, vsx, T10); T01 = fmaf(tk, vsy, T01);               // centre = mu' + (t_s + tau) v'
+  }
+  if (!any) return false;
+  float w[11];
+  w[0] = fmaf(rc.cx, M10, rc.cy * M01);                               // d sigma / d centre
+  w[1] = fmaf(rc.cy, M10, rc.cz * M01);
+  w[2] = 0.5f * M20; w[3] = M11; w[4] = 0.5f * M02;
+  w[5] = M00;
+  w[6] = q_r; w[7] = q_g; w[8] = q_b;
+  w[9] = fmaf(rc.cx, T10, rc.cy * T01);                               // d / d pixel velocity
+  w[10] = fmaf(rc.cy, T10, rc.cz * T01);
+  pair_sum11(w);
+  if ((lane & 1) == 0) {
+    float* r0 = red + slot * (kRsComp * kRsStride) + (lane >> 1);
+#pragma unroll
+    for (int c = 0; c < kRsComp; ++c) r0[c * kRsStride] = w[c];
+  }
+  return true;
+}
 
 template <bool STATE>
 __global__ __launch_bounds__(256) void raster_bwd_rs_kernel(
@@ -193,124 +396,106 @@ __global__ __launch_bounds__(256) void raster_bwd_rs_kernel(
   range.x = __builtin_amdgcn_readfirstlane(range.x);
   range.y = __builtin_amdgcn_readfirstlane(range.y);
   if (range.y <= range.x) return;
-  const int px = tx * K::kTile + (lane & 15);
-  const int py0 = ty * K::kTile + (lane >> 4) * 4;
-  const float pxf = (float)px + 0.5f;
+  // lane -> its four pixels, one per 8x8 quadrant: pixel k at (px0 + 8 (k & 1), py0 + 8 (k >> 1))
+  const int px0 = tx * K::kTile + (lane & 7);
+  const int py0 = ty * K::kTile + (lane >> 3);
+  const float pxf = (float)px0 + 0.5f;
   const float bgr = prm.background[0], bgg = prm.background[1], bgb = prm.background[2];
-  float Tk[4], Dv[4], vr[4], vg[4], vb[4], pyf[4], tau[4];
-  int fin[4];
+  RsQuad pp;
   int my_end = range.x;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int y = py0 + k;
-    pyf[k] = (float)y + 0.5f;
-    tau[k] = (pyf[k] / (float)prm.H - 0.5f) * rs.rs_time + t_s;
-    Tk[k] = 1.f; Dv[k] = 0.f; fin[k] = range.x; vr[k] = vg[k] = vb[k] = 0.f;
-    if (px < prm.W && y < prm.H) {
-      const size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
+    const int x = px0 + 8 * (k & 1), y = py0 + 8 * (k >> 1);
+    float Tk = 1.f, Dv = 0.f, vr = 0.f, vg = 0.f, vb = 0.f;
+    int fin = range.x;
+    if (x < prm.W && y < prm.H) {
+      const size_t pix = ((size_t)s * prm.H + y) * prm.W + x;
       const float Tfin = out_T[pix];
-      fin[k] = min(max(final_idx[pix], range.x), range.y);   // a stop index never leaves the tile's list
-      vr[k] = v_img[pix * 3 + 0]; vg[k] = v_img[pix * 3 + 1]; vb[k] = v_img[pix * 3 + 2];
+      fin = min(max(final_idx[pix], range.x), range.y);      // a stop index never leaves the tile's list
+      vr = v_img[pix * 3 + 0]; vg = v_img[pix * 3 + 1]; vb = v_img[pix * 3 + 2];
       if (prm.cmb_scale) {
-        const size_t q = ((size_t)y * prm.W + px) * 3;
-        vr[k] = combine_grad(vr[k], prm.cmb_scale[q + 0], prm.cmb_gamma, prm.cmb_min);
-        vg[k] = combine_grad(vg[k], prm.cmb_scale[q + 1], prm.cmb_gamma, prm.cmb_min);
-        vb[k] = combine_grad(vb[k], prm.cmb_scale[q + 2], prm.cmb_gamma, prm.cmb_min);
+        const size_t q = ((size_t)y * prm.W + x) * 3;
+        vr = combine_grad(vr, prm.cmb_scale[q + 0], prm.cmb_gamma, prm.cmb_min);
+        vg = combine_grad(vg, prm.cmb_scale[q + 1], prm.cmb_gamma, prm.cmb_min);
+        vb = combine_grad(vb, prm.cmb_scale[q + 2], prm.cmb_gamma, prm.cmb_min);
       }
       const float va_out = v_alpha ? v_alpha[pix] : 0.f;
-      const float va = Tfin * (va_out - (bgr * vr[k] + bgg * vg[k] + bgb * vb[k]));
-      Tk[k] = Tfin;
-      Dv[k] = -va;
-      if (STATE) { Tk[k] = bwd_T[pix]; Dv[k] = bwd_B[pix] - va; }
+      const float va = Tfin * (va_out - (bgr * vr + bgg * vg + bgb * vb));
+      Tk = Tfin;
+      Dv = -va;
+      if (STATE) { Tk = bwd_T[pix]; Dv = bwd_B[pix] - va; }
     }
-    my_end = max(my_end, fin[k]);
+    my_end = max(my_end, fin);
+    pp.T[k] = Tk; pp.Dv[k] = Dv; pp.vr[k] = vr; pp.vg[k] = vg; pp.vb[k] = vb; pp.py[k] = (float)y + 0.5f; pp.fin[k] = fin;
   }
+  pp.tau[0] = rs_tau((float)py0 + 0.5f, (float)prm.H, rs.rs_time, t_s);
+  pp.tau[1] = rs_tau((float)(py0 + 8) + 0.5f, (float)prm.H, rs.rs_time, t_s);
   const int wave_end = __builtin_amdgcn_readfirstlane(wave_max_i(my_end));
   const float agm = prm.alpha_grad_max;
   const unsigned s_base = shared ? 0u : (unsigned)s * (unsigned)rs.N;
+  const unsigned max_g = (unsigned)(rs.N - 1);
   // shared list: the S samples' waves write the SAME entry's gradients — every (entry, sample) pair gets a tuple of its
   // own, e * S + s (the S tuples of an entry are adjacent, a Gaussian's tuples stay one contiguous range)
   const unsigned tmul = shared ? (unsigned)prm.S : 1u, tofs = shared ? (unsigned)s : 0u;
-  const int row = lane;
-  const int row_g = row / kRsComp, row_c = row - row_g * kRsComp;
-  if (wave_end > range.x) {
-    for (int b = (wave_end - 1) & ~3; b >= (range.x & ~3); b -= 4) {
+  const unsigned n = (unsigned)(wave_end - range.x);
+  if (n != 0u) {
+    const int row = lane;                                    // row-sum role: lanes 0..43
+    const int row_g = row / kRsComp, row_c = row - row_g * kRsComp;
+    const int4* __restrict__ ids4 = reinterpret_cast<const int4*>(ids);
+    const int4* __restrict__ eids4 = reinterpret_cast<const int4*>(eids);
+    auto rec = [&](int id) {
+      const unsigned gi = min((unsigned)id, max_id);
+      return load_rs_b(records, rs.pix_vel, gi, min(gi - s_base, max_g));
+    };
+    int b = (wave_end - 1) & ~3;
+    const int b_last = range.x & ~3;
+    int4 idv = ids4[b >> 2];
+    RsRecB a0 = rec(idv.w), a1 = rec(idv.z);
+    for (;;) {
+      // pair A (entries b+3, b+2) is ready; put pair B (b+1, b) and the indices of the next (lower) group in flight
+      asm volatile("" :: "s"(a0.x), "s"(a1.x), "s"(a0.pvx), "s"(a1.pvx) : "memory");
+      const RsRecB b0 = rec(idv.y), b1 = rec(idv.x);
+      const int4 ev = eids4[b >> 2];
+      idv = ids4[max(b - 4, 0) >> 2];
+      asm volatile("" ::: "memory");
       unsigned filled = 0;
-#pragma unroll
-      for (int slot = 3; slot >= 0; --slot) {
-        const int i = b + slot;
-        if (i < range.x || i >= wave_end) continue;
-        const unsigned gi = min((unsigned)ids[i], max_id);
-        const RsRec rc = load_rs_rec<false>(records, rs.pix_vel, gi, gi - s_base);
-        const float dx0 = rc.x - pxf;
-        float dxk[4], dyk[4], vis[4], ov[4];
-        bool hit[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float s2 = rs_exponent(rc, dx0, rc.y - pyf[k], tau[k], dxk[k], dyk[k]);
-          vis[k] = __builtin_amdgcn_exp2f(s2);
-          ov[k] = rc.op * vis[k];
-          hit[k] = (i < fin[k]) && (s2 <= 0.f) && (fminf(K::kAlphaMax, ov[k]) >= K::kAlphaMin);
-        }
-        if (__ballot(hit[0] || hit[1] || hit[2] || hit[3]) == 0ull) continue;
-        float p[kRsComp];
-#pragma unroll
-        for (int c = 0; c < kRsComp; ++c) p[c] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float alpha = hit[k] ? fminf(K::kAlphaMax, ov[k]) : 0.f;      // alpha = 0: every term below is an exact zero
-          const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
-          Tk[k] *= ra;                                                         // transmittance in front of this entry
-          const float fac = alpha * Tk[k];
-          p[6] += fac * vr[k]; p[7] += fac * vg[k]; p[8] += fac * vb[k];
-          const float cv = rc.r * vr[k] + rc.g * vg[k] + rc.b * vb[k];
-          const float v_al = Tk[k] * cv - ra * Dv[k];
-          Dv[k] += fac * cv;
-          const bool free_ = hit[k] && ov[k] <= agm;                           // d min(0.999, o*vis) = 0 when clamped
-          const float vism = free_ ? vis[k] : 0.f;
-          const float v_sigma = -(rc.op * vism) * v_al;
-          p[5] += vism * v_al;
-          const float gdx = v_sigma * (rc.cx * dxk[k] + rc.cy * dyk[k]);       // d sigma / d dx
-          const float gdy = v_sigma * (rc.cy * dxk[k] + rc.cz * dyk[k]);
-          p[0] += gdx; p[1] += gdy;
-          p[9] += tau[k] * gdx; p[10] += tau[k] * gdy;                          // centre = mu' + (t_s + tau) v'
-          p[2] += 0.5f * v_sigma * dxk[k] * dxk[k];
-          p[3] += v_sigma * dxk[k] * dyk[k];
-          p[4] += 0.5f * v_sigma * dyk[k] * dyk[k];
-        }
-        filled |= 1u << slot;
-        float* r0 = red + slot * (kRsComp * kRsStride) + lane;
-#pragma unroll
-        for (int c = 0; c < kRsComp; ++c) r0[c * kRsStride] = p[c];
-      }
+      if ((unsigned)(b + 3 - range.x) < n && rs_bwd_entry(a0, pxf, b + 3, pp, red, 3, lane, agm)) filled |= 8u;
+      if ((unsigned)(b + 2 - range.x) < n && rs_bwd_entry(a1, pxf, b + 2, pp, red, 2, lane, agm)) filled |= 4u;
+      asm volatile("" :: "s"(b0.x), "s"(b1.x), "s"(b0.pvx), "s"(b1.pvx), "s"(idv.x), "s"(ev.x) : "memory");
+      a0 = rec(idv.w); a1 = rec(idv.z);
+      asm volatile("" ::: "memory");
+      if ((unsigned)(b + 1 - range.x) < n && rs_bwd_entry(b0, pxf, b + 1, pp, red, 1, lane, agm)) filled |= 2u;
+      if ((unsigned)(b - range.x) < n && rs_bwd_entry(b1, pxf, b, pp, red, 0, lane, agm)) filled |= 1u;
       if (filled) {
         __builtin_amdgcn_wave_barrier();
         if (row < kRsGroup * kRsComp && ((filled >> row_g) & 1u)) {
           const f4* rp = reinterpret_cast<const f4*>(red + row * kRsStride);
-          f4 a0 = rp[0], a1 = rp[1], a2 = rp[2], a3 = rp[3];
-#pragma unroll
-          for (int q = 4; q < 16; q += 4) { a0 += rp[q]; a1 += rp[q + 1]; a2 += rp[q + 2]; a3 += rp[q + 3]; }
-          const f4 v = (a0 + a1) + (a2 + a3);
+          f4 s0 = rp[0], s1 = rp[1], s2 = rp[2], s3 = rp[3];
+          s0 += rp[4]; s1 += rp[5]; s2 += rp[6]; s3 += rp[7];
+          const f4 v = (s0 + s1) + (s2 + s3);
           const float sum = (v.x + v.y) + (v.z + v.w);
-          const size_t e = (size_t)(unsigned)eids[b + row_g] * tmul + tofs;
+          const int id_e = row_g == 0 ? ev.x : (row_g == 1 ? ev.y : (row_g == 2 ? ev.z : ev.w));
+          const size_t e = (size_t)(unsigned)id_e * tmul + tofs;
           tuples[e * kGradFloats + row_c] = sum;
-          if (row_c == 0) flags[e] = 1;
+          if (row_c == 0) flags[e] = 2;                      // 2: slot 5 is the plain sum of v_sigma
         }
         __builtin_amdgcn_wave_barrier();
       }
+      if (b <= b_last) break;
+      b -= 4;
     }
   }
   if (STATE) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int y = py0 + k;
-      if (px < prm.W && y < prm.H) {
-        const size_t pix = ((size_t)s * prm.H + y) * prm.W + px;
+      const int x = px0 + 8 * (k & 1), y = py0 + 8 * (k >> 1);
+      if (x < prm.W && y < prm.H) {
+        const size_t pix = ((size_t)s * prm.H + y) * prm.W + x;
         const float Tfin = out_T[pix];
         const float va_out = v_alpha ? v_alpha[pix] : 0.f;
-        const float va = Tfin * (va_out - (bgr * vr[k] + bgg * vg[k] + bgb * vb[k]));
-        bwd_T[pix] = Tk[k];
-        bwd_B[pix] = Dv[k] + va;
+        const float va = Tfin * (va_out - (bgr * pp.vr[k] + bgg * pp.vg[k] + bgb * pp.vb[k]));
+        bwd_T[pix] = pp.T[k];
+        bwd_B[pix] = pp.Dv[k] + va;
       }
     }
   }

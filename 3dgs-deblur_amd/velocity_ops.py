@@ -110,7 +110,7 @@ class RasterizeGaussiansPixvel(Function):
         S = len(times)
         tx, ty = _tiles(H, W)
         # records [N,16] with the SWEPT tile box (gs_math.h::tile_bounds_swept, float32 op for op: the rolling-shutter
-        # compositors read floats 0..9 and the packed box only)
+        # compositors read floats 0..9, the packed box and the constants 12..15)
         half = torch.tensor(0.5 * span, dtype=torch.float32, device=dev)
         inv_tile = torch.tensor(1.0 / TILE, dtype=torch.float32, device=dev)
         xa, xb = xys[:, 0] - half * pv[:, 0], xys[:, 0] + half * pv[:, 0]
@@ -125,6 +125,14 @@ class RasterizeGaussiansPixvel(Function):
         records = torch.zeros(N, REC, device=dev)
         records[:, 0:2], records[:, 2:5], records[:, 5], records[:, 6:9], records[:, 9] = xys, conics, opacity, colors, depths
         records[:, 10:12] = torch.stack([x0 | (y0 << 16), x1 | (y1 << 16)], dim=1).view(torch.float32)
+        # floats 12..15: the compositors' per-entry constants (csrc/gs_math.h::rec_aux): nmid = log2(255 op) / 2,
+        # kmul = op 2^-nmid (alpha = kmul 2^u, u = nmid - log2(e) sigma; |u| <= nmid <=> sigma >= 0 and alpha >= 1/255),
+        # and the conic's diagonal pre-scaled by -log2(e) / 2
+        blend = opacity >= (1.0 / 255.0)
+        nmid = torch.where(blend, 0.5 * torch.log2(255.0 * opacity.clamp_min(1e-30)), torch.full_like(opacity, -1.0))
+        records[:, 12] = nmid
+        records[:, 13] = torch.where(blend, opacity * torch.exp2(-nmid), torch.zeros_like(opacity))
+        records[:, 14], records[:, 15] = conics[:, 0] * (-0.5 * 1.4426950408889634), conics[:, 2] * (-0.5 * 1.4426950408889634)
         records = torch.where(ok[:, None], records, torch.zeros_like(records)).contiguous()
         ntiles = torch.where(ok, area, torch.zeros_like(area)).contiguous()
         dkeys = torch.where(ok, depths.view(torch.int32), torch.full_like(area, -1)).contiguous()

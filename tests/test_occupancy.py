@@ -19,6 +19,9 @@ BUDGET = {
     ("raster.hip", "raster_fwd_sload_kernel<false>"): (72, False),            # 7 waves per SIMD
     ("raster_bwd.hip", "raster_bwd_sload_kernel<false, 1>"): (96, False),     # 5 waves (launch bound)
     ("raster_bwd.hip", "raster_bwd_sload_kernel<true, 1>"): (96, False),
+    ("raster_rs.hip", "raster_fwd_rs_kernel<false>"): (72, False),            # round 6: the pixel-velocity compositors
+    ("raster_rs.hip", "raster_bwd_rs_kernel<false>"): (96, False),            # in the current kernel generation (was 140)
+    ("raster_rs.hip", "raster_bwd_rs_kernel<true>"): (104, False),
     ("project.hip", "project_fused_fwd_kernel<16, true>"): (96, False),       # 5 waves
     ("project.hip", "project_fused_bwd_sparse_kernel<16, true>"): (256, True),   # 2 waves: the zero fill needs them
     ("project.hip", "project_needle_hp_kernel"): (168, False),                # 3 waves
