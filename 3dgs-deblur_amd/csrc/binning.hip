@@ -724,7 +724,10 @@ __global__ __launch_bounds__(256) void gather_counts_kernel(size_t n, const unsi
 // slack keeps the test conservative against the compositor's float32 rounding: culled pairs
 // contribute exactly nothing, so images are unchanged.
 // ---------------------------------------------------------------------------
-struct Ellipse { float gx, gy, a, b, c, tau, ra, rc, ustar, vstar, vext; };
+struct Ellipse { float gx, gy, a, b, c, tau, ra, rc, ustar, vstar, vext;
+                 // swept form (round 6, pixel-velocity compositors): the centre moves, gx + t pvx, gy + t pvy, over the
+                 // times the pixels of a tile row can see it: t in [st0 + tau(row), st1 + tau(row)], tau(y) = ((y + .5)/H - .5) srs
+                 float pvx, pvy, st0, st1, srs; };
 // ustar = largest |u| on the ellipse (reached at v = -b*ustar/c), vext = largest |v|, vstar = b*ustar/c
 
 // everything the tile tests need beyond (gx, gy, a, b, c, tau): the same arithmetic wherever an ellipse is rebuilt
@@ -766,14 +769,29 @@ __device__ __forceinline__ Ellipse make_ellipse(const float* __restrict__ rec) {
 // emission must take the SAME decision for every tile wherever this is inlined.
 struct RowSpan { float ul, ur; };
 
+template <bool SWEEP = false>
 __device__ __forceinline__ RowSpan row_span(const Ellipse& e, int ty, int H) {
 #pragma clang fp contract(off)
   RowSpan r;
   r.ul = 1.f; r.ur = -1.f;                                 // empty
   if (e.tau < 0.f) return r;
   if (e.ustar > 1.0e37f) { r.ul = -3.0e38f; r.ur = 3.0e38f; return r; }
-  const float v0 = (float)(ty * K::kTile) + 0.5f - e.gy;
-  const float v1 = fminf((float)(ty * K::kTile + K::kTile) - 0.5f, (float)H - 0.5f) - e.gy;
+  float v0 = (float)(ty * K::kTile) + 0.5f - e.gy;
+  float v1 = fminf((float)(ty * K::kTile + K::kTile) - 0.5f, (float)H - 0.5f) - e.gy;
+  float ox0 = 0.f, ox1 = 0.f;
+  if (SWEEP) {
+    // SWEEP: the offsets the centre can have while a pixel of this tile row is exposed — x and y taken as independent
+    // intervals (a box around the swept segment: conservative).  A pixel at (x, y) sees the splat at
+    // (x - gx - ox, y - gy - oy): the row band widens by the y offsets, the column interval by the x offsets.
+    const float invH = 1.0f / (float)H;
+    const float ya = (float)(ty * K::kTile) + 0.5f, yb = fminf((float)(ty * K::kTile + K::kTile) - 0.5f, (float)H - 0.5f);
+    const float ta = (ya * invH - 0.5f) * e.srs, tb = (yb * invH - 0.5f) * e.srs;
+    const float t_lo = e.st0 + fminf(ta, tb), t_hi = e.st1 + fmaxf(ta, tb);
+    const float slack = 1e-3f + 1e-5f * (fabsf(t_lo) + fabsf(t_hi)) * (fabsf(e.pvx) + fabsf(e.pvy));
+    ox0 = fminf(t_lo * e.pvx, t_hi * e.pvx) - slack; ox1 = fmaxf(t_lo * e.pvx, t_hi * e.pvx) + slack;
+    const float oy0 = fminf(t_lo * e.pvy, t_hi * e.pvy) - slack, oy1 = fmaxf(t_lo * e.pvy, t_hi * e.pvy) + slack;
+    v0 -= oy1; v1 -= oy0;
+  }
   if (v1 < -e.vext || v0 > e.vext) return r;
   const float w0 = fmaxf(v0, -e.vext), w1 = fminf(v1, e.vext);
   // chord of the ellipse on the line v = w: u = (-b w -/+ sqrt(2 a tau - det w^2)) / a
@@ -786,8 +804,8 @@ __device__ __forceinline__ RowSpan row_span(const Ellipse& e, int ty, int H) {
   if (-e.vstar >= w0 && -e.vstar <= w1) ur = e.ustar;
   if (e.vstar >= w0 && e.vstar <= w1) ul = -e.ustar;
   const float eps = 2e-3f + 2e-6f * (fabsf(e.gx) + e.ustar);
-  r.ur = fmaxf(ur, ul) + eps;
-  r.ul = fminf(ul, ur) - eps;
+  r.ur = fmaxf(ur, ul) + eps + ox1;
+  r.ul = fminf(ul, ur) - eps + ox0;
   return r;
 }
 
@@ -805,9 +823,10 @@ __device__ __forceinline__ void span_tiles(const Ellipse& e, const RowSpan& sp, 
   if (t1 < t0) t1 = t0;
 }
 
+template <bool SWEEP = false>
 __device__ __forceinline__ bool tile_hit(const Ellipse& e, int tx, int ty, int W, int H) {
   (void)W;
-  const RowSpan sp = row_span(e, ty, H);
+  const RowSpan sp = row_span<SWEEP>(e, ty, H);
   int t0, t1;
   span_tiles(e, sp, tx, tx + 1, t0, t1);
   return t1 > t0;
@@ -1122,7 +1141,12 @@ __device__ __forceinline__ unsigned long long row_window(const unsigned long lon
 
 // WAVE_PER_G: one Gaussian per wave (lane 0 owns it) — for slices of few, large Gaussians, where 64 big
 // boxes per wave would serialise ~25k tile tests in each of only a few hundred waves.
-template <bool WAVE_PER_G>
+// SWEEP (round 6): the pixel-velocity compositors move every splat by (sample time + row time) * pixel velocity; the
+// hit test then covers every position the centre takes while a pixel of the tile row is exposed (row_span<true>), so
+// the lists of those frames are culled by the swept ellipse instead of holding their whole swept bounding boxes.
+struct SweepP { const float* pix_vel; float t_min, t_max, rs_time; };
+
+template <bool WAVE_PER_G, bool SWEEP = false>
 __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, SliceDesc sd, int N, int tiles_x,
                                                                  int tiles_y, const unsigned* __restrict__ sorted_gi,
                                                                  const float* __restrict__ records,
@@ -1134,7 +1158,7 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
                                                                  unsigned long long* __restrict__ masks,  // nullable
                                                                  unsigned* __restrict__ mask_off,
                                                                  const unsigned long long* __restrict__ open_bits,
-                                                                 const int* __restrict__ gate) {
+                                                                 const int* __restrict__ gate, SweepP sw) {
   __shared__ unsigned long long s_words[4][kMaskWords];
   __shared__ unsigned long long s_mid[WAVE_PER_G ? 1 : 4][256];      // lane-private bit strings of mid-sized boxes
   const int lane = lane_id();
@@ -1166,6 +1190,11 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
     }
     if (area > 0) el = make_ellipse(rec);
     if (el.tau < 0.f) area = 0;
+    if (SWEEP && area > 0) {
+      const unsigned g = gi % (unsigned)N;
+      el.pvx = sw.pix_vel[2 * (size_t)g]; el.pvy = sw.pix_vel[2 * (size_t)g + 1];
+      el.st0 = sw.t_min; el.st1 = sw.t_max; el.srs = sw.rs_time;
+    }
   }
   const unsigned T = (unsigned)(tiles_x * tiles_y);
   const int W64 = (tiles_x + 63) >> 6;
@@ -1215,7 +1244,7 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
           const int y = yb + k;
           if (y >= y1) break;
           int t0, t1;
-          span_tiles(el, row_span(el, y, H), x0, x1, t0, t1);
+          span_tiles(el, row_span<SWEEP>(el, y, H), x0, x1, t0, t1);
           if (t1 <= t0) continue;
           unsigned long long rowbits = (t1 - t0 >= 64 ? ~0ull : ((1ull << (t1 - t0)) - 1ull)) << (t0 - x0);   // w <= 64
           unsigned long long win = a[k] >> sh;                     // row_window(row, x0, w) on the prefetched words
@@ -1227,7 +1256,7 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
     } else {
       for (int y = y0; y < y1; ++y) {
         int t0, t1;
-        span_tiles(el, row_span(el, y, H), x0, x1, t0, t1);
+        span_tiles(el, row_span<SWEEP>(el, y, H), x0, x1, t0, t1);
         if (t1 <= t0) continue;
         put(y, (t1 - t0 >= 64 ? ~0ull : ((1ull << (t1 - t0)) - 1ull)) << (t0 - x0));
       }
@@ -1251,6 +1280,10 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
     eg.gx = readlane_f(el.gx, src); eg.gy = readlane_f(el.gy, src); eg.a = readlane_f(el.a, src);
     eg.b = readlane_f(el.b, src); eg.c = readlane_f(el.c, src); eg.tau = readlane_f(el.tau, src);
     ellipse_derive(eg);
+    if (SWEEP) {
+      eg.pvx = readlane_f(el.pvx, src); eg.pvy = readlane_f(el.pvy, src);
+      eg.st0 = sw.t_min; eg.st1 = sw.t_max; eg.srs = sw.rs_time;
+    }
     const int x0 = l & 0xFFFF, y0 = l >> 16, x1 = h & 0xFFFF, y1 = h >> 16;
     const int w = x1 - x0, rows = y1 - y0, a = w * rows;
     const unsigned pidx = g / (unsigned)N;
@@ -1265,7 +1298,7 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
       __builtin_amdgcn_wave_barrier();
       for (int r = lane; r < rows; r += 64) {
         int t0, t1;
-        span_tiles(eg, row_span(eg, y0 + r, H), x0, x1, t0, t1);
+        span_tiles(eg, row_span<SWEEP>(eg, y0 + r, H), x0, x1, t0, t1);
         const unsigned long long* orow = open_bits ? open_bits + ((size_t)pidx * tiles_y + (y0 + r)) * W64 : nullptr;
         // the row's local bits in chunks of 64 columns
         for (int c0 = 0; c0 < w; c0 += 64) {
@@ -1298,7 +1331,7 @@ __global__ __launch_bounds__(256) void slice_counts_exact_kernel(int n_slice, Sl
         if (t < a) {
           const int q = (int)(((float)t + 0.5f) * rw);
           const int tx = x0 + (t - q * w), ty = y0 + q;
-          ok = tile_hit(eg, tx, ty, W, H) && (!done || done[pbase + (unsigned)(ty * tiles_x + tx)] == 0);
+          ok = tile_hit<SWEEP>(eg, tx, ty, W, H) && (!done || done[pbase + (unsigned)(ty * tiles_x + tx)] == 0);
         }
         const unsigned long long m = __ballot(ok);
         if (masks && lane == 0) masks[mo + (unsigned)(base >> 6)] = m;
@@ -1917,14 +1950,45 @@ GS_EXPORT int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_
   if (hit_masks && (!cum_rank || !mask_off)) return GS_ERR_INVALID;
   if ((tile_done != nullptr) != (open_bits != nullptr)) return GS_ERR_INVALID;   // both describe the same closed tiles
   int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
+  const SweepP none{nullptr, 0.f, 0.f, 0.f};
   if (wave_per_gaussian)
     hipLaunchKernelGGL(slice_counts_exact_kernel<true>, dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W, H, slice_gi, counts,
-                       cum_rank, hit_masks, mask_off, open_bits, gate);
+                       cum_rank, hit_masks, mask_off, open_bits, gate, none);
   else
     hipLaunchKernelGGL(slice_counts_exact_kernel<false>, dim3((n_slice + 255) / 256), dim3(256), 0,
                        (hipStream_t)stream, n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W,
-                       H, slice_gi, counts, cum_rank, hit_masks, mask_off, open_bits, gate);
+                       H, slice_gi, counts, cum_rank, hit_masks, mask_off, open_bits, gate, none);
+  return gs_launch_status();
+}
+
+// gs_slice_counts_exact for the lists of the pixel-velocity compositors (gs_rasterize_*_rs_slice): a splat's centre is
+// records[gi].xy + t * pix_vel[gi % N], t = a sample time in [t_min, t_max] plus the row time
+// ((y + 0.5) / H - 0.5) * rolling_shutter_time of the pixel that looks at it; a tile is counted (and its hit-mask bit
+// set: hit_masks is required) when the alpha >= 1/255 ellipse reaches it at ANY such time.  The records' tile boxes
+// must already be swept (gs_project_pixvel_fwd).  Per-sample lists: t_min = t_max = 0.
+GS_EXPORT int gs_slice_counts_exact_swept(int n_slice, int P, int N, const int* slice_begin, const int* slice_prefix,
+                                          const unsigned* sorted_gi, const float* records, const int* sat,
+                                          const unsigned char* tile_done, int H, int W, unsigned* slice_gi,
+                                          unsigned* counts, int wave_per_gaussian, const unsigned* cum_rank,
+                                          unsigned long long* hit_masks, unsigned* mask_off,
+                                          const unsigned long long* open_bits, const float* pix_vel, float t_min,
+                                          float t_max, float rolling_shutter_time, void* stream) {
+  SliceDesc sd;
+  if (n_slice <= 0 || N <= 0 || !pix_vel || !hit_masks || !cum_rank || !mask_off ||
+      !make_slice_desc(P, slice_begin, slice_prefix, sd))
+    return GS_ERR_INVALID;
+  if ((tile_done != nullptr) != (open_bits != nullptr)) return GS_ERR_INVALID;
+  int tiles_x = (W + K::kTile - 1) / K::kTile, tiles_y = (H + K::kTile - 1) / K::kTile;
+  const SweepP sw{pix_vel, fminf(t_min, t_max), fmaxf(t_min, t_max), rolling_shutter_time};
+  if (wave_per_gaussian)
+    hipLaunchKernelGGL((slice_counts_exact_kernel<true, true>), dim3((n_slice + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W, H, slice_gi, counts,
+                       cum_rank, hit_masks, mask_off, open_bits, (const int*)nullptr, sw);
+  else
+    hipLaunchKernelGGL((slice_counts_exact_kernel<false, true>), dim3((n_slice + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, n_slice, sd, N, tiles_x, tiles_y, sorted_gi, records, sat, tile_done, W,
+                       H, slice_gi, counts, cum_rank, hit_masks, mask_off, open_bits, (const int*)nullptr, sw);
   return gs_launch_status();
 }
 

@@ -370,7 +370,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   std::vector<std::vector<long long>> bnd(P), rel(P);
   long long n_total = 0, true_total = 0;
   int K = 1;
-  bool use_masks = false;
+  bool use_masks = false, rs_exact = false;
   std::vector<std::vector<int>> begins, prefixes;
   std::vector<long long> n_of, I_of;
   // phase 0: the frame's plan (select: ONE slice, the selection); phase 1: the plan of the pairs behind the selection,
@@ -412,7 +412,11 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
     }
     true_total = 0;
     for (int p = 0; p < P; ++p) true_total += seg_totals[p];
-    use_masks = planned && !rs && true_total < 4294967296ll - 64;
+    use_masks = planned && true_total < 4294967296ll - 64;
+    // pixel-velocity compositors (rs): exact lists need the hit masks (the emission expands them; it has no swept test of
+    // its own) — without them the lists hold the swept boxes whole, as in rounds 3-5
+    rs_exact = rs && use_masks;
+    if (rs && !rs_exact) use_masks = false;
     // slice descriptors (host arrays: they travel in the kernel arguments) and the slices' list capacities
     begins.assign(K, std::vector<int>(P));
     prefixes.assign(K, std::vector<int>(P + 1));
@@ -541,7 +545,15 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
       if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
       if (lazy)
         CHECK(gs_slice_project_records((int)n_k, P, N, beg_s.data(), pre_s.data(), sorted_gi, lazy, H, W, records, st));
-      if (rs)
+      if (rs_exact)
+        // round 6: the swept alpha >= 1/255 ellipse instead of the whole swept box (the box lists held ~3x the entries a
+        // sample's pixels can blend: every one of them cost the compositors a full four-pixel evaluation)
+        CHECK(gs_slice_counts_exact_swept((int)n_k, P, N, beg_s.data(), pre_s.data(), sorted_gi, records,
+                                          have_holes ? sat : nullptr, have_holes ? tile_done : nullptr, H, W, slice_gi,
+                                          counts, wave_per_g, cum, masks, mask_off, have_holes ? open_bits : nullptr,
+                                          pix_vel, shared ? d.sweep_t_min : 0.f, shared ? d.sweep_t_max : 0.f,
+                                          d.rolling_shutter_time, st));
+      else if (rs)
         CHECK(gs_slice_counts((int)n_k, P, N, beg_s.data(), pre_s.data(), sorted_gi, records,
                               have_holes ? sat : nullptr, H, W, slice_gi, counts, st));
       else
@@ -569,13 +581,13 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
       if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
       {
         StageScope sc(ST_EMIT, st);
-        if (rs && first && !holes0)
+        if (rs && !rs_exact && first && !holes0)
           // every tile is open and the counts are the boxes: the slice holds exactly its ranks' box pairs
           CHECK(gs_emit_intersects(n_k, N, H, W, slice_gi, cum_k, records, I_k, keys, vals, invalid_key, st));
         else
           CHECK(gs_emit_open_intersects((int)n_k, N, H, W, slice_gi, counts, cum_k, records,
-                                        (!first || holes0) ? tile_done : nullptr, keys, vals, invalid_key, rs ? 0 : 1,
-                                        wave_per_g, masks, mask_off, rs ? nullptr : tile_hot, st));
+                                        (!first || holes0) ? tile_done : nullptr, keys, vals, invalid_key,
+                                        (rs && !rs_exact) ? 0 : 1, wave_per_g, masks, mask_off, rs ? nullptr : tile_hot, st));
       }
       int r1 = 0, r2 = 0;
       {

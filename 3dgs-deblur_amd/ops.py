@@ -502,6 +502,8 @@ class _FrameDesc(ctypes.Structure):
                                                                                      ("combine_min_level", ctypes.c_float),
                                                                                      ("band_clipped", ctypes.c_int),
                                                                                      ("depth_select", ctypes.c_int),
+                                                                                     ("sweep_t_min", ctypes.c_float),
+                                                                                     ("sweep_t_max", ctypes.c_float),
                                                                                      ("lazy_records", ctypes.c_void_p)]
 
 
@@ -695,6 +697,7 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
                       float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0, frame_poll(), int(shared),
                       float(combine[0]) if combine is not None else 1.0, float(combine[1]) if combine is not None else 0.0,
                       int(bool(band_clipped)), int(bool(depth_select and slice_base > 0)),
+                      float(rs[3][0]) if shared and len(rs) > 3 else 0.0, float(rs[3][1]) if shared and len(rs) > 3 else 0.0,
                       ctypes.addressof(lazy) if lazy is not None else None)
     state = _FrameState()
     out_img = torch.empty(S, H, W, 3, device=dev)
@@ -1125,7 +1128,7 @@ class _RenderSubposes(Function):
                 raise ValueError(f"times must hold {S} sample times")
             t_c = 0.5 * (min(tl) + max(tl))
             shared = (torch.tensor([t - t_c for t in tl], dtype=torch.float32, device=means3d.device),
-                      (max(tl) - min(tl)) + abs(rs_time))
+                      (max(tl) - min(tl)) + abs(rs_time), (min(tl) - t_c, max(tl) - t_c))
             times = torch.tensor([t_c], dtype=torch.float32, device=means3d.device)
             P = 1
         if pixvel:
@@ -1171,7 +1174,7 @@ class _RenderSubposes(Function):
         if shared is not None and backend is not None:
             raise ValueError("the shared-list mode runs through the library's frame path only")
         pix_vel = torch.empty(N, 2, device=dev) if (rs_time != 0.0 or shared is not None) else None
-        rs = None if pix_vel is None else (pix_vel, rs_time) + ((shared[0],) if shared is not None else ())
+        rs = None if pix_vel is None else (pix_vel, rs_time) + ((shared[0], shared[2]) if shared is not None else ())
         box_sweep = shared[1] if shared is not None else rs_time      # what the projection widens the tile boxes by
         ctx.rs = rs
 

@@ -368,6 +368,18 @@ int gs_slice_counts_exact(int n_slice, int P, int N, const int* slice_begin /*HO
                                             count is 0 without looking at anything — a slice launched before anybody
                                             knows whether it is needed costs next to nothing when it is not*/,
                           void* stream);
+/* gs_slice_counts_exact for the lists of the pixel-velocity compositors (round 6): the alpha >= 1/255 ellipse swept
+ * over the times a tile row's pixels can see the splat — sample times in [t_min, t_max] (0, 0 for per-sample lists)
+ * plus the row time ((y + 0.5) / H - 0.5) * rolling_shutter_time — centre = records[gi].xy + t * pix_vel[gi % N].
+ * hit_masks / cum_rank / mask_off are required (the emission expands the masks); no upstream counterpart (upstream
+ * lists hold whole bounding boxes). */
+int gs_slice_counts_exact_swept(int n_slice, int P, int N, const int* slice_begin, const int* slice_prefix,
+                                const unsigned* sorted_gi, const float* records, const int* sat,
+                                const unsigned char* tile_done, int img_height, int img_width, unsigned* slice_gi,
+                                unsigned* counts, int wave_per_gaussian, const unsigned* cum_rank,
+                                unsigned long long* hit_masks, unsigned* mask_off, const unsigned long long* open_bits,
+                                const float* pix_vel, float t_min, float t_max, float rolling_shutter_time,
+                                void* stream);
 int gs_emit_open_intersects(int n_slice, int N, int img_height, int img_width, const unsigned* slice_gi,
                             const unsigned* counts, const unsigned* cum_excl, const float* records,
                             const unsigned char* tile_done /*NULL: all open*/, unsigned* keys, unsigned* vals,
@@ -552,6 +564,9 @@ typedef struct gs_frame_desc {
                                 the first slice's budget reaches (gs_depth_select + gs_segmented_sort_select_u32); the
                                 pairs behind them are sorted and planned (budget doubled) only if that slice leaves a
                                 tile open.  Same images bit for bit; for scenes whose frames stop in their first slice */
+  float sweep_t_min, sweep_t_max; /* shared_list: smallest / largest of sample_times (host copies): with planned slices the
+                                lists are culled by the alpha >= 1/255 ellipse swept over [sweep_t_min, sweep_t_max] + the
+                                row times (gs_slice_counts_exact_swept) instead of holding the swept boxes whole */
   const struct gs_project_inputs* lazy_records;   /* NULL, or (the projection ran with defer_color bit 4: `records` holds
                                 nothing yet) what it was called with: every issued slice first projects the records of
                                 its own pairs (gs_slice_project_records).  SE(3) sub-poses only (pix_vel == NULL) */
