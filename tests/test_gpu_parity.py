@@ -2026,7 +2026,13 @@ def test_native_frame_orchestration_equals_python_orchestration(gs, dev, case):
     finally:
         ops.NATIVE_FRAME, ops.SLICE_BASE, ops.SLICE_MERGE, ops.BAND_AWARE = saved
     a, b = res
-    assert a[5] == b[5] and a[6] == b[6] and a[5] > 0
+    if case.startswith("exact_rolling_shutter"):
+        # round 6: the library culls the pixel-velocity lists by the swept alpha >= 1/255 ellipse
+        # (gs_slice_counts_exact_swept); the Python twin keeps the swept boxes whole.  What is culled can blend nothing:
+        # same pair total, fewer list entries, the same images and gradients bit for bit (asserted below)
+        assert a[5] == b[5] and a[5] > 0 and 0 < sum(a[6]) < sum(b[6]), (a[5], b[5], a[6], b[6])
+    else:
+        assert a[5] == b[5] and a[6] == b[6] and a[5] > 0
     if case in ("multi_slice", "tiny_budget"):
         assert len(a[6]) >= 2
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
