@@ -545,6 +545,150 @@ __global__ __launch_bounds__(256, GS_BWD_SLOAD_WAVES) void raster_bwd_sload_kern
 }
 
 // ---------------------------------------------------------------------------
+// Splat-parallel backward (round 6; VERDICT round 5 item 2a: "build, not cost").  MEASURED NEGATIVE, kept selectable
+// (variant bit 1024) so that the measurement can be repeated: profiles/r06_bwd_splat_parallel.md.
+// Lane = one list entry of a 64-entry chunk (chunks back to front, lane 0 = the chunk's last entry); the tile's 256
+// pixels stream through the wave as a systolic pipeline: at step s lane j works on pixel s - j, whose running state
+// (transmittance in front, behind-colour . v_out) it takes over from lane j - 1 with two wave-wide DPP shifts — lane 0
+// feeds pixel s from LDS, lane 63 hands pixel s - 63 back to LDS for the next chunk.  A lane accumulates ITS entry's
+// nine sums over all 256 pixels in registers and stores the finished tuple itself: no cross-lane reduction, no LDS
+// transpose, no tuple flags race.  What it pays: every (entry, pixel) pair costs a full evaluation — the tile-per-wave
+// kernel above skips an entry with four wave-uniform quadrant tests when nobody blends it, and averages 64 VALU
+// wave-instructions per entry on the fitted-model-like scene where this form needs ~60 per STEP, 319 steps per chunk.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dpp_wave_shr1(float fresh_lane0, float v) {
+  // lane j <- lane j - 1; lane 0 has no source and keeps `old` = the value fed into the pipeline (bound_ctrl off)
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fresh_lane0), __float_as_int(v), 0x138 /*wave_shr:1*/,
+                                                    0xf, 0xf, false));
+}
+
+template <bool STATE>
+__global__ __launch_bounds__(256) void raster_bwd_splat_kernel(
+    RasterParams prm, const int* __restrict__ ids, const int* __restrict__ eids, const float* __restrict__ records,
+    unsigned max_id, const float* __restrict__ out_T, const int* __restrict__ final_idx, const float* __restrict__ v_img,
+    const float* __restrict__ v_alpha, unsigned n_blocks, float* __restrict__ bwd_T, float* __restrict__ bwd_B,
+    float* __restrict__ tuples, unsigned char* __restrict__ flags) {
+  __shared__ float s_all[4][6][256];                       // per wave: vr, vg, vb, T, Dv, fin (int bits)
+  const int lane = lane_id();
+  float (*sp)[256] = s_all[threadIdx.x >> 6];
+  const int T = prm.tiles_x * prm.tiles_y;
+  const unsigned work = (unsigned)__builtin_amdgcn_readfirstlane(
+      (int)(xcd_remap(blockIdx.x, n_blocks) * 4u + (threadIdx.x >> 6)));
+  if (work >= (unsigned)(prm.S * T)) return;
+  const int s = work / T, t = work % T;
+  const int ty = t / prm.tiles_x, tx = t % prm.tiles_x;
+  const int p_sub = s * prm.R + find_band(prm.band_edges, prm.R, ty);
+  int2 range = prm.tile_bins[(size_t)p_sub * T + t];
+  range.x = __builtin_amdgcn_readfirstlane(range.x);
+  range.y = __builtin_amdgcn_readfirstlane(range.y);
+  if (range.y <= range.x) return;
+  const float bgr = prm.background[0], bgg = prm.background[1], bgb = prm.background[2];
+  int my_end = range.x;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int pidx = lane + 64 * q;
+    const int x = tx * K::kTile + (pidx & 15), y = ty * K::kTile + (pidx >> 4);
+    float Tk = 1.f, Dv = 0.f, vr = 0.f, vg = 0.f, vb = 0.f;
+    int fin = range.x;
+    if (x < prm.W && y < prm.H) {
+      const size_t pix = ((size_t)s * prm.H + y) * prm.W + x;
+      const float Tfin = out_T[pix];
+      fin = final_idx[pix];
+      vr = v_img[pix * 3 + 0]; vg = v_img[pix * 3 + 1]; vb = v_img[pix * 3 + 2];
+      if (prm.cmb_scale) {
+        const size_t qq = ((size_t)y * prm.W + x) * 3;
+        vr = combine_grad(vr, prm.cmb_scale[qq + 0], prm.cmb_gamma, prm.cmb_min);
+        vg = combine_grad(vg, prm.cmb_scale[qq + 1], prm.cmb_gamma, prm.cmb_min);
+        vb = combine_grad(vb, prm.cmb_scale[qq + 2], prm.cmb_gamma, prm.cmb_min);
+      }
+      const float va_out = v_alpha ? v_alpha[pix] : 0.f;
+      const float va = Tfin * (va_out - (bgr * vr + bgg * vg + bgb * vb));
+      Tk = Tfin;
+      Dv = -va;
+      if (STATE) { Tk = bwd_T[pix]; Dv = bwd_B[pix] - va; }
+    }
+    my_end = max(my_end, fin);
+    sp[0][pidx] = vr; sp[1][pidx] = vg; sp[2][pidx] = vb; sp[3][pidx] = Tk; sp[4][pidx] = Dv;
+    sp[5][pidx] = __int_as_float(fin);
+  }
+  const int wave_end = __builtin_amdgcn_readfirstlane(wave_max_i(my_end));
+  const float agm = prm.alpha_grad_max;
+  const float x0f = (float)(tx * K::kTile) + 0.5f, y0f = (float)(ty * K::kTile) + 0.5f;
+  __builtin_amdgcn_wave_barrier();
+  for (int e_hi = wave_end - 1; e_hi >= range.x; e_hi -= 64) {
+    const int e = e_hi - lane;
+    const bool active = e >= range.x;
+    const unsigned gi = active ? min((unsigned)ids[e], max_id) : 0u;
+    const float4* rp = reinterpret_cast<const float4*>(records + (size_t)gi * kRecFloats);
+    const float4 ra4 = rp[0], rb4 = rp[1], rc4 = rp[2], rd4 = rp[3];
+    const float gx = ra4.x, gy = ra4.y, cx = ra4.z, cy = ra4.w, cz = rb4.x, cr = rb4.z, cg = rb4.w, cb = rc4.x;
+    const float nmid = active ? rd4.x : -1.f, kmul = rd4.y, qx = rd4.z, qz = rd4.w;    // nmid < 0: never valid
+    const float qyn = cy * kNegLog2e;
+    float M0 = 0.f, X0 = 0.f, Y0 = 0.f, XX = 0.f, XY = 0.f, YY = 0.f, q_r = 0.f, q_g = 0.f, q_b = 0.f;
+    bool touched = false;
+    float Tp = 0.f, Dp = 0.f;                                  // the pipeline registers of this lane
+    asm volatile("" ::: "memory");
+#pragma unroll 1
+    for (int st = 0; st < 256 + 63; ++st) {
+      const int feed = min(st, 255);
+      Tp = dpp_wave_shr1(sp[3][feed], Tp);
+      Dp = dpp_wave_shr1(sp[4][feed], Dp);
+      const int pidx = st - lane;
+      const bool inp = (unsigned)pidx < 256u;
+      const int pc = inp ? pidx : 0;
+      const float vr = sp[0][pc], vg = sp[1][pc], vb = sp[2][pc];
+      const int fin = __float_as_int(sp[5][pc]);
+      const float dx = gx - (x0f + (float)(pc & 15)), dy = gy - (y0f + (float)(pc >> 4));
+      // the forward's validity expression, operand for operand (raster.hip blend_entry)
+      const float hx = fmaf(qx * dx, dx, nmid), bx = qyn * dx;
+      const float u = fmaf(dy, fmaf(qz, dy, bx), hx);
+      const bool hit = inp && (e < fin) && (fabsf(u) <= nmid);
+      const float ov = kmul * __builtin_amdgcn_exp2f(u);
+      const float alpha = hit ? fminf(K::kAlphaMax, ov) : 0.f;
+      const float ovm = (hit && ov <= agm) ? ov : 0.f;
+      const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+      Tp *= ra;
+      const float fac = alpha * Tp;
+      q_r = fmaf(fac, vr, q_r); q_g = fmaf(fac, vg, q_g); q_b = fmaf(fac, vb, q_b);
+      const float cv = fmaf(cb, vb, fmaf(cg, vg, cr * vr));
+      const float v_al = fmaf(Tp, cv, -(ra * Dp));
+      Dp = fmaf(fac, cv, Dp);
+      const float v_sigma = -ovm * v_al;
+      const float vsx = v_sigma * dx, vsy = v_sigma * dy;
+      M0 += v_sigma; X0 += vsx; Y0 += vsy;
+      XX = fmaf(vsx, dx, XX); XY = fmaf(vsx, dy, XY); YY = fmaf(vsy, dy, YY);
+      touched |= hit;
+      if (lane == 63 && inp) { sp[3][pidx] = Tp; sp[4][pidx] = Dp; }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (active && touched) {
+      const size_t slot = (size_t)(unsigned)eids[e];
+      float4* dst = reinterpret_cast<float4*>(tuples + slot * kGradFloats);
+      dst[0] = make_float4(fmaf(cx, X0, cy * Y0), fmaf(cy, X0, cz * Y0), 0.5f * XX, XY);
+      dst[1] = make_float4(0.5f * YY, M0, q_r, q_g);
+      dst[2] = make_float4(q_b, 0.f, 0.f, 0.f);
+      flags[slot] = 2;                                          // slot 5: the plain sum of v_sigma
+    }
+  }
+  if (STATE) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pidx = lane + 64 * q;
+      const int x = tx * K::kTile + (pidx & 15), y = ty * K::kTile + (pidx >> 4);
+      if (x < prm.W && y < prm.H) {
+        const size_t pix = ((size_t)s * prm.H + y) * prm.W + x;
+        const float Tfin = out_T[pix];
+        const float va_out = v_alpha ? v_alpha[pix] : 0.f;
+        const float va = Tfin * (va_out - (bgr * sp[0][pidx] + bgg * sp[1][pidx] + bgb * sp[2][pidx]));
+        bwd_T[pix] = sp[3][pidx];
+        bwd_B[pix] = sp[4][pidx] + va;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Segmented sum of the gradient tuples of one depth slice.  The tuples of slice Gaussian j occupy
 // [cum[j], cum[j]+counts[j]) (emission order); flags mark the entries the backward actually touched.
 // A wave owns 64 Gaussians: short segments are summed by their own lane, long ones (near Gaussians
@@ -729,6 +873,16 @@ GS_EXPORT int gs_rasterize_bwd_slice(const float* records, const int* sorted_val
   // scalar-cache kernels: record index per sorted entry = sorted_ids, or sorted_vals itself when it holds Gaussian ids
   const int* ids = sorted_ids ? sorted_ids : (gi_of_e ? nullptr : sorted_vals);
   const unsigned max_id = (unsigned)(n_records > 0 ? n_records - 1 : 0);
+  if (variant == 1024 && n_records > 0 && ids && tup) {
+    // the splat-parallel formulation (measurement only: see raster_bwd_splat_kernel)
+    if (bwd_T && bwd_B)
+      hipLaunchKernelGGL((raster_bwd_splat_kernel<true>), dim3(blocks), dim3(256), 0, st, prm, ids, sorted_vals, records,
+                         max_id, out_T, final_idx, v_img, v_alpha, blocks, bwd_T, bwd_B, tuples, flags);
+    else
+      hipLaunchKernelGGL((raster_bwd_splat_kernel<false>), dim3(blocks), dim3(256), 0, st, prm, ids, sorted_vals, records,
+                         max_id, out_T, final_idx, v_img, v_alpha, blocks, (float*)nullptr, (float*)nullptr, tuples, flags);
+    return gs_launch_status();
+  }
   if (variant == 0 && n_records > 0 && ids) {
     if (tup) {
       if (bwd_T && bwd_B)

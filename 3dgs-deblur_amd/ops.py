@@ -212,8 +212,14 @@ def _proj_grad_flags() -> int:
     return (UPSTREAM_GRADS & 1) | (0 if NEEDLE_HP else 8)
 
 
+# measurement only (round 6): 1 = the compositing backward in its splat-parallel formulation
+# (csrc/raster_bwd.hip raster_bwd_splat_kernel: lane = list entry, pixels streamed through the wave) instead of the
+# tile-per-wave kernel.  Same gradients up to summation order; 3-4x slower (profiles/r06_bwd_splat_parallel.md).
+BWD_SPLAT = int(os.environ.get("GSD_BWD_SPLAT", "0"))
+
+
 def _bwd_variant() -> int:
-    return 256 if (UPSTREAM_GRADS & 4) else 0
+    return (256 if (UPSTREAM_GRADS & 4) else 0) | (1024 if BWD_SPLAT else 0)
 # per-slice emitted intersection counts of the last frame: ints, or 1-element device tensors that are only read back
 # when somebody asks (module attribute `last_slice_intersects`, see __getattr__ below) — the frame itself never waits
 _slice_totals = []

@@ -2037,8 +2037,10 @@ def test_native_frame_orchestration_equals_python_orchestration(gs, dev, case):
         assert len(a[6]) >= 2
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     for k in a[4]:
-        if k in ("lin", "ang", "V"):
-            # the viewmat gradient is summed over the Gaussians with fp32 atomics (order differs run to run)
+        if k in ("lin", "ang", "V") or case.startswith("exact_rolling_shutter"):
+            # camera-level tensors: two orchestrations, two block structures of the ordered sum; exact rolling shutter
+            # (round 6): the library's culled lists hold fewer tuples per Gaussian than the twin's box lists, so the
+            # segmented tuple sum adds the SAME non-zero tuples in another order
             assert rel_max(a[4][k].cpu(), b[4][k].cpu()) < 1e-4, k
         else:
             assert torch.equal(a[4][k], b[4][k]), k

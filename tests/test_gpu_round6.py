@@ -486,3 +486,46 @@ def test_bench_runs_every_exchange_mode_over_rccl_at_world_1(dev):
         assert c["per_rank"] and c["per_rank"][0]["readback"]["local_rank"] == 0 and c["rccl_version"]
         out[mode] = (line["exchange_ms"], line["ms_per_step"], c["per_rank"][0]["gaussians_with_gradient"])
     print("exchange modes over RCCL at world 1 (exchange_ms, ms_per_step, rows with a gradient):", out)
+
+
+# --------------------------------------------------------------------------- #
+# the splat-parallel backward (built and measured — a negative, kept selectable)
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("base,R", [(512, 1), (24, 1), (48, 3)])
+def test_splat_parallel_backward_gives_the_same_gradients(gs, dev, base, R):
+    """csrc/raster_bwd.hip raster_bwd_splat_kernel (lane = list entry of a 64-entry chunk, the tile's pixels streamed
+    through the wave, a lane accumulates its entry's sums in registers) against the tile-per-wave kernel: same image
+    (the forward is untouched), every gradient equal up to fp32 summation order — one slice, many slices (the
+    reverse-traversal state goes through HBM between them), rolling-shutter bands."""
+    from gsdeblur_amd import ops
+    n, W, H, S = 40000, 208, 176, 2
+    sc = to_dev(gs.data.synthetic_scene(n, W, H, seed=41, scale_mult=3.0), dev)
+    times, _, _ = gs.subpose_schedule(S, 1 / 60, R, 1 / 30 if R > 1 else 0.0)
+    tt = torch.tensor(times, device=dev)
+    g = torch.Generator().manual_seed(8)
+    wt, wa = torch.rand(H, W, 3, generator=g).to(dev), torch.rand(S, H, W, generator=g).to(dev)
+    saved = (ops.BWD_SPLAT, ops.SLICE_BASE)
+    res = []
+    try:
+        ops.SLICE_BASE = base
+        for splat in (1, 0):
+            ops.BWD_SPLAT = splat
+            p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+            V = sc["viewmat"].clone().requires_grad_(True)
+            vms = gs.subpose_viewmats(V, sc["lin_vel"] * 5, sc["ang_vel"] * 3, tt)
+            rgb, alphas, _ = gs.render_combined(p["means"], p["log_scales"], p["quats"], p["opacity_logits"], p["sh"], vms, None,
+                                                S, R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2, min_rgb_level=10.0,
+                                                raw_params=True, hints=ops.FrameHints())
+            ((rgb * wt).sum() + (alphas * wa).sum()).backward()
+            res.append((rgb.detach().clone(), {k: v.grad.clone() for k, v in p.items()}, V.grad.clone(),
+                        len([v for v in ops.last_slice_intersects if int(v) > 0])))
+    finally:
+        ops.BWD_SPLAT, ops.SLICE_BASE = saved
+    a, b = res
+    print(f"splat-parallel backward, base {base} R={R}: slices {a[3]}")
+    assert torch.equal(a[0], b[0]) and a[3] == b[3] and (a[3] >= 2 or base == 512)
+    for k in a[1]:
+        ga, gb = a[1][k], b[1][k]
+        assert float(gb.abs().max()) > 0
+        assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max()), (k, float((ga - gb).abs().max()), float(gb.abs().max()))
+    assert float((a[2] - b[2]).abs().max()) <= 1e-4 * float(b[2].abs().max())

@@ -28,6 +28,23 @@ for step in "$@"; do
         GSD_DEPTH_SELECT=$sel timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --gaussians 2000000 --subposes 5 --rs-bands 2 > $OUT/c4_s${sel}.log 2>&1; line "config4 sel=$sel" $OUT/c4_s${sel}.log | tee -a $S
         GSD_DEPTH_SELECT=$sel timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --gaussians 5000000 --width 3840 --height 2160 --subposes 10 > $OUT/c5_s${sel}.log 2>&1; line "config5 sel=$sel" $OUT/c5_s${sel}.log | tee -a $S
       done ;;
+    splat_ab)
+      # the splat-parallel backward (GSD_BWD_SPLAT=1) against the tile-per-wave kernel, headline and fitted-model-like scene
+      for sc in survey trained; do for v in 0 1; do
+        GSD_BWD_SPLAT=$v timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --scene $sc > $OUT/splat${v}_$sc.log 2>&1; line "$sc splat=$v" $OUT/splat${v}_$sc.log | tee -a $S
+      done; done
+      R=${GRAFT_REPO_ROOT:-$(pwd)}
+      (cd /tmp && GSD_BWD_SPLAT=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_splat -o trace -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-view-sweep --scene trained) > $OUT/prof_splat.log 2>&1
+      for f in $(find $OUT/prof_splat -name "*kernel_stats*.csv" | head -1); do cp $f $OUT/kernel_stats_splat_trained.csv; head -8 $f | cut -c1-220 | tee -a $S; done
+      rm -rf $OUT/prof_splat/*/*kernel_trace* 2>/dev/null ;;
+    nored_ab)
+      # upper bound of ANY rewrite of the backward's per-entry reduction: a build whose bwd_entry computes the nine sums
+      # and reduces / stores nothing (tools/patches/bwd_no_reduction.json; gradients are wrong, times are the point)
+      python tools/ab_patch.py tools/patches/bwd_no_reduction.json /tmp/libgsd_nored.so > $OUT/nored_build.log 2>&1 || { tail -3 $OUT/nored_build.log | tee -a $S; }
+      for sc in survey trained; do for v in 1 2; do
+        timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --scene $sc > $OUT/nored_base${v}_$sc.log 2>&1; line "$sc base$v" $OUT/nored_base${v}_$sc.log | tee -a $S
+        GSD_LIB_PATH=/tmp/libgsd_nored.so timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --scene $sc > $OUT/nored_alt${v}_$sc.log 2>&1; line "$sc no-reduction$v" $OUT/nored_alt${v}_$sc.log | tee -a $S
+      done; done ;;
     *) rest+=("$step") ;;
   esac
 done
