@@ -362,6 +362,9 @@ class Rasterized:
     final_T: torch.Tensor    # [H,W]
     final_idx: torch.Tensor  # [H,W] int32: one past the last contributing sorted entry (tile start if none)
     fragile: torch.Tensor    # [H,W] bool: a threshold decision was within rounding of flipping
+    # [2,H,W] float: how deep inside its band the pixel's closest decision sits, as a fraction of the band — row 0 the
+    # alpha = 1/255 decisions, row 1 the T = 1e-4 decisions; < 1 <=> flagged by that criterion (tools/fragile_histogram.py)
+    margin: Optional[torch.Tensor] = None
 
 
 def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.ndarray, tile_bins: np.ndarray,
@@ -381,6 +384,7 @@ def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.nda
     bg = torch.zeros(3, dtype=dt) if background is None else background.to(dt)
     out_idx = torch.zeros(H, W, dtype=torch.int32)
     frag = torch.zeros(H, W, dtype=torch.bool)
+    margin = torch.full((2, H, W), float("inf"), dtype=torch.float32)
     row_imgs, row_Ts = [], []
     for ty in range(tiles_y):
         y_lo, y_hi = ty * TILE, min((ty + 1) * TILE, H)
@@ -443,6 +447,11 @@ def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.nda
                 band_T = FRAGILE_T_FLOOR + FRAGILE_T_GAIN * torch.sqrt(torch.cumsum(amp * amp, dim=0))
                 f2 = (valid & reach & ((Tincl / T_MIN - 1.0).abs() < band_T)).any(dim=0)
                 f3 = (reach & (sigma.abs() < 1e-7) & (sigma != 0)).any(dim=0)
+                inf_ = torch.full_like(alpha, float("inf"))
+                m1 = torch.where(reach, (alpha / ALPHA_MIN - 1.0).abs() / FRAGILE_ALPHA_BAND, inf_).min(dim=0).values
+                m2 = torch.where(valid & reach, (Tincl / T_MIN - 1.0).abs() / band_T, inf_).min(dim=0).values
+                margin[0, y_lo:y_hi, x_lo:x_hi] = m1.reshape(hh, ww).float()
+                margin[1, y_lo:y_hi, x_lo:x_hi] = m2.reshape(hh, ww).float()
             tile_imgs.append(C.reshape(hh, ww, 3))
             tile_Ts.append(Tfin.reshape(hh, ww))
             out_idx[y_lo:y_hi, x_lo:x_hi] = last.reshape(hh, ww).to(torch.int32)
@@ -451,7 +460,7 @@ def rasterize_sorted(xys, conics, colors, opacities, gaussian_ids_sorted: np.nda
         row_Ts.append(torch.cat(tile_Ts, dim=1))
     img = torch.cat(row_imgs, dim=0)
     Tm = torch.cat(row_Ts, dim=0)
-    return Rasterized(img=img, alpha=1.0 - Tm, final_T=Tm, final_idx=out_idx, fragile=frag)
+    return Rasterized(img=img, alpha=1.0 - Tm, final_T=Tm, final_idx=out_idx, fragile=frag, margin=margin)
 
 
 def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
