@@ -722,11 +722,21 @@ def _baseline_config_vs_oracle(gs, oracle, dev, tag, S, R, W, H, n, mult, up):
         q["lin_vel"], q["ang_vel"], background=bg.double(), return_parts=True)
     good = ~frag
     check_fragile(frag, f"baseline {tag}")
+    # round 6: the frame-level mask is the UNION over the S * R sub-poses — a pixel of the averaged
+    # image is fragile when any sample's is — which is what makes the small multi-sample scenes' shares 1.7-3.7 %; a
+    # sample image is only compared where ITS OWN sub-poses are fragile (0.2-0.4 % each: profiles/r06_fragile_histogram.txt)
+    _, samp_of, _ = O.subpose_times(S, et, R, rt)
+    frag_s = torch.zeros(S, H, W, dtype=torch.bool)
+    for pi, part in enumerate(parts):
+        frag_s[samp_of[pi]] |= part[4].fragile
+    per_sample = float(frag_s.float().mean())
+    print(f"[fragile baseline {tag}] per sample image {per_sample:.5f} (frame-level union {float(frag.float().mean()):.5f})")
+    assert per_sample < 0.01, per_sample
     # the loss ignores the fragile pixels on both sides (a flipped threshold there changes the gradient by O(1))
     wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(5)) * good[..., None]
     (ref * wt.double()).sum().backward()
     out, alpha, samples, vms, p, radii = _run_full(gs, O, dev, sc, H, W, S, R, et, rt, gamma, mlevel, 3, bg, wt)
-    assert (samples.detach().cpu().double() - ref_samples)[:, good].abs().max().item() < IMG_ATOL
+    assert (samples.detach().cpu().double() - ref_samples)[~frag_s].abs().max().item() < IMG_ATOL
     assert (out.detach().cpu().double() - ref.detach())[good].abs().max().item() < 5e-4
     worst = {}
     for k in names:
