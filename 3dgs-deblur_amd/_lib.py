@@ -80,6 +80,7 @@ _SIGS = {
     "gs_dp_pack_masked_rows": [_I, _P, _P, _I, _P, _I, _P, _P, _P, _P],
     "gs_dp_scatter_add_payload": [_I, _P, _I, _P, _P, _F, _P],
     "gs_slice_project_records": [_I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P],
+    "gs_project_records": [_I, _I, _P, _I, _I, _P, _P],
     "gs_frame_forward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P],
     "gs_frame_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _L, _P],
     "gs_frame_profile_enable": [ctypes.c_uint],

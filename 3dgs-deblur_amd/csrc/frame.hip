@@ -501,6 +501,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   long long open_before = (long long)S * T;                          // tiles a compositor launch visits
   std::vector<int> beg_s, pre_s;
   int slice_no = 0;                                                  // issued-slice counter over both phases
+  bool lazy_done = false;                                            // lazy records: every pair's record exists by now
   for (int phase = 0; phase < 2; ++phase) {
   long long open_left = 0;                                           // tiles the phase's last compositor left open
   for (int k = 0, k1 = 0; k < K; k = k1, ++slice_no) {
@@ -543,8 +544,16 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
       const long long ws_b = gs_scan_workspace_bytes(n_k);
       char* ws = A.take<char>(ws_b);
       if (!A.ok) { state->arena_required = 2 * A.off; return GS_ERR_WORKSPACE; }
-      if (lazy)
-        CHECK(gs_slice_project_records((int)n_k, P, N, beg_s.data(), pre_s.data(), sorted_gi, lazy, H, W, records, st));
+      if (lazy && !lazy_done) {
+        // lazy records: the FIRST issued slice projects its own pairs (tens of thousands, by gathers); a frame that goes
+        // on projects everything that is left in one coalesced pass of the eager kernel (round 6)
+        if (slice_no == 0)
+          CHECK(gs_slice_project_records((int)n_k, P, N, beg_s.data(), pre_s.data(), sorted_gi, lazy, H, W, records, st));
+        else {
+          CHECK(gs_project_records(P, N, lazy, H, W, records, st));
+          lazy_done = true;
+        }
+      }
       if (rs_exact)
         // round 6: the swept alpha >= 1/255 ellipse instead of the whole swept box (the box lists held ~3x the entries a
         // sample's pixels can blend: every one of them cost the compositors a full four-pixel evaluation)

@@ -306,6 +306,7 @@ struct FusedParams {
   // projects the records of the Gaussians a depth slice actually holds (gs_slice_project_records, same arithmetic):
   // the benchmark scene writes 4 M records (256 MB of the kernel's 314 MB) and its one slice reads 55 k of them.
   int no_records;
+  int records_only;  // 1 (round 6, gs_project_records): write the records and NOTHING else (keys, counts and radii exist already)
   // > 1: sub-pose p = s * rs_bands + r only ever composites the tile rows of rolling-shutter band r
   // ([r * tiles_y / R, (r + 1) * tiles_y / R), the formula of ops._band_edges): a pair whose tile box misses its band's
   // rows is culled HERE (culled depth key, no tile count, no record) instead of being keyed, depth-sorted, scanned and
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
       float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       r[0] = z; r[1] = z; r[2] = z; r[3] = z;
     }
+    if (fp.records_only) continue;
     depth_keys[idx] = ok ? (unsigned)__float_as_int(o.depth) : 0xFFFFFFFFu;
     ntiles[idx] = ok ? o.ntiles : 0;
     if (radii) radii[idx] = radius_out;
@@ -1155,6 +1157,7 @@ static inline FusedParams make_fused(int N, int P, const float* means, const flo
   fp.defer_color = defer_color & 1;
   fp.skip_culled = (defer_color >> 1) & 1;
   fp.no_records = (defer_color >> 4) & 1;
+  fp.records_only = 0;
   fp.rs_bands = (defer_color & 4) ? ((defer_color >> 8) & 0xFFFF) : 0;
   fp.in = make_intrin(fx, fy, cx, cy, H, W, clip);
   fp.pixvel = 0; fp.twist = nullptr; fp.times = nullptr; fp.flags = 0; fp.rs_half = 0.f; fp.pix_vel_out = nullptr;
@@ -1204,6 +1207,24 @@ GS_EXPORT int gs_slice_project_records(int n_slice, int P, int N, const int* sli
   fp.act = in->param_flags;
   hipLaunchKernelGGL(slice_records_kernel, dim3((n_slice + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_slice, sd,
                      sorted_gi, fp, records);
+  return gs_launch_status();
+}
+
+// The records of ALL pairs of a frame projected with defer_color bit 4, in one coalesced pass of the eager kernel (which
+// writes nothing but records here: the frame's keys, counts and radii exist and the keys may be consumed already).  A
+// lazy frame that goes beyond its first depth slice calls this once instead of projecting slice after slice by gathers
+// (round 6: a view that looks past the scene's edge walks every slice of its plan, and 4 M gathered pairs cost 0.6 ms
+// where this pass costs 0.08).  Rows bit-identical to gs_project_fused_fwd's and to gs_slice_project_records'.
+GS_EXPORT int gs_project_records(int P, int N, const gs_project_inputs* in, int H, int W, float* records, void* stream) {
+  if (P <= 0 || N <= 0 || !in || !records) return GS_ERR_INVALID;
+  if (!in->means || !in->scales || !in->quats || !in->opacities || !in->viewmats) return GS_ERR_INVALID;
+  FusedParams fp = make_fused(N, P, in->means, in->scales, in->glob_scale, in->quats, in->opacities, nullptr, 1, 0,
+                              in->viewmats, in->fx, in->fy, in->cx, in->cy, H, W, in->clip_thresh, in->antialiased,
+                              (in->defer_color | 1 | 2) & ~16);
+  fp.act = in->param_flags;
+  fp.records_only = 1;
+  hipLaunchKernelGGL((project_fused_fwd_kernel<16, true>), dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, fp,
+                     records, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr);
   return gs_launch_status();
 }
 

@@ -527,6 +527,10 @@ typedef struct gs_project_inputs {
 int gs_slice_project_records(int n_slice, int P, int N, const int* slice_begin, const int* slice_prefix,
                              const unsigned* sorted_gi, const gs_project_inputs* in, int img_height, int img_width,
                              float* records, void* stream);
+/* the records of ALL pairs of such a frame in one coalesced pass (nothing but records is written); gs_frame_forward calls
+ * it once when a lazy frame goes beyond its first depth slice */
+int gs_project_records(int P, int N, const struct gs_project_inputs* in, int img_height, int img_width, float* records,
+                       void* stream);
 
 /* ---- one frame's depth-sliced pipeline issued by the library itself (csrc/frame.hip) -------------------------------
  * What the fork's Python layer does between project_gaussians and the returned image — binning, sorting and compositing
