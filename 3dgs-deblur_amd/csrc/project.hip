@@ -465,9 +465,17 @@ __global__ __launch_bounds__(256) void project_fused_fwd_kernel(FusedParams fp, 
       // (all four 16-byte stores of the 64-byte record: leaving the last one out — or non-temporal stores — made this
       //  kernel SLOWER, 0.107 -> 0.137 / 0.283 ms on the headline; visit r4_v4)
       r[0] = make_float4(o.x, o.y, o.conic_x, o.conic_y);
-      r[1] = make_float4(o.conic_z, op, cr, cg);
-      r[2] = make_float4(cb, o.depth, __int_as_float(o.tmin_x | (o.tmin_y << 16)),
-                         __int_as_float(o.tmax_x | (o.tmax_y << 16)));
+      if (fp.records_only) {
+        // the rows of an earlier depth slice exist already and carry their deferred COLOUR (gs_slice_colors): everything
+        // but the three colour floats is written (same values), those are left as they are
+        float* rf = reinterpret_cast<float*>(r);
+        rf[4] = o.conic_z; rf[5] = op; rf[9] = o.depth;
+        rf[10] = __int_as_float(o.tmin_x | (o.tmin_y << 16)); rf[11] = __int_as_float(o.tmax_x | (o.tmax_y << 16));
+      } else {
+        r[1] = make_float4(o.conic_z, op, cr, cg);
+        r[2] = make_float4(cb, o.depth, __int_as_float(o.tmin_x | (o.tmin_y << 16)),
+                           __int_as_float(o.tmax_x | (o.tmax_y << 16)));
+      }
       r[3] = make_float4(aux[0], aux[1], aux[2], aux[3]);
     } else if (!fp.skip_culled) {
       // (a fifth of the benchmark scene's pairs, nine in ten of a band-aware rolling-shutter frame's: 64 bytes each that
