@@ -166,8 +166,9 @@ def readback_mode() -> dict:
             "local_rank": int(os.environ.get("LOCAL_RANK", "0") or 0),
             "local_world": int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1),
             "forced": "GSD_FRAME_POLL" in os.environ}
-# widest radix digit of the compacting depth pre-sort: 8 -> 4 passes of 8 bits, 11 -> 3 passes of 11/10/10 bits
-DEPTH_SORT_DIGIT = int(os.environ.get("GSD_DEPTH_SORT_DIGIT", "8"))
+# widest radix digit of the compacting depth pre-sort: 8 -> 4 passes of 8 bits (11 -> 3 passes of 11/10/10 bits was measured
+# slower at this pipeline's sizes and lost its environment switch in round 6; the tests still drive both through here)
+DEPTH_SORT_DIGIT = 8
 # Gradient conventions (SURVEY App. A "Backward"), bit mask: three places where upstream gsplat 0.1.11's
 # backward, as recollected, is not the derivative of its forward, each a straight-through rule: 1 = back-propagate
 # through the fov clamp of x/z, y/z as if inactive; 2 = quaternion gradient w.r.t. the (assumed unit) quaternion, without

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box visit, parametrised (replaces the round-3 one-off recipes).  Usage, from the repo root on the GPU box:
 #   bash tools/gpu_visit.sh <tag> [steps...]      steps: suite | tests:<pytest -k expr> | smoke | bench | benchq | ab:<ENV=V,...>
-#                                                        | prof | pmc | prof_trained | prof_exchange | motions | fuzz | configs
+#                                                        | prof | pmc | pmc_trained | prof_trained | prof_exchange | motions | fuzz | configs
 # Everything lands in gpurun_out/<tag>/; a summary is printed at the end.
 set -u
 TAG=${1:-visit}; shift || true
@@ -114,7 +114,16 @@ PY
         tail -1 $OUT/pmc_$t.log | cut -c1-200 | tee -a $S
       done
       python tools/pmc_summary.py $OUT 2>&1 | tail -40 | tee -a $S
-      python tools/make_traffic.py $OUT "round 5 $TAG" > $OUT/traffic.json 2>/dev/null; head -c 600 $OUT/traffic.json | tee -a $S ;;
+      python tools/make_traffic.py $OUT "round 6 $TAG" > $OUT/traffic.json 2>/dev/null; head -c 600 $OUT/traffic.json | tee -a $S ;;
+    pmc_trained)
+      # the same three --pmc passes on the fitted-model-like scene (rows of the settled single-slice frames: <false, 1>)
+      for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR"; do
+        t=$(echo $pmc | cut -d' ' -f1)
+        (cd /tmp && timeout 900 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $R/$OUT/pmct_$t -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-view-sweep --scene trained) > $OUT/pmct_$t.log 2>&1
+        tail -1 $OUT/pmct_$t.log | cut -c1-200 | tee -a $S
+      done
+      mkdir -p $OUT/trained && for t in FETCH_SIZE WRITE_SIZE SQ_WAVES; do rm -rf $OUT/trained/pmc_$t; cp -r $OUT/pmct_$t $OUT/trained/pmc_$t; done
+      python tools/pmc_summary.py $OUT/trained 2>&1 | tail -40 | tee $OUT/pmc_trained_summary.txt | tee -a $S ;;
     *) echo "unknown step $step" | tee -a $S ;;
   esac
 done
