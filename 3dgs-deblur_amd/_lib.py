@@ -44,7 +44,7 @@ _SIGS = {
     "gs_segmented_sort_compact_u32": [_L, _L, _P, _P, _P, _P, _I, _I, _I, ctypes.c_uint, _P, _P, _P, _P, _L,
                                       ctypes.POINTER(_I), _P],
     "gs_segmented_sort_select_u32": [_L, _L, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_uint, _P, _P, _P, _P, _P, _P, _L,
-                                     ctypes.POINTER(_I), _P],
+                                     ctypes.POINTER(_I), _L, _P],
     "gs_depth_select": [_L, _L, _P, _P, _L, _P, _P, _P, _L, _P],
     "gs_exclusive_scan_segments_u32": [_L, _L, _P, _P, _P, _P, _P, _L, _P],
     "gs_make_depth_keys64": [_L, _I, _P, _P, _P],

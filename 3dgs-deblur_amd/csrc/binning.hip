@@ -604,10 +604,18 @@ static void radix_pass(size_t n, size_t seg_len, const KeyT* kin, const unsigned
                        int shift, unsigned mask, void* ws, size_t hist_bytes, hipStream_t st,
                        const unsigned* gather_src = nullptr, unsigned* gather_out = nullptr,
                        const unsigned* n_dev = nullptr, SegDev sd = SegDev{nullptr, nullptr, nullptr, 0ull, nullptr, nullptr},
-                       const unsigned* p2_in = nullptr, unsigned* p2_out = nullptr, int pack = 0, int pack_bits = 0) {
+                       const unsigned* p2_in = nullptr, unsigned* p2_out = nullptr, int pack = 0, int pack_bits = 0,
+                       unsigned tail_blocks = 0) {
   SegInfo sg;
   unsigned nblk = sort_nblk_seg<KeyT>(n, seg_len, &sg.nblk_seg);
   sg.seg_len = (seg_len == 0 || seg_len >= n) ? n : seg_len;
+  if (tail_blocks && tail_blocks < sg.nblk_seg) {
+    // a pass over the SURVIVORS of a compacting sort whose caller bounds them (gs_segmented_sort_select_u32 tail_cap): the
+    // grids, the [digit][block] histogram and its scan cover tail_blocks blocks per segment instead of the capacity's
+    // (a selection of 11 k pairs per sub-pose sat in 245 blocks' worth of launches: 32 us per pass, all of it latency)
+    nblk = nblk / sg.nblk_seg * tail_blocks;
+    sg.nblk_seg = tail_blocks;
+  }
   unsigned* ghist = reinterpret_cast<unsigned*>(ws);
   {
     size_t hn = ((size_t)1 << BITS) * nblk;
@@ -643,7 +651,7 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
                       const unsigned* n_dev = nullptr, unsigned* seg_counts = nullptr,
                       unsigned long long skip_key = 0ull, const unsigned* p2_src = nullptr, unsigned* p2_a = nullptr,
                       unsigned* p2_b = nullptr, int* result_p2 = nullptr, const KeyT* k_src = nullptr,
-                      const unsigned* key_lo = nullptr, const unsigned* key_hi = nullptr) {
+                      const unsigned* key_lo = nullptr, const unsigned* key_hi = nullptr, unsigned tail_blocks = 0) {
   // k_src != NULL: the FIRST pass reads its keys from k_src (left intact) instead of k0 — k0 / k1 are both scratch then
   // key_lo / key_hi (compacting sorts only, device arrays per segment, either nullable): see SegDev
   // p2_src != NULL: a second payload travels with every key (p2_src[i] belongs to input element i); pass p writes it
@@ -691,10 +699,10 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
     }
     const KeyT* kin = (p == 0 && k_src) ? k_src : kk[cur];
     switch (tb) {
-      case 8:  radix_pass<KeyT, 8>(n, seg_len, kin, vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, pack, pack_bits); break;
-      case 9:  radix_pass<KeyT, 9>(n, seg_len, kin, vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
-      case 10: radix_pass<KeyT, 10>(n, seg_len, kin, vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
-      default: radix_pass<KeyT, 11>(n, seg_len, kin, vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o); break;
+      case 8:  radix_pass<KeyT, 8>(n, seg_len, kin, vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, pack, pack_bits, p > 0 ? tail_blocks : 0u); break;
+      case 9:  radix_pass<KeyT, 9>(n, seg_len, kin, vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, 0, 0, p > 0 ? tail_blocks : 0u); break;
+      case 10: radix_pass<KeyT, 10>(n, seg_len, kin, vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, 0, 0, p > 0 ? tail_blocks : 0u); break;
+      default: radix_pass<KeyT, 11>(n, seg_len, kin, vin, kk[cur ^ 1], vv[cur ^ 1], shift, mask, ws, hist_bytes, st, gs_, go_, n_dev, sd, p2i, p2o, 0, 0, p > 0 ? tail_blocks : 0u); break;
     }
     shift += w;
     cur ^= 1;
@@ -1894,19 +1902,24 @@ GS_EXPORT int gs_depth_select(long long n, long long seg_len, const unsigned* ke
 // gs_segmented_sort_compact_u32 restricted to a key range per segment: only keys in [key_lo[s], key_hi[s]) (device
 // arrays, either nullable; the skip key is dropped as well) are kept and sorted.  keys_src is read by the first pass and
 // left INTACT; keys0 / keys1 are scratch (n keys each).  Everything else as gs_segmented_sort_compact_u32.
+// tail_cap > 0: the caller PROMISES that no segment keeps more than tail_cap keys — the passes behind the compacting one
+// are then sized for that many (launch-latency bound otherwise); a segment that keeps more comes out WRONG beyond
+// tail_cap: the caller must check seg_counts against it (gs_frame_forward does, and sorts again without the promise).
 GS_EXPORT int gs_segmented_sort_select_u32(long long n, long long seg_len, const unsigned* keys_src, unsigned* keys0,
                                            unsigned* vals0, unsigned* keys1, unsigned* vals1, int begin_bit, int end_bit,
                                            int max_digit_bits, unsigned skip_key, const unsigned* key_lo,
                                            const unsigned* key_hi, unsigned* seg_counts, const unsigned* gather_src,
                                            unsigned* gather_out, void* ws, long long ws_bytes, int* result_buf,
-                                           void* stream) {
-  if (n <= 0 || seg_len <= 0 || n % seg_len != 0 || begin_bit < 0 || end_bit > 32 || !seg_counts || !keys_src)
+                                           long long tail_cap, void* stream) {
+  if (n <= 0 || seg_len <= 0 || n % seg_len != 0 || begin_bit < 0 || end_bit > 32 || !seg_counts || !keys_src ||
+      tail_cap < 0)
     return GS_ERR_INVALID;
   if ((gather_src != nullptr) != (gather_out != nullptr)) return GS_ERR_INVALID;
   return radix_sort<unsigned>((size_t)n, (size_t)seg_len, keys0, vals0, keys1, vals1, 1, begin_bit, end_bit, ws,
                               (size_t)ws_bytes, result_buf, (hipStream_t)stream, max_digit_bits, gather_src,
                               gather_out, nullptr, seg_counts, (unsigned long long)skip_key, nullptr, nullptr, nullptr,
-                              nullptr, keys_src, key_lo, key_hi);
+                              nullptr, keys_src, key_lo, key_hi,
+                              tail_cap > 0 ? (unsigned)((tail_cap + sort_block_keys<unsigned>() - 1) / sort_block_keys<unsigned>()) : 0u);
 }
 
 // sat [P*(tiles_y+1)*(tiles_x+1)]: summed-area table of tiles that are NOT done.

@@ -334,7 +334,9 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
 
   const unsigned* sorted_gi = nullptr;
   // phase 0: everything (or the selection); phase 1: the pairs behind the selection
-  auto presort = [&](int phase) -> int {
+  // tail_cap: promise to the selective sort that no sub-pose keeps more pairs (desc.select_cap, from the last frame's
+  // selection; 0: none) — checked against the counts the plan read-back brings, below
+  auto presort = [&](int phase, long long tail_cap) -> int {
     int res = 0;
     {
       StageScope sc(ST_DEPTH_SORT, st);
@@ -350,7 +352,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
         CHECK(gs_segmented_sort_select_u32(n, N, depth_keys, k0s, v0, k1, v1, 0, 31, digit, 0xFFFFFFFFu,
                                            phase == 0 ? nullptr : thr_dev, phase == 0 ? thr_dev : nullptr, n_live,
                                            reinterpret_cast<const unsigned*>(num_tiles_hit), counts_r, sort_ws, sort_ws_b,
-                                           &res, st));
+                                           &res, phase == 0 ? tail_cap : 0, st));
       }
     }
     sorted_gi = res == 1 ? v1 : v0;
@@ -358,7 +360,8 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
     CHECK(gs_exclusive_scan_segments_u32(n, N, n_live, counts_r, cum, total, scan_ws, scan_ws_b, st));
     return GS_OK;
   };
-  CHECK(presort(0));
+  long long tail_cap = (select && d.select_cap > 0) ? (long long)d.select_cap : 0;
+  CHECK(presort(0, tail_cap));
 
   // ---- slice plan: the ONE read-back every frame needs ---------------------------------------------------------------
   // word 0 of the pinned buffer is the sequence word of the polled read-backs, the payload follows
@@ -442,6 +445,18 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
     return GS_OK;
   };
   CHECK(make_plan(0));
+  if (tail_cap > 0) {
+    // the promise is checked: a sub-pose that selected more pairs than the tail passes were sized for is sorted wrong
+    // behind tail_cap — sort and plan again without it (one wasted sort; the caller learns the larger count below)
+    long long most = 0;
+    for (int p = 0; p < P; ++p) most = std::max(most, NV[p]);
+    if (most > tail_cap) {
+      state->select_overflow = 1;
+      CHECK(presort(0, 0));
+      CHECK(make_plan(0));
+    }
+  }
+  for (int p = 0; p < P; ++p) state->max_selected = std::max<long long>(state->max_selected, select ? NV[p] : 0);
   state->n_total = n_total;
   state->depth_select = select ? 1 : 0;
   state->open_after_first = -1.f;
@@ -687,7 +702,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   state->depth_select = 2;
   rest_behind = false;
   span = 1;
-  CHECK(presort(1));
+  CHECK(presort(1, 0));
   CHECK(make_plan(1));
   }
   state->n_slices = n_out;

@@ -52,13 +52,15 @@ class FrameHints:
     so two scenes of one shape never fight over one hint.  Thread-safe."""
 
     __slots__ = ("mult", "age", "arena_bytes", "arena_retries", "frames", "box_share", "last_slices", "select_misses",
-                 "_recent", "_lock")
+                 "select_cap", "select_overflows", "_recent", "_lock")
 
     def __init__(self):
         self.mult, self.age, self.arena_bytes, self.arena_retries, self.frames = 1, 0, 0, 0, 0
         self.box_share = None           # share of the last frame's bounding-box pairs its issued slices held (None: no frame yet)
         self.last_slices = None         # slices the last frame issued (None: no frame yet)
         self.select_misses = 0          # frames whose nearest-first selection had to be followed by the full sort
+        self.select_cap = 0             # bound on a sub-pose's selected pairs handed to the next frame (0: none yet)
+        self.select_overflows = 0       # frames whose selection outgrew it (sorted twice)
         self._recent = []               # (issued slices, budget multiplier, arena retries) of the last frames
         self._lock = threading.Lock()
 
@@ -66,7 +68,7 @@ class FrameHints:
         return SLICE_BASE * (self.mult if SLICE_ADAPT and SLICE_BASE > 0 else 1)
 
     def feedback(self, n_issued: int, retries: int = 0, box_share: Optional[float] = None, select_state: int = 0,
-                 open_after_first: Optional[float] = None) -> None:
+                 open_after_first: Optional[float] = None, max_selected: int = 0, select_overflow: int = 0) -> None:
         """open_after_first: share of the tile lists the frame's first slice left open (gs_frame_state; None: unknown).
         The budget only grows when that slice left at least SLICE_GROW_OPEN of them open — a frame whose tiles mostly do
         not saturate (a fitted model seen through faint splats).  A frame that needed more slices for a FEW tiles (a view
@@ -78,6 +80,12 @@ class FrameHints:
             self.last_slices = int(n_issued)
             if select_state == 2:
                 self.select_misses += 1
+            if max_selected > 0:
+                # what the selective sort's tail passes are sized for next time: the largest selection seen lately, with
+                # slack (a frame that outgrows it sorts twice and raises it)
+                want = int(1.5 * max_selected) + 4096
+                self.select_cap = want if (select_overflow or want > self.select_cap) else max(want, int(0.9 * self.select_cap))
+            self.select_overflows += int(bool(select_overflow))
             if box_share is not None:
                 self.box_share = float(box_share)
             self.arena_retries += retries
@@ -114,7 +122,7 @@ class FrameHints:
     def reset(self) -> None:
         with self._lock:
             self.mult, self.age, self.arena_bytes, self._recent, self.box_share = 1, 0, 0, [], None
-            self.last_slices = None
+            self.last_slices, self.select_cap = None, 0
 
 
 _hints = {}          # default owner: (device, N, P, S, H, W, shared, storage of means3d) -> FrameHints
@@ -509,6 +517,7 @@ class _FrameDesc(ctypes.Structure):
                                                                                      ("combine_min_level", ctypes.c_float),
                                                                                      ("band_clipped", ctypes.c_int),
                                                                                      ("depth_select", ctypes.c_int),
+                                                                                     ("select_cap", ctypes.c_int),
                                                                                      ("sweep_t_min", ctypes.c_float),
                                                                                      ("sweep_t_max", ctypes.c_float),
                                                                                      ("lazy_records", ctypes.c_void_p)]
@@ -530,8 +539,8 @@ class _FrameSlice(ctypes.Structure):
 class _FrameState(ctypes.Structure):
     _fields_ = ([(k, ctypes.c_int) for k in ("n_slices", "P", "N", "S", "R", "H", "W")] +
                 [("rolling_shutter_time", ctypes.c_float), ("shared_list", ctypes.c_int), ("depth_select", ctypes.c_int),
-                 ("open_after_first", ctypes.c_float)] +
-                [(k, ctypes.c_longlong) for k in ("n_total", "arena_used", "arena_required")] +
+                 ("select_overflow", ctypes.c_int), ("open_after_first", ctypes.c_float)] +
+                [(k, ctypes.c_longlong) for k in ("n_total", "max_selected", "arena_used", "arena_required")] +
                 [("slice", _FrameSlice * 16)])
 
 
@@ -704,6 +713,7 @@ def native_frame_forward(records: Tensor, depth_keys: Tensor, num_tiles_hit: Ten
                       float(SLICE_MERGE), float(rs[1]) if rs is not None else 0.0, frame_poll(), int(shared),
                       float(combine[0]) if combine is not None else 1.0, float(combine[1]) if combine is not None else 0.0,
                       int(bool(band_clipped)), int(bool(depth_select and slice_base > 0)),
+                      int(min(hints.select_cap, 2 ** 31 - 1)) if depth_select else 0,
                       float(rs[3][0]) if shared and len(rs) > 3 else 0.0, float(rs[3][1]) if shared and len(rs) > 3 else 0.0,
                       ctypes.addressof(lazy) if lazy is not None else None)
     state = _FrameState()
@@ -1242,7 +1252,8 @@ class _RenderSubposes(Function):
                                                                      any(ctx.needs_input_grad), rs, averaged, hints,
                                                                      bool(defer_flags & 4), lazy)
                     hints.feedback(int(ctx.frame["state"].n_slices), retries, _box_share(ctx.frame["state"]),
-                                   int(ctx.frame["state"].depth_select), float(ctx.frame["state"].open_after_first))
+                                   int(ctx.frame["state"].depth_select), float(ctx.frame["state"].open_after_first),
+                                   int(ctx.frame["state"].max_selected), int(ctx.frame["state"].select_overflow))
                     break
                 except _ArenaTooSmall:
                     retries += 1

@@ -258,7 +258,11 @@ int gs_segmented_sort_select_u32(long long n, long long seg_len, const unsigned*
                                  unsigned* vals0, unsigned* keys1, unsigned* vals1, int begin_bit, int end_bit,
                                  int max_digit_bits, unsigned skip_key, const unsigned* key_lo, const unsigned* key_hi,
                                  unsigned* seg_counts, const unsigned* gather_src, unsigned* gather_out, void* ws,
-                                 long long ws_bytes, int* result_buf /*host*/, void* stream);
+                                 long long ws_bytes, int* result_buf /*host*/,
+                                 long long tail_cap /*0, or a PROMISE that no segment keeps more keys than this: the
+                                                     passes behind the compacting one are sized for it; a segment that
+                                                     keeps more comes out wrong — check seg_counts*/,
+                                 void* stream);
 /* exclusive scan where only the first seg_counts[s] values of every seg_len-long segment are live (the rest count as
  * zero and are never read).  out is defined for the live ranks and at every segment's first rank (the slice plan reads
  * those); behind a segment's live ranks it is unspecified */
@@ -568,6 +572,9 @@ typedef struct gs_frame_desc {
                                 the first slice's budget reaches (gs_depth_select + gs_segmented_sort_select_u32); the
                                 pairs behind them are sorted and planned (budget doubled) only if that slice leaves a
                                 tile open.  Same images bit for bit; for scenes whose frames stop in their first slice */
+  int select_cap;            /* depth_select: 0, or a bound on the pairs a sub-pose's selection holds (what the last frame's did,
+                                with slack): the sort passes over the selection are sized for it instead of for N.  Checked
+                                — a frame that selects more sorts again without it (gs_frame_state.select_overflow) */
   float sweep_t_min, sweep_t_max; /* shared_list: smallest / largest of sample_times (host copies): with planned slices the
                                 lists are culled by the alpha >= 1/255 ellipse swept over [sweep_t_min, sweep_t_max] + the
                                 row times (gs_slice_counts_exact_swept) instead of holding the swept boxes whole */
@@ -586,9 +593,11 @@ typedef struct gs_frame_state {
   int shared_list;           /* copied from the descriptor */
   int depth_select;          /* 0: every visible pair was depth-sorted; 1: only the nearest-first selection; 2: the
                                 selection, and later the pairs behind it (the first slice left tiles open) */
+  int select_overflow;       /* 1: the selection outgrew desc.select_cap and was sorted a second time */
   float open_after_first;    /* share of the (sample, tile) lists the frame's FIRST issued slice left open (its read-back:
                                 0 = every tile stopped within it); -1: the first slice was also the last, nothing was read */
   long long n_total;         /* bounding-box tile intersections of the frame */
+  long long max_selected;    /* depth_select: the most pairs any sub-pose's selection held (0 otherwise) */
   long long arena_used;      /* bytes of the arena the forward occupies (kept alive until the backward ran) */
   long long arena_required;  /* on GS_ERR_WORKSPACE (3): an arena size that holds the frame as far as it is known */
   gs_frame_slice slice[GS_FRAME_MAX_SLICES];

@@ -138,22 +138,25 @@ def test_depth_select_bound_and_selective_sort(gs, dev, P, N, budget, dist):
     assert (int(grand.item()) & 0xFFFFFFFF) == (tot & 0xFFFFFFFF)
     # the selective sort, both sides of the bound
     sort_ws_b = L.gs_segmented_sort_compact_workspace_bytes(n, N, 0, 31, 8)
-    for side in ("below", "behind"):
+    below_most = max(int(((keys[p * N:(p + 1) * N] < int(got_thr[p]))).sum()) for p in range(P))
+    for side in ("below", "below, tail passes sized for the selection", "behind"):
+        # tail_cap: a promise that no segment keeps more keys — the passes behind the compacting one are sized for it
+        tail_cap = below_most + 5 if side.endswith("selection") else 0
         k0, v0, k1, v1, cnt_out = (torch.full((n,), 0x7F7F7F7F, dtype=torch.int32, device=dev) for _ in range(5))
         n_live = torch.zeros(P, dtype=torch.int32, device=dev)
         sws = torch.empty(sort_ws_b, dtype=torch.uint8, device=dev)
         res = ctypes.c_int(0)
-        lo, hi = (None, thr) if side == "below" else (thr, None)
+        lo, hi = (None, thr) if side.startswith("below") else (thr, None)
         _lib.check(L.gs_segmented_sort_select_u32(n, N, _ptr(dk), _ptr(k0), _ptr(v0), _ptr(k1), _ptr(v1), 0, 31, 8,
                                                   0xFFFFFFFF, _ptr(lo), _ptr(hi), _ptr(n_live), _ptr(dw), _ptr(cnt_out),
-                                                  _ptr(sws), sort_ws_b, ctypes.byref(res), _stream()), "sort_select")
+                                                  _ptr(sws), sort_ws_b, ctypes.byref(res), tail_cap, _stream()), "sort_select")
         sk, sv = ((k1, v1) if res.value == 1 else (k0, v0))
         sk, sv, cc, nl = sk.cpu().numpy().view(np.uint32), sv.cpu().numpy(), cnt_out.cpu().numpy(), n_live.cpu().numpy()
         assert np.array_equal(dk.cpu().numpy().view(np.uint32).astype(np.int64), keys)       # source intact
         for p in range(P):
             seg = keys[p * N:(p + 1) * N]
             t = int(got_thr[p])
-            keep = (seg < t) if side == "below" else ((seg >= t) & (seg < 2 ** 31))
+            keep = (seg < t) if side.startswith("below") else ((seg >= t) & (seg < 2 ** 31))
             idx = np.nonzero(keep)[0]
             order = idx[np.argsort(seg[idx], kind="stable")]
             m = order.size
@@ -280,8 +283,15 @@ def test_frame_hints_switch_the_selection_on_and_off(gs, dev):
         assert st0 == 0 and k0 == 1 and h.depth_select()            # first frame: full sort; it stopped in one small slice
         img1, st1, k1 = frame(h)
         assert st1 == 1 and k1 == 1 and torch.equal(img0, img1)      # from now on: the selection
+        assert h.select_cap > 0                                        # the selection's size is remembered ...
         img2, st2, _ = frame(h)
         assert st2 == 1 and torch.equal(img0, img2) and h.select_misses == 0 and h.settled
+        # ... and sizes the next frame's tail passes; a promise that turns out too small is noticed and sorted again
+        h.select_cap = 64
+        img2b, st2b, _ = frame(h)
+        assert st2b == 1 and torch.equal(img0, img2b) and h.select_overflows == 1 and h.select_cap > 64
+        img2c, _, _ = frame(h)
+        assert torch.equal(img0, img2c) and h.select_overflows == 1
         # a budget this scene does not stop within: the selection of the next frame falls short once, then it is off
         ops.SLICE_BASE = 2
         h2 = ops.FrameHints()
