@@ -227,23 +227,6 @@ def _proj_grad_flags() -> int:
 BWD_SPLAT = int(os.environ.get("GSD_BWD_SPLAT", "0"))
 
 
-# The dense gradient outputs of the projection backward (59 floats per Gaussian: 236 MB at 1M) are zero except for the few
-# thousand rows the frame touched.  Rounds 4-5 had the projection backward zero-fill them itself (72 us of its 90 on the
-# headline; 0.23 ms at 2M Gaussians).  1 (default, round 6): the fill runs on a SIDE STREAM while the compositing backward —
-# VALU-bound, it leaves the memory system idle — runs on the caller's stream; the projection backward then waits for the
-# fill's event and writes the touched rows only.  0: the in-kernel fill.  Same bits either way.
-OVERLAP_FILL = int(os.environ.get("GSD_OVERLAP_FILL", "1"))
-_side_streams = {}
-
-
-def _side_stream(dev):
-    key = str(dev)
-    st = _side_streams.get(key)
-    if st is None:
-        st = _side_streams[key] = (torch.cuda.Stream(device=dev), torch.cuda.Event())
-    return st
-
-
 def _bwd_variant() -> int:
     return (256 if (UPSTREAM_GRADS & 4) else 0) | (1024 if BWD_SPLAT else 0)
 # per-slice emitted intersection counts of the last frame: ints, or 1-element device tensors that are only read back
@@ -1363,36 +1346,23 @@ class _RenderSubposes(Function):
             v_records = torch.zeros(P * N, GRAD, device=dev)
             touched = None
 
-        # the dense gradient outputs are carved out of ONE buffer, zero outside the touched rows: filled on a side stream
-        # while the compositing backward runs (OVERLAP_FILL), or by the projection backward itself (grad flag 32)
-        sh_rest = ctx.sh_rest
-        sizes = [3 * N, 3 * N, 4 * N, N] + ([3 * K * N] if sh_rest is None else [3 * N, 3 * (K - 1) * N])
-        shapes = [(N, 3), (N, 3), (N, 4), (N,)] + ([(N, K, 3)] if sh_rest is None else [tuple(sh.shape), (N, K - 1, 3)])
-        flat = torch.empty(sum(sizes), device=dev)
-        fill_event = None
-        if touched is not None and OVERLAP_FILL:
-            main = torch.cuda.current_stream(dev)
-            side, fill_event = _side_stream(dev)
-            side.wait_stream(main)          # the allocator may hand out memory that queued work on `main` still reads
-            with torch.cuda.stream(side):
-                flat.zero_()
-                if ctx.xy_grad_out is not None:
-                    ctx.xy_grad_out.zero_()
-            flat.record_stream(side)
-            fill_event.record(side)
         if ctx.frame is not None:
             native_frame_backward(ctx.frame, records, bg, edges, out_T, v_img, v_al, v_records, touched, combine)
         else:
             ctx.backend.sliced_backward(records, ctx.slices, S, R, H, W, bg, edges, out_T, v_img, v_al, v_records, touched,
                                         combine, ctx.rs)
-        if fill_event is not None:
-            torch.cuda.current_stream(dev).wait_event(fill_event)
+        # the dense gradient outputs are carved out of ONE buffer; with touched flags the projection backward zero-fills
+        # its own outputs (grad flag 32): no fill launches (round 3: one 236 MB fill per step)
+        sh_rest = ctx.sh_rest
+        sizes = [3 * N, 3 * N, 4 * N, N] + ([3 * K * N] if sh_rest is None else [3 * N, 3 * (K - 1) * N])
+        shapes = [(N, 3), (N, 3), (N, 4), (N,)] + ([(N, K, 3)] if sh_rest is None else [tuple(sh.shape), (N, K - 1, 3)])
+        flat = torch.empty(sum(sizes), device=dev)
         outs = [t.view(shape) for t, shape in zip(flat.split(sizes), shapes)]
         v_means, v_scales, v_quats, v_opac, v_sh = outs[:5]
         v_sh_rest = outs[5] if sh_rest is not None else None
         need_v = ctx.needs_input_grad[5]
         xy_out = ctx.xy_grad_out
-        fill_flag = 32 if (touched is not None and fill_event is None) else 0
+        fill_flag = 32 if touched is not None else 0
         pf = ctx.param_flags
         v_lin = v_ang = None
         # scratch of the ordered camera-gradient reduction (the sparse form runs when touched flags exist)
