@@ -45,6 +45,20 @@ for step in "$@"; do
         timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --scene $sc > $OUT/nored_base${v}_$sc.log 2>&1; line "$sc base$v" $OUT/nored_base${v}_$sc.log | tee -a $S
         GSD_LIB_PATH=/tmp/libgsd_nored.so timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --scene $sc > $OUT/nored_alt${v}_$sc.log 2>&1; line "$sc no-reduction$v" $OUT/nored_alt${v}_$sc.log | tee -a $S
       done; done ;;
+    nostore_ab)
+      # how much of the backward's reduction cost is the tuple STORES (36 scattered bytes per touched entry): a build that
+      # reduces in LDS as the product does and stores nothing (tools/patches/bwd_no_tuple_stores.json)
+      python tools/ab_patch.py tools/patches/bwd_no_tuple_stores.json /tmp/libgsd_nostore.so > $OUT/nostore_build.log 2>&1 || { tail -3 $OUT/nostore_build.log | tee -a $S; }
+      for sc in survey trained; do for v in 1 2; do
+        timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --scene $sc > $OUT/nostore_base${v}_$sc.log 2>&1; line "$sc base$v" $OUT/nostore_base${v}_$sc.log | tee -a $S
+        GSD_LIB_PATH=/tmp/libgsd_nostore.so timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --scene $sc > $OUT/nostore_alt${v}_$sc.log 2>&1; line "$sc no-tuple-stores$v" $OUT/nostore_alt${v}_$sc.log | tee -a $S
+      done; done ;;
+    budget_ab)
+      # first-slice budget on the large configurations: does a smaller budget + a second slice pay where the tile sort is big?
+      for base in 512 384 256; do
+        GSD_SLICE_BASE=$base timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --gaussians 5000000 --width 3840 --height 2160 --subposes 10 > $OUT/c5_b$base.log 2>&1; line "config5 base=$base" $OUT/c5_b$base.log | tee -a $S
+        GSD_SLICE_BASE=$base timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --gaussians 2000000 --subposes 5 --rs-bands 2 > $OUT/c4_b$base.log 2>&1; line "config4 base=$base" $OUT/c4_b$base.log | tee -a $S
+      done ;;
     *) rest+=("$step") ;;
   esac
 done
