@@ -38,7 +38,7 @@ KNOBS = ("SLICE_BASE", "EXACT_TILE_CULL", "COMPACT_EMIT", "HIT_MASKS", "GRAD_TUP
 ROUTES = ("SPECULATE", "TILE_SORT_CARRY", "DEPTH_SORT_COMPACT", "DEVICE_SIZES", "PREALLOC_BWD")
 # round 3: half of the trials go through the C++ frame orchestration (gs_frame_forward / gs_frame_backward; it needs the
 # default routes) with slice merging and the polled read-backs drawn at random; the radix passes run in either form
-FRAME = ("NATIVE_FRAME", "SLICE_MERGE", "FRAME_POLL", "LAZY_RECORDS")
+FRAME = ("NATIVE_FRAME", "SLICE_MERGE", "FRAME_POLL", "LAZY_RECORDS", "DEPTH_SELECT")
 saved = {k: getattr(ops, k) for k in KNOBS + ROUTES + FRAME}
 from gsdeblur_amd import _lib  # noqa: E402
 _L = _lib.load()
@@ -83,7 +83,9 @@ for trial in range(trials):
     frame = {"NATIVE_FRAME": int(native), "SLICE_MERGE": rng.choice([0.0, 0.3, 0.75]), "FRAME_POLL": rng.choice([0, 1]),
              # round 5: lazy records (never / always), drawn from a generator of its own so that the older draws — and
              # with them every trial of an earlier seed — stay what they were
-             "LAZY_RECORDS": random.Random(seed * 7919 + trial).choice([0, 2])}
+             "LAZY_RECORDS": random.Random(seed * 7919 + trial).choice([0, 2]),
+             # round 6: nearest-first selection (never / always), its own generator again
+             "DEPTH_SELECT": random.Random(seed * 104729 + trial).choice([0, 2])}
     single_pass = rng.choice([0, 1])      # (round 6: the single-pass sort is gone; the draw stays so that earlier seeds replay)
     rs_time = 0.0
     if pixvel:
@@ -107,7 +109,7 @@ for trial in range(trials):
             for k in ROUTES:
                 setattr(ops, k, saved[k] if plain else routes[k])
             for k in FRAME:
-                setattr(ops, k, (0 if k == "NATIVE_FRAME" else saved[k]) if plain else frame[k])
+                setattr(ops, k, (0 if k in ("NATIVE_FRAME", "DEPTH_SELECT") else saved[k]) if plain else frame[k])
             if plain and rs_time:
                 # exact rolling shutter needs the tuple backward and box lists: its "plain" side is the Python
                 # orchestration with every planned slice folded into one
@@ -188,7 +190,7 @@ for trial in range(trials):
     bad += 0 if ok else 1
     print(f"trial {trial:3d} n={n:6d} {W}x{H} S={S} R={R} mult={mult} base={base} slices={nsl} "
           f"deg={deg} aa={int(aa)} gamma={gamma} routes={''.join(str(routes[k]) for k in ROUTES)} "
-          f"frame={int(native)}/{frame['SLICE_MERGE']}/{frame['FRAME_POLL']}/lazy{frame['LAZY_RECORDS']} sort1p={single_pass} "
+          f"frame={int(native)}/{frame['SLICE_MERGE']}/{frame['FRAME_POLL']}/lazy{frame['LAZY_RECORDS']}/sel{frame['DEPTH_SELECT']} "
           f"{'pixvel rs=%.3f ' % rs_time if pixvel else ''}img_equal={torch.equal(img_f, img_p)} grad_rel={worst:.1e} ({worst_key}){extra} "
           f"{'ok' if ok else 'FAIL'}", flush=True)
 print(f"fuzz: {trials - bad}/{trials} trials ok in {time.time() - t0:.0f} s")
