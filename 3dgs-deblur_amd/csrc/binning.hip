@@ -199,6 +199,36 @@ __global__ __launch_bounds__(256) void scan_apply_fused_kernel(size_t n, const u
   if (total_out && blockIdx.x == last_block && threadIdx.x == 0) *total_out = prefix + total;
 }
 
+// a whole scan in ONE block (round 6): the histogram scans of the selective sort's tail passes hold a few thousand entries
+// (256 digits x a handful of blocks), and two launches at their latency floor for that was 9 us per pass
+constexpr size_t kScanSmallMax = 16384;
+__global__ __launch_bounds__(256) void scan_small_kernel(size_t n, const unsigned* __restrict__ in, unsigned* __restrict__ out,
+                                                         unsigned* __restrict__ total_out) {
+  __shared__ unsigned lds[8];
+  unsigned carry = 0;
+  for (size_t base0 = 0; base0 < n; base0 += kScanBlock) {
+    const size_t base = base0 + (size_t)threadIdx.x * kScanItems;
+    unsigned v[kScanItems];
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      const size_t i = base + k;
+      v[k] = i < n ? in[i] : 0u;
+      s += v[k];
+    }
+    unsigned total;
+    unsigned ex = block_excl_scan(s, total, lds) + carry;      // (in == out: everything of this chunk is read by now)
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+      const size_t i = base + k;
+      if (i < n) out[i] = ex;
+      ex += v[k];
+    }
+    carry += total;
+  }
+  if (total_out && threadIdx.x == 0) *total_out = carry;
+}
+
 static inline size_t scan_ws_bytes(size_t n) {
   size_t nb = (n + kScanBlock - 1) / kScanBlock;
   return (nb + 1) * sizeof(unsigned);
@@ -207,6 +237,10 @@ static inline size_t scan_ws_bytes(size_t n) {
 static int run_scan(size_t n, const unsigned* in, unsigned* out, unsigned* total_out, void* ws, hipStream_t st,
                     DevLen dl = DevLen{nullptr, 1u, 1u}, SegMask sm = SegMask{nullptr, 1}) {
   size_t nb = (n + kScanBlock - 1) / kScanBlock;
+  if (n <= kScanSmallMax && !dl.keys && !sm.cnt) {
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(256), 0, st, n, in, out, total_out);
+    return gs_launch_status();
+  }
   unsigned* bsum = reinterpret_cast<unsigned*>(ws);
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bsum, dl, sm);
   if (nb <= kScanFusedMaxBlocks || dl.keys || sm.cnt) {
