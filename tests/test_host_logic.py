@@ -408,7 +408,9 @@ def test_polled_readbacks_need_two_cores_per_local_rank(gs, monkeypatch):
     monkeypatch.setattr(ops, "FRAME_POLL", 1)
     monkeypatch.setattr(ops, "_host_cores", lambda: 16)
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
-    assert ops.frame_poll() == 1 and ops.readback_mode() == {"poll": True, "host_cores": 16, "local_world": 8, "forced": False}
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert ops.frame_poll() == 1 and ops.readback_mode() == {"poll": True, "host_cores": 16, "local_rank": 3, "local_world": 8,
+                                                            "forced": False}
     monkeypatch.setattr(ops, "_host_cores", lambda: 12)
     assert ops.frame_poll() == 0
     monkeypatch.setenv("GSD_FRAME_POLL", "1")
