@@ -505,7 +505,12 @@ def main():
                       # lazy records: does this scene's next frame project without records, and on what grounds
                       "lazy_records": bool(args.motion == "se3" and (ops.LAZY_RECORDS == 2 or
                                                                        (ops.LAZY_RECORDS and wl.hints.lazy_records()))),
-                      "box_share_of_issued_slices": None if wl.hints.box_share is None else round(wl.hints.box_share, 4)}
+                      "box_share_of_issued_slices": None if wl.hints.box_share is None else round(wl.hints.box_share, 4),
+                      # nearest-first selection: does the next frame rank only the pairs its first slice reaches, how many it
+                      # promises the sort's tail passes, and how often a selection fell short / outgrew the promise
+                      "depth_select": bool(ops.DEPTH_SELECT == 2 or (ops.DEPTH_SELECT and wl.hints.depth_select())),
+                      "select_cap": wl.hints.select_cap, "select_misses": wl.hints.select_misses,
+                      "select_overflows": wl.hints.select_overflows}
     rows_with_grad = wl.rows_with_gradient()
     sweep = None
     if world == 1 and not args.no_view_sweep and args.motion == "se3":
