@@ -209,6 +209,7 @@ def view_sweep(wl, ops, n_views=16, cycles=4, fixed_frames=6):
             else:
                 per_view[i].append(ms)
     retries_all = wl.hints.arena_retries
+    overflows = wl.hints.select_overflows
     wl.viewmat, wl.lin, wl.ang, wl.hints = saved
     flat = [m for v in per_view for m in v]
     ratio = [max(v) / f for v, f in zip(per_view, fixed)]
@@ -228,6 +229,7 @@ def view_sweep(wl, ops, n_views=16, cycles=4, fixed_frames=6):
             "slices_per_frame": {"min": min(slices), "max": max(slices)},
             "lazy_eager_flips": flips([d[0] for d in decisions]), "selection_flips": flips([d[1] for d in decisions]),
             "selection_misses": sum(1 for s_ in select_state if s_ == 2),
+            "selection_outgrew_its_promised_size": overflows,
             "budget_multiplier_history": hist, "arena_retries_first_cycle": retries0,
             "arena_retries_later_cycles": retries_all - retries0,
             "note": "wall clock per frame (synchronize around every step: includes launch latency the back-to-back "
