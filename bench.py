@@ -449,18 +449,27 @@ def main():
     # (they normally have: the headline scene stops after its first slice) — no allocation inside the timed region
     warm_frames = wl.warm_until_settled(args.warmup)
 
+    issue_trace = []
+
     def timed_region(w, k):
         """EXACTLY k steps between barrier + synchronize on both sides -> seconds (this rank)"""
         if world > 1:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        marks = [t0]
         for _ in range(k):
             w.step()
+            marks.append(time.perf_counter())
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier(device_ids=[local_rank])
-        return time.perf_counter() - t0
+        t1 = time.perf_counter()
+        # when the HOST finished issuing each step (a step ends in polled read-backs, so this tracks the device closely):
+        # a stalled attempt shows WHICH step the host lost its time in
+        issue_trace.clear()
+        issue_trace.extend(round((b - a) * 1e3, 3) for a, b in zip(marks, marks[1:] + [t1]))
+        return t1 - t0
 
     def stage_pass(w, k):
         """k extra (untimed) steps with HIP events around every stage -> {stage: [ms per launch]}"""
@@ -495,6 +504,7 @@ def main():
     # `value` is the FIRST attempt, whatever the retries show (taking the last of 1-3 attempts selected
     # toward the fastest); the retries only tell whether a stall repeats
     attempts = [round(dt / args.steps * 1e3, 4)]
+    first_issue_trace = list(issue_trace)
     while (world == 1 and len(attempts) < 3 and
            stall_of(attempts[-1], stages, n_stage_steps, exchange_ms or 0.0) > 0.10 * attempts[-1]):
         ops.profiler = ops.StageProfiler(only={DOMINANT_STAGE})
@@ -760,6 +770,8 @@ def main():
             "exchange_ms": None if exchange_ms is None else round(exchange_ms, 4),
             "stage_ms": stage_ms,
             "host_stall_ms": round(host_stall, 4), "timing_attempts_ms": attempts,
+            # first attempt, per step: ms until the host had issued it (the last entry is the closing synchronize)
+            "host_issue_ms_per_step": first_issue_trace[:65] if host_stall > 0.10 * ms_per_step else None,
             "timing_attempt_reported": "first (retries only diagnose a host stall; they never replace the value)",
             "host_stall_check": stall_check,
             "stage_ms_source": f"{n_stage_steps} extra steps with HIP events around every stage, after the timed region",
