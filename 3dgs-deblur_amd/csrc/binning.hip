@@ -22,6 +22,7 @@
 // wave64 match-any ranking (ballot per digit bit), one contiguous key run per wave
 // so stability needs no block-wide exchange.
 #include <algorithm>
+#include <atomic>
 #include "gs_common.h"
 
 namespace gs {
@@ -589,6 +590,187 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(size_t n, const KeyT
   }
 }
 
+// ---------------------------------------------------------------------------
+// The tail of a compacting segmented sort whose survivors are FEW (a nearest-first selection: ~11 k of 1 M keys per
+// sub-pose on the headline): ONE block per segment finishes the sort — every key bit from begin_bit up — inside its
+// registers and LDS, in one launch.  The three hist + scan + scatter passes it replaces were nine launches of ~25
+// blocks each: 83 us of launch latency around microseconds of work.
+//   * the block reads its segment's n = cnt_in[seg] survivors (n > kTailLocalCap: it leaves the segment alone — the
+//     caller's promise was broken and it must sort again, exactly as with the tail_cap of the multi-block passes);
+//   * wave w owns elements [w * Re * 64, (w + 1) * Re * 64), Re = ceil(n / 1024) rounds of 64: the same contiguous,
+//     round-major ownership as radix_scatter_kernel, so the same ballot ranking is stable without an exchange;
+//   * the digits are cut from (key - base) with base = the block's smallest key rounded down to 2^begin_bit (the passes
+//     below begin_bit ordered the low bits of the KEY; a multiple of 2^begin_bit leaves them alone): a selection's keys
+//     span a narrow depth range, so 24 key bits are typically 17-18 significant ones — two passes of 9 bits, not three;
+//   * the payloads live in one 4-byte staging array between the passes; a pass lifts them into registers, sends the
+//     keys through the array to their sorted slots and back, and drops the payloads into theirs (LDS holds 24 k words
+//     + the per-wave digit counters, not two copies of the pairs; registers hold keys + payloads only transiently);
+//   * the last step is the PACK = 2 epilogue of radix_scatter_kernel (index / packed count split).
+// The result is the stable sort by key bits [begin_bit, end_bit): bit-identical to the multi-block passes.
+// ---------------------------------------------------------------------------
+constexpr int kTailR = 24;                               // keys per thread
+constexpr int kTailLocalCap = kTailR * 1024;             // 24576 survivors per segment
+constexpr int kTailMaxBits = 9;
+constexpr size_t kTailLds = ((size_t)kTailLocalCap + 16 * (1 << kTailMaxBits) + 64) * sizeof(unsigned);
+
+__global__ __launch_bounds__(1024) void seg_tail_sort_kernel(size_t seg_len, const unsigned* __restrict__ keys_in,
+                                                             const unsigned* __restrict__ vals_in,
+                                                             unsigned* __restrict__ keys_out,
+                                                             unsigned* __restrict__ vals_out,
+                                                             const unsigned* __restrict__ cnt_in, int begin_bit, int end_bit,
+                                                             const unsigned* __restrict__ gather_src,
+                                                             unsigned* __restrict__ gather_out, int pack_bits) {
+  extern __shared__ unsigned tail_lds[];
+  unsigned* const stage = tail_lds;                               // [kTailLocalCap]: the payloads between the passes
+  unsigned* const cnt = stage + kTailLocalCap;                    // [16][1 << w]
+  unsigned* const red = cnt + 16 * (1 << kTailMaxBits);           // [64]
+  const unsigned seg = blockIdx.x;
+  const unsigned n = cnt_in[seg];
+  if (n == 0 || n > (unsigned)kTailLocalCap) return;
+  const size_t org = (size_t)seg * seg_len;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const unsigned Re = (n + 1023u) >> 10;
+  const unsigned wbase = (unsigned)wave * Re * 64u;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  unsigned key[kTailR];
+  unsigned pos2[kTailR / 2];                                     // two 16-bit ranks / slots per register
+  unsigned kmin = 0xffffffffu, kmax = 0u;
+  const unsigned emask = end_bit >= 32 ? 0xffffffffu : (1u << end_bit) - 1u;    // bits from end_bit up do not order
+#pragma unroll
+  for (int r = 0; r < kTailR; ++r) {
+    const unsigned e = wbase + (unsigned)r * 64u + lane;
+    const bool ok = (unsigned)r < Re && e < n;
+    key[r] = ok ? keys_in[org + e] : 0u;
+    if (ok) {
+      stage[e] = vals_in[org + e];            // (read back by this very thread: no barrier in between)
+      kmin = min(kmin, key[r] & emask);
+      kmax = max(kmax, key[r] & emask);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
+    kmax = max(kmax, (unsigned)__shfl_xor((int)kmax, o));
+  }
+  if (lane == 0) { red[wave] = kmin; red[16 + wave] = kmax; }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { kmin = min(kmin, red[w]); kmax = max(kmax, red[16 + w]); }
+  const unsigned base = kmin & ~((1u << begin_bit) - 1u);
+  const unsigned span = (kmax - base) >> begin_bit;
+  const int rem = span ? 32 - __clz((int)span) : 0;               // significant bits left to order
+  const int passes = (rem + kTailMaxBits - 1) / kTailMaxBits;
+  const int wbits = passes ? (rem + passes - 1) / passes : 0;
+  const unsigned nb = 1u << wbits, mask = nb - 1u;
+  int shift = begin_bit;
+  for (int p = 0; p < passes; ++p, shift += wbits) {
+    for (unsigned d = threadIdx.x; d < 16u * nb; d += 1024u) cnt[d] = 0u;
+    __syncthreads();
+    unsigned* const wcnt = cnt + (unsigned)wave * nb;
+#pragma unroll
+    for (int r = 0; r < kTailR; ++r) {
+      if ((unsigned)r < Re) {                                     // (uniform over the block)
+        const unsigned e = wbase + (unsigned)r * 64u + lane;
+        const bool valid = e < n;
+        const unsigned digit = (((key[r] & emask) - base) >> shift) & mask;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kTailMaxBits; ++b) {
+          if (b < wbits) {
+            const bool bit = (digit >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+          }
+        }
+        const unsigned prefix = __popcll(peers & lt_mask), total = __popcll(peers);
+        unsigned c0 = 0;
+        if (valid) c0 = wcnt[digit];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && prefix == 0) wcnt[digit] = c0 + total;
+        __builtin_amdgcn_wave_barrier();
+        pos2[r >> 1] = (r & 1) ? (pos2[r >> 1] | ((c0 + prefix) << 16)) : (c0 + prefix);
+      }
+    }
+    __syncthreads();
+    {
+      // digit d = thread d: its count over the 16 waves -> exclusive scan over the digits -> every wave's first slot
+      const unsigned d = threadIdx.x;
+      unsigned c = 0;
+      if (d < nb) {
+#pragma unroll
+        for (int w = 0; w < 16; ++w) c += cnt[(unsigned)w * nb + d];
+      }
+      unsigned inc = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+      }
+      if (lane == 63) red[32 + wave] = inc;
+      __syncthreads();
+      unsigned run = inc - c;
+      for (int w = 0; w < wave; ++w) run += red[32 + w];
+      if (d < nb) {
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+          const unsigned cw = cnt[(unsigned)w * nb + d];
+          cnt[(unsigned)w * nb + d] = run;
+          run += cw;
+        }
+      }
+    }
+    __syncthreads();
+    // the payloads leave the staging array for registers, the keys take the trip to their sorted slots and back to
+    // their new owners, the payloads follow and STAY in the staging array (slot e = its owner's next-pass position)
+    unsigned val[kTailR];
+#pragma unroll
+    for (int r = 0; r < kTailR; ++r) {
+      const unsigned e = wbase + (unsigned)r * 64u + lane;
+      if ((unsigned)r < Re && e < n) {
+        val[r] = stage[e];
+        const unsigned rank = (r & 1) ? pos2[r >> 1] >> 16 : pos2[r >> 1] & 0xffffu;
+        const unsigned slot = wcnt[(((key[r] & emask) - base) >> shift) & mask] + rank;
+        pos2[r >> 1] = (r & 1) ? ((pos2[r >> 1] & 0xffffu) | (slot << 16)) : ((pos2[r >> 1] & 0xffff0000u) | slot);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kTailR; ++r) {
+      const unsigned e = wbase + (unsigned)r * 64u + lane;
+      if ((unsigned)r < Re && e < n) stage[(r & 1) ? pos2[r >> 1] >> 16 : pos2[r >> 1] & 0xffffu] = key[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kTailR; ++r) {
+      const unsigned e = wbase + (unsigned)r * 64u + lane;
+      if ((unsigned)r < Re && e < n) key[r] = stage[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kTailR; ++r) {
+      const unsigned e = wbase + (unsigned)r * 64u + lane;
+      if ((unsigned)r < Re && e < n) stage[(r & 1) ? pos2[r >> 1] >> 16 : pos2[r >> 1] & 0xffffu] = val[r];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < kTailR; ++r) {
+    const unsigned e = wbase + (unsigned)r * 64u + lane;
+    if ((unsigned)r < Re && e < n) {
+      keys_out[org + e] = key[r];
+      const unsigned v = stage[e];
+      if (pack_bits) {
+        const unsigned idx = v & ((1u << pack_bits) - 1u), c = v >> pack_bits;
+        vals_out[org + e] = idx;
+        gather_out[org + e] = c == (1u << (32 - pack_bits)) - 1u ? gather_src[idx] : c;
+      } else {
+        vals_out[org + e] = v;
+        if (gather_out) gather_out[org + e] = gather_src[v];
+      }
+    }
+  }
+}
+
 template <typename KeyT>
 static inline unsigned sort_nblk(size_t n) {
   return (unsigned)((n + sort_block_keys<KeyT>() - 1) / sort_block_keys<KeyT>());
@@ -740,6 +922,31 @@ static int radix_sort(size_t n, size_t seg_len, KeyT* k0, unsigned* v0, KeyT* k1
     }
     shift += w;
     cur ^= 1;
+    if constexpr (sizeof(KeyT) == 4) {
+      // few survivors promised (tail_blocks * 4096 <= kTailLocalCap): one block per segment finishes the sort
+      if (p == 0 && passes >= 2 && seg_counts && !p2_src && tail_blocks &&
+          (size_t)tail_blocks * sort_block_keys<KeyT>() <= (size_t)kTailLocalCap && (pack_bits || !gather_out || gather_src)) {
+        // (131 KB of dynamic LDS needs the attribute once per device; a process may drive several)
+        static std::atomic<unsigned long long> lds_set{0ull};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        bool lds_ok = (lds_set.load(std::memory_order_relaxed) & bit) != 0;
+        if (!lds_ok && hipFuncSetAttribute(reinterpret_cast<const void*>(seg_tail_sort_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTailLds) == hipSuccess) {
+          lds_set.fetch_or(bit, std::memory_order_relaxed);
+          lds_ok = true;
+        }
+        if (lds_ok) {
+          const size_t sl = (seg_len == 0 || seg_len >= n) ? n : seg_len;
+          hipLaunchKernelGGL(seg_tail_sort_kernel, dim3((unsigned)((n + sl - 1) / sl)), dim3(1024), kTailLds, st, sl,
+                             reinterpret_cast<const unsigned*>(kk[cur]), vv[cur], reinterpret_cast<unsigned*>(kk[cur ^ 1]),
+                             vv[cur ^ 1], seg_counts, shift, end_bit, gather_src, gather_out, pack_bits);
+          *result_buf = cur ^ 1;
+          return gs_launch_status();
+        }
+      }
+    }
   }
   *result_buf = cur;
   if (result_p2) *result_p2 = (passes - 1) & 1;

@@ -166,6 +166,59 @@ def test_depth_select_bound_and_selective_sort(gs, dev, P, N, budget, dist):
             assert np.array_equal(cc[p * N:p * N + m].astype(np.int64), w[p * N:(p + 1) * N][order]), (side, p)
 
 
+@pytest.mark.parametrize("spread", ["wide", "narrow", "equal"])
+def test_one_block_tail_of_the_selective_sort(gs, dev, spread):
+    """a promised selection of at most 24 576 keys per segment is finished by ONE block per segment
+    (seg_tail_sort_kernel: registers + LDS, digits cut from key - smallest key) instead of three multi-block passes:
+    against numpy's stable sort and bit-identical to the sort without the promise, over segments that keep 0, 1, 63, 1025,
+    12 345 and exactly 24 576 keys; keys over the whole positive range (three 8-bit digits), within a few thousand ulps
+    (one digit) and all equal (none)."""
+    import ctypes
+    import numpy as np
+    from gsdeblur_amd import _lib
+    from gsdeblur_amd.ops import _ptr, _stream
+    L = _lib.load()
+    keeps = [0, 1, 63, 1025, 12_345, 24_576]
+    P, N = len(keeps), 60_000
+    n = P * N
+    rng = np.random.default_rng({"wide": 1, "narrow": 2, "equal": 3}[spread])
+    keys = np.full(n, 0xFFFFFFFF, dtype=np.int64)
+    for p, m in enumerate(keeps):
+        where = rng.choice(N, m, replace=False) + p * N
+        if spread == "wide":
+            keys[where] = rng.integers(1, 2 ** 31 - 1, m)
+        elif spread == "narrow":
+            keys[where] = 0x3F800000 + rng.integers(0, 5000, m)
+        else:
+            keys[where] = 0x40490FDB
+    w = rng.integers(1, 700, n).astype(np.int64)
+    w[rng.random(n) < 0.01] = 9000                        # (beyond the packed field's 13 bits: these take the gather)
+    dk = torch.from_numpy(keys.astype(np.uint32).view(np.int32)).to(dev)
+    dw = torch.from_numpy(w.astype(np.int32)).to(dev)
+    ws_b = L.gs_segmented_sort_compact_workspace_bytes(n, N, 0, 31, 8)
+    got = {}
+    for tail_cap in (24_576, 0):
+        k0, v0, k1, v1, cnt_out = (torch.full((n,), 0x7F7F7F7F, dtype=torch.int32, device=dev) for _ in range(5))
+        n_live = torch.zeros(P, dtype=torch.int32, device=dev)
+        sws = torch.empty(ws_b, dtype=torch.uint8, device=dev)
+        res = ctypes.c_int(-1)
+        _lib.check(L.gs_segmented_sort_select_u32(n, N, _ptr(dk), _ptr(k0), _ptr(v0), _ptr(k1), _ptr(v1), 0, 31, 8,
+                                                  0xFFFFFFFF, None, None, _ptr(n_live), _ptr(dw), _ptr(cnt_out),
+                                                  _ptr(sws), ws_b, ctypes.byref(res), tail_cap, _stream()), "sort_select")
+        sk, sv = ((k1, v1) if res.value == 1 else (k0, v0))
+        got[tail_cap] = (sk.cpu().numpy().view(np.uint32).astype(np.int64), sv.cpu().numpy().astype(np.int64),
+                         cnt_out.cpu().numpy().astype(np.int64), n_live.cpu().numpy())
+    for tail_cap, (sk, sv, cc, nl) in got.items():
+        assert list(nl) == keeps
+        for p, m in enumerate(keeps):
+            seg = keys[p * N:(p + 1) * N]
+            idx = np.nonzero(seg != 0xFFFFFFFF)[0]
+            order = idx[np.argsort(seg[idx], kind="stable")]
+            assert np.array_equal(sv[p * N:p * N + m], order + p * N), (tail_cap, p)
+            assert np.array_equal(sk[p * N:p * N + m], seg[order]), (tail_cap, p)
+            assert np.array_equal(cc[p * N:p * N + m], w[p * N:(p + 1) * N][order]), (tail_cap, p)
+
+
 def _saturating_scene(gs, dev, n, W, H, seed=23):
     """the seeded scene with its nearest 3000 Gaussians made large and opaque: every pixel stops within a few dozen
     entries, i.e. within the first depth slice of any budget — the shape of the benchmark frame at test size"""

@@ -28,6 +28,7 @@ BUDGET = {
     ("binning.hip", "radix_scatter_kernel<unsigned int, 8, 0>"): (168, False),   # 3 waves (the tile sort's passes)
     ("binning.hip", "radix_scatter_kernel<unsigned int, 8, 1>"): (168, False),   # depth pre-sort: counts packed ...
     ("binning.hip", "radix_scatter_kernel<unsigned int, 8, 2>"): (168, False),   # ... and unpacked
+    ("binning.hip", "seg_tail_sort_kernel"): (128, True),                     # 1024 threads: 24 keys + payloads per thread
     ("binning.hip", "slice_counts_exact_kernel<true, false>"): (80, False),   # 6 waves
     ("binning.hip", "slice_counts_exact_kernel<true, true>"): (96, False),    # the swept form (pixel-velocity lists)
 }

@@ -2,6 +2,7 @@
 # round-6 GPU visits: bash tools/visit_r6.sh <tag> <step...>; steps as tools/gpu_visit.sh plus:
 #   r6tests           tests/test_gpu_round6.py
 #   sel_ab            headline + configs with GSD_DEPTH_SELECT=1 (default) against 0, interleaved
+#   c5x3              config 5's share three times on one box (stall hunt)
 TAG=${1:-r6}; shift || true
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 S=$OUT/summary_r6.log; : > $S
@@ -58,6 +59,20 @@ for step in "$@"; do
       for base in 512 384 256; do
         GSD_SLICE_BASE=$base timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --gaussians 5000000 --width 3840 --height 2160 --subposes 10 > $OUT/c5_b$base.log 2>&1; line "config5 base=$base" $OUT/c5_b$base.log | tee -a $S
         GSD_SLICE_BASE=$base timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --gaussians 2000000 --subposes 5 --rs-bands 2 > $OUT/c4_b$base.log 2>&1; line "config4 base=$base" $OUT/c4_b$base.log | tee -a $S
+      done ;;
+    c5x3)
+      # config 5's share on one GPU, three times on one box (visit r6_final2 saw ONE first attempt at 48.7 ms against 12.2 in
+      # its retry and in every other visit): ms, attempts, and the per-step host issue times of a stalled attempt
+      for v in 1 2 3; do
+        timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --gaussians 5000000 --width 3840 --height 2160 --subposes 10 > $OUT/c5_run$v.log 2>&1
+        python - $OUT/c5_run$v.log <<'PY' | tee -a $S
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith('{'):
+        d = json.loads(l)
+        print('config5 run', sys.argv[1][-5], 'ms', d['ms_per_step'], 'attempts', d['timing_attempts_ms'], 'stall', d['host_stall_ms'],
+              'issue', d.get('host_issue_ms_per_step'), 'stages', d['stage_ms'])
+PY
       done ;;
     *) rest+=("$step") ;;
   esac
