@@ -17,7 +17,7 @@ KERNELS = ["raster_bwd_sload_kernel", "raster_fwd_sload_kernel", "raster_bwd_ker
            "project_fused_fwd_kernel", "project_fused_bwd_sparse_kernel", "slice_counts_exact_kernel",
            "slice_colors_kernel", "emit_open_kernel", "reduce_tuples_wave_kernel", "radix_scatter_kernel",
            "radix_hist_kernel", "slice_records_kernel", "depth_hist_kernel", "depth_find_kernel", "bin_edges_kernel",
-           "scan_apply_fused_kernel", "pose_reduce_kernel"]
+           "scan_apply_fused_kernel", "pose_reduce_kernel", "seg_tail_sort_kernel"]
 # issue cycles per VALU wave-instruction of the kernel's inner-loop mix (tools/valu_mix.py x tools/valu_bench.hip)
 # round 4 (profiles/r04_valu_mix.txt): static mix of the final inner loops, the backward's with all four quadrants hit
 MIX = {"raster_fwd_sload_kernel": 785.1 / 221, "raster_bwd_sload_kernel": 1708.0 / 599,
