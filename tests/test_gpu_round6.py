@@ -166,13 +166,13 @@ def test_depth_select_bound_and_selective_sort(gs, dev, P, N, budget, dist):
             assert np.array_equal(cc[p * N:p * N + m].astype(np.int64), w[p * N:(p + 1) * N][order]), (side, p)
 
 
-@pytest.mark.parametrize("spread", ["wide", "narrow", "equal"])
+@pytest.mark.parametrize("spread", ["wide", "medium", "narrow", "equal"])
 def test_one_block_tail_of_the_selective_sort(gs, dev, spread):
     """a promised selection of at most 24 576 keys per segment is finished by ONE block per segment
     (seg_tail_sort_kernel: registers + LDS, digits cut from key - smallest key) instead of three multi-block passes:
     against numpy's stable sort and bit-identical to the sort without the promise, over segments that keep 0, 1, 63, 1025,
-    12 345 and exactly 24 576 keys; keys over the whole positive range (three 8-bit digits), within a few thousand ulps
-    (one digit) and all equal (none)."""
+    12 345 and exactly 24 576 keys; keys over the whole positive range (three 8-bit digits), over 2^26 ulps (two 9-bit
+    digits: a selection's depth range), within a few thousand ulps (one digit) and all equal (none)."""
     import ctypes
     import numpy as np
     from gsdeblur_amd import _lib
@@ -181,12 +181,14 @@ def test_one_block_tail_of_the_selective_sort(gs, dev, spread):
     keeps = [0, 1, 63, 1025, 12_345, 24_576]
     P, N = len(keeps), 60_000
     n = P * N
-    rng = np.random.default_rng({"wide": 1, "narrow": 2, "equal": 3}[spread])
+    rng = np.random.default_rng({"wide": 1, "narrow": 2, "equal": 3, "medium": 4}[spread])
     keys = np.full(n, 0xFFFFFFFF, dtype=np.int64)
     for p, m in enumerate(keeps):
         where = rng.choice(N, m, replace=False) + p * N
         if spread == "wide":
             keys[where] = rng.integers(1, 2 ** 31 - 1, m)
+        elif spread == "medium":
+            keys[where] = 0x3F000000 + rng.integers(0, 2 ** 26, m)
         elif spread == "narrow":
             keys[where] = 0x3F800000 + rng.integers(0, 5000, m)
         else:
