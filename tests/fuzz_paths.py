@@ -102,6 +102,7 @@ for trial in range(trials):
     times, _, _ = gs.subpose_schedule(S, 1 / 60, R, 1 / 30)
     wt = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(trial)).to(dev)
     res = []
+    twice_any = False
     try:
         for plain in (False, True):
             for k in KNOBS:
@@ -118,24 +119,31 @@ for trial in range(trials):
                 ops.SLICE_BASE = 0
             if not plain:
                 ops.SLICE_BASE = base
-            p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
-            if pixvel:
-                rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
-                                                        torch.sigmoid(p["opacity_logits"]), p["sh"], sc["viewmat"],
-                                                        None if bg is None else bg.to(dev), S, R, sc["fx"], sc["fy"],
-                                                        sc["cx"], sc["cy"], H, W, gamma=gamma, min_rgb_level=mlevel,
-                                                        sh_degree=deg, antialiased=aa, lin_vel=sc["lin_vel"] * 20,
-                                                        ang_vel=sc["ang_vel"] * 10, times=torch.tensor(times, device=dev),
-                                                        rolling_shutter_time=rs_time)
-            else:
-                vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"] * 20, sc["ang_vel"] * 10,
-                                          torch.tensor(times, device=dev))
-                rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
-                                                        torch.sigmoid(p["opacity_logits"]), p["sh"], vms,
-                                                        None if bg is None else bg.to(dev), S, R, sc["fx"], sc["fy"],
-                                                        sc["cx"], sc["cy"], H, W, gamma=gamma, min_rgb_level=mlevel,
-                                                        sh_degree=deg, antialiased=aa)
-            ((rgb * wt).sum() + 0.5 * alphas.sum()).backward()
+            # round 6: half of the selecting trials render the frame TWICE through one FrameHints and compare the second
+            # frame — its sort runs with the first frame's selection size as a promise (the one-block tail of the
+            # selective sort, the overflow re-sort when the promise is too small)
+            hints = ops.FrameHints()
+            twice = (not plain) and frame["DEPTH_SELECT"] == 2 and random.Random(seed * 7919 + trial).random() < 0.5
+            twice_any = twice_any or twice
+            for _warm in range(2 if twice else 1):
+              p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+              if pixvel:
+                  rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
+                                                          torch.sigmoid(p["opacity_logits"]), p["sh"], sc["viewmat"],
+                                                          None if bg is None else bg.to(dev), S, R, sc["fx"], sc["fy"],
+                                                          sc["cx"], sc["cy"], H, W, gamma=gamma, min_rgb_level=mlevel,
+                                                          sh_degree=deg, antialiased=aa, lin_vel=sc["lin_vel"] * 20,
+                                                          ang_vel=sc["ang_vel"] * 10, times=torch.tensor(times, device=dev),
+                                                          rolling_shutter_time=rs_time, hints=hints)
+              else:
+                  vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"] * 20, sc["ang_vel"] * 10,
+                                            torch.tensor(times, device=dev))
+                  rgb, alphas, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
+                                                          torch.sigmoid(p["opacity_logits"]), p["sh"], vms,
+                                                          None if bg is None else bg.to(dev), S, R, sc["fx"], sc["fy"],
+                                                          sc["cx"], sc["cy"], H, W, gamma=gamma, min_rgb_level=mlevel,
+                                                          sh_degree=deg, antialiased=aa, hints=hints)
+              ((rgb * wt).sum() + 0.5 * alphas.sum()).backward()
             res.append((rgb.detach().clone(), alphas.detach().clone(), {k: v.grad.clone() for k, v in p.items()},
                         len(ops.last_slice_intersects)))
     finally:
@@ -190,7 +198,7 @@ for trial in range(trials):
     bad += 0 if ok else 1
     print(f"trial {trial:3d} n={n:6d} {W}x{H} S={S} R={R} mult={mult} base={base} slices={nsl} "
           f"deg={deg} aa={int(aa)} gamma={gamma} routes={''.join(str(routes[k]) for k in ROUTES)} "
-          f"frame={int(native)}/{frame['SLICE_MERGE']}/{frame['FRAME_POLL']}/lazy{frame['LAZY_RECORDS']}/sel{frame['DEPTH_SELECT']} "
+          f"frame={int(native)}/{frame['SLICE_MERGE']}/{frame['FRAME_POLL']}/lazy{frame['LAZY_RECORDS']}/sel{frame['DEPTH_SELECT']}{'x2' if twice_any else ''} "
           f"{'pixvel rs=%.3f ' % rs_time if pixvel else ''}img_equal={torch.equal(img_f, img_p)} grad_rel={worst:.1e} ({worst_key}){extra} "
           f"{'ok' if ok else 'FAIL'}", flush=True)
 print(f"fuzz: {trials - bad}/{trials} trials ok in {time.time() - t0:.0f} s")
