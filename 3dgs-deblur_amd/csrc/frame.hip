@@ -336,6 +336,7 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
   // phase 0: everything (or the selection); phase 1: the pairs behind the selection
   // tail_cap: promise to the selective sort that no sub-pose keeps more pairs (desc.select_cap, from the last frame's
   // selection; 0: none) — checked against the counts the plan read-back brings, below
+  bool bound_known = false;
   auto presort = [&](int phase, long long tail_cap) -> int {
     int res = 0;
     {
@@ -346,9 +347,13 @@ GS_EXPORT int gs_frame_forward(const gs_frame_desc* dp, float* records, unsigned
                                             reinterpret_cast<const unsigned*>(num_tiles_hit), counts_r, sort_ws, sort_ws_b,
                                             &res, st));
       } else {
-        if (phase == 0)
+        // (once per frame: a re-sort after a broken promise keeps the bound — its workspace and the frame total it
+        //  accumulates into are only zero the first time)
+        if (phase == 0 && !bound_known) {
           CHECK(gs_depth_select(n, N, depth_keys, reinterpret_cast<const unsigned*>(num_tiles_hit), base0, thr_dev,
                                 sel_grand, zero_blk, sel_b - 256, st));
+          bound_known = true;
+        }
         CHECK(gs_segmented_sort_select_u32(n, N, depth_keys, k0s, v0, k1, v1, 0, 31, digit, 0xFFFFFFFFu,
                                            phase == 0 ? nullptr : thr_dev, phase == 0 ? thr_dev : nullptr, n_live,
                                            reinterpret_cast<const unsigned*>(num_tiles_hit), counts_r, sort_ws, sort_ws_b,

@@ -341,10 +341,13 @@ def test_frame_hints_switch_the_selection_on_and_off(gs, dev):
         assert h.select_cap > 0                                        # the selection's size is remembered ...
         img2, st2, _ = frame(h)
         assert st2 == 1 and torch.equal(img0, img2) and h.select_misses == 0 and h.settled
-        # ... and sizes the next frame's tail passes; a promise that turns out too small is noticed and sorted again
+        pairs2, slice2 = ops.last_num_intersects, [int(v) for v in ops.last_slice_intersects]
+        # ... and sizes the next frame's tail passes; a promise that turns out too small is noticed and sorted again —
+        # with the SAME bound (the selection is not run a second time: same slice, same frame total)
         h.select_cap = 64
         img2b, st2b, _ = frame(h)
         assert st2b == 1 and torch.equal(img0, img2b) and h.select_overflows == 1 and h.select_cap > 64
+        assert ops.last_num_intersects == pairs2 and [int(v) for v in ops.last_slice_intersects] == slice2
         img2c, _, _ = frame(h)
         assert torch.equal(img0, img2c) and h.select_overflows == 1
         # a budget this scene does not stop within: the selection of the next frame falls short once, then it is off
