@@ -146,6 +146,14 @@ class SplatfactoDeblurModel(nn.Module):
         # binding's module state, so two models of one shape never share it
         self.frame_hints = ops.FrameHints()
 
+    def _hints_of(self, camera):
+        """a camera that names itself (metadata['cam_idx'], as the datamanager's training cameras do:
+        /root/reference/render_model.py:216-219) has its own memory inside this model's FrameHints (ops.FrameHints.view): a
+        training loop revisits the same cameras, and what a frame teaches the next one is a property of the camera; a
+        camera without an index (a novel view) goes through the scene-level memory"""
+        idx = camera.metadata.get("cam_idx") if camera.metadata else None
+        return self.frame_hints if idx is None else self.frame_hints.view(int(idx))
+
     # -- splatfacto-style accessors ------------------------------------------------
     @property
     def num_points(self) -> int:
@@ -318,7 +326,7 @@ class SplatfactoDeblurModel(nn.Module):
             lin_vel=lin if pixvel else None, ang_vel=ang if pixvel else None,
             times=(list(times) if shared else times_t) if pixvel else None,
             return_depth=want_depth, rolling_shutter_time=self._rs_time(camera) if pixvel else 0.0,
-            sh_rest=rest_, raw_params=True, shared_list=shared, hints=self.frame_hints)
+            sh_rest=rest_, raw_params=True, shared_list=shared, hints=self._hints_of(camera))
         rgb, alphas, radii = res[:3]
         depth_acc = res[3] if want_depth else None
         self.radii = radii
@@ -378,7 +386,7 @@ class SplatfactoDeblurModel(nn.Module):
             sh_degree=self.active_sh_degree(), antialiased=(cfg.rasterize_mode == "antialiased"),
             sh_rest=self.features_rest, raw_params=True, motion_model=cfg.motion_model, xy_grad_out=self.xy_grad,
             camera_grads=bool(cam_leaves), background_grad=bg.requires_grad,
-            rolling_shutter_time=self._rs_time(camera) if pixvel else 0.0, shared_list=shared, hints=self.frame_hints)
+            rolling_shutter_time=self._rs_time(camera) if pixvel else 0.0, shared_list=shared, hints=self._hints_of(camera))
         for p, gr in ((self.means, g["means"]), (self.scales, g["scales"]), (self.quats, g["quats"]),
                       (self.opacities, g["opacities"]), (self.features_dc, g["sh"]), (self.features_rest, g["sh_rest"])):
             gr = gr.view_as(p)

@@ -52,7 +52,7 @@ class FrameHints:
     so two scenes of one shape never fight over one hint.  Thread-safe."""
 
     __slots__ = ("mult", "age", "arena_bytes", "arena_retries", "frames", "box_share", "last_slices", "select_misses",
-                 "select_cap", "select_overflows", "_recent", "_lock")
+                 "select_cap", "select_overflows", "_recent", "_lock", "_views")
 
     def __init__(self):
         self.mult, self.age, self.arena_bytes, self.arena_retries, self.frames = 1, 0, 0, 0, 0
@@ -63,6 +63,7 @@ class FrameHints:
         self.select_overflows = 0       # frames whose selection outgrew it (sorted twice)
         self._recent = []               # (issued slices, budget multiplier, arena retries) of the last frames
         self._lock = threading.Lock()
+        self._views = {}                # view(key): per-camera memories
 
     def slice_base(self) -> int:
         return SLICE_BASE * (self.mult if SLICE_ADAPT and SLICE_BASE > 0 else 1)
@@ -119,10 +120,74 @@ class FrameHints:
         small part of the frame: the last frame issued ONE slice that held under half of its bounding-box pairs"""
         return self.last_slices == 1 and self.box_share is not None and self.box_share < 0.5
 
+    def view(self, key) -> "ViewHints":
+        """The memory of ONE camera of this scene (round 6).  A training loop comes back to the same cameras epoch after
+        epoch, and what a frame teaches the next one — did it stop in its first slice, what share of its pairs did that
+        slice hold, how many pairs did it select — is a property of the CAMERA: a view that looks past the scene's edge
+        needs five slices every time, its neighbour in the batch one.  With one last-frame memory for all cameras the
+        cheap view sorted everything whenever it followed the expensive one (bench.py view_sweep: 1.13x its own
+        fixed-view time).  The budget multiplier, the arena estimate and the counters stay with the scene (this object);
+        a camera seen for the first time starts from the scene's last frame.  key: any hashable (the camera index)."""
+        with self._lock:
+            v = self._views.get(key)
+            if v is None:
+                if len(self._views) >= 16384:
+                    self._views.clear()
+                v = self._views[key] = ViewHints(self)
+                v.box_share, v.last_slices, v.select_cap = self.box_share, self.last_slices, self.select_cap
+            return v
+
     def reset(self) -> None:
         with self._lock:
             self.mult, self.age, self.arena_bytes, self._recent, self.box_share = 1, 0, 0, [], None
             self.last_slices, self.select_cap = None, 0
+            self._views.clear()
+
+
+class ViewHints:
+    """FrameHints.view(key): what one camera's last frame learned (slices issued, share of the pairs they held, size of the
+    selection); everything else — budget multiplier, arena estimate, counters — is read from and reported to the scene's
+    FrameHints.  Takes the place of a FrameHints wherever one is accepted (`hints=`)."""
+
+    __slots__ = ("scene", "box_share", "last_slices", "select_cap")
+
+    def __init__(self, scene: "FrameHints"):
+        self.scene = scene
+        self.box_share, self.last_slices, self.select_cap = None, None, 0
+
+    arena_bytes = property(lambda self: self.scene.arena_bytes,
+                           lambda self, v: setattr(self.scene, "arena_bytes", v))
+    mult = property(lambda self: self.scene.mult)
+    frames = property(lambda self: self.scene.frames)
+    arena_retries = property(lambda self: self.scene.arena_retries)
+    select_misses = property(lambda self: self.scene.select_misses)
+    select_overflows = property(lambda self: self.scene.select_overflows)
+    settled = property(lambda self: self.scene.settled)
+
+    def slice_base(self) -> int:
+        return self.scene.slice_base()
+
+    def lazy_records(self) -> bool:
+        return self.scene.mult == 1 and (self.box_share is None or self.box_share < 0.25)
+
+    def depth_select(self) -> bool:
+        return self.last_slices == 1 and self.box_share is not None and self.box_share < 0.5
+
+    def view(self, key) -> "ViewHints":
+        return self.scene.view(key)
+
+    def feedback(self, n_issued: int, retries: int = 0, box_share: Optional[float] = None, select_state: int = 0,
+                 open_after_first: Optional[float] = None, max_selected: int = 0, select_overflow: int = 0) -> None:
+        sc = self.scene
+        with sc._lock:
+            # (the scene's feedback below sizes ITS promise from its own history; this camera's comes from this camera's)
+            self.last_slices = int(n_issued)
+            if box_share is not None:
+                self.box_share = float(box_share)
+            if max_selected > 0:
+                want = int(1.5 * max_selected) + 4096
+                self.select_cap = want if (select_overflow or want > self.select_cap) else max(want, int(0.9 * self.select_cap))
+        sc.feedback(n_issued, retries, box_share, select_state, open_after_first, max_selected, select_overflow)
 
 
 _hints = {}          # default owner: (device, N, P, S, H, W, shared, storage of means3d) -> FrameHints

@@ -80,6 +80,7 @@ class Workload:
         # this scene's frame-to-frame hints (adaptive slice budget, arena estimate): owned by the workload, as
         # SplatfactoDeblurModel owns its own — the headline and the secondary scene have the same shape
         self.hints = gs.ops.FrameHints()
+        self.view_key = None
 
     def warm_until_settled(self, at_least: int, at_most: int = 16) -> int:
         """untimed frames until the adaptive slice budget and the arena have converged (two consecutive frames with the
@@ -110,7 +111,7 @@ class Workload:
                                        self.R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], self.H, self.W, self.wt, gamma=2.2,
                                        min_rgb_level=10.0, sh_degree=3, antialiased=True, raw_params=True,
                                        motion_model="se3" if self.motion == "se3" else "pixel_velocity",
-                                       shared_list=self.motion == "pixel_velocity_shared", hints=self.hints)
+                                       shared_list=self.motion == "pixel_velocity_shared", hints=self.frame_hints())
             for k, name in (("means", "means"), ("log_scales", "scales"), ("quats", "quats"),
                             ("opacity_logits", "opacities"), ("sh", "sh")):
                 params[k].grad = g[name]
@@ -129,7 +130,7 @@ class Workload:
                                        params["opacity_logits"], params["sh"], vms, self.bg, self.S,
                                        self.R, sc["fx"], sc["fy"], sc["cx"], sc["cy"], self.H, self.W, gamma=2.2,
                                        min_rgb_level=10.0, sh_degree=3, antialiased=True,
-                                       return_alpha=False, raw_params=True, hints=self.hints)   # the loss reads RGB only
+                                       return_alpha=False, raw_params=True, hints=self.frame_hints())   # the loss reads RGB only
         # fixed d loss / d image = wt (the loss (out * wt).sum() without its two launches: the step times the renderer's
         # forward + backward to every parameter, not a reduction)
         out.backward(self.wt)
@@ -160,25 +161,34 @@ class Workload:
                 views.append((V.clone(), (self.sc["lin_vel"] * k).to(dev), (self.sc["ang_vel"] * k).to(dev)))
         return views
 
-    def set_view(self, view):
+    def set_view(self, view, key=None):
+        """key: the camera's index — its frames then go through hints.view(key), the camera's own memory inside the
+        scene's FrameHints (None: the scene-level memory, as for the fixed headline view)"""
         V, lin, ang = view
+        self.view_key = key
         self.viewmat = V.clone().requires_grad_(True)
         self.lin = lin.clone().requires_grad_(True)
         self.ang = ang.clone().requires_grad_(True)
+
+    def frame_hints(self):
+        return self.hints if self.view_key is None else self.hints.view(self.view_key)
 
     def rows_with_gradient(self):
         g = self.params["means"].grad
         return int((g != 0).any(dim=1).sum()) if g is not None else 0
 
 
-def view_sweep(wl, ops, n_views=16, cycles=4, fixed_frames=6):
+def view_sweep(wl, ops, n_views=16, cycles=4, fixed_frames=6, per_camera=True, fixed=None):
     """A training-shaped sequence: n_views distinct cameras cycled through ONE FrameHints — the
     way SplatfactoDeblurModel owns one for all its cameras — against every view's own fixed-view time (the same view
-    rendered back to back through a private FrameHints, which is what the headline measures).  Reported, never `value`."""
+    rendered back to back through a private FrameHints, which is what the headline measures).  per_camera: every camera's
+    frames go through hints.view(camera index), its own memory inside that one FrameHints (what the Model does with
+    camera.metadata['cam_idx']); False: one last-frame memory for all cameras (rounds 1-5, and any caller that passes no
+    camera key).  Reported, never `value`."""
     import statistics
     gs = wl.gs
     views = wl.sweep_views(n_views)
-    saved = (wl.viewmat, wl.lin, wl.ang, wl.hints)
+    saved = (wl.viewmat, wl.lin, wl.ang, wl.hints, wl.view_key)
 
     def timed_step():
         torch.cuda.synchronize()
@@ -186,20 +196,22 @@ def view_sweep(wl, ops, n_views=16, cycles=4, fixed_frames=6):
         wl.step()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) * 1e3
-    fixed = []
-    for view in views:                                      # each view's own steady state
-        wl.set_view(view)
-        wl.hints = gs.ops.FrameHints()
-        ms = [timed_step() for _ in range(fixed_frames)]
-        fixed.append(statistics.median(ms[2:]))
+    if fixed is None:
+        fixed = []
+        for view in views:                                      # each view's own steady state
+            wl.set_view(view)
+            wl.hints = gs.ops.FrameHints()
+            ms = [timed_step() for _ in range(fixed_frames)]
+            fixed.append(statistics.median(ms[2:]))
     wl.hints = gs.ops.FrameHints()                           # ONE hints object for the whole sweep
     per_view = [[] for _ in views]
     decisions, mults, slices, select_state = [], [], [], []
     retries0 = 0
     for c in range(cycles):
         for i, view in enumerate(views):
-            wl.set_view(view)
-            decisions.append((bool(ops.LAZY_RECORDS and wl.hints.lazy_records()), bool(ops.DEPTH_SELECT and wl.hints.depth_select())))
+            wl.set_view(view, i if per_camera else None)
+            h = wl.frame_hints()
+            decisions.append((bool(ops.LAZY_RECORDS and h.lazy_records()), bool(ops.DEPTH_SELECT and h.depth_select())))
             ms = timed_step()
             mults.append(wl.hints.mult)
             slices.append(len([v for v in ops.last_slice_intersects if int(v) > 0]))
@@ -210,16 +222,20 @@ def view_sweep(wl, ops, n_views=16, cycles=4, fixed_frames=6):
                 per_view[i].append(ms)
     retries_all = wl.hints.arena_retries
     overflows = wl.hints.select_overflows
-    wl.viewmat, wl.lin, wl.ang, wl.hints = saved
+    wl.viewmat, wl.lin, wl.ang, wl.hints, wl.view_key = saved
     flat = [m for v in per_view for m in v]
     ratio = [max(v) / f for v, f in zip(per_view, fixed)]
     ratio_med = [statistics.median(v) / f for v, f in zip(per_view, fixed)]
+    # (decisions of the later cycles only: in the first one every camera is new)
+    later = decisions[len(views):]
     flips = lambda seq: sum(1 for a, b in zip(seq, seq[1:]) if a != b)
     hist = []
     for m in mults:
         if not hist or hist[-1] != m:
             hist.append(m)
     return {"views": n_views, "cycles": cycles, "frames_timed": len(flat),
+            "memory": "one per camera (hints.view(camera index)) inside the one FrameHints" if per_camera else
+                      "one last-frame memory for all cameras",
             "ms_per_view": {"min": round(min(flat), 4), "median": round(statistics.median(flat), 4), "max": round(max(flat), 4)},
             "fixed_view_ms": {"min": round(min(fixed), 4), "median": round(statistics.median(fixed), 4), "max": round(max(fixed), 4)},
             # a view's slowest frame of the later cycles (and its median frame) over the MEDIAN of its own fixed-view frames
@@ -229,9 +245,12 @@ def view_sweep(wl, ops, n_views=16, cycles=4, fixed_frames=6):
             "slices_per_frame": {"min": min(slices), "max": max(slices)},
             "lazy_eager_flips": flips([d[0] for d in decisions]), "selection_flips": flips([d[1] for d in decisions]),
             "selection_misses": sum(1 for s_ in select_state if s_ == 2),
+            "selection_misses_after_first_cycle": sum(1 for s_ in select_state[len(views):] if s_ == 2),
+            "frames_selecting_after_first_cycle": sum(1 for d in later if d[1]),
             "selection_outgrew_its_promised_size": overflows,
             "budget_multiplier_history": hist, "arena_retries_first_cycle": retries0,
             "arena_retries_later_cycles": retries_all - retries0,
+            "_fixed": fixed,
             "note": "wall clock per frame (synchronize around every step: includes launch latency the back-to-back "
                     "headline loop hides); first cycle untimed; never part of `value`"}
 
@@ -530,6 +549,13 @@ def main():
     sweep = None
     if world == 1 and not args.no_view_sweep and args.motion == "se3":
         sweep = view_sweep(wl, ops)
+        # the same cameras through ONE last-frame memory (what rounds 1-5 did, and what a caller without camera keys gets)
+        one = view_sweep(wl, ops, per_camera=False, fixed=sweep.pop("_fixed"))
+        one.pop("_fixed", None)
+        sweep["one_memory_for_all_cameras"] = {k: one[k] for k in (
+            "ms_per_view", "worst_view_over_its_fixed_time", "worst_view_median_over_its_fixed_time",
+            "median_view_over_its_fixed_time", "lazy_eager_flips", "selection_flips", "selection_misses",
+            "frames_selecting_after_first_cycle", "budget_multiplier_history")}
     # second scene (reported beside the headline, never part of `value`): a fitted-model-like distribution in which
     # a large share of the Gaussians receives a gradient and the depth-sliced path needs several slices
     secondary = None

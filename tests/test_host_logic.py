@@ -400,6 +400,48 @@ def test_adaptive_slice_budget_schedule(gs):
         ops.SLICE_ADAPT, ops.SLICE_BASE = saved
 
 
+def test_a_camera_has_its_own_memory_inside_the_scenes_hints(gs):
+    """ops.FrameHints.view(key): slices issued, share of the pairs they held and the selection's size are remembered per
+    CAMERA; budget multiplier, arena estimate and counters stay with the scene; a camera seen for the first time starts
+    from the scene's last frame; the Model keys it by camera.metadata['cam_idx']"""
+    from gsdeblur_amd import ops
+    saved = (ops.SLICE_ADAPT, ops.SLICE_BASE)
+    try:
+        ops.SLICE_ADAPT, ops.SLICE_BASE = 1, 512
+        h = ops.FrameHints()
+        cheap, wide = h.view(0), h.view(7)
+        assert h.view(0) is cheap and cheap is not wide and cheap.view(7) is wide
+        assert not cheap.depth_select() and cheap.lazy_records()                 # nothing known yet
+        cheap.feedback(1, 0, 0.09, 1, 0.0, 11_000, 0)           # one slice holding 9 % of the pairs, 11 k selected
+        wide.feedback(5, 0, 0.8, 2, 0.02, 0, 0)                 # five slices for a FEW open tiles: the budget stays
+        assert cheap.depth_select() and cheap.lazy_records() and cheap.select_cap == int(1.5 * 11_000) + 4096
+        assert not wide.depth_select() and not wide.lazy_records()
+        assert h.mult == 1 and h.frames == 2 and h.select_misses == 1 and cheap.frames == 2 and wide.select_misses == 1
+        assert not h.depth_select()                             # the scene-level memory is the LAST frame's (the wide one)
+        new = h.view(3)                                         # a new camera starts from there
+        assert not new.depth_select() and new.select_cap == h.select_cap
+        # scene-level state is shared: the arena estimate through any view, the budget multiplier for every view
+        wide.arena_bytes = 123
+        assert h.arena_bytes == 123 and cheap.arena_bytes == 123
+        wide.feedback(3, 0, 0.9, 0, 0.7, 0, 0)                  # most tile lists left open: the scene's budget doubles
+        assert h.mult == 2 and cheap.slice_base() == 1024 and not cheap.lazy_records()
+        # a selection that outgrew its promise raises the camera's own promise at once
+        cheap.feedback(1, 0, 0.09, 1, 0.0, 40_000, 1)
+        assert cheap.select_cap == int(1.5 * 40_000) + 4096 and h.select_overflows == 1
+        h.reset()
+        assert h.view(0) is not cheap and h.mult == 1
+        # the Model: cameras that name themselves get their own memory, a novel view the scene's
+        import types
+        m = types.SimpleNamespace(frame_hints=ops.FrameHints())
+        from gsdeblur_amd.model import SplatfactoDeblurModel
+        cam = lambda md: types.SimpleNamespace(metadata=md)
+        assert SplatfactoDeblurModel._hints_of(m, cam({"cam_idx": 4})) is m.frame_hints.view(4)
+        assert SplatfactoDeblurModel._hints_of(m, cam({})) is m.frame_hints
+        assert SplatfactoDeblurModel._hints_of(m, cam(None)) is m.frame_hints
+    finally:
+        ops.SLICE_ADAPT, ops.SLICE_BASE = saved
+
+
 def test_polled_readbacks_need_two_cores_per_local_rank(gs, monkeypatch):
     """a polling rank spins a host core while it waits; with N ranks on one host the default
     only polls when the affinity mask holds two cores per local rank, GSD_FRAME_POLL set explicitly wins"""
