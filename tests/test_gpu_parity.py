@@ -2658,6 +2658,22 @@ def _full_size_vs_oracle_fixture(gs, oracle, dev, name):
     with torch.no_grad():
         samples, _, _ = gs.render_subposes(means, scales, quats, opac, sh, vms, None, S, R, sc["fx"], sc["fy"], sc["cx"],
                                            sc["cy"], H, W, return_alpha=False)
+    # ---- (b') the bench's STEADY state (round 6): the same frame three times through one FrameHints — the second frame
+    # ranks only the pairs its first slice reaches (nearest-first selection) and projects records lazily, the third sorts
+    # that selection under the second one's promise (one block per sub-pose finishes the sort).  Its sample images must
+    # be the default path's bit for bit: what is compared with the oracle's tiles below is what bench.py times.
+    h_steady = ops.FrameHints()
+    steady = []
+    for _ in range(3):
+        with torch.no_grad():
+            samples_steady, _, _ = gs.render_subposes(means, scales, quats, opac, sh, vms, None, S, R, sc["fx"], sc["fy"],
+                                                      sc["cx"], sc["cy"], H, W, return_alpha=False, hints=h_steady)
+        steady.append((int(ops.last_depth_select), int(h_steady.select_cap), len(ops.last_slice_intersects)))
+    print(f"[full-size {name}] three frames through one FrameHints (selection state, promised size, slices): {steady}")
+    assert torch.equal(samples_steady, samples)
+    if R == 1:
+        assert steady[1][0] == 1 and steady[2][0] == 1 and 0 < steady[1][1] <= 24576, steady
+    del samples_steady
     bins_c, svals_c = bins.cpu().numpy(), None
     rows = O.band_tile_rows(H, R)
     times, samp, band = O.subpose_times(S, sc["exposure_time"], R, sc["rolling_shutter_time"])
