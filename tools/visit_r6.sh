@@ -3,6 +3,7 @@
 #   r6tests           tests/test_gpu_round6.py
 #   sel_ab            headline + configs with GSD_DEPTH_SELECT=1 (default) against 0, interleaved
 #   c5x3              config 5's share three times on one box (stall hunt)
+#   merge_ab          the view sweep with everything behind an open slice issued as ONE slice (patch build) against the doubling spans
 TAG=${1:-r6}; shift || true
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 S=$OUT/summary_r6.log; : > $S
@@ -60,6 +61,21 @@ for step in "$@"; do
         GSD_SLICE_BASE=$base timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --gaussians 5000000 --width 3840 --height 2160 --subposes 10 > $OUT/c5_b$base.log 2>&1; line "config5 base=$base" $OUT/c5_b$base.log | tee -a $S
         GSD_SLICE_BASE=$base timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-view-sweep --gaussians 2000000 --subposes 5 --rs-bands 2 > $OUT/c4_b$base.log 2>&1; line "config4 base=$base" $OUT/c4_b$base.log | tee -a $S
       done ;;
+    merge_ab)
+      # how much of a multi-slice frame is slice boundaries: a build that issues everything behind a slice that left tiles
+      # open as ONE slice (tools/patches/merge_rest_after_first.json) against the doubling spans, on the view sweep
+      python tools/ab_patch.py tools/patches/merge_rest_after_first.json /tmp/libgsd_merge.so > $OUT/merge_build.log 2>&1 || { tail -3 $OUT/merge_build.log | tee -a $S; }
+      for v in 1 2; do for lib in base merge; do
+        env $( [ $lib = merge ] && echo GSD_LIB_PATH=/tmp/libgsd_merge.so ) timeout 400 python bench.py --steps 5 --warmup 3 --no-cpu-baseline > $OUT/merge_${lib}$v.log 2>&1
+        python - $OUT/merge_${lib}$v.log $lib$v <<'PY' | tee -a $S
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith('{'):
+        d = json.loads(l); v = d['config']['view_sweep']; s = d['config']['secondary']
+        print(sys.argv[2], 'headline', d['ms_per_step'], 'secondary', s['ms_per_step'], s['depth_slices'], 'sweep per-view', v['ms_per_view'], 'fixed', v['fixed_view_ms'],
+              'slices', v['slices_per_frame'], 'one-memory', v['one_memory_for_all_cameras']['ms_per_view'])
+PY
+      done; done ;;
     c5x3)
       # config 5's share on one GPU, three times on one box (visit r6_final2 saw ONE first attempt at 48.7 ms against 12.2 in
       # its retry and in every other visit): ms, attempts, and the per-step host issue times of a stalled attempt
