@@ -420,6 +420,9 @@ def main():
                     help="DP gradient exchange: row-sparse all-gather (default; dense fallback built in), "
                          "dense all-reduce, or reduce-scatter + all-gather")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second (fitted-model-like) scene")
+    ap.add_argument("--view", type=int, default=None,
+                    help="diagnostics: time camera K of the view sweep's 16 instead of the headline view (the line says so in "
+                         "config.workload; never the headline)")
     ap.add_argument("--no-view-sweep", action="store_true",
                     help="skip the view sweep (16 cameras cycled through one FrameHints; reported beside the headline)")
     ap.add_argument("--autograd", action="store_true",
@@ -463,6 +466,8 @@ def main():
     wl = Workload(gs, dev, rank, world, N, W, H, S, R, args.scene, args.allreduce, args.force_exchange, args.autograd,
                   args.motion)
     sc, params, step = wl.sc, wl.params, wl.step
+    if args.view is not None:
+        wl.set_view(wl.sweep_views(16)[args.view % 16])
 
     # W untimed warm-up frames, then further untimed ones until the scene's adaptive slice budget and arena have settled
     # (they normally have: the headline scene stops after its first slice) — no allocation inside the timed region
@@ -771,7 +776,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic scene (SURVEY §8d, seed 1234): {N} Gaussians, {W}x{H}, "
                                    f"S={S} motion-blur sub-poses x R={R} row bands, SH degree 3, gamma 2.2, "
-                                   f"fwd+bwd to all Gaussian params + viewmat + velocities",
+                                   f"fwd+bwd to all Gaussian params + viewmat + velocities"
+                                   + ("" if args.view is None else f" — DIAGNOSTIC: camera {args.view % 16} of the view sweep, "
+                                                                   f"not the headline view"),
                        "gaussians": N, "width": W, "height": H, "subposes": S, "rs_bands": R,
                        "motion_model": args.motion,
                        "tile_intersections_per_step": n_isect,
