@@ -432,7 +432,9 @@ def test_view_sweep_keeps_every_view_near_its_fixed_view_time(gs, dev):
         res = bench.view_sweep(wl, ops, n_views=12, cycles=4)
         fixed = res.pop("_fixed")
         print("view sweep:", res)
-        if res["worst_view_median_over_its_fixed_time"] > 1.2:
+        # (wall clock with a synchronize per frame: ONE frame that a busy host delays must not fail the suite — a sweep
+        #  that misses either bar is measured once more, and a stall that comes from the code repeats)
+        if res["worst_view_median_over_its_fixed_time"] > 1.2 or res["worst_view_over_its_fixed_time"] > 1.5:
             res = bench.view_sweep(wl, ops, n_views=12, cycles=4)
             fixed = res.pop("_fixed")
             print("view sweep, again:", res)
