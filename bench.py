@@ -240,6 +240,7 @@ def view_sweep(wl, ops, n_views=16, cycles=4, fixed_frames=6, per_camera=True, f
             "fixed_view_ms": {"min": round(min(fixed), 4), "median": round(statistics.median(fixed), 4), "max": round(max(fixed), 4)},
             # a view's slowest frame of the later cycles (and its median frame) over the MEDIAN of its own fixed-view frames
             "worst_view_over_its_fixed_time": round(max(ratio), 3),
+            "frames_over_1p5x_their_fixed_time": sum(1 for v, f in zip(per_view, fixed) for m in v if m > 1.5 * f),
             "worst_view_median_over_its_fixed_time": round(max(ratio_med), 3),
             "median_view_over_its_fixed_time": round(statistics.median(ratio), 3),
             "slices_per_frame": {"min": min(slices), "max": max(slices)},

