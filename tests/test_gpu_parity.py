@@ -2990,7 +2990,8 @@ def test_alternating_scenes_of_one_shape_keep_their_frame_time(gs, dev):
             print("alternating scenes, re-timed:", [[round(v, 2) for v in m] for m in retimed])
         for i in (0, 1):
             series = ms[i][4:] if retimed is None else retimed[i]
-            assert not slow_frames(series), (i, ms[i], retimed)
+            # (one delayed frame of twelve is the box; a frame that pays for the other scene's frames repeats every time)
+            assert len(slow_frames(series)) <= (0 if retimed is None else 1), (i, ms[i], retimed)
         assert all(h.arena_retries <= 1 for h in hints) and len(pool) == 1
     finally:
         ops.SLICE_ADAPT, ops.SLICE_BASE = saved
