@@ -421,6 +421,9 @@ def main():
                     help="DP gradient exchange: row-sparse all-gather (default; dense fallback built in), "
                          "dense all-reduce, or reduce-scatter + all-gather")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second (fitted-model-like) scene")
+    ap.add_argument("--strict-stall", action="store_true",
+                    help="exit 3 when a host stall above 10 %% of the step survives three timing attempts (always reported in "
+                         "`host_stall_check`)")
     ap.add_argument("--view", type=int, default=None,
                     help="diagnostics: time camera K of the view sweep's 16 instead of the headline view (the line says so in "
                          "config.workload; never the headline)")
@@ -521,7 +524,7 @@ def main():
     stages = stage_pass(wl, n_stage_steps)
     # host stall = step time no stage accounts for (the driver saw 86 ms/step on the secondary scene
     # against 8.7 ms of stages and the line said nothing).  Above 10 % of the step the K steps are timed again (every
-    # attempt is reported); a stall that survives three attempts fails the run (world 1; with N > 1 the rank skew and the
+    # attempt is reported); a stall that survives three attempts is flagged FAILED in the line (and fails the run with --strict-stall; world 1; with N > 1 the rank skew and the
     # exchange live in the same remainder and are reported per rank instead)
     def stall_of(ms, st, k, extra=0.0):
         return ms - sum(sum(v) for v in st.values()) / k - extra
@@ -818,8 +821,11 @@ def main():
     if world > 1 or args.force_exchange:
         dist.destroy_process_group()
     if rank == 0 and stall_check.startswith("FAILED"):
+        # the line above carries the verdict (`host_stall_check`) and every attempt; the exit code only follows it on
+        # request, so that a slow host still leaves a (flagged) measurement instead of none
         print(f"bench.py: {stall_check}", file=sys.stderr)
-        sys.exit(3)
+        if args.strict_stall:
+            sys.exit(3)
 
 
 if __name__ == "__main__":
