@@ -3,7 +3,8 @@
 #   r6tests           tests/test_gpu_round6.py
 #   sel_ab            headline + configs with GSD_DEPTH_SELECT=1 (default) against 0, interleaved
 #   c5x3              config 5's share three times on one box (stall hunt)
-#   merge_ab          the view sweep with everything behind an open slice issued as ONE slice (patch build) against the doubling spans
+#   merge_ab          the view sweep with everything behind an open slice issued as ONE slice (patch build; MERGE_PATCH=<name> picks
+#                     another patch of tools/patches/) against the doubling spans
 TAG=${1:-r6}; shift || true
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 S=$OUT/summary_r6.log; : > $S
@@ -64,7 +65,7 @@ for step in "$@"; do
     merge_ab)
       # how much of a multi-slice frame is slice boundaries: a build that issues everything behind a slice that left tiles
       # open as ONE slice (tools/patches/merge_rest_after_first.json) against the doubling spans, on the view sweep
-      python tools/ab_patch.py tools/patches/merge_rest_after_first.json /tmp/libgsd_merge.so > $OUT/merge_build.log 2>&1 || { tail -3 $OUT/merge_build.log | tee -a $S; }
+      python tools/ab_patch.py tools/patches/${MERGE_PATCH:-merge_rest_after_first}.json /tmp/libgsd_merge.so > $OUT/merge_build.log 2>&1 || { tail -3 $OUT/merge_build.log | tee -a $S; }
       for v in 1 2; do for lib in base merge; do
         env $( [ $lib = merge ] && echo GSD_LIB_PATH=/tmp/libgsd_merge.so ) timeout 400 python bench.py --steps 5 --warmup 3 --no-cpu-baseline > $OUT/merge_${lib}$v.log 2>&1
         python - $OUT/merge_${lib}$v.log $lib$v <<'PY' | tee -a $S
