@@ -1829,13 +1829,21 @@ def _full_size_two_paths(gs, dev, n, W, H, S, R, profile, other, min_slices=1, s
         for knobs in ({}, other):
             for k, v in saved.items():
                 setattr(ops, k, knobs.get(k, v))
-            p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
-            vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"], sc["ang_vel"], torch.tensor(times, device=dev))
-            rgb, _, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
-                                               torch.sigmoid(p["opacity_logits"]), p["sh"], vms, None, S, R, sc["fx"],
-                                               sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2, min_rgb_level=10.0,
-                                               return_alpha=False)
-            (rgb * wt).sum().backward()
+            # the default path is taken in its STEADY state (round 6): the third frame through one FrameHints — what the
+            # first two taught it is switched on (lazy records, nearest-first selection, the selection's size as a promise
+            # to the sort), which is how bench.py and a training loop run it
+            hints = ops.FrameHints() if not knobs else None
+            for _rep in range(3 if not knobs else 1):
+                p = {k: sc[k].clone().requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+                vms = gs.subpose_viewmats(sc["viewmat"], sc["lin_vel"], sc["ang_vel"], torch.tensor(times, device=dev))
+                rgb, _, radii = gs.render_combined(p["means"], p["log_scales"].exp(), p["quats"],
+                                                   torch.sigmoid(p["opacity_logits"]), p["sh"], vms, None, S, R, sc["fx"],
+                                                   sc["fy"], sc["cx"], sc["cy"], H, W, gamma=2.2, min_rgb_level=10.0,
+                                                   return_alpha=False, hints=hints)
+                (rgb * wt).sum().backward()
+            if not knobs:
+                print(f"[steady state {n} {W}x{H} S={S} R={R} {profile}] third frame: selection state "
+                      f"{ops.last_depth_select}, promised size {hints.select_cap}, lazy records {hints.lazy_records()}")
             res.append((rgb.detach().clone(), {k: v.grad.clone() for k, v in p.items()}, ops.last_num_intersects,
                         list(ops.last_slice_intersects)))
             del p, rgb, vms
